@@ -1,0 +1,146 @@
+/*
+ * ogc_ops.h — C ABI of libogc_ops.so, the MI355X (gfx950) implementation of OGC's
+ * point-cloud operator stack.
+ *
+ * This is the drop-in boundary for the reference's native extension `pointnet2_cuda`
+ * (PYBIND11_MODULE in pointnet2/src/pointnet2_api.cpp:10-25).  Every entry point below
+ * replaces exactly one of the ten pybind functions registered there; the argument order
+ * and meaning are the reference's, with `at::Tensor` replaced by raw device pointers and
+ * the implicit "current CUDA stream" replaced by an explicit hipStream_t (passed as
+ * void* so that this header has no HIP dependency).
+ *
+ * Contract shared by all entry points (reference: SURVEY.md §8b):
+ *   - all tensors are dense, row-major, contiguous device memory; floats are fp32,
+ *     indices are int32; dims are passed as int (flat offsets must fit in 32 bits);
+ *   - the CALLER allocates every output and scratch buffer and keeps ownership;
+ *   - launches are asynchronous on `stream`; no global state; re-entrant;
+ *   - return value: OGC_OK (0) or a negative OGC_ERR_* code.  Unlike the reference
+ *     (which prints and calls exit(-1), e.g. ball_query_gpu.cu:62-66) nothing here ever
+ *     terminates the process; ogc_last_error() gives a thread-local message.
+ *
+ * Distance arithmetic everywhere is the reference's source expression evaluated in fp32,
+ * left to right, WITHOUT fused multiply-add:
+ *     d = (ux-x)*(ux-x) + (uy-y)*(uy-y) + (uz-z)*(uz-z)
+ * (interpolate_gpu.cu:40, ball_query_gpu.cu:33, sampling_gpu.cu:133).
+ */
+#ifndef OGC_OPS_H
+#define OGC_OPS_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *ogc_stream_t; /* hipStream_t */
+
+enum {
+    OGC_OK = 0,
+    OGC_ERR_INVALID_ARG = -1, /* null pointer, negative dim, k out of range ... */
+    OGC_ERR_LAUNCH = -2,      /* hipGetLastError() != hipSuccess after the launch */
+    OGC_ERR_UNSUPPORTED = -3  /* shape outside what the kernels handle */
+};
+
+/* Library version (major*10000 + minor*100 + patch) and last error text (thread-local). */
+int ogc_version(void);
+const char *ogc_last_error(void);
+
+/* ---- furthest point sampling -------------------------------------------------------
+ * replaces furthest_point_sampling_wrapper(b, n, m, points, temp, idx)
+ *   pointnet2/src/sampling.cpp:38-49 -> sampling_gpu.cu:93-253
+ * xyz (b,n,3) f32; temp (b,n) f32 scratch, must arrive filled with 1e10 (pointnet2.py:33),
+ * left holding the final min-distances; idx (b,m) i32, idx[:,0] = 0.
+ * Tie order among equal maxima reproduces the reference's block reduction for
+ * block_size = min(1024, 2^floor(log2 n)) (cuda_utils.h:10-14). */
+int ogc_furthest_point_sampling(int b, int n, int m, const float *xyz, float *temp,
+                                int *idx, ogc_stream_t stream);
+
+/* ---- gather -------------------------------------------------------------------------
+ * replaces gather_points_wrapper(b, c, n, npoints, points, idx, out)
+ *   sampling.cpp:11-21 -> sampling_gpu.cu:8-43
+ * out[b,c,j] = points[b,c,idx[b,j]];  points (b,c,n), idx (b,npoints), out (b,c,npoints) */
+int ogc_gather_points(int b, int c, int n, int npoints, const float *points, const int *idx,
+                      float *out, ogc_stream_t stream);
+
+/* replaces gather_points_grad_wrapper(b, c, n, npoints, grad_out, idx, grad_points)
+ *   sampling.cpp:24-35 -> sampling_gpu.cu:46-90
+ * grad_points[b,c,idx[b,j]] += grad_out[b,c,j]; caller zero-fills grad_points (pointnet2.py:73) */
+int ogc_gather_points_grad(int b, int c, int n, int npoints, const float *grad_out,
+                           const int *idx, float *grad_points, ogc_stream_t stream);
+
+/* ---- k nearest neighbours ----------------------------------------------------------
+ * replaces knn_wrapper(b, n, m, k, unknown, known, dist2, idx)
+ *   interpolate.cpp:26-36 -> interpolate_gpu.cu:9-79
+ * unknown (b,n,3), known (b,m,3); dist2 (b,n,k) SQUARED distances ascending, idx (b,n,k).
+ * Ties keep the lower index first; if m < k the tail is idx=0, dist2=+inf; non-finite
+ * distances are never selected.  1 <= k <= 200 (the reference's scratch-array bound,
+ * interpolate_gpu.cu:30-31); larger k returns OGC_ERR_INVALID_ARG instead of overrunning. */
+int ogc_knn(int b, int n, int m, int k, const float *unknown, const float *known,
+            float *dist2, int *idx, ogc_stream_t stream);
+
+/* replaces three_nn_wrapper(b, n, m, unknown, known, dist2, idx)
+ *   interpolate.cpp:14-23 -> interpolate_gpu.cu:81-146 ; k = 3 special case of ogc_knn */
+int ogc_three_nn(int b, int n, int m, const float *unknown, const float *known, float *dist2,
+                 int *idx, ogc_stream_t stream);
+
+/* ---- three-point interpolation -----------------------------------------------------
+ * replaces three_interpolate_wrapper(b, c, m, n, points, idx, weight, out)
+ *   interpolate.cpp:39-52 -> interpolate_gpu.cu:149-189
+ * out[b,c,i] = w[b,i,0]*p[b,c,idx[b,i,0]] + w[b,i,1]*p[..1] + w[b,i,2]*p[..2], left to right
+ * points (b,c,m), idx/weight (b,n,3), out (b,c,n) */
+int ogc_three_interpolate(int b, int c, int m, int n, const float *points, const int *idx,
+                          const float *weight, float *out, ogc_stream_t stream);
+
+/* replaces three_interpolate_grad_wrapper(b, c, n, m, grad_out, idx, weight, grad_points)
+ *   interpolate.cpp:55-68 -> interpolate_gpu.cu:192-232
+ * grad_points[b,c,idx[b,i,j]] += grad_out[b,c,i]*w[b,i,j]; caller zero-fills (pointnet2.py:181) */
+int ogc_three_interpolate_grad(int b, int c, int n, int m, const float *grad_out,
+                               const int *idx, const float *weight, float *grad_points,
+                               ogc_stream_t stream);
+
+/* ---- grouping ------------------------------------------------------------------------
+ * replaces group_points_wrapper(b, c, n, npoints, nsample, points, idx, out)
+ *   group_points.cpp:26-36 -> group_points_gpu.cu:47-86
+ * out[b,c,p,s] = points[b,c,idx[b,p,s]]; points (b,c,n), idx (b,npoints,nsample) */
+int ogc_group_points(int b, int c, int n, int npoints, int nsample, const float *points,
+                     const int *idx, float *out, ogc_stream_t stream);
+
+/* replaces group_points_grad_wrapper(b, c, n, npoints, nsample, grad_out, idx, grad_points)
+ *   group_points.cpp:11-23 -> group_points_gpu.cu:8-44
+ * grad_points[b,c,idx[b,p,s]] += grad_out[b,c,p,s]; caller zero-fills (pointnet2.py:224) */
+int ogc_group_points_grad(int b, int c, int n, int npoints, int nsample, const float *grad_out,
+                          const int *idx, float *grad_points, ogc_stream_t stream);
+
+/* ---- ball query ------------------------------------------------------------------------
+ * replaces ball_query_wrapper(b, n, m, radius, nsample, new_xyz, xyz, idx)
+ *   ball_query.cpp:16-27 -> ball_query_gpu.cu:9-66
+ * xyz (b,n,3) candidates, new_xyz (b,m,3) centres, idx (b,m,nsample) pre-zeroed by the
+ * caller (pointnet2.py:251).  Row = first nsample indices k (ascending) with
+ * d2(k) < radius*radius, padded with the first hit; a centre with no hit gets an all-zero row. */
+int ogc_ball_query(int b, int n, int m, float radius, int nsample, const float *new_xyz,
+                   const float *xyz, int *idx, ogc_stream_t stream);
+
+/* ==== fused extensions (no counterpart in the reference's native module; they replace
+ * Python-level op sequences of the reference, cited per function) ======================= */
+
+/* kNN followed by the radius clamp every reference caller applies in Python
+ *   pointnet2/pointnet2.py:283-286, utils/flowstep3d_util.py:42-44,
+ *   losses/seg_loss_unsup.py:120-122, losses/flow_loss_unsup.py:57-59:
+ *     dist = sqrt(dist2); idx[dist > radius] = idx[..., 0]
+ * One launch, no host synchronisation (the reference's boolean-mask assignment syncs).
+ * dist (b,n,k) receives sqrt(dist2) (what KNN.forward returns, pointnet2.py:103), idx the
+ * clamped indices.  radius < 0 means "no clamp" (QueryAndGroup radius=None). */
+int ogc_knn_clamped(int b, int n, int m, int k, float radius, const float *unknown,
+                    const float *known, float *dist, int *idx, ogc_stream_t stream);
+
+/* Weighted-Kabsch moments: the streaming replacement for the (B*K,N,N) diag_embed product in
+ *   losses/seg_loss_unsup.py:25-36 (fit_motion_svd_batch with a mask).
+ * pc1, pc2 (b,n,3); mask (b,n,k) soft assignment (point-major, as the models emit it).
+ * out (b,k,16) f32: [0]=sum w, [1:4]=sum w*p, [4:7]=sum w*q, [7:16]=sum w * p q^T (row-major 3x3),
+ * accumulated in fp32.  The centred cross-covariance S follows on the host side as
+ * S = M_pq - (sum w p)(sum w q)^T / sum w. */
+int ogc_kabsch_moments(int b, int n, int k, const float *pc1, const float *pc2,
+                       const float *mask, float *out, ogc_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OGC_OPS_H */
