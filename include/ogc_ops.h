@@ -131,15 +131,6 @@ int ogc_ball_query(int b, int n, int m, float radius, int nsample, const float *
 int ogc_knn_clamped(int b, int n, int m, int k, float radius, const float *unknown,
                     const float *known, float *dist, int *idx, ogc_stream_t stream);
 
-/* Weighted-Kabsch moments: the streaming replacement for the (B*K,N,N) diag_embed product in
- *   losses/seg_loss_unsup.py:25-36 (fit_motion_svd_batch with a mask).
- * pc1, pc2 (b,n,3); mask (b,n,k) soft assignment (point-major, as the models emit it).
- * out (b,k,16) f32: [0]=sum w, [1:4]=sum w*p, [4:7]=sum w*q, [7:16]=sum w * p q^T (row-major 3x3),
- * accumulated in fp32.  The centred cross-covariance S follows on the host side as
- * S = M_pq - (sum w p)(sum w q)^T / sum w. */
-int ogc_kabsch_moments(int b, int n, int k, const float *pc1, const float *pc2,
-                       const float *mask, float *out, ogc_stream_t stream);
-
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,65 @@
+"""ctypes binding of libogc_ops.so (C ABI declared in include/ogc_ops.h).
+
+The library is HIP-only.  There is deliberately no CPU fallback: if the shared object is missing
+or a tensor is not resident on a HIP device, the call raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libogc_ops.so")
+
+_vp = ctypes.c_void_p
+_int = ctypes.c_int
+_flt = ctypes.c_float
+
+# name -> argtypes (stream is always the trailing void*)
+SIGNATURES = {
+    "ogc_furthest_point_sampling": [_int, _int, _int, _vp, _vp, _vp, _vp],
+    "ogc_gather_points": [_int, _int, _int, _int, _vp, _vp, _vp, _vp],
+    "ogc_gather_points_grad": [_int, _int, _int, _int, _vp, _vp, _vp, _vp],
+    "ogc_knn": [_int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp],
+    "ogc_three_nn": [_int, _int, _int, _vp, _vp, _vp, _vp, _vp],
+    "ogc_three_interpolate": [_int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp],
+    "ogc_three_interpolate_grad": [_int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp],
+    "ogc_group_points": [_int, _int, _int, _int, _int, _vp, _vp, _vp, _vp],
+    "ogc_group_points_grad": [_int, _int, _int, _int, _int, _vp, _vp, _vp, _vp],
+    "ogc_ball_query": [_int, _int, _int, _flt, _int, _vp, _vp, _vp, _vp],
+    "ogc_knn_clamped": [_int, _int, _int, _int, _flt, _vp, _vp, _vp, _vp, _vp],
+}
+
+_lib = None
+
+
+class OgcOpsError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes handle.  Raises if the HIP library has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise OgcOpsError(
+                "libogc_ops.so not found at %s — build it with `python ogc_amd/csrc/build.py` "
+                "(there is no CPU fallback)" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.argtypes = argtypes
+            fn.restype = _int
+        L.ogc_version.restype = _int
+        L.ogc_last_error.restype = ctypes.c_char_p
+        _lib = L
+    return _lib
+
+
+def call(name, *args):
+    """Invoke an entry point; non-zero status becomes a Python exception (the reference would
+    have printed and exit(-1)'d, e.g. ball_query_gpu.cu:62-66)."""
+    L = load()
+    rc = getattr(L, name)(*args)
+    if rc != 0:
+        msg = L.ogc_last_error().decode("utf-8", "replace")
+        raise OgcOpsError("%s failed (status %d): %s" % (name, rc, msg))
+    return rc

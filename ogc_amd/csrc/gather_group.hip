@@ -1,0 +1,155 @@
+// gather_group.hip — index gathers and their scatter-add gradients (bandwidth kernels).
+//
+// Replaces gather_points_kernel_fast / gather_points_grad_kernel_fast
+//   (reference: pointnet2/src/sampling_gpu.cu:8-24, :46-63) and
+// group_points_kernel_fast / group_points_grad_kernel_fast
+//   (reference: pointnet2/src/group_points_gpu.cu:47-66, :8-25).
+//
+// The reference launches one thread per (channel, output element), so the index tensor is re-read
+// once per channel (grid.y = C).  Here a thread owns up to four consecutive output positions, loads
+// their indices once (one 16-byte load) and walks the channels, issuing 16-byte stores; a group of
+// CH_PER_BLOCK channels per workgroup keeps enough workgroups in flight for small tensors.
+//
+// group_points is ONE kernel for both ops: gather_points is group_points with nsample = 1.
+#include "ogc_common.h"
+
+namespace {
+
+constexpr int GG_THREADS = 256;
+
+// out[b,c,t] = points[b,c,idx[b,t]],  t in [0, T)   (T = npoints*nsample)
+template <bool VEC4>
+__global__ __launch_bounds__(GG_THREADS) void group_fwd_kernel(int c, int n, int T, int ch_per_block,
+                                                               const float *__restrict__ points,
+                                                               const int *__restrict__ idx,
+                                                               float *__restrict__ out) {
+    const int b = blockIdx.z;
+    const int c0 = blockIdx.y * ch_per_block;
+    const int c1 = min(c, c0 + ch_per_block);
+    const int *id = idx + (size_t)b * T;
+    const float *p = points + ((size_t)b * c + c0) * n;
+    float *o = out + ((size_t)b * c + c0) * T;
+    if (VEC4) {
+        const int t4 = (blockIdx.x * GG_THREADS + threadIdx.x) * 4;
+        if (t4 >= T) return;
+        const int4 i4 = *reinterpret_cast<const int4 *>(id + t4);
+        for (int ch = c0; ch < c1; ++ch, p += n, o += T) {
+            float4 v;
+            v.x = p[i4.x]; v.y = p[i4.y]; v.z = p[i4.z]; v.w = p[i4.w];
+            *reinterpret_cast<float4 *>(o + t4) = v;
+        }
+    } else {
+        const int t = blockIdx.x * GG_THREADS + threadIdx.x;
+        if (t >= T) return;
+        const int i = id[t];
+        for (int ch = c0; ch < c1; ++ch, p += n, o += T) o[t] = p[i];
+    }
+}
+
+// grad_points[b,c,idx[b,t]] += grad_out[b,c,t]
+template <bool VEC4>
+__global__ __launch_bounds__(GG_THREADS) void group_bwd_kernel(int c, int n, int T, int ch_per_block,
+                                                               const float *__restrict__ grad_out,
+                                                               const int *__restrict__ idx,
+                                                               float *__restrict__ grad_points) {
+    const int b = blockIdx.z;
+    const int c0 = blockIdx.y * ch_per_block;
+    const int c1 = min(c, c0 + ch_per_block);
+    const int *id = idx + (size_t)b * T;
+    const float *g = grad_out + ((size_t)b * c + c0) * T;
+    float *gp = grad_points + ((size_t)b * c + c0) * n;
+    if (VEC4) {
+        const int t4 = (blockIdx.x * GG_THREADS + threadIdx.x) * 4;
+        if (t4 >= T) return;
+        const int4 i4 = *reinterpret_cast<const int4 *>(id + t4);
+        for (int ch = c0; ch < c1; ++ch, g += T, gp += n) {
+            const float4 v = *reinterpret_cast<const float4 *>(g + t4);
+            unsafeAtomicAdd(gp + i4.x, v.x);
+            unsafeAtomicAdd(gp + i4.y, v.y);
+            unsafeAtomicAdd(gp + i4.z, v.z);
+            unsafeAtomicAdd(gp + i4.w, v.w);
+        }
+    } else {
+        const int t = blockIdx.x * GG_THREADS + threadIdx.x;
+        if (t >= T) return;
+        const int i = id[t];
+        for (int ch = c0; ch < c1; ++ch, g += T, gp += n) unsafeAtomicAdd(gp + i, g[t]);
+    }
+}
+
+int pick_ch_per_block(int b, int c, int blocks_x) {
+    // aim for >= ~2048 workgroups (8 per CU) before giving each workgroup more channels
+    int cpb = 1;
+    while (cpb < c && (long long)b * blocks_x * ((c + 2 * cpb - 1) / (2 * cpb)) >= 2048) cpb *= 2;
+    return cpb;
+}
+
+bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
+
+int group_fwd(const char *name, int b, int c, int n, int T, const float *points, const int *idx,
+              float *out, ogc_stream_t stream) {
+    OGC_REQUIRE(b >= 0 && c >= 0 && n >= 0 && T >= 0, "%s: negative dimension", name);
+    if (b == 0 || c == 0 || T == 0) return OGC_OK;
+    OGC_REQUIRE(points && idx && out, "%s: null pointer", name);
+    OGC_REQUIRE((long long)b * c * T < (1ll << 31) && (long long)b * c * n < (1ll << 31),
+                "%s: tensor exceeds 32-bit indexing (group_points_gpu.cu:63)", name);
+    const bool vec = (T % 4 == 0) && aligned16(idx) && aligned16(out);
+    const int bx = ogc_divup(T, vec ? GG_THREADS * 4 : GG_THREADS);
+    const int cpb = pick_ch_per_block(b, c, bx);
+    dim3 grid(bx, ogc_divup(c, cpb), b);
+    if (vec)
+        hipLaunchKernelGGL(group_fwd_kernel<true>, grid, dim3(GG_THREADS), 0, (hipStream_t)stream, c, n, T,
+                           cpb, points, idx, out);
+    else
+        hipLaunchKernelGGL(group_fwd_kernel<false>, grid, dim3(GG_THREADS), 0, (hipStream_t)stream, c, n, T,
+                           cpb, points, idx, out);
+    OGC_CHECK_LAUNCH(name);
+    return OGC_OK;
+}
+
+int group_bwd(const char *name, int b, int c, int n, int T, const float *grad_out, const int *idx,
+              float *grad_points, ogc_stream_t stream) {
+    OGC_REQUIRE(b >= 0 && c >= 0 && n >= 0 && T >= 0, "%s: negative dimension", name);
+    if (b == 0 || c == 0 || T == 0) return OGC_OK;
+    OGC_REQUIRE(grad_out && idx && grad_points, "%s: null pointer", name);
+    OGC_REQUIRE((long long)b * c * T < (1ll << 31) && (long long)b * c * n < (1ll << 31),
+                "%s: tensor exceeds 32-bit indexing", name);
+    const bool vec = (T % 4 == 0) && aligned16(idx) && aligned16(grad_out);
+    const int bx = ogc_divup(T, vec ? GG_THREADS * 4 : GG_THREADS);
+    const int cpb = pick_ch_per_block(b, c, bx);
+    dim3 grid(bx, ogc_divup(c, cpb), b);
+    if (vec)
+        hipLaunchKernelGGL(group_bwd_kernel<true>, grid, dim3(GG_THREADS), 0, (hipStream_t)stream, c, n, T,
+                           cpb, grad_out, idx, grad_points);
+    else
+        hipLaunchKernelGGL(group_bwd_kernel<false>, grid, dim3(GG_THREADS), 0, (hipStream_t)stream, c, n, T,
+                           cpb, grad_out, idx, grad_points);
+    OGC_CHECK_LAUNCH(name);
+    return OGC_OK;
+}
+
+} // namespace
+
+extern "C" int ogc_gather_points(int b, int c, int n, int npoints, const float *points, const int *idx,
+                                 float *out, ogc_stream_t stream) {
+    return group_fwd("ogc_gather_points", b, c, n, npoints, points, idx, out, stream);
+}
+
+extern "C" int ogc_gather_points_grad(int b, int c, int n, int npoints, const float *grad_out,
+                                      const int *idx, float *grad_points, ogc_stream_t stream) {
+    return group_bwd("ogc_gather_points_grad", b, c, n, npoints, grad_out, idx, grad_points, stream);
+}
+
+extern "C" int ogc_group_points(int b, int c, int n, int npoints, int nsample, const float *points,
+                                const int *idx, float *out, ogc_stream_t stream) {
+    OGC_REQUIRE(npoints >= 0 && nsample >= 0 && (long long)npoints * nsample < (1ll << 31),
+                "ogc_group_points: bad npoints/nsample");
+    return group_fwd("ogc_group_points", b, c, n, npoints * nsample, points, idx, out, stream);
+}
+
+extern "C" int ogc_group_points_grad(int b, int c, int n, int npoints, int nsample, const float *grad_out,
+                                     const int *idx, float *grad_points, ogc_stream_t stream) {
+    OGC_REQUIRE(npoints >= 0 && nsample >= 0 && (long long)npoints * nsample < (1ll << 31),
+                "ogc_group_points_grad: bad npoints/nsample");
+    return group_bwd("ogc_group_points_grad", b, c, n, npoints * nsample, grad_out, idx, grad_points, stream);
+}

@@ -1,0 +1,111 @@
+"""Drop-in for the reference's native extension module ``pointnet2_cuda``.
+
+The reference builds that module from pointnet2/src/*.cpp,*.cu (PYBIND11_MODULE at
+pointnet2/src/pointnet2_api.cpp:10-25) and imports it at pointnet2/pointnet2.py:7.  This module
+exposes the same ten functions with the same positional signatures, backed by the hand-written HIP
+kernels in libogc_ops.so through its C ABI (include/ogc_ops.h).  Registering it as
+``sys.modules['pointnet2_cuda']`` (``ogc_amd.install_drop_in()``) lets reference-style callers run
+unchanged on an MI355X.
+
+Like the reference's wrappers, every function fills caller-allocated tensors in place and launches
+asynchronously on the *current* stream of the tensor's device, looked up at call time (backward
+runs on autograd's thread: SURVEY.md §7 "Autograd threading").
+"""
+import torch
+
+from . import _lib
+
+
+def _check(t, dtype, name):
+    # ball_query.cpp:12-19 (CHECK_INPUT) is the only reference wrapper that validates; here all do.
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s must be a torch.Tensor" % name)
+    if t.device.type != "cuda":
+        raise RuntimeError("%s must be a CUDA tensor (HIP device); ogc_amd has no CPU path" % name)
+    if not t.is_contiguous():
+        raise RuntimeError("%s must be contiguous" % name)
+    if t.dtype != dtype:
+        raise RuntimeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    return t.data_ptr()
+
+
+def _f(t, name):
+    return _check(t, torch.float32, name)
+
+
+def _i(t, name):
+    return _check(t, torch.int32, name)
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _run(name, ref_tensor, *args):
+    # kernels must be launched with the tensor's device current (multi-GPU processes)
+    if torch.cuda.current_device() != ref_tensor.device.index:
+        with torch.cuda.device(ref_tensor.device):
+            return _lib.call(name, *args, _stream(ref_tensor))
+    return _lib.call(name, *args, _stream(ref_tensor))
+
+
+def ball_query_wrapper(b, n, m, radius, nsample, new_xyz, xyz, idx):
+    _run("ogc_ball_query", xyz, b, n, m, float(radius), nsample, _f(new_xyz, "new_xyz"), _f(xyz, "xyz"),
+         _i(idx, "idx"))
+    return 1
+
+
+def group_points_wrapper(b, c, n, npoints, nsample, points, idx, out):
+    _run("ogc_group_points", points, b, c, n, npoints, nsample, _f(points, "points"), _i(idx, "idx"),
+         _f(out, "out"))
+    return 1
+
+
+def group_points_grad_wrapper(b, c, n, npoints, nsample, grad_out, idx, grad_points):
+    _run("ogc_group_points_grad", grad_out, b, c, n, npoints, nsample, _f(grad_out, "grad_out"),
+         _i(idx, "idx"), _f(grad_points, "grad_points"))
+    return 1
+
+
+def gather_points_wrapper(b, c, n, npoints, points, idx, out):
+    _run("ogc_gather_points", points, b, c, n, npoints, _f(points, "points"), _i(idx, "idx"), _f(out, "out"))
+    return 1
+
+
+def gather_points_grad_wrapper(b, c, n, npoints, grad_out, idx, grad_points):
+    _run("ogc_gather_points_grad", grad_out, b, c, n, npoints, _f(grad_out, "grad_out"), _i(idx, "idx"),
+         _f(grad_points, "grad_points"))
+    return 1
+
+
+def furthest_point_sampling_wrapper(b, n, m, points, temp, idx):
+    _run("ogc_furthest_point_sampling", points, b, n, m, _f(points, "points"), _f(temp, "temp"),
+         _i(idx, "idx"))
+    return 1
+
+
+def knn_wrapper(b, n, m, k, unknown, known, dist2, idx):
+    _run("ogc_knn", unknown, b, n, m, k, _f(unknown, "unknown"), _f(known, "known"), _f(dist2, "dist2"),
+         _i(idx, "idx"))
+
+
+def three_nn_wrapper(b, n, m, unknown, known, dist2, idx):
+    _run("ogc_three_nn", unknown, b, n, m, _f(unknown, "unknown"), _f(known, "known"), _f(dist2, "dist2"),
+         _i(idx, "idx"))
+
+
+def three_interpolate_wrapper(b, c, m, n, points, idx, weight, out):
+    _run("ogc_three_interpolate", points, b, c, m, n, _f(points, "points"), _i(idx, "idx"),
+         _f(weight, "weight"), _f(out, "out"))
+
+
+def three_interpolate_grad_wrapper(b, c, n, m, grad_out, idx, weight, grad_points):
+    _run("ogc_three_interpolate_grad", grad_out, b, c, n, m, _f(grad_out, "grad_out"), _i(idx, "idx"),
+         _f(weight, "weight"), _f(grad_points, "grad_points"))
+
+
+# ---- fused extension (no reference counterpart at this level; see include/ogc_ops.h) ----------
+def knn_clamped_wrapper(b, n, m, k, radius, unknown, known, dist, idx):
+    """kNN + sqrt + radius clamp in one launch; radius < 0 disables the clamp."""
+    _run("ogc_knn_clamped", unknown, b, n, m, k, float(radius), _f(unknown, "unknown"), _f(known, "known"),
+         _f(dist, "dist"), _i(idx, "idx"))

@@ -1,0 +1,312 @@
+"""GPU parity tests: the HIP kernels (called through the C ABI via ogc_amd.pointnet2_cuda) against the
+CPU oracle on the same seeded inputs.  Integer indices must be bit-exact; forward floats bit-exact
+(same fp32 rounding sequence); scatter-add gradients within 1e-5 relative (atomic order differs)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def nat():
+    assert torch.cuda.is_available(), "gpu tests need a HIP device"
+    import ogc_amd  # noqa: F401  (fails loudly if libogc_ops.so is missing)
+    from ogc_amd import pointnet2_cuda
+    return pointnet2_cuda
+
+
+def cloud(rng, B, N, scale=(60, 4, 80), dup=0):
+    pc = ((rng.random((B, N, 3), dtype=np.float32) - 0.5) * np.array(scale, np.float32)).astype(np.float32)
+    if dup and N > 2:
+        src = rng.integers(0, N, size=dup)
+        dst = rng.integers(0, N, size=dup)
+        pc[:, dst] = pc[:, src]
+    return pc
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def run_knn(nat, k, u, kn):
+    B, n, _ = u.shape
+    m = kn.shape[1]
+    d2 = torch.empty(B, n, k, device=DEV)
+    idx = torch.empty(B, n, k, dtype=torch.int32, device=DEV)
+    nat.knn_wrapper(B, n, m, k, T(u), T(kn), d2, idx)
+    return d2.cpu().numpy(), idx.cpu().numpy()
+
+
+KNN_CASES = [(37, 50, 5), (64, 64, 16), (100, 7, 10), (65, 129, 1), (300, 1000, 64), (130, 700, 200),
+             (1, 1, 1), (513, 2048, 32), (2048, 2048, 4), (256, 512, 24)]
+
+
+@pytest.mark.parametrize("n,m,k", KNN_CASES)
+def test_knn_bit_exact(nat, oracle, n, m, k):
+    rng = np.random.default_rng(n * 7 + m * 3 + k)
+    u, kn = cloud(rng, 3, n), cloud(rng, 3, m, dup=max(1, m // 10))
+    d2, idx = run_knn(nat, k, u, kn)
+    d2r, idxr = oracle.knn(k, u, kn)
+    assert np.array_equal(idx, idxr)
+    assert np.array_equal(d2, d2r)
+
+
+def test_knn_self_query_with_many_duplicates(nat, oracle):
+    rng = np.random.default_rng(11)
+    pc = cloud(rng, 2, 700, scale=(1, 1, 1))
+    pc[:, 100:400] = pc[:, :300]  # every one of these has an exact twin
+    d2, idx = run_knn(nat, 16, pc, pc)
+    d2r, idxr = oracle.knn(16, pc, pc)
+    assert np.array_equal(idx, idxr) and np.array_equal(d2, d2r)
+
+
+def test_knn_nonfinite_candidates(nat, oracle):
+    rng = np.random.default_rng(12)
+    u, kn = cloud(rng, 1, 70), cloud(rng, 1, 90)
+    kn[0, 3, 0] = np.inf
+    kn[0, 17, 1] = np.nan
+    kn[0, 40] = 3e19  # squared distance overflows to +inf
+    d2, idx = run_knn(nat, 90, u, kn)
+    d2r, idxr = oracle.knn(90, u, kn)
+    assert np.array_equal(idx, idxr)
+    assert np.array_equal(d2, d2r)
+
+
+def test_knn_config_scale_kitti_loss(nat, oracle):
+    # C4 loss shape: n = m = 8192, k = 32 (config/seg/kittisf/kittisf_unsup.yaml via SURVEY §8)
+    rng = np.random.default_rng(1234)
+    pc = cloud(rng, 1, 8192)
+    d2, idx = run_knn(nat, 32, pc, pc)
+    d2r, idxr = oracle.knn(32, pc, pc)
+    assert np.array_equal(idx, idxr) and np.array_equal(d2, d2r)
+
+
+def test_knn_config_scale_sa1(nat, oracle):
+    # segnet_kitti SA1 grouper: 2048 centres <- 8192 points, k = 64
+    rng = np.random.default_rng(4321)
+    pc = cloud(rng, 2, 8192)
+    centres = pc[:, ::4].copy()
+    d2, idx = run_knn(nat, 64, centres, pc)
+    d2r, idxr = oracle.knn(64, centres, pc)
+    assert np.array_equal(idx, idxr) and np.array_equal(d2, d2r)
+
+
+def test_knn_rejects_bad_k(nat):
+    pc = torch.zeros(1, 4, 3, device=DEV)
+    d2 = torch.empty(1, 4, 201, device=DEV)
+    idx = torch.empty(1, 4, 201, dtype=torch.int32, device=DEV)
+    with pytest.raises(RuntimeError):
+        nat.knn_wrapper(1, 4, 4, 201, pc, pc, d2, idx)
+    with pytest.raises(RuntimeError):
+        nat.knn_wrapper(1, 4, 4, 0, pc, pc, d2, idx)
+
+
+@pytest.mark.parametrize("n,m,k,r", [(300, 1000, 16, 3.0), (2048, 2048, 16, 1.5), (100, 7, 10, 5.0), (64, 200, 8, None)])
+def test_knn_clamped(nat, oracle, n, m, k, r):
+    rng = np.random.default_rng(n + m)
+    u, kn = cloud(rng, 2, n), cloud(rng, 2, m)
+    dist = torch.empty(2, n, k, device=DEV)
+    idx = torch.empty(2, n, k, dtype=torch.int32, device=DEV)
+    nat.knn_clamped_wrapper(2, n, m, k, -1.0 if r is None else r, T(u), T(kn), dist, idx)
+    d2r, idxr = oracle.knn(k, u, kn)
+    distr = np.sqrt(d2r)
+    if r is not None:
+        first = np.repeat(idxr[:, :, :1], k, axis=2)
+        idxr = np.where(distr > np.float32(r), first, idxr)
+    assert np.array_equal(idx.cpu().numpy(), idxr)
+    assert np.array_equal(dist.cpu().numpy(), distr)
+
+
+@pytest.mark.parametrize("n,m", [(37, 50), (1000, 3), (8192, 2048), (1, 2), (513, 1)])
+def test_three_nn_bit_exact(nat, oracle, n, m):
+    rng = np.random.default_rng(n + m)
+    u, kn = cloud(rng, 2, n), cloud(rng, 2, m, dup=1)
+    d2 = torch.empty(2, n, 3, device=DEV)
+    idx = torch.empty(2, n, 3, dtype=torch.int32, device=DEV)
+    nat.three_nn_wrapper(2, n, m, T(u), T(kn), d2, idx)
+    d2r, idxr = oracle.three_nn(u, kn)
+    assert np.array_equal(idx.cpu().numpy(), idxr)
+    assert np.array_equal(d2.cpu().numpy(), d2r)
+
+
+def run_bq(nat, r, ns, xyz, new):
+    B, n, _ = xyz.shape
+    m = new.shape[1]
+    idx = torch.zeros(B, m, ns, dtype=torch.int32, device=DEV)
+    nat.ball_query_wrapper(B, n, m, r, ns, T(new), T(xyz), idx)
+    return idx.cpu().numpy()
+
+
+@pytest.mark.parametrize("n,m,ns,r", [(200, 64, 16, 8.0), (512, 100, 64, 20.0), (64, 64, 4, 0.01), (300, 33, 8, 1000.0),
+                                      (1000, 1000, 1, 5.0), (4096, 4096, 16, 0.04 * 60), (129, 65, 200, 30.0)])
+def test_ball_query_bit_exact(nat, oracle, n, m, ns, r):
+    rng = np.random.default_rng(n + m + ns)
+    xyz, new = cloud(rng, 2, n), cloud(rng, 2, m)
+    assert np.array_equal(run_bq(nat, r, ns, xyz, new), oracle.ball_query(r, ns, xyz, new))
+
+
+def test_ball_query_config_scale(nat, oracle):
+    # C4 loss shape: M = N = 8192, nsample = 64, r = 2
+    rng = np.random.default_rng(1234)
+    pc = cloud(rng, 2, 8192)
+    got = run_bq(nat, 2.0, 64, pc, pc)
+    assert np.array_equal(got, oracle.ball_query(2.0, 64, pc, pc))
+    # the centre itself is always the first hit
+    assert np.array_equal(got[:, :, 0], np.broadcast_to(np.arange(8192, dtype=np.int32), (2, 8192)))
+
+
+def test_ball_query_empty_and_saturated(nat, oracle):
+    rng = np.random.default_rng(5)
+    xyz = cloud(rng, 1, 500)
+    assert (run_bq(nat, 1.0, 8, xyz, xyz + 1000.0) == 0).all()
+    got = run_bq(nat, 1e4, 8, xyz, xyz)  # every centre saturates after 8 candidates -> early exit path
+    assert np.array_equal(got, np.broadcast_to(np.arange(8, dtype=np.int32), (1, 500, 8)))
+
+
+def run_fps(nat, xyz, m):
+    B, N, _ = xyz.shape
+    temp = torch.full((B, N), 1e10, device=DEV)
+    idx = torch.empty(B, m, dtype=torch.int32, device=DEV)
+    nat.furthest_point_sampling_wrapper(B, N, m, T(xyz), temp, idx)
+    return idx.cpu().numpy(), temp.cpu().numpy()
+
+
+FPS_CASES = [(1, 1), (2, 2), (37, 20), (64, 64), (100, 50), (129, 7), (512, 256), (700, 64), (1000, 1000), (1024, 128),
+             (1500, 300), (2048, 2048), (3000, 100), (4096, 1024), (8192, 2048), (10000, 64), (16384, 1024),
+             (20000, 128)]
+
+
+@pytest.mark.parametrize("N,m", FPS_CASES)
+def test_fps_bit_exact(nat, oracle, N, m):
+    rng = np.random.default_rng(N * 3 + m)
+    B = 3 if N <= 4096 else 2
+    xyz = cloud(rng, B, N, dup=N // 5)
+    got, temp = run_fps(nat, xyz, m)
+    ref, temp_ref = oracle.fps(xyz, m, return_temp=True)
+    assert np.array_equal(got, ref)
+    assert np.array_equal(temp, temp_ref)
+
+
+@pytest.mark.parametrize("shape", [(8, 8, 4), (16, 16, 8), (20, 10, 7)])
+def test_fps_lattice_ties(nat, oracle, shape):
+    g = np.stack(np.meshgrid(*[np.arange(s) for s in shape], indexing="ij"), -1).reshape(1, -1, 3).astype(np.float32)
+    m = g.shape[1] // 2
+    got, _ = run_fps(nat, g, m)
+    assert np.array_equal(got, oracle.fps(g, m))
+
+
+def test_fps_all_points_identical(nat, oracle):
+    xyz = np.ones((2, 300, 3), np.float32)
+    got, _ = run_fps(nat, xyz, 40)
+    assert np.array_equal(got, oracle.fps(xyz, 40))
+
+
+def test_gather_and_group_forward_exact(nat, oracle):
+    rng = np.random.default_rng(3)
+    for (B, C, N, P, S) in [(2, 5, 50, 11, 4), (2, 96, 2048, 1024, 64), (1, 3, 8192, 2048, 64), (3, 7, 100, 13, 3),
+                            (2, 10, 8192, 8192, 32)]:
+        feats = rng.standard_normal((B, C, N)).astype(np.float32)
+        idx = rng.integers(0, N, (B, P, S)).astype(np.int32)
+        out = torch.empty(B, C, P, S, device=DEV)
+        nat.group_points_wrapper(B, C, N, P, S, T(feats), T(idx), out)
+        assert np.array_equal(out.cpu().numpy(), oracle.group(feats, idx))
+        gi = rng.integers(0, N, (B, P)).astype(np.int32)
+        out = torch.empty(B, C, P, device=DEV)
+        nat.gather_points_wrapper(B, C, N, P, T(feats), T(gi), out)
+        assert np.array_equal(out.cpu().numpy(), oracle.gather(feats, gi))
+
+
+def test_gather_and_group_grad(nat, oracle):
+    rng = np.random.default_rng(4)
+    for (B, C, N, P, S) in [(2, 5, 50, 11, 4), (2, 16, 512, 256, 64), (3, 7, 100, 13, 3)]:
+        idx = rng.integers(0, N, (B, P, S)).astype(np.int32)
+        go = rng.standard_normal((B, C, P, S)).astype(np.float32)
+        gp = torch.zeros(B, C, N, device=DEV)
+        nat.group_points_grad_wrapper(B, C, N, P, S, T(go), T(idx), gp)
+        np.testing.assert_allclose(gp.cpu().numpy(), oracle.group_grad(go, idx, N), rtol=1e-5, atol=1e-5)
+        gi = rng.integers(0, N, (B, P)).astype(np.int32)
+        go = rng.standard_normal((B, C, P)).astype(np.float32)
+        gp = torch.zeros(B, C, N, device=DEV)
+        nat.gather_points_grad_wrapper(B, C, N, P, T(go), T(gi), gp)
+        np.testing.assert_allclose(gp.cpu().numpy(), oracle.gather_grad(go, gi, N), rtol=1e-5, atol=1e-5)
+
+
+def test_three_interpolate(nat, oracle):
+    rng = np.random.default_rng(6)
+    for (B, C, M, N) in [(2, 5, 50, 70), (2, 256, 512, 1024), (1, 64, 2048, 8192), (3, 1, 3, 5)]:
+        feats = rng.standard_normal((B, C, M)).astype(np.float32)
+        i3 = rng.integers(0, M, (B, N, 3)).astype(np.int32)
+        w = rng.random((B, N, 3)).astype(np.float32)
+        out = torch.empty(B, C, N, device=DEV)
+        nat.three_interpolate_wrapper(B, C, M, N, T(feats), T(i3), T(w), out)
+        assert np.array_equal(out.cpu().numpy(), oracle.three_interpolate(feats, i3, w))
+        go = rng.standard_normal((B, C, N)).astype(np.float32)
+        gp = torch.zeros(B, C, M, device=DEV)
+        nat.three_interpolate_grad_wrapper(B, C, N, M, T(go), T(i3), T(w), gp)
+        np.testing.assert_allclose(gp.cpu().numpy(), oracle.three_interpolate_grad(go, i3, w, M), rtol=1e-5, atol=1e-5)
+
+
+def test_operator_api_autograd(nat):
+    """The autograd.Function layer: gradients equal those of an index_select formulation."""
+    from ogc_amd.pointnet2.pointnet2 import gather_operation, grouping_operation, three_interpolate
+    torch.manual_seed(0)
+    B, C, N, P, S = 2, 6, 64, 16, 8
+    feats = torch.randn(B, C, N, device=DEV, requires_grad=True)
+    idx = torch.randint(0, N, (B, P, S), device=DEV, dtype=torch.int32)
+    out = grouping_operation(feats, idx)
+    ref = torch.gather(feats.unsqueeze(2).expand(-1, -1, P, -1), 3, idx.long().unsqueeze(1).expand(-1, C, -1, -1))
+    assert torch.equal(out, ref)
+    g = torch.randn_like(out)
+    (ga,) = torch.autograd.grad(out, feats, g)
+    (gb,) = torch.autograd.grad(ref, feats, g)
+    torch.testing.assert_close(ga, gb, rtol=1e-5, atol=1e-5)
+
+    gi = torch.randint(0, N, (B, P), device=DEV, dtype=torch.int32)
+    out = gather_operation(feats, gi)
+    ref = torch.gather(feats, 2, gi.long().unsqueeze(1).expand(-1, C, -1))
+    assert torch.equal(out, ref)
+    g = torch.randn_like(out)
+    torch.testing.assert_close(torch.autograd.grad(out, feats, g)[0], torch.autograd.grad(ref, feats, g)[0],
+                               rtol=1e-5, atol=1e-5)
+
+    i3 = torch.randint(0, N, (B, P, 3), device=DEV, dtype=torch.int32)
+    w = torch.rand(B, P, 3, device=DEV)
+    out = three_interpolate(feats, i3, w)
+    gathered = torch.gather(feats.unsqueeze(2).expand(-1, -1, P, -1), 3, i3.long().unsqueeze(1).expand(-1, C, -1, -1))
+    ref = (gathered * w.unsqueeze(1)).sum(-1)
+    torch.testing.assert_close(out, ref, rtol=1e-5, atol=1e-6)
+    g = torch.randn_like(out)
+    torch.testing.assert_close(torch.autograd.grad(out, feats, g)[0], torch.autograd.grad(ref, feats, g)[0],
+                               rtol=1e-5, atol=1e-5)
+
+
+def test_query_and_group_matches_unfused(nat, oracle):
+    from ogc_amd.pointnet2.pointnet2 import QueryAndGroup
+    rng = np.random.default_rng(8)
+    xyz = cloud(rng, 2, 1024)
+    new = xyz[:, ::4].copy()
+    feats = rng.standard_normal((2, 5, 1024)).astype(np.float32)
+    qg = QueryAndGroup(radius=4.0, nsample=16)
+    nf, gx = qg(T(xyz), T(new), T(feats))
+    d2, idx = oracle.knn(16, new, xyz)
+    idx = np.where(np.sqrt(d2) > np.float32(4.0), idx[:, :, :1], idx)
+    gx_ref = oracle.group(xyz.transpose(0, 2, 1).copy(), idx) - new.transpose(0, 2, 1)[..., None]
+    gf_ref = oracle.group(feats, idx)
+    assert np.array_equal(gx.cpu().numpy(), gx_ref)
+    assert np.array_equal(nf.cpu().numpy(), np.concatenate([gx_ref, gf_ref], 1))
+
+
+def test_runs_on_the_current_stream(nat, oracle):
+    rng = np.random.default_rng(9)
+    pc = cloud(rng, 1, 2048)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        t = T(pc)
+        d2 = torch.empty(1, 2048, 8, device=DEV)
+        idx = torch.empty(1, 2048, 8, dtype=torch.int32, device=DEV)
+        nat.knn_wrapper(1, 2048, 2048, 8, t, t, d2, idx)
+    s.synchronize()
+    assert np.array_equal(idx.cpu().numpy(), oracle.knn(8, pc, pc)[1])

@@ -1,0 +1,116 @@
+"""Per-operator timings on one MI355X at the config shapes of SURVEY.md §8 (development tool).
+
+    python tools/bench_ops.py [--ops knn,ball,...] [--iters 20]
+
+Prints one line per case: ms per launch, algorithmic GB/s (SURVEY §8d byte counts) and, for the
+all-pairs ops, G pair-evaluations/s.
+"""
+import argparse
+import sys, os
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ogc_amd  # noqa: E402
+from ogc_amd import pointnet2_cuda as nat  # noqa: E402
+
+DEV = "cuda"
+
+
+def cloud(B, N, g, scale=(60.0, 4.0, 80.0)):
+    return ((torch.rand(B, N, 3, generator=g) - 0.5) * torch.tensor(scale)).to(DEV).contiguous()
+
+
+def timeit(fn, iters, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ops", default="knn,nn3,ball,fps,group,interp")
+    ap.add_argument("--iters", type=int, default=10)
+    a = ap.parse_args()
+    ops = a.ops.split(",")
+    g = torch.Generator().manual_seed(1234)
+    print("device:", torch.cuda.get_device_name(0))
+
+    if "knn" in ops:
+        for (B, n, m, k) in [(1, 8192, 8192, 32), (4, 8192, 8192, 32), (16, 2048, 8192, 64), (16, 1024, 2048, 64),
+                             (16, 512, 1024, 64), (1, 2048, 2048, 16), (1, 4096, 8192, 32), (1, 8192, 8192, 1),
+                             (8, 16384, 16384, 32)]:
+            pc = cloud(B, m, g)
+            q = pc[:, :: m // n].contiguous() if n <= m else cloud(B, n, g)
+            d2 = torch.empty(B, n, k, device=DEV)
+            idx = torch.empty(B, n, k, dtype=torch.int32, device=DEV)
+            ms = timeit(lambda: nat.knn_wrapper(B, n, m, k, q, pc, d2, idx), a.iters)
+            byt = B * (12 * n + 12 * m + 8 * n * k)
+            print("knn   B=%-3d n=%-6d m=%-6d k=%-3d %9.3f ms  %8.2f GB/s  %8.1f Gpair/s" %
+                  (B, n, m, k, ms, byt / ms / 1e6, B * n * m / ms / 1e6))
+    if "nn3" in ops:
+        for (B, n, m) in [(16, 8192, 2048), (16, 2048, 1024), (1, 100000, 8192)]:
+            pc = cloud(B, m, g)
+            q = cloud(B, n, g)
+            d2 = torch.empty(B, n, 3, device=DEV)
+            idx = torch.empty(B, n, 3, dtype=torch.int32, device=DEV)
+            ms = timeit(lambda: nat.three_nn_wrapper(B, n, m, q, pc, d2, idx), a.iters)
+            byt = B * (12 * n + 12 * m + 24 * n)
+            print("nn3   B=%-3d n=%-6d m=%-6d       %9.3f ms  %8.2f GB/s  %8.1f Gpair/s" %
+                  (B, n, m, ms, byt / ms / 1e6, B * n * m / ms / 1e6))
+    if "ball" in ops:
+        for (B, n, ns, r) in [(1, 8192, 64, 2.0), (4, 8192, 64, 2.0), (16, 8192, 64, 2.0), (8, 16384, 64, 2.0),
+                              (16, 4096, 16, 2.4)]:
+            pc = cloud(B, n, g)
+            idx = torch.zeros(B, n, ns, dtype=torch.int32, device=DEV)
+            ms = timeit(lambda: nat.ball_query_wrapper(B, n, n, r, ns, pc, pc, idx), a.iters)
+            byt = B * (12 * n + 12 * n + 4 * n * ns)
+            print("ball  B=%-3d M=N=%-6d ns=%-3d r=%-4.1f  %9.3f ms  %8.2f GB/s  %8.1f Gpair/s" %
+                  (B, n, ns, r, ms, byt / ms / 1e6, B * n * n / ms / 1e6))
+    if "fps" in ops:
+        for (B, N, m) in [(16, 8192, 2048), (16, 2048, 1024), (16, 1024, 512), (1, 2048, 2048), (1, 8192, 4096),
+                          (8, 16384, 4096), (1, 100000, 8192)]:
+            pc = cloud(B, N, g)
+            idx = torch.empty(B, m, dtype=torch.int32, device=DEV)
+            temp = torch.empty(B, N, device=DEV)
+
+            def run():
+                temp.fill_(1e10)
+                nat.furthest_point_sampling_wrapper(B, N, m, pc, temp, idx)
+            ms = timeit(run, max(2, a.iters // 3), warm=1)
+            print("fps   B=%-3d N=%-6d m=%-6d       %9.3f ms  %8.3f us/round" % (B, N, m, ms, ms * 1e3 / m))
+    if "group" in ops:
+        for (B, C, N, P, S) in [(16, 96, 2048, 1024, 64), (16, 128, 1024, 512, 64), (16, 3, 8192, 2048, 64),
+                                (4, 10, 8192, 8192, 64), (1, 64, 2048, 2048, 16)]:
+            feats = torch.randn(B, C, N, device=DEV)
+            idx = torch.randint(0, N, (B, P, S), dtype=torch.int32, device=DEV)
+            out = torch.empty(B, C, P, S, device=DEV)
+            ms = timeit(lambda: nat.group_points_wrapper(B, C, N, P, S, feats, idx, out), a.iters)
+            byt = B * (4 * C * N + 4 * P * S + 4 * C * P * S)
+            gp = torch.zeros(B, C, N, device=DEV)
+            ms2 = timeit(lambda: nat.group_points_grad_wrapper(B, C, N, P, S, out, idx, gp), a.iters)
+            print("group B=%-3d C=%-4d N=%-5d P=%-5d S=%-3d fwd %8.3f ms %8.1f GB/s | bwd %8.3f ms %8.1f GB/s" %
+                  (B, C, N, P, S, ms, byt / ms / 1e6, ms2, byt / ms2 / 1e6))
+    if "interp" in ops:
+        for (B, C, M, N) in [(16, 256, 512, 1024), (16, 128, 1024, 2048), (16, 64, 2048, 8192)]:
+            feats = torch.randn(B, C, M, device=DEV)
+            i3 = torch.randint(0, M, (B, N, 3), dtype=torch.int32, device=DEV)
+            w = torch.rand(B, N, 3, device=DEV)
+            out = torch.empty(B, C, N, device=DEV)
+            ms = timeit(lambda: nat.three_interpolate_wrapper(B, C, M, N, feats, i3, w, out), a.iters)
+            byt = B * (4 * C * M + 24 * N + 4 * C * N)
+            gp = torch.zeros(B, C, M, device=DEV)
+            ms2 = timeit(lambda: nat.three_interpolate_grad_wrapper(B, C, N, M, out, i3, w, gp), a.iters)
+            print("interp B=%-3d C=%-4d M=%-5d N=%-5d fwd %8.3f ms %8.1f GB/s | bwd %8.3f ms %8.1f GB/s" %
+                  (B, C, M, N, ms, byt / ms / 1e6, ms2, byt / ms2 / 1e6))
+
+
+if __name__ == "__main__":
+    main()
