@@ -173,7 +173,7 @@ __global__ __launch_bounds__(OGC_WAVE) void knn_heap_kernel(int n, int m, int k,
             id = (int)(unsigned)key;
         }
         if (MODE == 1) {
-            d = __fsqrt_rn(d);
+            d = sqrtf(d); // IEEE-correct (hipcc default: -fhip-fp32-correctly-rounded-divide-sqrt)
             if (d > radius && radius >= 0.0f) id = hs > 0 ? (int)(unsigned)heap[ql] : 0;
         }
         dist_out[base + t] = d;
