@@ -1,0 +1,257 @@
+"""Unsupervised OGC segmentation losses (reference: losses/seg_loss_unsup.py) on the HIP operators.
+
+Same classes, constructor arguments, forward signatures, returned values and ``loss_dict`` keys.  What changed
+is how the values are computed on the device:
+  * ``fit_motion_svd_batch`` never materialises the (B*K, N, N) ``diag_embed`` (10.7 GB at B*K=40, N=8192;
+    reference :36) — the weighted cross-covariance is formed as P_c^T (w * Q_c);
+  * it has no host synchronisation (the reference's ``valid_batches.any()`` and boolean indexing sync);
+  * kNN + radius clamp is one fused launch (``knn_radius_clamp``);
+  * ``UnsupervisedOGCLoss`` gathers its monitored scalars with a single device->host copy instead of six
+    ``.item()`` calls.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from scipy.optimize import linear_sum_assignment
+
+from ..pointnet2.pointnet2 import ball_query, grouping_operation, knn, knn_radius_clamp
+
+
+def fit_motion_svd_batch(pc1, pc2, mask=None):
+    """Weighted Kabsch: rigid (R, t) minimising sum_n w_n |R p_n + t - q_n|^2 per batch item.
+    pc1, pc2 (B, N, 3), mask (B, N) -> R (B, 3, 3), t (B, 3).  Reference: seg_loss_unsup.py:10-61.
+    Items whose covariance contains NaN (e.g. an all-zero mask) get the identity transform."""
+    if mask is None:
+        pc1_mean = pc1.mean(dim=1, keepdim=True)
+        pc2_mean = pc2.mean(dim=1, keepdim=True)
+        weighted_q = pc2 - pc2_mean
+    else:
+        denom = mask.sum(dim=1, keepdim=True)                                       # (B, 1)
+        pc1_mean = (torch.einsum('bnd,bn->bd', pc1, mask) / denom).unsqueeze(1)     # (B, 1, 3)
+        pc2_mean = (torch.einsum('bnd,bn->bd', pc2, mask) / denom).unsqueeze(1)
+        weighted_q = (pc2 - pc2_mean) * mask.unsqueeze(-1)                          # diag(w) @ Q_c, row by row
+    S = (pc1 - pc1_mean).transpose(1, 2).bmm(weighted_q)                            # (B, 3, 3)
+
+    valid = ~torch.isnan(S).flatten(1).any(dim=1)                                   # (B,)
+    eye = torch.eye(3, device=pc1.device, dtype=S.dtype).expand_as(S)
+    S_safe = torch.where(valid.view(-1, 1, 1), S, eye)
+    u, _, vh = torch.linalg.svd(S_safe)
+    v = vh.transpose(1, 2)
+    det = torch.det(v.bmm(u.transpose(1, 2)))
+    # reflection -> rotation: R = V diag(1, 1, det) U^T  (:49-53)
+    diag = torch.ones_like(S[..., 0])
+    diag[:, 2] = det
+    R = v.bmm(torch.diag_embed(diag).bmm(u.transpose(1, 2)))
+    t = pc2_mean.squeeze(1) - R.bmm(pc1_mean.transpose(1, 2)).squeeze(2)
+
+    R = torch.where(valid.view(-1, 1, 1), R, eye)
+    t = torch.where(valid.view(-1, 1), t, torch.zeros_like(t))
+    return R, t
+
+
+class DynamicLoss(nn.Module):
+    """Per-slot rigid fit of the flow; mask-blended transformed cloud vs pc + flow. Reference: :64-98."""
+
+    def __init__(self, loss_norm=2):
+        super().__init__()
+        self.loss_norm = loss_norm
+
+    def forward(self, pc, mask, flow):
+        # pc (B, N, 3), mask (B, N, K), flow (B, N, 3) -> scalar
+        n_batch, n_point, n_object = mask.size()
+        pc2 = pc + flow
+        mask_t = mask.transpose(1, 2)                                               # (B, K, N)
+        pc_rep = pc.unsqueeze(1).expand(-1, n_object, -1, -1).reshape(n_batch * n_object, n_point, 3)
+        pc2_rep = pc2.unsqueeze(1).expand(-1, n_object, -1, -1).reshape(n_batch * n_object, n_point, 3)
+        with torch.no_grad():  # the transformed cloud is detached in the reference (:91)
+            object_R, object_t = fit_motion_svd_batch(pc_rep, pc2_rep, mask_t.reshape(n_batch * n_object, n_point))
+            pc_transformed = torch.einsum('bij,bnj->bni', object_R, pc_rep) + object_t.unsqueeze(1)
+            pc_transformed = pc_transformed.reshape(n_batch, n_object, n_point, 3)
+        blended = (mask_t.unsqueeze(-1) * pc_transformed).sum(1)
+        return (blended - pc2).norm(p=self.loss_norm, dim=-1).mean()
+
+
+def _neighbour_consistency(mask, idx, k, cross_entropy, loss_norm):
+    """mask (B, K, N) vs its values at neighbour indices idx (B, N, k). Reference: :123-129, :152-158."""
+    nn_mask = grouping_operation(mask, idx.detach())
+    if cross_entropy:
+        target = mask.unsqueeze(3).expand(-1, -1, -1, k).detach()
+        loss = F.binary_cross_entropy(nn_mask, target, reduction='none').sum(dim=1).mean(dim=-1)
+    else:
+        loss = (mask.unsqueeze(3) - nn_mask).norm(p=loss_norm, dim=1).mean(dim=-1)
+    return loss.mean()
+
+
+class KnnLoss(nn.Module):
+    """Mask smoothness over the k nearest neighbours (those beyond ``radius`` replaced by the nearest).
+    Reference: :101-129."""
+
+    def __init__(self, k, radius, cross_entropy=False, loss_norm=1, **kwargs):
+        super().__init__()
+        self.k = k
+        self.radius = radius
+        self.cross_entropy = cross_entropy
+        self.loss_norm = loss_norm
+
+    def forward(self, pc, mask):
+        mask = mask.permute(0, 2, 1).contiguous()
+        _, idx = knn_radius_clamp(self.k, self.radius, pc, pc)
+        return _neighbour_consistency(mask, idx, self.k, self.cross_entropy, self.loss_norm)
+
+
+class BallQLoss(nn.Module):
+    """Mask smoothness over ball-query neighbours. Reference: :132-158."""
+
+    def __init__(self, k, radius, cross_entropy=False, loss_norm=1, **kwargs):
+        super().__init__()
+        self.k = k
+        self.radius = radius
+        self.cross_entropy = cross_entropy
+        self.loss_norm = loss_norm
+
+    def forward(self, pc, mask):
+        mask = mask.permute(0, 2, 1).contiguous()
+        idx = ball_query(self.radius, self.k, pc.contiguous(), pc.contiguous())
+        return _neighbour_consistency(mask, idx, self.k, self.cross_entropy, self.loss_norm)
+
+
+class SmoothLoss(nn.Module):
+    """Reference: :161-180."""
+
+    def __init__(self, w_knn, w_ball_q, knn_loss_params, ball_q_loss_params):
+        super().__init__()
+        self.knn_loss = KnnLoss(**knn_loss_params)
+        self.ball_q_loss = BallQLoss(**ball_q_loss_params)
+        self.w_knn = w_knn
+        self.w_ball_q = w_ball_q
+
+    def forward(self, pc, mask):
+        return (self.w_knn * self.knn_loss(pc, mask)) + (self.w_ball_q * self.ball_q_loss(pc, mask))
+
+
+def interpolate_mask_by_flow(pc1, pc2, mask1, flow1, k=1):
+    """Mask of pc2 interpolated from the k nearest points of pc1 + flow1. Reference: :183-209."""
+    warped_pc1 = (pc1 + flow1).contiguous()
+    dist, idx = knn(k, pc2.contiguous(), warped_pc1)
+    grouped = grouping_operation(mask1.transpose(1, 2).contiguous(), idx.detach())   # (B, K, N, k)
+    if k == 1:
+        out = grouped.squeeze(-1)
+    else:
+        inv = 1.0 / dist.clamp(min=1e-10)
+        weight = inv / inv.sum(dim=2, keepdim=True)
+        out = (weight.unsqueeze(1) * grouped).sum(dim=-1)
+    return out.transpose(1, 2)
+
+
+def match_mask_by_iou(mask1, mask2):
+    """Hungarian matching of the hard segmentations by IoU -> permutation matrices (B, K, K).
+    Reference: :212-240 (scipy on the host; here with one device->host copy for the whole batch)."""
+    n_batch, _, n_object = mask1.size()
+    eye = torch.eye(n_object, dtype=torch.float32, device=mask1.device)
+    onehot1 = eye[mask1.argmax(-1).detach()]
+    onehot2 = eye[mask2.argmax(-1).detach()]
+    intersection = torch.einsum('bng,bnp->bgp', onehot1, onehot2)
+    union = onehot1.sum(dim=1).unsqueeze(-1) + onehot2.sum(dim=1, keepdim=True) - intersection
+    iou = (intersection / union.clamp(1e-10)).cpu().numpy()
+    perm = np.stack([linear_sum_assignment(iou[b], maximize=True)[1] for b in range(n_batch)], 0)
+    return eye[torch.from_numpy(perm).to(mask1.device)]
+
+
+class InvarianceLoss(nn.Module):
+    """Reference: :243-280."""
+
+    def __init__(self, cross_entropy=False, loss_norm=2):
+        super().__init__()
+        self.cross_entropy = cross_entropy
+        self.loss_norm = loss_norm
+
+    def distance(self, mask1, mask2):
+        if self.cross_entropy:
+            loss = F.binary_cross_entropy(mask1, mask2, reduction='none').sum(dim=1)
+        else:
+            loss = (mask1 - mask2).norm(p=self.loss_norm, dim=-1)
+        return loss.mean()
+
+    def forward(self, mask1, mask2):
+        perm2 = match_mask_by_iou(mask1, mask2)
+        target_mask1 = torch.einsum('bij,bnj->bni', perm2, mask2).detach()
+        perm1 = match_mask_by_iou(mask2, mask1)
+        target_mask2 = torch.einsum('bij,bnj->bni', perm1, mask1).detach()
+        return self.distance(mask1, target_mask1) + self.distance(mask2, target_mask2)
+
+
+class EntropyLoss(nn.Module):
+    """Reference: :283-297."""
+
+    def forward(self, mask, epsilon=1e-5):
+        return (-(mask * torch.log(mask.clamp(epsilon))).sum(dim=-1)).mean()
+
+
+class RankLoss(nn.Module):
+    """Mean nuclear norm of the (N, K) masks. Reference: :300-314."""
+
+    def forward(self, mask):
+        return torch.linalg.matrix_norm(mask, ord='nuc', dim=(1, 2)).mean()
+
+
+class UnsupervisedOGCLoss(nn.Module):
+    """Weighted sum of dynamic / smooth / invariance terms (+ entropy and rank for monitoring).
+    Reference: :317-409; returns ``(loss, loss_dict)`` with keys dynamic, smooth, invariance, entropy, rank, sum."""
+
+    def __init__(self, dynamic_loss, smooth_loss, invariance_loss, entropy_loss, rank_loss,
+                 weights=[10.0, 0.1, 0.1], start_steps=[0, 0, 0]):
+        super().__init__()
+        self.dynamic_loss = dynamic_loss
+        self.smooth_loss = smooth_loss
+        self.invariance_loss = invariance_loss
+        self.w_dynamic, self.w_smooth, self.w_invariance = weights
+        self.start_step_dynamic, self.start_step_smooth, self.start_step_invariance = start_steps
+        self.entropy_loss = entropy_loss
+        self.rank_loss = rank_loss
+
+    def step_lossw(self, it, weight, start_step=0):
+        return 0 if it < start_step else weight
+
+    def forward(self, pcs, masks, flows, step_w=False, it=0, aug_transform=False):
+        # pcs / masks / flows: lists of 2 (or 4 with aug_transform) tensors (B, N, 3) / (B, N, K) / (B, N, 3)
+        assert len(pcs) == len(masks) == len(flows), "Inconsistent number of frames!"
+        n_view = 4 if aug_transform else 2
+        pcs, masks, flows = list(pcs)[:n_view], list(masks)[:n_view], list(flows)[:n_view]
+        assert len(pcs) == n_view
+
+        def weight(w, start):
+            return self.step_lossw(it, weight=w, start_step=start) if step_w else w
+
+        def total(vals):
+            # the reference's association: (v1 + v2), then += (v3 + v4), then * 0.5  (:358-361)
+            out = vals[0] + vals[1]
+            if aug_transform:
+                out = 0.5 * (out + (vals[2] + vals[3]))
+            return out
+
+        terms = {}
+        l_dynamic = total([self.dynamic_loss(p, m, f) for p, m, f in zip(pcs, masks, flows)])
+        terms['dynamic'] = l_dynamic
+        loss = weight(self.w_dynamic, self.start_step_dynamic) * l_dynamic
+
+        l_smooth = total([self.smooth_loss(p, m) for p, m in zip(pcs, masks)])
+        terms['smooth'] = l_smooth
+        loss = loss + weight(self.w_smooth, self.start_step_smooth) * l_smooth
+
+        if aug_transform:
+            l_invariance = self.invariance_loss(masks[0], masks[2]) + self.invariance_loss(masks[1], masks[3])
+            terms['invariance'] = l_invariance
+            loss = loss + weight(self.w_invariance, self.start_step_invariance) * l_invariance
+
+        with torch.no_grad():  # monitoring only (:394-405)
+            terms['entropy'] = total([self.entropy_loss(m) for m in masks])
+            terms['rank'] = total([self.rank_loss(m) for m in masks])
+        terms['sum'] = loss
+
+        keys = list(terms)
+        values = torch.stack([terms[k].detach().float().reshape(()) for k in keys]).tolist()  # one sync
+        loss_dict = dict(zip(keys, values))
+        loss_dict.setdefault('invariance', 0)
+        loss_dict = {k: loss_dict[k] for k in ('dynamic', 'smooth', 'invariance', 'entropy', 'rank', 'sum')}
+        return loss, loss_dict

@@ -1,0 +1,242 @@
+"""Shared implementation of the three ``FlowStep3D`` variants (reference: models/flownet_kitti.py,
+models/flownet_sapien.py, models/flownet_ogcdr.py — same recurrent structure, different widths /
+neighbourhood sizes / encoder depth).  Sub-module and attribute names follow the reference so that its
+checkpoints (``encoder_loc.sa1.mlp_convs.0.weight``, ``global_corr_layer.epsilon``, ...) load unchanged.
+"""
+import torch
+import torch.nn as nn
+
+from ..utils.flowstep3d_util import FlowEmbedding, PointNetFeaturePropogation, PointNetSetAbstraction
+
+
+def _sa(npoint, nsample, in_channel, mlp, inorm, **kw):
+    return PointNetSetAbstraction(npoint=npoint, radius=None, nsample=nsample, in_channel=in_channel, mlp=mlp,
+                                  group_all=False, use_instance_norm=inorm, **kw)
+
+
+class Flow0Regressor(nn.Module):
+    """Reference: flownet_kitti.py:6-19."""
+
+    def __init__(self, npoint, use_instance_norm, cfg):
+        super().__init__()
+        w = cfg["width"]
+        self.sa1 = _sa(int(npoint / 4), cfg["reg_nsample"], w, [w, w, w], use_instance_norm)
+        self.fc = torch.nn.Linear(w, 3)
+
+    def forward(self, pc1_l_loc, corr_feats):
+        _, x = self.sa1(pc1_l_loc[2], corr_feats)
+        return self.fc(x.permute(0, 2, 1).contiguous()).permute(0, 2, 1).contiguous()
+
+
+class FlowRegressor(nn.Module):
+    """Reference: flownet_kitti.py:22-38."""
+
+    def __init__(self, npoint, use_instance_norm, cfg):
+        super().__init__()
+        w = cfg["width"]
+        self.sa1 = _sa(int(npoint / 4), cfg["reg_nsample"], w, [w, w, w], use_instance_norm)
+        self.sa2 = _sa(int(npoint / 4), cfg["reg_nsample"], w, [w, w, w], use_instance_norm)
+        self.fc = torch.nn.Linear(w, 3)
+
+    def forward(self, pc1_l_loc, corr_feats):
+        _, x = self.sa1(pc1_l_loc[2], corr_feats)
+        _, x = self.sa2(pc1_l_loc[2], x)
+        return self.fc(x.permute(0, 2, 1).contiguous()).permute(0, 2, 1).contiguous()
+
+
+class GlobalCorrLayer(nn.Module):
+    """Dense soft correlation between the coarsest levels of both clouds, then upsampling of the resulting
+    coarse flow through FP/SA stages.  Reference: flownet_kitti.py:41-81 (3 levels) and
+    flownet_sapien.py:41-76 (2 levels)."""
+
+    def __init__(self, npoint, use_instance_norm, cfg):
+        super().__init__()
+        self.support_th = 10 ** 2  # 10 m
+        self.epsilon = torch.nn.Parameter(torch.zeros(1))
+        self.fp0 = PointNetFeaturePropogation(in_channel=3, mlp=[])
+        stages = cfg["glob_corr_sa"]  # [(div, nsample, in_channel, mlp), ...] coarse -> fine
+        self.n_stage = len(stages)
+        for i, (div, nsample, cin, mlp) in enumerate(stages, start=1):
+            setattr(self, "sa%d" % i, _sa(int(npoint / div), nsample, cin, list(mlp), use_instance_norm))
+            setattr(self, "fp%d" % i, PointNetFeaturePropogation(in_channel=mlp[-1], mlp=[]))
+
+    def calc_corr_mat(self, pcloud1, pcloud2, feature1, feature2):
+        # pcloud (B, n, 3), feature (B, n, C) -> (B, n1, n2); reference flownet_kitti.py:53-65
+        eps = torch.exp(self.epsilon) + 0.03
+        distance_matrix = torch.sum(pcloud1 ** 2, -1, keepdim=True)
+        distance_matrix = distance_matrix + torch.sum(pcloud2 ** 2, -1, keepdim=True).transpose(1, 2)
+        distance_matrix = distance_matrix - 2 * torch.bmm(pcloud1, pcloud2.transpose(1, 2))
+        support = (distance_matrix < self.support_th).float()
+        feature1 = feature1 / torch.sqrt(torch.sum(feature1 ** 2, -1, keepdim=True) + 1e-8)
+        feature2 = feature2 / torch.sqrt(torch.sum(feature2 ** 2, -1, keepdim=True) + 1e-8)
+        C = 1.0 - torch.bmm(feature1, feature2.transpose(1, 2))
+        return torch.exp(-C / eps) * support
+
+    def forward(self, pc1_l_glob, pc2_l_glob, feats1_glob, feats2_glob):
+        top = self.n_stage + 1  # index of the coarsest level in pc*_l_glob
+        pcloud1 = pc1_l_glob[top].permute(0, 2, 1)
+        pcloud2 = pc2_l_glob[top].permute(0, 2, 1)
+        corr_mat = self.calc_corr_mat(pcloud1, pcloud2, feats1_glob.permute(0, 2, 1), feats2_glob.permute(0, 2, 1))
+        row_sum = corr_mat.sum(-1, keepdim=True)
+        flow0 = (corr_mat @ pcloud2.contiguous()) / (row_sum + 1e-8) - pcloud1.contiguous()
+
+        feats = self.fp0(pc1_l_glob[top - 1], pc1_l_glob[top], None, flow0.permute(0, 2, 1).contiguous())
+        for i in range(1, self.n_stage + 1):
+            level = top - i
+            _, feats = getattr(self, "sa%d" % i)(pc1_l_glob[level], feats)
+            feats = getattr(self, "fp%d" % i)(pc1_l_glob[level - 1], pc1_l_glob[level], None, feats)
+        return feats
+
+
+class EncoderLoc(nn.Module):
+    """Two SA levels (N/2, N/4) that can re-use cached FPS indices. Reference: flownet_kitti.py:84-100."""
+
+    def __init__(self, npoint, use_instance_norm, cfg):
+        super().__init__()
+        k = cfg["loc_nsample"]
+        self.sa1 = _sa(int(npoint / 2), k, 3, [32, 32, 32], use_instance_norm, return_fps=True)
+        self.sa2 = _sa(int(npoint / 4), k, 32, [64, 64, 64], use_instance_norm, return_fps=True)
+
+    def forward(self, pc, feature, fps_idx=None):
+        fps_idx1 = fps_idx[0] if fps_idx is not None else None
+        pc_l1, feat_l1, fps_idx1 = self.sa1(pc, feature, fps_idx=fps_idx1)
+        fps_idx2 = fps_idx[1] if fps_idx is not None else None
+        pc_l2, feat_l2, fps_idx2 = self.sa2(pc_l1, feat_l1, fps_idx=fps_idx2)
+        return [pc, pc_l1, pc_l2], feat_l2, [fps_idx1, fps_idx2]
+
+
+class EncoderGlob(nn.Module):
+    """Reference: flownet_kitti.py:103-118 (3 SA) / flownet_sapien.py:97-109 (2 SA)."""
+
+    def __init__(self, npoint, use_instance_norm, cfg):
+        super().__init__()
+        self.n_sa = len(cfg["glob_enc"])
+        for i, (div, nsample, cin, mlp) in enumerate(cfg["glob_enc"], start=1):
+            setattr(self, "sa%d" % i, _sa(int(npoint / div), nsample, cin, list(mlp), use_instance_norm))
+
+    def forward(self, pc, feature):
+        pc_l = [pc]
+        for i in range(1, self.n_sa + 1):
+            pc_i, feature = getattr(self, "sa%d" % i)(pc_l[-1], feature)
+            pc_l.append(pc_i)
+        return pc_l, feature
+
+
+class H0Net(nn.Module):
+    """Reference: flownet_kitti.py:121-132."""
+
+    def __init__(self, npoint, use_instance_norm, cfg):
+        super().__init__()
+        w, k = cfg["width"], cfg["h0_nsample"]
+        self.sa1 = _sa(int(npoint / 4), k, 64, [w, w, w], use_instance_norm)
+        self.sa2 = _sa(int(npoint / 4), k, w, [w], use_instance_norm, use_act=False)
+
+    def forward(self, pc, feature):
+        _, feat_l1 = self.sa1(pc, feature)
+        _, feat_l2 = self.sa2(pc, feat_l1)
+        return feat_l2
+
+
+class GRU(nn.Module):
+    """Gated recurrent unit whose gates are set-abstraction convolutions (nsample = 4).
+    Reference: flownet_kitti.py:135-151."""
+
+    def __init__(self, npoint, hidden_dim, input_dim, use_instance_norm):
+        super().__init__()
+        in_ch = hidden_dim + input_dim
+        for name in ("convz", "convr", "convq"):
+            setattr(self, name, _sa(int(npoint / 4), 4, in_ch, [hidden_dim], use_instance_norm, use_act=False))
+
+    def forward(self, h, x, pc):
+        hx = torch.cat([h, x], dim=1)
+        z = torch.sigmoid(self.convz(pc, hx)[1])
+        r = torch.sigmoid(self.convr(pc, hx)[1])
+        q = torch.tanh(self.convq(pc, torch.cat([r * h, x], dim=1))[1])
+        return (1 - z) * h + z * q
+
+
+class NoGRU(nn.Module):
+    """Reference: flownet_kitti.py:154-163 (unused by FlowStep3D, kept for API parity)."""
+
+    def __init__(self, npoint, hidden_dim, input_dim, use_instance_norm):
+        super().__init__()
+        self.conv = _sa(int(npoint / 4), 4, input_dim, [hidden_dim], use_instance_norm)
+
+    def forward(self, x, pc):
+        return self.conv(pc, x)[1]
+
+
+class FlowStep3DBase(nn.Module):
+    """Reference forward: models/flownet_kitti.py:209-252."""
+
+    def __init__(self, cfg, npoint, use_instance_norm, loc_flow_nn, loc_flow_rad, k_decay_fact):
+        super().__init__()
+        w = cfg["width"]
+        self.k_decay_fact = k_decay_fact
+        self.encoder_loc = EncoderLoc(npoint, use_instance_norm, cfg)
+        self.encoder_glob = EncoderGlob(npoint, use_instance_norm, cfg)
+        self.global_corr_layer = GlobalCorrLayer(npoint, use_instance_norm, cfg)
+        self.h0_net = H0Net(npoint, use_instance_norm, cfg)
+        self.flow0_regressor = Flow0Regressor(npoint, use_instance_norm, cfg)
+        self.flow_regressor = FlowRegressor(npoint, use_instance_norm, cfg)
+        self.local_corr_layer = FlowEmbedding(radius=loc_flow_rad, nsample=loc_flow_nn, in_channel=64, mlp=[w, w, w],
+                                              pooling='max', corr_func='concat', use_instance_norm=use_instance_norm)
+        self.gru = GRU(npoint, hidden_dim=w, input_dim=w + 64 + 16 + 3, use_instance_norm=use_instance_norm)
+        k1, k2 = cfg["flow_conv_nsample"]
+        self.flow_conv1 = _sa(int(npoint / 4), k1, 3, [32, 32, 32], use_instance_norm)
+        self.flow_conv2 = _sa(int(npoint / 4), k2, 32, [16, 16, 16], use_instance_norm)
+        self.flow_up_sample = PointNetFeaturePropogation(in_channel=3, mlp=[])
+
+    def calc_glob_corr(self, pc1_loc, feats1_loc, pc2_loc, feats2_loc):
+        pc1_l_glob, feats1_glob = self.encoder_glob(pc1_loc, feats1_loc)
+        pc2_l_glob, feats2_glob = self.encoder_glob(pc2_loc, feats2_loc)
+        return self.global_corr_layer(pc1_l_glob, pc2_l_glob, feats1_glob, feats2_glob)
+
+    def calc_h0(self, feats1_loc, pc):
+        return torch.tanh(self.h0_net(pc, feats1_loc))
+
+    def get_x(self, feats1_loc_new, corr_feats, flow, pc):
+        _, flow_feats = self.flow_conv1(pc, flow)
+        _, flow_feats = self.flow_conv2(pc, flow_feats)
+        return torch.cat([feats1_loc_new, corr_feats, flow_feats, flow], dim=1)
+
+    def get_x_slim(self, feats1_loc_new, corr_feats):
+        return torch.cat([feats1_loc_new, corr_feats], dim=1)
+
+    def forward(self, pc1, pc2, feature1, feature2, iters=1):
+        # pc*, feature* (B, N, 3) -> list of `iters` flow predictions, each (B, N, 3)
+        flow_predictions = []
+        pc1 = pc1.permute(0, 2, 1).contiguous()
+        pc2 = pc2.permute(0, 2, 1).contiguous()
+        feature1 = feature1.permute(0, 2, 1).contiguous()
+        feature2 = feature2.permute(0, 2, 1).contiguous()
+
+        pc1_l_loc, feats1_loc, fps_idx1 = self.encoder_loc(pc1, feature1)
+        pc2_l_loc, feats2_loc, _ = self.encoder_loc(pc2, feature2)
+
+        corr_feats = self.calc_glob_corr(pc1_l_loc[-1], feats1_loc, pc2_l_loc[-1], feats2_loc)
+        flow0_lr = self.flow0_regressor(pc1_l_loc, corr_feats)
+        flow0 = self.flow_up_sample(pc1_l_loc[0], pc1_l_loc[2], None, flow0_lr)
+        flow_predictions.append(flow0.permute(0, 2, 1))
+
+        h = self.calc_h0(feats1_loc, pc1_l_loc[-1])
+
+        pc1_new = pc1 + flow0.detach()
+        pc1_new_lr = pc1_l_loc[2] + flow0_lr.detach()
+        for it in range(iters - 1):
+            pc1_new = pc1_new.detach()
+            pc1_new_lr = pc1_new_lr.detach()
+            flow_lr = pc1_new_lr - pc1_l_loc[2]
+
+            pc1_new_l_loc, feats1_loc_new, _ = self.encoder_loc(pc1_new, pc1_new, fps_idx1)
+            _, corr_feats = self.local_corr_layer(pc1_new_l_loc[-1], pc2_l_loc[-1], feats1_loc_new, feats2_loc)
+
+            x = self.get_x(feats1_loc_new, corr_feats, flow_lr, pc=pc1_l_loc[2])
+            h = self.gru(h=h, x=x, pc=pc1_l_loc[-1])
+            delta_flow_lr = self.flow_regressor(pc1_l_loc, h) / (self.k_decay_fact * it + 1)
+            pc1_new_lr = pc1_new_lr + delta_flow_lr
+
+            delta_flow = self.flow_up_sample(pc1_l_loc[0], pc1_l_loc[2], None, delta_flow_lr)
+            pc1_new = pc1_new + delta_flow
+            flow_predictions.append((pc1_new - pc1).permute(0, 2, 1))
+        return flow_predictions

@@ -1,0 +1,58 @@
+"""Shared implementation of the three ``MaskFormer3D`` variants (reference: models/segnet_kitti.py,
+models/segnet_sapien.py, models/segnet_ogcdr.py — they differ only in the encoder/decoder table)."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..utils.nn_util import Seq
+from ..utils.pointnet2_util import PointnetFPModule, PointnetSAModule, PointnetSAModuleMSG
+from ..utils.transformer_util import MaskFormerHead
+
+BN_CONFIG = {"class": "GroupNorm", "num_groups": 4}
+
+
+class MaskFormer3DBase(nn.Module):
+    """PointNet++ encoder/decoder -> per-point embedding; MaskFormer head -> K slot embeddings;
+    mask = softmax_K(cos(point, slot) / 0.05).  Reference forward: models/segnet_kitti.py:62-89.
+
+    ``sa_specs``: list of dicts, the first (multi-scale) with keys div, radii, nsamples, mlps and the others
+    (single-scale) with div, radius, nsample, mlp; ``fp_specs``: list of MLP channel lists (finest first).
+    """
+
+    def __init__(self, sa_specs, fp_specs, n_slot, n_point, use_xyz, bn, n_transformer_layer,
+                 transformer_embed_dim, transformer_input_pos_enc):
+        super().__init__()
+        self.SA_modules = nn.ModuleList()
+        for spec in sa_specs:
+            npoint = int(n_point / spec["div"])
+            if "radii" in spec:
+                self.SA_modules.append(PointnetSAModuleMSG(
+                    npoint=npoint, radii=list(spec["radii"]), nsamples=list(spec["nsamples"]),
+                    mlps=[list(m) for m in spec["mlps"]], use_xyz=use_xyz, bn=bn))
+            else:
+                self.SA_modules.append(PointnetSAModule(
+                    npoint=npoint, radius=spec["radius"], nsample=spec["nsample"], mlp=list(spec["mlp"]),
+                    use_xyz=use_xyz, bn=bn))
+        self.FP_modules = nn.ModuleList(PointnetFPModule(mlp=list(m), bn=bn) for m in fp_specs)
+
+        self.MF_head = MaskFormerHead(
+            n_slot=n_slot, input_dim=256, n_transformer_layer=n_transformer_layer,
+            transformer_embed_dim=transformer_embed_dim, transformer_n_head=8,
+            transformer_hidden_dim=transformer_embed_dim, input_pos_enc=transformer_input_pos_enc)
+        self.object_mlp = Seq(transformer_embed_dim).conv1d(transformer_embed_dim, bn=bn).conv1d(64, activation=None)
+
+    def forward(self, pc, point_feats):
+        # pc (B, N, 3), point_feats (B, N, 3) -> mask (B, N, K)
+        l_pc, l_feats = [pc], [point_feats.transpose(1, 2).contiguous()]
+        for sa in self.SA_modules:
+            li_pc, li_feats = sa(l_pc[-1], l_feats[-1])
+            l_pc.append(li_pc)
+            l_feats.append(li_feats)
+        # decoder: coarsest -> finest, FP_modules[i] produces level i
+        for i in range(len(self.FP_modules) - 1, -1, -1):
+            l_feats[i] = self.FP_modules[i](l_pc[i], l_pc[i + 1], l_feats[i], l_feats[i + 1])
+
+        slot = self.MF_head(l_feats[-1].transpose(1, 2), l_pc[-1])        # (B, K, D)
+        slot = self.object_mlp(slot.transpose(1, 2))                      # (B, 64, K)
+        logits = torch.einsum('bdn,bdk->bnk', F.normalize(l_feats[0], dim=1), F.normalize(slot, dim=1)) / 0.05
+        return logits.softmax(dim=-1)

@@ -1,0 +1,13 @@
+"""``MaskFormer3D`` for OGC-DR / OGC-DRSV rooms (reference: models/segnet_ogcdr.py:11-52):
+the SAPIEN layout with half the radii (N/2 MSG r={0.05,0.1}, N/4 r=0.2)."""
+from ._segnet import BN_CONFIG, MaskFormer3DBase
+
+
+class MaskFormer3D(MaskFormer3DBase):
+    def __init__(self, n_slot, n_point=2048, use_xyz=True, bn=BN_CONFIG, n_transformer_layer=2,
+                 transformer_embed_dim=256, transformer_input_pos_enc=False):
+        sa = [dict(div=2, radii=[0.05, 0.1], nsamples=[64, 64], mlps=[[3, 64, 64, 64], [3, 64, 64, 128]]),
+              dict(div=4, radius=0.2, nsample=64, mlp=[64 + 128, 128, 128, 256])]
+        fp = [[128 + 3, 128, 128, 64], [256 + 64 + 128, 256, 128]]
+        super().__init__(sa, fp, n_slot, n_point, use_xyz, bn, n_transformer_layer, transformer_embed_dim,
+                         transformer_input_pos_enc)

@@ -1,0 +1,47 @@
+"""Object-aware ICP: scene-flow refinement from object masks (reference: oa_icp.py:16-84).
+
+``weighted_kabsch`` and ``object_aware_icp`` keep the reference's signatures and results.  The per-slot clouds
+are broadcast views instead of K-fold ``repeat`` copies; the round driver (oa_icp.py:87-236, dataset I/O) is
+outside the hot path.
+"""
+import torch
+
+from .losses.seg_loss_unsup import fit_motion_svd_batch, interpolate_mask_by_flow, match_mask_by_iou
+
+
+def _rigid_flow_per_object(pc, flow, mask_t):
+    """Fit one rigid motion per (sample, slot) to ``flow`` and return the mask-blended rigid flow.
+    pc, flow (B, N, 3); mask_t (B, K, N) -> (B, N, 3).  Reference: oa_icp.py:24-38 / :75-83."""
+    n_batch, n_object, n_point = mask_t.shape
+    pc_rep = pc.unsqueeze(1).expand(-1, n_object, -1, -1).reshape(n_batch * n_object, n_point, 3)
+    flow_rep = flow.unsqueeze(1).expand(-1, n_object, -1, -1).reshape(n_batch * n_object, n_point, 3)
+    object_R, object_t = fit_motion_svd_batch(pc_rep, pc_rep + flow_rep, mask_t.reshape(n_batch * n_object, n_point))
+    pc_transformed = torch.einsum('bij,bnj->bni', object_R, pc_rep) + object_t.unsqueeze(1)
+    pc_transformed = pc_transformed.reshape(n_batch, n_object, n_point, 3)
+    return torch.einsum('bkn,bkni->bni', mask_t, pc_transformed) - pc
+
+
+def weighted_kabsch(pc, flow, mask):
+    """pc, flow (B, N, 3), mask (B, N, K) -> object-wise rigid flow (B, N, 3). Reference: oa_icp.py:16-38."""
+    return _rigid_flow_per_object(pc, flow, mask.transpose(1, 2))
+
+
+def object_aware_icp(pc1, pc2, flow, mask1, mask2, icp_iter=10, temperature=0.01):
+    """Alternate soft nearest-neighbour correspondences (restricted to consistent objects) and per-object
+    rigid fits.  pc1, pc2, flow (B, N, 3); mask1, mask2 (B, N, K) -> refined flow (B, N, 3).
+    Reference: oa_icp.py:41-84."""
+    # align the slot order of frame 2 to frame 1
+    mask2_interpolated = interpolate_mask_by_flow(pc1, pc2, mask1, flow)
+    perm = match_mask_by_iou(mask2_interpolated, mask2)
+    mask2 = torch.einsum('bij,bnj->bni', perm, mask2)
+
+    consistency12 = torch.einsum('bmk,bnk->bmn', mask1, mask2)   # object-consistency scores (B, N1, N2)
+    mask1_t = mask1.transpose(1, 2)
+
+    for _ in range(icp_iter):
+        corr12 = (-torch.cdist(pc1 + flow, pc2) / temperature).softmax(-1)
+        corr12 = corr12 * consistency12
+        corr12 = corr12 / corr12.sum(-1, keepdim=True).clamp(1e-10)
+        flow = torch.einsum('bmn,bnj->bmj', corr12, pc2) - pc1
+        flow = _rigid_flow_per_object(pc1, flow, mask1_t)
+    return flow

@@ -1,0 +1,194 @@
+"""Layer builders for the per-point MLPs (reference: utils/nn_util.py).
+
+What must be preserved is the *naming contract*: checkpoints of the reference address parameters as
+``...layer{i}.conv.weight``, ``...layer{i}.normlayer.gn.{weight,bias}`` (GroupNorm) or
+``...normlayer.bn.*`` (BatchNorm), ``...fc.weight`` (SURVEY.md §5 "checkpoint / resume").  Every block is
+therefore an ``nn.Sequential`` whose children carry exactly those names, in the reference's order
+(conv -> norm -> activation, or norm -> activation -> conv when ``preact``).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+
+class GroupNorm(nn.Sequential):
+    """``<name>gn`` = nn.GroupNorm(num_groups, in_size), affine initialised to (1, 0). Ref nn_util.py:6-11."""
+
+    def __init__(self, in_size, num_groups, name=""):
+        super().__init__()
+        gn = nn.GroupNorm(num_groups, in_size)
+        nn.init.ones_(gn.weight)
+        nn.init.zeros_(gn.bias)
+        self.add_module(name + "gn", gn)
+
+
+class _BatchNormNd(nn.Sequential):
+    """``<name>bn`` = BatchNorm{1,2}d(in_size), affine initialised to (1, 0). Ref nn_util.py:14-30."""
+    _cls = None
+
+    def __init__(self, in_size, name=""):
+        super().__init__()
+        bn = self._cls(in_size)
+        nn.init.ones_(bn.weight)
+        nn.init.zeros_(bn.bias)
+        self.add_module(name + "bn", bn)
+
+
+class BatchNorm1d(_BatchNormNd):
+    _cls = nn.BatchNorm1d
+
+
+class BatchNorm2d(_BatchNormNd):
+    _cls = nn.BatchNorm2d
+
+
+def get_norm_layer(layer_def, dimension, **kwargs):
+    """``layer_def`` = {"class": "GroupNorm"|"BatchNorm", **ctor kwargs}; None -> Identity. Ref nn_util.py:33-42."""
+    if layer_def is None:
+        return nn.Identity()
+    spec = dict(kwargs)
+    spec.update(layer_def)
+    kind = spec.pop("class")
+    if kind == "GroupNorm":
+        return GroupNorm(**spec)
+    if kind == "BatchNorm":
+        return (BatchNorm1d, BatchNorm2d)[dimension - 1](**spec)
+    raise KeyError(kind)
+
+
+def _assemble(seq, name, main_name, main, norm, activation, preact):
+    """Children in the reference's order (nn_util.py:67-82, 138-152)."""
+    tail = []
+    if norm is not None:
+        tail.append((name + "normlayer", norm))
+    if activation is not None:
+        tail.append((name + "activation", activation))
+    order = tail + [(name + main_name, main)] if preact else [(name + main_name, main)] + tail
+    for key, mod in order:
+        seq.add_module(key, mod)
+
+
+class _ConvNd(nn.Sequential):
+    """conv (+ norm) (+ activation).  The conv has a bias only when there is no norm layer. Ref nn_util.py:45-82."""
+    _conv = None
+    _dim = None
+
+    def __init__(self, in_size, out_size, kernel_size, stride, padding, dilation, activation, bn, init, bias,
+                 preact, name):
+        super().__init__()
+        use_bias = bias and (bn is None)
+        conv = self._conv(in_size, out_size, kernel_size=kernel_size, stride=stride, padding=padding,
+                          dilation=dilation, bias=use_bias)
+        init(conv.weight)
+        if use_bias:
+            nn.init.zeros_(conv.bias)
+        norm = None
+        if bn is not None:
+            norm = get_norm_layer(bn, self._dim, in_size=in_size if preact else out_size)
+        _assemble(self, name, "conv", conv, norm, activation, preact)
+
+
+class Conv1d(_ConvNd):
+    _conv, _dim = nn.Conv1d, 1
+
+    def __init__(self, in_size, out_size, kernel_size=1, stride=1, padding=0, dilation=1,
+                 activation=nn.ReLU(inplace=True), bn=None, init=nn.init.kaiming_normal_, bias=True,
+                 preact=False, name=""):
+        super().__init__(in_size, out_size, kernel_size, stride, padding, dilation, activation, bn, init, bias,
+                         preact, name)
+
+
+class Conv2d(_ConvNd):
+    _conv, _dim = nn.Conv2d, 2
+
+    def __init__(self, in_size, out_size, kernel_size=(1, 1), stride=(1, 1), padding=(0, 0), dilation=(1, 1),
+                 activation=nn.ReLU(inplace=True), bn=None, init=nn.init.kaiming_normal_, bias=True,
+                 preact=False, name=""):
+        super().__init__(in_size, out_size, kernel_size, stride, padding, dilation, activation, bn, init, bias,
+                         preact, name)
+
+
+class FC(nn.Sequential):
+    """Linear (+ norm) (+ activation); child name ``fc``. Ref nn_util.py:113-152."""
+
+    def __init__(self, in_size, out_size, activation=nn.ReLU(inplace=True), bn=None, init=None, preact=False,
+                 name=""):
+        super().__init__()
+        fc = nn.Linear(in_size, out_size, bias=bn is None)
+        if init is not None:
+            init(fc.weight)
+        if bn is None:
+            nn.init.zeros_(fc.bias)
+        norm = None
+        if bn is not None:
+            norm = get_norm_layer(bn, 1, in_size=in_size if preact else out_size)
+        _assemble(self, name, "fc", fc, norm, activation, preact)
+
+
+class SharedMLP(nn.Sequential):
+    """Stack of 1x1 Conv2d blocks ``layer0 .. layer{n-2}`` over channel sizes ``args``. Ref nn_util.py:155-172."""
+
+    def __init__(self, args, bn=None, activation=nn.ReLU(inplace=True), preact=False, first=False, name=""):
+        super().__init__()
+        for i, (c_in, c_out) in enumerate(zip(args[:-1], args[1:])):
+            bare = first and preact and i == 0  # the very first pre-activation layer has no norm/act
+            self.add_module(name + "layer%d" % i,
+                            Conv2d(c_in, c_out, bn=None if bare else bn, activation=None if bare else activation,
+                                   preact=preact))
+
+
+def knead_leading_dims(n_dim: int, data: torch.Tensor):
+    """Merge the first ``n_dim`` dimensions. Ref nn_util.py:175-181."""
+    if data is None:
+        return None
+    shape = list(data.size())
+    return data.view(int(np.prod(shape[:n_dim])), *shape[n_dim:])
+
+
+def break_leading_dim(dim_size: list, data: torch.Tensor):
+    """Inverse of knead_leading_dims. Ref nn_util.py:184-189."""
+    if data is None:
+        return None
+    return data.view(*dim_size, *list(data.size())[1:])
+
+
+class Seq(nn.Sequential):
+    """Fluent builder: ``Seq(c).conv1d(...).conv1d(...)``; children are named "0", "1", ... Ref nn_util.py:192-249."""
+
+    def __init__(self, input_channels):
+        super().__init__()
+        self.count = 0
+        self.current_channels = input_channels
+
+    def _push(self, module, out_channels=None):
+        self.add_module(str(self.count), module)
+        self.count += 1
+        if out_channels is not None:
+            self.current_channels = out_channels
+        return self
+
+    def conv1d(self, out_size, kernel_size=1, stride=1, padding=0, dilation=1, activation=nn.ReLU(inplace=True),
+               leaky=False, bn=None, init=nn.init.kaiming_normal_, bias=True, preact=False, name=""):
+        if leaky:
+            activation = nn.LeakyReLU(0.1, inplace=True)
+        return self._push(Conv1d(self.current_channels, out_size, kernel_size=kernel_size, stride=stride,
+                                 padding=padding, dilation=dilation, activation=activation, bn=bn, init=init,
+                                 bias=bias, preact=preact, name=name), out_size)
+
+    def conv2d(self, out_size, kernel_size=(1, 1), stride=(1, 1), padding=(0, 0), dilation=(1, 1),
+               activation=nn.ReLU(inplace=True), bn=None, init=nn.init.kaiming_normal_, bias=True, preact=False,
+               name=""):
+        return self._push(Conv2d(self.current_channels, out_size, kernel_size=kernel_size, stride=stride,
+                                 padding=padding, dilation=dilation, activation=activation, bn=bn, init=init,
+                                 bias=bias, preact=preact, name=name), out_size)
+
+    def fc(self, out_size, activation=nn.ReLU(inplace=True), bn=None, init=None, preact=False, name=""):
+        return self._push(FC(self.current_channels, out_size, activation=activation, bn=bn, init=init,
+                             preact=preact, name=name), out_size)
+
+    def dropout(self, p=0.5):
+        return self._push(nn.Dropout(p=p))
+
+    def maxpool2d(self, kernel_size, stride=None, padding=0, dilation=1, return_indices=False, ceil_mode=False):
+        return self._push(nn.MaxPool2d(kernel_size=kernel_size, stride=stride, padding=padding, dilation=dilation,
+                                       return_indices=return_indices, ceil_mode=ceil_mode))

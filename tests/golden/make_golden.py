@@ -1,0 +1,262 @@
+"""Generates tests/golden/*.npz by running THE REFERENCE'S OWN PYTHON (imported from /root/reference, which
+exists only in the build container) on top of the CPU oracle's operators.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+What this pins: every Python-level layer of the hot path above the native boundary — the autograd Functions
+and QueryAndGroup of pointnet2/pointnet2.py, the SA/FP/FlowEmbedding modules, the three MaskFormer3D and
+FlowStep3D variants, the OGC losses, weighted Kabsch and OA-ICP — as executed by the reference code with
+torch 2.10.0 / scipy 1.15.3.  What it does NOT pin: the ten native kernels themselves (the reference's CUDA
+sources cannot be built here); those are the oracle's line-cited restatement (oracle/ogc_oracle.c).
+
+In-process shims needed to import the reference on a CPU-only box:
+  1. sys.modules['pointnet2_cuda'] = the oracle's ten *_wrapper functions;
+  2. torch.cuda.FloatTensor / IntTensor -> CPU factories (pointnet2.py hard-codes CUDA allocation);
+  3. Tensor.cuda / Module.cuda -> identity (utils/transformer_util.py:110);
+  4. a stub `tensorboardX` (imported by utils/pytorch_util.py, which oa_icp.py pulls in).
+Nothing from the reference is copied: only inputs and outputs are written.
+"""
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import detgen  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+
+
+def install_shims():
+    backend = orc.Pointnet2CudaCPU()
+    mod = types.ModuleType("pointnet2_cuda")
+    for name in dir(backend):
+        if name.endswith("_wrapper"):
+            setattr(mod, name, getattr(backend, name))
+    sys.modules["pointnet2_cuda"] = mod
+    torch.cuda.FloatTensor = lambda *shape: torch.empty(*shape, dtype=torch.float32)
+    torch.cuda.IntTensor = lambda *shape: torch.empty(*shape, dtype=torch.int32)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+    tbx = types.ModuleType("tensorboardX")
+    tbx.SummaryWriter = object
+    sys.modules["tensorboardX"] = tbx
+    sys.path.insert(0, REF)
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def grads_summary(module, loss):
+    """Per-parameter gradient L2 norm + the first 32 entries (keeps fixtures small)."""
+    module.zero_grad()
+    loss.backward()
+    out = {}
+    for name, p in module.named_parameters():
+        g = p.grad if p.grad is not None else torch.zeros_like(p)
+        out["gnorm/" + name] = g.norm().reshape(1).numpy()
+        out["ghead/" + name] = g.flatten()[:32].clone().numpy()
+    return out
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrays.items()})
+    print("wrote %-28s %7.1f KB  (%d arrays)" % (name + ".npz", os.path.getsize(path) / 1024, len(arrays)))
+
+
+def gen_operator_layer():
+    from pointnet2.pointnet2 import (QueryAndGroup, ball_query, furthest_point_sample, gather_operation,
+                                     grouping_operation, knn, three_interpolate, three_nn)
+    pc = detgen.cloud(2, 700, 11)
+    pc[:, 300:350] = pc[:, :50]  # duplicates -> FPS / kNN ties
+    xyz = T(pc)
+    fps_idx = furthest_point_sample(xyz, 128)
+    new_xyz = torch.gather(xyz, 1, fps_idx.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+    dist, idx = knn(16, new_xyz, xyz)
+    d3, i3 = three_nn(xyz, new_xyz)
+    bq = ball_query(6.0, 24, xyz, new_xyz)
+    feats = T(detgen.uniform((2, 7, 700), 12)).requires_grad_(True)
+    qg = QueryAndGroup(radius=5.0, nsample=16)
+    new_features, grouped_xyz = qg(xyz, new_xyz, feats)
+    g_feats = torch.autograd.grad(new_features, feats, T(detgen.uniform(tuple(new_features.shape), 13)))[0]
+    w = torch.rand(2, 700, 3, generator=torch.Generator().manual_seed(1))
+    f128 = T(detgen.uniform((2, 7, 128), 14)).requires_grad_(True)
+    interp = three_interpolate(f128, i3, w)
+    g_interp = torch.autograd.grad(interp, f128, T(detgen.uniform(tuple(interp.shape), 15)))[0]
+    gathered = gather_operation(feats, fps_idx)
+    g_gather = torch.autograd.grad(gathered, feats, T(detgen.uniform(tuple(gathered.shape), 16)))[0]
+    grouped = grouping_operation(feats, bq)
+    save("operator_layer", fps_idx=fps_idx, knn_dist=dist, knn_idx=idx, nn3_dist=d3, nn3_idx=i3, ball_idx=bq,
+         qg_features=new_features.detach(), qg_xyz=grouped_xyz, qg_grad=g_feats, interp_w=w, interp=interp.detach(),
+         interp_grad=g_interp, gathered=gathered.detach(), gather_grad=g_gather, grouped_ball=grouped.detach())
+
+
+def gen_modules():
+    from utils.flowstep3d_util import FlowEmbedding, PointNetFeaturePropogation, PointNetSetAbstraction
+    from utils.pointnet2_util import PointnetFPModule, PointnetSAModuleMSG
+    bn = {"class": "GroupNorm", "num_groups": 4}
+    pc = T(detgen.cloud(2, 512, 21, scale=(1, 1, 1)))
+    feats = T(detgen.uniform((2, 3, 512), 22))
+    sa = detgen.fill_module(PointnetSAModuleMSG(npoint=128, radii=[0.2, 0.4], nsamples=[16, 32],
+                                                mlps=[[3, 16, 16], [3, 16, 32]], bn=bn), 1)
+    new_xyz, new_feats, inds = sa(pc, feats, return_inds=True)
+    fp = detgen.fill_module(PointnetFPModule(mlp=[48 + 3, 32, 16], bn=bn), 2)
+    up = fp(pc, new_xyz, feats, new_feats)
+    out = dict(sa_xyz=new_xyz, sa_feats=new_feats.detach(), sa_inds=inds, fp_out=up.detach())
+    out.update({"sa_" + k: v for k, v in grads_summary(sa, (new_feats ** 2).mean()).items()})
+
+    # FlowStep3D flavour (BatchNorm in train mode => batch statistics)
+    xyz_t = pc.transpose(1, 2).contiguous()
+    f3 = detgen.fill_module(PointNetSetAbstraction(npoint=128, radius=None, nsample=8, in_channel=3, mlp=[16, 32],
+                                                   group_all=False, return_fps=True), 3)
+    nx, nf, fidx = f3(xyz_t, feats)
+    f3b = detgen.fill_module(PointNetSetAbstraction(npoint=128, radius=0.3, nsample=8, in_channel=32, mlp=[16],
+                                                    group_all=False, use_act=False, mean_aggr=True), 4)
+    nx2, nf2 = f3b(nx, nf)  # npoint == N: FPS returns a permutation
+    fpf = detgen.fill_module(PointNetFeaturePropogation(in_channel=32 + 3, mlp=[16]), 5)
+    upf = fpf(xyz_t, nx, feats, nf)
+    pc_b = T(detgen.cloud(2, 128, 23, scale=(1, 1, 1))).transpose(1, 2).contiguous()
+    fb = T(detgen.uniform((2, 32, 128), 24))
+    fe = detgen.fill_module(FlowEmbedding(radius=0.5, nsample=8, in_channel=32, mlp=[32, 32]), 6)
+    _, corr = fe(nx, pc_b, nf, fb)
+    out.update(f3_xyz=nx, f3_feats=nf.detach(), f3_fps=fidx, f3b_feats=nf2.detach(), fpf_out=upf.detach(),
+               fe_out=corr.detach())
+    out.update({"fe_" + k: v for k, v in grads_summary(fe, (corr ** 2).mean()).items()})
+    save("modules", **out)
+
+
+def gen_losses():
+    from losses.flow_loss_unsup import ChamferLoss, UnsupervisedFlowStep3DLoss
+    from losses.flow_loss_unsup import SmoothLoss as FlowSmoothLoss
+    from losses.seg_loss_unsup import (DynamicLoss, EntropyLoss, InvarianceLoss, RankLoss, SmoothLoss,
+                                       UnsupervisedOGCLoss, fit_motion_svd_batch, interpolate_mask_by_flow,
+                                       match_mask_by_iou)
+    from oa_icp import object_aware_icp, weighted_kabsch
+    B, N, K = 2, 512, 6
+    scenes = [detgen.rigid_scene(B, N, K, 31 + 10 * v) for v in range(4)]
+    pcs = [T(s[0]) for s in scenes]
+    flows = [T(s[1]) for s in scenes]
+    masks = [T(s[2]).requires_grad_(True) for s in scenes]
+    out = {}
+    for v in range(4):
+        out["pc%d" % v], out["flow%d" % v], out["mask%d" % v] = scenes[v]
+
+    R, t = fit_motion_svd_batch(pcs[0], pcs[0] + flows[0], masks[0][..., 0].detach())
+    out["svd_R"], out["svd_t"] = R, t
+    R, t = fit_motion_svd_batch(pcs[0], pcs[0] + flows[0], None)
+    out["svd_R_nomask"], out["svd_t_nomask"] = R, t
+    zero_mask = masks[0][..., 0].detach().clone()
+    zero_mask[1] = 0.0  # ill-posed item -> identity (seg_loss_unsup.py:38-42)
+    R, t = fit_motion_svd_batch(pcs[0], pcs[0] + flows[0], zero_mask)
+    out["svd_R_zero"], out["svd_t_zero"] = R, t
+
+    smooth_params = {'w_knn': 3., 'w_ball_q': 1.,
+                     'knn_loss_params': {'k': 8, 'radius': 0.1, 'cross_entropy': False, 'loss_norm': 1},
+                     'ball_q_loss_params': {'k': 16, 'radius': 0.2, 'cross_entropy': False, 'loss_norm': 1}}
+    dyn, smooth, inv = DynamicLoss(loss_norm=2), SmoothLoss(**smooth_params), InvarianceLoss(loss_norm=2)
+    ent, rank = EntropyLoss(), RankLoss()
+    crit = UnsupervisedOGCLoss(dyn, smooth, inv, ent, rank, weights=[10.0, 0.1, 0.1], start_steps=[0, 100, 0])
+
+    for tag, aug, step_w, it in [("2v", False, False, 0), ("4v", True, True, 50)]:
+        nv = 4 if aug else 2
+        loss, ld = crit(pcs[:nv], masks[:nv], flows[:nv], step_w=step_w, it=it, aug_transform=aug)
+        gs = torch.autograd.grad(loss, masks[:nv])
+        out["ogc_%s_loss" % tag] = loss.detach()
+        out["ogc_%s_dict" % tag] = np.array([ld[k] for k in ('dynamic', 'smooth', 'invariance', 'entropy', 'rank', 'sum')],
+                                            np.float64)
+        for v in range(nv):
+            out["ogc_%s_gmask%d" % (tag, v)] = gs[v]
+    out["dyn"] = dyn(pcs[0], masks[0], flows[0]).detach()
+    out["smooth_knn"] = smooth.knn_loss(pcs[0], masks[0]).detach()
+    out["smooth_ball"] = smooth.ball_q_loss(pcs[0], masks[0]).detach()
+    ce = SmoothLoss(3., 1., {'k': 8, 'radius': 0.1, 'cross_entropy': True}, {'k': 16, 'radius': 0.2, 'cross_entropy': True})
+    out["smooth_ce"] = ce(pcs[0], masks[0]).detach()
+    out["interp_mask_k1"] = interpolate_mask_by_flow(pcs[0], pcs[1], masks[0].detach(), flows[0], k=1)
+    out["interp_mask_k3"] = interpolate_mask_by_flow(pcs[0], pcs[1], masks[0].detach(), flows[0], k=3)
+    out["perm"] = match_mask_by_iou(masks[0].detach(), masks[2].detach())
+    out["inv"] = inv(masks[0], masks[2]).detach()
+    out["entropy"], out["rank"] = ent(masks[0]).detach(), rank(masks[0]).detach()
+
+    # flow losses
+    fcrit = UnsupervisedFlowStep3DLoss(ChamferLoss(loss_norm=2),
+                                       FlowSmoothLoss(3., 1., {'k': 4, 'radius': 0.05, 'loss_norm': 1},
+                                                      {'k': 8, 'radius': 0.1, 'loss_norm': 1}),
+                                       weights=[0.75, 0.25], iters_w=[0.5, 1.0])
+    fp = [flows[0].clone().requires_grad_(True), (flows[0] * 0.9).clone().requires_grad_(True)]
+    pc2 = (pcs[0] + flows[0])[:, torch.randperm(N, generator=torch.Generator().manual_seed(3))].contiguous()
+    out["flow_pc2"] = pc2
+    floss, fd = fcrit(pcs[0], pc2, fp)
+    g = torch.autograd.grad(floss, fp)
+    out["flow_loss"] = floss.detach()
+    out["flow_dict"] = np.array([fd[k] for k in sorted(fd)], np.float64)
+    out["flow_g0"], out["flow_g1"] = g
+
+    # OA-ICP
+    out["kabsch_flow"] = weighted_kabsch(pcs[0], flows[0], masks[0].detach())
+    noisy = flows[0] + T(detgen.uniform((B, N, 3), 99, -0.01, 0.01))
+    out["icp_noisy_flow"] = noisy
+    out["icp_flow"] = object_aware_icp(pcs[0], pc2, noisy, masks[0].detach(), masks[0].detach()[:, :, [1, 0, 2, 3, 4, 5]],
+                                       icp_iter=3, temperature=0.01)
+    save("losses", **{k: (v.detach().numpy() if torch.is_tensor(v) else v) for k, v in out.items()})
+
+
+def gen_models():
+    import importlib
+    for name, kw, N, B in [("segnet_sapien", dict(n_slot=8, n_point=512, transformer_embed_dim=128), 512, 2),
+                           ("segnet_ogcdr", dict(n_slot=8, n_point=512, transformer_embed_dim=128), 512, 2),
+                           ("segnet_kitti", dict(n_slot=10, n_point=1024, transformer_embed_dim=128), 1024, 2)]:
+        mod = importlib.import_module("models." + name)
+        torch.manual_seed(10)
+        net = detgen.fill_module(mod.MaskFormer3D(**kw), 7)
+        scale = (60, 4, 80) if name == "segnet_kitti" else (1, 1, 1)
+        pc = T(detgen.cloud(B, N, 41, scale=scale))
+        mask = net(pc, pc)
+        target = T(detgen.uniform(tuple(mask.shape), 42, 0.0, 1.0))
+        out = dict(mask=mask.detach())
+        out.update(grads_summary(net, ((mask - target) ** 2).mean()))
+        out["n_state"] = np.array([len(net.state_dict())])
+        out["state_keys"] = np.array(sorted(net.state_dict().keys()))
+        save("model_" + name, **out)
+
+    for name, kw, N, iters in [("flownet_sapien", dict(npoint=512, loc_flow_nn=8, loc_flow_rad=0.3), 512, 3),
+                               ("flownet_ogcdr", dict(npoint=512, loc_flow_nn=8, loc_flow_rad=0.3), 512, 2),
+                               ("flownet_kitti", dict(npoint=1024, loc_flow_nn=16, loc_flow_rad=1.5), 1024, 2)]:
+        mod = importlib.import_module("models." + name)
+        net = detgen.fill_module(mod.FlowStep3D(**kw), 8)
+        net.eval()  # BatchNorm with the (deterministic) running statistics, as in test_flow_*.py
+        scale = (60, 4, 80) if name == "flownet_kitti" else (1, 1, 1)
+        pc1 = T(detgen.cloud(2, N, 51, scale=scale))
+        pc2 = pc1 + T(detgen.uniform((2, N, 3), 52, -0.05, 0.05))
+        pc2 = pc2[:, torch.randperm(N, generator=torch.Generator().manual_seed(5))].contiguous()
+        preds = net(pc1, pc2, pc1, pc2, iters=iters)
+        out = {"flow%d" % i: p.detach() for i, p in enumerate(preds)}
+        out["pc2"] = pc2
+        out.update(grads_summary(net, sum((p ** 2).mean() for p in preds)))
+        out["state_keys"] = np.array(sorted(net.state_dict().keys()))
+        save("model_" + name, **out)
+
+
+if __name__ == "__main__":
+    assert os.path.isdir(REF), "the reference tree is only present in the build container"
+    install_shims()
+    orc.build()
+    which = sys.argv[1:] or ["ops", "modules", "losses", "models"]
+    with torch.no_grad():
+        pass
+    if "ops" in which:
+        gen_operator_layer()
+    if "modules" in which:
+        gen_modules()
+    if "losses" in which:
+        gen_losses()
+    if "models" in which:
+        gen_models()

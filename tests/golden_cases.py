@@ -1,0 +1,242 @@
+"""Re-runs the scenarios of tests/golden/make_golden.py with THIS repo's host-side layers (ogc_amd.*) on a given
+device and compares with the committed outputs of the reference's Python.  Shared by the CPU tests (operators =
+the oracle, injected as ogc_amd.pointnet2.pointnet2._native) and the GPU tests (operators = HIP kernels)."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import detgen  # noqa: E402
+
+GOLD = os.path.join(HERE, "golden")
+
+
+def load(name):
+    return dict(np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=False))
+
+
+def close(got, want, rtol, atol, what):
+    got = got.detach().cpu().numpy() if torch.is_tensor(got) else np.asarray(got)
+    want = np.asarray(want)
+    assert got.shape == want.shape, "%s: shape %s vs %s" % (what, got.shape, want.shape)
+    if not np.allclose(got, want, rtol=rtol, atol=atol, equal_nan=True):
+        err = np.abs(got.astype(np.float64) - want.astype(np.float64))
+        rel = err / (np.abs(want).astype(np.float64) + atol)
+        raise AssertionError("%s: max abs err %.3e, max rel err %.3e (rtol %.1e atol %.1e)" %
+                             (what, err.max(), rel.max(), rtol, atol))
+
+
+def close_scaled(got, want, rel, what):
+    """|got - want| <= rel * max|want| — for gradients of ill-conditioned terms (unit-direction vectors of tiny
+    residuals amplify 1e-7 coordinate differences), where an element-wise relative test is meaningless."""
+    want = np.asarray(want)
+    close(got, want, 0.0, rel * float(np.abs(want).max()), what)
+
+
+def exact(got, want, what):
+    got = got.detach().cpu().numpy() if torch.is_tensor(got) else np.asarray(got)
+    assert np.array_equal(got, np.asarray(want)), "%s: integer/bit mismatch" % what
+
+
+def check_grads(module, loss, gold, prefix, rtol, atol):
+    module.zero_grad()
+    loss.backward()
+    for name, p in module.named_parameters():
+        g = p.grad if p.grad is not None else torch.zeros_like(p)
+        want_norm = gold[prefix + "gnorm/" + name]
+        close(g.norm().reshape(1), want_norm, rtol, atol * 10, prefix + "gnorm/" + name)
+        scale = float(want_norm[0]) / max(np.sqrt(p.numel()), 1.0)
+        close(g.flatten()[:32], gold[prefix + "ghead/" + name], rtol, atol + 10 * rtol * scale,
+              prefix + "ghead/" + name)
+
+
+def run_operator_layer(dev, rtol=1e-6, atol=1e-7):
+    from ogc_amd.pointnet2.pointnet2 import (QueryAndGroup, ball_query, furthest_point_sample, gather_operation,
+                                             grouping_operation, knn, three_interpolate, three_nn)
+    g = load("operator_layer")
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    pc = detgen.cloud(2, 700, 11)
+    pc[:, 300:350] = pc[:, :50]
+    xyz = T(pc)
+    fps_idx = furthest_point_sample(xyz, 128)
+    exact(fps_idx, g["fps_idx"], "fps_idx")
+    new_xyz = torch.gather(xyz, 1, fps_idx.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+    dist, idx = knn(16, new_xyz, xyz)
+    exact(idx, g["knn_idx"], "knn_idx")
+    close(dist, g["knn_dist"], 1e-6, 0, "knn_dist")
+    d3, i3 = three_nn(xyz, new_xyz)
+    exact(i3, g["nn3_idx"], "nn3_idx")
+    close(d3, g["nn3_dist"], 1e-6, 0, "nn3_dist")
+    bq = ball_query(6.0, 24, xyz, new_xyz)
+    exact(bq, g["ball_idx"], "ball_idx")
+    feats = T(detgen.uniform((2, 7, 700), 12)).requires_grad_(True)
+    nf, gx = QueryAndGroup(radius=5.0, nsample=16)(xyz, new_xyz, feats)
+    exact(nf, g["qg_features"], "qg_features")
+    exact(gx, g["qg_xyz"], "qg_xyz")
+    gg = torch.autograd.grad(nf, feats, T(detgen.uniform(tuple(nf.shape), 13)))[0]
+    close(gg, g["qg_grad"], 1e-5, 1e-5, "qg_grad")
+    w = T(g["interp_w"])
+    f128 = T(detgen.uniform((2, 7, 128), 14)).requires_grad_(True)
+    interp = three_interpolate(f128, i3, w)
+    exact(interp, g["interp"], "interp")
+    gi = torch.autograd.grad(interp, f128, T(detgen.uniform(tuple(interp.shape), 15)))[0]
+    close(gi, g["interp_grad"], 1e-5, 1e-5, "interp_grad")
+    gathered = gather_operation(feats, fps_idx)
+    exact(gathered, g["gathered"], "gathered")
+    g2 = torch.autograd.grad(gathered, feats, T(detgen.uniform(tuple(gathered.shape), 16)))[0]
+    close(g2, g["gather_grad"], 1e-5, 1e-5, "gather_grad")
+    exact(grouping_operation(feats, bq), g["grouped_ball"], "grouped_ball")
+
+
+def run_modules(dev, rtol=1e-5, atol=1e-6):
+    from ogc_amd.utils.flowstep3d_util import FlowEmbedding, PointNetFeaturePropogation, PointNetSetAbstraction
+    from ogc_amd.utils.pointnet2_util import PointnetFPModule, PointnetSAModuleMSG
+    g = load("modules")
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    bn = {"class": "GroupNorm", "num_groups": 4}
+    pc = T(detgen.cloud(2, 512, 21, scale=(1, 1, 1)))
+    feats = T(detgen.uniform((2, 3, 512), 22))
+    sa = detgen.fill_module(PointnetSAModuleMSG(npoint=128, radii=[0.2, 0.4], nsamples=[16, 32],
+                                                mlps=[[3, 16, 16], [3, 16, 32]], bn=bn), 1).to(dev)
+    new_xyz, new_feats, inds = sa(pc, feats, return_inds=True)
+    exact(inds, g["sa_inds"], "sa_inds")
+    exact(new_xyz, g["sa_xyz"], "sa_xyz")
+    close(new_feats, g["sa_feats"], rtol, atol, "sa_feats")
+    fp = detgen.fill_module(PointnetFPModule(mlp=[48 + 3, 32, 16], bn=bn), 2).to(dev)
+    close(fp(pc, new_xyz, feats, new_feats), g["fp_out"], rtol, atol, "fp_out")
+    check_grads(sa, (new_feats ** 2).mean(), g, "sa_", 1e-4, 1e-7)
+
+    xyz_t = pc.transpose(1, 2).contiguous()
+    f3 = detgen.fill_module(PointNetSetAbstraction(npoint=128, radius=None, nsample=8, in_channel=3, mlp=[16, 32],
+                                                   group_all=False, return_fps=True), 3).to(dev)
+    nx, nf, fidx = f3(xyz_t, feats)
+    exact(fidx, g["f3_fps"], "f3_fps")
+    exact(nx, g["f3_xyz"], "f3_xyz")
+    close(nf, g["f3_feats"], rtol, atol, "f3_feats")
+    f3b = detgen.fill_module(PointNetSetAbstraction(npoint=128, radius=0.3, nsample=8, in_channel=32, mlp=[16],
+                                                    group_all=False, use_act=False, mean_aggr=True), 4).to(dev)
+    close(f3b(nx, nf)[1], g["f3b_feats"], rtol, atol, "f3b_feats")
+    fpf = detgen.fill_module(PointNetFeaturePropogation(in_channel=32 + 3, mlp=[16]), 5).to(dev)
+    close(fpf(xyz_t, nx, feats, nf), g["fpf_out"], rtol, atol, "fpf_out")
+    pc_b = T(detgen.cloud(2, 128, 23, scale=(1, 1, 1))).transpose(1, 2).contiguous()
+    fb = T(detgen.uniform((2, 32, 128), 24))
+    fe = detgen.fill_module(FlowEmbedding(radius=0.5, nsample=8, in_channel=32, mlp=[32, 32]), 6).to(dev)
+    _, corr = fe(nx, pc_b, nf.detach(), fb)
+    close(corr, g["fe_out"], rtol, atol, "fe_out")
+    check_grads(fe, (corr ** 2).mean(), g, "fe_", 1e-4, 1e-7)
+
+
+def run_losses(dev, rtol=1e-5, atol=1e-6, grad_rel=5e-3):
+    from ogc_amd.losses.flow_loss_unsup import ChamferLoss, UnsupervisedFlowStep3DLoss
+    from ogc_amd.losses.flow_loss_unsup import SmoothLoss as FlowSmoothLoss
+    from ogc_amd.losses.seg_loss_unsup import (DynamicLoss, EntropyLoss, InvarianceLoss, RankLoss, SmoothLoss,
+                                               UnsupervisedOGCLoss, fit_motion_svd_batch, interpolate_mask_by_flow,
+                                               match_mask_by_iou)
+    from ogc_amd.oa_icp import object_aware_icp, weighted_kabsch
+    g = load("losses")
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    B, N, K = 2, 512, 6
+    pcs = [T(g["pc%d" % v]) for v in range(4)]
+    flows = [T(g["flow%d" % v]) for v in range(4)]
+    masks = [T(g["mask%d" % v]).requires_grad_(True) for v in range(4)]
+
+    R, t = fit_motion_svd_batch(pcs[0], pcs[0] + flows[0], masks[0][..., 0].detach())
+    close(R, g["svd_R"], rtol, 1e-5, "svd_R")
+    close(t, g["svd_t"], rtol, 1e-5, "svd_t")
+    R, t = fit_motion_svd_batch(pcs[0], pcs[0] + flows[0], None)
+    close(R, g["svd_R_nomask"], rtol, 1e-5, "svd_R_nomask")
+    close(t, g["svd_t_nomask"], rtol, 1e-5, "svd_t_nomask")
+    zero_mask = masks[0][..., 0].detach().clone()
+    zero_mask[1] = 0.0
+    R, t = fit_motion_svd_batch(pcs[0], pcs[0] + flows[0], zero_mask)
+    close(R, g["svd_R_zero"], rtol, 1e-5, "svd_R_zero")
+    close(t, g["svd_t_zero"], rtol, 1e-5, "svd_t_zero")
+
+    smooth_params = {'w_knn': 3., 'w_ball_q': 1.,
+                     'knn_loss_params': {'k': 8, 'radius': 0.1, 'cross_entropy': False, 'loss_norm': 1},
+                     'ball_q_loss_params': {'k': 16, 'radius': 0.2, 'cross_entropy': False, 'loss_norm': 1}}
+    dyn, smooth, inv = DynamicLoss(loss_norm=2), SmoothLoss(**smooth_params), InvarianceLoss(loss_norm=2)
+    ent, rank = EntropyLoss(), RankLoss()
+    crit = UnsupervisedOGCLoss(dyn, smooth, inv, ent, rank, weights=[10.0, 0.1, 0.1], start_steps=[0, 100, 0])
+    keys = ('dynamic', 'smooth', 'invariance', 'entropy', 'rank', 'sum')
+    for tag, aug, step_w, it in [("2v", False, False, 0), ("4v", True, True, 50)]:
+        nv = 4 if aug else 2
+        loss, ld = crit(pcs[:nv], masks[:nv], flows[:nv], step_w=step_w, it=it, aug_transform=aug)
+        assert tuple(ld.keys()) == keys
+        gs = torch.autograd.grad(loss, masks[:nv])
+        close(loss, g["ogc_%s_loss" % tag], rtol, atol, "ogc_%s_loss" % tag)
+        close(np.array([ld[k] for k in keys]), g["ogc_%s_dict" % tag], rtol, atol, "ogc_%s_dict" % tag)
+        for v in range(nv):
+            close_scaled(gs[v], g["ogc_%s_gmask%d" % (tag, v)], grad_rel, "ogc_%s_gmask%d" % (tag, v))
+    close(dyn(pcs[0], masks[0], flows[0]), g["dyn"], rtol, atol, "dyn")
+    close(smooth.knn_loss(pcs[0], masks[0]), g["smooth_knn"], rtol, atol, "smooth_knn")
+    close(smooth.ball_q_loss(pcs[0], masks[0]), g["smooth_ball"], rtol, atol, "smooth_ball")
+    ce = SmoothLoss(3., 1., {'k': 8, 'radius': 0.1, 'cross_entropy': True}, {'k': 16, 'radius': 0.2, 'cross_entropy': True})
+    close(ce(pcs[0], masks[0]), g["smooth_ce"], rtol, atol, "smooth_ce")
+    close(interpolate_mask_by_flow(pcs[0], pcs[1], masks[0].detach(), flows[0], k=1), g["interp_mask_k1"], rtol, atol, "interp_mask_k1")
+    close(interpolate_mask_by_flow(pcs[0], pcs[1], masks[0].detach(), flows[0], k=3), g["interp_mask_k3"], rtol, atol, "interp_mask_k3")
+    exact(match_mask_by_iou(masks[0].detach(), masks[2].detach()), g["perm"], "perm")
+    close(inv(masks[0], masks[2]), g["inv"], rtol, atol, "inv")
+    close(ent(masks[0]), g["entropy"], rtol, atol, "entropy")
+    close(rank(masks[0]), g["rank"], rtol, atol, "rank")
+
+    fcrit = UnsupervisedFlowStep3DLoss(ChamferLoss(loss_norm=2),
+                                       FlowSmoothLoss(3., 1., {'k': 4, 'radius': 0.05, 'loss_norm': 1},
+                                                      {'k': 8, 'radius': 0.1, 'loss_norm': 1}),
+                                       weights=[0.75, 0.25], iters_w=[0.5, 1.0])
+    fp = [flows[0].clone().requires_grad_(True), (flows[0] * 0.9).clone().requires_grad_(True)]
+    pc2 = T(g["flow_pc2"])
+    floss, fd = fcrit(pcs[0], pc2, fp)
+    gr = torch.autograd.grad(floss, fp)
+    close(floss, g["flow_loss"], rtol, atol, "flow_loss")
+    close(np.array([fd[k] for k in sorted(fd)]), g["flow_dict"], rtol, atol, "flow_dict")
+    close_scaled(gr[0], g["flow_g0"], grad_rel, "flow_g0")
+    close_scaled(gr[1], g["flow_g1"], grad_rel, "flow_g1")
+
+    close(weighted_kabsch(pcs[0], flows[0], masks[0].detach()), g["kabsch_flow"], rtol, 1e-5, "kabsch_flow")
+    icp = object_aware_icp(pcs[0], pc2, T(g["icp_noisy_flow"]), masks[0].detach(),
+                           masks[0].detach()[:, :, [1, 0, 2, 3, 4, 5]], icp_iter=3, temperature=0.01)
+    close(icp, g["icp_flow"], 1e-4, 1e-5, "icp_flow")
+
+
+SEG_CASES = [("segnet_sapien", dict(n_slot=8, n_point=512, transformer_embed_dim=128), 512, 2),
+             ("segnet_ogcdr", dict(n_slot=8, n_point=512, transformer_embed_dim=128), 512, 2),
+             ("segnet_kitti", dict(n_slot=10, n_point=1024, transformer_embed_dim=128), 1024, 2)]
+FLOW_CASES = [("flownet_sapien", dict(npoint=512, loc_flow_nn=8, loc_flow_rad=0.3), 512, 3),
+              ("flownet_ogcdr", dict(npoint=512, loc_flow_nn=8, loc_flow_rad=0.3), 512, 2),
+              ("flownet_kitti", dict(npoint=1024, loc_flow_nn=16, loc_flow_rad=1.5), 1024, 2)]
+
+
+def run_segnet(dev, name, kw, N, B, rtol=1e-4, atol=1e-6, grad_rtol=1e-3):
+    g = load("model_" + name)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    mod = importlib.import_module("ogc_amd.models." + name)
+    net = detgen.fill_module(mod.MaskFormer3D(**kw), 7).to(dev)
+    assert sorted(net.state_dict().keys()) == [str(k) for k in g["state_keys"]], "state_dict keys differ from the reference"
+    scale = (60, 4, 80) if name == "segnet_kitti" else (1, 1, 1)
+    pc = T(detgen.cloud(B, N, 41, scale=scale))
+    mask = net(pc, pc)
+    close(mask, g["mask"], rtol, atol, name + ".mask")
+    target = T(detgen.uniform(tuple(mask.shape), 42, 0.0, 1.0))
+    check_grads(net, ((mask - target) ** 2).mean(), g, "", grad_rtol, 1e-8)
+
+
+def run_flownet(dev, name, kw, N, iters, rtol=1e-4, atol=1e-5, grad_rtol=2e-3):
+    g = load("model_" + name)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    mod = importlib.import_module("ogc_amd.models." + name)
+    net = detgen.fill_module(mod.FlowStep3D(**kw), 8).to(dev)
+    net.eval()
+    assert sorted(net.state_dict().keys()) == [str(k) for k in g["state_keys"]], "state_dict keys differ from the reference"
+    scale = (60, 4, 80) if name == "flownet_kitti" else (1, 1, 1)
+    pc1 = T(detgen.cloud(2, N, 51, scale=scale))
+    pc2 = T(g["pc2"])
+    preds = net(pc1, pc2, pc1, pc2, iters=iters)
+    assert len(preds) == iters
+    for i, p in enumerate(preds):
+        close(p, g["flow%d" % i], rtol, atol, "%s.flow%d" % (name, i))
+    check_grads(net, sum((p ** 2).mean() for p in preds), g, "", grad_rtol, 1e-8)
