@@ -1,0 +1,169 @@
+"""Headline benchmark: unsupervised OGC segmentation training throughput on 8192-point KITTI-SF-shaped scenes.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = `Trainer._train_it` of the reference (train_seg.py:47-86) on config C4 (SURVEY.md §8,
+config/seg/kittisf/kittisf_unsup.yaml): per GPU 4 samples x 4 views (2 frames + 2 augmented) of 8192 points,
+MaskFormer3D(segnet_kitti) forward on 16 clouds, UnsupervisedOGCLoss with all three terms active, backward,
+NaN-gradient check, Adam step.  Inputs are synthetic, seeded and already resident in HBM.  Weak scaling: every
+rank has its own batch; gradients are averaged by DDP over RCCL (one ~2.4 MB bucket).
+
+Rank 0 prints ONE JSON line: value = whole-job point-clouds/s.  `roofline` is measured live (HIP events on the
+launch stream, inside the timed steps) for the ball-query kernel, the kernel BASELINE.json's metric names;
+`cpu_baseline` is the same step on the host cores with the CPU oracle's operators, on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak (MI355X_MICROARCH.md)
+FP32_VALU_PEAK_TF = 157.3  # fp32 vector peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4, help="samples per GPU (config batch_size: 4)")
+    ap.add_argument("--npoint", type=int, default=8192)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(npoint):
+    """The same train step on the host with the CPU oracle's operators ("port"), 1 sample x 4 views."""
+    import ogc_amd.pointnet2.pointnet2 as api
+    from oracle import oracle as orc
+    from ogc_amd.models.segnet_kitti import MaskFormer3D
+    from ogc_amd.train_step import KITTI_LOSS, build_criterion, train_step
+    from ogc_amd.utils.synthetic import make_scene_batch
+    orc.build()
+    saved = api._native
+    api._native = orc.Pointnet2CudaCPU()
+    try:
+        torch.manual_seed(10)
+        net = MaskFormer3D(n_slot=10, n_point=npoint, transformer_embed_dim=128)
+        crit = build_criterion(KITTI_LOSS)
+        opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+        batch = make_scene_batch(1, npoint, 10, seed=1234, aug=True)
+        t0 = time.time()
+        train_step(net, crit, opt, batch, 1000, True)
+        dt = time.time() - t0
+    finally:
+        api._native = saved
+    cores = min(torch.get_num_threads(), os.cpu_count() or 1)
+    return {"value": round(4 / dt, 4), "unit": "point-clouds/s", "cores": cores, "kind": "port",
+            "sample": "1 train step, 1 sample x 4 views (4 clouds) of %d pts: torch-CPU layers + oracle operators "
+                      "(OpenMP), %.1f s" % (npoint, dt)}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == a.gpus, "--gpus %d but WORLD_SIZE=%d" % (a.gpus, world)
+
+    import ogc_amd  # noqa: F401  (fails loudly if libogc_ops.so is missing)
+    from ogc_amd import pointnet2_cuda as nat
+    from ogc_amd.models.segnet_kitti import MaskFormer3D
+    from ogc_amd.train_step import KITTI_LOSS, build_criterion, train_step
+    from ogc_amd.utils.synthetic import make_scene_batch
+
+    torch.manual_seed(10)  # random_seed: 10 in the reference YAMLs; identical init on every rank
+    net = MaskFormer3D(n_slot=10, n_point=a.npoint, use_xyz=True, n_transformer_layer=2,
+                       transformer_embed_dim=128, transformer_input_pos_enc=False).to(dev)
+    model = net
+    if world > 1:
+        model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[local], bucket_cap_mb=25,
+                                                          gradient_as_bucket_view=True)
+    crit = build_criterion(KITTI_LOSS)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, weight_decay=0.0)
+    batch = make_scene_batch(a.batch, a.npoint, 10, seed=1234 + rank, outdoor=True, aug=True, device=dev)
+    clouds_per_step = a.batch * 4
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    it = 1000  # it*b >= every start_step -> dynamic + smooth + invariance all active
+    for _ in range(a.warmup):
+        train_step(model, crit, opt, batch, it, True)
+    sync()
+    with nat.LaunchTimer({"ogc_ball_query", "ogc_knn_clamped", "ogc_furthest_point_sampling"}) as timer:
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            loss_dict, stepped = train_step(model, crit, opt, batch, it, True)
+        sync()
+        elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        durs = timer.durations_ms()
+        bq = durs.get("ogc_ball_query", [])
+        roof = None
+        if bq:
+            ms = sum(d for d, _ in bq) / len(bq)
+            b_, n_, m_, _r, ns_ = bq[0][1][:5]
+            alg = b_ * (12 * m_ + 12 * n_ + 4 * m_ * ns_)            # 12M + 12N + 4M*nsample per cloud
+            gbs = alg / (ms * 1e-3) / 1e9
+            flop = 8.0 * b_ * n_ * m_
+            roof = {"kernel": "ball_query_kernel", "bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": None,
+                    "launches": len(bq), "avg_ms": round(ms, 4), "algorithmic_bytes": alg,
+                    "shape": {"B": b_, "N": n_, "M": m_, "nsample": ns_},
+                    "valu": {"achieved_tflops": round(flop / (ms * 1e-3) / 1e12, 3), "peak_tflops": FP32_VALU_PEAK_TF,
+                             "frac": round(flop / (ms * 1e-3) / 1e12 / FP32_VALU_PEAK_TF, 4),
+                             "note": "all-pairs scan is ~230 flop/B: VALU-bound, not HBM-bound (SURVEY §8d)"}}
+        others = {}
+        for name in ("ogc_knn_clamped", "ogc_furthest_point_sampling"):
+            if name in durs:
+                per = {}
+                for d, dims in durs[name]:
+                    per.setdefault(str(dims[:4]), []).append(d)
+                others[name] = {k: round(sum(v) / len(v), 4) for k, v in per.items()}
+        out = {
+            "metric": "point-clouds/sec (8192 pts) segnet fwd+bwd",
+            "value": round(clouds_per_step * a.steps * world / elapsed, 3),
+            "unit": "point-clouds/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(elapsed / a.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C4 KITTI-SF train_seg unsup: segnet_kitti fwd + OGC loss (dynamic+smooth+invariance) "
+                                   "+ bwd + Adam, %d samples x 4 views x %d pts per GPU" % (a.batch, a.npoint),
+                       "clouds_per_step_per_gpu": clouds_per_step, "n_point": a.npoint, "n_slot": 10,
+                       "parallelism": "dp%d" % world, "optimizer_stepped": bool(stepped),
+                       "loss": {k: round(v, 5) for k, v in loss_dict.items()}},
+            "roofline": roof,
+            "kernel_ms": others,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.npoint)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

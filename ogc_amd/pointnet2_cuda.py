@@ -41,11 +41,46 @@ def _stream(t):
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
+class LaunchTimer:
+    """Optional per-launch timing with HIP events recorded on the launch stream (bench.py's roofline leg).
+    ``with LaunchTimer({"ogc_ball_query"}) as t: ...; t.durations_ms()`` -> {name: [ms, ...]}."""
+
+    def __init__(self, names):
+        self.names = set(names)
+        self.records = []
+
+    def __enter__(self):
+        global _timer
+        _timer = self
+        return self
+
+    def __exit__(self, *exc):
+        global _timer
+        _timer = None
+
+    def durations_ms(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, e0, e1, dims in self.records:
+            out.setdefault(name, []).append((e0.elapsed_time(e1), dims))
+        return out
+
+
+_timer = None
+
+
 def _run(name, ref_tensor, *args):
     # kernels must be launched with the tensor's device current (multi-GPU processes)
     if torch.cuda.current_device() != ref_tensor.device.index:
         with torch.cuda.device(ref_tensor.device):
-            return _lib.call(name, *args, _stream(ref_tensor))
+            return _run(name, ref_tensor, *args)
+    if _timer is not None and name in _timer.names:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = _lib.call(name, *args, _stream(ref_tensor))
+        e1.record()
+        _timer.records.append((name, e0, e1, tuple(a for a in args if isinstance(a, (int, float)))))
+        return rc
     return _lib.call(name, *args, _stream(ref_tensor))
 
 

@@ -1,0 +1,51 @@
+"""One optimisation step of unsupervised OGC segmentation training — the body of the reference's
+``Trainer._train_it`` (train_seg.py:47-86) — factored out so that the benchmark, the smoke test and the
+training driver share it.  Semantics kept: views are flattened into the batch for the network, the loss is
+called with ``step_w=True, it=it*b``, and the optimiser step is skipped when any gradient contains NaN
+(train_seg.py:81-83; here one fused check and one host sync instead of one per parameter)."""
+import torch
+
+from .losses.seg_loss_unsup import (DynamicLoss, EntropyLoss, InvarianceLoss, RankLoss, SmoothLoss,
+                                    UnsupervisedOGCLoss)
+
+KITTI_LOSS = dict(  # config/seg/kittisf/kittisf_unsup.yaml:40-56
+    weights=[10.0, 0.1, 0.1], start_steps=[0, 100, 1000],
+    dynamic_loss_params=dict(loss_norm=2),
+    smooth_loss_params=dict(w_knn=3., w_ball_q=1., knn_loss_params=dict(k=32, radius=1., loss_norm=1),
+                            ball_q_loss_params=dict(k=64, radius=2., loss_norm=1)),
+    invariance_loss_params=dict(loss_norm=2))
+
+SAPIEN_LOSS = dict(  # config/seg/sapien/sapien_unsup.yaml
+    weights=[10.0, 0.1, 0.1], start_steps=[0, 0, 0],
+    dynamic_loss_params=dict(loss_norm=2),
+    smooth_loss_params=dict(w_knn=3., w_ball_q=1., knn_loss_params=dict(k=8, radius=0.1, loss_norm=1),
+                            ball_q_loss_params=dict(k=16, radius=0.2, loss_norm=1)),
+    invariance_loss_params=dict(loss_norm=2))
+
+
+def build_criterion(cfg):
+    return UnsupervisedOGCLoss(DynamicLoss(**cfg["dynamic_loss_params"]), SmoothLoss(**cfg["smooth_loss_params"]),
+                               InvarianceLoss(**cfg["invariance_loss_params"]), EntropyLoss(), RankLoss(),
+                               weights=cfg["weights"], start_steps=cfg["start_steps"])
+
+
+def train_step(segnet, criterion, optimizer, batch, it, aug_transform):
+    """batch = (pcs (b,t,n,3), segms (b,t,n), flows (b,t,n,3), valids), already on the device.
+    Returns (loss_dict, stepped)."""
+    segnet.train()
+    optimizer.zero_grad(set_to_none=True)
+    pcs, segms, flows, _ = batch
+    b, t, n = segms.size()
+    flat = pcs.view(b * t, n, -1).contiguous()
+    masks = segnet(flat, flat).view(b, t, n, -1)
+    pcs_l = [pcs[:, tt].contiguous() for tt in range(t)]
+    masks_l = [masks[:, tt].contiguous() for tt in range(t)]
+    flows_l = [flows[:, tt].contiguous() for tt in range(t)]
+    loss, loss_dict = criterion(pcs_l, masks_l, flows_l, step_w=True, it=it * b, aug_transform=aug_transform)
+    loss.backward()
+    grads = [p.grad for p in segnet.parameters() if p.grad is not None]
+    bad = torch.isnan(torch.stack(torch._foreach_norm(grads)).sum())  # NaN anywhere -> NaN norm
+    if bool(bad):  # one host sync; under DDP the all-reduced grads make this decision identical on all ranks
+        return loss_dict, False
+    optimizer.step()
+    return loss_dict, True
