@@ -1,9 +1,9 @@
 // ball_query.hip — exact fixed-radius neighbour query (first `nsample` hits in index order).
 //
 // Replaces ball_query_kernel_fast (reference: pointnet2/src/ball_query_gpu.cu:9-45).
-// One lane = one centre, one workgroup = one wavefront.  The candidate point is wave-uniform and
-// arrives through scalar loads; a hit is appended to the lane's row in LDS; rows are padded with the
-// first hit and written with coalesced stores (the wave's 64 rows are contiguous in memory).
+// One lane = one centre, one workgroup = one wavefront.  Candidates stream through an LDS tile and are
+// evaluated eight at a time (ogc_scan_candidates); a hit is appended to the lane's row in LDS; rows are
+// padded with the first hit and written with coalesced stores (the wave's 64 rows are contiguous in memory).
 // The scan stops early only when every lane of the wave already holds `nsample` hits — the same
 // result as the reference's per-thread `break` (ball_query_gpu.cu:42), since a full lane ignores
 // further hits.
@@ -18,8 +18,9 @@ __global__ __launch_bounds__(OGC_WAVE) void ball_query_kernel(int n, int m, floa
                                                               const float *__restrict__ xyz,
                                                               int *__restrict__ idx) {
     extern __shared__ __attribute__((aligned(16))) int bq_smem[];
-    int *rows = bq_smem;                        // [nsample][BQ_LSTRIDE]
-    int *cnts = bq_smem + nsample * BQ_LSTRIDE; // [64]
+    float *tile = reinterpret_cast<float *>(bq_smem);   // [OGC_TILE_FLOATS] candidate tile (16-byte aligned)
+    int *rows = bq_smem + OGC_TILE_FLOATS;              // [nsample][BQ_LSTRIDE]
+    int *cnts = rows + nsample * BQ_LSTRIDE;            // [64]
 
     const int lane = threadIdx.x;
     const int b = blockIdx.y;
@@ -32,34 +33,29 @@ __global__ __launch_bounds__(OGC_WAVE) void ball_query_kernel(int n, int m, floa
     const float *__restrict__ pts = xyz + (size_t)b * n * 3;
 
     int cnt = 0;
-    bool done = false;
-#define BQ_VISIT(X, Y, Z, K)                                                   \
-    {                                                                          \
-        const float d2_ = ogc_sqdist(cx, cy, cz, (X), (Y), (Z));               \
-        const bool hit_ = d2_ < radius2;                                       \
-        if (__builtin_amdgcn_ballot_w64(hit_) != 0) {                          \
-            if (hit_ && cnt < nsample) {                                       \
-                rows[cnt * BQ_LSTRIDE + lane] = (K);                           \
-                ++cnt;                                                         \
-            }                                                                  \
-            done = __builtin_amdgcn_ballot_w64(cnt < nsample) == 0;            \
-        }                                                                      \
-    }
-    int k = 0;
-    for (; k + 4 <= n && !done; k += 4) {
-        const float *p = pts + (size_t)k * 3;
-        const float a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3], a4 = p[4], a5 = p[5];
-        const float a6 = p[6], a7 = p[7], a8 = p[8], a9 = p[9], a10 = p[10], a11 = p[11];
-        BQ_VISIT(a0, a1, a2, k)
-        BQ_VISIT(a3, a4, a5, k + 1)
-        BQ_VISIT(a6, a7, a8, k + 2)
-        BQ_VISIT(a9, a10, a11, k + 3)
-    }
-    for (; k < n && !done; ++k) {
-        const float *p = pts + (size_t)k * 3;
-        BQ_VISIT(p[0], p[1], p[2], k)
-    }
-#undef BQ_VISIT
+    auto try_hit = [&](float d, int k) {
+        if (d < radius2 && cnt < nsample) {
+            rows[cnt * BQ_LSTRIDE + lane] = k;
+            ++cnt;
+        }
+    };
+    auto all_full = [&]() { return __builtin_amdgcn_ballot_w64(cnt < nsample) == 0; };
+    ogc_scan_candidates(
+        pts, n, cx, cy, cz, tile, lane,
+        [&](const float (&d)[8], int base) {
+            if (__builtin_amdgcn_ballot_w64(ogc_min8_f32(d) < radius2) == 0) return false; // one branch per group
+            unsigned long long mk[8];
+            ogc_masks8(d, radius2, mk);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (mk[u] != 0) try_hit(d[u], base + u); // scalar branch: only candidates some lane hits
+            return all_full();
+        },
+        [&](float d, int k) {
+            if (__builtin_amdgcn_ballot_w64(d < radius2) == 0) return false;
+            try_hit(d, k);
+            return all_full();
+        });
     cnts[lane] = cnt;
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
@@ -84,7 +80,7 @@ extern "C" int ogc_ball_query(int b, int n, int m, float radius, int nsample, co
     OGC_REQUIRE(b >= 0 && n >= 0 && m >= 0 && nsample >= 0, "ogc_ball_query: negative dimension");
     if (b == 0 || m == 0 || nsample == 0) return OGC_OK;
     OGC_REQUIRE(new_xyz && idx && (xyz || n == 0), "ogc_ball_query: null pointer");
-    const size_t lds = ((size_t)nsample * BQ_LSTRIDE + OGC_WAVE) * sizeof(int);
+    const size_t lds = ((size_t)OGC_TILE_FLOATS + (size_t)nsample * BQ_LSTRIDE + OGC_WAVE) * sizeof(int);
     if (lds > 160 * 1024) {
         ogc_set_error("ogc_ball_query: nsample=%d needs %zu B of LDS (>160 KiB)", nsample, lds);
         return OGC_ERR_UNSUPPORTED;

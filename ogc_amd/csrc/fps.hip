@@ -2,18 +2,22 @@
 //
 // Replaces furthest_point_sampling_kernel (reference: pointnet2/src/sampling_gpu.cu:93-253).
 // The reference re-reads xyz and temp from global memory every round and runs an 11-barrier
-// shared-memory tree per round.  Here one workgroup (up to 16 wavefronts) owns one cloud and keeps
-// the cloud AND the running min-distances in registers for the whole run (N <= 16384); a round is
-//   VALU update -> DPP wave max -> LDS (16 floats) -> barrier -> tie resolution -> barrier.
+// shared-memory tree per round.  Here one workgroup owns one cloud and keeps the cloud AND the running
+// min-distances in registers for the whole run (N <= 16384); a round is
+//     VALU update -> DPP wave max -> DPP wave min over ranks -> one LDS record per wave -> ONE barrier.
+// One wavefront per SIMD (256 threads) so the whole CU's VALU works on the cloud and the barrier is cheap.
 //
-// Tie order.  The reference's winner among equal maxima is fixed by its reduction shape: the
-// strided per-thread scan keeps the smallest k (strict '>', sampling_gpu.cu:136-137) and each tree
-// step keeps the left operand on ties (__update, :86-91).  Unrolled, that is a total order: among
-// points with the maximal value the winner minimises
+// Tie order.  The reference's winner among equal maxima is fixed by its reduction shape: the strided
+// per-thread scan keeps the smallest k (strict '>', sampling_gpu.cu:136-137) and each tree step keeps the
+// left operand on ties (__update, :86-91).  Unrolled, that is a total order: among points with the maximal
+// value the winner minimises
 //       rank(k) = bitrev_{log2 bs}(k % bs) * S + k / bs,   S = ceil(N / bs),
-// with bs = min(1024, 2^floor(log2 N)) the reference's block size (cuda_utils.h:10-14).  The kernel
-// reduces (value, rank) explicitly, so its own launch shape is free to differ from the reference's.
+// with bs = min(1024, 2^floor(log2 N)) the reference's block size (cuda_utils.h:10-14).  Points are laid
+// out over (lane, register) in RANK order (lane t holds ranks t, t+T, t+2T, ...), so "first maximal register
+// of the lane, then minimal rank over lanes" is exactly the reference's winner, and the launch shape is
+// free to differ from the reference's.
 #include <math.h>
+#include <stdlib.h>
 
 #include "ogc_common.h"
 
@@ -21,35 +25,58 @@ namespace {
 
 typedef unsigned long long u64;
 
-__device__ __forceinline__ unsigned fps_rank(int k, int bs_mask, int bs_shift, int S) {
-    const unsigned tid = (unsigned)k & (unsigned)bs_mask;
-    const unsigned rev = bs_shift ? (__brev(tid) >> (32 - bs_shift)) : 0u;
-    return rev * (unsigned)S + ((unsigned)k >> bs_shift);
+constexpr int FPS_LDS_XYZ_MAX = 10240; // rank slots whose xyz copy fits in LDS (3 * 4 B * 10240 = 120 KiB)
+
+__device__ __forceinline__ unsigned ogc_wave_min_u32(unsigned v) {
+    v = min(v, ogc_dpp_u32<0xB1>(v));
+    v = min(v, ogc_dpp_u32<0x4E>(v));
+    v = min(v, ogc_dpp_u32<0x141>(v));
+    v = min(v, ogc_dpp_u32<0x140>(v));
+    const unsigned r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16);
+    const unsigned r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
+    return min(min(r0, r1), min(r2, r3));
 }
 
-// Register-resident variant: THREADS lanes, PTS points per lane (point k = t + j*THREADS).
-template <int PTS, int THREADS>
+// rank slot -> point index (>= n for padding slots)
+__device__ __forceinline__ int fps_rank_to_k(unsigned rho, int S, int bs_shift) {
+    const unsigned rev = rho / (unsigned)S;
+    const unsigned kd = rho - rev * (unsigned)S;
+    const unsigned tid = bs_shift ? (__brev(rev) >> (32 - bs_shift)) : 0u;
+    return (int)((kd << bs_shift) + tid);
+}
+
+struct FpsRecord { // one per wave per round
+    float vmax;
+    unsigned rho;
+    float x, y, z;
+};
+
+template <int PTS, int THREADS, bool LDS_XYZ>
 __global__ __launch_bounds__(THREADS) void fps_reg_kernel(int n, int m, int bs_shift,
                                                           const float *__restrict__ xyz,
-                                                          float *__restrict__ temp,
-                                                          int *__restrict__ idxs) {
+                                                          float *__restrict__ temp, int *__restrict__ idxs) {
     constexpr int NW = THREADS / OGC_WAVE;
-    __shared__ float s_wmax[2][16];
-    __shared__ u64 s_best[2];
+    extern __shared__ __attribute__((aligned(16))) float fps_smem[];
+    FpsRecord *rec = reinterpret_cast<FpsRecord *>(fps_smem); // [2][16]
+    float *lx = fps_smem + 2 * 16 * (sizeof(FpsRecord) / 4); // after 32 records
+    const int slots = PTS * THREADS;
+    float *ly = lx + slots, *lz = ly + slots;
 
     const int t = threadIdx.x;
+    const int lane = t & (OGC_WAVE - 1);
+    const int wave = t >> 6;
     const int b = blockIdx.x;
     const float *__restrict__ dataset = xyz + (size_t)b * n * 3;
     float *tmp = temp + (size_t)b * n;
     int *out = idxs + (size_t)b * m;
-
-    const int bs_mask = (1 << bs_shift) - 1;
-    const int S = (n + bs_mask) >> bs_shift;
+    const int S = (n + (1 << bs_shift) - 1) >> bs_shift;
+    const int nslot = S << bs_shift; // rank slots in use (>= n)
 
     float px[PTS], py[PTS], pz[PTS], td[PTS];
 #pragma unroll
     for (int j = 0; j < PTS; ++j) {
-        const int k = t + j * THREADS;
+        const unsigned rho = (unsigned)(t + j * THREADS);
+        const int k = rho < (unsigned)nslot ? fps_rank_to_k(rho, S, bs_shift) : n;
         if (k < n) {
             px[j] = dataset[k * 3 + 0];
             py[j] = dataset[k * 3 + 1];
@@ -57,56 +84,73 @@ __global__ __launch_bounds__(THREADS) void fps_reg_kernel(int n, int m, int bs_s
             td[j] = tmp[k];
         } else {
             px[j] = py[j] = pz[j] = 0.0f;
-            td[j] = -1.0f; // padding never wins (real values are >= 0)
+            td[j] = -1.0f; // padding never wins: real values are >= 0 and fminf(d, -1) = -1
+        }
+        if (LDS_XYZ) {
+            lx[rho] = px[j];
+            ly[rho] = py[j];
+            lz[rho] = pz[j];
         }
     }
-    if (t == 0) {
-        out[0] = 0;
-        s_best[0] = ~0ull;
-        s_best[1] = ~0ull;
-    }
+    if (t == 0) out[0] = 0;
+    float x1 = dataset[0], y1 = dataset[1], z1 = dataset[2];
     __syncthreads();
 
-    int old = 0;
     for (int r = 1; r < m; ++r) {
         const int par = r & 1;
-        const float x1 = dataset[old * 3 + 0], y1 = dataset[old * 3 + 1], z1 = dataset[old * 3 + 2];
         float tmax = -1.0f;
 #pragma unroll
         for (int j = 0; j < PTS; ++j) {
             const float d = ogc_sqdist(px[j], py[j], pz[j], x1, y1, z1);
-            // padding lanes keep -1: fminf(d, -1) = -1
-            td[j] = fminf(d, td[j]);
+            td[j] = ogc_min_f32(d, td[j]);
             tmax = fmaxf(tmax, td[j]);
         }
         const float wmax = ogc_wave_max_f32(tmax);
-        if ((t & (OGC_WAVE - 1)) == 0) s_wmax[par][t >> 6] = wmax;
-        __syncthreads();
-        float gmax = s_wmax[par][0];
+        unsigned rho = 0xFFFFFFFFu;
+        if (tmax == wmax) {
 #pragma unroll
-        for (int w = 1; w < NW; ++w) gmax = fmaxf(gmax, s_wmax[par][w]);
-        if (tmax == gmax) {
-            u64 best = ~0ull;
-#pragma unroll
-            for (int j = 0; j < PTS; ++j) {
-                const int k = t + j * THREADS;
-                if (td[j] == gmax) {
-                    const u64 key = ((u64)fps_rank(k, bs_mask, bs_shift, S) << 32) | (unsigned)k;
-                    best = key < best ? key : best;
-                }
-            }
-            atomicMin(&s_best[par], best);
+            for (int j = PTS - 1; j >= 0; --j) rho = td[j] == wmax ? (unsigned)(t + j * THREADS) : rho;
         }
-        if (t == 0) s_best[par ^ 1] = ~0ull;
+        const unsigned wrho = ogc_wave_min_u32(rho);
+        if (lane == 0) {
+            FpsRecord rc;
+            rc.vmax = wmax;
+            rc.rho = wrho;
+            if (LDS_XYZ) {
+                rc.x = lx[wrho]; rc.y = ly[wrho]; rc.z = lz[wrho];
+            } else {
+                const int k = fps_rank_to_k(wrho, S, bs_shift);
+                rc.x = dataset[k * 3 + 0]; rc.y = dataset[k * 3 + 1]; rc.z = dataset[k * 3 + 2];
+            }
+            rec[par * 16 + wave] = rc;
+        }
         __syncthreads();
-        old = __builtin_amdgcn_readfirstlane((int)(unsigned)s_best[par]);
-        if (t == 0) out[r] = old;
+        FpsRecord best = rec[par * 16];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) {
+            const FpsRecord c = rec[par * 16 + w];
+            const bool better = c.vmax > best.vmax || (c.vmax == best.vmax && c.rho < best.rho);
+            best.vmax = better ? c.vmax : best.vmax;
+            best.rho = better ? c.rho : best.rho;
+            best.x = better ? c.x : best.x;
+            best.y = better ? c.y : best.y;
+            best.z = better ? c.z : best.z;
+        }
+        x1 = best.x; y1 = best.y; z1 = best.z;
+        if (t == 0) out[r] = fps_rank_to_k(best.rho, S, bs_shift);
     }
 #pragma unroll
     for (int j = 0; j < PTS; ++j) {
-        const int k = t + j * THREADS;
+        const unsigned rho = (unsigned)(t + j * THREADS);
+        const int k = rho < (unsigned)nslot ? fps_rank_to_k(rho, S, bs_shift) : n;
         if (k < n) tmp[k] = td[j];
     }
+}
+
+__device__ __forceinline__ unsigned fps_rank(int k, int bs_mask, int bs_shift, int S) {
+    const unsigned tid = (unsigned)k & (unsigned)bs_mask;
+    const unsigned rev = bs_shift ? (__brev(tid) >> (32 - bs_shift)) : 0u;
+    return rev * (unsigned)S + ((unsigned)k >> bs_shift);
 }
 
 // Large-N fallback (N > 16384): same rounds, but xyz/temp stay in global memory (L2-resident).
@@ -164,11 +208,24 @@ int fps_ref_block_shift(int work_size) {
     return pow_2;
 }
 
-} // namespace
+template <int PTS, int THREADS>
+void fps_launch(int b, int n, int m, int shift, const float *xyz, float *temp, int *idx, hipStream_t stream) {
+    constexpr int slots = PTS * THREADS;
+    constexpr bool lds_xyz = slots <= FPS_LDS_XYZ_MAX;
+    constexpr size_t lds = 32 * sizeof(FpsRecord) + (lds_xyz ? 3 * slots * sizeof(float) : 0);
+    auto kern = fps_reg_kernel<PTS, THREADS, lds_xyz>;
+    if (lds > 64 * 1024) {
+        static bool once = false; // raise the dynamic-LDS cap once per process for this instantiation
+        if (!once) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            once = true;
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3(b), dim3(THREADS), lds, stream, n, m, shift, xyz, temp, idx);
+}
 
-#define FPS_LAUNCH(PTS, THREADS)                                                                  \
-    hipLaunchKernelGGL((fps_reg_kernel<PTS, THREADS>), dim3(b), dim3(THREADS), 0, (hipStream_t)stream, \
-                       n, m, shift, xyz, temp, idx)
+} // namespace
 
 extern "C" int ogc_furthest_point_sampling(int b, int n, int m, const float *xyz, float *temp, int *idx,
                                            ogc_stream_t stream) {
@@ -178,18 +235,31 @@ extern "C" int ogc_furthest_point_sampling(int b, int n, int m, const float *xyz
     OGC_REQUIRE(xyz && temp && idx, "ogc_furthest_point_sampling: null pointer");
     OGC_REQUIRE((long long)b * n * 3 < (1ll << 31), "ogc_furthest_point_sampling: xyz exceeds 32-bit indexing");
     const int shift = fps_ref_block_shift(n);
-    if (n <= 64) FPS_LAUNCH(1, 64);
-    else if (n <= 128) FPS_LAUNCH(1, 128);
-    else if (n <= 256) FPS_LAUNCH(1, 256);
-    else if (n <= 512) FPS_LAUNCH(1, 512);
-    else if (n <= 1024) FPS_LAUNCH(1, 1024);
-    else if (n <= 2048) FPS_LAUNCH(2, 1024);
-    else if (n <= 4096) FPS_LAUNCH(4, 1024);
-    else if (n <= 8192) FPS_LAUNCH(8, 1024);
-    else if (n <= 16384) FPS_LAUNCH(16, 1024);
+    const int bs = 1 << shift;
+    const int slots = ((n + bs - 1) / bs) * bs; // rank slots = bs * ceil(n / bs)
+    hipStream_t s = (hipStream_t)stream;
+    static const int force_threads = getenv("OGC_FPS_THREADS") ? atoi(getenv("OGC_FPS_THREADS")) : 0; // dev knob
+    if (force_threads == 1024 && slots > 1024 && slots <= 8192) {
+        if (slots <= 2048) fps_launch<2, 1024>(b, n, m, shift, xyz, temp, idx, s);
+        else if (slots <= 4096) fps_launch<4, 1024>(b, n, m, shift, xyz, temp, idx, s);
+        else fps_launch<8, 1024>(b, n, m, shift, xyz, temp, idx, s);
+    } else if (force_threads == 512 && slots > 512 && slots <= 8192) {
+        if (slots <= 1024) fps_launch<2, 512>(b, n, m, shift, xyz, temp, idx, s);
+        else if (slots <= 2048) fps_launch<4, 512>(b, n, m, shift, xyz, temp, idx, s);
+        else if (slots <= 4096) fps_launch<8, 512>(b, n, m, shift, xyz, temp, idx, s);
+        else fps_launch<16, 512>(b, n, m, shift, xyz, temp, idx, s);
+    } else
+    if (slots <= 64) fps_launch<1, 64>(b, n, m, shift, xyz, temp, idx, s);
+    else if (slots <= 128) fps_launch<2, 64>(b, n, m, shift, xyz, temp, idx, s);
+    else if (slots <= 256) fps_launch<4, 64>(b, n, m, shift, xyz, temp, idx, s);
+    else if (slots <= 512) fps_launch<2, 256>(b, n, m, shift, xyz, temp, idx, s);
+    else if (slots <= 1024) fps_launch<4, 256>(b, n, m, shift, xyz, temp, idx, s);
+    else if (slots <= 2048) fps_launch<8, 256>(b, n, m, shift, xyz, temp, idx, s);
+    else if (slots <= 4096) fps_launch<16, 256>(b, n, m, shift, xyz, temp, idx, s);
+    else if (slots <= 8192) fps_launch<32, 256>(b, n, m, shift, xyz, temp, idx, s);
+    else if (slots <= 16384) fps_launch<32, 512>(b, n, m, shift, xyz, temp, idx, s);
     else
-        hipLaunchKernelGGL(fps_mem_kernel, dim3(b), dim3(1024), 0, (hipStream_t)stream, n, m, shift, xyz,
-                           temp, idx);
+        hipLaunchKernelGGL(fps_mem_kernel, dim3(b), dim3(1024), 0, s, n, m, shift, xyz, temp, idx);
     OGC_CHECK_LAUNCH("ogc_furthest_point_sampling");
     return OGC_OK;
 }

@@ -77,6 +77,48 @@ __global__ __launch_bounds__(GG_THREADS) void group_bwd_kernel(int c, int n, int
     }
 }
 
+// LDS-privatised scatter-add: a workgroup owns CC channels x one slice of the T positions of batch b,
+// accumulates into an LDS image acc[CC][n] with ds_add_f32 (no global atomic contention: kNN neighbour lists
+// overlap heavily, group_points_gpu.cu:24 serialises on popular points), then merges the non-zero entries
+// into grad_points with one global atomic each.
+template <int CC>
+__global__ __launch_bounds__(GG_THREADS) void group_bwd_lds_kernel(int c, int n, int T, int t_per_block,
+                                                                   const float *__restrict__ grad_out,
+                                                                   const int *__restrict__ idx,
+                                                                   float *__restrict__ grad_points) {
+    extern __shared__ __attribute__((aligned(16))) float gb_acc[]; // [CC][n]
+    const int b = blockIdx.z;
+    const int c0 = blockIdx.y * CC;
+    const int ncc = min(CC, c - c0);
+    const int t_begin = blockIdx.x * t_per_block;
+    const int t_end = min(T, t_begin + t_per_block);
+    for (int i = threadIdx.x; i < CC * n; i += GG_THREADS) gb_acc[i] = 0.0f;
+    __syncthreads();
+    const int *id = idx + (size_t)b * T;
+    const float *g = grad_out + ((size_t)b * c + c0) * T;
+    // t_begin and t_per_block are multiples of 4; T % 4 == 0 is guaranteed by the launcher
+    for (int t4 = t_begin + threadIdx.x * 4; t4 < t_end; t4 += GG_THREADS * 4) {
+        const int4 i4 = *reinterpret_cast<const int4 *>(id + t4);
+#pragma unroll
+        for (int cc = 0; cc < CC; ++cc) {
+            if (cc < ncc) {
+                const float4 v = *reinterpret_cast<const float4 *>(g + (size_t)cc * T + t4);
+                float *a = gb_acc + cc * n;
+                atomicAdd(a + i4.x, v.x);
+                atomicAdd(a + i4.y, v.y);
+                atomicAdd(a + i4.z, v.z);
+                atomicAdd(a + i4.w, v.w);
+            }
+        }
+    }
+    __syncthreads();
+    float *gp = grad_points + ((size_t)b * c + c0) * n;
+    for (int i = threadIdx.x; i < ncc * n; i += GG_THREADS) {
+        const float v = gb_acc[i];
+        if (v != 0.0f) unsafeAtomicAdd(gp + i, v);
+    }
+}
+
 int pick_ch_per_block(int b, int c, int blocks_x) {
     // aim for >= ~2048 workgroups (8 per CU) before giving each workgroup more channels
     int cpb = 1;
@@ -115,6 +157,30 @@ int group_bwd(const char *name, int b, int c, int n, int T, const float *grad_ou
     OGC_REQUIRE((long long)b * c * T < (1ll << 31) && (long long)b * c * n < (1ll << 31),
                 "%s: tensor exceeds 32-bit indexing", name);
     const bool vec = (T % 4 == 0) && aligned16(idx) && aligned16(grad_out);
+    // LDS-privatised path: the per-channel image (n floats) must fit a 64 KiB budget at least once
+    if (vec && n <= 16384 && T >= 4096) {
+        int cc = 16384 / n; // channels per workgroup within 64 KiB
+        cc = cc >= 8 ? 8 : (cc >= 4 ? 4 : (cc >= 2 ? 2 : 1));
+        while (cc > 1 && cc / 2 >= c) cc /= 2;
+        const int chunks = ogc_divup(c, cc);
+        // split T so that >= ~512 workgroups exist, but keep >= 8192 positions per workgroup
+        int splits = 1;
+        while ((long long)b * chunks * splits < 512 && T / (splits * 2) >= 8192) splits *= 2;
+        int tpb = ogc_divup(T, splits);
+        tpb = (tpb + 1023) / 1024 * 1024;
+        dim3 grid(ogc_divup(T, tpb), chunks, b);
+        const size_t lds = (size_t)cc * n * sizeof(float);
+#define GB_LAUNCH(CCV)                                                                                    \
+    hipLaunchKernelGGL(group_bwd_lds_kernel<CCV>, grid, dim3(GG_THREADS), lds, (hipStream_t)stream, c, n, T, \
+                       tpb, grad_out, idx, grad_points)
+        if (cc == 8) GB_LAUNCH(8);
+        else if (cc == 4) GB_LAUNCH(4);
+        else if (cc == 2) GB_LAUNCH(2);
+        else GB_LAUNCH(1);
+#undef GB_LAUNCH
+        OGC_CHECK_LAUNCH(name);
+        return OGC_OK;
+    }
     const int bx = ogc_divup(T, vec ? GG_THREADS * 4 : GG_THREADS);
     const int cpb = pick_ch_per_block(b, c, bx);
     dim3 grid(bx, ogc_divup(c, cpb), b);

@@ -25,7 +25,8 @@ namespace {
 
 typedef unsigned long long u64;
 
-constexpr int KNN_BUF = 8;      // pending candidates per lane between heap updates
+constexpr int KNN_BUF = 16;     // pending candidates per lane between heap updates
+constexpr int KNN_GROUP = 8;    // candidates evaluated back to back (ILP) before one wave-level test
 constexpr int KNN_LSTRIDE = 65; // LDS row stride (in elements) -> conflict-free both ways
 
 __device__ __forceinline__ u64 knn_pack(float d, int i) {
@@ -86,8 +87,9 @@ __global__ __launch_bounds__(OGC_WAVE) void knn_heap_kernel(int n, int m, int k,
                                                             float *__restrict__ dist_out,
                                                             int *__restrict__ idx_out) {
     extern __shared__ __attribute__((aligned(16))) u64 knn_smem[];
-    u64 *heap = knn_smem;                   // [k][KNN_LSTRIDE]
-    u64 *buf = knn_smem + k * KNN_LSTRIDE;  // [KNN_BUF][KNN_LSTRIDE]
+    float *tile = reinterpret_cast<float *>(knn_smem);       // [OGC_TILE_FLOATS] candidate tile
+    u64 *heap = knn_smem + OGC_TILE_FLOATS / 2;              // [k][KNN_LSTRIDE]
+    u64 *buf = heap + k * KNN_LSTRIDE;                       // [KNN_BUF][KNN_LSTRIDE]
     int *hsizes = (int *)(buf + KNN_BUF * KNN_LSTRIDE); // [64]
 
     const int lane = threadIdx.x;
@@ -103,35 +105,35 @@ __global__ __launch_bounds__(OGC_WAVE) void knn_heap_kernel(int n, int m, int k,
     float tau = INFINITY;
     int hsize = 0, nbuf = 0;
 
-#define KNN_VISIT(X, Y, Z, I)                                                  \
-    {                                                                          \
-        const float d_ = ogc_sqdist(ux, uy, uz, (X), (Y), (Z));                \
-        const bool pass_ = d_ < tau;                                           \
-        if (__builtin_amdgcn_ballot_w64(pass_) != 0) {                         \
-            if (pass_) {                                                       \
-                buf[nbuf * KNN_LSTRIDE + lane] = knn_pack(d_, (I));            \
-                ++nbuf;                                                        \
-            }                                                                  \
-            if (__builtin_amdgcn_ballot_w64(nbuf == KNN_BUF) != 0)             \
-                knn_flush(heap, buf, lane, k, hsize, tau, nbuf);               \
-        }                                                                      \
-    }
-
-    int i = 0;
-    for (; i + 4 <= m; i += 4) { // 12 consecutive floats: wave-uniform -> scalar loads
-        const float *p = kn + (size_t)i * 3;
-        const float a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3], a4 = p[4], a5 = p[5];
-        const float a6 = p[6], a7 = p[7], a8 = p[8], a9 = p[9], a10 = p[10], a11 = p[11];
-        KNN_VISIT(a0, a1, a2, i)
-        KNN_VISIT(a3, a4, a5, i + 1)
-        KNN_VISIT(a6, a7, a8, i + 2)
-        KNN_VISIT(a9, a10, a11, i + 3)
-    }
-    for (; i < m; ++i) {
-        const float *p = kn + (size_t)i * 3;
-        KNN_VISIT(p[0], p[1], p[2], i)
-    }
-#undef KNN_VISIT
+    // Admitted candidates (d < tau) are appended to the pending buffer in index order; the heap is only touched
+    // when some lane's buffer could overflow on the next group (see ogc_scan_candidates for the scan structure).
+    auto try_admit = [&](float d, int i) {
+        if (d < tau) {
+            buf[nbuf * KNN_LSTRIDE + lane] = knn_pack(d, i);
+            ++nbuf;
+        }
+    };
+    auto maybe_flush = [&]() {
+        if (__builtin_amdgcn_ballot_w64(nbuf > KNN_BUF - KNN_GROUP) != 0) knn_flush(heap, buf, lane, k, hsize, tau, nbuf);
+    };
+    ogc_scan_candidates(
+        kn, m, ux, uy, uz, tile, lane,
+        [&](const float (&d)[8], int base) {
+            if (__builtin_amdgcn_ballot_w64(ogc_min8_f32(d) < tau) == 0) return false;
+            unsigned long long mk[8];
+            ogc_masks8(d, tau, mk);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (mk[u] != 0) try_admit(d[u], base + u); // scalar branch: only candidates some lane admits
+            maybe_flush();
+            return false;
+        },
+        [&](float d, int i) {
+            if (__builtin_amdgcn_ballot_w64(d < tau) == 0) return false;
+            try_admit(d, i);
+            maybe_flush();
+            return false;
+        });
     knn_flush(heap, buf, lane, k, hsize, tau, nbuf);
 
     // heap sort in place: ascending (dist, index) in heap[0..hsize)
@@ -182,11 +184,13 @@ __global__ __launch_bounds__(OGC_WAVE) void knn_heap_kernel(int n, int m, int k,
 }
 
 // k = 3 in registers (interpolate_gpu.cu:101-121: if / else-if / else-if chain with strict '<').
-__global__ __launch_bounds__(256) void three_nn_kernel(int n, int m, const float *__restrict__ unknown,
-                                                       const float *__restrict__ known,
-                                                       float *__restrict__ dist2, int *__restrict__ idx) {
+__global__ __launch_bounds__(OGC_WAVE) void three_nn_kernel(int n, int m, const float *__restrict__ unknown,
+                                                            const float *__restrict__ known,
+                                                            float *__restrict__ dist2, int *__restrict__ idx) {
+    __shared__ __attribute__((aligned(16))) float tile[OGC_TILE_FLOATS];
+    const int lane = threadIdx.x;
     const int b = blockIdx.y;
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    const int q = blockIdx.x * OGC_WAVE + lane;
     const int qc = q < n ? q : n - 1;
     const float *u = unknown + ((size_t)b * n + qc) * 3;
     const float ux = u[0], uy = u[1], uz = u[2];
@@ -194,34 +198,30 @@ __global__ __launch_bounds__(256) void three_nn_kernel(int n, int m, const float
 
     float b1 = INFINITY, b2 = INFINITY, b3 = INFINITY;
     int i1 = 0, i2 = 0, i3 = 0;
-#define NN3_VISIT(X, Y, Z, I)                                   \
-    {                                                           \
-        const float d_ = ogc_sqdist(ux, uy, uz, (X), (Y), (Z)); \
-        if (__builtin_amdgcn_ballot_w64(d_ < b3) != 0) {        \
-            const bool c1 = d_ < b1, c2 = d_ < b2, c3 = d_ < b3; \
-            b3 = c2 ? b2 : (c3 ? d_ : b3);                      \
-            i3 = c2 ? i2 : (c3 ? (I) : i3);                     \
-            b2 = c1 ? b1 : (c2 ? d_ : b2);                      \
-            i2 = c1 ? i1 : (c2 ? (I) : i2);                     \
-            b1 = c1 ? d_ : b1;                                  \
-            i1 = c1 ? (I) : i1;                                 \
-        }                                                       \
-    }
-    int i = 0;
-    for (; i + 4 <= m; i += 4) {
-        const float *p = kn + (size_t)i * 3;
-        const float a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3], a4 = p[4], a5 = p[5];
-        const float a6 = p[6], a7 = p[7], a8 = p[8], a9 = p[9], a10 = p[10], a11 = p[11];
-        NN3_VISIT(a0, a1, a2, i)
-        NN3_VISIT(a3, a4, a5, i + 1)
-        NN3_VISIT(a6, a7, a8, i + 2)
-        NN3_VISIT(a9, a10, a11, i + 3)
-    }
-    for (; i < m; ++i) {
-        const float *p = kn + (size_t)i * 3;
-        NN3_VISIT(p[0], p[1], p[2], i)
-    }
-#undef NN3_VISIT
+    auto update = [&](float d, int i) { // interpolate_gpu.cu:109-120
+        const bool c1 = d < b1, c2 = d < b2, c3 = d < b3;
+        b3 = c2 ? b2 : (c3 ? d : b3);
+        i3 = c2 ? i2 : (c3 ? i : i3);
+        b2 = c1 ? b1 : (c2 ? d : b2);
+        i2 = c1 ? i1 : (c2 ? i : i2);
+        b1 = c1 ? d : b1;
+        i1 = c1 ? i : i1;
+    };
+    ogc_scan_candidates(
+        kn, m, ux, uy, uz, tile, lane,
+        [&](const float (&d)[8], int base) {
+            if (__builtin_amdgcn_ballot_w64(ogc_min8_f32(d) < b3) == 0) return false;
+            unsigned long long mk[8];
+            ogc_masks8(d, b3, mk); // b3 only shrinks, so a candidate outside the mask can never enter later
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (mk[u] != 0) update(d[u], base + u);
+            return false;
+        },
+        [&](float d, int i) {
+            update(d, i);
+            return false;
+        });
     if (q < n) {
         float *o = dist2 + ((size_t)b * n + q) * 3;
         int *oi = idx + ((size_t)b * n + q) * 3;
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void three_nn_kernel(int n, int m, const float
 }
 
 size_t knn_lds_bytes(int k) {
-    return (size_t)(k + KNN_BUF) * KNN_LSTRIDE * sizeof(u64) + OGC_WAVE * sizeof(int);
+    return OGC_TILE_FLOATS * sizeof(float) + (size_t)(k + KNN_BUF) * KNN_LSTRIDE * sizeof(u64) + OGC_WAVE * sizeof(int);
 }
 
 template <int MODE>
@@ -268,8 +268,8 @@ extern "C" int ogc_three_nn(int b, int n, int m, const float *unknown, const flo
     OGC_REQUIRE(b >= 0 && n >= 0 && m >= 0, "ogc_three_nn: negative dimension");
     if (b == 0 || n == 0) return OGC_OK;
     OGC_REQUIRE(unknown && known && dist2 && idx, "ogc_three_nn: null pointer");
-    dim3 grid(ogc_divup(n, 256), b);
-    hipLaunchKernelGGL(three_nn_kernel, grid, dim3(256), 0, (hipStream_t)stream, n, m, unknown, known,
+    dim3 grid(ogc_divup(n, OGC_WAVE), b);
+    hipLaunchKernelGGL(three_nn_kernel, grid, dim3(OGC_WAVE), 0, (hipStream_t)stream, n, m, unknown, known,
                        dist2, idx);
     OGC_CHECK_LAUNCH("ogc_three_nn");
     return OGC_OK;

@@ -1,0 +1,20 @@
+"""Run ONE operator a few times (for rocprofv3 --pmc / --kernel-trace runs).  python tools/one_op.py ball|knn|fps|..."""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ogc_amd
+from ogc_amd import pointnet2_cuda as nat
+op = sys.argv[1]; B = int(sys.argv[2]) if len(sys.argv) > 2 else 16; reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+g = torch.Generator().manual_seed(1234)
+pc = ((torch.rand(B, 8192, 3, generator=g) - 0.5) * torch.tensor([60.0, 4.0, 80.0])).cuda().contiguous()
+for _ in range(reps):
+    if op == "ball":
+        idx = torch.zeros(B, 8192, 64, dtype=torch.int32, device="cuda")
+        nat.ball_query_wrapper(B, 8192, 8192, 2.0, 64, pc, pc, idx)
+    elif op == "knn":
+        d2 = torch.empty(B, 8192, 32, device="cuda"); idx = torch.empty(B, 8192, 32, dtype=torch.int32, device="cuda")
+        nat.knn_wrapper(B, 8192, 8192, 32, pc, pc, d2, idx)
+    elif op == "fps":
+        idx = torch.empty(B, 2048, dtype=torch.int32, device="cuda"); temp = torch.full((B, 8192), 1e10, device="cuda")
+        nat.furthest_point_sampling_wrapper(B, 8192, 2048, pc, temp, idx)
+torch.cuda.synchronize()
