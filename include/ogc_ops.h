@@ -131,6 +131,13 @@ int ogc_ball_query(int b, int n, int m, float radius, int nsample, const float *
 int ogc_knn_clamped(int b, int n, int m, int k, float radius, const float *unknown,
                     const float *known, float *dist, int *idx, ogc_stream_t stream);
 
+/* Batched 3x3 Kabsch rotation.  Replaces torch.svd + the reflection fix of the weighted-Kabsch fit
+ *   losses/seg_loss_unsup.py:44-53:  u,s,v = svd(S); R = v diag(1,1,det(v u^T)) u^T.
+ * S (nb,3,3) f32 cross-covariances (P_c^T diag(w) Q_c), R (nb,3,3) f32 out; valid (nb) i32 out or NULL:
+ * 0 where S contains NaN/inf (then R = I — the reference's `valid_batches` rule, :38-42), else 1.
+ * One thread per matrix, Jacobi eigen-solve of S^T S in fp64. */
+int ogc_kabsch_rotation(int nb, const float *S, float *R, int *valid, ogc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

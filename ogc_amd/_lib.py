@@ -26,6 +26,7 @@ SIGNATURES = {
     "ogc_group_points_grad": [_int, _int, _int, _int, _int, _vp, _vp, _vp, _vp],
     "ogc_ball_query": [_int, _int, _int, _flt, _int, _vp, _vp, _vp, _vp],
     "ogc_knn_clamped": [_int, _int, _int, _int, _flt, _vp, _vp, _vp, _vp, _vp],
+    "ogc_kabsch_rotation": [_int, _vp, _vp, _vp, _vp],
 }
 
 _lib = None

@@ -18,6 +18,25 @@ from scipy.optimize import linear_sum_assignment
 from ..pointnet2.pointnet2 import ball_query, grouping_operation, knn, knn_radius_clamp
 
 
+def _kabsch_rotation(S, valid, eye):
+    """R = V diag(1, 1, det(V U^T)) U^T for S = U diag(s) V^T (reference :44-53).  On the GPU this is one launch
+    of the HIP 3x3 kernel (ogc_kabsch_rotation); otherwise torch's SVD, like the reference."""
+    from ..pointnet2 import pointnet2 as _api
+    fused = getattr(_api._native, "kabsch_rotation_wrapper", None)
+    if fused is not None and S.is_cuda:
+        S = S.detach().contiguous().float()
+        R = torch.empty_like(S)
+        fused(S.shape[0], S, R)
+        return R
+    S_safe = torch.where(valid.view(-1, 1, 1), S, eye)
+    u, _, vh = torch.linalg.svd(S_safe)
+    v = vh.transpose(1, 2)
+    det = torch.det(v.bmm(u.transpose(1, 2)))
+    diag = torch.ones_like(S[..., 0])
+    diag[:, 2] = det
+    return v.bmm(torch.diag_embed(diag).bmm(u.transpose(1, 2)))
+
+
 def fit_motion_svd_batch(pc1, pc2, mask=None):
     """Weighted Kabsch: rigid (R, t) minimising sum_n w_n |R p_n + t - q_n|^2 per batch item.
     pc1, pc2 (B, N, 3), mask (B, N) -> R (B, 3, 3), t (B, 3).  Reference: seg_loss_unsup.py:10-61.
@@ -35,14 +54,7 @@ def fit_motion_svd_batch(pc1, pc2, mask=None):
 
     valid = ~torch.isnan(S).flatten(1).any(dim=1)                                   # (B,)
     eye = torch.eye(3, device=pc1.device, dtype=S.dtype).expand_as(S)
-    S_safe = torch.where(valid.view(-1, 1, 1), S, eye)
-    u, _, vh = torch.linalg.svd(S_safe)
-    v = vh.transpose(1, 2)
-    det = torch.det(v.bmm(u.transpose(1, 2)))
-    # reflection -> rotation: R = V diag(1, 1, det) U^T  (:49-53)
-    diag = torch.ones_like(S[..., 0])
-    diag[:, 2] = det
-    R = v.bmm(torch.diag_embed(diag).bmm(u.transpose(1, 2)))
+    R = _kabsch_rotation(S, valid, eye)
     t = pc2_mean.squeeze(1) - R.bmm(pc1_mean.transpose(1, 2)).squeeze(2)
 
     R = torch.where(valid.view(-1, 1, 1), R, eye)
@@ -192,7 +204,13 @@ class RankLoss(nn.Module):
     """Mean nuclear norm of the (N, K) masks. Reference: :300-314."""
 
     def forward(self, mask):
-        return torch.linalg.matrix_norm(mask, ord='nuc', dim=(1, 2)).mean()
+        # sum of singular values of the (N, K) mask = sum_i sqrt(eig_i(M^T M)); the K x K Gram matrix is formed and
+        # decomposed in fp64, so the value matches an fp32 SVD of M to fp32 accuracy without a tall-matrix SVD
+        # (rocSOLVER's bidiagonalisation of (B, 8192, 10) is ~300 tiny launches per step).
+        m64 = mask.detach().double()
+        gram = m64.transpose(1, 2).bmm(m64)
+        sv = torch.linalg.eigvalsh(gram).clamp_min(0).sqrt()
+        return sv.sum(dim=1).mean().to(mask.dtype)
 
 
 class UnsupervisedOGCLoss(nn.Module):

@@ -144,3 +144,8 @@ def knn_clamped_wrapper(b, n, m, k, radius, unknown, known, dist, idx):
     """kNN + sqrt + radius clamp in one launch; radius < 0 disables the clamp."""
     _run("ogc_knn_clamped", unknown, b, n, m, k, float(radius), _f(unknown, "unknown"), _f(known, "known"),
          _f(dist, "dist"), _i(idx, "idx"))
+
+
+def kabsch_rotation_wrapper(nb, S, R, valid=None):
+    """R = V diag(1,1,det) U^T per 3x3 cross-covariance (ogc_kabsch_rotation); NaN matrices give the identity."""
+    _run("ogc_kabsch_rotation", S, nb, _f(S, "S"), _f(R, "R"), 0 if valid is None else _i(valid, "valid"))

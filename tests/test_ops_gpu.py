@@ -324,3 +324,38 @@ def test_knn_clamped_equals_unfused_torch_path(nat):
     i2 = torch.empty_like(idx)
     nat.knn_clamped_wrapper(2, 2048, 4096, 32, 2.5, q, pc, d2, i2)
     assert torch.equal(d2, dist) and torch.equal(i2, idx)
+
+
+def test_kabsch_rotation_kernel(nat):
+    """HIP 3x3 Kabsch rotation vs the reference's torch.svd formula (fp64 on the host), incl. degenerate cases."""
+    g = torch.Generator().manual_seed(7)
+    S = torch.randn(64, 3, 3, generator=g)
+    S[1] = torch.diag(torch.tensor([3.0, 2.0, 0.0]))                 # rank 2
+    S[2] = torch.tensor([[1.0, 0, 0], [0, 1, 0], [0, 0, -1]])          # reflection
+    S[3] = torch.outer(torch.tensor([1.0, 2, 3]), torch.tensor([0.5, -1, 2]))  # rank 1
+    S[4] = float("nan")                                               # ill-posed -> identity
+    S[5] *= 1e-12
+    S[6] *= 1e12
+    R = torch.empty(64, 3, 3, device=DEV)
+    valid = torch.empty(64, dtype=torch.int32, device=DEV)
+    nat.kabsch_rotation_wrapper(64, S.to(DEV).contiguous(), R, valid)
+    R = R.cpu().double()
+    assert valid.cpu().tolist() == [0 if i == 4 else 1 for i in range(64)]
+    assert torch.equal(R[4], torch.eye(3, dtype=torch.float64))
+    for i in range(64):
+        if i == 4:
+            continue
+        # orthonormal, det +1
+        assert torch.allclose(R[i] @ R[i].T, torch.eye(3, dtype=torch.float64), atol=1e-6)
+        assert abs(torch.det(R[i]).item() - 1.0) < 1e-6
+        if i in (1, 3):
+            continue  # rank-deficient: R not unique; optimality checked below
+        u, s, vh = torch.linalg.svd(S[i].double())
+        v = vh.T
+        d = torch.det(v @ u.T)
+        Rref = v @ torch.diag(torch.tensor([1.0, 1.0, d.item()], dtype=torch.float64)) @ u.T
+        assert torch.allclose(R[i], Rref, atol=2e-6), i
+    for i in (1, 3):  # optimality: trace(R S) equals s1 + s2 - |s3| for the best rotation
+        s = torch.linalg.svdvals(S[i].double())
+        best = s[0] + s[1] + s[2] * torch.sign(torch.det(S[i].double()))
+        assert abs(torch.trace(R[i] @ S[i].double()).item() - best.item()) < 1e-5 * max(1.0, best.item())
