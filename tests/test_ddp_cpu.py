@@ -1,0 +1,79 @@
+"""Multi-process data-parallel test on CPU (gloo, world_size 2): the N>1 path of bench.py / the training driver.
+
+Each rank runs `train_step` on its own shard with DDP gradient averaging; the averaged gradients and the updated
+weights must equal a single process that steps on the concatenated batch (GroupNorm has no cross-sample
+statistics, so the only coupling between shards is the gradient mean — SURVEY.md §8e).  The native operators are
+replaced by the CPU oracle inside the worker processes (test infrastructure only)."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _setup_cpu_ops():
+    sys.path.insert(0, ROOT)
+    import ogc_amd.pointnet2.pointnet2 as api
+    from oracle import oracle as orc
+    api._native = orc.Pointnet2CudaCPU()
+    orc.set_threads(2)
+    torch.set_num_threads(2)
+
+
+def _make(npoint=256):
+    from ogc_amd.models.segnet_sapien import MaskFormer3D
+    from ogc_amd.train_step import SAPIEN_LOSS, build_criterion
+    torch.manual_seed(10)
+    net = MaskFormer3D(n_slot=4, n_point=npoint, transformer_embed_dim=32)
+    return net, build_criterion(SAPIEN_LOSS)
+
+
+def _loss_and_grads(model, crit, batch):
+    pcs, segms, flows, _ = batch
+    b, t, n = segms.size()
+    flat = pcs.view(b * t, n, -1).contiguous()
+    masks = model(flat, flat).view(b, t, n, -1)
+    loss, _ = crit([pcs[:, i].contiguous() for i in range(t)], [masks[:, i].contiguous() for i in range(t)],
+                   [flows[:, i].contiguous() for i in range(t)], step_w=True, it=10, aug_transform=False)
+    return loss
+
+
+def _worker(rank, world, port, out_dir):
+    _setup_cpu_ops()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ogc_amd.utils.synthetic import make_scene_batch
+    net, crit = _make()
+    ddp = torch.nn.parallel.DistributedDataParallel(net)
+    full = make_scene_batch(2 * world, 256, 4, seed=3, outdoor=False, aug=False)
+    shard = tuple(x[rank * 2:(rank + 1) * 2].contiguous() for x in full)
+    opt = torch.optim.SGD(net.parameters(), lr=0.1)
+    opt.zero_grad()
+    _loss_and_grads(ddp, crit, shard).backward()
+    opt.step()
+    if rank == 0:
+        torch.save({k: v.clone() for k, v in net.state_dict().items()}, os.path.join(out_dir, "ddp.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_ddp_two_ranks_equal_single_process(tmp_path):
+    world, port = 2, 29000 + os.getpid() % 2000
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    _setup_cpu_ops()
+    from ogc_amd.utils.synthetic import make_scene_batch
+    net, crit = _make()
+    full = make_scene_batch(2 * world, 256, 4, seed=3, outdoor=False, aug=False)
+    opt = torch.optim.SGD(net.parameters(), lr=0.1)
+    opt.zero_grad()
+    # every loss term is a mean over the batch dimension, so the 2-rank mean of shard losses == the full-batch loss
+    _loss_and_grads(net, crit, full).backward()
+    opt.step()
+    ddp_state = torch.load(os.path.join(str(tmp_path), "ddp.pt"))
+    for k, v in net.state_dict().items():
+        torch.testing.assert_close(ddp_state[k], v, rtol=2e-4, atol=2e-6, msg=lambda m: "%s: %s" % (k, m))
