@@ -138,6 +138,20 @@ int ogc_knn_clamped(int b, int n, int m, int k, float radius, const float *unkno
  * One thread per matrix, Jacobi eigen-solve of S^T S in fp64. */
 int ogc_kabsch_rotation(int nb, const float *S, float *R, int *valid, ogc_stream_t stream);
 
+/* Fused GroupNorm (+ ReLU) forward / backward.  Replaces the nn.GroupNorm -> ReLU(inplace) tail of every
+ * Conv2d block of the segmentation nets' SharedMLPs
+ *   utils/nn_util.py:6-11 (GroupNorm), :45-85 (_ConvBase ordering), models/segnet_kitti.py:8 (BN_CONFIG).
+ * x, y, grad_y, grad_x (b, c, hw) f32 contiguous; gamma, beta, grad_gamma, grad_beta (c); mean, rstd (b*groups)
+ * (written by fwd, read by bwd); biased variance, rstd = 1/sqrt(var + eps); relu != 0 applies max(.,0) in fwd
+ * and masks grad_y where the output was <= 0 in bwd.
+ * ws: caller-allocated scratch, fwd: 2*b*groups doubles; bwd: 2*b*c doubles + 2*b*groups floats. */
+int ogc_group_norm_fwd(int b, int c, int hw, int groups, float eps, int relu, const float *x,
+                       const float *gamma, const float *beta, float *y, float *mean, float *rstd,
+                       double *ws, ogc_stream_t stream);
+int ogc_group_norm_bwd(int b, int c, int hw, int groups, int relu, const float *x, const float *gamma,
+                       const float *beta, const float *mean, const float *rstd, const float *grad_y,
+                       float *grad_x, float *grad_gamma, float *grad_beta, double *ws, ogc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

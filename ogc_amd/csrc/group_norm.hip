@@ -1,0 +1,319 @@
+// group_norm.hip — fused GroupNorm (+ ReLU) forward and backward for the per-point MLPs.
+//
+// Replaces the Conv2d -> nn.GroupNorm(4) -> ReLU(inplace) tail of every SharedMLP layer of the segmentation nets
+// (reference: utils/nn_util.py:6-11, :45-85; models/segnet_kitti.py:8 BN_CONFIG).  PyTorch's GroupNorm forward
+// reduces each (sample, group) row — here 64 rows of ~1M elements — with ONE workgroup per row
+// (RowwiseMomentsCUDAKernel: 0.74 ms per layer, 22 % of the training step on MI355X); ReLU and its backward are
+// separate full passes.  Here:
+//   forward : stats  (many workgroups per row, fp64 partials)            1 read
+//             apply  y = relu(a_c * x + b_c)                             1 read + 1 write
+//   backward: sums   ds = sum dy'*x, db = sum dy' per (sample, channel)  2 reads       (dy' = dy * [y > 0])
+//             params c2, c3 per (sample, group); dgamma, dbeta           tiny
+//             dx     = dy' * gamma_c * rstd + c2 * x + c3                2 reads + 1 write
+// x is (B, C, HW) fp32 contiguous; the channels of a group are contiguous, so a (sample, group) row is one
+// contiguous run of (C/G)*HW floats.  Statistics: biased variance, rstd = 1/sqrt(var + eps), as nn.GroupNorm.
+#include "ogc_common.h"
+
+namespace {
+
+constexpr int GN_THREADS = 256;
+
+// block-wide sum of two doubles; result valid in thread 0
+__device__ __forceinline__ void gn_block_sum2(double &a, double &b, double *smem /* [2*GN_THREADS/64] */) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        a += __shfl_down(a, off, 64);
+        b += __shfl_down(b, off, 64);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        smem[wave * 2] = a;
+        smem[wave * 2 + 1] = b;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a = 0.0;
+        b = 0.0;
+        for (int w = 0; w < GN_THREADS / 64; ++w) {
+            a += smem[w * 2];
+            b += smem[w * 2 + 1];
+        }
+    }
+}
+
+// ---- forward ------------------------------------------------------------------------------------------------
+// grid (chunks, B*G): partial sum / sum of squares of one slice of a row -> atomicAdd into ws[row][0..1] (fp64).
+__global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(long long row_len, long long chunk_len,
+                                                              const float *__restrict__ x, double *__restrict__ ws) {
+    __shared__ double smem[2 * GN_THREADS / 64];
+    const long long row = blockIdx.y;
+    const long long begin = (long long)blockIdx.x * chunk_len;
+    const long long end = min(row_len, begin + chunk_len);
+    const float *p = x + row * row_len;
+    double s = 0.0, ss = 0.0;
+    if (((row_len | chunk_len) & 3) == 0 && ((uintptr_t)p & 15) == 0) {
+        for (long long i = begin + threadIdx.x * 4; i < end; i += GN_THREADS * 4 * 4) {
+            float fs = 0.0f, fss = 0.0f; // fp32 over <= 16 elements, then fp64
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long long j = i + (long long)u * GN_THREADS * 4;
+                if (j < end) {
+                    const float4 v = *reinterpret_cast<const float4 *>(p + j);
+                    fs += (v.x + v.y) + (v.z + v.w);
+                    fss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+                }
+            }
+            s += fs;
+            ss += fss;
+        }
+    } else {
+        for (long long i = begin + threadIdx.x; i < end; i += GN_THREADS) {
+            const float v = p[i];
+            s += v;
+            ss += (double)v * v;
+        }
+    }
+    gn_block_sum2(s, ss, smem);
+    if (threadIdx.x == 0) {
+        atomicAdd(ws + row * 2, s);
+        atomicAdd(ws + row * 2 + 1, ss);
+    }
+}
+
+// grid (chunks over HW, C, B): y = act(a_c * x + b_c).  The first chunk of the first channel of a group also
+// publishes mean / rstd for the backward pass.
+template <bool RELU>
+__global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(int c, int hw, int groups, float eps,
+                                                              const float *__restrict__ x,
+                                                              const float *__restrict__ gamma,
+                                                              const float *__restrict__ beta,
+                                                              const double *__restrict__ ws, float *__restrict__ y,
+                                                              float *__restrict__ mean_out,
+                                                              float *__restrict__ rstd_out) {
+    const int b = blockIdx.z, ch = blockIdx.y;
+    const int cg = c / groups, g = ch / cg;
+    const int row = b * groups + g;
+    const double n = (double)cg * hw;
+    const double m = ws[row * 2] / n;
+    const double var = fmax(ws[row * 2 + 1] / n - m * m, 0.0);
+    const float mean = (float)m;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    if (blockIdx.x == 0 && ch == g * cg && threadIdx.x == 0) {
+        mean_out[row] = mean;
+        rstd_out[row] = rstd;
+    }
+    const float a = rstd * gamma[ch];
+    const float bb = beta[ch] - mean * a;
+    const size_t base = ((size_t)b * c + ch) * hw;
+    const float *px = x + base;
+    float *py = y + base;
+    if ((hw & 3) == 0 && (((uintptr_t)px | (uintptr_t)py) & 15) == 0) {
+        for (int i = (blockIdx.x * GN_THREADS + threadIdx.x) * 4; i < hw; i += gridDim.x * GN_THREADS * 4) {
+            float4 v = *reinterpret_cast<const float4 *>(px + i);
+            v.x = fmaf(a, v.x, bb); v.y = fmaf(a, v.y, bb); v.z = fmaf(a, v.z, bb); v.w = fmaf(a, v.w, bb);
+            if (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            *reinterpret_cast<float4 *>(py + i) = v;
+        }
+    } else {
+        for (int i = blockIdx.x * GN_THREADS + threadIdx.x; i < hw; i += gridDim.x * GN_THREADS) {
+            float v = fmaf(a, px[i], bb);
+            py[i] = RELU ? fmaxf(v, 0.f) : v;
+        }
+    }
+}
+
+// ---- backward -----------------------------------------------------------------------------------------------
+// grid (chunks, C, B): ds[b,c] += sum dy'*x, db[b,c] += sum dy'   (fp64 atomics into dsdb[b*c][2])
+template <bool RELU>
+__global__ __launch_bounds__(GN_THREADS) void gn_bwd_sums_kernel(int c, int hw, int groups,
+                                                                 const float *__restrict__ x,
+                                                                 const float *__restrict__ gamma,
+                                                                 const float *__restrict__ beta,
+                                                                 const float *__restrict__ mean,
+                                                                 const float *__restrict__ rstd,
+                                                                 const float *__restrict__ dy,
+                                                                 double *__restrict__ dsdb) {
+    __shared__ double smem[2 * GN_THREADS / 64];
+    const int b = blockIdx.z, ch = blockIdx.y;
+    const int cg = c / groups, row = b * groups + ch / cg;
+    const float a = rstd[row] * gamma[ch];
+    const float bb = beta[ch] - mean[row] * a;
+    const size_t base = ((size_t)b * c + ch) * hw;
+    const float *px = x + base, *pd = dy + base;
+    double s = 0.0, sb = 0.0;
+    if ((hw & 3) == 0 && (((uintptr_t)px | (uintptr_t)pd) & 15) == 0) {
+        for (int i = (blockIdx.x * GN_THREADS + threadIdx.x) * 4; i < hw; i += gridDim.x * GN_THREADS * 4) {
+            const float4 v = *reinterpret_cast<const float4 *>(px + i);
+            float4 d = *reinterpret_cast<const float4 *>(pd + i);
+            if (RELU) {
+                d.x = fmaf(a, v.x, bb) > 0.f ? d.x : 0.f; d.y = fmaf(a, v.y, bb) > 0.f ? d.y : 0.f;
+                d.z = fmaf(a, v.z, bb) > 0.f ? d.z : 0.f; d.w = fmaf(a, v.w, bb) > 0.f ? d.w : 0.f;
+            }
+            s += (double)((d.x * v.x + d.y * v.y) + (d.z * v.z + d.w * v.w));
+            sb += (double)((d.x + d.y) + (d.z + d.w));
+        }
+    } else {
+        for (int i = blockIdx.x * GN_THREADS + threadIdx.x; i < hw; i += gridDim.x * GN_THREADS) {
+            const float v = px[i];
+            float d = pd[i];
+            if (RELU) d = fmaf(a, v, bb) > 0.f ? d : 0.f;
+            s += (double)d * v;
+            sb += d;
+        }
+    }
+    gn_block_sum2(s, sb, smem);
+    if (threadIdx.x == 0) {
+        atomicAdd(dsdb + ((size_t)b * c + ch) * 2, s);
+        atomicAdd(dsdb + ((size_t)b * c + ch) * 2 + 1, sb);
+    }
+}
+
+// one thread per channel: dgamma, dbeta; one thread per (b, g): c2, c3.  grid ceil((c + b*groups)/256)
+__global__ void gn_bwd_params_kernel(int b, int c, int hw, int groups, const float *__restrict__ gamma,
+                                     const float *__restrict__ mean, const float *__restrict__ rstd,
+                                     const double *__restrict__ dsdb, float *__restrict__ dgamma,
+                                     float *__restrict__ dbeta, float *__restrict__ c2c3) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int cg = c / groups;
+    if (t < c) {
+        const int g = t / cg;
+        double dg = 0.0, dbt = 0.0;
+        for (int bi = 0; bi < b; ++bi) {
+            const double ds = dsdb[((size_t)bi * c + t) * 2], db = dsdb[((size_t)bi * c + t) * 2 + 1];
+            const int row = bi * groups + g;
+            dg += (ds - (double)mean[row] * db) * (double)rstd[row];
+            dbt += db;
+        }
+        dgamma[t] = (float)dg;
+        dbeta[t] = (float)dbt;
+    } else if (t < c + b * groups) {
+        const int row = t - c, bi = row / groups, g = row % groups;
+        double dsg = 0.0, dbg = 0.0;
+        for (int k = 0; k < cg; ++k) {
+            const int ch = g * cg + k;
+            dsg += dsdb[((size_t)bi * c + ch) * 2] * (double)gamma[ch];
+            dbg += dsdb[((size_t)bi * c + ch) * 2 + 1] * (double)gamma[ch];
+        }
+        const double m = mean[row], r = rstd[row], n = (double)cg * hw;
+        const double c2 = (dbg * m - dsg) * r * r * r / n;
+        const double c3 = -c2 * m - dbg * r / n;
+        c2c3[row * 2] = (float)c2;
+        c2c3[row * 2 + 1] = (float)c3;
+    }
+}
+
+template <bool RELU>
+__global__ __launch_bounds__(GN_THREADS) void gn_bwd_dx_kernel(int c, int hw, int groups,
+                                                               const float *__restrict__ x,
+                                                               const float *__restrict__ gamma,
+                                                               const float *__restrict__ beta,
+                                                               const float *__restrict__ mean,
+                                                               const float *__restrict__ rstd,
+                                                               const float *__restrict__ c2c3,
+                                                               const float *__restrict__ dy, float *__restrict__ dx) {
+    const int b = blockIdx.z, ch = blockIdx.y;
+    const int cg = c / groups, row = b * groups + ch / cg;
+    const float r = rstd[row];
+    const float a = r * gamma[ch];
+    const float bb = beta[ch] - mean[row] * a;
+    const float c2 = c2c3[row * 2], c3 = c2c3[row * 2 + 1];
+    const size_t base = ((size_t)b * c + ch) * hw;
+    const float *px = x + base, *pd = dy + base;
+    float *po = dx + base;
+    if ((hw & 3) == 0 && (((uintptr_t)px | (uintptr_t)pd | (uintptr_t)po) & 15) == 0) {
+        for (int i = (blockIdx.x * GN_THREADS + threadIdx.x) * 4; i < hw; i += gridDim.x * GN_THREADS * 4) {
+            const float4 v = *reinterpret_cast<const float4 *>(px + i);
+            float4 d = *reinterpret_cast<const float4 *>(pd + i);
+            if (RELU) {
+                d.x = fmaf(a, v.x, bb) > 0.f ? d.x : 0.f; d.y = fmaf(a, v.y, bb) > 0.f ? d.y : 0.f;
+                d.z = fmaf(a, v.z, bb) > 0.f ? d.z : 0.f; d.w = fmaf(a, v.w, bb) > 0.f ? d.w : 0.f;
+            }
+            float4 o;
+            o.x = fmaf(a, d.x, fmaf(c2, v.x, c3)); o.y = fmaf(a, d.y, fmaf(c2, v.y, c3));
+            o.z = fmaf(a, d.z, fmaf(c2, v.z, c3)); o.w = fmaf(a, d.w, fmaf(c2, v.w, c3));
+            *reinterpret_cast<float4 *>(po + i) = o;
+        }
+    } else {
+        for (int i = blockIdx.x * GN_THREADS + threadIdx.x; i < hw; i += gridDim.x * GN_THREADS) {
+            const float v = px[i];
+            float d = pd[i];
+            if (RELU) d = fmaf(a, v, bb) > 0.f ? d : 0.f;
+            po[i] = fmaf(a, d, fmaf(c2, v, c3));
+        }
+    }
+}
+
+int hw_chunks(int b, int c, int hw) {
+    // enough workgroups to fill the chip (>= ~2048) without making them tiny (>= 4096 elements each)
+    int chunks = 1;
+    while ((long long)b * c * chunks < 2048 && hw / (chunks * 2) >= 4096) chunks *= 2;
+    return chunks;
+}
+
+} // namespace
+
+extern "C" int ogc_group_norm_fwd(int b, int c, int hw, int groups, float eps, int relu, const float *x,
+                                  const float *gamma, const float *beta, float *y, float *mean, float *rstd,
+                                  double *ws, ogc_stream_t stream) {
+    OGC_REQUIRE(b >= 0 && c >= 1 && hw >= 1 && groups >= 1 && c % groups == 0, "ogc_group_norm_fwd: bad shape");
+    if (b == 0) return OGC_OK;
+    OGC_REQUIRE(x && gamma && beta && y && mean && rstd && ws, "ogc_group_norm_fwd: null pointer");
+    OGC_REQUIRE((long long)b * c * hw < (1ll << 31), "ogc_group_norm_fwd: tensor exceeds 32-bit indexing");
+    hipStream_t s = (hipStream_t)stream;
+    const int rows = b * groups;
+    const long long row_len = (long long)(c / groups) * hw;
+    if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * rows, s) != hipSuccess) {
+        ogc_set_error("ogc_group_norm_fwd: memset failed");
+        return OGC_ERR_LAUNCH;
+    }
+    int chunks = 1;
+    while ((long long)rows * chunks < 2048 && row_len / (chunks * 2) >= 16384) chunks *= 2;
+    long long chunk_len = (row_len + chunks - 1) / chunks;
+    chunk_len = (chunk_len + 3) / 4 * 4;
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(ogc_divup(row_len, chunk_len), rows), dim3(GN_THREADS), 0, s, row_len,
+                       chunk_len, x, ws);
+    dim3 grid(hw_chunks(b, c, hw), c, b);
+    if (relu)
+        hipLaunchKernelGGL(gn_apply_kernel<true>, grid, dim3(GN_THREADS), 0, s, c, hw, groups, eps, x, gamma, beta, ws,
+                           y, mean, rstd);
+    else
+        hipLaunchKernelGGL(gn_apply_kernel<false>, grid, dim3(GN_THREADS), 0, s, c, hw, groups, eps, x, gamma, beta, ws,
+                           y, mean, rstd);
+    OGC_CHECK_LAUNCH("ogc_group_norm_fwd");
+    return OGC_OK;
+}
+
+extern "C" int ogc_group_norm_bwd(int b, int c, int hw, int groups, int relu, const float *x, const float *gamma,
+                                  const float *beta, const float *mean, const float *rstd, const float *grad_y,
+                                  float *grad_x, float *grad_gamma, float *grad_beta, double *ws,
+                                  ogc_stream_t stream) {
+    OGC_REQUIRE(b >= 0 && c >= 1 && hw >= 1 && groups >= 1 && c % groups == 0, "ogc_group_norm_bwd: bad shape");
+    if (b == 0) return OGC_OK;
+    OGC_REQUIRE(x && gamma && beta && mean && rstd && grad_y && grad_x && grad_gamma && grad_beta && ws,
+                "ogc_group_norm_bwd: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    // ws layout: dsdb [b*c][2] fp64, then c2c3 [b*groups][2] fp32
+    double *dsdb = ws;
+    float *c2c3 = reinterpret_cast<float *>(ws + (size_t)2 * b * c);
+    if (hipMemsetAsync(dsdb, 0, sizeof(double) * 2 * b * c, s) != hipSuccess) {
+        ogc_set_error("ogc_group_norm_bwd: memset failed");
+        return OGC_ERR_LAUNCH;
+    }
+    dim3 grid(hw_chunks(b, c, hw), c, b);
+    if (relu)
+        hipLaunchKernelGGL(gn_bwd_sums_kernel<true>, grid, dim3(GN_THREADS), 0, s, c, hw, groups, x, gamma, beta, mean,
+                           rstd, grad_y, dsdb);
+    else
+        hipLaunchKernelGGL(gn_bwd_sums_kernel<false>, grid, dim3(GN_THREADS), 0, s, c, hw, groups, x, gamma, beta, mean,
+                           rstd, grad_y, dsdb);
+    hipLaunchKernelGGL(gn_bwd_params_kernel, dim3(ogc_divup(c + b * groups, 256)), dim3(256), 0, s, b, c, hw, groups,
+                       gamma, mean, rstd, dsdb, grad_gamma, grad_beta, c2c3);
+    if (relu)
+        hipLaunchKernelGGL(gn_bwd_dx_kernel<true>, grid, dim3(GN_THREADS), 0, s, c, hw, groups, x, gamma, beta, mean,
+                           rstd, c2c3, grad_y, grad_x);
+    else
+        hipLaunchKernelGGL(gn_bwd_dx_kernel<false>, grid, dim3(GN_THREADS), 0, s, c, hw, groups, x, gamma, beta, mean,
+                           rstd, c2c3, grad_y, grad_x);
+    OGC_CHECK_LAUNCH("ogc_group_norm_bwd");
+    return OGC_OK;
+}

@@ -149,3 +149,17 @@ def knn_clamped_wrapper(b, n, m, k, radius, unknown, known, dist, idx):
 def kabsch_rotation_wrapper(nb, S, R, valid=None):
     """R = V diag(1,1,det) U^T per 3x3 cross-covariance (ogc_kabsch_rotation); NaN matrices give the identity."""
     _run("ogc_kabsch_rotation", S, nb, _f(S, "S"), _f(R, "R"), 0 if valid is None else _i(valid, "valid"))
+
+
+def group_norm_fwd_wrapper(b, c, hw, groups, eps, relu, x, gamma, beta, y, mean, rstd, ws):
+    """Fused GroupNorm(+ReLU) forward (ogc_group_norm_fwd); ws: float64 scratch of 2*b*groups elements."""
+    _run("ogc_group_norm_fwd", x, b, c, hw, groups, float(eps), int(relu), _f(x, "x"), _f(gamma, "gamma"),
+         _f(beta, "beta"), _f(y, "y"), _f(mean, "mean"), _f(rstd, "rstd"), _check(ws, torch.float64, "ws"))
+
+
+def group_norm_bwd_wrapper(b, c, hw, groups, relu, x, gamma, beta, mean, rstd, grad_y, grad_x, grad_gamma, grad_beta,
+                           ws):
+    """Fused GroupNorm(+ReLU) backward (ogc_group_norm_bwd); ws: float64 scratch of 2*b*c + b*groups elements."""
+    _run("ogc_group_norm_bwd", x, b, c, hw, groups, int(relu), _f(x, "x"), _f(gamma, "gamma"), _f(beta, "beta"),
+         _f(mean, "mean"), _f(rstd, "rstd"), _f(grad_y, "grad_y"), _f(grad_x, "grad_x"),
+         _f(grad_gamma, "grad_gamma"), _f(grad_beta, "grad_beta"), _check(ws, torch.float64, "ws"))

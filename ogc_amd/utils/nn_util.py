@@ -86,6 +86,18 @@ class _ConvNd(nn.Sequential):
         if bn is not None:
             norm = get_norm_layer(bn, self._dim, in_size=in_size if preact else out_size)
         _assemble(self, name, "conv", conv, norm, activation, preact)
+        # conv -> GroupNorm -> (ReLU | nothing) is executed as conv + ONE fused GroupNorm/activation op
+        self._gn_fuse = (not preact and isinstance(norm, GroupNorm)
+                         and (activation is None or type(activation) is nn.ReLU))
+        self._names = (name + "conv", name + "normlayer", activation is not None)
+
+    def forward(self, input):
+        if self._gn_fuse:
+            from ..fused import group_norm_act
+            conv_name, norm_name, relu = self._names
+            y = getattr(self, conv_name)(input)
+            return group_norm_act(y, getattr(self, norm_name)[0], relu)
+        return super().forward(input)
 
 
 class Conv1d(_ConvNd):

@@ -359,3 +359,33 @@ def test_kabsch_rotation_kernel(nat):
         s = torch.linalg.svdvals(S[i].double())
         best = s[0] + s[1] + s[2] * torch.sign(torch.det(S[i].double()))
         assert abs(torch.trace(R[i] @ S[i].double()).item() - best.item()) < 1e-5 * max(1.0, best.item())
+
+
+@pytest.mark.parametrize("shape,groups,relu", [((4, 32, 256, 64), 4, True), ((2, 8, 37, 5), 4, True), ((3, 64, 1000, 1), 4, False),
+                                               ((2, 128, 10), 4, True), ((16, 32, 2048, 64), 4, True), ((1, 4, 7), 2, False)])
+def test_fused_group_norm_act(nat, shape, groups, relu):
+    """Fused GroupNorm(+ReLU) fwd/bwd vs torch's own composition evaluated in fp64."""
+    from ogc_amd.fused import group_norm_act
+    torch.manual_seed(1)
+    C = shape[1]
+    gn = torch.nn.GroupNorm(groups, C).to(DEV)
+    with torch.no_grad():
+        gn.weight.uniform_(0.5, 1.5)
+        gn.bias.uniform_(-0.2, 0.2)
+    x = (torch.randn(*shape, device=DEV) * 2 + 0.7).requires_grad_(True)
+    y = group_norm_act(x, gn, relu)
+    g = torch.randn_like(y)
+    gx, gw, gb = torch.autograd.grad(y, [x, gn.weight, gn.bias], g)
+    x64 = x.detach().double().requires_grad_(True)
+    w64 = gn.weight.detach().double().requires_grad_(True)
+    b64 = gn.bias.detach().double().requires_grad_(True)
+    y64 = torch.nn.functional.group_norm(x64, groups, w64, b64, gn.eps)
+    if relu:
+        y64 = torch.relu(y64)
+    gx64, gw64, gb64 = torch.autograd.grad(y64, [x64, w64, b64], g.double())
+    torch.testing.assert_close(y.double(), y64, rtol=1e-5, atol=1e-5)
+    # the ReLU gate of an output within rounding of zero may legitimately differ between fp32 and fp64
+    safe = (y64.detach().abs() > 1e-5) | (not relu)
+    torch.testing.assert_close(torch.where(safe, gx.double(), gx64), gx64, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(gw.double(), gw64, rtol=1e-4, atol=1e-4 * max(1.0, gw64.abs().max().item()))
+    torch.testing.assert_close(gb.double(), gb64, rtol=1e-4, atol=1e-4 * max(1.0, gb64.abs().max().item()))
