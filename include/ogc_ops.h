@@ -152,6 +152,19 @@ int ogc_group_norm_bwd(int b, int c, int hw, int groups, int relu, const float *
                        const float *beta, const float *mean, const float *rstd, const float *grad_y,
                        float *grad_x, float *grad_gamma, float *grad_beta, double *ws, ogc_stream_t stream);
 
+/* GroupNorm (+ ReLU) fused with the max over the neighbourhood — the tail of a set-abstraction MLP
+ *   utils/pointnet2_util.py:38-42 (SharedMLP then F.max_pool2d over nsample).
+ * x (b, c, p, s) -> out (b, c, p), argmax (b, c, p) i32 (index in [0, s) of the winning neighbour; first index on
+ * ties).  s must be a power of two in [4, 256] and x 16-byte aligned (OGC_ERR_UNSUPPORTED otherwise).
+ * bwd: grad_out (b, c, p) -> grad_x (b, c, p, s), grad_gamma, grad_beta; scratch sizes as for ogc_group_norm_*. */
+int ogc_group_norm_maxpool_fwd(int b, int c, int p, int s, int groups, float eps, int relu, const float *x,
+                               const float *gamma, const float *beta, float *out, int *argmax, float *mean,
+                               float *rstd, double *ws, ogc_stream_t stream);
+int ogc_group_norm_maxpool_bwd(int b, int c, int p, int s, int groups, int relu, const float *x,
+                               const float *gamma, const float *mean, const float *rstd, const float *out,
+                               const int *argmax, const float *grad_out, float *grad_x, float *grad_gamma,
+                               float *grad_beta, double *ws, ogc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

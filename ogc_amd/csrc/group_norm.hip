@@ -243,6 +243,120 @@ __global__ __launch_bounds__(GN_THREADS) void gn_bwd_dx_kernel(int c, int hw, in
     }
 }
 
+// ---- GroupNorm + ReLU + max over the neighbourhood (last layer of a set-abstraction MLP) ----------------------
+// x (B, C, P, S) -> out (B, C, P) = max_s act(a_c x + b_c), argmax (B, C, P).  The normalised activation is never
+// written: this removes one full write, the separate max-reduction pass (utils/pointnet2_util.py:39-42 max_pool2d)
+// and, in the backward pass, the dense gradient of the max.  L = S/4 lanes share a row (one float4 each, fully
+// coalesced); the row maximum is reduced with xor-shuffles inside the L-lane group (first index wins ties).
+template <bool RELU>
+__global__ __launch_bounds__(GN_THREADS) void gn_apply_maxpool_kernel(int c, int p, int s, int groups, float eps,
+                                                                      const float *__restrict__ x,
+                                                                      const float *__restrict__ gamma,
+                                                                      const float *__restrict__ beta,
+                                                                      const double *__restrict__ ws,
+                                                                      float *__restrict__ out, int *__restrict__ arg,
+                                                                      float *__restrict__ mean_out,
+                                                                      float *__restrict__ rstd_out) {
+    const int b = blockIdx.z, ch = blockIdx.y;
+    const int cg = c / groups, g = ch / cg, row = b * groups + g;
+    const double n = (double)cg * p * s;
+    const double m = ws[row * 2] / n;
+    const double var = fmax(ws[row * 2 + 1] / n - m * m, 0.0);
+    const float mean = (float)m;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    if (blockIdx.x == 0 && ch == g * cg && threadIdx.x == 0) {
+        mean_out[row] = mean;
+        rstd_out[row] = rstd;
+    }
+    const float a = rstd * gamma[ch];
+    const float bb = beta[ch] - mean * a;
+    const int L = s >> 2;                         // lanes per row (power of two, <= 64)
+    const int rows_per_block = GN_THREADS / L;
+    const int sub = threadIdx.x % L;
+    const size_t base = ((size_t)b * c + ch) * p;
+    for (int pr = blockIdx.x * rows_per_block + threadIdx.x / L; pr < p + (rows_per_block - 1);
+         pr += gridDim.x * rows_per_block) { // uniform trip count for the shuffles; tail rows are clamped
+        const int prc = min(pr, p - 1);
+        const float4 v = *reinterpret_cast<const float4 *>(x + (base + prc) * s + sub * 4);
+        float y0 = fmaf(a, v.x, bb), y1 = fmaf(a, v.y, bb), y2 = fmaf(a, v.z, bb), y3 = fmaf(a, v.w, bb);
+        if (RELU) { y0 = fmaxf(y0, 0.f); y1 = fmaxf(y1, 0.f); y2 = fmaxf(y2, 0.f); y3 = fmaxf(y3, 0.f); }
+        float best = y0;
+        int bi = sub * 4;
+        if (y1 > best) { best = y1; bi = sub * 4 + 1; }
+        if (y2 > best) { best = y2; bi = sub * 4 + 2; }
+        if (y3 > best) { best = y3; bi = sub * 4 + 3; }
+        for (int off = 1; off < L; off <<= 1) {
+            const float ob = __shfl_xor(best, off, 64);
+            const int oi = __shfl_xor(bi, off, 64);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        if (sub == 0 && pr < p) {
+            out[base + pr] = best;
+            arg[base + pr] = bi;
+        }
+    }
+}
+
+// grid (chunks over P, C, B): ds, db from the sparse gradient (non-zero only at the arg-max element)
+template <bool RELU>
+__global__ __launch_bounds__(GN_THREADS) void gn_maxpool_bwd_sums_kernel(int c, int p, int s,
+                                                                         const float *__restrict__ x,
+                                                                         const float *__restrict__ out,
+                                                                         const int *__restrict__ arg,
+                                                                         const float *__restrict__ gout,
+                                                                         double *__restrict__ dsdb) {
+    __shared__ double smem[2 * GN_THREADS / 64];
+    const int b = blockIdx.z, ch = blockIdx.y;
+    const size_t base = ((size_t)b * c + ch) * p;
+    double ds = 0.0, db = 0.0;
+    for (int pr = blockIdx.x * GN_THREADS + threadIdx.x; pr < p; pr += gridDim.x * GN_THREADS) {
+        float g = gout[base + pr];
+        if (RELU && !(out[base + pr] > 0.f)) g = 0.f;
+        ds += (double)g * (double)x[(base + pr) * s + arg[base + pr]];
+        db += g;
+    }
+    gn_block_sum2(ds, db, smem);
+    if (threadIdx.x == 0) {
+        atomicAdd(dsdb + ((size_t)b * c + ch) * 2, ds);
+        atomicAdd(dsdb + ((size_t)b * c + ch) * 2 + 1, db);
+    }
+}
+
+// dx = c2 * x + c3 everywhere, + a * g' at the arg-max element of each row
+template <bool RELU>
+__global__ __launch_bounds__(GN_THREADS) void gn_maxpool_bwd_dx_kernel(int c, int p, int s, int groups,
+                                                                       const float *__restrict__ x,
+                                                                       const float *__restrict__ gamma,
+                                                                       const float *__restrict__ rstd,
+                                                                       const float *__restrict__ c2c3,
+                                                                       const float *__restrict__ out,
+                                                                       const int *__restrict__ arg,
+                                                                       const float *__restrict__ gout,
+                                                                       float *__restrict__ dx) {
+    const int b = blockIdx.z, ch = blockIdx.y;
+    const int cg = c / groups, row = b * groups + ch / cg;
+    const float a = rstd[row] * gamma[ch];
+    const float c2 = c2c3[row * 2], c3 = c2c3[row * 2 + 1];
+    const int L = s >> 2;
+    const int rows_per_block = GN_THREADS / L;
+    const int sub = threadIdx.x % L;
+    const size_t base = ((size_t)b * c + ch) * p;
+    for (int pr = blockIdx.x * rows_per_block + threadIdx.x / L; pr < p; pr += gridDim.x * rows_per_block) {
+        const size_t off = (base + pr) * s + sub * 4;
+        const float4 v = *reinterpret_cast<const float4 *>(x + off);
+        float g = gout[base + pr];
+        if (RELU && !(out[base + pr] > 0.f)) g = 0.f;
+        const int rel = arg[base + pr] - sub * 4;
+        const float ag = a * g;
+        float4 o;
+        o.x = fmaf(c2, v.x, c3) + (rel == 0 ? ag : 0.f);
+        o.y = fmaf(c2, v.y, c3) + (rel == 1 ? ag : 0.f);
+        o.z = fmaf(c2, v.z, c3) + (rel == 2 ? ag : 0.f);
+        o.w = fmaf(c2, v.w, c3) + (rel == 3 ? ag : 0.f);
+        *reinterpret_cast<float4 *>(dx + off) = o;
+    }
+}
+
 int hw_chunks(int b, int c, int hw) {
     // enough workgroups to fill the chip (>= ~2048) without making them tiny (>= 4096 elements each)
     int chunks = 1;
@@ -315,5 +429,87 @@ extern "C" int ogc_group_norm_bwd(int b, int c, int hw, int groups, int relu, co
         hipLaunchKernelGGL(gn_bwd_dx_kernel<false>, grid, dim3(GN_THREADS), 0, s, c, hw, groups, x, gamma, beta, mean,
                            rstd, c2c3, grad_y, grad_x);
     OGC_CHECK_LAUNCH("ogc_group_norm_bwd");
+    return OGC_OK;
+}
+
+static bool gn_pool_shape_ok(int s) { return s >= 4 && s <= 256 && (s & (s - 1)) == 0; }
+
+extern "C" int ogc_group_norm_maxpool_fwd(int b, int c, int p, int s, int groups, float eps, int relu, const float *x,
+                                          const float *gamma, const float *beta, float *out, int *argmax,
+                                          float *mean, float *rstd, double *ws, ogc_stream_t stream) {
+    OGC_REQUIRE(b >= 0 && c >= 1 && p >= 1 && groups >= 1 && c % groups == 0, "ogc_group_norm_maxpool_fwd: bad shape");
+    if (!gn_pool_shape_ok(s) || ((uintptr_t)x & 15) != 0) {
+        ogc_set_error("ogc_group_norm_maxpool_fwd: nsample=%d must be a power of two in [4,256] and x 16-byte aligned", s);
+        return OGC_ERR_UNSUPPORTED;
+    }
+    if (b == 0) return OGC_OK;
+    OGC_REQUIRE(x && gamma && beta && out && argmax && mean && rstd && ws, "ogc_group_norm_maxpool_fwd: null pointer");
+    OGC_REQUIRE((long long)b * c * p * s < (1ll << 31), "ogc_group_norm_maxpool_fwd: tensor exceeds 32-bit indexing");
+    hipStream_t st = (hipStream_t)stream;
+    const int rows = b * groups;
+    const long long row_len = (long long)(c / groups) * p * s;
+    if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * rows, st) != hipSuccess) {
+        ogc_set_error("ogc_group_norm_maxpool_fwd: memset failed");
+        return OGC_ERR_LAUNCH;
+    }
+    int chunks = 1;
+    while ((long long)rows * chunks < 2048 && row_len / (chunks * 2) >= 16384) chunks *= 2;
+    long long chunk_len = (row_len + chunks - 1) / chunks;
+    chunk_len = (chunk_len + 3) / 4 * 4;
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(ogc_divup(row_len, chunk_len), rows), dim3(GN_THREADS), 0, st, row_len,
+                       chunk_len, x, ws);
+    const int rows_per_block = GN_THREADS / (s / 4);
+    int bx = ogc_divup(p, rows_per_block);
+    while (bx > 1 && (long long)bx * c * b > 8192) bx = (bx + 1) / 2;
+    dim3 grid(bx, c, b);
+    if (relu)
+        hipLaunchKernelGGL(gn_apply_maxpool_kernel<true>, grid, dim3(GN_THREADS), 0, st, c, p, s, groups, eps, x, gamma,
+                           beta, ws, out, argmax, mean, rstd);
+    else
+        hipLaunchKernelGGL(gn_apply_maxpool_kernel<false>, grid, dim3(GN_THREADS), 0, st, c, p, s, groups, eps, x,
+                           gamma, beta, ws, out, argmax, mean, rstd);
+    OGC_CHECK_LAUNCH("ogc_group_norm_maxpool_fwd");
+    return OGC_OK;
+}
+
+extern "C" int ogc_group_norm_maxpool_bwd(int b, int c, int p, int s, int groups, int relu, const float *x,
+                                          const float *gamma, const float *mean, const float *rstd, const float *out,
+                                          const int *argmax, const float *grad_out, float *grad_x, float *grad_gamma,
+                                          float *grad_beta, double *ws, ogc_stream_t stream) {
+    OGC_REQUIRE(b >= 0 && c >= 1 && p >= 1 && groups >= 1 && c % groups == 0, "ogc_group_norm_maxpool_bwd: bad shape");
+    if (!gn_pool_shape_ok(s) || (((uintptr_t)x | (uintptr_t)grad_x) & 15) != 0) {
+        ogc_set_error("ogc_group_norm_maxpool_bwd: unsupported nsample=%d or misaligned tensors", s);
+        return OGC_ERR_UNSUPPORTED;
+    }
+    if (b == 0) return OGC_OK;
+    OGC_REQUIRE(x && gamma && mean && rstd && out && argmax && grad_out && grad_x && grad_gamma && grad_beta && ws,
+                "ogc_group_norm_maxpool_bwd: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    double *dsdb = ws;
+    float *c2c3 = reinterpret_cast<float *>(ws + (size_t)2 * b * c);
+    if (hipMemsetAsync(dsdb, 0, sizeof(double) * 2 * b * c, st) != hipSuccess) {
+        ogc_set_error("ogc_group_norm_maxpool_bwd: memset failed");
+        return OGC_ERR_LAUNCH;
+    }
+    dim3 gsum(ogc_divup(p, GN_THREADS * 4) > 0 ? ogc_divup(p, GN_THREADS * 4) : 1, c, b);
+    if (relu)
+        hipLaunchKernelGGL(gn_maxpool_bwd_sums_kernel<true>, gsum, dim3(GN_THREADS), 0, st, c, p, s, x, out, argmax,
+                           grad_out, dsdb);
+    else
+        hipLaunchKernelGGL(gn_maxpool_bwd_sums_kernel<false>, gsum, dim3(GN_THREADS), 0, st, c, p, s, x, out, argmax,
+                           grad_out, dsdb);
+    hipLaunchKernelGGL(gn_bwd_params_kernel, dim3(ogc_divup(c + b * groups, 256)), dim3(256), 0, st, b, c, p * s, groups,
+                       gamma, mean, rstd, dsdb, grad_gamma, grad_beta, c2c3);
+    const int rows_per_block = GN_THREADS / (s / 4);
+    int bx = ogc_divup(p, rows_per_block);
+    while (bx > 1 && (long long)bx * c * b > 8192) bx = (bx + 1) / 2;
+    dim3 grid(bx, c, b);
+    if (relu)
+        hipLaunchKernelGGL(gn_maxpool_bwd_dx_kernel<true>, grid, dim3(GN_THREADS), 0, st, c, p, s, groups, x, gamma, rstd,
+                           c2c3, out, argmax, grad_out, grad_x);
+    else
+        hipLaunchKernelGGL(gn_maxpool_bwd_dx_kernel<false>, grid, dim3(GN_THREADS), 0, st, c, p, s, groups, x, gamma,
+                           rstd, c2c3, out, argmax, grad_out, grad_x);
+    OGC_CHECK_LAUNCH("ogc_group_norm_maxpool_bwd");
     return OGC_OK;
 }

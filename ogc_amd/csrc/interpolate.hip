@@ -59,6 +59,48 @@ __global__ __launch_bounds__(TI_THREADS) void three_interp_bwd_kernel(int c, int
     }
 }
 
+// LDS-privatised variant of the backward: a workgroup owns CC channels x a slice of the n target points,
+// accumulates the three weighted contributions per point into an LDS image acc[CC][m] (ds_add_f32) and merges the
+// non-zero entries into grad_points with one global atomic each (cf. group_bwd_lds_kernel).
+template <int CC>
+__global__ __launch_bounds__(TI_THREADS) void three_interp_bwd_lds_kernel(int c, int n, int m, int n_per_block,
+                                                                          const float *__restrict__ grad_out,
+                                                                          const int *__restrict__ idx,
+                                                                          const float *__restrict__ weight,
+                                                                          float *__restrict__ grad_points) {
+    extern __shared__ __attribute__((aligned(16))) float ti_acc[]; // [CC][m]
+    const int b = blockIdx.z;
+    const int c0 = blockIdx.y * CC;
+    const int ncc = min(CC, c - c0);
+    const int i_begin = blockIdx.x * n_per_block;
+    const int i_end = min(n, i_begin + n_per_block);
+    for (int t = threadIdx.x; t < CC * m; t += TI_THREADS) ti_acc[t] = 0.0f;
+    __syncthreads();
+    const float *g = grad_out + ((size_t)b * c + c0) * n;
+    for (int i = i_begin + threadIdx.x; i < i_end; i += TI_THREADS) {
+        const int *id = idx + ((size_t)b * n + i) * 3;
+        const float *w = weight + ((size_t)b * n + i) * 3;
+        const int i0 = id[0], i1 = id[1], i2 = id[2];
+        const float w0 = w[0], w1 = w[1], w2 = w[2];
+#pragma unroll
+        for (int cc = 0; cc < CC; ++cc) {
+            if (cc < ncc) {
+                const float go = g[(size_t)cc * n + i];
+                float *a = ti_acc + cc * m;
+                atomicAdd(a + i0, __fmul_rn(go, w0));
+                atomicAdd(a + i1, __fmul_rn(go, w1));
+                atomicAdd(a + i2, __fmul_rn(go, w2));
+            }
+        }
+    }
+    __syncthreads();
+    float *gp = grad_points + ((size_t)b * c + c0) * m;
+    for (int t = threadIdx.x; t < ncc * m; t += TI_THREADS) {
+        const float v = ti_acc[t];
+        if (v != 0.0f) unsafeAtomicAdd(gp + t, v);
+    }
+}
+
 int ti_ch_per_block(int b, int c, int blocks_x) {
     int cpb = 1;
     while (cpb < c && (long long)b * blocks_x * ((c + 2 * cpb - 1) / (2 * cpb)) >= 2048) cpb *= 2;
@@ -90,6 +132,27 @@ extern "C" int ogc_three_interpolate_grad(int b, int c, int n, int m, const floa
     OGC_REQUIRE(grad_out && idx && weight && grad_points, "ogc_three_interpolate_grad: null pointer");
     OGC_REQUIRE((long long)b * c * n < (1ll << 31) && (long long)b * c * m < (1ll << 31),
                 "ogc_three_interpolate_grad: tensor exceeds 32-bit indexing");
+    if (m <= 16384 && n >= 1024) { // LDS-privatised path: CC channel images of m floats within 64 KiB
+        int cc = 16384 / m;
+        cc = cc >= 8 ? 8 : (cc >= 4 ? 4 : (cc >= 2 ? 2 : 1));
+        while (cc > 1 && cc / 2 >= c) cc /= 2;
+        const int chunks = ogc_divup(c, cc);
+        int splits = 1;
+        while ((long long)b * chunks * splits < 512 && n / (splits * 2) >= 2048) splits *= 2;
+        const int npb = ogc_divup(n, splits);
+        dim3 grid(ogc_divup(n, npb), chunks, b);
+        const size_t lds = (size_t)cc * m * sizeof(float);
+#define TI_LAUNCH(CCV)                                                                                          \
+    hipLaunchKernelGGL(three_interp_bwd_lds_kernel<CCV>, grid, dim3(TI_THREADS), lds, (hipStream_t)stream, c, n, m, \
+                       npb, grad_out, idx, weight, grad_points)
+        if (cc == 8) TI_LAUNCH(8);
+        else if (cc == 4) TI_LAUNCH(4);
+        else if (cc == 2) TI_LAUNCH(2);
+        else TI_LAUNCH(1);
+#undef TI_LAUNCH
+        OGC_CHECK_LAUNCH("ogc_three_interpolate_grad");
+        return OGC_OK;
+    }
     const int bx = ogc_divup(n, TI_THREADS);
     const int cpb = ti_ch_per_block(b, c, bx);
     dim3 grid(bx, ogc_divup(c, cpb), b);

