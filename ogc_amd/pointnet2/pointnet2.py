@@ -252,10 +252,17 @@ class QueryAndGroup(nn.Module):
         super().__init__()
         self.radius, self.nsample, self.use_xyz = radius, nsample, use_xyz
 
-    def forward(self, xyz: torch.Tensor, new_xyz: torch.Tensor, features: torch.Tensor = None):
+    def forward(self, xyz: torch.Tensor, new_xyz: torch.Tensor, features: torch.Tensor = None, neighbours=None):
         # xyz (B, N, 3), new_xyz (B, npoint, 3), features (B, C, N)
         # -> new_features (B, 3 + C, npoint, nsample), grouped_xyz (B, 3, npoint, nsample)
-        _, idx = knn_radius_clamp(self.nsample, self.radius, new_xyz, xyz)
+        # `neighbours` (optional, not in the reference): an un-clamped (dist, idx) = knn(nsample, new_xyz, xyz) shared
+        # by several groupers of a multi-scale level, which differ only in the radius of the clamp.
+        if neighbours is None:
+            _, idx = knn_radius_clamp(self.nsample, self.radius, new_xyz, xyz)
+        else:
+            dist, idx = neighbours
+            if self.radius is not None:
+                idx = torch.where(dist > self.radius, idx[:, :, :1], idx)
         xyz_trans = xyz.transpose(1, 2).contiguous()
         grouped_xyz = grouping_operation(xyz_trans, idx) - new_xyz.transpose(1, 2).unsqueeze(-1)
 

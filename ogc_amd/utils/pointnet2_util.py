@@ -4,8 +4,8 @@
 import torch
 import torch.nn as nn
 
-from ..pointnet2.pointnet2 import (GroupAll, QueryAndGroup, furthest_point_sample, gather_nd, three_interpolate,
-                                   three_nn)
+from ..pointnet2.pointnet2 import (GroupAll, QueryAndGroup, furthest_point_sample, gather_nd, knn_radius_clamp,
+                                   three_interpolate, three_nn)
 from .nn_util import SharedMLP
 
 
@@ -27,8 +27,18 @@ class _PointnetSAModuleBase(nn.Module):
             new_xyz = gather_nd(xyz, new_inds)  # == gather on the transposed cloud, transposed back (:22-27)
 
         pooled = []
+        shared = {}  # nsample -> un-clamped kNN, computed once per level (the scales only differ in the clamp radius)
+        n_same = {}
+        for grouper in self.groupers:
+            if isinstance(grouper, QueryAndGroup):
+                n_same[grouper.nsample] = n_same.get(grouper.nsample, 0) + 1
         for grouper, mlp in zip(self.groupers, self.mlps):
-            grouped = grouper(xyz, new_xyz, features)[0]      # (B, C', npoint, nsample)
+            if isinstance(grouper, QueryAndGroup) and n_same[grouper.nsample] > 1:
+                if grouper.nsample not in shared:
+                    shared[grouper.nsample] = knn_radius_clamp(grouper.nsample, None, new_xyz, xyz)
+                grouped = grouper(xyz, new_xyz, features, neighbours=shared[grouper.nsample])[0]
+            else:
+                grouped = grouper(xyz, new_xyz, features)[0]  # (B, C', npoint, nsample)
             pooled.append(mlp.forward_maxpool(grouped))       # shared MLP, then max over nsample (:38-42)
         new_features = torch.cat(pooled, dim=1)
         if return_inds:
