@@ -40,22 +40,18 @@ __global__ __launch_bounds__(OGC_WAVE) void ball_query_kernel(int n, int m, floa
         }
     };
     auto all_full = [&]() { return __builtin_amdgcn_ballot_w64(cnt < nsample) == 0; };
-    ogc_scan_candidates(
-        pts, n, cx, cy, cz, tile, lane,
-        [&](const float (&d)[8], int base) {
-            if (__builtin_amdgcn_ballot_w64(ogc_min8_f32(d) < radius2) == 0) return false; // one branch per group
-            unsigned long long mk[8];
-            ogc_masks8(d, radius2, mk);
+    ogc_scan_candidates(pts, n, cx, cy, cz, tile, lane, [&](const float (&d)[8], int base) {
+        if (__builtin_amdgcn_ballot_w64(ogc_min8_f32(d) < radius2) == 0) return false; // one branch per group
+        unsigned long long mk[8];
+        ogc_masks8(d, radius2, mk);
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (mk[u] != 0) try_hit(d[u], base + u); // scalar branch: only candidates some lane hits
-            return all_full();
-        },
-        [&](float d, int k) {
-            if (__builtin_amdgcn_ballot_w64(d < radius2) == 0) return false;
-            try_hit(d, k);
-            return all_full();
-        });
+        for (int u = 0; u < 8; ++u)
+            if (mk[u] != 0) {               // wave-uniform: a scalar branch skips candidates no lane hits
+                asm volatile("" ::: "memory"); // keep it a branch (do not fold into the divergent predicate below)
+                try_hit(d[u], base + u);
+            }
+        return all_full();
+    });
     cnts[lane] = cnt;
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();

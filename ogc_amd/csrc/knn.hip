@@ -116,24 +116,19 @@ __global__ __launch_bounds__(OGC_WAVE) void knn_heap_kernel(int n, int m, int k,
     auto maybe_flush = [&]() {
         if (__builtin_amdgcn_ballot_w64(nbuf > KNN_BUF - KNN_GROUP) != 0) knn_flush(heap, buf, lane, k, hsize, tau, nbuf);
     };
-    ogc_scan_candidates(
-        kn, m, ux, uy, uz, tile, lane,
-        [&](const float (&d)[8], int base) {
-            if (__builtin_amdgcn_ballot_w64(ogc_min8_f32(d) < tau) == 0) return false;
-            unsigned long long mk[8];
-            ogc_masks8(d, tau, mk);
+    ogc_scan_candidates(kn, m, ux, uy, uz, tile, lane, [&](const float (&d)[8], int base) {
+        if (__builtin_amdgcn_ballot_w64(ogc_min8_f32(d) < tau) == 0) return false; // one branch per group
+        unsigned long long mk[8];
+        ogc_masks8(d, tau, mk);
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (mk[u] != 0) try_admit(d[u], base + u); // scalar branch: only candidates some lane admits
-            maybe_flush();
-            return false;
-        },
-        [&](float d, int i) {
-            if (__builtin_amdgcn_ballot_w64(d < tau) == 0) return false;
-            try_admit(d, i);
-            maybe_flush();
-            return false;
-        });
+        for (int u = 0; u < 8; ++u)
+            if (mk[u] != 0) {               // wave-uniform: a scalar branch skips candidates no lane admits
+                asm volatile("" ::: "memory");
+                try_admit(d[u], base + u);
+            }
+        maybe_flush();
+        return false;
+    });
     knn_flush(heap, buf, lane, k, hsize, tau, nbuf);
 
     // heap sort in place: ascending (dist, index) in heap[0..hsize)
@@ -207,21 +202,18 @@ __global__ __launch_bounds__(OGC_WAVE) void three_nn_kernel(int n, int m, const 
         b1 = c1 ? d : b1;
         i1 = c1 ? i : i1;
     };
-    ogc_scan_candidates(
-        kn, m, ux, uy, uz, tile, lane,
-        [&](const float (&d)[8], int base) {
-            if (__builtin_amdgcn_ballot_w64(ogc_min8_f32(d) < b3) == 0) return false;
-            unsigned long long mk[8];
-            ogc_masks8(d, b3, mk); // b3 only shrinks, so a candidate outside the mask can never enter later
+    ogc_scan_candidates(kn, m, ux, uy, uz, tile, lane, [&](const float (&d)[8], int base) {
+        if (__builtin_amdgcn_ballot_w64(ogc_min8_f32(d) < b3) == 0) return false;
+        unsigned long long mk[8];
+        ogc_masks8(d, b3, mk); // b3 only shrinks, so a candidate outside its mask can never enter later
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (mk[u] != 0) update(d[u], base + u);
-            return false;
-        },
-        [&](float d, int i) {
-            update(d, i);
-            return false;
-        });
+        for (int u = 0; u < 8; ++u)
+            if (mk[u] != 0) {
+                asm volatile("" ::: "memory");
+                update(d[u], base + u);
+            }
+        return false;
+    });
     if (q < n) {
         float *o = dist2 + ((size_t)b * n + q) * 3;
         int *oi = idx + ((size_t)b * n + q) * 3;

@@ -59,21 +59,6 @@ __device__ __forceinline__ float ogc_min8_f32(const float (&d)[8]) {
     return ogc_min_f32(ogc_min3_f32(ogc_min3_f32(d[0], d[1], d[2]), d[3], d[4]), ogc_min3_f32(d[5], d[6], d[7]));
 }
 
-// ---- all-pairs scan engine shared by kNN / three-NN / ball query ---------------------------------------------
-// Streams the `n` candidate points of a cloud (AoS xyz) past the lane's query point (qx, qy, qz).  One wavefront
-// per workgroup, so everything below is wave-synchronous (LDS operations of one wave complete in issue order; no
-// barriers).
-//   * Candidates are staged through a 6 KiB LDS tile (OGC_TILE points): the wave loads the NEXT tile from global
-//     memory into registers with coalesced 16-byte loads while it scans the current one, so HBM/L2 latency is
-//     off the critical path.  (A first version fed the candidates through scalar loads / SGPR operands; one wave
-//     can only keep one scalar request in flight and the ~800-cycle round trip per 8 candidates bounded the scan.)
-//   * Every lane reads the same LDS address (broadcast ds_read_b128, conflict-free), eight candidates = 96 B at a
-//     time, and the next group's reads are issued before the current group is evaluated.
-//   * The eight squared distances are evaluated as eight independent chains in stage-major order: a dependent
-//     VALU op issues only every ~8 cycles per wave on gfx950 (measured, tools/clock_probe.hip) and these kernels
-//     run at 1-2 waves per SIMD, so instruction-level parallelism is what fills the pipe.
-//   group(d, base)  : called with the 8 squared distances of candidates base..base+7; returns true to stop.
-//   single(d, idx)  : called for the < 8 tail candidates; returns true to stop.
 // Wave-level masks of "d[u] < thr" for the eight candidates of a group: eight independent v_cmp (no serial
 // dependence), after which the per-candidate slow paths are guarded by cheap scalar branches.
 __device__ __forceinline__ void ogc_masks8(const float (&d)[8], float thr, unsigned long long (&mk)[8]) {
@@ -81,96 +66,118 @@ __device__ __forceinline__ void ogc_masks8(const float (&d)[8], float thr, unsig
     for (int u = 0; u < 8; ++u) mk[u] = __builtin_amdgcn_ballot_w64(d[u] < thr);
 }
 
+// ---- all-pairs scan engine shared by kNN / three-NN / ball query ---------------------------------------------
+// Streams the `n` candidate points of a cloud (AoS xyz) past the lane's query point (qx, qy, qz).  One wavefront
+// per workgroup, so everything below is wave-synchronous (LDS operations of one wave complete in issue order; no
+// barriers).  What the PMC counters say about these kernels (rocprofv3, ball query): a wave issues one instruction
+// per 4 cycles whatever its kind, a dependent VALU op issues every 8, and LDS footprints keep occupancy at
+// 1-2 waves per SIMD — so the scan is bounded by INSTRUCTIONS PER CANDIDATE, not by memory.  Hence:
+//   * candidates are staged through a 6 KiB LDS tile stored as SoA (x[512] | y[512] | z[512]); the wave fetches the
+//     NEXT tile from global memory (12-byte loads, one point per lane, coalesced) while it scans the current one;
+//   * a group of eight candidates = six broadcast ds_read_b128 (every lane reads the same address); thanks to the
+//     SoA layout consecutive registers hold the same coordinate of neighbouring candidates, so the distance
+//     arithmetic runs as packed fp32 (v_pk_add/v_pk_mul, two candidates per instruction, same IEEE results);
+//   * the eight distances are independent chains, the next group's reads are issued before the current group is
+//     evaluated, and the whole group is tested with ONE wave-level branch.
+// Slots past the end of the cloud are filled with +inf coordinates: their distance is +inf (or NaN) and can never
+// satisfy a strict `<` test, so callers need no tail handling.
+//   group(d, base) : called with the 8 squared distances of candidates base..base+7; returns true to stop.
 constexpr int OGC_TILE = 512;                 // candidates per tile
 constexpr int OGC_TILE_FLOATS = OGC_TILE * 3; // 1536 floats = 6 KiB
 
-__device__ __forceinline__ void ogc_dist8(const float4 (&c)[6], float qx, float qy, float qz, float (&d)[8]) {
-    const float x[8] = {c[0].x, c[0].w, c[1].z, c[2].y, c[3].x, c[3].w, c[4].z, c[5].y};
-    const float y[8] = {c[0].y, c[1].x, c[1].w, c[2].z, c[3].y, c[4].x, c[4].w, c[5].z};
-    const float z[8] = {c[0].z, c[1].y, c[2].x, c[2].w, c[3].z, c[4].y, c[5].x, c[5].w};
-    float dx[8], dy[8], dz[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) dx[u] = __fsub_rn(qx, x[u]);
-#pragma unroll
-    for (int u = 0; u < 8; ++u) dy[u] = __fsub_rn(qy, y[u]);
-#pragma unroll
-    for (int u = 0; u < 8; ++u) dz[u] = __fsub_rn(qz, z[u]);
-#pragma unroll
-    for (int u = 0; u < 8; ++u) dx[u] = __fmul_rn(dx[u], dx[u]);
-#pragma unroll
-    for (int u = 0; u < 8; ++u) dy[u] = __fmul_rn(dy[u], dy[u]);
-#pragma unroll
-    for (int u = 0; u < 8; ++u) dz[u] = __fmul_rn(dz[u], dz[u]);
-#pragma unroll
-    for (int u = 0; u < 8; ++u) d[u] = __fadd_rn(dx[u], dy[u]);
-#pragma unroll
-    for (int u = 0; u < 8; ++u) d[u] = __fadd_rn(d[u], dz[u]);
+typedef float ogc_v2f __attribute__((ext_vector_type(2)));
+
+struct OgcGroup { // eight candidates, SoA
+    float4 x0, x1, y0, y1, z0, z1;
+};
+
+__device__ __forceinline__ void ogc_group_read(const float *tile, int g, OgcGroup &c) {
+    const float4 *tx = reinterpret_cast<const float4 *>(tile) + 2 * g;
+    const float4 *ty = reinterpret_cast<const float4 *>(tile + OGC_TILE) + 2 * g;
+    const float4 *tz = reinterpret_cast<const float4 *>(tile + 2 * OGC_TILE) + 2 * g;
+    c.x0 = tx[0]; c.x1 = tx[1];
+    c.y0 = ty[0]; c.y1 = ty[1];
+    c.z0 = tz[0]; c.z1 = tz[1];
 }
 
-// Loads tile `t` (floats [t*1536, t*1536+1536) of the cloud, clipped to nfloats) into registers:
-// lane l holds float4 #(i*64 + l), i = 0..5.  ALIGNED: the cloud base is 16-byte aligned.
-template <bool ALIGNED>
-__device__ __forceinline__ void ogc_tile_fetch(const float *__restrict__ pts, int nfloats, int t, int lane,
-                                               float4 (&r)[6]) {
-    const int base = t * OGC_TILE_FLOATS;
+__device__ __forceinline__ void ogc_dist8(const OgcGroup &c, float qx, float qy, float qz, float (&d)[8]) {
+#pragma clang fp contract(off)
+    const ogc_v2f q2x = {qx, qx}, q2y = {qy, qy}, q2z = {qz, qz};
+    const ogc_v2f X[4] = {{c.x0.x, c.x0.y}, {c.x0.z, c.x0.w}, {c.x1.x, c.x1.y}, {c.x1.z, c.x1.w}};
+    const ogc_v2f Y[4] = {{c.y0.x, c.y0.y}, {c.y0.z, c.y0.w}, {c.y1.x, c.y1.y}, {c.y1.z, c.y1.w}};
+    const ogc_v2f Z[4] = {{c.z0.x, c.z0.y}, {c.z0.z, c.z0.w}, {c.z1.x, c.z1.y}, {c.z1.z, c.z1.w}};
+    ogc_v2f dx[4], dy[4], dz[4], s[4];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        const int f = base + (i * OGC_WAVE + lane) * 4;
-        if (ALIGNED && f + 3 < nfloats) {
-            r[i] = *reinterpret_cast<const float4 *>(pts + f);
+    for (int u = 0; u < 4; ++u) dx[u] = q2x - X[u];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) dy[u] = q2y - Y[u];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) dz[u] = q2z - Z[u];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) dx[u] = dx[u] * dx[u];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) dy[u] = dy[u] * dy[u];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) dz[u] = dz[u] * dz[u];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s[u] = dx[u] + dy[u];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s[u] = s[u] + dz[u];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        d[2 * u] = s[u].x;
+        d[2 * u + 1] = s[u].y;
+    }
+}
+
+// Fetch tile `t` into registers: lane l holds points t*512 + i*64 + l, i = 0..7 (+inf beyond the cloud).
+__device__ __forceinline__ void ogc_tile_fetch(const float *__restrict__ pts, int n, int t, int lane,
+                                               float (&r)[8][3]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int p = t * OGC_TILE + i * OGC_WAVE + lane;
+        if (p < n) {
+            const float *q = pts + (size_t)p * 3;
+            r[i][0] = q[0]; r[i][1] = q[1]; r[i][2] = q[2];
         } else {
-            r[i].x = f + 0 < nfloats ? pts[f + 0] : 0.0f;
-            r[i].y = f + 1 < nfloats ? pts[f + 1] : 0.0f;
-            r[i].z = f + 2 < nfloats ? pts[f + 2] : 0.0f;
-            r[i].w = f + 3 < nfloats ? pts[f + 3] : 0.0f;
+            r[i][0] = r[i][1] = r[i][2] = INFINITY;
         }
     }
 }
 
-template <bool ALIGNED, class Group, class Single>
-__device__ __forceinline__ void ogc_scan_tiles(const float *__restrict__ pts, int n, float qx, float qy, float qz,
-                                               float *tile, int lane, Group &&group, Single &&single) {
-    const int nfloats = n * 3;
+template <class Group>
+__device__ __forceinline__ void ogc_scan_candidates(const float *__restrict__ pts, int n, float qx, float qy,
+                                                    float qz, float *tile, int lane, Group &&group) {
     const int ntiles = (n + OGC_TILE - 1) / OGC_TILE;
-    float4 *tile4 = reinterpret_cast<float4 *>(tile);
-    float4 pre[6];
-    if (ntiles > 0) ogc_tile_fetch<ALIGNED>(pts, nfloats, 0, lane, pre);
+    float pre[8][3];
+    if (ntiles > 0) ogc_tile_fetch(pts, n, 0, lane, pre);
     bool stop = false;
     for (int t = 0; t < ntiles && !stop; ++t) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) tile4[i * OGC_WAVE + lane] = pre[i];
-        if (t + 1 < ntiles) ogc_tile_fetch<ALIGNED>(pts, nfloats, t + 1, lane, pre); // in flight during the scan
+        for (int i = 0; i < 8; ++i) {
+            tile[i * OGC_WAVE + lane] = pre[i][0];
+            tile[OGC_TILE + i * OGC_WAVE + lane] = pre[i][1];
+            tile[2 * OGC_TILE + i * OGC_WAVE + lane] = pre[i][2];
+        }
+        if (t + 1 < ntiles) ogc_tile_fetch(pts, n, t + 1, lane, pre); // in flight during the scan
         const int cnt = min(OGC_TILE, n - t * OGC_TILE);
-        const int ngroups = cnt >> 3;
+        const int ngroups = (cnt + 7) >> 3;   // the last group may contain +inf padding
         const int base = t * OGC_TILE;
-        float4 c[6], nx[6];
-        if (ngroups > 0) {
-#pragma unroll
-            for (int i = 0; i < 6; ++i) c[i] = tile4[i];
-        }
-        for (int g = 0; g < ngroups && !stop; ++g) {
-            const int gn = min(g + 1, ngroups - 1) * 6; // clamped LDS prefetch of the next group
-#pragma unroll
-            for (int i = 0; i < 6; ++i) nx[i] = tile4[gn + i];
+        OgcGroup ga, gb;
+        ogc_group_read(tile, 0, ga);
+        // two groups per iteration with ping-pong registers: no copies, next group's reads ahead of the math
+        for (int g = 0; g < ngroups && !stop; g += 2) {
             float d[8];
-            ogc_dist8(c, qx, qy, qz, d);
+            ogc_group_read(tile, min(g + 1, OGC_TILE / 8 - 1), gb);
+            ogc_dist8(ga, qx, qy, qz, d);
             stop = group(d, base + g * 8);
-#pragma unroll
-            for (int i = 0; i < 6; ++i) c[i] = nx[i];
+            if (g + 1 < ngroups && !stop) {
+                ogc_group_read(tile, min(g + 2, OGC_TILE / 8 - 1), ga);
+                ogc_dist8(gb, qx, qy, qz, d);
+                stop = group(d, base + g * 8 + 8);
+            }
         }
-        for (int k = ngroups * 8; k < cnt && !stop; ++k)
-            stop = single(ogc_sqdist(qx, qy, qz, tile[3 * k], tile[3 * k + 1], tile[3 * k + 2]), base + k);
     }
-}
-
-template <class Group, class Single>
-__device__ __forceinline__ void ogc_scan_candidates(const float *__restrict__ pts, int n, float qx, float qy,
-                                                    float qz, float *tile, int lane, Group &&group,
-                                                    Single &&single) {
-    if ((reinterpret_cast<uintptr_t>(pts) & 15) == 0)
-        ogc_scan_tiles<true>(pts, n, qx, qy, qz, tile, lane, group, single);
-    else
-        ogc_scan_tiles<false>(pts, n, qx, qy, qz, tile, lane, group, single);
 }
 
 // ---- DPP cross-lane helpers (wave64) ---------------------------------------------------------

@@ -83,6 +83,24 @@ class DynamicLoss(nn.Module):
         blended = (mask_t.unsqueeze(-1) * pc_transformed).sum(1)
         return (blended - pc2).norm(p=self.loss_norm, dim=-1).mean()
 
+    def forward_views(self, pcs, masks, flows):
+        """The per-view losses [forward(pc_v, mask_v, flow_v) for v] computed with ONE batched Kabsch fit over all
+        views (the views are independent samples, so concatenating them along the batch changes no value)."""
+        n_view, n_batch = len(pcs), pcs[0].shape[0]
+        pc, mask, flow = torch.cat(pcs), torch.cat(masks), torch.cat(flows)
+        n_point, n_object = mask.shape[1], mask.shape[2]
+        pc2 = pc + flow
+        mask_t = mask.transpose(1, 2)
+        pc_rep = pc.unsqueeze(1).expand(-1, n_object, -1, -1).reshape(-1, n_point, 3)
+        pc2_rep = pc2.unsqueeze(1).expand(-1, n_object, -1, -1).reshape(-1, n_point, 3)
+        with torch.no_grad():
+            object_R, object_t = fit_motion_svd_batch(pc_rep, pc2_rep, mask_t.reshape(-1, n_point))
+            pc_transformed = torch.einsum('bij,bnj->bni', object_R, pc_rep) + object_t.unsqueeze(1)
+            pc_transformed = pc_transformed.reshape(-1, n_object, n_point, 3)
+        blended = (mask_t.unsqueeze(-1) * pc_transformed).sum(1)
+        per_point = (blended - pc2).norm(p=self.loss_norm, dim=-1)                  # (V*B, N)
+        return list(per_point.view(n_view, n_batch * n_point).mean(dim=1))
+
 
 def _neighbour_consistency(mask, idx, k, cross_entropy, loss_norm):
     """mask (B, K, N) vs its values at neighbour indices idx (B, N, k). Reference: :123-129, :152-158."""
@@ -93,6 +111,17 @@ def _neighbour_consistency(mask, idx, k, cross_entropy, loss_norm):
     else:
         loss = (mask.unsqueeze(3) - nn_mask).norm(p=loss_norm, dim=1).mean(dim=-1)
     return loss.mean()
+
+
+def _neighbour_consistency_views(mask, idx, k, cross_entropy, loss_norm, n_view):
+    """Same as _neighbour_consistency for `n_view` views concatenated along the batch: one value per view."""
+    nn_mask = grouping_operation(mask, idx.detach())
+    if cross_entropy:
+        target = mask.unsqueeze(3).expand(-1, -1, -1, k).detach()
+        loss = F.binary_cross_entropy(nn_mask, target, reduction='none').sum(dim=1).mean(dim=-1)
+    else:
+        loss = (mask.unsqueeze(3) - nn_mask).norm(p=loss_norm, dim=1).mean(dim=-1)   # (V*B, N)
+    return loss.view(n_view, -1).mean(dim=1)
 
 
 class KnnLoss(nn.Module):
@@ -140,6 +169,19 @@ class SmoothLoss(nn.Module):
 
     def forward(self, pc, mask):
         return (self.w_knn * self.knn_loss(pc, mask)) + (self.w_ball_q * self.ball_q_loss(pc, mask))
+
+    def forward_views(self, pcs, masks):
+        """[forward(pc_v, mask_v) for v] with ONE kNN and ONE ball-query launch over all views (B*V clouds fill the
+        GPU far better than V launches of B clouds)."""
+        n_view = len(pcs)
+        pc = torch.cat(pcs).contiguous()
+        mask = torch.cat(masks).permute(0, 2, 1).contiguous()
+        kl, bl = self.knn_loss, self.ball_q_loss
+        _, idx = knn_radius_clamp(kl.k, kl.radius, pc, pc)
+        l_knn = _neighbour_consistency_views(mask, idx, kl.k, kl.cross_entropy, kl.loss_norm, n_view)
+        idx = ball_query(bl.radius, bl.k, pc, pc)
+        l_ball = _neighbour_consistency_views(mask, idx, bl.k, bl.cross_entropy, bl.loss_norm, n_view)
+        return list(self.w_knn * l_knn + self.w_ball_q * l_ball)
 
 
 def interpolate_mask_by_flow(pc1, pc2, mask1, flow1, k=1):
@@ -249,11 +291,17 @@ class UnsupervisedOGCLoss(nn.Module):
             return out
 
         terms = {}
-        l_dynamic = total([self.dynamic_loss(p, m, f) for p, m, f in zip(pcs, masks, flows)])
+        if hasattr(self.dynamic_loss, "forward_views"):
+            l_dynamic = total(self.dynamic_loss.forward_views(pcs, masks, flows))
+        else:
+            l_dynamic = total([self.dynamic_loss(p, m, f) for p, m, f in zip(pcs, masks, flows)])
         terms['dynamic'] = l_dynamic
         loss = weight(self.w_dynamic, self.start_step_dynamic) * l_dynamic
 
-        l_smooth = total([self.smooth_loss(p, m) for p, m in zip(pcs, masks)])
+        if hasattr(self.smooth_loss, "forward_views"):
+            l_smooth = total(self.smooth_loss.forward_views(pcs, masks))
+        else:
+            l_smooth = total([self.smooth_loss(p, m) for p, m in zip(pcs, masks)])
         terms['smooth'] = l_smooth
         loss = loss + weight(self.w_smooth, self.start_step_smooth) * l_smooth
 
