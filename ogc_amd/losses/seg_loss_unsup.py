@@ -170,17 +170,26 @@ class SmoothLoss(nn.Module):
     def forward(self, pc, mask):
         return (self.w_knn * self.knn_loss(pc, mask)) + (self.w_ball_q * self.ball_q_loss(pc, mask))
 
-    def forward_views(self, pcs, masks):
-        """[forward(pc_v, mask_v) for v] with ONE kNN and ONE ball-query launch over all views (B*V clouds fill the
-        GPU far better than V launches of B clouds)."""
-        n_view = len(pcs)
-        pc = torch.cat(pcs).contiguous()
-        mask = torch.cat(masks).permute(0, 2, 1).contiguous()
+    def plan_views(self, pcs):
+        """Neighbour indices of all views (coordinates only; may run ahead on a side stream): ONE kNN and ONE
+        ball-query launch over the concatenated views (B*V clouds fill the GPU far better than V launches of B)."""
+        pc = torch.cat(list(pcs)).contiguous()
         kl, bl = self.knn_loss, self.ball_q_loss
-        _, idx = knn_radius_clamp(kl.k, kl.radius, pc, pc)
-        l_knn = _neighbour_consistency_views(mask, idx, kl.k, kl.cross_entropy, kl.loss_norm, n_view)
-        idx = ball_query(bl.radius, bl.k, pc, pc)
-        l_ball = _neighbour_consistency_views(mask, idx, bl.k, bl.cross_entropy, bl.loss_norm, n_view)
+        _, idx_knn = knn_radius_clamp(kl.k, kl.radius, pc, pc)
+        idx_ball = ball_query(bl.radius, bl.k, pc, pc)
+        return {"knn": idx_knn, "ball": idx_ball}
+
+    def forward_views(self, pcs, masks, geometry=None):
+        """[forward(pc_v, mask_v) for v], evaluated on the views concatenated along the batch."""
+        n_view = len(pcs)
+        if geometry is None:
+            geometry = self.plan_views(pcs)
+        elif hasattr(geometry, "get"):
+            geometry = geometry.get()
+        mask = torch.cat(list(masks)).permute(0, 2, 1).contiguous()
+        kl, bl = self.knn_loss, self.ball_q_loss
+        l_knn = _neighbour_consistency_views(mask, geometry["knn"], kl.k, kl.cross_entropy, kl.loss_norm, n_view)
+        l_ball = _neighbour_consistency_views(mask, geometry["ball"], bl.k, bl.cross_entropy, bl.loss_norm, n_view)
         return list(self.w_knn * l_knn + self.w_ball_q * l_ball)
 
 
@@ -198,18 +207,38 @@ def interpolate_mask_by_flow(pc1, pc2, mask1, flow1, k=1):
     return out.transpose(1, 2)
 
 
-def match_mask_by_iou(mask1, mask2):
-    """Hungarian matching of the hard segmentations by IoU -> permutation matrices (B, K, K).
-    Reference: :212-240 (scipy on the host; here with one device->host copy for the whole batch)."""
-    n_batch, _, n_object = mask1.size()
+def _iou_matrix(mask1, mask2):
+    """Pairwise IoU (B, K, K) of the hard (arg-max) segmentations. Reference: :220-233."""
+    n_object = mask1.size(2)
     eye = torch.eye(n_object, dtype=torch.float32, device=mask1.device)
     onehot1 = eye[mask1.argmax(-1).detach()]
     onehot2 = eye[mask2.argmax(-1).detach()]
     intersection = torch.einsum('bng,bnp->bgp', onehot1, onehot2)
     union = onehot1.sum(dim=1).unsqueeze(-1) + onehot2.sum(dim=1, keepdim=True) - intersection
-    iou = (intersection / union.clamp(1e-10)).cpu().numpy()
-    perm = np.stack([linear_sum_assignment(iou[b], maximize=True)[1] for b in range(n_batch)], 0)
-    return eye[torch.from_numpy(perm).to(mask1.device)]
+    return intersection / union.clamp(1e-10)
+
+
+def _hungarian_perm(iou_np, eye):
+    """scipy Hungarian per sample (maximising IoU) -> permutation matrices. Reference: :234-239."""
+    perm = np.stack([linear_sum_assignment(m, maximize=True)[1] for m in iou_np], 0)
+    return eye[torch.from_numpy(perm).to(eye.device)]
+
+
+def match_mask_by_iou(mask1, mask2):
+    """Hungarian matching of the hard segmentations by IoU -> permutation matrices (B, K, K).
+    Reference: :212-240 (scipy on the host; here with one device->host copy for the whole batch)."""
+    eye = torch.eye(mask1.size(2), dtype=torch.float32, device=mask1.device)
+    return _hungarian_perm(_iou_matrix(mask1, mask2).cpu().numpy(), eye)
+
+
+def match_mask_pairs_both_ways(pairs):
+    """For every (mask_a, mask_b): (match_mask_by_iou(a, b), match_mask_by_iou(b, a)) — the IoU of the reverse
+    direction is the transpose — with ONE device->host copy for all pairs (the reference syncs once per sample and
+    direction)."""
+    ious = torch.stack([_iou_matrix(a, b) for a, b in pairs])                 # (P, B, K, K)
+    host = ious.cpu().numpy()
+    eye = torch.eye(pairs[0][0].size(2), dtype=torch.float32, device=pairs[0][0].device)
+    return [(_hungarian_perm(h, eye), _hungarian_perm(np.ascontiguousarray(h.transpose(0, 2, 1)), eye)) for h in host]
 
 
 class InvarianceLoss(nn.Module):
@@ -227,12 +256,19 @@ class InvarianceLoss(nn.Module):
             loss = (mask1 - mask2).norm(p=self.loss_norm, dim=-1)
         return loss.mean()
 
-    def forward(self, mask1, mask2):
-        perm2 = match_mask_by_iou(mask1, mask2)
+    def _from_perms(self, mask1, mask2, perm2, perm1):
         target_mask1 = torch.einsum('bij,bnj->bni', perm2, mask2).detach()
-        perm1 = match_mask_by_iou(mask2, mask1)
         target_mask2 = torch.einsum('bij,bnj->bni', perm1, mask1).detach()
         return self.distance(mask1, target_mask1) + self.distance(mask2, target_mask2)
+
+    def forward(self, mask1, mask2):
+        (perm2, perm1), = match_mask_pairs_both_ways([(mask1, mask2)])
+        return self._from_perms(mask1, mask2, perm2, perm1)
+
+    def forward_pairs(self, pairs):
+        """[forward(a, b) for (a, b) in pairs] with a single host round trip for all Hungarian matchings."""
+        perms = match_mask_pairs_both_ways(pairs)
+        return [self._from_perms(a, b, p2, p1) for (a, b), (p2, p1) in zip(pairs, perms)]
 
 
 class EntropyLoss(nn.Module):
@@ -273,7 +309,14 @@ class UnsupervisedOGCLoss(nn.Module):
     def step_lossw(self, it, weight, start_step=0):
         return 0 if it < start_step else weight
 
-    def forward(self, pcs, masks, flows, step_w=False, it=0, aug_transform=False):
+    def plan_geometry(self, pcs, aug_transform=False):
+        """Coordinate-only part of the loss (neighbour searches of the smooth term) for forward(..., geometry=...)."""
+        n_view = 4 if aug_transform else 2
+        if hasattr(self.smooth_loss, "plan_views"):
+            return self.smooth_loss.plan_views(list(pcs)[:n_view])
+        return None
+
+    def forward(self, pcs, masks, flows, step_w=False, it=0, aug_transform=False, geometry=None):
         # pcs / masks / flows: lists of 2 (or 4 with aug_transform) tensors (B, N, 3) / (B, N, K) / (B, N, 3)
         assert len(pcs) == len(masks) == len(flows), "Inconsistent number of frames!"
         n_view = 4 if aug_transform else 2
@@ -299,14 +342,18 @@ class UnsupervisedOGCLoss(nn.Module):
         loss = weight(self.w_dynamic, self.start_step_dynamic) * l_dynamic
 
         if hasattr(self.smooth_loss, "forward_views"):
-            l_smooth = total(self.smooth_loss.forward_views(pcs, masks))
+            l_smooth = total(self.smooth_loss.forward_views(pcs, masks, geometry))
         else:
             l_smooth = total([self.smooth_loss(p, m) for p, m in zip(pcs, masks)])
         terms['smooth'] = l_smooth
         loss = loss + weight(self.w_smooth, self.start_step_smooth) * l_smooth
 
         if aug_transform:
-            l_invariance = self.invariance_loss(masks[0], masks[2]) + self.invariance_loss(masks[1], masks[3])
+            if hasattr(self.invariance_loss, "forward_pairs"):
+                inv_a, inv_b = self.invariance_loss.forward_pairs([(masks[0], masks[2]), (masks[1], masks[3])])
+                l_invariance = inv_a + inv_b
+            else:
+                l_invariance = self.invariance_loss(masks[0], masks[2]) + self.invariance_loss(masks[1], masks[3])
             terms['invariance'] = l_invariance
             loss = loss + weight(self.w_invariance, self.start_step_invariance) * l_invariance
 

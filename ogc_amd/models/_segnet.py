@@ -41,16 +41,50 @@ class MaskFormer3DBase(nn.Module):
             transformer_hidden_dim=transformer_embed_dim, input_pos_enc=transformer_input_pos_enc)
         self.object_mlp = Seq(transformer_embed_dim).conv1d(transformer_embed_dim, bn=bn).conv1d(64, activation=None)
 
+    overlap_geometry = True  # run the coordinate-only work (FPS, kNN, 3-NN) on a side stream on the GPU
+
+    def _plan(self, pc):
+        """Geometry of all levels, in dependency order (each level samples from the previous level's centres)."""
+        sa_plans, l_pc = [], [pc]
+        for sa in self.SA_modules:
+            g = sa.plan_geometry(l_pc[-1])
+            sa_plans.append(g)
+            l_pc.append(g["new_xyz"])
+        fp_plans = [fp.plan_geometry(l_pc[i], l_pc[i + 1]) for i, fp in enumerate(self.FP_modules)]
+        return sa_plans, fp_plans
+
     def forward(self, pc, point_feats):
         # pc (B, N, 3), point_feats (B, N, 3) -> mask (B, N, K)
+        n_sa, n_fp = len(self.SA_modules), len(self.FP_modules)
+        sa_geo, fp_geo = [None] * n_sa, [None] * n_fp
+        if pc.is_cuda and self.overlap_geometry:
+            from ..utils.streams import Pending, launch_on_side, side_stream
+            stream = side_stream(pc.device, "segnet-geometry")
+            main = torch.cuda.current_stream()
+            stream.wait_stream(main)
+            with torch.cuda.stream(stream):  # one event per level so that SA1 can start as soon as ITS plan is ready
+                l_last = pc
+                for i, sa in enumerate(self.SA_modules):
+                    g = sa.plan_geometry(l_last)
+                    ev = torch.cuda.Event()
+                    ev.record(stream)
+                    sa_geo[i] = Pending(g, ev)
+                    l_last = g["new_xyz"]
+                cents = [pc] + [p._value["new_xyz"] for p in sa_geo]
+                for i, fp in enumerate(self.FP_modules):
+                    g = fp.plan_geometry(cents[i], cents[i + 1])
+                    ev = torch.cuda.Event()
+                    ev.record(stream)
+                    fp_geo[i] = Pending(g, ev)
+
         l_pc, l_feats = [pc], [point_feats.transpose(1, 2).contiguous()]
-        for sa in self.SA_modules:
-            li_pc, li_feats = sa(l_pc[-1], l_feats[-1])
+        for i, sa in enumerate(self.SA_modules):
+            li_pc, li_feats = sa(l_pc[-1], l_feats[-1], geometry=sa_geo[i])
             l_pc.append(li_pc)
             l_feats.append(li_feats)
         # decoder: coarsest -> finest, FP_modules[i] produces level i
-        for i in range(len(self.FP_modules) - 1, -1, -1):
-            l_feats[i] = self.FP_modules[i](l_pc[i], l_pc[i + 1], l_feats[i], l_feats[i + 1])
+        for i in range(n_fp - 1, -1, -1):
+            l_feats[i] = self.FP_modules[i](l_pc[i], l_pc[i + 1], l_feats[i], l_feats[i + 1], geometry=fp_geo[i])
 
         slot = self.MF_head(l_feats[-1].transpose(1, 2), l_pc[-1])        # (B, K, D)
         slot = self.object_mlp(slot.transpose(1, 2))                      # (B, 64, K)

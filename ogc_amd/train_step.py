@@ -37,11 +37,19 @@ def train_step(segnet, criterion, optimizer, batch, it, aug_transform):
     pcs, segms, flows, _ = batch
     b, t, n = segms.size()
     flat = pcs.view(b * t, n, -1).contiguous()
-    masks = segnet(flat, flat).view(b, t, n, -1)
     pcs_l = [pcs[:, tt].contiguous() for tt in range(t)]
-    masks_l = [masks[:, tt].contiguous() for tt in range(t)]
     flows_l = [flows[:, tt].contiguous() for tt in range(t)]
-    loss, loss_dict = criterion(pcs_l, masks_l, flows_l, step_w=True, it=it * b, aug_transform=aug_transform)
+    loss_geometry = None
+    if pcs.is_cuda and hasattr(criterion, "plan_geometry"):
+        # the smooth term's neighbour searches depend on coordinates only: start them now on a side stream so they
+        # overlap the network's forward pass instead of serialising after it
+        from .utils.streams import launch_on_side, side_stream
+        loss_geometry = launch_on_side(side_stream(pcs.device, "loss-geometry"),
+                                       lambda: criterion.plan_geometry(pcs_l, aug_transform))
+    masks = segnet(flat, flat).view(b, t, n, -1)
+    masks_l = [masks[:, tt].contiguous() for tt in range(t)]
+    kw = {"geometry": loss_geometry} if loss_geometry is not None else {}
+    loss, loss_dict = criterion(pcs_l, masks_l, flows_l, step_w=True, it=it * b, aug_transform=aug_transform, **kw)
     loss.backward()
     grads = [p.grad for p in segnet.parameters() if p.grad is not None]
     bad = torch.isnan(torch.stack(torch._foreach_norm(grads)).sum())  # NaN anywhere -> NaN norm

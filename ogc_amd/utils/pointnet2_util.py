@@ -19,24 +19,35 @@ class _PointnetSAModuleBase(nn.Module):
         self.groupers = None
         self.mlps = None
 
-    def forward(self, xyz, features=None, return_inds=False):
+    def plan_geometry(self, xyz):
+        """Everything of this level that depends on coordinates only: FPS indices, the sampled centres and the
+        un-clamped kNN of every neighbourhood size in use (the scales of a multi-scale level differ only in the
+        radius of the clamp, so one search serves them all).  May be evaluated ahead of time on a side stream."""
+        if self.npoint is None:
+            return None
+        new_inds = furthest_point_sample(xyz, self.npoint).long()
+        new_xyz = gather_nd(xyz, new_inds)  # == gather on the transposed cloud, transposed back (:22-27)
+        knn = {}
+        for grouper in self.groupers:
+            if isinstance(grouper, QueryAndGroup) and grouper.nsample not in knn:
+                knn[grouper.nsample] = knn_radius_clamp(grouper.nsample, None, new_xyz, xyz)
+        return {"new_inds": new_inds, "new_xyz": new_xyz, "knn": knn}
+
+    def forward(self, xyz, features=None, return_inds=False, geometry=None):
         # xyz (B, N, 3), features (B, C, N) -> new_xyz (B, npoint, 3), new_features (B, sum(mlp[-1]), npoint)
-        new_xyz, new_inds = None, None
-        if self.npoint is not None:
-            new_inds = furthest_point_sample(xyz, self.npoint).long()
-            new_xyz = gather_nd(xyz, new_inds)  # == gather on the transposed cloud, transposed back (:22-27)
+        # `geometry` (optional, not in the reference): the result of plan_geometry(xyz), possibly still pending on a
+        # side stream.
+        if geometry is None:
+            geometry = self.plan_geometry(xyz)
+        elif hasattr(geometry, "get"):
+            geometry = geometry.get()
+        new_xyz = geometry["new_xyz"] if geometry is not None else None
+        new_inds = geometry["new_inds"] if geometry is not None else None
 
         pooled = []
-        shared = {}  # nsample -> un-clamped kNN, computed once per level (the scales only differ in the clamp radius)
-        n_same = {}
-        for grouper in self.groupers:
-            if isinstance(grouper, QueryAndGroup):
-                n_same[grouper.nsample] = n_same.get(grouper.nsample, 0) + 1
         for grouper, mlp in zip(self.groupers, self.mlps):
-            if isinstance(grouper, QueryAndGroup) and n_same[grouper.nsample] > 1:
-                if grouper.nsample not in shared:
-                    shared[grouper.nsample] = knn_radius_clamp(grouper.nsample, None, new_xyz, xyz)
-                grouped = grouper(xyz, new_xyz, features, neighbours=shared[grouper.nsample])[0]
+            if isinstance(grouper, QueryAndGroup):
+                grouped = grouper(xyz, new_xyz, features, neighbours=geometry["knn"][grouper.nsample])[0]
             else:
                 grouped = grouper(xyz, new_xyz, features)[0]  # (B, C', npoint, nsample)
             pooled.append(mlp.forward_maxpool(grouped))       # shared MLP, then max over nsample (:38-42)
@@ -78,13 +89,22 @@ class PointnetFPModule(nn.Module):
         super().__init__()
         self.mlp = SharedMLP(mlp, bn=bn)
 
-    def forward(self, unknown, known, unknow_feats, known_feats):
+    @staticmethod
+    def plan_geometry(unknown, known):
+        """3-NN indices and inverse-distance weights (coordinates only; may run ahead on a side stream)."""
+        dist, idx = three_nn(unknown.contiguous(), known.contiguous())
+        dist_recip = 1.0 / (dist + 1e-8)                                  # :99
+        weight = dist_recip / dist_recip.sum(dim=2, keepdim=True)         # :100-101
+        return {"idx": idx.contiguous(), "weight": weight.contiguous()}
+
+    def forward(self, unknown, known, unknow_feats, known_feats, geometry=None):
         # unknown (B, n, 3), known (B, m, 3), unknow_feats (B, C1, n), known_feats (B, C2, m) -> (B, mlp[-1], n)
         if known is not None:
-            dist, idx = three_nn(unknown.contiguous(), known.contiguous())
-            dist_recip = 1.0 / (dist + 1e-8)                                  # :99
-            weight = dist_recip / dist_recip.sum(dim=2, keepdim=True)         # :100-101
-            interpolated = three_interpolate(known_feats.contiguous(), idx.contiguous(), weight.contiguous())
+            if geometry is None:
+                geometry = self.plan_geometry(unknown, known)
+            elif hasattr(geometry, "get"):
+                geometry = geometry.get()
+            interpolated = three_interpolate(known_feats.contiguous(), geometry["idx"], geometry["weight"])
         else:
             interpolated = known_feats.expand(*known_feats.size()[0:2], unknown.size(1))
         if unknow_feats is not None:

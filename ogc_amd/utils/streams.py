@@ -1,0 +1,52 @@
+"""Side-stream helpers: overlap the coordinate-only part of a step (FPS, kNN, three-NN, ball query — none of it
+depends on learned features) with the dense feature work.  FPS keeps one workgroup per cloud busy (16 of 256 CUs at
+B = 16), so running it next to the GEMM / GroupNorm kernels costs nothing.  Results are identical: only the launch
+stream changes; ordering is enforced with events and the caching allocator is told about cross-stream use."""
+import torch
+
+_side = {}
+
+
+def side_stream(device, key="geometry"):
+    k = (torch.device(device).index, key)
+    if k not in _side:
+        _side[k] = torch.cuda.Stream(device=device)
+    return _side[k]
+
+
+class Pending:
+    """A value being produced on a side stream.  ``get()`` makes the current stream wait for it (once)."""
+
+    def __init__(self, value, event):
+        self._value, self._event = value, event
+
+    def get(self):
+        if self._event is not None:
+            main = torch.cuda.current_stream()
+            main.wait_event(self._event)
+            for t in _tensors(self._value):
+                t.record_stream(main)
+            self._event = None
+        return self._value
+
+
+def _tensors(obj):
+    if torch.is_tensor(obj):
+        yield obj
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            yield from _tensors(v)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            yield from _tensors(v)
+
+
+def launch_on_side(stream, fn):
+    """Run ``fn()`` on ``stream`` after everything already queued on the current stream; returns a Pending."""
+    main = torch.cuda.current_stream()
+    stream.wait_stream(main)
+    with torch.cuda.stream(stream):
+        value = fn()
+        event = torch.cuda.Event()
+        event.record(stream)
+    return Pending(value, event)
