@@ -45,26 +45,33 @@ __device__ __forceinline__ int fps_rank_to_k(unsigned rho, int S, int bs_shift) 
     return (int)((kd << bs_shift) + tid);
 }
 
-struct FpsRecord { // one per wave per round
-    float vmax;
-    unsigned rho;
-    float x, y, z;
-};
+// Max over the 64 lanes of non-negative floats (or the -1 padding value) compared as signed integers — the bit
+// patterns order identically — so every step is ONE v_max_i32 with a DPP operand (fmaxf costs a canonicalising
+// v_max + v_max per step, and every dependent VALU op is 8 cycles of latency on the per-round critical path).
+__device__ __forceinline__ float fps_wave_max(float v) {
+    int x = __float_as_int(v);
+    x = max(x, __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false));
+    x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false));
+    x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x141, 0xF, 0xF, false));
+    x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x140, 0xF, 0xF, false));
+    const int r0 = __builtin_amdgcn_readlane(x, 0), r1 = __builtin_amdgcn_readlane(x, 16);
+    const int r2 = __builtin_amdgcn_readlane(x, 32), r3 = __builtin_amdgcn_readlane(x, 48);
+    return __int_as_float(max(max(r0, r1), max(r2, r3)));
+}
 
 template <int PTS, int THREADS, bool LDS_XYZ>
 __global__ __launch_bounds__(THREADS) void fps_reg_kernel(int n, int m, int bs_shift,
                                                           const float *__restrict__ xyz,
                                                           float *__restrict__ temp, int *__restrict__ idxs) {
-    constexpr int NW = THREADS / OGC_WAVE;
     extern __shared__ __attribute__((aligned(16))) float fps_smem[];
-    FpsRecord *rec = reinterpret_cast<FpsRecord *>(fps_smem); // [2][16]
-    float *lx = fps_smem + 2 * 16 * (sizeof(FpsRecord) / 4); // after 32 records
+    // [0..1]: two 64-bit "best of the round" words (double-buffered); then the SoA xyz copy in rank order
+    u64 *best_word = reinterpret_cast<u64 *>(fps_smem);
+    float *lx = fps_smem + 4;
     const int slots = PTS * THREADS;
     float *ly = lx + slots, *lz = ly + slots;
 
     const int t = threadIdx.x;
     const int lane = t & (OGC_WAVE - 1);
-    const int wave = t >> 6;
     const int b = blockIdx.x;
     const float *__restrict__ dataset = xyz + (size_t)b * n * 3;
     float *tmp = temp + (size_t)b * n;
@@ -92,7 +99,11 @@ __global__ __launch_bounds__(THREADS) void fps_reg_kernel(int n, int m, int bs_s
             lz[rho] = pz[j];
         }
     }
-    if (t == 0) out[0] = 0;
+    if (t == 0) {
+        out[0] = 0; // slot 0 of the output holds point 0; later slots hold RANKS until the final conversion pass
+        best_word[0] = 0ull;
+        best_word[1] = 0ull;
+    }
     float x1 = dataset[0], y1 = dataset[1], z1 = dataset[2];
     __syncthreads();
 
@@ -105,39 +116,26 @@ __global__ __launch_bounds__(THREADS) void fps_reg_kernel(int n, int m, int bs_s
             td[j] = ogc_min_f32(d, td[j]);
             tmax = fmaxf(tmax, td[j]);
         }
-        const float wmax = ogc_wave_max_f32(tmax);
-        unsigned rho = 0xFFFFFFFFu;
-        if (tmax == wmax) {
+        // lane-local "first register holding the lane maximum": independent of the wave reduction below, so the two
+        // dependency chains overlap
+        unsigned rho = (unsigned)(t + (PTS - 1) * THREADS);
 #pragma unroll
-            for (int j = PTS - 1; j >= 0; --j) rho = td[j] == wmax ? (unsigned)(t + j * THREADS) : rho;
-        }
-        const unsigned wrho = ogc_wave_min_u32(rho);
-        if (lane == 0) {
-            FpsRecord rc;
-            rc.vmax = wmax;
-            rc.rho = wrho;
-            if (LDS_XYZ) {
-                rc.x = lx[wrho]; rc.y = ly[wrho]; rc.z = lz[wrho];
-            } else {
-                const int k = fps_rank_to_k(wrho, S, bs_shift);
-                rc.x = dataset[k * 3 + 0]; rc.y = dataset[k * 3 + 1]; rc.z = dataset[k * 3 + 2];
-            }
-            rec[par * 16 + wave] = rc;
-        }
+        for (int j = PTS - 2; j >= 0; --j) rho = td[j] == tmax ? (unsigned)(t + j * THREADS) : rho;
+        const float wmax = fps_wave_max(tmax);
+        const unsigned wrho = ogc_wave_min_u32(tmax == wmax ? rho : 0xFFFFFFFFu);
+        // cross-wave: one 64-bit LDS max per wave; key = (value bits, ~rank) so that larger value, then smaller rank wins
+        if (lane == 0)
+            atomicMax(&best_word[par], ((u64)__float_as_uint(wmax) << 32) | (u64)(0xFFFFFFFFu - wrho));
+        if (t == 0) best_word[par ^ 1] = 0ull;
         __syncthreads();
-        FpsRecord best = rec[par * 16];
-#pragma unroll
-        for (int w = 1; w < NW; ++w) {
-            const FpsRecord c = rec[par * 16 + w];
-            const bool better = c.vmax > best.vmax || (c.vmax == best.vmax && c.rho < best.rho);
-            best.vmax = better ? c.vmax : best.vmax;
-            best.rho = better ? c.rho : best.rho;
-            best.x = better ? c.x : best.x;
-            best.y = better ? c.y : best.y;
-            best.z = better ? c.z : best.z;
+        const unsigned brho = 0xFFFFFFFFu - (unsigned)best_word[par];
+        if (LDS_XYZ) {
+            x1 = lx[brho]; y1 = ly[brho]; z1 = lz[brho];
+        } else {
+            const int k = fps_rank_to_k(brho, S, bs_shift);
+            x1 = dataset[k * 3 + 0]; y1 = dataset[k * 3 + 1]; z1 = dataset[k * 3 + 2];
         }
-        x1 = best.x; y1 = best.y; z1 = best.z;
-        if (t == 0) out[r] = fps_rank_to_k(best.rho, S, bs_shift);
+        if (t == 0) out[r] = (int)brho;
     }
 #pragma unroll
     for (int j = 0; j < PTS; ++j) {
@@ -145,6 +143,9 @@ __global__ __launch_bounds__(THREADS) void fps_reg_kernel(int n, int m, int bs_s
         const int k = rho < (unsigned)nslot ? fps_rank_to_k(rho, S, bs_shift) : n;
         if (k < n) tmp[k] = td[j];
     }
+    // ranks -> point indices (kept off the per-round critical path: the division is ~20 dependent instructions)
+    __syncthreads();
+    for (int r = 1 + t; r < m; r += THREADS) out[r] = fps_rank_to_k((unsigned)out[r], S, bs_shift);
 }
 
 __device__ __forceinline__ unsigned fps_rank(int k, int bs_mask, int bs_shift, int S) {
@@ -212,7 +213,7 @@ template <int PTS, int THREADS>
 void fps_launch(int b, int n, int m, int shift, const float *xyz, float *temp, int *idx, hipStream_t stream) {
     constexpr int slots = PTS * THREADS;
     constexpr bool lds_xyz = slots <= FPS_LDS_XYZ_MAX;
-    constexpr size_t lds = 32 * sizeof(FpsRecord) + (lds_xyz ? 3 * slots * sizeof(float) : 0);
+    constexpr size_t lds = 4 * sizeof(float) + (lds_xyz ? 3 * slots * sizeof(float) : 0);
     auto kern = fps_reg_kernel<PTS, THREADS, lds_xyz>;
     if (lds > 64 * 1024) {
         static bool once = false; // raise the dynamic-LDS cap once per process for this instantiation
@@ -243,11 +244,9 @@ extern "C" int ogc_furthest_point_sampling(int b, int n, int m, const float *xyz
         if (slots <= 2048) fps_launch<2, 1024>(b, n, m, shift, xyz, temp, idx, s);
         else if (slots <= 4096) fps_launch<4, 1024>(b, n, m, shift, xyz, temp, idx, s);
         else fps_launch<8, 1024>(b, n, m, shift, xyz, temp, idx, s);
-    } else if (force_threads == 512 && slots > 512 && slots <= 8192) {
-        if (slots <= 1024) fps_launch<2, 512>(b, n, m, shift, xyz, temp, idx, s);
-        else if (slots <= 2048) fps_launch<4, 512>(b, n, m, shift, xyz, temp, idx, s);
-        else if (slots <= 4096) fps_launch<8, 512>(b, n, m, shift, xyz, temp, idx, s);
-        else fps_launch<16, 512>(b, n, m, shift, xyz, temp, idx, s);
+    } else if (force_threads == 256 && slots > 2048 && slots <= 8192) {
+        if (slots <= 4096) fps_launch<16, 256>(b, n, m, shift, xyz, temp, idx, s);
+        else fps_launch<32, 256>(b, n, m, shift, xyz, temp, idx, s);
     } else
     if (slots <= 64) fps_launch<1, 64>(b, n, m, shift, xyz, temp, idx, s);
     else if (slots <= 128) fps_launch<2, 64>(b, n, m, shift, xyz, temp, idx, s);
@@ -255,8 +254,8 @@ extern "C" int ogc_furthest_point_sampling(int b, int n, int m, const float *xyz
     else if (slots <= 512) fps_launch<2, 256>(b, n, m, shift, xyz, temp, idx, s);
     else if (slots <= 1024) fps_launch<4, 256>(b, n, m, shift, xyz, temp, idx, s);
     else if (slots <= 2048) fps_launch<8, 256>(b, n, m, shift, xyz, temp, idx, s);
-    else if (slots <= 4096) fps_launch<16, 256>(b, n, m, shift, xyz, temp, idx, s);
-    else if (slots <= 8192) fps_launch<32, 256>(b, n, m, shift, xyz, temp, idx, s);
+    else if (slots <= 4096) fps_launch<8, 512>(b, n, m, shift, xyz, temp, idx, s);
+    else if (slots <= 8192) fps_launch<16, 512>(b, n, m, shift, xyz, temp, idx, s);
     else if (slots <= 16384) fps_launch<32, 512>(b, n, m, shift, xyz, temp, idx, s);
     else
         hipLaunchKernelGGL(fps_mem_kernel, dim3(b), dim3(1024), 0, s, n, m, shift, xyz, temp, idx);
