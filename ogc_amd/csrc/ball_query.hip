@@ -7,6 +7,8 @@
 // The scan stops early only when every lane of the wave already holds `nsample` hits — the same
 // result as the reference's per-thread `break` (ball_query_gpu.cu:42), since a full lane ignores
 // further hits.
+#include <stdlib.h>
+
 #include "ogc_common.h"
 
 namespace {
@@ -71,6 +73,9 @@ __global__ __launch_bounds__(OGC_WAVE) void ball_query_kernel(int n, int m, floa
 
 } // namespace
 
+int ogc_ball_query_grid(int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz,
+                        int *idx, hipStream_t s); // grid.hip
+
 extern "C" int ogc_ball_query(int b, int n, int m, float radius, int nsample, const float *new_xyz,
                               const float *xyz, int *idx, ogc_stream_t stream) {
     OGC_REQUIRE(b >= 0 && n >= 0 && m >= 0 && nsample >= 0, "ogc_ball_query: negative dimension");
@@ -82,6 +87,18 @@ extern "C" int ogc_ball_query(int b, int n, int m, float radius, int nsample, co
         return OGC_ERR_UNSUPPORTED;
     }
     OGC_REQUIRE((long long)b * m * nsample < (1ll << 31), "ogc_ball_query: idx exceeds 32-bit indexing");
+    // Cell-list path (identical results, ~N/100 candidates per centre); the all-pairs scan below remains for small
+    // clouds and as the fallback.  OGC_BALL_QUERY=brute|grid forces a path (development / tests).
+    static const char *mode = getenv("OGC_BALL_QUERY");
+    if (!(mode && mode[0] == 'b') && xyz) {
+        const int rc = ogc_ball_query_grid(b, n, m, radius, nsample, new_xyz, xyz, idx, (hipStream_t)stream);
+        if (rc != OGC_ERR_UNSUPPORTED) return rc;
+        if (mode && mode[0] == 'g') {
+            ogc_set_error("ogc_ball_query: grid path forced but not applicable (n=%d, nsample=%d, r=%g)", n, nsample,
+                          (double)radius);
+            return OGC_ERR_UNSUPPORTED;
+        }
+    }
     dim3 grid(ogc_divup(m, OGC_WAVE), b);
     hipLaunchKernelGGL(ball_query_kernel, grid, dim3(OGC_WAVE), lds, (hipStream_t)stream, n, m,
                        radius * radius, nsample, new_xyz, xyz, idx);

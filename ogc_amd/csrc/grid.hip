@@ -1,0 +1,371 @@
+// grid.hip — uniform-grid (cell-list) acceleration of the fixed-radius query, with results identical to the
+// brute-force scan.
+//
+// The reference's ball query (ball_query_gpu.cu:9-45) tests every centre against every point: 8*N*M flop for
+// ~2.3 MB of input/output per 8192-point cloud, i.e. compute-bound by two orders of magnitude.  A radius query only
+// needs the points of the 27 cells around the centre when the cell edge is >= the radius.  Per call:
+//   grid_build_kernel   one workgroup per cloud: bounding box -> cell edge h >= 1.01 r (enlarged until the grid has
+//                       <= GRID_MAX_CELLS cells) -> LDS histogram -> scan -> scatter: cell_start[], and the points
+//                       re-ordered by cell (indices + coordinates, so the query reads contiguous runs);
+//   ball_query_grid     one lane per centre, centres taken in cell order (neighbouring lanes walk the same runs);
+//                       the 3 x-adjacent cells of a (y, z) pair are one contiguous run, so 9 runs per centre; the
+//                       squared distance uses the reference's exact fp32 expression; hits go to a per-lane LDS
+//                       max-heap keyed by point index that keeps the `nsample` SMALLEST indices; heap-sort ->
+//                       ascending -> padded with the first -> the row the reference produces by scanning in index
+//                       order and stopping after nsample hits.
+// Exactness: a hit satisfies |dx| < r in every axis, the cell coordinate is floor((x - min) / h) with h >= 1.01 r, so
+// the cell coordinates of a centre and any of its hits differ by at most one even with fp32 rounding of the
+// quotient (relative error 1e-7 * up to 16384 cells << 0.01); points with non-finite coordinates can never be
+// hits (their distance is inf/NaN) and are left out of the grid.
+#include "ogc_common.h"
+
+namespace ogc_grid {
+
+constexpr int GRID_MAX_CELLS = 16384;
+constexpr int BUILD_THREADS = 1024;
+
+struct GridHdr { // one per cloud
+    float minx, miny, minz, inv_h;
+    int gx, gy, gz, npts; // npts = finite points inserted
+    int dense;            // 1: the 27-cell neighbourhood holds a large share of the cloud -> all-pairs scan instead
+    int pad[3];
+};
+
+__device__ __forceinline__ int cell_coord(float x, float mn, float inv_h, int g) {
+    // floor((x - mn) * inv_h) clamped to [-2, g + 1]; NaN -> -2 (outside every neighbourhood)
+    const float f = floorf((x - mn) * inv_h);
+    if (!(f >= -2.0f)) return -2;
+    if (f > (float)(g + 1)) return g + 1;
+    return (int)f;
+}
+
+__global__ __launch_bounds__(BUILD_THREADS) void grid_build_kernel(int n, float radius, int stride_cells,
+                                                                   const float *__restrict__ xyz,
+                                                                   GridHdr *__restrict__ hdrs,
+                                                                   int *__restrict__ cell_start,
+                                                                   int *__restrict__ sorted_idx,
+                                                                   float *__restrict__ sorted_xyz) {
+    __shared__ int s_cnt[GRID_MAX_CELLS]; // histogram -> exclusive starts -> scatter cursors
+    __shared__ float s_red[6][BUILD_THREADS / 64];
+    __shared__ int s_part[BUILD_THREADS];
+    __shared__ GridHdr s_hdr;
+    __shared__ int s_tail; // cursor for points left out of the grid (non-finite coordinates)
+    const int t = threadIdx.x, b = blockIdx.x;
+    const float *pts = xyz + (size_t)b * n * 3;
+
+    // 1. bounding box of the finite points
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int k = t; k < n; k += BUILD_THREADS) {
+        const float x = pts[k * 3], y = pts[k * 3 + 1], z = pts[k * 3 + 2];
+        if (isfinite(x) && isfinite(y) && isfinite(z)) {
+            mn[0] = fminf(mn[0], x); mn[1] = fminf(mn[1], y); mn[2] = fminf(mn[2], z);
+            mx[0] = fmaxf(mx[0], x); mx[1] = fmaxf(mx[1], y); mx[2] = fmaxf(mx[2], z);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        for (int off = 32; off > 0; off >>= 1) {
+            mn[a] = fminf(mn[a], __shfl_xor(mn[a], off, 64));
+            mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], off, 64));
+        }
+        if ((t & 63) == 0) {
+            s_red[a][t >> 6] = mn[a];
+            s_red[3 + a][t >> 6] = mx[a];
+        }
+    }
+    for (int c = t; c < GRID_MAX_CELLS; c += BUILD_THREADS) s_cnt[c] = 0;
+    __syncthreads();
+    if (t == 0) {
+        float lo[3], hi[3];
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = s_red[a][0];
+            hi[a] = s_red[3 + a][0];
+            for (int w = 1; w < BUILD_THREADS / 64; ++w) {
+                lo[a] = fminf(lo[a], s_red[a][w]);
+                hi[a] = fmaxf(hi[a], s_red[3 + a][w]);
+            }
+        }
+        GridHdr h;
+        const bool any = lo[0] <= hi[0];
+        double ext[3];
+        for (int a = 0; a < 3; ++a) ext[a] = any ? (double)hi[a] - (double)lo[a] : 0.0;
+        double edge = (double)radius * 1.01;
+        const double maxext = fmax(ext[0], fmax(ext[1], ext[2]));
+        if (!(edge > 0.0) || !isfinite(edge)) edge = fmax(maxext, 1.0);      // degenerate radius: one cell per axis
+        edge = fmax(edge, maxext * 1e-6);                                    // keep the quotient well inside int range
+        double g[3];
+        for (int it = 0; it < 64; ++it) {
+            for (int a = 0; a < 3; ++a) g[a] = floor(ext[a] / edge) + 1.0;
+            const double total = g[0] * g[1] * g[2];
+            if (total <= (double)GRID_MAX_CELLS) break;
+            edge *= cbrt(total / (double)GRID_MAX_CELLS) * 1.02;
+        }
+        h.minx = any ? lo[0] : 0.f; h.miny = any ? lo[1] : 0.f; h.minz = any ? lo[2] : 0.f;
+        h.inv_h = (float)(1.0 / edge);
+        h.gx = (int)g[0]; h.gy = (int)g[1]; h.gz = (int)g[2];
+        h.npts = 0;
+        h.dense = 0;
+        s_hdr = h;
+    }
+    __syncthreads();
+    const GridHdr h = s_hdr;
+    const int ncell = h.gx * h.gy * h.gz;
+
+    // 2. histogram (LDS atomics)
+    for (int k = t; k < n; k += BUILD_THREADS) {
+        const float x = pts[k * 3], y = pts[k * 3 + 1], z = pts[k * 3 + 2];
+        if (isfinite(x) && isfinite(y) && isfinite(z)) {
+            const int cx = min(max(cell_coord(x, h.minx, h.inv_h, h.gx), 0), h.gx - 1);
+            const int cy = min(max(cell_coord(y, h.miny, h.inv_h, h.gy), 0), h.gy - 1);
+            const int cz = min(max(cell_coord(z, h.minz, h.inv_h, h.gz), 0), h.gz - 1);
+            atomicAdd(&s_cnt[cx + h.gx * (cy + h.gy * cz)], 1);
+        }
+    }
+    __syncthreads();
+
+    // 3. exclusive scan of s_cnt[0..ncell): each thread owns a contiguous chunk
+    const int per = (ncell + BUILD_THREADS - 1) / BUILD_THREADS;
+    const int c0 = min(t * per, ncell), c1 = min(c0 + per, ncell);
+    int sum = 0;
+    for (int c = c0; c < c1; ++c) sum += s_cnt[c];
+    s_part[t] = sum;
+    __syncthreads();
+    for (int off = 1; off < BUILD_THREADS; off <<= 1) { // Hillis-Steele inclusive scan over the 1024 partials
+        const int v = t >= off ? s_part[t - off] : 0;
+        __syncthreads();
+        s_part[t] += v;
+        __syncthreads();
+    }
+    int run = t > 0 ? s_part[t - 1] : 0;
+    int *cs = cell_start + (size_t)b * stride_cells;
+    for (int c = c0; c < c1; ++c) {
+        const int cnt = s_cnt[c];
+        s_cnt[c] = run; // becomes the scatter cursor
+        cs[c] = run;
+        run += cnt;
+    }
+    if (t == BUILD_THREADS - 1) {
+        cs[ncell] = s_part[BUILD_THREADS - 1];
+        s_tail = s_part[BUILD_THREADS - 1];
+        GridHdr out = h;
+        out.npts = s_part[BUILD_THREADS - 1];
+        // mean number of candidates a centre would test (27 cells at the mean occupancy).  When that is a large share
+        // of the cloud the cell lists buy nothing, and rows saturate early, which the index-ordered all-pairs scan
+        // exploits (it stops after nsample hits) while a cell-ordered scan cannot.
+        const double per_query = 27.0 * (double)out.npts / (double)ncell;
+        out.dense = per_query > 0.25 * (double)n ? 1 : 0;
+        hdrs[b] = out;
+    }
+    __syncthreads();
+
+    // 4. scatter (order inside a cell is arbitrary; the query sorts its hits by index)
+    int *sidx = sorted_idx + (size_t)b * n;
+    float *sxyz = sorted_xyz + (size_t)b * n * 3;
+    for (int k = t; k < n; k += BUILD_THREADS) {
+        const float x = pts[k * 3], y = pts[k * 3 + 1], z = pts[k * 3 + 2];
+        if (isfinite(x) && isfinite(y) && isfinite(z)) {
+            const int cx = min(max(cell_coord(x, h.minx, h.inv_h, h.gx), 0), h.gx - 1);
+            const int cy = min(max(cell_coord(y, h.miny, h.inv_h, h.gy), 0), h.gy - 1);
+            const int cz = min(max(cell_coord(z, h.minz, h.inv_h, h.gz), 0), h.gz - 1);
+            const int pos = atomicAdd(&s_cnt[cx + h.gx * (cy + h.gy * cz)], 1);
+            sidx[pos] = k;
+            sxyz[pos * 3] = x; sxyz[pos * 3 + 1] = y; sxyz[pos * 3 + 2] = z;
+        } else { // not in any cell; listed after the cells so that a same-set query still emits its (empty) row
+            const int pos = atomicAdd(&s_tail, 1);
+            sidx[pos] = k;
+            sxyz[pos * 3] = NAN; sxyz[pos * 3 + 1] = NAN; sxyz[pos * 3 + 2] = NAN;
+        }
+    }
+}
+
+constexpr int BQ_LSTRIDE = 65;
+
+// Max-heap on column `lane` of rows[][BQ_LSTRIDE]: place value v at `pos` and sift it down within [0, end).
+__device__ __forceinline__ void sift_down(int *rows, int lane, int pos, int end, int v) {
+    for (;;) {
+        int c = 2 * pos + 1;
+        if (c >= end) break;
+        int cv = rows[c * BQ_LSTRIDE + lane];
+        if (c + 1 < end) {
+            const int cv2 = rows[(c + 1) * BQ_LSTRIDE + lane];
+            if (cv2 > cv) { cv = cv2; ++c; }
+        }
+        if (cv <= v) break;
+        rows[pos * BQ_LSTRIDE + lane] = cv;
+        pos = c;
+    }
+    rows[pos * BQ_LSTRIDE + lane] = v;
+}
+
+// rows[0..cnt) holds positions in the cell-sorted arrays: turn them into point indices and build the max-heap
+__device__ __forceinline__ void to_index_heap(int *rows, int lane, int cnt, const int *__restrict__ sidx) {
+    for (int j = 0; j < cnt; ++j) rows[j * BQ_LSTRIDE + lane] = sidx[rows[j * BQ_LSTRIDE + lane]];
+    for (int i = cnt / 2 - 1; i >= 0; --i) sift_down(rows, lane, i, cnt, rows[i * BQ_LSTRIDE + lane]);
+}
+
+__device__ __forceinline__ int wave_min_i32(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+// The centres are the grid's own points, visited in cell order (neighbouring lanes walk the same runs, so their
+// loads hit the same cache lines).  One lane = one centre; the three x-adjacent cells of a (y, z) pair are ONE
+// contiguous run of the cell-sorted arrays, so a centre walks at most nine runs.  All eighteen run bounds are
+// fetched up front (independent loads), and inside a run the next candidate's coordinates are requested before the
+// current one is tested, so the loop is not a chain of exposed cache round trips.
+__global__ __launch_bounds__(OGC_WAVE) void ball_query_grid_kernel(int n, int m, float radius2, int nsample,
+                                                                   int stride_cells,
+                                                                   const float *__restrict__ xyz,
+                                                                   const GridHdr *__restrict__ hdrs,
+                                                                   const int *__restrict__ cell_start,
+                                                                   const int *__restrict__ sorted_idx,
+                                                                   const float *__restrict__ sorted_xyz,
+                                                                   int *__restrict__ idx_out) {
+    extern __shared__ __attribute__((aligned(16))) int gq_smem[];
+    float *tile = reinterpret_cast<float *>(gq_smem);   // [OGC_TILE_FLOATS] (dense fallback only)
+    int *rows = gq_smem + OGC_TILE_FLOATS;              // [nsample][BQ_LSTRIDE]
+    int *cnts = rows + nsample * BQ_LSTRIDE;            // [64]
+    int *qrow = cnts + OGC_WAVE;                        // [64] output row of each lane (-1: none)
+    const int lane = threadIdx.x, b = blockIdx.y;
+    const int p = blockIdx.x * OGC_WAVE + lane;
+    const GridHdr h = hdrs[b];
+    const int *cs = cell_start + (size_t)b * stride_cells;
+    const int *sidx = sorted_idx + (size_t)b * n;
+    const float *sxyz = sorted_xyz + (size_t)b * n * 3;
+
+    int q = -1;
+    float qx = NAN, qy = NAN, qz = NAN;
+    if (p < n) { // positions >= h.npts hold the non-finite points (NaN coordinates -> no hit -> zero row)
+        q = sidx[p];
+        qx = sxyz[p * 3]; qy = sxyz[p * 3 + 1]; qz = sxyz[p * 3 + 2];
+    }
+    const bool in_grid = p < h.npts;
+
+    // A hit is first just APPENDED (its position in the cell-sorted arrays, no memory access): rows rarely fill up
+    // (~12 hits per centre against nsample = 64 on outdoor clouds).  Only a lane whose row becomes full switches to
+    // "keep the nsample smallest point indices" with a max-heap.  Either way the row is heap-sorted at the end.
+    int cnt = 0;
+    bool heap_mode = false;
+    auto offer = [&](int pos) {
+        if (!heap_mode) {
+            rows[cnt * BQ_LSTRIDE + lane] = pos;
+            if (++cnt == nsample) {
+                to_index_heap(rows, lane, cnt, sidx);
+                heap_mode = true;
+            }
+        } else {
+            const int v = sidx[pos];
+            if (v < rows[lane]) sift_down(rows, lane, 0, nsample, v);
+        }
+    };
+    if (h.dense) {
+        // dense cloud: scan ALL points in index order (hits arrive sorted, the wave stops once every lane is full)
+        ogc_scan_candidates(xyz + (size_t)b * n * 3, n, qx, qy, qz, tile, lane, [&](const float (&d)[8], int base) {
+            if (__builtin_amdgcn_ballot_w64(ogc_min8_f32(d) < radius2) == 0) return false;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (d[u] < radius2 && cnt < nsample) {
+                    rows[cnt * BQ_LSTRIDE + lane] = base + u;
+                    ++cnt;
+                }
+            return __builtin_amdgcn_ballot_w64(cnt < nsample && q >= 0) == 0;
+        });
+    } else if (in_grid) {
+        const int cx = cell_coord(qx, h.minx, h.inv_h, h.gx);
+        const int cy = cell_coord(qy, h.miny, h.inv_h, h.gy);
+        const int cz = cell_coord(qz, h.minz, h.inv_h, h.gz);
+        const int x0 = max(cx - 1, 0), x1 = min(cx + 1, h.gx - 1);
+        int lo[9], hi[9];
+#pragma unroll
+        for (int r = 0; r < 9; ++r) { // eighteen independent loads
+            const int y = cy + (r % 3) - 1, z = cz + (r / 3) - 1;
+            const bool ok = y >= 0 && y < h.gy && z >= 0 && z < h.gz && x0 <= x1;
+            const int rowc = h.gx * (y + h.gy * z);
+            lo[r] = ok ? cs[rowc + x0] : 0;
+            hi[r] = ok ? cs[rowc + x1 + 1] : 0;
+        }
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            int j = lo[r];
+            const int jend = hi[r];
+            if (j >= jend) continue;
+            float ax = sxyz[j * 3], ay = sxyz[j * 3 + 1], az = sxyz[j * 3 + 2];
+            for (; j < jend; ++j) {
+                const int jn = min(j + 1, jend - 1);
+                const float bx = sxyz[jn * 3], by = sxyz[jn * 3 + 1], bz = sxyz[jn * 3 + 2]; // next candidate in flight
+                if (ogc_sqdist(qx, qy, qz, ax, ay, az) < radius2) offer(j);
+                ax = bx; ay = by; az = bz;
+            }
+        }
+    }
+    if (!h.dense) {
+        if (!heap_mode) to_index_heap(rows, lane, cnt, sidx);
+        // heap sort in place -> ascending indices in rows[0..cnt)
+        for (int end = cnt - 1; end > 0; --end) {
+            const int v = rows[end * BQ_LSTRIDE + lane];
+            rows[end * BQ_LSTRIDE + lane] = rows[lane];
+            sift_down(rows, lane, 0, end, v);
+        }
+    }
+    cnts[lane] = cnt;
+    qrow[lane] = q;
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+
+    // write-out: 16 lanes per output row (64 contiguous bytes per store instruction and row), 4 rows at a time
+    const int sub = lane & 15;
+    for (int it = 0; it < OGC_WAVE / 4; ++it) {
+        const int r = it * 4 + (lane >> 4);
+        const int row = qrow[r];
+        if (row < 0) continue;
+        const int c = cnts[r];
+        int *o = idx_out + ((size_t)b * m + row) * nsample;
+        for (int j = sub; j < nsample; j += 16)
+            o[j] = c > 0 ? rows[(j < c ? j : 0) * BQ_LSTRIDE + r] : 0;
+    }
+}
+
+} // namespace ogc_grid
+
+using namespace ogc_grid;
+
+// Returns OGC_OK after queueing the grid path, or OGC_ERR_UNSUPPORTED if the caller should use the brute-force scan.
+int ogc_ball_query_grid(int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz,
+                        int *idx, hipStream_t s) {
+    const size_t lds = ((size_t)OGC_TILE_FLOATS + (size_t)nsample * BQ_LSTRIDE + 2 * OGC_WAVE) * sizeof(int);
+    // the cell-ordered traversal needs the centres to BE the points (ball_query(pc, pc), the reference's only live
+    // use: losses/seg_loss_unsup.py:151, losses/flow_loss_unsup.py:84); other centre sets use the all-pairs scan
+    const bool same = (new_xyz == xyz) && (m == n);
+    if (!same || n < 1024 || lds > 64 * 1024 || !(radius > 0.0f) || !(radius < 3.0e38f)) return OGC_ERR_UNSUPPORTED;
+    const int stride_cells = GRID_MAX_CELLS + 1;
+    const size_t bytes_hdr = (sizeof(GridHdr) * b + 255) / 256 * 256;
+    const size_t bytes_cs = (sizeof(int) * (size_t)b * stride_cells + 255) / 256 * 256;
+    const size_t bytes_idx = (sizeof(int) * (size_t)b * n + 255) / 256 * 256;
+    const size_t bytes_xyz = sizeof(float) * (size_t)b * n * 3;
+    char *ws = nullptr;
+    if (hipMallocAsync((void **)&ws, bytes_hdr + bytes_cs + bytes_idx + bytes_xyz, s) != hipSuccess || !ws) {
+        (void)hipGetLastError();
+        return OGC_ERR_UNSUPPORTED;
+    }
+    GridHdr *hdrs = reinterpret_cast<GridHdr *>(ws);
+    int *cell_start = reinterpret_cast<int *>(ws + bytes_hdr);
+    int *sorted_idx = reinterpret_cast<int *>(ws + bytes_hdr + bytes_cs);
+    float *sorted_xyz = reinterpret_cast<float *>(ws + bytes_hdr + bytes_cs + bytes_idx);
+    hipLaunchKernelGGL(grid_build_kernel, dim3(b), dim3(BUILD_THREADS), 0, s, n, radius, stride_cells, xyz, hdrs,
+                       cell_start, sorted_idx, sorted_xyz);
+    hipLaunchKernelGGL(ball_query_grid_kernel, dim3(ogc_divup(n, OGC_WAVE), b), dim3(OGC_WAVE), lds, s, n, m,
+                       radius * radius, nsample, stride_cells, xyz, hdrs, cell_start, sorted_idx, sorted_xyz, idx);
+    const hipError_t e = hipGetLastError();
+    (void)hipFreeAsync(ws, s);
+    if (e != hipSuccess) {
+        ogc_set_error("ogc_ball_query (grid): launch failed: %s", hipGetErrorString(e));
+        return OGC_ERR_LAUNCH;
+    }
+    return OGC_OK;
+}

@@ -425,3 +425,51 @@ def test_fused_group_norm_act_maxpool(nat, shape, groups, relu):
     if frac == 1.0:
         torch.testing.assert_close(gw.double(), gw64, rtol=1e-4, atol=1e-4 * max(1.0, gw64.abs().max().item()))
         torch.testing.assert_close(gb.double(), gb64, rtol=1e-4, atol=1e-4 * max(1.0, gb64.abs().max().item()))
+
+
+GRID_BQ_CASES = [  # (n, m_or_None(same set), nsample, radius, scale)
+    (8192, None, 64, 2.0, (60, 4, 80)), (4096, None, 16, 0.04, (1, 1, 1)), (1024, None, 8, 0.1, (1, 1, 1)),
+    (3000, 700, 32, 3.0, (60, 4, 80)), (2048, None, 4, 50.0, (60, 4, 80)),   # dense: hits >> nsample
+    (5000, 5000, 64, 1e-4, (60, 4, 80)),                                     # only exact duplicates hit
+    (1500, None, 200, 1000.0, (60, 4, 80)),                                  # one cell, nsample > typical
+    (16384, None, 64, 2.0, (60, 4, 80)), (1025, 3, 16, 5.0, (60, 4, 80)),
+]
+
+
+@pytest.mark.parametrize("n,m,ns,r,scale", GRID_BQ_CASES)
+def test_ball_query_grid_path_bit_exact(nat, oracle, n, m, ns, r, scale):
+    """The cell-list path (n >= 1024) must reproduce the brute-force semantics exactly, including the
+    first-nsample-in-index-order rule, duplicates, points outside the query set's extent and non-finite points."""
+    rng = np.random.default_rng(n + ns)
+    xyz = cloud(rng, 2, n, scale=scale, dup=n // 7)
+    if m is None:
+        new = xyz
+    else:
+        new = cloud(rng, 2, m, scale=tuple(1.3 * v for v in scale))  # some centres lie outside the cloud's box
+    xyz[1, 5] = np.nan
+    xyz[1, 77, 1] = np.inf
+    if m is None:
+        new = xyz
+    t_xyz = T(xyz)
+    t_new = t_xyz if m is None else T(new)
+    idx = torch.zeros(2, new.shape[1], ns, dtype=torch.int32, device=DEV)
+    nat.ball_query_wrapper(2, n, new.shape[1], r, ns, t_new, t_xyz, idx)
+    assert np.array_equal(idx.cpu().numpy(), oracle.ball_query(r, ns, xyz, new))
+
+
+def test_ball_query_grid_clustered(nat, oracle):
+    """Strongly non-uniform density (a LiDAR-like cloud: dense near the origin) and a flat (2-D) cloud."""
+    rng = np.random.default_rng(99)
+    rad = rng.random((2, 8192, 1), dtype=np.float32) ** 3 * 60
+    ang = rng.random((2, 8192, 1), dtype=np.float32) * 2 * np.pi
+    pc = np.concatenate([rad * np.cos(ang), rng.random((2, 8192, 1), dtype=np.float32) * 2 - 1, rad * np.sin(ang)], -1).astype(np.float32)
+    t = T(pc)
+    idx = torch.zeros(2, 8192, 64, dtype=torch.int32, device=DEV)
+    nat.ball_query_wrapper(2, 8192, 8192, 2.0, 64, t, t, idx)
+    assert np.array_equal(idx.cpu().numpy(), oracle.ball_query(2.0, 64, pc, pc))
+    flat = pc.copy()
+    flat[..., 1] = 0.25
+    t = T(flat)
+    idx.zero_()
+    nat.ball_query_wrapper(2, 8192, 8192, 1.0, 64, t, t, idx)
+    assert np.array_equal(idx.cpu().numpy(), oracle.ball_query(1.0, 64, flat, flat))
