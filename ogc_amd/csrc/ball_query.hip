@@ -10,6 +10,7 @@
 #include <stdlib.h>
 
 #include "ogc_common.h"
+#include "grid.h"
 
 namespace {
 
@@ -18,7 +19,10 @@ constexpr int BQ_LSTRIDE = 65;
 __global__ __launch_bounds__(OGC_WAVE) void ball_query_kernel(int n, int m, float radius2, int nsample,
                                                               const float *__restrict__ new_xyz,
                                                               const float *__restrict__ xyz,
-                                                              int *__restrict__ idx) {
+                                                              int *__restrict__ idx,
+                                                              const ogc_grid::GridHdr *__restrict__ only_dense) {
+    // when the cell-list path is active, this kernel only serves the clouds it flagged as dense
+    if (only_dense && !only_dense[blockIdx.y].dense) return;
     extern __shared__ __attribute__((aligned(16))) int bq_smem[];
     float *tile = reinterpret_cast<float *>(bq_smem);   // [OGC_TILE_FLOATS] candidate tile (16-byte aligned)
     int *rows = bq_smem + OGC_TILE_FLOATS;              // [nsample][BQ_LSTRIDE]
@@ -73,9 +77,6 @@ __global__ __launch_bounds__(OGC_WAVE) void ball_query_kernel(int n, int m, floa
 
 } // namespace
 
-int ogc_ball_query_grid(int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz,
-                        int *idx, hipStream_t s); // grid.hip
-
 extern "C" int ogc_ball_query(int b, int n, int m, float radius, int nsample, const float *new_xyz,
                               const float *xyz, int *idx, ogc_stream_t stream) {
     OGC_REQUIRE(b >= 0 && n >= 0 && m >= 0 && nsample >= 0, "ogc_ball_query: negative dimension");
@@ -90,10 +91,13 @@ extern "C" int ogc_ball_query(int b, int n, int m, float radius, int nsample, co
     // Cell-list path (identical results, ~N/100 candidates per centre); the all-pairs scan below remains for small
     // clouds and as the fallback.  OGC_BALL_QUERY=brute|grid forces a path (development / tests).
     static const char *mode = getenv("OGC_BALL_QUERY");
+    const ogc_grid::GridHdr *only_dense = nullptr;
+    void *grid_ws = nullptr;
     if (!(mode && mode[0] == 'b') && xyz) {
-        const int rc = ogc_ball_query_grid(b, n, m, radius, nsample, new_xyz, xyz, idx, (hipStream_t)stream);
-        if (rc != OGC_ERR_UNSUPPORTED) return rc;
-        if (mode && mode[0] == 'g') {
+        const int rc = ogc_ball_query_grid(b, n, m, radius, nsample, new_xyz, xyz, idx, (hipStream_t)stream,
+                                           &only_dense, &grid_ws);
+        if (rc != OGC_OK && rc != OGC_ERR_UNSUPPORTED) return rc;
+        if (rc == OGC_ERR_UNSUPPORTED && mode && mode[0] == 'g') {
             ogc_set_error("ogc_ball_query: grid path forced but not applicable (n=%d, nsample=%d, r=%g)", n, nsample,
                           (double)radius);
             return OGC_ERR_UNSUPPORTED;
@@ -101,7 +105,8 @@ extern "C" int ogc_ball_query(int b, int n, int m, float radius, int nsample, co
     }
     dim3 grid(ogc_divup(m, OGC_WAVE), b);
     hipLaunchKernelGGL(ball_query_kernel, grid, dim3(OGC_WAVE), lds, (hipStream_t)stream, n, m,
-                       radius * radius, nsample, new_xyz, xyz, idx);
+                       radius * radius, nsample, new_xyz, xyz, idx, only_dense);
+    if (grid_ws) ogc_ball_query_grid_release(grid_ws, (hipStream_t)stream);
     OGC_CHECK_LAUNCH("ogc_ball_query");
     return OGC_OK;
 }

@@ -1,0 +1,21 @@
+// grid.h — shared declarations of the cell-list acceleration (grid.hip) used by ball_query.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace ogc_grid {
+
+struct GridHdr { // one per cloud, written by grid_build_kernel
+    float minx, miny, minz, inv_h;
+    int gx, gy, gz, npts; // npts = points with finite coordinates (the ones inserted)
+    int dense;            // 1: the 27-cell neighbourhood holds a large share of the cloud -> all-pairs scan instead
+    int pad[3];
+};
+
+} // namespace ogc_grid
+
+// Queues build + query on `s`.  Returns OGC_OK, or OGC_ERR_UNSUPPORTED when the caller should run the all-pairs scan.
+// On OGC_OK the caller must ALSO launch its all-pairs kernel gated on `*dense_hdrs` (clouds flagged dense are skipped
+// by the cell-list kernel) and then call ogc_ball_query_grid_release.
+int ogc_ball_query_grid(int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz,
+                        int *idx, hipStream_t s, const ogc_grid::GridHdr **dense_hdrs, void **workspace);
+void ogc_ball_query_grid_release(void *workspace, hipStream_t s);

@@ -18,18 +18,12 @@
 // quotient (relative error 1e-7 * up to 16384 cells << 0.01); points with non-finite coordinates can never be
 // hits (their distance is inf/NaN) and are left out of the grid.
 #include "ogc_common.h"
+#include "grid.h"
 
 namespace ogc_grid {
 
 constexpr int GRID_MAX_CELLS = 16384;
 constexpr int BUILD_THREADS = 1024;
-
-struct GridHdr { // one per cloud
-    float minx, miny, minz, inv_h;
-    int gx, gy, gz, npts; // npts = finite points inserted
-    int dense;            // 1: the 27-cell neighbourhood holds a large share of the cloud -> all-pairs scan instead
-    int pad[3];
-};
 
 __device__ __forceinline__ int cell_coord(float x, float mn, float inv_h, int g) {
     // floor((x - mn) * inv_h) clamped to [-2, g + 1]; NaN -> -2 (outside every neighbourhood)
@@ -178,66 +172,36 @@ __global__ __launch_bounds__(BUILD_THREADS) void grid_build_kernel(int n, float 
     }
 }
 
-constexpr int BQ_LSTRIDE = 65;
+constexpr int SUB = 8;               // lanes cooperating on one centre
+constexpr int QPW = OGC_WAVE / SUB;  // centres per wavefront
 
-// Max-heap on column `lane` of rows[][BQ_LSTRIDE]: place value v at `pos` and sift it down within [0, end).
-__device__ __forceinline__ void sift_down(int *rows, int lane, int pos, int end, int v) {
-    for (;;) {
-        int c = 2 * pos + 1;
-        if (c >= end) break;
-        int cv = rows[c * BQ_LSTRIDE + lane];
-        if (c + 1 < end) {
-            const int cv2 = rows[(c + 1) * BQ_LSTRIDE + lane];
-            if (cv2 > cv) { cv = cv2; ++c; }
-        }
-        if (cv <= v) break;
-        rows[pos * BQ_LSTRIDE + lane] = cv;
-        pos = c;
-    }
-    rows[pos * BQ_LSTRIDE + lane] = v;
-}
-
-// rows[0..cnt) holds positions in the cell-sorted arrays: turn them into point indices and build the max-heap
-__device__ __forceinline__ void to_index_heap(int *rows, int lane, int cnt, const int *__restrict__ sidx) {
-    for (int j = 0; j < cnt; ++j) rows[j * BQ_LSTRIDE + lane] = sidx[rows[j * BQ_LSTRIDE + lane]];
-    for (int i = cnt / 2 - 1; i >= 0; --i) sift_down(rows, lane, i, cnt, rows[i * BQ_LSTRIDE + lane]);
-}
-
-__device__ __forceinline__ int wave_min_i32(int v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
-    return v;
-}
-__device__ __forceinline__ int wave_max_i32(int v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
-    return v;
-}
-
-// The centres are the grid's own points, visited in cell order (neighbouring lanes walk the same runs, so their
-// loads hit the same cache lines).  One lane = one centre; the three x-adjacent cells of a (y, z) pair are ONE
-// contiguous run of the cell-sorted arrays, so a centre walks at most nine runs.  All eighteen run bounds are
-// fetched up front (independent loads), and inside a run the next candidate's coordinates are requested before the
-// current one is tested, so the loop is not a chain of exposed cache round trips.
+// EIGHT lanes per centre.  With one lane per centre a 16 x 8192 batch is only 2048 wavefronts (two per SIMD) of
+// long serial pointer-walks; eight lanes per centre give 16384 short wavefronts, so the chip hides the cache
+// latency of the candidate reads by switching waves.  The centres are the grid's own points in cell order; the
+// three x-adjacent cells of a (y, z) pair are ONE contiguous run of the cell-sorted arrays, so a centre has nine
+// runs, and the eight lanes stride through each run together (consecutive candidates -> one cache line).
+//   hits       : slot = cnt + (number of hitting lanes below me in my group), from one wave ballot — no atomics;
+//   row full   : the group keeps the nsample SMALLEST point indices (replace the current maximum, re-scan it);
+//   finish     : rank sort by the eight lanes (indices are distinct), pad with the smallest, 32-byte stores.
 __global__ __launch_bounds__(OGC_WAVE) void ball_query_grid_kernel(int n, int m, float radius2, int nsample,
                                                                    int stride_cells,
-                                                                   const float *__restrict__ xyz,
                                                                    const GridHdr *__restrict__ hdrs,
                                                                    const int *__restrict__ cell_start,
                                                                    const int *__restrict__ sorted_idx,
                                                                    const float *__restrict__ sorted_xyz,
                                                                    int *__restrict__ idx_out) {
     extern __shared__ __attribute__((aligned(16))) int gq_smem[];
-    float *tile = reinterpret_cast<float *>(gq_smem);   // [OGC_TILE_FLOATS] (dense fallback only)
-    int *rows = gq_smem + OGC_TILE_FLOATS;              // [nsample][BQ_LSTRIDE]
-    int *cnts = rows + nsample * BQ_LSTRIDE;            // [64]
-    int *qrow = cnts + OGC_WAVE;                        // [64] output row of each lane (-1: none)
     const int lane = threadIdx.x, b = blockIdx.y;
-    const int p = blockIdx.x * OGC_WAVE + lane;
     const GridHdr h = hdrs[b];
+    if (h.dense) return; // this cloud is handled by the all-pairs kernel
+    const int sub = lane & (SUB - 1), qi = lane >> 3;
+    int *kept = gq_smem + qi * nsample;                 // [QPW][nsample] indices kept so far (unordered)
+    int *outr = gq_smem + (QPW + qi) * nsample;         // [QPW][nsample] sorted + padded row
+    const int p = blockIdx.x * QPW + qi;
     const int *cs = cell_start + (size_t)b * stride_cells;
     const int *sidx = sorted_idx + (size_t)b * n;
     const float *sxyz = sorted_xyz + (size_t)b * n * 3;
+    const unsigned below = (1u << sub) - 1u;
 
     int q = -1;
     float qx = NAN, qy = NAN, qz = NAN;
@@ -245,45 +209,30 @@ __global__ __launch_bounds__(OGC_WAVE) void ball_query_grid_kernel(int n, int m,
         q = sidx[p];
         qx = sxyz[p * 3]; qy = sxyz[p * 3 + 1]; qz = sxyz[p * 3 + 2];
     }
-    const bool in_grid = p < h.npts;
-
-    // A hit is first just APPENDED (its position in the cell-sorted arrays, no memory access): rows rarely fill up
-    // (~12 hits per centre against nsample = 64 on outdoor clouds).  Only a lane whose row becomes full switches to
-    // "keep the nsample smallest point indices" with a max-heap.  Either way the row is heap-sorted at the end.
-    int cnt = 0;
-    bool heap_mode = false;
-    auto offer = [&](int pos) {
-        if (!heap_mode) {
-            rows[cnt * BQ_LSTRIDE + lane] = pos;
-            if (++cnt == nsample) {
-                to_index_heap(rows, lane, cnt, sidx);
-                heap_mode = true;
-            }
-        } else {
-            const int v = sidx[pos];
-            if (v < rows[lane]) sift_down(rows, lane, 0, nsample, v);
+    int cnt = 0, maxv = -1, maxpos = 0; // uniform within the group
+    // (re)compute the largest kept index of a FULL row: each lane scans nsample/8 entries, then a 3-step butterfly
+    auto rescan_max = [&]() {
+        int mv = -1, mp = 0;
+        for (int e = sub; e < nsample; e += SUB) {
+            const int v = kept[e];
+            if (v > mv) { mv = v; mp = e; }
         }
-    };
-    if (h.dense) {
-        // dense cloud: scan ALL points in index order (hits arrive sorted, the wave stops once every lane is full)
-        ogc_scan_candidates(xyz + (size_t)b * n * 3, n, qx, qy, qz, tile, lane, [&](const float (&d)[8], int base) {
-            if (__builtin_amdgcn_ballot_w64(ogc_min8_f32(d) < radius2) == 0) return false;
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (d[u] < radius2 && cnt < nsample) {
-                    rows[cnt * BQ_LSTRIDE + lane] = base + u;
-                    ++cnt;
-                }
-            return __builtin_amdgcn_ballot_w64(cnt < nsample && q >= 0) == 0;
-        });
-    } else if (in_grid) {
+        for (int off = 1; off < SUB; off <<= 1) {
+            const int ov = __shfl_xor(mv, off, 64), op = __shfl_xor(mp, off, 64);
+            if (ov > mv) { mv = ov; mp = op; }
+        }
+        maxv = mv;
+        maxpos = mp;
+    };
+    if (p < h.npts) {
         const int cx = cell_coord(qx, h.minx, h.inv_h, h.gx);
         const int cy = cell_coord(qy, h.miny, h.inv_h, h.gy);
         const int cz = cell_coord(qz, h.minz, h.inv_h, h.gz);
         const int x0 = max(cx - 1, 0), x1 = min(cx + 1, h.gx - 1);
         int lo[9], hi[9];
 #pragma unroll
-        for (int r = 0; r < 9; ++r) { // eighteen independent loads
+        for (int r = 0; r < 9; ++r) { // eighteen independent loads (the same addresses for the 8 lanes of a group)
             const int y = cy + (r % 3) - 1, z = cz + (r / 3) - 1;
             const bool ok = y >= 0 && y < h.gy && z >= 0 && z < h.gz && x0 <= x1;
             const int rowc = h.gx * (y + h.gy * z);
@@ -292,42 +241,51 @@ __global__ __launch_bounds__(OGC_WAVE) void ball_query_grid_kernel(int n, int m,
         }
 #pragma unroll
         for (int r = 0; r < 9; ++r) {
-            int j = lo[r];
-            const int jend = hi[r];
-            if (j >= jend) continue;
-            float ax = sxyz[j * 3], ay = sxyz[j * 3 + 1], az = sxyz[j * 3 + 2];
-            for (; j < jend; ++j) {
-                const int jn = min(j + 1, jend - 1);
-                const float bx = sxyz[jn * 3], by = sxyz[jn * 3 + 1], bz = sxyz[jn * 3 + 2]; // next candidate in flight
-                if (ogc_sqdist(qx, qy, qz, ax, ay, az) < radius2) offer(j);
-                ax = bx; ay = by; az = bz;
+            for (int j = lo[r] + sub; __builtin_amdgcn_ballot_w64(j < hi[r]) != 0; j += SUB) {
+                bool hit = false;
+                int v = 0;
+                if (j < hi[r]) {
+                    hit = ogc_sqdist(qx, qy, qz, sxyz[j * 3], sxyz[j * 3 + 1], sxyz[j * 3 + 2]) < radius2;
+                    if (hit) v = sidx[j];
+                }
+                const unsigned long long ball = __builtin_amdgcn_ballot_w64(hit);
+                if (ball == 0) continue;
+                const unsigned slice = (unsigned)(ball >> (qi * SUB)) & 0xFFu;
+                if (slice == 0) continue;
+                const int nh = __popc(slice);
+                if (cnt + nh <= nsample) { // common case: room for all of the group's hits
+                    if (hit) kept[cnt + __popc(slice & below)] = v;
+                    cnt += nh;
+                    if (cnt == nsample) rescan_max();
+                } else { // row (nearly) full: take the hits one by one, keep the nsample smallest indices
+                    for (int t = 0; t < SUB; ++t) {
+                        if (!((slice >> t) & 1u)) continue;
+                        const int vt = __shfl(v, qi * SUB + t, 64);
+                        if (cnt < nsample) {
+                            if (sub == 0) kept[cnt] = vt;
+                            if (++cnt == nsample) rescan_max();
+                        } else if (vt < maxv) {
+                            if (sub == 0) kept[maxpos] = vt;
+                            rescan_max();
+                        }
+                    }
+                }
             }
         }
     }
-    if (!h.dense) {
-        if (!heap_mode) to_index_heap(rows, lane, cnt, sidx);
-        // heap sort in place -> ascending indices in rows[0..cnt)
-        for (int end = cnt - 1; end > 0; --end) {
-            const int v = rows[end * BQ_LSTRIDE + lane];
-            rows[end * BQ_LSTRIDE + lane] = rows[lane];
-            sift_down(rows, lane, 0, end, v);
-        }
+    // rank sort (the kept indices are distinct): element e goes to position #{f : kept[f] < kept[e]}
+    for (int e = sub; e < cnt; e += SUB) {
+        const int ve = kept[e];
+        int rank = 0;
+        for (int f = 0; f < cnt; ++f) rank += kept[f] < ve ? 1 : 0;
+        outr[rank] = ve;
     }
-    cnts[lane] = cnt;
-    qrow[lane] = q;
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
-
-    // write-out: 16 lanes per output row (64 contiguous bytes per store instruction and row), 4 rows at a time
-    const int sub = lane & 15;
-    for (int it = 0; it < OGC_WAVE / 4; ++it) {
-        const int r = it * 4 + (lane >> 4);
-        const int row = qrow[r];
-        if (row < 0) continue;
-        const int c = cnts[r];
-        int *o = idx_out + ((size_t)b * m + row) * nsample;
-        for (int j = sub; j < nsample; j += 16)
-            o[j] = c > 0 ? rows[(j < c ? j : 0) * BQ_LSTRIDE + r] : 0;
+    if (q >= 0) {
+        const int first = cnt > 0 ? outr[0] : 0;
+        int *o = idx_out + ((size_t)b * m + q) * nsample;
+        for (int j = sub; j < nsample; j += SUB) o[j] = j < cnt ? outr[j] : first;
     }
 }
 
@@ -335,10 +293,9 @@ __global__ __launch_bounds__(OGC_WAVE) void ball_query_grid_kernel(int n, int m,
 
 using namespace ogc_grid;
 
-// Returns OGC_OK after queueing the grid path, or OGC_ERR_UNSUPPORTED if the caller should use the brute-force scan.
 int ogc_ball_query_grid(int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz,
-                        int *idx, hipStream_t s) {
-    const size_t lds = ((size_t)OGC_TILE_FLOATS + (size_t)nsample * BQ_LSTRIDE + 2 * OGC_WAVE) * sizeof(int);
+                        int *idx, hipStream_t s, const GridHdr **dense_hdrs, void **workspace) {
+    const size_t lds = (size_t)2 * QPW * nsample * sizeof(int);
     // the cell-ordered traversal needs the centres to BE the points (ball_query(pc, pc), the reference's only live
     // use: losses/seg_loss_unsup.py:151, losses/flow_loss_unsup.py:84); other centre sets use the all-pairs scan
     const bool same = (new_xyz == xyz) && (m == n);
@@ -359,13 +316,17 @@ int ogc_ball_query_grid(int b, int n, int m, float radius, int nsample, const fl
     float *sorted_xyz = reinterpret_cast<float *>(ws + bytes_hdr + bytes_cs + bytes_idx);
     hipLaunchKernelGGL(grid_build_kernel, dim3(b), dim3(BUILD_THREADS), 0, s, n, radius, stride_cells, xyz, hdrs,
                        cell_start, sorted_idx, sorted_xyz);
-    hipLaunchKernelGGL(ball_query_grid_kernel, dim3(ogc_divup(n, OGC_WAVE), b), dim3(OGC_WAVE), lds, s, n, m,
-                       radius * radius, nsample, stride_cells, xyz, hdrs, cell_start, sorted_idx, sorted_xyz, idx);
+    hipLaunchKernelGGL(ball_query_grid_kernel, dim3(ogc_divup(n, QPW), b), dim3(OGC_WAVE), lds, s, n, m,
+                       radius * radius, nsample, stride_cells, hdrs, cell_start, sorted_idx, sorted_xyz, idx);
     const hipError_t e = hipGetLastError();
-    (void)hipFreeAsync(ws, s);
     if (e != hipSuccess) {
+        (void)hipFreeAsync(ws, s);
         ogc_set_error("ogc_ball_query (grid): launch failed: %s", hipGetErrorString(e));
         return OGC_ERR_LAUNCH;
     }
+    *dense_hdrs = hdrs;
+    *workspace = ws;
     return OGC_OK;
 }
+
+void ogc_ball_query_grid_release(void *workspace, hipStream_t s) { (void)hipFreeAsync(workspace, s); }
