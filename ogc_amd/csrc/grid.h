@@ -19,3 +19,8 @@ struct GridHdr { // one per cloud, written by grid_build_kernel
 int ogc_ball_query_grid(int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz,
                         int *idx, hipStream_t s, const ogc_grid::GridHdr **dense_hdrs, void **workspace);
 void ogc_ball_query_grid_release(void *workspace, hipStream_t s);
+
+// Exact k-NN over cell lists (mode 0: squared distances, 1: sqrt + radius clamp).  OGC_OK, or OGC_ERR_UNSUPPORTED when
+// the caller should run the all-pairs scan (small clouds, k too large for the LDS budget).
+int ogc_knn_grid(int mode, int b, int n, int m, int k, float radius, const float *unknown, const float *known,
+                 float *dist, int *idx, hipStream_t s);

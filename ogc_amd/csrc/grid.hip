@@ -33,7 +33,7 @@ __device__ __forceinline__ int cell_coord(float x, float mn, float inv_h, int g)
     return (int)f;
 }
 
-__global__ __launch_bounds__(BUILD_THREADS) void grid_build_kernel(int n, float radius, int stride_cells,
+__global__ __launch_bounds__(BUILD_THREADS) void grid_build_kernel(int n, float radius, int knn_k, int stride_cells,
                                                                    const float *__restrict__ xyz,
                                                                    GridHdr *__restrict__ hdrs,
                                                                    int *__restrict__ cell_start,
@@ -85,7 +85,20 @@ __global__ __launch_bounds__(BUILD_THREADS) void grid_build_kernel(int n, float 
         for (int a = 0; a < 3; ++a) ext[a] = any ? (double)hi[a] - (double)lo[a] : 0.0;
         double edge = (double)radius * 1.01;
         const double maxext = fmax(ext[0], fmax(ext[1], ext[2]));
-        if (!(edge > 0.0) || !isfinite(edge)) edge = fmax(maxext, 1.0);      // degenerate radius: one cell per axis
+        if (knn_k > 0) {
+            // k-NN mode: pick the edge from the mean density so that the 3^d block around a query holds ~2.5 k points
+            // (d = number of axes with a non-negligible extent: flat or linear clouds get fewer cells per block)
+            int dims = 0;
+            double vol = 1.0;
+            for (int a = 0; a < 3; ++a)
+                if (ext[a] > 1e-3 * maxext && ext[a] > 0.0) { ++dims; vol *= ext[a]; }
+            int finite_pts = 0;
+            (void)finite_pts;
+            const double block = dims == 3 ? 27.0 : (dims == 2 ? 9.0 : 3.0);
+            const double per_cell = fmax(2.5 * (double)knn_k / block, 1.0);
+            edge = dims > 0 ? pow(vol * per_cell / (double)max(n, 1), 1.0 / (double)dims) : 1.0;
+        }
+        if (!(edge > 0.0) || !isfinite(edge)) edge = fmax(maxext, 1.0);      // degenerate: one cell per axis
         edge = fmax(edge, maxext * 1e-6);                                    // keep the quotient well inside int range
         double g[3];
         for (int it = 0; it < 64; ++it) {
@@ -289,6 +302,163 @@ __global__ __launch_bounds__(OGC_WAVE) void ball_query_grid_kernel(int n, int m,
     }
 }
 
+typedef unsigned long long u64;
+
+__device__ __forceinline__ u64 shfl_xor_u64(u64 v, int off) {
+    const unsigned lo = __shfl_xor((unsigned)v, off, 64), hi = __shfl_xor((unsigned)(v >> 32), off, 64);
+    return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ u64 shfl_u64(u64 v, int src) {
+    const unsigned lo = __shfl((unsigned)v, src, 64), hi = __shfl((unsigned)(v >> 32), src, 64);
+    return ((u64)hi << 32) | lo;
+}
+
+// Exact k nearest neighbours over the cell lists: "the k smallest (distance, index) keys", which is what the
+// reference's stable insertion computes (interpolate_gpu.cu:36-52).  EIGHT lanes per query, as in the ball query.
+// The query's block of (2R+1)^3 cells is scanned shell by shell (R = 1, 2, ...): every point closer than R*h lies
+// inside the block (the query is projected into the box first; projection is contractive per axis), so the search
+// stops as soon as k keys are held and the k-th distance is below (R*h)^2 (with a 0.1 % guard for the fp32 cell
+// quotient) — or the block covers the whole grid.  The kept set is an unordered LDS array with its maximum tracked;
+// a candidate is admitted iff its key is below that maximum (strict '<' on (distance, index)), exactly the
+// reference's rule whatever the order in which candidates are met.
+// MODE 0: squared distances (ogc_knn).  MODE 1: sqrt + radius clamp of the indices (ogc_knn_clamped).
+template <int MODE>
+__global__ __launch_bounds__(OGC_WAVE) void knn_grid_kernel(int n, int m, int k, float radius, int stride_cells,
+                                                            const float *__restrict__ unknown,
+                                                            const GridHdr *__restrict__ hdrs,
+                                                            const int *__restrict__ cell_start,
+                                                            const int *__restrict__ sorted_idx,
+                                                            const float *__restrict__ sorted_xyz,
+                                                            float *__restrict__ dist_out, int *__restrict__ idx_out) {
+    extern __shared__ __attribute__((aligned(16))) u64 kq_smem[];
+    const int lane = threadIdx.x, b = blockIdx.y;
+    const int sub = lane & (SUB - 1), qi = lane >> 3;
+    u64 *kept = kq_smem + (size_t)qi * k;           // [QPW][k]
+    u64 *outk = kq_smem + (size_t)(QPW + qi) * k;   // [QPW][k]
+    const int p = blockIdx.x * QPW + qi;
+    const GridHdr h = hdrs[b];
+    const int *cs = cell_start + (size_t)b * stride_cells;
+    const int *sidx = sorted_idx + (size_t)b * m;
+    const float *sxyz = sorted_xyz + (size_t)b * m * 3;
+    const unsigned below = (1u << sub) - 1u;
+
+    float qx = NAN, qy = NAN, qz = NAN;
+    if (p < n) {
+        const float *u = unknown + ((size_t)b * n + p) * 3;
+        qx = u[0]; qy = u[1]; qz = u[2];
+    }
+    int cnt = 0, maxpos = 0;
+    u64 maxkey = 0;
+    auto rescan_max = [&]() {
+        u64 mk = 0;
+        int mp = 0;
+        for (int e = sub; e < k; e += SUB) {
+            const u64 v = kept[e];
+            if (v >= mk) { mk = v; mp = e; }
+        }
+#pragma unroll
+        for (int off = 1; off < SUB; off <<= 1) {
+            const u64 ov = shfl_xor_u64(mk, off);
+            const int op = __shfl_xor(mp, off, 64);
+            if (ov > mk) { mk = ov; mp = op; }
+        }
+        maxkey = mk;
+        maxpos = mp;
+    };
+    // scan the run [j0, j1) of the cell-sorted arrays with the 8 lanes of the group
+    auto scan_run = [&](int j0, int j1) {
+        for (int j = j0 + sub; __builtin_amdgcn_ballot_w64(j < j1) != 0; j += SUB) {
+            bool adm = false;
+            u64 key = 0;
+            if (j < j1) {
+                const float d = ogc_sqdist(qx, qy, qz, sxyz[j * 3], sxyz[j * 3 + 1], sxyz[j * 3 + 2]);
+                if (d < INFINITY) { // NaN / inf are never selected
+                    key = ((u64)__float_as_uint(d) << 32) | (unsigned)sidx[j];
+                    adm = cnt < k || key < maxkey;
+                }
+            }
+            const u64 ball = __builtin_amdgcn_ballot_w64(adm);
+            if (ball == 0) continue;
+            const unsigned slice = (unsigned)(ball >> (qi * SUB)) & 0xFFu;
+            if (slice == 0) continue;
+            const int nh = __popc(slice);
+            if (cnt + nh <= k) {
+                if (adm) kept[cnt + __popc(slice & below)] = key;
+                cnt += nh;
+                if (cnt == k) rescan_max();
+            } else {
+                for (int t = 0; t < SUB; ++t) {
+                    if (!((slice >> t) & 1u)) continue;
+                    const u64 kt = shfl_u64(key, qi * SUB + t);
+                    if (cnt < k) {
+                        if (sub == 0) kept[cnt] = kt;
+                        if (++cnt == k) rescan_max();
+                    } else if (kt < maxkey) {
+                        if (sub == 0) kept[maxpos] = kt;
+                        rescan_max();
+                    }
+                }
+            }
+        }
+    };
+
+    const bool active = p < n && h.npts > 0 && qx == qx && qy == qy && qz == qz; // NaN queries select nothing
+    if (active) {
+        const float edge = 1.0f / h.inv_h;
+        const int cx = min(max(cell_coord(qx, h.minx, h.inv_h, h.gx), 0), h.gx - 1);
+        const int cy = min(max(cell_coord(qy, h.miny, h.inv_h, h.gy), 0), h.gy - 1);
+        const int cz = min(max(cell_coord(qz, h.minz, h.inv_h, h.gz), 0), h.gz - 1);
+        const int rmax = max(max(max(cx, h.gx - 1 - cx), max(cy, h.gy - 1 - cy)), max(cz, h.gz - 1 - cz));
+        for (int R = 1;; ++R) {
+            const int xa = max(cx - R, 0), xb = min(cx + R, h.gx - 1);
+            for (int z = max(cz - R, 0); z <= min(cz + R, h.gz - 1); ++z)
+                for (int y = max(cy - R, 0); y <= min(cy + R, h.gy - 1); ++y) {
+                    const int rowc = h.gx * (y + h.gy * z);
+                    const bool face = R == 1 || z == cz - R || z == cz + R || y == cy - R || y == cy + R;
+                    if (face) { // the whole x-extent of this row belongs to shell R (for R = 1: the full 3^3 block)
+                        scan_run(cs[rowc + xa], cs[rowc + xb + 1]);
+                    } else {    // inner row: only the two end cells are new
+                        if (cx - R >= 0) scan_run(cs[rowc + cx - R], cs[rowc + cx - R + 1]);
+                        if (cx + R <= h.gx - 1) scan_run(cs[rowc + cx + R], cs[rowc + cx + R + 1]);
+                    }
+                }
+            if (R >= rmax) break; // the block covers the grid
+            if (cnt == k) {
+                const float cover = (float)R * edge * 0.999f;
+                if (__uint_as_float((unsigned)(maxkey >> 32)) < cover * cover) break;
+            }
+        }
+    }
+    // rank sort (keys are distinct: the index is part of the key)
+    for (int e = sub; e < cnt; e += SUB) {
+        const u64 ve = kept[e];
+        int rank = 0;
+        for (int f = 0; f < cnt; ++f) rank += kept[f] < ve ? 1 : 0;
+        outk[rank] = ve;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    if (p < n) {
+        const size_t base = ((size_t)b * n + p) * k;
+        const int first = cnt > 0 ? (int)(unsigned)outk[0] : 0;
+        for (int j = sub; j < k; j += SUB) {
+            float d = INFINITY;
+            int id = 0;
+            if (j < cnt) {
+                const u64 key = outk[j];
+                d = __uint_as_float((unsigned)(key >> 32));
+                id = (int)(unsigned)key;
+            }
+            if (MODE == 1) {
+                d = sqrtf(d);
+                if (d > radius && radius >= 0.0f) id = first;
+            }
+            dist_out[base + j] = d;
+            idx_out[base + j] = id;
+        }
+    }
+}
+
 } // namespace ogc_grid
 
 using namespace ogc_grid;
@@ -314,7 +484,7 @@ int ogc_ball_query_grid(int b, int n, int m, float radius, int nsample, const fl
     int *cell_start = reinterpret_cast<int *>(ws + bytes_hdr);
     int *sorted_idx = reinterpret_cast<int *>(ws + bytes_hdr + bytes_cs);
     float *sorted_xyz = reinterpret_cast<float *>(ws + bytes_hdr + bytes_cs + bytes_idx);
-    hipLaunchKernelGGL(grid_build_kernel, dim3(b), dim3(BUILD_THREADS), 0, s, n, radius, stride_cells, xyz, hdrs,
+    hipLaunchKernelGGL(grid_build_kernel, dim3(b), dim3(BUILD_THREADS), 0, s, n, radius, 0, stride_cells, xyz, hdrs,
                        cell_start, sorted_idx, sorted_xyz);
     hipLaunchKernelGGL(ball_query_grid_kernel, dim3(ogc_divup(n, QPW), b), dim3(OGC_WAVE), lds, s, n, m,
                        radius * radius, nsample, stride_cells, hdrs, cell_start, sorted_idx, sorted_xyz, idx);
@@ -330,3 +500,40 @@ int ogc_ball_query_grid(int b, int n, int m, float radius, int nsample, const fl
 }
 
 void ogc_ball_query_grid_release(void *workspace, hipStream_t s) { (void)hipFreeAsync(workspace, s); }
+
+// k-NN over cell lists.  Returns OGC_OK after queueing build + query, or OGC_ERR_UNSUPPORTED (caller: all-pairs scan).
+int ogc_knn_grid(int mode, int b, int n, int m, int k, float radius, const float *unknown, const float *known,
+                 float *dist, int *idx, hipStream_t s) {
+    const size_t lds = (size_t)2 * QPW * k * sizeof(u64);
+    if (m < 1024 || m <= 4 * k || lds > 64 * 1024) return OGC_ERR_UNSUPPORTED;
+    const int stride_cells = GRID_MAX_CELLS + 1;
+    const size_t bytes_hdr = (sizeof(GridHdr) * b + 255) / 256 * 256;
+    const size_t bytes_cs = (sizeof(int) * (size_t)b * stride_cells + 255) / 256 * 256;
+    const size_t bytes_idx = (sizeof(int) * (size_t)b * m + 255) / 256 * 256;
+    const size_t bytes_xyz = sizeof(float) * (size_t)b * m * 3;
+    char *ws = nullptr;
+    if (hipMallocAsync((void **)&ws, bytes_hdr + bytes_cs + bytes_idx + bytes_xyz, s) != hipSuccess || !ws) {
+        (void)hipGetLastError();
+        return OGC_ERR_UNSUPPORTED;
+    }
+    GridHdr *hdrs = reinterpret_cast<GridHdr *>(ws);
+    int *cell_start = reinterpret_cast<int *>(ws + bytes_hdr);
+    int *sorted_idx = reinterpret_cast<int *>(ws + bytes_hdr + bytes_cs);
+    float *sorted_xyz = reinterpret_cast<float *>(ws + bytes_hdr + bytes_cs + bytes_idx);
+    hipLaunchKernelGGL(grid_build_kernel, dim3(b), dim3(BUILD_THREADS), 0, s, m, 0.0f, k, stride_cells, known, hdrs,
+                       cell_start, sorted_idx, sorted_xyz);
+    dim3 grid(ogc_divup(n, QPW), b);
+    if (mode == 1)
+        hipLaunchKernelGGL(knn_grid_kernel<1>, grid, dim3(OGC_WAVE), lds, s, n, m, k, radius, stride_cells, unknown, hdrs,
+                           cell_start, sorted_idx, sorted_xyz, dist, idx);
+    else
+        hipLaunchKernelGGL(knn_grid_kernel<0>, grid, dim3(OGC_WAVE), lds, s, n, m, k, radius, stride_cells, unknown, hdrs,
+                           cell_start, sorted_idx, sorted_xyz, dist, idx);
+    const hipError_t e = hipGetLastError();
+    (void)hipFreeAsync(ws, s);
+    if (e != hipSuccess) {
+        ogc_set_error("ogc_knn (grid): launch failed: %s", hipGetErrorString(e));
+        return OGC_ERR_LAUNCH;
+    }
+    return OGC_OK;
+}

@@ -19,7 +19,10 @@
 // "k smallest by (dist, index)" is what the reference's stable insertion computes, so results
 // are bit-identical: squared distance in fp32 with the reference's rounding sequence, non-finite
 // distances never selected, idx=0 / dist2=+inf tail when fewer than k candidates qualify.
+#include <stdlib.h>
+
 #include "ogc_common.h"
+#include "grid.h"
 
 namespace {
 
@@ -236,6 +239,17 @@ int knn_launch(const char *name, int b, int n, int m, int k, float radius, const
     OGC_REQUIRE(unknown && known && dist && idx, "%s: null pointer", name);
     OGC_REQUIRE((long long)b * n * k < (1ll << 31) && (long long)b * m * 3 < (1ll << 31),
                 "%s: tensor exceeds 32-bit indexing", name);
+    // Cell-list path (identical results); the all-pairs scan below remains for small clouds and as the fallback.
+    // OGC_KNN=brute|grid forces a path (development / tests).
+    static const char *mode = getenv("OGC_KNN");
+    if (!(mode && mode[0] == 'b')) {
+        const int rc = ogc_knn_grid(MODE, b, n, m, k, radius, unknown, known, dist, idx, (hipStream_t)stream);
+        if (rc != OGC_ERR_UNSUPPORTED) return rc;
+        if (mode && mode[0] == 'g') {
+            ogc_set_error("%s: grid path forced but not applicable (m=%d, k=%d)", name, m, k);
+            return OGC_ERR_UNSUPPORTED;
+        }
+    }
     dim3 grid(ogc_divup(n, OGC_WAVE), b);
     hipLaunchKernelGGL(knn_heap_kernel<MODE>, grid, dim3(OGC_WAVE), knn_lds_bytes(k),
                        (hipStream_t)stream, n, m, k, radius, unknown, known, dist, idx);

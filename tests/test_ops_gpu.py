@@ -473,3 +473,43 @@ def test_ball_query_grid_clustered(nat, oracle):
     idx.zero_()
     nat.ball_query_wrapper(2, 8192, 8192, 1.0, 64, t, t, idx)
     assert np.array_equal(idx.cpu().numpy(), oracle.ball_query(1.0, 64, flat, flat))
+
+
+GRID_KNN_CASES = [  # (n, m, k, scale, query_scale)
+    (2048, 8192, 64, (60, 4, 80), 1.0), (8192, 8192, 32, (60, 4, 80), 1.0), (700, 4096, 200, (1, 1, 1), 1.0),
+    (1000, 1024, 16, (60, 4, 80), 2.0),   # queries far outside the cloud's box
+    (513, 5000, 1, (60, 4, 80), 1.0), (64, 16384, 24, (60, 4, 80), 1.0), (300, 3000, 3, (1e-3, 1e-3, 1e-3), 1.0),
+]
+
+
+@pytest.mark.parametrize("n,m,k,scale,qs", GRID_KNN_CASES)
+def test_knn_grid_path_bit_exact(nat, oracle, n, m, k, scale, qs):
+    """Cell-list k-NN (m >= 1024): identical (dist2, idx) to the reference's stable insertion — duplicates, queries
+    outside the box, non-finite points and queries, shells beyond the first."""
+    rng = np.random.default_rng(n * 3 + m + k)
+    kn = cloud(rng, 2, m, scale=scale, dup=m // 6)
+    u = cloud(rng, 2, n, scale=tuple(qs * v for v in scale))
+    u[:, : min(n, 50)] = kn[:, : min(n, 50)]          # some queries coincide with points
+    kn[1, 7] = np.nan
+    kn[1, 300, 2] = np.inf
+    u[0, 3, 0] = np.nan
+    d2, idx = run_knn(nat, k, u, kn)
+    d2r, idxr = oracle.knn(k, u, kn)
+    assert np.array_equal(idx, idxr)
+    assert np.array_equal(d2, d2r)
+
+
+def test_knn_grid_clustered_and_flat(nat, oracle):
+    rng = np.random.default_rng(5)
+    rad = rng.random((2, 8192, 1), dtype=np.float32) ** 3 * 60
+    ang = rng.random((2, 8192, 1), dtype=np.float32) * 2 * np.pi
+    pc = np.concatenate([rad * np.cos(ang), rng.random((2, 8192, 1), dtype=np.float32) * 2 - 1, rad * np.sin(ang)], -1).astype(np.float32)
+    for cloud_ in (pc, np.concatenate([pc[..., :1], np.full_like(pc[..., :1], 0.5), pc[..., 2:]], -1)):
+        q = cloud_[:, ::4].copy()
+        d2, idx = run_knn(nat, 32, q, cloud_)
+        d2r, idxr = oracle.knn(32, q, cloud_)
+        assert np.array_equal(idx, idxr) and np.array_equal(d2, d2r)
+    same = np.ones((1, 2048, 3), np.float32)  # all points identical: every distance ties
+    d2, idx = run_knn(nat, 16, same[:, :100], same)
+    d2r, idxr = oracle.knn(16, same[:, :100], same)
+    assert np.array_equal(idx, idxr) and np.array_equal(d2, d2r)
