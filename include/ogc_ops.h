@@ -165,6 +165,14 @@ int ogc_group_norm_maxpool_bwd(int b, int c, int p, int s, int groups, int relu,
                                const int *argmax, const float *grad_out, float *grad_x, float *grad_gamma,
                                float *grad_beta, double *ws, ogc_stream_t stream);
 
+/* Weight gradient of a 1x1 convolution (bias-free), NCHW, fp32, on the fp32 MFMA pipe:
+ *   dw[co, ci] = sum_b sum_p dy[b, co, p] * x[b, ci, p]
+ * Replaces the weight-gradient half of the Conv2d(1x1) layers of SharedMLP (utils/nn_util.py:45-85, :155-172), which
+ * MIOpen computes through two full NCHW->NHWC transposes.  x (b, cin, hw), dy (b, cout, hw), dw (cout, cin) — dw is
+ * overwritten.  hw must be a multiple of 16 and x, dy 16-byte aligned (OGC_ERR_UNSUPPORTED otherwise). */
+int ogc_conv1x1_wgrad(int b, int cin, int cout, int hw, const float *x, const float *dy, float *dw,
+                      ogc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,148 @@
+// conv1x1.hip — weight gradient of the per-point (1x1) convolutions of the shared MLPs, on the fp32 MFMA pipe.
+//
+//     dW[co, ci] = sum_b sum_p dY[b, co, p] * X[b, ci, p]          X (B, Cin, HW), dY (B, Cout, HW), fp32, NCHW
+//
+// Replaces the weight-gradient half of the nn.Conv2d(kernel 1x1, bias=False) layers of SharedMLP
+// (reference: utils/nn_util.py:45-85, :155-172).  MIOpen serves this shape with an NHWC implicit-GEMM kernel wrapped
+// in two full-tensor NCHW->NHWC transposes (x and dy): on the C4 training step that is ~3 ms of transposes plus ~2 ms
+// of igemm per step.  Here the tensors are read once, in place:
+//   * GEMM view: M = Cout, N = Cin, K = B*HW (millions) — a tiny output and a huge reduction, i.e. a streaming,
+//     HBM-bound kernel; v_mfma_f32_16x16x4_f32 (exact fp32 FMA chains, 157 TF peak) keeps the math off the critical path;
+//   * operand layout without any shuffle: for a step of 16 positions, lane (i = l & 15, k = l >> 4) loads ONE float4
+//     = row (c0 + i), positions pb + 4k .. 4k+3.  MFMA k-slot k of sub-step s is position pb + 4k + s for BOTH
+//     operands, so component s of the two float4s are directly the A and B operands of sub-step s;
+//   * a wave owns a (16*COB) x (16*CIB) tile of dW in registers and strides over the positions; the next step's
+//     loads are issued before the current step's MFMAs; the four waves of a workgroup are reduced through LDS,
+//     workgroups through fp32 atomics into dW (zeroed by this entry point).
+#include "ogc_common.h"
+
+namespace {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+constexpr int WG_WAVES = 4;
+
+template <int COB, int CIB>
+__global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_wgrad_kernel(int batch, int cin, int cout, int hw,
+                                                                           int steps_per_wave,
+                                                                           const float *__restrict__ x,
+                                                                           const float *__restrict__ dy,
+                                                                           float *__restrict__ dw) {
+    __shared__ float red[COB * CIB * 256]; // the workgroup's partial tile: COB*CIB blocks of 16x16
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, k = lane >> 4;
+    const int co0 = blockIdx.y * (16 * COB), ci0 = blockIdx.z * (16 * CIB);
+    const int steps_per_img = hw >> 4;
+    const long long nsteps = (long long)batch * steps_per_img;
+    const long long first = ((long long)blockIdx.x * WG_WAVES + wave) * steps_per_wave;
+
+    v4f acc[COB][CIB];
+#pragma unroll
+    for (int a = 0; a < COB; ++a)
+#pragma unroll
+        for (int c = 0; c < CIB; ++c) acc[a][c] = (v4f){0.f, 0.f, 0.f, 0.f};
+
+    auto load = [&](long long step, float4(&yv)[COB], float4(&xv)[CIB]) {
+        const bool ok = step < nsteps;
+        const long long s = ok ? step : 0;
+        const int b = (int)(s / steps_per_img);
+        const int pb = (int)(s - (long long)b * steps_per_img) * 16 + 4 * k;
+#pragma unroll
+        for (int a = 0; a < COB; ++a) {
+            const int row = co0 + a * 16 + i;
+            yv[a] = (ok && row < cout) ? *reinterpret_cast<const float4 *>(dy + ((size_t)b * cout + row) * hw + pb)
+                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int c = 0; c < CIB; ++c) {
+            const int row = ci0 + c * 16 + i;
+            xv[c] = (ok && row < cin) ? *reinterpret_cast<const float4 *>(x + ((size_t)b * cin + row) * hw + pb)
+                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto fma16 = [&](const float4(&yv)[COB], const float4(&xv)[CIB]) {
+#pragma unroll
+        for (int a = 0; a < COB; ++a)
+#pragma unroll
+            for (int c = 0; c < CIB; ++c) {
+                acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(yv[a].x, xv[c].x, acc[a][c], 0, 0, 0);
+                acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(yv[a].y, xv[c].y, acc[a][c], 0, 0, 0);
+                acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(yv[a].z, xv[c].z, acc[a][c], 0, 0, 0);
+                acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(yv[a].w, xv[c].w, acc[a][c], 0, 0, 0);
+            }
+    };
+
+    float4 ya[COB], xa[CIB], yb[COB], xb[CIB];
+    load(first, ya, xa);
+    for (int s = 0; s < steps_per_wave; s += 2) { // ping-pong registers: next step's loads fly during the MFMAs
+        load(first + s + 1, yb, xb);
+        fma16(ya, xa);
+        load(first + s + 2, ya, xa);
+        if (s + 1 < steps_per_wave) fma16(yb, xb);
+    }
+
+    // C/D layout of 16x16x4: lane l holds rows (l >> 4) * 4 + r (r = 0..3) of column l & 15
+    for (int t = threadIdx.x; t < COB * CIB * 256; t += WG_WAVES * OGC_WAVE) red[t] = 0.0f;
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < COB; ++a)
+#pragma unroll
+        for (int c = 0; c < CIB; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                atomicAdd(&red[(a * CIB + c) * 256 + (k * 4 + r) * 16 + i], acc[a][c][r]);
+    __syncthreads();
+    for (int t = threadIdx.x; t < COB * CIB * 256; t += WG_WAVES * OGC_WAVE) {
+        const int blk = t >> 8, a = blk / CIB, c = blk % CIB;
+        const int row = co0 + a * 16 + ((t & 255) >> 4), col = ci0 + c * 16 + (t & 15);
+        const float v = red[t];
+        if (row < cout && col < cin && v != 0.0f) unsafeAtomicAdd(dw + (size_t)row * cin + col, v);
+    }
+}
+
+template <int COB, int CIB>
+void wgrad_launch(int b, int cin, int cout, int hw, const float *x, const float *dy, float *dw, hipStream_t s) {
+    const long long nsteps = (long long)b * (hw >> 4);
+    const int tiles = ogc_divup(cout, 16 * COB) * ogc_divup(cin, 16 * CIB);
+    // ~2048 waves over the chip per tile pair, but at least 8 steps (128 positions) per wave
+    long long waves = 2048 / tiles;
+    if (waves < 256) waves = 256;
+    long long spw = (nsteps + waves - 1) / waves;
+    if (spw < 8) spw = 8;
+    spw = (spw + 1) / 2 * 2;
+    const int wgs = (int)((nsteps + spw * WG_WAVES - 1) / (spw * WG_WAVES));
+    dim3 grid(wgs, ogc_divup(cout, 16 * COB), ogc_divup(cin, 16 * CIB));
+    hipLaunchKernelGGL((conv1x1_wgrad_kernel<COB, CIB>), grid, dim3(WG_WAVES * OGC_WAVE), 0, s, b, cin, cout, hw,
+                       (int)spw, x, dy, dw);
+}
+
+} // namespace
+
+extern "C" int ogc_conv1x1_wgrad(int b, int cin, int cout, int hw, const float *x, const float *dy, float *dw,
+                                 ogc_stream_t stream) {
+    OGC_REQUIRE(b >= 0 && cin >= 1 && cout >= 1 && hw >= 1, "ogc_conv1x1_wgrad: bad shape");
+    OGC_REQUIRE(x && dy && dw, "ogc_conv1x1_wgrad: null pointer");
+    if ((hw & 15) != 0 || (((uintptr_t)x | (uintptr_t)dy) & 15) != 0) {
+        ogc_set_error("ogc_conv1x1_wgrad: hw=%d must be a multiple of 16 and x/dy 16-byte aligned", hw);
+        return OGC_ERR_UNSUPPORTED;
+    }
+    OGC_REQUIRE((long long)b * cin * hw < (1ll << 31) && (long long)b * cout * hw < (1ll << 31),
+                "ogc_conv1x1_wgrad: tensor exceeds 32-bit indexing");
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(dw, 0, sizeof(float) * (size_t)cin * cout, s) != hipSuccess) {
+        ogc_set_error("ogc_conv1x1_wgrad: memset failed");
+        return OGC_ERR_LAUNCH;
+    }
+    if (b == 0) return OGC_OK;
+    // register tile per wave: (16*COB) x (16*CIB) outputs.  Small channel counts use small tiles so that no MFMA
+    // work is spent on padding; wide layers use 64x64 tiles (16 accumulators) and split the rest over the grid.
+    if (cout <= 16 && cin <= 16) wgrad_launch<1, 1>(b, cin, cout, hw, x, dy, dw, s);
+    else if (cout <= 32 && cin <= 16) wgrad_launch<2, 1>(b, cin, cout, hw, x, dy, dw, s);
+    else if (cout <= 32 && cin <= 32) wgrad_launch<2, 2>(b, cin, cout, hw, x, dy, dw, s);
+    else if (cin <= 16) wgrad_launch<4, 1>(b, cin, cout, hw, x, dy, dw, s);
+    else if (cin <= 32) wgrad_launch<4, 2>(b, cin, cout, hw, x, dy, dw, s);
+    else if (cout <= 32) wgrad_launch<2, 4>(b, cin, cout, hw, x, dy, dw, s);
+    else wgrad_launch<4, 4>(b, cin, cout, hw, x, dy, dw, s);
+    OGC_CHECK_LAUNCH("ogc_conv1x1_wgrad");
+    return OGC_OK;
+}

@@ -97,3 +97,41 @@ def group_norm_act_maxpool(x, gn: torch.nn.GroupNorm, relu: bool):
             and getattr(_api._native, "group_norm_maxpool_fwd_wrapper", None) is not None):
         return _GroupNormActMaxPool.apply(x, gn.weight, gn.bias, gn.num_groups, gn.eps, relu)
     return group_norm_act(x, gn, relu).max(dim=3)[0]
+
+
+class _PointwiseConv(Function):
+    """y = conv(x, w) for a bias-free 1x1 convolution.  Forward and the input gradient stay with the vendor library;
+    the WEIGHT gradient — which MIOpen computes through two full NCHW->NHWC transposes — is one launch of the fp32 MFMA
+    kernel ogc_conv1x1_wgrad on the NCHW tensors as they are."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        ctx.save_for_backward(x, weight)
+        return F.conv2d(x, weight) if x.dim() == 4 else F.conv1d(x, weight)
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        x, weight = ctx.saved_tensors
+        nd = x.dim() - 2
+        grad_y = grad_y.contiguous()
+        grad_x = grad_w = None
+        if ctx.needs_input_grad[0]:
+            grad_x = torch.ops.aten.convolution_backward(grad_y, x, weight, None, [1] * nd, [0] * nd, [1] * nd, False,
+                                                         [0] * nd, 1, [True, False, False])[0]
+        if ctx.needs_input_grad[1]:
+            B, cin = x.shape[0], x.shape[1]
+            cout = weight.shape[0]
+            grad_w = torch.empty(cout, cin, dtype=torch.float32, device=x.device)
+            _api._native.conv1x1_wgrad_wrapper(B, cin, cout, x.numel() // (B * cin), x, grad_y, grad_w)
+            grad_w = grad_w.view_as(weight)
+        return grad_x, grad_w
+
+
+def pointwise_conv(x, conv):
+    """Apply a Conv1d/Conv2d module; 1x1, stride-1, bias-free convolutions on the GPU go through _PointwiseConv."""
+    hw = x.numel() // max(x.shape[0] * x.shape[1], 1)
+    if (x.is_cuda and x.dtype == torch.float32 and conv.bias is None and conv.groups == 1 and hw % 16 == 0
+            and x.is_contiguous() and all(k == 1 for k in conv.kernel_size) and all(v == 1 for v in conv.stride)
+            and all(v == 0 for v in conv.padding) and getattr(_api._native, "conv1x1_wgrad_wrapper", None) is not None):
+        return _PointwiseConv.apply(x, conv.weight)
+    return conv(x)

@@ -177,3 +177,8 @@ def group_norm_maxpool_bwd_wrapper(b, c, p, s, groups, relu, x, gamma, mean, rst
          _f(mean, "mean"), _f(rstd, "rstd"), _f(out, "out"), _i(argmax, "argmax"), _f(grad_out, "grad_out"),
          _f(grad_x, "grad_x"), _f(grad_gamma, "grad_gamma"), _f(grad_beta, "grad_beta"),
          _check(ws, torch.float64, "ws"))
+
+
+def conv1x1_wgrad_wrapper(b, cin, cout, hw, x, dy, dw):
+    """dw[co, ci] = sum_{b,p} dy[b, co, p] x[b, ci, p] (ogc_conv1x1_wgrad); hw % 16 == 0."""
+    _run("ogc_conv1x1_wgrad", x, b, cin, cout, hw, _f(x, "x"), _f(dy, "dy"), _f(dw, "dw"))

@@ -93,18 +93,18 @@ class _ConvNd(nn.Sequential):
 
     def forward(self, input):
         if self._gn_fuse:
-            from ..fused import group_norm_act
+            from ..fused import group_norm_act, pointwise_conv
             conv_name, norm_name, relu = self._names
-            y = getattr(self, conv_name)(input)
+            y = pointwise_conv(input, getattr(self, conv_name))
             return group_norm_act(y, getattr(self, norm_name)[0], relu)
         return super().forward(input)
 
     def forward_maxpool(self, input):
         """forward followed by a max over the last dimension (fused with GroupNorm/ReLU where possible)."""
         if self._gn_fuse:
-            from ..fused import group_norm_act_maxpool
+            from ..fused import group_norm_act_maxpool, pointwise_conv
             conv_name, norm_name, relu = self._names
-            y = getattr(self, conv_name)(input)
+            y = pointwise_conv(input, getattr(self, conv_name))
             return group_norm_act_maxpool(y, getattr(self, norm_name)[0], relu)
         return self.forward(input).max(dim=-1)[0]
 
