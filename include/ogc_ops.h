@@ -173,6 +173,14 @@ int ogc_group_norm_maxpool_bwd(int b, int c, int p, int s, int groups, int relu,
 int ogc_conv1x1_wgrad(int b, int cin, int cout, int hw, const float *x, const float *dy, float *dw,
                       ogc_stream_t stream);
 
+/* Forward / input gradient of the same 1x1 convolution as one fp32-MFMA GEMM over NCHW tensors:
+ *   out[b, m, p] = sum_k A[m, k] * in[b, k, p]
+ * forward:        transpose_a = 0, A = w (M = Cout, K = Cin),  in = x,  out = y
+ * input gradient: transpose_a = 1, A = w^T (M = Cin, K = Cout), in = dy, out = dx      (w is always (Cout, Cin))
+ * Requires hw % 64 == 0, K <= 160 and 16-byte aligned tensors (OGC_ERR_UNSUPPORTED otherwise -> vendor conv). */
+int ogc_conv1x1_gemm(int b, int M, int K, int hw, int transpose_a, const float *w, const float *in,
+                     float *out, ogc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

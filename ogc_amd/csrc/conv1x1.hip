@@ -118,6 +118,113 @@ void wgrad_launch(int b, int cin, int cout, int hw, const float *x, const float 
 
 } // namespace
 
+namespace {
+
+// ---- forward / input-gradient GEMM:  OUT[b, m, p] = sum_k A[m, k] * IN[b, k, p] -----------------------------------
+// forward: A = W (M = Cout, K = Cin, IN = x);  input gradient: A = W^T (M = Cin, K = Cout, IN = dy).
+// A wave owns 64 positions.  Lane (k' = l >> 4, j = l & 15) loads the float4 IN[k0 + k'][p0 + 4j .. 4j+3]; MFMA column
+// block c (c = 0..3) takes component c of it, i.e. column j of block c is position p0 + 4j + c.  The same lane then
+// holds the four consecutive positions of an output row in its four column-block accumulators, so results leave as
+// float4 stores — no shuffles on either side.  The whole IN tile (K x 64) stays in registers (read from HBM exactly
+// once); A is staged through LDS in [k/4][m][4] order (conflict-free ds_read_b32 of the A operand) one 64-row tile at
+// a time and shared by the four waves of the workgroup.
+constexpr int FW_KQ_MAX = 40; // K <= 160 channels held in registers (40 float4 per lane)
+
+template <bool TRANSPOSE_A>
+__global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_gemm_kernel(int M, int K, int hw,
+                                                                          const float *__restrict__ w, // (Cout, Cin)
+                                                                          const float *__restrict__ in,
+                                                                          float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float a_lds[]; // [Kq][64][4] for the current 64-row tile of A
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, kk = lane >> 4;
+    const int b = blockIdx.y;
+    const int p0 = (blockIdx.x * WG_WAVES + wave) * 64;
+    const int Kq = (K + 3) >> 2;
+    const bool live = p0 < hw; // hw is a multiple of 64 for every wave that is live
+    const float *inb = in + (size_t)b * K * hw;
+    float *outb = out + (size_t)b * M * hw;
+
+    float4 xin[FW_KQ_MAX];
+#pragma unroll
+    for (int q = 0; q < FW_KQ_MAX; ++q) {
+        const int row = q * 4 + kk;
+        xin[q] = (live && q < Kq && row < K) ? *reinterpret_cast<const float4 *>(inb + (size_t)row * hw + p0 + 4 * j)
+                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int m0 = 0; m0 < M; m0 += 64) {
+        __syncthreads(); // previous tile fully consumed
+        // stage A[m0 .. m0+63][0 .. K) as a_lds[(q * 64 + mi) * 4 + kr] = A[m0 + mi][4q + kr]
+        for (int t = threadIdx.x; t < Kq * 256; t += WG_WAVES * OGC_WAVE) {
+            const int kr = t & 3, mi = (t >> 2) & 63, q = t >> 8;
+            const int m = m0 + mi, k = q * 4 + kr;
+            float v = 0.f;
+            if (m < M && k < K) v = TRANSPOSE_A ? w[(size_t)k * M + m] : w[(size_t)m * K + k];
+            a_lds[t] = v;
+        }
+        __syncthreads();
+        v4f acc[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[a][c] = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < FW_KQ_MAX; ++q) {
+            if (q < Kq) {
+                float av[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) av[a] = a_lds[(q * 64 + a * 16 + j) * 4 + kk]; // A[m0+16a+j][4q+kk]
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], xin[q].x, acc[a][0], 0, 0, 0);
+                    acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], xin[q].y, acc[a][1], 0, 0, 0);
+                    acc[a][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], xin[q].z, acc[a][2], 0, 0, 0);
+                    acc[a][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], xin[q].w, acc[a][3], 0, 0, 0);
+                }
+            }
+        }
+        if (live) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + a * 16 + kk * 4 + r; // C/D layout: row (l >> 4) * 4 + r, column l & 15
+                    if (m < M) {
+                        const float4 o = make_float4(acc[a][0][r], acc[a][1][r], acc[a][2][r], acc[a][3][r]);
+                        *reinterpret_cast<float4 *>(outb + (size_t)m * hw + p0 + 4 * j) = o;
+                    }
+                }
+        }
+    }
+}
+
+} // namespace
+
+// OUT[b, m, p] = sum_k A[m, k] IN[b, k, p];  transpose_a == 0: A = w (M x K);  != 0: A = w^T with w stored (K x M).
+extern "C" int ogc_conv1x1_gemm(int b, int M, int K, int hw, int transpose_a, const float *w, const float *in,
+                                float *out, ogc_stream_t stream) {
+    OGC_REQUIRE(b >= 0 && M >= 1 && K >= 1 && hw >= 1, "ogc_conv1x1_gemm: bad shape");
+    OGC_REQUIRE(w && in && out, "ogc_conv1x1_gemm: null pointer");
+    if ((hw & 63) != 0 || K > 4 * FW_KQ_MAX || (((uintptr_t)in | (uintptr_t)out) & 15) != 0) {
+        ogc_set_error("ogc_conv1x1_gemm: needs hw %% 64 == 0, K <= %d and 16-byte aligned tensors (hw=%d, K=%d)",
+                      4 * FW_KQ_MAX, hw, K);
+        return OGC_ERR_UNSUPPORTED;
+    }
+    OGC_REQUIRE((long long)b * M * hw < (1ll << 31) && (long long)b * K * hw < (1ll << 31),
+                "ogc_conv1x1_gemm: tensor exceeds 32-bit indexing");
+    if (b == 0) return OGC_OK;
+    const size_t lds = (size_t)((K + 3) / 4) * 256 * sizeof(float);
+    dim3 grid(ogc_divup(hw, 64 * WG_WAVES), b);
+    if (transpose_a)
+        hipLaunchKernelGGL(conv1x1_gemm_kernel<true>, grid, dim3(WG_WAVES * OGC_WAVE), lds, (hipStream_t)stream, M, K, hw, w,
+                           in, out);
+    else
+        hipLaunchKernelGGL(conv1x1_gemm_kernel<false>, grid, dim3(WG_WAVES * OGC_WAVE), lds, (hipStream_t)stream, M, K, hw,
+                           w, in, out);
+    OGC_CHECK_LAUNCH("ogc_conv1x1_gemm");
+    return OGC_OK;
+}
+
 extern "C" int ogc_conv1x1_wgrad(int b, int cin, int cout, int hw, const float *x, const float *dy, float *dw,
                                  ogc_stream_t stream) {
     OGC_REQUIRE(b >= 0 && cin >= 1 && cout >= 1 && hw >= 1, "ogc_conv1x1_wgrad: bad shape");

@@ -99,14 +99,26 @@ def group_norm_act_maxpool(x, gn: torch.nn.GroupNorm, relu: bool):
     return group_norm_act(x, gn, relu).max(dim=3)[0]
 
 
+def _gemm_ok(K, hw):
+    return hw % 64 == 0 and K <= 160
+
+
 class _PointwiseConv(Function):
-    """y = conv(x, w) for a bias-free 1x1 convolution.  Forward and the input gradient stay with the vendor library;
-    the WEIGHT gradient — which MIOpen computes through two full NCHW->NHWC transposes — is one launch of the fp32 MFMA
-    kernel ogc_conv1x1_wgrad on the NCHW tensors as they are."""
+    """y = conv(x, w) for a bias-free 1x1 convolution on NCHW fp32 tensors, on the hand-written fp32-MFMA kernels:
+    ogc_conv1x1_gemm for the forward and the input gradient (when the shape fits its register tile; the vendor library
+    otherwise) and ogc_conv1x1_wgrad for the weight gradient (which MIOpen computes through two full NCHW->NHWC
+    transposes)."""
 
     @staticmethod
     def forward(ctx, x, weight):
         ctx.save_for_backward(x, weight)
+        B, cin = x.shape[0], x.shape[1]
+        cout = weight.shape[0]
+        hw = x.numel() // (B * cin)
+        if _gemm_ok(cin, hw):
+            y = torch.empty((B, cout) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+            _api._native.conv1x1_gemm_wrapper(B, cout, cin, hw, 0, weight.detach().contiguous(), x, y)
+            return y
         return F.conv2d(x, weight) if x.dim() == 4 else F.conv1d(x, weight)
 
     @staticmethod
@@ -114,15 +126,20 @@ class _PointwiseConv(Function):
         x, weight = ctx.saved_tensors
         nd = x.dim() - 2
         grad_y = grad_y.contiguous()
+        B, cin = x.shape[0], x.shape[1]
+        cout = weight.shape[0]
+        hw = x.numel() // (B * cin)
         grad_x = grad_w = None
         if ctx.needs_input_grad[0]:
-            grad_x = torch.ops.aten.convolution_backward(grad_y, x, weight, None, [1] * nd, [0] * nd, [1] * nd, False,
-                                                         [0] * nd, 1, [True, False, False])[0]
+            if _gemm_ok(cout, hw):
+                grad_x = torch.empty_like(x)
+                _api._native.conv1x1_gemm_wrapper(B, cin, cout, hw, 1, weight.detach().contiguous(), grad_y, grad_x)
+            else:
+                grad_x = torch.ops.aten.convolution_backward(grad_y, x, weight, None, [1] * nd, [0] * nd, [1] * nd,
+                                                             False, [0] * nd, 1, [True, False, False])[0]
         if ctx.needs_input_grad[1]:
-            B, cin = x.shape[0], x.shape[1]
-            cout = weight.shape[0]
             grad_w = torch.empty(cout, cin, dtype=torch.float32, device=x.device)
-            _api._native.conv1x1_wgrad_wrapper(B, cin, cout, x.numel() // (B * cin), x, grad_y, grad_w)
+            _api._native.conv1x1_wgrad_wrapper(B, cin, cout, hw, x, grad_y, grad_w)
             grad_w = grad_w.view_as(weight)
         return grad_x, grad_w
 

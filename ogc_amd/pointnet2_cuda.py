@@ -182,3 +182,8 @@ def group_norm_maxpool_bwd_wrapper(b, c, p, s, groups, relu, x, gamma, mean, rst
 def conv1x1_wgrad_wrapper(b, cin, cout, hw, x, dy, dw):
     """dw[co, ci] = sum_{b,p} dy[b, co, p] x[b, ci, p] (ogc_conv1x1_wgrad); hw % 16 == 0."""
     _run("ogc_conv1x1_wgrad", x, b, cin, cout, hw, _f(x, "x"), _f(dy, "dy"), _f(dw, "dw"))
+
+
+def conv1x1_gemm_wrapper(b, M, K, hw, transpose_a, w, inp, out):
+    """out[b, m, p] = sum_k A[m, k] in[b, k, p], A = w or w^T (ogc_conv1x1_gemm); hw % 64 == 0, K <= 160."""
+    _run("ogc_conv1x1_gemm", inp, b, M, K, hw, int(transpose_a), _f(w, "w"), _f(inp, "in"), _f(out, "out"))

@@ -544,3 +544,23 @@ def test_pointwise_conv_autograd_matches_conv2d(nat):
     torch.testing.assert_close(y, y2, rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(gx, gx2, rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(gw, gw2, rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("B,cin,cout,hw", [(2, 6, 32, 256), (3, 32, 32, 1024), (2, 99, 64, 512), (2, 131, 128, 256),
+                                           (1, 64, 256, 64), (4, 32, 64, 131072), (2, 160, 48, 128), (2, 128, 256, 2048)])
+def test_conv1x1_gemm_forward_and_dgrad(nat, B, cin, cout, hw):
+    torch.manual_seed(cin + cout)
+    w = torch.randn(cout, cin, device=DEV) * 0.3
+    x = torch.randn(B, cin, hw, device=DEV)
+    y = torch.full((B, cout, hw), float("nan"), device=DEV)
+    nat.conv1x1_gemm_wrapper(B, cout, cin, hw, 0, w, x, y)
+    ref = torch.einsum("oi,bip->bop", w.double(), x.double())
+    scale = torch.einsum("oi,bip->bop", w.double().abs(), x.double().abs())
+    assert ((y.double() - ref).abs() / scale).max().item() < 1e-6
+    if cout <= 160:
+        dy = torch.randn(B, cout, hw, device=DEV)
+        dx = torch.full((B, cin, hw), float("nan"), device=DEV)
+        nat.conv1x1_gemm_wrapper(B, cin, cout, hw, 1, w, dy, dx)
+        ref = torch.einsum("oi,bop->bip", w.double(), dy.double())
+        scale = torch.einsum("oi,bop->bip", w.double().abs(), dy.double().abs())
+        assert ((dx.double() - ref).abs() / scale).max().item() < 1e-6
