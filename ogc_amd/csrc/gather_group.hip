@@ -96,18 +96,38 @@ __global__ __launch_bounds__(GG_THREADS) void group_bwd_lds_kernel(int c, int n,
     __syncthreads();
     const int *id = idx + (size_t)b * T;
     const float *g = grad_out + ((size_t)b * c + c0) * T;
-    // t_begin and t_per_block are multiples of 4; T % 4 == 0 is guaranteed by the launcher
-    for (int t4 = t_begin + threadIdx.x * 4; t4 < t_end; t4 += GG_THREADS * 4) {
-        const int4 i4 = *reinterpret_cast<const int4 *>(id + t4);
+    // A thread owns 16 consecutive positions (64 contiguous bytes per channel) and merges runs of equal indices
+    // before touching LDS: neighbour rows end in long runs of the SAME index (kNN rows clamped to the nearest
+    // neighbour beyond the radius, ball-query rows padded with the first hit), which would otherwise serialise as
+    // same-address atomics.  t_begin, t_per_block and T are multiples of 16 on this path.
+    for (int t16 = t_begin + threadIdx.x * 16; t16 < t_end; t16 += GG_THREADS * 16) {
+        int ids[16];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int4 i4 = *reinterpret_cast<const int4 *>(id + t16 + 4 * u);
+            ids[4 * u] = i4.x; ids[4 * u + 1] = i4.y; ids[4 * u + 2] = i4.z; ids[4 * u + 3] = i4.w;
+        }
 #pragma unroll
         for (int cc = 0; cc < CC; ++cc) {
             if (cc < ncc) {
-                const float4 v = *reinterpret_cast<const float4 *>(g + (size_t)cc * T + t4);
+                float v[16];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float4 f = *reinterpret_cast<const float4 *>(g + (size_t)cc * T + t16 + 4 * u);
+                    v[4 * u] = f.x; v[4 * u + 1] = f.y; v[4 * u + 2] = f.z; v[4 * u + 3] = f.w;
+                }
                 float *a = gb_acc + cc * n;
-                atomicAdd(a + i4.x, v.x);
-                atomicAdd(a + i4.y, v.y);
-                atomicAdd(a + i4.z, v.z);
-                atomicAdd(a + i4.w, v.w);
+                float run = v[0];
+#pragma unroll
+                for (int u = 1; u < 16; ++u) {
+                    if (ids[u] == ids[u - 1]) {
+                        run += v[u];
+                    } else {
+                        atomicAdd(a + ids[u - 1], run);
+                        run = v[u];
+                    }
+                }
+                atomicAdd(a + ids[15], run);
             }
         }
     }
@@ -158,7 +178,7 @@ int group_bwd(const char *name, int b, int c, int n, int T, const float *grad_ou
                 "%s: tensor exceeds 32-bit indexing", name);
     const bool vec = (T % 4 == 0) && aligned16(idx) && aligned16(grad_out);
     // LDS-privatised path: the per-channel image (n floats) must fit a 64 KiB budget at least once
-    if (vec && n <= 16384 && T >= 4096) {
+    if (vec && n <= 16384 && T >= 4096 && T % 16 == 0) {
         int cc = 16384 / n; // channels per workgroup within 64 KiB
         cc = cc >= 8 ? 8 : (cc >= 4 ? 4 : (cc >= 2 ? 2 : 1));
         while (cc > 1 && cc / 2 >= c) cc /= 2;
@@ -167,7 +187,7 @@ int group_bwd(const char *name, int b, int c, int n, int T, const float *grad_ou
         int splits = 1;
         while ((long long)b * chunks * splits < 512 && T / (splits * 2) >= 8192) splits *= 2;
         int tpb = ogc_divup(T, splits);
-        tpb = (tpb + 1023) / 1024 * 1024;
+        tpb = (tpb + 4095) / 4096 * 4096; // multiple of 256 threads x 16 positions
         dim3 grid(ogc_divup(T, tpb), chunks, b);
         const size_t lds = (size_t)cc * n * sizeof(float);
 #define GB_LAUNCH(CCV)                                                                                    \
