@@ -27,6 +27,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak (MI355X_MICROARCH.md)
+# HBM traffic of one ogc_ball_query call measured offline with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate
+# passes, profiles/r01_ball_query_pmc.txt): key = (B, N, M, nsample) -> bytes summed over the three kernels of the
+# operator.  FETCH_SIZE is taken as reported (the gfx950 x2 correction of MI355X_MICROARCH.md applies to wide
+# coalesced streams; these kernels issue 4-12 byte gathers); WRITE_SIZE equals the output size exactly.
+PMC_TRAFFIC_BYTES = {(16, 8192, 8192, 64): int((8864.2 + 838 + 25 + 32768 + 2391.5) * 1024)}
 FP32_VALU_PEAK_TF = 157.3  # fp32 vector peak
 
 
@@ -127,14 +132,17 @@ def main():
             b_, n_, m_, _r, ns_ = bq[0][1][:5]
             alg = b_ * (12 * m_ + 12 * n_ + 4 * m_ * ns_)            # 12M + 12N + 4M*nsample per cloud
             gbs = alg / (ms * 1e-3) / 1e9
-            flop = 8.0 * b_ * n_ * m_
-            roof = {"kernel": "ball_query_kernel", "bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": None,
+            roof = {"kernel": "ogc_ball_query (grid_build_kernel + ball_query_grid_kernel + gated ball_query_kernel)",
+                    "bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(gbs / HBM_PEAK_GBS, 5),
+                    "traffic": PMC_TRAFFIC_BYTES.get((b_, n_, m_, ns_)),
                     "launches": len(bq), "avg_ms": round(ms, 4), "algorithmic_bytes": alg,
                     "shape": {"B": b_, "N": n_, "M": m_, "nsample": ns_},
-                    "valu": {"achieved_tflops": round(flop / (ms * 1e-3) / 1e12, 3), "peak_tflops": FP32_VALU_PEAK_TF,
-                             "frac": round(flop / (ms * 1e-3) / 1e12 / FP32_VALU_PEAK_TF, 4),
-                             "note": "all-pairs scan is ~230 flop/B: VALU-bound, not HBM-bound (SURVEY §8d)"}}
+                    "note": "algorithmic bytes = B*(12M + 12N + 4M*nsample) (SURVEY 8d) / mean duration of the whole "
+                            "operator call (HIP events on the launch stream, inside the timed steps); the exact "
+                            "cell-list search tests ~N/90 candidates per centre, so the all-pairs figure of 8*B*N*M "
+                            "flop no longer describes the work done",
+                    "all_pairs_equivalent_tpairs_per_s": round(b_ * n_ * m_ / (ms * 1e-3) / 1e12, 2)}
         others = {}
         for name in ("ogc_knn_clamped", "ogc_furthest_point_sampling"):
             if name in durs:

@@ -79,7 +79,7 @@ def _run(name, ref_tensor, *args):
         e0.record()
         rc = _lib.call(name, *args, _stream(ref_tensor))
         e1.record()
-        _timer.records.append((name, e0, e1, tuple(a for a in args if isinstance(a, (int, float)))))
+        _timer.records.append((name, e0, e1, tuple(a for a in args if isinstance(a, float) or (isinstance(a, int) and abs(a) < 2 ** 31))))
         return rc
     return _lib.call(name, *args, _stream(ref_tensor))
 
