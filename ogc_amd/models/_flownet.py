@@ -6,7 +6,8 @@ checkpoints (``encoder_loc.sa1.mlp_convs.0.weight``, ``global_corr_layer.epsilon
 import torch
 import torch.nn as nn
 
-from ..utils.flowstep3d_util import FlowEmbedding, PointNetFeaturePropogation, PointNetSetAbstraction
+from ..utils.flowstep3d_util import (FlowEmbedding, PointNetFeaturePropogation, PointNetSetAbstraction,
+                                     geometry_memo)
 
 
 def _sa(npoint, nsample, in_channel, mlp, inorm, **kw):
@@ -205,6 +206,10 @@ class FlowStep3DBase(nn.Module):
 
     def forward(self, pc1, pc2, feature1, feature2, iters=1):
         # pc*, feature* (B, N, 3) -> list of `iters` flow predictions, each (B, N, 3)
+        with geometry_memo():  # FPS / kNN on unchanged coordinates are computed once per forward
+            return self._forward(pc1, pc2, feature1, feature2, iters)
+
+    def _forward(self, pc1, pc2, feature1, feature2, iters):
         flow_predictions = []
         pc1 = pc1.permute(0, 2, 1).contiguous()
         pc2 = pc2.permute(0, 2, 1).contiguous()

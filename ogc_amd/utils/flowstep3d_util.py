@@ -9,6 +9,36 @@ from ..pointnet2.pointnet2 import (GroupAll, QueryAndGroup, ball_query, furthest
                                    grouping_operation, knn, knn_radius_clamp, three_nn)
 
 
+class geometry_memo:
+    """Scope in which set-abstraction layers share coordinate-only work.  FlowStep3D applies ten different SA layers
+    to the SAME coordinates (`pc1_l_loc[2]`) in every refinement iteration, and every one of them re-runs a full FPS
+    (2048 sequential rounds) and a kNN on identical inputs (reference: models/flownet_kitti.py:231-250, SURVEY.md
+    §3.2).  FPS(xyz, npoint) and kNN(k, new_xyz, xyz) are pure functions of the coordinates, and the k nearest of a
+    larger search are a prefix of it, so inside this scope they are computed once per distinct coordinate tensor.
+    Keys hold a reference to the tensor, so a cached entry can never alias a recycled allocation."""
+    _active = None
+
+    def __enter__(self):
+        self._prev = geometry_memo._active
+        geometry_memo._active = {}
+        return self
+
+    def __exit__(self, *exc):
+        geometry_memo._active = self._prev
+
+    @staticmethod
+    def entry(xyz):
+        memo = geometry_memo._active
+        if memo is None:
+            return None
+        key = (xyz.data_ptr(), xyz._version, tuple(xyz.shape))
+        hit = memo.get(key)
+        if hit is None or hit["ref"] is not xyz:
+            hit = {"ref": xyz, "xyz_t": None, "fps": {}, "new_xyz": {}, "knn": {}}
+            memo[key] = hit
+        return hit
+
+
 def _norm2d(channels, use_instance_norm):
     return nn.InstanceNorm2d(channels, affine=True) if use_instance_norm else nn.BatchNorm2d(channels)
 
@@ -85,14 +115,45 @@ class PointNetSetAbstraction(nn.Module):
     def forward(self, xyz, points, fps_idx=None):
         # xyz (B, 3, N), points (B, D, N) -> new_xyz (B, 3, S), new_points (B, D', S) [, fps_idx (B, S)]
         xyz = xyz.contiguous()
-        xyz_t = xyz.permute(0, 2, 1).contiguous()
-        if (not self.group_all) and (self.npoint != -1):
+        memo = geometry_memo.entry(xyz)
+        if memo is not None and memo["xyz_t"] is not None:
+            xyz_t = memo["xyz_t"]
+        else:
+            xyz_t = xyz.permute(0, 2, 1).contiguous()
+            if memo is not None:
+                memo["xyz_t"] = xyz_t
+        sampled = (not self.group_all) and (self.npoint != -1)
+        given_idx = fps_idx is not None
+        if sampled:
             if fps_idx is None:
-                fps_idx = furthest_point_sample(xyz_t, self.npoint)
-            new_xyz = gather_operation(xyz, fps_idx)
+                if memo is not None and self.npoint in memo["fps"]:
+                    fps_idx = memo["fps"][self.npoint]
+                else:
+                    fps_idx = furthest_point_sample(xyz_t, self.npoint)
+                    if memo is not None:
+                        memo["fps"][self.npoint] = fps_idx
+            if memo is not None and not given_idx and self.npoint in memo["new_xyz"]:
+                new_xyz = memo["new_xyz"][self.npoint]
+            else:
+                new_xyz = gather_operation(xyz, fps_idx)
+                if memo is not None and not given_idx:
+                    memo["new_xyz"][self.npoint] = new_xyz
         else:
             new_xyz = xyz
-        new_points, _ = self.queryandgroup(xyz_t, new_xyz.transpose(2, 1).contiguous(), points)
+        neighbours = None
+        if memo is not None and sampled and not given_idx and isinstance(self.queryandgroup, QueryAndGroup):
+            # un-clamped kNN shared between layers: the k nearest are a prefix of any larger search on the same inputs
+            k = self.nsample
+            cached = memo["knn"].get(self.npoint)
+            if cached is None or cached[1].shape[2] < k:
+                kk = min(max(k, 32), xyz_t.shape[1])
+                cached = knn_radius_clamp(max(kk, k), None, new_xyz.transpose(2, 1).contiguous(), xyz_t)
+                memo["knn"][self.npoint] = cached
+            neighbours = (cached[0][:, :, :k].contiguous(), cached[1][:, :, :k].contiguous())
+        if neighbours is not None:
+            new_points, _ = self.queryandgroup(xyz_t, new_xyz.transpose(2, 1).contiguous(), points, neighbours=neighbours)
+        else:
+            new_points, _ = self.queryandgroup(xyz_t, new_xyz.transpose(2, 1).contiguous(), points)
         for conv, bn in zip(self.mlp_convs, self.mlp_bns):
             new_points = self.act(bn(conv(new_points))) if self.use_act else conv(new_points)
         new_points = new_points.mean(dim=-1) if self.mean_aggr else new_points.max(dim=-1)[0]
