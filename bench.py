@@ -81,7 +81,8 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    under_launcher = "RANK" in os.environ and "MASTER_ADDR" in os.environ
+    if world > 1 or under_launcher:  # a 1-process torchrun launch still exercises RCCL init + the DDP wrapper
         dist.init_process_group("nccl", device_id=dev)
     assert world == a.gpus, "--gpus %d but WORLD_SIZE=%d" % (a.gpus, world)
 
@@ -95,7 +96,7 @@ def main():
     net = MaskFormer3D(n_slot=10, n_point=a.npoint, use_xyz=True, n_transformer_layer=2,
                        transformer_embed_dim=128, transformer_input_pos_enc=False).to(dev)
     model = net
-    if world > 1:
+    if dist.is_initialized():
         model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[local], bucket_cap_mb=25,
                                                           gradient_as_bucket_view=True)
     crit = build_criterion(KITTI_LOSS)
@@ -104,7 +105,7 @@ def main():
     clouds_per_step = a.batch * 4
 
     def sync():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -119,7 +120,7 @@ def main():
         sync()
         elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-    if world > 1:
+    if dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
@@ -169,7 +170,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.npoint)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
