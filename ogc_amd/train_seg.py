@@ -1,0 +1,183 @@
+"""Unsupervised OGC segmentation training driver on the MI355X operators — the caller of the hot path
+(counterpart of the reference's train_seg.py:19-352, written against this repo's layers).
+
+    python -m ogc_amd.train_seg config.yaml --round 1 [--synthetic N_SCENES] [--max-iters K]
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m ogc_amd.train_seg config.yaml ...
+
+What is kept from the reference so that its configs, schedules and checkpoints carry over:
+  * the YAML schema (config/seg/*/*.yaml): dataset, save_path, random_seed, aug_transform_epoch, epochs, batch_size,
+    lr, lr_decay, lr_clip, bn_momentum, bn_decay, weight_decay, decay_step, segnet{...}, loss{...};
+  * Adam + LambdaLR(lr_curve) + norm-momentum schedule (train_seg.py:230-245), both driven by samples seen
+    (`it * batch_size`; under DDP the GLOBAL batch, so the schedule is independent of the number of GPUs);
+  * augmented views (and the invariance loss) switch on after `aug_transform_epoch` epochs (train_seg.py:151-154);
+  * loss weights gated by `it * batch` (train_seg.py:70), NaN-gradient skip (train_seg.py:81-83, in train_step);
+  * checkpoints {'model_state': state_dict} as current.pth.tar / best.pth.tar in `<save_path>_R<round>`, the initial
+    weights saved as both (utils/pytorch_util.py:84-99, train_seg.py:137-140).
+Out of scope here: the dataset readers, tensorboard, per-step segmentation metrics.  Without a dataset the
+driver trains on seeded synthetic scenes with the loaders' sample contract (ogc_amd/utils/synthetic.py).
+"""
+import argparse
+import importlib
+import json
+import os
+import shutil
+import time
+
+import torch
+import torch.distributed as dist
+import yaml
+
+from .train_step import build_criterion, train_step
+from .utils.synthetic import make_scene_batch
+
+SEGNETS = {"sapien": "segnet_sapien", "ogcdr": "segnet_ogcdr", "kittisf": "segnet_kitti", "waymo": "segnet_kitti"}
+NORM_LAYERS = (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d, torch.nn.BatchNorm3d, torch.nn.InstanceNorm1d,
+               torch.nn.InstanceNorm2d, torch.nn.InstanceNorm3d, torch.nn.GroupNorm)
+
+
+class SyntheticScenes(torch.utils.data.Dataset):
+    """`n_scene` seeded scenes; item = (pcs (t,N,3), segms (t,N), flows (t,N,3), valids (t,N)), t = 2 or 4 views."""
+
+    def __init__(self, n_scene, n_point, n_object, outdoor, seed=0):
+        self.n_scene, self.n_point, self.n_object, self.outdoor, self.seed = n_scene, n_point, n_object, outdoor, seed
+        self.aug_transform = False
+
+    def __len__(self):
+        return self.n_scene
+
+    def __getitem__(self, i):
+        pcs, segms, flows, valids = make_scene_batch(1, self.n_point, self.n_object, seed=self.seed + i,
+                                                     outdoor=self.outdoor, aug=self.aug_transform)
+        return pcs[0], segms[0], flows[0], valids[0]
+
+
+def schedule_factor(cfg, samples_seen):
+    """lr multiplier (train_seg.py:230-234)."""
+    return max(cfg["lr_decay"] ** int(samples_seen / cfg["decay_step"]), cfg["lr_clip"] / cfg["lr"])
+
+
+def norm_momentum(cfg, samples_seen):
+    """momentum of the norm layers (train_seg.py:237-245)."""
+    if cfg["decay_step"] == -1:
+        return cfg["bn_momentum"]
+    return max(cfg["bn_momentum"] * cfg["bn_decay"] ** int(samples_seen / cfg["decay_step"]), 1e-2)
+
+
+def save_checkpoint(net, exp_base, is_best):
+    state = {"model_state": net.state_dict()}
+    cur = os.path.join(exp_base, "current.pth.tar")
+    torch.save(state, cur)
+    if is_best:
+        shutil.copyfile(cur, os.path.join(exp_base, "best.pth.tar"))
+
+
+def evaluate(model, criterion, loader, device):
+    model.eval()
+    total, count = 0.0, 0
+    with torch.no_grad():
+        for pcs, segms, flows, valids in loader:
+            pcs, flows = pcs.to(device), flows.to(device)
+            b, t, n = segms.shape
+            flat = pcs.view(b * t, n, -1).contiguous()
+            masks = model(flat, flat).view(b, t, n, -1)
+            loss, _ = criterion([pcs[:, i].contiguous() for i in range(t)], [masks[:, i].contiguous() for i in range(t)],
+                                [flows[:, i].contiguous() for i in range(t)], step_w=False)
+            total += float(loss)
+            count += 1
+    return total / max(count, 1)
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("config")
+    ap.add_argument("--round", type=int, default=0)
+    ap.add_argument("--synthetic", type=int, default=64, help="number of synthetic training scenes")
+    ap.add_argument("--max-iters", type=int, default=0, help="stop after this many optimisation steps (0 = all epochs)")
+    ap.add_argument("--device", default="cuda")
+    args = ap.parse_args(argv)
+    with open(args.config) as f:
+        cfg = yaml.safe_load(f)
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    distributed = world > 1
+    if args.device == "cuda":
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        device = torch.device("cuda", local)
+    else:
+        device = torch.device(args.device)
+    if distributed:
+        dist.init_process_group("nccl" if device.type == "cuda" else "gloo")
+
+    torch.manual_seed(cfg["random_seed"])
+    seg = cfg["segnet"]
+    MaskFormer3D = importlib.import_module("ogc_amd.models." + SEGNETS[cfg["dataset"]]).MaskFormer3D
+    net = MaskFormer3D(n_slot=seg["n_slot"], n_point=seg["n_point"], use_xyz=seg["use_xyz"],
+                       n_transformer_layer=seg["n_transformer_layer"],
+                       transformer_embed_dim=seg["transformer_embed_dim"],
+                       transformer_input_pos_enc=seg["transformer_input_pos_enc"]).to(device)
+    model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[device.index] if device.type == "cuda" else None) \
+        if distributed else net
+
+    outdoor = cfg["dataset"] in ("kittisf", "waymo")
+    train_set = SyntheticScenes(args.synthetic, seg["n_point"], seg["n_slot"], outdoor, seed=1000 * (rank + 1))
+    val_set = SyntheticScenes(max(args.synthetic // 8, cfg["batch_size"]), seg["n_point"], seg["n_slot"], outdoor, seed=7)
+    sampler = torch.utils.data.distributed.DistributedSampler(train_set) if distributed else None
+    train_loader = torch.utils.data.DataLoader(train_set, batch_size=cfg["batch_size"], shuffle=sampler is None,
+                                               sampler=sampler, drop_last=True)
+    val_loader = torch.utils.data.DataLoader(val_set, batch_size=cfg["batch_size"], shuffle=False)
+
+    optimizer = torch.optim.Adam(net.parameters(), lr=cfg["lr"], weight_decay=cfg["weight_decay"])
+    criterion = build_criterion(cfg["loss"])
+    exp_base = cfg["save_path"] + "_R%d" % args.round
+    if rank == 0:
+        os.makedirs(exp_base, exist_ok=True)
+        save_checkpoint(net, exp_base, True)  # initial weights as current and best
+
+    global_batch = cfg["batch_size"] * world
+    it, best = 0, 1e10
+    aug = False
+    for epoch in range(1, cfg["epochs"] + 1):
+        if epoch == cfg["aug_transform_epoch"] + 1:
+            aug, train_set.aug_transform, best = True, True, 1e10
+        if sampler is not None:
+            sampler.set_epoch(epoch)
+        sums, t0 = {}, time.time()
+        for batch in train_loader:
+            seen = it * global_batch
+            for group in optimizer.param_groups:
+                group["lr"] = cfg["lr"] * schedule_factor(cfg, seen)
+            mom = norm_momentum(cfg, seen)
+            for m in net.modules():
+                if isinstance(m, NORM_LAYERS):
+                    m.momentum = mom
+            batch = tuple(x.to(device, non_blocking=True) for x in batch)
+            loss_dict, _ = train_step(model, criterion, optimizer, batch, it * world, aug)
+            it += 1
+            for k, v in loss_dict.items():
+                sums[k] = sums.get(k, 0.0) + v
+            if args.max_iters and it >= args.max_iters:
+                break
+        n_it = max(len(train_loader) if not args.max_iters else min(len(train_loader), it), 1)
+        val_loss = evaluate(model, criterion, val_loader, device)
+        if distributed:
+            t = torch.tensor([val_loss], device=device)
+            dist.all_reduce(t)
+            val_loss = float(t) / world
+        if rank == 0:
+            is_best = val_loss < best
+            best = min(best, val_loss)
+            save_checkpoint(net, exp_base, is_best)
+            print(json.dumps({"epoch": epoch, "it": it, "lr": optimizer.param_groups[0]["lr"], "aug": aug,
+                              "train": {k: round(v / n_it, 5) for k, v in sums.items()},
+                              "val_loss": round(val_loss, 5), "sec": round(time.time() - t0, 2)}), flush=True)
+        if args.max_iters and it >= args.max_iters:
+            break
+    if distributed:
+        dist.destroy_process_group()
+    return best
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,55 @@
+"""CPU test of the training driver: YAML schema, schedules, augmentation switch, checkpoint format."""
+import os
+
+import torch
+import yaml
+
+CFG = {
+    "dataset": "sapien", "save_path": None, "random_seed": 10,
+    "data": {"root": "/nonexistent", "aug_transform_args": {}, "decentralize": False},
+    "aug_transform_epoch": 1, "predflow_path": "flowstep3d", "ignore_npoint_thresh": 0,
+    "epochs": 2, "batch_size": 2, "lr": 1.0e-3, "lr_decay": 0.7, "lr_clip": 1.0e-5,
+    "bn_momentum": 0.9, "bn_decay": 1.0, "weight_decay": 0.0, "decay_step": 4,
+    "segnet": {"n_slot": 4, "n_point": 128, "use_xyz": True, "n_transformer_layer": 1, "transformer_embed_dim": 32,
+               "transformer_input_pos_enc": False},
+    "loss": {"weights": [10.0, 0.1, 0.1], "start_steps": [0, 0, 0], "dynamic_loss_params": {"loss_norm": 2},
+             "smooth_loss_params": {"w_knn": 3.0, "w_ball_q": 1.0,
+                                    "knn_loss_params": {"k": 4, "radius": 0.1, "loss_norm": 1},
+                                    "ball_q_loss_params": {"k": 8, "radius": 0.2, "loss_norm": 1}},
+             "invariance_loss_params": {"loss_norm": 2}},
+}
+
+
+def test_schedules_follow_the_reference_formulas():
+    from ogc_amd.train_seg import norm_momentum, schedule_factor
+    cfg = dict(CFG, decay_step=200000, lr_decay=0.7, lr=1e-3, lr_clip=1e-5, bn_momentum=0.9, bn_decay=0.5)
+    assert schedule_factor(cfg, 0) == 1.0
+    assert schedule_factor(cfg, 199999) == 1.0
+    assert abs(schedule_factor(cfg, 400000) - 0.49) < 1e-12            # train_seg.py:230-234
+    assert schedule_factor(cfg, 10 ** 9) == 1e-5 / 1e-3                 # clipped
+    assert norm_momentum(cfg, 200000) == 0.45 and norm_momentum(cfg, 10 ** 9) == 1e-2
+    assert norm_momentum(dict(cfg, decay_step=-1), 12345) == 0.9
+
+
+def test_driver_runs_and_writes_reference_style_checkpoints(tmp_path, monkeypatch, oracle, capsys):
+    import ogc_amd.pointnet2.pointnet2 as api
+    monkeypatch.setattr(api, "_native", oracle.Pointnet2CudaCPU())
+    from ogc_amd import train_seg
+    cfg = dict(CFG, save_path=str(tmp_path / "ckpt" / "seg"))
+    path = tmp_path / "cfg.yaml"
+    path.write_text(yaml.safe_dump(cfg))
+    os.makedirs(tmp_path / "ckpt", exist_ok=True)
+    train_seg.main([str(path), "--round", "1", "--synthetic", "4", "--device", "cpu"])
+    exp = cfg["save_path"] + "_R1"
+    for name in ("current.pth.tar", "best.pth.tar"):
+        state = torch.load(os.path.join(exp, name))
+        assert list(state.keys()) == ["model_state"]                    # utils/pytorch_util.py:84-90
+        assert "SA_modules.0.mlps.0.layer0.conv.weight" in state["model_state"]
+        assert "MF_head.query.weight" in state["model_state"]
+    lines = [l for l in capsys.readouterr().out.splitlines() if l.startswith("{")]
+    assert len(lines) == 2
+    import json
+    e1, e2 = json.loads(lines[0]), json.loads(lines[1])
+    assert e1["aug"] is False and e2["aug"] is True                      # views switch on after aug_transform_epoch
+    assert e1["train"]["invariance"] == 0 and e2["train"]["invariance"] > 0
+    assert e2["lr"] < e1["lr"] or e2["lr"] == e1["lr"] * 0.7 or e2["lr"] <= 1e-3
