@@ -89,7 +89,7 @@ def main():
     import ogc_amd  # noqa: F401  (fails loudly if libogc_ops.so is missing)
     from ogc_amd import pointnet2_cuda as nat
     from ogc_amd.models.segnet_kitti import MaskFormer3D
-    from ogc_amd.train_step import KITTI_LOSS, build_criterion, train_step
+    from ogc_amd.train_step import KITTI_LOSS, build_criterion, make_optimizer, train_step
     from ogc_amd.utils.synthetic import make_scene_batch
 
     torch.manual_seed(10)  # random_seed: 10 in the reference YAMLs; identical init on every rank
@@ -100,7 +100,7 @@ def main():
         model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[local], bucket_cap_mb=25,
                                                           gradient_as_bucket_view=True)
     crit = build_criterion(KITTI_LOSS)
-    opt = torch.optim.Adam(net.parameters(), lr=1e-3, weight_decay=0.0)
+    opt = make_optimizer(net.parameters(), lr=1e-3, weight_decay=0.0)
     batch = make_scene_batch(a.batch, a.npoint, 10, seed=1234 + rank, outdoor=True, aug=True, device=dev)
     clouds_per_step = a.batch * 4
 
@@ -116,9 +116,12 @@ def main():
     with nat.LaunchTimer({"ogc_ball_query", "ogc_knn_clamped", "ogc_furthest_point_sampling"}) as timer:
         t0 = time.perf_counter()
         for _ in range(a.steps):
-            loss_dict, stepped = train_step(model, crit, opt, batch, it, True)
+            # sync=False: the step's scalars (losses, NaN flag) travel to the host asynchronously and are read after
+            # the timed region; every step still computes and copies them
+            pending = train_step(model, crit, opt, batch, it, True, sync=False)
         sync()
         elapsed = time.perf_counter() - t0
+    loss_dict, stepped = pending.result()
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -138,6 +138,19 @@ int ogc_knn_clamped(int b, int n, int m, int k, float radius, const float *unkno
  * One thread per matrix, Jacobi eigen-solve of S^T S in fp64. */
 int ogc_kabsch_rotation(int nb, const float *S, float *R, int *valid, ogc_stream_t stream);
 
+/* Linear sum assignment (maximise), batched, on the device.  Replaces the host round trip of the invariance loss
+ *   losses/seg_loss_unsup.py:234-239:  scipy.optimize.linear_sum_assignment(iou[b], maximize=True)[1] per sample.
+ * score (np,k,k) f32 row-major (rows = slots of mask1), col4row (np,k) i32 out: column assigned to each row.
+ * Restates scipy's rectangular_lsap procedure (shortest augmenting paths, its column visiting order and its
+ * tie-break) in fp64, so tied IoUs (empty slots) resolve exactly as on the host.  A problem containing NaN or
+ * +inf scores yields -1 in every entry (scipy raises ValueError).  k <= 64. */
+int ogc_lsap_maximize(int np, int k, const float *score, int *col4row, ogc_stream_t stream);
+
+/* Eigenvalues (ascending) of small symmetric fp64 matrices, lower triangle referenced.  Replaces the singular
+ * values of the nuclear-norm monitor  losses/seg_loss_unsup.py:300-314  (sum sqrt(eig(M^T M)) == sum svd(M)).
+ * A (nb,k,k) f64, w (nb,k) f64 out; cyclic Jacobi, one wavefront per matrix; NaN/inf input -> NaN.  k <= 64. */
+int ogc_sym_eigvals(int nb, int k, const double *A, double *w, ogc_stream_t stream);
+
 /* Fused GroupNorm (+ ReLU) forward / backward.  Replaces the nn.GroupNorm -> ReLU(inplace) tail of every
  * Conv2d block of the segmentation nets' SharedMLPs
  *   utils/nn_util.py:6-11 (GroupNorm), :45-85 (_ConvBase ordering), models/segnet_kitti.py:8 (BN_CONFIG).

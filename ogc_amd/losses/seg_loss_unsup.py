@@ -218,27 +218,39 @@ def _iou_matrix(mask1, mask2):
     return intersection / union.clamp(1e-10)
 
 
-def _hungarian_perm(iou_np, eye):
-    """scipy Hungarian per sample (maximising IoU) -> permutation matrices. Reference: :234-239."""
-    perm = np.stack([linear_sum_assignment(m, maximize=True)[1] for m in iou_np], 0)
-    return eye[torch.from_numpy(perm).to(eye.device)]
+def _assign_columns(iou):
+    """(..., K, K) IoUs -> (..., K) int64 column matched to each row, maximising the total IoU with scipy's
+    tie-breaking.  On the GPU: one launch of ogc_lsap_maximize (no host round trip); otherwise scipy itself, as in
+    the reference (:234-239)."""
+    from ..pointnet2 import pointnet2 as _api
+    fused = getattr(_api._native, "lsap_maximize_wrapper", None)
+    K = iou.size(-1)
+    if fused is not None and iou.is_cuda:
+        flat = iou.detach().reshape(-1, K, K).contiguous().float()
+        cols = torch.empty(flat.shape[:2], dtype=torch.int32, device=iou.device)
+        fused(flat.size(0), K, flat, cols)
+        return cols.view(iou.shape[:-1]).long()
+    host = iou.detach().reshape(-1, K, K).cpu().numpy()
+    cols = np.stack([linear_sum_assignment(m, maximize=True)[1] for m in host], 0)
+    return torch.from_numpy(cols).to(iou.device).view(iou.shape[:-1])
 
 
 def match_mask_by_iou(mask1, mask2):
     """Hungarian matching of the hard segmentations by IoU -> permutation matrices (B, K, K).
-    Reference: :212-240 (scipy on the host; here with one device->host copy for the whole batch)."""
+    Reference: :212-240 (scipy on the host, one sync per sample; here on the device)."""
     eye = torch.eye(mask1.size(2), dtype=torch.float32, device=mask1.device)
-    return _hungarian_perm(_iou_matrix(mask1, mask2).cpu().numpy(), eye)
+    return eye[_assign_columns(_iou_matrix(mask1, mask2))]
 
 
 def match_mask_pairs_both_ways(pairs):
     """For every (mask_a, mask_b): (match_mask_by_iou(a, b), match_mask_by_iou(b, a)) — the IoU of the reverse
-    direction is the transpose — with ONE device->host copy for all pairs (the reference syncs once per sample and
-    direction)."""
+    direction is the transpose — solved in ONE batched launch for all pairs, samples and directions (the reference
+    makes a device->host->device round trip per sample and direction)."""
     ious = torch.stack([_iou_matrix(a, b) for a, b in pairs])                 # (P, B, K, K)
-    host = ious.cpu().numpy()
+    both = torch.stack([ious, ious.transpose(2, 3)], 1)                       # (P, 2, B, K, K)
     eye = torch.eye(pairs[0][0].size(2), dtype=torch.float32, device=pairs[0][0].device)
-    return [(_hungarian_perm(h, eye), _hungarian_perm(np.ascontiguousarray(h.transpose(0, 2, 1)), eye)) for h in host]
+    perms = eye[_assign_columns(both)]                                        # (P, 2, B, K, K)
+    return [(perms[i, 0], perms[i, 1]) for i in range(len(pairs))]
 
 
 class InvarianceLoss(nn.Module):
@@ -278,6 +290,19 @@ class EntropyLoss(nn.Module):
         return (-(mask * torch.log(mask.clamp(epsilon))).sum(dim=-1)).mean()
 
 
+def _sym_eigvals(gram):
+    """Eigenvalues of (B, K, K) symmetric fp64 matrices: the HIP Jacobi kernel on the GPU (torch.linalg.eigvalsh
+    checks LAPACK's `info` on the host, i.e. synchronises), torch otherwise."""
+    from ..pointnet2 import pointnet2 as _api
+    fused = getattr(_api._native, "sym_eigvals_wrapper", None)
+    if fused is not None and gram.is_cuda:
+        gram = gram.contiguous()
+        w = torch.empty(gram.shape[:2], dtype=torch.float64, device=gram.device)
+        fused(gram.size(0), gram.size(1), gram, w)
+        return w
+    return torch.linalg.eigvalsh(gram)
+
+
 class RankLoss(nn.Module):
     """Mean nuclear norm of the (N, K) masks. Reference: :300-314."""
 
@@ -292,8 +317,27 @@ class RankLoss(nn.Module):
         # slower on the GPU and an fp32 sum over all N would lose digits)
         mc = m.reshape(B, N // chunk, chunk, K)
         gram = torch.einsum('bcnk,bcnl->bckl', mc, mc).double().sum(dim=1)
-        sv = torch.linalg.eigvalsh(gram).clamp_min(0).sqrt()
+        sv = _sym_eigvals(gram).clamp_min(0).sqrt()
         return sv.sum(dim=1).mean().to(mask.dtype)
+
+
+class PendingLossDict:
+    """The monitored scalars of one loss evaluation, copied to the host asynchronously (one non-blocking copy of a
+    stacked tensor).  ``resolve()`` returns the reference's ``loss_dict`` of Python floats (:407-412)."""
+    KEYS = ('dynamic', 'smooth', 'invariance', 'entropy', 'rank', 'sum')
+
+    def __init__(self, terms):
+        from ..utils.streams import HostScalars
+        self._keys = list(terms)
+        self._scalars = HostScalars(torch.stack([terms[k].detach().float().reshape(()) for k in self._keys]))
+        self._dict = None
+
+    def resolve(self):
+        if self._dict is None:
+            d = dict(zip(self._keys, self._scalars.get()))
+            d.setdefault('invariance', 0)
+            self._dict = {k: d[k] for k in self.KEYS}
+        return self._dict
 
 
 class UnsupervisedOGCLoss(nn.Module):
@@ -321,7 +365,7 @@ class UnsupervisedOGCLoss(nn.Module):
             return self.smooth_loss.plan_views(list(pcs)[:n_view])
         return None
 
-    def forward(self, pcs, masks, flows, step_w=False, it=0, aug_transform=False, geometry=None):
+    def forward(self, pcs, masks, flows, step_w=False, it=0, aug_transform=False, geometry=None, sync=True):
         # pcs / masks / flows: lists of 2 (or 4 with aug_transform) tensors (B, N, 3) / (B, N, K) / (B, N, 3)
         assert len(pcs) == len(masks) == len(flows), "Inconsistent number of frames!"
         n_view = 4 if aug_transform else 2
@@ -367,9 +411,5 @@ class UnsupervisedOGCLoss(nn.Module):
             terms['rank'] = total([self.rank_loss(m) for m in masks])
         terms['sum'] = loss
 
-        keys = list(terms)
-        values = torch.stack([terms[k].detach().float().reshape(()) for k in keys]).tolist()  # one sync
-        loss_dict = dict(zip(keys, values))
-        loss_dict.setdefault('invariance', 0)
-        loss_dict = {k: loss_dict[k] for k in ('dynamic', 'smooth', 'invariance', 'entropy', 'rank', 'sum')}
-        return loss, loss_dict
+        pending = PendingLossDict(terms)
+        return loss, (pending.resolve() if sync else pending)

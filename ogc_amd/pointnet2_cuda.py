@@ -151,6 +151,16 @@ def kabsch_rotation_wrapper(nb, S, R, valid=None):
     _run("ogc_kabsch_rotation", S, nb, _f(S, "S"), _f(R, "R"), 0 if valid is None else _i(valid, "valid"))
 
 
+def lsap_maximize_wrapper(np_, k, score, col4row):
+    """Batched maximising linear-sum assignment with scipy's tie-breaking (ogc_lsap_maximize)."""
+    _run("ogc_lsap_maximize", score, np_, k, _f(score, "score"), _i(col4row, "col4row"))
+
+
+def sym_eigvals_wrapper(nb, k, A, w):
+    """Ascending eigenvalues of (nb, k, k) symmetric float64 matrices (ogc_sym_eigvals)."""
+    _run("ogc_sym_eigvals", A, nb, k, _check(A, torch.float64, "A"), _check(w, torch.float64, "w"))
+
+
 def group_norm_fwd_wrapper(b, c, hw, groups, eps, relu, x, gamma, beta, y, mean, rstd, ws):
     """Fused GroupNorm(+ReLU) forward (ogc_group_norm_fwd); ws: float64 scratch of 2*b*groups elements."""
     _run("ogc_group_norm_fwd", x, b, c, hw, groups, float(eps), int(relu), _f(x, "x"), _f(gamma, "gamma"),

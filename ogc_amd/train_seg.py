@@ -27,7 +27,7 @@ import torch
 import torch.distributed as dist
 import yaml
 
-from .train_step import build_criterion, train_step
+from .train_step import build_criterion, make_optimizer, train_step
 from .utils.synthetic import make_scene_batch
 
 SEGNETS = {"sapien": "segnet_sapien", "ogcdr": "segnet_ogcdr", "kittisf": "segnet_kitti", "waymo": "segnet_kitti"}
@@ -128,7 +128,7 @@ def main(argv=None):
                                                sampler=sampler, drop_last=True)
     val_loader = torch.utils.data.DataLoader(val_set, batch_size=cfg["batch_size"], shuffle=False)
 
-    optimizer = torch.optim.Adam(net.parameters(), lr=cfg["lr"], weight_decay=cfg["weight_decay"])
+    optimizer = make_optimizer(net.parameters(), lr=cfg["lr"], weight_decay=cfg["weight_decay"])
     criterion = build_criterion(cfg["loss"])
     exp_base = cfg["save_path"] + "_R%d" % args.round
     if rank == 0:
@@ -143,7 +143,13 @@ def main(argv=None):
             aug, train_set.aug_transform, best = True, True, 1e10
         if sampler is not None:
             sampler.set_epoch(epoch)
-        sums, t0 = {}, time.time()
+        sums, t0, in_flight = {}, time.time(), None
+
+        def account(pending):
+            if pending is not None:
+                for k, v in pending.result()[0].items():
+                    sums[k] = sums.get(k, 0.0) + v
+
         for batch in train_loader:
             seen = it * global_batch
             for group in optimizer.param_groups:
@@ -153,12 +159,14 @@ def main(argv=None):
                 if isinstance(m, NORM_LAYERS):
                     m.momentum = mom
             batch = tuple(x.to(device, non_blocking=True) for x in batch)
-            loss_dict, _ = train_step(model, criterion, optimizer, batch, it * world, aug)
+            # the scalars of step i are read while step i+1 is already queued: the host never waits inside a step
+            pending = train_step(model, criterion, optimizer, batch, it * world, aug, sync=False)
+            account(in_flight)
+            in_flight = pending
             it += 1
-            for k, v in loss_dict.items():
-                sums[k] = sums.get(k, 0.0) + v
             if args.max_iters and it >= args.max_iters:
                 break
+        account(in_flight)
         n_it = max(len(train_loader) if not args.max_iters else min(len(train_loader), it), 1)
         val_loss = evaluate(model, criterion, val_loader, device)
         if distributed:

@@ -29,9 +29,34 @@ def build_criterion(cfg):
                                weights=cfg["weights"], start_steps=cfg["start_steps"])
 
 
-def train_step(segnet, criterion, optimizer, batch, it, aug_transform):
+class PendingStep:
+    """Outcome of a train_step whose scalars are still on their way to the host.  ``result()`` -> (loss_dict, stepped)."""
+
+    def __init__(self, pending_losses, bad_scalar):
+        self._losses, self._bad, self._out = pending_losses, bad_scalar, None
+
+    def result(self):
+        if self._out is None:
+            losses = self._losses.resolve() if hasattr(self._losses, "resolve") else self._losses
+            self._out = (losses, not bool(self._bad.get()[0]))
+        return self._out
+
+
+def make_optimizer(params, lr, weight_decay=0.0):
+    """Adam as the reference builds it (train_seg.py:320).  On the GPU the fused implementation is used: the same
+    update, and it can skip itself on the device when handed a `found_inf` flag, which is what lets train_step apply
+    the reference's NaN-gradient rule (train_seg.py:81-83) without stopping to read the flag on the host."""
+    params = list(params)
+    fused = bool(params) and all(p.is_cuda for p in params)
+    return torch.optim.Adam(params, lr=lr, weight_decay=weight_decay, fused=fused)
+
+
+def train_step(segnet, criterion, optimizer, batch, it, aug_transform, sync=True):
     """batch = (pcs (b,t,n,3), segms (b,t,n), flows (b,t,n,3), valids), already on the device.
-    Returns (loss_dict, stepped)."""
+    Returns (loss_dict, stepped); with sync=False a PendingStep whose result() gives the same pair later, so the
+    host can queue the next step while this one still runs (no host synchronisation inside the step when the
+    optimizer is fused — see make_optimizer)."""
+    from .utils.streams import HostScalars
     segnet.train()
     optimizer.zero_grad(set_to_none=True)
     pcs, segms, flows, _ = batch
@@ -49,11 +74,25 @@ def train_step(segnet, criterion, optimizer, batch, it, aug_transform):
     masks = segnet(flat, flat).view(b, t, n, -1)
     masks_l = [masks[:, tt].contiguous() for tt in range(t)]
     kw = {"geometry": loss_geometry} if loss_geometry is not None else {}
-    loss, loss_dict = criterion(pcs_l, masks_l, flows_l, step_w=True, it=it * b, aug_transform=aug_transform, **kw)
+    loss, losses = criterion(pcs_l, masks_l, flows_l, step_w=True, it=it * b, aug_transform=aug_transform, sync=False,
+                             **kw)
     loss.backward()
     grads = [p.grad for p in segnet.parameters() if p.grad is not None]
     bad = torch.isnan(torch.stack(torch._foreach_norm(grads)).sum())  # NaN anywhere -> NaN norm
-    if bool(bad):  # one host sync; under DDP the all-reduced grads make this decision identical on all ranks
-        return loss_dict, False
-    optimizer.step()
-    return loss_dict, True
+    # under DDP the all-reduced gradients make this decision identical on all ranks
+    if getattr(optimizer, "_step_supports_amp_scaling", False) and bad.is_cuda:
+        # fused optimizer: the kernel itself skips the update (and the step count) when found_inf == 1
+        optimizer.grad_scale = None
+        optimizer.found_inf = bad.float().reshape(1)
+        try:
+            optimizer.step()
+        finally:
+            del optimizer.grad_scale
+            del optimizer.found_inf
+        pending = PendingStep(losses, HostScalars(bad.reshape(1)))
+    else:
+        skip = bool(bad)  # host sync
+        if not skip:
+            optimizer.step()
+        pending = PendingStep(losses, HostScalars(torch.tensor([skip])))
+    return pending.result() if sync else pending

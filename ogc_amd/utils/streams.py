@@ -50,3 +50,24 @@ def launch_on_side(stream, fn):
         event = torch.cuda.Event()
         event.record(stream)
     return Pending(value, event)
+
+
+class HostScalars:
+    """Device scalars on their way to the host without stopping the launch thread: a non-blocking copy into pinned
+    memory plus an event.  ``get()`` waits for that copy only (by then the next kernels are already queued)."""
+
+    def __init__(self, values):
+        values = values.detach()
+        if values.is_cuda:
+            self._host = torch.empty(values.shape, dtype=values.dtype, pin_memory=True)
+            self._host.copy_(values, non_blocking=True)
+            self._event = torch.cuda.Event()
+            self._event.record()
+        else:
+            self._host, self._event = values, None
+
+    def get(self):
+        if self._event is not None:
+            self._event.synchronize()
+            self._event = None
+        return self._host.tolist()

@@ -316,3 +316,68 @@ int oracle_ball_query(int b, int n, int m, float radius, int nsample, const floa
     }
     return 0;
 }
+
+/* Maximising linear-sum assignment with the tie-breaking of scipy.optimize.linear_sum_assignment — the host step of
+ * the invariance loss (losses/seg_loss_unsup.py:234-239).  scipy itself is the reference here (requirements.txt:1);
+ * this restatement of its shortest-augmenting-path procedure (Crouse 2016) is pinned against the installed scipy in
+ * tests/test_small_solvers.py and is what the HIP kernel is compared with where scipy's Python loop would be slow.
+ * score (np,k,k) f32, col4row (np,k) i32.  Returns 0; a problem with NaN/+inf scores gets -1 everywhere. */
+int oracle_lsap_maximize(int np, int k, const float *score, int *col4row_out) {
+    if (k <= 0) return 0;
+    for (int prob = 0; prob < np; ++prob) {
+        const float *sc = score + (size_t)prob * k * k;
+        double *u = calloc(k, sizeof(double)), *v = calloc(k, sizeof(double)), *spc = malloc(k * sizeof(double));
+        int *path = malloc(k * sizeof(int)), *col4row = malloc(k * sizeof(int)), *row4col = malloc(k * sizeof(int));
+        int *remaining = malloc(k * sizeof(int));
+        char *SR = malloc(k), *SC = malloc(k);
+        for (int i = 0; i < k; ++i) path[i] = col4row[i] = row4col[i] = -1;
+        int feasible = 1;
+        for (int e = 0; e < k * k; ++e) /* scipy rejects NaN and -inf costs (= +inf scores) before solving */
+            if (sc[e] != sc[e] || sc[e] == INFINITY) feasible = 0;
+        for (int cur = 0; cur < k && feasible; ++cur) {
+            double min_val = 0.0;
+            int num_remaining = k;
+            for (int it = 0; it < k; ++it) {
+                remaining[it] = k - it - 1;
+                SR[it] = SC[it] = 0;
+                spc[it] = INFINITY;
+            }
+            int sink = -1, i = cur;
+            while (sink == -1) {
+                int index = -1;
+                double lowest = INFINITY;
+                SR[i] = 1;
+                for (int it = 0; it < num_remaining; ++it) {
+                    const int j = remaining[it];
+                    const double r = min_val + (-(double)sc[i * k + j]) - u[i] - v[j];
+                    if (r < spc[j]) { path[j] = i; spc[j] = r; }
+                    if (spc[j] < lowest || (spc[j] == lowest && row4col[j] == -1)) { lowest = spc[j]; index = it; }
+                }
+                min_val = lowest;
+                if (!(min_val < INFINITY)) { feasible = 0; break; }
+                const int j = remaining[index];
+                if (row4col[j] == -1) sink = j; else i = row4col[j];
+                SC[j] = 1;
+                remaining[index] = remaining[--num_remaining];
+            }
+            if (!feasible) break;
+            u[cur] += min_val;
+            for (int r = 0; r < k; ++r)
+                if (SR[r] && r != cur) u[r] += min_val - spc[col4row[r]];
+            for (int j = 0; j < k; ++j)
+                if (SC[j]) v[j] -= min_val - spc[j];
+            int j = sink;
+            for (;;) {
+                const int r = path[j];
+                row4col[j] = r;
+                const int prev = col4row[r];
+                col4row[r] = j;
+                j = prev;
+                if (r == cur) break;
+            }
+        }
+        for (int r = 0; r < k; ++r) col4row_out[(size_t)prob * k + r] = feasible ? col4row[r] : -1;
+        free(u); free(v); free(spc); free(path); free(col4row); free(row4col); free(remaining); free(SR); free(SC);
+    }
+    return 0;
+}

@@ -54,6 +54,7 @@ def lib():
             "oracle_group_points": [_int, _int, _int, _int, _int, _f32p, _i32p, _f32p],
             "oracle_group_points_grad": [_int, _int, _int, _int, _int, _f32p, _i32p, _f32p],
             "oracle_ball_query": [_int, _int, _int, ctypes.c_float, _int, _f32p, _f32p, _i32p],
+            "oracle_lsap_maximize": [_int, _int, _f32p, _i32p],
         }
         for name, argtypes in sig.items():
             fn = getattr(L, name)
@@ -196,6 +197,15 @@ def ball_query(radius, nsample, xyz, new_xyz):
     _check(lib().oracle_ball_query(B, N, M, float(radius), nsample, pn, px, idx.ctypes.data_as(_i32p)),
            "ball_query")
     return idx
+
+
+def lsap_maximize(score):
+    """(P, K, K) float32 scores -> (P, K) int32 columns, scipy.optimize.linear_sum_assignment(maximize=True)[1]."""
+    score, ps = _f(score)
+    P, K, _ = score.shape
+    out = np.zeros((P, K), dtype=np.int32)
+    _check(lib().oracle_lsap_maximize(P, K, ps, out.ctypes.data_as(_i32p)), "lsap_maximize")
+    return out
 
 
 # ---------------------------------------------------------------- pointnet2_cuda-shaped face

@@ -36,7 +36,7 @@ def timeit(fn, iters, warm=3):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--ops", default="knn,nn3,ball,fps,group,interp")
+    ap.add_argument("--ops", default="knn,nn3,ball,fps,group,interp,conv,gn")
     ap.add_argument("--iters", type=int, default=10)
     a = ap.parse_args()
     ops = a.ops.split(",")
@@ -112,5 +112,39 @@ def main():
                   (B, C, M, N, ms, byt / ms / 1e6, ms2, byt / ms2 / 1e6))
 
 
+def bench_conv_gn(ops, iters):
+    if "conv" in ops:
+        for (B, cin, cout, hw) in [(16, 6, 32, 131072), (16, 32, 32, 131072), (16, 32, 64, 131072), (16, 99, 64, 65536),
+                                   (16, 64, 64, 65536), (16, 64, 128, 65536), (16, 131, 128, 32768), (16, 128, 128, 32768),
+                                   (16, 128, 256, 32768)]:
+            x = torch.randn(B, cin, hw, device=DEV)
+            w = torch.randn(cout, cin, device=DEV)
+            y = torch.empty(B, cout, hw, device=DEV)
+            dx = torch.empty_like(x)
+            dw = torch.empty(cout, cin, device=DEV)
+            f = timeit(lambda: nat.conv1x1_gemm_wrapper(B, cout, cin, hw, 0, w, x, y), iters)
+            d = timeit(lambda: nat.conv1x1_gemm_wrapper(B, cin, cout, hw, 1, w, y, dx), iters) if cout <= 160 else float("nan")
+            g = timeit(lambda: nat.conv1x1_wgrad_wrapper(B, cin, cout, hw, x, y, dw), iters)
+            byt = 4.0 * B * hw * (cin + cout)
+            print("conv  B=%-3d %4d->%-4d hw=%-6d fwd %7.3f ms %6.0f GB/s | dgrad %7.3f ms %6.0f GB/s | wgrad %7.3f ms %6.0f GB/s" %
+                  (B, cin, cout, hw, f, byt / f / 1e6, d, byt / d / 1e6, g, byt / g / 1e6))
+    if "gn" in ops:
+        from ogc_amd.fused import group_norm_act, group_norm_act_maxpool
+        for shape in [(16, 32, 2048, 64), (16, 64, 1024, 64), (16, 128, 512, 64), (16, 256, 512, 64)]:
+            gn = torch.nn.GroupNorm(4, shape[1]).to(DEV)
+            x = torch.randn(*shape, device=DEV, requires_grad=True)
+            y = group_norm_act(x, gn, True)
+            g = torch.randn_like(y)
+            f = timeit(lambda: group_norm_act(x, gn, True), iters)
+            bw = timeit(lambda: torch.autograd.grad(group_norm_act(x, gn, True), x, g), iters) - f
+            nbytes = 4.0 * x.numel()
+            print("gn    %-22s fwd %7.3f ms (%5.0f GB/s of 3 passes) | bwd %7.3f ms (%5.0f GB/s of 5 passes)" %
+                  (str(shape), f, 3 * nbytes / f / 1e6, bw, 5 * nbytes / bw / 1e6))
+
+
 if __name__ == "__main__":
     main()
+    import argparse as _ap
+    _a = _ap.ArgumentParser(); _a.add_argument("--ops", default="knn,nn3,ball,fps,group,interp,conv,gn"); _a.add_argument("--iters", type=int, default=10)
+    _args = _a.parse_args()
+    bench_conv_gn(_args.ops.split(","), _args.iters)
