@@ -106,11 +106,11 @@ __global__ __launch_bounds__(64) void sym_eigvals_kernel(int nb, int k, const do
         // symmetrise from the lower triangle, like LAPACK's UPLO='L' (torch.linalg.eigvalsh default)
         const double val = r >= c ? A[r * k + c] : A[c * k + r];
         eig_smem[r * ld + c] = val;
-        scale = fmax(scale, fabs(val));
+        scale = fabs(val) < INFINITY ? fmax(scale, fabs(val)) : INFINITY; // NaN and inf poison the scale
     }
     for (int off = 32; off > 0; off >>= 1) scale = fmax(scale, __shfl_xor(scale, off, 64));
     __syncthreads();
-    const bool finite = scale < INFINITY; // false for inf and NaN
+    const bool finite = scale < INFINITY;
     if (finite && scale > 0.0) {
         for (int sweep = 0; sweep < 40; ++sweep) {
             double off2 = 0.0;

@@ -83,7 +83,7 @@ def train_step(segnet, criterion, optimizer, batch, it, aug_transform, sync=True
     if getattr(optimizer, "_step_supports_amp_scaling", False) and bad.is_cuda:
         # fused optimizer: the kernel itself skips the update (and the step count) when found_inf == 1
         optimizer.grad_scale = None
-        optimizer.found_inf = bad.float().reshape(1)
+        optimizer.found_inf = bad.float().reshape(())
         try:
             optimizer.step()
         finally:
