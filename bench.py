@@ -110,15 +110,20 @@ def main():
         torch.cuda.synchronize()
 
     it = 1000  # it*b >= every start_step -> dynamic + smooth + invariance all active
+    # The trainer holds the next batch while a step runs (ogc_amd/train_seg.py reads one batch ahead), so each step
+    # also queues the coordinate-only work (FPS / kNN / ball query) of the FOLLOWING step on side streams and consumes
+    # the plan made during the previous step: one plan is computed per step, inside the timed region, none is reused.
+    pre = None
     for _ in range(a.warmup):
-        train_step(model, crit, opt, batch, it, True)
+        pre = train_step(model, crit, opt, batch, it, True, sync=False, prefetched=pre, next_batch=batch).prefetched
     sync()
     with nat.LaunchTimer({"ogc_ball_query", "ogc_knn_clamped", "ogc_furthest_point_sampling"}) as timer:
         t0 = time.perf_counter()
         for _ in range(a.steps):
             # sync=False: the step's scalars (losses, NaN flag) travel to the host asynchronously and are read after
             # the timed region; every step still computes and copies them
-            pending = train_step(model, crit, opt, batch, it, True, sync=False)
+            pending = train_step(model, crit, opt, batch, it, True, sync=False, prefetched=pre, next_batch=batch)
+            pre = pending.prefetched
         sync()
         elapsed = time.perf_counter() - t0
     loss_dict, stepped = pending.result()

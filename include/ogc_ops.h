@@ -151,6 +151,31 @@ int ogc_lsap_maximize(int np, int k, const float *score, int *col4row, ogc_strea
  * A (nb,k,k) f64, w (nb,k) f64 out; cyclic Jacobi, one wavefront per matrix; NaN/inf input -> NaN.  k <= 64. */
 int ogc_sym_eigvals(int nb, int k, const double *A, double *w, ogc_stream_t stream);
 
+/* Mask smoothness over neighbour lists, fused.  Replaces, in KnnLoss / BallQLoss
+ *   losses/seg_loss_unsup.py:123-129, :152-158:
+ *     nn_mask = grouping_operation(mask, idx); loss = (mask.unsqueeze(3) - nn_mask).norm(p, dim=1).mean(dim=-1)
+ * mask (b,n,c) f32 POINT-major (the layout the network emits), idx (b,n,k) i32 into the same cloud,
+ * out (b,n) f32: out[i] = (1/k) sum_j ||mask[i] - mask[idx[i,j]]||_p, p = 1 or 2. */
+int ogc_neighbour_consistency_fwd(int b, int n, int c, int k, int p, const float *mask, const int *idx, float *out,
+                                  ogc_stream_t stream);
+
+/* Transposed neighbour lists (coordinates only; lets the gradient above be a gather instead of a scatter-add).
+ * idx (b,n,k) i32 -> rev_start (b,n+1) i32: CSR offsets of the edges ARRIVING at each point; rev_src (b,n*k) i32:
+ * their source points (order inside a list unspecified; only rev_start[b][n] entries are used).  Edges that cannot
+ * contribute are left out and repeated ones merged: a self edge (idx[i][j] == i) has zero gradient; the copies of a
+ * row's first entry (ball-query padding, radius-clamped kNN) become ONE edge, marked by bit 31 of its rev_src entry,
+ * whose weight is rev_mult[b][i] (b,n) i32 = number of entries of row i equal to idx[i][0].  ws: (b,n) i32 scratch. */
+int ogc_reverse_neighbours(int b, int n, int k, const int *idx, int *rev_start, int *rev_src, int *rev_mult, int *ws,
+                           ogc_stream_t stream);
+
+/* Gradient of ogc_neighbour_consistency_fwd w.r.t. mask, through both the centre and the neighbour operand
+ * (torch's subgradients: sign(0) = 0 for p = 1, 0 where the norm vanishes for p = 2).
+ * rev_start / rev_src / rev_mult from ogc_reverse_neighbours(idx); grad_out (b,n) f32, grad_mask (b,n,c) f32 out
+ * (overwritten).  c <= 40. */
+int ogc_neighbour_consistency_bwd(int b, int n, int c, int k, int p, const float *mask, const int *idx,
+                                  const int *rev_start, const int *rev_src, const int *rev_mult, const float *grad_out,
+                                  float *grad_mask, ogc_stream_t stream);
+
 /* Fused GroupNorm (+ ReLU) forward / backward.  Replaces the nn.GroupNorm -> ReLU(inplace) tail of every
  * Conv2d block of the segmentation nets' SharedMLPs
  *   utils/nn_util.py:6-11 (GroupNorm), :45-85 (_ConvBase ordering), models/segnet_kitti.py:8 (BN_CONFIG).

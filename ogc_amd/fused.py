@@ -152,3 +152,55 @@ def pointwise_conv(x, conv):
             and all(v == 0 for v in conv.padding) and getattr(_api._native, "conv1x1_wgrad_wrapper", None) is not None):
         return _PointwiseConv.apply(x, conv.weight)
     return conv(x)
+
+
+class _NeighbourConsistency(Function):
+    """per-point mean_j ||m_i - m_idx[i,j]||_p for point-major masks — one launch forward, one backward (a gather over
+    the neighbour lists and their transposes).  Reference sequence: grouping_operation, broadcast difference, norm
+    over channels, mean over neighbours (losses/seg_loss_unsup.py:123-129, :152-158)."""
+
+    @staticmethod
+    def forward(ctx, mask, idx, rev_start, rev_src, rev_mult, p):
+        nat = _api._native
+        mask = mask.contiguous()
+        B, N, C = mask.shape
+        k = idx.shape[2]
+        out = torch.empty(B, N, dtype=torch.float32, device=mask.device)
+        nat.neighbour_consistency_fwd_wrapper(B, N, C, k, p, mask, idx, out)
+        ctx.save_for_backward(mask, idx, rev_start, rev_src, rev_mult)
+        ctx.p = p
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        nat = _api._native
+        mask, idx, rev_start, rev_src, rev_mult = ctx.saved_tensors
+        B, N, C = mask.shape
+        grad_mask = torch.empty_like(mask)
+        nat.neighbour_consistency_bwd_wrapper(B, N, C, idx.shape[2], ctx.p, mask, idx, rev_start, rev_src, rev_mult,
+                                              grad_out.contiguous(), grad_mask)
+        return grad_mask, None, None, None, None, None
+
+
+def reverse_neighbours(idx):
+    """Transposed neighbour lists of idx (B, N, k) int32: (rev_start (B, N+1), rev_src (B, N*k), rev_mult (B, N)) as
+    ogc_reverse_neighbours defines them.  Coordinates only — belongs to the geometry plan of a step."""
+    nat = _api._native
+    idx = idx.contiguous()
+    B, N, k = idx.shape
+    rev_start = torch.empty(B, N + 1, dtype=torch.int32, device=idx.device)
+    rev_src = torch.empty(B, N * k, dtype=torch.int32, device=idx.device)
+    rev_mult = torch.empty(B, N, dtype=torch.int32, device=idx.device)
+    ws = torch.empty(B, N, dtype=torch.int32, device=idx.device)
+    nat.reverse_neighbours_wrapper(B, N, k, idx, rev_start, rev_src, rev_mult, ws)
+    return rev_start, rev_src, rev_mult
+
+
+def neighbour_consistency_available(mask, loss_norm, cross_entropy):
+    return (mask.is_cuda and mask.dtype == torch.float32 and not cross_entropy and loss_norm in (1, 2)
+            and mask.shape[-1] <= 40 and getattr(_api._native, "neighbour_consistency_fwd_wrapper", None) is not None)
+
+
+def neighbour_consistency(mask, idx, reverse, p):
+    """mask (B, N, C) point-major, idx (B, N, k), reverse = reverse_neighbours(idx) -> (B, N)."""
+    return _NeighbourConsistency.apply(mask, idx, reverse[0], reverse[1], reverse[2], int(p))

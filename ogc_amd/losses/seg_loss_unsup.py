@@ -172,25 +172,43 @@ class SmoothLoss(nn.Module):
 
     def plan_views(self, pcs):
         """Neighbour indices of all views (coordinates only; may run ahead on a side stream): ONE kNN and ONE
-        ball-query launch over the concatenated views (B*V clouds fill the GPU far better than V launches of B)."""
+        ball-query launch over the concatenated views (B*V clouds fill the GPU far better than V launches of B), plus
+        the transposed lists the fused gradient kernel gathers over."""
         pc = torch.cat(list(pcs)).contiguous()
         kl, bl = self.knn_loss, self.ball_q_loss
         _, idx_knn = knn_radius_clamp(kl.k, kl.radius, pc, pc)
         idx_ball = ball_query(bl.radius, bl.k, pc, pc)
-        return {"knn": idx_knn, "ball": idx_ball}
+        plan = {"knn": idx_knn, "ball": idx_ball}
+        if pc.is_cuda:
+            from ..fused import reverse_neighbours
+            from ..pointnet2 import pointnet2 as _api
+            if getattr(_api._native, "reverse_neighbours_wrapper", None) is not None:
+                plan["knn_rev"] = reverse_neighbours(idx_knn)
+                plan["ball_rev"] = reverse_neighbours(idx_ball)
+        return plan
 
     def forward_views(self, pcs, masks, geometry=None):
         """[forward(pc_v, mask_v) for v], evaluated on the views concatenated along the batch."""
+        from ..fused import neighbour_consistency, neighbour_consistency_available
         n_view = len(pcs)
         if geometry is None:
             geometry = self.plan_views(pcs)
-        elif hasattr(geometry, "get"):
+        elif not isinstance(geometry, dict):  # a Pending from a side stream
             geometry = geometry.get()
-        mask = torch.cat(list(masks)).permute(0, 2, 1).contiguous()
         kl, bl = self.knn_loss, self.ball_q_loss
-        l_knn = _neighbour_consistency_views(mask, geometry["knn"], kl.k, kl.cross_entropy, kl.loss_norm, n_view)
-        l_ball = _neighbour_consistency_views(mask, geometry["ball"], bl.k, bl.cross_entropy, bl.loss_norm, n_view)
-        return list(self.w_knn * l_knn + self.w_ball_q * l_ball)
+        terms = []
+        mask_pm = torch.cat(list(masks))                                   # (V*B, N, K) point-major
+        mask_cm = None
+        for name, cfg in (("knn", kl), ("ball", bl)):
+            if name + "_rev" in geometry and neighbour_consistency_available(mask_pm, cfg.loss_norm, cfg.cross_entropy):
+                per_point = neighbour_consistency(mask_pm, geometry[name], geometry[name + "_rev"], cfg.loss_norm)
+                terms.append(per_point.view(n_view, -1).mean(dim=1))
+            else:
+                if mask_cm is None:
+                    mask_cm = mask_pm.permute(0, 2, 1).contiguous()
+                terms.append(_neighbour_consistency_views(mask_cm, geometry[name], cfg.k, cfg.cross_entropy,
+                                                          cfg.loss_norm, n_view))
+        return list(self.w_knn * terms[0] + self.w_ball_q * terms[1])
 
 
 def interpolate_mask_by_flow(pc1, pc2, mask1, flow1, k=1):

@@ -53,29 +53,44 @@ class MaskFormer3DBase(nn.Module):
         fp_plans = [fp.plan_geometry(l_pc[i], l_pc[i + 1]) for i, fp in enumerate(self.FP_modules)]
         return sa_plans, fp_plans
 
-    def forward(self, pc, point_feats):
-        # pc (B, N, 3), point_feats (B, N, 3) -> mask (B, N, K)
+    def plan_geometry_async(self, pc, after=None):
+        """Queue the coordinate-only work of a forward pass on `pc` (FPS, kNN, 3-NN of every level) on the geometry
+        side stream and return the handles `forward(..., geometry=...)` takes.  By default the side stream first waits
+        for the work already queued on the current stream; with `after` (an event marking `pc` ready) it waits for that
+        event only, so the plans of a FUTURE batch can run underneath the current step's dense kernels."""
+        from ..utils.streams import Pending, side_stream
         n_sa, n_fp = len(self.SA_modules), len(self.FP_modules)
         sa_geo, fp_geo = [None] * n_sa, [None] * n_fp
-        if pc.is_cuda and self.overlap_geometry:
-            from ..utils.streams import Pending, launch_on_side, side_stream
-            stream = side_stream(pc.device, "segnet-geometry")
-            main = torch.cuda.current_stream()
-            stream.wait_stream(main)
-            with torch.cuda.stream(stream):  # one event per level so that SA1 can start as soon as ITS plan is ready
-                l_last = pc
-                for i, sa in enumerate(self.SA_modules):
-                    g = sa.plan_geometry(l_last)
-                    ev = torch.cuda.Event()
-                    ev.record(stream)
-                    sa_geo[i] = Pending(g, ev)
-                    l_last = g["new_xyz"]
-                cents = [pc] + [p._value["new_xyz"] for p in sa_geo]
-                for i, fp in enumerate(self.FP_modules):
-                    g = fp.plan_geometry(cents[i], cents[i + 1])
-                    ev = torch.cuda.Event()
-                    ev.record(stream)
-                    fp_geo[i] = Pending(g, ev)
+        stream = side_stream(pc.device, "segnet-geometry")
+        if after is None:
+            stream.wait_stream(torch.cuda.current_stream())
+        else:
+            stream.wait_event(after)
+        pc.record_stream(stream)
+        with torch.cuda.stream(stream):  # one event per level so that SA1 can start as soon as ITS plan is ready
+            l_last = pc
+            for i, sa in enumerate(self.SA_modules):
+                g = sa.plan_geometry(l_last)
+                ev = torch.cuda.Event()
+                ev.record(stream)
+                sa_geo[i] = Pending(g, ev)
+                l_last = g["new_xyz"]
+            cents = [pc] + [p._value["new_xyz"] for p in sa_geo]
+            for i, fp in enumerate(self.FP_modules):
+                g = fp.plan_geometry(cents[i], cents[i + 1])
+                ev = torch.cuda.Event()
+                ev.record(stream)
+                fp_geo[i] = Pending(g, ev)
+        return sa_geo, fp_geo
+
+    def forward(self, pc, point_feats, geometry=None):
+        # pc (B, N, 3), point_feats (B, N, 3) -> mask (B, N, K);  geometry: plan_geometry_async(pc) made earlier
+        n_sa, n_fp = len(self.SA_modules), len(self.FP_modules)
+        sa_geo, fp_geo = [None] * n_sa, [None] * n_fp
+        if geometry is not None:
+            sa_geo, fp_geo = geometry
+        elif pc.is_cuda and self.overlap_geometry:
+            sa_geo, fp_geo = self.plan_geometry_async(pc)
 
         l_pc, l_feats = [pc], [point_feats.transpose(1, 2).contiguous()]
         for i, sa in enumerate(self.SA_modules):

@@ -161,6 +161,24 @@ def sym_eigvals_wrapper(nb, k, A, w):
     _run("ogc_sym_eigvals", A, nb, k, _check(A, torch.float64, "A"), _check(w, torch.float64, "w"))
 
 
+def neighbour_consistency_fwd_wrapper(b, n, c, k, p, mask, idx, out):
+    """out[i] = mean_j ||mask[i] - mask[idx[i, j]]||_p, mask (b, n, c) point-major (ogc_neighbour_consistency_fwd)."""
+    _run("ogc_neighbour_consistency_fwd", mask, b, n, c, k, int(p), _f(mask, "mask"), _i(idx, "idx"), _f(out, "out"))
+
+
+def reverse_neighbours_wrapper(b, n, k, idx, rev_start, rev_src, rev_mult, ws):
+    """CSR of incoming edges of the neighbour lists idx (b, n, k) (ogc_reverse_neighbours)."""
+    _run("ogc_reverse_neighbours", idx, b, n, k, _i(idx, "idx"), _i(rev_start, "rev_start"), _i(rev_src, "rev_src"),
+         _i(rev_mult, "rev_mult"), _i(ws, "ws"))
+
+
+def neighbour_consistency_bwd_wrapper(b, n, c, k, p, mask, idx, rev_start, rev_src, rev_mult, grad_out, grad_mask):
+    """Gradient of neighbour_consistency_fwd w.r.t. mask (ogc_neighbour_consistency_bwd)."""
+    _run("ogc_neighbour_consistency_bwd", mask, b, n, c, k, int(p), _f(mask, "mask"), _i(idx, "idx"),
+         _i(rev_start, "rev_start"), _i(rev_src, "rev_src"), _i(rev_mult, "rev_mult"), _f(grad_out, "grad_out"),
+         _f(grad_mask, "grad_mask"))
+
+
 def group_norm_fwd_wrapper(b, c, hw, groups, eps, relu, x, gamma, beta, y, mean, rstd, ws):
     """Fused GroupNorm(+ReLU) forward (ogc_group_norm_fwd); ws: float64 scratch of 2*b*groups elements."""
     _run("ogc_group_norm_fwd", x, b, c, hw, groups, float(eps), int(relu), _f(x, "x"), _f(gamma, "gamma"),

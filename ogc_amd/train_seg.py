@@ -150,7 +150,14 @@ def main(argv=None):
                 for k, v in pending.result()[0].items():
                     sums[k] = sums.get(k, 0.0) + v
 
-        for batch in train_loader:
+        def device_batches():
+            for cpu_batch in train_loader:
+                yield tuple(x.to(device, non_blocking=True) for x in cpu_batch)
+
+        stream_of_batches = device_batches()
+        batch, pre = next(stream_of_batches, None), None
+        while batch is not None:
+            upcoming = next(stream_of_batches, None)  # one batch ahead: its geometry is queued during this step
             seen = it * global_batch
             for group in optimizer.param_groups:
                 group["lr"] = cfg["lr"] * schedule_factor(cfg, seen)
@@ -158,9 +165,10 @@ def main(argv=None):
             for m in net.modules():
                 if isinstance(m, NORM_LAYERS):
                     m.momentum = mom
-            batch = tuple(x.to(device, non_blocking=True) for x in batch)
             # the scalars of step i are read while step i+1 is already queued: the host never waits inside a step
-            pending = train_step(model, criterion, optimizer, batch, it * world, aug, sync=False)
+            pending = train_step(model, criterion, optimizer, batch, it * world, aug, sync=False, prefetched=pre,
+                                 next_batch=upcoming)
+            pre, batch = pending.prefetched, upcoming
             account(in_flight)
             in_flight = pending
             it += 1

@@ -34,6 +34,7 @@ class PendingStep:
 
     def __init__(self, pending_losses, bad_scalar):
         self._losses, self._bad, self._out = pending_losses, bad_scalar, None
+        self.prefetched = None  # PrefetchedGeometry of the next batch, when train_step was given one
 
     def result(self):
         if self._out is None:
@@ -51,29 +52,65 @@ def make_optimizer(params, lr, weight_decay=0.0):
     return torch.optim.Adam(params, lr=lr, weight_decay=weight_decay, fused=fused)
 
 
-def train_step(segnet, criterion, optimizer, batch, it, aug_transform, sync=True):
-    """batch = (pcs (b,t,n,3), segms (b,t,n), flows (b,t,n,3), valids), already on the device.
-    Returns (loss_dict, stepped); with sync=False a PendingStep whose result() gives the same pair later, so the
-    host can queue the next step while this one still runs (no host synchronisation inside the step when the
-    optimizer is fused — see make_optimizer)."""
-    from .utils.streams import HostScalars
-    segnet.train()
-    optimizer.zero_grad(set_to_none=True)
+def _views(batch):
     pcs, segms, flows, _ = batch
     b, t, n = segms.size()
     flat = pcs.view(b * t, n, -1).contiguous()
-    pcs_l = [pcs[:, tt].contiguous() for tt in range(t)]
-    flows_l = [flows[:, tt].contiguous() for tt in range(t)]
-    loss_geometry = None
-    if pcs.is_cuda and hasattr(criterion, "plan_geometry"):
-        # the smooth term's neighbour searches depend on coordinates only: start them now on a side stream so they
-        # overlap the network's forward pass instead of serialising after it
+    return flat, [pcs[:, tt].contiguous() for tt in range(t)], [flows[:, tt].contiguous() for tt in range(t)]
+
+
+class PrefetchedGeometry:
+    """Coordinate-only work of a step (FPS / kNN / 3-NN of every encoder level, the smooth term's kNN and ball query)
+    queued ahead of time for `batch`.  None of it depends on the weights, so a trainer that already holds the next
+    batch can let it run on side streams underneath the current step's dense kernels (the sampling kernels keep one
+    workgroup per cloud busy — 16 of 256 CUs — for milliseconds)."""
+
+    def __init__(self, segnet, criterion, batch, aug_transform):
         from .utils.streams import launch_on_side, side_stream
-        loss_geometry = launch_on_side(side_stream(pcs.device, "loss-geometry"),
-                                       lambda: criterion.plan_geometry(pcs_l, aug_transform))
-    masks = segnet(flat, flat).view(b, t, n, -1)
+        net = segnet.module if hasattr(segnet, "module") else segnet
+        self.batch, self.aug = batch, aug_transform
+        self.flat, self.pcs_l, self.flows_l = _views(batch)
+        ready = torch.cuda.Event()
+        ready.record()
+        self.model = net.plan_geometry_async(self.flat, after=ready) if hasattr(net, "plan_geometry_async") else None
+        self.loss = None
+        if hasattr(criterion, "plan_geometry"):
+            for p in self.pcs_l:
+                p.record_stream(side_stream(p.device, "loss-geometry"))
+            self.loss = launch_on_side(side_stream(self.flat.device, "loss-geometry"),
+                                       lambda: criterion.plan_geometry(self.pcs_l, aug_transform), after=ready)
+
+
+def train_step(segnet, criterion, optimizer, batch, it, aug_transform, sync=True, prefetched=None, next_batch=None):
+    """batch = (pcs (b,t,n,3), segms (b,t,n), flows (b,t,n,3), valids), already on the device.
+    Returns (loss_dict, stepped); with sync=False a PendingStep whose result() gives the same pair later, so the
+    host can queue the next step while this one still runs (no host synchronisation inside the step when the
+    optimizer is fused — see make_optimizer).
+    next_batch: the batch of the following step, if the caller already has it: its geometry is queued on side
+    streams during this step and handed back as PendingStep.prefetched, to be passed as `prefetched=` next time."""
+    from .utils.streams import HostScalars
+    segnet.train()
+    optimizer.zero_grad(set_to_none=True)
+    b = batch[1].size(0)
+    on_gpu = batch[0].is_cuda
+    if prefetched is not None and (prefetched.batch is not batch or prefetched.aug != aug_transform):
+        prefetched = None
+    if prefetched is None and on_gpu:
+        prefetched = PrefetchedGeometry(segnet, criterion, batch, aug_transform)  # queued now, behind nothing
+    if prefetched is not None:
+        flat, pcs_l, flows_l = prefetched.flat, prefetched.pcs_l, prefetched.flows_l
+        masks = segnet(flat, flat, geometry=prefetched.model) if prefetched.model is not None else segnet(flat, flat)
+        kw = {"geometry": prefetched.loss} if prefetched.loss is not None else {}
+    else:
+        flat, pcs_l, flows_l = _views(batch)
+        masks = segnet(flat, flat)
+        kw = {}
+    t, n = batch[1].size(1), batch[1].size(2)
+    masks = masks.view(b, t, n, -1)
     masks_l = [masks[:, tt].contiguous() for tt in range(t)]
-    kw = {"geometry": loss_geometry} if loss_geometry is not None else {}
+    upcoming = None
+    if next_batch is not None and on_gpu:
+        upcoming = PrefetchedGeometry(segnet, criterion, next_batch, aug_transform)
     loss, losses = criterion(pcs_l, masks_l, flows_l, step_w=True, it=it * b, aug_transform=aug_transform, sync=False,
                              **kw)
     loss.backward()
@@ -95,4 +132,5 @@ def train_step(segnet, criterion, optimizer, batch, it, aug_transform, sync=True
         if not skip:
             optimizer.step()
         pending = PendingStep(losses, HostScalars(torch.tensor([skip])))
+    pending.prefetched = upcoming
     return pending.result() if sync else pending

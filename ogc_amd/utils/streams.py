@@ -41,10 +41,14 @@ def _tensors(obj):
             yield from _tensors(v)
 
 
-def launch_on_side(stream, fn):
-    """Run ``fn()`` on ``stream`` after everything already queued on the current stream; returns a Pending."""
-    main = torch.cuda.current_stream()
-    stream.wait_stream(main)
+def launch_on_side(stream, fn, after=None):
+    """Run ``fn()`` on ``stream`` after everything already queued on the current stream — or, with ``after`` (an
+    event), after that event only, so the work may overlap whatever the current stream still has queued; returns a
+    Pending."""
+    if after is None:
+        stream.wait_stream(torch.cuda.current_stream())
+    else:
+        stream.wait_event(after)
     with torch.cuda.stream(stream):
         value = fn()
         event = torch.cuda.Event()

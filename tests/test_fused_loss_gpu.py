@@ -1,0 +1,71 @@
+"""Fused loss kernels against the reference's op sequence written in plain torch (fp32 and fp64)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def composed(mask_pm, idx, p):
+    """losses/seg_loss_unsup.py:123-129 with torch ops only (gather instead of grouping_operation)."""
+    B, N, C = mask_pm.shape
+    k = idx.shape[2]
+    nn_mask = torch.gather(mask_pm.unsqueeze(1).expand(B, N, N, C) if False else mask_pm, 1,
+                           idx.long().reshape(B, N * k, 1).expand(B, N * k, C)).view(B, N, k, C)
+    return (mask_pm.unsqueeze(2) - nn_mask).norm(p=p, dim=-1).mean(dim=-1)
+
+
+@pytest.mark.parametrize("p", [1, 2])
+@pytest.mark.parametrize("shape", [(2, 300, 10, 7), (3, 1024, 8, 32), (1, 64, 1, 64), (2, 97, 40, 3)])
+def test_neighbour_consistency(p, shape):
+    from ogc_amd.fused import neighbour_consistency, reverse_neighbours
+    B, N, C, k = shape
+    g = torch.Generator().manual_seed(B * N + C + k + p)
+    mask = torch.rand(B, N, C, generator=g).softmax(-1)
+    mask[:, ::5] = mask[:, 1::5][:, :mask[:, ::5].shape[1]]            # equal rows: exercises sign(0) / zero norm
+    idx = torch.randint(0, N, (B, N, k), generator=g, dtype=torch.int32)
+    idx[:, :, 0] = torch.arange(N, dtype=torch.int32)                   # self edges (distance exactly 0)
+    idx[:, 3:, -1] = idx[:, 3:, 0]                                      # padded duplicates, like ball query rows
+    w = torch.rand(B, N, generator=g)
+    mask_d, idx_d, w_d = mask.cuda().requires_grad_(True), idx.cuda(), w.cuda()
+    rev = reverse_neighbours(idx_d)
+    # transposed lists: the edges that can carry gradient, copies of a row's first entry merged with a multiplicity
+    rs, src, mult = rev[0].cpu().numpy(), rev[1].cpu().numpy(), rev[2].cpu().numpy()
+    idx_np = idx.numpy()
+    for b in range(B):
+        want = []
+        for i in range(N):
+            row = idx_np[b, i]
+            assert mult[b, i] == (1 if row[0] == i else int((row == row[0]).sum()))
+            for j, d in enumerate(row):
+                if d != i and not (j > 0 and d == row[0]):
+                    want.append((int(d), i, j == 0))
+        got = [(j, int(s) & 0x7FFFFFFF, int(s) < 0) for j in range(N) for s in src[b, rs[b, j]:rs[b, j + 1]]]
+        assert rs[b, 0] == 0 and rs[b, -1] == len(want)
+        assert sorted(got) == sorted(want)
+    out = neighbour_consistency(mask_d, idx_d, rev, p)
+    (out * w_d).sum().backward()
+    ref_mask = mask.double().cuda().requires_grad_(True)
+    ref = composed(ref_mask, idx_d, p)
+    (ref * w_d.double()).sum().backward()
+    torch.testing.assert_close(out.detach().double(), ref.detach(), rtol=1e-5, atol=1e-6)
+    # the fp64 composition has the same subgradient conventions (sign(0) = 0; 0 at zero norm)
+    torch.testing.assert_close(mask_d.grad.double(), ref_mask.grad, rtol=1e-4, atol=2e-5)
+
+
+def test_smooth_loss_fused_matches_generic():
+    from ogc_amd.losses.seg_loss_unsup import SmoothLoss
+    from ogc_amd.pointnet2 import pointnet2 as api
+    loss = SmoothLoss(3., 1., dict(k=8, radius=0.3, loss_norm=1), dict(k=16, radius=0.4, loss_norm=1))
+    g = torch.Generator().manual_seed(3)
+    pcs = [torch.rand(2, 1500, 3, generator=g).cuda() for _ in range(4)]
+    logits = torch.randn(4, 2, 1500, 6, generator=g).cuda().requires_grad_(True)
+    masks = [logits[v].softmax(-1) for v in range(4)]
+    fused = loss.forward_views(pcs, masks)
+    torch.stack(fused).sum().backward()
+    g_fused = logits.grad.clone()
+    logits.grad = None
+    plain = [loss(p, m) for p, m in zip(pcs, [logits[v].softmax(-1) for v in range(4)])]   # reference-shaped path
+    torch.stack(plain).sum().backward()
+    torch.testing.assert_close(torch.stack(fused), torch.stack(plain), rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(g_fused, logits.grad, rtol=1e-4, atol=1e-7)
