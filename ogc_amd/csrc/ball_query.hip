@@ -19,10 +19,7 @@ constexpr int BQ_LSTRIDE = 65;
 __global__ __launch_bounds__(OGC_WAVE) void ball_query_kernel(int n, int m, float radius2, int nsample,
                                                               const float *__restrict__ new_xyz,
                                                               const float *__restrict__ xyz,
-                                                              int *__restrict__ idx,
-                                                              const ogc_grid::GridHdr *__restrict__ only_dense) {
-    // when the cell-list path is active, this kernel only serves the clouds it flagged as dense
-    if (only_dense && !only_dense[blockIdx.y].dense) return;
+                                                              int *__restrict__ idx) {
     extern __shared__ __attribute__((aligned(16))) int bq_smem[];
     float *tile = reinterpret_cast<float *>(bq_smem);   // [OGC_TILE_FLOATS] candidate tile (16-byte aligned)
     int *rows = bq_smem + OGC_TILE_FLOATS;              // [nsample][BQ_LSTRIDE]
@@ -91,13 +88,10 @@ extern "C" int ogc_ball_query(int b, int n, int m, float radius, int nsample, co
     // Cell-list path (identical results, ~N/100 candidates per centre); the all-pairs scan below remains for small
     // clouds and as the fallback.  OGC_BALL_QUERY=brute|grid forces a path (development / tests).
     static const char *mode = getenv("OGC_BALL_QUERY");
-    const ogc_grid::GridHdr *only_dense = nullptr;
-    void *grid_ws = nullptr;
     if (!(mode && mode[0] == 'b') && xyz) {
-        const int rc = ogc_ball_query_grid(b, n, m, radius, nsample, new_xyz, xyz, idx, (hipStream_t)stream,
-                                           &only_dense, &grid_ws);
-        if (rc != OGC_OK && rc != OGC_ERR_UNSUPPORTED) return rc;
-        if (rc == OGC_ERR_UNSUPPORTED && mode && mode[0] == 'g') {
+        const int rc = ogc_ball_query_grid(b, n, m, radius, nsample, new_xyz, xyz, idx, (hipStream_t)stream);
+        if (rc != OGC_ERR_UNSUPPORTED) return rc;
+        if (mode && mode[0] == 'g') {
             ogc_set_error("ogc_ball_query: grid path forced but not applicable (n=%d, nsample=%d, r=%g)", n, nsample,
                           (double)radius);
             return OGC_ERR_UNSUPPORTED;
@@ -105,8 +99,7 @@ extern "C" int ogc_ball_query(int b, int n, int m, float radius, int nsample, co
     }
     dim3 grid(ogc_divup(m, OGC_WAVE), b);
     hipLaunchKernelGGL(ball_query_kernel, grid, dim3(OGC_WAVE), lds, (hipStream_t)stream, n, m,
-                       radius * radius, nsample, new_xyz, xyz, idx, only_dense);
-    if (grid_ws) ogc_ball_query_grid_release(grid_ws, (hipStream_t)stream);
+                       radius * radius, nsample, new_xyz, xyz, idx);
     OGC_CHECK_LAUNCH("ogc_ball_query");
     return OGC_OK;
 }

@@ -13,12 +13,10 @@ struct GridHdr { // one per cloud, written by grid_build_kernel
 
 } // namespace ogc_grid
 
-// Queues build + query on `s`.  Returns OGC_OK, or OGC_ERR_UNSUPPORTED when the caller should run the all-pairs scan.
-// On OGC_OK the caller must ALSO launch its all-pairs kernel gated on `*dense_hdrs` (clouds flagged dense are skipped
-// by the cell-list kernel) and then call ogc_ball_query_grid_release.
+// Queues build + query on `s` (clouds the build flags dense are scanned in index order by the same kernel).
+// Returns OGC_OK, or OGC_ERR_UNSUPPORTED when the caller should run the all-pairs scan instead.
 int ogc_ball_query_grid(int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz,
-                        int *idx, hipStream_t s, const ogc_grid::GridHdr **dense_hdrs, void **workspace);
-void ogc_ball_query_grid_release(void *workspace, hipStream_t s);
+                        int *idx, hipStream_t s);
 
 // Exact k-NN over cell lists (mode 0: squared distances, 1: sqrt + radius clamp).  OGC_OK, or OGC_ERR_UNSUPPORTED when
 // the caller should run the all-pairs scan (small clouds, k too large for the LDS budget).

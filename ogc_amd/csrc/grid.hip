@@ -37,8 +37,7 @@ __global__ __launch_bounds__(BUILD_THREADS) void grid_build_kernel(int n, float 
                                                                    const float *__restrict__ xyz,
                                                                    GridHdr *__restrict__ hdrs,
                                                                    int *__restrict__ cell_start,
-                                                                   int *__restrict__ sorted_idx,
-                                                                   float *__restrict__ sorted_xyz) {
+                                                                   float4 *__restrict__ sorted_pts) {
     __shared__ int s_cnt[GRID_MAX_CELLS]; // histogram -> exclusive starts -> scatter cursors
     __shared__ float s_red[6][BUILD_THREADS / 64];
     __shared__ int s_part[BUILD_THREADS];
@@ -92,8 +91,6 @@ __global__ __launch_bounds__(BUILD_THREADS) void grid_build_kernel(int n, float 
             double vol = 1.0;
             for (int a = 0; a < 3; ++a)
                 if (ext[a] > 1e-3 * maxext && ext[a] > 0.0) { ++dims; vol *= ext[a]; }
-            int finite_pts = 0;
-            (void)finite_pts;
             const double block = dims == 3 ? 27.0 : (dims == 2 ? 9.0 : 3.0);
             const double per_cell = fmax(2.5 * (double)knn_k / block, 1.0);
             edge = dims > 0 ? pow(vol * per_cell / (double)max(n, 1), 1.0 / (double)dims) : 1.0;
@@ -165,9 +162,9 @@ __global__ __launch_bounds__(BUILD_THREADS) void grid_build_kernel(int n, float 
     }
     __syncthreads();
 
-    // 4. scatter (order inside a cell is arbitrary; the query sorts its hits by index)
-    int *sidx = sorted_idx + (size_t)b * n;
-    float *sxyz = sorted_xyz + (size_t)b * n * 3;
+    // 4. scatter (order inside a cell is arbitrary; the queries order their results themselves).  One 16-byte record
+    //    per point: x, y, z and the point's index (bit pattern), so a query reads a candidate with a single load.
+    float4 *sp = sorted_pts + (size_t)b * n;
     for (int k = t; k < n; k += BUILD_THREADS) {
         const float x = pts[k * 3], y = pts[k * 3 + 1], z = pts[k * 3 + 2];
         if (isfinite(x) && isfinite(y) && isfinite(z)) {
@@ -175,130 +172,287 @@ __global__ __launch_bounds__(BUILD_THREADS) void grid_build_kernel(int n, float 
             const int cy = min(max(cell_coord(y, h.miny, h.inv_h, h.gy), 0), h.gy - 1);
             const int cz = min(max(cell_coord(z, h.minz, h.inv_h, h.gz), 0), h.gz - 1);
             const int pos = atomicAdd(&s_cnt[cx + h.gx * (cy + h.gy * cz)], 1);
-            sidx[pos] = k;
-            sxyz[pos * 3] = x; sxyz[pos * 3 + 1] = y; sxyz[pos * 3 + 2] = z;
+            sp[pos] = make_float4(x, y, z, __int_as_float(k));
         } else { // not in any cell; listed after the cells so that a same-set query still emits its (empty) row
             const int pos = atomicAdd(&s_tail, 1);
-            sidx[pos] = k;
-            sxyz[pos * 3] = NAN; sxyz[pos * 3 + 1] = NAN; sxyz[pos * 3 + 2] = NAN;
+            sp[pos] = make_float4(NAN, NAN, NAN, __int_as_float(k));
         }
     }
 }
 
-constexpr int SUB = 8;               // lanes cooperating on one centre
-constexpr int QPW = OGC_WAVE / SUB;  // centres per wavefront
+constexpr int SUB = 8;               // lanes cooperating on one query in the finishing steps
+constexpr int QPW = OGC_WAVE / SUB;  // queries (centres) per wavefront
 
-// EIGHT lanes per centre.  With one lane per centre a 16 x 8192 batch is only 2048 wavefronts (two per SIMD) of
-// long serial pointer-walks; eight lanes per centre give 16384 short wavefronts, so the chip hides the cache
-// latency of the candidate reads by switching waves.  The centres are the grid's own points in cell order; the
-// three x-adjacent cells of a (y, z) pair are ONE contiguous run of the cell-sorted arrays, so a centre has nine
-// runs, and the eight lanes stride through each run together (consecutive candidates -> one cache line).
-//   hits       : slot = cnt + (number of hitting lanes below me in my group), from one wave ballot — no atomics;
-//   row full   : the group keeps the nsample SMALLEST point indices (replace the current maximum, re-scan it);
-//   finish     : rank sort by the eight lanes (indices are distinct), pad with the smallest, 32-byte stores.
+__device__ __forceinline__ int lane_bcast(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+__device__ __forceinline__ float lane_bcast(float v, int src) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
+
+// The candidate runs of a box of cells [xlo, xhi] x (y0-1 .. y0+1) x (z0-1 .. z0+1): the cells of one (y, z) row are
+// contiguous in the cell-sorted array, so the box is NINE runs.  Lane r < 9 fetches run r; the nine (start, offset)
+// pairs are then broadcast to scalars so that every lane can map a flat candidate number to an array position.
+// (A macro, not a struct: the eighteen scalars must stay in SGPRs — as members of an object passed by reference the
+// compiler put them in scratch memory and indexed them per candidate.)
+#define OGC_BOX_SETUP(XLO, XHI, Y0, Z0)                                                              \
+    {                                                                                                \
+        int lo_ = 0, len_ = 0;                                                                       \
+        if (lane < 9) {                                                                              \
+            const int y_ = (Y0) + (lane % 3) - 1, z_ = (Z0) + (lane / 3) - 1;                        \
+            if (y_ >= 0 && y_ < h.gy && z_ >= 0 && z_ < h.gz && (XLO) <= (XHI)) {                    \
+                const int rowc_ = h.gx * (y_ + h.gy * z_);                                           \
+                lo_ = cs[rowc_ + (XLO)];                                                             \
+                len_ = cs[rowc_ + (XHI) + 1] - lo_;                                                  \
+            }                                                                                        \
+        }                                                                                            \
+        int incl_ = len_;                                                                            \
+        _Pragma("unroll") for (int off_ = 1; off_ < 16; off_ <<= 1) {                                \
+            const int up_ = __shfl_up(incl_, off_, 64);                                              \
+            if (lane >= off_) incl_ += up_;                                                          \
+        }                                                                                            \
+        const int excl_ = incl_ - len_;                                                              \
+        box_total = lane_bcast(incl_, 8);                                                            \
+        b0 = lane_bcast(lo_ - excl_, 0);                                                             \
+        s1 = lane_bcast(excl_, 1); b1 = lane_bcast(lo_ - excl_, 1);                                  \
+        s2 = lane_bcast(excl_, 2); b2 = lane_bcast(lo_ - excl_, 2);                                  \
+        s3 = lane_bcast(excl_, 3); b3 = lane_bcast(lo_ - excl_, 3);                                  \
+        s4 = lane_bcast(excl_, 4); b4 = lane_bcast(lo_ - excl_, 4);                                  \
+        s5 = lane_bcast(excl_, 5); b5 = lane_bcast(lo_ - excl_, 5);                                  \
+        s6 = lane_bcast(excl_, 6); b6 = lane_bcast(lo_ - excl_, 6);                                  \
+        s7 = lane_bcast(excl_, 7); b7 = lane_bcast(lo_ - excl_, 7);                                  \
+        s8 = lane_bcast(excl_, 8); b8 = lane_bcast(lo_ - excl_, 8);                                  \
+    }
+// the LAST run whose start is <= f (empty runs share their start with the next one)
+#define OGC_BOX_POSITION(F)                                                                           \
+    ((F) + ((F) >= s8 ? b8 : (F) >= s7 ? b7 : (F) >= s6 ? b6 : (F) >= s5 ? b5 : (F) >= s4 ? b4       \
+                     : (F) >= s3 ? b3 : (F) >= s2 ? b2 : (F) >= s1 ? b1 : b0))
+
+// squared distances of ONE candidate to TWO centres, packed (v_pk_*_f32): the reference's fp32 expression per half
+__device__ __forceinline__ ogc_v2f sqdist_pair(ogc_v2f qx, ogc_v2f qy, ogc_v2f qz, float x, float y, float z) {
+#pragma clang fp contract(off)
+    const ogc_v2f cx2 = {x, x}, cy2 = {y, y}, cz2 = {z, z};
+    ogc_v2f dx = qx - cx2, dy = qy - cy2, dz = qz - cz2;
+    dx = dx * dx;
+    dy = dy * dy;
+    dz = dz * dz;
+    return (dx + dy) + dz;
+}
+
+// Ball query of a cloud against itself over the cell lists: ONE LANE PER CANDIDATE.
+// A wavefront takes eight centres that are consecutive in cell order.  Centres on the same (y, z) row of cells form a
+// batch (usually the whole wavefront is one batch); the union of their 27-cell neighbourhoods is a box of nine
+// contiguous runs, whose candidates are dealt to the 64 lanes (16-byte records, one load each).  Each centre of the
+// batch is then tested by all lanes at once — its coordinates are wave-uniform scalars, two centres per packed
+// instruction, the squared distance is the reference's fp32 expression — and one ballot turns the hits into
+// consecutive slots of the centre's hit list (hit counts live in scalar registers).  Testing a candidate outside a
+// centre's own 27 cells is harmless (the distance decides), so the box needs no per-centre bookkeeping.
+// Finish: eight lanes per centre rank-sort the hit list by point index (indices are distinct), keep the first
+// nsample, pad with the smallest, 16-byte stores — the row the reference produces by scanning in index order and
+// stopping after nsample hits.  A centre with more hits than the list holds is redone through an LDS bitmap over
+// point indices (set a bit per hit, read the first nsample set bits), also exact.
+// Clouds flagged dense by the build (the 27 cells hold a large share of the cloud, so cell lists buy nothing and
+// rows saturate early) are scanned in INDEX order instead, by the same wavefronts: hits then arrive in the order
+// of the output and a wavefront stops as soon as its eight rows are full.
 __global__ __launch_bounds__(OGC_WAVE) void ball_query_grid_kernel(int n, int m, float radius2, int nsample,
-                                                                   int stride_cells,
+                                                                   int hit_cap, int stride_cells,
+                                                                   const float *__restrict__ xyz,
                                                                    const GridHdr *__restrict__ hdrs,
                                                                    const int *__restrict__ cell_start,
-                                                                   const int *__restrict__ sorted_idx,
-                                                                   const float *__restrict__ sorted_xyz,
+                                                                   const float4 *__restrict__ sorted_pts,
                                                                    int *__restrict__ idx_out) {
     extern __shared__ __attribute__((aligned(16))) int gq_smem[];
     const int lane = threadIdx.x, b = blockIdx.y;
     const GridHdr h = hdrs[b];
-    if (h.dense) return; // this cloud is handled by the all-pairs kernel
-    const int sub = lane & (SUB - 1), qi = lane >> 3;
-    int *kept = gq_smem + qi * nsample;                 // [QPW][nsample] indices kept so far (unordered)
-    int *outr = gq_smem + (QPW + qi) * nsample;         // [QPW][nsample] sorted + padded row
-    const int p = blockIdx.x * QPW + qi;
+    int *hits = gq_smem;                                       // [QPW][hit_cap]
+    int *outr = gq_smem + QPW * hit_cap;                       // [QPW][nsample] sorted rows
+    unsigned *bitmap = reinterpret_cast<unsigned *>(outr + QPW * nsample); // [ceil(n / 32)], overflow path only
     const int *cs = cell_start + (size_t)b * stride_cells;
-    const int *sidx = sorted_idx + (size_t)b * n;
-    const float *sxyz = sorted_xyz + (size_t)b * n * 3;
-    const unsigned below = (1u << sub) - 1u;
+    const float4 *pts = sorted_pts + (size_t)b * n;
 
-    int q = -1;
-    float qx = NAN, qy = NAN, qz = NAN;
-    if (p < n) { // positions >= h.npts hold the non-finite points (NaN coordinates -> no hit -> zero row)
-        q = sidx[p];
-        qx = sxyz[p * 3]; qy = sxyz[p * 3 + 1]; qz = sxyz[p * 3 + 2];
-    }
-    int cnt = 0, maxv = -1, maxpos = 0; // uniform within the group
-    // (re)compute the largest kept index of a FULL row: each lane scans nsample/8 entries, then a 3-step butterfly
-    auto rescan_max = [&]() {
-        int mv = -1, mp = 0;
-        for (int e = sub; e < nsample; e += SUB) {
-            const int v = kept[e];
-            if (v > mv) { mv = v; mp = e; }
-        }
+    // every group of eight lanes holds the eight centres (lane & 7), so 8-lane butterflies see the whole set
+    const int pc = blockIdx.x * QPW + (lane & (QPW - 1));
+    float4 me = make_float4(NAN, NAN, NAN, __int_as_float(-1));
+    if (pc < n) me = pts[pc]; // positions >= h.npts hold the non-finite points: no hits, an all-zero row
+    const bool live = pc < h.npts;
+    int cnt_s[QPW]; // wave-uniform hit counts (may exceed hit_cap)
 #pragma unroll
-        for (int off = 1; off < SUB; off <<= 1) {
-            const int ov = __shfl_xor(mv, off, 64), op = __shfl_xor(mp, off, 64);
-            if (ov > mv) { mv = ov; mp = op; }
-        }
-        maxv = mv;
-        maxpos = mp;
-    };
-    if (p < h.npts) {
-        const int cx = cell_coord(qx, h.minx, h.inv_h, h.gx);
-        const int cy = cell_coord(qy, h.miny, h.inv_h, h.gy);
-        const int cz = cell_coord(qz, h.minz, h.inv_h, h.gz);
-        const int x0 = max(cx - 1, 0), x1 = min(cx + 1, h.gx - 1);
-        int lo[9], hi[9];
+    for (int c = 0; c < QPW; ++c) cnt_s[c] = 0;
+    unsigned sorted_rows = 0; // rows written in ascending order already (index-order scan, bitmap path)
+    int box_total, b0, s1, b1, s2, b2, s3, b3, s4, b4, s5, b5, s6, b6, s7, b7, s8, b8;
+    const unsigned live_mask = (unsigned)__builtin_amdgcn_ballot_w64(live) & 0xFFu;
+
+    if (h.dense) {
+        // ---- index-order scan of the whole cloud: rows come out sorted, stop when all rows are full
+        const float *src = xyz + (size_t)b * n * 3;
+        sorted_rows = 0xFFu;
+        for (int f0 = 0; f0 < n; f0 += OGC_WAVE) {
+            const int f = f0 + lane;
+            float x = NAN, y = NAN, z = NAN;
+            if (f < n) { x = src[f * 3]; y = src[f * 3 + 1]; z = src[f * 3 + 2]; }
+            bool all_full = true;
 #pragma unroll
-        for (int r = 0; r < 9; ++r) { // eighteen independent loads (the same addresses for the 8 lanes of a group)
-            const int y = cy + (r % 3) - 1, z = cz + (r / 3) - 1;
-            const bool ok = y >= 0 && y < h.gy && z >= 0 && z < h.gz && x0 <= x1;
-            const int rowc = h.gx * (y + h.gy * z);
-            lo[r] = ok ? cs[rowc + x0] : 0;
-            hi[r] = ok ? cs[rowc + x1 + 1] : 0;
-        }
+            for (int c = 0; c < QPW; c += 2) {
+                if (!((live_mask >> c) & 3u)) continue;
+                const ogc_v2f qx = {lane_bcast(me.x, c), lane_bcast(me.x, c + 1)};
+                const ogc_v2f qy = {lane_bcast(me.y, c), lane_bcast(me.y, c + 1)};
+                const ogc_v2f qz = {lane_bcast(me.z, c), lane_bcast(me.z, c + 1)};
+                const ogc_v2f d = sqdist_pair(qx, qy, qz, x, y, z);
 #pragma unroll
-        for (int r = 0; r < 9; ++r) {
-            for (int j = lo[r] + sub; __builtin_amdgcn_ballot_w64(j < hi[r]) != 0; j += SUB) {
-                bool hit = false;
-                int v = 0;
-                if (j < hi[r]) {
-                    hit = ogc_sqdist(qx, qy, qz, sxyz[j * 3], sxyz[j * 3 + 1], sxyz[j * 3 + 2]) < radius2;
-                    if (hit) v = sidx[j];
-                }
-                const unsigned long long ball = __builtin_amdgcn_ballot_w64(hit);
-                if (ball == 0) continue;
-                const unsigned slice = (unsigned)(ball >> (qi * SUB)) & 0xFFu;
-                if (slice == 0) continue;
-                const int nh = __popc(slice);
-                if (cnt + nh <= nsample) { // common case: room for all of the group's hits
-                    if (hit) kept[cnt + __popc(slice & below)] = v;
-                    cnt += nh;
-                    if (cnt == nsample) rescan_max();
-                } else { // row (nearly) full: take the hits one by one, keep the nsample smallest indices
-                    for (int t = 0; t < SUB; ++t) {
-                        if (!((slice >> t) & 1u)) continue;
-                        const int vt = __shfl(v, qi * SUB + t, 64);
-                        if (cnt < nsample) {
-                            if (sub == 0) kept[cnt] = vt;
-                            if (++cnt == nsample) rescan_max();
-                        } else if (vt < maxv) {
-                            if (sub == 0) kept[maxpos] = vt;
-                            rescan_max();
+                for (int u = 0; u < 2; ++u) {
+                    if (cnt_s[c + u] >= nsample) continue;
+                    const bool hit = (u == 0 ? d.x : d.y) < radius2;
+                    const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
+                    if (mask != 0) {
+                        if (hit) {
+                            const int slot = cnt_s[c + u] + (int)__builtin_amdgcn_mbcnt_hi(
+                                (unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                            if (slot < nsample) outr[(c + u) * nsample + slot] = f;
                         }
+                        cnt_s[c + u] += __popcll(mask);
+                    }
+                    if (cnt_s[c + u] < nsample && ((live_mask >> (c + u)) & 1u)) all_full = false;
+                }
+            }
+            if (all_full) break;
+        }
+    } else {
+        const int cx = cell_coord(me.x, h.minx, h.inv_h, h.gx);
+        const int cy = cell_coord(me.y, h.miny, h.inv_h, h.gy);
+        const int cz = cell_coord(me.z, h.minz, h.inv_h, h.gz);
+        unsigned todo = live_mask;
+        while (todo != 0) {
+            const int c0 = __ffs(todo) - 1;
+            const int y0 = lane_bcast(cy, c0), z0 = lane_bcast(cz, c0);
+            const bool mine = live && cy == y0 && cz == z0;
+            const unsigned batch = (unsigned)__builtin_amdgcn_ballot_w64(mine) & todo;
+            todo &= ~batch;
+            int xlo = mine ? cx : 0x7fffffff, xhi = mine ? cx : -1;
+#pragma unroll
+            for (int off = 1; off < QPW; off <<= 1) {
+                xlo = min(xlo, __shfl_xor(xlo, off, 64));
+                xhi = max(xhi, __shfl_xor(xhi, off, 64));
+            }
+            const int bx0 = max(lane_bcast(xlo, 0) - 1, 0), bx1 = min(lane_bcast(xhi, 0) + 1, h.gx - 1);
+            OGC_BOX_SETUP(bx0, bx1, y0, z0)
+            for (int f0 = 0; f0 < box_total; f0 += OGC_WAVE) {
+                const int f = f0 + lane;
+                float4 cand = make_float4(NAN, NAN, NAN, 0.0f); // NaN: never a hit
+                if (f < box_total) cand = pts[OGC_BOX_POSITION(f)];
+                const int v = __float_as_int(cand.w);
+#pragma unroll
+                for (int c = 0; c < QPW; c += 2) {
+                    if (!((batch >> c) & 3u)) continue; // wave-uniform
+                    const ogc_v2f qx = {lane_bcast(me.x, c), lane_bcast(me.x, c + 1)};
+                    const ogc_v2f qy = {lane_bcast(me.y, c), lane_bcast(me.y, c + 1)};
+                    const ogc_v2f qz = {lane_bcast(me.z, c), lane_bcast(me.z, c + 1)};
+                    const ogc_v2f d = sqdist_pair(qx, qy, qz, cand.x, cand.y, cand.z);
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        if (!((batch >> (c + u)) & 1u)) continue;
+                        const bool hit = (u == 0 ? d.x : d.y) < radius2;
+                        const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
+                        if (mask == 0) continue;
+                        if (hit) {
+                            const int slot = cnt_s[c + u] + (int)__builtin_amdgcn_mbcnt_hi(
+                                (unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                            if (slot < hit_cap) hits[(c + u) * hit_cap + slot] = v;
+                        }
+                        cnt_s[c + u] += __popcll(mask);
                     }
                 }
             }
         }
     }
-    // rank sort (the kept indices are distinct): element e goes to position #{f : kept[f] < kept[e]}
-    for (int e = sub; e < cnt; e += SUB) {
-        const int ve = kept[e];
-        int rank = 0;
-        for (int f = 0; f < cnt; ++f) rank += kept[f] < ve ? 1 : 0;
-        outr[rank] = ve;
+    // hit counts: lane c < 8 holds the count of centre c
+    int cnt = 0;
+#pragma unroll
+    for (int c = 0; c < QPW; ++c) cnt = lane == c ? cnt_s[c] : cnt;
+    if (h.dense) cnt = min(cnt, nsample);
+
+    // centres whose hit list overflowed: exact redo through a bitmap over point indices
+    unsigned over = h.dense ? 0u : (unsigned)__builtin_amdgcn_ballot_w64(lane < QPW && cnt > hit_cap);
+    while (over != 0) {
+        const int c = __ffs(over) - 1;
+        over &= over - 1;
+        sorted_rows |= 1u << c;
+        const int words = (n + 31) >> 5;
+        for (int w = lane; w < words; w += OGC_WAVE) bitmap[w] = 0u;
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        const float qx = lane_bcast(me.x, c), qy = lane_bcast(me.y, c), qz = lane_bcast(me.z, c);
+        const int ccx = cell_coord(qx, h.minx, h.inv_h, h.gx);
+        const int ccy = cell_coord(qy, h.miny, h.inv_h, h.gy);
+        const int ccz = cell_coord(qz, h.minz, h.inv_h, h.gz);
+        const int bx0 = max(ccx - 1, 0), bx1 = min(ccx + 1, h.gx - 1);
+        OGC_BOX_SETUP(bx0, bx1, ccy, ccz)
+        for (int f0 = 0; f0 < box_total; f0 += OGC_WAVE) {
+            const int f = f0 + lane;
+            if (f < box_total) {
+                const float4 cand = pts[OGC_BOX_POSITION(f)];
+                if (ogc_sqdist(qx, qy, qz, cand.x, cand.y, cand.z) < radius2) {
+                    const unsigned v = (unsigned)__float_as_int(cand.w);
+                    atomicOr(&bitmap[v >> 5], 1u << (v & 31u));
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        int found = 0;
+        for (int w0 = 0; w0 < words && found < nsample; w0 += OGC_WAVE) {
+            const int w = w0 + lane;
+            unsigned bits = w < words ? bitmap[w] : 0u;
+            const int pcn = __popc(bits);
+            int incl = pcn;
+#pragma unroll
+            for (int off = 1; off < OGC_WAVE; off <<= 1) {
+                const int up = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += up;
+            }
+            int pos = found + incl - pcn;
+            while (bits != 0u && pos < nsample) {
+                outr[c * nsample + pos] = (w << 5) + (__ffs(bits) - 1);
+                bits &= bits - 1u;
+                ++pos;
+            }
+            found += lane_bcast(incl, OGC_WAVE - 1);
+        }
+        if (lane == c) cnt = min(found, nsample);
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+
+    // finish: eight lanes per centre
+    const int sub = lane & (SUB - 1), qi = lane >> 3;
+    const int total_hits = __shfl(cnt, qi, 64);
+    const int q = __float_as_int(__shfl(me.w, qi, 64));
+    int *row = outr + qi * nsample;
+    if (!((sorted_rows >> qi) & 1u)) {
+        // rank sort (the indices are distinct): element e goes to position #{f : hits[f] < hits[e]}
+        const int *mine_hits = hits + qi * hit_cap;
+        for (int e = sub; e < total_hits; e += SUB) {
+            const int ve = mine_hits[e];
+            int rank = 0;
+            for (int f = 0; f < total_hits; ++f) rank += mine_hits[f] < ve ? 1 : 0;
+            if (rank < nsample) row[rank] = ve;
+        }
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
     if (q >= 0) {
-        const int first = cnt > 0 ? outr[0] : 0;
+        const int kept = min(total_hits, nsample);
+        const int first = kept > 0 ? row[0] : 0;
         int *o = idx_out + ((size_t)b * m + q) * nsample;
-        for (int j = sub; j < nsample; j += SUB) o[j] = j < cnt ? outr[j] : first;
+        if ((nsample & 3) == 0) { // 16-byte stores
+            for (int j = sub * 4; j < nsample; j += SUB * 4) {
+                int4 val;
+                val.x = j < kept ? row[j] : first;
+                val.y = j + 1 < kept ? row[j + 1] : first;
+                val.z = j + 2 < kept ? row[j + 2] : first;
+                val.w = j + 3 < kept ? row[j + 3] : first;
+                *reinterpret_cast<int4 *>(o + j) = val;
+            }
+        } else {
+            for (int j = sub; j < nsample; j += SUB) o[j] = j < kept ? row[j] : first;
+        }
     }
 }
 
@@ -327,8 +481,7 @@ __global__ __launch_bounds__(OGC_WAVE) void knn_grid_kernel(int n, int m, int k,
                                                             const float *__restrict__ unknown,
                                                             const GridHdr *__restrict__ hdrs,
                                                             const int *__restrict__ cell_start,
-                                                            const int *__restrict__ sorted_idx,
-                                                            const float *__restrict__ sorted_xyz,
+                                                            const float4 *__restrict__ sorted_pts,
                                                             float *__restrict__ dist_out, int *__restrict__ idx_out) {
     extern __shared__ __attribute__((aligned(16))) u64 kq_smem[];
     const int lane = threadIdx.x, b = blockIdx.y;
@@ -338,8 +491,7 @@ __global__ __launch_bounds__(OGC_WAVE) void knn_grid_kernel(int n, int m, int k,
     const int p = blockIdx.x * QPW + qi;
     const GridHdr h = hdrs[b];
     const int *cs = cell_start + (size_t)b * stride_cells;
-    const int *sidx = sorted_idx + (size_t)b * m;
-    const float *sxyz = sorted_xyz + (size_t)b * m * 3;
+    const float4 *pts = sorted_pts + (size_t)b * m;
     const unsigned below = (1u << sub) - 1u;
 
     float qx = NAN, qy = NAN, qz = NAN;
@@ -371,9 +523,10 @@ __global__ __launch_bounds__(OGC_WAVE) void knn_grid_kernel(int n, int m, int k,
             bool adm = false;
             u64 key = 0;
             if (j < j1) {
-                const float d = ogc_sqdist(qx, qy, qz, sxyz[j * 3], sxyz[j * 3 + 1], sxyz[j * 3 + 2]);
+                const float4 cand = pts[j];
+                const float d = ogc_sqdist(qx, qy, qz, cand.x, cand.y, cand.z);
                 if (d < INFINITY) { // NaN / inf are never selected
-                    key = ((u64)__float_as_uint(d) << 32) | (unsigned)sidx[j];
+                    key = ((u64)__float_as_uint(d) << 32) | (unsigned)__float_as_int(cand.w);
                     adm = cnt < k || key < maxkey;
                 }
             }
@@ -464,8 +617,9 @@ __global__ __launch_bounds__(OGC_WAVE) void knn_grid_kernel(int n, int m, int k,
 using namespace ogc_grid;
 
 int ogc_ball_query_grid(int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz,
-                        int *idx, hipStream_t s, const GridHdr **dense_hdrs, void **workspace) {
-    const size_t lds = (size_t)2 * QPW * nsample * sizeof(int);
+                        int *idx, hipStream_t s) {
+    const int hit_cap = nsample > 128 ? nsample : 128;
+    const size_t lds = ((size_t)QPW * (hit_cap + nsample) + (size_t)(n + 31) / 32) * sizeof(int);
     // the cell-ordered traversal needs the centres to BE the points (ball_query(pc, pc), the reference's only live
     // use: losses/seg_loss_unsup.py:151, losses/flow_loss_unsup.py:84); other centre sets use the all-pairs scan
     const bool same = (new_xyz == xyz) && (m == n);
@@ -473,33 +627,23 @@ int ogc_ball_query_grid(int b, int n, int m, float radius, int nsample, const fl
     const int stride_cells = GRID_MAX_CELLS + 1;
     const size_t bytes_hdr = (sizeof(GridHdr) * b + 255) / 256 * 256;
     const size_t bytes_cs = (sizeof(int) * (size_t)b * stride_cells + 255) / 256 * 256;
-    const size_t bytes_idx = (sizeof(int) * (size_t)b * n + 255) / 256 * 256;
-    const size_t bytes_xyz = sizeof(float) * (size_t)b * n * 3;
-    char *ws = nullptr;
-    if (hipMallocAsync((void **)&ws, bytes_hdr + bytes_cs + bytes_idx + bytes_xyz, s) != hipSuccess || !ws) {
-        (void)hipGetLastError();
-        return OGC_ERR_UNSUPPORTED;
-    }
+    const size_t bytes_pts = sizeof(float4) * (size_t)b * n;
+    char *ws = static_cast<char *>(ogc_workspace(s, bytes_hdr + bytes_cs + bytes_pts));
+    if (!ws) return OGC_ERR_UNSUPPORTED;
     GridHdr *hdrs = reinterpret_cast<GridHdr *>(ws);
     int *cell_start = reinterpret_cast<int *>(ws + bytes_hdr);
-    int *sorted_idx = reinterpret_cast<int *>(ws + bytes_hdr + bytes_cs);
-    float *sorted_xyz = reinterpret_cast<float *>(ws + bytes_hdr + bytes_cs + bytes_idx);
+    float4 *sorted_pts = reinterpret_cast<float4 *>(ws + bytes_hdr + bytes_cs);
     hipLaunchKernelGGL(grid_build_kernel, dim3(b), dim3(BUILD_THREADS), 0, s, n, radius, 0, stride_cells, xyz, hdrs,
-                       cell_start, sorted_idx, sorted_xyz);
+                       cell_start, sorted_pts);
     hipLaunchKernelGGL(ball_query_grid_kernel, dim3(ogc_divup(n, QPW), b), dim3(OGC_WAVE), lds, s, n, m,
-                       radius * radius, nsample, stride_cells, hdrs, cell_start, sorted_idx, sorted_xyz, idx);
+                       radius * radius, nsample, hit_cap, stride_cells, xyz, hdrs, cell_start, sorted_pts, idx);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
-        (void)hipFreeAsync(ws, s);
         ogc_set_error("ogc_ball_query (grid): launch failed: %s", hipGetErrorString(e));
         return OGC_ERR_LAUNCH;
     }
-    *dense_hdrs = hdrs;
-    *workspace = ws;
     return OGC_OK;
 }
-
-void ogc_ball_query_grid_release(void *workspace, hipStream_t s) { (void)hipFreeAsync(workspace, s); }
 
 // k-NN over cell lists.  Returns OGC_OK after queueing build + query, or OGC_ERR_UNSUPPORTED (caller: all-pairs scan).
 int ogc_knn_grid(int mode, int b, int n, int m, int k, float radius, const float *unknown, const float *known,
@@ -509,28 +653,22 @@ int ogc_knn_grid(int mode, int b, int n, int m, int k, float radius, const float
     const int stride_cells = GRID_MAX_CELLS + 1;
     const size_t bytes_hdr = (sizeof(GridHdr) * b + 255) / 256 * 256;
     const size_t bytes_cs = (sizeof(int) * (size_t)b * stride_cells + 255) / 256 * 256;
-    const size_t bytes_idx = (sizeof(int) * (size_t)b * m + 255) / 256 * 256;
-    const size_t bytes_xyz = sizeof(float) * (size_t)b * m * 3;
-    char *ws = nullptr;
-    if (hipMallocAsync((void **)&ws, bytes_hdr + bytes_cs + bytes_idx + bytes_xyz, s) != hipSuccess || !ws) {
-        (void)hipGetLastError();
-        return OGC_ERR_UNSUPPORTED;
-    }
+    const size_t bytes_pts = sizeof(float4) * (size_t)b * m;
+    char *ws = static_cast<char *>(ogc_workspace(s, bytes_hdr + bytes_cs + bytes_pts));
+    if (!ws) return OGC_ERR_UNSUPPORTED;
     GridHdr *hdrs = reinterpret_cast<GridHdr *>(ws);
     int *cell_start = reinterpret_cast<int *>(ws + bytes_hdr);
-    int *sorted_idx = reinterpret_cast<int *>(ws + bytes_hdr + bytes_cs);
-    float *sorted_xyz = reinterpret_cast<float *>(ws + bytes_hdr + bytes_cs + bytes_idx);
+    float4 *sorted_pts = reinterpret_cast<float4 *>(ws + bytes_hdr + bytes_cs);
     hipLaunchKernelGGL(grid_build_kernel, dim3(b), dim3(BUILD_THREADS), 0, s, m, 0.0f, k, stride_cells, known, hdrs,
-                       cell_start, sorted_idx, sorted_xyz);
+                       cell_start, sorted_pts);
     dim3 grid(ogc_divup(n, QPW), b);
     if (mode == 1)
         hipLaunchKernelGGL(knn_grid_kernel<1>, grid, dim3(OGC_WAVE), lds, s, n, m, k, radius, stride_cells, unknown, hdrs,
-                           cell_start, sorted_idx, sorted_xyz, dist, idx);
+                           cell_start, sorted_pts, dist, idx);
     else
         hipLaunchKernelGGL(knn_grid_kernel<0>, grid, dim3(OGC_WAVE), lds, s, n, m, k, radius, stride_cells, unknown, hdrs,
-                           cell_start, sorted_idx, sorted_xyz, dist, idx);
+                           cell_start, sorted_pts, dist, idx);
     const hipError_t e = hipGetLastError();
-    (void)hipFreeAsync(ws, s);
     if (e != hipSuccess) {
         ogc_set_error("ogc_knn (grid): launch failed: %s", hipGetErrorString(e));
         return OGC_ERR_LAUNCH;

@@ -9,6 +9,8 @@
 
 // ---- error plumbing (no exit(): SURVEY.md §5 "failure detection") -------------------------
 void ogc_set_error(const char *fmt, ...);
+// persistent stream-ordered scratch buffer of at least `bytes` for work queued on `stream` (api.hip); nullptr on failure
+void *ogc_workspace(hipStream_t stream, size_t bytes);
 
 #define OGC_REQUIRE(cond, ...)            \
     do {                                  \

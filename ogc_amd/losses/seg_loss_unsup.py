@@ -424,10 +424,24 @@ class UnsupervisedOGCLoss(nn.Module):
             terms['invariance'] = l_invariance
             loss = loss + weight(self.w_invariance, self.start_step_invariance) * l_invariance
 
-        with torch.no_grad():  # monitoring only (:394-405)
-            terms['entropy'] = total([self.entropy_loss(m) for m in masks])
-            terms['rank'] = total([self.rank_loss(m) for m in masks])
         terms['sum'] = loss
 
-        pending = PendingLossDict(terms)
+        def monitors():
+            with torch.no_grad():  # monitoring only (:394-405)
+                terms['entropy'] = total([self.entropy_loss(m) for m in masks])
+                terms['rank'] = total([self.rank_loss(m) for m in masks])
+            return PendingLossDict(terms)
+
+        if loss.is_cuda and not sync:
+            # the monitored values feed nothing downstream: compute and ship them on a side stream so that the
+            # backward pass does not queue behind ~80 small launches
+            from ..utils.streams import side_stream
+            side = side_stream(loss.device, "monitor")
+            side.wait_stream(torch.cuda.current_stream())
+            for t in list(masks) + list(terms.values()):
+                t.record_stream(side)
+            with torch.cuda.stream(side):
+                pending = monitors()
+        else:
+            pending = monitors()
         return loss, (pending.resolve() if sync else pending)

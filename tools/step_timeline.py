@@ -18,31 +18,35 @@ pcs, segms, flows, _ = batch
 b, t, n = segms.size()
 
 
+from ogc_amd.train_step import PrefetchedGeometry, make_optimizer
+opt = make_optimizer(net.parameters(), lr=1e-3)
+state = {"pre": None}
+
+
 def step(record=None):
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
     cpu = [time.perf_counter()]
     net.train(); opt.zero_grad(set_to_none=True)
-    flat = pcs.view(b * t, n, -1).contiguous()
-    pcs_l = [pcs[:, i].contiguous() for i in range(t)]
-    flows_l = [flows[:, i].contiguous() for i in range(t)]
+    pre = state["pre"] or PrefetchedGeometry(net, crit, batch, True)
     ev[0].record()
-    geo = launch_on_side(side_stream(pcs.device, "loss-geometry"), lambda: crit.plan_geometry(pcs_l, True))
-    masks = net(flat, flat).view(b, t, n, -1)
+    masks = net(pre.flat, pre.flat, geometry=pre.model).view(b, t, n, -1)
     ev[1].record(); cpu.append(time.perf_counter())
     masks_l = [masks[:, i].contiguous() for i in range(t)]
-    loss, ld = crit(pcs_l, masks_l, flows_l, step_w=True, it=4000, aug_transform=True, geometry=geo)
+    state["pre"] = PrefetchedGeometry(net, crit, batch, True)
+    loss, ld = crit(pre.pcs_l, masks_l, pre.flows_l, step_w=True, it=4000, aug_transform=True, geometry=pre.loss, sync=False)
     ev[2].record(); cpu.append(time.perf_counter())
     loss.backward()
     ev[3].record(); cpu.append(time.perf_counter())
     grads = [p.grad for p in net.parameters() if p.grad is not None]
-    bad = bool(torch.isnan(torch.stack(torch._foreach_norm(grads)).sum()))
+    bad = torch.isnan(torch.stack(torch._foreach_norm(grads)).sum())
+    opt.grad_scale = None; opt.found_inf = bad.float().reshape(())
     ev[4].record(); cpu.append(time.perf_counter())
     opt.step()
+    del opt.grad_scale, opt.found_inf
     ev[5].record(); cpu.append(time.perf_counter())
-    torch.cuda.synchronize()
     cpu.append(time.perf_counter())
     if record is not None:
-        record.append(([ev[i].elapsed_time(ev[i + 1]) for i in range(5)], [1e3 * (cpu[i + 1] - cpu[i]) for i in range(6)]))
+        record.append((ev, [1e3 * (cpu[i + 1] - cpu[i]) for i in range(6)]))
 
 
 for _ in range(3):
@@ -51,7 +55,10 @@ rec = []
 for _ in range(5):
     step(rec)
 names = ["forward", "loss", "backward", "nan-check", "optimizer", "final-sync"]
-g = [sum(r[0][i] for r in rec) / len(rec) for i in range(5)]
+torch.cuda.synchronize()
+g = [sum(r[0][i].elapsed_time(r[0][i + 1]) for r in rec) / len(rec) for i in range(5)]
+gap = sum(rec[j][0][5].elapsed_time(rec[j + 1][0][0]) for j in range(len(rec) - 1)) / (len(rec) - 1)
+print("between steps (opt end -> next forward start): %.2f ms" % gap)
 c = [sum(r[1][i] for r in rec) / len(rec) for i in range(6)]
 print("phase        gpu_ms(event)  cpu_ms(issue)")
 for i, nme in enumerate(names):
