@@ -28,10 +28,11 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak (MI355X_MICROARCH.md)
 # HBM traffic of one ogc_ball_query call measured offline with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate
-# passes, profiles/r01_ball_query_pmc.txt): key = (B, N, M, nsample) -> bytes summed over the three kernels of the
-# operator.  FETCH_SIZE is taken as reported (the gfx950 x2 correction of MI355X_MICROARCH.md applies to wide
-# coalesced streams; these kernels issue 4-12 byte gathers); WRITE_SIZE equals the output size exactly.
-PMC_TRAFFIC_BYTES = {(16, 8192, 8192, 64): int((8864.2 + 838 + 25 + 32768 + 2391.5) * 1024)}
+# passes, tools/pmc_op.sh -> profiles/r01_ball_query_pmc_v2.txt): key = (B, N, M, nsample) -> bytes summed over the two
+# kernels of the operator (grid_build_kernel + ball_query_grid_kernel; KiB as reported).  FETCH_SIZE is taken as
+# reported (the gfx950 x2 correction of MI355X_MICROARCH.md applies to wide coalesced streams; these kernels issue
+# 12-16 byte gathers); WRITE_SIZE of the query kernel equals the output size exactly.
+PMC_TRAFFIC_BYTES = {(16, 8192, 8192, 64): int((8653.8 + 855.6 + 32768 + 2199.5) * 1024)}
 FP32_VALU_PEAK_TF = 157.3  # fp32 vector peak
 
 
@@ -132,6 +133,22 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
+    isolated_ms = None
+    if rank == 0:
+        # the same ball-query call on an otherwise idle GPU (in the step it shares the chip with the dense kernels)
+        from ogc_amd.pointnet2.pointnet2 import ball_query
+        pc = torch.cat([batch[0][:, v] for v in range(4)]).contiguous()
+        bl = KITTI_LOSS["smooth_loss_params"]["ball_q_loss_params"]
+        for _ in range(3):
+            ball_query(bl["radius"], bl["k"], pc, pc)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(20):
+            ball_query(bl["radius"], bl["k"], pc, pc)
+        e1.record()
+        torch.cuda.synchronize()
+        isolated_ms = e0.elapsed_time(e1) / 20
     if rank == 0:
         durs = timer.durations_ms()
         bq = durs.get("ogc_ball_query", [])
@@ -141,16 +158,20 @@ def main():
             b_, n_, m_, _r, ns_ = bq[0][1][:5]
             alg = b_ * (12 * m_ + 12 * n_ + 4 * m_ * ns_)            # 12M + 12N + 4M*nsample per cloud
             gbs = alg / (ms * 1e-3) / 1e9
-            roof = {"kernel": "ogc_ball_query (grid_build_kernel + ball_query_grid_kernel + gated ball_query_kernel)",
+            roof = {"kernel": "ogc_ball_query (grid_build_kernel + ball_query_grid_kernel)",
                     "bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(gbs / HBM_PEAK_GBS, 5),
                     "traffic": PMC_TRAFFIC_BYTES.get((b_, n_, m_, ns_)),
                     "launches": len(bq), "avg_ms": round(ms, 4), "algorithmic_bytes": alg,
+                    "isolated": {"avg_ms": round(isolated_ms, 4), "achieved": round(alg / (isolated_ms * 1e-3) / 1e9, 2),
+                                 "frac": round(alg / (isolated_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                                 "note": "same call, 20 back-to-back launches on an idle GPU after the timed region"},
                     "shape": {"B": b_, "N": n_, "M": m_, "nsample": ns_},
                     "note": "algorithmic bytes = B*(12M + 12N + 4M*nsample) (SURVEY 8d) / mean duration of the whole "
                             "operator call (HIP events on the launch stream, inside the timed steps); the exact "
-                            "cell-list search tests ~N/90 candidates per centre, so the all-pairs figure of 8*B*N*M "
-                            "flop no longer describes the work done",
+                            "cell-list search tests ~N/60 candidates per centre, so the all-pairs figure of 8*B*N*M "
+                            "flop no longer describes the work done; in the step the operator runs on a side stream "
+                            "underneath the dense kernels, which lengthens it versus an idle GPU (tools/bench_ops.py)",
                     "all_pairs_equivalent_tpairs_per_s": round(b_ * n_ * m_ / (ms * 1e-3) / 1e12, 2)}
         others = {}
         for name in ("ogc_knn_clamped", "ogc_furthest_point_sampling"):
