@@ -138,6 +138,20 @@ int ogc_knn_clamped(int b, int n, int m, int k, float radius, const float *unkno
  * One thread per matrix, Jacobi eigen-solve of S^T S in fp64. */
 int ogc_kabsch_rotation(int nb, const float *S, float *R, int *valid, ogc_stream_t stream);
 
+/* Grouping with relative coordinates in front, in one output tensor.  Replaces, in QueryAndGroup.forward
+ *   pointnet2/pointnet2.py:284-296:  grouped_xyz = group(xyz^T, idx) - new_xyz^T[..., None];
+ *                                    new_features = cat([grouped_xyz, group(features, idx)], dim=1)
+ * (two gathers, a broadcast subtraction and a concatenation copy of the largest activation of the level).
+ * xyz (b,n,3), new_xyz (b,npoints,3), points (b,c,n) (NULL iff c == 0), idx (b,npoints,nsample) i32,
+ * out (b,3+c,npoints,nsample): channels 0..2 = xyz[idx] - new_xyz, channels 3.. = points[idx]. */
+int ogc_group_concat(int b, int c, int n, int npoints, int nsample, const float *xyz, const float *new_xyz,
+                     const float *points, const int *idx, float *out, ogc_stream_t stream);
+
+/* Gradient of ogc_group_concat w.r.t. points: scatter-add of channels 3.. of grad_out (b,3+c,npoints,nsample) into
+ * grad_points (b,c,n), which the caller zero-fills (as for ogc_group_points_grad). */
+int ogc_group_concat_grad(int b, int c, int n, int npoints, int nsample, const float *grad_out, const int *idx,
+                          float *grad_points, ogc_stream_t stream);
+
 /* Linear sum assignment (maximise), batched, on the device.  Replaces the host round trip of the invariance loss
  *   losses/seg_loss_unsup.py:234-239:  scipy.optimize.linear_sum_assignment(iou[b], maximize=True)[1] per sample.
  * score (np,k,k) f32 row-major (rows = slots of mask1), col4row (np,k) i32 out: column assigned to each row.

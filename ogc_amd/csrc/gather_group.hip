@@ -20,6 +20,7 @@ constexpr int GG_THREADS = 256;
 // out[b,c,t] = points[b,c,idx[b,t]],  t in [0, T)   (T = npoints*nsample)
 template <bool VEC4>
 __global__ __launch_bounds__(GG_THREADS) void group_fwd_kernel(int c, int n, int T, int ch_per_block,
+                                                               long long out_bstride,
                                                                const float *__restrict__ points,
                                                                const int *__restrict__ idx,
                                                                float *__restrict__ out) {
@@ -28,7 +29,7 @@ __global__ __launch_bounds__(GG_THREADS) void group_fwd_kernel(int c, int n, int
     const int c1 = min(c, c0 + ch_per_block);
     const int *id = idx + (size_t)b * T;
     const float *p = points + ((size_t)b * c + c0) * n;
-    float *o = out + ((size_t)b * c + c0) * T;
+    float *o = out + (size_t)b * out_bstride + (size_t)c0 * T; // out_bstride = c*T for a dense (b,c,T) output
     if (VEC4) {
         const int t4 = (blockIdx.x * GG_THREADS + threadIdx.x) * 4;
         if (t4 >= T) return;
@@ -49,6 +50,7 @@ __global__ __launch_bounds__(GG_THREADS) void group_fwd_kernel(int c, int n, int
 // grad_points[b,c,idx[b,t]] += grad_out[b,c,t]
 template <bool VEC4>
 __global__ __launch_bounds__(GG_THREADS) void group_bwd_kernel(int c, int n, int T, int ch_per_block,
+                                                               long long go_bstride,
                                                                const float *__restrict__ grad_out,
                                                                const int *__restrict__ idx,
                                                                float *__restrict__ grad_points) {
@@ -56,7 +58,7 @@ __global__ __launch_bounds__(GG_THREADS) void group_bwd_kernel(int c, int n, int
     const int c0 = blockIdx.y * ch_per_block;
     const int c1 = min(c, c0 + ch_per_block);
     const int *id = idx + (size_t)b * T;
-    const float *g = grad_out + ((size_t)b * c + c0) * T;
+    const float *g = grad_out + (size_t)b * go_bstride + (size_t)c0 * T;
     float *gp = grad_points + ((size_t)b * c + c0) * n;
     if (VEC4) {
         const int t4 = (blockIdx.x * GG_THREADS + threadIdx.x) * 4;
@@ -83,6 +85,7 @@ __global__ __launch_bounds__(GG_THREADS) void group_bwd_kernel(int c, int n, int
 // into grad_points with one global atomic each.
 template <int CC>
 __global__ __launch_bounds__(GG_THREADS) void group_bwd_lds_kernel(int c, int n, int T, int t_per_block,
+                                                                   long long go_bstride,
                                                                    const float *__restrict__ grad_out,
                                                                    const int *__restrict__ idx,
                                                                    float *__restrict__ grad_points) {
@@ -95,7 +98,7 @@ __global__ __launch_bounds__(GG_THREADS) void group_bwd_lds_kernel(int c, int n,
     for (int i = threadIdx.x; i < CC * n; i += GG_THREADS) gb_acc[i] = 0.0f;
     __syncthreads();
     const int *id = idx + (size_t)b * T;
-    const float *g = grad_out + ((size_t)b * c + c0) * T;
+    const float *g = grad_out + (size_t)b * go_bstride + (size_t)c0 * T;
     // A thread owns 16 consecutive positions (64 contiguous bytes per channel) and merges runs of equal indices
     // before touching LDS: neighbour rows end in long runs of the SAME index (kNN rows clamped to the nearest
     // neighbour beyond the radius, ball-query rows padded with the first hit), which would otherwise serialise as
@@ -139,6 +142,27 @@ __global__ __launch_bounds__(GG_THREADS) void group_bwd_lds_kernel(int c, int n,
     }
 }
 
+// out[b, ch, p*nsample + s] = xyz[b, idx[b,p,s], ch] - new_xyz[b, p, ch],  ch in 0..2 — the relative coordinates that
+// QueryAndGroup puts in front of the grouped features (pointnet2.py:286-288: group, then subtract the centre)
+__global__ __launch_bounds__(GG_THREADS) void group_xyz_rel_kernel(int n, int npoints, int nsample,
+                                                                   long long out_bstride,
+                                                                   const float *__restrict__ xyz,
+                                                                   const float *__restrict__ new_xyz,
+                                                                   const int *__restrict__ idx,
+                                                                   float *__restrict__ out) {
+    const int b = blockIdx.y;
+    const int T = npoints * nsample;
+    const int t = blockIdx.x * GG_THREADS + threadIdx.x;
+    if (t >= T) return;
+    const int i = idx[(size_t)b * T + t];
+    const float *p = xyz + ((size_t)b * n + i) * 3;
+    const float *q = new_xyz + ((size_t)b * npoints + t / nsample) * 3;
+    float *o = out + (size_t)b * out_bstride + t;
+    o[0] = __fsub_rn(p[0], q[0]);
+    o[T] = __fsub_rn(p[1], q[1]);
+    o[2 * (size_t)T] = __fsub_rn(p[2], q[2]);
+}
+
 int pick_ch_per_block(int b, int c, int blocks_x) {
     // aim for >= ~2048 workgroups (8 per CU) before giving each workgroup more channels
     int cpb = 1;
@@ -149,34 +173,36 @@ int pick_ch_per_block(int b, int c, int blocks_x) {
 bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 
 int group_fwd(const char *name, int b, int c, int n, int T, const float *points, const int *idx,
-              float *out, ogc_stream_t stream) {
+              float *out, ogc_stream_t stream, long long out_bstride = -1) {
+    if (out_bstride < 0) out_bstride = (long long)c * T;
     OGC_REQUIRE(b >= 0 && c >= 0 && n >= 0 && T >= 0, "%s: negative dimension", name);
     if (b == 0 || c == 0 || T == 0) return OGC_OK;
     OGC_REQUIRE(points && idx && out, "%s: null pointer", name);
-    OGC_REQUIRE((long long)b * c * T < (1ll << 31) && (long long)b * c * n < (1ll << 31),
+    OGC_REQUIRE((long long)b * out_bstride < (1ll << 31) && (long long)b * c * n < (1ll << 31),
                 "%s: tensor exceeds 32-bit indexing (group_points_gpu.cu:63)", name);
-    const bool vec = (T % 4 == 0) && aligned16(idx) && aligned16(out);
+    const bool vec = (T % 4 == 0) && aligned16(idx) && aligned16(out) && out_bstride % 4 == 0;
     const int bx = ogc_divup(T, vec ? GG_THREADS * 4 : GG_THREADS);
     const int cpb = pick_ch_per_block(b, c, bx);
     dim3 grid(bx, ogc_divup(c, cpb), b);
     if (vec)
         hipLaunchKernelGGL(group_fwd_kernel<true>, grid, dim3(GG_THREADS), 0, (hipStream_t)stream, c, n, T,
-                           cpb, points, idx, out);
+                           cpb, out_bstride, points, idx, out);
     else
         hipLaunchKernelGGL(group_fwd_kernel<false>, grid, dim3(GG_THREADS), 0, (hipStream_t)stream, c, n, T,
-                           cpb, points, idx, out);
+                           cpb, out_bstride, points, idx, out);
     OGC_CHECK_LAUNCH(name);
     return OGC_OK;
 }
 
 int group_bwd(const char *name, int b, int c, int n, int T, const float *grad_out, const int *idx,
-              float *grad_points, ogc_stream_t stream) {
+              float *grad_points, ogc_stream_t stream, long long go_bstride = -1) {
+    if (go_bstride < 0) go_bstride = (long long)c * T;
     OGC_REQUIRE(b >= 0 && c >= 0 && n >= 0 && T >= 0, "%s: negative dimension", name);
     if (b == 0 || c == 0 || T == 0) return OGC_OK;
     OGC_REQUIRE(grad_out && idx && grad_points, "%s: null pointer", name);
-    OGC_REQUIRE((long long)b * c * T < (1ll << 31) && (long long)b * c * n < (1ll << 31),
+    OGC_REQUIRE((long long)b * go_bstride < (1ll << 31) && (long long)b * c * n < (1ll << 31),
                 "%s: tensor exceeds 32-bit indexing", name);
-    const bool vec = (T % 4 == 0) && aligned16(idx) && aligned16(grad_out);
+    const bool vec = (T % 4 == 0) && aligned16(idx) && aligned16(grad_out) && go_bstride % 4 == 0;
     // LDS-privatised path: the per-channel image (n floats) must fit a 64 KiB budget at least once
     if (vec && n <= 16384 && T >= 4096 && T % 16 == 0) {
         int cc = 16384 / n; // channels per workgroup within 64 KiB
@@ -192,7 +218,7 @@ int group_bwd(const char *name, int b, int c, int n, int T, const float *grad_ou
         const size_t lds = (size_t)cc * n * sizeof(float);
 #define GB_LAUNCH(CCV)                                                                                    \
     hipLaunchKernelGGL(group_bwd_lds_kernel<CCV>, grid, dim3(GG_THREADS), lds, (hipStream_t)stream, c, n, T, \
-                       tpb, grad_out, idx, grad_points)
+                       tpb, go_bstride, grad_out, idx, grad_points)
         if (cc == 8) GB_LAUNCH(8);
         else if (cc == 4) GB_LAUNCH(4);
         else if (cc == 2) GB_LAUNCH(2);
@@ -206,10 +232,10 @@ int group_bwd(const char *name, int b, int c, int n, int T, const float *grad_ou
     dim3 grid(bx, ogc_divup(c, cpb), b);
     if (vec)
         hipLaunchKernelGGL(group_bwd_kernel<true>, grid, dim3(GG_THREADS), 0, (hipStream_t)stream, c, n, T,
-                           cpb, grad_out, idx, grad_points);
+                           cpb, go_bstride, grad_out, idx, grad_points);
     else
         hipLaunchKernelGGL(group_bwd_kernel<false>, grid, dim3(GG_THREADS), 0, (hipStream_t)stream, c, n, T,
-                           cpb, grad_out, idx, grad_points);
+                           cpb, go_bstride, grad_out, idx, grad_points);
     OGC_CHECK_LAUNCH(name);
     return OGC_OK;
 }
@@ -238,4 +264,33 @@ extern "C" int ogc_group_points_grad(int b, int c, int n, int npoints, int nsamp
     OGC_REQUIRE(npoints >= 0 && nsample >= 0 && (long long)npoints * nsample < (1ll << 31),
                 "ogc_group_points_grad: bad npoints/nsample");
     return group_bwd("ogc_group_points_grad", b, c, n, npoints * nsample, grad_out, idx, grad_points, stream);
+}
+
+extern "C" int ogc_group_concat(int b, int c, int n, int npoints, int nsample, const float *xyz, const float *new_xyz,
+                                const float *points, const int *idx, float *out, ogc_stream_t stream) {
+    OGC_REQUIRE(b >= 0 && c >= 0 && n >= 0 && npoints >= 0 && nsample >= 0 &&
+                    (long long)npoints * nsample < (1ll << 31),
+                "ogc_group_concat: bad dimensions");
+    const int T = npoints * nsample;
+    if (b == 0 || T == 0) return OGC_OK;
+    OGC_REQUIRE(xyz && new_xyz && idx && out && (points || c == 0), "ogc_group_concat: null pointer");
+    const long long bstride = (long long)(3 + c) * T;
+    OGC_REQUIRE((long long)b * bstride < (1ll << 31), "ogc_group_concat: tensor exceeds 32-bit indexing");
+    hipLaunchKernelGGL(group_xyz_rel_kernel, dim3(ogc_divup(T, GG_THREADS), b), dim3(GG_THREADS), 0,
+                       (hipStream_t)stream, n, npoints, nsample, bstride, xyz, new_xyz, idx, out);
+    OGC_CHECK_LAUNCH("ogc_group_concat");
+    if (c == 0) return OGC_OK;
+    return group_fwd("ogc_group_concat", b, c, n, T, points, idx, out + 3 * (size_t)T, stream, bstride);
+}
+
+extern "C" int ogc_group_concat_grad(int b, int c, int n, int npoints, int nsample, const float *grad_out,
+                                     const int *idx, float *grad_points, ogc_stream_t stream) {
+    OGC_REQUIRE(b >= 0 && c >= 0 && n >= 0 && npoints >= 0 && nsample >= 0 &&
+                    (long long)npoints * nsample < (1ll << 31),
+                "ogc_group_concat_grad: bad dimensions");
+    const int T = npoints * nsample;
+    if (b == 0 || c == 0 || T == 0) return OGC_OK;
+    OGC_REQUIRE(grad_out, "ogc_group_concat_grad: null pointer");
+    return group_bwd("ogc_group_concat_grad", b, c, n, T, grad_out + 3 * (size_t)T, idx, grad_points, stream,
+                     (long long)(3 + c) * T);
 }

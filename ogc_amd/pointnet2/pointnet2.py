@@ -201,6 +201,30 @@ class GroupingOperation(Function):
 grouping_operation = GroupingOperation.apply
 
 
+class GroupConcat(Function):
+    """cat([group(xyz^T, idx) - new_xyz^T[..., None], group(features, idx)], dim=1) written once (ogc_group_concat);
+    the op sequence of QueryAndGroup.forward (reference pointnet2.py:284-296).  Coordinates carry no gradient."""
+
+    @staticmethod
+    def forward(ctx, xyz, new_xyz, features, idx):
+        B, N, _ = xyz.size()
+        _, npoint, nsample = idx.size()
+        C = features.size(1)
+        out = _new(features, (B, 3 + C, npoint, nsample), torch.float32)
+        _native.group_concat_wrapper(B, C, N, npoint, nsample, xyz.contiguous(), new_xyz.contiguous(),
+                                     features.contiguous(), idx, out)
+        ctx.for_backwards = (idx, N, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        idx, N, C = ctx.for_backwards
+        B, _, npoint, nsample = grad_out.size()
+        grad_features = _new(grad_out, (B, C, N), torch.float32, fill=0.0)
+        _native.group_concat_grad_wrapper(B, C, N, npoint, nsample, grad_out.contiguous(), idx, grad_features)
+        return None, None, grad_features, None
+
+
 class BallQuery(Function):
     """Reference: pointnet2.py:233-260 -> ball_query_wrapper (note the (B, N, npoint) arg order)."""
 
@@ -252,17 +276,25 @@ class QueryAndGroup(nn.Module):
         super().__init__()
         self.radius, self.nsample, self.use_xyz = radius, nsample, use_xyz
 
-    def forward(self, xyz: torch.Tensor, new_xyz: torch.Tensor, features: torch.Tensor = None, neighbours=None):
+    def forward(self, xyz: torch.Tensor, new_xyz: torch.Tensor, features: torch.Tensor = None, neighbours=None,
+                idx=None):
         # xyz (B, N, 3), new_xyz (B, npoint, 3), features (B, C, N)
         # -> new_features (B, 3 + C, npoint, nsample), grouped_xyz (B, 3, npoint, nsample)
         # `neighbours` (optional, not in the reference): an un-clamped (dist, idx) = knn(nsample, new_xyz, xyz) shared
         # by several groupers of a multi-scale level, which differ only in the radius of the clamp.
-        if neighbours is None:
+        # `idx` (optional, not in the reference): the clamped neighbour indices themselves, from a geometry plan.
+        if idx is not None:
+            pass
+        elif neighbours is None:
             _, idx = knn_radius_clamp(self.nsample, self.radius, new_xyz, xyz)
         else:
             dist, idx = neighbours
             if self.radius is not None:
                 idx = torch.where(dist > self.radius, idx[:, :, :1], idx)
+        if (features is not None and self.use_xyz and getattr(_native, "group_concat_wrapper", None) is not None
+                and not xyz.requires_grad and not new_xyz.requires_grad):
+            new_features = GroupConcat.apply(xyz, new_xyz, features, idx.int().contiguous())
+            return new_features, new_features[:, :3]
         xyz_trans = xyz.transpose(1, 2).contiguous()
         grouped_xyz = grouping_operation(xyz_trans, idx) - new_xyz.transpose(1, 2).unsqueeze(-1)
 

@@ -151,6 +151,18 @@ def kabsch_rotation_wrapper(nb, S, R, valid=None):
     _run("ogc_kabsch_rotation", S, nb, _f(S, "S"), _f(R, "R"), 0 if valid is None else _i(valid, "valid"))
 
 
+def group_concat_wrapper(b, c, n, npoints, nsample, xyz, new_xyz, points, idx, out):
+    """out = cat([xyz[idx] - new_xyz, points[idx]], dim=1) (ogc_group_concat); points may be None when c == 0."""
+    _run("ogc_group_concat", xyz, b, c, n, npoints, nsample, _f(xyz, "xyz"), _f(new_xyz, "new_xyz"),
+         0 if points is None else _f(points, "points"), _i(idx, "idx"), _f(out, "out"))
+
+
+def group_concat_grad_wrapper(b, c, n, npoints, nsample, grad_out, idx, grad_points):
+    """grad_points += scatter of channels 3.. of grad_out (ogc_group_concat_grad)."""
+    _run("ogc_group_concat_grad", grad_out, b, c, n, npoints, nsample, _f(grad_out, "grad_out"), _i(idx, "idx"),
+         _f(grad_points, "grad_points"))
+
+
 def lsap_maximize_wrapper(np_, k, score, col4row):
     """Batched maximising linear-sum assignment with scipy's tie-breaking (ogc_lsap_maximize)."""
     _run("ogc_lsap_maximize", score, np_, k, _f(score, "score"), _i(col4row, "col4row"))

@@ -27,11 +27,18 @@ class _PointnetSAModuleBase(nn.Module):
             return None
         new_inds = furthest_point_sample(xyz, self.npoint).long()
         new_xyz = gather_nd(xyz, new_inds)  # == gather on the transposed cloud, transposed back (:22-27)
-        knn = {}
+        knn, idx = {}, []
         for grouper in self.groupers:
-            if isinstance(grouper, QueryAndGroup) and grouper.nsample not in knn:
+            if not isinstance(grouper, QueryAndGroup):
+                idx.append(None)
+                continue
+            if grouper.nsample not in knn:
                 knn[grouper.nsample] = knn_radius_clamp(grouper.nsample, None, new_xyz, xyz)
-        return {"new_inds": new_inds, "new_xyz": new_xyz, "knn": knn}
+            dist, nn_idx = knn[grouper.nsample]
+            if grouper.radius is not None:  # the clamp of pointnet2.py:283-286, per scale
+                nn_idx = torch.where(dist > grouper.radius, nn_idx[:, :, :1], nn_idx)
+            idx.append(nn_idx.contiguous())
+        return {"new_inds": new_inds, "new_xyz": new_xyz, "idx": idx}
 
     def forward(self, xyz, features=None, return_inds=False, geometry=None):
         # xyz (B, N, 3), features (B, C, N) -> new_xyz (B, npoint, 3), new_features (B, sum(mlp[-1]), npoint)
@@ -45,9 +52,9 @@ class _PointnetSAModuleBase(nn.Module):
         new_inds = geometry["new_inds"] if geometry is not None else None
 
         pooled = []
-        for grouper, mlp in zip(self.groupers, self.mlps):
+        for i, (grouper, mlp) in enumerate(zip(self.groupers, self.mlps)):
             if isinstance(grouper, QueryAndGroup):
-                grouped = grouper(xyz, new_xyz, features, neighbours=geometry["knn"][grouper.nsample])[0]
+                grouped = grouper(xyz, new_xyz, features, idx=geometry["idx"][i])[0]
             else:
                 grouped = grouper(xyz, new_xyz, features)[0]  # (B, C', npoint, nsample)
             pooled.append(mlp.forward_maxpool(grouped))       # shared MLP, then max over nsample (:38-42)

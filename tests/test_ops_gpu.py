@@ -564,3 +564,27 @@ def test_conv1x1_gemm_forward_and_dgrad(nat, B, cin, cout, hw):
         ref = torch.einsum("oi,bop->bip", w.double(), dy.double())
         scale = torch.einsum("oi,bop->bip", w.double().abs(), dy.double().abs())
         assert ((dx.double() - ref).abs() / scale).max().item() < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 5, 300, 40, 8), (3, 32, 1024, 256, 16), (1, 1, 64, 7, 3), (2, 99, 512, 128, 64)])
+def test_group_concat_matches_op_sequence(shape):
+    """ogc_group_concat / _grad against QueryAndGroup's reference op sequence (pointnet2.py:284-296), bit-exact."""
+    import ogc_amd.pointnet2.pointnet2 as api
+    B, C, N, P, S = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    xyz = torch.rand(B, N, 3, generator=g).cuda()
+    new_xyz = xyz[:, :P].contiguous()
+    feats = torch.randn(B, C, N, generator=g).cuda().requires_grad_(True)
+    idx = torch.randint(0, N, (B, P, S), generator=g, dtype=torch.int32).cuda()
+    idx[:, :, -1] = idx[:, :, 0]
+    fused = api.GroupConcat.apply(xyz, new_xyz, feats, idx)
+    w = torch.randn(fused.shape, generator=torch.Generator().manual_seed(1)).cuda()
+    (fused * w).sum().backward()
+    g_fused = feats.grad.clone()
+    feats.grad = None
+    grouped_xyz = api.grouping_operation(xyz.transpose(1, 2).contiguous(), idx) - new_xyz.transpose(1, 2).unsqueeze(-1)
+    ref = torch.cat([grouped_xyz, api.grouping_operation(feats, idx)], dim=1)
+    (ref * w).sum().backward()
+    assert torch.equal(fused, ref)
+    torch.testing.assert_close(g_fused, feats.grad, rtol=1e-5, atol=1e-5)  # scatter-add order differs
