@@ -233,6 +233,24 @@ int ogc_conv1x1_wgrad(int b, int cin, int cout, int hw, const float *x, const fl
 int ogc_conv1x1_gemm(int b, int M, int K, int hw, int transpose_a, const float *w, const float *in,
                      float *out, ogc_stream_t stream);
 
+/* The forward convolution above, also producing the first pass of the GroupNorm that follows every Conv2d of a
+ * SharedMLP (utils/nn_util.py:45-85): per (batch, group) the sum and the sum of squares of the outputs, fp64.
+ * stats: ogc_conv1x1_gn_slots() copies of a (b, groups, 2) f64 accumulator, slot-major (the copies spread the atomics
+ * over cache lines; their sum is the statistic) — overwritten.  Pass it to ogc_group_norm_fwd_stats /
+ * ogc_group_norm_maxpool_fwd_stats, which then skip their own statistics pass over the tensor.
+ * Requires, beyond ogc_conv1x1_gemm: groups <= 32 and (M / groups) % 4 == 0 (OGC_ERR_UNSUPPORTED otherwise). */
+int ogc_conv1x1_gn_slots(void);
+int ogc_conv1x1_gemm_gnstats(int b, int M, int K, int hw, int groups, const float *w, const float *in, float *out,
+                             double *stats, ogc_stream_t stream);
+
+/* ogc_group_norm_fwd / ogc_group_norm_maxpool_fwd with the statistics supplied (`slots` copies, see above). */
+int ogc_group_norm_fwd_stats(int b, int c, int hw, int groups, float eps, int relu, const float *x,
+                             const float *gamma, const float *beta, float *y, float *mean, float *rstd,
+                             const double *stats, int slots, ogc_stream_t stream);
+int ogc_group_norm_maxpool_fwd_stats(int b, int c, int p, int s, int groups, float eps, int relu, const float *x,
+                                     const float *gamma, const float *beta, float *out, int *argmax, float *mean,
+                                     float *rstd, const double *stats, int slots, ogc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

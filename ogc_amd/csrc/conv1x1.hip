@@ -129,13 +129,21 @@ namespace {
 // once); A is staged through LDS in [k/4][m][4] order (conflict-free ds_read_b32 of the A operand) one 64-row tile at
 // a time and shared by the four waves of the workgroup.
 constexpr int FW_KQ_MAX = 40; // K <= 160 channels held in registers (40 float4 per lane)
+constexpr int GN_SLOTS = 16;  // spread of the fused GroupNorm statistics over cache lines (see ogc_conv1x1_gemm_gnstats)
 
-template <bool TRANSPOSE_A>
-__global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_gemm_kernel(int M, int K, int hw,
+// KQ: compile-time bound on ceil(K / 4) — the IN tile costs KQ float4 registers per lane, so narrow layers get a small
+// register footprint and more wavefronts per SIMD.  STATS: also accumulate, per (batch, GroupNorm group), the sum and
+// the sum of squares of the outputs (the first pass of the GroupNorm that follows every one of these convolutions):
+// row sums are reduced over the 16 lanes of a DPP row, then over the workgroup in LDS (fp64), then one fp64 atomic
+// per (group, statistic) and workgroup into one of GN_SLOTS copies of the accumulator.
+template <bool TRANSPOSE_A, int KQ, bool STATS>
+__global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_gemm_kernel(int M, int K, int hw, int groups,
                                                                           const float *__restrict__ w, // (Cout, Cin)
                                                                           const float *__restrict__ in,
-                                                                          float *__restrict__ out) {
+                                                                          float *__restrict__ out,
+                                                                          double *__restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) float a_lds[]; // [Kq][64][4] for the current 64-row tile of A
+    __shared__ double s_stats[STATS ? 64 : 1];                    // [groups][2]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 15, kk = lane >> 4;
     const int b = blockIdx.y;
@@ -144,14 +152,16 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_gemm_kernel(int M,
     const bool live = p0 < hw; // hw is a multiple of 64 for every wave that is live
     const float *inb = in + (size_t)b * K * hw;
     float *outb = out + (size_t)b * M * hw;
+    if (STATS && threadIdx.x < 2 * groups) s_stats[threadIdx.x] = 0.0;
 
-    float4 xin[FW_KQ_MAX];
+    float4 xin[KQ];
 #pragma unroll
-    for (int q = 0; q < FW_KQ_MAX; ++q) {
+    for (int q = 0; q < KQ; ++q) {
         const int row = q * 4 + kk;
         xin[q] = (live && q < Kq && row < K) ? *reinterpret_cast<const float4 *>(inb + (size_t)row * hw + p0 + 4 * j)
                                              : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    const int cpg = STATS ? M / groups : 1; // channels per group, a multiple of 4 on this path
     for (int m0 = 0; m0 < M; m0 += 64) {
         __syncthreads(); // previous tile fully consumed
         // stage A[m0 .. m0+63][0 .. K) as a_lds[(q * 64 + mi) * 4 + kr] = A[m0 + mi][4q + kr]
@@ -163,23 +173,26 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_gemm_kernel(int M,
             a_lds[t] = v;
         }
         __syncthreads();
+        const int nblk = min(4, (M - m0 + 15) >> 4); // 16-row blocks of this tile that hold real rows (uniform)
         v4f acc[4][4];
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
             for (int c = 0; c < 4; ++c) acc[a][c] = (v4f){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int q = 0; q < FW_KQ_MAX; ++q) {
+        for (int q = 0; q < KQ; ++q) {
             if (q < Kq) {
                 float av[4];
 #pragma unroll
                 for (int a = 0; a < 4; ++a) av[a] = a_lds[(q * 64 + a * 16 + j) * 4 + kk]; // A[m0+16a+j][4q+kk]
 #pragma unroll
                 for (int a = 0; a < 4; ++a) {
-                    acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], xin[q].x, acc[a][0], 0, 0, 0);
-                    acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], xin[q].y, acc[a][1], 0, 0, 0);
-                    acc[a][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], xin[q].z, acc[a][2], 0, 0, 0);
-                    acc[a][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], xin[q].w, acc[a][3], 0, 0, 0);
+                    if (a < nblk) { // no MFMA work on padding rows (M = 32: half of the tile)
+                        acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], xin[q].x, acc[a][0], 0, 0, 0);
+                        acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], xin[q].y, acc[a][1], 0, 0, 0);
+                        acc[a][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], xin[q].z, acc[a][2], 0, 0, 0);
+                        acc[a][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], xin[q].w, acc[a][3], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -194,8 +207,76 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_gemm_kernel(int M,
                         *reinterpret_cast<float4 *>(outb + (size_t)m * hw + p0 + 4 * j) = o;
                     }
                 }
+            if (STATS) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    if (a < nblk) {
+                        // the lane's 4 rows (m .. m+3) x 4 positions; rows >= M are exact zeros
+                        float sm = 0.f, sq = 0.f;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                const float v = acc[a][c][r];
+                                sm += v;
+                                sq += v * v;
+                            }
+                        // sum over the 16 lanes of the DPP row (same rows, the other 60 positions)
+                        sm += ogc_dpp_f32<0xB1>(sm); sq += ogc_dpp_f32<0xB1>(sq);
+                        sm += ogc_dpp_f32<0x4E>(sm); sq += ogc_dpp_f32<0x4E>(sq);
+                        sm += ogc_dpp_f32<0x141>(sm); sq += ogc_dpp_f32<0x141>(sq);
+                        sm += ogc_dpp_f32<0x140>(sm); sq += ogc_dpp_f32<0x140>(sq);
+                        const int m = m0 + a * 16 + kk * 4;
+                        if (j == 0 && m < M) {
+                            const int g = m / cpg;
+                            atomicAdd(&s_stats[2 * g], (double)sm);
+                            atomicAdd(&s_stats[2 * g + 1], (double)sq);
+                        }
+                    }
+                }
+            }
         }
     }
+    if (STATS) {
+        __syncthreads();
+        if (threadIdx.x < 2 * groups) {
+            const int slot = blockIdx.x % GN_SLOTS;
+            double *dst = stats + ((size_t)slot * gridDim.y + b) * 2 * groups;
+            atomicAdd(dst + threadIdx.x, s_stats[threadIdx.x]);
+        }
+    }
+}
+
+template <bool T, bool STATS>
+int gemm_launch(int b, int M, int K, int hw, int groups, const float *w, const float *in, float *out, double *stats,
+                hipStream_t s) {
+    const int Kq = (K + 3) / 4;
+    const size_t lds = (size_t)Kq * 256 * sizeof(float);
+    dim3 grid(ogc_divup(hw, 64 * WG_WAVES), b);
+#define OGC_GEMM(KQV)                                                                                             \
+    hipLaunchKernelGGL((conv1x1_gemm_kernel<T, KQV, STATS>), grid, dim3(WG_WAVES * OGC_WAVE), lds, s, M, K, hw, groups, \
+                       w, in, out, stats)
+    if (Kq <= 2) OGC_GEMM(2);
+    else if (Kq <= 8) OGC_GEMM(8);
+    else if (Kq <= 16) OGC_GEMM(16);
+    else if (Kq <= 25) OGC_GEMM(25);
+    else if (Kq <= 33) OGC_GEMM(33);
+    else OGC_GEMM(40);
+#undef OGC_GEMM
+    return OGC_OK;
+}
+
+int gemm_check(const char *name, int b, int M, int K, int hw, const float *w, const float *in, const float *out) {
+    OGC_REQUIRE(b >= 0 && M >= 1 && K >= 1 && hw >= 1, "%s: bad shape", name);
+    OGC_REQUIRE(w && in && out, "%s: null pointer", name);
+    if ((hw & 63) != 0 || K > 4 * FW_KQ_MAX || (((uintptr_t)in | (uintptr_t)out) & 15) != 0) {
+        ogc_set_error("%s: needs hw %% 64 == 0, K <= %d and 16-byte aligned tensors (hw=%d, K=%d)", name,
+                      4 * FW_KQ_MAX, hw, K);
+        return OGC_ERR_UNSUPPORTED;
+    }
+    OGC_REQUIRE((long long)b * M * hw < (1ll << 31) && (long long)b * K * hw < (1ll << 31),
+                "%s: tensor exceeds 32-bit indexing", name);
+    return OGC_OK;
 }
 
 } // namespace
@@ -203,25 +284,35 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_gemm_kernel(int M,
 // OUT[b, m, p] = sum_k A[m, k] IN[b, k, p];  transpose_a == 0: A = w (M x K);  != 0: A = w^T with w stored (K x M).
 extern "C" int ogc_conv1x1_gemm(int b, int M, int K, int hw, int transpose_a, const float *w, const float *in,
                                 float *out, ogc_stream_t stream) {
-    OGC_REQUIRE(b >= 0 && M >= 1 && K >= 1 && hw >= 1, "ogc_conv1x1_gemm: bad shape");
-    OGC_REQUIRE(w && in && out, "ogc_conv1x1_gemm: null pointer");
-    if ((hw & 63) != 0 || K > 4 * FW_KQ_MAX || (((uintptr_t)in | (uintptr_t)out) & 15) != 0) {
-        ogc_set_error("ogc_conv1x1_gemm: needs hw %% 64 == 0, K <= %d and 16-byte aligned tensors (hw=%d, K=%d)",
-                      4 * FW_KQ_MAX, hw, K);
+    const int rc = gemm_check("ogc_conv1x1_gemm", b, M, K, hw, w, in, out);
+    if (rc != OGC_OK) return rc;
+    if (b == 0) return OGC_OK;
+    if (transpose_a) gemm_launch<true, false>(b, M, K, hw, 1, w, in, out, nullptr, (hipStream_t)stream);
+    else gemm_launch<false, false>(b, M, K, hw, 1, w, in, out, nullptr, (hipStream_t)stream);
+    OGC_CHECK_LAUNCH("ogc_conv1x1_gemm");
+    return OGC_OK;
+}
+
+extern "C" int ogc_conv1x1_gn_slots(void) { return GN_SLOTS; }
+
+// Forward convolution that also produces the statistics of the GroupNorm that follows it.
+extern "C" int ogc_conv1x1_gemm_gnstats(int b, int M, int K, int hw, int groups, const float *w, const float *in,
+                                        float *out, double *stats, ogc_stream_t stream) {
+    const int rc = gemm_check("ogc_conv1x1_gemm_gnstats", b, M, K, hw, w, in, out);
+    if (rc != OGC_OK) return rc;
+    OGC_REQUIRE(stats, "ogc_conv1x1_gemm_gnstats: null pointer");
+    if (groups < 1 || groups > 32 || M % groups != 0 || (M / groups) % 4 != 0) {
+        ogc_set_error("ogc_conv1x1_gemm_gnstats: needs 1 <= groups <= 32 and (M / groups) %% 4 == 0 (M=%d, groups=%d)", M,
+                      groups);
         return OGC_ERR_UNSUPPORTED;
     }
-    OGC_REQUIRE((long long)b * M * hw < (1ll << 31) && (long long)b * K * hw < (1ll << 31),
-                "ogc_conv1x1_gemm: tensor exceeds 32-bit indexing");
     if (b == 0) return OGC_OK;
-    const size_t lds = (size_t)((K + 3) / 4) * 256 * sizeof(float);
-    dim3 grid(ogc_divup(hw, 64 * WG_WAVES), b);
-    if (transpose_a)
-        hipLaunchKernelGGL(conv1x1_gemm_kernel<true>, grid, dim3(WG_WAVES * OGC_WAVE), lds, (hipStream_t)stream, M, K, hw, w,
-                           in, out);
-    else
-        hipLaunchKernelGGL(conv1x1_gemm_kernel<false>, grid, dim3(WG_WAVES * OGC_WAVE), lds, (hipStream_t)stream, M, K, hw,
-                           w, in, out);
-    OGC_CHECK_LAUNCH("ogc_conv1x1_gemm");
+    if (hipMemsetAsync(stats, 0, sizeof(double) * 2 * GN_SLOTS * (size_t)b * groups, (hipStream_t)stream) != hipSuccess) {
+        ogc_set_error("ogc_conv1x1_gemm_gnstats: memset failed");
+        return OGC_ERR_LAUNCH;
+    }
+    gemm_launch<false, true>(b, M, K, hw, groups, w, in, out, stats, (hipStream_t)stream);
+    OGC_CHECK_LAUNCH("ogc_conv1x1_gemm_gnstats");
     return OGC_OK;
 }
 

@@ -87,15 +87,22 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(int c, int hw, int
                                                               const float *__restrict__ x,
                                                               const float *__restrict__ gamma,
                                                               const float *__restrict__ beta,
-                                                              const double *__restrict__ ws, float *__restrict__ y,
+                                                              const double *__restrict__ ws, int slots,
+                                                              float *__restrict__ y,
                                                               float *__restrict__ mean_out,
                                                               float *__restrict__ rstd_out) {
     const int b = blockIdx.z, ch = blockIdx.y;
     const int cg = c / groups, g = ch / cg;
     const int row = b * groups + g;
     const double n = (double)cg * hw;
-    const double m = ws[row * 2] / n;
-    const double var = fmax(ws[row * 2 + 1] / n - m * m, 0.0);
+    double sum = 0.0, sumsq = 0.0; // `slots` copies of the accumulator (1 from gn_stats_kernel, more from the fused conv)
+    for (int sl = 0; sl < slots; ++sl) {
+        const double *wsl = ws + ((size_t)sl * gridDim.z * groups + row) * 2;
+        sum += wsl[0];
+        sumsq += wsl[1];
+    }
+    const double m = sum / n;
+    const double var = fmax(sumsq / n - m * m, 0.0);
     const float mean = (float)m;
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
     if (blockIdx.x == 0 && ch == g * cg && threadIdx.x == 0) {
@@ -253,15 +260,21 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_maxpool_kernel(int c, int
                                                                       const float *__restrict__ x,
                                                                       const float *__restrict__ gamma,
                                                                       const float *__restrict__ beta,
-                                                                      const double *__restrict__ ws,
+                                                                      const double *__restrict__ ws, int slots,
                                                                       float *__restrict__ out, int *__restrict__ arg,
                                                                       float *__restrict__ mean_out,
                                                                       float *__restrict__ rstd_out) {
     const int b = blockIdx.z, ch = blockIdx.y;
     const int cg = c / groups, g = ch / cg, row = b * groups + g;
     const double n = (double)cg * p * s;
-    const double m = ws[row * 2] / n;
-    const double var = fmax(ws[row * 2 + 1] / n - m * m, 0.0);
+    double sum = 0.0, sumsq = 0.0;
+    for (int sl = 0; sl < slots; ++sl) {
+        const double *wsl = ws + ((size_t)sl * gridDim.z * groups + row) * 2;
+        sum += wsl[0];
+        sumsq += wsl[1];
+    }
+    const double m = sum / n;
+    const double var = fmax(sumsq / n - m * m, 0.0);
     const float mean = (float)m;
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
     if (blockIdx.x == 0 && ch == g * cg && threadIdx.x == 0) {
@@ -366,35 +379,58 @@ int hw_chunks(int b, int c, int hw) {
 
 } // namespace
 
+namespace {
+// stats == nullptr: first pass (sum, sum of squares per (batch, group), fp64) into ws, then apply.
+// stats != nullptr: `slots` copies of that accumulator already exist (ogc_conv1x1_gemm_gnstats), apply only.
+int gn_fwd_impl(const char *name, int b, int c, int hw, int groups, float eps, int relu, const float *x,
+                const float *gamma, const float *beta, float *y, float *mean, float *rstd, double *ws,
+                const double *stats, int slots, ogc_stream_t stream) {
+    OGC_REQUIRE(b >= 0 && c >= 1 && hw >= 1 && groups >= 1 && c % groups == 0, "%s: bad shape", name);
+    if (b == 0) return OGC_OK;
+    OGC_REQUIRE(x && gamma && beta && y && mean && rstd && (ws || stats), "%s: null pointer", name);
+    OGC_REQUIRE((long long)b * c * hw < (1ll << 31), "%s: tensor exceeds 32-bit indexing", name);
+    hipStream_t s = (hipStream_t)stream;
+    if (!stats) {
+        const int rows = b * groups;
+        const long long row_len = (long long)(c / groups) * hw;
+        if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * rows, s) != hipSuccess) {
+            ogc_set_error("%s: memset failed", name);
+            return OGC_ERR_LAUNCH;
+        }
+        int chunks = 1;
+        while ((long long)rows * chunks < 2048 && row_len / (chunks * 2) >= 16384) chunks *= 2;
+        long long chunk_len = (row_len + chunks - 1) / chunks;
+        chunk_len = (chunk_len + 3) / 4 * 4;
+        hipLaunchKernelGGL(gn_stats_kernel, dim3(ogc_divup(row_len, chunk_len), rows), dim3(GN_THREADS), 0, s, row_len,
+                           chunk_len, x, ws);
+        stats = ws;
+        slots = 1;
+    }
+    dim3 grid(hw_chunks(b, c, hw), c, b);
+    if (relu)
+        hipLaunchKernelGGL(gn_apply_kernel<true>, grid, dim3(GN_THREADS), 0, s, c, hw, groups, eps, x, gamma, beta, stats,
+                           slots, y, mean, rstd);
+    else
+        hipLaunchKernelGGL(gn_apply_kernel<false>, grid, dim3(GN_THREADS), 0, s, c, hw, groups, eps, x, gamma, beta,
+                           stats, slots, y, mean, rstd);
+    OGC_CHECK_LAUNCH(name);
+    return OGC_OK;
+}
+} // namespace
+
 extern "C" int ogc_group_norm_fwd(int b, int c, int hw, int groups, float eps, int relu, const float *x,
                                   const float *gamma, const float *beta, float *y, float *mean, float *rstd,
                                   double *ws, ogc_stream_t stream) {
-    OGC_REQUIRE(b >= 0 && c >= 1 && hw >= 1 && groups >= 1 && c % groups == 0, "ogc_group_norm_fwd: bad shape");
-    if (b == 0) return OGC_OK;
-    OGC_REQUIRE(x && gamma && beta && y && mean && rstd && ws, "ogc_group_norm_fwd: null pointer");
-    OGC_REQUIRE((long long)b * c * hw < (1ll << 31), "ogc_group_norm_fwd: tensor exceeds 32-bit indexing");
-    hipStream_t s = (hipStream_t)stream;
-    const int rows = b * groups;
-    const long long row_len = (long long)(c / groups) * hw;
-    if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * rows, s) != hipSuccess) {
-        ogc_set_error("ogc_group_norm_fwd: memset failed");
-        return OGC_ERR_LAUNCH;
-    }
-    int chunks = 1;
-    while ((long long)rows * chunks < 2048 && row_len / (chunks * 2) >= 16384) chunks *= 2;
-    long long chunk_len = (row_len + chunks - 1) / chunks;
-    chunk_len = (chunk_len + 3) / 4 * 4;
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(ogc_divup(row_len, chunk_len), rows), dim3(GN_THREADS), 0, s, row_len,
-                       chunk_len, x, ws);
-    dim3 grid(hw_chunks(b, c, hw), c, b);
-    if (relu)
-        hipLaunchKernelGGL(gn_apply_kernel<true>, grid, dim3(GN_THREADS), 0, s, c, hw, groups, eps, x, gamma, beta, ws,
-                           y, mean, rstd);
-    else
-        hipLaunchKernelGGL(gn_apply_kernel<false>, grid, dim3(GN_THREADS), 0, s, c, hw, groups, eps, x, gamma, beta, ws,
-                           y, mean, rstd);
-    OGC_CHECK_LAUNCH("ogc_group_norm_fwd");
-    return OGC_OK;
+    return gn_fwd_impl("ogc_group_norm_fwd", b, c, hw, groups, eps, relu, x, gamma, beta, y, mean, rstd, ws, nullptr, 0,
+                       stream);
+}
+
+extern "C" int ogc_group_norm_fwd_stats(int b, int c, int hw, int groups, float eps, int relu, const float *x,
+                                        const float *gamma, const float *beta, float *y, float *mean, float *rstd,
+                                        const double *stats, int slots, ogc_stream_t stream) {
+    OGC_REQUIRE(stats && slots >= 1, "ogc_group_norm_fwd_stats: no statistics");
+    return gn_fwd_impl("ogc_group_norm_fwd_stats", b, c, hw, groups, eps, relu, x, gamma, beta, y, mean, rstd, nullptr,
+                       stats, slots, stream);
 }
 
 extern "C" int ogc_group_norm_bwd(int b, int c, int hw, int groups, int relu, const float *x, const float *gamma,
@@ -434,42 +470,64 @@ extern "C" int ogc_group_norm_bwd(int b, int c, int hw, int groups, int relu, co
 
 static bool gn_pool_shape_ok(int s) { return s >= 4 && s <= 256 && (s & (s - 1)) == 0; }
 
-extern "C" int ogc_group_norm_maxpool_fwd(int b, int c, int p, int s, int groups, float eps, int relu, const float *x,
-                                          const float *gamma, const float *beta, float *out, int *argmax,
-                                          float *mean, float *rstd, double *ws, ogc_stream_t stream) {
-    OGC_REQUIRE(b >= 0 && c >= 1 && p >= 1 && groups >= 1 && c % groups == 0, "ogc_group_norm_maxpool_fwd: bad shape");
+namespace {
+int gn_pool_fwd_impl(const char *name, int b, int c, int p, int s, int groups, float eps, int relu, const float *x,
+                     const float *gamma, const float *beta, float *out, int *argmax, float *mean, float *rstd,
+                     double *ws, const double *stats, int slots, ogc_stream_t stream) {
+    OGC_REQUIRE(b >= 0 && c >= 1 && p >= 1 && groups >= 1 && c % groups == 0, "%s: bad shape", name);
     if (!gn_pool_shape_ok(s) || ((uintptr_t)x & 15) != 0) {
-        ogc_set_error("ogc_group_norm_maxpool_fwd: nsample=%d must be a power of two in [4,256] and x 16-byte aligned", s);
+        ogc_set_error("%s: nsample=%d must be a power of two in [4,256] and x 16-byte aligned", name, s);
         return OGC_ERR_UNSUPPORTED;
     }
     if (b == 0) return OGC_OK;
-    OGC_REQUIRE(x && gamma && beta && out && argmax && mean && rstd && ws, "ogc_group_norm_maxpool_fwd: null pointer");
-    OGC_REQUIRE((long long)b * c * p * s < (1ll << 31), "ogc_group_norm_maxpool_fwd: tensor exceeds 32-bit indexing");
+    OGC_REQUIRE(x && gamma && beta && out && argmax && mean && rstd && (ws || stats), "%s: null pointer", name);
+    OGC_REQUIRE((long long)b * c * p * s < (1ll << 31), "%s: tensor exceeds 32-bit indexing", name);
     hipStream_t st = (hipStream_t)stream;
-    const int rows = b * groups;
-    const long long row_len = (long long)(c / groups) * p * s;
-    if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * rows, st) != hipSuccess) {
-        ogc_set_error("ogc_group_norm_maxpool_fwd: memset failed");
-        return OGC_ERR_LAUNCH;
+    if (!stats) {
+        const int rows = b * groups;
+        const long long row_len = (long long)(c / groups) * p * s;
+        if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * rows, st) != hipSuccess) {
+            ogc_set_error("%s: memset failed", name);
+            return OGC_ERR_LAUNCH;
+        }
+        int chunks = 1;
+        while ((long long)rows * chunks < 2048 && row_len / (chunks * 2) >= 16384) chunks *= 2;
+        long long chunk_len = (row_len + chunks - 1) / chunks;
+        chunk_len = (chunk_len + 3) / 4 * 4;
+        hipLaunchKernelGGL(gn_stats_kernel, dim3(ogc_divup(row_len, chunk_len), rows), dim3(GN_THREADS), 0, st, row_len,
+                           chunk_len, x, ws);
+        stats = ws;
+        slots = 1;
     }
-    int chunks = 1;
-    while ((long long)rows * chunks < 2048 && row_len / (chunks * 2) >= 16384) chunks *= 2;
-    long long chunk_len = (row_len + chunks - 1) / chunks;
-    chunk_len = (chunk_len + 3) / 4 * 4;
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(ogc_divup(row_len, chunk_len), rows), dim3(GN_THREADS), 0, st, row_len,
-                       chunk_len, x, ws);
     const int rows_per_block = GN_THREADS / (s / 4);
     int bx = ogc_divup(p, rows_per_block);
     while (bx > 1 && (long long)bx * c * b > 8192) bx = (bx + 1) / 2;
     dim3 grid(bx, c, b);
     if (relu)
         hipLaunchKernelGGL(gn_apply_maxpool_kernel<true>, grid, dim3(GN_THREADS), 0, st, c, p, s, groups, eps, x, gamma,
-                           beta, ws, out, argmax, mean, rstd);
+                           beta, stats, slots, out, argmax, mean, rstd);
     else
         hipLaunchKernelGGL(gn_apply_maxpool_kernel<false>, grid, dim3(GN_THREADS), 0, st, c, p, s, groups, eps, x,
-                           gamma, beta, ws, out, argmax, mean, rstd);
-    OGC_CHECK_LAUNCH("ogc_group_norm_maxpool_fwd");
+                           gamma, beta, stats, slots, out, argmax, mean, rstd);
+    OGC_CHECK_LAUNCH(name);
     return OGC_OK;
+}
+} // namespace
+
+extern "C" int ogc_group_norm_maxpool_fwd(int b, int c, int p, int s, int groups, float eps, int relu, const float *x,
+                                          const float *gamma, const float *beta, float *out, int *argmax,
+                                          float *mean, float *rstd, double *ws, ogc_stream_t stream) {
+    return gn_pool_fwd_impl("ogc_group_norm_maxpool_fwd", b, c, p, s, groups, eps, relu, x, gamma, beta, out, argmax,
+                            mean, rstd, ws, nullptr, 0, stream);
+}
+
+extern "C" int ogc_group_norm_maxpool_fwd_stats(int b, int c, int p, int s, int groups, float eps, int relu,
+                                                const float *x, const float *gamma, const float *beta, float *out,
+                                                int *argmax, float *mean, float *rstd, const double *stats, int slots,
+                                                ogc_stream_t stream) {
+    OGC_REQUIRE(stats && slots >= 1, "ogc_group_norm_maxpool_fwd_stats: no statistics");
+    return gn_pool_fwd_impl("ogc_group_norm_maxpool_fwd_stats", b, c, p, s, groups, eps, relu, x, gamma, beta, out,
+                            argmax, mean, rstd, nullptr, stats, slots, stream);
 }
 
 extern "C" int ogc_group_norm_maxpool_bwd(int b, int c, int p, int s, int groups, int relu, const float *x,

@@ -12,7 +12,7 @@ class _GroupNormAct(Function):
     Reference sequence: nn.GroupNorm then nn.ReLU(inplace=True) (utils/nn_util.py:6-11, :45-85)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, groups, eps, relu):
+    def forward(ctx, x, weight, bias, groups, eps, relu, stats=None):
         nat = _api._native
         x = x.contiguous()
         B, C = x.shape[0], x.shape[1]
@@ -20,9 +20,14 @@ class _GroupNormAct(Function):
         y = torch.empty_like(x)
         mean = torch.empty(B * groups, dtype=torch.float32, device=x.device)
         rstd = torch.empty_like(mean)
-        ws = torch.empty(2 * B * groups, dtype=torch.float64, device=x.device)
-        nat.group_norm_fwd_wrapper(B, C, hw, groups, eps, relu, x, weight.detach().contiguous(),
-                                   bias.detach().contiguous(), y, mean, rstd, ws)
+        if stats is not None:  # first pass already done by the producing convolution
+            nat.group_norm_fwd_stats_wrapper(B, C, hw, groups, eps, relu, x, weight.detach().contiguous(),
+                                             bias.detach().contiguous(), y, mean, rstd, stats,
+                                             stats.numel() // (2 * B * groups))
+        else:
+            ws = torch.empty(2 * B * groups, dtype=torch.float64, device=x.device)
+            nat.group_norm_fwd_wrapper(B, C, hw, groups, eps, relu, x, weight.detach().contiguous(),
+                                       bias.detach().contiguous(), y, mean, rstd, ws)
         ctx.save_for_backward(x, weight, bias, mean, rstd)
         ctx.cfg = (groups, relu, hw)
         return y
@@ -40,15 +45,16 @@ class _GroupNormAct(Function):
         ws = torch.empty(2 * B * C + B * groups, dtype=torch.float64, device=x.device)
         nat.group_norm_bwd_wrapper(B, C, hw, groups, relu, x, weight.detach().contiguous(), bias.detach().contiguous(),
                                    mean, rstd, grad_y, grad_x, gw, gb, ws)
-        return grad_x, gw, gb, None, None, None
+        return grad_x, gw, gb, None, None, None, None
 
 
-def group_norm_act(x, gn: torch.nn.GroupNorm, relu: bool):
+def group_norm_act(x, gn: torch.nn.GroupNorm, relu: bool, stats=None):
     """GroupNorm followed by an optional ReLU.  HIP-fused on the GPU (fp32); the plain torch composition
-    otherwise (that is what the reference runs)."""
+    otherwise (that is what the reference runs).  stats: the statistics pass, when the convolution that produced x
+    already made it (pointwise_conv(..., gn=...))."""
     if (x.is_cuda and x.dtype == torch.float32 and gn.affine
             and getattr(_api._native, "group_norm_fwd_wrapper", None) is not None):
-        return _GroupNormAct.apply(x, gn.weight, gn.bias, gn.num_groups, gn.eps, relu)
+        return _GroupNormAct.apply(x, gn.weight, gn.bias, gn.num_groups, gn.eps, relu, stats)
     y = F.group_norm(x, gn.num_groups, gn.weight, gn.bias, gn.eps)
     return F.relu(y) if relu else y
 
@@ -58,7 +64,7 @@ class _GroupNormActMaxPool(Function):
     Reference sequence: nn.GroupNorm, nn.ReLU, F.max_pool2d over nsample (utils/pointnet2_util.py:38-42)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, groups, eps, relu):
+    def forward(ctx, x, weight, bias, groups, eps, relu, stats=None):
         nat = _api._native
         x = x.contiguous()
         B, C, P, S = x.shape
@@ -66,9 +72,14 @@ class _GroupNormActMaxPool(Function):
         arg = torch.empty(B, C, P, dtype=torch.int32, device=x.device)
         mean = torch.empty(B * groups, dtype=torch.float32, device=x.device)
         rstd = torch.empty_like(mean)
-        ws = torch.empty(2 * B * groups, dtype=torch.float64, device=x.device)
-        nat.group_norm_maxpool_fwd_wrapper(B, C, P, S, groups, eps, relu, x, weight.detach().contiguous(),
-                                           bias.detach().contiguous(), out, arg, mean, rstd, ws)
+        if stats is not None:
+            nat.group_norm_maxpool_fwd_stats_wrapper(B, C, P, S, groups, eps, relu, x, weight.detach().contiguous(),
+                                                     bias.detach().contiguous(), out, arg, mean, rstd, stats,
+                                                     stats.numel() // (2 * B * groups))
+        else:
+            ws = torch.empty(2 * B * groups, dtype=torch.float64, device=x.device)
+            nat.group_norm_maxpool_fwd_wrapper(B, C, P, S, groups, eps, relu, x, weight.detach().contiguous(),
+                                               bias.detach().contiguous(), out, arg, mean, rstd, ws)
         ctx.save_for_backward(x, weight, mean, rstd, out, arg)
         ctx.cfg = (groups, relu)
         ctx.mark_non_differentiable(arg)
@@ -86,17 +97,17 @@ class _GroupNormActMaxPool(Function):
         ws = torch.empty(2 * B * C + B * groups, dtype=torch.float64, device=x.device)
         nat.group_norm_maxpool_bwd_wrapper(B, C, P, S, groups, relu, x, weight.detach().contiguous(), mean, rstd, out,
                                            arg, grad_out.contiguous(), grad_x, gw, gb, ws)
-        return grad_x, gw, gb, None, None, None
+        return grad_x, gw, gb, None, None, None, None
 
 
-def group_norm_act_maxpool(x, gn: torch.nn.GroupNorm, relu: bool):
+def group_norm_act_maxpool(x, gn: torch.nn.GroupNorm, relu: bool, stats=None):
     """max over the last dimension of act(GroupNorm(x)), x (B, C, P, S).  Fused when S is a power of two in
     [4, 256] on the GPU; otherwise group_norm_act followed by a max."""
     S = x.shape[-1]
     if (x.is_cuda and x.dtype == torch.float32 and gn.affine and x.dim() == 4 and 4 <= S <= 256 and S & (S - 1) == 0
             and getattr(_api._native, "group_norm_maxpool_fwd_wrapper", None) is not None):
-        return _GroupNormActMaxPool.apply(x, gn.weight, gn.bias, gn.num_groups, gn.eps, relu)
-    return group_norm_act(x, gn, relu).max(dim=3)[0]
+        return _GroupNormActMaxPool.apply(x, gn.weight, gn.bias, gn.num_groups, gn.eps, relu, stats)
+    return group_norm_act(x, gn, relu, stats).max(dim=3)[0]
 
 
 def _gemm_ok(K, hw):
@@ -110,19 +121,32 @@ class _PointwiseConv(Function):
     transposes)."""
 
     @staticmethod
-    def forward(ctx, x, weight):
+    def forward(ctx, x, weight, gn_groups=0):
+        # gn_groups > 0: also return the statistics of the GroupNorm (gn_groups groups) that consumes y, or None
         ctx.save_for_backward(x, weight)
+        nat = _api._native
         B, cin = x.shape[0], x.shape[1]
         cout = weight.shape[0]
         hw = x.numel() // (B * cin)
+        stats = None
         if _gemm_ok(cin, hw):
             y = torch.empty((B, cout) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
-            _api._native.conv1x1_gemm_wrapper(B, cout, cin, hw, 0, weight.detach().contiguous(), x, y)
-            return y
-        return F.conv2d(x, weight) if x.dim() == 4 else F.conv1d(x, weight)
+            if (gn_groups > 0 and gn_groups <= 32 and cout % gn_groups == 0 and (cout // gn_groups) % 4 == 0
+                    and getattr(nat, "conv1x1_gemm_gnstats_wrapper", None) is not None):
+                stats = torch.empty(nat.conv1x1_gn_slots() * B * gn_groups * 2, dtype=torch.float64, device=x.device)
+                nat.conv1x1_gemm_gnstats_wrapper(B, cout, cin, hw, gn_groups, weight.detach().contiguous(), x, y, stats)
+            else:
+                nat.conv1x1_gemm_wrapper(B, cout, cin, hw, 0, weight.detach().contiguous(), x, y)
+        else:
+            y = F.conv2d(x, weight) if x.dim() == 4 else F.conv1d(x, weight)
+        if gn_groups > 0:
+            if stats is not None:
+                ctx.mark_non_differentiable(stats)
+            return y, stats
+        return y
 
     @staticmethod
-    def backward(ctx, grad_y):
+    def backward(ctx, grad_y, _grad_stats=None):
         x, weight = ctx.saved_tensors
         nd = x.dim() - 2
         grad_y = grad_y.contiguous()
@@ -141,17 +165,23 @@ class _PointwiseConv(Function):
             grad_w = torch.empty(cout, cin, dtype=torch.float32, device=x.device)
             _api._native.conv1x1_wgrad_wrapper(B, cin, cout, hw, x, grad_y, grad_w)
             grad_w = grad_w.view_as(weight)
-        return grad_x, grad_w
+        return grad_x, grad_w, None
 
 
-def pointwise_conv(x, conv):
-    """Apply a Conv1d/Conv2d module; 1x1, stride-1, bias-free convolutions on the GPU go through _PointwiseConv."""
+def pointwise_conv(x, conv, gn=None):
+    """Apply a Conv1d/Conv2d module; 1x1, stride-1, bias-free convolutions on the GPU go through _PointwiseConv.
+    gn: the GroupNorm that follows — then returns (y, stats), stats being that norm's statistics pass when the
+    convolution kernel could produce it on the way (None otherwise)."""
     hw = x.numel() // max(x.shape[0] * x.shape[1], 1)
     if (x.is_cuda and x.dtype == torch.float32 and conv.bias is None and conv.groups == 1 and hw % 16 == 0
             and x.is_contiguous() and all(k == 1 for k in conv.kernel_size) and all(v == 1 for v in conv.stride)
             and all(v == 0 for v in conv.padding) and getattr(_api._native, "conv1x1_wgrad_wrapper", None) is not None):
-        return _PointwiseConv.apply(x, conv.weight)
-    return conv(x)
+        if gn is None:
+            return _PointwiseConv.apply(x, conv.weight)
+        if gn.affine:
+            return _PointwiseConv.apply(x, conv.weight, gn.num_groups)
+        return _PointwiseConv.apply(x, conv.weight), None
+    return (conv(x), None) if gn is not None else conv(x)
 
 
 class _NeighbourConsistency(Function):

@@ -224,6 +224,31 @@ def conv1x1_wgrad_wrapper(b, cin, cout, hw, x, dy, dw):
     _run("ogc_conv1x1_wgrad", x, b, cin, cout, hw, _f(x, "x"), _f(dy, "dy"), _f(dw, "dw"))
 
 
+def conv1x1_gn_slots():
+    """Number of accumulator copies conv1x1_gemm_gnstats_wrapper fills (ogc_conv1x1_gn_slots)."""
+    return _lib.load().ogc_conv1x1_gn_slots()
+
+
+def conv1x1_gemm_gnstats_wrapper(b, M, K, hw, groups, w, inp, out, stats):
+    """Forward 1x1 convolution that also accumulates the following GroupNorm's statistics (ogc_conv1x1_gemm_gnstats);
+    stats: float64, conv1x1_gn_slots() * b * groups * 2 elements."""
+    _run("ogc_conv1x1_gemm_gnstats", inp, b, M, K, hw, groups, _f(w, "w"), _f(inp, "in"), _f(out, "out"),
+         _check(stats, torch.float64, "stats"))
+
+
+def group_norm_fwd_stats_wrapper(b, c, hw, groups, eps, relu, x, gamma, beta, y, mean, rstd, stats, slots):
+    _run("ogc_group_norm_fwd_stats", x, b, c, hw, groups, float(eps), int(relu), _f(x, "x"), _f(gamma, "gamma"),
+         _f(beta, "beta"), _f(y, "y"), _f(mean, "mean"), _f(rstd, "rstd"), _check(stats, torch.float64, "stats"),
+         int(slots))
+
+
+def group_norm_maxpool_fwd_stats_wrapper(b, c, p, s, groups, eps, relu, x, gamma, beta, out, argmax, mean, rstd, stats,
+                                         slots):
+    _run("ogc_group_norm_maxpool_fwd_stats", x, b, c, p, s, groups, float(eps), int(relu), _f(x, "x"),
+         _f(gamma, "gamma"), _f(beta, "beta"), _f(out, "out"), _i(argmax, "argmax"), _f(mean, "mean"),
+         _f(rstd, "rstd"), _check(stats, torch.float64, "stats"), int(slots))
+
+
 def conv1x1_gemm_wrapper(b, M, K, hw, transpose_a, w, inp, out):
     """out[b, m, p] = sum_k A[m, k] in[b, k, p], A = w or w^T (ogc_conv1x1_gemm); hw % 64 == 0, K <= 160."""
     _run("ogc_conv1x1_gemm", inp, b, M, K, hw, int(transpose_a), _f(w, "w"), _f(inp, "in"), _f(out, "out"))

@@ -95,8 +95,9 @@ class _ConvNd(nn.Sequential):
         if self._gn_fuse:
             from ..fused import group_norm_act, pointwise_conv
             conv_name, norm_name, relu = self._names
-            y = pointwise_conv(input, getattr(self, conv_name))
-            return group_norm_act(y, getattr(self, norm_name)[0], relu)
+            gn = getattr(self, norm_name)[0]
+            y, stats = pointwise_conv(input, getattr(self, conv_name), gn)
+            return group_norm_act(y, gn, relu, stats)
         return super().forward(input)
 
     def forward_maxpool(self, input):
@@ -104,8 +105,9 @@ class _ConvNd(nn.Sequential):
         if self._gn_fuse:
             from ..fused import group_norm_act_maxpool, pointwise_conv
             conv_name, norm_name, relu = self._names
-            y = pointwise_conv(input, getattr(self, conv_name))
-            return group_norm_act_maxpool(y, getattr(self, norm_name)[0], relu)
+            gn = getattr(self, norm_name)[0]
+            y, stats = pointwise_conv(input, getattr(self, conv_name), gn)
+            return group_norm_act_maxpool(y, gn, relu, stats)
         return self.forward(input).max(dim=-1)[0]
 
 

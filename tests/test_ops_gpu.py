@@ -588,3 +588,42 @@ def test_group_concat_matches_op_sequence(shape):
     (ref * w).sum().backward()
     assert torch.equal(fused, ref)
     torch.testing.assert_close(g_fused, feats.grad, rtol=1e-5, atol=1e-5)  # scatter-add order differs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 6, 32, 4096, 4), (3, 32, 64, 1024, 4), (2, 99, 64, 2048, 4), (1, 131, 128, 512, 8),
+                                   (2, 128, 256, 256, 4), (2, 16, 48, 640, 4)])
+def test_conv_gemm_gnstats(shape):
+    """Forward conv with fused GroupNorm statistics: same output as the plain GEMM, statistics equal to fp64 sums."""
+    from ogc_amd import pointnet2_cuda as nat
+    B, cin, cout, hw, groups = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(B, cin, hw, generator=g).cuda()
+    w = torch.randn(cout, cin, generator=g).cuda()
+    y0 = torch.empty(B, cout, hw, device="cuda")
+    y1 = torch.empty_like(y0)
+    slots = nat.conv1x1_gn_slots()
+    stats = torch.full((slots * B * groups * 2,), float("nan"), dtype=torch.float64, device="cuda")
+    nat.conv1x1_gemm_wrapper(B, cout, cin, hw, 0, w, x, y0)
+    nat.conv1x1_gemm_gnstats_wrapper(B, cout, cin, hw, groups, w, x, y1, stats)
+    assert torch.equal(y0, y1)
+    got = stats.view(slots, B, groups, 2).sum(0)
+    yg = y1.double().view(B, groups, -1)
+    ref = torch.stack([yg.sum(-1), (yg * yg).sum(-1)], -1)
+    # fp32 partial sums over 256 outputs, fp64 beyond: the error scales with the sum of magnitudes, not with the sum
+    scale = torch.stack([yg.abs().sum(-1), (yg * yg).sum(-1)], -1)
+    assert ((got - ref).abs() <= 1e-6 * scale + 1e-9).all()
+    # and through the GroupNorm that consumes them
+    gamma, beta = torch.rand(cout, generator=g).cuda() + 0.5, torch.randn(cout, generator=g).cuda()
+    outs = []
+    for use_stats in (False, True):
+        y = torch.empty_like(y1)
+        mean, rstd = torch.empty(B * groups, device="cuda"), torch.empty(B * groups, device="cuda")
+        if use_stats:
+            nat.group_norm_fwd_stats_wrapper(B, cout, hw, groups, 1e-5, 1, y1, gamma, beta, y, mean, rstd, stats, slots)
+        else:
+            ws = torch.empty(2 * B * groups, dtype=torch.float64, device="cuda")
+            nat.group_norm_fwd_wrapper(B, cout, hw, groups, 1e-5, 1, y1, gamma, beta, y, mean, rstd, ws)
+        outs.append((y, mean, rstd))
+    for a, b_ in zip(outs[0], outs[1]):
+        torch.testing.assert_close(a, b_, rtol=2e-6, atol=2e-6)
