@@ -217,6 +217,31 @@ int ogc_group_norm_maxpool_bwd(int b, int c, int p, int s, int groups, int relu,
                                const int *argmax, const float *grad_out, float *grad_x, float *grad_gamma,
                                float *grad_beta, double *ws, ogc_stream_t stream);
 
+/* Fused BatchNorm2d (+ ReLU) (+ max over the neighbourhood), forward / backward — the F.relu(bn(conv(.))) chains and
+ * the trailing .max(dim=-1) of the FlowStep3D blocks
+ *   utils/flowstep3d_util.py:57-66 (FlowEmbedding), :126-138 (PointNetSetAbstraction), :181-183 (feature propagation).
+ * nn.BatchNorm2d semantics.  training != 0: batch statistics per channel over (b, hw), biased variance,
+ * rstd = 1/sqrt(var + eps); running_mean / running_var (c), when non-NULL, are updated in place with `momentum` and the
+ * unbiased variance.  training == 0: running statistics (required) are used, and the backward is the affine map's.
+ * x, y, grad_y, grad_x (b, c, hw) [maxpool: x (b, c, p, s) -> out, argmax (b, c, p); s a power of two in [4, 256]];
+ * gamma, beta, grad_gamma, grad_beta, mean, rstd (c) (mean / rstd written by fwd, read by bwd).
+ * stats / slots: optional statistics supplied by the producing kernel (`slots` copies of a (c, 2) f64 accumulator), else
+ * NULL / 0 and ws (2c f64) is used.  bwd ws: 3c f64. */
+int ogc_batch_norm_fwd(int b, int c, int hw, float eps, int relu, int training, float momentum, const float *x,
+                       const float *gamma, const float *beta, float *running_mean, float *running_var, float *y,
+                       float *mean, float *rstd, double *ws, const double *stats, int slots, ogc_stream_t stream);
+int ogc_batch_norm_bwd(int b, int c, int hw, int relu, int training, const float *x, const float *gamma,
+                       const float *beta, const float *mean, const float *rstd, const float *grad_y, float *grad_x,
+                       float *grad_gamma, float *grad_beta, double *ws, ogc_stream_t stream);
+int ogc_batch_norm_maxpool_fwd(int b, int c, int p, int s, float eps, int relu, int training, float momentum,
+                               const float *x, const float *gamma, const float *beta, float *running_mean,
+                               float *running_var, float *out, int *argmax, float *mean, float *rstd, double *ws,
+                               const double *stats, int slots, ogc_stream_t stream);
+int ogc_batch_norm_maxpool_bwd(int b, int c, int p, int s, int relu, int training, const float *x, const float *gamma,
+                               const float *mean, const float *rstd, const float *out, const int *argmax,
+                               const float *grad_out, float *grad_x, float *grad_gamma, float *grad_beta, double *ws,
+                               ogc_stream_t stream);
+
 /* Weight gradient of a 1x1 convolution (bias-free), NCHW, fp32, on the fp32 MFMA pipe:
  *   dw[co, ci] = sum_b sum_p dy[b, co, p] * x[b, ci, p]
  * Replaces the weight-gradient half of the Conv2d(1x1) layers of SharedMLP (utils/nn_util.py:45-85, :155-172), which

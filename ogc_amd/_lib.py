@@ -39,6 +39,13 @@ SIGNATURES = {
     "ogc_group_norm_maxpool_fwd": [_int, _int, _int, _int, _int, _flt, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "ogc_conv1x1_gemm": [_int, _int, _int, _int, _int, _vp, _vp, _vp, _vp],
     "ogc_conv1x1_gn_slots": [],
+    "ogc_batch_norm_fwd": [_int, _int, _int, _flt, _int, _int, _flt, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                           _int, _vp],
+    "ogc_batch_norm_bwd": [_int, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "ogc_batch_norm_maxpool_fwd": [_int, _int, _int, _int, _flt, _int, _int, _flt, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                   _vp, _vp, _vp, _vp, _int, _vp],
+    "ogc_batch_norm_maxpool_bwd": [_int, _int, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                   _vp, _vp, _vp],
     "ogc_conv1x1_gemm_gnstats": [_int, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp],
     "ogc_group_norm_fwd_stats": [_int, _int, _int, _int, _flt, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp],
     "ogc_group_norm_maxpool_fwd_stats": [_int, _int, _int, _int, _int, _flt, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp,

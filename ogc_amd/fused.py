@@ -234,3 +234,111 @@ def neighbour_consistency_available(mask, loss_norm, cross_entropy):
 def neighbour_consistency(mask, idx, reverse, p):
     """mask (B, N, C) point-major, idx (B, N, k), reverse = reverse_neighbours(idx) -> (B, N)."""
     return _NeighbourConsistency.apply(mask, idx, reverse[0], reverse[1], reverse[2], int(p))
+
+
+# ---- BatchNorm flavour (FlowStep3D nets) ----------------------------------------------------------------------
+def _bn_buffers(bn):
+    return (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
+
+
+class _BatchNormAct(Function):
+    """y = act(BatchNorm(x)), act = ReLU or identity; batch statistics in training (running statistics updated in
+    place by the kernel), running statistics in evaluation.  Reference sequence: F.relu(bn(.)) in
+    utils/flowstep3d_util.py:57-66, :126-138."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, relu, stats):
+        nat = _api._native
+        x = x.contiguous()
+        B, C = x.shape[0], x.shape[1]
+        hw = x.numel() // max(B * C, 1)
+        y = torch.empty_like(x)
+        mean = torch.empty(C, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        ws = None if (stats is not None or not training) else torch.empty(2 * C, dtype=torch.float64, device=x.device)
+        nat.batch_norm_fwd_wrapper(B, C, hw, eps, relu, training, momentum, x, weight.detach().contiguous(),
+                                   bias.detach().contiguous(), running_mean, running_var, y, mean, rstd, ws, stats,
+                                   0 if stats is None else stats.numel() // (2 * C))
+        ctx.save_for_backward(x, weight, bias, mean, rstd)
+        ctx.cfg = (relu, training, hw)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        nat = _api._native
+        x, weight, bias, mean, rstd = ctx.saved_tensors
+        relu, training, hw = ctx.cfg
+        B, C = x.shape[0], x.shape[1]
+        grad_x = torch.empty_like(x)
+        gw = torch.empty_like(weight)
+        gb = torch.empty_like(bias)
+        ws = torch.empty(3 * C, dtype=torch.float64, device=x.device)
+        nat.batch_norm_bwd_wrapper(B, C, hw, relu, training, x, weight.detach().contiguous(),
+                                   bias.detach().contiguous(), mean, rstd, grad_y.contiguous(), grad_x, gw, gb, ws)
+        return grad_x, gw, gb, None, None, None, None, None, None, None
+
+
+class _BatchNormActMaxPool(Function):
+    """out[b,c,p] = max_s act(BatchNorm(x))[b,c,p,s] without materialising the normalised activation.
+    Reference sequence: F.relu(bn(.)) then .max(dim=-1) (utils/flowstep3d_util.py:64-66, :134-136)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, relu, stats):
+        nat = _api._native
+        x = x.contiguous()
+        B, C, P, S = x.shape
+        out = torch.empty(B, C, P, dtype=torch.float32, device=x.device)
+        arg = torch.empty(B, C, P, dtype=torch.int32, device=x.device)
+        mean = torch.empty(C, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        ws = None if (stats is not None or not training) else torch.empty(2 * C, dtype=torch.float64, device=x.device)
+        nat.batch_norm_maxpool_fwd_wrapper(B, C, P, S, eps, relu, training, momentum, x, weight.detach().contiguous(),
+                                           bias.detach().contiguous(), running_mean, running_var, out, arg, mean, rstd,
+                                           ws, stats, 0 if stats is None else stats.numel() // (2 * C))
+        ctx.save_for_backward(x, weight, mean, rstd, out, arg)
+        ctx.cfg = (relu, training)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        nat = _api._native
+        x, weight, mean, rstd, out, arg = ctx.saved_tensors
+        relu, training = ctx.cfg
+        B, C, P, S = x.shape
+        grad_x = torch.empty_like(x)
+        gw = torch.empty_like(weight)
+        gb = torch.empty_like(weight)
+        ws = torch.empty(3 * C, dtype=torch.float64, device=x.device)
+        nat.batch_norm_maxpool_bwd_wrapper(B, C, P, S, relu, training, x, weight.detach().contiguous(), mean, rstd, out,
+                                           arg, grad_out.contiguous(), grad_x, gw, gb, ws)
+        return grad_x, gw, gb, None, None, None, None, None, None, None
+
+
+def _bn_fusable(x, bn):
+    return (isinstance(bn, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)) and x.is_cuda and x.dtype == torch.float32
+            and bn.affine and bn.momentum is not None and (bn.training or bn.track_running_stats)
+            and getattr(_api._native, "batch_norm_fwd_wrapper", None) is not None)
+
+
+def _bn_call(fn, x, bn, relu, stats):
+    training = bn.training or not bn.track_running_stats
+    rm, rv = _bn_buffers(bn)
+    if training and bn.track_running_stats:
+        bn.num_batches_tracked.add_(1)
+    return fn.apply(x, bn.weight, bn.bias, rm, rv, training, float(bn.momentum), bn.eps, relu, stats)
+
+
+def conv_norm_act(x, conv, norm, relu=True, maxpool=False):
+    """act(norm(conv(x))) (+ max over the last dimension) for the conv / BatchNorm / ReLU chains of the FlowStep3D
+    blocks.  On the GPU: MFMA convolution and the fused BatchNorm kernels; otherwise the reference's op sequence."""
+    y = pointwise_conv(x, conv)
+    if _bn_fusable(y, norm):
+        S = y.shape[-1]
+        if maxpool and y.dim() == 4 and 4 <= S <= 256 and S & (S - 1) == 0:
+            return _bn_call(_BatchNormActMaxPool, y, norm, relu, None)
+        y = _bn_call(_BatchNormAct, y, norm, relu, None)
+    else:
+        y = norm(y)
+        if relu:
+            y = F.relu(y)
+    return y.max(dim=-1)[0] if maxpool else y

@@ -224,6 +224,41 @@ def conv1x1_wgrad_wrapper(b, cin, cout, hw, x, dy, dw):
     _run("ogc_conv1x1_wgrad", x, b, cin, cout, hw, _f(x, "x"), _f(dy, "dy"), _f(dw, "dw"))
 
 
+def _opt(t, dtype, name):
+    return 0 if t is None else _check(t, dtype, name)
+
+
+def batch_norm_fwd_wrapper(b, c, hw, eps, relu, training, momentum, x, gamma, beta, running_mean, running_var, y, mean,
+                           rstd, ws, stats, slots):
+    """Fused BatchNorm(+ReLU) forward (ogc_batch_norm_fwd); running statistics updated in place when training."""
+    _run("ogc_batch_norm_fwd", x, b, c, hw, float(eps), int(relu), int(training), float(momentum), _f(x, "x"),
+         _f(gamma, "gamma"), _f(beta, "beta"), _opt(running_mean, torch.float32, "running_mean"),
+         _opt(running_var, torch.float32, "running_var"), _f(y, "y"), _f(mean, "mean"), _f(rstd, "rstd"),
+         _opt(ws, torch.float64, "ws"), _opt(stats, torch.float64, "stats"), int(slots))
+
+
+def batch_norm_bwd_wrapper(b, c, hw, relu, training, x, gamma, beta, mean, rstd, grad_y, grad_x, grad_gamma, grad_beta,
+                           ws):
+    _run("ogc_batch_norm_bwd", x, b, c, hw, int(relu), int(training), _f(x, "x"), _f(gamma, "gamma"), _f(beta, "beta"),
+         _f(mean, "mean"), _f(rstd, "rstd"), _f(grad_y, "grad_y"), _f(grad_x, "grad_x"), _f(grad_gamma, "grad_gamma"),
+         _f(grad_beta, "grad_beta"), _check(ws, torch.float64, "ws"))
+
+
+def batch_norm_maxpool_fwd_wrapper(b, c, p, s, eps, relu, training, momentum, x, gamma, beta, running_mean, running_var,
+                                   out, argmax, mean, rstd, ws, stats, slots):
+    _run("ogc_batch_norm_maxpool_fwd", x, b, c, p, s, float(eps), int(relu), int(training), float(momentum), _f(x, "x"),
+         _f(gamma, "gamma"), _f(beta, "beta"), _opt(running_mean, torch.float32, "running_mean"),
+         _opt(running_var, torch.float32, "running_var"), _f(out, "out"), _i(argmax, "argmax"), _f(mean, "mean"),
+         _f(rstd, "rstd"), _opt(ws, torch.float64, "ws"), _opt(stats, torch.float64, "stats"), int(slots))
+
+
+def batch_norm_maxpool_bwd_wrapper(b, c, p, s, relu, training, x, gamma, mean, rstd, out, argmax, grad_out, grad_x,
+                                   grad_gamma, grad_beta, ws):
+    _run("ogc_batch_norm_maxpool_bwd", x, b, c, p, s, int(relu), int(training), _f(x, "x"), _f(gamma, "gamma"),
+         _f(mean, "mean"), _f(rstd, "rstd"), _f(out, "out"), _i(argmax, "argmax"), _f(grad_out, "grad_out"),
+         _f(grad_x, "grad_x"), _f(grad_gamma, "grad_gamma"), _f(grad_beta, "grad_beta"), _check(ws, torch.float64, "ws"))
+
+
 def conv1x1_gn_slots():
     """Number of accumulator copies conv1x1_gemm_gnstats_wrapper fills (ogc_conv1x1_gn_slots)."""
     return _lib.load().ogc_conv1x1_gn_slots()

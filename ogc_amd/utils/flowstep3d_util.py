@@ -39,6 +39,18 @@ class geometry_memo:
         return hit
 
 
+def _shared_mlp(x, convs, norms, pool):
+    """[relu(norm(conv(x))) for every layer] (+ max over the last dimension): the MLP tail of every FlowStep3D block
+    (reference flowstep3d_util.py:64-66, :134-136, :181-183), through the fused conv / BatchNorm kernels on the GPU."""
+    from ..fused import conv_norm_act
+    n = len(convs)
+    for i, (conv, norm) in enumerate(zip(convs, norms)):
+        x = conv_norm_act(x, conv, norm, relu=True, maxpool=pool and i == n - 1)
+    if pool and n == 0:
+        x = x.max(dim=-1)[0]
+    return x
+
+
 def _norm2d(channels, use_instance_norm):
     return nn.InstanceNorm2d(channels, affine=True) if use_instance_norm else nn.BatchNorm2d(channels)
 
@@ -82,9 +94,7 @@ class FlowEmbedding(nn.Module):
         if self.corr_func == 'concat':
             feat_diff = torch.cat([feat2_grouped, feature1.view(B, -1, N, 1).expand(-1, -1, -1, self.nsample)], dim=1)
         feat1_new = torch.cat([pos_diff, feat_diff], dim=1)                          # (B, 2C+3, N, S)
-        for conv, bn in zip(self.mlp_convs, self.mlp_bns):
-            feat1_new = F.relu(bn(conv(feat1_new)))
-        return pos1, feat1_new.max(dim=-1)[0]
+        return pos1, _shared_mlp(feat1_new, self.mlp_convs, self.mlp_bns, pool=True)
 
 
 class PointNetSetAbstraction(nn.Module):
@@ -154,9 +164,16 @@ class PointNetSetAbstraction(nn.Module):
             new_points, _ = self.queryandgroup(xyz_t, new_xyz.transpose(2, 1).contiguous(), points, neighbours=neighbours)
         else:
             new_points, _ = self.queryandgroup(xyz_t, new_xyz.transpose(2, 1).contiguous(), points)
-        for conv, bn in zip(self.mlp_convs, self.mlp_bns):
-            new_points = self.act(bn(conv(new_points))) if self.use_act else conv(new_points)
-        new_points = new_points.mean(dim=-1) if self.mean_aggr else new_points.max(dim=-1)[0]
+        if self.use_act and self.act is F.relu:
+            new_points = _shared_mlp(new_points, self.mlp_convs, self.mlp_bns, pool=not self.mean_aggr)
+            if self.mean_aggr:
+                new_points = new_points.mean(dim=-1)
+        else:
+            from ..fused import pointwise_conv
+            for conv, bn in zip(self.mlp_convs, self.mlp_bns):
+                new_points = self.act(bn(pointwise_conv(new_points, conv))) if self.use_act else \
+                    pointwise_conv(new_points, conv)
+            new_points = new_points.mean(dim=-1) if self.mean_aggr else new_points.max(dim=-1)[0]
         if self.return_fps:
             return new_xyz, new_points, fps_idx
         return new_xyz, new_points
@@ -189,6 +206,5 @@ class PointNetFeaturePropogation(nn.Module):
         interpolated = (grouping_operation(feature2, idx) * weight.view(B, 1, N, 3)).sum(dim=-1)
         feat_new = interpolated if feature1 is None else torch.cat([interpolated, feature1], dim=1)
         if self.apply_mlp:
-            for conv, bn in zip(self.mlp_convs, self.mlp_bns):
-                feat_new = F.relu(bn(conv(feat_new)))
+            feat_new = _shared_mlp(feat_new, self.mlp_convs, self.mlp_bns, pool=False)
         return feat_new

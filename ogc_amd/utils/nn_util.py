@@ -98,7 +98,13 @@ class _ConvNd(nn.Sequential):
             gn = getattr(self, norm_name)[0]
             y, stats = pointwise_conv(input, getattr(self, conv_name), gn)
             return group_norm_act(y, gn, relu, stats)
-        return super().forward(input)
+        # other norms (BatchNorm in the FlowStep3D nets) / pre-activation order: the children in sequence, with the
+        # bias-free 1x1 convolution on the MFMA kernels where it qualifies
+        from ..fused import pointwise_conv
+        x = input
+        for mod in self:
+            x = pointwise_conv(x, mod) if isinstance(mod, (nn.Conv1d, nn.Conv2d)) else mod(x)
+        return x
 
     def forward_maxpool(self, input):
         """forward followed by a max over the last dimension (fused with GroupNorm/ReLU where possible)."""

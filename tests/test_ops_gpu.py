@@ -627,3 +627,43 @@ def test_conv_gemm_gnstats(shape):
         outs.append((y, mean, rstd))
     for a, b_ in zip(outs[0], outs[1]):
         torch.testing.assert_close(a, b_, rtol=2e-6, atol=2e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("pool", [False, True])
+@pytest.mark.parametrize("shape", [(3, 16, 40, 8), (2, 35, 128, 16), (4, 64, 33, 4)])
+def test_batch_norm_act_fused(shape, pool, training):
+    """conv -> BatchNorm2d -> ReLU (-> max over nsample) through the fused kernels vs the torch op sequence
+    (utils/flowstep3d_util.py:64-66): outputs, input / parameter gradients and running statistics."""
+    import copy
+    from ogc_amd.fused import conv_norm_act
+    B, C, P, S = shape
+    g = torch.Generator().manual_seed(sum(shape) + pool + 2 * training)
+    conv = torch.nn.Conv2d(7, C, 1, bias=False).cuda()
+    bn = torch.nn.BatchNorm2d(C, momentum=0.3).cuda()
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(C, generator=g))
+        bn.running_mean.copy_(torch.randn(C, generator=g) * 0.1)
+        bn.running_var.copy_(torch.rand(C, generator=g) + 0.5)
+    conv2, bn2 = copy.deepcopy(conv), copy.deepcopy(bn)
+    for m in (bn, bn2):
+        m.train(training)
+    x = torch.randn(B, 7, P, S, generator=g).cuda()
+    x1, x2 = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    y1 = conv_norm_act(x1, conv, bn, relu=True, maxpool=pool)
+    y2 = torch.relu(bn2(conv2(x2)))
+    if pool:
+        y2 = y2.max(dim=-1)[0]
+    w = torch.randn(y2.shape, generator=g).cuda()
+    (y1 * w).sum().backward()
+    (y2 * w).sum().backward()
+    torch.testing.assert_close(y1, y2, rtol=1e-5, atol=2e-5)
+    torch.testing.assert_close(x1.grad, x2.grad, rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(conv.weight.grad, conv2.weight.grad, rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(bn.weight.grad, bn2.weight.grad, rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(bn.bias.grad, bn2.bias.grad, rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(bn.running_mean, bn2.running_mean, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(bn.running_var, bn2.running_var, rtol=1e-5, atol=1e-6)
+    assert int(bn.num_batches_tracked) == int(bn2.num_batches_tracked)
