@@ -6,8 +6,24 @@ checkpoints (``encoder_loc.sa1.mlp_convs.0.weight``, ``global_corr_layer.epsilon
 import torch
 import torch.nn as nn
 
+from ..pointnet2.pointnet2 import furthest_point_sample, gather_operation
 from ..utils.flowstep3d_util import (FlowEmbedding, PointNetFeaturePropogation, PointNetSetAbstraction,
                                      geometry_memo)
+
+
+def joint_fps(xyz_a, xyz_b, npoints):
+    """FPS chains of TWO clouds in one launch per level.  Sampling is per cloud, so stacking both clouds along the
+    batch gives each its own indices unchanged, but the sequential rounds (one workgroup per cloud) are paid once
+    instead of twice.  xyz_* (B, 3, N) -> ([idx level 1, idx level 2, ...] for a, the same for b)."""
+    B = xyz_a.shape[0]
+    level = torch.cat([xyz_a, xyz_b])                                   # (2B, 3, N)
+    idx_a, idx_b = [], []
+    for npoint in npoints:
+        idx = furthest_point_sample(level.permute(0, 2, 1).contiguous(), npoint)
+        idx_a.append(idx[:B].contiguous())
+        idx_b.append(idx[B:].contiguous())
+        level = gather_operation(level.contiguous(), idx)
+    return idx_a, idx_b
 
 
 def _sa(npoint, nsample, in_channel, mlp, inorm, **kw):
@@ -115,10 +131,14 @@ class EncoderGlob(nn.Module):
         for i, (div, nsample, cin, mlp) in enumerate(cfg["glob_enc"], start=1):
             setattr(self, "sa%d" % i, _sa(int(npoint / div), nsample, cin, list(mlp), use_instance_norm))
 
-    def forward(self, pc, feature):
+    def npoints(self):
+        return [getattr(self, "sa%d" % i).npoint for i in range(1, self.n_sa + 1)]
+
+    def forward(self, pc, feature, fps_idx=None):
         pc_l = [pc]
         for i in range(1, self.n_sa + 1):
-            pc_i, feature = getattr(self, "sa%d" % i)(pc_l[-1], feature)
+            pc_i, feature = getattr(self, "sa%d" % i)(pc_l[-1], feature,
+                                                      fps_idx=None if fps_idx is None else fps_idx[i - 1])
             pc_l.append(pc_i)
         return pc_l, feature
 
@@ -189,8 +209,11 @@ class FlowStep3DBase(nn.Module):
         self.flow_up_sample = PointNetFeaturePropogation(in_channel=3, mlp=[])
 
     def calc_glob_corr(self, pc1_loc, feats1_loc, pc2_loc, feats2_loc):
-        pc1_l_glob, feats1_glob = self.encoder_glob(pc1_loc, feats1_loc)
-        pc2_l_glob, feats2_glob = self.encoder_glob(pc2_loc, feats2_loc)
+        fps1 = fps2 = None
+        if pc1_loc.is_cuda and pc1_loc.shape == pc2_loc.shape:
+            fps1, fps2 = joint_fps(pc1_loc, pc2_loc, self.encoder_glob.npoints())
+        pc1_l_glob, feats1_glob = self.encoder_glob(pc1_loc, feats1_loc, fps1)
+        pc2_l_glob, feats2_glob = self.encoder_glob(pc2_loc, feats2_loc, fps2)
         return self.global_corr_layer(pc1_l_glob, pc2_l_glob, feats1_glob, feats2_glob)
 
     def calc_h0(self, feats1_loc, pc):
@@ -216,8 +239,11 @@ class FlowStep3DBase(nn.Module):
         feature1 = feature1.permute(0, 2, 1).contiguous()
         feature2 = feature2.permute(0, 2, 1).contiguous()
 
-        pc1_l_loc, feats1_loc, fps_idx1 = self.encoder_loc(pc1, feature1)
-        pc2_l_loc, feats2_loc, _ = self.encoder_loc(pc2, feature2)
+        fps_idx1 = fps_idx2 = None
+        if pc1.is_cuda and pc1.shape == pc2.shape:  # both sampling chains in one launch per level
+            fps_idx1, fps_idx2 = joint_fps(pc1, pc2, [self.encoder_loc.sa1.npoint, self.encoder_loc.sa2.npoint])
+        pc1_l_loc, feats1_loc, fps_idx1 = self.encoder_loc(pc1, feature1, fps_idx1)
+        pc2_l_loc, feats2_loc, _ = self.encoder_loc(pc2, feature2, fps_idx2)
 
         corr_feats = self.calc_glob_corr(pc1_l_loc[-1], feats1_loc, pc2_l_loc[-1], feats2_loc)
         flow0_lr = self.flow0_regressor(pc1_l_loc, corr_feats)
