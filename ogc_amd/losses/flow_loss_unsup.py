@@ -71,8 +71,53 @@ class SmoothLoss(nn.Module):
         self.w_knn = w_knn
         self.w_ball_q = w_ball_q
 
-    def forward(self, pc, flow):
-        return (self.w_knn * self.knn_loss(pc, flow)) + (self.w_ball_q * self.ball_q_loss(pc, flow))
+    def plan(self, pc):
+        """Neighbour lists of `pc` (and their transposes for the fused gradient) — coordinates only.  The reference
+        searches them again for every refinement iteration's prediction (:126-130) although pc1 never changes."""
+        pc = pc.contiguous()
+        kl, bl = self.knn_loss, self.ball_q_loss
+        _, idx_knn = knn_radius_clamp(kl.k, kl.radius, pc, pc)
+        idx_ball = ball_query(bl.radius, bl.k, pc, pc)
+        plan = {"knn": idx_knn, "ball": idx_ball}
+        if pc.is_cuda:
+            from ..fused import reverse_neighbours
+            from ..pointnet2 import pointnet2 as _api
+            if getattr(_api._native, "reverse_neighbours_wrapper", None) is not None:
+                plan["knn_rev"] = reverse_neighbours(idx_knn)
+                plan["ball_rev"] = reverse_neighbours(idx_ball)
+        return plan
+
+    def forward(self, pc, flow, plan=None):
+        if plan is None:
+            return (self.w_knn * self.knn_loss(pc, flow)) + (self.w_ball_q * self.ball_q_loss(pc, flow))
+        from ..fused import neighbour_consistency, neighbour_consistency_available
+        terms = []
+        flow_cm = None
+        for name, cfg in (("knn", self.knn_loss), ("ball", self.ball_q_loss)):
+            if name + "_rev" in plan and neighbour_consistency_available(flow, cfg.loss_norm, False):
+                terms.append(neighbour_consistency(flow.contiguous(), plan[name], plan[name + "_rev"],
+                                                   cfg.loss_norm).mean())
+            else:
+                if flow_cm is None:
+                    flow_cm = flow.permute(0, 2, 1).contiguous()
+                nn_flow = grouping_operation(flow_cm, plan[name].detach())
+                terms.append((flow_cm.unsqueeze(3) - nn_flow).norm(p=cfg.loss_norm, dim=1).mean())
+        return self.w_knn * terms[0] + self.w_ball_q * terms[1]
+
+
+class PendingFlowLossDict:
+    """loss_dict of one evaluation on its way to the host (one non-blocking copy); resolve() -> dict of floats."""
+
+    def __init__(self, monitored):
+        from ..utils.streams import HostScalars
+        self._keys = [k for k, _ in monitored]
+        self._scalars = HostScalars(torch.stack([v.detach().float().reshape(()) for _, v in monitored]))
+        self._dict = None
+
+    def resolve(self):
+        if self._dict is None:
+            self._dict = dict(zip(self._keys, self._scalars.get()))
+        return self._dict
 
 
 class UnsupervisedFlowStep3DLoss(nn.Module):
@@ -86,14 +131,15 @@ class UnsupervisedFlowStep3DLoss(nn.Module):
         self.w_chamfer, self.w_smooth = weights
         self.iters_w = iters_w
 
-    def forward(self, pc1, pc2, flow_preds):
+    def forward(self, pc1, pc2, flow_preds, sync=True):
         assert len(flow_preds) == len(self.iters_w)
         monitored, loss = [], 0
+        plan = self.smooth_loss.plan(pc1) if hasattr(self.smooth_loss, "plan") else None
         for i, flow_pred in enumerate(flow_preds):
             chamfer_i = self.chamfer_loss(pc1, pc2, flow_pred)
-            smooth_i = self.smooth_loss(pc1, flow_pred)
+            smooth_i = self.smooth_loss(pc1, flow_pred, plan) if plan is not None else self.smooth_loss(pc1, flow_pred)
             monitored += [('chamfer_loss_#%d' % i, chamfer_i), ('smooth_loss_#%d' % i, smooth_i)]
             loss = loss + self.iters_w[i] * (self.w_chamfer * chamfer_i + self.w_smooth * smooth_i)
         monitored.append(('sum', loss))
-        values = torch.stack([v.detach().float().reshape(()) for _, v in monitored]).tolist()
-        return loss, {k: v for (k, _), v in zip(monitored, values)}
+        pending = PendingFlowLossDict(monitored)
+        return loss, (pending.resolve() if sync else pending)

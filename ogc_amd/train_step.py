@@ -134,3 +134,40 @@ def train_step(segnet, criterion, optimizer, batch, it, aug_transform, sync=True
         pending = PendingStep(losses, HostScalars(torch.tensor([skip])))
     pending.prefetched = upcoming
     return pending.result() if sync else pending
+
+
+def _nan_safe_step(params, optimizer):
+    """The reference's NaN-gradient rule (train_seg.py:81-83, train_flow.py:84-86) without a host round trip when the
+    optimizer is fused; returns a HostScalars holding the 'skipped' flag."""
+    from .utils.streams import HostScalars
+    grads = [p.grad for p in params if p.grad is not None]
+    bad = torch.isnan(torch.stack(torch._foreach_norm(grads)).sum())  # NaN anywhere -> NaN norm
+    if getattr(optimizer, "_step_supports_amp_scaling", False) and bad.is_cuda:
+        optimizer.grad_scale = None
+        optimizer.found_inf = bad.float().reshape(())
+        try:
+            optimizer.step()
+        finally:
+            del optimizer.grad_scale
+            del optimizer.found_inf
+        return HostScalars(bad.reshape(1))
+    skip = bool(bad)  # host sync
+    if not skip:
+        optimizer.step()
+    return HostScalars(torch.tensor([skip]))
+
+
+def flow_train_step(flownet, criterion, optimizer, batch, model_iters, sync=True):
+    """One unsupervised FlowStep3D step (body of the reference's train_flow.py:62-88).
+    batch = (pcs (b,t,n,3), segms, flows, valids) on the device; the pair is (pcs[:, 0], pcs[:, 1]).
+    Returns (loss_dict, stepped), or a PendingStep with sync=False."""
+    flownet.train()
+    optimizer.zero_grad(set_to_none=True)
+    pcs = batch[0]
+    pc1, pc2 = pcs[:, 0].contiguous(), pcs[:, 1].contiguous()
+    flow_preds = flownet(pc1, pc2, pc1, pc2, iters=model_iters)
+    loss, losses = criterion(pc1, pc2, flow_preds, sync=False)
+    loss.backward()
+    net = flownet.module if hasattr(flownet, "module") else flownet
+    pending = PendingStep(losses, _nan_safe_step(list(net.parameters()), optimizer))
+    return pending.result() if sync else pending

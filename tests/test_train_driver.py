@@ -53,3 +53,35 @@ def test_driver_runs_and_writes_reference_style_checkpoints(tmp_path, monkeypatc
     assert e1["aug"] is False and e2["aug"] is True                      # views switch on after aug_transform_epoch
     assert e1["train"]["invariance"] == 0 and e2["train"]["invariance"] > 0
     assert e2["lr"] < e1["lr"] or e2["lr"] == e1["lr"] * 0.7 or e2["lr"] <= 1e-3
+
+
+def test_flow_driver_runs_and_writes_checkpoints(tmp_path, monkeypatch, oracle, capsys):
+    """train_flow on the CPU oracle's operators: the reference's config schema (config/flow/sapien/sapien_unsup.yaml),
+    its loss_dict keys (losses/flow_loss_unsup.py:128-138) and checkpoint format."""
+    import json
+    import ogc_amd.pointnet2.pointnet2 as api
+    monkeypatch.setattr(api, "_native", oracle.Pointnet2CudaCPU())
+    from ogc_amd import train_flow
+    cfg = {
+        "dataset": "sapien", "save_path": str(tmp_path / "ckpt" / "flow"), "random_seed": 10,
+        "flownet": {"npoint": 256, "use_instance_norm": False, "loc_flow_nn": 8, "loc_flow_rad": 0.1, "k_decay_fact": 1.0},
+        "model_iters": 2, "epochs": 2, "batch_size": 2, "lr": 1e-3, "lr_decay": 0.5, "lr_clip": 1e-5,
+        "bn_momentum": 0.9, "bn_decay": 0.5, "weight_decay": 0.0, "decay_step": 4,
+        "loss": {"weights": [0.75, 0.25], "iters_w": [0.5, 0.3], "chamfer_loss_params": {"loss_norm": 2},
+                 "smooth_loss_params": {"w_knn": 3.0, "w_ball_q": 1.0,
+                                        "knn_loss_params": {"k": 4, "radius": 0.05, "loss_norm": 1},
+                                        "ball_q_loss_params": {"k": 8, "radius": 0.1, "loss_norm": 1}}},
+    }
+    path = tmp_path / "flow.yaml"
+    path.write_text(yaml.safe_dump(cfg))
+    train_flow.main([str(path), "--synthetic", "4", "--device", "cpu"])
+    for name in ("current.pth.tar", "best.pth.tar"):
+        state = torch.load(os.path.join(cfg["save_path"], name))
+        assert list(state.keys()) == ["model_state"]
+        assert "encoder_loc.sa1.mlp_convs.0.weight" in state["model_state"]
+        assert "global_corr_layer.epsilon" in state["model_state"]
+    lines = [json.loads(l) for l in capsys.readouterr().out.splitlines() if l.startswith("{")]
+    assert len(lines) == 2
+    assert set(lines[0]["train"]) == {"chamfer_loss_#0", "smooth_loss_#0", "chamfer_loss_#1", "smooth_loss_#1", "sum"}
+    assert lines[1]["lr"] == 0.5e-3                                          # lr_curve: 4 samples seen -> one decay
+    assert all(v == v for v in lines[1]["train"].values())

@@ -34,16 +34,26 @@ net.train()
 crit = UnsupervisedFlowStep3DLoss(ChamferLoss(2), SmoothLoss(3., 1., {'k': 4, 'radius': 0.5, 'loss_norm': 1},
                                                               {'k': 8, 'radius': 1.0, 'loss_norm': 1}),
                                   weights=[0.75, 0.25], iters_w=[0.8, 0.2, 0.4, 0.6])
-opt = torch.optim.Adam(net.parameters(), lr=1e-3)
-
-
-def step():
-    opt.zero_grad(set_to_none=True)
-    preds = net(pc1, pc2, pc1, pc2, iters=4)
-    loss, _ = crit(pc1, pc2, preds)
-    loss.backward()
-    opt.step()
-
+from ogc_amd.train_step import flow_train_step, make_optimizer
+opt = make_optimizer(net.parameters(), lr=1e-3)
+batch = (pcs, None, flows, None)
 
 if B > 1:
+    state = {}
+    def step():
+        state["p"] = flow_train_step(net, crit, opt, batch, 4, sync=False)
     print("train step iters=4 (B=%d): %.2f ms" % (B, timed(step)))
+    print(state["p"].result())
+
+# the correlation layer alone (config C3: 2048 points of each cloud at level 2, 64-d features, 16 neighbours)
+from ogc_amd.utils.flowstep3d_util import FlowEmbedding
+corr = net.local_corr_layer
+g = torch.Generator().manual_seed(3)
+p1 = ((torch.rand(B, 3, 2048, generator=g) - 0.5) * torch.tensor([60.0, 4.0, 80.0]).view(1, 3, 1)).to(dev)
+p2 = (p1 + 0.1 * torch.randn(B, 3, 2048, generator=g).to(dev)).contiguous()
+f1, f2 = torch.randn(B, 64, 2048, generator=g).to(dev), torch.randn(B, 64, 2048, generator=g).to(dev)
+net.eval()
+with torch.no_grad():
+    ms = timed(lambda: corr(p1, p2, f1, f2), reps=20, warm=5)
+flops = 2.0 * B * 2048 * 16 * (131 * 128 + 128 * 128 + 128 * 128)
+print("correlation layer fwd (eval, B=%d, 2048 pts, k=16): %.3f ms  -> %.2f TFLOP/s of the 3 GEMMs" % (B, ms, flops / ms / 1e9))
