@@ -190,6 +190,16 @@ int ogc_neighbour_consistency_bwd(int b, int n, int c, int k, int p, const float
                                   const int *rev_start, const int *rev_src, const int *rev_mult, const float *grad_out,
                                   float *grad_mask, ogc_stream_t stream);
 
+/* Soft nearest-neighbour targets of object-aware ICP, fused.  Replaces, per refinement iteration of
+ *   oa_icp.py:62-72:  corr = softmax(-cdist(p1, p2) / temperature); corr *= mask1 @ mask2^T;
+ *                     corr /= corr.sum(-1).clamp(1e-10); target = corr @ p2
+ * (two (b, n1, n2) tensors — 1 GB each at b = 4, n = 8192 — written and re-read several times) by one pass with
+ * running-maximum rescaling.  p1 (b,n1,3) warped source points, p2 (b,n2,3), mask1 (b,n1,k), mask2 (b,n2,k) with the
+ * slots of mask2 already permuted to mask1's order; target (b,n1,3) out.  Distances use torch.cdist's large-matrix
+ * formula (|a|^2 + |b|^2 - 2 a.b, clamped, sqrt).  k <= 32. */
+int ogc_soft_nn_target(int b, int n1, int n2, int k, float temperature, const float *p1, const float *p2,
+                       const float *mask1, const float *mask2, float *target, ogc_stream_t stream);
+
 /* Fused GroupNorm (+ ReLU) forward / backward.  Replaces the nn.GroupNorm -> ReLU(inplace) tail of every
  * Conv2d block of the segmentation nets' SharedMLPs
  *   utils/nn_util.py:6-11 (GroupNorm), :45-85 (_ConvBase ordering), models/segnet_kitti.py:8 (BN_CONFIG).

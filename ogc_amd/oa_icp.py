@@ -1,8 +1,8 @@
 """Object-aware ICP: scene-flow refinement from object masks (reference: oa_icp.py:16-84).
 
 ``weighted_kabsch`` and ``object_aware_icp`` keep the reference's signatures and results.  The per-slot clouds
-are broadcast views instead of K-fold ``repeat`` copies; the round driver (oa_icp.py:87-236, dataset I/O) is
-outside the hot path.
+are broadcast views instead of K-fold ``repeat`` copies; on the GPU the soft correspondence step of every iteration
+is one fused kernel (no (B, N, N) tensors); the round driver (oa_icp.py:87-236, dataset I/O) is outside the hot path.
 """
 import torch
 
@@ -35,9 +35,22 @@ def object_aware_icp(pc1, pc2, flow, mask1, mask2, icp_iter=10, temperature=0.01
     perm = match_mask_by_iou(mask2_interpolated, mask2)
     mask2 = torch.einsum('bij,bnj->bni', perm, mask2)
 
-    consistency12 = torch.einsum('bmk,bnk->bmn', mask1, mask2)   # object-consistency scores (B, N1, N2)
     mask1_t = mask1.transpose(1, 2)
+    from .pointnet2 import pointnet2 as _api
+    fused = getattr(_api._native, "soft_nn_target_wrapper", None)
+    if (fused is not None and pc1.is_cuda and mask1.shape[2] <= 32
+            and not any(t.requires_grad for t in (pc1, pc2, flow, mask1, mask2))):
+        # one pass per iteration, nothing of size (B, N1, N2) is materialised (ogc_soft_nn_target)
+        B, N1, K = mask1.shape
+        N2 = pc2.shape[1]
+        pc2c, m1c, m2c = pc2.contiguous().float(), mask1.contiguous().float(), mask2.contiguous().float()
+        target = torch.empty(B, N1, 3, dtype=torch.float32, device=pc1.device)
+        for _ in range(icp_iter):
+            fused(B, N1, N2, K, temperature, (pc1 + flow).contiguous().float(), pc2c, m1c, m2c, target)
+            flow = _rigid_flow_per_object(pc1, target - pc1, mask1_t)
+        return flow
 
+    consistency12 = torch.einsum('bmk,bnk->bmn', mask1, mask2)   # object-consistency scores (B, N1, N2)
     for _ in range(icp_iter):
         corr12 = (-torch.cdist(pc1 + flow, pc2) / temperature).softmax(-1)
         corr12 = corr12 * consistency12

@@ -163,6 +163,12 @@ def group_concat_grad_wrapper(b, c, n, npoints, nsample, grad_out, idx, grad_poi
          _f(grad_points, "grad_points"))
 
 
+def soft_nn_target_wrapper(b, n1, n2, k, temperature, p1, p2, mask1, mask2, target):
+    """Soft nearest-neighbour targets of OA-ICP without the (b, n1, n2) tensors (ogc_soft_nn_target)."""
+    _run("ogc_soft_nn_target", p1, b, n1, n2, k, float(temperature), _f(p1, "p1"), _f(p2, "p2"), _f(mask1, "mask1"),
+         _f(mask2, "mask2"), _f(target, "target"))
+
+
 def lsap_maximize_wrapper(np_, k, score, col4row):
     """Batched maximising linear-sum assignment with scipy's tie-breaking (ogc_lsap_maximize)."""
     _run("ogc_lsap_maximize", score, np_, k, _f(score, "score"), _i(col4row, "col4row"))

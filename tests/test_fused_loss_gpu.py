@@ -69,3 +69,35 @@ def test_smooth_loss_fused_matches_generic():
     torch.stack(plain).sum().backward()
     torch.testing.assert_close(torch.stack(fused), torch.stack(plain), rtol=1e-5, atol=1e-7)
     torch.testing.assert_close(g_fused, logits.grad, rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("shape", [(2, 300, 257, 6), (1, 1024, 1500, 10), (3, 64, 64, 17), (2, 700, 90, 32)])
+@pytest.mark.parametrize("scale", [1.0, 40.0])
+def test_soft_nn_target(shape, scale):
+    """ogc_soft_nn_target vs the reference's op sequence (oa_icp.py:62-72) in fp64 and in fp32 torch."""
+    from ogc_amd import pointnet2_cuda as nat
+    B, N1, N2, K = shape
+    g = torch.Generator().manual_seed(sum(shape) + int(scale))
+    p2 = ((torch.rand(B, N2, 3, generator=g) - 0.5) * scale).cuda()
+    src = torch.randint(0, N2, (B, N1), generator=g).cuda()
+    p1 = (torch.gather(p2, 1, src.unsqueeze(-1).expand(-1, -1, 3)) + 0.02 * torch.randn(B, N1, 3, generator=g).cuda())
+    m1 = torch.randn(B, N1, K, generator=g).cuda().mul(3).softmax(-1)
+    m2 = torch.randn(B, N2, K, generator=g).cuda().mul(3).softmax(-1)
+    m1[:, ::7] = torch.eye(K).cuda()[0]                      # some rows with (near-)zero consistency everywhere
+    m2[:, :, 0] = 0.0
+    tau = 0.01
+    out = torch.empty(B, N1, 3, device="cuda")
+    nat.soft_nn_target_wrapper(B, N1, N2, K, tau, p1.contiguous(), p2.contiguous(), m1.contiguous(), m2.contiguous(), out)
+
+    def ref(dtype):
+        a, b_, ma, mb = p1.to(dtype), p2.to(dtype), m1.to(dtype), m2.to(dtype)
+        corr = (-torch.cdist(a, b_) / tau).softmax(-1)
+        corr = corr * torch.einsum('bmk,bnk->bmn', ma, mb)
+        corr = corr / corr.sum(-1, keepdim=True).clamp(1e-10)
+        return torch.einsum('bmn,bnj->bmj', corr, b_)
+
+    exact, single = ref(torch.float64), ref(torch.float32)
+    # rows whose consistency sum is below the clamp are tiny numbers divided by 1e-10: compare the others relatively
+    err_kernel = (out.double() - exact).abs().max().item()
+    err_torch = (single.double() - exact).abs().max().item()
+    assert err_kernel <= max(4.0 * err_torch, 1e-5 * scale), (err_kernel, err_torch)
