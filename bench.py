@@ -192,6 +192,7 @@ def main():
                                    "+ bwd + Adam, %d samples x 4 views x %d pts per GPU" % (a.batch, a.npoint),
                        "clouds_per_step_per_gpu": clouds_per_step, "n_point": a.npoint, "n_slot": 10,
                        "parallelism": "dp%d" % world, "optimizer_stepped": bool(stepped),
+                       "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
                        "loss": {k: round(v, 5) for k, v in loss_dict.items()}},
             "roofline": roof,
             "kernel_ms": others,

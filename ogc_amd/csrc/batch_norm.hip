@@ -361,7 +361,7 @@ extern "C" int ogc_batch_norm_fwd(int b, int c, int hw, float eps, int relu, int
     OGC_REQUIRE(b >= 0 && c >= 1 && hw >= 1, "ogc_batch_norm_fwd: bad shape");
     if (b == 0) return OGC_OK;
     OGC_REQUIRE(x && gamma && beta && y && mean && rstd, "ogc_batch_norm_fwd: null pointer");
-    OGC_REQUIRE((long long)b * c * hw < (1ll << 31), "ogc_batch_norm_fwd: tensor exceeds 32-bit indexing");
+    OGC_REQUIRE((long long)c * hw < (1ll << 31) && b <= 65535, "ogc_batch_norm_fwd: one sample exceeds 32-bit indexing");
     hipStream_t s = (hipStream_t)stream;
     const int rc = bn_prepare("ogc_batch_norm_fwd", b, c, hw, eps, training, momentum, x, running_mean, running_var,
                               mean, rstd, ws, stats, slots, s);
@@ -420,7 +420,8 @@ extern "C" int ogc_batch_norm_maxpool_fwd(int b, int c, int p, int s, float eps,
     }
     if (b == 0) return OGC_OK;
     OGC_REQUIRE(x && gamma && beta && out && argmax && mean && rstd, "ogc_batch_norm_maxpool_fwd: null pointer");
-    OGC_REQUIRE((long long)b * c * p * s < (1ll << 31), "ogc_batch_norm_maxpool_fwd: tensor exceeds 32-bit indexing");
+    OGC_REQUIRE((long long)c * p * s < (1ll << 31) && b <= 65535,
+                "ogc_batch_norm_maxpool_fwd: one sample exceeds 32-bit indexing");
     hipStream_t st = (hipStream_t)stream;
     const int rc = bn_prepare("ogc_batch_norm_maxpool_fwd", b, c, p * s, eps, training, momentum, x, running_mean,
                               running_var, mean, rstd, ws, stats, slots, st);

@@ -274,8 +274,9 @@ int gemm_check(const char *name, int b, int M, int K, int hw, const float *w, co
                       4 * FW_KQ_MAX, hw, K);
         return OGC_ERR_UNSUPPORTED;
     }
-    OGC_REQUIRE((long long)b * M * hw < (1ll << 31) && (long long)b * K * hw < (1ll << 31),
-                "%s: tensor exceeds 32-bit indexing", name);
+    // batch offsets are 64-bit in the kernels; only one sample's activation must fit 32-bit offsets
+    OGC_REQUIRE((long long)M * hw < (1ll << 31) && (long long)K * hw < (1ll << 31) && b <= 65535,
+                "%s: one sample exceeds 32-bit indexing", name);
     return OGC_OK;
 }
 
@@ -324,8 +325,8 @@ extern "C" int ogc_conv1x1_wgrad(int b, int cin, int cout, int hw, const float *
         ogc_set_error("ogc_conv1x1_wgrad: hw=%d must be a multiple of 16 and x/dy 16-byte aligned", hw);
         return OGC_ERR_UNSUPPORTED;
     }
-    OGC_REQUIRE((long long)b * cin * hw < (1ll << 31) && (long long)b * cout * hw < (1ll << 31),
-                "ogc_conv1x1_wgrad: tensor exceeds 32-bit indexing");
+    OGC_REQUIRE((long long)cin * hw < (1ll << 31) && (long long)cout * hw < (1ll << 31),
+                "ogc_conv1x1_wgrad: one sample exceeds 32-bit indexing");
     hipStream_t s = (hipStream_t)stream;
     if (hipMemsetAsync(dw, 0, sizeof(float) * (size_t)cin * cout, s) != hipSuccess) {
         ogc_set_error("ogc_conv1x1_wgrad: memset failed");

@@ -178,8 +178,9 @@ int group_fwd(const char *name, int b, int c, int n, int T, const float *points,
     OGC_REQUIRE(b >= 0 && c >= 0 && n >= 0 && T >= 0, "%s: negative dimension", name);
     if (b == 0 || c == 0 || T == 0) return OGC_OK;
     OGC_REQUIRE(points && idx && out, "%s: null pointer", name);
-    OGC_REQUIRE((long long)b * out_bstride < (1ll << 31) && (long long)b * c * n < (1ll << 31),
-                "%s: tensor exceeds 32-bit indexing (group_points_gpu.cu:63)", name);
+    // the reference indexes the whole tensor with 32-bit ints (group_points_gpu.cu:63); here batch offsets are 64-bit
+    OGC_REQUIRE(out_bstride < (1ll << 31) && (long long)c * n < (1ll << 31) && b <= 65535,
+                "%s: one sample exceeds 32-bit indexing", name);
     const bool vec = (T % 4 == 0) && aligned16(idx) && aligned16(out) && out_bstride % 4 == 0;
     const int bx = ogc_divup(T, vec ? GG_THREADS * 4 : GG_THREADS);
     const int cpb = pick_ch_per_block(b, c, bx);
@@ -200,8 +201,8 @@ int group_bwd(const char *name, int b, int c, int n, int T, const float *grad_ou
     OGC_REQUIRE(b >= 0 && c >= 0 && n >= 0 && T >= 0, "%s: negative dimension", name);
     if (b == 0 || c == 0 || T == 0) return OGC_OK;
     OGC_REQUIRE(grad_out && idx && grad_points, "%s: null pointer", name);
-    OGC_REQUIRE((long long)b * go_bstride < (1ll << 31) && (long long)b * c * n < (1ll << 31),
-                "%s: tensor exceeds 32-bit indexing", name);
+    OGC_REQUIRE(go_bstride < (1ll << 31) && (long long)c * n < (1ll << 31) && b <= 65535,
+                "%s: one sample exceeds 32-bit indexing", name);
     const bool vec = (T % 4 == 0) && aligned16(idx) && aligned16(grad_out) && go_bstride % 4 == 0;
     // LDS-privatised path: the per-channel image (n floats) must fit a 64 KiB budget at least once
     if (vec && n <= 16384 && T >= 4096 && T % 16 == 0) {
@@ -275,7 +276,7 @@ extern "C" int ogc_group_concat(int b, int c, int n, int npoints, int nsample, c
     if (b == 0 || T == 0) return OGC_OK;
     OGC_REQUIRE(xyz && new_xyz && idx && out && (points || c == 0), "ogc_group_concat: null pointer");
     const long long bstride = (long long)(3 + c) * T;
-    OGC_REQUIRE((long long)b * bstride < (1ll << 31), "ogc_group_concat: tensor exceeds 32-bit indexing");
+    OGC_REQUIRE(bstride < (1ll << 31) && b <= 65535, "ogc_group_concat: one sample exceeds 32-bit indexing");
     hipLaunchKernelGGL(group_xyz_rel_kernel, dim3(ogc_divup(T, GG_THREADS), b), dim3(GG_THREADS), 0,
                        (hipStream_t)stream, n, npoints, nsample, bstride, xyz, new_xyz, idx, out);
     OGC_CHECK_LAUNCH("ogc_group_concat");

@@ -388,7 +388,7 @@ int gn_fwd_impl(const char *name, int b, int c, int hw, int groups, float eps, i
     OGC_REQUIRE(b >= 0 && c >= 1 && hw >= 1 && groups >= 1 && c % groups == 0, "%s: bad shape", name);
     if (b == 0) return OGC_OK;
     OGC_REQUIRE(x && gamma && beta && y && mean && rstd && (ws || stats), "%s: null pointer", name);
-    OGC_REQUIRE((long long)b * c * hw < (1ll << 31), "%s: tensor exceeds 32-bit indexing", name);
+    OGC_REQUIRE((long long)c * hw < (1ll << 31) && b <= 65535, "%s: one sample exceeds 32-bit indexing", name);
     hipStream_t s = (hipStream_t)stream;
     if (!stats) {
         const int rows = b * groups;
@@ -481,7 +481,7 @@ int gn_pool_fwd_impl(const char *name, int b, int c, int p, int s, int groups, f
     }
     if (b == 0) return OGC_OK;
     OGC_REQUIRE(x && gamma && beta && out && argmax && mean && rstd && (ws || stats), "%s: null pointer", name);
-    OGC_REQUIRE((long long)b * c * p * s < (1ll << 31), "%s: tensor exceeds 32-bit indexing", name);
+    OGC_REQUIRE((long long)c * p * s < (1ll << 31) && b <= 65535, "%s: one sample exceeds 32-bit indexing", name);
     hipStream_t st = (hipStream_t)stream;
     if (!stats) {
         const int rows = b * groups;

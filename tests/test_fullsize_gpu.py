@@ -149,3 +149,46 @@ def test_train_step_is_deterministic_in_indices_and_finite():
         vals.append(ld)
     for k in vals[0]:
         assert abs(vals[0][k] - vals[1][k]) <= 1e-5 * max(1.0, abs(vals[0][k])), k
+
+
+@pytest.mark.gpu
+def test_activations_beyond_2_31_elements():
+    """288 GB sizing: activation tensors with more than 2^31 elements (the reference's kernels index with 32-bit ints,
+    group_points_gpu.cu:63).  Conv + fused GroupNorm statistics + apply on a (34, 64, 2^20) output (2.28e9 elements):
+    the last sample must equal the same sample computed alone."""
+    from ogc_amd import pointnet2_cuda as nat
+    free, _ = torch.cuda.mem_get_info()
+    if free < 40 * 2 ** 30:
+        pytest.skip("needs ~35 GiB of free HBM")
+    B, cin, cout, hw, groups = 34, 32, 64, 1 << 20, 4
+    assert B * cout * hw > 2 ** 31
+    g = torch.Generator().manual_seed(7)
+    w = torch.randn(cout, cin, generator=g).cuda()
+    gamma, beta = torch.rand(cout, generator=g).cuda() + 0.5, torch.randn(cout, generator=g).cuda()
+    x = torch.empty(B, cin, hw, device="cuda")
+    x.normal_(generator=torch.Generator(device="cuda").manual_seed(3))
+
+    def run(xs):
+        b = xs.shape[0]
+        y = torch.empty(b, cout, hw, device="cuda")
+        slots = nat.conv1x1_gn_slots()
+        stats = torch.empty(slots * b * groups * 2, dtype=torch.float64, device="cuda")
+        nat.conv1x1_gemm_gnstats_wrapper(b, cout, cin, hw, groups, w, xs, y, stats)
+        z = torch.empty_like(y)
+        mean, rstd = torch.empty(b * groups, device="cuda"), torch.empty(b * groups, device="cuda")
+        nat.group_norm_fwd_stats_wrapper(b, cout, hw, groups, 1e-5, 1, y, gamma, beta, z, mean, rstd, stats, slots)
+        return y, z, mean
+
+    y, z, mean = run(x)
+    y1, z1, mean1 = run(x[-1:].contiguous())
+    assert torch.equal(y[-1:], y1)
+    torch.testing.assert_close(z[-1:], z1, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(mean[-groups:], mean1, rtol=1e-6, atol=1e-7)
+    # weight gradient over the whole batch == sum of two halves
+    dw = torch.empty(cout, cin, device="cuda")
+    nat.conv1x1_wgrad_wrapper(B, cin, cout, hw, x, z, dw)
+    half = B // 2
+    dwa, dwb = torch.empty_like(dw), torch.empty_like(dw)
+    nat.conv1x1_wgrad_wrapper(half, cin, cout, hw, x[:half], z[:half], dwa)
+    nat.conv1x1_wgrad_wrapper(B - half, cin, cout, hw, x[half:], z[half:], dwb)
+    torch.testing.assert_close(dw, dwa + dwb, rtol=1e-4, atol=1e-1)
