@@ -172,7 +172,14 @@ def main():
                             "cell-list search tests ~N/60 candidates per centre, so the all-pairs figure of 8*B*N*M "
                             "flop no longer describes the work done; in the step the operator runs on a side stream "
                             "underneath the dense kernels, which lengthens it versus an idle GPU (tools/bench_ops.py)",
-                    "all_pairs_equivalent_tpairs_per_s": round(b_ * n_ * m_ / (ms * 1e-3) / 1e12, 2)}
+                    "all_pairs_equivalent_tpairs_per_s": round(b_ * n_ * m_ / (ms * 1e-3) / 1e12, 2),
+                    # offline (rocprofv3 --pmc SQ_INSTS_VALU + --kernel-trace, profiles/r01_ball_query_pmc_v2.txt):
+                    # what actually bounds the search kernel is VALU issue, not HBM
+                    "valu_issue_offline": {"kernel": "ball_query_grid_kernel", "wave_insts": 12.84e6, "kernel_us": 29.4,
+                                           "achieved_ginst_s": round(12.84e6 / 29.4e-6 / 1e9, 1),
+                                           "peak_ginst_s": round(256 * 4 * 2.4 / 4 * 1e3 / 1e3, 1),
+                                           "frac": round(12.84e6 / 29.4e-6 / (256 * 4 * 2.4e9 / 4), 3),
+                                           "shape": "B=16, N=M=8192, nsample=64"}}
         others = {}
         for name in ("ogc_knn_clamped", "ogc_furthest_point_sampling"):
             if name in durs:
