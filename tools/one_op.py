@@ -17,4 +17,11 @@ for _ in range(reps):
     elif op == "fps":
         idx = torch.empty(B, 2048, dtype=torch.int32, device="cuda"); temp = torch.full((B, 8192), 1e10, device="cuda")
         nat.furthest_point_sampling_wrapper(B, 8192, 2048, pc, temp, idx)
+if op == "conv":  # 128 -> 128 on (B, 128, 512*64): the MFMA-bound layer shape of SA3
+    x = torch.randn(B, 128, 32768, device="cuda"); w = torch.randn(128, 128, device="cuda")
+    y = torch.empty(B, 128, 32768, device="cuda"); dw = torch.empty(128, 128, device="cuda")
+    for _ in range(reps):
+        nat.conv1x1_gemm_wrapper(B, 128, 128, 32768, 0, w, x, y)
+        nat.conv1x1_gemm_wrapper(B, 128, 128, 32768, 1, w, y, x)
+        nat.conv1x1_wgrad_wrapper(B, 128, 128, 32768, x, y, dw)
 torch.cuda.synchronize()

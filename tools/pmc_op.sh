@@ -3,7 +3,8 @@
 # (counter passes carry --kernel-trace only).   tools/pmc_op.sh ball 16 [name-filter] > profiles/rNN_<op>_pmc.txt
 OP=${1:-ball}; B=${2:-16}; FILTER=${3:-grid}
 export TMPDIR=/tmp
-for PM in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU"; do
+EXTRA=${4:-}
+for PM in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" $EXTRA; do
   rm -rf /tmp/pmc
   timeout 300 rocprofv3 --pmc $PM --kernel-trace --output-format csv -d /tmp/pmc -o p -- python tools/one_op.py $OP $B 3 > /dev/null 2>&1
   python - "$FILTER" <<'PY'
