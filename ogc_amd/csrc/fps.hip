@@ -201,6 +201,108 @@ __global__ __launch_bounds__(1024) void fps_mem_kernel(int n, int m, int bs_shif
     }
 }
 
+// Large single clouds (the 10^5-point raw scans of the test / data-preparation pipelines, utils/data_util.py:8-20):
+// G workgroups per cloud, each with its slice of the points and their running minimum distances in registers.  A
+// round = local update + local winner -> one 64-bit (distance bits, ~rank) word per workgroup in global memory ->
+// grid barrier on a per-cloud counter -> every workgroup reduces the G words itself (one lane per word) and fetches
+// the winner's coordinates.  The words are double-buffered by round parity; a workgroup cannot run two rounds ahead
+// because every round needs everyone's arrival.  Launched cooperatively (all workgroups resident, or the launch
+// fails and the one-workgroup kernel above runs instead); the wait is bounded so that a lost workgroup cannot hang
+// the device.
+constexpr int FPS_COOP_PTS = 4;      // points per thread
+constexpr int FPS_COOP_THREADS = 1024;
+
+__global__ __launch_bounds__(FPS_COOP_THREADS) void fps_coop_kernel(int n, int m, int bs_shift, int G,
+                                                                    const float *__restrict__ xyz,
+                                                                    float *__restrict__ temp, int *__restrict__ idxs,
+                                                                    u64 *__restrict__ words /* [b][2][G] */,
+                                                                    unsigned *__restrict__ counters /* [b] */) {
+    __shared__ u64 s_best[2];
+    __shared__ u64 s_winner;
+    const int t = threadIdx.x, lane = t & 63;
+    const int b = blockIdx.x / G, g = blockIdx.x % G;
+    const float *__restrict__ dataset = xyz + (size_t)b * n * 3;
+    float *tmp = temp + (size_t)b * n;
+    int *out = idxs + (size_t)b * m;
+    u64 *wb = words + (size_t)b * 2 * G;
+    unsigned *counter = counters + b;
+    const int bs_mask = (1 << bs_shift) - 1;
+    const int S = (n + bs_mask) >> bs_shift;
+    const int slice = (n + G - 1) / G;
+    const int k0 = g * slice;
+    // this thread's points: k0 + t + j * 1024
+    float px[FPS_COOP_PTS], py[FPS_COOP_PTS], pz[FPS_COOP_PTS], td[FPS_COOP_PTS];
+    unsigned inv_rank[FPS_COOP_PTS];
+#pragma unroll
+    for (int j = 0; j < FPS_COOP_PTS; ++j) {
+        const int k = k0 + t + j * FPS_COOP_THREADS;
+        const bool ok = k < min(n, k0 + slice);
+        px[j] = ok ? dataset[k * 3] : 0.f;
+        py[j] = ok ? dataset[k * 3 + 1] : 0.f;
+        pz[j] = ok ? dataset[k * 3 + 2] : 0.f;
+        td[j] = ok ? tmp[k] : -1.0f; // padding can never win (distances are >= 0)
+        inv_rank[j] = ok ? 0xFFFFFFFFu - fps_rank(k, bs_mask, bs_shift, S) : 0u;
+    }
+    if (t == 0) { s_best[0] = 0ull; s_best[1] = 0ull; }
+    if (g == 0 && t == 0) out[0] = 0;
+    __syncthreads();
+    float x1 = dataset[0], y1 = dataset[1], z1 = dataset[2];
+    for (int r = 1; r < m; ++r) {
+        const int par = r & 1;
+        u64 best = 0ull;
+#pragma unroll
+        for (int j = 0; j < FPS_COOP_PTS; ++j) {
+            const float d = ogc_sqdist(px[j], py[j], pz[j], x1, y1, z1);
+            if (td[j] >= 0.0f) td[j] = ogc_min_f32(d, td[j]);
+            const u64 key = ((u64)__float_as_uint(fmaxf(td[j], 0.0f)) << 32) | inv_rank[j];
+            if (td[j] >= 0.0f && key > best) best = key;
+        }
+        // wave max of the 64-bit key, then one LDS atomic per wave
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned lo = __shfl_xor((unsigned)best, off, 64), hi = __shfl_xor((unsigned)(best >> 32), off, 64);
+            const u64 o = ((u64)hi << 32) | lo;
+            if (o > best) best = o;
+        }
+        if (lane == 0) atomicMax(&s_best[par], best);
+        if (t == 0) s_best[par ^ 1] = 0ull;
+        __syncthreads();
+        if (t < 64) { // first wave: publish, barrier, reduce the G words
+            if (t == 0) {
+                __hip_atomic_store(&wb[par * G + g], s_best[par], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned want = (unsigned)G * (unsigned)r;
+                long long spins = 0;
+                while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want && spins < (1ll << 22))
+                    ++spins;
+            }
+            __builtin_amdgcn_wave_barrier();
+            u64 wv = 0ull;
+            for (int i = lane; i < G; i += 64) {
+                const u64 v = __hip_atomic_load(&wb[par * G + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (v > wv) wv = v;
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const unsigned lo = __shfl_xor((unsigned)wv, off, 64), hi = __shfl_xor((unsigned)(wv >> 32), off, 64);
+                const u64 o = ((u64)hi << 32) | lo;
+                if (o > wv) wv = o;
+            }
+            if (t == 0) s_winner = wv;
+        }
+        __syncthreads();
+        const unsigned rho = 0xFFFFFFFFu - (unsigned)s_winner;
+        const int k = fps_rank_to_k(rho, S, bs_shift);
+        x1 = dataset[k * 3]; y1 = dataset[k * 3 + 1]; z1 = dataset[k * 3 + 2];
+        if (g == 0 && t == 0) out[r] = k;
+    }
+#pragma unroll
+    for (int j = 0; j < FPS_COOP_PTS; ++j) {
+        const int k = k0 + t + j * FPS_COOP_THREADS;
+        if (k < min(n, k0 + slice)) tmp[k] = td[j];
+    }
+}
+
 // cuda_utils.h:10-14 opt_n_threads(), evaluated through double log() exactly like the reference.
 int fps_ref_block_shift(int work_size) {
     int pow_2 = (int)(log((double)work_size) / log(2.0));
@@ -257,8 +359,27 @@ extern "C" int ogc_furthest_point_sampling(int b, int n, int m, const float *xyz
     else if (slots <= 4096) fps_launch<8, 512>(b, n, m, shift, xyz, temp, idx, s);
     else if (slots <= 8192) fps_launch<16, 512>(b, n, m, shift, xyz, temp, idx, s);
     else if (slots <= 16384) fps_launch<32, 512>(b, n, m, shift, xyz, temp, idx, s);
-    else
-        hipLaunchKernelGGL(fps_mem_kernel, dim3(b), dim3(1024), 0, s, n, m, shift, xyz, temp, idx);
+    else {
+        // cooperative multi-workgroup kernel when the whole job fits on the chip at once, else one workgroup per cloud
+        static const char *mode = getenv("OGC_FPS_LARGE"); // "single": development override
+        const int G = ogc_divup(n, FPS_COOP_PTS * FPS_COOP_THREADS);
+        bool done = false;
+        if (!(mode && mode[0] == 's') && (long long)b * G <= 256 && G <= 64 * 16) {
+            const size_t bytes_words = sizeof(u64) * (size_t)b * 2 * G;
+            char *ws = static_cast<char *>(ogc_workspace(s, bytes_words + sizeof(unsigned) * b));
+            if (ws && hipMemsetAsync(ws, 0, bytes_words + sizeof(unsigned) * b, s) == hipSuccess) {
+                u64 *words = reinterpret_cast<u64 *>(ws);
+                unsigned *counters = reinterpret_cast<unsigned *>(ws + bytes_words);
+                int gg = G;
+                void *args[] = {&n, &m, const_cast<int *>(&shift), &gg, &xyz, &temp, &idx, &words, &counters};
+                const hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(fps_coop_kernel),
+                                                                dim3(b * G), dim3(FPS_COOP_THREADS), args, 0, s);
+                if (e == hipSuccess) done = true;
+                else (void)hipGetLastError();
+            }
+        }
+        if (!done) hipLaunchKernelGGL(fps_mem_kernel, dim3(b), dim3(1024), 0, s, n, m, shift, xyz, temp, idx);
+    }
     OGC_CHECK_LAUNCH("ogc_furthest_point_sampling");
     return OGC_OK;
 }

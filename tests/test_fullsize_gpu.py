@@ -192,3 +192,35 @@ def test_activations_beyond_2_31_elements():
     nat.conv1x1_wgrad_wrapper(half, cin, cout, hw, x[:half], z[:half], dwa)
     nat.conv1x1_wgrad_wrapper(B - half, cin, cout, hw, x[half:], z[half:], dwb)
     torch.testing.assert_close(dw, dwa + dwb, rtol=1e-4, atol=1e-1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(1, 20000, 1500), (2, 50001, 700), (1, 16385, 300), (3, 30000, 64)])
+def test_fps_large_clouds_match_oracle(shape, oracle):
+    """N > 16384 (raw scans, utils/data_util.py:8-20): the cooperative multi-workgroup kernel and the one-workgroup
+    kernel both reproduce the oracle's indices, ties included (a lattice has thousands of equal distances)."""
+    import os
+    import subprocess
+    import sys
+    from ogc_amd import pointnet2_cuda as nat
+    B, N, m = shape
+    g = torch.Generator().manual_seed(N)
+    pc = (torch.rand(B, N, 3, generator=g) - 0.5) * torch.tensor([60.0, 4.0, 80.0])
+    pc[0, : N // 2] = torch.round(pc[0, : N // 2])          # lattice half: mass ties
+    want = oracle.fps(pc.numpy(), m)
+    idx = torch.empty(B, m, dtype=torch.int32, device="cuda")
+    temp = torch.full((B, N), 1e10, device="cuda")
+    nat.furthest_point_sampling_wrapper(B, N, m, pc.cuda().contiguous(), temp, idx)
+    np.testing.assert_array_equal(idx.cpu().numpy(), want)
+    # the same through the single-workgroup kernel (separate process: the override is read once)
+    code = ("import sys, torch, numpy as np; sys.path.insert(0, %r); import ogc_amd; from ogc_amd import pointnet2_cuda as nat;"
+            "pc = torch.load(sys.argv[1]).cuda().contiguous(); B, N, _ = pc.shape; m = int(sys.argv[2]);"
+            "idx = torch.empty(B, m, dtype=torch.int32, device='cuda'); temp = torch.full((B, N), 1e10, device='cuda');"
+            "nat.furthest_point_sampling_wrapper(B, N, m, pc, temp, idx); np.save(sys.argv[3], idx.cpu().numpy())")
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        torch.save(pc, os.path.join(d, "pc.pt"))
+        env = dict(os.environ, OGC_FPS_LARGE="single")
+        subprocess.run([sys.executable, "-c", code % os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                        os.path.join(d, "pc.pt"), str(m), os.path.join(d, "out.npy")], check=True, env=env, timeout=300)
+        np.testing.assert_array_equal(np.load(os.path.join(d, "out.npy")), want)
