@@ -1,0 +1,117 @@
+"""One round of scene-flow refinement by object-aware ICP (counterpart of the reference's
+oa_icp.py:87-236 written against this repo's layers).
+
+    python -m ogc_amd.oa_icp_round config.yaml --round R [--save] [--flow-root DIR] [--synthetic N_SCENES]
+
+Kept from the reference so that rounds chain with `train_seg`:
+  * the segmentation YAML (config/seg/*/*.yaml) and the checkpoint `<save_path>_R<round>/best.pth.tar`
+    (`{'model_state': ...}`, oa_icp.py:137-139);
+  * frame pairs `view_sels = [[0, 1], [1, 0]]` of every scene (oa_icp.py:160), flows predicted for both directions;
+  * input flows from `<flow-root>/flow_preds/<predflow_path>[_R<round-1>]/<scene id>/flow{1,2}.npy`
+    (oa_icp.py:143-146, datasets/dataset_kittisf.py:125-137), refined flows written to
+    `<flow-root>/flow_preds/<saveflow_path>_R<round>/<scene id>/flow{1,2}.npy` (oa_icp.py:183-186);
+  * ICP iterations per round {1: 20, 2: 10, 3: 5, 4: 3} (oa_icp.py:175);
+  * the three reported flows: input, weighted-Kabsch, object-aware ICP (end-point error only here; the reference's
+    accuracy / outlier metrics live in metrics/flow_metric.py, out of scope).
+Dataset readers are out of scope: scenes are the seeded synthetic ones of `train_seg`; when no predicted
+flow exists on disk for a scene, the ground-truth flow plus noise stands in for the flow network's prediction.
+"""
+import argparse
+import importlib
+import json
+import os
+
+import numpy as np
+import torch
+import yaml
+
+from .oa_icp import object_aware_icp, weighted_kabsch
+from .train_seg import SEGNETS, SyntheticScenes
+
+ICP_ITERS = {1: 20, 2: 10, 3: 5, 4: 3}
+
+
+def flow_dir(flow_root, name, round_):
+    return os.path.join(flow_root, "flow_preds", name if round_ is None else "%s_R%d" % (name, round_))
+
+
+def load_flows(directory, scene_id, fallback):
+    """(flow 0->1, flow 1->0) of a scene from `<directory>/<scene id>/flow{1,2}.npy`, or `fallback()`."""
+    paths = [os.path.join(directory, scene_id, "flow%d.npy" % v) for v in (1, 2)]
+    if all(os.path.exists(p) for p in paths):
+        return [torch.from_numpy(np.load(p)) for p in paths]
+    return fallback()
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("config")
+    ap.add_argument("--round", type=int, default=1)
+    ap.add_argument("--test_batch_size", type=int, default=8)
+    ap.add_argument("--save", action="store_true")
+    ap.add_argument("--saveflow_path", default="flowstep3d")
+    ap.add_argument("--flow-root", default="ckpt/synthetic_data")
+    ap.add_argument("--synthetic", type=int, default=16, help="number of synthetic scenes")
+    ap.add_argument("--device", default="cuda")
+    args = ap.parse_args(argv)
+    with open(args.config) as f:
+        cfg = yaml.safe_load(f)
+    device = torch.device(args.device)
+
+    seg = cfg["segnet"]
+    MaskFormer3D = importlib.import_module("ogc_amd.models." + SEGNETS[cfg["dataset"]]).MaskFormer3D
+    segnet = MaskFormer3D(n_slot=seg["n_slot"], n_point=seg["n_point"], use_xyz=seg["use_xyz"],
+                          n_transformer_layer=seg["n_transformer_layer"],
+                          transformer_embed_dim=seg["transformer_embed_dim"],
+                          transformer_input_pos_enc=seg["transformer_input_pos_enc"]).to(device)
+    weight_path = os.path.join(cfg["save_path"] + "_R%d" % args.round, "best.pth.tar")
+    segnet.load_state_dict(torch.load(weight_path, map_location=device)["model_state"])
+    segnet.eval()
+
+    predflow = cfg.get("predflow_path", "flowstep3d")
+    in_dir = flow_dir(args.flow_root, predflow, args.round - 1 if args.round > 1 else None)
+    out_dir = flow_dir(args.flow_root, args.saveflow_path, args.round)
+    if args.save:
+        os.makedirs(out_dir, exist_ok=True)
+    outdoor = cfg["dataset"] in ("kittisf", "waymo")
+    scenes = SyntheticScenes(args.synthetic, seg["n_point"], seg["n_slot"], outdoor, seed=1000)
+    icp_iter = ICP_ITERS[args.round]
+    noise = 0.05 if outdoor else 0.005
+
+    sums, count = {"input": 0.0, "kabsch": 0.0, "oa_icp": 0.0}, 0
+    per_batch = max(args.test_batch_size // 2, 1)  # both pairs of a scene stay in one batch (oa_icp.py:179-180)
+    for start in range(0, len(scenes), per_batch):
+        ids = list(range(start, min(start + per_batch, len(scenes))))
+        pc1, pc2, gt, pred = [], [], [], []
+        for i in ids:
+            pcs, _, flows, _ = scenes[i]
+            g = torch.Generator().manual_seed(77 + i)
+            guess = load_flows(in_dir, "%06d" % i, lambda: [flows[v] + noise * torch.randn(flows[v].shape, generator=g)
+                                                            for v in (0, 1)])
+            for a, b_ in ((0, 1), (1, 0)):                  # view_sels [[0, 1], [1, 0]]
+                pc1.append(pcs[a]); pc2.append(pcs[b_]); gt.append(flows[a]); pred.append(guess[a])
+        pc1, pc2 = torch.stack(pc1).to(device), torch.stack(pc2).to(device)
+        gt, pred = torch.stack(gt).to(device), torch.stack(pred).float().to(device)
+        with torch.no_grad():
+            mask1, mask2 = segnet(pc1, pc1), segnet(pc2, pc2)
+            kabsch = weighted_kabsch(pc1, pred, mask1)
+            refined = object_aware_icp(pc1, pc2, pred, mask1, mask2, icp_iter=icp_iter)
+        for key, flow in (("input", pred), ("kabsch", kabsch), ("oa_icp", refined)):
+            sums[key] += float((flow - gt).norm(dim=-1).mean(dim=-1).sum())
+        count += pc1.shape[0]
+        if args.save:
+            host = refined.cpu().numpy()
+            for j, i in enumerate(ids):
+                scene_dir = os.path.join(out_dir, "%06d" % i)
+                os.makedirs(scene_dir, exist_ok=True)
+                np.save(os.path.join(scene_dir, "flow1.npy"), host[2 * j])
+                np.save(os.path.join(scene_dir, "flow2.npy"), host[2 * j + 1])
+    report = {"round": args.round, "icp_iter": icp_iter, "pairs": count,
+              "EPE": {k: round(v / max(count, 1), 5) for k, v in sums.items()},
+              "saved_to": out_dir if args.save else None}
+    print(json.dumps(report), flush=True)
+    return report
+
+
+if __name__ == "__main__":
+    main()

@@ -38,9 +38,12 @@ NORM_LAYERS = (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d, torch.nn.BatchNorm3d,
 class SyntheticScenes(torch.utils.data.Dataset):
     """`n_scene` seeded scenes; item = (pcs (t,N,3), segms (t,N), flows (t,N,3), valids (t,N)), t = 2 or 4 views."""
 
-    def __init__(self, n_scene, n_point, n_object, outdoor, seed=0):
+    def __init__(self, n_scene, n_point, n_object, outdoor, seed=0, predflow_dir=None):
         self.n_scene, self.n_point, self.n_object, self.outdoor, self.seed = n_scene, n_point, n_object, outdoor, seed
         self.aug_transform = False
+        # flows predicted for the two frames of scene i, `<predflow_dir>/<i as %06d>/flow{1,2}.npy` (the layout
+        # datasets/dataset_kittisf.py:125-137 writes and :99-104 reads); ground-truth flows when absent
+        self.predflow_dir = predflow_dir
 
     def __len__(self):
         return self.n_scene
@@ -48,7 +51,13 @@ class SyntheticScenes(torch.utils.data.Dataset):
     def __getitem__(self, i):
         pcs, segms, flows, valids = make_scene_batch(1, self.n_point, self.n_object, seed=self.seed + i,
                                                      outdoor=self.outdoor, aug=self.aug_transform)
-        return pcs[0], segms[0], flows[0], valids[0]
+        pcs, segms, flows, valids = pcs[0], segms[0], flows[0], valids[0]
+        if self.predflow_dir is not None and not self.aug_transform:
+            import numpy as np
+            paths = [os.path.join(self.predflow_dir, "%06d" % i, "flow%d.npy" % v) for v in (1, 2)]
+            if all(os.path.exists(p) for p in paths):
+                flows = torch.stack([torch.from_numpy(np.load(p)).float() for p in paths])
+        return pcs, segms, flows, valids
 
 
 def schedule_factor(cfg, samples_seen):
@@ -94,6 +103,8 @@ def main(argv=None):
     ap.add_argument("--synthetic", type=int, default=64, help="number of synthetic training scenes")
     ap.add_argument("--max-iters", type=int, default=0, help="stop after this many optimisation steps (0 = all epochs)")
     ap.add_argument("--device", default="cuda")
+    ap.add_argument("--flow-root", default=None,
+                    help="read predicted flows from <flow-root>/flow_preds/<predflow_path>[_R<round-1>] (train_seg.py:277-280)")
     args = ap.parse_args(argv)
     with open(args.config) as f:
         cfg = yaml.safe_load(f)
@@ -121,7 +132,12 @@ def main(argv=None):
         if distributed else net
 
     outdoor = cfg["dataset"] in ("kittisf", "waymo")
-    train_set = SyntheticScenes(args.synthetic, seg["n_point"], seg["n_slot"], outdoor, seed=1000 * (rank + 1))
+    predflow_dir = None
+    if args.flow_root is not None:
+        name = cfg.get("predflow_path", "flowstep3d")
+        predflow_dir = os.path.join(args.flow_root, "flow_preds", name if args.round <= 1 else "%s_R%d" % (name, args.round - 1))
+    train_set = SyntheticScenes(args.synthetic, seg["n_point"], seg["n_slot"], outdoor, seed=1000 * (rank + 1),
+                                predflow_dir=predflow_dir)
     val_set = SyntheticScenes(max(args.synthetic // 8, cfg["batch_size"]), seg["n_point"], seg["n_slot"], outdoor, seed=7)
     sampler = torch.utils.data.distributed.DistributedSampler(train_set) if distributed else None
     train_loader = torch.utils.data.DataLoader(train_set, batch_size=cfg["batch_size"], shuffle=sampler is None,

@@ -85,3 +85,32 @@ def test_flow_driver_runs_and_writes_checkpoints(tmp_path, monkeypatch, oracle, 
     assert set(lines[0]["train"]) == {"chamfer_loss_#0", "smooth_loss_#0", "chamfer_loss_#1", "smooth_loss_#1", "sum"}
     assert lines[1]["lr"] == 0.5e-3                                          # lr_curve: 4 samples seen -> one decay
     assert all(v == v for v in lines[1]["train"].values())
+
+
+def test_train_refine_train_loop(tmp_path, monkeypatch, oracle, capsys):
+    """train_seg round 1 -> oa_icp_round (refined flows on disk in the reference's layout) -> train_seg round 2 reading
+    them: the loop of the reference's README (train_seg.py / oa_icp.py --save / train_seg.py --round 2)."""
+    import json
+    import numpy as np
+    import ogc_amd.pointnet2.pointnet2 as api
+    monkeypatch.setattr(api, "_native", oracle.Pointnet2CudaCPU())
+    from ogc_amd import oa_icp_round, train_seg
+    cfg = dict(CFG, save_path=str(tmp_path / "ckpt" / "seg"), epochs=1)
+    path = tmp_path / "cfg.yaml"
+    path.write_text(yaml.safe_dump(cfg))
+    root = str(tmp_path / "data")
+    train_seg.main([str(path), "--round", "1", "--synthetic", "2", "--device", "cpu"])
+    rep = oa_icp_round.main([str(path), "--round", "1", "--synthetic", "2", "--device", "cpu", "--save", "--flow-root", root,
+                             "--test_batch_size", "4"])
+    assert rep["icp_iter"] == 20 and rep["pairs"] == 4
+    out = os.path.join(root, "flow_preds", "flowstep3d_R1")
+    for scene in ("000000", "000001"):
+        for v in (1, 2):
+            f = np.load(os.path.join(out, scene, "flow%d.npy" % v))
+            assert f.shape == (cfg["segnet"]["n_point"], 3) and f.dtype == np.float32 and np.isfinite(f).all()
+    # round 2 needs the round-2 checkpoint directory to start from scratch weights: train it reading the refined flows
+    train_seg.main([str(path), "--round", "2", "--synthetic", "2", "--device", "cpu", "--flow-root", root])
+    assert os.path.exists(os.path.join(cfg["save_path"] + "_R2", "best.pth.tar"))
+    ds = train_seg.SyntheticScenes(2, cfg["segnet"]["n_point"], cfg["segnet"]["n_slot"], False, seed=1000,
+                                   predflow_dir=out)
+    np.testing.assert_array_equal(ds[1][2][0].numpy(), np.load(os.path.join(out, "000001", "flow1.npy")))
