@@ -273,7 +273,8 @@ int ogc_conv1x1_gemm(int b, int M, int K, int hw, int transpose_a, const float *
  * stats: ogc_conv1x1_gn_slots() copies of a (b, groups, 2) f64 accumulator, slot-major (the copies spread the atomics
  * over cache lines; their sum is the statistic) — overwritten.  Pass it to ogc_group_norm_fwd_stats /
  * ogc_group_norm_maxpool_fwd_stats, which then skip their own statistics pass over the tensor.
- * Requires, beyond ogc_conv1x1_gemm: groups <= 32 and (M / groups) % 4 == 0 (OGC_ERR_UNSUPPORTED otherwise). */
+ * Requires, beyond ogc_conv1x1_gemm: groups <= 32, (M / groups) % 4 == 0 and K <= 100 (OGC_ERR_UNSUPPORTED otherwise:
+ * wider layers run the plain GEMM and the GroupNorm entry points compute their own statistics). */
 int ogc_conv1x1_gn_slots(void);
 int ogc_conv1x1_gemm_gnstats(int b, int M, int K, int hw, int groups, const float *w, const float *in, float *out,
                              double *stats, ogc_stream_t stream);

@@ -307,6 +307,12 @@ extern "C" int ogc_conv1x1_gemm_gnstats(int b, int M, int K, int hw, int groups,
                       groups);
         return OGC_ERR_UNSUPPORTED;
     }
+    if (K > 100) {
+        // with the 33- and 40-float4 input tiles the kernel has no registers to spare: the statistics epilogue costs
+        // 0.08-0.15 ms there against 0.05-0.10 ms for the separate statistics pass (tools/bench_ops.py --ops conv)
+        ogc_set_error("ogc_conv1x1_gemm_gnstats: not profitable for K > 100 (K=%d); use ogc_conv1x1_gemm", K);
+        return OGC_ERR_UNSUPPORTED;
+    }
     if (b == 0) return OGC_OK;
     if (hipMemsetAsync(stats, 0, sizeof(double) * 2 * GN_SLOTS * (size_t)b * groups, (hipStream_t)stream) != hipSuccess) {
         ogc_set_error("ogc_conv1x1_gemm_gnstats: memset failed");

@@ -132,6 +132,7 @@ class _PointwiseConv(Function):
         if _gemm_ok(cin, hw):
             y = torch.empty((B, cout) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
             if (gn_groups > 0 and gn_groups <= 32 and cout % gn_groups == 0 and (cout // gn_groups) % 4 == 0
+                    and cin <= 100  # wider input tiles leave the kernel no registers for the statistics epilogue
                     and getattr(nat, "conv1x1_gemm_gnstats_wrapper", None) is not None):
                 stats = torch.empty(nat.conv1x1_gn_slots() * B * gn_groups * 2, dtype=torch.float64, device=x.device)
                 nat.conv1x1_gemm_gnstats_wrapper(B, cout, cin, hw, gn_groups, weight.detach().contiguous(), x, y, stats)

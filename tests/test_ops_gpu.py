@@ -591,8 +591,8 @@ def test_group_concat_matches_op_sequence(shape):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", [(2, 6, 32, 4096, 4), (3, 32, 64, 1024, 4), (2, 99, 64, 2048, 4), (1, 131, 128, 512, 8),
-                                   (2, 128, 256, 256, 4), (2, 16, 48, 640, 4)])
+@pytest.mark.parametrize("shape", [(2, 6, 32, 4096, 4), (3, 32, 64, 1024, 4), (2, 99, 64, 2048, 4), (1, 67, 128, 512, 8),
+                                   (2, 100, 256, 256, 4), (2, 16, 48, 640, 4)])
 def test_conv_gemm_gnstats(shape):
     """Forward conv with fused GroupNorm statistics: same output as the plain GEMM, statistics equal to fp64 sums."""
     from ogc_amd import pointnet2_cuda as nat

@@ -123,6 +123,19 @@ def bench_conv_gn(ops, iters):
             dx = torch.empty_like(x)
             dw = torch.empty(cout, cin, device=DEV)
             f = timeit(lambda: nat.conv1x1_gemm_wrapper(B, cout, cin, hw, 0, w, x, y), iters)
+            st = torch.empty(nat.conv1x1_gn_slots() * B * 4 * 2, dtype=torch.float64, device=DEV)
+            fs = timeit(lambda: nat.conv1x1_gemm_gnstats_wrapper(B, cout, cin, hw, 4, w, x, y, st), iters)
+            wsd = torch.empty(2 * B * 4, dtype=torch.float64, device=DEV)
+            from ogc_amd import _lib as _l
+            def stats_only():
+                import ctypes
+                mean = torch.empty(B * 4, device=DEV); rstd = torch.empty(B * 4, device=DEV)
+                nat.group_norm_fwd_wrapper(B, cout, hw, 4, 1e-5, 1, y, torch.ones(cout, device=DEV), torch.zeros(cout, device=DEV), y2, mean, rstd, wsd)
+            y2 = torch.empty_like(y)
+            gfull = timeit(stats_only, iters)
+            mean = torch.empty(B * 4, device=DEV); rstd = torch.empty(B * 4, device=DEV)
+            gapply = timeit(lambda: nat.group_norm_fwd_stats_wrapper(B, cout, hw, 4, 1e-5, 1, y, torch.ones(cout, device=DEV), torch.zeros(cout, device=DEV), y2, mean, rstd, st, nat.conv1x1_gn_slots()), iters)
+            print("      conv+stats %.3f (+%.3f) | GN stats+apply %.3f vs apply-only %.3f (stats pass = %.3f)" % (fs, fs - f, gfull, gapply, gfull - gapply))
             d = timeit(lambda: nat.conv1x1_gemm_wrapper(B, cin, cout, hw, 1, w, y, dx), iters) if cout <= 160 else float("nan")
             g = timeit(lambda: nat.conv1x1_wgrad_wrapper(B, cin, cout, hw, x, y, dw), iters)
             byt = 4.0 * B * hw * (cin + cout)
