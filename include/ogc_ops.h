@@ -152,6 +152,36 @@ int ogc_group_concat(int b, int c, int n, int npoints, int nsample, const float 
 int ogc_group_concat_grad(int b, int c, int n, int npoints, int nsample, const float *grad_out, const int *idx,
                           float *grad_points, ogc_stream_t stream);
 
+/* Dynamic (rigid-motion) term of the OGC loss, fused.  Replaces DynamicLoss.forward + fit_motion_svd_batch
+ *   losses/seg_loss_unsup.py:64-98, :10-61 (K-fold expanded clouds, einsums, ~65 launches per step).
+ * ogc_rigid_moments: per (cloud, slot) the weighted moments of p = pc and q = pc2 with weights mask[:, slot], accumulated
+ *   in fp64 in ONE pass: mom (vb,k,16) f64 scratch {W, sum w p, sum w q, sum w p q^T}; outputs S (vb*k,3,3) f32 =
+ *   sum w (p - pbar)(q - qbar)^T (the input of ogc_kabsch_rotation) and means (vb*k,6) f32 = (pbar, qbar).  A slot with
+ *   zero weight gives NaN (as the reference's division does), which ogc_kabsch_rotation flags invalid.
+ * ogc_rigid_translation: t = qbar - R pbar; fits flagged invalid get R = I, t = 0 (:40-42, :58-59).  R is updated in place.
+ * ogc_rigid_blend: backward == 0: out (vb,n) = || sum_k mask[n,k] (R_k p_n + t_k) - q_n ||_p;  backward != 0:
+ *   out (vb,n,k) = d/d mask of that, times grad_out (vb,n) (the fit itself is detached, :91).  p = 1 or 2; k <= 32.
+ * pc, pc2 (vb,n,3), mask (vb,n,k) point-major, R (vb*k,3,3), t (vb*k,3). */
+int ogc_rigid_moments(int vb, int n, int k, const float *pc, const float *pc2, const float *mask, double *mom, float *S,
+                      float *means, ogc_stream_t stream);
+int ogc_rigid_translation(int total, const float *means, const int *valid, float *R, float *t, ogc_stream_t stream);
+int ogc_rigid_blend(int vb, int n, int k, int p, int backward, const float *pc, const float *pc2, const float *mask,
+                    const float *R, const float *t, const float *grad_out, float *out, ogc_stream_t stream);
+
+/* Invariance term of the OGC loss, fused.  Replaces match_mask_by_iou's IoU matrix and InvarianceLoss.distance
+ *   losses/seg_loss_unsup.py:212-233, :252-262 (arg-max, one-hot tensors, einsums, permutation products).
+ * ogc_mask_iou: iou (pb,k,k) f32 of the hard (arg-max, first maximum) segmentations of mask1 / mask2 (pb,n,k):
+ *   intersection / clamp(|g in 1| + |p in 2| - intersection, 1e-10); counts (pb,k,k) i32 scratch.
+ * ogc_matched_distance: backward == 0: out1 (pb,n) = ||mask1[n] - mask2[n, col12]||_p, out2 (pb,n) =
+ *   ||mask2[n] - mask1[n, col21]||_p with col12 / col21 (pb,k) i32 the assignments of ogc_lsap_maximize for iou and
+ *   iou^T; backward != 0: out1 / out2 (pb,n,k) = gradients w.r.t. mask1 / mask2 through the FIRST operand of each
+ *   distance only (the permuted targets are detached, :259-260), times grad12 / grad21 (pb,n).  p = 1 or 2; k <= 32. */
+int ogc_mask_iou(int pb, int n, int k, const float *mask1, const float *mask2, int *counts, float *iou,
+                 ogc_stream_t stream);
+int ogc_matched_distance(int pb, int n, int k, int p, int backward, const float *mask1, const float *mask2,
+                         const int *col12, const int *col21, const float *grad12, const float *grad21, float *out1,
+                         float *out2, ogc_stream_t stream);
+
 /* Linear sum assignment (maximise), batched, on the device.  Replaces the host round trip of the invariance loss
  *   losses/seg_loss_unsup.py:234-239:  scipy.optimize.linear_sum_assignment(iou[b], maximize=True)[1] per sample.
  * score (np,k,k) f32 row-major (rows = slots of mask1), col4row (np,k) i32 out: column assigned to each row.

@@ -28,6 +28,11 @@ SIGNATURES = {
     "ogc_knn_clamped": [_int, _int, _int, _int, _flt, _vp, _vp, _vp, _vp, _vp],
     "ogc_kabsch_rotation": [_int, _vp, _vp, _vp, _vp],
     "ogc_lsap_maximize": [_int, _int, _vp, _vp, _vp],
+    "ogc_rigid_moments": [_int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "ogc_rigid_translation": [_int, _vp, _vp, _vp, _vp, _vp],
+    "ogc_rigid_blend": [_int, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "ogc_mask_iou": [_int, _int, _int, _vp, _vp, _vp, _vp, _vp],
+    "ogc_matched_distance": [_int, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "ogc_soft_nn_target": [_int, _int, _int, _int, _flt, _vp, _vp, _vp, _vp, _vp, _vp],
     "ogc_group_concat": [_int, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp],
     "ogc_group_concat_grad": [_int, _int, _int, _int, _int, _vp, _vp, _vp, _vp],

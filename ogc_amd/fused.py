@@ -343,3 +343,103 @@ def conv_norm_act(x, conv, norm, relu=True, maxpool=False):
         if relu:
             y = F.relu(y)
     return y.max(dim=-1)[0] if maxpool else y
+
+
+# ---- dynamic / invariance terms of the OGC loss ---------------------------------------------------------------
+class _RigidBlend(Function):
+    """per-point || sum_k m_k (R_k p + t_k) - q ||_p with R, t constants (the fit is detached in the reference,
+    losses/seg_loss_unsup.py:91); gradient w.r.t. the mask only."""
+
+    @staticmethod
+    def forward(ctx, pc, pc2, mask, R, t, p):
+        nat = _api._native
+        VB, N, K = mask.shape
+        out = torch.empty(VB, N, dtype=torch.float32, device=mask.device)
+        nat.rigid_blend_wrapper(VB, N, K, p, 0, pc, pc2, mask, R, t, None, out)
+        ctx.save_for_backward(pc, pc2, mask, R, t)
+        ctx.p = p
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        nat = _api._native
+        pc, pc2, mask, R, t = ctx.saved_tensors
+        VB, N, K = mask.shape
+        grad_mask = torch.empty_like(mask)
+        nat.rigid_blend_wrapper(VB, N, K, ctx.p, 1, pc, pc2, mask, R, t, grad_out.contiguous(), grad_mask)
+        return None, None, grad_mask, None, None, None
+
+
+def rigid_residual_available(mask, loss_norm):
+    return (mask.is_cuda and mask.dtype == torch.float32 and loss_norm in (1, 2) and mask.shape[-1] <= 32
+            and getattr(_api._native, "rigid_blend_wrapper", None) is not None)
+
+
+def rigid_residual(pc, pc2, mask, loss_norm):
+    """DynamicLoss per point: fit one rigid motion per (cloud, slot) to (pc -> pc2) weighted by mask[:, :, slot]
+    (detached), blend the moved clouds by the mask, residual norm against pc2.  pc, pc2 (VB, N, 3), mask (VB, N, K)
+    -> (VB, N).  Five launches: moments, finalize, Kabsch, translation, blend."""
+    nat = _api._native
+    pc, pc2, mask = pc.contiguous(), pc2.contiguous(), mask.contiguous()
+    VB, N, K = mask.shape
+    dev = mask.device
+    with torch.no_grad():
+        mom = torch.empty(VB * K * 16, dtype=torch.float64, device=dev)
+        S = torch.empty(VB * K, 3, 3, dtype=torch.float32, device=dev)
+        means = torch.empty(VB * K, 6, dtype=torch.float32, device=dev)
+        nat.rigid_moments_wrapper(VB, N, K, pc, pc2, mask.detach(), mom, S, means)
+        R = torch.empty_like(S)
+        valid = torch.empty(VB * K, dtype=torch.int32, device=dev)
+        nat.kabsch_rotation_wrapper(VB * K, S, R, valid)
+        t = torch.empty(VB * K, 3, dtype=torch.float32, device=dev)
+        nat.rigid_translation_wrapper(VB * K, means, valid, R, t)
+    return _RigidBlend.apply(pc, pc2, mask, R, t, int(loss_norm))
+
+
+class _MatchedDistance(Function):
+    """(||m1 - m2[:, col12]||_p, ||m2 - m1[:, col21]||_p) per point, the permuted operands detached
+    (losses/seg_loss_unsup.py:252-262)."""
+
+    @staticmethod
+    def forward(ctx, mask1, mask2, col12, col21, p):
+        nat = _api._native
+        PB, N, K = mask1.shape
+        d12 = torch.empty(PB, N, dtype=torch.float32, device=mask1.device)
+        d21 = torch.empty_like(d12)
+        nat.matched_distance_wrapper(PB, N, K, p, 0, mask1, mask2, col12, col21, None, None, d12, d21)
+        ctx.save_for_backward(mask1, mask2, col12, col21)
+        ctx.p = p
+        return d12, d21
+
+    @staticmethod
+    def backward(ctx, g12, g21):
+        nat = _api._native
+        mask1, mask2, col12, col21 = ctx.saved_tensors
+        PB, N, K = mask1.shape
+        gm1, gm2 = torch.empty_like(mask1), torch.empty_like(mask2)
+        nat.matched_distance_wrapper(PB, N, K, ctx.p, 1, mask1, mask2, col12, col21, g12.contiguous(), g21.contiguous(),
+                                     gm1, gm2)
+        return gm1, gm2, None, None, None
+
+
+def matched_distance_available(mask, loss_norm, cross_entropy):
+    return (mask.is_cuda and mask.dtype == torch.float32 and not cross_entropy and loss_norm in (1, 2)
+            and mask.shape[-1] <= 32 and getattr(_api._native, "matched_distance_wrapper", None) is not None
+            and getattr(_api._native, "lsap_maximize_wrapper", None) is not None)
+
+
+def matched_distances(mask1, mask2, loss_norm):
+    """Hungarian-match the hard segmentations of mask1 / mask2 (PB, N, K) by IoU in both directions, then the
+    per-point distances to the permuted other mask: (d12, d21), each (PB, N).  Four launches."""
+    nat = _api._native
+    mask1, mask2 = mask1.contiguous(), mask2.contiguous()
+    PB, N, K = mask1.shape
+    dev = mask1.device
+    with torch.no_grad():
+        counts = torch.empty(PB * K * K, dtype=torch.int32, device=dev)
+        iou = torch.empty(PB, K, K, dtype=torch.float32, device=dev)
+        nat.mask_iou_wrapper(PB, N, K, mask1.detach(), mask2.detach(), counts, iou)
+        both = torch.stack([iou, iou.transpose(1, 2)]).contiguous()          # (2, PB, K, K)
+        cols = torch.empty(2 * PB, K, dtype=torch.int32, device=dev)
+        nat.lsap_maximize_wrapper(2 * PB, K, both, cols)
+    return _MatchedDistance.apply(mask1, mask2, cols[:PB], cols[PB:], int(loss_norm))

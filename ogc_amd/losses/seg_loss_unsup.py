@@ -90,6 +90,10 @@ class DynamicLoss(nn.Module):
         pc, mask, flow = torch.cat(pcs), torch.cat(masks), torch.cat(flows)
         n_point, n_object = mask.shape[1], mask.shape[2]
         pc2 = pc + flow
+        from ..fused import rigid_residual, rigid_residual_available
+        if rigid_residual_available(mask, self.loss_norm) and not (pc.requires_grad or flow.requires_grad):
+            per_point = rigid_residual(pc, pc2, mask, self.loss_norm)               # (V*B, N), fused kernels
+            return list(per_point.view(n_view, n_batch * n_point).mean(dim=1))
         mask_t = mask.transpose(1, 2)
         pc_rep = pc.unsqueeze(1).expand(-1, n_object, -1, -1).reshape(-1, n_point, 3)
         pc2_rep = pc2.unsqueeze(1).expand(-1, n_object, -1, -1).reshape(-1, n_point, 3)
@@ -296,7 +300,14 @@ class InvarianceLoss(nn.Module):
         return self._from_perms(mask1, mask2, perm2, perm1)
 
     def forward_pairs(self, pairs):
-        """[forward(a, b) for (a, b) in pairs] with a single host round trip for all Hungarian matchings."""
+        """[forward(a, b) for (a, b) in pairs]: all pairs, samples and directions matched in one batch."""
+        from ..fused import matched_distance_available, matched_distances
+        if matched_distance_available(pairs[0][0], self.loss_norm, self.cross_entropy):
+            n_pair = len(pairs)
+            d12, d21 = matched_distances(torch.cat([a for a, _ in pairs]), torch.cat([b for _, b in pairs]),
+                                         self.loss_norm)                        # (P*B, N) each
+            per_pair = d12.view(n_pair, -1).mean(dim=1) + d21.view(n_pair, -1).mean(dim=1)
+            return list(per_pair)
         perms = match_mask_pairs_both_ways(pairs)
         return [self._from_perms(a, b, p2, p1) for (a, b), (p2, p1) in zip(pairs, perms)]
 

@@ -169,6 +169,35 @@ def soft_nn_target_wrapper(b, n1, n2, k, temperature, p1, p2, mask1, mask2, targ
          _f(mask2, "mask2"), _f(target, "target"))
 
 
+def rigid_moments_wrapper(vb, n, k, pc, pc2, mask, mom, S, means):
+    """Weighted moments -> centred cross-covariances S and means per (cloud, slot) (ogc_rigid_moments)."""
+    _run("ogc_rigid_moments", pc, vb, n, k, _f(pc, "pc"), _f(pc2, "pc2"), _f(mask, "mask"),
+         _check(mom, torch.float64, "mom"), _f(S, "S"), _f(means, "means"))
+
+
+def rigid_translation_wrapper(total, means, valid, R, t):
+    """t = qbar - R pbar; invalid fits -> identity / zero (ogc_rigid_translation)."""
+    _run("ogc_rigid_translation", means, total, _f(means, "means"), _i(valid, "valid"), _f(R, "R"), _f(t, "t"))
+
+
+def rigid_blend_wrapper(vb, n, k, p, backward, pc, pc2, mask, R, t, grad_out, out):
+    """Per-point residual of the mask-blended rigid motions, or its gradient w.r.t. the mask (ogc_rigid_blend)."""
+    _run("ogc_rigid_blend", pc, vb, n, k, int(p), int(backward), _f(pc, "pc"), _f(pc2, "pc2"), _f(mask, "mask"),
+         _f(R, "R"), _f(t, "t"), 0 if grad_out is None else _f(grad_out, "grad_out"), _f(out, "out"))
+
+
+def mask_iou_wrapper(pb, n, k, mask1, mask2, counts, iou):
+    """IoU matrices of the arg-max segmentations (ogc_mask_iou)."""
+    _run("ogc_mask_iou", mask1, pb, n, k, _f(mask1, "mask1"), _f(mask2, "mask2"), _i(counts, "counts"), _f(iou, "iou"))
+
+
+def matched_distance_wrapper(pb, n, k, p, backward, mask1, mask2, col12, col21, grad12, grad21, out1, out2):
+    """Per-point distances between matched masks, or their gradients (ogc_matched_distance)."""
+    _run("ogc_matched_distance", mask1, pb, n, k, int(p), int(backward), _f(mask1, "mask1"), _f(mask2, "mask2"),
+         _i(col12, "col12"), _i(col21, "col21"), 0 if grad12 is None else _f(grad12, "grad12"),
+         0 if grad21 is None else _f(grad21, "grad21"), _f(out1, "out1"), _f(out2, "out2"))
+
+
 def lsap_maximize_wrapper(np_, k, score, col4row):
     """Batched maximising linear-sum assignment with scipy's tie-breaking (ogc_lsap_maximize)."""
     _run("ogc_lsap_maximize", score, np_, k, _f(score, "score"), _i(col4row, "col4row"))

@@ -101,3 +101,73 @@ def test_soft_nn_target(shape, scale):
     err_kernel = (out.double() - exact).abs().max().item()
     err_torch = (single.double() - exact).abs().max().item()
     assert err_kernel <= max(4.0 * err_torch, 1e-5 * scale), (err_kernel, err_torch)
+
+
+class _NoFused:
+    """The native module without the loss-level fused entry points: forces the reference-shaped op sequence."""
+    HIDE = ("rigid_blend_wrapper", "matched_distance_wrapper")
+
+    def __init__(self, native):
+        self._native = native
+
+    def __getattr__(self, name):
+        if name in self.HIDE:
+            raise AttributeError(name)
+        return getattr(self._native, name)
+
+
+@pytest.mark.parametrize("loss_norm", [1, 2])
+@pytest.mark.parametrize("shape", [(2, 3, 700, 6), (1, 4, 2048, 10), (2, 2, 97, 32)])
+def test_dynamic_loss_fused_matches_op_sequence(shape, loss_norm, monkeypatch):
+    import ogc_amd.pointnet2.pointnet2 as api
+    from ogc_amd.losses.seg_loss_unsup import DynamicLoss
+    V, B, N, K = shape
+    g = torch.Generator().manual_seed(sum(shape) + loss_norm)
+    pcs = [((torch.rand(B, N, 3, generator=g) - 0.5) * torch.tensor([60.0, 4.0, 80.0])).cuda() for _ in range(V)]
+    flows = [(0.3 * torch.randn(B, N, 3, generator=g)).cuda() for _ in range(V)]
+    logits = torch.randn(V, B, N, K, generator=g).cuda()
+    logits[0, 0, :, K - 1] = -1e4                       # a slot with (numerically) zero weight everywhere
+    logits.requires_grad_(True)
+    loss = DynamicLoss(loss_norm)
+
+    def run():
+        masks = [logits[v].softmax(-1) for v in range(V)]
+        out = torch.stack(loss.forward_views(pcs, masks, flows))
+        logits.grad = None
+        (out * torch.arange(1, V + 1, device="cuda")).sum().backward()
+        return out.detach().clone(), logits.grad.clone()
+
+    fused, g_fused = run()
+    monkeypatch.setattr(api, "_native", _NoFused(api._native))
+    plain, g_plain = run()
+    torch.testing.assert_close(fused, plain, rtol=2e-5, atol=1e-6)
+    torch.testing.assert_close(g_fused, g_plain, rtol=1e-3, atol=2e-7)
+
+
+@pytest.mark.parametrize("loss_norm", [1, 2])
+@pytest.mark.parametrize("shape", [(2, 3, 700, 6), (1, 4, 2048, 10), (3, 2, 97, 32)])
+def test_invariance_loss_fused_matches_op_sequence(shape, loss_norm, monkeypatch):
+    import ogc_amd.pointnet2.pointnet2 as api
+    from ogc_amd.losses.seg_loss_unsup import InvarianceLoss
+    P, B, N, K = shape
+    g = torch.Generator().manual_seed(sum(shape) + loss_norm)
+    la = (3 * torch.randn(P, B, N, K, generator=g)).cuda()
+    la[..., K // 2:] -= 50.0                             # unused slots: empty rows / columns in the IoU (ties)
+    lb = (la[:, :, :, torch.randperm(K, generator=g)] + torch.randn(P, B, N, K, generator=g).cuda())
+    la.requires_grad_(True)
+    lb.requires_grad_(True)
+    loss = InvarianceLoss(loss_norm=loss_norm)
+
+    def run():
+        pairs = [(la[i].softmax(-1), lb[i].softmax(-1)) for i in range(P)]
+        out = torch.stack(loss.forward_pairs(pairs))
+        la.grad = lb.grad = None
+        (out * torch.arange(1, P + 1, device="cuda")).sum().backward()
+        return out.detach().clone(), la.grad.clone(), lb.grad.clone()
+
+    fused, ga, gb = run()
+    monkeypatch.setattr(api, "_native", _NoFused(api._native))
+    plain, pa, pb_ = run()
+    torch.testing.assert_close(fused, plain, rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(ga, pa, rtol=1e-4, atol=1e-9)
+    torch.testing.assert_close(gb, pb_, rtol=1e-4, atol=1e-9)
