@@ -42,23 +42,31 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_wgrad_kernel(int b
 #pragma unroll
         for (int c = 0; c < CIB; ++c) acc[a][c] = (v4f){0.f, 0.f, 0.f, 0.f};
 
-    auto load = [&](long long step, float4(&yv)[COB], float4(&xv)[CIB]) {
-        const bool ok = step < nsteps;
-        const long long s = ok ? step : 0;
-        const int b = (int)(s / steps_per_img);
-        const int pb = (int)(s - (long long)b * steps_per_img) * 16 + 4 * k;
+    // The wave walks consecutive steps, so (image, position) advance incrementally: one division per wave instead of a
+    // 64-bit division per step (which cost more issue slots than the step's 64 MFMAs).
+    int cur_b = (int)(first / steps_per_img);
+    int cur_off = (int)(first - (long long)cur_b * steps_per_img);
+    long long cur_step = first;
+    int yrow[COB], xrow[CIB]; // one sample's activation fits 32-bit offsets (checked by the entry point)
 #pragma unroll
-        for (int a = 0; a < COB; ++a) {
-            const int row = co0 + a * 16 + i;
-            yv[a] = (ok && row < cout) ? *reinterpret_cast<const float4 *>(dy + ((size_t)b * cout + row) * hw + pb)
-                                       : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+    for (int a = 0; a < COB; ++a) yrow[a] = min(co0 + a * 16 + i, cout - 1) * hw;
 #pragma unroll
-        for (int c = 0; c < CIB; ++c) {
-            const int row = ci0 + c * 16 + i;
-            xv[c] = (ok && row < cin) ? *reinterpret_cast<const float4 *>(x + ((size_t)b * cin + row) * hw + pb)
-                                      : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+    for (int c = 0; c < CIB; ++c) xrow[c] = min(ci0 + c * 16 + i, cin - 1) * hw;
+    auto load = [&](float4(&yv)[COB], float4(&xv)[CIB]) { // loads step `cur_step`, then advances
+        const bool ok = cur_step < nsteps;
+        const int pb = cur_off * 16 + 4 * k;
+        const float *yb_ = dy + (size_t)cur_b * cout * hw + pb;
+        const float *xb_ = x + (size_t)cur_b * cin * hw + pb;
+#pragma unroll
+        for (int a = 0; a < COB; ++a)
+            yv[a] = (ok && co0 + a * 16 + i < cout) ? *reinterpret_cast<const float4 *>(yb_ + yrow[a])
+                                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int c = 0; c < CIB; ++c)
+            xv[c] = (ok && ci0 + c * 16 + i < cin) ? *reinterpret_cast<const float4 *>(xb_ + xrow[c])
+                                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+        ++cur_step;
+        if (++cur_off == steps_per_img) { cur_off = 0; ++cur_b; }
     };
     auto fma16 = [&](const float4(&yv)[COB], const float4(&xv)[CIB]) {
 #pragma unroll
@@ -73,11 +81,11 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_wgrad_kernel(int b
     };
 
     float4 ya[COB], xa[CIB], yb[COB], xb[CIB];
-    load(first, ya, xa);
+    load(ya, xa);
     for (int s = 0; s < steps_per_wave; s += 2) { // ping-pong registers: next step's loads fly during the MFMAs
-        load(first + s + 1, yb, xb);
+        load(yb, xb);
         fma16(ya, xa);
-        load(first + s + 2, ya, xa);
+        load(ya, xa);
         if (s + 1 < steps_per_wave) fma16(yb, xb);
     }
 

@@ -124,6 +124,12 @@ def bench_conv_gn(ops, iters):
             dw = torch.empty(cout, cin, device=DEV)
             f = timeit(lambda: nat.conv1x1_gemm_wrapper(B, cout, cin, hw, 0, w, x, y), iters)
             st = torch.empty(nat.conv1x1_gn_slots() * B * 4 * 2, dtype=torch.float64, device=DEV)
+            if cin > 100:  # the fused statistics are only offered up to K = 100
+                print("conv  B=%-3d %4d->%-4d hw=%-6d fwd %7.3f ms %6.0f GB/s | dgrad %7.3f ms %6.0f GB/s | wgrad %7.3f ms %6.0f GB/s" %
+                      (B, cin, cout, hw, f, 4.0 * B * hw * (cin + cout) / f / 1e6,
+                       *(lambda d: (d, 4.0 * B * hw * (cin + cout) / d / 1e6))(timeit(lambda: nat.conv1x1_gemm_wrapper(B, cin, cout, hw, 1, w, y, x.new_empty(B, cin, hw)), iters) if cout <= 160 else float("nan")),
+                       *(lambda g_: (g_, 4.0 * B * hw * (cin + cout) / g_ / 1e6))(timeit(lambda: nat.conv1x1_wgrad_wrapper(B, cin, cout, hw, x, y, w.new_empty(cout, cin)), iters))))
+                continue
             fs = timeit(lambda: nat.conv1x1_gemm_gnstats_wrapper(B, cout, cin, hw, 4, w, x, y, st), iters)
             wsd = torch.empty(2 * B * 4, dtype=torch.float64, device=DEV)
             from ogc_amd import _lib as _l
