@@ -309,6 +309,22 @@ int ogc_conv1x1_gn_slots(void);
 int ogc_conv1x1_gemm_gnstats(int b, int M, int K, int hw, int groups, const float *w, const float *in, float *out,
                              double *stats, ogc_stream_t stream);
 
+/* Deferred normalisation: inside a SharedMLP the GroupNorm (+ ReLU) output of one layer is only ever read by the next
+ * layer's convolution, so it need not be written.  ogc_group_norm_coeffs turns the statistics of layer l (supplied by
+ * the producing convolution, or computed here from x when stats == NULL; ws: 2*b*groups f64 then) into mean / rstd
+ * (b*groups) for the backward pass and the per-(b, channel) affine map a, bb (b*c):  GroupNorm(x)[b, ch] = a*x + bb.
+ * ogc_conv1x1_gemm_affine is the forward convolution of layer l+1 on act(a*in + bb) applied while loading (relu != 0:
+ * act = ReLU; groups > 0: also the statistics of ITS output, as ogc_conv1x1_gemm_gnstats, same restrictions);
+ * ogc_conv1x1_wgrad_affine is that layer's weight gradient with the same recomputed operand.  The input gradient is
+ * ogc_conv1x1_gemm(transpose_a = 1) followed by ogc_group_norm_bwd on (in, mean, rstd), unchanged. */
+int ogc_group_norm_coeffs(int b, int c, int hw, int groups, float eps, const float *x, const float *gamma,
+                          const float *beta, const double *stats, int slots, double *ws, float *mean, float *rstd,
+                          float *a, float *bb, ogc_stream_t stream);
+int ogc_conv1x1_gemm_affine(int b, int M, int K, int hw, int relu, int groups, const float *w, const float *in,
+                            const float *pa, const float *pb, float *out, double *stats, ogc_stream_t stream);
+int ogc_conv1x1_wgrad_affine(int b, int cin, int cout, int hw, int relu, const float *x, const float *pa,
+                             const float *pb, const float *dy, float *dw, ogc_stream_t stream);
+
 /* ogc_group_norm_fwd / ogc_group_norm_maxpool_fwd with the statistics supplied (`slots` copies, see above). */
 int ogc_group_norm_fwd_stats(int b, int c, int hw, int groups, float eps, int relu, const float *x,
                              const float *gamma, const float *beta, float *y, float *mean, float *rstd,

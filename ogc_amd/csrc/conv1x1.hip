@@ -22,12 +22,16 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 
 constexpr int WG_WAVES = 4;
 
-template <int COB, int CIB>
+// PRO: the layer's input was never materialised — x holds the previous layer's raw convolution output and the operand
+// is act(pa[b, ci] * x + pb[b, ci]), recomputed while loading (see conv1x1_gemm_kernel).
+template <int COB, int CIB, bool PRO>
 __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_wgrad_kernel(int batch, int cin, int cout, int hw,
                                                                            int steps_per_wave,
                                                                            const float *__restrict__ x,
                                                                            const float *__restrict__ dy,
-                                                                           float *__restrict__ dw) {
+                                                                           float *__restrict__ dw,
+                                                                           const float *__restrict__ aff_a,
+                                                                           const float *__restrict__ aff_b, int pro_relu) {
     __shared__ float red[COB * CIB * 256]; // the workgroup's partial tile: COB*CIB blocks of 16x16
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, k = lane >> 4;
@@ -52,7 +56,21 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_wgrad_kernel(int b
     for (int a = 0; a < COB; ++a) yrow[a] = min(co0 + a * 16 + i, cout - 1) * hw;
 #pragma unroll
     for (int c = 0; c < CIB; ++c) xrow[c] = min(ci0 + c * 16 + i, cin - 1) * hw;
-    auto load = [&](float4(&yv)[COB], float4(&xv)[CIB]) { // loads step `cur_step`, then advances
+    // PRO: the affine map of this lane's input channels for image cur_b.  It is applied when a buffer is CONSUMED, not when
+    // it is loaded (a VALU op on freshly loaded registers would put the wait for the load right behind its issue and
+    // undo the ping-pong), so every buffer carries the coefficients of the image its step belongs to.
+    float ca[CIB], cb[CIB];
+    auto load_coeffs = [&](int img) {
+#pragma unroll
+        for (int c = 0; c < CIB; ++c) {
+            const bool have = ci0 + c * 16 + i < cin;
+            const int ch = min(ci0 + c * 16 + i, cin - 1);
+            ca[c] = have ? aff_a[(size_t)img * cin + ch] : 0.f; // padding rows: act(0 * 0 + 0) = 0
+            cb[c] = have ? aff_b[(size_t)img * cin + ch] : 0.f;
+        }
+    };
+    if (PRO && cur_b < batch) load_coeffs(cur_b);
+    auto load = [&](float4(&yv)[COB], float4(&xv)[CIB], float(&fa)[CIB], float(&fb)[CIB]) { // step cur_step, then advance
         const bool ok = cur_step < nsteps;
         const int pb = cur_off * 16 + 4 * k;
         const float *yb_ = dy + (size_t)cur_b * cout * hw + pb;
@@ -62,13 +80,31 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_wgrad_kernel(int b
             yv[a] = (ok && co0 + a * 16 + i < cout) ? *reinterpret_cast<const float4 *>(yb_ + yrow[a])
                                                     : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int c = 0; c < CIB; ++c)
+        for (int c = 0; c < CIB; ++c) {
             xv[c] = (ok && ci0 + c * 16 + i < cin) ? *reinterpret_cast<const float4 *>(xb_ + xrow[c])
                                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (PRO) { fa[c] = ok ? ca[c] : 0.f; fb[c] = ok ? cb[c] : 0.f; }
+        }
         ++cur_step;
-        if (++cur_off == steps_per_img) { cur_off = 0; ++cur_b; }
+        if (++cur_off == steps_per_img) {
+            cur_off = 0;
+            ++cur_b;
+            if (PRO && cur_b < batch) load_coeffs(cur_b);
+        }
     };
-    auto fma16 = [&](const float4(&yv)[COB], const float4(&xv)[CIB]) {
+    auto fma16 = [&](const float4(&yv)[COB], const float4(&xraw)[CIB], const float(&fa)[CIB], const float(&fb)[CIB]) {
+        float4 xv[CIB];
+#pragma unroll
+        for (int c = 0; c < CIB; ++c) {
+            xv[c] = xraw[c];
+            if (PRO) {
+                float4 v = xraw[c];
+                v.x = fmaf(fa[c], v.x, fb[c]); v.y = fmaf(fa[c], v.y, fb[c]);
+                v.z = fmaf(fa[c], v.z, fb[c]); v.w = fmaf(fa[c], v.w, fb[c]);
+                if (pro_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                xv[c] = v;
+            }
+        }
 #pragma unroll
         for (int a = 0; a < COB; ++a)
 #pragma unroll
@@ -81,12 +117,13 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_wgrad_kernel(int b
     };
 
     float4 ya[COB], xa[CIB], yb[COB], xb[CIB];
-    load(ya, xa);
+    float faa[CIB], fba[CIB], fab[CIB], fbb[CIB];
+    load(ya, xa, faa, fba);
     for (int s = 0; s < steps_per_wave; s += 2) { // ping-pong registers: next step's loads fly during the MFMAs
-        load(yb, xb);
-        fma16(ya, xa);
-        load(ya, xa);
-        if (s + 1 < steps_per_wave) fma16(yb, xb);
+        load(yb, xb, fab, fbb);
+        fma16(ya, xa, faa, fba);
+        load(ya, xa, faa, fba);
+        if (s + 1 < steps_per_wave) fma16(yb, xb, fab, fbb);
     }
 
     // C/D layout of 16x16x4: lane l holds rows (l >> 4) * 4 + r (r = 0..3) of column l & 15
@@ -109,7 +146,8 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_wgrad_kernel(int b
 }
 
 template <int COB, int CIB>
-void wgrad_launch(int b, int cin, int cout, int hw, const float *x, const float *dy, float *dw, hipStream_t s) {
+void wgrad_launch(int b, int cin, int cout, int hw, const float *x, const float *dy, float *dw, const float *pa,
+                  const float *pb, int pro_relu, hipStream_t s) {
     const long long nsteps = (long long)b * (hw >> 4);
     const int tiles = ogc_divup(cout, 16 * COB) * ogc_divup(cin, 16 * CIB);
     // ~2048 waves over the chip per tile pair, but at least 8 steps (128 positions) per wave
@@ -120,8 +158,12 @@ void wgrad_launch(int b, int cin, int cout, int hw, const float *x, const float 
     spw = (spw + 1) / 2 * 2;
     const int wgs = (int)((nsteps + spw * WG_WAVES - 1) / (spw * WG_WAVES));
     dim3 grid(wgs, ogc_divup(cout, 16 * COB), ogc_divup(cin, 16 * CIB));
-    hipLaunchKernelGGL((conv1x1_wgrad_kernel<COB, CIB>), grid, dim3(WG_WAVES * OGC_WAVE), 0, s, b, cin, cout, hw,
-                       (int)spw, x, dy, dw);
+    if (pa)
+        hipLaunchKernelGGL((conv1x1_wgrad_kernel<COB, CIB, true>), grid, dim3(WG_WAVES * OGC_WAVE), 0, s, b, cin, cout, hw,
+                           (int)spw, x, dy, dw, pa, pb, pro_relu);
+    else
+        hipLaunchKernelGGL((conv1x1_wgrad_kernel<COB, CIB, false>), grid, dim3(WG_WAVES * OGC_WAVE), 0, s, b, cin, cout,
+                           hw, (int)spw, x, dy, dw, pa, pb, pro_relu);
 }
 
 } // namespace
@@ -144,12 +186,16 @@ constexpr int GN_SLOTS = 16;  // spread of the fused GroupNorm statistics over c
 // the sum of squares of the outputs (the first pass of the GroupNorm that follows every one of these convolutions):
 // row sums are reduced over the 16 lanes of a DPP row, then over the workgroup in LDS (fp64), then one fp64 atomic
 // per (group, statistic) and workgroup into one of GN_SLOTS copies of the accumulator.
-template <bool TRANSPOSE_A, int KQ, bool STATS>
+// PRO: the input is act(pa[b, k] * in + pb[b, k]) — the GroupNorm (+ ReLU) of the PREVIOUS layer applied while its raw
+// convolution output is loaded, so that the normalised activation is never written to memory.
+template <bool TRANSPOSE_A, int KQ, bool STATS, bool PRO>
 __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_gemm_kernel(int M, int K, int hw, int groups,
                                                                           const float *__restrict__ w, // (Cout, Cin)
                                                                           const float *__restrict__ in,
                                                                           float *__restrict__ out,
-                                                                          double *__restrict__ stats) {
+                                                                          double *__restrict__ stats,
+                                                                          const float *__restrict__ pa,
+                                                                          const float *__restrict__ pb, int pro_relu) {
     extern __shared__ __attribute__((aligned(16))) float a_lds[]; // [Kq][64][4] for the current 64-row tile of A
     __shared__ double s_stats[STATS ? 64 : 1];                    // [groups][2]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -168,6 +214,32 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_gemm_kernel(int M,
         const int row = q * 4 + kk;
         xin[q] = (live && q < Kq && row < K) ? *reinterpret_cast<const float4 *>(inb + (size_t)row * hw + p0 + 4 * j)
                                              : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (PRO) { // a second pass, so that all loads above are in flight before the first one is waited for; in chunks
+               // of eight rows so that the coefficients stay transient in wide layers (no spare registers there)
+        constexpr int CH = 8;
+#pragma unroll
+        for (int q0 = 0; q0 < KQ; q0 += CH) {
+            float ca[CH], cb[CH];
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                const int q = q0 + u, row = q * 4 + kk;
+                const bool have = q < KQ && live && q < Kq && row < K; // padding rows stay exact zeros: act(0 * 0 + 0)
+                ca[u] = have ? pa[(size_t)b * K + row] : 0.f;
+                cb[u] = have ? pb[(size_t)b * K + row] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                const int q = q0 + u;
+                if (q < KQ) {
+                    float4 v = xin[q];
+                    v.x = fmaf(ca[u], v.x, cb[u]); v.y = fmaf(ca[u], v.y, cb[u]);
+                    v.z = fmaf(ca[u], v.z, cb[u]); v.w = fmaf(ca[u], v.w, cb[u]);
+                    if (pro_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    xin[q] = v;
+                }
+            }
+        }
     }
     const int cpg = STATS ? M / groups : 1; // channels per group, a multiple of 4 on this path
     for (int m0 = 0; m0 < M; m0 += 64) {
@@ -255,15 +327,15 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_gemm_kernel(int M,
     }
 }
 
-template <bool T, bool STATS>
+template <bool T, bool STATS, bool PRO>
 int gemm_launch(int b, int M, int K, int hw, int groups, const float *w, const float *in, float *out, double *stats,
-                hipStream_t s) {
+                const float *pa, const float *pb, int pro_relu, hipStream_t s) {
     const int Kq = (K + 3) / 4;
     const size_t lds = (size_t)Kq * 256 * sizeof(float);
     dim3 grid(ogc_divup(hw, 64 * WG_WAVES), b);
-#define OGC_GEMM(KQV)                                                                                             \
-    hipLaunchKernelGGL((conv1x1_gemm_kernel<T, KQV, STATS>), grid, dim3(WG_WAVES * OGC_WAVE), lds, s, M, K, hw, groups, \
-                       w, in, out, stats)
+#define OGC_GEMM(KQV)                                                                                              \
+    hipLaunchKernelGGL((conv1x1_gemm_kernel<T, KQV, STATS, PRO>), grid, dim3(WG_WAVES * OGC_WAVE), lds, s, M, K, hw, \
+                       groups, w, in, out, stats, pa, pb, pro_relu)
     if (Kq <= 2) OGC_GEMM(2);
     else if (Kq <= 8) OGC_GEMM(8);
     else if (Kq <= 16) OGC_GEMM(16);
@@ -296,8 +368,8 @@ extern "C" int ogc_conv1x1_gemm(int b, int M, int K, int hw, int transpose_a, co
     const int rc = gemm_check("ogc_conv1x1_gemm", b, M, K, hw, w, in, out);
     if (rc != OGC_OK) return rc;
     if (b == 0) return OGC_OK;
-    if (transpose_a) gemm_launch<true, false>(b, M, K, hw, 1, w, in, out, nullptr, (hipStream_t)stream);
-    else gemm_launch<false, false>(b, M, K, hw, 1, w, in, out, nullptr, (hipStream_t)stream);
+    if (transpose_a) gemm_launch<true, false, false>(b, M, K, hw, 1, w, in, out, nullptr, nullptr, nullptr, 0, (hipStream_t)stream);
+    else gemm_launch<false, false, false>(b, M, K, hw, 1, w, in, out, nullptr, nullptr, nullptr, 0, (hipStream_t)stream);
     OGC_CHECK_LAUNCH("ogc_conv1x1_gemm");
     return OGC_OK;
 }
@@ -326,36 +398,77 @@ extern "C" int ogc_conv1x1_gemm_gnstats(int b, int M, int K, int hw, int groups,
         ogc_set_error("ogc_conv1x1_gemm_gnstats: memset failed");
         return OGC_ERR_LAUNCH;
     }
-    gemm_launch<false, true>(b, M, K, hw, groups, w, in, out, stats, (hipStream_t)stream);
+    gemm_launch<false, true, false>(b, M, K, hw, groups, w, in, out, stats, nullptr, nullptr, 0, (hipStream_t)stream);
     OGC_CHECK_LAUNCH("ogc_conv1x1_gemm_gnstats");
     return OGC_OK;
 }
 
-extern "C" int ogc_conv1x1_wgrad(int b, int cin, int cout, int hw, const float *x, const float *dy, float *dw,
-                                 ogc_stream_t stream) {
-    OGC_REQUIRE(b >= 0 && cin >= 1 && cout >= 1 && hw >= 1, "ogc_conv1x1_wgrad: bad shape");
-    OGC_REQUIRE(x && dy && dw, "ogc_conv1x1_wgrad: null pointer");
+namespace {
+int wgrad_impl(const char *name, int b, int cin, int cout, int hw, const float *x, const float *dy, float *dw,
+               const float *pa, const float *pb, int pro_relu, ogc_stream_t stream) {
+    OGC_REQUIRE(b >= 0 && cin >= 1 && cout >= 1 && hw >= 1, "%s: bad shape", name);
+    OGC_REQUIRE(x && dy && dw, "%s: null pointer", name);
     if ((hw & 15) != 0 || (((uintptr_t)x | (uintptr_t)dy) & 15) != 0) {
-        ogc_set_error("ogc_conv1x1_wgrad: hw=%d must be a multiple of 16 and x/dy 16-byte aligned", hw);
+        ogc_set_error("%s: hw=%d must be a multiple of 16 and x/dy 16-byte aligned", name, hw);
         return OGC_ERR_UNSUPPORTED;
     }
     OGC_REQUIRE((long long)cin * hw < (1ll << 31) && (long long)cout * hw < (1ll << 31),
-                "ogc_conv1x1_wgrad: one sample exceeds 32-bit indexing");
+                "%s: one sample exceeds 32-bit indexing", name);
     hipStream_t s = (hipStream_t)stream;
     if (hipMemsetAsync(dw, 0, sizeof(float) * (size_t)cin * cout, s) != hipSuccess) {
-        ogc_set_error("ogc_conv1x1_wgrad: memset failed");
+        ogc_set_error("%s: memset failed", name);
         return OGC_ERR_LAUNCH;
     }
     if (b == 0) return OGC_OK;
     // register tile per wave: (16*COB) x (16*CIB) outputs.  Small channel counts use small tiles so that no MFMA
     // work is spent on padding; wide layers use 64x64 tiles (16 accumulators) and split the rest over the grid.
-    if (cout <= 16 && cin <= 16) wgrad_launch<1, 1>(b, cin, cout, hw, x, dy, dw, s);
-    else if (cout <= 32 && cin <= 16) wgrad_launch<2, 1>(b, cin, cout, hw, x, dy, dw, s);
-    else if (cout <= 32 && cin <= 32) wgrad_launch<2, 2>(b, cin, cout, hw, x, dy, dw, s);
-    else if (cin <= 16) wgrad_launch<4, 1>(b, cin, cout, hw, x, dy, dw, s);
-    else if (cin <= 32) wgrad_launch<4, 2>(b, cin, cout, hw, x, dy, dw, s);
-    else if (cout <= 32) wgrad_launch<2, 4>(b, cin, cout, hw, x, dy, dw, s);
-    else wgrad_launch<4, 4>(b, cin, cout, hw, x, dy, dw, s);
-    OGC_CHECK_LAUNCH("ogc_conv1x1_wgrad");
+    if (cout <= 16 && cin <= 16) wgrad_launch<1, 1>(b, cin, cout, hw, x, dy, dw, pa, pb, pro_relu, s);
+    else if (cout <= 32 && cin <= 16) wgrad_launch<2, 1>(b, cin, cout, hw, x, dy, dw, pa, pb, pro_relu, s);
+    else if (cout <= 32 && cin <= 32) wgrad_launch<2, 2>(b, cin, cout, hw, x, dy, dw, pa, pb, pro_relu, s);
+    else if (cin <= 16) wgrad_launch<4, 1>(b, cin, cout, hw, x, dy, dw, pa, pb, pro_relu, s);
+    else if (cin <= 32) wgrad_launch<4, 2>(b, cin, cout, hw, x, dy, dw, pa, pb, pro_relu, s);
+    else if (cout <= 32) wgrad_launch<2, 4>(b, cin, cout, hw, x, dy, dw, pa, pb, pro_relu, s);
+    else wgrad_launch<4, 4>(b, cin, cout, hw, x, dy, dw, pa, pb, pro_relu, s);
+    OGC_CHECK_LAUNCH(name);
     return OGC_OK;
+}
+} // namespace
+
+extern "C" int ogc_conv1x1_wgrad(int b, int cin, int cout, int hw, const float *x, const float *dy, float *dw,
+                                 ogc_stream_t stream) {
+    return wgrad_impl("ogc_conv1x1_wgrad", b, cin, cout, hw, x, dy, dw, nullptr, nullptr, 0, stream);
+}
+
+// The two kernels above with the previous layer's GroupNorm (+ ReLU) folded into the operand load:
+// in' = act(pa[b, k] * in + pb[b, k]).  groups == 0: no statistics of the output.
+extern "C" int ogc_conv1x1_gemm_affine(int b, int M, int K, int hw, int relu, int groups, const float *w, const float *in,
+                                       const float *pa, const float *pb, float *out, double *stats,
+                                       ogc_stream_t stream) {
+    const int rc = gemm_check("ogc_conv1x1_gemm_affine", b, M, K, hw, w, in, out);
+    if (rc != OGC_OK) return rc;
+    OGC_REQUIRE(pa && pb, "ogc_conv1x1_gemm_affine: null pointer");
+    if (b == 0) return OGC_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (groups > 0) {
+        OGC_REQUIRE(stats, "ogc_conv1x1_gemm_affine: null pointer");
+        if (groups > 32 || M % groups != 0 || (M / groups) % 4 != 0 || K > 100) {
+            ogc_set_error("ogc_conv1x1_gemm_affine: output statistics need groups <= 32, (M / groups) %% 4 == 0, K <= 100");
+            return OGC_ERR_UNSUPPORTED;
+        }
+        if (hipMemsetAsync(stats, 0, sizeof(double) * 2 * GN_SLOTS * (size_t)b * groups, s) != hipSuccess) {
+            ogc_set_error("ogc_conv1x1_gemm_affine: memset failed");
+            return OGC_ERR_LAUNCH;
+        }
+        gemm_launch<false, true, true>(b, M, K, hw, groups, w, in, out, stats, pa, pb, relu, s);
+    } else {
+        gemm_launch<false, false, true>(b, M, K, hw, 1, w, in, out, nullptr, pa, pb, relu, s);
+    }
+    OGC_CHECK_LAUNCH("ogc_conv1x1_gemm_affine");
+    return OGC_OK;
+}
+
+extern "C" int ogc_conv1x1_wgrad_affine(int b, int cin, int cout, int hw, int relu, const float *x, const float *pa,
+                                        const float *pb, const float *dy, float *dw, ogc_stream_t stream) {
+    OGC_REQUIRE(pa && pb, "ogc_conv1x1_wgrad_affine: null pointer");
+    return wgrad_impl("ogc_conv1x1_wgrad_affine", b, cin, cout, hw, x, dy, dw, pa, pb, relu, stream);
 }

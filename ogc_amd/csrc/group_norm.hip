@@ -418,6 +418,68 @@ int gn_fwd_impl(const char *name, int b, int c, int hw, int groups, float eps, i
 }
 } // namespace
 
+namespace {
+// one thread per (b, channel): the affine map y -> a * y + bb that GroupNorm applies to channel ch of sample b
+__global__ void gn_coeffs_kernel(int b, int c, int hw, int groups, float eps, const float *__restrict__ gamma,
+                                 const float *__restrict__ beta, const double *__restrict__ stats, int slots,
+                                 float *__restrict__ mean_out, float *__restrict__ rstd_out, float *__restrict__ a_out,
+                                 float *__restrict__ bb_out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= b * c) return;
+    const int bi = t / c, ch = t % c;
+    const int cg = c / groups, g = ch / cg, row = bi * groups + g;
+    const double n = (double)cg * hw;
+    double sum = 0.0, sumsq = 0.0;
+    for (int sl = 0; sl < slots; ++sl) {
+        const double *wsl = stats + ((size_t)sl * b * groups + row) * 2;
+        sum += wsl[0];
+        sumsq += wsl[1];
+    }
+    const double m = sum / n;
+    const double var = fmax(sumsq / n - m * m, 0.0);
+    const float mean = (float)m;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    if (ch == g * cg) {
+        mean_out[row] = mean;
+        rstd_out[row] = rstd;
+    }
+    const float a = rstd * gamma[ch];
+    a_out[t] = a;
+    bb_out[t] = beta[ch] - mean * a;
+}
+} // namespace
+
+// Statistics (unless supplied) -> mean, rstd per (b, group) and the per-(b, channel) affine coefficients, WITHOUT
+// applying them: the consumer (ogc_conv1x1_gemm_affine / ogc_conv1x1_wgrad_affine) applies them while loading.
+extern "C" int ogc_group_norm_coeffs(int b, int c, int hw, int groups, float eps, const float *x, const float *gamma,
+                                     const float *beta, const double *stats, int slots, double *ws, float *mean,
+                                     float *rstd, float *a, float *bb, ogc_stream_t stream) {
+    OGC_REQUIRE(b >= 0 && c >= 1 && hw >= 1 && groups >= 1 && c % groups == 0, "ogc_group_norm_coeffs: bad shape");
+    if (b == 0) return OGC_OK;
+    OGC_REQUIRE(gamma && beta && mean && rstd && a && bb && (stats || (ws && x)), "ogc_group_norm_coeffs: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    if (!stats) {
+        const int rows = b * groups;
+        const long long row_len = (long long)(c / groups) * hw;
+        if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * rows, s) != hipSuccess) {
+            ogc_set_error("ogc_group_norm_coeffs: memset failed");
+            return OGC_ERR_LAUNCH;
+        }
+        int chunks = 1;
+        while ((long long)rows * chunks < 2048 && row_len / (chunks * 2) >= 16384) chunks *= 2;
+        long long chunk_len = (row_len + chunks - 1) / chunks;
+        chunk_len = (chunk_len + 3) / 4 * 4;
+        hipLaunchKernelGGL(gn_stats_kernel, dim3(ogc_divup(row_len, chunk_len), rows), dim3(GN_THREADS), 0, s, row_len,
+                           chunk_len, x, ws);
+        stats = ws;
+        slots = 1;
+    }
+    hipLaunchKernelGGL(gn_coeffs_kernel, dim3(ogc_divup(b * c, 256)), dim3(256), 0, s, b, c, hw, groups, eps, gamma, beta,
+                       stats, slots, mean, rstd, a, bb);
+    OGC_CHECK_LAUNCH("ogc_group_norm_coeffs");
+    return OGC_OK;
+}
+
 extern "C" int ogc_group_norm_fwd(int b, int c, int hw, int groups, float eps, int relu, const float *x,
                                   const float *gamma, const float *beta, float *y, float *mean, float *rstd,
                                   double *ws, ogc_stream_t stream) {

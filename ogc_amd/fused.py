@@ -443,3 +443,87 @@ def matched_distances(mask1, mask2, loss_norm):
         cols = torch.empty(2 * PB, K, dtype=torch.int32, device=dev)
         nat.lsap_maximize_wrapper(2 * PB, K, both, cols)
     return _MatchedDistance.apply(mask1, mask2, cols[:PB], cols[PB:], int(loss_norm))
+
+
+# ---- deferred normalisation inside a SharedMLP ----------------------------------------------------------------
+class _NormActConv(Function):
+    """y = conv(act(GroupNorm(y_prev))) WITHOUT materialising the normalised activation: the norm of the previous layer
+    is applied while the convolution loads its input (ogc_conv1x1_gemm_affine), recomputed the same way by the weight
+    gradient (ogc_conv1x1_wgrad_affine); the input gradient continues through the GroupNorm backward kernels.
+    Returns (y, statistics of y for the NEXT GroupNorm or None)."""
+
+    @staticmethod
+    def forward(ctx, y_prev, stats_prev, gn_weight, gn_bias, conv_weight, gn_groups, eps, relu, next_groups):
+        nat = _api._native
+        y_prev = y_prev.contiguous()
+        B, cin = y_prev.shape[0], y_prev.shape[1]
+        cout = conv_weight.shape[0]
+        hw = y_prev.numel() // (B * cin)
+        dev = y_prev.device
+        mean = torch.empty(B * gn_groups, dtype=torch.float32, device=dev)
+        rstd = torch.empty_like(mean)
+        a = torch.empty(B * cin, dtype=torch.float32, device=dev)
+        bb = torch.empty_like(a)
+        gamma, beta = gn_weight.detach().contiguous(), gn_bias.detach().contiguous()
+        if stats_prev is not None:
+            nat.group_norm_coeffs_wrapper(B, cin, hw, gn_groups, eps, None, gamma, beta, stats_prev,
+                                          stats_prev.numel() // (2 * B * gn_groups), None, mean, rstd, a, bb)
+        else:
+            ws = torch.empty(2 * B * gn_groups, dtype=torch.float64, device=dev)
+            nat.group_norm_coeffs_wrapper(B, cin, hw, gn_groups, eps, y_prev, gamma, beta, None, 0, ws, mean, rstd, a, bb)
+        y = torch.empty((B, cout) + tuple(y_prev.shape[2:]), dtype=torch.float32, device=dev)
+        w = conv_weight.detach().contiguous()
+        stats = None
+        if (next_groups > 0 and next_groups <= 32 and cout % next_groups == 0 and (cout // next_groups) % 4 == 0
+                and cin <= 100):
+            stats = torch.empty(nat.conv1x1_gn_slots() * B * next_groups * 2, dtype=torch.float64, device=dev)
+            nat.conv1x1_gemm_affine_wrapper(B, cout, cin, hw, relu, next_groups, w, y_prev, a, bb, y, stats)
+        else:
+            nat.conv1x1_gemm_affine_wrapper(B, cout, cin, hw, relu, 0, w, y_prev, a, bb, y, None)
+        ctx.save_for_backward(y_prev, gn_weight, gn_bias, conv_weight, mean, rstd, a, bb)
+        ctx.cfg = (gn_groups, relu, hw)
+        if stats is not None:
+            ctx.mark_non_differentiable(stats)
+        return y, stats
+
+    @staticmethod
+    def backward(ctx, grad_y, _grad_stats=None):
+        nat = _api._native
+        y_prev, gn_weight, gn_bias, conv_weight, mean, rstd, a, bb = ctx.saved_tensors
+        gn_groups, relu, hw = ctx.cfg
+        B, cin = y_prev.shape[0], y_prev.shape[1]
+        cout = conv_weight.shape[0]
+        grad_y = grad_y.contiguous()
+        w = conv_weight.detach().contiguous()
+        grad_w = torch.empty(cout, cin, dtype=torch.float32, device=y_prev.device)
+        nat.conv1x1_wgrad_affine_wrapper(B, cin, cout, hw, relu, y_prev, a, bb, grad_y, grad_w)
+        # gradient w.r.t. the (never stored) normalised activation, then through GroupNorm (+ ReLU)
+        if _gemm_ok(cout, hw):
+            grad_z = torch.empty_like(y_prev)
+            nat.conv1x1_gemm_wrapper(B, cin, cout, hw, 1, w, grad_y, grad_z)
+        else:
+            grad_z = torch.matmul(w.view(cout, cin).t(), grad_y.reshape(B, cout, hw)).view_as(y_prev)
+        grad_prev = torch.empty_like(y_prev)
+        gw, gb = torch.empty_like(gn_weight), torch.empty_like(gn_bias)
+        ws = torch.empty(2 * B * cin + B * gn_groups, dtype=torch.float64, device=y_prev.device)
+        nat.group_norm_bwd_wrapper(B, cin, hw, gn_groups, relu, y_prev, gn_weight.detach().contiguous(),
+                                   gn_bias.detach().contiguous(), mean, rstd, grad_z, grad_prev, gw, gb, ws)
+        return grad_prev, None, gw, gb, grad_w.view_as(conv_weight), None, None, None, None
+
+
+def norm_act_conv_available(y_prev, gn, conv):
+    """Can conv(act(gn(y_prev))) run with the norm folded into the convolution's operand load?"""
+    if not (y_prev.is_cuda and y_prev.dtype == torch.float32 and gn.affine and conv.bias is None and conv.groups == 1
+            and all(k == 1 for k in conv.kernel_size) and all(v == 1 for v in conv.stride)
+            and all(v == 0 for v in conv.padding)
+            and getattr(_api._native, "conv1x1_gemm_affine_wrapper", None) is not None):
+        return False
+    hw = y_prev.numel() // max(y_prev.shape[0] * y_prev.shape[1], 1)
+    return _gemm_ok(y_prev.shape[1], hw)
+
+
+def norm_act_conv(y_prev, stats_prev, gn, relu, conv, next_gn=None):
+    """(y, stats of y for next_gn or None) = conv(act(gn(y_prev))), see _NormActConv."""
+    next_groups = next_gn.num_groups if (next_gn is not None and next_gn.affine) else 0
+    return _NormActConv.apply(y_prev, stats_prev, gn.weight, gn.bias, conv.weight, gn.num_groups, gn.eps, bool(relu),
+                              next_groups)

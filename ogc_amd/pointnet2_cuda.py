@@ -294,6 +294,25 @@ def batch_norm_maxpool_bwd_wrapper(b, c, p, s, relu, training, x, gamma, mean, r
          _f(grad_x, "grad_x"), _f(grad_gamma, "grad_gamma"), _f(grad_beta, "grad_beta"), _check(ws, torch.float64, "ws"))
 
 
+def group_norm_coeffs_wrapper(b, c, hw, groups, eps, x, gamma, beta, stats, slots, ws, mean, rstd, a, bb):
+    """GroupNorm as a per-(b, channel) affine map, not applied (ogc_group_norm_coeffs)."""
+    _run("ogc_group_norm_coeffs", gamma, b, c, hw, groups, float(eps), _opt(x, torch.float32, "x"), _f(gamma, "gamma"),
+         _f(beta, "beta"), _opt(stats, torch.float64, "stats"), int(slots), _opt(ws, torch.float64, "ws"),
+         _f(mean, "mean"), _f(rstd, "rstd"), _f(a, "a"), _f(bb, "bb"))
+
+
+def conv1x1_gemm_affine_wrapper(b, M, K, hw, relu, groups, w, inp, pa, pb, out, stats):
+    """Forward conv on act(pa * in + pb), optionally with the output's GroupNorm statistics (ogc_conv1x1_gemm_affine)."""
+    _run("ogc_conv1x1_gemm_affine", inp, b, M, K, hw, int(relu), int(groups), _f(w, "w"), _f(inp, "in"), _f(pa, "pa"),
+         _f(pb, "pb"), _f(out, "out"), _opt(stats, torch.float64, "stats"))
+
+
+def conv1x1_wgrad_affine_wrapper(b, cin, cout, hw, relu, x, pa, pb, dy, dw):
+    """Weight gradient with the operand act(pa * x + pb) recomputed on load (ogc_conv1x1_wgrad_affine)."""
+    _run("ogc_conv1x1_wgrad_affine", x, b, cin, cout, hw, int(relu), _f(x, "x"), _f(pa, "pa"), _f(pb, "pb"),
+         _f(dy, "dy"), _f(dw, "dw"))
+
+
 def conv1x1_gn_slots():
     """Number of accumulator copies conv1x1_gemm_gnstats_wrapper fills (ogc_conv1x1_gn_slots)."""
     return _lib.load().ogc_conv1x1_gn_slots()

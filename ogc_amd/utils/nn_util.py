@@ -166,18 +166,53 @@ class SharedMLP(nn.Sequential):
                                    preact=preact))
 
 
+def _shared_mlp_run(self, x, pool):
+    """The layers in sequence.  Inside the stack the output of conv -> GroupNorm -> ReLU is only read by the next
+    convolution, so on the GPU it is never written: the raw convolution output travels on together with the norm's
+    statistics (`pending`) and the norm is applied by the next convolution while loading (fused.norm_act_conv).  The
+    last layer's norm / activation (/ max over the neighbourhood, `pool`) is one fused op."""
+    from ..fused import (group_norm_act, group_norm_act_maxpool, norm_act_conv, norm_act_conv_available, pointwise_conv)
+    layers = list(self.children())
+    pending = None  # (raw conv output, its GroupNorm statistics or None, the GroupNorm, relu?)
+
+    def flush(p, last):
+        y, stats, gn, relu = p
+        if last and pool:
+            return group_norm_act_maxpool(y, gn, relu, stats)
+        return group_norm_act(y, gn, relu, stats)
+
+    for li, layer in enumerate(layers):
+        fusable = isinstance(layer, _ConvNd) and layer._gn_fuse
+        if not fusable:
+            if pending is not None:
+                x, pending = flush(pending, False), None
+            x = layer(x)
+            continue
+        conv_name, norm_name, relu = layer._names
+        conv, gn = getattr(layer, conv_name), getattr(layer, norm_name)[0]
+        if pending is not None and norm_act_conv_available(pending[0], pending[2], conv):
+            y, stats = norm_act_conv(pending[0], pending[1], pending[2], pending[3], conv, gn)
+        else:
+            if pending is not None:
+                x, pending = flush(pending, False), None
+            y, stats = pointwise_conv(x, conv, gn)
+        pending = (y, stats, gn, relu)
+    if pending is not None:
+        return flush(pending, True)
+    return x.max(dim=-1)[0] if pool else x
+
+
+def _shared_mlp_forward(self, x):
+    return _shared_mlp_run(self, x, False)
+
+
 def _shared_mlp_forward_maxpool(self, x):
     """SharedMLP applied to (B, C, npoint, nsample) followed by the max over nsample
     (reference: utils/pointnet2_util.py:38-42); the last layer's norm/activation/pooling run as one fused op."""
-    layers = list(self.children())
-    for layer in layers[:-1]:
-        x = layer(x)
-    last = layers[-1]
-    if hasattr(last, "forward_maxpool"):
-        return last.forward_maxpool(x)
-    return last(x).max(dim=-1)[0]
+    return _shared_mlp_run(self, x, True)
 
 
+SharedMLP.forward = _shared_mlp_forward
 SharedMLP.forward_maxpool = _shared_mlp_forward_maxpool
 
 

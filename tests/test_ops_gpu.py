@@ -667,3 +667,47 @@ def test_batch_norm_act_fused(shape, pool, training):
     torch.testing.assert_close(bn.running_mean, bn2.running_mean, rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(bn.running_var, bn2.running_var, rtol=1e-5, atol=1e-6)
     assert int(bn.num_batches_tracked) == int(bn2.num_batches_tracked)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pool", [False, True])
+@pytest.mark.parametrize("spec", [([6, 32, 32, 64], 2, 256, 16), ([99, 64, 64, 128], 3, 64, 64), ([131, 128, 128, 256], 2, 32, 64),
+                                  ([384, 128, 128], 2, 512, 1), ([35, 16], 2, 64, 8)])
+def test_shared_mlp_deferred_normalisation(spec, pool, monkeypatch):
+    """SharedMLP with the inner GroupNorm(+ReLU) applied inside the next convolution's operand load, against the same
+    stack with every normalised activation materialised: outputs, input gradient and all parameter gradients."""
+    import copy
+    import ogc_amd.pointnet2.pointnet2 as api
+    from ogc_amd.utils.nn_util import SharedMLP
+    channels, B, P, S = spec
+    torch.manual_seed(sum(channels) + pool)
+    mlp = SharedMLP(list(channels), bn={"class": "GroupNorm", "num_groups": 4}).cuda()
+    for p in mlp.parameters():
+        if p.dim() == 1:
+            p.data.uniform_(0.5, 1.5)
+    ref = copy.deepcopy(mlp)
+    x = torch.randn(B, channels[0], P, S, device="cuda")
+    x1, x2 = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    run = (lambda m, t: m.forward_maxpool(t)) if pool else (lambda m, t: m(t))
+    y1 = run(mlp, x1)
+    w = torch.randn_like(y1)
+    (y1 * w).sum().backward()
+
+    class NoDeferred:
+        def __init__(self, native):
+            self._native = native
+
+        def __getattr__(self, name):
+            if name == "conv1x1_gemm_affine_wrapper":
+                raise AttributeError(name)
+            return getattr(self._native, name)
+
+    monkeypatch.setattr(api, "_native", NoDeferred(api._native))
+    y2 = run(ref, x2)
+    (y2 * w).sum().backward()
+    torch.testing.assert_close(y1, y2, rtol=1e-4, atol=1e-4)
+    scale = x2.grad.abs().max().item()
+    torch.testing.assert_close(x1.grad, x2.grad, rtol=1e-3, atol=1e-4 * max(scale, 1.0))
+    for (n1, p1), (_, p2) in zip(mlp.named_parameters(), ref.named_parameters()):
+        s = p2.grad.abs().max().item()
+        torch.testing.assert_close(p1.grad, p2.grad, rtol=2e-3, atol=2e-4 * max(s, 1.0), msg=lambda m, n=n1: n + ": " + m)
