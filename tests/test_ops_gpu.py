@@ -672,7 +672,8 @@ def test_batch_norm_act_fused(shape, pool, training):
 @pytest.mark.gpu
 @pytest.mark.parametrize("pool", [False, True])
 @pytest.mark.parametrize("spec", [([6, 32, 32, 64], 2, 256, 16), ([99, 64, 64, 128], 3, 64, 64), ([131, 128, 128, 256], 2, 32, 64),
-                                  ([384, 128, 128], 2, 512, 1), ([35, 16], 2, 64, 8)])
+                                  ([384, 128, 128], 2, 512, 1), ([35, 16], 2, 64, 8),
+                                  ([9, 20, 24, 12], 1, 37, 5), ([6, 32, 64], 3, 24, 2), ([67, 64, 64, 64], 2, 100, 16)])
 def test_shared_mlp_deferred_normalisation(spec, pool, monkeypatch):
     """SharedMLP with the inner GroupNorm(+ReLU) applied inside the next convolution's operand load, against the same
     stack with every normalised activation materialised: outputs, input gradient and all parameter gradients."""
