@@ -114,39 +114,38 @@ def main():
 
 def bench_conv_gn(ops, iters):
     if "conv" in ops:
+        slots = nat.conv1x1_gn_slots()
         for (B, cin, cout, hw) in [(16, 6, 32, 131072), (16, 32, 32, 131072), (16, 32, 64, 131072), (16, 99, 64, 65536),
                                    (16, 64, 64, 65536), (16, 64, 128, 65536), (16, 131, 128, 32768), (16, 128, 128, 32768),
                                    (16, 128, 256, 32768)]:
             x = torch.randn(B, cin, hw, device=DEV)
             w = torch.randn(cout, cin, device=DEV)
-            y = torch.empty(B, cout, hw, device=DEV)
+            y, y2 = torch.empty(B, cout, hw, device=DEV), torch.empty(B, cout, hw, device=DEV)
             dx = torch.empty_like(x)
             dw = torch.empty(cout, cin, device=DEV)
+            byt = 4.0 * B * hw * (cin + cout)
             f = timeit(lambda: nat.conv1x1_gemm_wrapper(B, cout, cin, hw, 0, w, x, y), iters)
-            st = torch.empty(nat.conv1x1_gn_slots() * B * 4 * 2, dtype=torch.float64, device=DEV)
-            if cin > 100:  # the fused statistics are only offered up to K = 100
-                print("conv  B=%-3d %4d->%-4d hw=%-6d fwd %7.3f ms %6.0f GB/s | dgrad %7.3f ms %6.0f GB/s | wgrad %7.3f ms %6.0f GB/s" %
-                      (B, cin, cout, hw, f, 4.0 * B * hw * (cin + cout) / f / 1e6,
-                       *(lambda d: (d, 4.0 * B * hw * (cin + cout) / d / 1e6))(timeit(lambda: nat.conv1x1_gemm_wrapper(B, cin, cout, hw, 1, w, y, x.new_empty(B, cin, hw)), iters) if cout <= 160 else float("nan")),
-                       *(lambda g_: (g_, 4.0 * B * hw * (cin + cout) / g_ / 1e6))(timeit(lambda: nat.conv1x1_wgrad_wrapper(B, cin, cout, hw, x, y, w.new_empty(cout, cin)), iters))))
-                continue
-            fs = timeit(lambda: nat.conv1x1_gemm_gnstats_wrapper(B, cout, cin, hw, 4, w, x, y, st), iters)
-            wsd = torch.empty(2 * B * 4, dtype=torch.float64, device=DEV)
-            from ogc_amd import _lib as _l
-            def stats_only():
-                import ctypes
-                mean = torch.empty(B * 4, device=DEV); rstd = torch.empty(B * 4, device=DEV)
-                nat.group_norm_fwd_wrapper(B, cout, hw, 4, 1e-5, 1, y, torch.ones(cout, device=DEV), torch.zeros(cout, device=DEV), y2, mean, rstd, wsd)
-            y2 = torch.empty_like(y)
-            gfull = timeit(stats_only, iters)
-            mean = torch.empty(B * 4, device=DEV); rstd = torch.empty(B * 4, device=DEV)
-            gapply = timeit(lambda: nat.group_norm_fwd_stats_wrapper(B, cout, hw, 4, 1e-5, 1, y, torch.ones(cout, device=DEV), torch.zeros(cout, device=DEV), y2, mean, rstd, st, nat.conv1x1_gn_slots()), iters)
-            print("      conv+stats %.3f (+%.3f) | GN stats+apply %.3f vs apply-only %.3f (stats pass = %.3f)" % (fs, fs - f, gfull, gapply, gfull - gapply))
             d = timeit(lambda: nat.conv1x1_gemm_wrapper(B, cin, cout, hw, 1, w, y, dx), iters) if cout <= 160 else float("nan")
             g = timeit(lambda: nat.conv1x1_wgrad_wrapper(B, cin, cout, hw, x, y, dw), iters)
-            byt = 4.0 * B * hw * (cin + cout)
             print("conv  B=%-3d %4d->%-4d hw=%-6d fwd %7.3f ms %6.0f GB/s | dgrad %7.3f ms %6.0f GB/s | wgrad %7.3f ms %6.0f GB/s" %
                   (B, cin, cout, hw, f, byt / f / 1e6, d, byt / d / 1e6, g, byt / g / 1e6))
+            # variants of the same layer: GroupNorm statistics in the epilogue (offered up to K = 100) and the previous
+            # layer's GroupNorm + ReLU folded into the operand load
+            gamma, beta = torch.ones(cout, device=DEV), torch.zeros(cout, device=DEV)
+            mean, rstd = torch.empty(B * 4, device=DEV), torch.empty(B * 4, device=DEV)
+            ws = torch.empty(2 * B * 4, dtype=torch.float64, device=DEV)
+            gn_full = timeit(lambda: nat.group_norm_fwd_wrapper(B, cout, hw, 4, 1e-5, 1, y, gamma, beta, y2, mean, rstd, ws), iters)
+            a, bb = torch.rand(B * cin, device=DEV), torch.randn(B * cin, device=DEV)
+            fa = timeit(lambda: nat.conv1x1_gemm_affine_wrapper(B, cout, cin, hw, 1, 0, w, x, a, bb, y, None), iters)
+            ga = timeit(lambda: nat.conv1x1_wgrad_affine_wrapper(B, cin, cout, hw, 1, x, a, bb, y, dw), iters)
+            line = "      input norm folded in: fwd %+.3f, wgrad %+.3f ms" % (fa - f, ga - g)
+            if cin <= 100:
+                st = torch.empty(slots * B * 4 * 2, dtype=torch.float64, device=DEV)
+                fs = timeit(lambda: nat.conv1x1_gemm_gnstats_wrapper(B, cout, cin, hw, 4, w, x, y, st), iters)
+                gn_apply = timeit(lambda: nat.group_norm_fwd_stats_wrapper(B, cout, hw, 4, 1e-5, 1, y, gamma, beta, y2, mean,
+                                                                           rstd, st, slots), iters)
+                line += " | output statistics in the epilogue: %+.3f ms vs %.3f ms for the separate pass" % (fs - f, gn_full - gn_apply)
+            print(line + " | GroupNorm+ReLU of the output (stats + apply): %.3f ms" % gn_full)
     if "gn" in ops:
         from ogc_amd.fused import group_norm_act, group_norm_act_maxpool
         for shape in [(16, 32, 2048, 64), (16, 64, 1024, 64), (16, 128, 512, 64), (16, 256, 512, 64)]:
