@@ -148,7 +148,7 @@ __global__ __launch_bounds__(SL_THREADS) void rigid_blend_kernel(int n, int k, c
 }
 
 // grid (chunks, PB): counts[pb][g][p] += 1 for (g, p) = (argmax m1, argmax m2) of every point (first maximum wins,
-// like torch.argmax); after the last chunk... the IoU is formed by mask_iou_kernel
+// like torch.argmax), privatised in LDS; mask_iou_kernel turns the counts into IoUs
 __global__ __launch_bounds__(SL_THREADS) void mask_confusion_kernel(int n, int k, const float *__restrict__ m1,
                                                                     const float *__restrict__ m2,
                                                                     int *__restrict__ counts) {
