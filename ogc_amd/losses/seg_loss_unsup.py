@@ -456,3 +456,59 @@ class UnsupervisedOGCLoss(nn.Module):
         else:
             pending = monitors()
         return loss, (pending.resolve() if sync else pending)
+
+
+class UnsupervisedOGCLossSingleFrame(UnsupervisedOGCLoss):
+    """The Waymo variant (reference: train_seg_waymo.py:244-334): the trainer keeps every other view
+    (`pcs[:, ::2]`, :59 — Waymo only has backward flow), so a sample is ONE frame, plus its augmented twin once
+    augmentation is on.  Dynamic / smooth / entropy / rank are averaged over the one or two views; the invariance term
+    pairs the frame with its twin.  Same ``loss_dict`` keys."""
+
+    def plan_geometry(self, pcs, aug_transform=False):
+        n_view = 2 if aug_transform else 1
+        if hasattr(self.smooth_loss, "plan_views"):
+            return self.smooth_loss.plan_views(list(pcs)[:n_view])
+        return None
+
+    def forward(self, pcs, masks, flows, step_w=False, it=0, aug_transform=False, geometry=None, sync=True):
+        assert len(pcs) == len(masks) == len(flows), "Inconsistent number of frames!"
+        n_view = 2 if aug_transform else 1
+        pcs, masks, flows = list(pcs)[:n_view], list(masks)[:n_view], list(flows)[:n_view]
+        assert len(pcs) == n_view
+
+        def weight(w, start):
+            return self.step_lossw(it, weight=w, start_step=start) if step_w else w
+
+        def total(vals):  # (v1 + v2) * 0.5 with augmentation, v1 alone without (:287-291, :300-304)
+            return 0.5 * (vals[0] + vals[1]) if aug_transform else vals[0]
+
+        terms = {}
+        l_dynamic = total(self.dynamic_loss.forward_views(pcs, masks, flows))
+        terms['dynamic'] = l_dynamic
+        loss = weight(self.w_dynamic, self.start_step_dynamic) * l_dynamic
+        l_smooth = total(self.smooth_loss.forward_views(pcs, masks, geometry))
+        terms['smooth'] = l_smooth
+        loss = loss + weight(self.w_smooth, self.start_step_smooth) * l_smooth
+        if aug_transform:
+            l_invariance = self.invariance_loss.forward_pairs([(masks[0], masks[1])])[0]
+            terms['invariance'] = l_invariance
+            loss = loss + weight(self.w_invariance, self.start_step_invariance) * l_invariance
+        terms['sum'] = loss
+
+        def monitors():
+            with torch.no_grad():
+                terms['entropy'] = total([self.entropy_loss(m) for m in masks])
+                terms['rank'] = total([self.rank_loss(m) for m in masks])
+            return PendingLossDict(terms)
+
+        if loss.is_cuda and not sync:
+            from ..utils.streams import side_stream
+            side = side_stream(loss.device, "monitor")
+            side.wait_stream(torch.cuda.current_stream())
+            for t in list(masks) + list(terms.values()):
+                t.record_stream(side)
+            with torch.cuda.stream(side):
+                pending = monitors()
+        else:
+            pending = monitors()
+        return loss, (pending.resolve() if sync else pending)

@@ -80,11 +80,13 @@ def save_checkpoint(net, exp_base, is_best):
         shutil.copyfile(cur, os.path.join(exp_base, "best.pth.tar"))
 
 
-def evaluate(model, criterion, loader, device):
+def evaluate(model, criterion, loader, device, single_frame=False):
     model.eval()
     total, count = 0.0, 0
     with torch.no_grad():
         for pcs, segms, flows, valids in loader:
+            if single_frame:
+                pcs, segms, flows = pcs[:, ::2].contiguous(), segms[:, ::2].contiguous(), flows[:, ::2].contiguous()
             pcs, flows = pcs.to(device), flows.to(device)
             b, t, n = segms.shape
             flat = pcs.view(b * t, n, -1).contiguous()
@@ -145,7 +147,10 @@ def main(argv=None):
     val_loader = torch.utils.data.DataLoader(val_set, batch_size=cfg["batch_size"], shuffle=False)
 
     optimizer = make_optimizer(net.parameters(), lr=cfg["lr"], weight_decay=cfg["weight_decay"])
-    criterion = build_criterion(cfg["loss"])
+    # Waymo: only backward flow exists, the trainer keeps every other view and uses the one-frame loss
+    # (train_seg_waymo.py:59, :244-334)
+    single_frame = cfg["dataset"] == "waymo"
+    criterion = build_criterion(cfg["loss"], single_frame=single_frame)
     exp_base = cfg["save_path"] + "_R%d" % args.round
     if rank == 0:
         os.makedirs(exp_base, exist_ok=True)
@@ -168,6 +173,8 @@ def main(argv=None):
 
         def device_batches():
             for cpu_batch in train_loader:
+                if single_frame:
+                    cpu_batch = tuple(x[:, ::2].contiguous() for x in cpu_batch)
                 yield tuple(x.to(device, non_blocking=True) for x in cpu_batch)
 
         stream_of_batches = device_batches()
@@ -192,7 +199,7 @@ def main(argv=None):
                 break
         account(in_flight)
         n_it = max(len(train_loader) if not args.max_iters else min(len(train_loader), it), 1)
-        val_loss = evaluate(model, criterion, val_loader, device)
+        val_loss = evaluate(model, criterion, val_loader, device, single_frame)
         if distributed:
             t = torch.tensor([val_loss], device=device)
             dist.all_reduce(t)

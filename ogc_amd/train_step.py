@@ -6,6 +6,7 @@ called with ``step_w=True, it=it*b``, and the optimiser step is skipped when any
 import torch
 
 from .losses.seg_loss_unsup import (DynamicLoss, EntropyLoss, InvarianceLoss, RankLoss, SmoothLoss,
+                                    UnsupervisedOGCLossSingleFrame,
                                     UnsupervisedOGCLoss)
 
 KITTI_LOSS = dict(  # config/seg/kittisf/kittisf_unsup.yaml:40-56
@@ -23,8 +24,10 @@ SAPIEN_LOSS = dict(  # config/seg/sapien/sapien_unsup.yaml
     invariance_loss_params=dict(loss_norm=2))
 
 
-def build_criterion(cfg):
-    return UnsupervisedOGCLoss(DynamicLoss(**cfg["dynamic_loss_params"]), SmoothLoss(**cfg["smooth_loss_params"]),
+def build_criterion(cfg, single_frame=False):
+    """single_frame: the Waymo variant of the loss (one frame per sample, train_seg_waymo.py:244-334)."""
+    cls = UnsupervisedOGCLossSingleFrame if single_frame else UnsupervisedOGCLoss
+    return cls(DynamicLoss(**cfg["dynamic_loss_params"]), SmoothLoss(**cfg["smooth_loss_params"]),
                                InvarianceLoss(**cfg["invariance_loss_params"]), EntropyLoss(), RankLoss(),
                                weights=cfg["weights"], start_steps=cfg["start_steps"])
 

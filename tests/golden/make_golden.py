@@ -209,6 +209,34 @@ def gen_losses():
     save("losses", **{k: (v.detach().numpy() if torch.is_tensor(v) else v) for k, v in out.items()})
 
 
+def gen_waymo_loss():
+    """The single-frame loss variant that lives in the reference's train_seg_waymo.py:244-334 (same inputs as `losses`)."""
+    import train_seg_waymo as ref_waymo  # the module guards its driver with __main__
+    from losses.seg_loss_unsup import DynamicLoss, EntropyLoss, InvarianceLoss, RankLoss, SmoothLoss
+    B, N, K = 2, 512, 6
+    scenes = [detgen.rigid_scene(B, N, K, 31 + 10 * v) for v in range(4)]
+    smooth_params = {'w_knn': 3., 'w_ball_q': 1.,
+                     'knn_loss_params': {'k': 8, 'radius': 0.1, 'cross_entropy': False, 'loss_norm': 1},
+                     'ball_q_loss_params': {'k': 16, 'radius': 0.2, 'cross_entropy': False, 'loss_norm': 1}}
+    crit = ref_waymo.UnsupervisedOGCLoss(DynamicLoss(loss_norm=2), SmoothLoss(**smooth_params), InvarianceLoss(loss_norm=2),
+                                         EntropyLoss(), RankLoss(), weights=[10.0, 0.1, 0.1], start_steps=[0, 100, 0])
+    out = {}
+    # views as the Waymo trainer selects them (train_seg_waymo.py:59): frame 0 and, with augmentation, its augmented twin
+    views = [0, 2]
+    for tag, aug, step_w, it in [("1v", False, False, 0), ("2v", True, True, 50), ("2v_gated", True, True, 500)]:
+        sel = views[:2 if aug else 1]
+        pcs = [T(scenes[v][0]) for v in sel]
+        flows = [T(scenes[v][1]) for v in sel]
+        masks = [T(scenes[v][2]).requires_grad_(True) for v in sel]
+        loss, ld = crit(pcs, masks, flows, step_w=step_w, it=it, aug_transform=aug)
+        gs = torch.autograd.grad(loss, masks)
+        out["%s_loss" % tag] = loss.detach().numpy()
+        out["%s_dict" % tag] = np.array([ld[k] for k in ('dynamic', 'smooth', 'invariance', 'entropy', 'rank', 'sum')], np.float64)
+        for i, g in enumerate(gs):
+            out["%s_gmask%d" % (tag, i)] = g.numpy()
+    save("losses_waymo", **out)
+
+
 def gen_models():
     import importlib
     for name, kw, N, B in [("segnet_sapien", dict(n_slot=8, n_point=512, transformer_embed_dim=128), 512, 2),
@@ -249,7 +277,7 @@ if __name__ == "__main__":
     assert os.path.isdir(REF), "the reference tree is only present in the build container"
     install_shims()
     orc.build()
-    which = sys.argv[1:] or ["ops", "modules", "losses", "models"]
+    which = sys.argv[1:] or ["ops", "modules", "losses", "waymo", "models"]
     with torch.no_grad():
         pass
     if "ops" in which:
@@ -258,5 +286,7 @@ if __name__ == "__main__":
         gen_modules()
     if "losses" in which:
         gen_losses()
+    if "waymo" in which:
+        gen_waymo_loss()
     if "models" in which:
         gen_models()

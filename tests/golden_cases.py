@@ -130,6 +130,33 @@ def run_modules(dev, rtol=1e-5, atol=1e-6):
     check_grads(fe, (corr ** 2).mean(), g, "fe_", 1e-4, 1e-7)
 
 
+def run_waymo_loss(dev, rtol=1e-5, atol=1e-6, grad_rel=5e-3):
+    """UnsupervisedOGCLossSingleFrame against the class in the reference's train_seg_waymo.py:244-334 (fixture
+    losses_waymo.npz, inputs shared with `losses`)."""
+    from ogc_amd.losses.seg_loss_unsup import (DynamicLoss, EntropyLoss, InvarianceLoss, RankLoss, SmoothLoss,
+                                               UnsupervisedOGCLossSingleFrame)
+    g, gw = load("losses"), load("losses_waymo")
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    smooth_params = {'w_knn': 3., 'w_ball_q': 1.,
+                     'knn_loss_params': {'k': 8, 'radius': 0.1, 'cross_entropy': False, 'loss_norm': 1},
+                     'ball_q_loss_params': {'k': 16, 'radius': 0.2, 'cross_entropy': False, 'loss_norm': 1}}
+    crit = UnsupervisedOGCLossSingleFrame(DynamicLoss(loss_norm=2), SmoothLoss(**smooth_params), InvarianceLoss(loss_norm=2),
+                                          EntropyLoss(), RankLoss(), weights=[10.0, 0.1, 0.1], start_steps=[0, 100, 0])
+    keys = ('dynamic', 'smooth', 'invariance', 'entropy', 'rank', 'sum')
+    for tag, aug, step_w, it in [("1v", False, False, 0), ("2v", True, True, 50), ("2v_gated", True, True, 500)]:
+        sel = [0, 2][:2 if aug else 1]
+        pcs = [T(g["pc%d" % v]) for v in sel]
+        flows = [T(g["flow%d" % v]) for v in sel]
+        masks = [T(g["mask%d" % v]).requires_grad_(True) for v in sel]
+        loss, ld = crit(pcs, masks, flows, step_w=step_w, it=it, aug_transform=aug)
+        assert tuple(ld.keys()) == keys
+        gs = torch.autograd.grad(loss, masks)
+        close(loss, gw["%s_loss" % tag], rtol, atol, "waymo_%s_loss" % tag)
+        close(np.array([ld[k] for k in keys]), gw["%s_dict" % tag], rtol, atol, "waymo_%s_dict" % tag)
+        for i, gr in enumerate(gs):
+            close_scaled(gr, gw["%s_gmask%d" % (tag, i)], grad_rel, "waymo_%s_gmask%d" % (tag, i))
+
+
 def run_losses(dev, rtol=1e-5, atol=1e-6, grad_rel=5e-3):
     from ogc_amd.losses.flow_loss_unsup import ChamferLoss, UnsupervisedFlowStep3DLoss
     from ogc_amd.losses.flow_loss_unsup import SmoothLoss as FlowSmoothLoss

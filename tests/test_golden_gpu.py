@@ -27,6 +27,10 @@ def test_losses_and_oa_icp():
     gc.run_losses("cuda", rtol=1e-5, atol=1e-6)
 
 
+def test_waymo_single_frame_loss():
+    gc.run_waymo_loss("cuda", rtol=1e-5, atol=1e-6)
+
+
 @pytest.mark.parametrize("name,kw,N,B", gc.SEG_CASES, ids=[c[0] for c in gc.SEG_CASES])
 def test_segnet_forward_backward(name, kw, N, B):
     gc.run_segnet("cuda", name, kw, N, B, rtol=1e-3, atol=1e-5, grad_rtol=1e-2)
