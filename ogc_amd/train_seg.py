@@ -38,20 +38,32 @@ NORM_LAYERS = (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d, torch.nn.BatchNorm3d,
 class SyntheticScenes(torch.utils.data.Dataset):
     """`n_scene` seeded scenes; item = (pcs (t,N,3), segms (t,N), flows (t,N,3), valids (t,N)), t = 2 or 4 views."""
 
-    def __init__(self, n_scene, n_point, n_object, outdoor, seed=0, predflow_dir=None):
+    def __init__(self, n_scene, n_point, n_object, outdoor, seed=0, predflow_dir=None, aug_transform_args=None):
         self.n_scene, self.n_point, self.n_object, self.outdoor, self.seed = n_scene, n_point, n_object, outdoor, seed
         self.aug_transform = False
         # flows predicted for the two frames of scene i, `<predflow_dir>/<i as %06d>/flow{1,2}.npy` (the layout
         # datasets/dataset_kittisf.py:125-137 writes and :99-104 reads); ground-truth flows when absent
         self.predflow_dir = predflow_dir
+        # `data.aug_transform_args` of the reference's YAMLs: when given, augmented samples are built the way its
+        # datasets build them (datasets/dataset_kittisf.py:113-117): utils.data_util.augment_transform draws TWO
+        # similarity transforms of the frame pair -> 4 views, none of them the untouched pair
+        self.aug_transform_args = aug_transform_args
 
     def __len__(self):
         return self.n_scene
 
     def __getitem__(self, i):
+        by_reference_recipe = self.aug_transform and self.aug_transform_args is not None
         pcs, segms, flows, valids = make_scene_batch(1, self.n_point, self.n_object, seed=self.seed + i,
-                                                     outdoor=self.outdoor, aug=self.aug_transform)
+                                                     outdoor=self.outdoor, aug=self.aug_transform and not by_reference_recipe)
         pcs, segms, flows, valids = pcs[0], segms[0], flows[0], valids[0]
+        if by_reference_recipe:
+            import numpy as np
+            from .utils.data_util import augment_transform
+            a, f = augment_transform(pcs.numpy().astype(np.float64), flows.numpy().astype(np.float64),
+                                     self.aug_transform_args, rng=np.random.RandomState(self.seed + i))
+            pcs, flows = torch.from_numpy(a.astype(np.float32)), torch.from_numpy(f.astype(np.float32))
+            segms, valids = torch.cat([segms, segms]), torch.cat([valids, valids])
         if self.predflow_dir is not None and not self.aug_transform:
             import numpy as np
             paths = [os.path.join(self.predflow_dir, "%06d" % i, "flow%d.npy" % v) for v in (1, 2)]
@@ -139,7 +151,8 @@ def main(argv=None):
         name = cfg.get("predflow_path", "flowstep3d")
         predflow_dir = os.path.join(args.flow_root, "flow_preds", name if args.round <= 1 else "%s_R%d" % (name, args.round - 1))
     train_set = SyntheticScenes(args.synthetic, seg["n_point"], seg["n_slot"], outdoor, seed=1000 * (rank + 1),
-                                predflow_dir=predflow_dir)
+                                predflow_dir=predflow_dir,
+                                aug_transform_args=(cfg.get("data") or {}).get("aug_transform_args") or None)
     val_set = SyntheticScenes(max(args.synthetic // 8, cfg["batch_size"]), seg["n_point"], seg["n_slot"], outdoor, seed=7)
     sampler = torch.utils.data.distributed.DistributedSampler(train_set) if distributed else None
     train_loader = torch.utils.data.DataLoader(train_set, batch_size=cfg["batch_size"], shuffle=sampler is None,

@@ -237,6 +237,23 @@ def gen_waymo_loss():
     save("losses_waymo", **out)
 
 
+def gen_data_util():
+    """Host-side helpers of utils/data_util.py: augment_transform under a fixed numpy seed, label compression."""
+    from utils.data_util import augment_transform, compress_label_id, segm_to_mask
+    pcs = detgen.uniform((2, 64, 3), 7, -1.0, 1.0).astype(np.float64)
+    flows = detgen.uniform((2, 64, 3), 8, -0.1, 0.1).astype(np.float64)
+    args_seg = {'scale_low': 0.95, 'scale_high': 1.05, 'degree_range': [0, 180, 0], 'shift_range': [0, 0.1, 0.2]}
+    args_flow = dict(args_seg, degree_range=[5, 10, 15], aug_pc2={'degree_range': [1, 2, 3], 'shift_range': [0.01, 0.02, 0.03]})
+    out = {"pcs": pcs, "flows": flows}
+    for tag, args, nv in (("seg", args_seg, 2), ("flow", args_flow, 3)):
+        np.random.seed(1234)
+        a, b = augment_transform(pcs, flows, args, n_view=nv)
+        out["aug_%s_pcs" % tag], out["aug_%s_flows" % tag] = a, b
+    segm = np.array([7, 3, 3, 12, 7, 0, 12, 12, 5], np.int64)
+    out["segm"], out["segm_cpr"], out["segm_mask"], out["segm_mask8"] = segm, compress_label_id(segm), segm_to_mask(segm), segm_to_mask(segm, 8)
+    save("data_util", **out)
+
+
 def gen_models():
     import importlib
     for name, kw, N, B in [("segnet_sapien", dict(n_slot=8, n_point=512, transformer_embed_dim=128), 512, 2),
@@ -277,7 +294,7 @@ if __name__ == "__main__":
     assert os.path.isdir(REF), "the reference tree is only present in the build container"
     install_shims()
     orc.build()
-    which = sys.argv[1:] or ["ops", "modules", "losses", "waymo", "models"]
+    which = sys.argv[1:] or ["ops", "modules", "losses", "waymo", "data", "models"]
     with torch.no_grad():
         pass
     if "ops" in which:
@@ -288,5 +305,7 @@ if __name__ == "__main__":
         gen_losses()
     if "waymo" in which:
         gen_waymo_loss()
+    if "data" in which:
+        gen_data_util()
     if "models" in which:
         gen_models()

@@ -27,6 +27,25 @@ def test_losses_and_oa_icp(cpu_ops):
     gc.run_losses("cpu")
 
 
+def test_data_util_helpers():
+    """augment_transform (same numpy seed -> same augmentations) and the label helpers vs the reference's own."""
+    import numpy as np
+    from ogc_amd.utils.data_util import augment_transform, compress_label_id, segm_to_mask
+    g = gc.load("data_util")
+    args_seg = {'scale_low': 0.95, 'scale_high': 1.05, 'degree_range': [0, 180, 0], 'shift_range': [0, 0.1, 0.2]}
+    args_flow = dict(args_seg, degree_range=[5, 10, 15], aug_pc2={'degree_range': [1, 2, 3], 'shift_range': [0.01, 0.02, 0.03]})
+    for tag, args, nv in (("seg", args_seg, 2), ("flow", args_flow, 3)):
+        np.random.seed(1234)
+        a, b = augment_transform(g["pcs"], g["flows"], args, n_view=nv)
+        np.testing.assert_allclose(a, g["aug_%s_pcs" % tag], rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(b, g["aug_%s_flows" % tag], rtol=1e-12, atol=1e-12)
+        a2, _ = augment_transform(g["pcs"], g["flows"], args, n_view=nv, rng=np.random.RandomState(1234))
+        np.testing.assert_allclose(a2, a, rtol=0, atol=0)
+    np.testing.assert_array_equal(compress_label_id(g["segm"]), g["segm_cpr"])
+    np.testing.assert_array_equal(segm_to_mask(g["segm"]), g["segm_mask"])
+    np.testing.assert_array_equal(segm_to_mask(g["segm"], 8), g["segm_mask8"])
+
+
 def test_waymo_single_frame_loss(cpu_ops):
     gc.run_waymo_loss("cpu")
 

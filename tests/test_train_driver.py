@@ -6,7 +6,8 @@ import yaml
 
 CFG = {
     "dataset": "sapien", "save_path": None, "random_seed": 10,
-    "data": {"root": "/nonexistent", "aug_transform_args": {}, "decentralize": False},
+    "data": {"root": "/nonexistent", "aug_transform_args": {"scale_low": 0.95, "scale_high": 1.05, "degree_range": [0, 180, 0],
+                                                          "shift_range": [0, 0, 0]}, "decentralize": False},
     "aug_transform_epoch": 1, "predflow_path": "flowstep3d", "ignore_npoint_thresh": 0,
     "epochs": 2, "batch_size": 2, "lr": 1.0e-3, "lr_decay": 0.7, "lr_clip": 1.0e-5,
     "bn_momentum": 0.9, "bn_decay": 1.0, "weight_decay": 0.0, "decay_step": 4,
