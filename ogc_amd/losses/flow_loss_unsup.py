@@ -131,7 +131,8 @@ class UnsupervisedFlowStep3DLoss(nn.Module):
         self.w_chamfer, self.w_smooth = weights
         self.iters_w = iters_w
 
-    def forward(self, pc1, pc2, flow_preds, sync=True):
+    def forward(self, pc1, pc2, flow_preds, sync=True, extra=None):
+        # extra: [(name, scalar tensor)] appended to the monitored dict (e.g. the EPE terms the reference's trainer adds)
         assert len(flow_preds) == len(self.iters_w)
         monitored, loss = [], 0
         plan = self.smooth_loss.plan(pc1) if hasattr(self.smooth_loss, "plan") else None
@@ -141,5 +142,7 @@ class UnsupervisedFlowStep3DLoss(nn.Module):
             monitored += [('chamfer_loss_#%d' % i, chamfer_i), ('smooth_loss_#%d' % i, smooth_i)]
             loss = loss + self.iters_w[i] * (self.w_chamfer * chamfer_i + self.w_smooth * smooth_i)
         monitored.append(('sum', loss))
+        if extra:
+            monitored += list(extra)
         pending = PendingFlowLossDict(monitored)
         return loss, (pending.resolve() if sync else pending)

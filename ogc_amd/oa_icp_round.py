@@ -11,8 +11,8 @@ Kept from the reference so that rounds chain with `train_seg`:
     (oa_icp.py:143-146, datasets/dataset_kittisf.py:125-137), refined flows written to
     `<flow-root>/flow_preds/<saveflow_path>_R<round>/<scene id>/flow{1,2}.npy` (oa_icp.py:183-186);
   * ICP iterations per round {1: 20, 2: 10, 3: 5, 4: 3} (oa_icp.py:175);
-  * the three reported flows: input, weighted-Kabsch, object-aware ICP (end-point error only here; the reference's
-    accuracy / outlier metrics live in metrics/flow_metric.py, out of scope).
+  * the three reported flows: input, weighted-Kabsch, object-aware ICP, each with EPE / AccS / AccR / Outlier
+    (metrics/flow_metric.py:4-25, computed on the device).
 Dataset readers are out of scope: scenes are the seeded synthetic ones of `train_seg`; when no predicted
 flow exists on disk for a scene, the ground-truth flow plus noise stands in for the flow network's prediction.
 """
@@ -25,6 +25,7 @@ import numpy as np
 import torch
 import yaml
 
+from .metrics.flow_metric import flow_metrics
 from .oa_icp import object_aware_icp, weighted_kabsch
 from .train_seg import SEGNETS, SyntheticScenes
 
@@ -78,6 +79,7 @@ def main(argv=None):
     icp_iter = ICP_ITERS[args.round]
     noise = 0.05 if outdoor else 0.005
 
+    thresh = 0.05 if outdoor else 0.01  # epe_norm_thresh per dataset (oa_icp.py:112,116,124)
     sums, count = {"input": 0.0, "kabsch": 0.0, "oa_icp": 0.0}, 0
     per_batch = max(args.test_batch_size // 2, 1)  # both pairs of a scene stay in one batch (oa_icp.py:179-180)
     for start in range(0, len(scenes), per_batch):
@@ -97,7 +99,7 @@ def main(argv=None):
             kabsch = weighted_kabsch(pc1, pred, mask1)
             refined = object_aware_icp(pc1, pc2, pred, mask1, mask2, icp_iter=icp_iter)
         for key, flow in (("input", pred), ("kabsch", kabsch), ("oa_icp", refined)):
-            sums[key] += float((flow - gt).norm(dim=-1).mean(dim=-1).sum())
+            sums[key] = sums[key] + flow_metrics(gt, flow, epe_norm_thresh=thresh) * pc1.shape[0]
         count += pc1.shape[0]
         if args.save:
             host = refined.cpu().numpy()
@@ -107,7 +109,8 @@ def main(argv=None):
                 np.save(os.path.join(scene_dir, "flow1.npy"), host[2 * j])
                 np.save(os.path.join(scene_dir, "flow2.npy"), host[2 * j + 1])
     report = {"round": args.round, "icp_iter": icp_iter, "pairs": count,
-              "EPE": {k: round(v / max(count, 1), 5) for k, v in sums.items()},
+              "metrics": {k: dict(zip(("EPE", "AccS", "AccR", "Outlier"), [round(x, 5) for x in (v / max(count, 1)).tolist()]))
+                          for k, v in sums.items()},
               "saved_to": out_dir if args.save else None}
     print(json.dumps(report), flush=True)
     return report

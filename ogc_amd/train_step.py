@@ -169,7 +169,11 @@ def flow_train_step(flownet, criterion, optimizer, batch, model_iters, sync=True
     pcs = batch[0]
     pc1, pc2 = pcs[:, 0].contiguous(), pcs[:, 1].contiguous()
     flow_preds = flownet(pc1, pc2, pc1, pc2, iters=model_iters)
-    loss, losses = criterion(pc1, pc2, flow_preds, sync=False)
+    extra = None
+    if batch[2] is not None:  # ground-truth flow of the first frame: EPE per iteration, monitored (train_flow.py:75-76)
+        from .metrics.flow_metric import epe_terms
+        extra = epe_terms(batch[2][:, 0], flow_preds)
+    loss, losses = criterion(pc1, pc2, flow_preds, sync=False, extra=extra)
     loss.backward()
     net = flownet.module if hasattr(flownet, "module") else flownet
     pending = PendingStep(losses, _nan_safe_step(list(net.parameters()), optimizer))

@@ -251,6 +251,12 @@ def gen_data_util():
         out["aug_%s_pcs" % tag], out["aug_%s_flows" % tag] = a, b
     segm = np.array([7, 3, 3, 12, 7, 0, 12, 12, 5], np.int64)
     out["segm"], out["segm_cpr"], out["segm_mask"], out["segm_mask8"] = segm, compress_label_id(segm), segm_to_mask(segm), segm_to_mask(segm, 8)
+    from metrics.flow_metric import eval_flow
+    gt = T(detgen.uniform((2, 300, 3), 21, -0.2, 0.2))
+    pred = gt + T(detgen.uniform((2, 300, 3), 22, -0.05, 0.05)) * T(detgen.uniform((2, 300, 1), 23, 0.0, 1.0)) ** 3
+    out["metric_gt"], out["metric_pred"] = gt.numpy(), pred.numpy()
+    out["metric_005"] = np.array(eval_flow(gt, pred, epe_norm_thresh=0.05), np.float64)
+    out["metric_001"] = np.array(eval_flow(gt, pred, epe_norm_thresh=0.01), np.float64)
     save("data_util", **out)
 
 

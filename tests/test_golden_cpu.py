@@ -44,6 +44,12 @@ def test_data_util_helpers():
     np.testing.assert_array_equal(compress_label_id(g["segm"]), g["segm_cpr"])
     np.testing.assert_array_equal(segm_to_mask(g["segm"]), g["segm_mask"])
     np.testing.assert_array_equal(segm_to_mask(g["segm"], 8), g["segm_mask8"])
+    from ogc_amd.metrics.flow_metric import epe_metric, eval_flow
+    import torch
+    gt, pred = torch.from_numpy(g["metric_gt"]), torch.from_numpy(g["metric_pred"])
+    np.testing.assert_allclose(eval_flow(gt, pred, 0.05), g["metric_005"], rtol=1e-6)
+    np.testing.assert_allclose(eval_flow(gt, pred, 0.01), g["metric_001"], rtol=1e-6)
+    assert abs(epe_metric(gt, [pred, gt])["epe3d_#0"] - g["metric_005"][0]) < 1e-7 and epe_metric(gt, [pred, gt])["epe3d_#1"] == 0
 
 
 def test_waymo_single_frame_loss(cpu_ops):

@@ -83,7 +83,8 @@ def test_flow_driver_runs_and_writes_checkpoints(tmp_path, monkeypatch, oracle, 
         assert "global_corr_layer.epsilon" in state["model_state"]
     lines = [json.loads(l) for l in capsys.readouterr().out.splitlines() if l.startswith("{")]
     assert len(lines) == 2
-    assert set(lines[0]["train"]) == {"chamfer_loss_#0", "smooth_loss_#0", "chamfer_loss_#1", "smooth_loss_#1", "sum"}
+    assert set(lines[0]["train"]) == {"chamfer_loss_#0", "smooth_loss_#0", "chamfer_loss_#1", "smooth_loss_#1", "sum",
+                                      "epe3d_#0", "epe3d_#1"}          # loss_dict | epe_dict (train_flow.py:75-76)
     assert lines[1]["lr"] == 0.5e-3                                          # lr_curve: 4 samples seen -> one decay
     assert all(v == v for v in lines[1]["train"].values())
 
@@ -104,6 +105,7 @@ def test_train_refine_train_loop(tmp_path, monkeypatch, oracle, capsys):
     rep = oa_icp_round.main([str(path), "--round", "1", "--synthetic", "2", "--device", "cpu", "--save", "--flow-root", root,
                              "--test_batch_size", "4"])
     assert rep["icp_iter"] == 20 and rep["pairs"] == 4
+    assert set(rep["metrics"]) == {"input", "kabsch", "oa_icp"} and set(rep["metrics"]["oa_icp"]) == {"EPE", "AccS", "AccR", "Outlier"}
     out = os.path.join(root, "flow_preds", "flowstep3d_R1")
     for scene in ("000000", "000001"):
         for v in (1, 2):
