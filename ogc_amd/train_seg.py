@@ -13,7 +13,8 @@ What is kept from the reference so that its configs, schedules and checkpoints c
   * loss weights gated by `it * batch` (train_seg.py:70), NaN-gradient skip (train_seg.py:81-83, in train_step);
   * checkpoints {'model_state': state_dict} as current.pth.tar / best.pth.tar in `<save_path>_R<round>`, the initial
     weights saved as both (utils/pytorch_util.py:84-99, train_seg.py:137-140).
-Out of scope here: the dataset readers, tensorboard, per-step segmentation metrics.  Without a dataset the
+Out of scope here: the dataset readers and tensorboard.  Validation reports AP / PQ / F1 / Pre / Rec
+(ogc_amd/metrics/seg_metric.py) next to the loss; the per-training-step metrics of the reference's loop are not computed.  Without a dataset the
 driver trains on seeded synthetic scenes with the loaders' sample contract (ogc_amd/utils/synthetic.py).
 """
 import argparse
@@ -92,9 +93,13 @@ def save_checkpoint(net, exp_base, is_best):
         shutil.copyfile(cur, os.path.join(exp_base, "best.pth.tar"))
 
 
-def evaluate(model, criterion, loader, device, single_frame=False):
+def evaluate(model, criterion, loader, device, single_frame=False, ignore_npoint_thresh=0):
+    """Mean validation loss and the segmentation metrics of the first frame (train_seg.py:88-133: AP, PQ, F1, Pre, Rec)."""
+    import numpy as np
+    from .metrics.seg_metric import accumulate_eval_results, calculate_AP, calculate_PQ_F1
     model.eval()
     total, count = 0.0, 0
+    ious, matched, confs, n_gt = [], [], [], 0
     with torch.no_grad():
         for pcs, segms, flows, valids in loader:
             if single_frame:
@@ -107,7 +112,12 @@ def evaluate(model, criterion, loader, device, single_frame=False):
                                 [flows[:, i].contiguous() for i in range(t)], step_w=False)
             total += float(loss)
             count += 1
-    return total / max(count, 1)
+            a, m, c, g = accumulate_eval_results(segms[:, 0].to(device), masks[:, 0], ignore_npoint_thresh)
+            ious.append(a); matched.append(m); confs.append(c); n_gt += g
+    ious, matched, confs = np.concatenate(ious), np.concatenate(matched), np.concatenate(confs)
+    pq, f1, pre, rec = calculate_PQ_F1(ious, matched, n_gt)
+    metrics = {"AP": calculate_AP(matched, confs, n_gt), "PQ": float(pq), "F1": float(f1), "Pre": float(pre), "Rec": float(rec)}
+    return total / max(count, 1), metrics
 
 
 def main(argv=None):
@@ -212,7 +222,8 @@ def main(argv=None):
                 break
         account(in_flight)
         n_it = max(len(train_loader) if not args.max_iters else min(len(train_loader), it), 1)
-        val_loss = evaluate(model, criterion, val_loader, device, single_frame)
+        val_loss, val_metrics = evaluate(model, criterion, val_loader, device, single_frame,
+                                         cfg.get("ignore_npoint_thresh", 0))
         if distributed:
             t = torch.tensor([val_loss], device=device)
             dist.all_reduce(t)
@@ -223,7 +234,8 @@ def main(argv=None):
             save_checkpoint(net, exp_base, is_best)
             print(json.dumps({"epoch": epoch, "it": it, "lr": optimizer.param_groups[0]["lr"], "aug": aug,
                               "train": {k: round(v / n_it, 5) for k, v in sums.items()},
-                              "val_loss": round(val_loss, 5), "sec": round(time.time() - t0, 2)}), flush=True)
+                              "val_loss": round(val_loss, 5), "val": {k: round(v, 4) for k, v in val_metrics.items()},
+                              "sec": round(time.time() - t0, 2)}), flush=True)
         if args.max_iters and it >= args.max_iters:
             break
     if distributed:

@@ -257,6 +257,19 @@ def gen_data_util():
     out["metric_gt"], out["metric_pred"] = gt.numpy(), pred.numpy()
     out["metric_005"] = np.array(eval_flow(gt, pred, epe_norm_thresh=0.05), np.float64)
     out["metric_001"] = np.array(eval_flow(gt, pred, epe_norm_thresh=0.01), np.float64)
+    from metrics.seg_metric import accumulate_eval_results, calculate_AP, calculate_PQ_F1
+    B, N, K = 3, 400, 7
+    segm = (detgen.uniform((B, N), 41, 0.0, 5.0).astype(np.int64) * 3 + 2)          # non-consecutive labels 2, 5, 8, ...
+    segm[1, :30] = 99                                                                 # a small object (ignored at thresh 40)
+    onehot = np.eye(K, dtype=np.float32)[(segm // 3) % K]
+    mask = T(onehot * 4.0 + detgen.uniform((B, N, K), 42, -2.5, 2.5).astype(np.float32)).softmax(-1)
+    out["seg_segm"], out["seg_mask"] = segm, mask.numpy()
+    for thresh in (0, 40):
+        iou, matched, conf, n_gt = accumulate_eval_results(T(segm), mask, ignore_npoint_thresh=thresh)
+        out["seg_iou_%d" % thresh], out["seg_matched_%d" % thresh], out["seg_conf_%d" % thresh] = iou, matched, conf
+        out["seg_ngt_%d" % thresh] = np.array([n_gt], np.int64)
+        out["seg_ap_%d" % thresh] = np.array([calculate_AP(matched, conf, n_gt)], np.float64)
+        out["seg_pqf1_%d" % thresh] = np.array(calculate_PQ_F1(iou, matched, n_gt), np.float64)
     save("data_util", **out)
 
 

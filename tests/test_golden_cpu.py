@@ -52,6 +52,23 @@ def test_data_util_helpers():
     assert abs(epe_metric(gt, [pred, gt])["epe3d_#0"] - g["metric_005"][0]) < 1e-7 and epe_metric(gt, [pred, gt])["epe3d_#1"] == 0
 
 
+def test_seg_metrics():
+    """Device-style accumulate_eval_results + AP / PQ / F1 against the reference's numpy implementation."""
+    import numpy as np
+    import torch
+    from ogc_amd.metrics.seg_metric import accumulate_eval_results, calculate_AP, calculate_PQ_F1
+    g = gc.load("data_util")
+    segm, mask = torch.from_numpy(g["seg_segm"]), torch.from_numpy(g["seg_mask"])
+    for thresh in (0, 40):
+        iou, matched, conf, n_gt = accumulate_eval_results(segm, mask, ignore_npoint_thresh=thresh)
+        assert n_gt == int(g["seg_ngt_%d" % thresh][0])
+        np.testing.assert_allclose(iou, g["seg_iou_%d" % thresh], rtol=1e-12, atol=1e-12)
+        np.testing.assert_array_equal(matched, g["seg_matched_%d" % thresh])
+        np.testing.assert_allclose(conf, g["seg_conf_%d" % thresh], rtol=1e-6)
+        np.testing.assert_allclose(calculate_AP(matched, conf, n_gt), g["seg_ap_%d" % thresh][0], rtol=1e-12)
+        np.testing.assert_allclose(calculate_PQ_F1(iou, matched, n_gt), g["seg_pqf1_%d" % thresh], rtol=1e-12)
+
+
 def test_waymo_single_frame_loss(cpu_ops):
     gc.run_waymo_loss("cpu")
 
