@@ -1,6 +1,8 @@
 """Instance-segmentation metrics (reference: metrics/seg_metric.py:8-161): per-prediction IoU / matched flag /
 confidence accumulated over batches, then AP (MS-COCO 101-point), PQ, F1, precision, recall.
 
+`ClusteringMetrics` (mean IoU under the best one-to-one matching, Rand index; :167-243) completes the set.
+
 The reference evaluates every sample on the host with numpy loops over (GT instance, predicted instance) pairs — inside
 the training loop (train_seg.py:171).  Here the per-batch part is a handful of tensor ops on the device (one bincount
 gives all intersections) and ONE device->host copy of the small per-prediction table; the curve arithmetic of AP / PQ
@@ -92,3 +94,58 @@ def calculate_PQ_F1(Pred_IoU, Pred_Matched, N_GT_Inst, eps=1e-10):
     rec = tp / max(tp + fn, eps)
     f1 = (2 * pre * rec) / max(pre + rec, eps)
     return pq, f1, pre, rec
+
+
+class ClusteringMetrics:
+    """Per-scan mean IoU (Hungarian-matched) and Rand index of hard predictions against GT labels starting at 0
+    (reference: seg_metric.py:167-243, adapted there from MultiBodySync).  ``__call__(mask, segm, thresh)`` ->
+    {'iou': [per sample], 'ri': [per sample]}.
+
+    The reference compares two (B, N, N) same-cluster matrices for the Rand index (N = 8192: 268 MB each per sample).
+    Both metrics are functions of the (GT, prediction) contingency table alone — of the N_v^2 ordered pairs of valid
+    points, the ones on which the two partitions agree number  N_v^2 - sum_g a_g^2 - sum_p b_p^2 + 2 sum_gp n_gp^2
+    — so one bincount on the device and one small copy to the host replace them."""
+    IOU = 1
+    RI = 2
+
+    def __init__(self, spec=None):
+        self.spec = [self.IOU, self.RI] if spec is None else spec
+
+    def forward(self, mask, segm, ignore_npoint_thresh=0):
+        from scipy.optimize import linear_sum_assignment
+        n_batch, k_mask = mask.shape[0], mask.shape[-1]
+        gt = segm.reshape(n_batch, -1).detach().long()                               # (B, N)
+        pred = mask.reshape(n_batch, -1, k_mask).detach().argmax(dim=-1)             # (B, N)
+        n_data = gt.shape[-1]
+        n_gt_segms = (gt.max(dim=1).values + 1).cpu().numpy()
+        k = int(max(k_mask, n_gt_segms.max()))
+        flat = (torch.arange(n_batch, device=gt.device).view(-1, 1) * k + gt) * k + pred
+        table = torch.bincount(flat.reshape(-1), minlength=n_batch * k * k).view(n_batch, k, k).cpu().numpy()
+        out = {}
+        ious, ris = [], []
+        for b in range(n_batch):
+            n = table[b].astype(np.int64)                                            # [gt, prediction]
+            gt_sizes = n.sum(1)
+            nonsmall = gt_sizes >= ignore_npoint_thresh
+            if ignore_npoint_thresh > 0:
+                n = n * nonsmall[:, None]                                            # points of small GT objects drop out of both
+            if self.IOU in self.spec:
+                matching = n.astype(np.float32)
+                union = (n.sum(1).astype(np.float32)[:, None] + n.sum(0).astype(np.float32)[None, :]) - matching
+                iou = matching / (union + np.float32(1e-8))
+                rows = iou[:n_gt_segms[b]]
+                if ignore_npoint_thresh > 0:
+                    rows = rows[nonsmall[:n_gt_segms[b]]]
+                r, c = linear_sum_assignment(rows, maximize=True)
+                ious.append(np.mean(rows[r, c]))
+            if self.RI in self.spec:
+                n_valid = int(n.sum()) if ignore_npoint_thresh > 0 else n_data
+                agree = n_valid * n_valid - int((n.sum(1) ** 2).sum()) - int((n.sum(0) ** 2).sum()) + 2 * int((n ** 2).sum())
+                ris.append(agree / (n_valid * n_valid) if n_valid else float('nan'))
+        if self.IOU in self.spec:
+            out["iou"] = ious
+        if self.RI in self.spec:
+            out["ri"] = ris
+        return out
+
+    __call__ = forward

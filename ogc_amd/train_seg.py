@@ -120,6 +120,16 @@ def evaluate(model, criterion, loader, device, single_frame=False, ignore_npoint
     return total / max(count, 1), metrics
 
 
+def build_segnet(cfg):
+    """The MaskFormer3D of the config's dataset, built from its `segnet` block (train_seg.py:302-307)."""
+    seg = cfg["segnet"]
+    MaskFormer3D = importlib.import_module("ogc_amd.models." + SEGNETS[cfg["dataset"]]).MaskFormer3D
+    return MaskFormer3D(n_slot=seg["n_slot"], n_point=seg["n_point"], use_xyz=seg["use_xyz"],
+                        n_transformer_layer=seg["n_transformer_layer"],
+                        transformer_embed_dim=seg["transformer_embed_dim"],
+                        transformer_input_pos_enc=seg["transformer_input_pos_enc"])
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("config")
@@ -147,11 +157,7 @@ def main(argv=None):
 
     torch.manual_seed(cfg["random_seed"])
     seg = cfg["segnet"]
-    MaskFormer3D = importlib.import_module("ogc_amd.models." + SEGNETS[cfg["dataset"]]).MaskFormer3D
-    net = MaskFormer3D(n_slot=seg["n_slot"], n_point=seg["n_point"], use_xyz=seg["use_xyz"],
-                       n_transformer_layer=seg["n_transformer_layer"],
-                       transformer_embed_dim=seg["transformer_embed_dim"],
-                       transformer_input_pos_enc=seg["transformer_input_pos_enc"]).to(device)
+    net = build_segnet(cfg).to(device)
     model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[device.index] if device.type == "cuda" else None) \
         if distributed else net
 

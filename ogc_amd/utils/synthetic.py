@@ -55,3 +55,30 @@ def make_scene_batch(B, N, K, seed=1234, outdoor=True, aug=False, device="cpu"):
     segms = torch.stack(segms, 1).contiguous().to(device)
     valids = torch.ones_like(segms, dtype=torch.bool)
     return pcs, segms, flows, valids
+
+
+def make_sequence(T, N, K, seed=1234, outdoor=True, device="cpu"):
+    """One scene observed over T frames — the unit multi-frame voting works on (vote.py:95-131).
+    Returns pc (T, N, 3), segm (T, N), flows (T-1, 2, N, 3): flows[t, 0] is the forward flow of frame t (to t+1),
+    flows[t, 1] the backward flow of frame t+1 (to t); every step moves each object rigidly, adds noise and re-orders
+    the points, as make_scene_batch does for a pair."""
+    g = torch.Generator().manual_seed(seed)
+    scale = torch.tensor([60.0, 4.0, 80.0]) if outdoor else torch.ones(3)
+    max_shift, noise = (0.5, 0.01) if outdoor else (0.05, 0.002)
+    pc = (torch.rand(N, 3, generator=g) - 0.5) * scale
+    centres = pc[torch.randperm(N, generator=g)[:K]]
+    segm = torch.cdist(pc, centres).argmin(-1)
+    pcs, segms, flows = [pc], [segm], []
+    for _ in range(T - 1):
+        R = _rot_y((torch.rand(K, generator=g) - 0.5) * 2 * math.radians(5.0))
+        shift = (torch.rand(K, 3, generator=g) - 0.5) * 2 * max_shift
+        moved = torch.einsum("nij,nj->ni", R[segm], pc - centres[segm]) + centres[segm] + shift[segm]
+        fwd = moved - pc
+        perm = torch.randperm(N, generator=g)
+        nxt = (moved + torch.randn(N, 3, generator=g) * noise)[perm]
+        flows.append(torch.stack([fwd, (-fwd)[perm]]))
+        centres = centres + shift
+        pc, segm = nxt, segm[perm]
+        pcs.append(pc)
+        segms.append(segm)
+    return torch.stack(pcs).to(device), torch.stack(segms).to(device), torch.stack(flows).to(device)

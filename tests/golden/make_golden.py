@@ -273,6 +273,37 @@ def gen_data_util():
     save("data_util", **out)
 
 
+def gen_vote():
+    """Multi-frame voting (vote.py:17-131) and the clustering metrics it is evaluated with (metrics/seg_metric.py:167-243)."""
+    import vote as ref_vote  # the module guards its driver with __main__
+    from metrics.seg_metric import ClusteringMetrics
+    from ogc_amd.utils.synthetic import make_sequence
+    T_, N, K = 4, 200, 5
+    pc, segm, flows = make_sequence(T_, N, K, seed=77, outdoor=False)
+    flows = flows + T(detgen.uniform(tuple(flows.shape), 61, -0.004, 0.004).astype(np.float32))   # imperfect flow estimates
+    noise = T(detgen.uniform((T_, N, K), 62, -2.0, 2.0).astype(np.float32))
+    mask = (4.0 * torch.eye(K)[segm] + noise).softmax(-1)
+    # every frame predicts the objects in its own slot order: the alignment step has something to do
+    orders = [[0, 1, 2, 3, 4], [2, 0, 1, 4, 3], [4, 3, 2, 1, 0], [1, 2, 3, 4, 0]]
+    mask = torch.stack([mask[t][:, orders[t]] for t in range(T_)]).contiguous()
+    out = {"pc": pc, "segm": segm, "flows": flows, "mask": mask}
+    corrs = ref_vote.collect_correspondences(pc, flows)
+    for key in ("0_1", "2_0", "0_3", "3_1"):
+        out["corr_" + key] = corrs[key][0]
+    out["matched_ce"] = ref_vote.match_mask_by_cost(mask[0], mask[1], measure='ce')
+    out["matched_iou"] = ref_vote.match_mask_by_cost(mask[0], mask[2], measure='iou')
+    for w in (1, 3):
+        out["voted_w%d" % w] = ref_vote.mask_voting(pc, mask, flows, time_window_size=w)
+    segm_small = segm.clone()
+    segm_small[0, :12] = K                       # a 12-point extra object in frame 0 (ignored at thresh 30)
+    for thresh in (0, 30):
+        res = ClusteringMetrics()(mask, segm_small, ignore_npoint_thresh=thresh)
+        out["cluster_iou_%d" % thresh] = np.array(res["iou"], np.float64)
+        out["cluster_ri_%d" % thresh] = np.array(res["ri"], np.float64)
+    out["segm_small"] = segm_small
+    save("vote", **{k: (v.numpy() if torch.is_tensor(v) else v) for k, v in out.items()})
+
+
 def gen_models():
     import importlib
     for name, kw, N, B in [("segnet_sapien", dict(n_slot=8, n_point=512, transformer_embed_dim=128), 512, 2),
@@ -313,7 +344,7 @@ if __name__ == "__main__":
     assert os.path.isdir(REF), "the reference tree is only present in the build container"
     install_shims()
     orc.build()
-    which = sys.argv[1:] or ["ops", "modules", "losses", "waymo", "data", "models"]
+    which = sys.argv[1:] or ["ops", "modules", "losses", "waymo", "data", "vote", "models"]
     with torch.no_grad():
         pass
     if "ops" in which:
@@ -326,5 +357,7 @@ if __name__ == "__main__":
         gen_waymo_loss()
     if "data" in which:
         gen_data_util()
+    if "vote" in which:
+        gen_vote()
     if "models" in which:
         gen_models()

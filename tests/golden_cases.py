@@ -157,6 +157,44 @@ def run_waymo_loss(dev, rtol=1e-5, atol=1e-6, grad_rel=5e-3):
             close_scaled(gr, gw["%s_gmask%d" % (tag, i)], grad_rel, "waymo_%s_gmask%d" % (tag, i))
 
 
+def run_vote(dev, rtol=1e-4, atol=1e-6, corr_rtol=1e-4):
+    """Multi-frame voting and the clustering metrics against the reference's vote.py / metrics.seg_metric (fixture
+    vote.npz: a 4-frame sequence, every frame predicting the objects in its own slot order).
+    corr_rtol: the correspondence weights are softmax(-cdist / 0.01); torch.cdist's |a|^2 + |b|^2 - 2ab form leaves
+    ~1e-7 absolute error on d^2, i.e. ~1e-5 on a centimetre distance and ~1e-3 on its logit, so two BLAS back ends
+    (the fixture was made on the CPU) agree on individual weights to ~1e-3 relative only; sums over them (the carried
+    and voted masks) agree far better."""
+    from ogc_amd import vote
+    from ogc_amd.metrics.seg_metric import ClusteringMetrics
+    g = load("vote")
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    pc, flows, mask = T(g["pc"]), T(g["flows"]), T(g["mask"])
+    corrs = vote.collect_correspondences(pc, flows)
+    assert set(corrs) == {"%d_%d" % (a, b) for a in range(4) for b in range(4)}
+    for key in ("0_1", "2_0", "0_3", "3_1"):
+        assert corrs[key].shape == (1, 200, 200)
+        close(corrs[key][0], g["corr_" + key], corr_rtol, atol, "corr_" + key)
+    # the chain-free path: (chained correspondence) @ X from the adjacent pairs only
+    adj = vote._adjacent(pc, flows)
+    for (t, v) in ((0, 3), (3, 1), (2, 0), (1, 2)):
+        close(vote._carry(adj, t, v, mask[v]), (corrs["%d_%d" % (t, v)][0] @ mask[v]).cpu().numpy(), rtol, atol,
+              "carry_%d_%d" % (t, v))
+    close(vote.match_mask_by_cost(mask[0], mask[1], measure='ce'), g["matched_ce"], 0, 0, "matched_ce")
+    close(vote.match_mask_by_cost(mask[0], mask[2], measure='iou'), g["matched_iou"], 0, 0, "matched_iou")
+    for w in (1, 3):
+        close(vote.mask_voting(pc, mask, flows, time_window_size=w), g["voted_w%d" % w], rtol, atol, "voted_w%d" % w)
+    close(vote.vote_batch(torch.cat([pc, pc]), torch.cat([mask, mask]),
+                          torch.cat([flows, flows[:1], flows, flows[:1]]), 4, 3),
+          np.concatenate([g["voted_w3"], g["voted_w3"]]), rtol, atol, "vote_batch")
+    segm = T(g["segm_small"])
+    for thresh in (0, 30):
+        res = ClusteringMetrics()(mask, segm, ignore_npoint_thresh=thresh)
+        close(np.array(res["iou"], np.float64), g["cluster_iou_%d" % thresh], 1e-6, 1e-7, "cluster_iou_%d" % thresh)
+        close(np.array(res["ri"], np.float64), g["cluster_ri_%d" % thresh], 1e-6, 1e-7, "cluster_ri_%d" % thresh)
+    only_ri = ClusteringMetrics(spec=[ClusteringMetrics.RI])(mask, segm)
+    assert list(only_ri) == ["ri"]
+
+
 def run_losses(dev, rtol=1e-5, atol=1e-6, grad_rel=5e-3):
     from ogc_amd.losses.flow_loss_unsup import ChamferLoss, UnsupervisedFlowStep3DLoss
     from ogc_amd.losses.flow_loss_unsup import SmoothLoss as FlowSmoothLoss

@@ -73,6 +73,10 @@ def test_waymo_single_frame_loss(cpu_ops):
     gc.run_waymo_loss("cpu")
 
 
+def test_vote_and_clustering_metrics(cpu_ops):
+    gc.run_vote("cpu")
+
+
 @pytest.mark.parametrize("name,kw,N,B", gc.SEG_CASES, ids=[c[0] for c in gc.SEG_CASES])
 def test_segnet_forward_backward(cpu_ops, name, kw, N, B):
     gc.run_segnet("cpu", name, kw, N, B)

@@ -31,6 +31,10 @@ def test_waymo_single_frame_loss():
     gc.run_waymo_loss("cuda", rtol=1e-5, atol=1e-6)
 
 
+def test_vote_and_clustering_metrics():
+    gc.run_vote("cuda", rtol=2e-3, atol=1e-5, corr_rtol=1e-2)
+
+
 @pytest.mark.parametrize("name,kw,N,B", gc.SEG_CASES, ids=[c[0] for c in gc.SEG_CASES])
 def test_segnet_forward_backward(name, kw, N, B):
     gc.run_segnet("cuda", name, kw, N, B, rtol=1e-3, atol=1e-5, grad_rtol=1e-2)

@@ -117,3 +117,24 @@ def test_train_refine_train_loop(tmp_path, monkeypatch, oracle, capsys):
     ds = train_seg.SyntheticScenes(2, cfg["segnet"]["n_point"], cfg["segnet"]["n_slot"], False, seed=1000,
                                    predflow_dir=out)
     np.testing.assert_array_equal(ds[1][2][0].numpy(), np.load(os.path.join(out, "000001", "flow1.npy")))
+
+
+def test_vote_driver_evaluates_a_trained_checkpoint(tmp_path, monkeypatch, oracle, capsys):
+    """train_seg writes best.pth.tar; `python -m ogc_amd.vote` loads it, runs the network on 4-frame synthetic
+    sequences and reports the reference's metrics for the raw and the voted masks (vote.py:284-352)."""
+    import math
+    import ogc_amd.pointnet2.pointnet2 as api
+    monkeypatch.setattr(api, "_native", oracle.Pointnet2CudaCPU())
+    from ogc_amd import train_seg, vote
+    cfg = dict(CFG, save_path=str(tmp_path / "ckpt" / "seg"), epochs=1)
+    path = tmp_path / "cfg.yaml"
+    path.write_text(yaml.safe_dump(cfg))
+    os.makedirs(tmp_path / "ckpt", exist_ok=True)
+    train_seg.main([str(path), "--round", "1", "--synthetic", "2", "--device", "cpu"])
+    res = vote.main([str(path), "--round", "1", "--n_sequence", "2", "--device", "cpu"])
+    assert set(res) == {"raw", "voted"}
+    for key in ("raw", "voted"):
+        assert set(res[key]) == {"AP", "PQ", "F1", "Pre", "Rec", "mIoU", "RI"}
+        assert all(math.isfinite(v) and 0.0 <= v <= 1.0 for v in res[key].values()), res[key]
+    out = capsys.readouterr().out
+    assert "Loaded weights from" in out and "voted" in out
