@@ -13,6 +13,9 @@ Kept from the reference so that rounds chain with `train_seg`:
   * ICP iterations per round {1: 20, 2: 10, 3: 5, 4: 3} (oa_icp.py:175);
   * the three reported flows: input, weighted-Kabsch, object-aware ICP, each with EPE / AccS / AccR / Outlier
     (metrics/flow_metric.py:4-25, computed on the device).
+  * with `--frames 4` the SAPIEN / OGC-DR variant: six ordered pairs of the four frames of a scene
+    (`[[0,1],[1,0],[1,2],[2,1],[2,3],[3,2]]`, oa_icp.py:148), flows stored as `<dir>/<scene id>.npy` (6, N, 3) next to
+    `<dir>.json` {"view_sel": ...} (oa_icp.py:187-191, datasets/dataset_ogcdr.py:147-157) — ogc_amd/utils/flow_store.py.
 Dataset readers are out of scope: scenes are the seeded synthetic ones of `train_seg`; when no predicted
 flow exists on disk for a scene, the ground-truth flow plus noise stands in for the flow network's prediction.
 """
@@ -27,7 +30,8 @@ import yaml
 
 from .metrics.flow_metric import flow_metrics
 from .oa_icp import object_aware_icp, weighted_kabsch
-from .train_seg import SEGNETS, SyntheticScenes
+from .train_seg import SEGNETS, SyntheticScenes, SyntheticSequenceScenes
+from .utils import flow_store
 
 ICP_ITERS = {1: 20, 2: 10, 3: 5, 4: 3}
 
@@ -54,6 +58,7 @@ def main(argv=None):
     ap.add_argument("--flow-root", default="ckpt/synthetic_data")
     ap.add_argument("--synthetic", type=int, default=16, help="number of synthetic scenes")
     ap.add_argument("--device", default="cuda")
+    ap.add_argument("--frames", type=int, default=2, help="2: frame pairs (KITTI layout); 4: SAPIEN / OGC-DR sequences")
     args = ap.parse_args(argv)
     with open(args.config) as f:
         cfg = yaml.safe_load(f)
@@ -75,22 +80,43 @@ def main(argv=None):
     if args.save:
         os.makedirs(out_dir, exist_ok=True)
     outdoor = cfg["dataset"] in ("kittisf", "waymo")
-    scenes = SyntheticScenes(args.synthetic, seg["n_point"], seg["n_slot"], outdoor, seed=1000)
+    sequences = args.frames > 2
+    if sequences:
+        assert not outdoor and args.frames == 4, "sequences are the SAPIEN / OGC-DR sample format (4 frames)"
+        view_sels = flow_store.SEQUENCE_PAIRS
+        scenes = SyntheticSequenceScenes(args.synthetic, seg["n_point"], seg["n_slot"], view_sels, args.frames, seed=1000)
+        in_meta = flow_store.read_meta(in_dir)
+        if args.save:
+            flow_store.write_meta(out_dir, view_sels)
+    else:
+        view_sels = [[0, 1], [1, 0]]
+        scenes = SyntheticScenes(args.synthetic, seg["n_point"], seg["n_slot"], outdoor, seed=1000)
+    n_pair = len(view_sels)
     icp_iter = ICP_ITERS[args.round]
     noise = 0.05 if outdoor else 0.005
 
     thresh = 0.05 if outdoor else 0.01  # epe_norm_thresh per dataset (oa_icp.py:112,116,124)
     sums, count = {"input": 0.0, "kabsch": 0.0, "oa_icp": 0.0}, 0
-    per_batch = max(args.test_batch_size // 2, 1)  # both pairs of a scene stay in one batch (oa_icp.py:179-180)
-    for start in range(0, len(scenes), per_batch):
-        ids = list(range(start, min(start + per_batch, len(scenes))))
+    per_batch = max(args.test_batch_size // n_pair, 1)  # all pairs of a scene stay in one batch (oa_icp.py:179-180)
+    n_scene = args.synthetic
+    for start in range(0, n_scene, per_batch):
+        ids = list(range(start, min(start + per_batch, n_scene)))
         pc1, pc2, gt, pred = [], [], [], []
         for i in ids:
-            pcs, _, flows, _ = scenes[i]
             g = torch.Generator().manual_seed(77 + i)
+            if sequences:
+                pc, _, seq_flows = scenes.scene(i)
+                for a, b_ in view_sels:
+                    truth = scenes.pair_flows(seq_flows, a, b_)[0]
+                    stored = flow_store.load_pair(in_dir, "%06d" % i, (a, b_), in_meta) if in_meta is not None else None
+                    guess = torch.from_numpy(np.asarray(stored[0])) if stored is not None else \
+                        truth + noise * torch.randn(truth.shape, generator=g)
+                    pc1.append(pc[a]); pc2.append(pc[b_]); gt.append(truth); pred.append(guess)
+                continue
+            pcs, _, flows, _ = scenes[i]
             guess = load_flows(in_dir, "%06d" % i, lambda: [flows[v] + noise * torch.randn(flows[v].shape, generator=g)
                                                             for v in (0, 1)])
-            for a, b_ in ((0, 1), (1, 0)):                  # view_sels [[0, 1], [1, 0]]
+            for a, b_ in view_sels:
                 pc1.append(pcs[a]); pc2.append(pcs[b_]); gt.append(flows[a]); pred.append(guess[a])
         pc1, pc2 = torch.stack(pc1).to(device), torch.stack(pc2).to(device)
         gt, pred = torch.stack(gt).to(device), torch.stack(pred).float().to(device)
@@ -104,10 +130,10 @@ def main(argv=None):
         if args.save:
             host = refined.cpu().numpy()
             for j, i in enumerate(ids):
-                scene_dir = os.path.join(out_dir, "%06d" % i)
-                os.makedirs(scene_dir, exist_ok=True)
-                np.save(os.path.join(scene_dir, "flow1.npy"), host[2 * j])
-                np.save(os.path.join(scene_dir, "flow2.npy"), host[2 * j + 1])
+                if sequences:
+                    flow_store.save_sequence(out_dir, "%06d" % i, host[n_pair * j:n_pair * (j + 1)])
+                else:
+                    flow_store.save_pair(out_dir, "%06d" % i, host[2 * j], host[2 * j + 1])
     report = {"round": args.round, "icp_iter": icp_iter, "pairs": count,
               "metrics": {k: dict(zip(("EPE", "AccS", "AccR", "Outlier"), [round(x, 5) for x in (v / max(count, 1)).tolist()]))
                           for k, v in sums.items()},

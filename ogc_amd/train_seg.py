@@ -73,6 +73,58 @@ class SyntheticScenes(torch.utils.data.Dataset):
         return pcs, segms, flows, valids
 
 
+class SyntheticSequenceScenes(torch.utils.data.Dataset):
+    """Scenes of `n_frame` consecutive frames, sampled as frame pairs the way the reference's SAPIEN / OGC-DR loaders do
+    (datasets/dataset_ogcdr.py:77-79,100-112): `len = n_scene * len(view_sels)`, item = the two frames of one pair with
+    the flow of each towards the other; predicted flows come from the sequence layout of utils/flow_store.py."""
+
+    def __init__(self, n_scene, n_point, n_object, view_sels, n_frame=4, seed=0, predflow_dir=None, aug_transform_args=None):
+        from .utils import flow_store
+        self.n_scene, self.n_point, self.n_object, self.n_frame, self.seed = n_scene, n_point, n_object, n_frame, seed
+        self.view_sels = [list(v) for v in view_sels]
+        self.aug_transform, self.aug_transform_args = False, aug_transform_args
+        self.predflow_dir, self.meta = predflow_dir, None
+        if predflow_dir is not None:
+            self.meta = flow_store.read_meta(predflow_dir)
+            if self.meta is None or any(v not in self.meta for v in self.view_sels):
+                raise ValueError("Flow predictions cannot cover the specified view selections!")
+
+    def __len__(self):
+        return self.n_scene * len(self.view_sels)
+
+    def scene(self, i):
+        from .utils.synthetic import make_sequence
+        return make_sequence(self.n_frame, self.n_point, self.n_object, seed=self.seed + i, outdoor=False)
+
+    @staticmethod
+    def pair_flows(seq_flows, a, b):
+        """Ground-truth flows of the ordered pair (a, b) of adjacent frames: [a->b on frame a, b->a on frame b]."""
+        assert abs(a - b) == 1, "synthetic sequences carry flows between adjacent frames only"
+        lo = min(a, b)
+        fwd, bwd = seq_flows[lo, 0], seq_flows[lo, 1]
+        return [fwd, bwd] if a < b else [bwd, fwd]
+
+    def __getitem__(self, sid):
+        import numpy as np
+        from .utils import flow_store
+        i, (a, b) = sid // len(self.view_sels), self.view_sels[sid % len(self.view_sels)]
+        pc, segm, seq_flows = self.scene(i)
+        pcs, segms = torch.stack([pc[a], pc[b]]), torch.stack([segm[a], segm[b]])
+        flows = torch.stack(self.pair_flows(seq_flows, a, b))
+        if self.predflow_dir is not None:
+            stored = flow_store.load_pair(self.predflow_dir, "%06d" % i, (a, b), self.meta)
+            if stored is not None:
+                flows = torch.stack([torch.from_numpy(np.asarray(f)).float() for f in stored])
+        valids = torch.ones_like(segms, dtype=torch.bool)
+        if self.aug_transform and self.aug_transform_args is not None:
+            from .utils.data_util import augment_transform
+            p, f = augment_transform(pcs.numpy().astype(np.float64), flows.numpy().astype(np.float64),
+                                     self.aug_transform_args, rng=np.random.RandomState(self.seed + sid))
+            pcs, flows = torch.from_numpy(p.astype(np.float32)), torch.from_numpy(f.astype(np.float32))
+            segms, valids = torch.cat([segms, segms]), torch.cat([valids, valids])
+        return pcs, segms, flows, valids
+
+
 def schedule_factor(cfg, samples_seen):
     """lr multiplier (train_seg.py:230-234)."""
     return max(cfg["lr_decay"] ** int(samples_seen / cfg["decay_step"]), cfg["lr_clip"] / cfg["lr"])
@@ -139,6 +191,9 @@ def main(argv=None):
     ap.add_argument("--device", default="cuda")
     ap.add_argument("--flow-root", default=None,
                     help="read predicted flows from <flow-root>/flow_preds/<predflow_path>[_R<round-1>] (train_seg.py:277-280)")
+    ap.add_argument("--frames", type=int, default=2,
+                    help="frames per synthetic scene: 2 = frame pairs (KITTI-style), 4 = SAPIEN / OGC-DR style sequences "
+                         "sampled as the pairs [[0,1],[1,2],[2,3]] (train_seg.py:295), flows in the sequence layout")
     args = ap.parse_args(argv)
     with open(args.config) as f:
         cfg = yaml.safe_load(f)
@@ -166,9 +221,15 @@ def main(argv=None):
     if args.flow_root is not None:
         name = cfg.get("predflow_path", "flowstep3d")
         predflow_dir = os.path.join(args.flow_root, "flow_preds", name if args.round <= 1 else "%s_R%d" % (name, args.round - 1))
-    train_set = SyntheticScenes(args.synthetic, seg["n_point"], seg["n_slot"], outdoor, seed=1000 * (rank + 1),
-                                predflow_dir=predflow_dir,
-                                aug_transform_args=(cfg.get("data") or {}).get("aug_transform_args") or None)
+    aug_args = (cfg.get("data") or {}).get("aug_transform_args") or None
+    if args.frames > 2:
+        from .utils.flow_store import TRAIN_PAIRS
+        assert not outdoor and args.frames == 4, "sequences are the SAPIEN / OGC-DR sample format (4 frames)"
+        train_set = SyntheticSequenceScenes(args.synthetic, seg["n_point"], seg["n_slot"], TRAIN_PAIRS, args.frames,
+                                            seed=1000 * (rank + 1), predflow_dir=predflow_dir, aug_transform_args=aug_args)
+    else:
+        train_set = SyntheticScenes(args.synthetic, seg["n_point"], seg["n_slot"], outdoor, seed=1000 * (rank + 1),
+                                    predflow_dir=predflow_dir, aug_transform_args=aug_args)
     val_set = SyntheticScenes(max(args.synthetic // 8, cfg["batch_size"]), seg["n_point"], seg["n_slot"], outdoor, seed=7)
     sampler = torch.utils.data.distributed.DistributedSampler(train_set) if distributed else None
     train_loader = torch.utils.data.DataLoader(train_set, batch_size=cfg["batch_size"], shuffle=sampler is None,

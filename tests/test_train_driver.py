@@ -138,3 +138,45 @@ def test_vote_driver_evaluates_a_trained_checkpoint(tmp_path, monkeypatch, oracl
         assert all(math.isfinite(v) and 0.0 <= v <= 1.0 for v in res[key].values()), res[key]
     out = capsys.readouterr().out
     assert "Loaded weights from" in out and "voted" in out
+
+
+def test_sequence_layout_train_refine_train_loop(tmp_path, monkeypatch, oracle, capsys):
+    """The SAPIEN / OGC-DR flavour of the loop: 4-frame scenes sampled as the reference's frame pairs, refined flows
+    stored as `<dir>/<scene>.npy` (6, N, 3) + `<dir>.json` {'view_sel'} (oa_icp.py:187-191, dataset_ogcdr.py:147-157)
+    and read back by round-2 training through the same meta file."""
+    import json
+    import numpy as np
+    import pytest
+    import ogc_amd.pointnet2.pointnet2 as api
+    monkeypatch.setattr(api, "_native", oracle.Pointnet2CudaCPU())
+    from ogc_amd import oa_icp_round, train_seg
+    from ogc_amd.utils import flow_store
+    cfg = dict(CFG, save_path=str(tmp_path / "ckpt" / "seg"), epochs=2)
+    path = tmp_path / "cfg.yaml"
+    path.write_text(yaml.safe_dump(cfg))
+    root = str(tmp_path / "data")
+    N = cfg["segnet"]["n_point"]
+    train_seg.main([str(path), "--round", "1", "--synthetic", "2", "--device", "cpu", "--frames", "4"])
+    lines = [json.loads(l) for l in capsys.readouterr().out.splitlines() if l.startswith("{")]
+    assert lines[0]["it"] == 3 and lines[1]["it"] == 6            # 2 scenes x 3 pairs / batch 2 per epoch
+    assert lines[1]["aug"] is True and lines[1]["train"]["invariance"] > 0
+    rep = oa_icp_round.main([str(path), "--round", "1", "--synthetic", "2", "--device", "cpu", "--save", "--flow-root", root,
+                             "--test_batch_size", "6", "--frames", "4"])
+    assert rep["pairs"] == 12
+    out = os.path.join(root, "flow_preds", "flowstep3d_R1")
+    assert flow_store.read_meta(out) == flow_store.SEQUENCE_PAIRS
+    stored = np.load(os.path.join(out, "000001.npy"))
+    assert stored.shape == (6, N, 3) and stored.dtype == np.float32 and np.isfinite(stored).all()
+    # the refined flow is a flow of the right pair: closer to the ground truth than to its reverse
+    ds_gt = train_seg.SyntheticSequenceScenes(2, N, cfg["segnet"]["n_slot"], flow_store.TRAIN_PAIRS, seed=1000)
+    ds = train_seg.SyntheticSequenceScenes(2, N, cfg["segnet"]["n_slot"], flow_store.TRAIN_PAIRS, seed=1000, predflow_dir=out)
+    assert len(ds) == 6
+    pcs, segms, flows, valids = ds[4]                                  # scene 1, pair [1, 2]
+    assert pcs.shape == (2, N, 3) and flows.shape == (2, N, 3)
+    np.testing.assert_array_equal(flows[0].numpy(), stored[2])         # [1, 2] is entry 2 of the meta order
+    np.testing.assert_array_equal(flows[1].numpy(), stored[3])         # [2, 1] is entry 3
+    assert (flows - ds_gt[4][2]).norm(dim=-1).mean() < 0.05
+    with pytest.raises(ValueError, match="cannot cover"):
+        flow_store.load_pair(out, "000001", (0, 2), flow_store.read_meta(out))
+    train_seg.main([str(path), "--round", "2", "--synthetic", "2", "--device", "cpu", "--flow-root", root, "--frames", "4"])
+    assert os.path.exists(os.path.join(cfg["save_path"] + "_R2", "best.pth.tar"))
