@@ -64,15 +64,34 @@ __device__ __forceinline__ bool rev_keep(const int *__restrict__ idx, long long 
     return dst != src && !first_dup;
 }
 
+// ROWWISE: k is a power of two <= 64, so a row is a group of k consecutive lanes of one wavefront: the row's
+// multiplicity (1 + its padding copies) is one ballot + popcount instead of up to k-1 atomics on the same address —
+// a ball-query row at the C4 loss shape holds ~14 hits and ~50 copies, and those same-address atomics were the whole
+// cost of this kernel.  mult is written for every row, so it needs no initialisation on this path.
+template <bool ROWWISE>
 __global__ __launch_bounds__(256) void rev_count_kernel(long long total, int n, int k, const int *__restrict__ idx,
                                                         int *__restrict__ deg, int *__restrict__ mult) {
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (e >= total) return;
-    const long long b = e / ((long long)n * k);
-    int dst, src;
-    bool dup;
-    if (rev_keep(idx, e, n, k, dst, src, dup)) atomicAdd(&deg[b * (n + 1) + dst], 1);
-    else if (dup && dst != src) atomicAdd(&mult[b * n + src], 1);
+    const bool in = e < total;
+    int dst = 0, src = 0;
+    bool dup = false, keep = false;
+    long long b = 0;
+    if (in) {
+        b = e / ((long long)n * k);
+        keep = rev_keep(idx, e, n, k, dst, src, dup);
+    }
+    if (keep) atomicAdd(&deg[b * (n + 1) + dst], 1);
+    const bool extra = in && !keep && dup && dst != src;
+    if (ROWWISE) {
+        const unsigned long long copies = __builtin_amdgcn_ballot_w64(extra);
+        const int lane = threadIdx.x & 63, row0 = lane & ~(k - 1);
+        if (in && lane == row0) {
+            const unsigned long long row_mask = k == 64 ? ~0ull : ((1ull << k) - 1ull) << row0;
+            mult[b * n + src] = 1 + __popcll(copies & row_mask);
+        }
+    } else if (extra) {
+        atomicAdd(&mult[b * n + src], 1);
+    }
 }
 
 __global__ __launch_bounds__(1024) void rev_scan_kernel(int n, int *__restrict__ deg_to_start, int *__restrict__ cursor) {
@@ -214,8 +233,13 @@ extern "C" int ogc_reverse_neighbours(int b, int n, int k, const int *idx, int *
     if (total == 0) return OGC_OK;
     OGC_REQUIRE(idx && rev_src && rev_mult && ws, "ogc_reverse_neighbours: null pointer");
     const unsigned blocks = (unsigned)((total + 255) / 256);
-    hipLaunchKernelGGL(fill_ones_kernel, dim3(ogc_divup(b * n, 256)), dim3(256), 0, s, (long long)b * n, rev_mult);
-    hipLaunchKernelGGL(rev_count_kernel, dim3(blocks), dim3(256), 0, s, total, n, k, idx, rev_start, rev_mult);
+    if (k <= 64 && (k & (k - 1)) == 0) {
+        hipLaunchKernelGGL(rev_count_kernel<true>, dim3(blocks), dim3(256), 0, s, total, n, k, idx, rev_start, rev_mult);
+    } else {
+        hipLaunchKernelGGL(fill_ones_kernel, dim3(ogc_divup(b * n, 256)), dim3(256), 0, s, (long long)b * n, rev_mult);
+        hipLaunchKernelGGL(rev_count_kernel<false>, dim3(blocks), dim3(256), 0, s, total, n, k, idx, rev_start,
+                           rev_mult);
+    }
     hipLaunchKernelGGL(rev_scan_kernel, dim3(b), dim3(1024), 0, s, n, rev_start, ws);
     hipLaunchKernelGGL(rev_fill_kernel, dim3(blocks), dim3(256), 0, s, total, n, k, idx, ws, rev_src);
     OGC_CHECK_LAUNCH("ogc_reverse_neighbours");

@@ -36,3 +36,14 @@ def run(reuse, steps=20, warm=5):
 
 for rep in range(2):
     print("A production loop: %.2f ms/step    B plans re-used: %.2f ms/step" % (run(False), run(True)))
+
+# which plan costs what: freeze one of the two (its result is handed out again, nothing is launched for it)
+fixed = PrefetchedGeometry(net, crit, batch, True)
+torch.cuda.synchronize()
+orig_model, orig_loss = net.plan_geometry_async, crit.plan_geometry
+net.plan_geometry_async = lambda pc, after=None: fixed.model
+print("C network plan frozen (loss plan recomputed): %.2f ms/step" % run(False))
+net.plan_geometry_async = orig_model
+crit.plan_geometry = lambda pcs, aug=False: fixed.loss.get()
+print("D loss plan frozen (network plan recomputed): %.2f ms/step" % run(False))
+crit.plan_geometry = orig_loss
