@@ -236,7 +236,11 @@ int ogc_soft_nn_target(int b, int n1, int n2, int k, float temperature, const fl
  * x, y, grad_y, grad_x (b, c, hw) f32 contiguous; gamma, beta, grad_gamma, grad_beta (c); mean, rstd (b*groups)
  * (written by fwd, read by bwd); biased variance, rstd = 1/sqrt(var + eps); relu != 0 applies max(.,0) in fwd
  * and masks grad_y where the output was <= 0 in bwd.
- * ws: caller-allocated scratch, fwd: 2*b*groups doubles; bwd: 2*b*c doubles + 2*b*groups floats. */
+ * ws: caller-allocated scratch holding per-slice partial sums (every entry used is written before it is read: no
+ * clearing, no atomics).  fwd: 2*b*groups*ogc_group_norm_stats_slots() doubles; bwd: 2*b*c*ogc_group_norm_bwd_slots()
+ * doubles. */
+int ogc_group_norm_stats_slots(void);
+int ogc_group_norm_bwd_slots(void);
 int ogc_group_norm_fwd(int b, int c, int hw, int groups, float eps, int relu, const float *x,
                        const float *gamma, const float *beta, float *y, float *mean, float *rstd,
                        double *ws, ogc_stream_t stream);
@@ -311,7 +315,7 @@ int ogc_conv1x1_gemm_gnstats(int b, int M, int K, int hw, int groups, const floa
 
 /* Deferred normalisation: inside a SharedMLP the GroupNorm (+ ReLU) output of one layer is only ever read by the next
  * layer's convolution, so it need not be written.  ogc_group_norm_coeffs turns the statistics of layer l (supplied by
- * the producing convolution, or computed here from x when stats == NULL; ws: 2*b*groups f64 then) into mean / rstd
+ * the producing convolution, or computed here from x when stats == NULL; ws: 2*b*groups*ogc_group_norm_stats_slots() f64 then) into mean / rstd
  * (b*groups) for the backward pass and the per-(b, channel) affine map a, bb (b*c):  GroupNorm(x)[b, ch] = a*x + bb.
  * ogc_conv1x1_gemm_affine is the forward convolution of layer l+1 on act(a*in + bb) applied while loading (relu != 0:
  * act = ReLU; groups > 0: also the statistics of ITS output, as ogc_conv1x1_gemm_gnstats, same restrictions);

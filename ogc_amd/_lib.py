@@ -45,6 +45,8 @@ SIGNATURES = {
     "ogc_group_norm_maxpool_fwd": [_int, _int, _int, _int, _int, _flt, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "ogc_conv1x1_gemm": [_int, _int, _int, _int, _int, _vp, _vp, _vp, _vp],
     "ogc_conv1x1_gn_slots": [],
+    "ogc_group_norm_stats_slots": [],
+    "ogc_group_norm_bwd_slots": [],
     "ogc_group_norm_coeffs": [_int, _int, _int, _int, _flt, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _vp, _vp, _vp],
     "ogc_conv1x1_gemm_affine": [_int, _int, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "ogc_conv1x1_wgrad_affine": [_int, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp],

@@ -42,7 +42,8 @@ __device__ __forceinline__ void gn_block_sum2(double &a, double &b, double *smem
 }
 
 // ---- forward ------------------------------------------------------------------------------------------------
-// grid (chunks, B*G): partial sum / sum of squares of one slice of a row -> atomicAdd into ws[row][0..1] (fp64).
+// grid (chunks, B*G): sum / sum of squares of one slice of a row -> ws[chunk][row][0..1] (fp64).  Every slot is written
+// exactly once, so the buffer needs no clearing and no atomics; the consumers add the `slots` = chunks partial sums.
 __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(long long row_len, long long chunk_len,
                                                               const float *__restrict__ x, double *__restrict__ ws) {
     __shared__ double smem[2 * GN_THREADS / 64];
@@ -75,8 +76,9 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(long long row_len,
     }
     gn_block_sum2(s, ss, smem);
     if (threadIdx.x == 0) {
-        atomicAdd(ws + row * 2, s);
-        atomicAdd(ws + row * 2 + 1, ss);
+        double *dst = ws + ((size_t)blockIdx.x * gridDim.y + row) * 2;
+        dst[0] = s;
+        dst[1] = ss;
     }
 }
 
@@ -130,7 +132,8 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(int c, int hw, int
 }
 
 // ---- backward -----------------------------------------------------------------------------------------------
-// grid (chunks, C, B): ds[b,c] += sum dy'*x, db[b,c] += sum dy'   (fp64 atomics into dsdb[b*c][2])
+// grid (chunks, C, B): ds = sum dy'*x, db = sum dy' of one slice of a channel -> dsdb[chunk][b*c][2] (fp64, every slot
+// written once: no clearing, no atomics)
 template <bool RELU>
 __global__ __launch_bounds__(GN_THREADS) void gn_bwd_sums_kernel(int c, int hw, int groups,
                                                                  const float *__restrict__ x,
@@ -170,42 +173,59 @@ __global__ __launch_bounds__(GN_THREADS) void gn_bwd_sums_kernel(int c, int hw, 
     }
     gn_block_sum2(s, sb, smem);
     if (threadIdx.x == 0) {
-        atomicAdd(dsdb + ((size_t)b * c + ch) * 2, s);
-        atomicAdd(dsdb + ((size_t)b * c + ch) * 2 + 1, sb);
+        double *dst = dsdb + (((size_t)blockIdx.x * gridDim.z + b) * c + ch) * 2;
+        dst[0] = s;
+        dst[1] = sb;
     }
 }
 
-// one thread per channel: dgamma, dbeta; one thread per (b, g): c2, c3.  grid ceil((c + b*groups)/256)
-__global__ void gn_bwd_params_kernel(int b, int c, int hw, int groups, const float *__restrict__ gamma,
-                                     const float *__restrict__ mean, const float *__restrict__ rstd,
-                                     const double *__restrict__ dsdb, float *__restrict__ dgamma,
-                                     float *__restrict__ dbeta, float *__restrict__ c2c3) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int cg = c / groups;
-    if (t < c) {
-        const int g = t / cg;
+// Prologue of the dx kernels (block (chunk, ch, b)): from the partial sums of gn_*_bwd_sums_kernel
+//   c2, c3 of the block's (b, group):  dx = a * dy' + c2 * x + c3   (returned to every thread), and
+//   dgamma[ch], dbeta[ch] — summed over the batch by the block (0, ch, 0).
+// This used to be a launch of its own between the two passes; the few hundred fp64 values it reads per block are
+// nothing next to the block's share of the activation.
+__device__ __forceinline__ void gn_bwd_prologue(int c, int groups, double n_group, int slots,
+                                                const float *__restrict__ gamma, const float *__restrict__ mean,
+                                                const float *__restrict__ rstd, const double *__restrict__ dsdb,
+                                                float *__restrict__ dgamma, float *__restrict__ dbeta, float &c2,
+                                                float &c3) {
+    __shared__ double red[2 * GN_THREADS / 64];
+    __shared__ float coef[2];
+    const int b = blockIdx.z, ch = blockIdx.y, nb = gridDim.z;
+    const int cg = c / groups, g = ch / cg, row = b * groups + g;
+    double dsg = 0.0, dbg = 0.0;
+    for (int e = threadIdx.x; e < cg * slots; e += GN_THREADS) {
+        const int k = g * cg + e % cg, sl = e / cg;
+        const double *src = dsdb + (((size_t)sl * nb + b) * c + k) * 2;
+        const double gk = (double)gamma[k];
+        dsg += src[0] * gk;
+        dbg += src[1] * gk;
+    }
+    gn_block_sum2(dsg, dbg, red);
+    if (threadIdx.x == 0) {
+        const double m = mean[row], r = rstd[row];
+        const double v2 = (dbg * m - dsg) * r * r * r / n_group;
+        coef[0] = (float)v2;
+        coef[1] = (float)(-v2 * m - dbg * r / n_group);
+    }
+    __syncthreads();
+    c2 = coef[0];
+    c3 = coef[1];
+    if (blockIdx.x == 0 && b == 0) { // uniform per block
+        __syncthreads();
         double dg = 0.0, dbt = 0.0;
-        for (int bi = 0; bi < b; ++bi) {
-            const double ds = dsdb[((size_t)bi * c + t) * 2], db = dsdb[((size_t)bi * c + t) * 2 + 1];
-            const int row = bi * groups + g;
-            dg += (ds - (double)mean[row] * db) * (double)rstd[row];
-            dbt += db;
+        for (int e = threadIdx.x; e < nb * slots; e += GN_THREADS) {
+            const int bi = e % nb, sl = e / nb;
+            const double *src = dsdb + (((size_t)sl * nb + bi) * c + ch) * 2;
+            const int r2 = bi * groups + g;
+            dg += (src[0] - (double)mean[r2] * src[1]) * (double)rstd[r2];
+            dbt += src[1];
         }
-        dgamma[t] = (float)dg;
-        dbeta[t] = (float)dbt;
-    } else if (t < c + b * groups) {
-        const int row = t - c, bi = row / groups, g = row % groups;
-        double dsg = 0.0, dbg = 0.0;
-        for (int k = 0; k < cg; ++k) {
-            const int ch = g * cg + k;
-            dsg += dsdb[((size_t)bi * c + ch) * 2] * (double)gamma[ch];
-            dbg += dsdb[((size_t)bi * c + ch) * 2 + 1] * (double)gamma[ch];
+        gn_block_sum2(dg, dbt, red);
+        if (threadIdx.x == 0) {
+            dgamma[ch] = (float)dg;
+            dbeta[ch] = (float)dbt;
         }
-        const double m = mean[row], r = rstd[row], n = (double)cg * hw;
-        const double c2 = (dbg * m - dsg) * r * r * r / n;
-        const double c3 = -c2 * m - dbg * r / n;
-        c2c3[row * 2] = (float)c2;
-        c2c3[row * 2 + 1] = (float)c3;
     }
 }
 
@@ -216,14 +236,16 @@ __global__ __launch_bounds__(GN_THREADS) void gn_bwd_dx_kernel(int c, int hw, in
                                                                const float *__restrict__ beta,
                                                                const float *__restrict__ mean,
                                                                const float *__restrict__ rstd,
-                                                               const float *__restrict__ c2c3,
-                                                               const float *__restrict__ dy, float *__restrict__ dx) {
+                                                               const double *__restrict__ dsdb, int slots,
+                                                               const float *__restrict__ dy, float *__restrict__ dx,
+                                                               float *__restrict__ dgamma, float *__restrict__ dbeta) {
     const int b = blockIdx.z, ch = blockIdx.y;
     const int cg = c / groups, row = b * groups + ch / cg;
     const float r = rstd[row];
     const float a = r * gamma[ch];
     const float bb = beta[ch] - mean[row] * a;
-    const float c2 = c2c3[row * 2], c3 = c2c3[row * 2 + 1];
+    float c2, c3;
+    gn_bwd_prologue(c, groups, (double)cg * hw, slots, gamma, mean, rstd, dsdb, dgamma, dbeta, c2, c3);
     const size_t base = ((size_t)b * c + ch) * hw;
     const float *px = x + base, *pd = dy + base;
     float *po = dx + base;
@@ -330,8 +352,9 @@ __global__ __launch_bounds__(GN_THREADS) void gn_maxpool_bwd_sums_kernel(int c, 
     }
     gn_block_sum2(ds, db, smem);
     if (threadIdx.x == 0) {
-        atomicAdd(dsdb + ((size_t)b * c + ch) * 2, ds);
-        atomicAdd(dsdb + ((size_t)b * c + ch) * 2 + 1, db);
+        double *dst = dsdb + (((size_t)blockIdx.x * gridDim.z + b) * c + ch) * 2;
+        dst[0] = ds;
+        dst[1] = db;
     }
 }
 
@@ -340,16 +363,20 @@ template <bool RELU>
 __global__ __launch_bounds__(GN_THREADS) void gn_maxpool_bwd_dx_kernel(int c, int p, int s, int groups,
                                                                        const float *__restrict__ x,
                                                                        const float *__restrict__ gamma,
+                                                                       const float *__restrict__ mean,
                                                                        const float *__restrict__ rstd,
-                                                                       const float *__restrict__ c2c3,
+                                                                       const double *__restrict__ dsdb, int slots,
                                                                        const float *__restrict__ out,
                                                                        const int *__restrict__ arg,
                                                                        const float *__restrict__ gout,
-                                                                       float *__restrict__ dx) {
+                                                                       float *__restrict__ dx,
+                                                                       float *__restrict__ dgamma,
+                                                                       float *__restrict__ dbeta) {
     const int b = blockIdx.z, ch = blockIdx.y;
     const int cg = c / groups, row = b * groups + ch / cg;
     const float a = rstd[row] * gamma[ch];
-    const float c2 = c2c3[row * 2], c3 = c2c3[row * 2 + 1];
+    float c2, c3;
+    gn_bwd_prologue(c, groups, (double)cg * p * s, slots, gamma, mean, rstd, dsdb, dgamma, dbeta, c2, c3);
     const int L = s >> 2;
     const int rows_per_block = GN_THREADS / L;
     const int sub = threadIdx.x % L;
@@ -370,11 +397,26 @@ __global__ __launch_bounds__(GN_THREADS) void gn_maxpool_bwd_dx_kernel(int c, in
     }
 }
 
+constexpr int GN_STATS_SLOTS = 32; // most partial sums per (b, group) the first pass writes  (ogc_group_norm_stats_slots)
+constexpr int GN_BWD_SLOTS = 8;    // most partial sums per (b, channel) of the backward sums  (ogc_group_norm_bwd_slots)
+
 int hw_chunks(int b, int c, int hw) {
     // enough workgroups to fill the chip (>= ~2048) without making them tiny (>= 4096 elements each)
     int chunks = 1;
-    while ((long long)b * c * chunks < 2048 && hw / (chunks * 2) >= 4096) chunks *= 2;
+    while ((long long)b * c * chunks < 2048 && hw / (chunks * 2) >= 4096 && chunks < GN_BWD_SLOTS) chunks *= 2;
     return chunks;
+}
+
+// First pass of a GroupNorm: partial (sum, sum of squares) of every (b, group) row into ws[slot][rows][2]; returns the
+// number of slots written (<= GN_STATS_SLOTS).
+int launch_gn_stats(int rows, long long row_len, const float *x, double *ws, hipStream_t s) {
+    int chunks = 1;
+    while ((long long)rows * chunks < 2048 && row_len / (chunks * 2) >= 16384 && chunks < GN_STATS_SLOTS) chunks *= 2;
+    long long chunk_len = (row_len + chunks - 1) / chunks;
+    chunk_len = (chunk_len + 3) / 4 * 4;
+    const int slots = (int)ogc_divup(row_len, chunk_len);
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(slots, rows), dim3(GN_THREADS), 0, s, row_len, chunk_len, x, ws);
+    return slots;
 }
 
 } // namespace
@@ -393,18 +435,8 @@ int gn_fwd_impl(const char *name, int b, int c, int hw, int groups, float eps, i
     if (!stats) {
         const int rows = b * groups;
         const long long row_len = (long long)(c / groups) * hw;
-        if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * rows, s) != hipSuccess) {
-            ogc_set_error("%s: memset failed", name);
-            return OGC_ERR_LAUNCH;
-        }
-        int chunks = 1;
-        while ((long long)rows * chunks < 2048 && row_len / (chunks * 2) >= 16384) chunks *= 2;
-        long long chunk_len = (row_len + chunks - 1) / chunks;
-        chunk_len = (chunk_len + 3) / 4 * 4;
-        hipLaunchKernelGGL(gn_stats_kernel, dim3(ogc_divup(row_len, chunk_len), rows), dim3(GN_THREADS), 0, s, row_len,
-                           chunk_len, x, ws);
+        slots = launch_gn_stats(rows, row_len, x, ws, s);
         stats = ws;
-        slots = 1;
     }
     dim3 grid(hw_chunks(b, c, hw), c, b);
     if (relu)
@@ -461,24 +493,17 @@ extern "C" int ogc_group_norm_coeffs(int b, int c, int hw, int groups, float eps
     if (!stats) {
         const int rows = b * groups;
         const long long row_len = (long long)(c / groups) * hw;
-        if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * rows, s) != hipSuccess) {
-            ogc_set_error("ogc_group_norm_coeffs: memset failed");
-            return OGC_ERR_LAUNCH;
-        }
-        int chunks = 1;
-        while ((long long)rows * chunks < 2048 && row_len / (chunks * 2) >= 16384) chunks *= 2;
-        long long chunk_len = (row_len + chunks - 1) / chunks;
-        chunk_len = (chunk_len + 3) / 4 * 4;
-        hipLaunchKernelGGL(gn_stats_kernel, dim3(ogc_divup(row_len, chunk_len), rows), dim3(GN_THREADS), 0, s, row_len,
-                           chunk_len, x, ws);
+        slots = launch_gn_stats(rows, row_len, x, ws, s);
         stats = ws;
-        slots = 1;
     }
     hipLaunchKernelGGL(gn_coeffs_kernel, dim3(ogc_divup(b * c, 256)), dim3(256), 0, s, b, c, hw, groups, eps, gamma, beta,
                        stats, slots, mean, rstd, a, bb);
     OGC_CHECK_LAUNCH("ogc_group_norm_coeffs");
     return OGC_OK;
 }
+
+extern "C" int ogc_group_norm_stats_slots(void) { return GN_STATS_SLOTS; }
+extern "C" int ogc_group_norm_bwd_slots(void) { return GN_BWD_SLOTS; }
 
 extern "C" int ogc_group_norm_fwd(int b, int c, int hw, int groups, float eps, int relu, const float *x,
                                   const float *gamma, const float *beta, float *y, float *mean, float *rstd,
@@ -504,28 +529,22 @@ extern "C" int ogc_group_norm_bwd(int b, int c, int hw, int groups, int relu, co
     OGC_REQUIRE(x && gamma && beta && mean && rstd && grad_y && grad_x && grad_gamma && grad_beta && ws,
                 "ogc_group_norm_bwd: null pointer");
     hipStream_t s = (hipStream_t)stream;
-    // ws layout: dsdb [b*c][2] fp64, then c2c3 [b*groups][2] fp32
+    // ws: partial sums dsdb[slot][b*c][2] (fp64), slot < ogc_group_norm_bwd_slots(); written by the first pass, read by
+    // the prologue of the second (which also produces grad_gamma / grad_beta)
     double *dsdb = ws;
-    float *c2c3 = reinterpret_cast<float *>(ws + (size_t)2 * b * c);
-    if (hipMemsetAsync(dsdb, 0, sizeof(double) * 2 * b * c, s) != hipSuccess) {
-        ogc_set_error("ogc_group_norm_bwd: memset failed");
-        return OGC_ERR_LAUNCH;
-    }
     dim3 grid(hw_chunks(b, c, hw), c, b);
-    if (relu)
+    const int slots = (int)grid.x;
+    if (relu) {
         hipLaunchKernelGGL(gn_bwd_sums_kernel<true>, grid, dim3(GN_THREADS), 0, s, c, hw, groups, x, gamma, beta, mean,
                            rstd, grad_y, dsdb);
-    else
+        hipLaunchKernelGGL(gn_bwd_dx_kernel<true>, grid, dim3(GN_THREADS), 0, s, c, hw, groups, x, gamma, beta, mean,
+                           rstd, dsdb, slots, grad_y, grad_x, grad_gamma, grad_beta);
+    } else {
         hipLaunchKernelGGL(gn_bwd_sums_kernel<false>, grid, dim3(GN_THREADS), 0, s, c, hw, groups, x, gamma, beta, mean,
                            rstd, grad_y, dsdb);
-    hipLaunchKernelGGL(gn_bwd_params_kernel, dim3(ogc_divup(c + b * groups, 256)), dim3(256), 0, s, b, c, hw, groups,
-                       gamma, mean, rstd, dsdb, grad_gamma, grad_beta, c2c3);
-    if (relu)
-        hipLaunchKernelGGL(gn_bwd_dx_kernel<true>, grid, dim3(GN_THREADS), 0, s, c, hw, groups, x, gamma, beta, mean,
-                           rstd, c2c3, grad_y, grad_x);
-    else
         hipLaunchKernelGGL(gn_bwd_dx_kernel<false>, grid, dim3(GN_THREADS), 0, s, c, hw, groups, x, gamma, beta, mean,
-                           rstd, c2c3, grad_y, grad_x);
+                           rstd, dsdb, slots, grad_y, grad_x, grad_gamma, grad_beta);
+    }
     OGC_CHECK_LAUNCH("ogc_group_norm_bwd");
     return OGC_OK;
 }
@@ -548,18 +567,8 @@ int gn_pool_fwd_impl(const char *name, int b, int c, int p, int s, int groups, f
     if (!stats) {
         const int rows = b * groups;
         const long long row_len = (long long)(c / groups) * p * s;
-        if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * rows, st) != hipSuccess) {
-            ogc_set_error("%s: memset failed", name);
-            return OGC_ERR_LAUNCH;
-        }
-        int chunks = 1;
-        while ((long long)rows * chunks < 2048 && row_len / (chunks * 2) >= 16384) chunks *= 2;
-        long long chunk_len = (row_len + chunks - 1) / chunks;
-        chunk_len = (chunk_len + 3) / 4 * 4;
-        hipLaunchKernelGGL(gn_stats_kernel, dim3(ogc_divup(row_len, chunk_len), rows), dim3(GN_THREADS), 0, st, row_len,
-                           chunk_len, x, ws);
+        slots = launch_gn_stats(rows, row_len, x, ws, st);
         stats = ws;
-        slots = 1;
     }
     const int rows_per_block = GN_THREADS / (s / 4);
     int bx = ogc_divup(p, rows_per_block);
@@ -605,31 +614,25 @@ extern "C" int ogc_group_norm_maxpool_bwd(int b, int c, int p, int s, int groups
     OGC_REQUIRE(x && gamma && mean && rstd && out && argmax && grad_out && grad_x && grad_gamma && grad_beta && ws,
                 "ogc_group_norm_maxpool_bwd: null pointer");
     hipStream_t st = (hipStream_t)stream;
-    double *dsdb = ws;
-    float *c2c3 = reinterpret_cast<float *>(ws + (size_t)2 * b * c);
-    if (hipMemsetAsync(dsdb, 0, sizeof(double) * 2 * b * c, st) != hipSuccess) {
-        ogc_set_error("ogc_group_norm_maxpool_bwd: memset failed");
-        return OGC_ERR_LAUNCH;
-    }
-    dim3 gsum(ogc_divup(p, GN_THREADS * 4) > 0 ? ogc_divup(p, GN_THREADS * 4) : 1, c, b);
-    if (relu)
-        hipLaunchKernelGGL(gn_maxpool_bwd_sums_kernel<true>, gsum, dim3(GN_THREADS), 0, st, c, p, s, x, out, argmax,
-                           grad_out, dsdb);
-    else
-        hipLaunchKernelGGL(gn_maxpool_bwd_sums_kernel<false>, gsum, dim3(GN_THREADS), 0, st, c, p, s, x, out, argmax,
-                           grad_out, dsdb);
-    hipLaunchKernelGGL(gn_bwd_params_kernel, dim3(ogc_divup(c + b * groups, 256)), dim3(256), 0, st, b, c, p * s, groups,
-                       gamma, mean, rstd, dsdb, grad_gamma, grad_beta, c2c3);
+    double *dsdb = ws; // partial sums dsdb[slot][b*c][2], as in ogc_group_norm_bwd
+    int slots = ogc_divup(p, GN_THREADS * 4) > 0 ? ogc_divup(p, GN_THREADS * 4) : 1;
+    if (slots > GN_BWD_SLOTS) slots = GN_BWD_SLOTS; // the kernel strides over the rest
+    dim3 gsum(slots, c, b);
     const int rows_per_block = GN_THREADS / (s / 4);
     int bx = ogc_divup(p, rows_per_block);
     while (bx > 1 && (long long)bx * c * b > 8192) bx = (bx + 1) / 2;
     dim3 grid(bx, c, b);
-    if (relu)
-        hipLaunchKernelGGL(gn_maxpool_bwd_dx_kernel<true>, grid, dim3(GN_THREADS), 0, st, c, p, s, groups, x, gamma, rstd,
-                           c2c3, out, argmax, grad_out, grad_x);
-    else
+    if (relu) {
+        hipLaunchKernelGGL(gn_maxpool_bwd_sums_kernel<true>, gsum, dim3(GN_THREADS), 0, st, c, p, s, x, out, argmax,
+                           grad_out, dsdb);
+        hipLaunchKernelGGL(gn_maxpool_bwd_dx_kernel<true>, grid, dim3(GN_THREADS), 0, st, c, p, s, groups, x, gamma, mean,
+                           rstd, dsdb, slots, out, argmax, grad_out, grad_x, grad_gamma, grad_beta);
+    } else {
+        hipLaunchKernelGGL(gn_maxpool_bwd_sums_kernel<false>, gsum, dim3(GN_THREADS), 0, st, c, p, s, x, out, argmax,
+                           grad_out, dsdb);
         hipLaunchKernelGGL(gn_maxpool_bwd_dx_kernel<false>, grid, dim3(GN_THREADS), 0, st, c, p, s, groups, x, gamma,
-                           rstd, c2c3, out, argmax, grad_out, grad_x);
+                           mean, rstd, dsdb, slots, out, argmax, grad_out, grad_x, grad_gamma, grad_beta);
+    }
     OGC_CHECK_LAUNCH("ogc_group_norm_maxpool_bwd");
     return OGC_OK;
 }

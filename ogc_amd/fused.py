@@ -25,7 +25,7 @@ class _GroupNormAct(Function):
                                              bias.detach().contiguous(), y, mean, rstd, stats,
                                              stats.numel() // (2 * B * groups))
         else:
-            ws = torch.empty(2 * B * groups, dtype=torch.float64, device=x.device)
+            ws = _api._native.group_norm_ws(B, C, groups, False, x.device)
             nat.group_norm_fwd_wrapper(B, C, hw, groups, eps, relu, x, weight.detach().contiguous(),
                                        bias.detach().contiguous(), y, mean, rstd, ws)
         ctx.save_for_backward(x, weight, bias, mean, rstd)
@@ -42,7 +42,7 @@ class _GroupNormAct(Function):
         grad_x = torch.empty_like(x)
         gw = torch.empty_like(weight)
         gb = torch.empty_like(bias)
-        ws = torch.empty(2 * B * C + B * groups, dtype=torch.float64, device=x.device)
+        ws = _api._native.group_norm_ws(B, C, groups, True, x.device)
         nat.group_norm_bwd_wrapper(B, C, hw, groups, relu, x, weight.detach().contiguous(), bias.detach().contiguous(),
                                    mean, rstd, grad_y, grad_x, gw, gb, ws)
         return grad_x, gw, gb, None, None, None, None
@@ -77,7 +77,7 @@ class _GroupNormActMaxPool(Function):
                                                      bias.detach().contiguous(), out, arg, mean, rstd, stats,
                                                      stats.numel() // (2 * B * groups))
         else:
-            ws = torch.empty(2 * B * groups, dtype=torch.float64, device=x.device)
+            ws = _api._native.group_norm_ws(B, C, groups, False, x.device)
             nat.group_norm_maxpool_fwd_wrapper(B, C, P, S, groups, eps, relu, x, weight.detach().contiguous(),
                                                bias.detach().contiguous(), out, arg, mean, rstd, ws)
         ctx.save_for_backward(x, weight, mean, rstd, out, arg)
@@ -94,7 +94,7 @@ class _GroupNormActMaxPool(Function):
         grad_x = torch.empty_like(x)
         gw = torch.empty_like(weight)
         gb = torch.empty_like(weight)
-        ws = torch.empty(2 * B * C + B * groups, dtype=torch.float64, device=x.device)
+        ws = _api._native.group_norm_ws(B, C, groups, True, x.device)
         nat.group_norm_maxpool_bwd_wrapper(B, C, P, S, groups, relu, x, weight.detach().contiguous(), mean, rstd, out,
                                            arg, grad_out.contiguous(), grad_x, gw, gb, ws)
         return grad_x, gw, gb, None, None, None, None
@@ -123,6 +123,7 @@ class _PointwiseConv(Function):
     @staticmethod
     def forward(ctx, x, weight, gn_groups=0):
         # gn_groups > 0: also return the statistics of the GroupNorm (gn_groups groups) that consumes y, or None
+        ctx.set_materialize_grads(False)  # no zero tensor (one fill launch per layer) for the statistics output
         ctx.save_for_backward(x, weight)
         nat = _api._native
         B, cin = x.shape[0], x.shape[1]
@@ -148,6 +149,8 @@ class _PointwiseConv(Function):
 
     @staticmethod
     def backward(ctx, grad_y, _grad_stats=None):
+        if grad_y is None:
+            return None, None, None
         x, weight = ctx.saved_tensors
         nd = x.dim() - 2
         grad_y = grad_y.contiguous()
@@ -455,6 +458,7 @@ class _NormActConv(Function):
     @staticmethod
     def forward(ctx, y_prev, stats_prev, gn_weight, gn_bias, conv_weight, gn_groups, eps, relu, next_groups):
         nat = _api._native
+        ctx.set_materialize_grads(False)  # no zero tensor (one fill launch per layer) for the statistics output
         y_prev = y_prev.contiguous()
         B, cin = y_prev.shape[0], y_prev.shape[1]
         cout = conv_weight.shape[0]
@@ -469,7 +473,7 @@ class _NormActConv(Function):
             nat.group_norm_coeffs_wrapper(B, cin, hw, gn_groups, eps, None, gamma, beta, stats_prev,
                                           stats_prev.numel() // (2 * B * gn_groups), None, mean, rstd, a, bb)
         else:
-            ws = torch.empty(2 * B * gn_groups, dtype=torch.float64, device=dev)
+            ws = nat.group_norm_ws(B, cin, gn_groups, False, dev)
             nat.group_norm_coeffs_wrapper(B, cin, hw, gn_groups, eps, y_prev, gamma, beta, None, 0, ws, mean, rstd, a, bb)
         y = torch.empty((B, cout) + tuple(y_prev.shape[2:]), dtype=torch.float32, device=dev)
         w = conv_weight.detach().contiguous()
@@ -488,6 +492,8 @@ class _NormActConv(Function):
 
     @staticmethod
     def backward(ctx, grad_y, _grad_stats=None):
+        if grad_y is None:
+            return (None,) * 9
         nat = _api._native
         y_prev, gn_weight, gn_bias, conv_weight, mean, rstd, a, bb = ctx.saved_tensors
         gn_groups, relu, hw = ctx.cfg
@@ -505,7 +511,7 @@ class _NormActConv(Function):
             grad_z = torch.matmul(w.view(cout, cin).t(), grad_y.reshape(B, cout, hw)).view_as(y_prev)
         grad_prev = torch.empty_like(y_prev)
         gw, gb = torch.empty_like(gn_weight), torch.empty_like(gn_bias)
-        ws = torch.empty(2 * B * cin + B * gn_groups, dtype=torch.float64, device=y_prev.device)
+        ws = nat.group_norm_ws(B, cin, gn_groups, True, y_prev.device)
         nat.group_norm_bwd_wrapper(B, cin, hw, gn_groups, relu, y_prev, gn_weight.detach().contiguous(),
                                    gn_bias.detach().contiguous(), mean, rstd, grad_z, grad_prev, gw, gb, ws)
         return grad_prev, None, gw, gb, grad_w.view_as(conv_weight), None, None, None, None

@@ -313,6 +313,14 @@ def conv1x1_wgrad_affine_wrapper(b, cin, cout, hw, relu, x, pa, pb, dy, dw):
          _f(dy, "dy"), _f(dw, "dw"))
 
 
+def group_norm_ws(b, c, groups, backward, device):
+    """Scratch of the GroupNorm entry points: per-slice partial sums, 2*b*groups*ogc_group_norm_stats_slots() doubles
+    for a forward statistics pass, 2*b*c*ogc_group_norm_bwd_slots() for the backward pass (include/ogc_ops.h)."""
+    L = _lib.load()
+    n = 2 * b * c * L.ogc_group_norm_bwd_slots() if backward else 2 * b * groups * L.ogc_group_norm_stats_slots()
+    return torch.empty(max(n, 1), dtype=torch.float64, device=device)
+
+
 def conv1x1_gn_slots():
     """Number of accumulator copies conv1x1_gemm_gnstats_wrapper fills (ogc_conv1x1_gn_slots)."""
     return _lib.load().ogc_conv1x1_gn_slots()

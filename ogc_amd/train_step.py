@@ -110,7 +110,8 @@ def train_step(segnet, criterion, optimizer, batch, it, aug_transform, sync=True
         kw = {}
     t, n = batch[1].size(1), batch[1].size(2)
     masks = masks.view(b, t, n, -1)
-    masks_l = [masks[:, tt].contiguous() for tt in range(t)]
+    # unbind, not masks[:, tt]: its backward is one stack instead of a zero-fill, a copy and an add per view
+    masks_l = [m.contiguous() for m in masks.unbind(1)]
     upcoming = None
     if next_batch is not None and on_gpu:
         upcoming = PrefetchedGeometry(segnet, criterion, next_batch, aug_transform)

@@ -622,7 +622,7 @@ def test_conv_gemm_gnstats(shape):
         if use_stats:
             nat.group_norm_fwd_stats_wrapper(B, cout, hw, groups, 1e-5, 1, y1, gamma, beta, y, mean, rstd, stats, slots)
         else:
-            ws = torch.empty(2 * B * groups, dtype=torch.float64, device="cuda")
+            ws = nat.group_norm_ws(B, cout, groups, False, "cuda")
             nat.group_norm_fwd_wrapper(B, cout, hw, groups, 1e-5, 1, y1, gamma, beta, y, mean, rstd, ws)
         outs.append((y, mean, rstd))
     for a, b_ in zip(outs[0], outs[1]):

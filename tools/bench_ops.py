@@ -133,7 +133,7 @@ def bench_conv_gn(ops, iters):
             # layer's GroupNorm + ReLU folded into the operand load
             gamma, beta = torch.ones(cout, device=DEV), torch.zeros(cout, device=DEV)
             mean, rstd = torch.empty(B * 4, device=DEV), torch.empty(B * 4, device=DEV)
-            ws = torch.empty(2 * B * 4, dtype=torch.float64, device=DEV)
+            ws = nat.group_norm_ws(B, cout, 4, False, DEV)
             gn_full = timeit(lambda: nat.group_norm_fwd_wrapper(B, cout, hw, 4, 1e-5, 1, y, gamma, beta, y2, mean, rstd, ws), iters)
             a, bb = torch.rand(B * cin, device=DEV), torch.randn(B * cin, device=DEV)
             fa = timeit(lambda: nat.conv1x1_gemm_affine_wrapper(B, cout, cin, hw, 1, 0, w, x, a, bb, y, None), iters)
