@@ -112,7 +112,7 @@ def main():
 
     it = 1000  # it*b >= every start_step -> dynamic + smooth + invariance all active
     # The trainer holds the next batch while a step runs (ogc_amd/train_seg.py reads one batch ahead), so each step
-    # also queues the coordinate-only work (FPS / kNN / ball query) of the FOLLOWING step on side streams and consumes
+    # also queues the network's coordinate-only work (FPS / kNN / 3-NN) of the FOLLOWING step on a side stream and consumes
     # the plan made during the previous step: one plan is computed per step, inside the timed region, none is reused.
     pre = None
     for _ in range(a.warmup):
@@ -170,8 +170,8 @@ def main():
                     "note": "algorithmic bytes = B*(12M + 12N + 4M*nsample) (SURVEY 8d) / mean duration of the whole "
                             "operator call (HIP events on the launch stream, inside the timed steps); the exact "
                             "cell-list search tests ~N/60 candidates per centre, so the all-pairs figure of 8*B*N*M "
-                            "flop no longer describes the work done; in the step the operator runs on a side stream "
-                            "underneath the dense kernels, which lengthens it versus an idle GPU (tools/bench_ops.py)",
+                            "flop no longer describes the work done; in the step the next batch's network geometry plan "
+                            "(FPS / kNN on a side stream) shares the chip with it (tools/bench_ops.py has the idle-GPU table)",
                     "all_pairs_equivalent_tpairs_per_s": round(b_ * n_ * m_ / (ms * 1e-3) / 1e12, 2),
                     # offline (rocprofv3 --pmc SQ_INSTS_VALU + --kernel-trace, profiles/r01_ball_query_pmc_v2.txt):
                     # what actually bounds the search kernel is VALU issue, not HBM

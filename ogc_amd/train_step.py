@@ -63,12 +63,15 @@ def _views(batch):
 
 
 class PrefetchedGeometry:
-    """Coordinate-only work of a step (FPS / kNN / 3-NN of every encoder level, the smooth term's kNN and ball query)
-    queued ahead of time for `batch`.  None of it depends on the weights, so a trainer that already holds the next
-    batch can let it run on side streams underneath the current step's dense kernels (the sampling kernels keep one
-    workgroup per cloud busy — 16 of 256 CUs — for milliseconds)."""
+    """Coordinate-only work of a step (FPS / kNN / 3-NN of every encoder level) queued ahead of time for `batch`.  None
+    of it depends on the weights, so a trainer that already holds the next batch can let it run on a side stream
+    underneath the current step's dense kernels (the sampling kernels keep one workgroup per cloud busy — 16 of 256
+    CUs — for milliseconds, each launch waiting on the last).
+    loss_ahead: also queue the smooth term's neighbour searches (kNN, ball query, transposed lists) ahead.  Off by
+    default: those kernels fill the chip for ~0.55 ms, so underneath the dense kernels they take as much from them as
+    they cost when run in line before the loss (measured at C4: 18.5 ms per step ahead, 18.2 ms in line)."""
 
-    def __init__(self, segnet, criterion, batch, aug_transform):
+    def __init__(self, segnet, criterion, batch, aug_transform, loss_ahead=False):
         from .utils.streams import launch_on_side, side_stream
         net = segnet.module if hasattr(segnet, "module") else segnet
         self.batch, self.aug = batch, aug_transform
@@ -77,7 +80,7 @@ class PrefetchedGeometry:
         ready.record()
         self.model = net.plan_geometry_async(self.flat, after=ready) if hasattr(net, "plan_geometry_async") else None
         self.loss = None
-        if hasattr(criterion, "plan_geometry"):
+        if loss_ahead and hasattr(criterion, "plan_geometry"):
             for p in self.pcs_l:
                 p.record_stream(side_stream(p.device, "loss-geometry"))
             self.loss = launch_on_side(side_stream(self.flat.device, "loss-geometry"),

@@ -25,8 +25,18 @@ class _PointnetSAModuleBase(nn.Module):
         radius of the clamp, so one search serves them all).  May be evaluated ahead of time on a side stream."""
         if self.npoint is None:
             return None
+        plan = self.plan_sampling(xyz)
+        plan["idx"] = self.plan_neighbours(xyz, plan["new_xyz"])
+        return plan
+
+    def plan_sampling(self, xyz):
+        """The sequential part: FPS indices and the sampled centres (:22-27)."""
         new_inds = furthest_point_sample(xyz, self.npoint).long()
         new_xyz = gather_nd(xyz, new_inds)  # == gather on the transposed cloud, transposed back (:22-27)
+        return {"new_inds": new_inds, "new_xyz": new_xyz}
+
+    def plan_neighbours(self, xyz, new_xyz):
+        """Neighbour lists of every scale around the sampled centres."""
         knn, idx = {}, []
         for grouper in self.groupers:
             if not isinstance(grouper, QueryAndGroup):
@@ -38,7 +48,7 @@ class _PointnetSAModuleBase(nn.Module):
             if grouper.radius is not None:  # the clamp of pointnet2.py:283-286, per scale
                 nn_idx = torch.where(dist > grouper.radius, nn_idx[:, :, :1], nn_idx)
             idx.append(nn_idx.contiguous())
-        return {"new_inds": new_inds, "new_xyz": new_xyz, "idx": idx}
+        return idx
 
     def forward(self, xyz, features=None, return_inds=False, geometry=None):
         # xyz (B, N, 3), features (B, C, N) -> new_xyz (B, npoint, 3), new_features (B, sum(mlp[-1]), npoint)
@@ -48,6 +58,8 @@ class _PointnetSAModuleBase(nn.Module):
             geometry = self.plan_geometry(xyz)
         elif hasattr(geometry, "get"):
             geometry = geometry.get()
+        if geometry is not None and "idx" not in geometry:  # only the sampling was planned ahead
+            geometry = dict(geometry, idx=self.plan_neighbours(xyz, geometry["new_xyz"]))
         new_xyz = geometry["new_xyz"] if geometry is not None else None
         new_inds = geometry["new_inds"] if geometry is not None else None
 
