@@ -230,6 +230,22 @@ int ogc_neighbour_consistency_bwd(int b, int n, int c, int k, int p, const float
 int ogc_soft_nn_target(int b, int n1, int n2, int k, float temperature, const float *p1, const float *p2,
                        const float *mask1, const float *mask2, float *target, ogc_stream_t stream);
 
+/* Attention core of the MaskFormer head's nn.MultiheadAttention layers
+ *   utils/transformer_util.py:5-62 (cross-attention slots <- points, self-attention among the slots; 8 heads,
+ *   models/segnet_kitti.py:49-51):   out = softmax(scale * Q K^T) V   per (sample, head), fp32.
+ * q (b, lq, .), k, v (b, lk, .) are read in place from the projection outputs: row strides ldq / ldk / ldv floats, the
+ * pointer is the first column of the operand inside its packed buffer, head i is the column block [i*d, (i+1)*d).
+ * out (b, lq, h*d) contiguous, heads merged (what the output projection takes); prob (b, h, lq, lk) the attention
+ * probabilities, kept for the backward pass.  d in {16, 32} (OGC_ERR_UNSUPPORTED otherwise); pointers 16-byte aligned,
+ * strides multiples of 4.
+ * bwd: dout (b, lq, h*d) -> dq / dk / dv written with row strides lddq / lddk / lddv (e.g. the column blocks of one
+ * packed (b, l, 3*h*d) gradient); needs lq * lk floats of LDS per workgroup (OGC_ERR_UNSUPPORTED beyond 64 KiB). */
+int ogc_attention_fwd(int b, int lq, int lk, int h, int d, float scale, const float *q, int ldq, const float *k,
+                      int ldk, const float *v, int ldv, float *out, float *prob, ogc_stream_t stream);
+int ogc_attention_bwd(int b, int lq, int lk, int h, int d, float scale, const float *q, int ldq, const float *k,
+                      int ldk, const float *v, int ldv, const float *out, const float *prob, const float *dout,
+                      float *dq, int lddq, float *dk, int lddk, float *dv, int lddv, ogc_stream_t stream);
+
 /* Fused GroupNorm (+ ReLU) forward / backward.  Replaces the nn.GroupNorm -> ReLU(inplace) tail of every
  * Conv2d block of the segmentation nets' SharedMLPs
  *   utils/nn_util.py:6-11 (GroupNorm), :45-85 (_ConvBase ordering), models/segnet_kitti.py:8 (BN_CONFIG).

@@ -44,6 +44,9 @@ SIGNATURES = {
     "ogc_group_norm_bwd": [_int, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "ogc_group_norm_maxpool_fwd": [_int, _int, _int, _int, _int, _flt, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "ogc_conv1x1_gemm": [_int, _int, _int, _int, _int, _vp, _vp, _vp, _vp],
+    "ogc_attention_fwd": [_int, _int, _int, _int, _int, _flt, _vp, _int, _vp, _int, _vp, _int, _vp, _vp, _vp],
+    "ogc_attention_bwd": [_int, _int, _int, _int, _int, _flt, _vp, _int, _vp, _int, _vp, _int, _vp, _vp, _vp, _vp, _int,
+                          _vp, _int, _vp, _int, _vp],
     "ogc_conv1x1_gn_slots": [],
     "ogc_group_norm_stats_slots": [],
     "ogc_group_norm_bwd_slots": [],

@@ -533,3 +533,89 @@ def norm_act_conv(y_prev, stats_prev, gn, relu, conv, next_gn=None):
     next_groups = next_gn.num_groups if (next_gn is not None and next_gn.affine) else 0
     return _NormActConv.apply(y_prev, stats_prev, gn.weight, gn.bias, conv.weight, gn.num_groups, gn.eps, bool(relu),
                               next_groups)
+
+
+class _SelfAttentionCore(Function):
+    """softmax(Q K^T / sqrt(d)) V with Q, K, V the three column blocks of one packed projection (B, L, 3E) — the core
+    of nn.MultiheadAttention's self-attention — as one launch each way (ogc_attention_fwd / _bwd) instead of the head
+    split / merge copies, two batched GEMMs, scaling and softmax torch runs.  Returns (B, L, E), heads merged."""
+
+    @staticmethod
+    def forward(ctx, qkv, n_head):
+        nat = _api._native
+        qkv = qkv.contiguous()
+        B, L, E3 = qkv.shape
+        E = E3 // 3
+        out = torch.empty(B, L, E, dtype=torch.float32, device=qkv.device)
+        prob = torch.empty(B, n_head, L, L, dtype=torch.float32, device=qkv.device)
+        scale = (E // n_head) ** -0.5
+        nat.attention_fwd_wrapper(n_head, scale, qkv[:, :, :E], qkv[:, :, E:2 * E], qkv[:, :, 2 * E:], out, prob)
+        ctx.save_for_backward(qkv, out, prob)
+        ctx.cfg = (n_head, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        qkv, out, prob = ctx.saved_tensors
+        n_head, scale = ctx.cfg
+        E = qkv.shape[2] // 3
+        grad = torch.empty_like(qkv)
+        _api._native.attention_bwd_wrapper(n_head, scale, qkv[:, :, :E], qkv[:, :, E:2 * E], qkv[:, :, 2 * E:], out, prob,
+                                           grad_out.contiguous(), grad[:, :, :E], grad[:, :, E:2 * E], grad[:, :, 2 * E:])
+        return grad, None
+
+
+class _CrossAttentionCore(Function):
+    """As _SelfAttentionCore with the queries (B, Lq, E) projected from one tensor and keys / values the two column
+    blocks of a packed projection (B, Lk, 2E) of another."""
+
+    @staticmethod
+    def forward(ctx, q, kv, n_head):
+        nat = _api._native
+        q, kv = q.contiguous(), kv.contiguous()
+        B, Lq, E = q.shape
+        Lk = kv.shape[1]
+        out = torch.empty(B, Lq, E, dtype=torch.float32, device=q.device)
+        prob = torch.empty(B, n_head, Lq, Lk, dtype=torch.float32, device=q.device)
+        scale = (E // n_head) ** -0.5
+        nat.attention_fwd_wrapper(n_head, scale, q, kv[:, :, :E], kv[:, :, E:], out, prob)
+        ctx.save_for_backward(q, kv, out, prob)
+        ctx.cfg = (n_head, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        q, kv, out, prob = ctx.saved_tensors
+        n_head, scale = ctx.cfg
+        E = q.shape[2]
+        gq, gkv = torch.empty_like(q), torch.empty_like(kv)
+        _api._native.attention_bwd_wrapper(n_head, scale, q, kv[:, :, :E], kv[:, :, E:], out, prob, grad_out.contiguous(),
+                                           gq, gkv[:, :, :E], gkv[:, :, E:])
+        return gq, gkv, None
+
+
+def attention_core_available(embed_dim, n_head, lq, lk, *tensors):
+    """The fused attention core handles heads of 16 or 32 columns and needs lq * lk floats of LDS in its backward."""
+    nat = _api._native
+    return (getattr(nat, "attention_fwd_wrapper", None) is not None and embed_dim % n_head == 0
+            and embed_dim // n_head in (16, 32) and 4 * (lq * lk + 2 * lq * (embed_dim // n_head) + lq + 4) <= 64 * 1024
+            and all(t.is_cuda and t.dtype == torch.float32 for t in tensors))
+
+
+def multihead_attention(mha, query, key, value):
+    """``mha(query, key, value, need_weights=False)[0]`` for a batch-first nn.MultiheadAttention without masks or
+    dropout (the use in utils/transformer_util.py:39-47), with the module's own parameters: the three projections stay
+    GEMMs (packed: one for self-attention, one for the queries and one for keys + values when key is value), the core
+    between them is the fused kernel.  Falls back to the module itself where that does not apply."""
+    E, H = mha.embed_dim, mha.num_heads
+    ok = (mha.batch_first and mha._qkv_same_embed_dim and mha.in_proj_bias is not None and mha.dropout == 0.0
+          and mha.bias_k is None and not mha.add_zero_attn and query.dim() == 3 and key is value
+          and attention_core_available(E, H, query.shape[1], key.shape[1], query, key))
+    if not ok:
+        return mha(query, key, value, need_weights=False)[0]
+    W, b = mha.in_proj_weight, mha.in_proj_bias
+    if query is key:
+        core = _SelfAttentionCore.apply(F.linear(query, W, b), H)
+    else:
+        core = _CrossAttentionCore.apply(F.linear(query, W[:E], b[:E]), F.linear(key, W[E:], b[E:]), H)
+    return F.linear(core, mha.out_proj.weight, mha.out_proj.bias)

@@ -313,6 +313,37 @@ def conv1x1_wgrad_affine_wrapper(b, cin, cout, hw, relu, x, pa, pb, dy, dw):
          _f(dy, "dy"), _f(dw, "dw"))
 
 
+def _rows(t, name):
+    """(pointer, row stride) of a (b, l, w) fp32 operand read in place from a packed projection output: a column slice
+    of a contiguous (b, l, W) tensor (unit stride along the last axis, rows W apart, samples l*W apart)."""
+    if not isinstance(t, torch.Tensor) or t.device.type != "cuda" or t.dtype != torch.float32 or t.dim() != 3:
+        raise RuntimeError("%s must be a 3-D float32 CUDA tensor" % name)
+    ld = t.stride(1)
+    if t.stride(2) != 1 or ld < t.shape[2] or (t.shape[0] > 1 and t.stride(0) != t.shape[1] * ld):
+        raise RuntimeError("%s must be a column slice of a contiguous (b, l, W) tensor" % name)
+    return t.data_ptr(), ld
+
+
+def attention_fwd_wrapper(h, scale, q, k, v, out, prob):
+    """out = softmax(scale * Q K^T) V per (sample, head) (ogc_attention_fwd).  q (b, lq, e), k / v (b, lk, e) may be
+    column slices of packed projections; out (b, lq, e) and prob (b, h, lq, lk) contiguous."""
+    b, lq, e = q.shape
+    lk = k.shape[1]
+    (qp, ldq), (kp, ldk), (vp, ldv) = _rows(q, "q"), _rows(k, "k"), _rows(v, "v")
+    _run("ogc_attention_fwd", q, b, lq, lk, h, e // h, float(scale), qp, ldq, kp, ldk, vp, ldv, _f(out, "out"),
+         _f(prob, "prob"))
+
+
+def attention_bwd_wrapper(h, scale, q, k, v, out, prob, dout, dq, dk, dv):
+    """Gradients of attention_fwd_wrapper (ogc_attention_bwd); dq / dk / dv may be column slices of packed buffers."""
+    b, lq, e = q.shape
+    lk = k.shape[1]
+    (qp, ldq), (kp, ldk), (vp, ldv) = _rows(q, "q"), _rows(k, "k"), _rows(v, "v")
+    (dqp, lddq), (dkp, lddk), (dvp, lddv) = _rows(dq, "dq"), _rows(dk, "dk"), _rows(dv, "dv")
+    _run("ogc_attention_bwd", q, b, lq, lk, h, e // h, float(scale), qp, ldq, kp, ldk, vp, ldv, _f(out, "out"),
+         _f(prob, "prob"), _f(dout, "dout"), dqp, lddq, dkp, lddk, dvp, lddv)
+
+
 def group_norm_ws(b, c, groups, backward, device):
     """Scratch of the GroupNorm entry points: per-slice partial sums, 2*b*groups*ogc_group_norm_stats_slots() doubles
     for a forward statistics pass, 2*b*c*ogc_group_norm_bwd_slots() for the backward pass (include/ogc_ops.h)."""

@@ -1,6 +1,7 @@
 """MaskFormer-style transformer head on top of the point features (reference: utils/transformer_util.py).
-Plain torch.nn; the only change is that the slot-index tensor is created on the input's device instead of
-the reference's hard-coded ``.cuda()`` (transformer_util.py:110)."""
+torch.nn modules with the reference's parameter names; on the GPU the attention core between the projections is the
+fused kernel of ogc_amd/csrc/attention.hip (ogc_amd.fused.multihead_attention), and nothing is created with the
+reference's hard-coded ``.cuda()`` (transformer_util.py:110)."""
 import torch
 import torch.nn as nn
 
@@ -21,10 +22,14 @@ class TransformerDecoderLayer(nn.Module):
 
     def forward(self, slot, point_feats, pos_enc=None):
         # slot (B, K, C), point_feats (B, N, C), pos_enc (B, N, C) or None -> (B, K, C)
-        key = point_feats if pos_enc is None else point_feats + pos_enc
-        slot = slot + self.cross_attn(query=self.norm_slot1(slot), key=key, value=point_feats)[0]
+        from ..fused import multihead_attention  # the module's own parameters; fused attention core on the GPU
+        if pos_enc is None:
+            slot = slot + multihead_attention(self.cross_attn, self.norm_slot1(slot), point_feats, point_feats)
+        else:
+            slot = slot + self.cross_attn(query=self.norm_slot1(slot), key=point_feats + pos_enc, value=point_feats,
+                                          need_weights=False)[0]
         s2 = self.norm_slot2(slot)
-        slot = slot + self.self_attn(query=s2, key=s2, value=s2)[0]
+        slot = slot + multihead_attention(self.self_attn, s2, s2, s2)
         return slot + self.mlp(self.norm_pre_ff(slot))
 
 
@@ -47,8 +52,9 @@ class MaskFormerHead(nn.Module):
     def forward(self, point_feats, point_pos):
         # point_feats (B, N, C_in), point_pos (B, N, 3) -> slots (B, K, D)
         n_batch = point_feats.shape[0]
-        slot_ids = torch.arange(self.n_slot, device=point_feats.device).expand(n_batch, self.n_slot)
-        slot = self.query(slot_ids)
+        # every sample looks up slots 0..K-1 (transformer_util.py:108-111): the embedding table itself, broadcast —
+        # same values, and the backward is one sum over the batch instead of an index sort + scatter
+        slot = self.query.weight.unsqueeze(0).expand(n_batch, -1, -1)
         inputs = self.norm_input(self.mlp_input(point_feats))
         pos_enc = self.input_pos_enc(point_pos) if self.input_pos_enc is not None else None
         for layer in self.transformer_layers:
