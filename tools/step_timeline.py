@@ -34,6 +34,8 @@ def step(record=None):
     marks = []
 
     def mark():
+        if os.environ.get("MARK"):
+            torch.cuda._sleep(2000)  # shows up in a kernel trace as a marker between the phases (tools/phase_busy.py)
         ev = torch.cuda.Event(enable_timing=True)
         ev.record()
         marks.append((ev, time.perf_counter()))
