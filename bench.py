@@ -120,7 +120,10 @@ def main():
     sync()
     with nat.LaunchTimer({"ogc_ball_query", "ogc_knn_clamped", "ogc_furthest_point_sampling"}) as timer:
         t0 = time.perf_counter()
+        mark = bool(os.environ.get("OGC_BENCH_MARK"))  # profiling aid: a marker kernel per step (tools/prof_summary.py)
         for _ in range(a.steps):
+            if mark:
+                torch.cuda._sleep(1000)
             # sync=False: the step's scalars (losses, NaN flag) travel to the host asynchronously and are read after
             # the timed region; every step still computes and copies them
             pending = train_step(model, crit, opt, batch, it, True, sync=False, prefetched=pre, next_batch=batch)
