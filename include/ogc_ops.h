@@ -326,6 +326,13 @@ int ogc_conv1x1_gemm(int b, int M, int K, int hw, int transpose_a, const float *
  * Requires, beyond ogc_conv1x1_gemm: groups <= 32, (M / groups) % 4 == 0 and K <= 100 (OGC_ERR_UNSUPPORTED otherwise:
  * wider layers run the plain GEMM and the GroupNorm entry points compute their own statistics). */
 int ogc_conv1x1_gn_slots(void);
+
+/* Operand precision of ogc_conv1x1_gemm* / ogc_conv1x1_wgrad* (process-wide; returns the previous setting).
+ * 0 (default): fp32 operands on v_mfma_f32_16x16x4_f32 — exact fp32 FMA chains, the parity mode.
+ * 1: operands rounded to bf16 (nearest even) on v_mfma_f32_16x16x16_bf16, fp32 accumulation, tensors in memory stay
+ *    fp32 — the arithmetic torch.autocast(bfloat16) gives the reference's Conv2d layers (BASELINE config "OGC-DR ...,
+ *    bf16"); GroupNorm statistics, losses and everything else stay fp32. */
+int ogc_set_matmul_precision(int bf16);
 int ogc_conv1x1_gemm_gnstats(int b, int M, int K, int hw, int groups, const float *w, const float *in, float *out,
                              double *stats, ogc_stream_t stream);
 

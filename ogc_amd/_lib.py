@@ -48,6 +48,7 @@ SIGNATURES = {
     "ogc_attention_bwd": [_int, _int, _int, _int, _int, _flt, _vp, _int, _vp, _int, _vp, _int, _vp, _vp, _vp, _vp, _int,
                           _vp, _int, _vp, _int, _vp],
     "ogc_conv1x1_gn_slots": [],
+    "ogc_set_matmul_precision": [_int],
     "ogc_group_norm_stats_slots": [],
     "ogc_group_norm_bwd_slots": [],
     "ogc_group_norm_coeffs": [_int, _int, _int, _int, _flt, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _vp, _vp, _vp],

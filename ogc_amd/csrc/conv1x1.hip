@@ -19,12 +19,29 @@
 namespace {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef short v4s __attribute__((ext_vector_type(4)));  // four bf16 MFMA operand values
 
 constexpr int WG_WAVES = 4;
 
+// Operand precision of the convolution kernels (ogc_set_matmul_precision): 0 = fp32 operands on
+// v_mfma_f32_16x16x4_f32 (default; results are exact fp32 FMA chains), 1 = operands rounded to bf16 (nearest even) on
+// v_mfma_f32_16x16x16_bf16, fp32 accumulation, tensors in memory stay fp32 — what autocast(bfloat16) gives the
+// reference's Conv2d layers (BASELINE config "OGC-DR ..., bf16").  Layers of 128 channels and more sit on the fp32
+// MFMA roof (157 TFLOP/s); with bf16 operands (2.5 PFLOP/s) they fall back onto the HBM roof.
+int g_matmul_bf16 = 0;
+
+__device__ __forceinline__ v4s ogc_pack_bf16(float a, float b, float c, float d) {
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
+    union { v2bf h[2]; v4s s; } u;
+    u.h[0] = __builtin_convertvector((v2f){a, b}, v2bf); // one v_cvt_pk_bf16_f32 per pair
+    u.h[1] = __builtin_convertvector((v2f){c, d}, v2bf);
+    return u.s;
+}
+
 // PRO: the layer's input was never materialised — x holds the previous layer's raw convolution output and the operand
 // is act(pa[b, ci] * x + pb[b, ci]), recomputed while loading (see conv1x1_gemm_kernel).
-template <int COB, int CIB, bool PRO>
+template <int COB, int CIB, bool PRO, bool BF>
 __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_wgrad_kernel(int batch, int cin, int cout, int hw,
                                                                            int steps_per_wave,
                                                                            const float *__restrict__ x,
@@ -105,15 +122,29 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_wgrad_kernel(int b
                 xv[c] = v;
             }
         }
+        if constexpr (BF) {
+            // the lane's four consecutive positions are the four k-slots 4k .. 4k+3 of ONE 16x16x16 MFMA
+            v4s yb16[COB], xb16[CIB];
 #pragma unroll
-        for (int a = 0; a < COB; ++a)
+            for (int a = 0; a < COB; ++a) yb16[a] = ogc_pack_bf16(yv[a].x, yv[a].y, yv[a].z, yv[a].w);
 #pragma unroll
-            for (int c = 0; c < CIB; ++c) {
-                acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(yv[a].x, xv[c].x, acc[a][c], 0, 0, 0);
-                acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(yv[a].y, xv[c].y, acc[a][c], 0, 0, 0);
-                acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(yv[a].z, xv[c].z, acc[a][c], 0, 0, 0);
-                acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(yv[a].w, xv[c].w, acc[a][c], 0, 0, 0);
-            }
+            for (int c = 0; c < CIB; ++c) xb16[c] = ogc_pack_bf16(xv[c].x, xv[c].y, xv[c].z, xv[c].w);
+#pragma unroll
+            for (int a = 0; a < COB; ++a)
+#pragma unroll
+                for (int c = 0; c < CIB; ++c)
+                    acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(yb16[a], xb16[c], acc[a][c], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int a = 0; a < COB; ++a)
+#pragma unroll
+                for (int c = 0; c < CIB; ++c) {
+                    acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(yv[a].x, xv[c].x, acc[a][c], 0, 0, 0);
+                    acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(yv[a].y, xv[c].y, acc[a][c], 0, 0, 0);
+                    acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(yv[a].z, xv[c].z, acc[a][c], 0, 0, 0);
+                    acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(yv[a].w, xv[c].w, acc[a][c], 0, 0, 0);
+                }
+        }
     };
 
     float4 ya[COB], xa[CIB], yb[COB], xb[CIB];
@@ -158,12 +189,17 @@ void wgrad_launch(int b, int cin, int cout, int hw, const float *x, const float 
     spw = (spw + 1) / 2 * 2;
     const int wgs = (int)((nsteps + spw * WG_WAVES - 1) / (spw * WG_WAVES));
     dim3 grid(wgs, ogc_divup(cout, 16 * COB), ogc_divup(cin, 16 * CIB));
-    if (pa)
-        hipLaunchKernelGGL((conv1x1_wgrad_kernel<COB, CIB, true>), grid, dim3(WG_WAVES * OGC_WAVE), 0, s, b, cin, cout, hw,
-                           (int)spw, x, dy, dw, pa, pb, pro_relu);
-    else
-        hipLaunchKernelGGL((conv1x1_wgrad_kernel<COB, CIB, false>), grid, dim3(WG_WAVES * OGC_WAVE), 0, s, b, cin, cout,
-                           hw, (int)spw, x, dy, dw, pa, pb, pro_relu);
+#define OGC_WGRAD(PROV, BFV)                                                                                          \
+    hipLaunchKernelGGL((conv1x1_wgrad_kernel<COB, CIB, PROV, BFV>), grid, dim3(WG_WAVES * OGC_WAVE), 0, s, b, cin, cout, \
+                       hw, (int)spw, x, dy, dw, pa, pb, pro_relu)
+    if (g_matmul_bf16) {
+        if (pa) OGC_WGRAD(true, true);
+        else OGC_WGRAD(false, true);
+    } else {
+        if (pa) OGC_WGRAD(true, false);
+        else OGC_WGRAD(false, false);
+    }
+#undef OGC_WGRAD
 }
 
 } // namespace
@@ -188,7 +224,10 @@ constexpr int GN_SLOTS = 16;  // spread of the fused GroupNorm statistics over c
 // per (group, statistic) and workgroup into one of GN_SLOTS copies of the accumulator.
 // PRO: the input is act(pa[b, k] * in + pb[b, k]) — the GroupNorm (+ ReLU) of the PREVIOUS layer applied while its raw
 // convolution output is loaded, so that the normalised activation is never written to memory.
-template <bool TRANSPOSE_A, int KQ, bool STATS, bool PRO>
+// BF: bf16 operands.  Sixteen input rows (four register quads q .. q+3) feed one 16x16x16 MFMA: k-slot 4*kk + i of
+// lane group kk is input row 4*(q+i) + kk for BOTH operands (a permutation of the sixteen rows, which a sum over k
+// does not see), so the register-resident tile needs no shuffle; the weights are staged in LDS already packed that way.
+template <bool TRANSPOSE_A, int KQ, bool STATS, bool PRO, bool BF>
 __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_gemm_kernel(int M, int K, int hw, int groups,
                                                                           const float *__restrict__ w, // (Cout, Cin)
                                                                           const float *__restrict__ in,
@@ -241,9 +280,39 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_gemm_kernel(int M,
             }
         }
     }
+    constexpr int GQ = (KQ + 3) / 4;
+    v4s xb[BF ? GQ : 1][4]; // BF: the tile as packed bf16 operands (half the registers of the fp32 tile, which dies here)
+    if constexpr (BF) {
+#pragma unroll
+        for (int g = 0; g < GQ; ++g) {
+            float4 r[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) r[i] = 4 * g + i < KQ ? xin[4 * g + i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            xb[g][0] = ogc_pack_bf16(r[0].x, r[1].x, r[2].x, r[3].x);
+            xb[g][1] = ogc_pack_bf16(r[0].y, r[1].y, r[2].y, r[3].y);
+            xb[g][2] = ogc_pack_bf16(r[0].z, r[1].z, r[2].z, r[3].z);
+            xb[g][3] = ogc_pack_bf16(r[0].w, r[1].w, r[2].w, r[3].w);
+        }
+    }
     const int cpg = STATS ? M / groups : 1; // channels per group, a multiple of 4 on this path
     for (int m0 = 0; m0 < M; m0 += 64) {
         __syncthreads(); // previous tile fully consumed
+        if constexpr (BF) {
+            // a_bf[(g * 64 + mi) * 4 + kr] = bf16 x 4 of A[m0 + mi][4 * (4g + i) + kr], i = 0..3
+            v4s *a_bf = reinterpret_cast<v4s *>(a_lds);
+            const int Gq = (Kq + 3) >> 2;
+            for (int t = threadIdx.x; t < Gq * 256; t += WG_WAVES * OGC_WAVE) {
+                const int kr = t & 3, mi = (t >> 2) & 63, g = t >> 8;
+                const int m = m0 + mi;
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int k = 4 * (4 * g + i) + kr;
+                    v[i] = (m < M && k < K) ? (TRANSPOSE_A ? w[(size_t)k * M + m] : w[(size_t)m * K + k]) : 0.f;
+                }
+                a_bf[t] = ogc_pack_bf16(v[0], v[1], v[2], v[3]);
+            }
+        } else {
         // stage A[m0 .. m0+63][0 .. K) as a_lds[(q * 64 + mi) * 4 + kr] = A[m0 + mi][4q + kr]
         for (int t = threadIdx.x; t < Kq * 256; t += WG_WAVES * OGC_WAVE) {
             const int kr = t & 3, mi = (t >> 2) & 63, q = t >> 8;
@@ -252,6 +321,7 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_gemm_kernel(int M,
             if (m < M && k < K) v = TRANSPOSE_A ? w[(size_t)k * M + m] : w[(size_t)m * K + k];
             a_lds[t] = v;
         }
+        }
         __syncthreads();
         const int nblk = min(4, (M - m0 + 15) >> 4); // 16-row blocks of this tile that hold real rows (uniform)
         v4f acc[4][4];
@@ -259,6 +329,25 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_gemm_kernel(int M,
         for (int a = 0; a < 4; ++a)
 #pragma unroll
             for (int c = 0; c < 4; ++c) acc[a][c] = (v4f){0.f, 0.f, 0.f, 0.f};
+        if constexpr (BF) {
+            const v4s *a_bf = reinterpret_cast<const v4s *>(a_lds);
+#pragma unroll
+            for (int g = 0; g < GQ; ++g) {
+                if (4 * g < Kq) {
+                    v4s av[4];
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) av[a] = a_bf[(g * 64 + a * 16 + j) * 4 + kk];
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        if (a < nblk) {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c)
+                                acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av[a], xb[g][c], acc[a][c], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        } else {
 #pragma unroll
         for (int q = 0; q < KQ; ++q) {
             if (q < Kq) {
@@ -275,6 +364,7 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_gemm_kernel(int M,
                     }
                 }
             }
+        }
         }
         if (live) {
 #pragma unroll
@@ -333,9 +423,15 @@ int gemm_launch(int b, int M, int K, int hw, int groups, const float *w, const f
     const int Kq = (K + 3) / 4;
     const size_t lds = (size_t)Kq * 256 * sizeof(float);
     dim3 grid(ogc_divup(hw, 64 * WG_WAVES), b);
-#define OGC_GEMM(KQV)                                                                                              \
-    hipLaunchKernelGGL((conv1x1_gemm_kernel<T, KQV, STATS, PRO>), grid, dim3(WG_WAVES * OGC_WAVE), lds, s, M, K, hw, \
-                       groups, w, in, out, stats, pa, pb, pro_relu)
+#define OGC_GEMM(KQV)                                                                                                  \
+    do {                                                                                                               \
+        if (g_matmul_bf16)                                                                                             \
+            hipLaunchKernelGGL((conv1x1_gemm_kernel<T, KQV, STATS, PRO, true>), grid, dim3(WG_WAVES * OGC_WAVE), lds, s, \
+                               M, K, hw, groups, w, in, out, stats, pa, pb, pro_relu);                                 \
+        else                                                                                                           \
+            hipLaunchKernelGGL((conv1x1_gemm_kernel<T, KQV, STATS, PRO, false>), grid, dim3(WG_WAVES * OGC_WAVE), lds, \
+                               s, M, K, hw, groups, w, in, out, stats, pa, pb, pro_relu);                              \
+    } while (0)
     if (Kq <= 2) OGC_GEMM(2);
     else if (Kq <= 8) OGC_GEMM(8);
     else if (Kq <= 16) OGC_GEMM(16);
@@ -375,6 +471,12 @@ extern "C" int ogc_conv1x1_gemm(int b, int M, int K, int hw, int transpose_a, co
 }
 
 extern "C" int ogc_conv1x1_gn_slots(void) { return GN_SLOTS; }
+
+extern "C" int ogc_set_matmul_precision(int bf16) {
+    const int previous = g_matmul_bf16;
+    g_matmul_bf16 = bf16 ? 1 : 0;
+    return previous;
+}
 
 // Forward convolution that also produces the statistics of the GroupNorm that follows it.
 extern "C" int ogc_conv1x1_gemm_gnstats(int b, int M, int K, int hw, int groups, const float *w, const float *in,

@@ -352,6 +352,14 @@ def group_norm_ws(b, c, groups, backward, device):
     return torch.empty(max(n, 1), dtype=torch.float64, device=device)
 
 
+def set_matmul_precision(mode):
+    """'fp32' (default, exact) or 'bf16' operands for the 1x1-convolution kernels (ogc_set_matmul_precision);
+    returns the previous mode."""
+    if mode not in ("fp32", "bf16"):
+        raise ValueError("matmul precision must be 'fp32' or 'bf16'")
+    return "bf16" if _lib.load().ogc_set_matmul_precision(1 if mode == "bf16" else 0) else "fp32"
+
+
 def conv1x1_gn_slots():
     """Number of accumulator copies conv1x1_gemm_gnstats_wrapper fills (ogc_conv1x1_gn_slots)."""
     return _lib.load().ogc_conv1x1_gn_slots()

@@ -212,6 +212,11 @@ def main(argv=None):
 
     torch.manual_seed(cfg["random_seed"])
     seg = cfg["segnet"]
+    if device.type == "cuda" and cfg.get("matmul_precision", "fp32") != "fp32":
+        # `matmul_precision: bf16` (not a key of the reference's YAMLs): bf16 operands, fp32 accumulation in the 1x1
+        # convolutions — what running the reference under torch.autocast(bfloat16) does to its Conv2d layers
+        from .pointnet2 import pointnet2 as _api
+        _api._native.set_matmul_precision(cfg["matmul_precision"])
     net = build_segnet(cfg).to(device)
     model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[device.index] if device.type == "cuda" else None) \
         if distributed else net
