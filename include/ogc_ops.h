@@ -286,7 +286,9 @@ int ogc_group_norm_maxpool_bwd(int b, int c, int p, int s, int groups, int relu,
  * x, y, grad_y, grad_x (b, c, hw) [maxpool: x (b, c, p, s) -> out, argmax (b, c, p); s a power of two in [4, 256]];
  * gamma, beta, grad_gamma, grad_beta, mean, rstd (c) (mean / rstd written by fwd, read by bwd).
  * stats / slots: optional statistics supplied by the producing kernel (`slots` copies of a (c, 2) f64 accumulator), else
- * NULL / 0 and ws (2c f64) is used.  bwd ws: 3c f64. */
+ * NULL / 0 and ws (2c f64) is used.  bwd ws: 3c f64.
+ * training == 0 with mean == rstd == NULL (inference, nothing kept for a backward pass): the affine map is formed from the
+ * running statistics inside the apply kernel itself — one launch. */
 int ogc_batch_norm_fwd(int b, int c, int hw, float eps, int relu, int training, float momentum, const float *x,
                        const float *gamma, const float *beta, float *running_mean, float *running_var, float *y,
                        float *mean, float *rstd, double *ws, const double *stats, int slots, ogc_stream_t stream);

@@ -104,9 +104,12 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(int c, int hw, con
                                                               const float *__restrict__ gamma,
                                                               const float *__restrict__ beta,
                                                               const float *__restrict__ mean,
-                                                              const float *__restrict__ rstd, float *__restrict__ y) {
+                                                              const float *__restrict__ rstd,
+                                                              const float *__restrict__ var, float eps,
+                                                              float *__restrict__ y) {
     const int b = blockIdx.z, ch = blockIdx.y;
-    const float a = rstd[ch] * gamma[ch];
+    // var != nullptr: evaluation straight from the running statistics (mean = running_mean), no finalize launch
+    const float a = (var ? (float)(1.0 / sqrt((double)var[ch] + (double)eps)) : rstd[ch]) * gamma[ch];
     const float bb = beta[ch] - mean[ch] * a;
     const size_t base = ((size_t)b * c + ch) * hw;
     const float *px = x + base;
@@ -134,9 +137,10 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_maxpool_kernel(int c, int
                                                                       const float *__restrict__ beta,
                                                                       const float *__restrict__ mean,
                                                                       const float *__restrict__ rstd,
+                                                                      const float *__restrict__ var, float eps,
                                                                       float *__restrict__ out, int *__restrict__ arg) {
     const int b = blockIdx.z, ch = blockIdx.y;
-    const float a = rstd[ch] * gamma[ch];
+    const float a = (var ? (float)(1.0 / sqrt((double)var[ch] + (double)eps)) : rstd[ch]) * gamma[ch];
     const float bb = beta[ch] - mean[ch] * a;
     const int L = s >> 2;
     const int rows_per_block = BN_THREADS / L;
@@ -360,17 +364,29 @@ extern "C" int ogc_batch_norm_fwd(int b, int c, int hw, float eps, int relu, int
                                   const double *stats, int slots, ogc_stream_t stream) {
     OGC_REQUIRE(b >= 0 && c >= 1 && hw >= 1, "ogc_batch_norm_fwd: bad shape");
     if (b == 0) return OGC_OK;
-    OGC_REQUIRE(x && gamma && beta && y && mean && rstd, "ogc_batch_norm_fwd: null pointer");
+    // evaluation without mean / rstd outputs (nothing will be back-propagated): the affine map is formed from the running
+    // statistics inside the apply kernel — one launch
+    const bool inline_eval = !training && !mean && !rstd;
+    OGC_REQUIRE(x && gamma && beta && y && (inline_eval || (mean && rstd)), "ogc_batch_norm_fwd: null pointer");
     OGC_REQUIRE((long long)c * hw < (1ll << 31) && b <= 65535, "ogc_batch_norm_fwd: one sample exceeds 32-bit indexing");
     hipStream_t s = (hipStream_t)stream;
-    const int rc = bn_prepare("ogc_batch_norm_fwd", b, c, hw, eps, training, momentum, x, running_mean, running_var,
-                              mean, rstd, ws, stats, slots, s);
-    if (rc != OGC_OK) return rc;
+    const float *var = nullptr;
+    if (inline_eval) {
+        OGC_REQUIRE(running_mean && running_var, "ogc_batch_norm_fwd: evaluation mode needs running statistics");
+        mean = running_mean;
+        var = running_var;
+    } else {
+        const int rc = bn_prepare("ogc_batch_norm_fwd", b, c, hw, eps, training, momentum, x, running_mean, running_var,
+                                  mean, rstd, ws, stats, slots, s);
+        if (rc != OGC_OK) return rc;
+    }
     dim3 grid(bn_chunks(b, c, hw), c, b);
     if (relu)
-        hipLaunchKernelGGL(bn_apply_kernel<true>, grid, dim3(BN_THREADS), 0, s, c, hw, x, gamma, beta, mean, rstd, y);
+        hipLaunchKernelGGL(bn_apply_kernel<true>, grid, dim3(BN_THREADS), 0, s, c, hw, x, gamma, beta, mean, rstd, var, eps,
+                           y);
     else
-        hipLaunchKernelGGL(bn_apply_kernel<false>, grid, dim3(BN_THREADS), 0, s, c, hw, x, gamma, beta, mean, rstd, y);
+        hipLaunchKernelGGL(bn_apply_kernel<false>, grid, dim3(BN_THREADS), 0, s, c, hw, x, gamma, beta, mean, rstd, var,
+                           eps, y);
     OGC_CHECK_LAUNCH("ogc_batch_norm_fwd");
     return OGC_OK;
 }
@@ -419,23 +435,32 @@ extern "C" int ogc_batch_norm_maxpool_fwd(int b, int c, int p, int s, float eps,
         return OGC_ERR_UNSUPPORTED;
     }
     if (b == 0) return OGC_OK;
-    OGC_REQUIRE(x && gamma && beta && out && argmax && mean && rstd, "ogc_batch_norm_maxpool_fwd: null pointer");
+    const bool inline_eval = !training && !mean && !rstd; // as in ogc_batch_norm_fwd
+    OGC_REQUIRE(x && gamma && beta && out && argmax && (inline_eval || (mean && rstd)),
+                "ogc_batch_norm_maxpool_fwd: null pointer");
     OGC_REQUIRE((long long)c * p * s < (1ll << 31) && b <= 65535,
                 "ogc_batch_norm_maxpool_fwd: one sample exceeds 32-bit indexing");
     hipStream_t st = (hipStream_t)stream;
-    const int rc = bn_prepare("ogc_batch_norm_maxpool_fwd", b, c, p * s, eps, training, momentum, x, running_mean,
-                              running_var, mean, rstd, ws, stats, slots, st);
-    if (rc != OGC_OK) return rc;
+    const float *var = nullptr;
+    if (inline_eval) {
+        OGC_REQUIRE(running_mean && running_var, "ogc_batch_norm_maxpool_fwd: evaluation mode needs running statistics");
+        mean = running_mean;
+        var = running_var;
+    } else {
+        const int rc = bn_prepare("ogc_batch_norm_maxpool_fwd", b, c, p * s, eps, training, momentum, x, running_mean,
+                                  running_var, mean, rstd, ws, stats, slots, st);
+        if (rc != OGC_OK) return rc;
+    }
     const int rows_per_block = BN_THREADS / (s / 4);
     int bx = ogc_divup(p, rows_per_block);
     while (bx > 1 && (long long)bx * c * b > 8192) bx = (bx + 1) / 2;
     dim3 grid(bx, c, b);
     if (relu)
         hipLaunchKernelGGL(bn_apply_maxpool_kernel<true>, grid, dim3(BN_THREADS), 0, st, c, p, s, x, gamma, beta, mean,
-                           rstd, out, argmax);
+                           rstd, var, eps, out, argmax);
     else
         hipLaunchKernelGGL(bn_apply_maxpool_kernel<false>, grid, dim3(BN_THREADS), 0, st, c, p, s, x, gamma, beta, mean,
-                           rstd, out, argmax);
+                           rstd, var, eps, out, argmax);
     OGC_CHECK_LAUNCH("ogc_batch_norm_maxpool_fwd");
     return OGC_OK;
 }

@@ -257,13 +257,16 @@ class _BatchNormAct(Function):
         B, C = x.shape[0], x.shape[1]
         hw = x.numel() // max(B * C, 1)
         y = torch.empty_like(x)
-        mean = torch.empty(C, dtype=torch.float32, device=x.device)
-        rstd = torch.empty_like(mean)
+        # inference: nothing to save for a backward pass -> the kernel reads the running statistics itself (one launch)
+        lean = not training and not any(ctx.needs_input_grad[:3])
+        mean = None if lean else torch.empty(C, dtype=torch.float32, device=x.device)
+        rstd = None if lean else torch.empty_like(mean)
         ws = None if (stats is not None or not training) else torch.empty(2 * C, dtype=torch.float64, device=x.device)
         nat.batch_norm_fwd_wrapper(B, C, hw, eps, relu, training, momentum, x, weight.detach().contiguous(),
                                    bias.detach().contiguous(), running_mean, running_var, y, mean, rstd, ws, stats,
                                    0 if stats is None else stats.numel() // (2 * C))
-        ctx.save_for_backward(x, weight, bias, mean, rstd)
+        if not lean:
+            ctx.save_for_backward(x, weight, bias, mean, rstd)
         ctx.cfg = (relu, training, hw)
         return y
 
@@ -293,13 +296,15 @@ class _BatchNormActMaxPool(Function):
         B, C, P, S = x.shape
         out = torch.empty(B, C, P, dtype=torch.float32, device=x.device)
         arg = torch.empty(B, C, P, dtype=torch.int32, device=x.device)
-        mean = torch.empty(C, dtype=torch.float32, device=x.device)
-        rstd = torch.empty_like(mean)
+        lean = not training and not any(ctx.needs_input_grad[:3])
+        mean = None if lean else torch.empty(C, dtype=torch.float32, device=x.device)
+        rstd = None if lean else torch.empty_like(mean)
         ws = None if (stats is not None or not training) else torch.empty(2 * C, dtype=torch.float64, device=x.device)
         nat.batch_norm_maxpool_fwd_wrapper(B, C, P, S, eps, relu, training, momentum, x, weight.detach().contiguous(),
                                            bias.detach().contiguous(), running_mean, running_var, out, arg, mean, rstd,
                                            ws, stats, 0 if stats is None else stats.numel() // (2 * C))
-        ctx.save_for_backward(x, weight, mean, rstd, out, arg)
+        if not lean:
+            ctx.save_for_backward(x, weight, mean, rstd, out, arg)
         ctx.cfg = (relu, training)
         return out
 
@@ -329,7 +334,10 @@ def _bn_call(fn, x, bn, relu, stats):
     rm, rv = _bn_buffers(bn)
     if training and bn.track_running_stats:
         bn.num_batches_tracked.add_(1)
-    return fn.apply(x, bn.weight, bn.bias, rm, rv, training, float(bn.momentum), bn.eps, relu, stats)
+    w, b_ = bn.weight, bn.bias
+    if not training and not (torch.is_grad_enabled() and (x.requires_grad or w.requires_grad or b_.requires_grad)):
+        x, w, b_ = x.detach(), w.detach(), b_.detach()  # inference: the Functions then keep nothing for a backward pass
+    return fn.apply(x, w, b_, rm, rv, training, float(bn.momentum), bn.eps, relu, stats)
 
 
 def conv_norm_act(x, conv, norm, relu=True, maxpool=False):

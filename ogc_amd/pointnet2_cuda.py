@@ -268,8 +268,8 @@ def batch_norm_fwd_wrapper(b, c, hw, eps, relu, training, momentum, x, gamma, be
     """Fused BatchNorm(+ReLU) forward (ogc_batch_norm_fwd); running statistics updated in place when training."""
     _run("ogc_batch_norm_fwd", x, b, c, hw, float(eps), int(relu), int(training), float(momentum), _f(x, "x"),
          _f(gamma, "gamma"), _f(beta, "beta"), _opt(running_mean, torch.float32, "running_mean"),
-         _opt(running_var, torch.float32, "running_var"), _f(y, "y"), _f(mean, "mean"), _f(rstd, "rstd"),
-         _opt(ws, torch.float64, "ws"), _opt(stats, torch.float64, "stats"), int(slots))
+         _opt(running_var, torch.float32, "running_var"), _f(y, "y"), _opt(mean, torch.float32, "mean"),
+         _opt(rstd, torch.float32, "rstd"), _opt(ws, torch.float64, "ws"), _opt(stats, torch.float64, "stats"), int(slots))
 
 
 def batch_norm_bwd_wrapper(b, c, hw, relu, training, x, gamma, beta, mean, rstd, grad_y, grad_x, grad_gamma, grad_beta,
@@ -283,8 +283,9 @@ def batch_norm_maxpool_fwd_wrapper(b, c, p, s, eps, relu, training, momentum, x,
                                    out, argmax, mean, rstd, ws, stats, slots):
     _run("ogc_batch_norm_maxpool_fwd", x, b, c, p, s, float(eps), int(relu), int(training), float(momentum), _f(x, "x"),
          _f(gamma, "gamma"), _f(beta, "beta"), _opt(running_mean, torch.float32, "running_mean"),
-         _opt(running_var, torch.float32, "running_var"), _f(out, "out"), _i(argmax, "argmax"), _f(mean, "mean"),
-         _f(rstd, "rstd"), _opt(ws, torch.float64, "ws"), _opt(stats, torch.float64, "stats"), int(slots))
+         _opt(running_var, torch.float32, "running_var"), _f(out, "out"), _i(argmax, "argmax"),
+         _opt(mean, torch.float32, "mean"), _opt(rstd, torch.float32, "rstd"), _opt(ws, torch.float64, "ws"),
+         _opt(stats, torch.float64, "stats"), int(slots))
 
 
 def batch_norm_maxpool_bwd_wrapper(b, c, p, s, relu, training, x, gamma, mean, rstd, out, argmax, grad_out, grad_x,
