@@ -114,6 +114,13 @@ def _gemm_ok(K, hw):
     return hw % 64 == 0 and K <= 160
 
 
+# Below this many positions (B * hw) a 1x1 convolution goes to the vendor library: the MFMA kernel gives a wavefront 64
+# positions x all output rows, so a 128 -> 128 layer costs ~28 us however few positions there are (2048 positions: 8
+# workgroups on 256 CUs), where rocBLAS / MIOpen split the output rows as well and need 3-8 us (tools/small_conv.py).
+# FlowStep3D at B = 1 runs ~65 such layers per forward pass.
+_SMALL_CONV_POSITIONS = 49152
+
+
 class _PointwiseConv(Function):
     """y = conv(x, w) for a bias-free 1x1 convolution on NCHW fp32 tensors, on the hand-written fp32-MFMA kernels:
     ogc_conv1x1_gemm for the forward and the input gradient (when the shape fits its register tile; the vendor library
@@ -130,7 +137,8 @@ class _PointwiseConv(Function):
         cout = weight.shape[0]
         hw = x.numel() // (B * cin)
         stats = None
-        if _gemm_ok(cin, hw):
+        ctx.small = gn_groups == 0 and B * hw < _SMALL_CONV_POSITIONS
+        if _gemm_ok(cin, hw) and not ctx.small:
             y = torch.empty((B, cout) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
             if (gn_groups > 0 and gn_groups <= 32 and cout % gn_groups == 0 and (cout // gn_groups) % 4 == 0
                     and cin <= 100  # wider input tiles leave the kernel no registers for the statistics epilogue
@@ -158,6 +166,11 @@ class _PointwiseConv(Function):
         cout = weight.shape[0]
         hw = x.numel() // (B * cin)
         grad_x = grad_w = None
+        if ctx.small:
+            grad_x, grad_w, _ = torch.ops.aten.convolution_backward(
+                grad_y, x, weight, None, [1] * nd, [0] * nd, [1] * nd, False, [0] * nd, 1,
+                [bool(ctx.needs_input_grad[0]), bool(ctx.needs_input_grad[1]), False])
+            return grad_x, grad_w, None
         if ctx.needs_input_grad[0]:
             if _gemm_ok(cout, hw):
                 grad_x = torch.empty_like(x)
