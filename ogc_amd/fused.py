@@ -114,6 +114,14 @@ def _gemm_ok(K, hw):
     return hw % 64 == 0 and K <= 160
 
 
+def _plain_gemm_mine(K):
+    """A PLAIN product (no folded normalisation on the way in, no statistics on the way out) of reduction length K:
+    the MFMA kernel wins up to 32 channels; from 64 up rocBLAS is 15-35 % faster at every C4 layer shape
+    (tools/dgrad_compare.py: 128 -> 128 input gradient 0.246 vs 0.173 ms), so those go through torch.matmul, unless bf16
+    operands were asked for (which only this repo's kernels provide)."""
+    return K <= 32 or _api._native.get_matmul_precision() != "fp32"
+
+
 # Below this many positions (B * hw) a 1x1 convolution goes to the vendor library: the MFMA kernel gives a wavefront 64
 # positions x all output rows, so a 128 -> 128 layer costs ~28 us however few positions there are (2048 positions: 8
 # workgroups on 256 CUs), where rocBLAS / MIOpen split the output rows as well and need 3-8 us (tools/small_conv.py).
@@ -145,8 +153,10 @@ class _PointwiseConv(Function):
                     and getattr(nat, "conv1x1_gemm_gnstats_wrapper", None) is not None):
                 stats = torch.empty(nat.conv1x1_gn_slots() * B * gn_groups * 2, dtype=torch.float64, device=x.device)
                 nat.conv1x1_gemm_gnstats_wrapper(B, cout, cin, hw, gn_groups, weight.detach().contiguous(), x, y, stats)
-            else:
+            elif _plain_gemm_mine(cin):
                 nat.conv1x1_gemm_wrapper(B, cout, cin, hw, 0, weight.detach().contiguous(), x, y)
+            else:
+                torch.matmul(weight.detach().view(cout, cin), x.reshape(B, cin, hw), out=y.view(B, cout, hw))
         else:
             y = F.conv2d(x, weight) if x.dim() == 4 else F.conv1d(x, weight)
         if gn_groups > 0:
@@ -172,15 +182,22 @@ class _PointwiseConv(Function):
                 [bool(ctx.needs_input_grad[0]), bool(ctx.needs_input_grad[1]), False])
             return grad_x, grad_w, None
         if ctx.needs_input_grad[0]:
-            if _gemm_ok(cout, hw):
+            if _gemm_ok(cout, hw) and _plain_gemm_mine(cout):
                 grad_x = torch.empty_like(x)
                 _api._native.conv1x1_gemm_wrapper(B, cin, cout, hw, 1, weight.detach().contiguous(), grad_y, grad_x)
+            elif _gemm_ok(cout, hw):
+                grad_x = torch.matmul(weight.detach().view(cout, cin).t(), grad_y.reshape(B, cout, hw)).view_as(x)
             else:
                 grad_x = torch.ops.aten.convolution_backward(grad_y, x, weight, None, [1] * nd, [0] * nd, [1] * nd,
                                                              False, [0] * nd, 1, [True, False, False])[0]
         if ctx.needs_input_grad[1]:
-            grad_w = torch.empty(cout, cin, dtype=torch.float32, device=x.device)
-            _api._native.conv1x1_wgrad_wrapper(B, cin, cout, hw, x, grad_y, grad_w)
+            if B * hw <= 262144 and _api._native.get_matmul_precision() == "fp32":
+                # few positions (feature-propagation layers): one batched rocBLAS product per sample and a sum beat
+                # the streaming kernel, whose waves need long position ranges (tools/wgrad_compare.py: 2-3x)
+                grad_w = torch.bmm(grad_y.reshape(B, cout, hw), x.reshape(B, cin, hw).transpose(1, 2)).sum(0)
+            else:
+                grad_w = torch.empty(cout, cin, dtype=torch.float32, device=x.device)
+                _api._native.conv1x1_wgrad_wrapper(B, cin, cout, hw, x, grad_y, grad_w)
             grad_w = grad_w.view_as(weight)
         return grad_x, grad_w, None
 
@@ -525,7 +542,7 @@ class _NormActConv(Function):
         grad_w = torch.empty(cout, cin, dtype=torch.float32, device=y_prev.device)
         nat.conv1x1_wgrad_affine_wrapper(B, cin, cout, hw, relu, y_prev, a, bb, grad_y, grad_w)
         # gradient w.r.t. the (never stored) normalised activation, then through GroupNorm (+ ReLU)
-        if _gemm_ok(cout, hw):
+        if _gemm_ok(cout, hw) and _plain_gemm_mine(cout):
             grad_z = torch.empty_like(y_prev)
             nat.conv1x1_gemm_wrapper(B, cin, cout, hw, 1, w, grad_y, grad_z)
         else:

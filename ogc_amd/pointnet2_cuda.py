@@ -353,12 +353,22 @@ def group_norm_ws(b, c, groups, backward, device):
     return torch.empty(max(n, 1), dtype=torch.float64, device=device)
 
 
+_precision = "fp32"
+
+
 def set_matmul_precision(mode):
     """'fp32' (default, exact) or 'bf16' operands for the 1x1-convolution kernels (ogc_set_matmul_precision);
     returns the previous mode."""
+    global _precision
     if mode not in ("fp32", "bf16"):
         raise ValueError("matmul precision must be 'fp32' or 'bf16'")
-    return "bf16" if _lib.load().ogc_set_matmul_precision(1 if mode == "bf16" else 0) else "fp32"
+    previous = "bf16" if _lib.load().ogc_set_matmul_precision(1 if mode == "bf16" else 0) else "fp32"
+    _precision = mode
+    return previous
+
+
+def get_matmul_precision():
+    return _precision
 
 
 def conv1x1_gn_slots():
