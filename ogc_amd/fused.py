@@ -191,9 +191,10 @@ class _PointwiseConv(Function):
                 grad_x = torch.ops.aten.convolution_backward(grad_y, x, weight, None, [1] * nd, [0] * nd, [1] * nd,
                                                              False, [0] * nd, 1, [True, False, False])[0]
         if ctx.needs_input_grad[1]:
-            if B * hw <= 262144 and _api._native.get_matmul_precision() == "fp32":
-                # few positions (feature-propagation layers): one batched rocBLAS product per sample and a sum beat
-                # the streaming kernel, whose waves need long position ranges (tools/wgrad_compare.py: 2-3x)
+            if hw <= 16384 and _api._native.get_matmul_precision() == "fp32":
+                # few positions per sample (feature-propagation layers): one batched rocBLAS product per sample and a
+                # sum beat the streaming kernel, whose waves need long position ranges (tools/wgrad_compare.py: 2-3x at
+                # hw <= 16384; beyond that the streaming kernel wins — FlowStep3D's hw = 32768 layers lose 7 % here)
                 grad_w = torch.bmm(grad_y.reshape(B, cout, hw), x.reshape(B, cin, hw).transpose(1, 2)).sum(0)
             else:
                 grad_w = torch.empty(cout, cin, dtype=torch.float32, device=x.device)
