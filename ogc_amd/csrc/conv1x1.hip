@@ -182,7 +182,11 @@ void wgrad_launch(int b, int cin, int cout, int hw, const float *x, const float 
     const long long nsteps = (long long)b * (hw >> 4);
     const int tiles = ogc_divup(cout, 16 * COB) * ogc_divup(cin, 16 * CIB);
     // ~2048 waves over the chip per tile pair, but at least 8 steps (128 positions) per wave
-    long long waves = 2048 / tiles;
+    // Wavefronts over the chip per tile pair.  The 64x64 tiles (COB = CIB = 4) run best with ~1024 wavefronts in total —
+    // one workgroup per CU, twice the positions per wavefront, half as many LDS reductions and atomic epilogues
+    // (64 -> 64: 0.169 -> 0.150 ms, 128 -> 128: 0.258 -> 0.222 ms) — unless the tile grid is ragged (131 -> 128: six
+    // tiles, two of them nearly empty), where the finer split balances better; the small tiles keep ~2048.
+    long long waves = ((COB * CIB == 16 && tiles <= 4) ? 1024 : 2048) / tiles;
     if (waves < 256) waves = 256;
     long long spw = (nsteps + waves - 1) / waves;
     if (spw < 8) spw = 8;
