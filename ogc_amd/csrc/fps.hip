@@ -59,6 +59,17 @@ __device__ __forceinline__ float fps_wave_max(float v) {
     return __int_as_float(max(max(r0, r1), max(r2, r3)));
 }
 
+// (p - q)^2 summed over the axes for two points at once; per half: ((dx*dx + dy*dy) + dz*dz), one rounding per operation
+// (sampling_gpu.cu:133), never contracted.
+__device__ __forceinline__ ogc_v2f fps_sqdist2(ogc_v2f px, ogc_v2f py, ogc_v2f pz, ogc_v2f qx, ogc_v2f qy, ogc_v2f qz) {
+#pragma clang fp contract(off)
+    ogc_v2f dx = px - qx, dy = py - qy, dz = pz - qz;
+    dx = dx * dx;
+    dy = dy * dy;
+    dz = dz * dz;
+    return (dx + dy) + dz;
+}
+
 template <int PTS, int THREADS, bool LDS_XYZ>
 __global__ __launch_bounds__(THREADS) void fps_reg_kernel(int n, int m, int bs_shift,
                                                           const float *__restrict__ xyz,
@@ -110,11 +121,26 @@ __global__ __launch_bounds__(THREADS) void fps_reg_kernel(int n, int m, int bs_s
     for (int r = 1; r < m; ++r) {
         const int par = r & 1;
         float tmax = -1.0f;
+        if constexpr (PTS >= 2) {
+            // two of the lane's points per packed instruction (v_pk_add / v_pk_mul_f32): each half is the reference's
+            // fp32 expression, un-fused, so the eight scalar operations per point become four
+            const ogc_v2f qx = {x1, x1}, qy = {y1, y1}, qz = {z1, z1};
 #pragma unroll
-        for (int j = 0; j < PTS; ++j) {
-            const float d = ogc_sqdist(px[j], py[j], pz[j], x1, y1, z1);
-            td[j] = ogc_min_f32(d, td[j]);
-            tmax = fmaxf(tmax, td[j]);
+            for (int j = 0; j < PTS; j += 2) {
+                const ogc_v2f d = fps_sqdist2((ogc_v2f){px[j], px[j + 1]}, (ogc_v2f){py[j], py[j + 1]},
+                                              (ogc_v2f){pz[j], pz[j + 1]}, qx, qy, qz);
+                td[j] = ogc_min_f32(d.x, td[j]);
+                td[j + 1] = ogc_min_f32(d.y, td[j + 1]);
+                tmax = fmaxf(tmax, td[j]);
+                tmax = fmaxf(tmax, td[j + 1]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < PTS; ++j) {
+                const float d = ogc_sqdist(px[j], py[j], pz[j], x1, y1, z1);
+                td[j] = ogc_min_f32(d, td[j]);
+                tmax = fmaxf(tmax, td[j]);
+            }
         }
         // lane-local "first register holding the lane maximum": independent of the wave reduction below, so the two
         // dependency chains overlap
