@@ -118,7 +118,8 @@ def main():
     for _ in range(a.warmup):
         pre = train_step(model, crit, opt, batch, it, True, sync=False, prefetched=pre, next_batch=batch).prefetched
     sync()
-    with nat.LaunchTimer({"ogc_ball_query", "ogc_knn_clamped", "ogc_furthest_point_sampling"}) as timer:
+    with nat.LaunchTimer({"ogc_ball_query", "ogc_knn_clamped", "ogc_furthest_point_sampling",
+                          "ogc_furthest_point_sampling_chain"}) as timer:
         t0 = time.perf_counter()
         mark = bool(os.environ.get("OGC_BENCH_MARK"))  # profiling aid: a marker kernel per step (tools/prof_summary.py)
         for _ in range(a.steps):
@@ -184,7 +185,7 @@ def main():
                                            "frac": round(12.84e6 / 29.4e-6 / (256 * 4 * 2.4e9 / 4), 3),
                                            "shape": "B=16, N=M=8192, nsample=64"}}
         others = {}
-        for name in ("ogc_knn_clamped", "ogc_furthest_point_sampling"):
+        for name in ("ogc_knn_clamped", "ogc_furthest_point_sampling", "ogc_furthest_point_sampling_chain"):
             if name in durs:
                 per = {}
                 for d, dims in durs[name]:

@@ -53,6 +53,21 @@ const char *ogc_last_error(void);
 int ogc_furthest_point_sampling(int b, int n, int m, const float *xyz, float *temp,
                                 int *idx, ogc_stream_t stream);
 
+/* Furthest point sampling along a CHAIN of levels (utils/pointnet2_util.py:22-27 and utils/flowstep3d_util.py:112-118
+ * sample level l+1 from the centres of level l, which are stored in sampling order).
+ * ties_out (b) i32, optional: the first round of this run in which more than one point attained the maximum (exact
+ * fp32 ties: duplicated points, lattices, and — late in a run that keeps a large share of the cloud — chance
+ * coincidences), INT_MAX if there was none.
+ * ties_in (b) i32, optional: ties_out of the run that PRODUCED this cloud (xyz = its first n samples, in sampling
+ * order).  Where ties_in[i] >= m the result is known without sampling: every one of the parent's first m rounds picked
+ * the unique farthest point from its earlier samples in the whole cloud, so inside the subset sample r is still the
+ * unique farthest point from samples 0..r-1 — the answer is 0, 1, ..., m-1 (written directly; temp is left untouched
+ * and ties_out[i] = ties_in[i], so the chain can go on).  Otherwise the rounds are run as usual, so the result is in
+ * every case the one ogc_furthest_point_sampling returns.  Clouds of more than 16384 points are always sampled and
+ * report ties_out = 0 (nothing known). */
+int ogc_furthest_point_sampling_chain(int b, int n, int m, const float *xyz, float *temp, int *idx,
+                                      const int *ties_in, int *ties_out, ogc_stream_t stream);
+
 /* ---- gather -------------------------------------------------------------------------
  * replaces gather_points_wrapper(b, c, n, npoints, points, idx, out)
  *   sampling.cpp:11-21 -> sampling_gpu.cu:8-43

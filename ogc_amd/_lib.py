@@ -16,6 +16,7 @@ _flt = ctypes.c_float
 # name -> argtypes (stream is always the trailing void*)
 SIGNATURES = {
     "ogc_furthest_point_sampling": [_int, _int, _int, _vp, _vp, _vp, _vp],
+    "ogc_furthest_point_sampling_chain": [_int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp],
     "ogc_gather_points": [_int, _int, _int, _int, _vp, _vp, _vp, _vp],
     "ogc_gather_points_grad": [_int, _int, _int, _int, _vp, _vp, _vp, _vp],
     "ogc_knn": [_int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp],

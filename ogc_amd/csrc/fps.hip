@@ -73,11 +73,12 @@ __device__ __forceinline__ ogc_v2f fps_sqdist2(ogc_v2f px, ogc_v2f py, ogc_v2f p
 template <int PTS, int THREADS, bool LDS_XYZ>
 __global__ __launch_bounds__(THREADS) void fps_reg_kernel(int n, int m, int bs_shift,
                                                           const float *__restrict__ xyz,
-                                                          float *__restrict__ temp, int *__restrict__ idxs) {
+                                                          float *__restrict__ temp, int *__restrict__ idxs,
+                                                          const int *__restrict__ ties_in, int *__restrict__ ties_out) {
     extern __shared__ __attribute__((aligned(16))) float fps_smem[];
     // [0..1]: two 64-bit "best of the round" words (double-buffered); then the SoA xyz copy in rank order
     u64 *best_word = reinterpret_cast<u64 *>(fps_smem);
-    float *lx = fps_smem + 4;
+    float *lx = fps_smem + 8;
     const int slots = PTS * THREADS;
     float *ly = lx + slots, *lz = ly + slots;
 
@@ -89,6 +90,20 @@ __global__ __launch_bounds__(THREADS) void fps_reg_kernel(int n, int m, int bs_s
     int *out = idxs + (size_t)b * m;
     const int S = (n + (1 << bs_shift) - 1) >> bs_shift;
     const int nslot = S << bs_shift; // rank slots in use (>= n)
+
+    // This cloud is the first n samples, in sampling order, of a run whose first m rounds each had a UNIQUE farthest
+    // point: sampling it again reproduces that order — round r picks the point that was farthest from the first r
+    // samples in the whole cloud, which is sample r itself, and it is still the only maximum — so the answer is
+    // 0, 1, ..., m-1 without a single round (see ogc_furthest_point_sampling_chain).
+    // L: how many leading samples are known without sampling (the parent run's tie-free rounds)
+    const int L = ties_in ? max(1, min(ties_in[b], m)) : 1;
+    if (L >= m) {
+        for (int r = threadIdx.x; r < m; r += THREADS) out[r] = r;
+        if (threadIdx.x == 0 && ties_out) ties_out[b] = ties_in[b];
+        return;
+    }
+    const bool track = ties_out != nullptr;
+    int first_tie = 0x7fffffff;
 
     float px[PTS], py[PTS], pz[PTS], td[PTS];
 #pragma unroll
@@ -115,11 +130,51 @@ __global__ __launch_bounds__(THREADS) void fps_reg_kernel(int n, int m, int bs_s
         best_word[0] = 0ull;
         best_word[1] = 0ull;
     }
-    float x1 = dataset[0], y1 = dataset[1], z1 = dataset[2];
+    // Samples 0 .. L-1 are points 0 .. L-1 (the known prefix): fold samples 0 .. L-2 into the running minima — the same
+    // arithmetic as L-2 rounds, but with no maximum to find there is nothing sequential about it — and enter the rounds
+    // at r = L with sample L-1 as the point just selected.
+    for (int s0 = 0; s0 < L - 1; s0 += 8) { // eight samples' coordinates in flight at a time (wave-uniform loads)
+        float sc[8][3];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int sidx = min(s0 + u, L - 2); // the tail repeats the last sample: taking a minimum twice is harmless
+            sc[u][0] = dataset[sidx * 3 + 0]; sc[u][1] = dataset[sidx * 3 + 1]; sc[u][2] = dataset[sidx * 3 + 2];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int j = 0; j < PTS; ++j)
+                td[j] = ogc_min_f32(ogc_sqdist(px[j], py[j], pz[j], sc[u][0], sc[u][1], sc[u][2]), td[j]);
+    }
+    for (int r = 1 + t; r < L; r += THREADS) out[r] = r; // final indices already (not ranks): skipped by the conversion
+    float x1 = dataset[(L - 1) * 3], y1 = dataset[(L - 1) * 3 + 1], z1 = dataset[(L - 1) * 3 + 2];
     __syncthreads();
 
-    for (int r = 1; r < m; ++r) {
+    unsigned prev_bits = 0u, prev_rho = 0u; // maximum (bit pattern) and winner of the previous round
+    float tmax_prev = -1.0f;                // this lane's maximum in the previous round
+    auto note_ties = [&](int round) {
+        // Did another point attain the previous round's maximum?  Only lanes whose own maximum equals it can hold one:
+        // one compare and a ballot per round for every wavefront but the winner's; a lane that holds the value without
+        // owning the winning rank slot is a tie, the owner looks for a second register with it.
+        const float pm = __uint_as_float(prev_bits);
+        const bool cand = tmax_prev == pm;
+        if (__builtin_amdgcn_ballot_w64(cand) != 0) { // wave-uniform
+            bool tie = false;
+            if (cand) {
+                if (prev_rho % THREADS != (unsigned)t) tie = true;
+                else {
+                    int c = 0;
+#pragma unroll
+                    for (int j = 0; j < PTS; ++j) c += td[j] == pm ? 1 : 0;
+                    tie = c > 1;
+                }
+            }
+            if (tie && first_tie > round) first_tie = round;
+        }
+    };
+    for (int r = L; r < m; ++r) {
         const int par = r & 1;
+        if (track && r > L) note_ties(r - 1);
         float tmax = -1.0f;
         if constexpr (PTS >= 2) {
             // two of the lane's points per packed instruction (v_pk_add / v_pk_mul_f32): each half is the reference's
@@ -155,6 +210,9 @@ __global__ __launch_bounds__(THREADS) void fps_reg_kernel(int n, int m, int bs_s
         if (t == 0) best_word[par ^ 1] = 0ull;
         __syncthreads();
         const unsigned brho = 0xFFFFFFFFu - (unsigned)best_word[par];
+        prev_bits = (unsigned)(best_word[par] >> 32);
+        prev_rho = brho;
+        tmax_prev = tmax;
         if (LDS_XYZ) {
             x1 = lx[brho]; y1 = ly[brho]; z1 = lz[brho];
         } else {
@@ -171,7 +229,17 @@ __global__ __launch_bounds__(THREADS) void fps_reg_kernel(int n, int m, int bs_s
     }
     // ranks -> point indices (kept off the per-round critical path: the division is ~20 dependent instructions)
     __syncthreads();
-    for (int r = 1 + t; r < m; r += THREADS) out[r] = fps_rank_to_k((unsigned)out[r], S, bs_shift);
+    for (int r = L + t; r < m; r += THREADS) out[r] = fps_rank_to_k((unsigned)out[r], S, bs_shift);
+    if (track) { // smallest round over all lanes (rounds are < 2^31, so the bit patterns order as unsigned)
+        note_ties(m - 1); // L < m: at least one round was run
+        const unsigned w = ogc_wave_min_u32((unsigned)first_tie);
+        __syncthreads();
+        if (t == 0) best_word[0] = ~0ull;
+        __syncthreads();
+        if (lane == 0) atomicMin(&best_word[0], (u64)w);
+        __syncthreads();
+        if (t == 0) ties_out[b] = (int)(unsigned)best_word[0];
+    }
 }
 
 __device__ __forceinline__ unsigned fps_rank(int k, int bs_mask, int bs_shift, int S) {
@@ -338,10 +406,11 @@ int fps_ref_block_shift(int work_size) {
 }
 
 template <int PTS, int THREADS>
-void fps_launch(int b, int n, int m, int shift, const float *xyz, float *temp, int *idx, hipStream_t stream) {
+void fps_launch(int b, int n, int m, int shift, const float *xyz, float *temp, int *idx, const int *ties_in,
+                int *ties_out, hipStream_t stream) {
     constexpr int slots = PTS * THREADS;
     constexpr bool lds_xyz = slots <= FPS_LDS_XYZ_MAX;
-    constexpr size_t lds = 4 * sizeof(float) + (lds_xyz ? 3 * slots * sizeof(float) : 0);
+    constexpr size_t lds = 8 * sizeof(float) + (lds_xyz ? 3 * slots * sizeof(float) : 0);
     auto kern = fps_reg_kernel<PTS, THREADS, lds_xyz>;
     if (lds > 64 * 1024) {
         static bool once = false; // raise the dynamic-LDS cap once per process for this instantiation
@@ -351,41 +420,46 @@ void fps_launch(int b, int n, int m, int shift, const float *xyz, float *temp, i
             once = true;
         }
     }
-    hipLaunchKernelGGL(kern, dim3(b), dim3(THREADS), lds, stream, n, m, shift, xyz, temp, idx);
+    hipLaunchKernelGGL(kern, dim3(b), dim3(THREADS), lds, stream, n, m, shift, xyz, temp, idx, ties_in, ties_out);
 }
 
 } // namespace
 
-extern "C" int ogc_furthest_point_sampling(int b, int n, int m, const float *xyz, float *temp, int *idx,
-                                           ogc_stream_t stream) {
-    OGC_REQUIRE(b >= 0 && n >= 0 && m >= 0, "ogc_furthest_point_sampling: negative dimension");
+static int fps_impl(const char *name, int b, int n, int m, const float *xyz, float *temp, int *idx, const int *ties_in,
+                    int *ties_out, ogc_stream_t stream) {
+    OGC_REQUIRE(b >= 0 && n >= 0 && m >= 0, "%s: negative dimension", name);
     if (b == 0 || m <= 0) return OGC_OK; // sampling_gpu.cu:98
-    OGC_REQUIRE(n >= 1, "ogc_furthest_point_sampling: n must be >= 1 when m > 0");
-    OGC_REQUIRE(xyz && temp && idx, "ogc_furthest_point_sampling: null pointer");
-    OGC_REQUIRE((long long)b * n * 3 < (1ll << 31), "ogc_furthest_point_sampling: xyz exceeds 32-bit indexing");
+    OGC_REQUIRE(n >= 1, "%s: n must be >= 1 when m > 0", name);
+    OGC_REQUIRE(xyz && temp && idx, "%s: null pointer", name);
+    OGC_REQUIRE((long long)b * n * 3 < (1ll << 31), "%s: xyz exceeds 32-bit indexing", name);
     const int shift = fps_ref_block_shift(n);
     const int bs = 1 << shift;
     const int slots = ((n + bs - 1) / bs) * bs; // rank slots = bs * ceil(n / bs)
     hipStream_t s = (hipStream_t)stream;
     static const int force_threads = getenv("OGC_FPS_THREADS") ? atoi(getenv("OGC_FPS_THREADS")) : 0; // dev knob
     if (force_threads == 1024 && slots > 1024 && slots <= 8192) {
-        if (slots <= 2048) fps_launch<2, 1024>(b, n, m, shift, xyz, temp, idx, s);
-        else if (slots <= 4096) fps_launch<4, 1024>(b, n, m, shift, xyz, temp, idx, s);
-        else fps_launch<8, 1024>(b, n, m, shift, xyz, temp, idx, s);
+        if (slots <= 2048) fps_launch<2, 1024>(b, n, m, shift, xyz, temp, idx, ties_in, ties_out, s);
+        else if (slots <= 4096) fps_launch<4, 1024>(b, n, m, shift, xyz, temp, idx, ties_in, ties_out, s);
+        else fps_launch<8, 1024>(b, n, m, shift, xyz, temp, idx, ties_in, ties_out, s);
     } else if (force_threads == 256 && slots > 2048 && slots <= 8192) {
-        if (slots <= 4096) fps_launch<16, 256>(b, n, m, shift, xyz, temp, idx, s);
-        else fps_launch<32, 256>(b, n, m, shift, xyz, temp, idx, s);
+        if (slots <= 4096) fps_launch<16, 256>(b, n, m, shift, xyz, temp, idx, ties_in, ties_out, s);
+        else fps_launch<32, 256>(b, n, m, shift, xyz, temp, idx, ties_in, ties_out, s);
     } else
-    if (slots <= 64) fps_launch<1, 64>(b, n, m, shift, xyz, temp, idx, s);
-    else if (slots <= 128) fps_launch<2, 64>(b, n, m, shift, xyz, temp, idx, s);
-    else if (slots <= 256) fps_launch<4, 64>(b, n, m, shift, xyz, temp, idx, s);
-    else if (slots <= 512) fps_launch<2, 256>(b, n, m, shift, xyz, temp, idx, s);
-    else if (slots <= 1024) fps_launch<4, 256>(b, n, m, shift, xyz, temp, idx, s);
-    else if (slots <= 2048) fps_launch<8, 256>(b, n, m, shift, xyz, temp, idx, s);
-    else if (slots <= 4096) fps_launch<8, 512>(b, n, m, shift, xyz, temp, idx, s);
-    else if (slots <= 8192) fps_launch<16, 512>(b, n, m, shift, xyz, temp, idx, s);
-    else if (slots <= 16384) fps_launch<32, 512>(b, n, m, shift, xyz, temp, idx, s);
+    if (slots <= 64) fps_launch<1, 64>(b, n, m, shift, xyz, temp, idx, ties_in, ties_out, s);
+    else if (slots <= 128) fps_launch<2, 64>(b, n, m, shift, xyz, temp, idx, ties_in, ties_out, s);
+    else if (slots <= 256) fps_launch<4, 64>(b, n, m, shift, xyz, temp, idx, ties_in, ties_out, s);
+    else if (slots <= 512) fps_launch<2, 256>(b, n, m, shift, xyz, temp, idx, ties_in, ties_out, s);
+    else if (slots <= 1024) fps_launch<4, 256>(b, n, m, shift, xyz, temp, idx, ties_in, ties_out, s);
+    else if (slots <= 2048) fps_launch<8, 256>(b, n, m, shift, xyz, temp, idx, ties_in, ties_out, s);
+    else if (slots <= 4096) fps_launch<8, 512>(b, n, m, shift, xyz, temp, idx, ties_in, ties_out, s);
+    else if (slots <= 8192) fps_launch<16, 512>(b, n, m, shift, xyz, temp, idx, ties_in, ties_out, s);
+    else if (slots <= 16384) fps_launch<32, 512>(b, n, m, shift, xyz, temp, idx, ties_in, ties_out, s);
     else {
+        // (these kernels do not track ties: a chain through them never takes the shortcut afterwards)
+        if (ties_out && hipMemsetAsync(ties_out, 0, sizeof(int) * (size_t)b, s) != hipSuccess) {
+            ogc_set_error("%s: memset failed", name);
+            return OGC_ERR_LAUNCH;
+        }
         // cooperative multi-workgroup kernel when the whole job fits on the chip at once, else one workgroup per cloud
         static const char *mode = getenv("OGC_FPS_LARGE"); // "single": development override
         const int G = ogc_divup(n, FPS_COOP_PTS * FPS_COOP_THREADS);
@@ -406,6 +480,16 @@ extern "C" int ogc_furthest_point_sampling(int b, int n, int m, const float *xyz
         }
         if (!done) hipLaunchKernelGGL(fps_mem_kernel, dim3(b), dim3(1024), 0, s, n, m, shift, xyz, temp, idx);
     }
-    OGC_CHECK_LAUNCH("ogc_furthest_point_sampling");
+    OGC_CHECK_LAUNCH(name);
     return OGC_OK;
+}
+
+extern "C" int ogc_furthest_point_sampling(int b, int n, int m, const float *xyz, float *temp, int *idx,
+                                           ogc_stream_t stream) {
+    return fps_impl("ogc_furthest_point_sampling", b, n, m, xyz, temp, idx, nullptr, nullptr, stream);
+}
+
+extern "C" int ogc_furthest_point_sampling_chain(int b, int n, int m, const float *xyz, float *temp, int *idx,
+                                                 const int *ties_in, int *ties_out, ogc_stream_t stream) {
+    return fps_impl("ogc_furthest_point_sampling_chain", b, n, m, xyz, temp, idx, ties_in, ties_out, stream);
 }

@@ -6,24 +6,27 @@ checkpoints (``encoder_loc.sa1.mlp_convs.0.weight``, ``global_corr_layer.epsilon
 import torch
 import torch.nn as nn
 
-from ..pointnet2.pointnet2 import furthest_point_sample, gather_operation
+from ..pointnet2.pointnet2 import furthest_point_sample_chain, gather_operation
 from ..utils.flowstep3d_util import (FlowEmbedding, PointNetFeaturePropogation, PointNetSetAbstraction,
                                      geometry_memo)
 
 
-def joint_fps(xyz_a, xyz_b, npoints):
+def joint_fps(xyz_a, xyz_b, npoints, parent_ties=None, return_ties=False):
     """FPS chains of TWO clouds in one launch per level.  Sampling is per cloud, so stacking both clouds along the
     batch gives each its own indices unchanged, but the sequential rounds (one workgroup per cloud) are paid once
-    instead of twice.  xyz_* (B, 3, N) -> ([idx level 1, idx level 2, ...] for a, the same for b)."""
+    instead of twice.  Every level samples from the previous level's centres, which are stored in sampling order: a
+    cloud whose parent run never saw a tie needs no rounds at all from the second level on
+    (furthest_point_sample_chain); `parent_ties` continues a chain started elsewhere (the clouds must then be that
+    chain's last centres).  xyz_* (B, 3, N) -> ([idx level 1, idx level 2, ...] for a, the same for b[, ties])."""
     B = xyz_a.shape[0]
     level = torch.cat([xyz_a, xyz_b])                                   # (2B, 3, N)
-    idx_a, idx_b = [], []
+    idx_a, idx_b, ties = [], [], parent_ties
     for npoint in npoints:
-        idx = furthest_point_sample(level.permute(0, 2, 1).contiguous(), npoint)
+        idx, ties = furthest_point_sample_chain(level.permute(0, 2, 1).contiguous(), npoint, ties)
         idx_a.append(idx[:B].contiguous())
         idx_b.append(idx[B:].contiguous())
         level = gather_operation(level.contiguous(), idx)
-    return idx_a, idx_b
+    return (idx_a, idx_b, ties) if return_ties else (idx_a, idx_b)
 
 
 def _sa(npoint, nsample, in_channel, mlp, inorm, **kw):
@@ -208,10 +211,11 @@ class FlowStep3DBase(nn.Module):
         self.flow_conv2 = _sa(int(npoint / 4), k2, 32, [16, 16, 16], use_instance_norm)
         self.flow_up_sample = PointNetFeaturePropogation(in_channel=3, mlp=[])
 
-    def calc_glob_corr(self, pc1_loc, feats1_loc, pc2_loc, feats2_loc):
+    def calc_glob_corr(self, pc1_loc, feats1_loc, pc2_loc, feats2_loc, parent_ties=None):
+        # parent_ties: the local encoder's sampling chain, which these centres end (they are in sampling order)
         fps1 = fps2 = None
         if pc1_loc.is_cuda and pc1_loc.shape == pc2_loc.shape:
-            fps1, fps2 = joint_fps(pc1_loc, pc2_loc, self.encoder_glob.npoints())
+            fps1, fps2 = joint_fps(pc1_loc, pc2_loc, self.encoder_glob.npoints(), parent_ties)
         pc1_l_glob, feats1_glob = self.encoder_glob(pc1_loc, feats1_loc, fps1)
         pc2_l_glob, feats2_glob = self.encoder_glob(pc2_loc, feats2_loc, fps2)
         return self.global_corr_layer(pc1_l_glob, pc2_l_glob, feats1_glob, feats2_glob)
@@ -239,13 +243,14 @@ class FlowStep3DBase(nn.Module):
         feature1 = feature1.permute(0, 2, 1).contiguous()
         feature2 = feature2.permute(0, 2, 1).contiguous()
 
-        fps_idx1 = fps_idx2 = None
+        fps_idx1 = fps_idx2 = loc_ties = None
         if pc1.is_cuda and pc1.shape == pc2.shape:  # both sampling chains in one launch per level
-            fps_idx1, fps_idx2 = joint_fps(pc1, pc2, [self.encoder_loc.sa1.npoint, self.encoder_loc.sa2.npoint])
+            fps_idx1, fps_idx2, loc_ties = joint_fps(pc1, pc2, [self.encoder_loc.sa1.npoint, self.encoder_loc.sa2.npoint],
+                                                     return_ties=True)
         pc1_l_loc, feats1_loc, fps_idx1 = self.encoder_loc(pc1, feature1, fps_idx1)
         pc2_l_loc, feats2_loc, _ = self.encoder_loc(pc2, feature2, fps_idx2)
 
-        corr_feats = self.calc_glob_corr(pc1_l_loc[-1], feats1_loc, pc2_l_loc[-1], feats2_loc)
+        corr_feats = self.calc_glob_corr(pc1_l_loc[-1], feats1_loc, pc2_l_loc[-1], feats2_loc, loc_ties)
         flow0_lr = self.flow0_regressor(pc1_l_loc, corr_feats)
         flow0 = self.flow_up_sample(pc1_l_loc[0], pc1_l_loc[2], None, flow0_lr)
         flow_predictions.append(flow0.permute(0, 2, 1))

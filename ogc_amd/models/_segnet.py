@@ -46,8 +46,10 @@ class MaskFormer3DBase(nn.Module):
     def _plan(self, pc):
         """Geometry of all levels, in dependency order (each level samples from the previous level's centres)."""
         sa_plans, l_pc = [], [pc]
+        ties = None  # level l+1 samples from the centres of level l, stored in sampling order (FPS chain)
         for sa in self.SA_modules:
-            g = sa.plan_geometry(l_pc[-1])
+            g = sa.plan_geometry(l_pc[-1], ties)
+            ties = g.get("ties")
             sa_plans.append(g)
             l_pc.append(g["new_xyz"])
         fp_plans = [fp.plan_geometry(l_pc[i], l_pc[i + 1]) for i, fp in enumerate(self.FP_modules)]
@@ -68,9 +70,10 @@ class MaskFormer3DBase(nn.Module):
             stream.wait_event(after)
         pc.record_stream(stream)
         with torch.cuda.stream(stream):  # one event per level so that SA1 can start as soon as ITS plan is ready
-            l_last = pc
+            l_last, ties = pc, None  # level l+1 samples from the centres of level l, stored in sampling order
             for i, sa in enumerate(self.SA_modules):
-                g = sa.plan_geometry(l_last)
+                g = sa.plan_geometry(l_last, ties)
+                ties = g.get("ties")
                 ev = torch.cuda.Event()
                 ev.record(stream)
                 sa_geo[i] = Pending(g, ev)

@@ -71,6 +71,24 @@ class FurthestPointSampling(Function):
 furthest_point_sample = FurthestPointSampling.apply
 
 
+def furthest_point_sample_chain(xyz: torch.Tensor, npoint: int, parent_ties=None):
+    """furthest_point_sample for a level of a sampling chain (not in the reference): -> (idx (B, npoint) int32, ties).
+    `parent_ties`: the `ties` returned for the level that produced `xyz` — `xyz` must be that level's sampled centres in
+    sampling order.  Samples whose parent run had a unique farthest point in each of its first `npoint` rounds need no
+    rounds at all here (the answer is 0..npoint-1, see include/ogc_ops.h); the others are sampled as usual, so the indices are always those of
+    furthest_point_sample.  Without the native entry point this is furthest_point_sample and ties is None."""
+    chain = getattr(_native, "furthest_point_sampling_chain_wrapper", None)
+    if chain is None or not xyz.is_cuda:
+        return furthest_point_sample(xyz, npoint), None
+    assert xyz.is_contiguous()
+    B, N, _ = xyz.size()
+    output = _new(xyz, (B, npoint), torch.int32)
+    temp = _new(xyz, (B, N), torch.float32, fill=1e10)
+    ties = torch.empty(B, dtype=torch.int32, device=xyz.device)
+    chain(B, N, npoint, xyz, temp, output, parent_ties, ties)
+    return output, ties
+
+
 class GatherOperation(Function):
     """Reference: pointnet2.py:45-78 -> gather_points_wrapper / gather_points_grad_wrapper."""
 

@@ -119,6 +119,15 @@ def furthest_point_sampling_wrapper(b, n, m, points, temp, idx):
     return 1
 
 
+def furthest_point_sampling_chain_wrapper(b, n, m, points, temp, idx, ties_in, ties_out):
+    """FPS along a chain of levels (ogc_furthest_point_sampling_chain): `ties_in` (b,) int32 from the run that produced
+    `points` (its first n samples in order) lets tie-free samples skip the rounds; `ties_out` (b,) int32 records this
+    run's tie count.  Either may be None."""
+    _run("ogc_furthest_point_sampling_chain", points, b, n, m, _f(points, "points"), _f(temp, "temp"), _i(idx, "idx"),
+         _opt(ties_in, torch.int32, "ties_in"), _opt(ties_out, torch.int32, "ties_out"))
+    return 1
+
+
 def knn_wrapper(b, n, m, k, unknown, known, dist2, idx):
     _run("ogc_knn", unknown, b, n, m, k, _f(unknown, "unknown"), _f(known, "known"), _f(dist2, "dist2"),
          _i(idx, "idx"))

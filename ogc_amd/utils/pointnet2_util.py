@@ -4,7 +4,8 @@
 import torch
 import torch.nn as nn
 
-from ..pointnet2.pointnet2 import (GroupAll, QueryAndGroup, furthest_point_sample, gather_nd, knn_radius_clamp,
+from ..pointnet2.pointnet2 import (GroupAll, QueryAndGroup, furthest_point_sample, furthest_point_sample_chain, gather_nd,
+                                   knn_radius_clamp,
                                    three_interpolate, three_nn)
 from .nn_util import SharedMLP
 
@@ -19,21 +20,23 @@ class _PointnetSAModuleBase(nn.Module):
         self.groupers = None
         self.mlps = None
 
-    def plan_geometry(self, xyz):
+    def plan_geometry(self, xyz, parent_ties=None):
         """Everything of this level that depends on coordinates only: FPS indices, the sampled centres and the
         un-clamped kNN of every neighbourhood size in use (the scales of a multi-scale level differ only in the
         radius of the clamp, so one search serves them all).  May be evaluated ahead of time on a side stream."""
         if self.npoint is None:
             return None
-        plan = self.plan_sampling(xyz)
+        plan = self.plan_sampling(xyz, parent_ties)
         plan["idx"] = self.plan_neighbours(xyz, plan["new_xyz"])
         return plan
 
-    def plan_sampling(self, xyz):
-        """The sequential part: FPS indices and the sampled centres (:22-27)."""
-        new_inds = furthest_point_sample(xyz, self.npoint).long()
+    def plan_sampling(self, xyz, parent_ties=None):
+        """The sequential part: FPS indices and the sampled centres (:22-27).  parent_ties: `ties` of the plan whose
+        `new_xyz` this `xyz` is (the previous level of the encoder) — lets tie-free clouds skip the sampling rounds."""
+        new_inds, ties = furthest_point_sample_chain(xyz, self.npoint, parent_ties)
+        new_inds = new_inds.long()
         new_xyz = gather_nd(xyz, new_inds)  # == gather on the transposed cloud, transposed back (:22-27)
-        return {"new_inds": new_inds, "new_xyz": new_xyz}
+        return {"new_inds": new_inds, "new_xyz": new_xyz, "ties": ties}
 
     def plan_neighbours(self, xyz, new_xyz):
         """Neighbour lists of every scale around the sampled centres."""

@@ -1,0 +1,103 @@
+"""Furthest point sampling along a chain of levels (ogc_furthest_point_sampling_chain): the shortcut for tie-free parents
+and the fall-back for everything else both return what plain FPS (and the CPU oracle) return on the same cloud."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _api():
+    import ogc_amd  # noqa: F401
+    from ogc_amd.pointnet2 import pointnet2 as api
+    return api
+
+
+def lattice(n_side):
+    g = torch.arange(n_side, dtype=torch.float32)
+    return torch.stack(torch.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
+
+
+def chain(api, pc, sizes):
+    """Levels of a chain -> list of (idx via the chain entry point, idx via the plain operator, ties)."""
+    out, ties, cur = [], None, pc
+    for m in sizes:
+        idx, t = api.furthest_point_sample_chain(cur, m, ties)
+        plain = api.furthest_point_sample(cur, m)
+        out.append((idx, plain, t))
+        cur = api.gather_nd(cur, idx.long()).contiguous()
+        ties = t
+    return out
+
+
+def test_tie_free_clouds_skip_the_rounds_and_match(oracle):
+    api = _api()
+    g = torch.Generator().manual_seed(3)
+    pc = ((torch.rand(4, 8192, 3, generator=g) - 0.5) * torch.tensor([60.0, 4.0, 80.0])).cuda().contiguous()
+    levels = chain(api, pc, [2048, 1024, 512])
+    for lvl, (idx, plain, ties) in enumerate(levels):
+        assert torch.equal(idx, plain), "level %d" % lvl
+        assert ties.dtype == torch.int32 and bool((ties >= idx.shape[1]).all())   # no tie before the last round
+    for idx, _, _ in levels[1:]:  # the shortcut's answer: the first m samples of the parent, in order
+        assert torch.equal(idx, torch.arange(idx.shape[1], device="cuda", dtype=torch.int32).expand_as(idx))
+    # level 2 against the oracle on the gathered centres (the plain operator is pinned to it elsewhere)
+    centres = api.gather_nd(pc, levels[0][0].long()).contiguous()
+    want = oracle.fps(centres.cpu().numpy(), 1024)
+    np.testing.assert_array_equal(levels[1][0].cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("kind", ["lattice", "duplicates", "identical"])
+def test_clouds_with_ties_are_sampled_for_real(kind, oracle):
+    api = _api()
+    if kind == "lattice":
+        pc = lattice(16).unsqueeze(0)                                   # 4096 points, masses of exact ties
+    elif kind == "duplicates":
+        g = torch.Generator().manual_seed(5)
+        base = torch.rand(1, 700, 3, generator=g)
+        pc = torch.cat([base, base[:, :324]], 1)                        # 1024 points, 324 of them twice
+    else:
+        pc = torch.ones(1, 512, 3)
+    pc = pc.cuda().contiguous()
+    n = pc.shape[1]
+    levels = chain(api, pc, [n // 2, n // 4, n // 8])
+    assert int(levels[0][2][0]) < n // 4                                 # the parent run saw a tie early ...
+    cur = pc
+    for lvl, (idx, plain, ties) in enumerate(levels):                    # ... so every level was really sampled
+        assert torch.equal(idx, plain), "%s level %d" % (kind, lvl)
+        np.testing.assert_array_equal(idx.cpu().numpy(), oracle.fps(cur.cpu().numpy(), idx.shape[1]))
+        cur = api.gather_nd(cur, idx.long()).contiguous()
+
+
+def test_mixed_batch_decides_per_sample(oracle):
+    api = _api()
+    g = torch.Generator().manual_seed(9)
+    rnd = torch.rand(4096, 3, generator=g) * 15.0
+    pc = torch.stack([rnd, lattice(16), rnd.flip(0).contiguous()]).cuda().contiguous()
+    levels = chain(api, pc, [1024, 512])
+    ties = levels[0][2].cpu().tolist()
+    assert ties[0] >= 512 and ties[1] < 512 and ties[2] >= 512
+    for idx, plain, _ in levels:
+        assert torch.equal(idx, plain)
+    ar = torch.arange(512, device="cuda", dtype=torch.int32)
+    assert torch.equal(levels[1][0][0], ar) and torch.equal(levels[1][0][2], ar)
+    assert not torch.equal(levels[1][0][1], ar)                          # the lattice is NOT an ordered prefix
+
+
+def test_large_clouds_never_claim_to_be_tie_free():
+    api = _api()
+    pc = torch.rand(1, 20000, 3, generator=torch.Generator().manual_seed(1)).cuda().contiguous()
+    idx, ties = api.furthest_point_sample_chain(pc, 64, None)
+    assert torch.equal(idx, api.furthest_point_sample(pc, 64)) and int(ties[0]) == 0
+
+
+def test_segnet_plan_uses_the_chain():
+    import ogc_amd  # noqa: F401
+    from ogc_amd.models.segnet_kitti import MaskFormer3D
+    torch.manual_seed(0)
+    net = MaskFormer3D(n_slot=10, n_point=2048, transformer_embed_dim=128).cuda()
+    pc = ((torch.rand(2, 2048, 3) - 0.5) * torch.tensor([60.0, 4.0, 80.0])).cuda().contiguous()
+    sa_plans, _ = net._plan(pc)
+    ar = lambda m: torch.arange(m, device="cuda").expand(2, m)  # noqa: E731
+    assert bool((sa_plans[0]["ties"] >= 512).all())
+    assert torch.equal(sa_plans[1]["new_inds"], ar(sa_plans[1]["new_inds"].shape[1]))
+    assert torch.equal(sa_plans[2]["new_inds"], ar(sa_plans[2]["new_inds"].shape[1]))
