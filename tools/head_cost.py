@@ -47,3 +47,7 @@ with profile(activities=[ProfilerActivity.CUDA]) as prof:
     step(); torch.cuda.synchronize()
 n = sum(1 for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA)
 print("kernels + copies per call:", n)
+import collections
+c = collections.Counter(e.name[:70] for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA)
+for k, v in c.most_common(40):
+    print("%4d  %s" % (v, k))
