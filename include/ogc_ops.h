@@ -167,6 +167,18 @@ int ogc_group_concat(int b, int c, int n, int npoints, int nsample, const float 
 int ogc_group_concat_grad(int b, int c, int n, int npoints, int nsample, const float *grad_out, const int *idx,
                           float *grad_points, ogc_stream_t stream);
 
+/* First layer of a set-abstraction MLP without the grouped tensor (utils/pointnet2_util.py:33-40: QueryAndGroup, then the
+ * first Conv2d of the SharedMLP).  That layer is linear in [x_j - c_i ; f_j], so its feature part commutes with the
+ * gather:  y[b, m, i, j] = P[b, m, idx[b, i, j]] + sum_k wx[m, k] * rel[b, k, i, j],  P = W_f . f per point (b, m, n),
+ * rel (b, 3, npoints, nsample) the relative coordinates (ogc_group_concat with c = 0), wx (m, 3) the xyz columns of the
+ * weight.  The (b, 3 + c, npoints, nsample) grouped tensor, its read by the convolution and the scatter of its gradient
+ * never happen.  groups > 0: also the statistics of y for the GroupNorm that follows, in the layout of
+ * ogc_conv1x1_gemm_gnstats (ogc_conv1x1_gn_slots() copies of (b, groups, 2) f64, overwritten).
+ * Needs npoints * nsample % 4 == 0 and 16-byte aligned tensors (OGC_ERR_UNSUPPORTED otherwise).
+ * Backward, from existing entry points: dP = ogc_group_points_grad(dy), d wx = ogc_conv1x1_wgrad(rel, dy). */
+int ogc_group_linear_fwd(int b, int m, int n, int npoints, int nsample, int groups, const float *P, const int *idx,
+                         const float *rel, const float *wx, float *y, double *stats, ogc_stream_t stream);
+
 /* Dynamic (rigid-motion) term of the OGC loss, fused.  Replaces DynamicLoss.forward + fit_motion_svd_batch
  *   losses/seg_loss_unsup.py:64-98, :10-61 (K-fold expanded clouds, einsums, ~65 launches per step).
  * ogc_rigid_moments: per (cloud, slot) the weighted moments of p = pc and q = pc2 with weights mask[:, slot], accumulated

@@ -284,6 +284,104 @@ extern "C" int ogc_group_concat(int b, int c, int n, int npoints, int nsample, c
     return group_fwd("ogc_group_concat", b, c, n, T, points, idx, out + 3 * (size_t)T, stream, bstride);
 }
 
+namespace {
+// First layer of a set-abstraction MLP without the grouped tensor.  The layer is linear in [x_j - c_i ; f_j], so the
+// feature part commutes with the gather:  y[b, m, (i, j)] = P[b, m, idx[b, i, j]] + sum_k wx[m, k] * rel[b, k, (i, j)]
+// with P = W_f . f computed per POINT (a small GEMM) and rel = x_j - c_i formed first, exactly as the reference
+// does (pointnet2.py:286-288), so nothing cancels.  A thread owns four consecutive positions: one 16-byte index load,
+// three 16-byte loads of rel, then per output channel four gathered reads of P (L2-resident: b*m*n floats) and a
+// 16-byte store.  A workgroup stays inside one GroupNorm group and adds its (sum, sum of squares) to one of
+// GL_SLOTS copies of the (b, groups, 2) fp64 accumulator — the layout ogc_conv1x1_gemm_gnstats fills.
+constexpr int GL_SLOTS = 16;
+
+__global__ __launch_bounds__(GG_THREADS) void group_linear_fwd_kernel(int m, int n, int T, int cpb, int cg, int groups,
+                                                                      const float *__restrict__ P,
+                                                                      const int *__restrict__ idx,
+                                                                      const float *__restrict__ rel,
+                                                                      const float *__restrict__ wx,
+                                                                      float *__restrict__ y,
+                                                                      double *__restrict__ stats) {
+    __shared__ double red[2 * GG_THREADS / 64];
+    const int b = blockIdx.z, c0 = blockIdx.y * cpb;
+    const int t4 = (blockIdx.x * GG_THREADS + threadIdx.x) * 4;
+    float s = 0.f, ss = 0.f;
+    if (t4 < T) {
+        const int4 i4 = *reinterpret_cast<const int4 *>(idx + (size_t)b * T + t4);
+        const float *rb = rel + (size_t)b * 3 * T + t4;
+        const float4 rx = *reinterpret_cast<const float4 *>(rb), ry = *reinterpret_cast<const float4 *>(rb + T),
+                     rz = *reinterpret_cast<const float4 *>(rb + 2 * (size_t)T);
+        const float *p = P + ((size_t)b * m + c0) * n;
+        float *o = y + ((size_t)b * m + c0) * T + t4;
+        for (int ch = c0; ch < c0 + cpb; ++ch, p += n, o += T) {
+            const float w0 = wx[ch * 3], w1 = wx[ch * 3 + 1], w2 = wx[ch * 3 + 2];
+            float4 v;
+            v.x = fmaf(w2, rz.x, fmaf(w1, ry.x, fmaf(w0, rx.x, p[i4.x])));
+            v.y = fmaf(w2, rz.y, fmaf(w1, ry.y, fmaf(w0, rx.y, p[i4.y])));
+            v.z = fmaf(w2, rz.z, fmaf(w1, ry.z, fmaf(w0, rx.z, p[i4.z])));
+            v.w = fmaf(w2, rz.w, fmaf(w1, ry.w, fmaf(w0, rx.w, p[i4.w])));
+            *reinterpret_cast<float4 *>(o) = v;
+            s += (v.x + v.y) + (v.z + v.w);
+            ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        }
+    }
+    if (stats) { // uniform
+        double ds = s, dss = ss;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            ds += __shfl_down(ds, off, 64);
+            dss += __shfl_down(dss, off, 64);
+        }
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        if (lane == 0) {
+            red[wave * 2] = ds;
+            red[wave * 2 + 1] = dss;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double a = 0.0, q = 0.0;
+            for (int w = 0; w < GG_THREADS / 64; ++w) {
+                a += red[w * 2];
+                q += red[w * 2 + 1];
+            }
+            double *dst = stats + (((size_t)(blockIdx.x % GL_SLOTS) * gridDim.z + b) * groups + c0 / cg) * 2;
+            atomicAdd(dst, a);
+            atomicAdd(dst + 1, q);
+        }
+    }
+}
+} // namespace
+
+extern "C" int ogc_group_linear_fwd(int b, int m, int n, int npoints, int nsample, int groups, const float *P,
+                                    const int *idx, const float *rel, const float *wx, float *y, double *stats,
+                                    ogc_stream_t stream) {
+    OGC_REQUIRE(b >= 0 && m >= 1 && n >= 1 && npoints >= 0 && nsample >= 0 && groups >= 0 &&
+                    (long long)npoints * nsample < (1ll << 31),
+                "ogc_group_linear_fwd: bad dimensions");
+    const int T = npoints * nsample;
+    if (b == 0 || T == 0) return OGC_OK;
+    OGC_REQUIRE(P && idx && rel && wx && y && (stats || groups == 0), "ogc_group_linear_fwd: null pointer");
+    OGC_REQUIRE((long long)m * T < (1ll << 31) && (long long)m * n < (1ll << 31) && b <= 65535,
+                "ogc_group_linear_fwd: one sample exceeds 32-bit indexing");
+    if ((T & 3) != 0 || !aligned16(idx) || !aligned16(rel) || !aligned16(y) || (groups > 0 && m % groups != 0)) {
+        ogc_set_error("ogc_group_linear_fwd: needs npoints * nsample %% 4 == 0, 16-byte aligned tensors, m %% groups == 0");
+        return OGC_ERR_UNSUPPORTED;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int cg = groups > 0 ? m / groups : m;
+    int cpb = 1; // channels per workgroup: the largest power of two <= 16 dividing the group width
+    while (cpb < 16 && cg % (cpb * 2) == 0) cpb *= 2;
+    if (groups > 0 &&
+        hipMemsetAsync(stats, 0, sizeof(double) * 2 * GL_SLOTS * (size_t)b * groups, s) != hipSuccess) {
+        ogc_set_error("ogc_group_linear_fwd: memset failed");
+        return OGC_ERR_LAUNCH;
+    }
+    dim3 grid(ogc_divup(T, GG_THREADS * 4), m / cpb, b);
+    hipLaunchKernelGGL(group_linear_fwd_kernel, grid, dim3(GG_THREADS), 0, s, m, n, T, cpb, cg, groups, P, idx, rel, wx,
+                       y, groups > 0 ? stats : nullptr);
+    OGC_CHECK_LAUNCH("ogc_group_linear_fwd");
+    return OGC_OK;
+}
+
 extern "C" int ogc_group_concat_grad(int b, int c, int n, int npoints, int nsample, const float *grad_out,
                                      const int *idx, float *grad_points, ogc_stream_t stream) {
     OGC_REQUIRE(b >= 0 && c >= 0 && n >= 0 && npoints >= 0 && nsample >= 0 &&

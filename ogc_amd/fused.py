@@ -658,3 +658,72 @@ def multihead_attention(mha, query, key, value):
     else:
         core = _CrossAttentionCore.apply(F.linear(query, W[:E], b[:E]), F.linear(key, W[E:], b[E:]), H)
     return F.linear(core, mha.out_proj.weight, mha.out_proj.bias)
+
+
+class _GroupedFirstLayer(Function):
+    """conv(cat([xyz[idx] - new_xyz, features[idx]])) — grouping followed by the first (bias-free 1x1) convolution of a
+    set-abstraction MLP — without the grouped tensor: the layer is linear, so its feature columns are applied per POINT
+    (P = W_f f, a small GEMM) and gathered, the three xyz columns are applied to the relative coordinates, which are
+    formed first as in the reference (ogc_group_linear_fwd).  Returns (y (B, M, npoint, nsample), GroupNorm statistics of
+    y or None).  Backward from existing operators: dP = scatter-add of dy (group_points_grad), then two small GEMMs for
+    d features and d W_f; d W_xyz is a weight gradient with three input channels."""
+
+    @staticmethod
+    def forward(ctx, xyz, new_xyz, features, idx, weight, gn_groups):
+        nat = _api._native
+        ctx.set_materialize_grads(False)
+        B, C, N = features.shape
+        npoint, nsample = idx.shape[1], idx.shape[2]
+        M = weight.shape[0]
+        w = weight.detach().reshape(M, 3 + C)
+        wx, wf = w[:, :3].contiguous(), w[:, 3:].contiguous()
+        rel = torch.empty(B, 3, npoint, nsample, dtype=torch.float32, device=xyz.device)
+        nat.group_concat_wrapper(B, 0, N, npoint, nsample, xyz, new_xyz, None, idx, rel)
+        P = torch.matmul(wf, features.detach())                                    # (B, M, N)
+        y = torch.empty(B, M, npoint, nsample, dtype=torch.float32, device=xyz.device)
+        stats = None
+        if gn_groups > 0:
+            stats = torch.empty(nat.conv1x1_gn_slots() * B * gn_groups * 2, dtype=torch.float64, device=xyz.device)
+        nat.group_linear_fwd_wrapper(B, M, N, npoint, nsample, gn_groups, P, idx, rel, wx, y, stats)
+        ctx.save_for_backward(features, idx, rel, weight)
+        if stats is not None:
+            ctx.mark_non_differentiable(stats)
+        return y, stats
+
+    @staticmethod
+    def backward(ctx, grad_y, _grad_stats=None):
+        if grad_y is None:
+            return (None,) * 6
+        nat = _api._native
+        features, idx, rel, weight = ctx.saved_tensors
+        B, C, N = features.shape
+        npoint, nsample = idx.shape[1], idx.shape[2]
+        M = weight.shape[0]
+        grad_y = grad_y.contiguous()
+        wf = weight.detach().reshape(M, 3 + C)[:, 3:]
+        dP = torch.zeros(B, M, N, dtype=torch.float32, device=grad_y.device)
+        nat.group_points_grad_wrapper(B, M, N, npoint, nsample, grad_y, idx, dP)
+        grad_feat = torch.matmul(wf.t(), dP) if ctx.needs_input_grad[2] else None
+        grad_w = None
+        if ctx.needs_input_grad[4]:
+            dwx = torch.empty(M, 3, dtype=torch.float32, device=grad_y.device)
+            nat.conv1x1_wgrad_wrapper(B, 3, M, npoint * nsample, rel, grad_y, dwx)
+            dwf = torch.bmm(dP, features.detach().transpose(1, 2)).sum(0)
+            grad_w = torch.cat([dwx, dwf], 1).view_as(weight)
+        return None, None, grad_feat, None, grad_w, None
+
+
+def grouped_first_layer_available(xyz, new_xyz, features, idx, conv, gn):
+    nat = _api._native
+    return (features is not None and features.is_cuda and features.dtype == torch.float32 and idx is not None
+            and getattr(nat, "group_linear_fwd_wrapper", None) is not None and conv.bias is None
+            and conv.weight.shape[1] == 3 + features.shape[1] and (idx.shape[1] * idx.shape[2]) % 16 == 0
+            and not xyz.requires_grad and not new_xyz.requires_grad
+            and (gn is None or (gn.num_groups <= 32 and conv.weight.shape[0] % gn.num_groups == 0))
+            and nat.get_matmul_precision() == "fp32")
+
+
+def grouped_first_layer(xyz, new_xyz, features, idx, conv, gn):
+    """(conv(QueryAndGroup(...)), statistics for `gn`) — see _GroupedFirstLayer."""
+    return _GroupedFirstLayer.apply(xyz.contiguous(), new_xyz.contiguous(), features.contiguous(), idx.int().contiguous(),
+                                    conv.weight, 0 if gn is None else gn.num_groups)

@@ -172,6 +172,13 @@ def group_concat_grad_wrapper(b, c, n, npoints, nsample, grad_out, idx, grad_poi
          _f(grad_points, "grad_points"))
 
 
+def group_linear_fwd_wrapper(b, m, n, npoints, nsample, groups, P, idx, rel, wx, y, stats):
+    """y = P[idx] + wx . rel — the first layer of a set-abstraction MLP without the grouped tensor (ogc_group_linear_fwd);
+    stats: float64, conv1x1_gn_slots() * b * groups * 2 elements, or None with groups == 0."""
+    _run("ogc_group_linear_fwd", P, b, m, n, npoints, nsample, int(groups), _f(P, "P"), _i(idx, "idx"), _f(rel, "rel"),
+         _f(wx, "wx"), _f(y, "y"), _opt(stats, torch.float64, "stats"))
+
+
 def soft_nn_target_wrapper(b, n1, n2, k, temperature, p1, p2, mask1, mask2, target):
     """Soft nearest-neighbour targets of OA-ICP without the (b, n1, n2) tensors (ogc_soft_nn_target)."""
     _run("ogc_soft_nn_target", p1, b, n1, n2, k, float(temperature), _f(p1, "p1"), _f(p2, "p2"), _f(mask1, "mask1"),

@@ -166,11 +166,13 @@ class SharedMLP(nn.Sequential):
                                    preact=preact))
 
 
-def _shared_mlp_run(self, x, pool):
+def _shared_mlp_run(self, x, pool, first=None):
     """The layers in sequence.  Inside the stack the output of conv -> GroupNorm -> ReLU is only read by the next
     convolution, so on the GPU it is never written: the raw convolution output travels on together with the norm's
     statistics (`pending`) and the norm is applied by the next convolution while loading (fused.norm_act_conv).  The
-    last layer's norm / activation (/ max over the neighbourhood, `pool`) is one fused op."""
+    last layer's norm / activation (/ max over the neighbourhood, `pool`) is one fused op.
+    first: optional callable (conv, gn) -> (raw output, statistics) that evaluates the FIRST layer's convolution (a set-
+    abstraction level fuses it with the grouping, fused.grouped_first_layer); `x` is then unused."""
     from ..fused import (group_norm_act, group_norm_act_maxpool, norm_act_conv, norm_act_conv_available, pointwise_conv)
     layers = list(self.children())
     pending = None  # (raw conv output, its GroupNorm statistics or None, the GroupNorm, relu?)
@@ -195,7 +197,7 @@ def _shared_mlp_run(self, x, pool):
         else:
             if pending is not None:
                 x, pending = flush(pending, False), None
-            y, stats = pointwise_conv(x, conv, gn)
+            y, stats = first(conv, gn) if (first is not None and li == 0) else pointwise_conv(x, conv, gn)
         pending = (y, stats, gn, relu)
     if pending is not None:
         return flush(pending, True)
@@ -206,14 +208,24 @@ def _shared_mlp_forward(self, x):
     return _shared_mlp_run(self, x, False)
 
 
-def _shared_mlp_forward_maxpool(self, x):
+def _shared_mlp_forward_maxpool(self, x, first=None):
     """SharedMLP applied to (B, C, npoint, nsample) followed by the max over nsample
     (reference: utils/pointnet2_util.py:38-42); the last layer's norm/activation/pooling run as one fused op."""
-    return _shared_mlp_run(self, x, True)
+    return _shared_mlp_run(self, x, True, first)
+
+
+def _shared_mlp_first_layer(self):
+    """(conv, GroupNorm) of the first layer when it is a fusable conv -> GroupNorm -> act block, else None."""
+    layers = list(self.children())
+    if not layers or not (isinstance(layers[0], _ConvNd) and layers[0]._gn_fuse):
+        return None
+    conv_name, norm_name, _ = layers[0]._names
+    return getattr(layers[0], conv_name), getattr(layers[0], norm_name)[0]
 
 
 SharedMLP.forward = _shared_mlp_forward
 SharedMLP.forward_maxpool = _shared_mlp_forward_maxpool
+SharedMLP.first_layer = _shared_mlp_first_layer
 
 
 def knead_leading_dims(n_dim: int, data: torch.Tensor):
