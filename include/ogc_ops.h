@@ -175,9 +175,15 @@ int ogc_group_concat_grad(int b, int c, int n, int npoints, int nsample, const f
  * never happen.  groups > 0: also the statistics of y for the GroupNorm that follows, in the layout of
  * ogc_conv1x1_gemm_gnstats (ogc_conv1x1_gn_slots() copies of (b, groups, 2) f64, overwritten).
  * Needs npoints * nsample % 4 == 0 and 16-byte aligned tensors (OGC_ERR_UNSUPPORTED otherwise).
- * Backward, from existing entry points: dP = ogc_group_points_grad(dy), d wx = ogc_conv1x1_wgrad(rel, dy). */
+ * ogc_group_linear_bwd reads the gradient tensor ONCE for both results that need it:  grad_p[b, m, idx] += grad_y (the
+ * scatter-add of ogc_group_points_grad: grad_p (b, m, n) must be zeroed by the caller) and dwx[m, k] += sum grad_y * rel
+ * (dwx (m, 3), zeroed by the caller).  Needs n <= 16384, npoints * nsample >= 4096 and a multiple of 16
+ * (OGC_ERR_UNSUPPORTED otherwise: use ogc_group_points_grad and ogc_conv1x1_wgrad on (rel, grad_y)).  The remaining
+ * gradients are small per-point GEMMs: d features = W_f^T grad_p, d W_f = sum_b grad_p f^T. */
 int ogc_group_linear_fwd(int b, int m, int n, int npoints, int nsample, int groups, const float *P, const int *idx,
                          const float *rel, const float *wx, float *y, double *stats, ogc_stream_t stream);
+int ogc_group_linear_bwd(int b, int m, int n, int npoints, int nsample, const float *grad_y, const int *idx,
+                         const float *rel, float *grad_p, float *dwx, ogc_stream_t stream);
 
 /* Dynamic (rigid-motion) term of the OGC loss, fused.  Replaces DynamicLoss.forward + fit_motion_svd_batch
  *   losses/seg_loss_unsup.py:64-98, :10-61 (K-fold expanded clouds, einsums, ~65 launches per step).

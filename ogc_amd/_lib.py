@@ -37,6 +37,7 @@ SIGNATURES = {
     "ogc_soft_nn_target": [_int, _int, _int, _int, _flt, _vp, _vp, _vp, _vp, _vp, _vp],
     "ogc_group_concat": [_int, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp],
     "ogc_group_linear_fwd": [_int, _int, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "ogc_group_linear_bwd": [_int, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp],
     "ogc_group_concat_grad": [_int, _int, _int, _int, _int, _vp, _vp, _vp, _vp],
     "ogc_neighbour_consistency_fwd": [_int, _int, _int, _int, _int, _vp, _vp, _vp, _vp],
     "ogc_reverse_neighbours": [_int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp],

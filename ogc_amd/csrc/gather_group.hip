@@ -83,12 +83,17 @@ __global__ __launch_bounds__(GG_THREADS) void group_bwd_kernel(int c, int n, int
 // accumulates into an LDS image acc[CC][n] with ds_add_f32 (no global atomic contention: kNN neighbour lists
 // overlap heavily, group_points_gpu.cu:24 serialises on popular points), then merges the non-zero entries
 // into grad_points with one global atomic each.
-template <int CC>
+// WX: the gradient tensor is also multiplied with the relative coordinates rel (b, 3, T) on the way —
+// dwx[ch, k] += sum_t grad_out[b, ch, t] * rel[b, k, t], the xyz columns of the weight gradient of ogc_group_linear_fwd's
+// layer — so that the tensor is read once for both results.
+template <int CC, bool WX>
 __global__ __launch_bounds__(GG_THREADS) void group_bwd_lds_kernel(int c, int n, int T, int t_per_block,
                                                                    long long go_bstride,
                                                                    const float *__restrict__ grad_out,
                                                                    const int *__restrict__ idx,
-                                                                   float *__restrict__ grad_points) {
+                                                                   float *__restrict__ grad_points,
+                                                                   const float *__restrict__ rel,
+                                                                   float *__restrict__ dwx) {
     extern __shared__ __attribute__((aligned(16))) float gb_acc[]; // [CC][n]
     const int b = blockIdx.z;
     const int c0 = blockIdx.y * CC;
@@ -103,12 +108,25 @@ __global__ __launch_bounds__(GG_THREADS) void group_bwd_lds_kernel(int c, int n,
     // before touching LDS: neighbour rows end in long runs of the SAME index (kNN rows clamped to the nearest
     // neighbour beyond the radius, ball-query rows padded with the first hit), which would otherwise serialise as
     // same-address atomics.  t_begin, t_per_block and T are multiples of 16 on this path.
+    float wacc[WX ? CC : 1][3];
+#pragma unroll
+    for (int cc = 0; cc < (WX ? CC : 1); ++cc) wacc[cc][0] = wacc[cc][1] = wacc[cc][2] = 0.0f;
     for (int t16 = t_begin + threadIdx.x * 16; t16 < t_end; t16 += GG_THREADS * 16) {
         int ids[16];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int4 i4 = *reinterpret_cast<const int4 *>(id + t16 + 4 * u);
             ids[4 * u] = i4.x; ids[4 * u + 1] = i4.y; ids[4 * u + 2] = i4.z; ids[4 * u + 3] = i4.w;
+        }
+        float rl[WX ? 3 : 1][16];
+        if constexpr (WX) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float4 f = *reinterpret_cast<const float4 *>(rel + ((size_t)b * 3 + k) * T + t16 + 4 * u);
+                    rl[k][4 * u] = f.x; rl[k][4 * u + 1] = f.y; rl[k][4 * u + 2] = f.z; rl[k][4 * u + 3] = f.w;
+                }
         }
 #pragma unroll
         for (int cc = 0; cc < CC; ++cc) {
@@ -118,6 +136,12 @@ __global__ __launch_bounds__(GG_THREADS) void group_bwd_lds_kernel(int c, int n,
                 for (int u = 0; u < 4; ++u) {
                     const float4 f = *reinterpret_cast<const float4 *>(g + (size_t)cc * T + t16 + 4 * u);
                     v[4 * u] = f.x; v[4 * u + 1] = f.y; v[4 * u + 2] = f.z; v[4 * u + 3] = f.w;
+                }
+                if constexpr (WX) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) wacc[cc][k] = fmaf(v[u], rl[k][u], wacc[cc][k]);
                 }
                 float *a = gb_acc + cc * n;
                 float run = v[0];
@@ -139,6 +163,17 @@ __global__ __launch_bounds__(GG_THREADS) void group_bwd_lds_kernel(int c, int n,
     for (int i = threadIdx.x; i < ncc * n; i += GG_THREADS) {
         const float v = gb_acc[i];
         if (v != 0.0f) unsafeAtomicAdd(gp + i, v);
+    }
+    if constexpr (WX) { // wavefront sums, then one atomic per (channel, axis) and wavefront
+#pragma unroll
+        for (int cc = 0; cc < CC; ++cc)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                float w = wacc[cc][k];
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) w += __shfl_down(w, off, 64);
+                if ((threadIdx.x & 63) == 0 && cc < ncc && w != 0.0f) unsafeAtomicAdd(dwx + (size_t)(c0 + cc) * 3 + k, w);
+            }
     }
 }
 
@@ -196,7 +231,9 @@ int group_fwd(const char *name, int b, int c, int n, int T, const float *points,
 }
 
 int group_bwd(const char *name, int b, int c, int n, int T, const float *grad_out, const int *idx,
-              float *grad_points, ogc_stream_t stream, long long go_bstride = -1) {
+              float *grad_points, ogc_stream_t stream, long long go_bstride = -1, const float *rel = nullptr,
+              float *dwx = nullptr) {
+    // rel / dwx: also accumulate dwx[ch, k] += sum grad_out * rel (LDS path only; the caller checks group_bwd_fuses_wx)
     if (go_bstride < 0) go_bstride = (long long)c * T;
     OGC_REQUIRE(b >= 0 && c >= 0 && n >= 0 && T >= 0, "%s: negative dimension", name);
     if (b == 0 || c == 0 || T == 0) return OGC_OK;
@@ -217,9 +254,15 @@ int group_bwd(const char *name, int b, int c, int n, int T, const float *grad_ou
         tpb = (tpb + 4095) / 4096 * 4096; // multiple of 256 threads x 16 positions
         dim3 grid(ogc_divup(T, tpb), chunks, b);
         const size_t lds = (size_t)cc * n * sizeof(float);
-#define GB_LAUNCH(CCV)                                                                                    \
-    hipLaunchKernelGGL(group_bwd_lds_kernel<CCV>, grid, dim3(GG_THREADS), lds, (hipStream_t)stream, c, n, T, \
-                       tpb, go_bstride, grad_out, idx, grad_points)
+#define GB_LAUNCH(CCV)                                                                                             \
+    do {                                                                                                           \
+        if (dwx)                                                                                                   \
+            hipLaunchKernelGGL((group_bwd_lds_kernel<CCV, true>), grid, dim3(GG_THREADS), lds, (hipStream_t)stream, c, n, \
+                               T, tpb, go_bstride, grad_out, idx, grad_points, rel, dwx);                          \
+        else                                                                                                       \
+            hipLaunchKernelGGL((group_bwd_lds_kernel<CCV, false>), grid, dim3(GG_THREADS), lds, (hipStream_t)stream, c,  \
+                               n, T, tpb, go_bstride, grad_out, idx, grad_points, rel, dwx);                       \
+    } while (0)
         if (cc == 8) GB_LAUNCH(8);
         else if (cc == 4) GB_LAUNCH(4);
         else if (cc == 2) GB_LAUNCH(2);
@@ -227,6 +270,10 @@ int group_bwd(const char *name, int b, int c, int n, int T, const float *grad_ou
 #undef GB_LAUNCH
         OGC_CHECK_LAUNCH(name);
         return OGC_OK;
+    }
+    if (dwx) {
+        ogc_set_error("%s: the fused xyz weight gradient needs the LDS path (n <= 16384, T >= 4096, T %% 16 == 0)", name);
+        return OGC_ERR_UNSUPPORTED;
     }
     const int bx = ogc_divup(T, vec ? GG_THREADS * 4 : GG_THREADS);
     const int cpb = pick_ch_per_block(b, c, bx);
@@ -380,6 +427,21 @@ extern "C" int ogc_group_linear_fwd(int b, int m, int n, int npoints, int nsampl
                        y, groups > 0 ? stats : nullptr);
     OGC_CHECK_LAUNCH("ogc_group_linear_fwd");
     return OGC_OK;
+}
+
+extern "C" int ogc_group_linear_bwd(int b, int m, int n, int npoints, int nsample, const float *grad_y, const int *idx,
+                                    const float *rel, float *grad_p, float *dwx, ogc_stream_t stream) {
+    OGC_REQUIRE(b >= 0 && m >= 1 && n >= 1 && npoints >= 0 && nsample >= 0 &&
+                    (long long)npoints * nsample < (1ll << 31),
+                "ogc_group_linear_bwd: bad dimensions");
+    const int T = npoints * nsample;
+    if (b == 0 || T == 0) return OGC_OK;
+    OGC_REQUIRE(grad_y && idx && rel && grad_p && dwx, "ogc_group_linear_bwd: null pointer");
+    if (!aligned16(rel) || !aligned16(grad_y) || !aligned16(idx)) {
+        ogc_set_error("ogc_group_linear_bwd: tensors must be 16-byte aligned");
+        return OGC_ERR_UNSUPPORTED;
+    }
+    return group_bwd("ogc_group_linear_bwd", b, m, n, T, grad_y, idx, grad_p, stream, -1, rel, dwx);
 }
 
 extern "C" int ogc_group_concat_grad(int b, int c, int n, int npoints, int nsample, const float *grad_out,

@@ -701,13 +701,22 @@ class _GroupedFirstLayer(Function):
         M = weight.shape[0]
         grad_y = grad_y.contiguous()
         wf = weight.detach().reshape(M, 3 + C)[:, 3:]
-        dP = torch.zeros(B, M, N, dtype=torch.float32, device=grad_y.device)
-        nat.group_points_grad_wrapper(B, M, N, npoint, nsample, grad_y, idx, dP)
+        T = npoint * nsample
+        one_pass = ctx.needs_input_grad[4] and N <= 16384 and T >= 4096 and T % 16 == 0
+        # dP and the three xyz columns of the weight gradient share one pass over grad_y where the scatter kernel's
+        # LDS path applies; otherwise the scatter-add and a three-channel weight gradient
+        zeroed = torch.zeros(B * M * N + M * 3, dtype=torch.float32, device=grad_y.device)
+        dP, dwx = zeroed[:B * M * N].view(B, M, N), zeroed[B * M * N:].view(M, 3)
+        if one_pass:
+            nat.group_linear_bwd_wrapper(B, M, N, npoint, nsample, grad_y, idx, rel, dP, dwx)
+        else:
+            nat.group_points_grad_wrapper(B, M, N, npoint, nsample, grad_y, idx, dP)
         grad_feat = torch.matmul(wf.t(), dP) if ctx.needs_input_grad[2] else None
         grad_w = None
         if ctx.needs_input_grad[4]:
-            dwx = torch.empty(M, 3, dtype=torch.float32, device=grad_y.device)
-            nat.conv1x1_wgrad_wrapper(B, 3, M, npoint * nsample, rel, grad_y, dwx)
+            if not one_pass:
+                dwx = torch.empty(M, 3, dtype=torch.float32, device=grad_y.device)
+                nat.conv1x1_wgrad_wrapper(B, 3, M, T, rel, grad_y, dwx)
             dwf = torch.bmm(dP, features.detach().transpose(1, 2)).sum(0)
             grad_w = torch.cat([dwx, dwf], 1).view_as(weight)
         return None, None, grad_feat, None, grad_w, None

@@ -179,6 +179,13 @@ def group_linear_fwd_wrapper(b, m, n, npoints, nsample, groups, P, idx, rel, wx,
          _f(wx, "wx"), _f(y, "y"), _opt(stats, torch.float64, "stats"))
 
 
+def group_linear_bwd_wrapper(b, m, n, npoints, nsample, grad_y, idx, rel, grad_p, dwx):
+    """grad_p += scatter of grad_y, dwx += grad_y . rel in one pass over grad_y (ogc_group_linear_bwd); both zeroed by
+    the caller.  Raises OgcOpsError (unsupported) outside n <= 16384, npoints * nsample >= 4096 and % 16 == 0."""
+    _run("ogc_group_linear_bwd", grad_y, b, m, n, npoints, nsample, _f(grad_y, "grad_y"), _i(idx, "idx"), _f(rel, "rel"),
+         _f(grad_p, "grad_p"), _f(dwx, "dwx"))
+
+
 def soft_nn_target_wrapper(b, n1, n2, k, temperature, p1, p2, mask1, mask2, target):
     """Soft nearest-neighbour targets of OA-ICP without the (b, n1, n2) tensors (ogc_soft_nn_target)."""
     _run("ogc_soft_nn_target", p1, b, n1, n2, k, float(temperature), _f(p1, "p1"), _f(p2, "p2"), _f(mask1, "mask1"),
