@@ -728,8 +728,7 @@ def grouped_first_layer_available(xyz, new_xyz, features, idx, conv, gn):
             and getattr(nat, "group_linear_fwd_wrapper", None) is not None and conv.bias is None
             and conv.weight.shape[1] == 3 + features.shape[1] and (idx.shape[1] * idx.shape[2]) % 16 == 0
             and not xyz.requires_grad and not new_xyz.requires_grad
-            and (gn is None or (gn.num_groups <= 32 and conv.weight.shape[0] % gn.num_groups == 0))
-            and nat.get_matmul_precision() == "fp32")
+            and (gn is None or (gn.num_groups <= 32 and conv.weight.shape[0] % gn.num_groups == 0)))
 
 
 def grouped_first_layer(xyz, new_xyz, features, idx, conv, gn):
