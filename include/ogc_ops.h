@@ -279,6 +279,21 @@ int ogc_attention_bwd(int b, int lq, int lk, int h, int d, float scale, const fl
                       int ldk, const float *v, int ldv, const float *out, const float *prob, const float *dout,
                       float *dq, int lddq, float *dk, int lddk, float *dv, int lddv, ogc_stream_t stream);
 
+/* Mask read-out of the segmentation nets
+ *   models/segnet_kitti.py:85-88 (segnet_sapien.py / segnet_ogcdr.py :77-80):
+ *   mask = softmax_k( F.normalize(feats, dim=1)^T F.normalize(slots, dim=1) / temperature ),  temperature = 0.05.
+ * feats (b, d, n) per-point features, slots (b, d, k) object embeddings, mask (b, n, k); fp32, contiguous.  The norms
+ * are clamped at 1e-12 as F.normalize does.  k <= 32, d <= 256 (OGC_ERR_UNSUPPORTED otherwise).
+ * bwd: grad_mask (b, n, k) -> grad_feats (b, d, n) and grad_slots (b, d, k), both overwritten; mask is the forward
+ * output.  ws: scratch of ogc_slot_masks_ws_floats(b, d, n, k) floats (per-workgroup partial sums of the slot
+ * gradient, added in a fixed order: the result repeats bit for bit). */
+long long ogc_slot_masks_ws_floats(int b, int d, int n, int k);
+int ogc_slot_masks_fwd(int b, int d, int n, int k, float temperature, const float *feats, const float *slots,
+                       float *mask, ogc_stream_t stream);
+int ogc_slot_masks_bwd(int b, int d, int n, int k, float temperature, const float *feats, const float *slots,
+                       const float *mask, const float *grad_mask, float *grad_feats, float *grad_slots, float *ws,
+                       ogc_stream_t stream);
+
 /* Fused GroupNorm (+ ReLU) forward / backward.  Replaces the nn.GroupNorm -> ReLU(inplace) tail of every
  * Conv2d block of the segmentation nets' SharedMLPs
  *   utils/nn_util.py:6-11 (GroupNorm), :45-85 (_ConvBase ordering), models/segnet_kitti.py:8 (BN_CONFIG).

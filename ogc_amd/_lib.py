@@ -50,6 +50,9 @@ SIGNATURES = {
     "ogc_attention_fwd": [_int, _int, _int, _int, _int, _flt, _vp, _int, _vp, _int, _vp, _int, _vp, _vp, _vp],
     "ogc_attention_bwd": [_int, _int, _int, _int, _int, _flt, _vp, _int, _vp, _int, _vp, _int, _vp, _vp, _vp, _vp, _int,
                           _vp, _int, _vp, _int, _vp],
+    "ogc_slot_masks_ws_floats": [_int, _int, _int, _int],
+    "ogc_slot_masks_fwd": [_int, _int, _int, _int, _flt, _vp, _vp, _vp, _vp],
+    "ogc_slot_masks_bwd": [_int, _int, _int, _int, _flt, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "ogc_conv1x1_gn_slots": [],
     "ogc_set_matmul_precision": [_int],
     "ogc_group_norm_stats_slots": [],
@@ -94,6 +97,7 @@ def load():
             fn.argtypes = argtypes
             fn.restype = _int
         L.ogc_version.restype = _int
+        L.ogc_slot_masks_ws_floats.restype = ctypes.c_longlong
         L.ogc_last_error.restype = ctypes.c_char_p
         _lib = L
     return _lib

@@ -633,6 +633,42 @@ class _CrossAttentionCore(Function):
         return gq, gkv, None
 
 
+class _SlotMasks(Function):
+    """softmax_k(normalize(feats, 1)^T normalize(slots, 1) / temperature): the mask read-out of the segmentation nets
+    (models/segnet_kitti.py:85-88) as one launch forward and two backward (ogc_slot_masks_fwd / _bwd) instead of the
+    two normalisations, the einsum, the scaling and the softmax with their adjoints (~35 launches, nine passes over the
+    (B, D, N) features or their gradient)."""
+
+    @staticmethod
+    def forward(ctx, feats, slots, temperature):
+        feats, slots = feats.contiguous(), slots.contiguous()
+        B, D, N = feats.shape
+        mask = torch.empty(B, N, slots.shape[2], dtype=torch.float32, device=feats.device)
+        _api._native.slot_masks_fwd_wrapper(temperature, feats, slots, mask)
+        ctx.save_for_backward(feats, slots, mask)
+        ctx.temperature = temperature
+        return mask
+
+    @staticmethod
+    def backward(ctx, grad_mask):
+        feats, slots, mask = ctx.saved_tensors
+        gf, gs = torch.empty_like(feats), torch.empty_like(slots)
+        _api._native.slot_masks_bwd_wrapper(ctx.temperature, feats, slots, mask, grad_mask.contiguous(), gf, gs)
+        return gf, gs, None
+
+
+def slot_masks_available(feats, slots):
+    """The fused mask read-out takes fp32 device tensors with at most 32 slots and 256 feature channels."""
+    return (getattr(_api._native, "slot_masks_fwd_wrapper", None) is not None and feats.dim() == 3 and slots.dim() == 3
+            and feats.shape[1] == slots.shape[1] <= 256 and 0 < slots.shape[2] <= 32 and feats.shape[2] > 0
+            and all(t.is_cuda and t.dtype == torch.float32 for t in (feats, slots)))
+
+
+def slot_masks(feats, slots, temperature=0.05):
+    """(B, N, K) soft masks from point features (B, D, N) and slot embeddings (B, D, K)."""
+    return _SlotMasks.apply(feats, slots, float(temperature))
+
+
 def attention_core_available(embed_dim, n_head, lq, lk, *tensors):
     """The fused attention core handles heads of 16 or 32 columns and needs lq * lk floats of LDS in its backward."""
     nat = _api._native

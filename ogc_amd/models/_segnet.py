@@ -4,6 +4,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import fused
 from ..utils.nn_util import Seq
 from ..utils.pointnet2_util import PointnetFPModule, PointnetSAModule, PointnetSAModuleMSG
 from ..utils.transformer_util import MaskFormerHead
@@ -106,5 +107,7 @@ class MaskFormer3DBase(nn.Module):
 
         slot = self.MF_head(l_feats[-1].transpose(1, 2), l_pc[-1])        # (B, K, D)
         slot = self.object_mlp(slot.transpose(1, 2))                      # (B, 64, K)
+        if fused.slot_masks_available(l_feats[0], slot):
+            return fused.slot_masks(l_feats[0], slot, 0.05)
         logits = torch.einsum('bdn,bdk->bnk', F.normalize(l_feats[0], dim=1), F.normalize(slot, dim=1)) / 0.05
         return logits.softmax(dim=-1)

@@ -368,6 +368,25 @@ def attention_bwd_wrapper(h, scale, q, k, v, out, prob, dout, dq, dk, dv):
          _f(prob, "prob"), _f(dout, "dout"), dqp, lddq, dkp, lddk, dvp, lddv)
 
 
+def slot_masks_fwd_wrapper(temperature, feats, slots, mask):
+    """mask (b, n, k) = softmax_k(normalize(feats, 1)^T normalize(slots, 1) / temperature) (ogc_slot_masks_fwd);
+    feats (b, d, n), slots (b, d, k)."""
+    b, d, n = feats.shape
+    _run("ogc_slot_masks_fwd", feats, b, d, n, slots.shape[2], float(temperature), _f(feats, "feats"),
+         _f(slots, "slots"), _f(mask, "mask"))
+
+
+def slot_masks_bwd_wrapper(temperature, feats, slots, mask, grad_mask, grad_feats, grad_slots):
+    """Gradients of slot_masks_fwd_wrapper (ogc_slot_masks_bwd); the scratch is allocated here."""
+    b, d, n = feats.shape
+    k = slots.shape[2]
+    ws = torch.empty(max(int(_lib.load().ogc_slot_masks_ws_floats(b, d, n, k)), 1), dtype=torch.float32,
+                     device=feats.device)
+    _run("ogc_slot_masks_bwd", feats, b, d, n, k, float(temperature), _f(feats, "feats"), _f(slots, "slots"),
+         _f(mask, "mask"), _f(grad_mask, "grad_mask"), _f(grad_feats, "grad_feats"), _f(grad_slots, "grad_slots"),
+         _f(ws, "ws"))
+
+
 def group_norm_ws(b, c, groups, backward, device):
     """Scratch of the GroupNorm entry points: per-slice partial sums, 2*b*groups*ogc_group_norm_stats_slots() doubles
     for a forward statistics pass, 2*b*c*ogc_group_norm_bwd_slots() for the backward pass (include/ogc_ops.h)."""
