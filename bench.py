@@ -8,7 +8,7 @@ One "step" = `Trainer._train_it` of the reference (train_seg.py:47-86) on config
 config/seg/kittisf/kittisf_unsup.yaml): per GPU 4 samples x 4 views (2 frames + 2 augmented) of 8192 points,
 MaskFormer3D(segnet_kitti) forward on 16 clouds, UnsupervisedOGCLoss with all three terms active, backward,
 NaN-gradient check, Adam step.  Inputs are synthetic, seeded and already resident in HBM.  Weak scaling: every
-rank has its own batch; gradients are averaged by DDP over RCCL (one ~2.4 MB bucket).
+rank has its own batch; gradients are averaged over RCCL by one flat ~2.4 MB all-reduce per step (utils/dist_util.py).
 
 Rank 0 prints ONE JSON line: value = whole-job point-clouds/s.  `roofline` is measured live (HIP events on the
 launch stream, inside the timed steps) for the ball-query kernel, the kernel BASELINE.json's metric names;
@@ -84,7 +84,9 @@ def main():
     dev = torch.device("cuda", local)
     under_launcher = "RANK" in os.environ and "MASTER_ADDR" in os.environ
     if world > 1 or under_launcher:  # a 1-process torchrun launch still exercises RCCL init + the DDP wrapper
-        dist.init_process_group("nccl", device_id=dev)
+        # no device_id: binding the group to the device at init (eager communicator) slows EVERY later launch of this
+        # process on this stack — the same un-wrapped step takes 17.5 ms instead of 14.9 (tools/ddp_cost.py)
+        dist.init_process_group("nccl")
     assert world == a.gpus, "--gpus %d but WORLD_SIZE=%d" % (a.gpus, world)
 
     import ogc_amd  # noqa: F401  (fails loudly if libogc_ops.so is missing)
@@ -98,8 +100,11 @@ def main():
                        transformer_embed_dim=128, transformer_input_pos_enc=False).to(dev)
     model = net
     if dist.is_initialized():
-        model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[local], bucket_cap_mb=25,
-                                                          gradient_as_bucket_view=True)
+        # one flat gradient all-reduce per step instead of DistributedDataParallel's per-parameter hooks (its host
+        # overhead would make the launch thread the bottleneck): ogc_amd/utils/dist_util.py
+        from ogc_amd.utils.dist_util import FlatDataParallel, always_reduce
+        always_reduce(True)  # a one-process launch still goes through RCCL
+        model = FlatDataParallel(net)
     crit = build_criterion(KITTI_LOSS)
     opt = make_optimizer(net.parameters(), lr=1e-3, weight_decay=0.0)
     batch = make_scene_batch(a.batch, a.npoint, 10, seed=1234 + rank, outdoor=True, aug=True, device=dev)
@@ -107,7 +112,7 @@ def main():
 
     def sync():
         if dist.is_initialized():
-            dist.barrier()
+            dist.barrier(device_ids=[local])
         torch.cuda.synchronize()
 
     it = 1000  # it*b >= every start_step -> dynamic + smooth + invariance all active

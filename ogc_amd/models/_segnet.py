@@ -87,6 +87,12 @@ class MaskFormer3DBase(nn.Module):
                 fp_geo[i] = Pending(g, ev)
         return sa_geo, fp_geo
 
+    overlap_head = True      # run the slot branch on a side stream underneath the feature-propagation stack
+
+    def _slots(self, coarse_feats, coarse_pc):
+        slot = self.MF_head(coarse_feats.transpose(1, 2), coarse_pc)      # (B, K, D)
+        return self.object_mlp(slot.transpose(1, 2))                      # (B, 64, K)
+
     def forward(self, pc, point_feats, geometry=None):
         # pc (B, N, 3), point_feats (B, N, 3) -> mask (B, N, K);  geometry: plan_geometry_async(pc) made earlier
         n_sa, n_fp = len(self.SA_modules), len(self.FP_modules)
@@ -101,12 +107,29 @@ class MaskFormer3DBase(nn.Module):
             li_pc, li_feats = sa(l_pc[-1], l_feats[-1], geometry=sa_geo[i])
             l_pc.append(li_pc)
             l_feats.append(li_feats)
+        # The slot branch (MaskFormer head + object MLP) reads only the coarsest level, the feature-propagation stack
+        # does not write it: the two meet at the mask read-out.  The slot branch is ~100 launches of a few microseconds
+        # on (B, K, E) tensors that leave the GPU almost empty, so on the GPU it runs on a side stream underneath the
+        # decoder's dense kernels — in the forward pass here and, because autograd replays every node on the stream
+        # its forward ran on, in the backward pass as well.
+        branch = None
+        if pc.is_cuda and self.overlap_head:
+            from ..utils.streams import side_stream
+            cur = torch.cuda.current_stream(pc.device)
+            branch = side_stream(pc.device, "segnet-slots")
+            branch.wait_stream(cur)
+            l_feats[-1].record_stream(branch)
+            l_pc[-1].record_stream(branch)
+            with torch.cuda.stream(branch):
+                slot = self._slots(l_feats[-1], l_pc[-1])
         # decoder: coarsest -> finest, FP_modules[i] produces level i
         for i in range(n_fp - 1, -1, -1):
             l_feats[i] = self.FP_modules[i](l_pc[i], l_pc[i + 1], l_feats[i], l_feats[i + 1], geometry=fp_geo[i])
-
-        slot = self.MF_head(l_feats[-1].transpose(1, 2), l_pc[-1])        # (B, K, D)
-        slot = self.object_mlp(slot.transpose(1, 2))                      # (B, 64, K)
+        if branch is None:
+            slot = self._slots(l_feats[-1], l_pc[-1])
+        else:
+            cur.wait_stream(branch)
+            slot.record_stream(cur)
         if fused.slot_masks_available(l_feats[0], slot):
             return fused.slot_masks(l_feats[0], slot, 0.05)
         logits = torch.einsum('bdn,bdk->bnk', F.normalize(l_feats[0], dim=1), F.normalize(slot, dim=1)) / 0.05

@@ -58,6 +58,8 @@ def main(argv=None):
     ap.add_argument("--synthetic", type=int, default=64, help="number of synthetic training pairs")
     ap.add_argument("--max-iters", type=int, default=0, help="stop after this many optimisation steps (0 = all epochs)")
     ap.add_argument("--device", default="cuda")
+    ap.add_argument("--ddp", action="store_true",
+                    help="average gradients with torch's DistributedDataParallel instead of one flat collective per step")
     args = ap.parse_args(argv)
     with open(args.config) as f:
         cfg = yaml.safe_load(f)
@@ -80,8 +82,14 @@ def main(argv=None):
     k_decay = fl["k_decay_fact"]
     net = FlowStep3D(npoint=fl["npoint"], use_instance_norm=fl["use_instance_norm"], loc_flow_nn=fl["loc_flow_nn"],
                      loc_flow_rad=fl["loc_flow_rad"], k_decay_fact=float(k_decay)).to(device)
-    model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[device.index] if device.type == "cuda" else None) \
-        if distributed else net
+    # one gradient collective per step (utils/dist_util.py); `--ddp` keeps torch's DistributedDataParallel
+    if distributed and getattr(args, "ddp", False):
+        model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[device.index] if device.type == "cuda" else None)
+    elif distributed:
+        from .utils.dist_util import FlatDataParallel
+        model = FlatDataParallel(net)
+    else:
+        model = net
     model_iters = cfg.get("model_iters", len(cfg["loss"]["iters_w"]))
 
     outdoor = cfg["dataset"] in ("kittisf", "waymo")

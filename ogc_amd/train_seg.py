@@ -189,6 +189,8 @@ def main(argv=None):
     ap.add_argument("--synthetic", type=int, default=64, help="number of synthetic training scenes")
     ap.add_argument("--max-iters", type=int, default=0, help="stop after this many optimisation steps (0 = all epochs)")
     ap.add_argument("--device", default="cuda")
+    ap.add_argument("--ddp", action="store_true",
+                    help="average gradients with torch's DistributedDataParallel instead of one flat collective per step")
     ap.add_argument("--flow-root", default=None,
                     help="read predicted flows from <flow-root>/flow_preds/<predflow_path>[_R<round-1>] (train_seg.py:277-280)")
     ap.add_argument("--frames", type=int, default=2,
@@ -218,8 +220,14 @@ def main(argv=None):
         from .pointnet2 import pointnet2 as _api
         _api._native.set_matmul_precision(cfg["matmul_precision"])
     net = build_segnet(cfg).to(device)
-    model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[device.index] if device.type == "cuda" else None) \
-        if distributed else net
+    # one gradient collective per step (utils/dist_util.py); `--ddp` keeps torch's DistributedDataParallel
+    if distributed and getattr(args, "ddp", False):
+        model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[device.index] if device.type == "cuda" else None)
+    elif distributed:
+        from .utils.dist_util import FlatDataParallel
+        model = FlatDataParallel(net)
+    else:
+        model = net
 
     outdoor = cfg["dataset"] in ("kittisf", "waymo")
     predflow_dir = None

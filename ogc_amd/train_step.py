@@ -121,6 +121,7 @@ def train_step(segnet, criterion, optimizer, batch, it, aug_transform, sync=True
     loss, losses = criterion(pcs_l, masks_l, flows_l, step_w=True, it=it * b, aug_transform=aug_transform, sync=False,
                              **kw)
     loss.backward()
+    _average_gradients(segnet)
     grads = [p.grad for p in segnet.parameters() if p.grad is not None]
     bad = torch.isnan(torch.stack(torch._foreach_norm(grads)).sum())  # NaN anywhere -> NaN norm
     # under DDP the all-reduced gradients make this decision identical on all ranks
@@ -141,6 +142,14 @@ def train_step(segnet, criterion, optimizer, batch, it, aug_transform, sync=True
         pending = PendingStep(losses, HostScalars(torch.tensor([skip])))
     pending.prefetched = upcoming
     return pending.result() if sync else pending
+
+
+def _average_gradients(model):
+    """Data-parallel gradient mean when the model is wrapped by utils/dist_util.FlatDataParallel (one collective per
+    step); DistributedDataParallel has already averaged inside backward(), a bare module has nothing to do."""
+    average = getattr(model, "average_gradients", None)
+    if average is not None:
+        average()
 
 
 def _nan_safe_step(params, optimizer):
@@ -179,6 +188,7 @@ def flow_train_step(flownet, criterion, optimizer, batch, model_iters, sync=True
         extra = epe_terms(batch[2][:, 0], flow_preds)
     loss, losses = criterion(pc1, pc2, flow_preds, sync=False, extra=extra)
     loss.backward()
+    _average_gradients(flownet)
     net = flownet.module if hasattr(flownet, "module") else flownet
     pending = PendingStep(losses, _nan_safe_step(list(net.parameters()), optimizer))
     return pending.result() if sync else pending

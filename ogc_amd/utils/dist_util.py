@@ -1,0 +1,83 @@
+"""Data parallelism for the training steps: one process per GPU, ONE gradient collective per step.
+
+The reference trains on a single GPU (train_seg.py / train_flow.py have no distributed path); SURVEY.md §8e scales
+its step the only way it shards: every rank steps on its own batch and the gradients are averaged.  The segmentation
+net has 2.4 MB of parameters in ~190 tensors, so the all-reduce itself is tens of microseconds over xGMI — what costs
+is per-tensor bookkeeping.  `torch.nn.parallel.DistributedDataParallel` runs an autograd hook per parameter and
+several Python layers per forward: measured on the C4 step (tools/ddp_cost.py, one process, RCCL) it adds 2.6 ms of
+launch-thread time to a 14.9 ms step whose launch thread is only ~3 ms ahead of the GPU, and the step becomes
+16.1 ms.  `FlatDataParallel` does the same arithmetic with three launches after the backward pass:
+
+    flat = cat(all gradients)  ->  all_reduce(flat, SUM) / world  ->  multi-tensor copy back into the .grad tensors
+
+(no overlap with the backward pass is attempted: there is nothing worth hiding), and broadcasts rank 0's parameters
+and buffers once at construction, as DistributedDataParallel does.  Results equal DistributedDataParallel's: the mean
+of the ranks' gradients in every .grad (tests/test_ddp_cpu.py, tests/test_ddp_gpu.py)."""
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+
+class FlatDataParallel(nn.Module):
+    """Wraps `module` (kept as ``.module``, like DistributedDataParallel, so checkpoints and ``hasattr(m, 'module')``
+    unwrapping work unchanged).  The training steps call ``average_gradients()`` between backward() and the
+    optimizer; gradients that are None on this rank take part as zeros (every rank must own the same parameters)."""
+
+    def __init__(self, module, process_group=None, broadcast=True):
+        super().__init__()
+        self.module = module
+        self.process_group = process_group
+        self.world_size = dist.get_world_size(process_group)
+        self._params = [p for p in module.parameters() if p.requires_grad]
+        if broadcast and self.world_size > 1:
+            self._broadcast([p.data for p in module.parameters()])
+            bufs = [b.data for b in module.buffers() if b.is_floating_point()]
+            if bufs:
+                self._broadcast(bufs)
+
+    def _broadcast(self, tensors):
+        by_dtype = {}
+        for t in tensors:
+            by_dtype.setdefault(t.dtype, []).append(t)
+        for group in by_dtype.values():
+            flat = torch.cat([t.reshape(-1) for t in group])
+            dist.broadcast(flat, src=dist.get_global_rank(self.process_group, 0) if self.process_group else 0,
+                           group=self.process_group)
+            torch._foreach_copy_(group, [v.view_as(t) for v, t in zip(flat.split([t.numel() for t in group]), group)])
+
+    def forward(self, *args, **kwargs):
+        return self.module(*args, **kwargs)
+
+    def average_gradients(self):
+        """.grad <- mean over the ranks of .grad, for every parameter; one collective."""
+        if self.world_size == 1 and not _always_reduce:
+            return
+        owners = [p for p in self._params if p.grad is not None]
+        missing = [p for p in self._params if p.grad is None]
+        parts = [p.grad.reshape(-1) for p in owners] + [torch.zeros_like(p).reshape(-1) for p in missing]
+        flat = torch.cat(parts)
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.process_group)
+        if self.world_size > 1:
+            flat.mul_(1.0 / self.world_size)
+        sizes = [p.numel() for p in owners + missing]
+        views = flat.split(sizes)
+        for p, v in zip(missing, views[len(owners):]):
+            p.grad = v.view_as(p).clone()
+        if owners:
+            torch._foreach_copy_([p.grad for p in owners], [v.view_as(p) for v, p in zip(views, owners)])
+
+
+_always_reduce = False
+
+
+def always_reduce(flag=True):
+    """Run the collective even in a one-process group (bench.py under a one-process launcher exercises RCCL)."""
+    global _always_reduce
+    _always_reduce = bool(flag)
+
+
+def data_parallel(module, process_group=None):
+    """`module` wrapped for gradient averaging when a process group is initialised, the module itself otherwise."""
+    if dist.is_available() and dist.is_initialized():
+        return FlatDataParallel(module, process_group)
+    return module

@@ -42,29 +42,39 @@ def _loss_and_grads(model, crit, batch):
     return loss
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, kind):
     _setup_cpu_ops()
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from ogc_amd.utils.synthetic import make_scene_batch
     net, crit = _make()
-    ddp = torch.nn.parallel.DistributedDataParallel(net)
+    if kind == "flat":   # one flat all-reduce after backward (ogc_amd/utils/dist_util.py): what bench.py and the drivers use
+        from ogc_amd.utils.dist_util import FlatDataParallel
+        if rank == 1:     # construction must broadcast rank 0's weights
+            with torch.no_grad():
+                for p in net.parameters():
+                    p.add_(0.5)
+        ddp = FlatDataParallel(net)
+    else:
+        ddp = torch.nn.parallel.DistributedDataParallel(net)
     full = make_scene_batch(2 * world, 256, 4, seed=3, outdoor=False, aug=False)
     shard = tuple(x[rank * 2:(rank + 1) * 2].contiguous() for x in full)
     opt = torch.optim.SGD(net.parameters(), lr=0.1)
     opt.zero_grad()
     _loss_and_grads(ddp, crit, shard).backward()
+    if kind == "flat":
+        ddp.average_gradients()
     opt.step()
-    if rank == 0:
-        torch.save({k: v.clone() for k, v in net.state_dict().items()}, os.path.join(out_dir, "ddp.pt"))
+    torch.save({k: v.clone() for k, v in net.state_dict().items()}, os.path.join(out_dir, "ddp%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()
 
 
 @pytest.mark.timeout(600)
-def test_ddp_two_ranks_equal_single_process(tmp_path):
-    world, port = 2, 29000 + os.getpid() % 2000
-    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+@pytest.mark.parametrize("kind", ["flat", "ddp"])
+def test_ddp_two_ranks_equal_single_process(tmp_path, kind):
+    world, port = 2, 29000 + (os.getpid() + (7 if kind == "flat" else 0)) % 2000
+    mp.spawn(_worker, args=(world, port, str(tmp_path), kind), nprocs=world, join=True)
     _setup_cpu_ops()
     from ogc_amd.utils.synthetic import make_scene_batch
     net, crit = _make()
@@ -74,6 +84,9 @@ def test_ddp_two_ranks_equal_single_process(tmp_path):
     # every loss term is a mean over the batch dimension, so the 2-rank mean of shard losses == the full-batch loss
     _loss_and_grads(net, crit, full).backward()
     opt.step()
-    ddp_state = torch.load(os.path.join(str(tmp_path), "ddp.pt"))
+    ddp_state = torch.load(os.path.join(str(tmp_path), "ddp0.pt"))
+    other = torch.load(os.path.join(str(tmp_path), "ddp1.pt"))
+    for k, v in ddp_state.items():
+        assert torch.equal(v, other[k]), k     # the replicas hold identical weights after the step
     for k, v in net.state_dict().items():
         torch.testing.assert_close(ddp_state[k], v, rtol=2e-4, atol=2e-6, msg=lambda m: "%s: %s" % (k, m))

@@ -45,12 +45,16 @@ def _run(model, crit, opt, batches):
     return [p.result() for p in results]
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, kind):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     net, crit, opt = _make()
-    ddp = torch.nn.parallel.DistributedDataParallel(net, device_ids=[0])
+    if kind == "flat":   # what bench.py and the drivers use: one flat all-reduce per step (utils/dist_util.py)
+        from ogc_amd.utils.dist_util import FlatDataParallel
+        ddp = FlatDataParallel(net)
+    else:
+        ddp = torch.nn.parallel.DistributedDataParallel(net, device_ids=[0])
     results = _run(ddp, crit, opt, _batches(slice(rank * 2, rank * 2 + 2)))
     assert all(stepped for _, stepped in results)
     torch.save({"state": {k: v.cpu() for k, v in net.state_dict().items()}, "losses": [r[0] for r in results]},
@@ -60,9 +64,10 @@ def _worker(rank, world, port, out_dir):
 
 
 @pytest.mark.timeout(900)
-def test_ddp_two_ranks_on_one_gpu(tmp_path):
-    world, port = 2, 31000 + os.getpid() % 2000
-    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+@pytest.mark.parametrize("kind", ["flat", "ddp"])
+def test_ddp_two_ranks_on_one_gpu(tmp_path, kind):
+    world, port = 2, 31000 + (os.getpid() + (7 if kind == "flat" else 0)) % 2000
+    mp.spawn(_worker, args=(world, port, str(tmp_path), kind), nprocs=world, join=True)
     a, b = (torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r)) for r in range(2))
     for k in a["state"]:
         assert torch.equal(a["state"][k], b["state"][k]), k     # replicas never diverge
