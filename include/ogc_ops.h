@@ -279,6 +279,17 @@ int ogc_attention_bwd(int b, int lq, int lk, int h, int d, float scale, const fl
                       int ldk, const float *v, int ldv, const float *out, const float *prob, const float *dout,
                       float *dq, int lddq, float *dk, int lddk, float *dv, int lddv, ogc_stream_t stream);
 
+/* nn.Linear on a few hundred rows (the decoder layers' projections and feed-forward network act on K slot embeddings
+ * per sample, utils/transformer_util.py:5-62; 160 rows x 128 features at C4), one launch per direction, fp32 FMAs:
+ *   fwd: y (rows, n_out) = x (rows, n_in) weight^T + bias        weight (n_out, n_in) as nn.Linear stores it; bias or NULL
+ *   bwd: grad_x = grad_y weight,  grad_weight = grad_y^T x,  grad_bias = sum over the rows of grad_y
+ *        — any of the three outputs may be NULL (not all); all are overwritten.
+ * Any sizes are accepted; the kernels are laid out for rows <= ~1000 (32 x 32 output tiles, no split over the rows). */
+int ogc_small_linear_fwd(int rows, int n_in, int n_out, const float *x, const float *weight, const float *bias,
+                         float *y, ogc_stream_t stream);
+int ogc_small_linear_bwd(int rows, int n_in, int n_out, const float *x, const float *weight, const float *grad_y,
+                         float *grad_x, float *grad_weight, float *grad_bias, ogc_stream_t stream);
+
 /* Mask read-out of the segmentation nets
  *   models/segnet_kitti.py:85-88 (segnet_sapien.py / segnet_ogcdr.py :77-80):
  *   mask = softmax_k( F.normalize(feats, dim=1)^T F.normalize(slots, dim=1) / temperature ),  temperature = 0.05.

@@ -677,6 +677,79 @@ def attention_core_available(embed_dim, n_head, lq, lk, *tensors):
             and all(t.is_cuda and t.dtype == torch.float32 for t in tensors))
 
 
+class _SmallLinear(Function):
+    """F.linear on a few hundred rows as one launch forward and one backward (ogc_small_linear_fwd / _bwd): the slot
+    branch's projections and feed-forward layers are 160 x 128 x 128 products, for which the vendor GEMM costs ~15 us a
+    call and autograd's backward is two of them plus a bias reduction."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        weight = weight.contiguous()
+        y = torch.empty(x2.shape[0], weight.shape[0], dtype=torch.float32, device=x.device)
+        _api._native.small_linear_fwd_wrapper(x2, weight, None if bias is None else bias.contiguous(), y)
+        ctx.save_for_backward(x2, weight)
+        ctx.shape = x.shape
+        ctx.has_bias = bias is not None
+        return y.view(*x.shape[:-1], weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, weight = ctx.saved_tensors
+        gy2 = gy.reshape(-1, gy.shape[-1]).contiguous()
+        gx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None
+        gw = torch.empty_like(weight) if ctx.needs_input_grad[1] else None
+        gb = torch.empty(weight.shape[0], dtype=torch.float32, device=gy.device) \
+            if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        if gx is not None or gw is not None or gb is not None:
+            _api._native.small_linear_bwd_wrapper(x2, weight, gy2, gx, gw, gb)
+        return (None if gx is None else gx.view(ctx.shape)), gw, gb
+
+
+_SMALL_LINEAR_ROWS = 1024
+
+
+def small_linear(x, weight, bias=None):
+    """F.linear(x, weight, bias); on the GPU, fp32 and at most 1024 rows, the single-launch kernels."""
+    if (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() >= 2
+            and 0 < x.numel() // x.shape[-1] <= _SMALL_LINEAR_ROWS
+            and getattr(_api._native, "small_linear_fwd_wrapper", None) is not None):
+        return _SmallLinear.apply(x, weight, bias)
+    return F.linear(x, weight, bias)
+
+
+class _ManyRowsLinear(Function):
+    """F.linear on a (B, L, E) input with many rows (the key / value projection of the point memory: 16 x 512 rows).
+    Forward and input gradient are the library GEMMs F.linear runs; the weight gradient, a (out x B*L) by (B*L x E)
+    product with a 128 x 256 result, is split over the batch (torch.bmm, then a sum over B) instead of one GEMM whose
+    32 output tiles leave the GPU empty (58 us per call on the slot branch's critical path, ~12 us this way)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        return F.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = gy.matmul(weight)
+        if ctx.needs_input_grad[1]:
+            gw = torch.bmm(gy.transpose(1, 2), x).sum(0)
+        if ctx.needs_input_grad[2]:
+            gb = gy.sum((0, 1))
+        return gx, gw, gb
+
+
+def many_rows_linear(x, weight, bias):
+    """F.linear(x, weight, bias); on the GPU, for (B, L, E) inputs with >= 4096 rows, with the batch-split weight
+    gradient of _ManyRowsLinear."""
+    if x.dim() == 3 and x.is_cuda and x.shape[0] > 1 and x.shape[0] * x.shape[1] >= 4096 and torch.is_grad_enabled():
+        return _ManyRowsLinear.apply(x, weight, bias)
+    return small_linear(x, weight, bias)
+
+
 def multihead_attention(mha, query, key, value):
     """``mha(query, key, value, need_weights=False)[0]`` for a batch-first nn.MultiheadAttention without masks or
     dropout (the use in utils/transformer_util.py:39-47), with the module's own parameters: the three projections stay
@@ -690,10 +763,10 @@ def multihead_attention(mha, query, key, value):
         return mha(query, key, value, need_weights=False)[0]
     W, b = mha.in_proj_weight, mha.in_proj_bias
     if query is key:
-        core = _SelfAttentionCore.apply(F.linear(query, W, b), H)
+        core = _SelfAttentionCore.apply(small_linear(query, W, b), H)
     else:
-        core = _CrossAttentionCore.apply(F.linear(query, W[:E], b[:E]), F.linear(key, W[E:], b[E:]), H)
-    return F.linear(core, mha.out_proj.weight, mha.out_proj.bias)
+        core = _CrossAttentionCore.apply(small_linear(query, W[:E], b[:E]), many_rows_linear(key, W[E:], b[E:]), H)
+    return small_linear(core, mha.out_proj.weight, mha.out_proj.bias)
 
 
 class _GroupedFirstLayer(Function):

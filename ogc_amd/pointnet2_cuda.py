@@ -368,6 +368,21 @@ def attention_bwd_wrapper(h, scale, q, k, v, out, prob, dout, dq, dk, dv):
          _f(prob, "prob"), _f(dout, "dout"), dqp, lddq, dkp, lddk, dvp, lddv)
 
 
+def small_linear_fwd_wrapper(x, weight, bias, y):
+    """y (rows, n_out) = x (rows, n_in) weight^T + bias (ogc_small_linear_fwd); bias may be None."""
+    rows, n_in = x.shape
+    _run("ogc_small_linear_fwd", x, rows, n_in, weight.shape[0], _f(x, "x"), _f(weight, "weight"),
+         None if bias is None else _f(bias, "bias"), _f(y, "y"))
+
+
+def small_linear_bwd_wrapper(x, weight, grad_y, grad_x, grad_weight, grad_bias):
+    """grad_x / grad_weight / grad_bias of small_linear_fwd_wrapper in one launch; any of them may be None."""
+    rows, n_in = x.shape
+    _run("ogc_small_linear_bwd", x, rows, n_in, weight.shape[0], _f(x, "x"), _f(weight, "weight"), _f(grad_y, "grad_y"),
+         None if grad_x is None else _f(grad_x, "grad_x"), None if grad_weight is None else _f(grad_weight, "grad_weight"),
+         None if grad_bias is None else _f(grad_bias, "grad_bias"))
+
+
 def slot_masks_fwd_wrapper(temperature, feats, slots, mask):
     """mask (b, n, k) = softmax_k(normalize(feats, 1)^T normalize(slots, 1) / temperature) (ogc_slot_masks_fwd);
     feats (b, d, n), slots (b, d, k)."""

@@ -3,7 +3,10 @@ torch.nn modules with the reference's parameter names (checkpoints are interchan
 between the projections is the fused kernel of ogc_amd/csrc/attention.hip (ogc_amd.fused.multihead_attention), and
 nothing is created with the reference's hard-coded ``.cuda()`` (transformer_util.py:110)."""
 import torch
+import torch.nn.functional as F
 from torch import nn
+
+from .. import fused
 
 
 def _attend(mha, query, key, value):
@@ -33,7 +36,9 @@ class TransformerDecoderLayer(nn.Module):
         slot = slot + _attend(self.cross_attn, self.norm_slot1(slot), keys, point_feats)
         inner = self.norm_slot2(slot)
         slot = slot + _attend(self.self_attn, inner, inner, inner)
-        return slot + self.mlp(self.norm_pre_ff(slot))
+        lin0, _, lin1 = self.mlp  # Linear, ReLU, Linear on B * K rows: one launch per layer and direction on the GPU
+        hidden = F.relu(fused.small_linear(self.norm_pre_ff(slot), lin0.weight, lin0.bias))
+        return slot + fused.small_linear(hidden, lin1.weight, lin1.bias)
 
 
 class MaskFormerHead(nn.Module):
@@ -57,7 +62,9 @@ class MaskFormerHead(nn.Module):
         # every sample looks up slots 0..K-1 (transformer_util.py:108-111): the embedding table itself, broadcast —
         # same values, and the backward is one sum over the batch instead of an index sort + scatter
         slot = self.query.weight.unsqueeze(0).expand(point_feats.shape[0], -1, -1)
-        memory = self.norm_input(self.mlp_input(point_feats))
+        lin0, _, lin1 = self.mlp_input  # Linear, ReLU, Linear on B * N rows: weight gradients split over the batch
+        hidden = F.relu(fused.many_rows_linear(point_feats, lin0.weight, lin0.bias))
+        memory = self.norm_input(fused.many_rows_linear(hidden, lin1.weight, lin1.bias))
         pos_enc = None if self.input_pos_enc is None else self.input_pos_enc(point_pos)
         for layer in self.transformer_layers:
             slot = layer(slot, memory, pos_enc)

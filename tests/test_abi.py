@@ -40,6 +40,31 @@ def test_python_binding_covers_every_entry_point():
     assert declared == set(_lib.SIGNATURES)
 
 
+def test_python_binding_matches_the_prototypes():
+    """Argument count and kind (int / float / pointer-or-stream) of every ctypes signature against include/ogc_ops.h:
+    a missing entry would make ctypes pass the stream as a 32-bit int."""
+    from ogc_amd import _lib
+    text = open(os.path.join(ROOT, "include", "ogc_ops.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"\s+", " ", text)
+    protos = dict(re.findall(r"\b(ogc_[a-z0-9_]+)\s*\(([^()]*)\)\s*;", text))
+    kinds = {ctypes.c_void_p: "ptr", ctypes.c_int: "int", ctypes.c_float: "float", ctypes.c_longlong: "ll"}
+    for name, argtypes in _lib.SIGNATURES.items():
+        params = [p.strip() for p in protos[name].split(",") if p.strip() not in ("", "void")]
+        want = []
+        for p in params:
+            if "*" in p or "ogc_stream_t" in p:
+                want.append("ptr")
+            elif p.startswith("float"):
+                want.append("float")
+            elif p.startswith("long long"):
+                want.append("ll")
+            else:
+                assert p.startswith("int"), (name, p)
+                want.append("int")
+        assert [kinds[a] for a in argtypes] == want, (name, protos[name])
+
+
 def test_drop_in_module_has_the_ten_pybind_names():
     # reference: pointnet2/src/pointnet2_api.cpp:10-25
     from ogc_amd import pointnet2_cuda as m
