@@ -7,43 +7,63 @@
 // backward has to wait for, that is ~35 us per layer where the arithmetic needs three.  Here
 //     forward : y = x W^T + b                                     (r x o)
 //     backward: dx = dy W (r x i),  dW = dy^T x (o x i),  db = sum_r dy        — all three in ONE launch
-// as 32 x 32 output tiles (256 threads, 2 x 2 outputs each, operands staged through LDS in 32-deep slices; plain fp32
+// as 32 x 32 output tiles (256 threads, 2 x 2 outputs each, operands staged through LDS in 64-deep slices; plain fp32
 // FMAs — there is no matrix-core shape worth filling at this size).  The workgroups of a backward launch are split
 // between the dx tiles and the dW tiles; the dW tiles of the first column block also produce db.
 #include "ogc_common.h"
 
 namespace {
 
-constexpr int SL_T = 32;   // tile edge and depth of a staged slice
+constexpr int SL_T = 32;   // tile edge
+constexpr int SL_K = 64;   // depth of a staged slice
+constexpr int SL_E = SL_T * SL_K / 256;   // elements of a slice per thread and operand
+
+// slice [k0, k0 + SL_K) of the operands of tile (m0, n0) into registers (zeros outside the matrices); the
+// faster-varying thread index follows the operand's unit stride
+__device__ __forceinline__ void sl_fetch(int M, int N, int K, const float *__restrict__ a, long am, long ak,
+                                         const float *__restrict__ b, long bk, long bn, int m0, int n0, int k0,
+                                         float (&ra)[SL_E], float (&rb)[SL_E]) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < SL_E; ++j) {
+        const int e = t + j * 256;
+        int mm, kk;
+        if (ak == 1) { kk = e % SL_K; mm = e / SL_K; } else { mm = e % SL_T; kk = e / SL_T; }
+        const int gm = m0 + mm, gk = k0 + kk;
+        ra[j] = (gm < M && gk < K) ? a[gm * am + gk * ak] : 0.f;
+        int nn, kb;
+        if (bn == 1) { nn = e % SL_T; kb = e / SL_T; } else { kb = e % SL_K; nn = e / SL_K; }
+        const int gn = n0 + nn, gkb = k0 + kb;
+        rb[j] = (gn < N && gkb < K) ? b[gkb * bk + gn * bn] : 0.f;
+    }
+}
 
 // C[m, n] (+ bias[n]) = sum_k A(m, k) B(k, n) for the 32 x 32 tile (tm, tn); A(m, k) = a[m * am + k * ak],
 // B(k, n) = b[k * bk + n * bn].  colsum != null: also colsum[m] = sum_k A(m, k) (written by the tn == 0 tiles).
+// The next slice is fetched into registers while the current one is multiplied out of LDS: one memory latency per
+// tile instead of one per slice (the operands are a few hundred KB, the loop is pure latency otherwise).
 __device__ __forceinline__ void sl_tile(int M, int N, int K, const float *__restrict__ a, long am, long ak,
                                         const float *__restrict__ b, long bk, long bn, const float *__restrict__ bias,
                                         float *__restrict__ c, int ldc, float *__restrict__ colsum, int tm, int tn) {
-    __shared__ float As[SL_T][SL_T + 1];   // [k][m]
-    __shared__ float Bs[SL_T][SL_T + 1];   // [k][n]
+    __shared__ float As[SL_K][SL_T + 1];   // [k][m]
+    __shared__ float Bs[SL_K][SL_T + 1];   // [k][n]
     const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
     const int m0 = tm * SL_T, n0 = tn * SL_T;
     float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
     float rs[2] = {0.f, 0.f};
-    for (int k0 = 0; k0 < K; k0 += SL_T) {
-        // 1024 elements per operand slice, 4 per thread; the faster-varying thread index follows the unit stride
+    float ra[SL_E], rb[SL_E];
+    sl_fetch(M, N, K, a, am, ak, b, bk, bn, m0, n0, 0, ra, rb);
+    for (int k0 = 0; k0 < K; k0 += SL_K) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < SL_E; ++j) {
             const int e = t + j * 256;
-            int mm, kk;
-            if (ak == 1) { kk = e & 31; mm = e >> 5; } else { mm = e & 31; kk = e >> 5; }
-            const int gm = m0 + mm, gk = k0 + kk;
-            As[kk][mm] = (gm < M && gk < K) ? a[gm * am + gk * ak] : 0.f;
-            int nn, kb;
-            if (bn == 1) { nn = e & 31; kb = e >> 5; } else { kb = e & 31; nn = e >> 5; }
-            const int gn = n0 + nn, gkb = k0 + kb;
-            Bs[kb][nn] = (gn < N && gkb < K) ? b[gkb * bk + gn * bn] : 0.f;
+            if (ak == 1) As[e % SL_K][e / SL_K] = ra[j]; else As[e / SL_T][e % SL_T] = ra[j];
+            if (bn == 1) Bs[e / SL_T][e % SL_T] = rb[j]; else Bs[e % SL_K][e / SL_K] = rb[j];
         }
         __syncthreads();
-#pragma unroll 8
-        for (int kk = 0; kk < SL_T; ++kk) {
+        if (k0 + SL_K < K) sl_fetch(M, N, K, a, am, ak, b, bk, bn, m0, n0, k0 + SL_K, ra, rb);
+#pragma unroll 16
+        for (int kk = 0; kk < SL_K; ++kk) {
             const float a0 = As[kk][ty * 2], a1 = As[kk][ty * 2 + 1];
             const float b0 = Bs[kk][tx * 2], b1 = Bs[kk][tx * 2 + 1];
             acc[0][0] = fmaf(a0, b0, acc[0][0]);

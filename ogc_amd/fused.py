@@ -750,6 +750,39 @@ def many_rows_linear(x, weight, bias):
     return small_linear(x, weight, bias)
 
 
+class _CrossProjections(Function):
+    """Query projection of the slots and packed key / value projection of the point memory with the module's ONE
+    in_proj_weight / in_proj_bias: (q, kv) = (query W[:E]^T + b[:E], memory W[E:]^T + b[E:]).  As separate F.linear
+    calls on slices of the parameters, autograd embeds each slice's gradient in a zero tensor and adds the two (ten
+    small launches per layer on the slot branch's backward chain); here the backward writes both halves of one
+    gradient tensor in place."""
+
+    @staticmethod
+    def forward(ctx, query, memory, weight, bias):
+        nat = _api._native
+        E = weight.shape[1]
+        q2 = query.reshape(-1, E).contiguous()
+        q = torch.empty(q2.shape[0], E, dtype=torch.float32, device=query.device)
+        nat.small_linear_fwd_wrapper(q2, weight[:E], bias[:E], q)
+        kv = F.linear(memory, weight[E:], bias[E:])
+        ctx.save_for_backward(q2, memory, weight)
+        ctx.qshape = query.shape
+        return q.view(query.shape), kv
+
+    @staticmethod
+    def backward(ctx, gq, gkv):
+        q2, memory, weight = ctx.saved_tensors
+        E = weight.shape[1]
+        gw = torch.empty_like(weight)
+        gb = torch.empty(weight.shape[0], dtype=torch.float32, device=weight.device)
+        gquery = torch.empty_like(q2) if ctx.needs_input_grad[0] else None
+        _api._native.small_linear_bwd_wrapper(q2, weight[:E], gq.reshape(-1, E).contiguous(), gquery, gw[:E], gb[:E])
+        gmem = gkv.matmul(weight[E:]) if ctx.needs_input_grad[1] else None
+        torch.sum(torch.bmm(gkv.transpose(1, 2), memory), 0, out=gw[E:])
+        torch.sum(gkv, (0, 1), out=gb[E:])
+        return (None if gquery is None else gquery.view(ctx.qshape)), gmem, gw, gb
+
+
 def multihead_attention(mha, query, key, value):
     """``mha(query, key, value, need_weights=False)[0]`` for a batch-first nn.MultiheadAttention without masks or
     dropout (the use in utils/transformer_util.py:39-47), with the module's own parameters: the three projections stay
@@ -765,7 +798,11 @@ def multihead_attention(mha, query, key, value):
     if query is key:
         core = _SelfAttentionCore.apply(small_linear(query, W, b), H)
     else:
-        core = _CrossAttentionCore.apply(small_linear(query, W[:E], b[:E]), many_rows_linear(key, W[E:], b[E:]), H)
+        if query.numel() // E <= _SMALL_LINEAR_ROWS and torch.is_grad_enabled():
+            q_proj, kv_proj = _CrossProjections.apply(query, key, W, b)
+        else:
+            q_proj, kv_proj = small_linear(query, W[:E], b[:E]), many_rows_linear(key, W[E:], b[E:])
+        core = _CrossAttentionCore.apply(q_proj, kv_proj, H)
     return small_linear(core, mha.out_proj.weight, mha.out_proj.bias)
 
 
