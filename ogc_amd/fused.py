@@ -738,7 +738,7 @@ class _ManyRowsLinear(Function):
         if ctx.needs_input_grad[1]:
             gw = torch.bmm(gy.transpose(1, 2), x).sum(0)
         if ctx.needs_input_grad[2]:
-            gb = gy.sum((0, 1))
+            gb = gy.sum(1).sum(0)   # two stages: B x out partial sums first (one long-column reduction is ~4x slower)
         return gx, gw, gb
 
 
@@ -779,7 +779,7 @@ class _CrossProjections(Function):
         _api._native.small_linear_bwd_wrapper(q2, weight[:E], gq.reshape(-1, E).contiguous(), gquery, gw[:E], gb[:E])
         gmem = gkv.matmul(weight[E:]) if ctx.needs_input_grad[1] else None
         torch.sum(torch.bmm(gkv.transpose(1, 2), memory), 0, out=gw[E:])
-        torch.sum(gkv, (0, 1), out=gb[E:])
+        torch.sum(gkv.sum(1), 0, out=gb[E:])   # two stages, as in _ManyRowsLinear
         return (None if gquery is None else gquery.view(ctx.qshape)), gmem, gw, gb
 
 

@@ -31,7 +31,34 @@ torch.manual_seed(10)
 net = MaskFormer3D(n_slot=10, n_point=8192, transformer_embed_dim=128).to("cuda")
 net.overlap_head = not os.environ.get("NO_OVERLAP")
 orig_slots = net._slots
-net._slots = lambda cf, cp: _Mark.apply(orig_slots(_Mark.apply(cf, "slot branch end"), cp), "slot branch start")
+FWD = {}
+
+
+def _ev(tag):
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    FWD[tag] = e
+
+
+def slots_probe(cf, cp):
+    _ev("fork")
+    out = _Mark.apply(orig_slots(_Mark.apply(cf, "slot branch end"), cp), "slot branch start")
+    _ev("slot branch end (fwd)")
+    return out
+
+
+net._slots = slots_probe
+fp_first = net.FP_modules[0]
+orig_fp0 = fp_first.forward
+
+
+def fp0_forward(*a, **k):
+    out = orig_fp0(*a, **k)
+    _ev("FP stack end (fwd)")
+    return out
+
+
+fp_first.forward = fp0_forward
 fp_last = net.FP_modules[-1]
 orig_fp = fp_last.forward
 
@@ -59,3 +86,5 @@ t0 = ev["backward start"]
 for tag in ("slot branch start", "slot branch end", "FP stack end"):
     print("%-20s +%.3f ms" % (tag, t0.elapsed_time(ev[tag])))
 print("%-20s +%.3f ms" % ("step end", t0.elapsed_time(end)))
+for tag in ("slot branch end (fwd)", "FP stack end (fwd)"):
+    print("%-22s +%.3f ms after the fork" % (tag, FWD["fork"].elapsed_time(FWD[tag])))
