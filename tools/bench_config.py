@@ -16,6 +16,8 @@ from ogc_amd.pointnet2 import pointnet2 as _api
 _api._native.set_matmul_precision(prec)
 torch.manual_seed(cfg["random_seed"])
 net = build_segnet(cfg).cuda()
+if os.environ.get("OVERLAP_HEAD") is not None:
+    net.overlap_head = os.environ["OVERLAP_HEAD"] == "1"
 single = cfg["dataset"] == "waymo"
 crit = build_criterion(cfg["loss"], single_frame=single)
 opt = make_optimizer(net.parameters(), lr=cfg["lr"])
