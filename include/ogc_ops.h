@@ -421,6 +421,26 @@ int ogc_group_norm_maxpool_fwd_stats(int b, int c, int p, int s, int groups, flo
                                      const float *gamma, const float *beta, float *out, int *argmax, float *mean,
                                      float *rstd, const double *stats, int slots, ogc_stream_t stream);
 
+/* Max-pool of a set-abstraction MLP without re-reading its last layer's output
+ *   utils/pointnet2_util.py:38-42: new_features = mlp(grouped); F.max_pool2d(new_features, [1, nsample]).
+ * The last layer is conv -> GroupNorm -> ReLU, and y -> act(a*y + bb) is monotone per (batch, channel): the pooled
+ * value is the activation of the LARGEST raw output of the neighbourhood when a >= 0 and of the SMALLEST when a < 0,
+ * and sign(a) = sign(gamma) is known before the convolution runs.
+ * ogc_conv1x1_gemm_affine_pool is ogc_conv1x1_gemm_affine (groups >= 1: statistics are always produced) whose
+ * positions are (centre, neighbour) pairs, hw = centres * nsample with nsample in {16, 32, 64}; next_gamma (M) is the
+ * scale of the GroupNorm that follows.  Next to out and stats it writes yext (b, M, centres) — per row the largest
+ * output of each neighbourhood where next_gamma >= 0, the smallest where it is negative — and aext, the index in
+ * [0, nsample) of the first neighbour attaining it.  ogc_group_norm_pool_extremes turns those and the statistics into
+ * exactly what ogc_group_norm_maxpool_fwd_stats computes from the full tensor — out (b, c, p), argmax, mean, rstd —
+ * so the backward pass (ogc_group_norm_maxpool_bwd) is unchanged.  (Two DIFFERENT raw values that round to the same
+ * activation are told apart here and not there; with gamma == 0 both report neighbour 0.) */
+int ogc_conv1x1_gemm_affine_pool(int b, int M, int K, int hw, int relu, int groups, int nsample, const float *w,
+                                 const float *in, const float *pa, const float *pb, const float *next_gamma,
+                                 float *out, double *stats, float *yext, int *aext, ogc_stream_t stream);
+int ogc_group_norm_pool_extremes(int b, int c, int p, int s, int groups, float eps, int relu, const float *yext,
+                                 const int *aext, const float *gamma, const float *beta, float *out, int *argmax,
+                                 float *mean, float *rstd, const double *stats, int slots, ogc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

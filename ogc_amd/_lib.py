@@ -50,6 +50,10 @@ SIGNATURES = {
     "ogc_attention_fwd": [_int, _int, _int, _int, _int, _flt, _vp, _int, _vp, _int, _vp, _int, _vp, _vp, _vp],
     "ogc_attention_bwd": [_int, _int, _int, _int, _int, _flt, _vp, _int, _vp, _int, _vp, _int, _vp, _vp, _vp, _vp, _int,
                           _vp, _int, _vp, _int, _vp],
+    "ogc_conv1x1_gemm_affine_pool": [_int, _int, _int, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                     _vp],
+    "ogc_group_norm_pool_extremes": [_int, _int, _int, _int, _int, _flt, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                     _int, _vp],
     "ogc_small_linear_fwd": [_int, _int, _int, _vp, _vp, _vp, _vp, _vp],
     "ogc_small_linear_bwd": [_int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "ogc_slot_masks_ws_floats": [_int, _int, _int, _int],

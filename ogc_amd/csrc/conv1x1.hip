@@ -231,14 +231,30 @@ constexpr int GN_SLOTS = 16;  // spread of the fused GroupNorm statistics over c
 // BF: bf16 operands.  Sixteen input rows (four register quads q .. q+3) feed one 16x16x16 MFMA: k-slot 4*kk + i of
 // lane group kk is input row 4*(q+i) + kk for BOTH operands (a permutation of the sixteen rows, which a sum over k
 // does not see), so the register-resident tile needs no shuffle; the weights are staged in LDS already packed that way.
-template <bool TRANSPOSE_A, int KQ, bool STATS, bool PRO, bool BF>
+// POOL: the positions are (centre, neighbour) pairs with pool_s in {16, 32, 64} neighbours per centre, and the kernel
+// also writes, per (batch, output row, centre), the extreme raw output over the neighbourhood and where it sits
+// (smallest neighbour index among equals): everything the max-pool over act(GroupNorm(out)) that ends a set-abstraction
+// MLP needs — the norm is a monotone map per (batch, row), rising or falling with the sign of its scale gamma[row],
+// which is known before the convolution runs, so one extreme per row suffices (the largest value for gamma >= 0, the
+// smallest for gamma < 0: the largest of the negated values) — and that pass never reads `out`
+// (ogc_group_norm_pool_extremes).  A wave's 64 positions hold whole neighbourhoods; values are reduced over the 4
+// accumulator columns of a lane and the pool_s / 4 lanes of a DPP row first, then the smallest index attaining them.
+struct PoolOut {
+    float *yext;          // (b, M, centres) largest raw output where sign[m] >= 0, smallest where sign[m] < 0
+    int *aext;            // its neighbour index
+    const float *sign;    // (M) the scale of the GroupNorm that follows (only its sign is used)
+    int s;
+};
+
+template <bool TRANSPOSE_A, int KQ, bool STATS, bool PRO, bool BF, bool POOL = false>
 __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_gemm_kernel(int M, int K, int hw, int groups,
                                                                           const float *__restrict__ w, // (Cout, Cin)
                                                                           const float *__restrict__ in,
                                                                           float *__restrict__ out,
                                                                           double *__restrict__ stats,
                                                                           const float *__restrict__ pa,
-                                                                          const float *__restrict__ pb, int pro_relu) {
+                                                                          const float *__restrict__ pb, int pro_relu,
+                                                                          PoolOut pool = PoolOut()) {
     extern __shared__ __attribute__((aligned(16))) float a_lds[]; // [Kq][64][4] for the current 64-row tile of A
     __shared__ double s_stats[STATS ? 64 : 1];                    // [groups][2]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -381,6 +397,39 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_gemm_kernel(int M,
                         *reinterpret_cast<float4 *>(outb + (size_t)m * hw + p0 + 4 * j) = o;
                     }
                 }
+            if constexpr (POOL) {
+                const int seg = pool.s >> 2;                 // lanes per neighbourhood: 4, 8 or 16
+                const int centres = hw / pool.s;
+                const int centre = (p0 + 4 * j) / pool.s;    // of this lane's four positions
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    if (a < nblk) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int m = m0 + a * 16 + kk * 4 + r;
+                            const float sg = (m < M && pool.sign[m] < 0.f) ? -1.f : 1.f;   // exact: +-1 * v
+                            const float v0 = sg * acc[a][0][r], v1 = sg * acc[a][1][r];
+                            const float v2 = sg * acc[a][2][r], v3 = sg * acc[a][3][r];
+                            float hi = fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
+                            hi = fmaxf(hi, ogc_dpp_f32<0xB1>(hi));
+                            hi = fmaxf(hi, ogc_dpp_f32<0x4E>(hi));
+                            if (seg >= 8) hi = fmaxf(hi, ogc_dpp_f32<0x141>(hi));
+                            if (seg >= 16) hi = fmaxf(hi, ogc_dpp_f32<0x140>(hi));
+                            // first position of the neighbourhood that attains it (64: none in this lane)
+                            unsigned idx = v0 == hi ? 4 * j : (v1 == hi ? 4 * j + 1 : (v2 == hi ? 4 * j + 2 : (v3 == hi ? 4 * j + 3 : 64)));
+                            idx = min(idx, ogc_dpp_u32<0xB1>(idx));
+                            idx = min(idx, ogc_dpp_u32<0x4E>(idx));
+                            if (seg >= 8) idx = min(idx, ogc_dpp_u32<0x141>(idx));
+                            if (seg >= 16) idx = min(idx, ogc_dpp_u32<0x140>(idx));
+                            if ((j & (seg - 1)) == 0 && m < M) {
+                                const size_t o = ((size_t)b * M + m) * centres + centre;
+                                pool.yext[o] = sg * hi;
+                                pool.aext[o] = (int)(idx & (unsigned)(pool.s - 1));   // index inside the neighbourhood
+                            }
+                        }
+                    }
+                }
+            }
             if (STATS) {
 #pragma unroll
                 for (int a = 0; a < 4; ++a) {
@@ -421,27 +470,30 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_gemm_kernel(int M,
     }
 }
 
-template <bool T, bool STATS, bool PRO>
+template <bool T, bool STATS, bool PRO, bool POOL = false>
 int gemm_launch(int b, int M, int K, int hw, int groups, const float *w, const float *in, float *out, double *stats,
-                const float *pa, const float *pb, int pro_relu, hipStream_t s) {
+                const float *pa, const float *pb, int pro_relu, hipStream_t s, PoolOut pool = PoolOut()) {
     const int Kq = (K + 3) / 4;
     const size_t lds = (size_t)Kq * 256 * sizeof(float);
     dim3 grid(ogc_divup(hw, 64 * WG_WAVES), b);
 #define OGC_GEMM(KQV)                                                                                                  \
     do {                                                                                                               \
         if (g_matmul_bf16)                                                                                             \
-            hipLaunchKernelGGL((conv1x1_gemm_kernel<T, KQV, STATS, PRO, true>), grid, dim3(WG_WAVES * OGC_WAVE), lds, s, \
-                               M, K, hw, groups, w, in, out, stats, pa, pb, pro_relu);                                 \
+            hipLaunchKernelGGL((conv1x1_gemm_kernel<T, KQV, STATS, PRO, true, POOL>), grid, dim3(WG_WAVES * OGC_WAVE), \
+                               lds, s, M, K, hw, groups, w, in, out, stats, pa, pb, pro_relu, pool);                   \
         else                                                                                                           \
-            hipLaunchKernelGGL((conv1x1_gemm_kernel<T, KQV, STATS, PRO, false>), grid, dim3(WG_WAVES * OGC_WAVE), lds, \
-                               s, M, K, hw, groups, w, in, out, stats, pa, pb, pro_relu);                              \
+            hipLaunchKernelGGL((conv1x1_gemm_kernel<T, KQV, STATS, PRO, false, POOL>), grid, dim3(WG_WAVES * OGC_WAVE), \
+                               lds, s, M, K, hw, groups, w, in, out, stats, pa, pb, pro_relu, pool);                   \
     } while (0)
     if (Kq <= 2) OGC_GEMM(2);
     else if (Kq <= 8) OGC_GEMM(8);
     else if (Kq <= 16) OGC_GEMM(16);
     else if (Kq <= 25) OGC_GEMM(25);
-    else if (Kq <= 33) OGC_GEMM(33);
-    else OGC_GEMM(40);
+    else if constexpr (POOL) return OGC_ERR_UNSUPPORTED; // the pooled variant is only offered with statistics, K <= 100
+    else {
+        if (Kq <= 33) OGC_GEMM(33);
+        else OGC_GEMM(40);
+    }
 #undef OGC_GEMM
     return OGC_OK;
 }
@@ -570,6 +622,36 @@ extern "C" int ogc_conv1x1_gemm_affine(int b, int M, int K, int hw, int relu, in
         gemm_launch<false, false, true>(b, M, K, hw, 1, w, in, out, nullptr, pa, pb, relu, s);
     }
     OGC_CHECK_LAUNCH("ogc_conv1x1_gemm_affine");
+    return OGC_OK;
+}
+
+// ogc_conv1x1_gemm_affine with output statistics, for the LAST layer of a set-abstraction MLP: positions are
+// (centre, neighbour) pairs, hw = centres * nsample, and the extreme of the raw output over each neighbourhood comes out
+// as well (see PoolOut) — the max-pool over the normalised activation is then ogc_group_norm_pool_extremes.
+extern "C" int ogc_conv1x1_gemm_affine_pool(int b, int M, int K, int hw, int relu, int groups, int nsample,
+                                            const float *w, const float *in, const float *pa, const float *pb,
+                                            const float *next_gamma, float *out, double *stats, float *yext, int *aext,
+                                            ogc_stream_t stream) {
+    const int rc = gemm_check("ogc_conv1x1_gemm_affine_pool", b, M, K, hw, w, in, out);
+    if (rc != OGC_OK) return rc;
+    OGC_REQUIRE(pa && pb && next_gamma && stats && yext && aext, "ogc_conv1x1_gemm_affine_pool: null pointer");
+    if (groups < 1 || groups > 32 || M % groups != 0 || (M / groups) % 4 != 0 || K > 100 ||
+        (nsample != 16 && nsample != 32 && nsample != 64) || hw % nsample != 0) {
+        ogc_set_error("ogc_conv1x1_gemm_affine_pool: needs 1 <= groups <= 32, (M / groups) %% 4 == 0, K <= 100 and "
+                      "nsample in {16, 32, 64} dividing hw (M=%d, groups=%d, K=%d, nsample=%d)", M, groups, K, nsample);
+        return OGC_ERR_UNSUPPORTED;
+    }
+    if (b == 0) return OGC_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(stats, 0, sizeof(double) * 2 * GN_SLOTS * (size_t)b * groups, s) != hipSuccess) {
+        ogc_set_error("ogc_conv1x1_gemm_affine_pool: memset failed");
+        return OGC_ERR_LAUNCH;
+    }
+    PoolOut pool;
+    pool.yext = yext; pool.aext = aext; pool.sign = next_gamma; pool.s = nsample;
+    const int lrc = gemm_launch<false, true, true, true>(b, M, K, hw, groups, w, in, out, stats, pa, pb, relu, s, pool);
+    if (lrc != OGC_OK) return lrc;
+    OGC_CHECK_LAUNCH("ogc_conv1x1_gemm_affine_pool");
     return OGC_OK;
 }
 

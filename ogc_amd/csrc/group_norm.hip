@@ -332,6 +332,49 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_maxpool_kernel(int c, int
     }
 }
 
+// The same result from the extreme of x over each neighbourhood (written by the convolution that produced x,
+// ogc_conv1x1_gemm_affine_pool: the largest x where gamma >= 0, the smallest where gamma < 0): y -> act(a * y + bb) is
+// non-decreasing for a >= 0 and non-increasing for a < 0 — rounding included — so the maximum of the activation is the
+// activation of that extreme, and the first neighbour attaining it is the one the convolution recorded.  One workgroup
+// per (batch, channel); x is not read.
+template <bool RELU>
+__global__ __launch_bounds__(GN_THREADS) void gn_pool_extremes_kernel(int c, int p, int s, int groups, float eps,
+                                                                      const float *__restrict__ yext,
+                                                                      const int *__restrict__ aext,
+                                                                      const float *__restrict__ gamma,
+                                                                      const float *__restrict__ beta,
+                                                                      const double *__restrict__ ws, int slots,
+                                                                      float *__restrict__ out, int *__restrict__ arg,
+                                                                      float *__restrict__ mean_out,
+                                                                      float *__restrict__ rstd_out) {
+    const int b = blockIdx.y, ch = blockIdx.x;
+    const int cg = c / groups, g = ch / cg, row = b * groups + g;
+    const double n = (double)cg * p * s;
+    double sum = 0.0, sumsq = 0.0;
+    for (int sl = 0; sl < slots; ++sl) {
+        const double *wsl = ws + ((size_t)sl * gridDim.y * groups + row) * 2;
+        sum += wsl[0];
+        sumsq += wsl[1];
+    }
+    const double m = sum / n;
+    const double var = fmax(sumsq / n - m * m, 0.0);
+    const float mean = (float)m;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    if (ch == g * cg && threadIdx.x == 0) {
+        mean_out[row] = mean;
+        rstd_out[row] = rstd;
+    }
+    const float a = rstd * gamma[ch];
+    const float bb = beta[ch] - mean * a;
+    const size_t base = ((size_t)b * c + ch) * p;
+    for (int pr = threadIdx.x; pr < p; pr += GN_THREADS) {
+        float y = fmaf(a, yext[base + pr], bb);
+        if (RELU) y = fmaxf(y, 0.f);
+        out[base + pr] = y;
+        arg[base + pr] = a != 0.f ? aext[base + pr] : 0;   // a == 0: every neighbour gives bb, the first wins the tie
+    }
+}
+
 // grid (chunks over P, C, B): ds, db from the sparse gradient (non-zero only at the arg-max element)
 template <bool RELU>
 __global__ __launch_bounds__(GN_THREADS) void gn_maxpool_bwd_sums_kernel(int c, int p, int s,
@@ -599,6 +642,28 @@ extern "C" int ogc_group_norm_maxpool_fwd_stats(int b, int c, int p, int s, int 
     OGC_REQUIRE(stats && slots >= 1, "ogc_group_norm_maxpool_fwd_stats: no statistics");
     return gn_pool_fwd_impl("ogc_group_norm_maxpool_fwd_stats", b, c, p, s, groups, eps, relu, x, gamma, beta, out,
                             argmax, mean, rstd, nullptr, stats, slots, stream);
+}
+
+extern "C" int ogc_group_norm_pool_extremes(int b, int c, int p, int s, int groups, float eps, int relu,
+                                            const float *yext, const int *aext, const float *gamma, const float *beta,
+                                            float *out, int *argmax, float *mean, float *rstd, const double *stats,
+                                            int slots, ogc_stream_t stream) {
+    OGC_REQUIRE(b >= 0 && c >= 1 && p >= 1 && s >= 1 && groups >= 1 && c % groups == 0 && slots >= 1,
+                "ogc_group_norm_pool_extremes: bad shape");
+    if (b == 0) return OGC_OK;
+    OGC_REQUIRE(yext && aext && gamma && beta && out && argmax && mean && rstd && stats,
+                "ogc_group_norm_pool_extremes: null pointer");
+    OGC_REQUIRE(b <= 65535, "ogc_group_norm_pool_extremes: too many samples for one grid");
+    const dim3 grid(c, b);
+    hipStream_t st = (hipStream_t)stream;
+    if (relu)
+        hipLaunchKernelGGL(gn_pool_extremes_kernel<true>, grid, dim3(GN_THREADS), 0, st, c, p, s, groups, eps, yext, aext,
+                           gamma, beta, stats, slots, out, argmax, mean, rstd);
+    else
+        hipLaunchKernelGGL(gn_pool_extremes_kernel<false>, grid, dim3(GN_THREADS), 0, st, c, p, s, groups, eps, yext, aext,
+                           gamma, beta, stats, slots, out, argmax, mean, rstd);
+    OGC_CHECK_LAUNCH("ogc_group_norm_pool_extremes");
+    return OGC_OK;
 }
 
 extern "C" int ogc_group_norm_maxpool_bwd(int b, int c, int p, int s, int groups, int relu, const float *x,

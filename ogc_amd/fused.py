@@ -64,7 +64,7 @@ class _GroupNormActMaxPool(Function):
     Reference sequence: nn.GroupNorm, nn.ReLU, F.max_pool2d over nsample (utils/pointnet2_util.py:38-42)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, groups, eps, relu, stats=None):
+    def forward(ctx, x, weight, bias, groups, eps, relu, stats=None, extremes=None):
         nat = _api._native
         x = x.contiguous()
         B, C, P, S = x.shape
@@ -72,7 +72,13 @@ class _GroupNormActMaxPool(Function):
         arg = torch.empty(B, C, P, dtype=torch.int32, device=x.device)
         mean = torch.empty(B * groups, dtype=torch.float32, device=x.device)
         rstd = torch.empty_like(mean)
-        if stats is not None:
+        if extremes is not None:
+            # the convolution that wrote x also left the extremes of every neighbourhood: x is not read again
+            yext, aext = extremes
+            nat.group_norm_pool_extremes_wrapper(B, C, P, S, groups, eps, relu, yext, aext,
+                                                 weight.detach().contiguous(), bias.detach().contiguous(), out, arg,
+                                                 mean, rstd, stats, stats.numel() // (2 * B * groups))
+        elif stats is not None:
             nat.group_norm_maxpool_fwd_stats_wrapper(B, C, P, S, groups, eps, relu, x, weight.detach().contiguous(),
                                                      bias.detach().contiguous(), out, arg, mean, rstd, stats,
                                                      stats.numel() // (2 * B * groups))
@@ -97,16 +103,17 @@ class _GroupNormActMaxPool(Function):
         ws = _api._native.group_norm_ws(B, C, groups, True, x.device)
         nat.group_norm_maxpool_bwd_wrapper(B, C, P, S, groups, relu, x, weight.detach().contiguous(), mean, rstd, out,
                                            arg, grad_out.contiguous(), grad_x, gw, gb, ws)
-        return grad_x, gw, gb, None, None, None, None
+        return grad_x, gw, gb, None, None, None, None, None
 
 
-def group_norm_act_maxpool(x, gn: torch.nn.GroupNorm, relu: bool, stats=None):
+def group_norm_act_maxpool(x, gn: torch.nn.GroupNorm, relu: bool, stats=None, extremes=None):
     """max over the last dimension of act(GroupNorm(x)), x (B, C, P, S).  Fused when S is a power of two in
     [4, 256] on the GPU; otherwise group_norm_act followed by a max."""
     S = x.shape[-1]
     if (x.is_cuda and x.dtype == torch.float32 and gn.affine and x.dim() == 4 and 4 <= S <= 256 and S & (S - 1) == 0
             and getattr(_api._native, "group_norm_maxpool_fwd_wrapper", None) is not None):
-        return _GroupNormActMaxPool.apply(x, gn.weight, gn.bias, gn.num_groups, gn.eps, relu, stats)
+        return _GroupNormActMaxPool.apply(x, gn.weight, gn.bias, gn.num_groups, gn.eps, relu, stats,
+                                          extremes if stats is not None else None)
     return group_norm_act(x, gn, relu, stats).max(dim=3)[0]
 
 
@@ -495,7 +502,8 @@ class _NormActConv(Function):
     Returns (y, statistics of y for the NEXT GroupNorm or None)."""
 
     @staticmethod
-    def forward(ctx, y_prev, stats_prev, gn_weight, gn_bias, conv_weight, gn_groups, eps, relu, next_groups):
+    def forward(ctx, y_prev, stats_prev, gn_weight, gn_bias, conv_weight, gn_groups, eps, relu, next_groups, pool=0,
+                next_gamma=None):
         nat = _api._native
         ctx.set_materialize_grads(False)  # no zero tensor (one fill launch per layer) for the statistics output
         y_prev = y_prev.contiguous()
@@ -516,23 +524,35 @@ class _NormActConv(Function):
             nat.group_norm_coeffs_wrapper(B, cin, hw, gn_groups, eps, y_prev, gamma, beta, None, 0, ws, mean, rstd, a, bb)
         y = torch.empty((B, cout) + tuple(y_prev.shape[2:]), dtype=torch.float32, device=dev)
         w = conv_weight.detach().contiguous()
-        stats = None
+        stats = extremes = None
         if (next_groups > 0 and next_groups <= 32 and cout % next_groups == 0 and (cout // next_groups) % 4 == 0
                 and cin <= 100):
             stats = torch.empty(nat.conv1x1_gn_slots() * B * next_groups * 2, dtype=torch.float64, device=dev)
-            nat.conv1x1_gemm_affine_wrapper(B, cout, cin, hw, relu, next_groups, w, y_prev, a, bb, y, stats)
+            if pool and next_gamma is not None and getattr(nat, "conv1x1_gemm_affine_pool_wrapper", None) is not None:
+                # last layer of a set-abstraction MLP: also the extreme of every neighbourhood, for the max-pool
+                centres = hw // pool
+                yext = torch.empty(B, cout, centres, dtype=torch.float32, device=dev)
+                aext = torch.empty(B, cout, centres, dtype=torch.int32, device=dev)
+                nat.conv1x1_gemm_affine_pool_wrapper(B, cout, cin, hw, relu, next_groups, pool, w, y_prev, a, bb,
+                                                     next_gamma.detach().contiguous(), y, stats, yext, aext)
+                extremes = (yext, aext)
+            else:
+                nat.conv1x1_gemm_affine_wrapper(B, cout, cin, hw, relu, next_groups, w, y_prev, a, bb, y, stats)
         else:
             nat.conv1x1_gemm_affine_wrapper(B, cout, cin, hw, relu, 0, w, y_prev, a, bb, y, None)
         ctx.save_for_backward(y_prev, gn_weight, gn_bias, conv_weight, mean, rstd, a, bb)
         ctx.cfg = (gn_groups, relu, hw)
+        if extremes is not None:
+            ctx.mark_non_differentiable(stats, *extremes)
+            return (y, stats) + extremes
         if stats is not None:
             ctx.mark_non_differentiable(stats)
         return y, stats
 
     @staticmethod
-    def backward(ctx, grad_y, _grad_stats=None):
+    def backward(ctx, grad_y, _grad_stats=None, *_grad_extremes):
         if grad_y is None:
-            return (None,) * 9
+            return (None,) * 11
         nat = _api._native
         y_prev, gn_weight, gn_bias, conv_weight, mean, rstd, a, bb = ctx.saved_tensors
         gn_groups, relu, hw = ctx.cfg
@@ -553,7 +573,7 @@ class _NormActConv(Function):
         ws = nat.group_norm_ws(B, cin, gn_groups, True, y_prev.device)
         nat.group_norm_bwd_wrapper(B, cin, hw, gn_groups, relu, y_prev, gn_weight.detach().contiguous(),
                                    gn_bias.detach().contiguous(), mean, rstd, grad_z, grad_prev, gw, gb, ws)
-        return grad_prev, None, gw, gb, grad_w.view_as(conv_weight), None, None, None, None
+        return grad_prev, None, gw, gb, grad_w.view_as(conv_weight), None, None, None, None, None, None
 
 
 def norm_act_conv_available(y_prev, gn, conv):
@@ -567,11 +587,17 @@ def norm_act_conv_available(y_prev, gn, conv):
     return _gemm_ok(y_prev.shape[1], hw)
 
 
-def norm_act_conv(y_prev, stats_prev, gn, relu, conv, next_gn=None):
-    """(y, stats of y for next_gn or None) = conv(act(gn(y_prev))), see _NormActConv."""
+def norm_act_conv(y_prev, stats_prev, gn, relu, conv, next_gn=None, pool=0):
+    """(y, stats of y for next_gn or None) = conv(act(gn(y_prev))), see _NormActConv.  pool = nsample (16, 32 or 64) on
+    the LAST layer of a set-abstraction MLP, y_prev (B, C, npoint, nsample): a third result, the extremes of y over
+    each neighbourhood for group_norm_act_maxpool (None when the kernel does not offer them for this shape)."""
     next_groups = next_gn.num_groups if (next_gn is not None and next_gn.affine) else 0
-    return _NormActConv.apply(y_prev, stats_prev, gn.weight, gn.bias, conv.weight, gn.num_groups, gn.eps, bool(relu),
-                              next_groups)
+    res = _NormActConv.apply(y_prev, stats_prev, gn.weight, gn.bias, conv.weight, gn.num_groups, gn.eps, bool(relu),
+                             next_groups, int(pool) if (pool in (16, 32, 64) and next_groups) else 0,
+                             next_gn.weight if next_groups else None)
+    if pool:
+        return res[0], res[1], (tuple(res[2:]) if len(res) > 2 else None)
+    return res[0], res[1]
 
 
 class _SelfAttentionCore(Function):

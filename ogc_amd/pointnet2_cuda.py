@@ -331,6 +331,24 @@ def conv1x1_gemm_affine_wrapper(b, M, K, hw, relu, groups, w, inp, pa, pb, out, 
          _f(pb, "pb"), _f(out, "out"), _opt(stats, torch.float64, "stats"))
 
 
+def conv1x1_gemm_affine_pool_wrapper(b, M, K, hw, relu, groups, nsample, w, inp, pa, pb, next_gamma, out, stats, yext,
+                                     aext):
+    """conv1x1_gemm_affine_wrapper with statistics, plus per neighbourhood the extreme of the raw output (largest where
+    next_gamma >= 0, smallest where it is negative) and its neighbour index (ogc_conv1x1_gemm_affine_pool);
+    hw = centres * nsample, nsample in {16, 32, 64}."""
+    _run("ogc_conv1x1_gemm_affine_pool", inp, b, M, K, hw, int(relu), int(groups), int(nsample), _f(w, "w"),
+         _f(inp, "in"), _f(pa, "pa"), _f(pb, "pb"), _f(next_gamma, "next_gamma"), _f(out, "out"),
+         _check(stats, torch.float64, "stats"), _f(yext, "yext"), _i(aext, "aext"))
+
+
+def group_norm_pool_extremes_wrapper(b, c, p, s, groups, eps, relu, yext, aext, gamma, beta, out, argmax, mean, rstd,
+                                     stats, slots):
+    """max over the neighbourhood of act(GroupNorm(x)) from the extremes of x (ogc_group_norm_pool_extremes)."""
+    _run("ogc_group_norm_pool_extremes", yext, b, c, p, s, groups, float(eps), int(relu), _f(yext, "yext"),
+         _i(aext, "aext"), _f(gamma, "gamma"), _f(beta, "beta"), _f(out, "out"), _i(argmax, "argmax"), _f(mean, "mean"),
+         _f(rstd, "rstd"), _check(stats, torch.float64, "stats"), int(slots))
+
+
 def conv1x1_wgrad_affine_wrapper(b, cin, cout, hw, relu, x, pa, pb, dy, dw):
     """Weight gradient with the operand act(pa * x + pb) recomputed on load (ogc_conv1x1_wgrad_affine)."""
     _run("ogc_conv1x1_wgrad_affine", x, b, cin, cout, hw, int(relu), _f(x, "x"), _f(pa, "pa"), _f(pb, "pb"),

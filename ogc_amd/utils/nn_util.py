@@ -175,12 +175,12 @@ def _shared_mlp_run(self, x, pool, first=None):
     abstraction level fuses it with the grouping, fused.grouped_first_layer); `x` is then unused."""
     from ..fused import (group_norm_act, group_norm_act_maxpool, norm_act_conv, norm_act_conv_available, pointwise_conv)
     layers = list(self.children())
-    pending = None  # (raw conv output, its GroupNorm statistics or None, the GroupNorm, relu?)
+    pending = None  # (raw conv output, its GroupNorm statistics or None, the GroupNorm, relu?, neighbourhood extremes)
 
     def flush(p, last):
-        y, stats, gn, relu = p
+        y, stats, gn, relu, extremes = p
         if last and pool:
-            return group_norm_act_maxpool(y, gn, relu, stats)
+            return group_norm_act_maxpool(y, gn, relu, stats, extremes)
         return group_norm_act(y, gn, relu, stats)
 
     for li, layer in enumerate(layers):
@@ -192,13 +192,20 @@ def _shared_mlp_run(self, x, pool, first=None):
             continue
         conv_name, norm_name, relu = layer._names
         conv, gn = getattr(layer, conv_name), getattr(layer, norm_name)[0]
+        extremes = None
         if pending is not None and norm_act_conv_available(pending[0], pending[2], conv):
-            y, stats = norm_act_conv(pending[0], pending[1], pending[2], pending[3], conv, gn)
+            if pool and li == len(layers) - 1 and pending[0].dim() == 4 and pending[0].shape[-1] in (16, 32, 64):
+                # last layer before the max over the neighbourhood: the convolution also leaves each neighbourhood's
+                # extremes, from which the pooled activation follows without reading its output again
+                y, stats, extremes = norm_act_conv(pending[0], pending[1], pending[2], pending[3], conv, gn,
+                                                   pool=pending[0].shape[-1])
+            else:
+                y, stats = norm_act_conv(pending[0], pending[1], pending[2], pending[3], conv, gn)
         else:
             if pending is not None:
                 x, pending = flush(pending, False), None
             y, stats = first(conv, gn) if (first is not None and li == 0) else pointwise_conv(x, conv, gn)
-        pending = (y, stats, gn, relu)
+        pending = (y, stats, gn, relu, extremes)
     if pending is not None:
         return flush(pending, True)
     return x.max(dim=-1)[0] if pool else x
