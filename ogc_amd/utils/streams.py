@@ -11,9 +11,6 @@ def side_stream(device, key="geometry", priority=0):
     """The process-wide side stream `key` of `device`; `priority` (-1 = high) applies when it is first created."""
     k = (torch.device(device).index, key)
     if k not in _side:
-        import os
-        if key in os.environ.get("OGC_HIPRIO", "").split(","):
-            priority = -1
         _side[k] = torch.cuda.Stream(device=device, priority=priority)
     return _side[k]
 
