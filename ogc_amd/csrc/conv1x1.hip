@@ -401,6 +401,11 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_gemm_kernel(int M,
                 const int seg = pool.s >> 2;                 // lanes per neighbourhood: 4, 8 or 16
                 const int centres = hw / pool.s;
                 const int centre = (p0 + 4 * j) / pool.s;    // of this lane's four positions
+                // outputs of row m0 + kk * 4 of this lane's centre; row a * 16 + r is (a * 16 + r) * centres further on
+                const size_t o0 = ((size_t)b * M + m0 + kk * 4) * centres + centre;
+                float *const ye = pool.yext + o0;
+                int *const ae = pool.aext + o0;
+                const bool writer = (j & (seg - 1)) == 0;
 #pragma unroll
                 for (int a = 0; a < 4; ++a) {
                     if (a < nblk) {
@@ -421,10 +426,10 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_gemm_kernel(int M,
                             idx = min(idx, ogc_dpp_u32<0x4E>(idx));
                             if (seg >= 8) idx = min(idx, ogc_dpp_u32<0x141>(idx));
                             if (seg >= 16) idx = min(idx, ogc_dpp_u32<0x140>(idx));
-                            if ((j & (seg - 1)) == 0 && m < M) {
-                                const size_t o = ((size_t)b * M + m) * centres + centre;
-                                pool.yext[o] = sg * hi;
-                                pool.aext[o] = (int)(idx & (unsigned)(pool.s - 1));   // index inside the neighbourhood
+                            if (writer && m < M) {
+                                const int o = (a * 16 + r) * centres;
+                                ye[o] = sg * hi;
+                                ae[o] = (int)(idx & (unsigned)(pool.s - 1));   // index inside the neighbourhood
                             }
                         }
                     }
