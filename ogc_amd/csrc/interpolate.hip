@@ -133,7 +133,8 @@ extern "C" int ogc_three_interpolate_grad(int b, int c, int n, int m, const floa
     OGC_REQUIRE((long long)b * c * n < (1ll << 31) && (long long)b * c * m < (1ll << 31),
                 "ogc_three_interpolate_grad: tensor exceeds 32-bit indexing");
     if (m <= 16384 && n >= 1024) { // LDS-privatised path: CC channel images of m floats within 64 KiB
-        int cc = 16384 / m;
+        int cc = 4096 / m;   // 16 KiB images (one channel when m > 4096): more workgroups per CU, see group_bwd
+        if (cc < 1) cc = 1;
         cc = cc >= 8 ? 8 : (cc >= 4 ? 4 : (cc >= 2 ? 2 : 1));
         while (cc > 1 && cc / 2 >= c) cc /= 2;
         const int chunks = ogc_divup(c, cc);
