@@ -243,11 +243,11 @@ int group_bwd(const char *name, int b, int c, int n, int T, const float *grad_ou
     const bool vec = (T % 4 == 0) && aligned16(idx) && aligned16(grad_out) && go_bstride % 4 == 0;
     // LDS-privatised path: the per-channel image (n floats) must fit a 64 KiB budget at least once
     if (vec && n <= 16384 && T >= 4096 && T % 16 == 0) {
-        // channels per workgroup: a 16 KiB image when more than one channel fits (one channel otherwise, up to 64 KiB).
-        // Small images mean more workgroups per CU: at C4, 8 channels x 2048 points (64 KiB) ran at 235 us per call,
-        // 2 channels at 179 us; 2 x 8192 points at 151 us, 1 x 8192 at 135 us (the index and rel rows a workgroup
-        // re-reads per channel group are small next to its share of the gradient tensor).
-        int cc = 4096 / n;
+        // channels per workgroup: one channel image of n floats (several only below 1024 points).  Small images mean
+        // more workgroups per CU: at C4, 8 channels x 2048 points (64 KiB) ran at 235 us per call, 2 channels at 179 us,
+        // 1 at 175 us; 2 x 8192 points at 151 us, 1 x 8192 at 135 us; 4 x 1024 at 231 us, 1 x 1024 at 175 us (the
+        // index and rel rows a workgroup re-reads per channel group are small next to its share of the gradient tensor).
+        int cc = 1024 / n;
         if (cc < 1) cc = 1;
         cc = cc >= 8 ? 8 : (cc >= 4 ? 4 : (cc >= 2 ? 2 : 1));
         while (cc > 1 && cc / 2 >= c) cc /= 2;
