@@ -18,6 +18,7 @@ Under DDP every rank normalises with its own BatchNorm statistics (no SyncBN), a
 import argparse
 import importlib
 import json
+import math
 import os
 import time
 
@@ -93,7 +94,7 @@ def main(argv=None):
     model_iters = cfg.get("model_iters", len(cfg["loss"]["iters_w"]))
 
     outdoor = cfg["dataset"] in ("kittisf", "waymo")
-    train_set = SyntheticScenes(args.synthetic, fl["npoint"], 8, outdoor, seed=1000 * (rank + 1))
+    train_set = SyntheticScenes(args.synthetic, fl["npoint"], 8, outdoor, seed=1000)  # one set on all ranks; the sampler shards it
     val_set = SyntheticScenes(max(args.synthetic // 8, cfg["batch_size"]), fl["npoint"], 8, outdoor, seed=7)
     sampler = torch.utils.data.distributed.DistributedSampler(train_set) if distributed else None
     train_loader = torch.utils.data.DataLoader(train_set, batch_size=cfg["batch_size"], shuffle=sampler is None,
@@ -105,6 +106,7 @@ def main(argv=None):
     exp_base = cfg["save_path"]
     if rank == 0:
         os.makedirs(exp_base, exist_ok=True)
+        save_checkpoint(net, exp_base, True)  # initial weights as current and best (train_flow.py:126-130)
 
     global_batch = cfg["batch_size"] * world
     it, best = 0, 1e10
@@ -116,7 +118,8 @@ def main(argv=None):
         def account(pending):
             if pending is not None:
                 for k, v in pending.result()[0].items():
-                    sums[k] = sums.get(k, 0.0) + v
+                    if math.isfinite(v):  # the reference's AverageMeter drops NaN values
+                        sums[k] = sums.get(k, 0.0) + v
 
         for cpu_batch in train_loader:
             seen = it * global_batch

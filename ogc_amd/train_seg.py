@@ -20,6 +20,7 @@ driver trains on seeded synthetic scenes with the loaders' sample contract (ogc_
 import argparse
 import importlib
 import json
+import math
 import os
 import shutil
 import time
@@ -32,6 +33,9 @@ from .train_step import build_criterion, make_optimizer, train_step
 from .utils.synthetic import make_scene_batch
 
 SEGNETS = {"sapien": "segnet_sapien", "ogcdr": "segnet_ogcdr", "kittisf": "segnet_kitti", "waymo": "segnet_kitti"}
+# ONE training set on every rank (DistributedSampler deals its scenes out): the flow store of oa_icp_round is keyed by
+# scene index, so all ranks — and the refinement round — must mean the same scene by the same index
+TRAIN_SEED = 1000
 NORM_LAYERS = (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d, torch.nn.BatchNorm3d, torch.nn.InstanceNorm1d,
                torch.nn.InstanceNorm2d, torch.nn.InstanceNorm3d, torch.nn.GroupNorm)
 
@@ -53,10 +57,24 @@ class SyntheticScenes(torch.utils.data.Dataset):
     def __len__(self):
         return self.n_scene
 
+    def stored_flows(self, i):
+        """The predicted flows of scene i as (2, N, 3), or None when the store has none for it."""
+        if self.predflow_dir is None:
+            return None
+        import numpy as np
+        paths = [os.path.join(self.predflow_dir, "%06d" % i, "flow%d.npy" % v) for v in (1, 2)]
+        if not all(os.path.exists(p) for p in paths):
+            return None
+        return torch.stack([torch.from_numpy(np.load(p)).float() for p in paths])
+
     def __getitem__(self, i):
+        # predicted flows first, augmentation second (datasets/dataset_kittisf.py:91-117): the augmented views carry
+        # the transformed PREDICTED flows, never the synthetic ground truth
         by_reference_recipe = self.aug_transform and self.aug_transform_args is not None
+        stored = self.stored_flows(i)
         pcs, segms, flows, valids = make_scene_batch(1, self.n_point, self.n_object, seed=self.seed + i,
-                                                     outdoor=self.outdoor, aug=self.aug_transform and not by_reference_recipe)
+                                                     outdoor=self.outdoor, aug=self.aug_transform and not by_reference_recipe,
+                                                     flows=None if stored is None else stored[None])
         pcs, segms, flows, valids = pcs[0], segms[0], flows[0], valids[0]
         if by_reference_recipe:
             import numpy as np
@@ -65,11 +83,6 @@ class SyntheticScenes(torch.utils.data.Dataset):
                                      self.aug_transform_args, rng=np.random.RandomState(self.seed + i))
             pcs, flows = torch.from_numpy(a.astype(np.float32)), torch.from_numpy(f.astype(np.float32))
             segms, valids = torch.cat([segms, segms]), torch.cat([valids, valids])
-        if self.predflow_dir is not None and not self.aug_transform:
-            import numpy as np
-            paths = [os.path.join(self.predflow_dir, "%06d" % i, "flow%d.npy" % v) for v in (1, 2)]
-            if all(os.path.exists(p) for p in paths):
-                flows = torch.stack([torch.from_numpy(np.load(p)).float() for p in paths])
         return pcs, segms, flows, valids
 
 
@@ -239,9 +252,9 @@ def main(argv=None):
         from .utils.flow_store import TRAIN_PAIRS
         assert not outdoor and args.frames == 4, "sequences are the SAPIEN / OGC-DR sample format (4 frames)"
         train_set = SyntheticSequenceScenes(args.synthetic, seg["n_point"], seg["n_slot"], TRAIN_PAIRS, args.frames,
-                                            seed=1000 * (rank + 1), predflow_dir=predflow_dir, aug_transform_args=aug_args)
+                                            seed=TRAIN_SEED, predflow_dir=predflow_dir, aug_transform_args=aug_args)
     else:
-        train_set = SyntheticScenes(args.synthetic, seg["n_point"], seg["n_slot"], outdoor, seed=1000 * (rank + 1),
+        train_set = SyntheticScenes(args.synthetic, seg["n_point"], seg["n_slot"], outdoor, seed=TRAIN_SEED,
                                     predflow_dir=predflow_dir, aug_transform_args=aug_args)
     val_set = SyntheticScenes(max(args.synthetic // 8, cfg["batch_size"]), seg["n_point"], seg["n_slot"], outdoor, seed=7)
     sampler = torch.utils.data.distributed.DistributedSampler(train_set) if distributed else None
@@ -272,7 +285,8 @@ def main(argv=None):
         def account(pending):
             if pending is not None:
                 for k, v in pending.result()[0].items():
-                    sums[k] = sums.get(k, 0.0) + v
+                    if math.isfinite(v):  # the reference's AverageMeter drops NaN values
+                        sums[k] = sums.get(k, 0.0) + v
 
         def device_batches():
             for cpu_batch in train_loader:

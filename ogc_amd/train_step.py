@@ -120,7 +120,14 @@ def train_step(segnet, criterion, optimizer, batch, it, aug_transform, sync=True
         upcoming = PrefetchedGeometry(segnet, criterion, next_batch, aug_transform)
     loss, losses = criterion(pcs_l, masks_l, flows_l, step_w=True, it=it * b, aug_transform=aug_transform, sync=False,
                              **kw)
-    loss.backward()
+    try:
+        loss.backward()
+    except RuntimeError:  # the reference returns without stepping (train_seg.py:75-78)
+        if _is_distributed(segnet):
+            raise  # a rank that leaves the step alone would hang the others in the gradient collective
+        pending = PendingStep(losses, HostScalars(torch.tensor([True])))
+        pending.prefetched = upcoming
+        return pending.result() if sync else pending
     _average_gradients(segnet)
     grads = [p.grad for p in segnet.parameters() if p.grad is not None]
     bad = torch.isnan(torch.stack(torch._foreach_norm(grads)).sum())  # NaN anywhere -> NaN norm
@@ -142,6 +149,10 @@ def train_step(segnet, criterion, optimizer, batch, it, aug_transform, sync=True
         pending = PendingStep(losses, HostScalars(torch.tensor([skip])))
     pending.prefetched = upcoming
     return pending.result() if sync else pending
+
+
+def _is_distributed(model):
+    return hasattr(model, "average_gradients") or isinstance(model, torch.nn.parallel.DistributedDataParallel)
 
 
 def _average_gradients(model):
@@ -187,7 +198,14 @@ def flow_train_step(flownet, criterion, optimizer, batch, model_iters, sync=True
         from .metrics.flow_metric import epe_terms
         extra = epe_terms(batch[2][:, 0], flow_preds)
     loss, losses = criterion(pc1, pc2, flow_preds, sync=False, extra=extra)
-    loss.backward()
+    try:
+        loss.backward()
+    except RuntimeError:  # train_flow.py:80-83: the step is skipped
+        if _is_distributed(flownet):
+            raise
+        from .utils.streams import HostScalars
+        pending = PendingStep(losses, HostScalars(torch.tensor([True])))
+        return pending.result() if sync else pending
     _average_gradients(flownet)
     net = flownet.module if hasattr(flownet, "module") else flownet
     pending = PendingStep(losses, _nan_safe_step(list(net.parameters()), optimizer))

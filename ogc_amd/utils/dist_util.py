@@ -52,19 +52,20 @@ class FlatDataParallel(nn.Module):
         """.grad <- mean over the ranks of .grad, for every parameter; one collective."""
         if self.world_size == 1 and not _always_reduce:
             return
-        owners = [p for p in self._params if p.grad is not None]
-        missing = [p for p in self._params if p.grad is None]
-        parts = [p.grad.reshape(-1) for p in owners] + [torch.zeros_like(p).reshape(-1) for p in missing]
+        # fixed parameter order on every rank, zeros in place of a missing gradient: the flat layouts agree even when
+        # a data-dependent branch left different parameters unused on different ranks
+        parts = [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self._params]
         flat = torch.cat(parts)
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.process_group)
         if self.world_size > 1:
             flat.mul_(1.0 / self.world_size)
-        sizes = [p.numel() for p in owners + missing]
-        views = flat.split(sizes)
-        for p, v in zip(missing, views[len(owners):]):
-            p.grad = v.view_as(p).clone()
+        views = [v.view_as(p) for v, p in zip(flat.split([p.numel() for p in self._params]), self._params)]
+        owners = [(p, v) for p, v in zip(self._params, views) if p.grad is not None]
+        for p, v in zip(self._params, views):
+            if p.grad is None:
+                p.grad = v.clone()
         if owners:
-            torch._foreach_copy_([p.grad for p in owners], [v.view_as(p) for v, p in zip(views, owners)])
+            torch._foreach_copy_([p.grad for p, _ in owners], [v for _, v in owners])
 
 
 _always_reduce = False

@@ -21,7 +21,9 @@ def _rot_y(angle):
     return R
 
 
-def make_scene_batch(B, N, K, seed=1234, outdoor=True, aug=False, device="cpu"):
+def make_scene_batch(B, N, K, seed=1234, outdoor=True, aug=False, device="cpu", flows=None):
+    """`flows` (B, 2, N, 3), when given, replaces the ground-truth flows of the two frames BEFORE the augmented views
+    are derived — predicted flows are loaded first and then augmented, as datasets/dataset_kittisf.py:91-117 does."""
     g = torch.Generator().manual_seed(seed)
     scale = torch.tensor([60.0, 4.0, 80.0]) if outdoor else torch.ones(3)
     max_shift, noise = (0.5, 0.01) if outdoor else (0.05, 0.002)
@@ -41,6 +43,8 @@ def make_scene_batch(B, N, K, seed=1234, outdoor=True, aug=False, device="cpu"):
     segm2 = segm1.gather(1, perm)
     flow2 = (-flow1).gather(1, perm[:, :, None].expand(-1, -1, 3))                    # backward flow of frame 2
 
+    if flows is not None:
+        flow1, flow2 = flows[:, 0].to(pc1), flows[:, 1].to(pc1)
     pcs, segms, flows = [pc1, pc2], [segm1, segm2], [flow1, flow2]
     if aug:
         s = 0.95 + 0.1 * torch.rand(B, 1, 1, generator=g)

@@ -90,3 +90,42 @@ def test_ddp_two_ranks_equal_single_process(tmp_path, kind):
         assert torch.equal(v, other[k]), k     # the replicas hold identical weights after the step
     for k, v in net.state_dict().items():
         torch.testing.assert_close(ddp_state[k], v, rtol=2e-4, atol=2e-6, msg=lambda m: "%s: %s" % (k, m))
+
+
+def _worker_unused(rank, world, port, out_dir):
+    """Rank 1 never touches `b` (its gradient stays None there); rank 0 never touches `c`."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ogc_amd.utils.dist_util import FlatDataParallel
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = torch.nn.Parameter(torch.ones(3))
+            self.b = torch.nn.Parameter(torch.ones(2, 2))
+            self.c = torch.nn.Parameter(torch.ones(5))
+
+        def forward(self, use_b):
+            return (self.a * 2).sum() + ((self.b * 3).sum() if use_b else (self.c * 7).sum())
+
+    net = Net()
+    dp = FlatDataParallel(net)
+    dp(rank == 0).backward()
+    dp.average_gradients()
+    torch.save({k: p.grad.clone() for k, p in net.named_parameters()}, os.path.join(out_dir, "g%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_flat_data_parallel_with_rank_dependent_unused_parameters(tmp_path):
+    """the flat buffer keeps the parameter order on every rank, so a parameter whose gradient is None on one
+    rank averages with the other rank's gradient of the SAME parameter."""
+    world, port = 2, 31000 + os.getpid() % 2000
+    mp.spawn(_worker_unused, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        g = torch.load(os.path.join(str(tmp_path), "g%d.pt" % r))
+        assert torch.equal(g["a"], torch.full((3,), 2.0))
+        assert torch.equal(g["b"], torch.full((2, 2), 1.5))
+        assert torch.equal(g["c"], torch.full((5,), 3.5))

@@ -180,3 +180,53 @@ def test_sequence_layout_train_refine_train_loop(tmp_path, monkeypatch, oracle, 
         flow_store.load_pair(out, "000001", (0, 2), flow_store.read_meta(out))
     train_seg.main([str(path), "--round", "2", "--synthetic", "2", "--device", "cpu", "--flow-root", root, "--frames", "4"])
     assert os.path.exists(os.path.join(cfg["save_path"] + "_R2", "best.pth.tar"))
+
+
+def test_stored_flows_are_loaded_before_augmentation(tmp_path):
+    """with augmentation on (aug_transform_epoch: 0 in the KITTI config) the dataset must hand out the
+    augmented PREDICTED flows (datasets/dataset_kittisf.py:91-117 loads them first), never the synthetic ground truth."""
+    import numpy as np
+    from ogc_amd import train_seg
+    from ogc_amd.utils.data_util import augment_transform
+    N, K = 64, 3
+    store = tmp_path / "flow_preds" / "flowstep3d"
+    rng = np.random.RandomState(5)
+    stored = rng.randn(2, N, 3).astype(np.float32)
+    os.makedirs(store / "000001")
+    for v in (1, 2):
+        np.save(store / "000001" / ("flow%d.npy" % v), stored[v - 1])
+    aug_args = CFG["data"]["aug_transform_args"]
+    # the reference's recipe: two similarity transforms of the pair
+    ds = train_seg.SyntheticScenes(2, N, K, False, seed=1000, predflow_dir=str(store), aug_transform_args=aug_args)
+    plain = ds[1]
+    np.testing.assert_array_equal(plain[2].numpy(), stored)
+    ds.aug_transform = True
+    pcs, segms, flows, valids = ds[1]
+    want_p, want_f = augment_transform(plain[0].numpy().astype(np.float64), stored.astype(np.float64), aug_args,
+                                       rng=np.random.RandomState(1000 + 1))
+    assert flows.shape == (4, N, 3)
+    np.testing.assert_array_equal(flows.numpy(), want_f.astype(np.float32))
+    np.testing.assert_array_equal(pcs.numpy(), want_p.astype(np.float32))
+    # the built-in recipe (no aug_transform_args): views 2, 3 are a similarity transform s*R of the STORED flows
+    ds2 = train_seg.SyntheticScenes(2, N, K, False, seed=1000, predflow_dir=str(store))
+    ds2.aug_transform = True
+    pcs, segms, flows, valids = ds2[1]
+    np.testing.assert_array_equal(flows[:2].numpy(), stored)
+    ratio = flows[2].norm(dim=-1) / torch.from_numpy(stored[0]).norm(dim=-1)
+    assert 0.95 <= float(ratio.min()) and float(ratio.max()) <= 1.05 and float(ratio.max() - ratio.min()) < 1e-5
+    gt = train_seg.SyntheticScenes(2, N, K, False, seed=1000)
+    gt.aug_transform = True
+    assert not torch.allclose(gt[1][2][2], flows[2])
+    # a scene without stored flows keeps the ground truth
+    torch.testing.assert_close(ds2[0][2], gt[0][2])
+
+
+def test_all_ranks_train_on_the_scenes_the_refinement_round_wrote(monkeypatch):
+    """the flow store is keyed by scene index, so every rank's training set and oa_icp_round must mean the
+    same scene by the same index (one seed, DistributedSampler shards)."""
+    import inspect
+    from ogc_amd import oa_icp_round, train_flow, train_seg
+    assert train_seg.TRAIN_SEED == 1000
+    src = inspect.getsource(train_seg.main) + inspect.getsource(train_flow.main)
+    assert "rank + 1" not in src
+    assert "seed=1000" in inspect.getsource(oa_icp_round.main)
