@@ -340,6 +340,81 @@ def gen_models():
         save("model_" + name, **out)
 
 
+def sha(t):
+    import hashlib
+    a = t.detach().cpu().numpy() if torch.is_tensor(t) else np.asarray(t)
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def gen_fullsize():
+    """BASELINE.json's config sizes, executed by the reference's Python on the oracle's operators (minutes of CPU):
+      * SHA-256 of the index tensors of the C4 / C5 / C3 / C2 geometry (FPS chains, kNN, ball query, 3-NN) —
+        SURVEY §8c's "config-sized index hashes";
+      * C2: segnet_ogcdr at n_point 4096 (B = 2), C5: segnet_kitti at n_point 16384 (B = 1): masks (every 16th point)
+        and parameter-gradient summaries;
+      * C3: flownet_kitti on an 8192-point pair (B = 1, 2 iterations, eval): flows (every 8th point)."""
+    import importlib
+    from pointnet2.pointnet2 import ball_query, furthest_point_sample, gather_nd, knn, three_nn
+    out = {}
+    hashes = {}
+
+    def geometry(tag, pc, levels, ks, loss_knn, loss_ball):
+        xyz = T(pc)
+        cur = xyz
+        for li, (npoint, k) in enumerate(zip(levels, ks)):
+            idx = furthest_point_sample(cur, npoint)
+            hashes["%s/fps%d" % (tag, li)] = sha(idx)
+            nxt = gather_nd(cur, idx.long())
+            if k:
+                d, ki = knn(k, nxt.contiguous(), cur.contiguous())
+                hashes["%s/knn%d" % (tag, li)] = sha(ki)
+                hashes["%s/knn%d_dist" % (tag, li)] = sha(d)
+            d3, i3 = three_nn(cur.contiguous(), nxt.contiguous())
+            hashes["%s/nn3_%d" % (tag, li)] = sha(i3)
+            cur = nxt.contiguous()
+        if loss_knn:
+            d, ki = knn(loss_knn[0], xyz, xyz)
+            hashes["%s/loss_knn" % tag] = sha(ki)
+        if loss_ball:
+            hashes["%s/loss_ball" % tag] = sha(ball_query(loss_ball[1], loss_ball[0], xyz, xyz))
+
+    geometry("C4", detgen.cloud(2, 8192, 81), [2048, 1024, 512], [64, 64, 64], (32, 1.0), (64, 2.0))
+    geometry("C5", detgen.cloud(1, 16384, 82), [4096, 2048, 1024], [64, 64, 64], (32, 1.0), (64, 2.0))
+    geometry("C2", detgen.cloud(2, 4096, 83, scale=(1, 1, 1)), [2048, 1024], [64, 64], (8, 0.02), (16, 0.04))
+    geometry("C3", detgen.cloud(1, 8192, 84), [4096, 2048, 1024, 512, 256], [32, 32, 32, 24, 16], None, None)
+    print("geometry hashes done", flush=True)
+
+    for tag, name, kw, N, B, scale in [("C2", "segnet_ogcdr", dict(n_slot=8, n_point=4096, transformer_embed_dim=128), 4096, 2, (1, 1, 1)),
+                                       ("C5", "segnet_kitti", dict(n_slot=10, n_point=16384, transformer_embed_dim=128), 16384, 1, (60, 4, 80))]:
+        mod = importlib.import_module("models." + name)
+        net = detgen.fill_module(mod.MaskFormer3D(**kw), 7)
+        pc = T(detgen.cloud(B, N, 85, scale=scale))
+        mask = net(pc, pc)
+        target = T(detgen.uniform(tuple(mask.shape), 86, 0.0, 1.0))
+        out["%s/mask" % tag] = mask.detach()[:, ::16].contiguous()
+        out["%s/mask_norm" % tag] = mask.detach().double().norm().reshape(1)
+        for k, v in grads_summary(net, ((mask - target) ** 2).mean()).items():
+            out["%s/%s" % (tag, k)] = v
+        print(tag, name, "done", flush=True)
+
+    mod = importlib.import_module("models.flownet_kitti")
+    net = detgen.fill_module(mod.FlowStep3D(npoint=8192, loc_flow_nn=16, loc_flow_rad=1.5), 8)
+    net.eval()
+    pc1 = T(detgen.cloud(1, 8192, 87))
+    pc2 = pc1 + T(detgen.uniform((1, 8192, 3), 88, -0.05, 0.05))
+    pc2 = pc2[:, torch.randperm(8192, generator=torch.Generator().manual_seed(5))].contiguous()
+    with torch.no_grad():
+        preds = net(pc1, pc2, pc1, pc2, iters=2)
+    out["C3/pc2"] = pc2
+    for i, p in enumerate(preds):
+        out["C3/flow%d" % i] = p[:, ::8].contiguous()
+        out["C3/flow%d_norm" % i] = p.double().norm().reshape(1)
+    print("C3 flownet_kitti done", flush=True)
+    out["hash_keys"] = np.array(sorted(hashes))
+    out["hash_vals"] = np.array([hashes[k] for k in sorted(hashes)])
+    save("fullsize", **{k: (v.detach().numpy() if torch.is_tensor(v) else v) for k, v in out.items()})
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "the reference tree is only present in the build container"
     install_shims()
@@ -361,3 +436,5 @@ if __name__ == "__main__":
         gen_vote()
     if "models" in which:
         gen_models()
+    if "fullsize" in which:
+        gen_fullsize()
