@@ -125,6 +125,8 @@ def main():
     for _ in range(a.warmup):
         pre = train_step(model, crit, opt, batch, it, True, sync=False, prefetched=pre, next_batch=batch).prefetched
     sync()
+    if hasattr(model, "time_collectives"):
+        model.time_collectives(True)
     with nat.LaunchTimer({"ogc_ball_query", "ogc_knn_clamped", "ogc_furthest_point_sampling",
                           "ogc_furthest_point_sampling_chain"}) as timer:
         t0 = time.perf_counter()
@@ -225,6 +227,11 @@ def main():
                 "note": "PMC counters summed over all kernels of a step; est_gbs doubles the reported fetch volume "
                         "(gfx950 tallies wide coalesced reads at half their bytes, MI355X_MICROARCH.md) and divides "
                         "by this run's step time: the step as a whole against the %.0f GB/s HBM peak" % HBM_PEAK_GBS}
+        if dist.is_initialized():
+            out["collective"] = {"backend": dist.get_backend(), "op": "all_reduce(SUM) of one flat fp32 gradient buffer per step",
+                                 "payload_bytes": model.payload_bytes(), "world": world,
+                                 "avg_ms": round(model.collective_ms() or 0.0, 4),
+                                 "note": "events on the launch stream around the collective, rank 0, inside the timed steps"}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.npoint)
         print(json.dumps(out), flush=True)

@@ -81,16 +81,19 @@ class GlobalCorrLayer(nn.Module):
             setattr(self, "fp%d" % i, PointNetFeaturePropogation(in_channel=mlp[-1], mlp=[]))
 
     def calc_corr_mat(self, pcloud1, pcloud2, feature1, feature2):
-        # pcloud (B, n, 3), feature (B, n, C) -> (B, n1, n2); reference flownet_kitti.py:53-65
-        eps = torch.exp(self.epsilon) + 0.03
-        distance_matrix = torch.sum(pcloud1 ** 2, -1, keepdim=True)
-        distance_matrix = distance_matrix + torch.sum(pcloud2 ** 2, -1, keepdim=True).transpose(1, 2)
-        distance_matrix = distance_matrix - 2 * torch.bmm(pcloud1, pcloud2.transpose(1, 2))
-        support = (distance_matrix < self.support_th).float()
-        feature1 = feature1 / torch.sqrt(torch.sum(feature1 ** 2, -1, keepdim=True) + 1e-8)
-        feature2 = feature2 / torch.sqrt(torch.sum(feature2 ** 2, -1, keepdim=True) + 1e-8)
-        C = 1.0 - torch.bmm(feature1, feature2.transpose(1, 2))
-        return torch.exp(-C / eps) * support
+        """Soft correspondence weights between the coarsest levels: pcloud (B, n, 3), feature (B, n, C) -> (B, n1, n2),
+        w_ij = exp(-(1 - cos(f1_i, f2_j)) / (e^epsilon + 0.03)) for pairs closer than sqrt(support_th), else 0.
+        Same arithmetic as the reference (flownet_kitti.py:53-65): squared distances in the expanded form
+        (|p|^2 + |q|^2) - 2 p.q with the inner products from one bmm, features normalised with the 1e-8 guard."""
+        temperature = self.epsilon.exp() + 0.03
+        sq1 = pcloud1.square().sum(-1, keepdim=True)                       # (B, n1, 1)
+        sq2 = pcloud2.square().sum(-1).unsqueeze(1)                        # (B, 1, n2)
+        gram = torch.bmm(pcloud1, pcloud2.transpose(1, 2))
+        within_reach = ((sq1 + sq2) - 2 * gram) < self.support_th
+        unit1 = feature1 / (feature1.square().sum(-1, keepdim=True) + 1e-8).sqrt()
+        unit2 = feature2 / (feature2.square().sum(-1, keepdim=True) + 1e-8).sqrt()
+        cosine_distance = 1.0 - torch.bmm(unit1, unit2.transpose(1, 2))
+        return torch.exp(-cosine_distance / temperature) * within_reach.to(cosine_distance.dtype)
 
     def forward(self, pc1_l_glob, pc2_l_glob, feats1_glob, feats2_glob):
         top = self.n_stage + 1  # index of the coarsest level in pc*_l_glob

@@ -128,8 +128,14 @@ class KNN(Function):
         m = known.size(1)
         dist2 = _new(unknown, (B, N, k), torch.float32)
         idx = _new(unknown, (B, N, k), torch.int32)
-        _native.knn_wrapper(B, N, m, k, unknown, known, dist2, idx)
         ctx.mark_non_differentiable(idx)
+        fused = getattr(_native, "knn_clamped_wrapper", None)
+        if fused is not None and unknown.is_cuda:
+            # the square root inside the search kernel (correctly rounded, like CUDA's sqrtf the reference's torch.sqrt
+            # runs; torch.sqrt on ROCm is not, so the distances would differ from the reference's in the last bit)
+            fused(B, N, m, k, -1.0, unknown, known, dist2, idx)
+            return dist2, idx
+        _native.knn_wrapper(B, N, m, k, unknown, known, dist2, idx)
         return torch.sqrt(dist2), idx
 
     @staticmethod

@@ -29,6 +29,7 @@ class FlatDataParallel(nn.Module):
         self.process_group = process_group
         self.world_size = dist.get_world_size(process_group)
         self._params = [p for p in module.parameters() if p.requires_grad]
+        self._events = None   # [(start, end)] around every collective when time_collectives() was called
         if broadcast and self.world_size > 1:
             self._broadcast([p.data for p in module.parameters()])
             bufs = [b.data for b in module.buffers() if b.is_floating_point()]
@@ -56,7 +57,14 @@ class FlatDataParallel(nn.Module):
         # a data-dependent branch left different parameters unused on different ranks
         parts = [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self._params]
         flat = torch.cat(parts)
+        timed = self._events is not None and flat.is_cuda
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.process_group)
+        if timed:
+            e1.record()
+            self._events.append((e0, e1))
         if self.world_size > 1:
             flat.mul_(1.0 / self.world_size)
         views = [v.view_as(p) for v, p in zip(flat.split([p.numel() for p in self._params]), self._params)]
@@ -66,6 +74,20 @@ class FlatDataParallel(nn.Module):
                 p.grad = v.clone()
         if owners:
             torch._foreach_copy_([p.grad for p, _ in owners], [v for _, v in owners])
+
+
+    def payload_bytes(self):
+        return sum(p.numel() * p.element_size() for p in self._params)
+
+    def time_collectives(self, on=True):
+        """Bracket every gradient all-reduce with events on the launch stream (benchmark reporting)."""
+        self._events = [] if on else None
+
+    def collective_ms(self):
+        """Mean duration of the timed all-reduces (call after a device synchronisation); None if none were timed."""
+        if not self._events:
+            return None
+        return sum(a.elapsed_time(b) for a, b in self._events) / len(self._events)
 
 
 _always_reduce = False

@@ -340,6 +340,21 @@ def gen_models():
         save("model_" + name, **out)
 
 
+def gen_data_ops():
+    """utils/data_util.py:8-38 — fps_downsample (numpy cloud -> FPS indices) and upsample_feat (3-NN inverse-distance
+    upsampling of per-point features), executed by the reference's functions on the oracle's operators."""
+    from utils.data_util import fps_downsample, upsample_feat
+    pc = detgen.cloud(1, 3000, 91)[0]
+    pc[100:140] = pc[:40]                                   # duplicated points: FPS ties
+    idx = fps_downsample(pc, n_sample_point=512)
+    pcs = T(detgen.cloud(2, 1500, 92))
+    sub = pcs[:, ::5].contiguous()
+    sub[:, :7] = pcs[:, :7]                                 # coincident points: zero distances -> the 1e-8 guard
+    feat = T(detgen.uniform((2, 300, 6), 93))
+    up = upsample_feat(pcs, sub, feat)
+    save("data_ops", fps_idx=idx, up_feat=up.numpy())
+
+
 def sha(t):
     import hashlib
     a = t.detach().cpu().numpy() if torch.is_tensor(t) else np.asarray(t)
@@ -438,3 +453,5 @@ if __name__ == "__main__":
         gen_models()
     if "fullsize" in which:
         gen_fullsize()
+    if "data_ops" in which:
+        gen_data_ops()

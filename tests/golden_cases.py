@@ -489,3 +489,22 @@ def run_global_corr(dev, name, npoint, n_level, feat_c, scale, rtol=1e-5, atol=1
         else:   # gradients; epsilon's is a single cancelling sum (the reference's own fp32 run is 8e-6 off on it)
             budget.add(key + k, v, g[key + k], t[key + k], 1e-4 if k == "g_eps" else 5e-6)
     return budget
+
+
+def run_data_ops(dev):
+    """fps_downsample / upsample_feat (reference utils/data_util.py:8-38; fixture data_ops.npz made by its functions)."""
+    from ogc_amd.utils.data_util import fps_downsample, upsample_feat
+    g = load("data_ops")
+    pc = detgen.cloud(1, 3000, 91)[0]
+    pc[100:140] = pc[:40]
+    idx = fps_downsample(pc, n_sample_point=512, device=dev)
+    assert isinstance(idx, np.ndarray) and idx.shape == (512,)
+    exact(idx, g["fps_idx"], "fps_downsample")
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    pcs = T(detgen.cloud(2, 1500, 92))
+    sub = pcs[:, ::5].contiguous()
+    sub[:, :7] = pcs[:, :7]
+    feat = T(detgen.uniform((2, 300, 6), 93))
+    up = upsample_feat(pcs, sub, feat)
+    assert up.shape == (2, 1500, 6)
+    close(up, g["up_feat"], 1e-5, 1e-6, "upsample_feat")

@@ -1,0 +1,136 @@
+"""The drivers on the MI355X with the HIP operators (SURVEY §8 f1 / f2 / e): train_seg.main, train_flow.main and the
+train -> OA-ICP refinement -> train loop through the on-disk flow store, at the real config shapes (C4: 8192-point
+KITTI-style scenes) for a few steps; and bench.py under a one-process torch.distributed launcher so that the RCCL code
+path (process-group init, FlatDataParallel, the flat all-reduce, barrier + MAX timing) is executed on the GPU box."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+import golden_cases as gc
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(autouse=True)
+def _hip():
+    assert torch.cuda.is_available()
+    import ogc_amd  # noqa: F401
+
+
+def _cfg(name, tmp_path, **over):
+    with open(os.path.join(ROOT, "config", name)) as f:
+        cfg = yaml.safe_load(f)
+    cfg.update(over)
+    cfg["save_path"] = str(tmp_path / "ckpt" / "run")
+    os.makedirs(tmp_path / "ckpt", exist_ok=True)
+    path = tmp_path / "cfg.yaml"
+    path.write_text(yaml.safe_dump(cfg))
+    return cfg, str(path)
+
+
+def _json_lines(capsys):
+    return [json.loads(l) for l in capsys.readouterr().out.splitlines() if l.startswith("{")]
+
+
+def test_train_seg_main_c4(tmp_path, capsys):
+    """config/kittisf_unsup_synthetic.yaml (C4: batch 4 x 4 views x 8192 points, augmentation on from epoch 1) for three
+    steps: finite losses, the reference's loss_dict keys, checkpoints holding exactly the reference's state_dict keys."""
+    from ogc_amd import train_seg
+    cfg, path = _cfg("kittisf_unsup_synthetic.yaml", tmp_path, epochs=1)
+    train_seg.main([path, "--round", "1", "--synthetic", "12", "--max-iters", "3"])
+    line = _json_lines(capsys)[-1]
+    assert line["it"] == 3 and line["aug"] is True
+    assert set(line["train"]) == {"dynamic", "smooth", "invariance", "entropy", "rank", "sum"}
+    assert all(np.isfinite(v) for v in line["train"].values()) and np.isfinite(line["val_loss"])
+    assert set(line["val"]) == {"AP", "PQ", "F1", "Pre", "Rec"}
+    want = [str(k) for k in gc.load("model_segnet_kitti")["state_keys"]]
+    for name in ("current.pth.tar", "best.pth.tar"):
+        state = torch.load(os.path.join(cfg["save_path"] + "_R1", name))
+        assert list(state) == ["model_state"] and sorted(state["model_state"]) == want
+    # the weights moved
+    init = torch.load(os.path.join(cfg["save_path"] + "_R1", "best.pth.tar"))["model_state"]
+    cur = torch.load(os.path.join(cfg["save_path"] + "_R1", "current.pth.tar"))["model_state"]
+    assert any(not torch.equal(init[k], cur[k]) for k in init) or line["val_loss"] < 1e10
+
+
+def test_train_flow_main_c3(tmp_path, capsys):
+    """config/kittisf_flow_synthetic.yaml (C3: FlowStep3D on 8192-point pairs) for two steps."""
+    from ogc_amd import train_flow
+    cfg, path = _cfg("kittisf_flow_synthetic.yaml", tmp_path, epochs=1, batch_size=1, model_iters=2)
+    cfg["loss"]["iters_w"] = cfg["loss"]["iters_w"][:2]
+    with open(path, "w") as f:
+        yaml.safe_dump(cfg, f)
+    train_flow.main([path, "--synthetic", "4", "--max-iters", "2"])
+    line = _json_lines(capsys)[-1]
+    assert line["it"] == 2
+    assert {"chamfer_loss_#0", "smooth_loss_#0", "chamfer_loss_#1", "smooth_loss_#1", "sum"} <= set(line["train"])
+    assert all(np.isfinite(v) for v in line["train"].values()) and np.isfinite(line["val_loss"])
+    want = [str(k) for k in gc.load("model_flownet_kitti")["state_keys"]]
+    for name in ("current.pth.tar", "best.pth.tar"):
+        state = torch.load(os.path.join(cfg["save_path"], name))
+        assert sorted(state["model_state"]) == want
+
+
+def test_train_refine_train_round_trip(tmp_path, capsys):
+    """Round 1 training -> oa_icp_round (HIP soft-NN, weighted Kabsch; flows written in the KITTI layout) -> round 2
+    training that reads them back through --flow-root, with augmentation on (the stored flows are what gets augmented)."""
+    from ogc_amd import oa_icp_round, train_seg
+    cfg, path = _cfg("kittisf_unsup_synthetic.yaml", tmp_path, epochs=1)
+    cfg["segnet"]["n_point"] = 2048
+    with open(path, "w") as f:
+        yaml.safe_dump(cfg, f)
+    root = str(tmp_path / "data")
+    train_seg.main([path, "--round", "1", "--synthetic", "4", "--max-iters", "1"])
+    rep = oa_icp_round.main([path, "--round", "1", "--synthetic", "4", "--save", "--flow-root", root, "--test_batch_size", "4"])
+    assert rep["icp_iter"] == 20 and rep["pairs"] == 8
+    m = rep["metrics"]
+    assert all(np.isfinite(v) for k in m for v in m[k].values())
+    assert m["oa_icp"]["EPE"] <= m["input"]["EPE"] + 1e-3       # refinement does not make the noisy flows worse
+    out = os.path.join(root, "flow_preds", "flowstep3d_R1")
+    stored = np.stack([np.load(os.path.join(out, "000002", "flow%d.npy" % v)) for v in (1, 2)])
+    assert stored.shape == (2, 2048, 3) and stored.dtype == np.float32 and np.isfinite(stored).all()
+    ds = train_seg.SyntheticScenes(4, 2048, cfg["segnet"]["n_slot"], True, seed=train_seg.TRAIN_SEED, predflow_dir=out)
+    ds.aug_transform = True
+    np.testing.assert_array_equal(ds[2][2][:2].numpy(), stored)
+    capsys.readouterr()
+    train_seg.main([path, "--round", "2", "--synthetic", "4", "--max-iters", "1", "--flow-root", root])
+    line = _json_lines(capsys)[-1]
+    assert all(np.isfinite(v) for v in line["train"].values())
+    assert os.path.exists(os.path.join(cfg["save_path"] + "_R2", "best.pth.tar"))
+
+
+def _bench(args, launcher):
+    cmd = [sys.executable]
+    if launcher:
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                "--master-port", str(29500 + os.getpid() % 1000)]
+    cmd += [os.path.join(ROOT, "bench.py")] + args
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.timeout(1800)
+def test_bench_under_one_process_rccl_launcher():
+    """`python -m torch.distributed.run --nproc-per-node 1 bench.py --gpus 1`: backend nccl (= RCCL), FlatDataParallel with
+    the collective forced on, barrier + MAX-over-ranks timing.  The JSON line must parse, carry the collective's
+    payload, and the step must cost what the un-launched step costs (the all-reduce of 2.4 MB is tens of microseconds)."""
+    args = ["--gpus", "1", "--steps", "6", "--warmup", "3", "--no-cpu-baseline"]
+    plain = _bench(args, launcher=False)
+    dist_ = _bench(args, launcher=True)
+    for r in (plain, dist_):
+        assert r["n_gpus"] == 1 and r["steps"] == 6 and r["unit"] == "point-clouds/s" and r["scaling"] == "weak"
+        assert r["config"]["optimizer_stepped"] is True
+    assert dist_["collective"]["backend"] == "nccl" and dist_["collective"]["payload_bytes"] == 4 * 597248
+    assert dist_["collective"]["avg_ms"] > 0
+    assert dist_["ms_per_step"] <= 1.10 * plain["ms_per_step"] + 0.3, (dist_["ms_per_step"], plain["ms_per_step"])

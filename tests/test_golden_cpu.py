@@ -27,6 +27,15 @@ def test_losses_and_oa_icp(cpu_ops):
     gc.run_losses("cpu")
 
 
+def test_data_ops(cpu_ops):
+    gc.run_data_ops("cpu")
+
+
+@pytest.mark.parametrize("name,npoint,n_level,feat_c,scale", gc.GCORR_CASES, ids=[c[0] for c in gc.GCORR_CASES])
+def test_global_corr_layer(cpu_ops, name, npoint, n_level, feat_c, scale):
+    gc.run_global_corr("cpu", name, npoint, n_level, feat_c, scale).check()
+
+
 def test_data_util_helpers():
     """augment_transform (same numpy seed -> same augmentations) and the label helpers vs the reference's own."""
     import numpy as np
