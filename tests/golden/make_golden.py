@@ -383,7 +383,11 @@ def gen_fullsize():
             if k:
                 d, ki = knn(k, nxt.contiguous(), cur.contiguous())
                 hashes["%s/knn%d" % (tag, li)] = sha(ki)
-                hashes["%s/knn%d_dist" % (tag, li)] = sha(d)
+                # torch's CPU sqrt is a vectorised approximation (differs from IEEE in the last bit on some inputs);
+                # the reference runs torch.sqrt on CUDA, which is correctly rounded — so the distances to pin are the
+                # IEEE square roots of the kernel's squared distances
+                d2 = orc.knn(k, nxt.contiguous().numpy(), cur.contiguous().numpy())[0]
+                hashes["%s/knn%d_dist" % (tag, li)] = sha(np.sqrt(d2))
             d3, i3 = three_nn(cur.contiguous(), nxt.contiguous())
             hashes["%s/nn3_%d" % (tag, li)] = sha(i3)
             cur = nxt.contiguous()

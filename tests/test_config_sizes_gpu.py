@@ -85,7 +85,7 @@ def test_segnet_at_config_size(tag, name, kw, N, B, scale):
     mask = net(pc, pc)
     # two fp32 evaluations of the same function: each is ~1e-6 (relative L2) from the exact result (test_truth_f64_gpu)
     assert gc.rel_l2(mask[:, ::16], g[tag + "/mask"]) < 5e-6
-    assert abs(float(mask.double().norm()) / float(g[tag + "/mask_norm"][0]) - 1.0) < 1e-6
+    assert abs(float(mask.detach().double().norm()) / float(g[tag + "/mask_norm"][0]) - 1.0) < 1e-6
     gc.close(mask[:, ::16], g[tag + "/mask"], 2e-4, 2e-6, tag + "/mask")
     target = T(detgen.uniform(tuple(mask.shape), 86, 0.0, 1.0))
     net.zero_grad()
