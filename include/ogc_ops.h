@@ -142,7 +142,11 @@ int ogc_ball_query(int b, int n, int m, float radius, int nsample, const float *
  *     dist = sqrt(dist2); idx[dist > radius] = idx[..., 0]
  * One launch, no host synchronisation (the reference's boolean-mask assignment syncs).
  * dist (b,n,k) receives sqrt(dist2) (what KNN.forward returns, pointnet2.py:103), idx the
- * clamped indices.  radius < 0 means "no clamp" (QueryAndGroup radius=None). */
+ * clamped indices.  radius < 0 means "no clamp" (QueryAndGroup radius=None).
+ * Entries whose index was clamped carry dist = +inf (every reference caller discards the
+ * distances after the clamp): with radius >= 0 the search is RADIUS-LIMITED — it stops as
+ * soon as the scanned cells cover the radius and the nearest neighbour is known, instead of
+ * collecting all k neighbours first (C4's smoothness term: k = 32, r = 1 m holds ~2 points). */
 int ogc_knn_clamped(int b, int n, int m, int k, float radius, const float *unknown,
                     const float *known, float *dist, int *idx, ogc_stream_t stream);
 

@@ -54,6 +54,15 @@ __device__ __forceinline__ GridHdr grid_header(const float (&lo)[3], const float
         const double block = dims == 3 ? 27.0 : (dims == 2 ? 9.0 : 3.0);
         const double per_cell = fmax(2.5 * (double)knn_k / block, 1.0);
         edge = dims > 0 ? pow(vol * per_cell / (double)max(n, 1), 1.0 / (double)dims) : 1.0;
+        // radius-clamped search (ogc_knn_clamped): neighbours beyond `radius` are replaced by the nearest one anyway,
+        // so the search may stop once the scanned block covers the radius.  When the radius is SHORTER than the
+        // density-based edge, cells of edge 1.01 r make that one shell of far fewer candidates (but never less than
+        // ~one point per cell: the nearest neighbour of a query in an empty region must still be found by shells).
+        if (radius > 0.0f && radius < 3.0e38f && dims > 0) {
+            const double one_per_cell = pow(vol / (double)max(n, 1), 1.0 / (double)dims);
+            const double limited = fmax((double)radius * 1.01, one_per_cell);
+            if (limited < edge) edge = limited;
+        }
     }
     if (!(edge > 0.0) || !isfinite(edge)) edge = fmax(maxext, 1.0);      // degenerate: one cell per axis
     edge = fmax(edge, maxext * 1e-6);                                    // keep the quotient well inside int range
@@ -533,6 +542,7 @@ __device__ __forceinline__ u64 shfl_u64(u64 v, int src) {
 // a candidate is admitted iff its key is below that maximum (strict '<' on (distance, index)), exactly the
 // reference's rule whatever the order in which candidates are met.
 // MODE 0: squared distances (ogc_knn).  MODE 1: sqrt + radius clamp of the indices (ogc_knn_clamped).
+constexpr int KNN_FLAT_CAP = 96; // positions of the first shell kept as one flat list per query (else: run by run)
 template <int MODE>
 __global__ __launch_bounds__(OGC_WAVE) void knn_grid_kernel(int n, int m, int k, float radius, int stride_cells,
                                                             const float *__restrict__ unknown,
@@ -545,6 +555,7 @@ __global__ __launch_bounds__(OGC_WAVE) void knn_grid_kernel(int n, int m, int k,
     const int sub = lane & (SUB - 1), qi = lane >> 3;
     u64 *kept = kq_smem + (size_t)qi * k;           // [QPW][k]
     u64 *outk = kq_smem + (size_t)(QPW + qi) * k;   // [QPW][k]
+    int *flat = reinterpret_cast<int *>(kq_smem + (size_t)2 * QPW * k); // [QPW][KNN_FLAT_CAP] positions of the first shell
     const int p = blockIdx.x * QPW + qi;
     const GridHdr h = hdrs[b];
     const int *cs = cell_start + (size_t)b * stride_cells;
@@ -558,6 +569,23 @@ __global__ __launch_bounds__(OGC_WAVE) void knn_grid_kernel(int n, int m, int k,
     }
     int cnt = 0, maxpos = 0;
     u64 maxkey = 0;
+    // Radius-limited search (MODE 1 with a radius): a neighbour beyond the radius is replaced by the nearest one in the
+    // output whatever it is, so only candidates WITHIN the radius are kept (in C4's smoothness term ~2 of the ~27 a
+    // block holds — the kept set, its maximum tracking and the final rank sort shrink accordingly); the nearest
+    // candidate of all is tracked on the side for the rows that have nobody within the radius.
+    // within  <=>  sqrtf(d2) <= radius  <=>  d2 <= lim2, lim2 = the largest float whose (correctly rounded) root is
+    // <= radius (sqrtf is monotone), found among the neighbours of radius^2.
+    const bool limited = MODE == 1 && radius >= 0.0f;
+    float lim2 = INFINITY;
+    if (limited) {
+        lim2 = radius * radius;
+        while (lim2 > 0.0f && sqrtf(lim2) > radius) lim2 = __uint_as_float(__float_as_uint(lim2) - 1u);
+        for (int it = 0; it < 4; ++it) {
+            const float up = __uint_as_float(__float_as_uint(lim2) + 1u);
+            if (up < INFINITY && sqrtf(up) <= radius) lim2 = up;
+        }
+    }
+    u64 best_any = ~0ull; // per lane: the smallest key this lane has seen (limited mode)
     auto rescan_max = [&]() {
         u64 mk = 0;
         int mp = 0;
@@ -574,41 +602,50 @@ __global__ __launch_bounds__(OGC_WAVE) void knn_grid_kernel(int n, int m, int k,
         maxkey = mk;
         maxpos = mp;
     };
+    // one round of the scan: the group's lane `sub` holds candidate `cand` (valid or not)
+    auto consider = [&](bool valid, const float4 cand) {
+        bool adm = false;
+        u64 key = 0;
+        if (valid) {
+            const float d = ogc_sqdist(qx, qy, qz, cand.x, cand.y, cand.z);
+            if (d < INFINITY) { // NaN / inf are never selected
+                key = ((u64)__float_as_uint(d) << 32) | (unsigned)__float_as_int(cand.w);
+                adm = cnt < k || key < maxkey;
+                if (limited) {
+                    best_any = key < best_any ? key : best_any;
+                    adm = adm && d <= lim2;
+                }
+            }
+        }
+        const u64 ball = __builtin_amdgcn_ballot_w64(adm);
+        if (ball == 0) return;
+        const unsigned slice = (unsigned)(ball >> (qi * SUB)) & 0xFFu;
+        if (slice == 0) return;
+        const int nh = __popc(slice);
+        if (cnt + nh <= k) {
+            if (adm) kept[cnt + __popc(slice & below)] = key;
+            cnt += nh;
+            if (cnt == k) rescan_max();
+        } else {
+            for (int t = 0; t < SUB; ++t) {
+                if (!((slice >> t) & 1u)) continue;
+                const u64 kt = shfl_u64(key, qi * SUB + t);
+                if (cnt < k) {
+                    if (sub == 0) kept[cnt] = kt;
+                    if (++cnt == k) rescan_max();
+                } else if (kt < maxkey) {
+                    if (sub == 0) kept[maxpos] = kt;
+                    rescan_max();
+                }
+            }
+        }
+    };
     // scan the run [j0, j1) of the cell-sorted arrays with the 8 lanes of the group
     auto scan_run = [&](int j0, int j1) {
         for (int j = j0 + sub; __builtin_amdgcn_ballot_w64(j < j1) != 0; j += SUB) {
-            bool adm = false;
-            u64 key = 0;
-            if (j < j1) {
-                const float4 cand = pts[j];
-                const float d = ogc_sqdist(qx, qy, qz, cand.x, cand.y, cand.z);
-                if (d < INFINITY) { // NaN / inf are never selected
-                    key = ((u64)__float_as_uint(d) << 32) | (unsigned)__float_as_int(cand.w);
-                    adm = cnt < k || key < maxkey;
-                }
-            }
-            const u64 ball = __builtin_amdgcn_ballot_w64(adm);
-            if (ball == 0) continue;
-            const unsigned slice = (unsigned)(ball >> (qi * SUB)) & 0xFFu;
-            if (slice == 0) continue;
-            const int nh = __popc(slice);
-            if (cnt + nh <= k) {
-                if (adm) kept[cnt + __popc(slice & below)] = key;
-                cnt += nh;
-                if (cnt == k) rescan_max();
-            } else {
-                for (int t = 0; t < SUB; ++t) {
-                    if (!((slice >> t) & 1u)) continue;
-                    const u64 kt = shfl_u64(key, qi * SUB + t);
-                    if (cnt < k) {
-                        if (sub == 0) kept[cnt] = kt;
-                        if (++cnt == k) rescan_max();
-                    } else if (kt < maxkey) {
-                        if (sub == 0) kept[maxpos] = kt;
-                        rescan_max();
-                    }
-                }
-            }
+            float4 cand = make_float4(NAN, NAN, NAN, 0.f);
+            if (j < j1) cand = pts[j];
+            consider(j < j1, cand);
         }
     };
 
@@ -621,21 +658,86 @@ __global__ __launch_bounds__(OGC_WAVE) void knn_grid_kernel(int n, int m, int k,
         const int rmax = max(max(max(cx, h.gx - 1 - cx), max(cy, h.gy - 1 - cy)), max(cz, h.gz - 1 - cz));
         for (int R = 1;; ++R) {
             const int xa = max(cx - R, 0), xb = min(cx + R, h.gx - 1);
-            for (int z = max(cz - R, 0); z <= min(cz + R, h.gz - 1); ++z)
-                for (int y = max(cy - R, 0); y <= min(cy + R, h.gy - 1); ++y) {
-                    const int rowc = h.gx * (y + h.gy * z);
-                    const bool face = R == 1 || z == cz - R || z == cz + R || y == cy - R || y == cy + R;
-                    if (face) { // the whole x-extent of this row belongs to shell R (for R = 1: the full 3^3 block)
-                        scan_run(cs[rowc + xa], cs[rowc + xb + 1]);
-                    } else {    // inner row: only the two end cells are new
-                        if (cx - R >= 0) scan_run(cs[rowc + cx - R], cs[rowc + cx - R + 1]);
-                        if (cx + R <= h.gx - 1) scan_run(cs[rowc + cx + R], cs[rowc + cx + R + 1]);
+            bool done_flat = false;
+            if (R == 1) {
+                // The 3^3 block is nine runs of the cell-sorted array; in a radius-limited search they hold two or three
+                // points each, so walking them one after the other is nine dependent (bounds -> records) round trips
+                // with most of the eight lanes idle.  Instead: the lanes fetch the bounds of all runs at once, write the
+                // record positions of the block as ONE flat list (LDS), and the group then scans that list eight
+                // candidates at a time with the next load in flight.
+                int j0 = 0, j1 = 0, j0b = 0, j1b = 0;
+                {
+                    const int z = cz + sub / 3 - 1, y = cy + sub % 3 - 1;
+                    if (z >= 0 && z < h.gz && y >= 0 && y < h.gy) {
+                        const int rowc = h.gx * (y + h.gy * z);
+                        j0 = cs[rowc + xa];
+                        j1 = cs[rowc + xb + 1];
+                    }
+                    if (sub == 0 && cz + 1 < h.gz && cy + 1 < h.gy) { // ninth run (y + 1, z + 1)
+                        const int rowc = h.gx * (cy + 1 + h.gy * (cz + 1));
+                        j0b = cs[rowc + xa];
+                        j1b = cs[rowc + xb + 1];
                     }
                 }
+                const int len = j1 - j0, lenb = j1b - j0b;
+                int incl = len;
+#pragma unroll
+                for (int off = 1; off < SUB; off <<= 1) {
+                    const int up = __shfl_up(incl, off, SUB);
+                    if (sub >= off) incl += up;
+                }
+                const int total8 = __shfl(incl, qi * SUB + SUB - 1, 64);
+                const int total = total8 + __shfl(lenb, qi * SUB, 64);
+                if (total <= KNN_FLAT_CAP) {
+                    int *mine = flat + qi * KNN_FLAT_CAP;
+                    for (int i = 0; i < len; ++i) mine[incl - len + i] = j0 + i;
+                    for (int i = 0; i < lenb; ++i) mine[total8 + i] = j0b + i;
+                    __builtin_amdgcn_s_waitcnt(0xc07f);
+                    __builtin_amdgcn_wave_barrier();
+                    const float4 nothing = make_float4(NAN, NAN, NAN, 0.f);
+                    int f = sub;
+                    float4 cur = nothing;
+                    if (f < total) cur = pts[mine[f]];
+                    while (__builtin_amdgcn_ballot_w64(f < total) != 0) {
+                        const int fn = f + SUB;
+                        float4 nxt = nothing;
+                        if (fn < total) nxt = pts[mine[fn]];
+                        consider(f < total, cur);
+                        cur = nxt;
+                        f = fn;
+                    }
+                    done_flat = true;
+                }
+            }
+            if (!done_flat) {
+                for (int z = max(cz - R, 0); z <= min(cz + R, h.gz - 1); ++z)
+                    for (int y = max(cy - R, 0); y <= min(cy + R, h.gy - 1); ++y) {
+                        const int rowc = h.gx * (y + h.gy * z);
+                        const bool face = R == 1 || z == cz - R || z == cz + R || y == cy - R || y == cy + R;
+                        if (face) { // the whole x-extent of this row belongs to shell R (for R = 1: the full 3^3 block)
+                            scan_run(cs[rowc + xa], cs[rowc + xb + 1]);
+                        } else {    // inner row: only the two end cells are new
+                            if (cx - R >= 0) scan_run(cs[rowc + cx - R], cs[rowc + cx - R + 1]);
+                            if (cx + R <= h.gx - 1) scan_run(cs[rowc + cx + R], cs[rowc + cx + R + 1]);
+                        }
+                    }
+            }
             if (R >= rmax) break; // the block covers the grid
+            const float cover = (float)R * edge * 0.999f;
             if (cnt == k) {
-                const float cover = (float)R * edge * 0.999f;
                 if (__uint_as_float((unsigned)(maxkey >> 32)) < cover * cover) break;
+            }
+            if (limited && cover >= radius) {
+                // every point within the radius has been seen (unseen points are farther than R * edge >= 1.001 r).
+                // Entry 0 must still be the true nearest neighbour: stop only when the nearest seen candidate lies
+                // inside the covered ball (always the case when somebody is within the radius).
+                u64 best = best_any;
+#pragma unroll
+                for (int off = 1; off < SUB; off <<= 1) {
+                    const u64 ob = shfl_xor_u64(best, off);
+                    best = ob < best ? ob : best;
+                }
+                if (best != ~0ull && __uint_as_float((unsigned)(best >> 32)) < cover * cover) break;
             }
         }
     }
@@ -650,7 +752,16 @@ __global__ __launch_bounds__(OGC_WAVE) void knn_grid_kernel(int n, int m, int k,
     __builtin_amdgcn_wave_barrier();
     if (p < n) {
         const size_t base = ((size_t)b * n + p) * k;
-        const int first = cnt > 0 ? (int)(unsigned)outk[0] : 0;
+        int first = cnt > 0 ? (int)(unsigned)outk[0] : 0;
+        if (limited && cnt == 0) { // nobody within the radius: every entry is the nearest neighbour of all
+            u64 best = best_any;
+#pragma unroll
+            for (int off = 1; off < SUB; off <<= 1) {
+                const u64 ob = shfl_xor_u64(best, off);
+                best = ob < best ? ob : best;
+            }
+            first = best != ~0ull ? (int)(unsigned)best : 0;
+        }
         for (int j = sub; j < k; j += SUB) {
             float d = INFINITY;
             int id = 0;
@@ -661,7 +772,7 @@ __global__ __launch_bounds__(OGC_WAVE) void knn_grid_kernel(int n, int m, int k,
             }
             if (MODE == 1) {
                 d = sqrtf(d);
-                if (d > radius && radius >= 0.0f) id = first;
+                if (d > radius && radius >= 0.0f) { id = first; d = INFINITY; } // clamped entries carry dist = +inf
             }
             dist_out[base + j] = d;
             idx_out[base + j] = id;
@@ -706,7 +817,7 @@ int ogc_ball_query_grid(int b, int n, int m, float radius, int nsample, const fl
 // k-NN over cell lists.  Returns OGC_OK after queueing build + query, or OGC_ERR_UNSUPPORTED (caller: all-pairs scan).
 int ogc_knn_grid(int mode, int b, int n, int m, int k, float radius, const float *unknown, const float *known,
                  float *dist, int *idx, hipStream_t s) {
-    const size_t lds = (size_t)2 * QPW * k * sizeof(u64);
+    const size_t lds = (size_t)2 * QPW * k * sizeof(u64) + (size_t)QPW * KNN_FLAT_CAP * sizeof(int);
     if (m < 1024 || m <= 4 * k || lds > 64 * 1024) return OGC_ERR_UNSUPPORTED;
     const int stride_cells = GRID_MAX_CELLS + 1;
     const size_t bytes_hdr = (sizeof(GridHdr) * b + 255) / 256 * 256;
@@ -717,7 +828,7 @@ int ogc_knn_grid(int mode, int b, int n, int m, int k, float radius, const float
     GridHdr *hdrs = reinterpret_cast<GridHdr *>(ws);
     int *cell_start = reinterpret_cast<int *>(ws + bytes_hdr);
     float4 *sorted_pts = reinterpret_cast<float4 *>(ws + bytes_hdr + bytes_cs);
-    launch_grid_build(b, m, 0.0f, k, stride_cells, known, hdrs, cell_start, sorted_pts, s);
+    launch_grid_build(b, m, mode == 1 ? radius : 0.0f, k, stride_cells, known, hdrs, cell_start, sorted_pts, s);
     dim3 grid(ogc_divup(n, QPW), b);
     if (mode == 1)
         hipLaunchKernelGGL(knn_grid_kernel<1>, grid, dim3(OGC_WAVE), lds, s, n, m, k, radius, stride_cells, unknown, hdrs,

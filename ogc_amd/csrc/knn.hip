@@ -174,7 +174,10 @@ __global__ __launch_bounds__(OGC_WAVE) void knn_heap_kernel(int n, int m, int k,
         }
         if (MODE == 1) {
             d = sqrtf(d); // IEEE-correct (hipcc default: -fhip-fp32-correctly-rounded-divide-sqrt)
-            if (d > radius && radius >= 0.0f) id = hs > 0 ? (int)(unsigned)heap[ql] : 0;
+            if (d > radius && radius >= 0.0f) { // clamped entries carry dist = +inf (see include/ogc_ops.h)
+                id = hs > 0 ? (int)(unsigned)heap[ql] : 0;
+                d = INFINITY;
+            }
         }
         dist_out[base + t] = d;
         idx_out[base + t] = id;

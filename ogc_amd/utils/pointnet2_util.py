@@ -41,12 +41,19 @@ class _PointnetSAModuleBase(nn.Module):
     def plan_neighbours(self, xyz, new_xyz):
         """Neighbour lists of every scale around the sampled centres."""
         knn, idx = {}, []
+        # one search per neighbourhood size, clamped at the LARGEST radius of the scales that share it: what lies beyond
+        # is replaced by the nearest neighbour in every one of them, and a radius-limited search stops early
+        reach = {}
+        for grouper in self.groupers:
+            if isinstance(grouper, QueryAndGroup):
+                r = reach.get(grouper.nsample, 0.0)
+                reach[grouper.nsample] = None if (r is None or grouper.radius is None) else max(r, grouper.radius)
         for grouper in self.groupers:
             if not isinstance(grouper, QueryAndGroup):
                 idx.append(None)
                 continue
             if grouper.nsample not in knn:
-                knn[grouper.nsample] = knn_radius_clamp(grouper.nsample, None, new_xyz, xyz)
+                knn[grouper.nsample] = knn_radius_clamp(grouper.nsample, reach[grouper.nsample], new_xyz, xyz)
             dist, nn_idx = knn[grouper.nsample]
             if grouper.radius is not None:  # the clamp of pointnet2.py:283-286, per scale
                 nn_idx = torch.where(dist > grouper.radius, nn_idx[:, :, :1], nn_idx)

@@ -104,7 +104,11 @@ def test_knn_rejects_bad_k(nat):
         nat.knn_wrapper(1, 4, 4, 0, pc, pc, d2, idx)
 
 
-@pytest.mark.parametrize("n,m,k,r", [(300, 1000, 16, 3.0), (2048, 2048, 16, 1.5), (100, 7, 10, 5.0), (64, 200, 8, None)])
+@pytest.mark.parametrize("n,m,k,r", [(300, 1000, 16, 3.0), (2048, 2048, 16, 1.5), (100, 7, 10, 5.0), (64, 200, 8, None),
+                                     # radius-limited searches over the cell lists: radius far below / around / above the
+                                     # k-th neighbour distance, queries == points and a disjoint query set, r = 0
+                                     (4096, 4096, 32, 1.0), (4096, 4096, 32, 2.5), (1024, 8192, 64, 2.0),
+                                     (2048, 8192, 64, 12.0), (3000, 5000, 8, 0.05), (2048, 4096, 16, 0.0)])
 def test_knn_clamped(nat, oracle, n, m, k, r):
     rng = np.random.default_rng(n + m)
     u, kn = cloud(rng, 2, n), cloud(rng, 2, m)
@@ -116,8 +120,52 @@ def test_knn_clamped(nat, oracle, n, m, k, r):
     if r is not None:
         first = np.repeat(idxr[:, :, :1], k, axis=2)
         idxr = np.where(distr > np.float32(r), first, idxr)
+        distr = np.where(distr > np.float32(r), np.float32(np.inf), distr)   # clamped entries carry +inf
     assert np.array_equal(idx.cpu().numpy(), idxr)
     assert np.array_equal(dist.cpu().numpy(), distr)
+
+
+def _clamped_reference(oracle, k, r, u, kn):
+    d2r, idxr = oracle.knn(k, u, kn)
+    distr = np.sqrt(d2r)
+    beyond = distr > np.float32(r)
+    first = np.repeat(idxr[:, :, :1], k, axis=2)
+    return np.where(beyond, np.float32(np.inf), distr), np.where(beyond, first, idxr)
+
+
+@pytest.mark.parametrize("case", ["queries_far_from_the_points", "clustered", "duplicates", "nonfinite", "c4_loss", "flat"])
+def test_knn_clamped_radius_limited_edge_cases(nat, oracle, case):
+    """The radius-limited search of ogc_knn_clamped must still return the TRUE nearest neighbour in entry 0 when nothing
+    lies within the radius (queries in empty regions, outside the bounding box), break ties by index, skip non-finite
+    points, and equal knn + clamp on the config's own shape (C4 smoothness term: k = 32, r = 1 m on 8192 points)."""
+    rng = np.random.default_rng(99)
+    k, r = 16, 1.5
+    if case == "queries_far_from_the_points":
+        kn = cloud(rng, 2, 4096)
+        u = cloud(rng, 2, 1500, scale=(200, 30, 240))          # most queries are metres away from every point
+    elif case == "clustered":
+        centres = cloud(rng, 2, 12)
+        kn = (centres[:, rng.integers(0, 12, 6000)] + rng.normal(0, 0.4, (2, 6000, 3))).astype(np.float32)
+        u = np.concatenate([kn[:, ::3], cloud(rng, 2, 500)], axis=1).copy()
+    elif case == "duplicates":
+        kn = cloud(rng, 2, 3000, dup=1500)
+        u = kn.copy()
+    elif case == "nonfinite":
+        kn = cloud(rng, 2, 2500)
+        kn[0, 7, 0] = np.nan; kn[1, 100, 2] = np.inf; kn[0, 900] = 3e19
+        u = cloud(rng, 2, 1100)
+        u[1, 5, 1] = np.nan
+    elif case == "c4_loss":
+        kn = cloud(rng, 2, 8192); u = kn; k, r = 32, 1.0
+    else:
+        kn = cloud(rng, 2, 4096, scale=(60, 0, 80)); u = kn[:, ::2].copy(); k, r = 24, 2.0
+    dist = torch.empty(2, u.shape[1], k, device=DEV)
+    idx = torch.empty(2, u.shape[1], k, dtype=torch.int32, device=DEV)
+    nat.knn_clamped_wrapper(2, u.shape[1], kn.shape[1], k, r, T(u), T(kn), dist, idx)
+    dr, ir = _clamped_reference(oracle, k, r, u, kn)
+    ok = ~np.isnan(u).any(-1)                                 # NaN queries: the reference's rows are unspecified garbage
+    assert np.array_equal(idx.cpu().numpy()[ok], ir[ok])
+    assert np.array_equal(dist.cpu().numpy()[ok], dr[ok])
 
 
 @pytest.mark.parametrize("n,m", [(37, 50), (1000, 3), (8192, 2048), (1, 2), (513, 1)])
@@ -320,6 +368,7 @@ def test_knn_clamped_equals_unfused_torch_path(nat):
     q = pc[:, ::2].contiguous()
     dist, idx = knn(32, q, pc)
     idx = torch.where(dist > 2.5, idx[:, :, :1], idx)
+    dist = torch.where(dist > 2.5, torch.full_like(dist, float("inf")), dist)
     d2 = torch.empty_like(dist)
     i2 = torch.empty_like(idx)
     nat.knn_clamped_wrapper(2, 2048, 4096, 32, 2.5, q, pc, d2, i2)

@@ -55,6 +55,16 @@ def main():
             byt = B * (12 * n + 12 * m + 8 * n * k)
             print("knn   B=%-3d n=%-6d m=%-6d k=%-3d %9.3f ms  %8.2f GB/s  %8.1f Gpair/s" %
                   (B, n, m, k, ms, byt / ms / 1e6, B * n * m / ms / 1e6))
+    if "knnc" in ops:   # kNN + radius clamp (ogc_knn_clamped) at the C4 shapes: loss term and the three SA levels
+        for (B, n, m, k, r) in [(16, 8192, 8192, 32, 1.0), (16, 2048, 8192, 64, 2.0), (16, 1024, 2048, 64, 4.0),
+                                (16, 512, 1024, 64, 8.0), (4, 16384, 16384, 32, 1.0), (16, 8192, 8192, 32, -1.0)]:
+            pc = cloud(B, m, g)
+            q = pc[:, :: m // n].contiguous()
+            d2 = torch.empty(B, n, k, device=DEV)
+            idx = torch.empty(B, n, k, dtype=torch.int32, device=DEV)
+            ms = timeit(lambda: nat.knn_clamped_wrapper(B, n, m, k, r, q, pc, d2, idx), a.iters)
+            byt = B * (12 * n + 12 * m + 8 * n * k)
+            print("knnc  B=%-3d n=%-6d m=%-6d k=%-3d r=%-4.1f %9.3f ms  %8.2f GB/s" % (B, n, m, k, r, ms, byt / ms / 1e6))
     if "nn3" in ops:
         for (B, n, m) in [(16, 8192, 2048), (16, 2048, 1024), (1, 100000, 8192)]:
             pc = cloud(B, m, g)

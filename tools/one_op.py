@@ -14,6 +14,9 @@ for _ in range(reps):
     elif op == "knn":
         d2 = torch.empty(B, 8192, 32, device="cuda"); idx = torch.empty(B, 8192, 32, dtype=torch.int32, device="cuda")
         nat.knn_wrapper(B, 8192, 8192, 32, pc, pc, d2, idx)
+    elif op == "knnc":   # C4 smoothness term: k = 32, clamp at 1 m
+        d2 = torch.empty(B, 8192, 32, device="cuda"); idx = torch.empty(B, 8192, 32, dtype=torch.int32, device="cuda")
+        nat.knn_clamped_wrapper(B, 8192, 8192, 32, 1.0, pc, pc, d2, idx)
     elif op == "fps":
         idx = torch.empty(B, 2048, dtype=torch.int32, device="cuda"); temp = torch.full((B, 8192), 1e10, device="cuda")
         nat.furthest_point_sampling_wrapper(B, 8192, 2048, pc, temp, idx)
