@@ -127,9 +127,11 @@ int ogc_group_points_grad(int b, int c, int n, int npoints, int nsample, const f
 /* ---- ball query ------------------------------------------------------------------------
  * replaces ball_query_wrapper(b, n, m, radius, nsample, new_xyz, xyz, idx)
  *   ball_query.cpp:16-27 -> ball_query_gpu.cu:9-66
- * xyz (b,n,3) candidates, new_xyz (b,m,3) centres, idx (b,m,nsample) pre-zeroed by the
- * caller (pointnet2.py:251).  Row = first nsample indices k (ascending) with
- * d2(k) < radius*radius, padded with the first hit; a centre with no hit gets an all-zero row. */
+ * xyz (b,n,3) candidates, new_xyz (b,m,3) centres, idx (b,m,nsample).  Row = first nsample
+ * indices k (ascending) with d2(k) < radius*radius, padded with the first hit; a centre with
+ * no hit gets an all-zero row.  The reference's kernel leaves such rows untouched and relies
+ * on the caller's pre-zeroed buffer (pointnet2.py:251); this one WRITES EVERY ROW, so idx may
+ * be uninitialised memory (a pre-zeroed buffer works unchanged). */
 int ogc_ball_query(int b, int n, int m, float radius, int nsample, const float *new_xyz,
                    const float *xyz, int *idx, ogc_stream_t stream);
 

@@ -95,6 +95,7 @@ __global__ __launch_bounds__(BUILD_THREADS) void grid_build_kernel(int n, float 
     __shared__ float s_red[6][BUILD_THREADS / 64];
     __shared__ int s_wave[BUILD_THREADS / 64];
     __shared__ int s_tail; // cursor for points left out of the grid (non-finite coordinates)
+    __shared__ GridHdr s_hdr;
     constexpr int R = PPT > 0 ? PPT : 1;
     const int t = threadIdx.x, b = blockIdx.x, lane = t & 63, wave = t >> 6;
     const float *pts = xyz + (size_t)b * n * 3;
@@ -130,18 +131,21 @@ __global__ __launch_bounds__(BUILD_THREADS) void grid_build_kernel(int n, float 
         if (lane == 0) { s_red[a][wave] = lo; s_red[3 + a][wave] = hi; }
     }
     __syncthreads();
-    float lo[3], hi[3];
+    // the grid parameters are derived ONCE (double-precision pow / cbrt / floor loops: hundreds of instructions that
+    // used to run on all 1024 threads of the one CU a cloud gets) and handed to the others through LDS
+    if (wave == 0) {
+        float lo[3], hi[3];
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        lo[a] = s_red[a][0];
-        hi[a] = s_red[3 + a][0];
-#pragma unroll
-        for (int w = 1; w < BUILD_THREADS / 64; ++w) {
-            lo[a] = fminf(lo[a], s_red[a][w]);
-            hi[a] = fmaxf(hi[a], s_red[3 + a][w]);
+        for (int a = 0; a < 3; ++a) {
+            const float l = lane < BUILD_THREADS / 64 ? s_red[a][lane] : INFINITY;
+            const float u = lane < BUILD_THREADS / 64 ? s_red[3 + a][lane] : -INFINITY;
+            lo[a] = -ogc_wave_max_f32(-l);
+            hi[a] = ogc_wave_max_f32(u);
         }
+        if (lane == 0) s_hdr = grid_header(lo, hi, n, radius, knn_k);
     }
-    GridHdr h = grid_header(lo, hi, n, radius, knn_k);
+    __syncthreads();
+    GridHdr h = s_hdr;
     const int ncell = h.gx * h.gy * h.gz;
     auto cell_of = [&](float x, float y, float z) -> int {
         if (!(isfinite(x) && isfinite(y) && isfinite(z))) return -1;

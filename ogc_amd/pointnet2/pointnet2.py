@@ -259,7 +259,11 @@ class BallQuery(Function):
         assert xyz.is_contiguous()
         B, N, _ = xyz.size()
         npoint = new_xyz.size(1)
-        idx = _new(xyz, (B, npoint, nsample), torch.int32, fill=0)  # pointnet2.py:251
+        # the reference pre-zeroes idx (pointnet2.py:251) because its kernel leaves rows without a hit untouched; the
+        # HIP kernels write every row themselves (empty rows as zeros), so on the GPU the 4 * npoint * nsample byte
+        # fill (32 MB and a launch per call at C4) is skipped
+        writes_all = getattr(_native, "BALL_QUERY_WRITES_ALL_ROWS", False) and xyz.is_cuda and B * npoint * nsample > 0
+        idx = _new(xyz, (B, npoint, nsample), torch.int32, fill=None if writes_all else 0)
         _native.ball_query_wrapper(B, N, npoint, radius, nsample, new_xyz, xyz, idx)
         ctx.mark_non_differentiable(idx)
         return idx

@@ -148,6 +148,10 @@ def three_interpolate_grad_wrapper(b, c, n, m, grad_out, idx, weight, grad_point
          _f(weight, "weight"), _f(grad_points, "grad_points"))
 
 
+# ogc_ball_query writes every row of idx itself (rows without a hit as zeros): callers need not pre-zero it
+BALL_QUERY_WRITES_ALL_ROWS = True
+
+
 # ---- fused extension (no reference counterpart at this level; see include/ogc_ops.h) ----------
 def knn_clamped_wrapper(b, n, m, k, radius, unknown, known, dist, idx):
     """kNN + sqrt + radius clamp in one launch; radius < 0 disables the clamp."""

@@ -183,7 +183,7 @@ def test_three_nn_bit_exact(nat, oracle, n, m):
 def run_bq(nat, r, ns, xyz, new):
     B, n, _ = xyz.shape
     m = new.shape[1]
-    idx = torch.zeros(B, m, ns, dtype=torch.int32, device=DEV)
+    idx = torch.full((B, m, ns), -7, dtype=torch.int32, device=DEV)
     nat.ball_query_wrapper(B, n, m, r, ns, T(new), T(xyz), idx)
     return idx.cpu().numpy()
 
@@ -501,7 +501,7 @@ def test_ball_query_grid_path_bit_exact(nat, oracle, n, m, ns, r, scale):
         new = xyz
     t_xyz = T(xyz)
     t_new = t_xyz if m is None else T(new)
-    idx = torch.zeros(2, new.shape[1], ns, dtype=torch.int32, device=DEV)
+    idx = torch.full((2, new.shape[1], ns), -7, dtype=torch.int32, device=DEV)
     nat.ball_query_wrapper(2, n, new.shape[1], r, ns, t_new, t_xyz, idx)
     assert np.array_equal(idx.cpu().numpy(), oracle.ball_query(r, ns, xyz, new))
 
@@ -513,7 +513,7 @@ def test_ball_query_grid_clustered(nat, oracle):
     ang = rng.random((2, 8192, 1), dtype=np.float32) * 2 * np.pi
     pc = np.concatenate([rad * np.cos(ang), rng.random((2, 8192, 1), dtype=np.float32) * 2 - 1, rad * np.sin(ang)], -1).astype(np.float32)
     t = T(pc)
-    idx = torch.zeros(2, 8192, 64, dtype=torch.int32, device=DEV)
+    idx = torch.full((2, 8192, 64), -7, dtype=torch.int32, device=DEV)
     nat.ball_query_wrapper(2, 8192, 8192, 2.0, 64, t, t, idx)
     assert np.array_equal(idx.cpu().numpy(), oracle.ball_query(2.0, 64, pc, pc))
     flat = pc.copy()
