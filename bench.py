@@ -27,15 +27,22 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak (MI355X_MICROARCH.md)
-# HBM traffic of one ogc_ball_query call measured offline with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate
-# passes, tools/pmc_op.sh -> profiles/r01_ball_query_pmc_v2.txt): key = (B, N, M, nsample) -> bytes summed over the two
-# kernels of the operator (grid_build_kernel + ball_query_grid_kernel; KiB as reported).  FETCH_SIZE is taken as
-# reported (the gfx950 x2 correction of MI355X_MICROARCH.md applies to wide coalesced streams; these kernels issue
-# 12-16 byte gathers); WRITE_SIZE of the query kernel equals the output size exactly.
-PMC_TRAFFIC_BYTES = {(16, 8192, 8192, 64): int((8653.8 + 855.6 + 32768 + 2199.5) * 1024)}
-FP32_VALU_PEAK_TF = 157.3  # fp32 vector peak
-# all kernels of one C4 step (16 clouds x 8192 points), MiB as reported by the counters (profiles/r01_step_hbm_traffic_v20.txt)
-STEP_FETCH_MIB, STEP_WRITE_MIB = 14922.5, 12373.3
+FP32_MFMA_PEAK_TF = 157.3  # v_mfma_f32_16x16x4_f32 / 32x32x2_f32: the fp32 matrix rate = the fp32 vector rate (same guide)
+# Numbers NOT measured by this run: PMC counter readings of earlier profiling passes, kept with the file they came from.
+# (rocprofv3 --pmc cannot run inside the timed region; `roofline.traffic` is the one field the contract asks for.)
+OFFLINE = {
+    "ball_query_traffic_bytes": {"shape": [16, 8192, 8192, 64], "bytes": int((8653.8 + 855.6 + 32768 + 2199.5) * 1024),
+                                 "source": "profiles/r02_ball_query_pmc.txt (FETCH_SIZE + WRITE_SIZE of grid_build_kernel + "
+                                           "ball_query_grid_kernel, separate rocprofv3 --pmc passes; FETCH_SIZE as reported — "
+                                           "these kernels issue 12-16 byte gathers, not the wide streams the x2 gfx950 "
+                                           "correction applies to)"},
+    "ball_query_valu_issue": {"kernel": "ball_query_grid_kernel", "wave_insts_valu": 12.84e6, "wave_insts_salu": 6.30e6,
+                              "kernel_us": 29.6, "peak_ginst_s": 614.4, "frac_of_issue_peak": round(12.84e6 / 29.6e-6 / 614.4e9, 3),
+                              "source": "profiles/r02_ball_query_pmc.txt"},
+    "knn_clamped_valu_issue": {"kernel": "knn_grid_kernel<1> (radius-limited)", "source": "profiles/r02_knn_clamped_pmc.txt"},
+    "step_traffic_mib": {"fetch_reported": 14922.5, "write": 12373.3,
+                         "source": "profiles/r01_step_hbm_traffic_v20.txt (round-1 kernels; per-kernel table of one C4 step)"},
+}
 
 
 def parse():
@@ -76,6 +83,84 @@ def cpu_baseline(npoint):
                       "(OpenMP), %.1f s" % (npoint, dt)}
 
 
+def _time(fn, iters=20, warm=3):
+    """Mean duration (ms) of `fn` over back-to-back launches on an idle GPU: events on torch's current stream, which is
+    the stream the operators launch on (ogc_amd/pointnet2_cuda.py::_stream)."""
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def measure_extras(pc, a):
+    """Live readings, taken after the timed region on the idle GPU, for the other kernels the north star names: k-NN
+    against the HBM roofline, a dense SharedMLP GEMM against the fp32 MFMA peak, and the FlowStep3D correlation layer."""
+    from ogc_amd import pointnet2_cuda as nat
+    out = {}
+    B, N, _ = pc.shape
+    k, r = KITTI_K, KITTI_R
+    d = torch.empty(B, N, k, device=pc.device)
+    i = torch.empty(B, N, k, dtype=torch.int32, device=pc.device)
+    alg = B * (12 * N + 12 * N + 8 * N * k)                       # SURVEY 8d: 12n + 12m + 8nk per cloud
+    ms_c = _time(lambda: nat.knn_clamped_wrapper(B, N, N, k, r, pc, pc, d, i))
+    ms_p = _time(lambda: nat.knn_wrapper(B, N, N, k, pc, pc, d, i))
+    out["roofline_knn"] = {
+        "kernel": "ogc_knn_clamped (grid_build_kernel + knn_grid_kernel<1>): the smoothness term's k-NN, k=%d clamped at %g m" % (k, r),
+        "bound": "hbm", "achieved": round(alg / ms_c / 1e6, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(alg / ms_c / 1e6 / HBM_PEAK_GBS, 5), "avg_ms": round(ms_c, 4), "algorithmic_bytes": alg,
+        "shape": {"B": B, "n": N, "m": N, "k": k, "radius": r},
+        "unclamped_ogc_knn": {"avg_ms": round(ms_p, 4), "achieved": round(alg / ms_p / 1e6, 2),
+                              "frac": round(alg / ms_p / 1e6 / HBM_PEAK_GBS, 5)},
+        "note": "idle GPU, 20 back-to-back launches; the radius-limited search stops once the scanned cells cover the clamp "
+                "radius (neighbours beyond it are replaced by the nearest one in the output).  Both searches are bound by "
+                "instruction issue, not by HBM (SURVEY 8d): the HBM fraction is reported because the north star asks for it"}
+    # dense per-group MLP GEMM on the fp32 matrix pipe: SA3's 128 -> 128 layer on 16 x 32768 positions
+    Bc, cin, cout, hw = B, 128, 128, 32768
+    x = torch.randn(Bc, cin, hw, device=pc.device)
+    w = torch.randn(cout, cin, device=pc.device)
+    y = torch.empty(Bc, cout, hw, device=pc.device)
+    ms_g = _time(lambda: nat.conv1x1_gemm_wrapper(Bc, cout, cin, hw, 0, w, x, y))
+    tf = 2.0 * Bc * hw * cin * cout / ms_g / 1e9
+    out["mfma"] = {"kernel": "conv1x1_gemm_kernel (v_mfma_f32_16x16x4_f32), SA3 layer 128 -> 128 on %d x %d positions" % (Bc, hw),
+                   "bound": "mfma", "achieved": round(tf, 2), "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                   "frac": round(tf / FP32_MFMA_PEAK_TF, 4), "avg_ms": round(ms_g, 4),
+                   "hbm_gbs": round(4.0 * Bc * hw * (cin + cout) / ms_g / 1e6, 1),
+                   "note": "MFMA utilisation of the widest hand-written GEMM of the step = useful fp32 flops / fp32 MFMA peak "
+                           "(this layer sits where the fp32 MFMA roof and the HBM roof meet; narrower layers are HBM-bound)"}
+    del x, y
+    # FlowStep3D correlation layer at config C3's level-2 shape (BASELINE config 3): B = 1, 2048 points, k = 16
+    from ogc_amd.utils.flowstep3d_util import FlowEmbedding
+    torch.manual_seed(0)
+    fe = FlowEmbedding(radius=1.5, nsample=16, in_channel=64, mlp=[128, 128, 128]).to(pc.device).eval()
+    p1 = pc[:1, :2048].transpose(1, 2).contiguous()
+    p2 = (pc[:1, :2048] + 0.05 * torch.randn(1, 2048, 3, device=pc.device)).transpose(1, 2).contiguous()
+    f1, f2 = torch.randn(1, 64, 2048, device=pc.device), torch.randn(1, 64, 2048, device=pc.device)
+    with torch.no_grad():
+        ms_fe = _time(lambda: fe(p1, p2, f1, f2))
+        dk = torch.empty(1, 2048, 16, device=pc.device)
+        ik = torch.empty(1, 2048, 16, dtype=torch.int32, device=pc.device)
+        q, kn = p1.transpose(1, 2).contiguous(), p2.transpose(1, 2).contiguous()
+        ms_k = _time(lambda: nat.knn_clamped_wrapper(1, 2048, 2048, 16, 1.5, q, kn, dk, ik))
+    flops = 2.0 * 2048 * 16 * (131 * 128 + 128 * 128 + 128 * 128)
+    algk = 12 * 2048 + 12 * 2048 + 8 * 2048 * 16
+    out["corr_layer"] = {"layer": "FlowEmbedding (utils/flowstep3d_util.py:27-66): kNN(16) + clamp 1.5 m -> group -> 131->128->128->128 "
+                                  "(BatchNorm eval) -> max, B=1, 2048 points",
+                         "avg_ms": round(ms_fe, 4),
+                         "knn": {"avg_ms": round(ms_k, 4), "achieved_gbs": round(algk / ms_k / 1e6, 3), "peak_gbs": HBM_PEAK_GBS,
+                                 "frac": round(algk / ms_k / 1e6 / HBM_PEAK_GBS, 6)},
+                         "mfma": {"tflops_over_whole_layer": round(flops / ms_fe / 1e9, 3), "peak": FP32_MFMA_PEAK_TF,
+                                  "frac": round(flops / ms_fe / 1e9 / FP32_MFMA_PEAK_TF, 5), "flops": flops},
+                         "note": "BASELINE.md 4: k-NN GB/s and MFMA TF/s against peak; at B = 1 the layer is a chain of small "
+                                 "launches (latency-bound), not a bandwidth- or MFMA-bound kernel"}
+    return out
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -96,6 +181,9 @@ def main():
     from ogc_amd.models.segnet_kitti import MaskFormer3D
     from ogc_amd.train_step import KITTI_LOSS, build_criterion, make_optimizer, train_step
     from ogc_amd.utils.synthetic import make_scene_batch
+    global KITTI_K, KITTI_R
+    KITTI_K = KITTI_LOSS["smooth_loss_params"]["knn_loss_params"]["k"]
+    KITTI_R = KITTI_LOSS["smooth_loss_params"]["knn_loss_params"]["radius"]
 
     torch.manual_seed(10)  # random_seed: 10 in the reference YAMLs; identical init on every rank
     net = MaskFormer3D(n_slot=10, n_point=a.npoint, use_xyz=True, n_transformer_layer=2,
@@ -146,22 +234,30 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
-    isolated_ms = None
+    isolated_ms, extras = None, {}
     if rank == 0:
         # the same ball-query call on an otherwise idle GPU (in the step it shares the chip with the dense kernels)
         from ogc_amd.pointnet2.pointnet2 import ball_query
         pc = torch.cat([batch[0][:, v] for v in range(4)]).contiguous()
         bl = KITTI_LOSS["smooth_loss_params"]["ball_q_loss_params"]
-        for _ in range(3):
-            ball_query(bl["radius"], bl["k"], pc, pc)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(20):
-            ball_query(bl["radius"], bl["k"], pc, pc)
-        e1.record()
-        torch.cuda.synchronize()
-        isolated_ms = e0.elapsed_time(e1) / 20
+        isolated_ms = _time(lambda: ball_query(bl["radius"], bl["k"], pc, pc))
+        extras = measure_extras(pc, a)
+        # steps with the FPS chain shortcut off: every encoder level runs all its sampling rounds, as it must for clouds
+        # with duplicated points (synthetic uniform clouds are tie-free, so levels 2-3 cost ~10 us in the headline)
+        import ogc_amd.utils.pointnet2_util as sa_util
+        sa_util.FPS_CHAIN_SHORTCUT = False
+        try:
+            pre2 = None
+            for _ in range(2):
+                pre2 = train_step(model, crit, opt, batch, it, True, sync=False, prefetched=pre2, next_batch=batch).prefetched
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                pre2 = train_step(model, crit, opt, batch, it, True, sync=False, prefetched=pre2, next_batch=batch).prefetched
+            torch.cuda.synchronize()
+            extras["ms_per_step_all_fps_rounds"] = round((time.perf_counter() - t1) / 5 * 1e3, 3)
+        finally:
+            sa_util.FPS_CHAIN_SHORTCUT = True
     if rank == 0:
         durs = timer.durations_ms()
         bq = durs.get("ogc_ball_query", [])
@@ -174,7 +270,8 @@ def main():
             roof = {"kernel": "ogc_ball_query (grid_build_kernel + ball_query_grid_kernel)",
                     "bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(gbs / HBM_PEAK_GBS, 5),
-                    "traffic": PMC_TRAFFIC_BYTES.get((b_, n_, m_, ns_)),
+                    "traffic": (OFFLINE["ball_query_traffic_bytes"]["bytes"]
+                                if [b_, n_, m_, ns_] == OFFLINE["ball_query_traffic_bytes"]["shape"] else None),
                     "launches": len(bq), "avg_ms": round(ms, 4), "algorithmic_bytes": alg,
                     "isolated": {"avg_ms": round(isolated_ms, 4), "achieved": round(alg / (isolated_ms * 1e-3) / 1e9, 2),
                                  "frac": round(alg / (isolated_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
@@ -185,14 +282,7 @@ def main():
                             "cell-list search tests ~N/60 candidates per centre, so the all-pairs figure of 8*B*N*M "
                             "flop no longer describes the work done; in the step the next batch's network geometry plan "
                             "(FPS / kNN on a side stream) shares the chip with it (tools/bench_ops.py has the idle-GPU table)",
-                    "all_pairs_equivalent_tpairs_per_s": round(b_ * n_ * m_ / (ms * 1e-3) / 1e12, 2),
-                    # offline (rocprofv3 --pmc SQ_INSTS_VALU + --kernel-trace, profiles/r01_ball_query_pmc_v2.txt):
-                    # what actually bounds the search kernel is VALU issue, not HBM
-                    "valu_issue_offline": {"kernel": "ball_query_grid_kernel", "wave_insts": 12.84e6, "kernel_us": 29.4,
-                                           "achieved_ginst_s": round(12.84e6 / 29.4e-6 / 1e9, 1),
-                                           "peak_ginst_s": round(256 * 4 * 2.4 / 4 * 1e3 / 1e3, 1),
-                                           "frac": round(12.84e6 / 29.4e-6 / (256 * 4 * 2.4e9 / 4), 3),
-                                           "shape": "B=16, N=M=8192, nsample=64"}}
+                    "all_pairs_equivalent_tpairs_per_s": round(b_ * n_ * m_ / (ms * 1e-3) / 1e12, 2)}
         others = {}
         for name in ("ogc_knn_clamped", "ogc_furthest_point_sampling", "ogc_furthest_point_sampling_chain"):
             if name in durs:
@@ -217,16 +307,15 @@ def main():
             "roofline": roof,
             "kernel_ms": others,
         }
+        out.update(extras)
+        out["fps_note"] = ("levels 2-3 of the encoder cost ~10 us in ms_per_step because the synthetic uniform clouds are free "
+                           "of exact fp32 distance ties (the chain shortcut, DESIGN.md); ms_per_step_all_fps_rounds is the same "
+                           "step with the shortcut off, i.e. what clouds with duplicated points pay (FPS runs on a side stream)")
+        out["offline"] = OFFLINE
         if (a.batch, a.npoint) == (4, 8192):
-            # HBM-side bytes of one whole step, measured offline (tools/pmc_step.sh, separate FETCH_SIZE / WRITE_SIZE
-            # passes -> profiles/r01_step_hbm_traffic_v20.txt); the average rate uses THIS run's per-rank step time
             ms_step = elapsed / a.steps * 1e3
-            out["step_traffic"] = {
-                "fetch_mib_reported": STEP_FETCH_MIB, "write_mib": STEP_WRITE_MIB,
-                "est_gbs": round((2 * STEP_FETCH_MIB + STEP_WRITE_MIB) * 2 ** 20 / (ms_step * 1e-3) / 1e9, 1),
-                "note": "PMC counters summed over all kernels of a step; est_gbs doubles the reported fetch volume "
-                        "(gfx950 tallies wide coalesced reads at half their bytes, MI355X_MICROARCH.md) and divides "
-                        "by this run's step time: the step as a whole against the %.0f GB/s HBM peak" % HBM_PEAK_GBS}
+            st = OFFLINE["step_traffic_mib"]
+            out["offline"]["step_traffic_est_gbs"] = round((2 * st["fetch_reported"] + st["write"]) * 2 ** 20 / (ms_step * 1e-3) / 1e9, 1)
         if dist.is_initialized():
             out["collective"] = {"backend": dist.get_backend(), "op": "all_reduce(SUM) of one flat fp32 gradient buffer per step",
                                  "payload_bytes": model.payload_bytes(), "world": world,

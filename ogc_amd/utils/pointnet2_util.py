@@ -10,6 +10,13 @@ from ..pointnet2.pointnet2 import (GroupAll, QueryAndGroup, furthest_point_sampl
 from .nn_util import SharedMLP
 
 
+# Levels 2+ of an encoder re-sample the previous level's centres; when that level's rounds were free of exact fp32 ties
+# the result is known in advance (DESIGN.md "FPS along a chain of levels") and the rounds are skipped.  bench.py turns
+# this off for a few extra steps to report what a step costs when every level has to run all its rounds (clouds with
+# duplicated points).
+FPS_CHAIN_SHORTCUT = True
+
+
 class _PointnetSAModuleBase(nn.Module):
     """FPS -> gather centres -> per scale [group -> shared MLP -> max over the neighbourhood] -> concat.
     Reference: pointnet2_util.py:9-49."""
@@ -33,7 +40,7 @@ class _PointnetSAModuleBase(nn.Module):
     def plan_sampling(self, xyz, parent_ties=None):
         """The sequential part: FPS indices and the sampled centres (:22-27).  parent_ties: `ties` of the plan whose
         `new_xyz` this `xyz` is (the previous level of the encoder) — lets tie-free clouds skip the sampling rounds."""
-        new_inds, ties = furthest_point_sample_chain(xyz, self.npoint, parent_ties)
+        new_inds, ties = furthest_point_sample_chain(xyz, self.npoint, parent_ties if FPS_CHAIN_SHORTCUT else None)
         new_inds = new_inds.long()
         new_xyz = gather_nd(xyz, new_inds)  # == gather on the transposed cloud, transposed back (:22-27)
         return {"new_inds": new_inds, "new_xyz": new_xyz, "ties": ties}
