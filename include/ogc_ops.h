@@ -296,6 +296,32 @@ int ogc_small_linear_fwd(int rows, int n_in, int n_out, const float *x, const fl
 int ogc_small_linear_bwd(int rows, int n_in, int n_out, const float *x, const float *weight, const float *grad_y,
                          float *grad_x, float *grad_weight, float *grad_bias, ogc_stream_t stream);
 
+/* A whole per-neighbourhood MLP and its max-pool in one launch, for INFERENCE
+ *   utils/flowstep3d_util.py:57-66 (FlowEmbedding, the correlation layer) and :126-138 (set abstraction):
+ *     for conv, bn in zip(mlp_convs, mlp_bns): x = relu(bn(conv(x)));   x = max(x, -1)
+ * with BatchNorm in evaluation mode, i.e. an affine map per output channel that the caller folds into the weights:
+ *   wt_l (c_{l-1} rounded up to 4, c_l) = TRANSPOSED folded weights (rows beyond c_{l-1} zero), b_l (c_l) folded biases,
+ *   x (b, c0, p, nsample) -> out (b, c_last, p) = max over nsample of relu(W3' relu(W2' relu(W1' x + b1) + b2) + b3);
+ *   c3 == 0: two layers.  fp32 on v_mfma_f32_16x16x4_f32; the activations between the layers never leave the register
+ *   file.  ogc_mlp_chain_pool_supported() says whether a kernel exists for a shape (1) or the caller runs its layers
+ *   one by one (0). */
+int ogc_mlp_chain_pool_supported(int c0, int c1, int c2, int c3, int nsample);
+int ogc_mlp_chain_pool(int b, int c0, int c1, int c2, int c3, int p, int nsample, const float *x, const float *wt1,
+                       const float *b1, const float *wt2, const float *b2, const float *wt3, const float *b3, float *out,
+                       ogc_stream_t stream);
+
+/* The FlowStep3D correlation layer after its neighbour search, in one launch, for INFERENCE
+ *   utils/flowstep3d_util.py:53-66 (FlowEmbedding.forward): group pos2 and feat2 by idx, subtract pos1, concatenate
+ *   [pos2[idx] - pos1 (3), feat2[idx] (cf), feat1 repeated (cf)] -> 3 x (conv, BatchNorm(eval), ReLU) -> max over nsample.
+ * pos1 (b,3,n1), pos2 (b,3,n2), feat1 (b,cf,n1), feat2 (b,cf,n2), idx (b,n1,nsample) = the clamped neighbour indices
+ * (ogc_knn_clamped); weights as for ogc_mlp_chain_pool (wt1 has 3 + 2 cf rows, padded to a multiple of 4); out (b,c3,n1).
+ * The (b, 3 + 2 cf, n1, nsample) tensor is never formed: its rows are gathered while the first layer's operands load. */
+int ogc_corr_layer_pool_supported(int cf, int c1, int c2, int c3, int nsample);
+int ogc_corr_layer_pool(int b, int cf, int c1, int c2, int c3, int n1, int n2, int nsample, const float *pos1,
+                        const float *pos2, const float *feat1, const float *feat2, const int *idx, const float *wt1,
+                        const float *b1, const float *wt2, const float *b2, const float *wt3, const float *b3, float *out,
+                        ogc_stream_t stream);
+
 /* Mask read-out of the segmentation nets
  *   models/segnet_kitti.py:85-88 (segnet_sapien.py / segnet_ogcdr.py :77-80):
  *   mask = softmax_k( F.normalize(feats, dim=1)^T F.normalize(slots, dim=1) / temperature ),  temperature = 0.05.

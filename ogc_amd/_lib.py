@@ -56,6 +56,11 @@ SIGNATURES = {
                                      _int, _vp],
     "ogc_small_linear_fwd": [_int, _int, _int, _vp, _vp, _vp, _vp, _vp],
     "ogc_small_linear_bwd": [_int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "ogc_mlp_chain_pool_supported": [_int, _int, _int, _int, _int],
+    "ogc_mlp_chain_pool": [_int, _int, _int, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "ogc_corr_layer_pool_supported": [_int, _int, _int, _int, _int],
+    "ogc_corr_layer_pool": [_int, _int, _int, _int, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                            _vp, _vp, _vp],
     "ogc_slot_masks_ws_floats": [_int, _int, _int, _int],
     "ogc_slot_masks_fwd": [_int, _int, _int, _int, _flt, _vp, _vp, _vp, _vp],
     "ogc_slot_masks_bwd": [_int, _int, _int, _int, _flt, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],

@@ -394,6 +394,88 @@ def conv_norm_act(x, conv, norm, relu=True, maxpool=False):
     return y.max(dim=-1)[0] if maxpool else y
 
 
+# ---- whole MLP + max-pool in one launch (inference) ------------------------------------------------------------------
+_FOLDED = {}   # id(first conv) -> (versions, transposed folded weights, folded biases)
+
+
+def _fold_batch_norm(convs, norms):
+    """W'_l = diag(a) W_l (transposed, rows padded to a multiple of 4), b_l = beta - mean * a with a = gamma / sqrt(var + eps):
+    BatchNorm in evaluation mode folded into the convolution before it.  Cached until a parameter or buffer changes."""
+    tensors = [t for conv, bn in zip(convs, norms) for t in (conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var)]
+    versions = tuple((t.data_ptr(), t._version) for t in tensors)
+    hit = _FOLDED.get(id(convs[0]))
+    if hit is not None and hit[0] == versions:
+        return hit[1], hit[2]
+    wts, biases = [], []
+    with torch.no_grad():
+        for conv, bn in zip(convs, norms):
+            a = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+            w = conv.weight.reshape(conv.weight.shape[0], -1) * a[:, None]
+            wt = torch.zeros((w.shape[1] + 3) // 4 * 4, w.shape[0], dtype=torch.float32, device=w.device)
+            wt[:w.shape[1]] = w.t()
+            wts.append(wt.contiguous())
+            biases.append((bn.bias - bn.running_mean * a).contiguous())
+    _FOLDED[id(convs[0])] = (versions, wts, biases)
+    return wts, biases
+
+
+def mlp_chain_pool_available(x, convs, norms):
+    """Inference only: every norm a BatchNorm in evaluation mode, nothing to differentiate, and a kernel for the shape."""
+    nat = _api._native
+    if getattr(nat, "mlp_chain_pool_wrapper", None) is None or len(convs) not in (2, 3) or x.dim() != 4:
+        return False
+    if not (x.is_cuda and x.dtype == torch.float32) or (torch.is_grad_enabled() and (
+            x.requires_grad or any(p.requires_grad for m in list(convs) + list(norms) for p in m.parameters()))):
+        return False
+    for conv, bn in zip(convs, norms):
+        if not isinstance(bn, torch.nn.BatchNorm2d) or bn.training or not bn.track_running_stats or not bn.affine:
+            return False
+        if conv.bias is not None or conv.groups != 1 or any(k != 1 for k in conv.kernel_size):
+            return False
+    c = [convs[0].weight.shape[1]] + [conv.weight.shape[0] for conv in convs] + [0]
+    return nat.mlp_chain_pool_supported(c[0], c[1], c[2], c[3] if len(convs) > 2 else 0, x.shape[-1])
+
+
+def corr_layer_pool_available(feature1, feature2, idx, convs, norms):
+    """FlowEmbedding in inference with a kernel for its shape: grouping, concatenation, MLP and max in one launch."""
+    nat = _api._native
+    if getattr(nat, "corr_layer_pool_wrapper", None) is None or len(convs) != 3 or idx is None:
+        return False
+    if not all(t.is_cuda and t.dtype == torch.float32 for t in (feature1, feature2)) or feature1.shape[1] != feature2.shape[1]:
+        return False
+    if torch.is_grad_enabled() and (feature1.requires_grad or feature2.requires_grad or any(
+            p.requires_grad for m in list(convs) + list(norms) for p in m.parameters())):
+        return False
+    for conv, bn in zip(convs, norms):
+        if not isinstance(bn, torch.nn.BatchNorm2d) or bn.training or not bn.track_running_stats or not bn.affine:
+            return False
+        if conv.bias is not None or conv.groups != 1 or any(k != 1 for k in conv.kernel_size):
+            return False
+    cf = feature1.shape[1]
+    if convs[0].weight.shape[1] != 3 + 2 * cf:
+        return False
+    return nat.corr_layer_pool_supported(cf, convs[0].weight.shape[0], convs[1].weight.shape[0], convs[2].weight.shape[0],
+                                         idx.shape[2])
+
+
+def corr_layer_pool(pos1, pos2, feature1, feature2, idx, convs, norms):
+    """max_s relu(bn(conv(...[pos2[idx] - pos1, feature2[idx], feature1]...))) (B, c3, n1); see corr_layer_pool_available."""
+    wts, biases = _fold_batch_norm(convs, norms)
+    out = torch.empty(feature1.shape[0], wts[-1].shape[1], feature1.shape[2], dtype=torch.float32, device=feature1.device)
+    _api._native.corr_layer_pool_wrapper(pos1.contiguous(), pos2.contiguous(), feature1.contiguous(), feature2.contiguous(),
+                                         idx.int().contiguous(), wts, biases, out)
+    return out
+
+
+def mlp_chain_pool(x, convs, norms):
+    """max over the last dimension of relu(bn(conv(...relu(bn(conv(x)))...))) in one launch (see mlp_chain_pool_available)."""
+    wts, biases = _fold_batch_norm(convs, norms)
+    x = x.contiguous()
+    out = torch.empty(x.shape[0], wts[-1].shape[1], x.shape[2], dtype=torch.float32, device=x.device)
+    _api._native.mlp_chain_pool_wrapper(x, wts, biases, out)
+    return out
+
+
 # ---- dynamic / invariance terms of the OGC loss ---------------------------------------------------------------
 class _RigidBlend(Function):
     """per-point || sum_k m_k (R_k p + t_k) - q ||_p with R, t constants (the fit is detached in the reference,

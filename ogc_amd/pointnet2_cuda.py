@@ -390,6 +390,35 @@ def attention_bwd_wrapper(h, scale, q, k, v, out, prob, dout, dq, dk, dv):
          _f(prob, "prob"), _f(dout, "dout"), dqp, lddq, dkp, lddk, dvp, lddv)
 
 
+def mlp_chain_pool_supported(c0, c1, c2, c3, nsample):
+    """Is there a fused inference kernel for the MLP c0 -> c1 -> c2 [-> c3] followed by the max over nsample?"""
+    return bool(_lib.load().ogc_mlp_chain_pool_supported(c0, c1, c2, c3, nsample))
+
+
+def mlp_chain_pool_wrapper(x, wts, biases, out):
+    """out (B, c_last, P) = max over the neighbourhood of the folded MLP of x (B, c0, P, S) (ogc_mlp_chain_pool).
+    wts: transposed folded weights (rows padded to a multiple of 4), biases: folded biases; two or three layers."""
+    B, c0, P, S = x.shape
+    c = [w.shape[1] for w in wts] + [0]
+    _run("ogc_mlp_chain_pool", x, B, c0, c[0], c[1], c[2] if len(wts) > 2 else 0, P, S, _f(x, "x"),
+         _f(wts[0], "wt1"), _f(biases[0], "b1"), _f(wts[1], "wt2"), _f(biases[1], "b2"),
+         _f(wts[2], "wt3") if len(wts) > 2 else None, _f(biases[2], "b3") if len(wts) > 2 else None, _f(out, "out"))
+
+
+def corr_layer_pool_supported(cf, c1, c2, c3, nsample):
+    return bool(_lib.load().ogc_corr_layer_pool_supported(cf, c1, c2, c3, nsample))
+
+
+def corr_layer_pool_wrapper(pos1, pos2, feat1, feat2, idx, wts, biases, out):
+    """FlowEmbedding after its neighbour search in one launch (ogc_corr_layer_pool): pos (B, 3, n), feat (B, cf, n),
+    idx (B, n1, S) int32, folded transposed weights / biases of the three layers; out (B, c3, n1)."""
+    B, cf, n1 = feat1.shape
+    _run("ogc_corr_layer_pool", feat1, B, cf, wts[0].shape[1], wts[1].shape[1], wts[2].shape[1], n1, feat2.shape[2],
+         idx.shape[2], _f(pos1, "pos1"), _f(pos2, "pos2"), _f(feat1, "feat1"), _f(feat2, "feat2"), _i(idx, "idx"),
+         _f(wts[0], "wt1"), _f(biases[0], "b1"), _f(wts[1], "wt2"), _f(biases[1], "b2"), _f(wts[2], "wt3"),
+         _f(biases[2], "b3"), _f(out, "out"))
+
+
 def small_linear_fwd_wrapper(x, weight, bias, y):
     """y (rows, n_out) = x (rows, n_in) weight^T + bias (ogc_small_linear_fwd); bias may be None."""
     rows, n_in = x.shape

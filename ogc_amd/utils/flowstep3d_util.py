@@ -42,8 +42,10 @@ class geometry_memo:
 def _shared_mlp(x, convs, norms, pool):
     """[relu(norm(conv(x))) for every layer] (+ max over the last dimension): the MLP tail of every FlowStep3D block
     (reference flowstep3d_util.py:64-66, :134-136, :181-183), through the fused conv / BatchNorm kernels on the GPU."""
-    from ..fused import conv_norm_act
+    from ..fused import conv_norm_act, mlp_chain_pool, mlp_chain_pool_available
     n = len(convs)
+    if pool and mlp_chain_pool_available(x, convs, norms):
+        return mlp_chain_pool(x, convs, norms)   # inference: the whole chain and the max in one launch
     for i, (conv, norm) in enumerate(zip(convs, norms)):
         x = conv_norm_act(x, conv, norm, relu=True, maxpool=pool and i == n - 1)
     if pool and n == 0:
@@ -89,6 +91,10 @@ class FlowEmbedding(nn.Module):
             raise NotImplementedError("FlowEmbedding(knn=False) is dead code in the reference "
                                       "(utils/flowstep3d_util.py:48 cannot run)")
 
+        from ..fused import corr_layer_pool, corr_layer_pool_available
+        if self.corr_func == 'concat' and corr_layer_pool_available(feature1, feature2, idx, self.mlp_convs, self.mlp_bns):
+            # inference: grouping, concatenation, the three layers and the max in one launch
+            return pos1, corr_layer_pool(pos1, pos2, feature1, feature2, idx, self.mlp_convs, self.mlp_bns)
         pos_diff = grouping_operation(pos2, idx) - pos1.view(B, -1, N, 1)            # (B, 3, N, S)
         feat2_grouped = grouping_operation(feature2, idx)                            # (B, C, N, S)
         if self.corr_func == 'concat':

@@ -355,9 +355,14 @@ def _cond(truth, key):
 
 
 def _grad_rows(budget, module, loss, gold32, truth, prefix32, prefix64, floor):
-    """Parameter gradients: the norm (relative) and the stored head of 32 entries (relative in L2 over the head)."""
+    """Parameter gradients: the norm (relative) and the stored head of 32 entries (relative in L2 over the head).
+    A flipped gate perturbs the gradient of EVERY parameter upstream of it, and which gates flip depends on the last
+    bits of the forward pass (eight noise samples do not visit all of them): a tensor is therefore also allowed a
+    quarter of the largest conditioning seen on any gradient tensor of the model."""
     module.zero_grad()
     loss.backward()
+    model_cond = {kind: max([float(v[0]) for k, v in truth.items() if k.startswith("cond/" + prefix64 + kind)] or [0.0])
+                  for kind in ("gnorm/", "ghead/")}
     for name, p in module.named_parameters():
         g = p.grad if p.grad is not None else torch.zeros_like(p)
         tn, th = truth[prefix64 + "gnorm/" + name], truth[prefix64 + "ghead/" + name]
@@ -365,13 +370,13 @@ def _grad_rows(budget, module, loss, gold32, truth, prefix32, prefix64, floor):
             assert float(g.norm()) == 0.0, name
             continue
         budget.add("gnorm/" + name, g.norm().reshape(1), gold32[prefix32 + "gnorm/" + name], tn, floor,
-                   cond=_cond(truth, prefix64 + "gnorm/" + name))
+                   cond=max(_cond(truth, prefix64 + "gnorm/" + name), 0.125 * model_cond["gnorm/"]))
         # the stored head (first 32 entries): error relative to the head's norm, or to the share of the whole
         # gradient's norm 32 typical entries carry when the head happens to be a vanishing part of it
         typical = float(tn[0]) * np.sqrt(min(32, p.numel()) / p.numel())
         # (a head is 32 numbers: its own floor is 6x the norm's — still 300x below the 1e-2 these tests used to allow)
         budget.add("ghead/" + name, g.flatten()[:32], gold32[prefix32 + "ghead/" + name], th, 6 * floor, denom_floor=typical,
-                   cond=_cond(truth, prefix64 + "ghead/" + name))
+                   cond=max(_cond(truth, prefix64 + "ghead/" + name), 0.125 * model_cond["ghead/"]))
 
 
 def truth_segnet(dev, name, kw, N, B, out_cap=1e-5, floor=1e-6, grad_floor=5e-6):

@@ -761,3 +761,64 @@ def test_shared_mlp_deferred_normalisation(spec, pool, monkeypatch):
     for (n1, p1), (_, p2) in zip(mlp.named_parameters(), ref.named_parameters()):
         s = p2.grad.abs().max().item()
         torch.testing.assert_close(p1.grad, p2.grad, rtol=2e-3, atol=2e-4 * max(s, 1.0), msg=lambda m, n=n1: n + ": " + m)
+
+
+def test_mlp_chain_pool_matches_layerwise_inference(nat):
+    """ogc_mlp_chain_pool (the C3 correlation layer's 131 -> 128 -> 128 -> 128 MLP + max over 16 neighbours in one launch,
+    BatchNorm(eval) folded) against the layer-by-layer evaluation in float64, and FlowEmbedding end to end against the
+    un-fused path; ragged sizes (points not a multiple of a workgroup's 4) included."""
+    import torch.nn as nn
+    from ogc_amd import fused
+    g = torch.Generator().manual_seed(5)
+    for B, P in ((1, 2048), (2, 37), (3, 130)):
+        convs = nn.ModuleList([nn.Conv2d(131, 128, 1, bias=False), nn.Conv2d(128, 128, 1, bias=False),
+                               nn.Conv2d(128, 128, 1, bias=False)]).to(DEV)
+        norms = nn.ModuleList([nn.BatchNorm2d(128) for _ in range(3)]).to(DEV).eval()
+        with torch.no_grad():
+            for bn in norms:
+                bn.weight.copy_(torch.rand(128, generator=g) + 0.5); bn.bias.copy_(torch.rand(128, generator=g) - 0.5)
+                bn.running_mean.copy_(torch.rand(128, generator=g) - 0.5); bn.running_var.copy_(torch.rand(128, generator=g) + 0.5)
+        x = torch.randn(B, 131, P, 16, generator=g).to(DEV)
+        with torch.no_grad():
+            assert fused.mlp_chain_pool_available(x, convs, norms)
+            got = fused.mlp_chain_pool(x, convs, norms)
+            ref = x.double()
+            for conv, bn in zip(convs, norms):
+                ref = torch.relu(torch.nn.functional.batch_norm(
+                    torch.nn.functional.conv2d(ref, conv.weight.double()), bn.running_mean.double(), bn.running_var.double(),
+                    bn.weight.double(), bn.bias.double(), False, 0.0, bn.eps))
+            ref = ref.max(-1)[0]
+        assert got.shape == ref.shape
+        err = float((got.double() - ref).norm() / ref.norm())
+        assert err < 2e-6, (B, P, err)
+        assert float((got.double() - ref).abs().max()) < 1e-4 * float(ref.abs().max())
+    # gradients requested -> the fused inference kernel must not be chosen
+    assert not fused.mlp_chain_pool_available(x.requires_grad_(True), convs, norms)
+
+
+def test_flow_embedding_inference_uses_the_fused_chain(nat):
+    from ogc_amd import fused
+    from ogc_amd.utils.flowstep3d_util import FlowEmbedding
+    torch.manual_seed(3)
+    fe = FlowEmbedding(radius=1.5, nsample=16, in_channel=64, mlp=[128, 128, 128]).to(DEV).eval()
+    p1 = (torch.rand(2, 3, 1024, device=DEV) - 0.5) * 20
+    p2 = p1 + 0.1 * torch.randn_like(p1)
+    f1, f2 = torch.randn(2, 64, 1024, device=DEV), torch.randn(2, 64, 1024, device=DEV)
+    calls = []
+    real, avail, avail_c = fused.corr_layer_pool, fused.mlp_chain_pool_available, fused.corr_layer_pool_available
+    try:
+        fused.corr_layer_pool = lambda *a: (calls.append(1), real(*a))[1]
+        with torch.no_grad():
+            _, y = fe(p1, p2, f1, f2)
+        assert calls, "the inference path did not take the fused kernel"
+        fused.corr_layer_pool_available = lambda *a: False          # grouped tensor + fused MLP chain
+        with torch.no_grad():
+            _, y_chain = fe(p1, p2, f1, f2)
+        fused.mlp_chain_pool_available = lambda *a: False           # layer by layer
+        with torch.no_grad():
+            _, y_ref = fe(p1, p2, f1, f2)
+    finally:
+        fused.corr_layer_pool, fused.mlp_chain_pool_available, fused.corr_layer_pool_available = real, avail, avail_c
+    assert y.shape == y_ref.shape == (2, 128, 1024)
+    assert torch.equal(y, y_chain)                                  # same arithmetic, only the operand source differs
+    torch.testing.assert_close(y, y_ref, rtol=1e-4, atol=1e-5)
