@@ -20,7 +20,7 @@ def test_operator_layer():
 
 
 def test_modules():
-    gc.run_modules("cuda", rtol=1e-4, atol=2e-6)  # element-wise vs ONE fp32 run; vs the exact result: test_truth_f64_gpu.py
+    gc.run_modules("cuda", rtol=1e-4, atol=1e-5)  # element-wise vs ONE fp32 run; vs the exact result: test_truth_f64_gpu.py
 
 
 def test_losses_and_oa_icp():
