@@ -37,7 +37,7 @@ __device__ __forceinline__ int cell_coord(float x, float mn, float inv_h, int g)
 
 // Grid parameters from the bounding box (every thread computes them redundantly: no serial section, no broadcast).
 __device__ __forceinline__ GridHdr grid_header(const float (&lo)[3], const float (&hi)[3], int n, float radius,
-                                               int knn_k) {
+                                               int knn_k, float knn_div) {
     GridHdr h;
     const bool any = lo[0] <= hi[0];
     double ext[3];
@@ -51,8 +51,10 @@ __device__ __forceinline__ GridHdr grid_header(const float (&lo)[3], const float
         double vol = 1.0;
         for (int a = 0; a < 3; ++a)
             if (ext[a] > 1e-3 * maxext && ext[a] > 0.0) { ++dims; vol *= ext[a]; }
-        const double block = dims == 3 ? 27.0 : (dims == 2 ? 9.0 : 3.0);
-        const double per_cell = fmax(2.5 * (double)knn_k / block, 1.0);
+        // cell edge = HALF the expected distance of the k-th neighbour (rho h^d = k / (V_d 2^d), V_d the unit ball): the
+        // search then ends after the 5^d block (R = 2), ~3.7 k candidates in 3-D, where an edge of 0.73 r_k (the former
+        // 2.5 k points per 3^d block) also needed R = 2 but scanned 11.6 k
+        const double per_cell = fmax((double)knn_k / (dims == 3 ? (double)knn_div : (dims == 2 ? 12.6 : 4.0)), 0.5);
         edge = dims > 0 ? pow(vol * per_cell / (double)max(n, 1), 1.0 / (double)dims) : 1.0;
         // radius-clamped search (ogc_knn_clamped): neighbours beyond `radius` are replaced by the nearest one anyway,
         // so the search may stop once the scanned block covers the radius.  When the radius is SHORTER than the
@@ -86,7 +88,7 @@ __device__ __forceinline__ GridHdr grid_header(const float (&lo)[3], const float
 // is read from memory once; PPT == 0: any size, the three passes re-read the cloud.  Five barriers in all: the
 // bounding box and the cell-count scan are wave-level (DPP / shuffles) with one 16-entry exchange through LDS each.
 template <int PPT>
-__global__ __launch_bounds__(BUILD_THREADS) void grid_build_kernel(int n, float radius, int knn_k, int stride_cells,
+__global__ __launch_bounds__(BUILD_THREADS) void grid_build_kernel(float knn_div, int n, float radius, int knn_k, int stride_cells,
                                                                    const float *__restrict__ xyz,
                                                                    GridHdr *__restrict__ hdrs,
                                                                    int *__restrict__ cell_start,
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(BUILD_THREADS) void grid_build_kernel(int n, float 
             lo[a] = -ogc_wave_max_f32(-l);
             hi[a] = ogc_wave_max_f32(u);
         }
-        if (lane == 0) s_hdr = grid_header(lo, hi, n, radius, knn_k);
+        if (lane == 0) s_hdr = grid_header(lo, hi, n, radius, knn_k, knn_div);
     }
     __syncthreads();
     GridHdr h = s_hdr;
@@ -235,14 +237,15 @@ __global__ __launch_bounds__(BUILD_THREADS) void grid_build_kernel(int n, float 
 
 static void launch_grid_build(int b, int n, float radius, int knn_k, int stride_cells, const float *xyz, GridHdr *hdrs,
                               int *cell_start, float4 *sorted_pts, hipStream_t s) {
+    const float knn_div = 33.5f; // points per cell = k / 33.5: cell edge = half the expected k-th neighbour distance
     if (n <= 8 * BUILD_THREADS)
-        hipLaunchKernelGGL(grid_build_kernel<8>, dim3(b), dim3(BUILD_THREADS), 0, s, n, radius, knn_k, stride_cells, xyz,
+        hipLaunchKernelGGL(grid_build_kernel<8>, dim3(b), dim3(BUILD_THREADS), 0, s, knn_div, n, radius, knn_k, stride_cells, xyz,
                            hdrs, cell_start, sorted_pts);
     else if (n <= 16 * BUILD_THREADS)
-        hipLaunchKernelGGL(grid_build_kernel<16>, dim3(b), dim3(BUILD_THREADS), 0, s, n, radius, knn_k, stride_cells,
+        hipLaunchKernelGGL(grid_build_kernel<16>, dim3(b), dim3(BUILD_THREADS), 0, s, knn_div, n, radius, knn_k, stride_cells,
                            xyz, hdrs, cell_start, sorted_pts);
     else
-        hipLaunchKernelGGL(grid_build_kernel<0>, dim3(b), dim3(BUILD_THREADS), 0, s, n, radius, knn_k, stride_cells, xyz,
+        hipLaunchKernelGGL(grid_build_kernel<0>, dim3(b), dim3(BUILD_THREADS), 0, s, knn_div, n, radius, knn_k, stride_cells, xyz,
                            hdrs, cell_start, sorted_pts);
 }
 
@@ -546,7 +549,7 @@ __device__ __forceinline__ u64 shfl_u64(u64 v, int src) {
 // a candidate is admitted iff its key is below that maximum (strict '<' on (distance, index)), exactly the
 // reference's rule whatever the order in which candidates are met.
 // MODE 0: squared distances (ogc_knn).  MODE 1: sqrt + radius clamp of the indices (ogc_knn_clamped).
-constexpr int KNN_FLAT_CAP = 96; // positions of the first shell kept as one flat list per query (else: run by run)
+constexpr int KNN_FLAT_CAP = 192; // positions of the first shell kept as one flat list per query (else: run by run)
 template <int MODE>
 __global__ __launch_bounds__(OGC_WAVE) void knn_grid_kernel(int n, int m, int k, float radius, int stride_cells,
                                                             const float *__restrict__ unknown,
@@ -660,42 +663,56 @@ __global__ __launch_bounds__(OGC_WAVE) void knn_grid_kernel(int n, int m, int k,
         const int cy = min(max(cell_coord(qy, h.miny, h.inv_h, h.gy), 0), h.gy - 1);
         const int cz = min(max(cell_coord(qz, h.minz, h.inv_h, h.gz), 0), h.gz - 1);
         const int rmax = max(max(max(cx, h.gx - 1 - cx), max(cy, h.gy - 1 - cy)), max(cz, h.gz - 1 - cz));
-        for (int R = 1;; ++R) {
+        const int R0 = limited ? 1 : 2; // radius (in cells) of the block scanned first
+        for (int R = R0;; ++R) {
             const int xa = max(cx - R, 0), xb = min(cx + R, h.gx - 1);
+            // Shell R as ONE flat list of record positions (LDS), scanned eight candidates at a time with the next load in
+            // flight.  A shell is (2R + 1)^2 rows of cells; a face row (or any row of the first block) contributes its
+            // whole x-extent as one run of the cell-sorted array, an inner row its two end cells.  Walking the runs one
+            // after the other is a dependent (bounds -> records) round trip per run with most of the eight lanes idle (a
+            // run holds a handful of points); here the lanes fetch the bounds of all runs (two passes: lengths, then
+            // positions), and the records are then read back to back.
             bool done_flat = false;
-            if (R == 1) {
-                // The 3^3 block is nine runs of the cell-sorted array; in a radius-limited search they hold two or three
-                // points each, so walking them one after the other is nine dependent (bounds -> records) round trips
-                // with most of the eight lanes idle.  Instead: the lanes fetch the bounds of all runs at once, write the
-                // record positions of the block as ONE flat list (LDS), and the group then scans that list eight
-                // candidates at a time with the next load in flight.
-                int j0 = 0, j1 = 0, j0b = 0, j1b = 0;
-                {
-                    const int z = cz + sub / 3 - 1, y = cy + sub % 3 - 1;
-                    if (z >= 0 && z < h.gz && y >= 0 && y < h.gy) {
-                        const int rowc = h.gx * (y + h.gy * z);
-                        j0 = cs[rowc + xa];
-                        j1 = cs[rowc + xb + 1];
+            {
+                const int side = 2 * R + 1, nrows = side * side;
+                auto row_runs = [&](int r, int &s0, int &l0, int &s1, int &l1) {
+                    s0 = l0 = s1 = l1 = 0;
+                    const int z = cz + r / side - R, y = cy + r % side - R;
+                    if (r >= nrows || z < 0 || z >= h.gz || y < 0 || y >= h.gy) return;
+                    const int rowc = h.gx * (y + h.gy * z);
+                    const bool face = R == R0 || z == cz - R || z == cz + R || y == cy - R || y == cy + R;
+                    if (face) {
+                        s0 = cs[rowc + xa];
+                        l0 = cs[rowc + xb + 1] - s0;
+                    } else {
+                        if (cx - R >= 0) { s0 = cs[rowc + cx - R]; l0 = cs[rowc + cx - R + 1] - s0; }
+                        if (cx + R <= h.gx - 1) { s1 = cs[rowc + cx + R]; l1 = cs[rowc + cx + R + 1] - s1; }
                     }
-                    if (sub == 0 && cz + 1 < h.gz && cy + 1 < h.gy) { // ninth run (y + 1, z + 1)
-                        const int rowc = h.gx * (cy + 1 + h.gy * (cz + 1));
-                        j0b = cs[rowc + xa];
-                        j1b = cs[rowc + xb + 1];
-                    }
+                };
+                int mine_total = 0;
+                for (int r = sub; r < nrows; r += SUB) {
+                    int s0, l0, s1, l1;
+                    row_runs(r, s0, l0, s1, l1);
+                    mine_total += l0 + l1;
                 }
-                const int len = j1 - j0, lenb = j1b - j0b;
-                int incl = len;
+                int incl = mine_total;
 #pragma unroll
                 for (int off = 1; off < SUB; off <<= 1) {
                     const int up = __shfl_up(incl, off, SUB);
                     if (sub >= off) incl += up;
                 }
-                const int total8 = __shfl(incl, qi * SUB + SUB - 1, 64);
-                const int total = total8 + __shfl(lenb, qi * SUB, 64);
+                const int total = __shfl(incl, qi * SUB + SUB - 1, 64);
                 if (total <= KNN_FLAT_CAP) {
                     int *mine = flat + qi * KNN_FLAT_CAP;
-                    for (int i = 0; i < len; ++i) mine[incl - len + i] = j0 + i;
-                    for (int i = 0; i < lenb; ++i) mine[total8 + i] = j0b + i;
+                    int w = incl - mine_total;
+                    for (int r = sub; r < nrows; r += SUB) {
+                        int s0, l0, s1, l1;
+                        row_runs(r, s0, l0, s1, l1);
+                        for (int i = 0; i < l0; ++i) mine[w + i] = s0 + i;
+                        w += l0;
+                        for (int i = 0; i < l1; ++i) mine[w + i] = s1 + i;
+                        w += l1;
+                    }
                     __builtin_amdgcn_s_waitcnt(0xc07f);
                     __builtin_amdgcn_wave_barrier();
                     const float4 nothing = make_float4(NAN, NAN, NAN, 0.f);
@@ -710,6 +727,7 @@ __global__ __launch_bounds__(OGC_WAVE) void knn_grid_kernel(int n, int m, int k,
                         cur = nxt;
                         f = fn;
                     }
+                    __builtin_amdgcn_wave_barrier(); // the list is rewritten by the next shell
                     done_flat = true;
                 }
             }
@@ -717,8 +735,8 @@ __global__ __launch_bounds__(OGC_WAVE) void knn_grid_kernel(int n, int m, int k,
                 for (int z = max(cz - R, 0); z <= min(cz + R, h.gz - 1); ++z)
                     for (int y = max(cy - R, 0); y <= min(cy + R, h.gy - 1); ++y) {
                         const int rowc = h.gx * (y + h.gy * z);
-                        const bool face = R == 1 || z == cz - R || z == cz + R || y == cy - R || y == cy + R;
-                        if (face) { // the whole x-extent of this row belongs to shell R (for R = 1: the full 3^3 block)
+                        const bool face = R == R0 || z == cz - R || z == cz + R || y == cy - R || y == cy + R;
+                        if (face) { // the whole x-extent of this row belongs to shell R (for R = R0: the full first block)
                             scan_run(cs[rowc + xa], cs[rowc + xb + 1]);
                         } else {    // inner row: only the two end cells are new
                             if (cx - R >= 0) scan_run(cs[rowc + cx - R], cs[rowc + cx - R + 1]);

@@ -44,7 +44,7 @@ def main():
     print("device:", torch.cuda.get_device_name(0))
 
     if "knn" in ops:
-        for (B, n, m, k) in [(1, 8192, 8192, 32), (4, 8192, 8192, 32), (16, 2048, 8192, 64), (16, 1024, 2048, 64),
+        for (B, n, m, k) in [(1, 8192, 8192, 32), (4, 8192, 8192, 32), (16, 8192, 8192, 32), (16, 2048, 8192, 64), (16, 1024, 2048, 64),
                              (16, 512, 1024, 64), (1, 2048, 2048, 16), (1, 4096, 8192, 32), (1, 8192, 8192, 1),
                              (8, 16384, 16384, 32)]:
             pc = cloud(B, m, g)
