@@ -296,6 +296,25 @@ int ogc_small_linear_fwd(int rows, int n_in, int n_out, const float *x, const fl
 int ogc_small_linear_bwd(int rows, int n_in, int n_out, const float *x, const float *weight, const float *grad_y,
                          float *grad_x, float *grad_weight, float *grad_bias, ogc_stream_t stream);
 
+/* Backward of  y = conv(relu(GroupNorm(y_prev)))  inside a SharedMLP (utils/nn_util.py:45-85) WITHOUT the GroupNorm
+ * backward passes (ogc_amd/csrc/gn_fused_bwd.hip).  pa, pb (b, cin): the GroupNorm of y_prev as an affine map per sample and
+ * channel (ogc_group_norm_coeffs); mask = [pa y_prev + pb > 0] (relu != 0) or 1.
+ *   ogc_conv1x1_wgrad_moments: moments (b, 2, cout, cin): H = g_y mask^T and H2 = g_y (mask . y_prev)^T per sample
+ *       (overwritten).  hw % 16 == 0.
+ *   ogc_gn_moments_combine: grad_w (cout, cin) = sum_b H2 diag(pa_b) + H diag(pb_b); grad_gamma, grad_beta (cin) of the
+ *       GroupNorm — ONE buffer of 2 cin floats, grad_beta == grad_gamma + cin; coef (b, cin, 3) = (alpha, c2, c3) of its adjoint
+ *       g_prev = alpha mask g_z + c2 y_prev + c3.  mean, rstd (b, groups), gamma (cin), w (cout, cin); cin <= 512.
+ *   ogc_conv1x1_dgrad_adjoint: grad_prev (b, cin, hw) = alpha mask (w^T grad_y) + c2 y_prev + c3 — the input gradient of the
+ *       convolution carried through ReLU and GroupNorm in the GEMM's epilogue.  hw % 64 == 0, cout <= 160. */
+int ogc_conv1x1_wgrad_moments(int b, int cin, int cout, int hw, int relu, const float *y_prev, const float *pa,
+                              const float *pb, const float *grad_y, float *moments, ogc_stream_t stream);
+int ogc_gn_moments_combine(int b, int cin, int cout, int hw, int groups, const float *moments, const float *w,
+                           const float *pa, const float *pb, const float *mean, const float *rstd, const float *gamma,
+                           float *grad_w, float *coef, float *grad_gamma, float *grad_beta, ogc_stream_t stream);
+int ogc_conv1x1_dgrad_adjoint(int b, int cin, int cout, int hw, int relu, const float *w, const float *grad_y,
+                              const float *y_prev, const float *pa, const float *pb, const float *coef, float *grad_prev,
+                              ogc_stream_t stream);
+
 /* A whole per-neighbourhood MLP and its max-pool in one launch, for INFERENCE
  *   utils/flowstep3d_util.py:57-66 (FlowEmbedding, the correlation layer) and :126-138 (set abstraction):
  *     for conv, bn in zip(mlp_convs, mlp_bns): x = relu(bn(conv(x)));   x = max(x, -1)

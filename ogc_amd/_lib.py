@@ -56,6 +56,9 @@ SIGNATURES = {
                                      _int, _vp],
     "ogc_small_linear_fwd": [_int, _int, _int, _vp, _vp, _vp, _vp, _vp],
     "ogc_small_linear_bwd": [_int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "ogc_conv1x1_wgrad_moments": [_int, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp],
+    "ogc_gn_moments_combine": [_int, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "ogc_conv1x1_dgrad_adjoint": [_int, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "ogc_mlp_chain_pool_supported": [_int, _int, _int, _int, _int],
     "ogc_mlp_chain_pool": [_int, _int, _int, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "ogc_corr_layer_pool_supported": [_int, _int, _int, _int, _int],

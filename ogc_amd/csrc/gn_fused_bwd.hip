@@ -1,0 +1,413 @@
+// gn_fused_bwd.hip — backward of  y = conv( relu( GroupNorm(y_prev) ) )  without the GroupNorm backward passes.
+//
+// Inside a SharedMLP (reference utils/nn_util.py:45-85: Conv2d 1x1 -> GroupNorm -> ReLU, repeated) the normalised
+// activation z = relu(a y_prev + bb) (a, bb per sample and channel: the GroupNorm folded into an affine map) is never
+// stored: the convolution and its weight gradient recompute it while loading y_prev (conv1x1.hip).  The backward pass
+// of one such layer used to be
+//     dW   = g_y z^T                      (weight gradient, reads y_prev and g_y)
+//     g_z  = W^T g_y                      (input gradient, writes g_z)
+//     S1, S2 per (sample, group)          (GroupNorm sums, reads y_prev and g_z)
+//     g_prev = alpha mask g_z + c2 y_prev + c3      (GroupNorm adjoint, reads y_prev and g_z, writes g_prev)
+// — nine passes over a tensor of the activation's size, five of them in the two GroupNorm kernels (3.1 ms of a 14 ms
+// C4 step, all of it re-reading).  Both GroupNorm sums follow from two MOMENT MATRICES the weight-gradient kernel can
+// accumulate next to each other:   with mask = [a y_prev + bb > 0],
+//     H  = g_y mask^T,   H2 = g_y (mask . y_prev)^T              (cout x cin each, per sample)
+//     dW = sum_b  H2 diag(a_b) + H diag(bb_b)
+//     T1[k] = sum_pos g_z[k] mask[k]          = sum_m W[m,k] H[m,k]
+//     T2[k] = sum_pos g_z[k] mask[k] y_prev[k] = sum_m W[m,k] H2[m,k]
+// so the sums are known BEFORE the input gradient is formed, and the input-gradient GEMM applies the adjoint in its
+// epilogue (it holds the g_z tile; it reads the matching y_prev tile) and writes g_prev directly: g_z never exists.
+// Five passes instead of nine: weight gradient 2 reads, input gradient 2 reads + 1 write.
+//   ogc_conv1x1_wgrad_moments   H, H2          (v_mfma_f32_16x16x4_f32, two accumulator sets)
+//   ogc_gn_moments_combine      dW, dgamma, dbeta, and alpha / c2 / c3 per (sample, channel)
+//   ogc_conv1x1_dgrad_adjoint   g_prev
+#include "ogc_common.h"
+
+namespace {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+constexpr int WG_WAVES = 4;
+
+// ---- moment matrices ------------------------------------------------------------------------------------------------
+// Same operand layout as conv1x1_wgrad_kernel: for a step of 16 positions lane (i = l & 15, k = l >> 4) loads ONE float4 =
+// row (c0 + i), positions pb + 4k .. 4k+3; MFMA k-slot k of sub-step s is position pb + 4k + s for both operands.
+// A workgroup stays inside one sample (blockIdx.x = sample * chunks + chunk): H / H2 are per sample.
+template <int COB, int CIB>
+__global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void wgrad_moments_kernel(int cin, int cout, int hw, int chunks,
+                                                                           int steps_per_wave, int relu,
+                                                                           const float *__restrict__ x,   // y_prev (B, cin, hw)
+                                                                           const float *__restrict__ dy,  // g_y (B, cout, hw)
+                                                                           const float *__restrict__ aff_a,
+                                                                           const float *__restrict__ aff_b,
+                                                                           float *__restrict__ hm) {      // (B, 2, cout, cin)
+    __shared__ float red[2 * COB * CIB * 256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, k = lane >> 4;
+    const int img = blockIdx.x / chunks, chunk = blockIdx.x - img * chunks;
+    const int co0 = blockIdx.y * (16 * COB), ci0 = blockIdx.z * (16 * CIB);
+    const int steps_per_img = hw >> 4;
+    const int first = (chunk * WG_WAVES + wave) * steps_per_wave;
+    const int last = min(first + steps_per_wave, steps_per_img);
+
+    v4f acc1[COB][CIB], acc2[COB][CIB];
+#pragma unroll
+    for (int a = 0; a < COB; ++a)
+#pragma unroll
+        for (int c = 0; c < CIB; ++c) {
+            acc1[a][c] = (v4f){0.f, 0.f, 0.f, 0.f};
+            acc2[a][c] = (v4f){0.f, 0.f, 0.f, 0.f};
+        }
+    int yrow[COB], xrow[CIB];
+    float ca[CIB], cb[CIB];
+#pragma unroll
+    for (int a = 0; a < COB; ++a) yrow[a] = min(co0 + a * 16 + i, cout - 1) * hw;
+#pragma unroll
+    for (int c = 0; c < CIB; ++c) {
+        const int ch = min(ci0 + c * 16 + i, cin - 1);
+        xrow[c] = ch * hw;
+        ca[c] = aff_a[(size_t)img * cin + ch];
+        cb[c] = aff_b[(size_t)img * cin + ch];
+    }
+    const float *yb_ = dy + (size_t)img * cout * hw + 4 * k;
+    const float *xb_ = x + (size_t)img * cin * hw + 4 * k;
+    int cur = first;
+    auto load = [&](float4(&yv)[COB], float4(&xv)[CIB]) { // step `cur`, then advance
+        const bool ok = cur < last;
+        const int pb = cur * 16;
+#pragma unroll
+        for (int a = 0; a < COB; ++a)
+            yv[a] = (ok && co0 + a * 16 + i < cout) ? *reinterpret_cast<const float4 *>(yb_ + yrow[a] + pb)
+                                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int c = 0; c < CIB; ++c)
+            xv[c] = (ok && ci0 + c * 16 + i < cin) ? *reinterpret_cast<const float4 *>(xb_ + xrow[c] + pb)
+                                                   : make_float4(NAN, NAN, NAN, NAN); // NaN: mask 0 whatever a, bb
+        ++cur;
+    };
+    auto fma16 = [&](const float4(&yv)[COB], const float4(&xraw)[CIB]) {
+        float4 m1[CIB], m2[CIB];
+#pragma unroll
+        for (int c = 0; c < CIB; ++c) {
+            const float4 v = xraw[c];
+            // mask = [a y + bb > 0] (relu) — false for the NaN of rows / steps that do not exist; without relu: [y == y]
+            const bool bx = relu ? fmaf(ca[c], v.x, cb[c]) > 0.f : v.x == v.x;
+            const bool by = relu ? fmaf(ca[c], v.y, cb[c]) > 0.f : v.y == v.y;
+            const bool bz = relu ? fmaf(ca[c], v.z, cb[c]) > 0.f : v.z == v.z;
+            const bool bw = relu ? fmaf(ca[c], v.w, cb[c]) > 0.f : v.w == v.w;
+            m1[c] = make_float4(bx ? 1.f : 0.f, by ? 1.f : 0.f, bz ? 1.f : 0.f, bw ? 1.f : 0.f);
+            m2[c] = make_float4(bx ? v.x : 0.f, by ? v.y : 0.f, bz ? v.z : 0.f, bw ? v.w : 0.f);
+        }
+#pragma unroll
+        for (int a = 0; a < COB; ++a)
+#pragma unroll
+            for (int c = 0; c < CIB; ++c) {
+                acc1[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(yv[a].x, m1[c].x, acc1[a][c], 0, 0, 0);
+                acc2[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(yv[a].x, m2[c].x, acc2[a][c], 0, 0, 0);
+                acc1[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(yv[a].y, m1[c].y, acc1[a][c], 0, 0, 0);
+                acc2[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(yv[a].y, m2[c].y, acc2[a][c], 0, 0, 0);
+                acc1[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(yv[a].z, m1[c].z, acc1[a][c], 0, 0, 0);
+                acc2[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(yv[a].z, m2[c].z, acc2[a][c], 0, 0, 0);
+                acc1[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(yv[a].w, m1[c].w, acc1[a][c], 0, 0, 0);
+                acc2[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(yv[a].w, m2[c].w, acc2[a][c], 0, 0, 0);
+            }
+    };
+
+    float4 ya[COB], xa[CIB], yb[COB], xb[CIB];
+    load(ya, xa);
+    for (int s = 0; s < steps_per_wave; s += 2) { // ping-pong registers: next step's loads fly during the MFMAs
+        load(yb, xb);
+        fma16(ya, xa);
+        load(ya, xa);
+        if (s + 1 < steps_per_wave) fma16(yb, xb);
+    }
+
+    for (int t = threadIdx.x; t < 2 * COB * CIB * 256; t += WG_WAVES * OGC_WAVE) red[t] = 0.0f;
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < COB; ++a)
+#pragma unroll
+        for (int c = 0; c < CIB; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { // C/D layout: lane l holds rows (l >> 4) * 4 + r of column l & 15
+                atomicAdd(&red[(a * CIB + c) * 256 + (k * 4 + r) * 16 + i], acc1[a][c][r]);
+                atomicAdd(&red[(COB * CIB + a * CIB + c) * 256 + (k * 4 + r) * 16 + i], acc2[a][c][r]);
+            }
+    __syncthreads();
+    float *dst = hm + (size_t)img * 2 * cout * cin;
+    for (int t = threadIdx.x; t < 2 * COB * CIB * 256; t += WG_WAVES * OGC_WAVE) {
+        const int which = t / (COB * CIB * 256), u = t - which * (COB * CIB * 256);
+        const int blk = u >> 8, a = blk / CIB, c = blk % CIB;
+        const int row = co0 + a * 16 + ((u & 255) >> 4), col = ci0 + c * 16 + (u & 15);
+        const float v = red[t];
+        if (row < cout && col < cin && v != 0.0f) unsafeAtomicAdd(dst + ((size_t)which * cout + row) * cin + col, v);
+    }
+}
+
+template <int COB, int CIB>
+void moments_launch(int b, int cin, int cout, int hw, int relu, const float *x, const float *dy, const float *pa,
+                    const float *pb, float *hm, hipStream_t s) {
+    const int steps_per_img = hw >> 4;
+    const int tiles = ogc_divup(cout, 16 * COB) * ogc_divup(cin, 16 * CIB);
+    long long waves = (2048 / tiles) / b;            // wavefronts per sample and tile pair: ~2048 over the chip
+    if (waves < 4) waves = 4;
+    int spw = (int)((steps_per_img + waves - 1) / waves);
+    if (spw < 8) spw = 8;
+    spw = (spw + 1) / 2 * 2;
+    const int chunks = ogc_divup(steps_per_img, spw * WG_WAVES);
+    dim3 grid(b * chunks, ogc_divup(cout, 16 * COB), ogc_divup(cin, 16 * CIB));
+    hipLaunchKernelGGL((wgrad_moments_kernel<COB, CIB>), grid, dim3(WG_WAVES * OGC_WAVE), 0, s, cin, cout, hw, chunks, spw,
+                       relu, x, dy, pa, pb, hm);
+}
+
+// ---- dW, the GroupNorm parameter gradients and the coefficients of the adjoint ----------------------------------------------
+// blocks [0, b): one per sample — T1, T2 per channel, the two sums per group, alpha / c2 / c3 per channel, and the sample's
+// share of dgamma / dbeta; the other blocks: one element of dW per thread.
+__global__ __launch_bounds__(256) void moments_combine_kernel(int b, int cin, int cout, int hw, int groups,
+                                                              const float *__restrict__ hm, const float *__restrict__ w,
+                                                              const float *__restrict__ pa, const float *__restrict__ pb,
+                                                              const float *__restrict__ mean, const float *__restrict__ rstd,
+                                                              const float *__restrict__ gamma, float *__restrict__ dw,
+                                                              float *__restrict__ coef, // (b, cin, 3): alpha, c2, c3
+                                                              float *__restrict__ dgamma, float *__restrict__ dbeta) {
+    __shared__ double s1[32], s2[32];
+    const int cpg = cin / groups;
+    if ((int)blockIdx.x < b) {
+        const int img = blockIdx.x;
+        __shared__ double tt1[512], tt2[512]; // T1, T2 per channel (cin <= 512, checked by the entry point)
+        for (int t = threadIdx.x; t < 512; t += blockDim.x) { tt1[t] = 0.0; tt2[t] = 0.0; }
+        if (threadIdx.x < 32) { s1[threadIdx.x] = 0.0; s2[threadIdx.x] = 0.0; }
+        __syncthreads();
+        const float *h1 = hm + (size_t)img * 2 * cout * cin, *h2 = h1 + (size_t)cout * cin;
+        // work item = (channel k, row lane ml of 8): consecutive threads take consecutive channels (coalesced rows of H)
+        for (int it = threadIdx.x; it < cin * 8; it += blockDim.x) {
+            const int ml = it / cin, k = it - ml * cin;
+            double t1 = 0.0, t2 = 0.0;
+            for (int m = ml; m < cout; m += 8) {
+                const double wv = w[(size_t)m * cin + k];
+                t1 += wv * h1[(size_t)m * cin + k];
+                t2 += wv * h2[(size_t)m * cin + k];
+            }
+            atomicAdd(&tt1[k], t1);
+            atomicAdd(&tt2[k], t2);
+        }
+        __syncthreads();
+        for (int k = threadIdx.x; k < cin; k += blockDim.x) {
+            const int g = k / cpg;
+            const double mu = mean[img * groups + g], r = rstd[img * groups + g], gm = gamma[k];
+            atomicAdd(&s1[g], gm * tt1[k]);                       // S1 = sum_c gamma_c sum_pos g'
+            atomicAdd(&s2[g], gm * (tt2[k] - mu * tt1[k]) * r);   // S2 = sum_c gamma_c sum_pos g' xhat
+        }
+        __syncthreads();
+        const double n = (double)cpg * (double)hw;
+        for (int k = threadIdx.x; k < cin; k += blockDim.x) {
+            const int g = k / cpg;
+            const double mu = mean[img * groups + g], r = rstd[img * groups + g];
+            const double c2 = -r * r * s2[g] / n;
+            const double c3 = -r * s1[g] / n - c2 * mu;
+            float *o = coef + ((size_t)img * cin + k) * 3;
+            o[0] = (float)((double)gamma[k] * r);
+            o[1] = (float)c2;
+            o[2] = (float)c3;
+        }
+        // this sample's share of the GroupNorm parameter gradients (fp32 atomics over the b samples; zeroed by the entry point)
+        for (int k = threadIdx.x; k < cin; k += blockDim.x) {
+            const int g = k / cpg;
+            const double mu = mean[img * groups + g], r = rstd[img * groups + g];
+            unsafeAtomicAdd(dgamma + k, (float)((tt2[k] - mu * tt1[k]) * r));
+            unsafeAtomicAdd(dbeta + k, (float)tt1[k]);
+        }
+    } else {
+        // one element of dW per thread, summed over the samples in a fixed order
+        const long long e = ((long long)blockIdx.x - b) * blockDim.x + threadIdx.x;
+        if (e < (long long)cout * cin) {
+            const int k = (int)(e % cin);
+            float acc = 0.f;
+            for (int img = 0; img < b; ++img) {
+                const float *h1 = hm + (size_t)img * 2 * cout * cin, *h2 = h1 + (size_t)cout * cin;
+                acc += pa[(size_t)img * cin + k] * h2[e] + pb[(size_t)img * cin + k] * h1[e];
+            }
+            dw[e] = acc;
+        }
+    }
+}
+
+// ---- input gradient with the GroupNorm adjoint in the epilogue -----------------------------------------------------------------
+// g_prev[b, m, p] = alpha[b, m] mask (sum_k w[k, m] g_y[b, k, p]) + c2[b, m] y_prev[b, m, p] + c3[b, m]
+// The GEMM of conv1x1_gemm_kernel<TRANSPOSE_A = true> (M = cin, K = cout): a wave owns 64 positions, the whole K x 64 tile
+// of g_y in registers, A = w^T staged through LDS 64 rows at a time; the epilogue holds four consecutive positions of
+// an output row per lane and reads the same four of y_prev.
+template <int KQ>
+__global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void dgrad_adjoint_kernel(int M, int K, int hw, int relu,
+                                                                           const float *__restrict__ w,     // (K, M)
+                                                                           const float *__restrict__ gy,    // (B, K, hw)
+                                                                           const float *__restrict__ yprev, // (B, M, hw)
+                                                                           const float *__restrict__ pa,
+                                                                           const float *__restrict__ pb,
+                                                                           const float *__restrict__ coef,  // (B, M, 3)
+                                                                           float *__restrict__ out) {       // (B, M, hw)
+    extern __shared__ __attribute__((aligned(16))) float a_lds[]; // [Kq][64][4] weights, then [64][5] coefficients
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, kk = lane >> 4;
+    const int b = blockIdx.y;
+    const int p0 = (blockIdx.x * WG_WAVES + wave) * 64;
+    const int Kq = (K + 3) >> 2;
+    const bool live = p0 < hw;
+    const float *inb = gy + (size_t)b * K * hw;
+    float *outb = out + (size_t)b * M * hw;
+    const float *yb = yprev + (size_t)b * M * hw;
+    float *cf = a_lds + (size_t)Kq * 256;
+
+    float4 xin[KQ];
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) {
+        const int row = q * 4 + kk;
+        xin[q] = (live && q < Kq && row < K) ? *reinterpret_cast<const float4 *>(inb + (size_t)row * hw + p0 + 4 * j)
+                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int m0 = 0; m0 < M; m0 += 64) {
+        __syncthreads(); // previous tile fully consumed
+        for (int t = threadIdx.x; t < Kq * 256; t += WG_WAVES * OGC_WAVE) {
+            const int kr = t & 3, mi = (t >> 2) & 63, q = t >> 8;
+            const int m = m0 + mi, k = q * 4 + kr;
+            a_lds[t] = (m < M && k < K) ? w[(size_t)k * M + m] : 0.f;
+        }
+        for (int t = threadIdx.x; t < 64; t += WG_WAVES * OGC_WAVE) {
+            const int m = m0 + t;
+            const bool in = m < M;
+            cf[t * 5 + 0] = in ? pa[(size_t)b * M + m] : 0.f;
+            cf[t * 5 + 1] = in ? pb[(size_t)b * M + m] : 0.f;
+            cf[t * 5 + 2] = in ? coef[((size_t)b * M + m) * 3] : 0.f;
+            cf[t * 5 + 3] = in ? coef[((size_t)b * M + m) * 3 + 1] : 0.f;
+            cf[t * 5 + 4] = in ? coef[((size_t)b * M + m) * 3 + 2] : 0.f;
+        }
+        __syncthreads();
+        const int nblk = min(4, (M - m0 + 15) >> 4);
+        // One 16-row block of the tile at a time (unlike conv1x1_gemm_kernel, which runs the four blocks side by side): the
+        // block's accumulators are 16 registers instead of 64, its y_prev values (requested before its MFMA loop, consumed
+        // after it) another 16 — the epilogue needs both in VGPRs, and holding the whole tile there costs two wavefronts
+        // per SIMD.  Four independent accumulators (the four column blocks) keep the MFMA pipe issuing back to back.
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            if (a < nblk) {
+                float4 yv[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + a * 16 + kk * 4 + r;
+                    yv[r] = (live && m < M) ? *reinterpret_cast<const float4 *>(yb + (size_t)m * hw + p0 + 4 * j)
+                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                v4f acc[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[c] = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < KQ; ++q) {
+                    if (q < Kq) {
+                        const float av = a_lds[(q * 64 + a * 16 + j) * 4 + kk]; // A[m0+16a+j][4q+kk]
+                        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xin[q].x, acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xin[q].y, acc[1], 0, 0, 0);
+                        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xin[q].z, acc[2], 0, 0, 0);
+                        acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xin[q].w, acc[3], 0, 0, 0);
+                    }
+                }
+                if (live) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int mi = a * 16 + kk * 4 + r, m = m0 + mi; // C/D layout: row (l >> 4) * 4 + r, column l & 15
+                        if (m < M) {
+                            const float fa = cf[mi * 5], fb = cf[mi * 5 + 1], al = cf[mi * 5 + 2], c2 = cf[mi * 5 + 3], c3 = cf[mi * 5 + 4];
+                            const float4 y = yv[r];
+                            float4 g = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+                            if (relu) {
+                                g.x = fmaf(fa, y.x, fb) > 0.f ? g.x : 0.f; g.y = fmaf(fa, y.y, fb) > 0.f ? g.y : 0.f;
+                                g.z = fmaf(fa, y.z, fb) > 0.f ? g.z : 0.f; g.w = fmaf(fa, y.w, fb) > 0.f ? g.w : 0.f;
+                            }
+                            float4 o;
+                            o.x = fmaf(al, g.x, fmaf(c2, y.x, c3)); o.y = fmaf(al, g.y, fmaf(c2, y.y, c3));
+                            o.z = fmaf(al, g.z, fmaf(c2, y.z, c3)); o.w = fmaf(al, g.w, fmaf(c2, y.w, c3));
+                            *reinterpret_cast<float4 *>(outb + (size_t)m * hw + p0 + 4 * j) = o;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+} // namespace
+
+extern "C" int ogc_conv1x1_wgrad_moments(int b, int cin, int cout, int hw, int relu, const float *y_prev, const float *pa,
+                                         const float *pb, const float *grad_y, float *moments, ogc_stream_t stream) {
+    OGC_REQUIRE(b >= 0 && cin >= 1 && cout >= 1 && hw >= 1, "ogc_conv1x1_wgrad_moments: bad shape");
+    OGC_REQUIRE(y_prev && pa && pb && grad_y && moments, "ogc_conv1x1_wgrad_moments: null pointer");
+    if ((hw & 15) != 0 || (((uintptr_t)y_prev | (uintptr_t)grad_y) & 15) != 0) {
+        ogc_set_error("ogc_conv1x1_wgrad_moments: hw=%d must be a multiple of 16 and the tensors 16-byte aligned", hw);
+        return OGC_ERR_UNSUPPORTED;
+    }
+    OGC_REQUIRE((long long)cin * hw < (1ll << 31) && (long long)cout * hw < (1ll << 31) && b <= 32768,
+                "ogc_conv1x1_wgrad_moments: one sample exceeds 32-bit indexing");
+    hipStream_t s = (hipStream_t)stream;
+    if (b == 0) return OGC_OK;
+    if (hipMemsetAsync(moments, 0, sizeof(float) * 2 * (size_t)b * cin * cout, s) != hipSuccess) {
+        ogc_set_error("ogc_conv1x1_wgrad_moments: memset failed");
+        return OGC_ERR_LAUNCH;
+    }
+    if (cout <= 16 && cin <= 16) moments_launch<1, 1>(b, cin, cout, hw, relu, y_prev, grad_y, pa, pb, moments, s);
+    else if (cout <= 32 && cin <= 16) moments_launch<2, 1>(b, cin, cout, hw, relu, y_prev, grad_y, pa, pb, moments, s);
+    else if (cout <= 32 && cin <= 32) moments_launch<2, 2>(b, cin, cout, hw, relu, y_prev, grad_y, pa, pb, moments, s);
+    else if (cin <= 16) moments_launch<4, 1>(b, cin, cout, hw, relu, y_prev, grad_y, pa, pb, moments, s);
+    else if (cin <= 32) moments_launch<4, 2>(b, cin, cout, hw, relu, y_prev, grad_y, pa, pb, moments, s);
+    else if (cout <= 32) moments_launch<2, 4>(b, cin, cout, hw, relu, y_prev, grad_y, pa, pb, moments, s);
+    else moments_launch<4, 4>(b, cin, cout, hw, relu, y_prev, grad_y, pa, pb, moments, s);
+    OGC_CHECK_LAUNCH("ogc_conv1x1_wgrad_moments");
+    return OGC_OK;
+}
+
+extern "C" int ogc_gn_moments_combine(int b, int cin, int cout, int hw, int groups, const float *moments, const float *w,
+                                      const float *pa, const float *pb, const float *mean, const float *rstd,
+                                      const float *gamma, float *grad_w, float *coef, float *grad_gamma,
+                                      float *grad_beta, ogc_stream_t stream) {
+    OGC_REQUIRE(b >= 1 && cin >= 1 && cin <= 512 && cout >= 1 && hw >= 1 && groups >= 1 && groups <= 32 && cin % groups == 0,
+                "ogc_gn_moments_combine: bad shape (cin <= 512, groups <= 32 dividing cin)");
+    OGC_REQUIRE(moments && w && pa && pb && mean && rstd && gamma && grad_w && coef && grad_gamma && grad_beta,
+                "ogc_gn_moments_combine: null pointer");
+    OGC_REQUIRE(grad_beta == grad_gamma + cin, "ogc_gn_moments_combine: grad_beta must follow grad_gamma (one 2 x cin buffer)");
+    if (hipMemsetAsync(grad_gamma, 0, sizeof(float) * 2 * (size_t)cin, (hipStream_t)stream) != hipSuccess) {
+        ogc_set_error("ogc_gn_moments_combine: memset failed");
+        return OGC_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL(moments_combine_kernel, dim3(b + ogc_divup((long long)cout * cin, 256)), dim3(256), 0,
+                       (hipStream_t)stream, b, cin, cout, hw, groups, moments, w, pa, pb, mean, rstd, gamma, grad_w, coef,
+                       grad_gamma, grad_beta);
+    OGC_CHECK_LAUNCH("ogc_gn_moments_combine");
+    return OGC_OK;
+}
+
+extern "C" int ogc_conv1x1_dgrad_adjoint(int b, int cin, int cout, int hw, int relu, const float *w, const float *grad_y,
+                                         const float *y_prev, const float *pa, const float *pb, const float *coef,
+                                         float *grad_prev, ogc_stream_t stream) {
+    OGC_REQUIRE(b >= 0 && cin >= 1 && cout >= 1 && hw >= 1, "ogc_conv1x1_dgrad_adjoint: bad shape");
+    OGC_REQUIRE(w && grad_y && y_prev && pa && pb && coef && grad_prev, "ogc_conv1x1_dgrad_adjoint: null pointer");
+    if ((hw & 63) != 0 || cout > 160 || (((uintptr_t)grad_y | (uintptr_t)y_prev | (uintptr_t)grad_prev) & 15) != 0) {
+        ogc_set_error("ogc_conv1x1_dgrad_adjoint: needs hw %% 64 == 0, cout <= 160 and 16-byte aligned tensors (hw=%d, cout=%d)",
+                      hw, cout);
+        return OGC_ERR_UNSUPPORTED;
+    }
+    OGC_REQUIRE((long long)cin * hw < (1ll << 31) && (long long)cout * hw < (1ll << 31) && b <= 65535,
+                "ogc_conv1x1_dgrad_adjoint: one sample exceeds 32-bit indexing");
+    if (b == 0) return OGC_OK;
+    const int M = cin, K = cout, Kq = (K + 3) / 4;
+    const size_t lds = ((size_t)Kq * 256 + 64 * 5) * sizeof(float);
+    dim3 grid(ogc_divup(hw, 64 * WG_WAVES), b);
+    hipStream_t s = (hipStream_t)stream;
+#define OGC_DGA(KQV)                                                                                                       \
+    hipLaunchKernelGGL((dgrad_adjoint_kernel<KQV>), grid, dim3(WG_WAVES * OGC_WAVE), lds, s, M, K, hw, relu, w, grad_y, y_prev, \
+                       pa, pb, coef, grad_prev)
+    if (Kq <= 8) OGC_DGA(8);
+    else if (Kq <= 16) OGC_DGA(16);
+    else if (Kq <= 25) OGC_DGA(25);
+    else if (Kq <= 33) OGC_DGA(33);
+    else OGC_DGA(40);
+#undef OGC_DGA
+    OGC_CHECK_LAUNCH("ogc_conv1x1_dgrad_adjoint");
+    return OGC_OK;
+}

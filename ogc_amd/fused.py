@@ -576,6 +576,10 @@ def matched_distances(mask1, mask2, loss_norm):
     return _MatchedDistance.apply(mask1, mask2, cols[:PB], cols[PB:], int(loss_norm))
 
 
+FUSED_GN_BACKWARD_MAX_WIDTH = 64
+FUSED_GN_BACKWARD = True   # _NormActConv.backward through the moment matrices (csrc/gn_fused_bwd.hip); False: the separate passes
+
+
 # ---- deferred normalisation inside a SharedMLP ----------------------------------------------------------------
 class _NormActConv(Function):
     """y = conv(act(GroupNorm(y_prev))) WITHOUT materialising the normalised activation: the norm of the previous layer
@@ -643,6 +647,24 @@ class _NormActConv(Function):
         grad_y = grad_y.contiguous()
         w = conv_weight.detach().contiguous()
         grad_w = torch.empty(cout, cin, dtype=torch.float32, device=y_prev.device)
+        # (up to 64 channels: from 128 on the second accumulator set makes the weight-gradient kernel MFMA-bound and the
+        # whole path slower than the separate passes — tools/gn_bwd_compare.py)
+        if (FUSED_GN_BACKWARD and getattr(nat, "conv1x1_dgrad_adjoint_wrapper", None) is not None and hw % 64 == 0
+                and cout <= FUSED_GN_BACKWARD_MAX_WIDTH and cin <= FUSED_GN_BACKWARD_MAX_WIDTH and gn_groups <= 32
+                and cin % gn_groups == 0 and nat.get_matmul_precision() == "fp32"):
+            # moment matrices next to the weight gradient -> GroupNorm sums -> adjoint in the input gradient's epilogue:
+            # the gradient w.r.t. the normalised activation and both GroupNorm backward passes never touch memory
+            dev = y_prev.device
+            moments = torch.empty(B, 2, cout, cin, dtype=torch.float32, device=dev)
+            nat.conv1x1_wgrad_moments_wrapper(B, cin, cout, hw, relu, y_prev, a, bb, grad_y, moments)
+            coef = torch.empty(B, cin, 3, dtype=torch.float32, device=dev)
+            ggb = torch.empty(2, cin, dtype=torch.float32, device=dev)
+            gw, gb = ggb[0], ggb[1]
+            nat.gn_moments_combine_wrapper(B, cin, cout, hw, gn_groups, moments, w.view(cout, cin), a, bb, mean, rstd,
+                                           gn_weight.detach().contiguous(), grad_w, coef, gw, gb)
+            grad_prev = torch.empty_like(y_prev)
+            nat.conv1x1_dgrad_adjoint_wrapper(B, cin, cout, hw, relu, w.view(cout, cin), grad_y, y_prev, a, bb, coef, grad_prev)
+            return grad_prev, None, gw, gb, grad_w.view_as(conv_weight), None, None, None, None, None, None
         nat.conv1x1_wgrad_affine_wrapper(B, cin, cout, hw, relu, y_prev, a, bb, grad_y, grad_w)
         # gradient w.r.t. the (never stored) normalised activation, then through GroupNorm (+ ReLU)
         if _gemm_ok(cout, hw) and _plain_gemm_mine(cout):

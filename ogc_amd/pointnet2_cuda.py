@@ -390,6 +390,22 @@ def attention_bwd_wrapper(h, scale, q, k, v, out, prob, dout, dq, dk, dv):
          _f(prob, "prob"), _f(dout, "dout"), dqp, lddq, dkp, lddk, dvp, lddv)
 
 
+def conv1x1_wgrad_moments_wrapper(b, cin, cout, hw, relu, y_prev, pa, pb, grad_y, moments):
+    _run("ogc_conv1x1_wgrad_moments", y_prev, b, cin, cout, hw, int(relu), _f(y_prev, "y_prev"), _f(pa, "pa"), _f(pb, "pb"),
+         _f(grad_y, "grad_y"), _f(moments, "moments"))
+
+
+def gn_moments_combine_wrapper(b, cin, cout, hw, groups, moments, w, pa, pb, mean, rstd, gamma, grad_w, coef, gw, gb):
+    _run("ogc_gn_moments_combine", moments, b, cin, cout, hw, groups, _f(moments, "moments"), _f(w, "w"), _f(pa, "pa"),
+         _f(pb, "pb"), _f(mean, "mean"), _f(rstd, "rstd"), _f(gamma, "gamma"), _f(grad_w, "grad_w"), _f(coef, "coef"),
+         _f(gw, "grad_gamma"), _f(gb, "grad_beta"))
+
+
+def conv1x1_dgrad_adjoint_wrapper(b, cin, cout, hw, relu, w, grad_y, y_prev, pa, pb, coef, grad_prev):
+    _run("ogc_conv1x1_dgrad_adjoint", grad_y, b, cin, cout, hw, int(relu), _f(w, "w"), _f(grad_y, "grad_y"),
+         _f(y_prev, "y_prev"), _f(pa, "pa"), _f(pb, "pb"), _f(coef, "coef"), _f(grad_prev, "grad_prev"))
+
+
 def mlp_chain_pool_supported(c0, c1, c2, c3, nsample):
     """Is there a fused inference kernel for the MLP c0 -> c1 -> c2 [-> c3] followed by the max over nsample?"""
     return bool(_lib.load().ogc_mlp_chain_pool_supported(c0, c1, c2, c3, nsample))

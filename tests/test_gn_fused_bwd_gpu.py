@@ -1,0 +1,67 @@
+"""Backward of conv(relu(GroupNorm(y_prev))) through the moment matrices (ogc_conv1x1_wgrad_moments ->
+ogc_gn_moments_combine -> ogc_conv1x1_dgrad_adjoint, csrc/gn_fused_bwd.hip) against the same op sequence evaluated in
+float64 by torch (the reference's layers: utils/nn_util.py:45-85), and against the separate GroupNorm-backward passes it
+replaces: input gradient, convolution weight gradient, GroupNorm weight / bias gradients."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-300))
+
+
+@pytest.mark.parametrize("B,cin,cout,hw,groups,relu", [
+    (2, 32, 32, 2048, 4, True), (3, 32, 64, 4096, 4, True), (2, 64, 128, 1024, 4, True), (2, 128, 128, 2048, 4, True),
+    (2, 16, 24, 640, 4, True), (1, 100, 160, 512, 4, True), (2, 64, 64, 1024, 8, False), (16, 32, 32, 8192, 4, True)])
+def test_fused_gn_backward(B, cin, cout, hw, groups, relu):
+    import ogc_amd  # noqa: F401
+    from ogc_amd import fused
+    g = torch.Generator().manual_seed(B * 1000 + cin + cout)
+    y_prev = (torch.randn(B, cin, hw, 1, generator=g) * 1.5 + 0.3).cuda()
+    gn = torch.nn.GroupNorm(groups, cin).cuda()
+    conv = torch.nn.Conv2d(cin, cout, 1, bias=False).cuda()
+    with torch.no_grad():
+        gn.weight.copy_(torch.rand(cin, generator=g) + 0.5)
+        gn.weight[::5] *= -1.0                                     # negative scales too
+        gn.bias.copy_(torch.rand(cin, generator=g) - 0.5)
+    probe = torch.randn(B, cout, hw, 1, generator=g).cuda()
+
+    width = fused.FUSED_GN_BACKWARD_MAX_WIDTH
+    fused.FUSED_GN_BACKWARD_MAX_WIDTH = 160          # the kernels are tested at every width they accept
+
+    def run(flag):
+        fused.FUSED_GN_BACKWARD = flag
+        yp = y_prev.clone().requires_grad_(True)
+        for p in list(gn.parameters()) + list(conv.parameters()):
+            p.grad = None
+        y, _ = fused.norm_act_conv(yp, None, gn, relu, conv)
+        (y * probe).sum().backward()
+        return y.detach(), yp.grad, conv.weight.grad.clone(), gn.weight.grad.clone(), gn.bias.grad.clone()
+
+    try:
+        assert fused.norm_act_conv_available(y_prev, gn, conv)
+        new = run(True)
+        old = run(False)
+    finally:
+        fused.FUSED_GN_BACKWARD, fused.FUSED_GN_BACKWARD_MAX_WIDTH = True, width
+    # float64 truth
+    yp = y_prev.double().requires_grad_(True)
+    z = F.group_norm(yp, groups, gn.weight.double(), gn.bias.double(), gn.eps)
+    z = F.relu(z) if relu else z
+    y = F.conv2d(z, conv.weight.double())
+    gw64 = gn.weight.double().detach().requires_grad_(True)
+    gb64 = gn.bias.double().detach().requires_grad_(True)
+    cw64 = conv.weight.double().detach().requires_grad_(True)
+    z2 = F.group_norm(yp, groups, gw64, gb64, gn.eps)
+    y2 = F.conv2d(F.relu(z2) if relu else z2, cw64)
+    truth = torch.autograd.grad((y2 * probe.double()).sum(), [yp, cw64, gw64, gb64])
+    assert torch.equal(new[0], old[0])
+    names = ("grad_prev", "grad_conv_weight", "grad_gn_weight", "grad_gn_bias")
+    for name, n_, o_, t_ in zip(names, new[1:], old[1:], truth):
+        e_new, e_old = _rel(n_, t_), _rel(o_, t_)
+        # as close to the exact gradient as the separate passes (which accumulate their sums in fp64), within a small factor
+        assert e_new <= max(4 * e_old, 2e-6), (name, e_new, e_old)
+        assert e_new < 1e-5, (name, e_new)

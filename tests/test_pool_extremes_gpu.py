@@ -1,7 +1,7 @@
 """Max-pool of a set-abstraction MLP from the neighbourhood extremes its last convolution records
 (ogc_conv1x1_gemm_affine_pool + ogc_group_norm_pool_extremes) against the pass over the full tensor
-(ogc_conv1x1_gemm_affine + ogc_group_norm_maxpool_fwd_stats): same pooled values and input gradients bit for bit (hence the same
-arg-max element in every neighbourhood), parameter gradients to rounding."""
+(ogc_conv1x1_gemm_affine + ogc_group_norm_maxpool_fwd_stats): same pooled values bit for bit, input gradients to the last bits
+(hence the same arg-max element in every neighbourhood), parameter gradients to rounding."""
 import pytest
 import torch
 
@@ -66,8 +66,12 @@ def test_pool_from_extremes_is_bit_identical(B, cin, widths, P, S):
     want = _run(mlp, x, w, False)
     assert len(got) == len(want)
     for i, (a, b) in enumerate(zip(got, want)):
-        if i < 2:      # pooled output and input gradient: bit for bit (same arg-max element in every neighbourhood)
+        if i == 0:     # pooled output: bit for bit
             assert torch.equal(a, b), (i, (a - b).abs().max().item())
+        elif i == 1:   # input gradient: same arg-max element in every neighbourhood (a different one would move whole entries);
+            # its GroupNorm sums now come from moment matrices accumulated with fp32 atomics (csrc/gn_fused_bwd.hip), so
+            # the last bits depend on the order of those additions
+            assert (a - b).abs().max().item() <= 2e-6 * b.abs().max().item(), (i, (a - b).abs().max().item())
         else:          # parameter gradients: the weight-gradient kernel adds its partial sums with atomics
             assert (a - b).abs().max().item() <= 1e-4 * b.abs().max().item() + 1e-6, (i, (a - b).abs().max().item())
 
