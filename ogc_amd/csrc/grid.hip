@@ -551,7 +551,7 @@ __device__ __forceinline__ u64 shfl_u64(u64 v, int src) {
 // MODE 0: squared distances (ogc_knn).  MODE 1: sqrt + radius clamp of the indices (ogc_knn_clamped).
 constexpr int KNN_FLAT_CAP = 192; // positions of the first shell kept as one flat list per query (else: run by run)
 template <int MODE>
-__global__ __launch_bounds__(OGC_WAVE) void knn_grid_kernel(int n, int m, int k, float radius, int stride_cells,
+__global__ __launch_bounds__(OGC_WAVE) void knn_grid_kernel(int n, int m, int k, float radius, float lim2, int stride_cells,
                                                             const float *__restrict__ unknown,
                                                             const GridHdr *__restrict__ hdrs,
                                                             const int *__restrict__ cell_start,
@@ -581,17 +581,8 @@ __global__ __launch_bounds__(OGC_WAVE) void knn_grid_kernel(int n, int m, int k,
     // block holds — the kept set, its maximum tracking and the final rank sort shrink accordingly); the nearest
     // candidate of all is tracked on the side for the rows that have nobody within the radius.
     // within  <=>  sqrtf(d2) <= radius  <=>  d2 <= lim2, lim2 = the largest float whose (correctly rounded) root is
-    // <= radius (sqrtf is monotone), found among the neighbours of radius^2.
+    // <= radius (sqrtf is monotone), found among the neighbours of radius^2 by the host (knn_radius_limit2).
     const bool limited = MODE == 1 && radius >= 0.0f;
-    float lim2 = INFINITY;
-    if (limited) {
-        lim2 = radius * radius;
-        while (lim2 > 0.0f && sqrtf(lim2) > radius) lim2 = __uint_as_float(__float_as_uint(lim2) - 1u);
-        for (int it = 0; it < 4; ++it) {
-            const float up = __uint_as_float(__float_as_uint(lim2) + 1u);
-            if (up < INFINITY && sqrtf(up) <= radius) lim2 = up;
-        }
-    }
     u64 best_any = ~0ull; // per lane: the smallest key this lane has seen (limited mode)
     auto rescan_max = [&]() {
         u64 mk = 0;
@@ -675,9 +666,11 @@ __global__ __launch_bounds__(OGC_WAVE) void knn_grid_kernel(int n, int m, int k,
             bool done_flat = false;
             {
                 const int side = 2 * R + 1, nrows = side * side;
+                const float inv_side = 1.0f / (float)side;
                 auto row_runs = [&](int r, int &s0, int &l0, int &s1, int &l1) {
                     s0 = l0 = s1 = l1 = 0;
-                    const int z = cz + r / side - R, y = cy + r % side - R;
+                    const int rz = (int)(((float)r + 0.5f) * inv_side); // r / side without an integer division (r < 2^12)
+                    const int z = cz + rz - R, y = cy + (r - rz * side) - R;
                     if (r >= nrows || z < 0 || z >= h.gz || y < 0 || y >= h.gy) return;
                     const int rowc = h.gx * (y + h.gy * z);
                     const bool face = R == R0 || z == cz - R || z == cz + R || y == cy - R || y == cy + R;
@@ -852,12 +845,22 @@ int ogc_knn_grid(int mode, int b, int n, int m, int k, float radius, const float
     float4 *sorted_pts = reinterpret_cast<float4 *>(ws + bytes_hdr + bytes_cs);
     launch_grid_build(b, m, mode == 1 ? radius : 0.0f, k, stride_cells, known, hdrs, cell_start, sorted_pts, s);
     dim3 grid(ogc_divup(n, QPW), b);
+    // d2 <= lim2  <=>  sqrtf(d2) <= radius: the largest float whose correctly rounded root does not exceed the radius
+    float lim2 = INFINITY;
+    if (mode == 1 && radius >= 0.0f) {
+        lim2 = radius * radius;
+        while (lim2 > 0.0f && sqrtf(lim2) > radius) lim2 = nextafterf(lim2, 0.0f);
+        for (int it = 0; it < 4; ++it) {
+            const float up = nextafterf(lim2, INFINITY);
+            if (up < INFINITY && sqrtf(up) <= radius) lim2 = up;
+        }
+    }
     if (mode == 1)
-        hipLaunchKernelGGL(knn_grid_kernel<1>, grid, dim3(OGC_WAVE), lds, s, n, m, k, radius, stride_cells, unknown, hdrs,
-                           cell_start, sorted_pts, dist, idx);
+        hipLaunchKernelGGL(knn_grid_kernel<1>, grid, dim3(OGC_WAVE), lds, s, n, m, k, radius, lim2, stride_cells, unknown,
+                           hdrs, cell_start, sorted_pts, dist, idx);
     else
-        hipLaunchKernelGGL(knn_grid_kernel<0>, grid, dim3(OGC_WAVE), lds, s, n, m, k, radius, stride_cells, unknown, hdrs,
-                           cell_start, sorted_pts, dist, idx);
+        hipLaunchKernelGGL(knn_grid_kernel<0>, grid, dim3(OGC_WAVE), lds, s, n, m, k, radius, lim2, stride_cells, unknown,
+                           hdrs, cell_start, sorted_pts, dist, idx);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         ogc_set_error("ogc_knn (grid): launch failed: %s", hipGetErrorString(e));
