@@ -651,7 +651,8 @@ class _NormActConv(Function):
         # whole path slower than the separate passes — tools/gn_bwd_compare.py)
         if (FUSED_GN_BACKWARD and getattr(nat, "conv1x1_dgrad_adjoint_wrapper", None) is not None and hw % 64 == 0
                 and cout <= FUSED_GN_BACKWARD_MAX_WIDTH and cin <= FUSED_GN_BACKWARD_MAX_WIDTH and gn_groups <= 32
-                and cin % gn_groups == 0 and nat.get_matmul_precision() == "fp32"):
+                and cin % gn_groups == 0):
+            # (fp32 operands also under `matmul_precision: bf16`: these layers are HBM-bound, bf16 operands buy nothing here)
             # moment matrices next to the weight gradient -> GroupNorm sums -> adjoint in the input gradient's epilogue:
             # the gradient w.r.t. the normalised activation and both GroupNorm backward passes never touch memory
             dev = y_prev.device
