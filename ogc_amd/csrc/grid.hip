@@ -548,6 +548,90 @@ __device__ __forceinline__ u64 shfl_u64(u64 v, int src) {
 // quotient) — or the block covers the whole grid.  The kept set is an unordered LDS array with its maximum tracked;
 // a candidate is admitted iff its key is below that maximum (strict '<' on (distance, index)), exactly the
 // reference's rule whatever the order in which candidates are met.
+// ---- the first block of a plain k-NN as ONE sorting network ------------------------------------------------------------------
+// 8 NK keys of a query (NK per lane of its 8-lane group, element e = lane * NK + register) sorted ascending by a bitonic
+// network: compare-exchange distances below NK stay inside a lane (register pairs, compile-time indices), the others are
+// lane exchanges (ds_swizzle xor 1 / 2 / 4).  All eight groups of the wavefront run the same instruction stream, so the
+// cost is per wavefront, not per admitted candidate as with the insert-and-rescan of `consider` (which serialises over
+// the candidates of all eight queries: ~60 % of the kernel's instructions at k = 32).
+template <int X>
+__device__ __forceinline__ u64 knn_xor_lane(u64 v) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_ds_swizzle((int)(unsigned)v, (X << 10) | 0x1F);
+    const unsigned hi = (unsigned)__builtin_amdgcn_ds_swizzle((int)(unsigned)(v >> 32), (X << 10) | 0x1F);
+    return ((u64)hi << 32) | lo;
+}
+
+template <int NK>
+__device__ __forceinline__ void knn_sort_keys(u64 (&key)[NK], int sub) {
+    constexpr int N = SUB * NK;
+#pragma unroll
+    for (int size = 2; size <= N; size <<= 1) {
+#pragma unroll
+        for (int d = size >> 1; d >= 1; d >>= 1) {
+            if (d >= NK) {
+                const int lx = d / NK;
+                const bool lower = (sub & lx) == 0;
+#pragma unroll
+                for (int t = 0; t < NK; ++t) {
+                    const u64 other = lx == 1 ? knn_xor_lane<1>(key[t]) : (lx == 2 ? knn_xor_lane<2>(key[t]) : knn_xor_lane<4>(key[t]));
+                    const bool up = ((sub * NK + t) & size) == 0;
+                    const bool take = (up == lower) ? other < key[t] : other > key[t];
+                    key[t] = take ? other : key[t];
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < NK; ++t) {
+                    if ((t & d) == 0) {
+                        const bool up = ((sub * NK + t) & size) == 0;
+                        const u64 a = key[t], c = key[t | d];
+                        const bool sw = up ? c < a : a < c;
+                        key[t] = sw ? c : a;
+                        key[t | d] = sw ? a : c;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// keys of the flat candidate list `mine[0 .. total)` (total <= 8 NK), sorted; the k smallest go to kept[] in ascending order.
+// Returns the number kept.
+template <int NK>
+__device__ __forceinline__ int knn_first_block(const float4 *__restrict__ pts, const int *mine, int total, float qx, float qy,
+                                               float qz, int sub, int k, u64 *kept, int have) {
+    // slots 0 .. have - 1: the keys kept so far (a later shell merges into them); then the `total` new candidates
+    u64 key[NK];
+    float4 cand[NK];
+#pragma unroll
+    for (int t = 0; t < NK; ++t) { // all loads in flight; slot t * 8 + sub (any assignment will do: everything is sorted)
+        const int f = t * SUB + sub - have;
+        cand[t] = make_float4(NAN, NAN, NAN, 0.f);
+        if (f >= 0 && f < total) cand[t] = pts[mine[f]];
+    }
+    int valid = 0;
+#pragma unroll
+    for (int t = 0; t < NK; ++t) {
+        const float d = ogc_sqdist(qx, qy, qz, cand[t].x, cand[t].y, cand[t].z);
+        bool ok = d < INFINITY; // NaN / inf are never selected (empty slots hold NaN)
+        key[t] = ok ? (((u64)__float_as_uint(d) << 32) | (unsigned)__float_as_int(cand[t].w)) : ~0ull;
+        if (t * SUB + sub < have) { key[t] = kept[t * SUB + sub]; ok = true; }
+        valid += ok ? 1 : 0;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier(); // kept[] is rewritten below
+    valid += __builtin_amdgcn_ds_swizzle(valid, (1 << 10) | 0x1F);
+    valid += __builtin_amdgcn_ds_swizzle(valid, (2 << 10) | 0x1F);
+    valid += __builtin_amdgcn_ds_swizzle(valid, (4 << 10) | 0x1F);
+    knn_sort_keys<NK>(key, sub);
+    const int keep = min(valid, k);
+#pragma unroll
+    for (int t = 0; t < NK; ++t) {
+        const int e = sub * NK + t;
+        if (e < keep) kept[e] = key[t];
+    }
+    return keep;
+}
+
 // MODE 0: squared distances (ogc_knn).  MODE 1: sqrt + radius clamp of the indices (ogc_knn_clamped).
 constexpr int KNN_FLAT_CAP = 192; // positions of the first shell kept as one flat list per query (else: run by run)
 template <int MODE>
@@ -584,6 +668,8 @@ __global__ __launch_bounds__(OGC_WAVE) void knn_grid_kernel(int n, int m, int k,
     // <= radius (sqrtf is monotone), found among the neighbours of radius^2 by the host (knn_radius_limit2).
     const bool limited = MODE == 1 && radius >= 0.0f;
     u64 best_any = ~0ull; // per lane: the smallest key this lane has seen (limited mode)
+    bool kept_sorted = false; // kept[0 .. cnt) is in ascending order (straight from the sorting network of the first block)
+    int total_scanned = 0;
     auto rescan_max = [&]() {
         u64 mk = 0;
         int mp = 0;
@@ -620,6 +706,7 @@ __global__ __launch_bounds__(OGC_WAVE) void knn_grid_kernel(int n, int m, int k,
         const unsigned slice = (unsigned)(ball >> (qi * SUB)) & 0xFFu;
         if (slice == 0) return;
         const int nh = __popc(slice);
+        kept_sorted = false;
         if (cnt + nh <= k) {
             if (adm) kept[cnt + __popc(slice & below)] = key;
             cnt += nh;
@@ -708,8 +795,19 @@ __global__ __launch_bounds__(OGC_WAVE) void knn_grid_kernel(int n, int m, int k,
                     }
                     __builtin_amdgcn_s_waitcnt(0xc07f);
                     __builtin_amdgcn_wave_barrier();
+                    if (!limited && R == R0 && total <= SUB * 16) {
+                        // plain k-NN, first block: select by sorting instead of insert-and-rescan (later shells admit few
+                        // candidates — the kept maximum filters them — and a merge network per shell measured slower)
+                        cnt = knn_first_block<16>(pts, mine, total, qx, qy, qz, sub, k, kept, 0);
+                        __builtin_amdgcn_s_waitcnt(0xc07f);
+                        __builtin_amdgcn_wave_barrier();
+                        kept_sorted = true;
+                        if (cnt == k) { maxkey = kept[k - 1]; maxpos = k - 1; }
+                        total_scanned = -1; // (marks: nothing left for the loop below)
+                    }
                     const float4 nothing = make_float4(NAN, NAN, NAN, 0.f);
-                    int f = sub;
+                    int f = total_scanned < 0 ? total : sub;
+                    total_scanned = 0;
                     float4 cur = nothing;
                     if (f < total) cur = pts[mine[f]];
                     while (__builtin_amdgcn_ballot_w64(f < total) != 0) {
@@ -756,12 +854,17 @@ __global__ __launch_bounds__(OGC_WAVE) void knn_grid_kernel(int n, int m, int k,
             }
         }
     }
-    // rank sort (keys are distinct: the index is part of the key)
-    for (int e = sub; e < cnt; e += SUB) {
-        const u64 ve = kept[e];
-        int rank = 0;
-        for (int f = 0; f < cnt; ++f) rank += kept[f] < ve ? 1 : 0;
-        outk[rank] = ve;
+    // rank sort (keys are distinct: the index is part of the key) — unless the kept set is still the sorted output of
+    // the first block's network
+    if (kept_sorted) {
+        outk = kept;
+    } else {
+        for (int e = sub; e < cnt; e += SUB) {
+            const u64 ve = kept[e];
+            int rank = 0;
+            for (int f = 0; f < cnt; ++f) rank += kept[f] < ve ? 1 : 0;
+            outk[rank] = ve;
+        }
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
