@@ -475,10 +475,158 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_gemm_kernel(int M,
     }
 }
 
+// ---- streaming variant for the wide forward layers (K > 100): load, compute and store OVERLAP ---------------------------------
+// conv1x1_gemm_kernel gives a wave ONE 64-position tile: load K x 64 (32 KB at K = 128), ~1000 MFMAs, store.  At 128 -> 128 the
+// memory time of a tile (load + store, every CU at once: ~13 us each at the HBM rate) equals its MFMA time (~27 us per pair of
+// co-resident waves), and the two waves a SIMD holds start together and stay in lockstep — both load, then both compute —
+// so the phases ADD: 216 us = 54 (load) + 109 (MFMA) + 54 (store) instead of max(108, 109).  Here a persistent wave walks over
+// tiles with two register sets: the next tile's loads are issued before the current tile's MFMAs and its stores drain behind
+// them; the whole weight matrix is staged in LDS once per workgroup (one workgroup of four waves per CU).
+// EXACT: K fills the KQ register quads (Kq == KQ) and M is a multiple of 64 — no wave-uniform branch is left between the
+// MFMAs of a tile (a scalar compare-and-branch between two MFMAs costs issue slots the matrix pipe cannot fill).
+template <int KQ, bool PRO, bool EXACT>
+__global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_gemm_stream_kernel(int M, int K, int hw, int ntiles,
+                                                                                 const float *__restrict__ w,
+                                                                                 const float *__restrict__ in,
+                                                                                 float *__restrict__ out,
+                                                                                 const float *__restrict__ pa,
+                                                                                 const float *__restrict__ pb, int pro_relu) {
+    extern __shared__ __attribute__((aligned(16))) float a_lds[]; // [M / 64 tiles][Kq][64][4]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, kk = lane >> 4;
+    const int Kq = (K + 3) >> 2, Mt = (M + 63) >> 6;
+    const int tiles_per_img = hw >> 6;
+    for (int t = threadIdx.x; t < Mt * Kq * 256; t += WG_WAVES * OGC_WAVE) {
+        const int mt = t / (Kq * 256), r = t - mt * (Kq * 256);
+        const int kr = r & 3, mi = (r >> 2) & 63, q = r >> 8;
+        const int m = mt * 64 + mi, k = q * 4 + kr;
+        a_lds[t] = (m < M && k < K) ? w[(size_t)m * K + k] : 0.f;
+    }
+    __syncthreads();
+    const int nw = gridDim.x * WG_WAVES;
+    auto load_tile = [&](int t, float4(&x)[KQ]) {
+        const int b = t / tiles_per_img, p0 = (t - b * tiles_per_img) * 64;
+        const float *inb = in + (size_t)b * K * hw + p0 + 4 * j;
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+            const int row = q * 4 + kk;
+            x[q] = (q < Kq && row < K) ? *reinterpret_cast<const float4 *>(inb + (size_t)row * hw)
+                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto compute_store = [&](int t, float4(&x)[KQ]) {
+        const int b = t / tiles_per_img, p0 = (t - b * tiles_per_img) * 64;
+        if (PRO) { // the previous layer's GroupNorm (+ ReLU) applied to the tile in place, eight rows of coefficients at a time
+            constexpr int CH = 8;
+#pragma unroll
+            for (int q0 = 0; q0 < KQ; q0 += CH) {
+                float ca[CH], cb[CH];
+#pragma unroll
+                for (int u = 0; u < CH; ++u) {
+                    const int q = q0 + u, row = q * 4 + kk;
+                    const bool have = q < KQ && q < Kq && row < K; // padding rows stay exact zeros: act(0 * 0 + 0)
+                    ca[u] = have ? pa[(size_t)b * K + row] : 0.f;
+                    cb[u] = have ? pb[(size_t)b * K + row] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < CH; ++u) {
+                    const int q = q0 + u;
+                    if (q < KQ) {
+                        float4 v = x[q];
+                        v.x = fmaf(ca[u], v.x, cb[u]); v.y = fmaf(ca[u], v.y, cb[u]);
+                        v.z = fmaf(ca[u], v.z, cb[u]); v.w = fmaf(ca[u], v.w, cb[u]);
+                        if (pro_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                        x[q] = v;
+                    }
+                }
+            }
+        }
+        float *outb = out + (size_t)b * M * hw + p0 + 4 * j;
+        for (int mt = 0; mt < Mt; ++mt) {
+            const float *at = a_lds + (size_t)mt * Kq * 256;
+            const int nblk = EXACT ? 4 : min(4, (M - mt * 64 + 15) >> 4);
+            v4f acc[4][4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[a][c] = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < KQ; ++q) {
+                if (EXACT || q < Kq) {
+                    float av[4];
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) av[a] = at[(q * 64 + a * 16 + j) * 4 + kk];
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        if (EXACT || a < nblk) {
+                            acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], x[q].x, acc[a][0], 0, 0, 0);
+                            acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], x[q].y, acc[a][1], 0, 0, 0);
+                            acc[a][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], x[q].z, acc[a][2], 0, 0, 0);
+                            acc[a][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], x[q].w, acc[a][3], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = mt * 64 + a * 16 + kk * 4 + r;
+                    if (m < M)
+                        *reinterpret_cast<float4 *>(outb + (size_t)m * hw) =
+                            make_float4(acc[a][0][r], acc[a][1][r], acc[a][2][r], acc[a][3][r]);
+                }
+        }
+    };
+    float4 xa[KQ], xb[KQ];
+    int t = blockIdx.x * WG_WAVES + wave;
+    if (t < ntiles) load_tile(t, xa);
+    for (; t < ntiles; t += 2 * nw) {
+        const int t2 = t + nw, t3 = t2 + nw;
+        if (t2 < ntiles) load_tile(t2, xb);
+        compute_store(t, xa);
+        if (t3 < ntiles) load_tile(t3, xa);
+        if (t2 < ntiles) compute_store(t2, xb);
+    }
+}
+
+// the streaming kernel for this shape, or false when the tile kernel should run
+template <bool PRO>
+bool gemm_stream_launch(int b, int M, int K, int hw, const float *w, const float *in, float *out, const float *pa,
+                        const float *pb, int pro_relu, hipStream_t s) {
+    const int Kq = (K + 3) / 4, Mt = (M + 63) / 64;
+    const long long ntiles = (long long)b * (hw / 64);
+    const size_t lds = (size_t)Mt * Kq * 256 * sizeof(float);
+    static const bool off = getenv("OGC_GEMM_STREAM") && getenv("OGC_GEMM_STREAM")[0] == '0';
+    if (off || Kq <= 25 || Kq > FW_KQ_MAX || lds > 150 * 1024 || ntiles < 2048 || ntiles >= (1ll << 31)) return false;
+    const int wgs = (int)(ntiles / WG_WAVES < 256 ? ntiles / WG_WAVES : 256);
+#define OGC_STREAM(KQV, EX)                                                                                                  \
+    do {                                                                                                                     \
+        static bool raised = false;                                                                                          \
+        const void *fn = reinterpret_cast<const void *>(&conv1x1_gemm_stream_kernel<KQV, PRO, EX>);                          \
+        if (!raised) {                                                                                                       \
+            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) return false;  \
+            raised = true;                                                                                                   \
+        }                                                                                                                    \
+        hipLaunchKernelGGL((conv1x1_gemm_stream_kernel<KQV, PRO, EX>), dim3(wgs), dim3(WG_WAVES * OGC_WAVE), lds, s, M, K, hw, \
+                           (int)ntiles, w, in, out, pa, pb, pro_relu);                                                       \
+    } while (0)
+    const bool full_rows = M % 64 == 0;
+    if (Kq == 32 && full_rows) OGC_STREAM(32, true);         // K = 125 .. 128 (the 128-channel layers)
+    else if (Kq == 33 && full_rows) OGC_STREAM(33, true);    // K = 129 .. 132 (131: 128 features + 3 coordinates)
+    else if (Kq <= 33) OGC_STREAM(33, false);
+    else OGC_STREAM(40, false);
+#undef OGC_STREAM
+    return true;
+}
+
 template <bool T, bool STATS, bool PRO, bool POOL = false>
 int gemm_launch(int b, int M, int K, int hw, int groups, const float *w, const float *in, float *out, double *stats,
                 const float *pa, const float *pb, int pro_relu, hipStream_t s, PoolOut pool = PoolOut()) {
     const int Kq = (K + 3) / 4;
+    if constexpr (!T && !STATS && !POOL) {
+        if (!g_matmul_bf16 && gemm_stream_launch<PRO>(b, M, K, hw, w, in, out, pa, pb, pro_relu, s)) return OGC_OK;
+    }
     const size_t lds = (size_t)Kq * 256 * sizeof(float);
     dim3 grid(ogc_divup(hw, 64 * WG_WAVES), b);
 #define OGC_GEMM(KQV)                                                                                                  \

@@ -596,7 +596,9 @@ def test_pointwise_conv_autograd_matches_conv2d(nat):
 
 
 @pytest.mark.parametrize("B,cin,cout,hw", [(2, 6, 32, 256), (3, 32, 32, 1024), (2, 99, 64, 512), (2, 131, 128, 256),
-                                           (1, 64, 256, 64), (4, 32, 64, 131072), (2, 160, 48, 128), (2, 128, 256, 2048)])
+                                           (1, 64, 256, 64), (4, 32, 64, 131072), (2, 160, 48, 128), (2, 128, 256, 2048),
+                                           # >= 2048 position tiles and K > 100: the streaming (double-buffered) forward kernel
+                                           (4, 128, 128, 32768), (3, 131, 256, 45056), (8, 160, 64, 16384), (5, 104, 40, 27008)])
 def test_conv1x1_gemm_forward_and_dgrad(nat, B, cin, cout, hw):
     torch.manual_seed(cin + cout)
     w = torch.randn(cout, cin, device=DEV) * 0.3
@@ -822,3 +824,25 @@ def test_flow_embedding_inference_uses_the_fused_chain(nat):
     assert y.shape == y_ref.shape == (2, 128, 1024)
     assert torch.equal(y, y_chain)                                  # same arithmetic, only the operand source differs
     torch.testing.assert_close(y, y_ref, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("B,cin,cout,hw,relu", [(4, 128, 128, 32768, 1), (3, 131, 256, 45056, 1), (8, 128, 64, 16384, 0)])
+def test_conv1x1_gemm_affine_streaming_kernel(nat, B, cin, cout, hw, relu):
+    """ogc_conv1x1_gemm_affine at shapes that take the streaming kernel (K > 100, >= 2048 position tiles): out = W act(pa x + pb)
+    against float64; and the same call with the streaming kernel switched off must give the same bits (same FMA chains)."""
+    import os
+    import subprocess
+    import sys
+    torch.manual_seed(cin + cout)
+    w = torch.randn(cout, cin, device=DEV) * 0.3
+    x = torch.randn(B, cin, hw, device=DEV)
+    pa = torch.rand(B, cin, device=DEV) + 0.5
+    pb = torch.randn(B, cin, device=DEV) * 0.5
+    y = torch.full((B, cout, hw), float("nan"), device=DEV)
+    nat.conv1x1_gemm_affine_wrapper(B, cout, cin, hw, relu, 0, w, x, pa, pb, y, None)
+    z = pa.double()[:, :, None] * x.double() + pb.double()[:, :, None]
+    z = torch.relu(z) if relu else z
+    ref = torch.einsum("oi,bip->bop", w.double(), z)
+    scale = torch.einsum("oi,bip->bop", w.double().abs(), z.abs())
+    assert ((y.double() - ref).abs() / scale.clamp_min(1e-30)).max().item() < 2e-6
+    assert torch.isfinite(y).all()
