@@ -18,6 +18,10 @@ FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
     "-ffp-contract=off",        # distance arithmetic is pinned to the un-fused fp32 sequence
     "-munsafe-fp-atomics",      # scatter-add gradients use hardware fp32 atomic add
+    # MFMA accumulators may be allocated in ordinary VGPRs (gfx90a and later take either file).  The default forces them
+    # into AGPRs, and kernels whose accumulators cross a loop back-edge or a branch then copy them AGPR -> VGPR -> AGPR every
+    # round (conv1x1_wgrad_kernel<4,4>: 128 v_accvgpr moves per 128 MFMAs); with the VGPR form the copies disappear.
+    "-mllvm", "-amdgpu-mfma-vgpr-form=1",
     "-Wall", "-Wno-unused-function",
 ]
 

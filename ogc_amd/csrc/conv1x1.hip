@@ -50,12 +50,14 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_wgrad_kernel(int b
                                                                            const float *__restrict__ aff_a,
                                                                            const float *__restrict__ aff_b, int pro_relu) {
     __shared__ float red[COB * CIB * 256]; // the workgroup's partial tile: COB*CIB blocks of 16x16
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 15, k = lane >> 4;
     const int co0 = blockIdx.y * (16 * COB), ci0 = blockIdx.z * (16 * CIB);
     const int steps_per_img = hw >> 4;
     const long long nsteps = (long long)batch * steps_per_img;
     const long long first = ((long long)blockIdx.x * WG_WAVES + wave) * steps_per_wave;
+    // this wavefront's steps: [first, first + mine) — everything about the walk is wave-uniform (SALU, scalar branches)
+    const int mine = (int)max(0LL, min((long long)steps_per_wave, nsteps - first));
 
     v4f acc[COB][CIB];
 #pragma unroll
@@ -65,48 +67,42 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_wgrad_kernel(int b
 
     // The wave walks consecutive steps, so (image, position) advance incrementally: one division per wave instead of a
     // 64-bit division per step (which cost more issue slots than the step's 64 MFMAs).
-    int cur_b = (int)(first / steps_per_img);
-    int cur_off = (int)(first - (long long)cur_b * steps_per_img);
-    long long cur_step = first;
-    int yrow[COB], xrow[CIB]; // one sample's activation fits 32-bit offsets (checked by the entry point)
+    const long long start = min(first, nsteps - 1);
+    int cur_b = (int)(start / steps_per_img);
+    int cur_off = (int)(start - (long long)cur_b * steps_per_img);
+    int left = mine - 1; // steps after the current one; the walk stays on the last step once they are used up
+    int yrow[COB], xrow[CIB], coef[CIB]; // one sample's activation fits 32-bit offsets (checked by the entry point)
 #pragma unroll
     for (int a = 0; a < COB; ++a) yrow[a] = min(co0 + a * 16 + i, cout - 1) * hw;
 #pragma unroll
-    for (int c = 0; c < CIB; ++c) xrow[c] = min(ci0 + c * 16 + i, cin - 1) * hw;
-    // PRO: the affine map of this lane's input channels for image cur_b.  It is applied when a buffer is CONSUMED, not when
-    // it is loaded (a VALU op on freshly loaded registers would put the wait for the load right behind its issue and
-    // undo the ping-pong), so every buffer carries the coefficients of the image its step belongs to.
-    float ca[CIB], cb[CIB];
-    auto load_coeffs = [&](int img) {
-#pragma unroll
-        for (int c = 0; c < CIB; ++c) {
-            const bool have = ci0 + c * 16 + i < cin;
-            const int ch = min(ci0 + c * 16 + i, cin - 1);
-            ca[c] = have ? aff_a[(size_t)img * cin + ch] : 0.f; // padding rows: act(0 * 0 + 0) = 0
-            cb[c] = have ? aff_b[(size_t)img * cin + ch] : 0.f;
-        }
-    };
-    if (PRO && cur_b < batch) load_coeffs(cur_b);
-    auto load = [&](float4(&yv)[COB], float4(&xv)[CIB], float(&fa)[CIB], float(&fb)[CIB]) { // step cur_step, then advance
-        const bool ok = cur_step < nsteps;
+    for (int c = 0; c < CIB; ++c) {
+        coef[c] = min(ci0 + c * 16 + i, cin - 1);
+        xrow[c] = coef[c] * hw;
+    }
+    // EVERY load of a step is unconditional and of the same shape: rows beyond the tensors are clamped onto the last row
+    // (they only feed rows / columns of the tile that are never stored), steps beyond the wave's share re-read its last
+    // step and are not computed with.  A load under a per-lane condition (`row < cout ? *p : 0`) becomes its own
+    // exec-masked block and the compiler then waits for ALL outstanding loads wherever it needs one — which serialised
+    // the ping-pong below: the next step's loads were waited for before the current step's MFMAs (50 % of the time of
+    // this kernel at one wavefront per SIMD).  PRO: the affine map of this lane's input channels travels WITH the step
+    // (eight cached dword loads more) for the same reason: loaded only at image changes, its wait was a vmcnt(0).
+    auto load = [&](float4(&yv)[COB], float4(&xv)[CIB], float(&fa)[CIB], float(&fb)[CIB]) { // current step, then advance
         const int pb = cur_off * 16 + 4 * k;
         const float *yb_ = dy + (size_t)cur_b * cout * hw + pb;
         const float *xb_ = x + (size_t)cur_b * cin * hw + pb;
 #pragma unroll
-        for (int a = 0; a < COB; ++a)
-            yv[a] = (ok && co0 + a * 16 + i < cout) ? *reinterpret_cast<const float4 *>(yb_ + yrow[a])
-                                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int a = 0; a < COB; ++a) yv[a] = *reinterpret_cast<const float4 *>(yb_ + yrow[a]);
 #pragma unroll
         for (int c = 0; c < CIB; ++c) {
-            xv[c] = (ok && ci0 + c * 16 + i < cin) ? *reinterpret_cast<const float4 *>(xb_ + xrow[c])
-                                                   : make_float4(0.f, 0.f, 0.f, 0.f);
-            if (PRO) { fa[c] = ok ? ca[c] : 0.f; fb[c] = ok ? cb[c] : 0.f; }
+            xv[c] = *reinterpret_cast<const float4 *>(xb_ + xrow[c]);
+            if (PRO) {
+                fa[c] = aff_a[(size_t)cur_b * cin + coef[c]];
+                fb[c] = aff_b[(size_t)cur_b * cin + coef[c]];
+            }
         }
-        ++cur_step;
-        if (++cur_off == steps_per_img) {
-            cur_off = 0;
-            ++cur_b;
-            if (PRO && cur_b < batch) load_coeffs(cur_b);
+        if (left > 0) {
+            --left;
+            if (++cur_off == steps_per_img) { cur_off = 0; ++cur_b; }
         }
     };
     auto fma16 = [&](const float4(&yv)[COB], const float4(&xraw)[CIB], const float(&fa)[CIB], const float(&fb)[CIB]) {
@@ -150,12 +146,14 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_wgrad_kernel(int b
     float4 ya[COB], xa[CIB], yb[COB], xb[CIB];
     float faa[CIB], fba[CIB], fab[CIB], fbb[CIB];
     load(ya, xa, faa, fba);
-    for (int s = 0; s < steps_per_wave; s += 2) { // ping-pong registers: next step's loads fly during the MFMAs
-        load(yb, xb, fab, fbb);
+    int s = 0;
+    for (; s + 1 < mine; s += 2) { // ping-pong registers: next step's loads fly during the MFMAs.  No branch inside the
+        load(yb, xb, fab, fbb);    // loop body: with one, the accumulators travelled AGPR -> VGPR -> AGPR every round
         fma16(ya, xa, faa, fba);
         load(ya, xa, faa, fba);
-        if (s + 1 < steps_per_wave) fma16(yb, xb, fab, fbb);
+        fma16(yb, xb, fab, fbb);
     }
+    if (s < mine) fma16(ya, xa, faa, fba);
 
     // C/D layout of 16x16x4: lane l holds rows (l >> 4) * 4 + r (r = 0..3) of column l & 15
     for (int t = threadIdx.x; t < COB * CIB * 256; t += WG_WAVES * OGC_WAVE) red[t] = 0.0f;
@@ -491,8 +489,8 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_gemm_stream_kernel
                                                                                  float *__restrict__ out,
                                                                                  const float *__restrict__ pa,
                                                                                  const float *__restrict__ pb, int pro_relu) {
-    extern __shared__ __attribute__((aligned(16))) float a_lds[]; // [M / 64 tiles][Kq][64][4]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    extern __shared__ __attribute__((aligned(16))) float a_lds[]; // [M / 64 tiles][Kq][64][4], then PRO: [wave][2][KQ * 4]
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 15, kk = lane >> 4;
     const int Kq = (K + 3) >> 2, Mt = (M + 63) >> 6;
     const int tiles_per_img = hw >> 6;
@@ -504,44 +502,54 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_gemm_stream_kernel
     }
     __syncthreads();
     const int nw = gridDim.x * WG_WAVES;
+    // The loads of a tile are unconditional and of one shape (a load under a per-lane condition becomes an exec-masked block
+    // of its own, and the compiler then waits for ALL outstanding loads — the prefetched next tile included — wherever it
+    // needs one): padding rows (k >= K) re-read the last row, their weights in LDS are zeros.
+    // Addresses: a wave-uniform base per row quad (SGPRs) + one of two 32-bit lane offsets — 33 64-bit lane addresses kept
+    // across the loop would cost 66 registers of the 512.
+    const unsigned off_main = (unsigned)(kk * hw + 4 * j);
+    const unsigned off_last = (unsigned)(min(kk, K - 1 - (Kq - 1) * 4) * hw + 4 * j); // last quad: rows >= K clamped
     auto load_tile = [&](int t, float4(&x)[KQ]) {
+        t = min(t, ntiles - 1); // beyond the wave's last tile: a harmless re-read
         const int b = t / tiles_per_img, p0 = (t - b * tiles_per_img) * 64;
-        const float *inb = in + (size_t)b * K * hw + p0 + 4 * j;
+        const float *inb = in + (size_t)b * K * hw + p0;
 #pragma unroll
-        for (int q = 0; q < KQ; ++q) {
-            const int row = q * 4 + kk;
-            x[q] = (q < Kq && row < K) ? *reinterpret_cast<const float4 *>(inb + (size_t)row * hw)
-                                       : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        for (int q = 0; q < KQ; ++q)
+            if (EXACT || q < Kq) {
+                const float *rowq = inb + (size_t)(q * 4) * hw;
+                x[q] = *reinterpret_cast<const float4 *>(rowq + ((EXACT ? q == KQ - 1 : q == Kq - 1) ? off_last : off_main));
+            }
     };
+    // PRO: the coefficients of the current image sit in a wave-private strip of LDS, refreshed when the image changes —
+    // read from global memory at compute time they would be the newest loads in flight, and waiting for them means
+    // waiting for the prefetched tile as well.
+    float *cw = a_lds + (size_t)Mt * Kq * 256 + wave * (2 * KQ * 4);
+    int coef_b = -1;
     auto compute_store = [&](int t, float4(&x)[KQ]) {
         const int b = t / tiles_per_img, p0 = (t - b * tiles_per_img) * 64;
-        if (PRO) { // the previous layer's GroupNorm (+ ReLU) applied to the tile in place, eight rows of coefficients at a time
-            constexpr int CH = 8;
-#pragma unroll
-            for (int q0 = 0; q0 < KQ; q0 += CH) {
-                float ca[CH], cb[CH];
-#pragma unroll
-                for (int u = 0; u < CH; ++u) {
-                    const int q = q0 + u, row = q * 4 + kk;
-                    const bool have = q < KQ && q < Kq && row < K; // padding rows stay exact zeros: act(0 * 0 + 0)
-                    ca[u] = have ? pa[(size_t)b * K + row] : 0.f;
-                    cb[u] = have ? pb[(size_t)b * K + row] : 0.f;
+        if (PRO) { // the previous layer's GroupNorm (+ ReLU) applied to the tile in place
+            if (b != coef_b) {
+                coef_b = b;
+                for (int r = lane; r < KQ * 4; r += OGC_WAVE) { // padding rows: act(0 * x + 0) = 0
+                    cw[r] = r < K ? pa[(size_t)b * K + r] : 0.f;
+                    cw[KQ * 4 + r] = r < K ? pb[(size_t)b * K + r] : 0.f;
                 }
+                __builtin_amdgcn_wave_barrier();
+            }
 #pragma unroll
-                for (int u = 0; u < CH; ++u) {
-                    const int q = q0 + u;
-                    if (q < KQ) {
-                        float4 v = x[q];
-                        v.x = fmaf(ca[u], v.x, cb[u]); v.y = fmaf(ca[u], v.y, cb[u]);
-                        v.z = fmaf(ca[u], v.z, cb[u]); v.w = fmaf(ca[u], v.w, cb[u]);
-                        if (pro_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                        x[q] = v;
-                    }
+            for (int q = 0; q < KQ; ++q) {
+                if (EXACT || q < Kq) {
+                    const float ca = cw[q * 4 + kk], cb = cw[KQ * 4 + q * 4 + kk];
+                    float4 v = x[q];
+                    v.x = fmaf(ca, v.x, cb); v.y = fmaf(ca, v.y, cb);
+                    v.z = fmaf(ca, v.z, cb); v.w = fmaf(ca, v.w, cb);
+                    if (pro_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    x[q] = v;
                 }
             }
         }
-        float *outb = out + (size_t)b * M * hw + p0 + 4 * j;
+        float *outb = out + (size_t)b * M * hw + p0;
+        const unsigned off_out = (unsigned)(kk * 4 * hw + 4 * j);
         for (int mt = 0; mt < Mt; ++mt) {
             const float *at = a_lds + (size_t)mt * Kq * 256;
             const int nblk = EXACT ? 4 : min(4, (M - mt * 64 + 15) >> 4);
@@ -571,23 +579,23 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_gemm_stream_kernel
             for (int a = 0; a < 4; ++a)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int m = mt * 64 + a * 16 + kk * 4 + r;
-                    if (m < M)
-                        *reinterpret_cast<float4 *>(outb + (size_t)m * hw) =
+                    const int m0 = mt * 64 + a * 16 + r; // the row is m0 + 4 kk
+                    if (EXACT || m0 + kk * 4 < M)
+                        *reinterpret_cast<float4 *>(outb + (size_t)m0 * hw + off_out) =
                             make_float4(acc[a][0][r], acc[a][1][r], acc[a][2][r], acc[a][3][r]);
                 }
         }
     };
     float4 xa[KQ], xb[KQ];
     int t = blockIdx.x * WG_WAVES + wave;
-    if (t < ntiles) load_tile(t, xa);
-    for (; t < ntiles; t += 2 * nw) {
-        const int t2 = t + nw, t3 = t2 + nw;
-        if (t2 < ntiles) load_tile(t2, xb);
+    load_tile(t, xa);
+    for (; t + nw < ntiles; t += 2 * nw) { // two tiles per round, no branch in the body
+        load_tile(t + nw, xb);
         compute_store(t, xa);
-        if (t3 < ntiles) load_tile(t3, xa);
-        if (t2 < ntiles) compute_store(t2, xb);
+        load_tile(t + 2 * nw, xa);
+        compute_store(t + nw, xb);
     }
+    if (t < ntiles) compute_store(t, xa);
 }
 
 // the streaming kernel for this shape, or false when the tile kernel should run
@@ -596,16 +604,16 @@ bool gemm_stream_launch(int b, int M, int K, int hw, const float *w, const float
                         const float *pb, int pro_relu, hipStream_t s) {
     const int Kq = (K + 3) / 4, Mt = (M + 63) / 64;
     const long long ntiles = (long long)b * (hw / 64);
-    const size_t lds = (size_t)Mt * Kq * 256 * sizeof(float);
+    const size_t lds = ((size_t)Mt * Kq * 256 + (PRO ? WG_WAVES * 2 * FW_KQ_MAX * 4 : 0)) * sizeof(float);
     static const bool off = getenv("OGC_GEMM_STREAM") && getenv("OGC_GEMM_STREAM")[0] == '0';
-    if (off || Kq <= 25 || Kq > FW_KQ_MAX || lds > 150 * 1024 || ntiles < 2048 || ntiles >= (1ll << 31)) return false;
+    if (off || Kq <= 25 || Kq > FW_KQ_MAX || lds > 156 * 1024 || ntiles < 2048 || ntiles >= (1ll << 31)) return false;
     const int wgs = (int)(ntiles / WG_WAVES < 256 ? ntiles / WG_WAVES : 256);
 #define OGC_STREAM(KQV, EX)                                                                                                  \
     do {                                                                                                                     \
         static bool raised = false;                                                                                          \
         const void *fn = reinterpret_cast<const void *>(&conv1x1_gemm_stream_kernel<KQV, PRO, EX>);                          \
         if (!raised) {                                                                                                       \
-            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) return false;  \
+            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess) return false;  \
             raised = true;                                                                                                   \
         }                                                                                                                    \
         hipLaunchKernelGGL((conv1x1_gemm_stream_kernel<KQV, PRO, EX>), dim3(wgs), dim3(WG_WAVES * OGC_WAVE), lds, s, M, K, hw, \

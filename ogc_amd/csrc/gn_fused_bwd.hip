@@ -41,13 +41,13 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void wgrad_moments_kernel(int c
                                                                            const float *__restrict__ aff_b,
                                                                            float *__restrict__ hm) {      // (B, 2, cout, cin)
     __shared__ float red[2 * COB * CIB * 256];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 15, k = lane >> 4;
     const int img = blockIdx.x / chunks, chunk = blockIdx.x - img * chunks;
     const int co0 = blockIdx.y * (16 * COB), ci0 = blockIdx.z * (16 * CIB);
     const int steps_per_img = hw >> 4;
     const int first = (chunk * WG_WAVES + wave) * steps_per_wave;
-    const int last = min(first + steps_per_wave, steps_per_img);
+    const int mine = max(0, min(steps_per_wave, steps_per_img - first)); // this wavefront's steps: [first, first + mine)
 
     v4f acc1[COB][CIB], acc2[COB][CIB];
 #pragma unroll
@@ -70,30 +70,30 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void wgrad_moments_kernel(int c
     }
     const float *yb_ = dy + (size_t)img * cout * hw + 4 * k;
     const float *xb_ = x + (size_t)img * cin * hw + 4 * k;
-    int cur = first;
+    int cur = min(first, steps_per_img - 1);
+    const int stop = min(first + mine, steps_per_img) - 1; // the walk stays on the wave's last step once it is reached
+    // Unconditional loads of one shape (see conv1x1_wgrad_kernel: a load under a per-lane condition makes the compiler wait
+    // for ALL outstanding loads wherever it needs one, which serialises the ping-pong): rows beyond the tensors are clamped
+    // onto the last row — they only reach rows / columns of H, H2 that are never stored — and steps beyond the wave's
+    // share re-read its last step and are not computed with.
     auto load = [&](float4(&yv)[COB], float4(&xv)[CIB]) { // step `cur`, then advance
-        const bool ok = cur < last;
         const int pb = cur * 16;
 #pragma unroll
-        for (int a = 0; a < COB; ++a)
-            yv[a] = (ok && co0 + a * 16 + i < cout) ? *reinterpret_cast<const float4 *>(yb_ + yrow[a] + pb)
-                                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int a = 0; a < COB; ++a) yv[a] = *reinterpret_cast<const float4 *>(yb_ + yrow[a] + pb);
 #pragma unroll
-        for (int c = 0; c < CIB; ++c)
-            xv[c] = (ok && ci0 + c * 16 + i < cin) ? *reinterpret_cast<const float4 *>(xb_ + xrow[c] + pb)
-                                                   : make_float4(NAN, NAN, NAN, NAN); // NaN: mask 0 whatever a, bb
-        ++cur;
+        for (int c = 0; c < CIB; ++c) xv[c] = *reinterpret_cast<const float4 *>(xb_ + xrow[c] + pb);
+        cur = min(cur + 1, max(stop, 0));
     };
     auto fma16 = [&](const float4(&yv)[COB], const float4(&xraw)[CIB]) {
         float4 m1[CIB], m2[CIB];
 #pragma unroll
         for (int c = 0; c < CIB; ++c) {
             const float4 v = xraw[c];
-            // mask = [a y + bb > 0] (relu) — false for the NaN of rows / steps that do not exist; without relu: [y == y]
-            const bool bx = relu ? fmaf(ca[c], v.x, cb[c]) > 0.f : v.x == v.x;
-            const bool by = relu ? fmaf(ca[c], v.y, cb[c]) > 0.f : v.y == v.y;
-            const bool bz = relu ? fmaf(ca[c], v.z, cb[c]) > 0.f : v.z == v.z;
-            const bool bw = relu ? fmaf(ca[c], v.w, cb[c]) > 0.f : v.w == v.w;
+            // mask = [a y + bb > 0] (relu); without relu: all ones
+            const bool bx = relu ? fmaf(ca[c], v.x, cb[c]) > 0.f : true;
+            const bool by = relu ? fmaf(ca[c], v.y, cb[c]) > 0.f : true;
+            const bool bz = relu ? fmaf(ca[c], v.z, cb[c]) > 0.f : true;
+            const bool bw = relu ? fmaf(ca[c], v.w, cb[c]) > 0.f : true;
             m1[c] = make_float4(bx ? 1.f : 0.f, by ? 1.f : 0.f, bz ? 1.f : 0.f, bw ? 1.f : 0.f);
             m2[c] = make_float4(bx ? v.x : 0.f, by ? v.y : 0.f, bz ? v.z : 0.f, bw ? v.w : 0.f);
         }
@@ -114,12 +114,14 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void wgrad_moments_kernel(int c
 
     float4 ya[COB], xa[CIB], yb[COB], xb[CIB];
     load(ya, xa);
-    for (int s = 0; s < steps_per_wave; s += 2) { // ping-pong registers: next step's loads fly during the MFMAs
+    int s = 0;
+    for (; s + 1 < mine; s += 2) { // ping-pong registers: next step's loads fly during the MFMAs (no branch in the body)
         load(yb, xb);
         fma16(ya, xa);
         load(ya, xa);
-        if (s + 1 < steps_per_wave) fma16(yb, xb);
+        fma16(yb, xb);
     }
+    if (s < mine) fma16(ya, xa);
 
     for (int t = threadIdx.x; t < 2 * COB * CIB * 256; t += WG_WAVES * OGC_WAVE) red[t] = 0.0f;
     __syncthreads();
