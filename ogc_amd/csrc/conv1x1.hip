@@ -15,6 +15,7 @@
 //     loads are issued before the current step's MFMAs; the four waves of a workgroup are reduced through LDS,
 //     workgroups through fp32 atomics into dW (zeroed by this entry point).
 #include "ogc_common.h"
+#include "conv_stage.h"
 
 namespace {
 
@@ -253,13 +254,13 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_gemm_kernel(int M,
                                                                           const float *__restrict__ pa,
                                                                           const float *__restrict__ pb, int pro_relu,
                                                                           PoolOut pool = PoolOut()) {
-    extern __shared__ __attribute__((aligned(16))) float a_lds[]; // [Kq][64][4] for the current 64-row tile of A
+    extern __shared__ __attribute__((aligned(16))) float a_lds[]; // [64][ogc_a_ld(Kq)]: the current 64-row tile of A (conv_stage.h)
     __shared__ double s_stats[STATS ? 64 : 1];                    // [groups][2]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 15, kk = lane >> 4;
     const int b = blockIdx.y;
     const int p0 = (blockIdx.x * WG_WAVES + wave) * 64;
-    const int Kq = (K + 3) >> 2;
+    const int Kq = (K + 3) >> 2, a_ld = ogc_a_ld(Kq);
     const bool live = p0 < hw; // hw is a multiple of 64 for every wave that is live
     const float *inb = in + (size_t)b * K * hw;
     float *outb = out + (size_t)b * M * hw;
@@ -331,14 +332,7 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_gemm_kernel(int M,
                 a_bf[t] = ogc_pack_bf16(v[0], v[1], v[2], v[3]);
             }
         } else {
-        // stage A[m0 .. m0+63][0 .. K) as a_lds[(q * 64 + mi) * 4 + kr] = A[m0 + mi][4q + kr]
-        for (int t = threadIdx.x; t < Kq * 256; t += WG_WAVES * OGC_WAVE) {
-            const int kr = t & 3, mi = (t >> 2) & 63, q = t >> 8;
-            const int m = m0 + mi, k = q * 4 + kr;
-            float v = 0.f;
-            if (m < M && k < K) v = TRANSPOSE_A ? w[(size_t)k * M + m] : w[(size_t)m * K + k];
-            a_lds[t] = v;
-        }
+        ogc_stage_weight_tile<TRANSPOSE_A, WG_WAVES>(a_lds, w, m0, M, K, Kq); // a_lds[mi * LD + k] = A[m0 + mi][k]
         }
         __syncthreads();
         const int nblk = min(4, (M - m0 + 15) >> 4); // 16-row blocks of this tile that hold real rows (uniform)
@@ -371,7 +365,7 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_gemm_kernel(int M,
             if (q < Kq) {
                 float av[4];
 #pragma unroll
-                for (int a = 0; a < 4; ++a) av[a] = a_lds[(q * 64 + a * 16 + j) * 4 + kk]; // A[m0+16a+j][4q+kk]
+                for (int a = 0; a < 4; ++a) av[a] = a_lds[(a * 16 + j) * a_ld + q * 4 + kk]; // A[m0+16a+j][4q+kk]
 #pragma unroll
                 for (int a = 0; a < 4; ++a) {
                     if (a < nblk) { // no MFMA work on padding rows (M = 32: half of the tile)
@@ -489,17 +483,13 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_gemm_stream_kernel
                                                                                  float *__restrict__ out,
                                                                                  const float *__restrict__ pa,
                                                                                  const float *__restrict__ pb, int pro_relu) {
-    extern __shared__ __attribute__((aligned(16))) float a_lds[]; // [M / 64 tiles][Kq][64][4], then PRO: [wave][2][KQ * 4]
+    extern __shared__ __attribute__((aligned(16))) float a_lds[]; // [M / 64 tiles][64][ogc_a_ld(Kq)], then PRO: [wave][2][KQ * 4]
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 15, kk = lane >> 4;
-    const int Kq = (K + 3) >> 2, Mt = (M + 63) >> 6;
+    const int Kq = (K + 3) >> 2, Mt = (M + 63) >> 6, a_ld = ogc_a_ld(Kq);
     const int tiles_per_img = hw >> 6;
-    for (int t = threadIdx.x; t < Mt * Kq * 256; t += WG_WAVES * OGC_WAVE) {
-        const int mt = t / (Kq * 256), r = t - mt * (Kq * 256);
-        const int kr = r & 3, mi = (r >> 2) & 63, q = r >> 8;
-        const int m = mt * 64 + mi, k = q * 4 + kr;
-        a_lds[t] = (m < M && k < K) ? w[(size_t)m * K + k] : 0.f;
-    }
+    for (int mt = 0; mt < Mt; ++mt)
+        ogc_stage_weight_tile<false, WG_WAVES>(a_lds + (size_t)mt * 64 * a_ld, w, mt * 64, M, K, Kq);
     __syncthreads();
     const int nw = gridDim.x * WG_WAVES;
     // The loads of a tile are unconditional and of one shape (a load under a per-lane condition becomes an exec-masked block
@@ -523,7 +513,7 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_gemm_stream_kernel
     // PRO: the coefficients of the current image sit in a wave-private strip of LDS, refreshed when the image changes —
     // read from global memory at compute time they would be the newest loads in flight, and waiting for them means
     // waiting for the prefetched tile as well.
-    float *cw = a_lds + (size_t)Mt * Kq * 256 + wave * (2 * KQ * 4);
+    float *cw = a_lds + (size_t)Mt * 64 * a_ld + wave * (2 * KQ * 4);
     int coef_b = -1;
     auto compute_store = [&](int t, float4(&x)[KQ]) {
         const int b = t / tiles_per_img, p0 = (t - b * tiles_per_img) * 64;
@@ -551,7 +541,7 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_gemm_stream_kernel
         float *outb = out + (size_t)b * M * hw + p0;
         const unsigned off_out = (unsigned)(kk * 4 * hw + 4 * j);
         for (int mt = 0; mt < Mt; ++mt) {
-            const float *at = a_lds + (size_t)mt * Kq * 256;
+            const float *at = a_lds + (size_t)mt * 64 * a_ld;
             const int nblk = EXACT ? 4 : min(4, (M - mt * 64 + 15) >> 4);
             v4f acc[4][4];
 #pragma unroll
@@ -563,7 +553,7 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_gemm_stream_kernel
                 if (EXACT || q < Kq) {
                     float av[4];
 #pragma unroll
-                    for (int a = 0; a < 4; ++a) av[a] = at[(q * 64 + a * 16 + j) * 4 + kk];
+                    for (int a = 0; a < 4; ++a) av[a] = at[(a * 16 + j) * a_ld + q * 4 + kk];
 #pragma unroll
                     for (int a = 0; a < 4; ++a) {
                         if (EXACT || a < nblk) {
@@ -604,7 +594,7 @@ bool gemm_stream_launch(int b, int M, int K, int hw, const float *w, const float
                         const float *pb, int pro_relu, hipStream_t s) {
     const int Kq = (K + 3) / 4, Mt = (M + 63) / 64;
     const long long ntiles = (long long)b * (hw / 64);
-    const size_t lds = ((size_t)Mt * Kq * 256 + (PRO ? WG_WAVES * 2 * FW_KQ_MAX * 4 : 0)) * sizeof(float);
+    const size_t lds = ((size_t)Mt * 64 * ogc_a_ld(Kq) + (PRO ? WG_WAVES * 2 * FW_KQ_MAX * 4 : 0)) * sizeof(float);
     static const bool off = getenv("OGC_GEMM_STREAM") && getenv("OGC_GEMM_STREAM")[0] == '0';
     if (off || Kq <= 25 || Kq > FW_KQ_MAX || lds > 156 * 1024 || ntiles < 2048 || ntiles >= (1ll << 31)) return false;
     const int wgs = (int)(ntiles / WG_WAVES < 256 ? ntiles / WG_WAVES : 256);
@@ -635,7 +625,7 @@ int gemm_launch(int b, int M, int K, int hw, int groups, const float *w, const f
     if constexpr (!T && !STATS && !POOL) {
         if (!g_matmul_bf16 && gemm_stream_launch<PRO>(b, M, K, hw, w, in, out, pa, pb, pro_relu, s)) return OGC_OK;
     }
-    const size_t lds = (size_t)Kq * 256 * sizeof(float);
+    const size_t lds = (size_t)64 * ogc_a_ld(Kq) * sizeof(float); // (the bf16 staging needs half of it)
     dim3 grid(ogc_divup(hw, 64 * WG_WAVES), b);
 #define OGC_GEMM(KQV)                                                                                                  \
     do {                                                                                                               \

@@ -22,6 +22,7 @@
 //   ogc_gn_moments_combine      dW, dgamma, dbeta, and alpha / c2 / c3 per (sample, channel)
 //   ogc_conv1x1_dgrad_adjoint   g_prev
 #include "ogc_common.h"
+#include "conv_stage.h"
 
 namespace {
 
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void dgrad_adjoint_kernel(int M
                                                                            const float *__restrict__ pb,
                                                                            const float *__restrict__ coef,  // (B, M, 3)
                                                                            float *__restrict__ out) {       // (B, M, hw)
-    extern __shared__ __attribute__((aligned(16))) float a_lds[]; // [Kq][64][4] weights, then [64][5] coefficients
+    extern __shared__ __attribute__((aligned(16))) float a_lds[]; // [64][ogc_a_ld(Kq)] weights (conv_stage.h), then [64][5] coefficients
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 15, kk = lane >> 4;
     const int b = blockIdx.y;
@@ -257,7 +258,8 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void dgrad_adjoint_kernel(int M
     const float *inb = gy + (size_t)b * K * hw;
     float *outb = out + (size_t)b * M * hw;
     const float *yb = yprev + (size_t)b * M * hw;
-    float *cf = a_lds + (size_t)Kq * 256;
+    const int a_ld = ogc_a_ld(Kq);
+    float *cf = a_lds + (size_t)64 * a_ld;
 
     float4 xin[KQ];
 #pragma unroll
@@ -268,11 +270,7 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void dgrad_adjoint_kernel(int M
     }
     for (int m0 = 0; m0 < M; m0 += 64) {
         __syncthreads(); // previous tile fully consumed
-        for (int t = threadIdx.x; t < Kq * 256; t += WG_WAVES * OGC_WAVE) {
-            const int kr = t & 3, mi = (t >> 2) & 63, q = t >> 8;
-            const int m = m0 + mi, k = q * 4 + kr;
-            a_lds[t] = (m < M && k < K) ? w[(size_t)k * M + m] : 0.f;
-        }
+        ogc_stage_weight_tile<true, WG_WAVES>(a_lds, w, m0, M, K, Kq);
         for (int t = threadIdx.x; t < 64; t += WG_WAVES * OGC_WAVE) {
             const int m = m0 + t;
             const bool in = m < M;
@@ -304,7 +302,7 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void dgrad_adjoint_kernel(int M
 #pragma unroll
                 for (int q = 0; q < KQ; ++q) {
                     if (q < Kq) {
-                        const float av = a_lds[(q * 64 + a * 16 + j) * 4 + kk]; // A[m0+16a+j][4q+kk]
+                        const float av = a_lds[(a * 16 + j) * a_ld + q * 4 + kk]; // A[m0+16a+j][4q+kk]
                         acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xin[q].x, acc[0], 0, 0, 0);
                         acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xin[q].y, acc[1], 0, 0, 0);
                         acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xin[q].z, acc[2], 0, 0, 0);
@@ -398,7 +396,7 @@ extern "C" int ogc_conv1x1_dgrad_adjoint(int b, int cin, int cout, int hw, int r
                 "ogc_conv1x1_dgrad_adjoint: one sample exceeds 32-bit indexing");
     if (b == 0) return OGC_OK;
     const int M = cin, K = cout, Kq = (K + 3) / 4;
-    const size_t lds = ((size_t)Kq * 256 + 64 * 5) * sizeof(float);
+    const size_t lds = ((size_t)64 * ogc_a_ld(Kq) + 64 * 5) * sizeof(float);
     dim3 grid(ogc_divup(hw, 64 * WG_WAVES), b);
     hipStream_t s = (hipStream_t)stream;
 #define OGC_DGA(KQV)                                                                                                       \

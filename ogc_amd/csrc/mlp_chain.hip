@@ -51,10 +51,23 @@ __device__ __forceinline__ float mc_group_max(float v) {
 template <int KP, int COUT>
 __device__ __forceinline__ void mc_stage_weights(float *lds, const float *__restrict__ wt, const float *__restrict__ bias) {
     constexpr int LD = COUT + 4;
-    for (int e = threadIdx.x * 4; e < KP * COUT; e += MC_THREADS * 4) {
-        const int k = e / COUT, m = e - k * COUT;
-        const float4 v = *reinterpret_cast<const float4 *>(wt + e);
-        *reinterpret_cast<float4 *>(lds + k * LD + m) = v;
+    // eight independent float4 loads in flight per thread and round (one load per round = one L2 round trip per round)
+    constexpr int U = 8;
+    for (int e0 = threadIdx.x * 4; e0 < KP * COUT; e0 += MC_THREADS * 4 * U) {
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = min(e0 + u * MC_THREADS * 4, KP * COUT - 4);
+            v[u] = *reinterpret_cast<const float4 *>(wt + e);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = e0 + u * MC_THREADS * 4;
+            if (e < KP * COUT) {
+                const int k = e / COUT, m = e - k * COUT;
+                *reinterpret_cast<float4 *>(lds + k * LD + m) = v[u];
+            }
+        }
     }
     for (int m = threadIdx.x; m < COUT; m += MC_THREADS) lds[KP * LD + m] = bias[m];
 }
