@@ -165,7 +165,10 @@ class _PointwiseConv(Function):
             else:
                 torch.matmul(weight.detach().view(cout, cin), x.reshape(B, cin, hw), out=y.view(B, cout, hw))
         else:
-            y = F.conv2d(x, weight) if x.dim() == 4 else F.conv1d(x, weight)
+            # shapes the MFMA kernels do not take (K > 160, ragged or tiny position counts): one batched rocBLAS product.
+            # NOT F.conv1d / F.conv2d: for these shapes MIOpen picks a naive direct-convolution kernel (0.46 ms for the
+            # 16 x 128 x 10 object features of the C4 step) or a Winograd kernel with transposes around it
+            y = torch.matmul(weight.detach().reshape(cout, cin), x.reshape(B, cin, hw)).view((B, cout) + tuple(x.shape[2:]))
         if gn_groups > 0:
             if stats is not None:
                 ctx.mark_non_differentiable(stats)
@@ -184,9 +187,11 @@ class _PointwiseConv(Function):
         hw = x.numel() // (B * cin)
         grad_x = grad_w = None
         if ctx.small:
-            grad_x, grad_w, _ = torch.ops.aten.convolution_backward(
-                grad_y, x, weight, None, [1] * nd, [0] * nd, [1] * nd, False, [0] * nd, 1,
-                [bool(ctx.needs_input_grad[0]), bool(ctx.needs_input_grad[1]), False])
+            g3, x3 = grad_y.reshape(B, cout, hw), x.reshape(B, cin, hw)
+            if ctx.needs_input_grad[0]:
+                grad_x = torch.matmul(weight.detach().reshape(cout, cin).t(), g3).view_as(x)
+            if ctx.needs_input_grad[1]:
+                grad_w = torch.bmm(g3, x3.transpose(1, 2)).sum(0).view_as(weight)
             return grad_x, grad_w, None
         if ctx.needs_input_grad[0]:
             if _gemm_ok(cout, hw) and _plain_gemm_mine(cout):
@@ -195,8 +200,7 @@ class _PointwiseConv(Function):
             elif _gemm_ok(cout, hw):
                 grad_x = torch.matmul(weight.detach().view(cout, cin).t(), grad_y.reshape(B, cout, hw)).view_as(x)
             else:
-                grad_x = torch.ops.aten.convolution_backward(grad_y, x, weight, None, [1] * nd, [0] * nd, [1] * nd,
-                                                             False, [0] * nd, 1, [True, False, False])[0]
+                grad_x = torch.matmul(weight.detach().reshape(cout, cin).t(), grad_y.reshape(B, cout, hw)).view_as(x)
         if ctx.needs_input_grad[1]:
             if hw <= 16384 and _api._native.get_matmul_precision() == "fp32":
                 # few positions per sample (feature-propagation layers): one batched rocBLAS product per sample and a
@@ -223,6 +227,17 @@ def pointwise_conv(x, conv, gn=None):
         if gn.affine:
             return _PointwiseConv.apply(x, conv.weight, gn.num_groups)
         return _PointwiseConv.apply(x, conv.weight), None
+    if (x.is_cuda and x.dtype == torch.float32 and conv.groups == 1 and x.dim() >= 3
+            and all(k == 1 for k in conv.kernel_size) and all(v == 1 for v in conv.stride)
+            and all(v == 0 for v in conv.padding)):
+        # every other 1x1 convolution (bias, strided input, ragged position count): a batched rocBLAS product through
+        # autograd instead of MIOpen's convolution (see _PointwiseConv.forward)
+        cout, cin = conv.weight.shape[0], conv.weight.shape[1]
+        y = torch.matmul(conv.weight.reshape(cout, cin), x.reshape(x.shape[0], cin, -1))
+        if conv.bias is not None:
+            y = y + conv.bias.view(1, cout, 1)
+        y = y.view((x.shape[0], cout) + tuple(x.shape[2:]))
+        return (y, None) if gn is not None else y
     return (conv(x), None) if gn is not None else conv(x)
 
 

@@ -63,7 +63,12 @@ class HostScalars:
 
     def __init__(self, values):
         values = values.detach()
-        if values.is_cuda:
+        self._dev = None
+        if values.is_cuda and torch.cuda.is_current_stream_capturing():
+            # inside a HIP-graph capture: no pinned allocation, no event — the values stay in a tensor of the graph's
+            # memory pool, rewritten by every replay, and get() reads it (a synchronising copy) when asked
+            self._dev, self._host, self._event = values.clone(), None, None
+        elif values.is_cuda:
             self._host = torch.empty(values.shape, dtype=values.dtype, pin_memory=True)
             self._host.copy_(values, non_blocking=True)
             self._event = torch.cuda.Event()
@@ -72,6 +77,8 @@ class HostScalars:
             self._host, self._event = values, None
 
     def get(self):
+        if self._dev is not None:
+            return self._dev.tolist()
         if self._event is not None:
             self._event.synchronize()
             self._event = None

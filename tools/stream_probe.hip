@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <vector>
+#include "../ogc_amd/csrc/conv_stage.h"
 typedef float v4f __attribute__((ext_vector_type(4)));
 constexpr int KQ = 32;
 
@@ -16,11 +17,8 @@ __global__ __launch_bounds__(WAVES * 64) void stream(int M, int K, int hw, int n
     const int j = lane & 15, kk = lane >> 4;
     const int Kq = K >> 2, Mt = M >> 6;
     const int tiles_per_img = hw >> 6;
-    for (int t = threadIdx.x; t < Mt * Kq * 256; t += WAVES * 64) {
-        const int mt = t / (Kq * 256), r = t - mt * (Kq * 256);
-        const int kr = r & 3, mi = (r >> 2) & 63, q = r >> 8;
-        a_lds[t] = w[(size_t)(mt * 64 + mi) * K + q * 4 + kr];
-    }
+    const int a_ld = ogc_a_ld(Kq);
+    for (int mt = 0; mt < Mt; ++mt) ogc_stage_weight_tile<false, WAVES>(a_lds + (size_t)mt * 64 * a_ld, w, mt * 64, M, K, Kq);
     __syncthreads();
     const int nw = gridDim.x * WAVES;
     const unsigned off_main = (unsigned)(kk * hw + 4 * j) * 4u; // BYTES: scalar base + 32-bit lane offset (saddr form)
@@ -37,7 +35,7 @@ __global__ __launch_bounds__(WAVES * 64) void stream(int M, int K, int hw, int n
         float *outb = out + (size_t)b * M * hw + p0;
         const unsigned off_out = (unsigned)(kk * 4 * hw + 4 * j) * 4u;
         for (int mt = 0; mt < Mt; ++mt) {
-            const float *at = a_lds + (size_t)mt * Kq * 256;
+            const float *at = a_lds + (size_t)mt * 64 * a_ld;
             v4f acc[4][4];
 #pragma unroll
             for (int a = 0; a < 4; ++a)
@@ -46,13 +44,14 @@ __global__ __launch_bounds__(WAVES * 64) void stream(int M, int K, int hw, int n
             if (MFMA) {
                 float av[2][4]; // the A operands of step q + 1 are read from LDS before the MFMAs of step q
 #pragma unroll
-                for (int a = 0; a < 4; ++a) av[0][a] = at[(a * 16 + j) * 4 + kk];
+                for (int a = 0; a < 4; ++a) av[0][a] = at[(a * 16 + j) * a_ld + kk];
 #pragma unroll
                 for (int q = 0; q < KQ; ++q) {
                     if (q + 1 < KQ) {
 #pragma unroll
-                        for (int a = 0; a < 4; ++a) av[(q + 1) & 1][a] = at[((q + 1) * 64 + a * 16 + j) * 4 + kk];
+                        for (int a = 0; a < 4; ++a) av[(q + 1) & 1][a] = at[(a * 16 + j) * a_ld + (q + 1) * 4 + kk];
                     }
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int a = 0; a < 4; ++a) {
                         acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q & 1][a], x[q].x, acc[a][0], 0, 0, 0);
@@ -60,6 +59,7 @@ __global__ __launch_bounds__(WAVES * 64) void stream(int M, int K, int hw, int n
                         acc[a][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q & 1][a], x[q].z, acc[a][2], 0, 0, 0);
                         acc[a][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q & 1][a], x[q].w, acc[a][3], 0, 0, 0);
                     }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             if (STORE || acc[0][0][0] == 12345.678f) { // (the comparison keeps the accumulators alive without stores)
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(WAVES * 64) void stream(int M, int K, int hw, int n
 template <bool L, bool F, bool S, int WAVES>
 void run(const char *name, int wgs, const float *w, const float *in, float *out) {
     const int B = 16, K = 128, M = 128, hw = 32768, ntiles = B * hw / 64;
-    const size_t lds = (size_t)(M / 64) * (K / 4) * 256 * 4;
+    const size_t lds = (size_t)(M / 64) * 64 * ogc_a_ld(K / 4) * 4;
     hipFuncSetAttribute(reinterpret_cast<const void *>(&stream<L, F, S, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
