@@ -1,0 +1,147 @@
+"""The whole segmentation training step — forward, OGC loss, backward, gradient all-reduce, fused Adam — as ONE HIP graph.
+
+Why: at C4 (16 clouds of 8192 points per GPU) the eager step launches ~600 kernels from Python; the launch thread needs
+10-12 ms for that whatever the cloud size (tools/graph_step.py: 2048-point clouds take 10.3 ms eagerly, 5.7 ms replayed),
+which is also what the GPU needs for the kernels of an 8192-point step.  A graph replay costs the host one call, so the
+step runs at the speed of its kernels, and kernels that are faster than the launch thread (the small ones of the loss and
+of the slot branch) stop being hidden behind it.
+
+What is captured is `train_step` itself (ogc_amd/train_step.py) — the same Python, the same kernels, the same side
+streams — on STATIC buffers:
+
+    cur   the batch being trained on (the trainer reads one batch ahead and hands the next one to step())
+    plan  the coordinate-only work (FPS / kNN / 3-NN of every encoder level) of `cur`, made during the previous replay
+
+and one step is:   replay (train on cur with plan)  ||  (side streams, eager) plan' = geometry of the next batch,
+then plan <- plan', cur <- next batch (two fused copies behind the replay).  Everything the step decides stays on the device (the
+NaN-gradient rule is the fused optimizer's found_inf flag, the Hungarian matching and the eigenvalues are kernels), so
+there is nothing for the host to do between two replays.
+
+Python-side constants are frozen at capture: the loss weights of iteration `it` (piecewise constant in the reference's
+schedule, losses/seg_loss_unsup.py `start_step`) — recapture with `recapture(it)` when they change — and the learning
+rate unless the optimizer was built with a tensor `lr`.  Reference step: train_seg.py:40-100.
+"""
+import torch
+
+from .train_step import PrefetchedGeometry, train_step
+from .utils import streams as _streams
+
+
+def _plan_tensors(obj):
+    """Every tensor of a geometry plan (nested dicts / lists / Pending / PrefetchedGeometry), in a fixed order."""
+    if torch.is_tensor(obj):
+        yield obj
+    elif isinstance(obj, _streams.Pending):
+        yield from _plan_tensors(obj._value)
+    elif isinstance(obj, PrefetchedGeometry):
+        yield from _plan_tensors([obj.flat, obj.pcs_l, obj.flows_l, obj.model, obj.loss])
+    elif isinstance(obj, dict):
+        for k in sorted(obj):
+            yield from _plan_tensors(obj[k])
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            yield from _plan_tensors(v)
+
+
+def _resolve(obj, wait):
+    """Pending -> waited for (wait=True: the current stream joins the producing stream) or marked as done."""
+    if isinstance(obj, _streams.Pending):
+        if wait:
+            obj.get()
+        else:
+            obj._event = None
+    elif isinstance(obj, PrefetchedGeometry):
+        _resolve([obj.model, obj.loss], wait)
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            _resolve(v, wait)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            _resolve(v, wait)
+
+
+def _join_side_streams(main):
+    """`main` (capturing) waits for every side stream that was forked into the capture."""
+    for st in list(_streams._side.values()):
+        with torch.cuda.stream(st):
+            forked = torch.cuda.is_current_stream_capturing()
+        if forked:
+            main.wait_stream(st)
+
+
+def _state_tensors(segnet, optimizer):
+    net = segnet.module if hasattr(segnet, "module") else segnet
+    ts = [p.data for p in net.parameters()] + [b.data for b in net.buffers()]
+    for st in optimizer.state.values():
+        ts += [v for v in st.values() if torch.is_tensor(v)]
+    return ts
+
+
+class GraphedTrainStep:
+    """step(next_batch) trains on the batch handed over by the PREVIOUS call (the first one: `first_batch`) and returns
+    that step's PendingStep; `next_batch` is planned meanwhile and trained on by the next call.
+
+    optimizer: torch.optim.Adam(..., fused=True, capturable=True) (train_step.make_optimizer(capturable=True))."""
+
+    def __init__(self, segnet, criterion, optimizer, first_batch, it, aug_transform):
+        assert first_batch[0].is_cuda, "GraphedTrainStep needs the batch on the GPU"
+        assert optimizer.defaults.get("capturable"), "build the optimizer with capturable=True (make_optimizer)"
+        self.segnet, self.criterion, self.optimizer, self.aug = segnet, criterion, optimizer, aug_transform
+        self.cur = tuple(t.clone() if torch.is_tensor(t) else t for t in first_batch)
+        self.stream = torch.cuda.Stream()
+        self.graph, self.pending, self.plan = None, None, None
+        self.recapture(it)
+
+    def _warm_up(self, it):
+        """One eager step on the capture stream, undone afterwards: library handles, the workspaces of this stream and of
+        the side streams and the optimizer's state tensors must exist before a capture begins (a capture records
+        allocations and zero-fills as nodes: the optimizer state would be reset by every replay)."""
+        fresh = len(self.optimizer.state) == 0
+        before = _state_tensors(self.segnet, self.optimizer)
+        saved = [t.clone() for t in before]
+        train_step(self.segnet, self.criterion, self.optimizer, self.cur, it, self.aug, sync=False)
+        torch._foreach_copy_(before, saved)
+        if fresh:  # the state the optimizer would have created on its first step: zeros
+            for st in self.optimizer.state.values():
+                for v in st.values():
+                    if torch.is_tensor(v):
+                        v.zero_()
+
+    def recapture(self, it):
+        """(Re)build the graph for the loss weights of iteration `it` (and the optimizer's current hyper-parameters)."""
+        self.it = it
+        s = self.stream
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            self._warm_up(it)
+            if self.plan is None:
+                self.plan = PrefetchedGeometry(self.segnet, self.criterion, self.cur, self.aug)
+            torch.cuda.synchronize()
+            _resolve(self.plan, wait=False)
+            self.optimizer.zero_grad(set_to_none=True)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=s):
+                pending = train_step(self.segnet, self.criterion, self.optimizer, self.cur, it, self.aug, sync=False,
+                                     prefetched=self.plan)
+                _join_side_streams(torch.cuda.current_stream())
+        torch.cuda.current_stream().wait_stream(s)
+        self.graph, self.pending = graph, pending
+        self._plan_dst = list(_plan_tensors(self.plan))
+
+    def step(self, next_batch):
+        s = self.stream
+        s.wait_stream(torch.cuda.current_stream())  # whoever produced next_batch
+        with torch.cuda.stream(s):
+            # The geometry of the next batch: ~40 eager launches on the side streams, which wait for the point reached on
+            # `s` HERE (the end of the previous step) and so run underneath the replay queued right after.  It is NOT a
+            # branch of the graph: the graph executor ran that branch after the step instead of underneath it (13.7 ms
+            # per step against 12.6 for the eager step with the same overlap).
+            upcoming = PrefetchedGeometry(self.segnet, self.criterion, next_batch, self.aug)
+            self.graph.replay()
+            _resolve(upcoming, wait=True)  # behind the replay: join the side streams, then shift
+            src = list(_plan_tensors(upcoming))
+            assert len(src) == len(self._plan_dst)
+            torch._foreach_copy_(self._plan_dst, src)
+            torch._foreach_copy_([d for d in self.cur if torch.is_tensor(d)],
+                                 [v for d, v in zip(self.cur, next_batch) if torch.is_tensor(d)])
+        return self.pending.refresh()  # its scalars now describe this replay

@@ -39,6 +39,13 @@ class PendingStep:
         self._losses, self._bad, self._out = pending_losses, bad_scalar, None
         self.prefetched = None  # PrefetchedGeometry of the next batch, when train_step was given one
 
+    def refresh(self):
+        """Forget the values read so far: the device scalars were rewritten (a graph replay of the step)."""
+        self._out = None
+        if hasattr(self._losses, "_dict"):
+            self._losses._dict = None
+        return self
+
     def result(self):
         if self._out is None:
             losses = self._losses.resolve() if hasattr(self._losses, "resolve") else self._losses
@@ -46,13 +53,14 @@ class PendingStep:
         return self._out
 
 
-def make_optimizer(params, lr, weight_decay=0.0):
+def make_optimizer(params, lr, weight_decay=0.0, capturable=False):
     """Adam as the reference builds it (train_seg.py:320).  On the GPU the fused implementation is used: the same
     update, and it can skip itself on the device when handed a `found_inf` flag, which is what lets train_step apply
     the reference's NaN-gradient rule (train_seg.py:81-83) without stopping to read the flag on the host."""
     params = list(params)
     fused = bool(params) and all(p.is_cuda for p in params)
-    return torch.optim.Adam(params, lr=lr, weight_decay=weight_decay, fused=fused)
+    # capturable: step counts live on the device, so optimizer.step() can be part of a HIP graph (graph_step.py)
+    return torch.optim.Adam(params, lr=lr, weight_decay=weight_decay, fused=fused, capturable=bool(capturable and fused))
 
 
 def _views(batch):

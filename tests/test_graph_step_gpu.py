@@ -1,0 +1,54 @@
+"""The training step replayed as one HIP graph (ogc_amd/graph_step.py) against the eager step: same batches in the
+same order, same losses step by step (up to the rounding noise of the scatter-add atomics, which both have)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(npoint):
+    from ogc_amd.models.segnet_kitti import MaskFormer3D
+    from ogc_amd.train_step import KITTI_LOSS, build_criterion, make_optimizer
+    torch.manual_seed(10)
+    net = MaskFormer3D(n_slot=10, n_point=npoint, use_xyz=True, n_transformer_layer=2, transformer_embed_dim=128,
+                       transformer_input_pos_enc=False).cuda()
+    return net, build_criterion(KITTI_LOSS), make_optimizer(net.parameters(), lr=1e-3, capturable=True)
+
+
+def test_graphed_step_matches_eager():
+    assert torch.cuda.is_available()
+    import ogc_amd  # noqa: F401
+    from ogc_amd.graph_step import GraphedTrainStep
+    from ogc_amd.train_step import train_step
+    from ogc_amd.utils.synthetic import make_scene_batch
+    npoint, steps = 1024, 6
+    batches = [make_scene_batch(2, npoint, 10, seed=77 + i, outdoor=True, aug=True, device="cuda") for i in range(3)]
+
+    net, crit, opt = _build(npoint)
+    eager, pre = [], None
+    for i in range(steps):
+        p = train_step(net, crit, opt, batches[i % 3], 1000, True, sync=False, prefetched=pre,
+                       next_batch=batches[(i + 1) % 3])
+        pre = p.prefetched
+        losses, stepped = p.result()
+        assert stepped
+        eager.append(losses)
+    w_eager = [p.detach().clone() for p in net.parameters()]
+
+    net, crit, opt = _build(npoint)
+    w0 = [p.detach().clone() for p in net.parameters()]
+    gs = GraphedTrainStep(net, crit, opt, batches[0], 1000, True)
+    # building the graph (one eager warm-up step, undone) leaves the model and the optimizer as they were
+    for a, b in zip(w0, net.parameters()):
+        assert torch.equal(a, b.detach())
+    assert all(float(st["step"]) == 0 for st in opt.state.values())
+    for i in range(steps):
+        losses, stepped = gs.step(batches[(i + 1) % 3]).result()
+        assert stepped
+        for k in ("sum", "dynamic", "smooth", "invariance"):
+            assert abs(losses[k] - eager[i][k]) <= 2e-3 * max(1.0, abs(eager[i][k])), (i, k, losses[k], eager[i][k])
+    assert all(float(st["step"]) == steps for st in opt.state.values())
+    # six Adam steps of 1e-3 move a weight by at most 6e-3; the two runs must agree far better than that on average
+    num = sum(float((a - b.detach()).abs().sum()) for a, b in zip(w_eager, net.parameters()))
+    den = sum(float((a - b).abs().sum()) for a, b in zip(w_eager, w0))
+    assert num <= 0.05 * den, (num, den)
