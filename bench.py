@@ -127,7 +127,7 @@ def measure_extras(pc, a):
     y = torch.empty(Bc, cout, hw, device=pc.device)
     ms_g = _time(lambda: nat.conv1x1_gemm_wrapper(Bc, cout, cin, hw, 0, w, x, y))
     tf = 2.0 * Bc * hw * cin * cout / ms_g / 1e9
-    out["mfma"] = {"kernel": "conv1x1_gemm_kernel (v_mfma_f32_16x16x4_f32), SA3 layer 128 -> 128 on %d x %d positions" % (Bc, hw),
+    out["mfma"] = {"kernel": "conv1x1_gemm_stream_kernel (v_mfma_f32_16x16x4_f32), SA3 layer 128 -> 128 on %d x %d positions" % (Bc, hw),
                    "bound": "mfma", "achieved": round(tf, 2), "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
                    "frac": round(tf / FP32_MFMA_PEAK_TF, 4), "avg_ms": round(ms_g, 4),
                    "hbm_gbs": round(4.0 * Bc * hw * (cin + cout) / ms_g / 1e6, 1),

@@ -128,6 +128,18 @@ class GraphedTrainStep:
         self.graph, self.pending = graph, pending
         self._plan_dst = list(_plan_tensors(self.plan))
 
+    def load(self, batch):
+        """Make `batch` the one the next step() trains on (start of an epoch, or after steps that did not go through this
+        object): its geometry plan is computed here, eagerly."""
+        s = self.stream
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            fresh = PrefetchedGeometry(self.segnet, self.criterion, batch, self.aug)
+            _resolve(fresh, wait=True)
+            torch._foreach_copy_(self._plan_dst, list(_plan_tensors(fresh)))
+            torch._foreach_copy_([d for d in self.cur if torch.is_tensor(d)],
+                                 [v for d, v in zip(self.cur, batch) if torch.is_tensor(d)])
+
     def step(self, next_batch):
         s = self.stream
         s.wait_stream(torch.cuda.current_stream())  # whoever produced next_batch
@@ -144,4 +156,20 @@ class GraphedTrainStep:
             torch._foreach_copy_(self._plan_dst, src)
             torch._foreach_copy_([d for d in self.cur if torch.is_tensor(d)],
                                  [v for d, v in zip(self.cur, next_batch) if torch.is_tensor(d)])
-        return self.pending.refresh()  # its scalars now describe this replay
+            return self._pending_of_this_replay()
+
+    def _pending_of_this_replay(self):
+        """The scalars of the replay just queued, on their way to the host (pinned copy + event, like an eager step's), so
+        that the caller can read step i while step i+1 is already running: the graph's own scalar tensors are rewritten by
+        the next replay."""
+        import copy
+        from .train_step import PendingStep
+        losses = self.pending._losses
+        if hasattr(losses, "_scalars") and getattr(losses._scalars, "_dev", None) is not None:
+            losses = copy.copy(losses)
+            losses._scalars = _streams.HostScalars(self.pending._losses._scalars._dev)
+            losses._dict = None
+        bad = self.pending._bad
+        if getattr(bad, "_dev", None) is not None:
+            bad = _streams.HostScalars(bad._dev)
+        return PendingStep(losses, bad)

@@ -204,6 +204,9 @@ def main(argv=None):
     ap.add_argument("--device", default="cuda")
     ap.add_argument("--ddp", action="store_true",
                     help="average gradients with torch's DistributedDataParallel instead of one flat collective per step")
+    ap.add_argument("--hip-graph", action="store_true",
+                    help="replay the training step as one HIP graph (ogc_amd/graph_step.py; one GPU): removes the launch "
+                         "thread's 10-12 ms per step, which is the bound for clouds of fewer than ~8192 points")
     ap.add_argument("--flow-root", default=None,
                     help="read predicted flows from <flow-root>/flow_preds/<predflow_path>[_R<round-1>] (train_seg.py:277-280)")
     ap.add_argument("--frames", type=int, default=2,
@@ -262,7 +265,9 @@ def main(argv=None):
                                                sampler=sampler, drop_last=True)
     val_loader = torch.utils.data.DataLoader(val_set, batch_size=cfg["batch_size"], shuffle=False)
 
-    optimizer = make_optimizer(net.parameters(), lr=cfg["lr"], weight_decay=cfg["weight_decay"])
+    use_graph = args.hip_graph and device.type == "cuda" and not distributed
+    optimizer = make_optimizer(net.parameters(), lr=cfg["lr"], weight_decay=cfg["weight_decay"], capturable=use_graph)
+    graphed, graphed_key, graph_holds = None, None, None
     # Waymo: only backward flow exists, the trainer keeps every other view and uses the one-frame loss
     # (train_seg_waymo.py:59, :244-334)
     single_frame = cfg["dataset"] == "waymo"
@@ -306,6 +311,28 @@ def main(argv=None):
                 if isinstance(m, NORM_LAYERS):
                     m.momentum = mom
             # the scalars of step i are read while step i+1 is already queued: the host never waits inside a step
+            if use_graph:
+                # everything the capture froze: learning rate, norm momentum, which loss terms are active, augmentation
+                gates = tuple(it * world * cfg["batch_size"] >= st for st in cfg["loss"].get("start_steps", [0, 0, 0]))
+                key = (optimizer.param_groups[0]["lr"], mom, gates, aug, tuple(batch[0].shape))
+                if graphed is None or key != graphed_key:
+                    from .graph_step import GraphedTrainStep
+                    if graphed is None or key[3:] != graphed_key[3:]:
+                        graphed = GraphedTrainStep(model, criterion, optimizer, batch, it * world, aug)
+                    else:
+                        graphed.load(batch)
+                        graphed.recapture(it * world)
+                    graphed_key, graph_holds = key, batch
+                elif graph_holds is not batch:
+                    graphed.load(batch)
+                pending = graphed.step(upcoming if upcoming is not None else batch)
+                account(in_flight)
+                in_flight = pending
+                graph_holds, batch = upcoming, upcoming
+                it += 1
+                if args.max_iters and it >= args.max_iters:
+                    break
+                continue
             pending = train_step(model, criterion, optimizer, batch, it * world, aug, sync=False, prefetched=pre,
                                  next_batch=upcoming)
             pre, batch = pending.prefetched, upcoming

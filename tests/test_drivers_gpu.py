@@ -60,6 +60,22 @@ def test_train_seg_main_c4(tmp_path, capsys):
     assert any(not torch.equal(init[k], cur[k]) for k in init) or line["val_loss"] < 1e10
 
 
+def test_train_seg_main_hip_graph(tmp_path, capsys):
+    """The same driver with --hip-graph (the step replayed as one HIP graph, ogc_amd/graph_step.py) against the eager run:
+    two epochs of three steps — the second one starts with a batch the graph did not plan — and the same epoch losses."""
+    from ogc_amd import train_seg
+    lines = {}
+    for mode, extra in (("eager", []), ("graph", ["--hip-graph"])):
+        cfg, path = _cfg("kittisf_unsup_synthetic.yaml", tmp_path, epochs=2, save_path=str(tmp_path / mode))
+        train_seg.main([path, "--round", "1", "--synthetic", "12"] + extra)
+        lines[mode] = _json_lines(capsys)[-2:]
+    for e, g in zip(lines["eager"], lines["graph"]):
+        assert e["it"] == g["it"] and e["epoch"] == g["epoch"]
+        for k in ("dynamic", "smooth", "invariance", "sum"):
+            assert abs(e["train"][k] - g["train"][k]) <= 5e-3 * max(1.0, abs(e["train"][k])), (k, e["train"], g["train"])
+        assert abs(e["val_loss"] - g["val_loss"]) <= 2e-2 * max(1.0, abs(e["val_loss"]))
+
+
 def test_train_flow_main_c3(tmp_path, capsys):
     """config/kittisf_flow_synthetic.yaml (C3: FlowStep3D on 8192-point pairs) for two steps."""
     from ogc_amd import train_flow
