@@ -248,6 +248,299 @@ __device__ __forceinline__ unsigned fps_rank(int k, int bs_mask, int bs_shift, i
     return rev * (unsigned)S + ((unsigned)k >> bs_shift);
 }
 
+
+// ---- 4097 .. 8192 points: the same rounds, but only the points a new sample can reach are touched -------------------------
+// A round of fps_reg_kernel updates the running minimum of EVERY point (16 points per lane, ~100 VALU instructions per
+// wavefront) although, once a few hundred samples are out, a new sample only lowers the minima of the points closer to
+// it than their current minimum — a small neighbourhood.  Here the cloud is cut into 64 buckets of 128 points that are
+// close in space (a counting sort on a 12-bit interleaved cell key whose bits go to the axes by extent: a kd-tree with
+// midpoint splits along the longest axis; any partition would be CORRECT, a compact one prunes well), each owned by one
+// wavefront (two points per lane and bucket).  Per bucket the owner keeps the bounding box, the largest running minimum
+// and the rank of the point holding it.  A round: (1) lanes 0 .. BPW-1 compute the squared distance from the new sample
+// to their bucket's box with the SAME fp32 expression as the point distances — IEEE rounding is monotonic, so it is a
+// lower bound of every computed point distance in the box — and a bucket whose bound is not below its maximum keeps all
+// its minima (min(d, t) = t for every point); (2) the other buckets are updated and re-reduced; (3) the wavefront's best
+// bucket goes to the 64-bit LDS maximum exactly as in fps_reg_kernel.  Values, winners and tie order are those of the
+// plain rounds (a skipped update is an update that changes nothing); tests/test_ops_gpu.py runs both against the oracle.
+// Clouds with a non-finite coordinate have no box: every bucket is updated every round.
+constexpr int FPSB_NB = 64;        // buckets
+constexpr int FPSB_SLOTS = 8192;   // points incl. padding: 64 buckets x 128
+constexpr int FPSB_KEYBITS = 12;
+
+template <int WAVES>
+__global__ __launch_bounds__(WAVES *OGC_WAVE) void fps_bucket_kernel(int n, int m, int bs_shift,
+                                                                      const float *__restrict__ xyz,
+                                                                      float *__restrict__ temp, int *__restrict__ idxs,
+                                                                      const int *__restrict__ ties_in,
+                                                                      int *__restrict__ ties_out) {
+    constexpr int THREADS = WAVES * OGC_WAVE, BPW = FPSB_NB / WAVES, PTS = 2 * BPW, NBIN = 1 << FPSB_KEYBITS;
+    extern __shared__ __attribute__((aligned(16))) float fps_smem[];
+    u64 *best_word = reinterpret_cast<u64 *>(fps_smem);           // [2]
+    float *red = fps_smem + 4;                                    // [8 * WAVES] reduction scratch
+    float *lx = fps_smem + 4 + 8 * 8, *ly = lx + FPSB_SLOTS, *lz = ly + FPSB_SLOTS; // xyz by RANK slot (rounds)
+    int *hist = reinterpret_cast<int *>(lx);                      // [NBIN]  (build only: aliases lx)
+    unsigned short *perm = reinterpret_cast<unsigned short *>(hist + NBIN); // [FPSB_SLOTS] sorted position -> point
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, b = blockIdx.x;
+    const float *__restrict__ dataset = xyz + (size_t)b * n * 3;
+    float *tmp = temp + (size_t)b * n;
+    int *out = idxs + (size_t)b * m;
+    const int S = (n + (1 << bs_shift) - 1) >> bs_shift, bs_mask = (1 << bs_shift) - 1;
+
+    const int L = ties_in ? max(1, min(ties_in[b], m)) : 1; // known prefix of the answer (see fps_reg_kernel)
+    if (L >= m) {
+        for (int r = t; r < m; r += THREADS) out[r] = r;
+        if (t == 0 && ties_out) ties_out[b] = ties_in[b];
+        return;
+    }
+    const bool track = ties_out != nullptr;
+    int first_tie = 0x7fffffff;
+
+    // ---- build: bounding box of the cloud
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    bool finite = true;
+    for (int k = t; k < n; k += THREADS) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float v = dataset[k * 3 + a];
+            finite = finite && fabsf(v) < INFINITY;
+            lo[a] = fminf(lo[a], v);
+            hi[a] = fmaxf(hi[a], v);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            lo[a] = fminf(lo[a], __shfl_xor(lo[a], off, 64));
+            hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off, 64));
+        }
+    }
+    const bool wave_finite = __builtin_amdgcn_ballot_w64(!finite) == 0;
+    if (lane == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { red[wave * 8 + a] = lo[a]; red[wave * 8 + 3 + a] = hi[a]; }
+        red[wave * 8 + 6] = wave_finite ? 1.0f : 0.0f;
+    }
+    if (t == 0) { best_word[0] = 0ull; best_word[1] = 0ull; }
+    __syncthreads();
+    bool all_finite = true;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], red[w * 8 + a]); hi[a] = fmaxf(hi[a], red[w * 8 + 3 + a]); }
+        all_finite = all_finite && red[w * 8 + 6] != 0.0f;
+    }
+    const bool always = !all_finite; // no usable boxes: every bucket is updated every round
+    // key bits to the axes, most significant first: each bit halves the axis whose cells are longest
+    int nbits[3] = {0, 0, 0};
+    unsigned seq = 0u; // 2 bits per key bit (most significant key bit in the low bits of seq)
+    {
+        float cell[3] = {hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]};
+        for (int i = 0; i < FPSB_KEYBITS; ++i) {
+            int a = 0;
+            if (cell[1] > cell[a]) a = 1;
+            if (cell[2] > cell[a]) a = 2;
+            seq |= (unsigned)a << (2 * i);
+            if (a == 0) { cell[0] *= 0.5f; ++nbits[0]; } else if (a == 1) { cell[1] *= 0.5f; ++nbits[1]; } else { cell[2] *= 0.5f; ++nbits[2]; }
+        }
+    }
+    float inv[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) inv[a] = (all_finite && hi[a] > lo[a]) ? (float)(1 << nbits[a]) / (hi[a] - lo[a]) : 0.0f;
+    for (int e = t; e < NBIN; e += THREADS) hist[e] = 0;
+    __syncthreads();
+    // ---- counting sort by key: bin counts, then exclusive starts, then positions
+    int mykey[PTS], myoff[PTS];
+#pragma unroll
+    for (int i = 0; i < PTS; ++i) {
+        const int k = t + i * THREADS;
+        mykey[i] = -1;
+        myoff[i] = 0;
+        if (k < n) {
+            int q[3], rem[3] = {nbits[0], nbits[1], nbits[2]};
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float v = dataset[k * 3 + a];
+                int c = (int)((v - lo[a]) * inv[a]);
+                q[a] = min(max(c, 0), (1 << nbits[a]) - 1);
+            }
+            int key = 0;
+            for (int j = 0; j < FPSB_KEYBITS; ++j) {
+                const int a = (seq >> (2 * j)) & 3;
+                int bit;
+                if (a == 0) { --rem[0]; bit = (q[0] >> rem[0]) & 1; }
+                else if (a == 1) { --rem[1]; bit = (q[1] >> rem[1]) & 1; }
+                else { --rem[2]; bit = (q[2] >> rem[2]) & 1; }
+                key = (key << 1) | bit;
+            }
+            mykey[i] = key;
+            myoff[i] = atomicAdd(&hist[key], 1);
+        }
+    }
+    __syncthreads();
+    {
+        constexpr int PER = NBIN / THREADS;
+        int c[PER], sum = 0;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) { c[i] = hist[t * PER + i]; sum += c[i]; }
+        int incl = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int up = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += up;
+        }
+        int *wsum = reinterpret_cast<int *>(red);
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int base = incl - sum;
+        for (int w = 0; w < wave; ++w) base += wsum[w];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) { hist[t * PER + i] = base; base += c[i]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PTS; ++i) {
+        const int k = t + i * THREADS;
+        if (k < n) perm[hist[mykey[i]] + myoff[i]] = (unsigned short)k;
+        else if (k < FPSB_SLOTS) perm[k] = 0xFFFFu; // sorted positions n .. 8191 are padding
+    }
+    __syncthreads();
+    // ---- this lane's points: bucket (s, wave) = s * WAVES + wave, sorted positions 128 * bucket + 2 * lane + {0, 1}
+    float px[PTS], py[PTS], pz[PTS], td[PTS];
+    unsigned rk[PTS];
+#pragma unroll
+    for (int j = 0; j < PTS; ++j) {
+        const int bucket = (j >> 1) * WAVES + wave;
+        const int k = perm[bucket * 128 + 2 * lane + (j & 1)];
+        if (k != 0xFFFF) {
+            px[j] = dataset[k * 3 + 0];
+            py[j] = dataset[k * 3 + 1];
+            pz[j] = dataset[k * 3 + 2];
+            td[j] = tmp[k];
+            rk[j] = fps_rank(k, bs_mask, bs_shift, S);
+        } else {
+            px[j] = py[j] = pz[j] = 0.0f;
+            td[j] = -1.0f; // padding never wins: real values are >= 0 and min(d, -1) = -1
+            rk[j] = 0xFFFFFFFFu;
+        }
+    }
+    __syncthreads(); // everybody has read perm: the region becomes the rank-ordered copy of the cloud
+#pragma unroll
+    for (int j = 0; j < PTS; ++j) {
+        if (rk[j] != 0xFFFFFFFFu) { lx[rk[j]] = px[j]; ly[rk[j]] = py[j]; lz[rk[j]] = pz[j]; }
+    }
+    if (t == 0) out[0] = 0;
+    // known prefix (see fps_reg_kernel): fold samples 0 .. L-2 into the minima of every point, enter at r = L
+    for (int s0 = 0; s0 < L - 1; ++s0) {
+        const float sx = dataset[s0 * 3], sy = dataset[s0 * 3 + 1], sz = dataset[s0 * 3 + 2];
+#pragma unroll
+        for (int j = 0; j < PTS; ++j) td[j] = ogc_min_f32(ogc_sqdist(px[j], py[j], pz[j], sx, sy, sz), td[j]);
+    }
+    for (int r = 1 + t; r < L; r += THREADS) out[r] = r;
+    float x1 = dataset[(L - 1) * 3], y1 = dataset[(L - 1) * 3 + 1], z1 = dataset[(L - 1) * 3 + 2];
+    // ---- bucket records: lane s < BPW holds the record of the wave's bucket s: box, largest minimum, the rank of the
+    // point that has it, and whether a second point of the bucket has it too
+    float blo[3] = {0.f, 0.f, 0.f}, bhi[3] = {0.f, 0.f, 0.f}, bmv = -1.0f;
+    unsigned bmr = 0xFFFFFFFFu;
+    int btie = 0;
+    auto reduce_bucket = [&](int s, float t0, float t1, unsigned r0, unsigned r1) {
+        const float tm = fmaxf(t0, t1);
+        const float wm = fps_wave_max(tm);
+        const bool h0 = t0 == wm, h1 = t1 == wm;
+        const unsigned cand = min(h0 ? r0 : 0xFFFFFFFFu, h1 ? r1 : 0xFFFFFFFFu);
+        // the usual case — one lane holds the maximum — needs one readlane instead of a second wave reduction
+        const unsigned long long holders = __builtin_amdgcn_ballot_w64(h0 || h1);
+        unsigned wr;
+        if (__popcll(holders) == 1) wr = (unsigned)__builtin_amdgcn_readlane((int)cand, (int)__builtin_ctzll(holders));
+        else wr = ogc_wave_min_u32(cand);
+        int tie = 0;
+        if (track) tie = __popcll(holders) > 1 || __builtin_amdgcn_ballot_w64(h0 && h1) != 0;
+        if (lane == s) { bmv = wm; bmr = wr; btie = tie; }
+    };
+#pragma unroll
+    for (int s = 0; s < BPW; ++s) {
+        const bool r0 = rk[2 * s] != 0xFFFFFFFFu, r1 = rk[2 * s + 1] != 0xFFFFFFFFu;
+        const float c0[3] = {px[2 * s], py[2 * s], pz[2 * s]}, c1[3] = {px[2 * s + 1], py[2 * s + 1], pz[2 * s + 1]};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            float mn = fminf(r0 ? c0[a] : INFINITY, r1 ? c1[a] : INFINITY);
+            float mx = fmaxf(r0 ? c0[a] : -INFINITY, r1 ? c1[a] : -INFINITY);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                mn = fminf(mn, __shfl_xor(mn, off, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+            }
+            if (lane == s) { blo[a] = mn; bhi[a] = mx; }
+        }
+        reduce_bucket(s, td[2 * s], td[2 * s + 1], rk[2 * s], rk[2 * s + 1]);
+    }
+    __syncthreads();
+
+    for (int r = L; r < m; ++r) {
+        const int par = r & 1;
+        // (1) which of the wave's buckets can the new sample reach?  The box distance, rounded like a point distance.
+        unsigned reach;
+        {
+#pragma clang fp contract(off)
+            float dx = fmaxf(fmaxf(blo[0] - x1, x1 - bhi[0]), 0.0f);
+            float dy = fmaxf(fmaxf(blo[1] - y1, y1 - bhi[1]), 0.0f);
+            float dz = fmaxf(fmaxf(blo[2] - z1, z1 - bhi[2]), 0.0f);
+            dx = dx * dx;
+            dy = dy * dy;
+            dz = dz * dz;
+            const float d2 = (dx + dy) + dz;
+            reach = (unsigned)__builtin_amdgcn_ballot_w64(lane < BPW && (always || d2 < bmv));
+        }
+        // (2) update and re-reduce those
+        if (reach != 0u) {
+            const ogc_v2f qx = {x1, x1}, qy = {y1, y1}, qz = {z1, z1};
+#pragma unroll
+            for (int s = 0; s < BPW; ++s) {
+                if ((reach >> s) & 1u) { // wave-uniform
+                    const ogc_v2f d = fps_sqdist2((ogc_v2f){px[2 * s], px[2 * s + 1]}, (ogc_v2f){py[2 * s], py[2 * s + 1]},
+                                                  (ogc_v2f){pz[2 * s], pz[2 * s + 1]}, qx, qy, qz);
+                    td[2 * s] = ogc_min_f32(d.x, td[2 * s]);
+                    td[2 * s + 1] = ogc_min_f32(d.y, td[2 * s + 1]);
+                    reduce_bucket(s, td[2 * s], td[2 * s + 1], rk[2 * s], rk[2 * s + 1]);
+                }
+            }
+        }
+        // (3) the wave's best bucket -> LDS maximum over the waves; key = (value bits, ~rank)
+        const float mine = lane < BPW ? bmv : -1.0f;
+        const float wmax = fps_wave_max(mine);
+        const bool holds = lane < BPW && bmv == wmax;
+        const unsigned long long holders = __builtin_amdgcn_ballot_w64(holds);
+        unsigned wrho;
+        if (__popcll(holders) == 1) wrho = (unsigned)__builtin_amdgcn_readlane((int)bmr, (int)__builtin_ctzll(holders));
+        else wrho = ogc_wave_min_u32(holds ? bmr : 0xFFFFFFFFu);
+        if (lane == 0) atomicMax(&best_word[par], ((u64)__float_as_uint(wmax) << 32) | (u64)(0xFFFFFFFFu - wrho));
+        if (t == 0) best_word[par ^ 1] = 0ull;
+        __syncthreads();
+        const u64 best = best_word[par];
+        const unsigned brho = 0xFFFFFFFFu - (unsigned)best;
+        x1 = lx[brho]; y1 = ly[brho]; z1 = lz[brho];
+        if (t == 0) out[r] = (int)brho;
+        if (track) { // did a second point attain this round's maximum?  Another bucket with it, or the winner's bucket twice
+            const bool eq = lane < BPW && __float_as_uint(bmv) == (unsigned)(best >> 32);
+            const bool tie = eq && (bmr != brho || btie != 0);
+            if (__builtin_amdgcn_ballot_w64(tie) != 0 && first_tie > r) first_tie = r;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < PTS; ++j) {
+        if (rk[j] != 0xFFFFFFFFu) tmp[fps_rank_to_k(rk[j], S, bs_shift)] = td[j];
+    }
+    __syncthreads();
+    for (int r = L + t; r < m; r += THREADS) out[r] = fps_rank_to_k((unsigned)out[r], S, bs_shift);
+    if (track) {
+        if (t == 0) best_word[0] = ~0ull;
+        __syncthreads();
+        if (lane == 0) atomicMin(&best_word[0], (u64)(unsigned)first_tie);
+        __syncthreads();
+        if (t == 0) ties_out[b] = (int)(unsigned)best_word[0];
+    }
+}
+
 // Large-N fallback (N > 16384): same rounds, but xyz/temp stay in global memory (L2-resident).
 __global__ __launch_bounds__(1024) void fps_mem_kernel(int n, int m, int bs_shift,
                                                        const float *__restrict__ xyz,
@@ -452,7 +745,24 @@ static int fps_impl(const char *name, int b, int n, int m, const float *xyz, flo
     else if (slots <= 1024) fps_launch<4, 256>(b, n, m, shift, xyz, temp, idx, ties_in, ties_out, s);
     else if (slots <= 2048) fps_launch<8, 256>(b, n, m, shift, xyz, temp, idx, ties_in, ties_out, s);
     else if (slots <= 4096) fps_launch<8, 512>(b, n, m, shift, xyz, temp, idx, ties_in, ties_out, s);
-    else if (slots <= 8192) fps_launch<16, 512>(b, n, m, shift, xyz, temp, idx, ties_in, ties_out, s);
+    else if (slots <= 8192) {
+        // bucketed rounds (fps_bucket_kernel) pay from a few hundred samples on; OGC_FPS_BUCKETS=0: the plain rounds
+        static const char *bk = getenv("OGC_FPS_BUCKETS");
+        const int mode = bk ? atoi(bk) : 8;
+        const size_t lds = (4 + 64 + 3 * FPSB_SLOTS) * sizeof(float);
+        if (mode > 0 && m >= 256) {
+            if (mode == 8) {
+                static bool once8 = false;
+                if (!once8) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fps_bucket_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once8 = true; }
+                hipLaunchKernelGGL(fps_bucket_kernel<8>, dim3(b), dim3(512), lds, s, n, m, shift, xyz, temp, idx, ties_in, ties_out);
+            } else {
+                static bool once4 = false;
+                if (!once4) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fps_bucket_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once4 = true; }
+                hipLaunchKernelGGL(fps_bucket_kernel<4>, dim3(b), dim3(256), lds, s, n, m, shift, xyz, temp, idx, ties_in, ties_out);
+            }
+        } else
+            fps_launch<16, 512>(b, n, m, shift, xyz, temp, idx, ties_in, ties_out, s);
+    }
     else if (slots <= 16384) fps_launch<32, 512>(b, n, m, shift, xyz, temp, idx, ties_in, ties_out, s);
     else {
         // (these kernels do not track ties: a chain through them never takes the shortcut afterwards)
