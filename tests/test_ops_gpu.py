@@ -238,6 +238,45 @@ def test_fps_bit_exact(nat, oracle, N, m):
     assert np.array_equal(temp, temp_ref)
 
 
+def _bucket_range_cloud(kind, rng, N):
+    """Clouds for the bucketed rounds (4097 .. 8192 points, fps_bucket_kernel): every shape the spatial partition could
+    stumble over — the answer must not depend on the partition at all."""
+    if kind == "blobs":       # a few dense clusters far apart: most buckets are never reached
+        c = rng.normal(0, 40, (12, 3)).astype(np.float32)
+        pc = (c[rng.integers(0, 12, N)] + rng.normal(0, 0.5, (N, 3))).astype(np.float32)
+    elif kind == "line":      # two axes have no extent: all key bits go to one axis
+        pc = np.zeros((N, 3), np.float32)
+        pc[:, 2] = rng.random(N, dtype=np.float32) * 100
+    elif kind == "plane":
+        pc = (rng.random((N, 3), dtype=np.float32) * np.array([50, 0, 50], np.float32)).astype(np.float32)
+    elif kind == "lattice":   # masses of exact ties
+        pc = np.round(rng.random((N, 3), dtype=np.float32) * np.array([12, 3, 12], np.float32)).astype(np.float32)
+    elif kind == "far":       # large offsets: few significant bits left for the distances
+        pc = (rng.random((N, 3), dtype=np.float32) * 30 + np.array([1e5, -3e4, 7e4], np.float32)).astype(np.float32)
+    elif kind == "identical":
+        pc = np.full((N, 3), 2.5, np.float32)
+    else:                     # "nonfinite": no usable boxes, every bucket is updated every round
+        pc = (rng.random((N, 3), dtype=np.float32) * 40).astype(np.float32)
+        bad = rng.integers(1, N, 9)
+        pc[bad[:3], 0] = np.nan
+        pc[bad[3:6], 1] = np.inf
+        pc[bad[6:], 2] = -np.inf
+    return pc[None]
+
+
+@pytest.mark.parametrize("kind", ["blobs", "line", "plane", "lattice", "far", "identical", "nonfinite"])
+@pytest.mark.parametrize("N,m", [(4097, 256), (5000, 1200), (6151, 3000), (8192, 4096), (8192, 8192)])
+def test_fps_bucketed_rounds_bit_exact(nat, oracle, kind, N, m):
+    if kind in ("lattice", "identical") and m > 3000:
+        m = 3000  # (tie-heavy rounds are slow in the scalar oracle)
+    rng = np.random.default_rng(N + m + len(kind))
+    xyz = _bucket_range_cloud(kind, rng, N)
+    got, temp = run_fps(nat, xyz, m)
+    ref, temp_ref = oracle.fps(xyz, m, return_temp=True)
+    assert np.array_equal(got, ref)
+    assert np.array_equal(temp, temp_ref, equal_nan=True)
+
+
 @pytest.mark.parametrize("shape", [(8, 8, 4), (16, 16, 8), (20, 10, 7)])
 def test_fps_lattice_ties(nat, oracle, shape):
     g = np.stack(np.meshgrid(*[np.arange(s) for s in shape], indexing="ij"), -1).reshape(1, -1, 3).astype(np.float32)
