@@ -191,6 +191,23 @@ int ogc_group_linear_fwd(int b, int m, int n, int npoints, int nsample, int grou
 int ogc_group_linear_bwd(int b, int m, int n, int npoints, int nsample, const float *grad_y, const int *idx,
                          const float *rel, float *grad_p, float *dwx, ogc_stream_t stream);
 
+/* The grouping gradient as a gather (round 2): grad_points[b,c,j] = sum of grad_out[b,c,t] over the positions t = p * nsample + s
+ * with idx[b,p,s] == j — group_points_gpu.cu:8-25 / ogc_group_points_grad without atomics, every output written once (the
+ * caller need not zero grad_points).  The transposed lists depend on idx only: ogc_group_reverse builds them once per
+ * neighbour tensor (all channels, every step that reuses the tensor): the positions are cut into chunks of
+ * tc = ogc_group_reverse_chunk(n, npoints, nsample); rev_start (b, chunks, n + 1) i32 delimits, per chunk and point, the
+ * entries in rev_pos (b, npoints * nsample) u16 (positions relative to their chunk; the lists of chunk ch start at ch * tc;
+ * order inside a list unspecified).  Inside every aligned group of 16 positions a run of equal indices (clamped / padded rows) is
+ * listed once, by its first position; heads (b, npoints * nsample / 16) u16 has one bit per position, set for run heads — the
+ * gradient kernel folds a run into its head while it stages the values.  Indices outside [0, n) are ignored.  n <= 16384,
+ * npoints * nsample a multiple of 16. */
+int ogc_group_reverse_chunk(int n, int npoints, int nsample);
+int ogc_group_reverse(int b, int n, int npoints, int nsample, const int *idx, int *rev_start, unsigned short *rev_pos,
+                      unsigned short *heads, ogc_stream_t stream);
+int ogc_group_points_grad_rev(int b, int c, int n, int npoints, int nsample, const float *grad_out, const int *rev_start,
+                              const unsigned short *rev_pos, const unsigned short *heads, float *grad_points,
+                              ogc_stream_t stream);
+
 /* Dynamic (rigid-motion) term of the OGC loss, fused.  Replaces DynamicLoss.forward + fit_motion_svd_batch
  *   losses/seg_loss_unsup.py:64-98, :10-61 (K-fold expanded clouds, einsums, ~65 launches per step).
  * ogc_rigid_moments: per (cloud, slot) the weighted moments of p = pc and q = pc2 with weights mask[:, slot], accumulated

@@ -460,3 +460,232 @@ extern "C" int ogc_group_concat_grad(int b, int c, int n, int npoints, int nsamp
     return group_bwd("ogc_group_concat_grad", b, c, n, T, grad_out + 3 * (size_t)T, idx, grad_points, stream,
                      (long long)(3 + c) * T);
 }
+
+// ---- the grouping gradient as a GATHER over transposed neighbour lists ------------------------------------------------------
+// grad_points[b, c, j] = sum over the positions t with idx[b, t] == j of grad_out[b, c, t].  The scatter form above is bound
+// by LDS float atomics (ds_add_f32: ~0.4 lane-atomics per cycle and CU, measured: 0.50 ms for a tensor the loads alone
+// stream in 0.09 ms).  The lists "which positions point at j" depend on coordinates only, so they are built once per
+// neighbour tensor (ogc_group_reverse, part of a step's geometry plan) and shared by all channels: the positions are cut into
+// chunks of tc (one chunk of one channel plane = tc floats fits LDS), rev_start[b][chunk * n + j] .. [chunk * n + j + 1]
+// delimits the entries of point j inside chunk `chunk`, rev_pos holds the positions relative to their chunk (16 bits).
+// The gradient kernel gives a workgroup one (b, c) plane: chunk by chunk it stages the plane in LDS with coalesced loads
+// (the next chunk's loads are in flight meanwhile) and every thread adds up the entries of ITS points — registers, no atomics,
+// one writer per output (the caller need not zero grad_points).
+namespace {
+
+constexpr int GR_THREADS = 512;
+
+// One workgroup per (sample, chunk): the chunk's tc positions are counted into an LDS histogram over the n points (integer LDS
+// atomics), the histogram is scanned in place, and the positions are dealt to their lists through LDS cursors — no global
+// atomics, one launch.  The lists of chunk `ch` occupy rev_pos[ch * tc ...); rev_start has n + 1 entries per chunk.
+constexpr int GRB_THREADS = 1024;
+
+// Runs: neighbour rows end in long runs of ONE index (kNN rows clamped to the nearest neighbour beyond the radius, ball-query
+// rows padded with the first hit) — the lists of those points would be tens of entries long per row and a few threads would
+// walk them while their wavefronts wait.  Inside every aligned group of 16 positions a run of equal indices is represented by
+// its FIRST position only (`heads`: one bit per position, set for run heads); the gradient kernel adds the run up into that
+// position while it stages the values.  T must be a multiple of 16.
+__global__ __launch_bounds__(GRB_THREADS) void group_reverse_kernel(int n, int T, int tc, const int *__restrict__ idx,
+                                                                    int *__restrict__ rev_start,
+                                                                    unsigned short *__restrict__ rev_pos,
+                                                                    unsigned short *__restrict__ heads) {
+    extern __shared__ int grb_hist[]; // [n] counts, then cursors
+    __shared__ int wsum[GRB_THREADS / 64];
+    __shared__ int carry;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int chunk = blockIdx.x, b = blockIdx.y, chunks = gridDim.x;
+    const int t0 = chunk * tc, t1 = min(T, t0 + tc);
+    const int *id = idx + (size_t)b * T;
+    for (int j = t; j < n; j += GRB_THREADS) grb_hist[j] = 0;
+    if (t == 0) carry = t0;
+    __syncthreads();
+    for (int p0 = t0; p0 < t1; p0 += GRB_THREADS) { // (t0, tc, T multiples of 16 and GRB_THREADS of 64: lane = p % 64)
+        const int p = p0 + t;
+        int j = -1;
+        bool head = false;
+        if (p < t1) {
+            j = id[p];
+            head = (p & 15) == 0 || id[p - 1] != j;
+        }
+        const unsigned long long hm = __builtin_amdgcn_ballot_w64(head);
+        if (p < t1 && (lane & 15) == 0) heads[((size_t)b * T + p) >> 4] = (unsigned short)(hm >> lane);
+        if (head && j >= 0 && j < n) atomicAdd(&grb_hist[j], 1);
+    }
+    __syncthreads();
+    int *rs = rev_start + ((size_t)b * chunks + chunk) * (n + 1);
+    for (int base = 0; base < n; base += GRB_THREADS * 4) { // exclusive scan, four bins per thread and round
+        const int e = base + t * 4;
+        int v[4], sum = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { v[u] = e + u < n ? grb_hist[e + u] : 0; sum += v[u]; }
+        int incl = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int up = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += up;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int pre = carry + incl - sum;
+        for (int w = 0; w < wave; ++w) pre += wsum[w];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (e + u < n) { rs[e + u] = pre; grb_hist[e + u] = pre; }
+            pre += v[u];
+        }
+        __syncthreads();
+        if (t == GRB_THREADS - 1) carry = pre;
+        __syncthreads();
+    }
+    if (t == 0) rs[n] = carry;
+    unsigned short *rp = rev_pos + (size_t)b * T;
+    for (int p = t0 + t; p < t1; p += GRB_THREADS) {
+        const int j = id[p];
+        const bool head = (p & 15) == 0 || id[p - 1] != j;
+        if (head && j >= 0 && j < n) rp[atomicAdd(&grb_hist[j], 1)] = (unsigned short)(p - t0);
+    }
+}
+
+// NA: points per thread (n <= NA * GR_THREADS).  Per chunk the workgroup stages tc gradient values — a thread brings one
+// aligned group of 16 positions and folds every run of equal indices into its first position (`heads`) — AND the chunk's
+// list entries (they are contiguous: the lists of chunk ch start at rev_pos[ch * tc]) in LDS with coalesced loads: walking
+// the lists out of global memory costs an L2 round trip per list step.  tc = 16 * GR_THREADS.
+template <int NA>
+__global__ __launch_bounds__(GR_THREADS) void group_bwd_rev_kernel(int c, int n, int T, int tc, long long go_bstride,
+                                                                   const float *__restrict__ grad_out,
+                                                                   const int *__restrict__ rev_start,
+                                                                   const unsigned short *__restrict__ rev_pos,
+                                                                   const unsigned short *__restrict__ heads,
+                                                                   float *__restrict__ grad_points) {
+    extern __shared__ __attribute__((aligned(16))) float gr_plane[]; // [tc] gradient values, then [tc] 16-bit positions
+    unsigned short *gr_pos = reinterpret_cast<unsigned short *>(gr_plane + tc);
+    const int t = threadIdx.x, ch = blockIdx.x, b = blockIdx.y;
+    const int chunks = (T + tc - 1) / tc;
+    const float *g = grad_out + (size_t)b * go_bstride + (size_t)ch * T;
+    const int *rs = rev_start + (size_t)b * chunks * (n + 1);
+    const unsigned short *rp = rev_pos + (size_t)b * T;
+    const unsigned short *hd = heads + ((size_t)b * T >> 4);
+    float4 pre[4];
+    uint4 prp[2]; // sixteen 16-bit list entries
+    unsigned hmask = 0xFFFFu;
+    auto fetch = [&](int chunk) {
+        const int p = t * 16, tt = chunk * tc + p;
+        const bool in = p < tc && tt < T;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) pre[u] = in ? *reinterpret_cast<const float4 *>(g + tt + 4 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) prp[u] = in ? *reinterpret_cast<const uint4 *>(rp + tt + 8 * u) : make_uint4(0u, 0u, 0u, 0u);
+        hmask = in ? hd[tt >> 4] : 0xFFFFu;
+    };
+    float acc[NA];
+#pragma unroll
+    for (int k = 0; k < NA; ++k) acc[k] = 0.0f;
+    fetch(0);
+    for (int chunk = 0; chunk < chunks; ++chunk) {
+        {
+            float v[16] = {pre[0].x, pre[0].y, pre[0].z, pre[0].w, pre[1].x, pre[1].y, pre[1].z, pre[1].w,
+                           pre[2].x, pre[2].y, pre[2].z, pre[2].w, pre[3].x, pre[3].y, pre[3].z, pre[3].w};
+#pragma unroll
+            for (int u = 15; u >= 1; --u) v[u - 1] += ((hmask >> u) & 1u) ? 0.0f : v[u]; // a run accumulates into its head
+            const int p = t * 16;
+            if (p < tc) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    *reinterpret_cast<float4 *>(gr_plane + p + 4 * u) = make_float4(v[4 * u], v[4 * u + 1], v[4 * u + 2], v[4 * u + 3]);
+                *reinterpret_cast<uint4 *>(gr_pos + p) = prp[0];
+                *reinterpret_cast<uint4 *>(gr_pos + p + 8) = prp[1];
+            }
+        }
+        __syncthreads();
+        if (chunk + 1 < chunks) fetch(chunk + 1); // in flight while the lists of this chunk are walked
+        const int base = chunk * tc;
+        int cur[NA], end[NA], longest = 0;
+#pragma unroll
+        for (int k = 0; k < NA; ++k) {
+            const int j = t + k * GR_THREADS;
+            cur[k] = end[k] = 0;
+            if (j < n) {
+                cur[k] = rs[(size_t)chunk * (n + 1) + j] - base;
+                end[k] = rs[(size_t)chunk * (n + 1) + j + 1] - base;
+            }
+            longest = max(longest, end[k] - cur[k]);
+        }
+        for (int step = 0; step < longest; ++step) { // the NA lists of a thread advance together: NA independent reads
+            float v[NA];
+#pragma unroll
+            for (int k = 0; k < NA; ++k) v[k] = cur[k] + step < end[k] ? gr_plane[gr_pos[cur[k] + step]] : 0.0f;
+#pragma unroll
+            for (int k = 0; k < NA; ++k) acc[k] += v[k];
+        }
+        __syncthreads();
+    }
+    float *gp = grad_points + ((size_t)b * c + ch) * n;
+#pragma unroll
+    for (int k = 0; k < NA; ++k) {
+        const int j = t + k * GR_THREADS;
+        if (j < n) gp[j] = acc[k];
+    }
+}
+
+} // namespace
+
+extern "C" int ogc_group_reverse_chunk(int n, int npoints, int nsample) {
+    // positions per chunk: 512 threads x one group of 16 positions (32 KiB of values + 16 KiB of list entries in LDS: three
+    // workgroups per CU)
+    if (n < 1 || (long long)npoints * nsample < 1) return 0;
+    return 8192;
+}
+
+extern "C" int ogc_group_reverse(int b, int n, int npoints, int nsample, const int *idx, int *rev_start,
+                                 unsigned short *rev_pos, unsigned short *heads, ogc_stream_t stream) {
+    OGC_REQUIRE(b >= 0 && n >= 1 && npoints >= 0 && nsample >= 0 && (long long)npoints * nsample < (1ll << 31),
+                "ogc_group_reverse: bad dimensions");
+    const int T = npoints * nsample;
+    if (b == 0 || T == 0) return OGC_OK;
+    OGC_REQUIRE(idx && rev_start && rev_pos && heads, "ogc_group_reverse: null pointer");
+    if (n > 16384 || b > 65535 || T % 16 != 0) {
+        ogc_set_error("ogc_group_reverse: n <= 16384 (an LDS histogram over the points), b <= 65535, positions %% 16 == 0");
+        return OGC_ERR_UNSUPPORTED;
+    }
+    const int tc = ogc_group_reverse_chunk(n, npoints, nsample);
+    const int chunks = (T + tc - 1) / tc;
+    hipLaunchKernelGGL(group_reverse_kernel, dim3(chunks, b), dim3(GRB_THREADS), (size_t)n * sizeof(int),
+                       (hipStream_t)stream, n, T, tc, idx, rev_start, rev_pos, heads);
+    OGC_CHECK_LAUNCH("ogc_group_reverse");
+    return OGC_OK;
+}
+
+extern "C" int ogc_group_points_grad_rev(int b, int c, int n, int npoints, int nsample, const float *grad_out,
+                                         const int *rev_start, const unsigned short *rev_pos,
+                                         const unsigned short *heads, float *grad_points, ogc_stream_t stream) {
+    OGC_REQUIRE(b >= 0 && c >= 0 && n >= 1 && npoints >= 0 && nsample >= 0 && (long long)npoints * nsample < (1ll << 31),
+                "ogc_group_points_grad_rev: bad dimensions");
+    const int T = npoints * nsample;
+    if (b == 0 || c == 0) return OGC_OK;
+    OGC_REQUIRE(grad_out && rev_start && rev_pos && heads && grad_points, "ogc_group_points_grad_rev: null pointer");
+    if (T % 16 != 0 || !aligned16(grad_out) || !aligned16(rev_pos) || n > 32 * GR_THREADS || b > 65535) {
+        ogc_set_error("ogc_group_points_grad_rev: needs npoints * nsample %% 16 == 0, 16-byte aligned tensors and n <= 16384");
+        return OGC_ERR_UNSUPPORTED;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (T == 0) {
+        if (hipMemsetAsync(grad_points, 0, sizeof(float) * (size_t)b * c * n, s) != hipSuccess) return OGC_ERR_LAUNCH;
+        return OGC_OK;
+    }
+    const int tc = ogc_group_reverse_chunk(n, npoints, nsample);
+    const size_t lds = (size_t)tc * (sizeof(float) + sizeof(unsigned short));
+    const long long go_bstride = (long long)c * T;
+    dim3 grid(c, b);
+#define GR_LAUNCH(NAV)                                                                                                  \
+    hipLaunchKernelGGL((group_bwd_rev_kernel<NAV>), grid, dim3(GR_THREADS), lds, s, c, n, T, tc, go_bstride, grad_out, \
+                       rev_start, rev_pos, heads, grad_points)
+    if (n <= GR_THREADS) GR_LAUNCH(1);
+    else if (n <= 2 * GR_THREADS) GR_LAUNCH(2);
+    else if (n <= 4 * GR_THREADS) GR_LAUNCH(4);
+    else if (n <= 8 * GR_THREADS) GR_LAUNCH(8);
+    else if (n <= 16 * GR_THREADS) GR_LAUNCH(16);
+    else GR_LAUNCH(32);
+#undef GR_LAUNCH
+    OGC_CHECK_LAUNCH("ogc_group_points_grad_rev");
+    return OGC_OK;
+}

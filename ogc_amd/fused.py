@@ -283,6 +283,25 @@ def reverse_neighbours(idx):
     return rev_start, rev_src, rev_mult
 
 
+def group_reverse(idx, n):
+    """Transposed lists of a grouping tensor idx (B, npoint, nsample) int32 into n source points, for the gather form of
+    the grouping gradient (ogc_group_reverse): (rev_start, rev_pos).  Coordinates only — part of a step's geometry plan.
+    None where the kernels do not apply."""
+    nat = _api._native
+    if (getattr(nat, "group_reverse_wrapper", None) is None or not idx.is_cuda or idx.dtype != torch.int32
+            or n > 16384 or (idx.shape[1] * idx.shape[2]) % 16 != 0 or idx.shape[1] * idx.shape[2] == 0):
+        return None
+    idx = idx.contiguous()
+    B, npoint, nsample = idx.shape
+    T = npoint * nsample
+    tc = nat.group_reverse_chunk(n, npoint, nsample)
+    rev_start = torch.empty(B, (T + tc - 1) // tc, n + 1, dtype=torch.int32, device=idx.device)
+    rev_pos = torch.empty(B, T, dtype=torch.int16, device=idx.device)
+    heads = torch.empty(B, T // 16, dtype=torch.int16, device=idx.device)
+    nat.group_reverse_wrapper(B, n, npoint, nsample, idx, rev_start, rev_pos, heads)
+    return rev_start, rev_pos, heads
+
+
 def neighbour_consistency_available(mask, loss_norm, cross_entropy):
     return (mask.is_cuda and mask.dtype == torch.float32 and not cross_entropy and loss_norm in (1, 2)
             and mask.shape[-1] <= 40 and getattr(_api._native, "neighbour_consistency_fwd_wrapper", None) is not None)
@@ -961,9 +980,10 @@ class _GroupedFirstLayer(Function):
     d features and d W_f; d W_xyz is a weight gradient with three input channels."""
 
     @staticmethod
-    def forward(ctx, xyz, new_xyz, features, idx, weight, gn_groups):
+    def forward(ctx, xyz, new_xyz, features, idx, weight, gn_groups, rev_start=None, rev_pos=None, rev_heads=None):
         nat = _api._native
         ctx.set_materialize_grads(False)
+        ctx.rev = (rev_start, rev_pos, rev_heads) if rev_start is not None else None
         B, C, N = features.shape
         npoint, nsample = idx.shape[1], idx.shape[2]
         M = weight.shape[0]
@@ -985,7 +1005,7 @@ class _GroupedFirstLayer(Function):
     @staticmethod
     def backward(ctx, grad_y, _grad_stats=None):
         if grad_y is None:
-            return (None,) * 6
+            return (None,) * 9
         nat = _api._native
         features, idx, rel, weight = ctx.saved_tensors
         B, C, N = features.shape
@@ -994,15 +1014,24 @@ class _GroupedFirstLayer(Function):
         grad_y = grad_y.contiguous()
         wf = weight.detach().reshape(M, 3 + C)[:, 3:]
         T = npoint * nsample
-        one_pass = ctx.needs_input_grad[4] and N <= 16384 and T >= 4096 and T % 16 == 0
-        # dP and the three xyz columns of the weight gradient share one pass over grad_y where the scatter kernel's
-        # LDS path applies; otherwise the scatter-add and a three-channel weight gradient
-        zeroed = torch.zeros(B * M * N + M * 3, dtype=torch.float32, device=grad_y.device)
-        dP, dwx = zeroed[:B * M * N].view(B, M, N), zeroed[B * M * N:].view(M, 3)
-        if one_pass:
-            nat.group_linear_bwd_wrapper(B, M, N, npoint, nsample, grad_y, idx, rel, dP, dwx)
+        # the gather wins where lists are long and planes many (C4: SA2, SA3: 0.50 -> 0.13 ms, 0.33 -> 0.07); with ~16 entries
+        # per point (SA1: 8192 points) the per-chunk list headers cost as much as the data and the atomic kernel stays
+        gather = ctx.rev is not None and GROUP_GRAD_GATHER and T >= GROUP_GRAD_GATHER_MIN_FANIN * N and B * M >= 256
+        one_pass = not gather and ctx.needs_input_grad[4] and N <= 16384 and T >= 4096 and T % 16 == 0
+        if gather:
+            # dP as a gather over the transposed neighbour lists of the geometry plan: no atomics, no zero fill; the three
+            # xyz columns of the weight gradient are a three-channel weight gradient (second read of grad_y, one of rel)
+            dP = torch.empty(B, M, N, dtype=torch.float32, device=grad_y.device)
+            nat.group_points_grad_rev_wrapper(B, M, N, npoint, nsample, grad_y, ctx.rev[0], ctx.rev[1], ctx.rev[2], dP)
         else:
-            nat.group_points_grad_wrapper(B, M, N, npoint, nsample, grad_y, idx, dP)
+            # dP and the three xyz columns of the weight gradient share one pass over grad_y where the scatter kernel's
+            # LDS path applies; otherwise the scatter-add and a three-channel weight gradient
+            zeroed = torch.zeros(B * M * N + M * 3, dtype=torch.float32, device=grad_y.device)
+            dP, dwx = zeroed[:B * M * N].view(B, M, N), zeroed[B * M * N:].view(M, 3)
+            if one_pass:
+                nat.group_linear_bwd_wrapper(B, M, N, npoint, nsample, grad_y, idx, rel, dP, dwx)
+            else:
+                nat.group_points_grad_wrapper(B, M, N, npoint, nsample, grad_y, idx, dP)
         grad_feat = torch.matmul(wf.t(), dP) if ctx.needs_input_grad[2] else None
         grad_w = None
         if ctx.needs_input_grad[4]:
@@ -1011,7 +1040,7 @@ class _GroupedFirstLayer(Function):
                 nat.conv1x1_wgrad_wrapper(B, 3, M, T, rel, grad_y, dwx)
             dwf = torch.bmm(dP, features.detach().transpose(1, 2)).sum(0)
             grad_w = torch.cat([dwx, dwf], 1).view_as(weight)
-        return None, None, grad_feat, None, grad_w, None
+        return None, None, grad_feat, None, grad_w, None, None, None, None
 
 
 def grouped_first_layer_available(xyz, new_xyz, features, idx, conv, gn):
@@ -1023,7 +1052,12 @@ def grouped_first_layer_available(xyz, new_xyz, features, idx, conv, gn):
             and (gn is None or (gn.num_groups <= 32 and conv.weight.shape[0] % gn.num_groups == 0)))
 
 
-def grouped_first_layer(xyz, new_xyz, features, idx, conv, gn):
-    """(conv(QueryAndGroup(...)), statistics for `gn`) — see _GroupedFirstLayer."""
+GROUP_GRAD_GATHER = True   # grouping gradient as a gather over transposed lists when the geometry plan has them
+GROUP_GRAD_GATHER_MIN_FANIN = 24
+
+
+def grouped_first_layer(xyz, new_xyz, features, idx, conv, gn, rev=None):
+    """(conv(QueryAndGroup(...)), statistics for `gn`) — see _GroupedFirstLayer.  rev: group_reverse(idx, N) or None."""
+    rev = rev if rev is not None else (None, None, None)
     return _GroupedFirstLayer.apply(xyz.contiguous(), new_xyz.contiguous(), features.contiguous(), idx.int().contiguous(),
-                                    conv.weight, 0 if gn is None else gn.num_groups)
+                                    conv.weight, 0 if gn is None else gn.num_groups, rev[0], rev[1], rev[2])

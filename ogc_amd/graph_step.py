@@ -133,6 +133,7 @@ class GraphedTrainStep:
         object): its geometry plan is computed here, eagerly."""
         s = self.stream
         s.wait_stream(torch.cuda.current_stream())
+        self.segnet.train()
         with torch.cuda.stream(s):
             fresh = PrefetchedGeometry(self.segnet, self.criterion, batch, self.aug)
             _resolve(fresh, wait=True)
@@ -142,6 +143,7 @@ class GraphedTrainStep:
 
     def step(self, next_batch):
         s = self.stream
+        self.segnet.train()
         s.wait_stream(torch.cuda.current_stream())  # whoever produced next_batch
         with torch.cuda.stream(s):
             # The geometry of the next batch: ~40 eager launches on the side streams, which wait for the point reached on

@@ -102,6 +102,27 @@ def group_points_grad_wrapper(b, c, n, npoints, nsample, grad_out, idx, grad_poi
     return 1
 
 
+def group_reverse_chunk(n, npoints, nsample):
+    """Positions per chunk of the transposed grouping lists (ogc_group_reverse_chunk)."""
+    return int(_lib.load().ogc_group_reverse_chunk(int(n), int(npoints), int(nsample)))
+
+
+def group_reverse_wrapper(b, n, npoints, nsample, idx, rev_start, rev_pos, heads):
+    """Transposed lists of a neighbour tensor idx (b, npoints, nsample) into n points (ogc_group_reverse): rev_start
+    (b, chunks, n + 1) int32, rev_pos (b, npoints * nsample) int16 storage (16-bit positions)."""
+    _run("ogc_group_reverse", idx, b, n, npoints, nsample, _i(idx, "idx"), _i(rev_start, "rev_start"),
+         _check(rev_pos, torch.int16, "rev_pos"), _check(heads, torch.int16, "heads"))
+    return 1
+
+
+def group_points_grad_rev_wrapper(b, c, n, npoints, nsample, grad_out, rev_start, rev_pos, heads, grad_points):
+    """grad_points (b, c, n) = gather-sum of grad_out (b, c, npoints, nsample) over the transposed lists; overwrites."""
+    _run("ogc_group_points_grad_rev", grad_out, b, c, n, npoints, nsample, _f(grad_out, "grad_out"),
+         _i(rev_start, "rev_start"), _check(rev_pos, torch.int16, "rev_pos"), _check(heads, torch.int16, "heads"),
+         _f(grad_points, "grad_points"))
+    return 1
+
+
 def gather_points_wrapper(b, c, n, npoints, points, idx, out):
     _run("ogc_gather_points", points, b, c, n, npoints, _f(points, "points"), _i(idx, "idx"), _f(out, "out"))
     return 1

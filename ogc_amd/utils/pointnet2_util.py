@@ -35,7 +35,18 @@ class _PointnetSAModuleBase(nn.Module):
             return None
         plan = self.plan_sampling(xyz, parent_ties)
         plan["idx"] = self.plan_neighbours(xyz, plan["new_xyz"])
+        plan["rev"] = self.plan_reverse(plan["idx"], xyz.shape[1])
         return plan
+
+    def plan_reverse(self, idx, n):
+        """Transposed neighbour lists (which (centre, slot) positions point at each source point) of every scale, for the
+        gather form of the grouping gradient; only where a gradient will be asked for."""
+        from .. import fused as _fused
+        group_reverse = _fused.group_reverse
+        if not torch.is_grad_enabled():  # (not self.training: a plan made ahead may precede the switch to train())
+            return [None] * len(idx)
+        want = lambda j: j is not None and j.is_cuda and j.shape[1] * j.shape[2] >= _fused.GROUP_GRAD_GATHER_MIN_FANIN * n
+        return [group_reverse(j.int().contiguous(), n) if want(j) else None for j in idx]
 
     def plan_sampling(self, xyz, parent_ties=None):
         """The sequential part: FPS indices and the sampled centres (:22-27).  parent_ties: `ties` of the plan whose
@@ -77,6 +88,8 @@ class _PointnetSAModuleBase(nn.Module):
             geometry = geometry.get()
         if geometry is not None and "idx" not in geometry:  # only the sampling was planned ahead
             geometry = dict(geometry, idx=self.plan_neighbours(xyz, geometry["new_xyz"]))
+        if geometry is not None and "rev" not in geometry:
+            geometry = dict(geometry, rev=self.plan_reverse(geometry["idx"], xyz.shape[1]))
         new_xyz = geometry["new_xyz"] if geometry is not None else None
         new_inds = geometry["new_inds"] if geometry is not None else None
 
@@ -88,8 +101,8 @@ class _PointnetSAModuleBase(nn.Module):
                 head = mlp.first_layer() if (grouper.use_xyz and xyz.is_cuda) else None
                 if head is not None and grouped_first_layer_available(xyz, new_xyz, features, nn_idx, head[0], head[1]):
                     # grouping + first convolution without the (B, 3 + C, npoint, nsample) tensor in between
-                    pooled.append(mlp.forward_maxpool(None, first=lambda conv, gn, j=nn_idx: grouped_first_layer(
-                        xyz, new_xyz, features, j, conv, gn)))
+                    pooled.append(mlp.forward_maxpool(None, first=lambda conv, gn, j=nn_idx, rv=geometry["rev"][i]:
+                                                      grouped_first_layer(xyz, new_xyz, features, j, conv, gn, rv)))
                     continue
                 grouped = grouper(xyz, new_xyz, features, idx=nn_idx)[0]
             else:

@@ -291,6 +291,47 @@ def test_fps_all_points_identical(nat, oracle):
     assert np.array_equal(got, oracle.fps(xyz, 40))
 
 
+@pytest.mark.parametrize("B,C,N,P,S", [(2, 5, 50, 11, 16), (2, 96, 2048, 1024, 64), (1, 3, 8192, 2048, 64), (3, 7, 100, 13, 16),
+                                       (2, 10, 8192, 8192, 32), (1, 4, 16384, 4096, 16), (2, 33, 1024, 512, 64)])
+def test_group_gradient_as_a_gather(nat, B, C, N, P, S):
+    """ogc_group_reverse + ogc_group_points_grad_rev (the grouping gradient without atomics) against a float64 scatter-add
+    and against the atomic kernel it replaces; neighbour rows with long runs of one index (clamped kNN rows) included."""
+    from ogc_amd import fused
+    rng = np.random.default_rng(B * 1000 + C)
+    idx = rng.integers(0, N, (B, P, S)).astype(np.int32)
+    idx[:, ::3, S // 2:] = idx[:, ::3, :1]           # padded / clamped rows
+    idx[0, 0, :] = N - 1
+    g = rng.standard_normal((B, C, P, S)).astype(np.float32)
+    want = np.zeros((B, C, N))
+    for b in range(B):
+        np.add.at(want[b].T, idx[b].reshape(-1), g[b].reshape(C, -1).T.astype(np.float64))
+    rev = fused.group_reverse(T(idx), N)
+    assert rev is not None
+    got = torch.full((B, C, N), 7.0, device=DEV)     # the kernel overwrites: no zero fill needed
+    nat.group_points_grad_rev_wrapper(B, C, N, P, S, T(g), rev[0], rev[1], rev[2], got)
+    scale = np.abs(want).max() + 1e-30
+    assert np.abs(got.cpu().numpy() - want).max() <= 2e-6 * scale
+    old = torch.zeros(B, C, N, device=DEV)
+    nat.group_points_grad_wrapper(B, C, N, P, S, T(g), T(idx), old)
+    assert np.abs(old.cpu().numpy() - got.cpu().numpy()).max() <= 4e-6 * scale
+    # every position appears exactly once in the lists
+    rs, rp = rev[0].cpu().numpy(), rev[1].cpu().numpy().view(np.uint16)
+    tc = nat.group_reverse_chunk(N, P, S)
+    flat = idx.reshape(B, -1)
+    head = np.ones_like(flat, bool)
+    head[:, 1:] = flat[:, 1:] != flat[:, :-1]
+    head[:, ::16] = True
+    hd = rev[2].cpu().numpy().view(np.uint16)
+    for b in range(B):
+        seen = []
+        for ch in range(rs.shape[1]):
+            assert rs[b, ch, 0] == ch * tc and (np.diff(rs[b, ch]) >= 0).all()
+            seen.append(ch * tc + rp[b, rs[b, ch, 0]:rs[b, ch, -1]].astype(np.int64))
+        assert np.array_equal(np.sort(np.concatenate(seen)), np.nonzero(head[b])[0])   # every run head exactly once
+        bits = (hd[b][:, None] >> np.arange(16)) & 1
+        assert np.array_equal(bits.reshape(-1).astype(bool), head[b])
+
+
 def test_gather_and_group_forward_exact(nat, oracle):
     rng = np.random.default_rng(3)
     for (B, C, N, P, S) in [(2, 5, 50, 11, 4), (2, 96, 2048, 1024, 64), (1, 3, 8192, 2048, 64), (3, 7, 100, 13, 3),

@@ -106,8 +106,15 @@ def main():
             byt = B * (4 * C * N + 4 * P * S + 4 * C * P * S)
             gp = torch.zeros(B, C, N, device=DEV)
             ms2 = timeit(lambda: nat.group_points_grad_wrapper(B, C, N, P, S, out, idx, gp), a.iters)
-            print("group B=%-3d C=%-4d N=%-5d P=%-5d S=%-3d fwd %8.3f ms %8.1f GB/s | bwd %8.3f ms %8.1f GB/s" %
-                  (B, C, N, P, S, ms, byt / ms / 1e6, ms2, byt / ms2 / 1e6))
+            from ogc_amd import fused
+            rev = fused.group_reverse(idx, N)
+            ms3 = ms4 = float("nan")
+            if rev is not None:
+                ms3 = timeit(lambda: fused.group_reverse(idx, N), a.iters)
+                ms4 = timeit(lambda: nat.group_points_grad_rev_wrapper(B, C, N, P, S, out, rev[0], rev[1], rev[2], gp), a.iters)
+            print("group B=%-3d C=%-4d N=%-5d P=%-5d S=%-3d fwd %8.3f ms %8.1f GB/s | bwd (atomics) %8.3f ms %8.1f GB/s | "
+                  "bwd (gather) %8.3f ms %8.1f GB/s + lists %6.3f ms once per neighbour tensor" %
+                  (B, C, N, P, S, ms, byt / ms / 1e6, ms2, byt / ms2 / 1e6, ms4, byt / ms4 / 1e6, ms3))
     if "interp" in ops:
         for (B, C, M, N) in [(16, 256, 512, 1024), (16, 128, 1024, 2048), (16, 64, 2048, 8192)]:
             feats = torch.randn(B, C, M, device=DEV)
