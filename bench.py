@@ -229,6 +229,9 @@ def main():
         sync()
         elapsed = time.perf_counter() - t0
     loss_dict, stepped = pending.result()
+    # train_step follows the reference in swallowing a RuntimeError of backward() (train_seg.py:75-78): a bench line for steps
+    # that did not run their backward pass and optimizer would be worthless, so it must not be printed
+    assert stepped and all(v == v for v in loss_dict.values()), "the timed steps did not step the optimizer: %r" % (loss_dict,)
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

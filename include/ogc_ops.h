@@ -208,6 +208,12 @@ int ogc_group_points_grad_rev(int b, int c, int n, int npoints, int nsample, con
                               const unsigned short *rev_pos, const unsigned short *heads, float *grad_points,
                               ogc_stream_t stream);
 
+/* The gradient of three_interpolate as the same gather: rev_* = ogc_group_reverse(b, m, n, 3, idx (b,n,3), ...) — position
+ * t = 3 i + k stands for grad_out[b,c,i] * weight[b,i,k].  grad_points (b,c,m) is overwritten.  3 n a multiple of 16. */
+int ogc_three_interpolate_grad_rev(int b, int c, int n, int m, const float *grad_out, const float *weight,
+                                   const int *rev_start, const unsigned short *rev_pos, const unsigned short *heads,
+                                   float *grad_points, ogc_stream_t stream);
+
 /* Dynamic (rigid-motion) term of the OGC loss, fused.  Replaces DynamicLoss.forward + fit_motion_svd_batch
  *   losses/seg_loss_unsup.py:64-98, :10-61 (K-fold expanded clouds, einsums, ~65 launches per step).
  * ogc_rigid_moments: per (cloud, slot) the weighted moments of p = pc and q = pc2 with weights mask[:, slot], accumulated

@@ -27,6 +27,7 @@ SIGNATURES = {
     "ogc_group_points_grad": [_int, _int, _int, _int, _int, _vp, _vp, _vp, _vp],
     "ogc_group_reverse_chunk": [_int, _int, _int],
     "ogc_group_reverse": [_int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp],
+    "ogc_three_interpolate_grad_rev": [_int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "ogc_group_points_grad_rev": [_int, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp],
     "ogc_ball_query": [_int, _int, _int, _flt, _int, _vp, _vp, _vp, _vp],
     "ogc_knn_clamped": [_int, _int, _int, _int, _flt, _vp, _vp, _vp, _vp, _vp],

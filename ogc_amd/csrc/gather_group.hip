@@ -550,18 +550,22 @@ __global__ __launch_bounds__(GRB_THREADS) void group_reverse_kernel(int n, int T
 // aligned group of 16 positions and folds every run of equal indices into its first position (`heads`) — AND the chunk's
 // list entries (they are contiguous: the lists of chunk ch start at rev_pos[ch * tc]) in LDS with coalesced loads: walking
 // the lists out of global memory costs an L2 round trip per list step.  tc = 16 * GR_THREADS.
-template <int NA>
+// INTERP: the gradient of three_interpolate — position t = 3 i + k stands for grad_out[b, c, i] * weight[b, i, k] (the plane
+// has T / 3 values, the products are formed while staging).
+template <int NA, bool INTERP>
 __global__ __launch_bounds__(GR_THREADS) void group_bwd_rev_kernel(int c, int n, int T, int tc, long long go_bstride,
                                                                    const float *__restrict__ grad_out,
                                                                    const int *__restrict__ rev_start,
                                                                    const unsigned short *__restrict__ rev_pos,
                                                                    const unsigned short *__restrict__ heads,
+                                                                   const float *__restrict__ weight,
                                                                    float *__restrict__ grad_points) {
     extern __shared__ __attribute__((aligned(16))) float gr_plane[]; // [tc] gradient values, then [tc] 16-bit positions
     unsigned short *gr_pos = reinterpret_cast<unsigned short *>(gr_plane + tc);
     const int t = threadIdx.x, ch = blockIdx.x, b = blockIdx.y;
     const int chunks = (T + tc - 1) / tc;
-    const float *g = grad_out + (size_t)b * go_bstride + (size_t)ch * T;
+    const float *g = grad_out + (size_t)b * go_bstride + (size_t)ch * (INTERP ? T / 3 : T);
+    const float *wt = INTERP ? weight + (size_t)b * T : nullptr;
     const int *rs = rev_start + (size_t)b * chunks * (n + 1);
     const unsigned short *rp = rev_pos + (size_t)b * T;
     const unsigned short *hd = heads + ((size_t)b * T >> 4);
@@ -572,7 +576,18 @@ __global__ __launch_bounds__(GR_THREADS) void group_bwd_rev_kernel(int c, int n,
         const int p = t * 16, tt = chunk * tc + p;
         const bool in = p < tc && tt < T;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) pre[u] = in ? *reinterpret_cast<const float4 *>(g + tt + 4 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int u = 0; u < 4; ++u) {
+            pre[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (in) {
+                if constexpr (INTERP) {
+                    const float4 w4 = *reinterpret_cast<const float4 *>(wt + tt + 4 * u);
+                    const int q = tt + 4 * u;
+                    pre[u] = make_float4(w4.x * g[q / 3], w4.y * g[(q + 1) / 3], w4.z * g[(q + 2) / 3], w4.w * g[(q + 3) / 3]);
+                } else {
+                    pre[u] = *reinterpret_cast<const float4 *>(g + tt + 4 * u);
+                }
+            }
+        }
 #pragma unroll
         for (int u = 0; u < 2; ++u) prp[u] = in ? *reinterpret_cast<const uint4 *>(rp + tt + 8 * u) : make_uint4(0u, 0u, 0u, 0u);
         hmask = in ? hd[tt >> 4] : 0xFFFFu;
@@ -676,9 +691,9 @@ extern "C" int ogc_group_points_grad_rev(int b, int c, int n, int npoints, int n
     const size_t lds = (size_t)tc * (sizeof(float) + sizeof(unsigned short));
     const long long go_bstride = (long long)c * T;
     dim3 grid(c, b);
-#define GR_LAUNCH(NAV)                                                                                                  \
-    hipLaunchKernelGGL((group_bwd_rev_kernel<NAV>), grid, dim3(GR_THREADS), lds, s, c, n, T, tc, go_bstride, grad_out, \
-                       rev_start, rev_pos, heads, grad_points)
+#define GR_LAUNCH(NAV)                                                                                                         \
+    hipLaunchKernelGGL((group_bwd_rev_kernel<NAV, false>), grid, dim3(GR_THREADS), lds, s, c, n, T, tc, go_bstride, grad_out, \
+                       rev_start, rev_pos, heads, nullptr, grad_points)
     if (n <= GR_THREADS) GR_LAUNCH(1);
     else if (n <= 2 * GR_THREADS) GR_LAUNCH(2);
     else if (n <= 4 * GR_THREADS) GR_LAUNCH(4);
@@ -687,5 +702,39 @@ extern "C" int ogc_group_points_grad_rev(int b, int c, int n, int npoints, int n
     else GR_LAUNCH(32);
 #undef GR_LAUNCH
     OGC_CHECK_LAUNCH("ogc_group_points_grad_rev");
+    return OGC_OK;
+}
+
+extern "C" int ogc_three_interpolate_grad_rev(int b, int c, int n, int m, const float *grad_out, const float *weight,
+                                              const int *rev_start, const unsigned short *rev_pos,
+                                              const unsigned short *heads, float *grad_points, ogc_stream_t stream) {
+    OGC_REQUIRE(b >= 0 && c >= 0 && n >= 0 && m >= 1 && (long long)n * 3 < (1ll << 31), "ogc_three_interpolate_grad_rev: bad dimensions");
+    if (b == 0 || c == 0) return OGC_OK;
+    OGC_REQUIRE(grad_out && weight && rev_start && rev_pos && heads && grad_points, "ogc_three_interpolate_grad_rev: null pointer");
+    const int T = 3 * n;
+    if (T % 16 != 0 || !aligned16(weight) || !aligned16(rev_pos) || m > 32 * GR_THREADS || b > 65535) {
+        ogc_set_error("ogc_three_interpolate_grad_rev: needs 3 n %% 16 == 0, 16-byte aligned tensors and m <= 16384");
+        return OGC_ERR_UNSUPPORTED;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (T == 0) {
+        if (hipMemsetAsync(grad_points, 0, sizeof(float) * (size_t)b * c * m, s) != hipSuccess) return OGC_ERR_LAUNCH;
+        return OGC_OK;
+    }
+    const int tc = ogc_group_reverse_chunk(m, n, 3);
+    const size_t lds = (size_t)tc * (sizeof(float) + sizeof(unsigned short));
+    const long long go_bstride = (long long)c * n;
+    dim3 grid(c, b);
+#define GR_LAUNCH(NAV)                                                                                                        \
+    hipLaunchKernelGGL((group_bwd_rev_kernel<NAV, true>), grid, dim3(GR_THREADS), lds, s, c, m, T, tc, go_bstride, grad_out, \
+                       rev_start, rev_pos, heads, weight, grad_points)
+    if (m <= GR_THREADS) GR_LAUNCH(1);
+    else if (m <= 2 * GR_THREADS) GR_LAUNCH(2);
+    else if (m <= 4 * GR_THREADS) GR_LAUNCH(4);
+    else if (m <= 8 * GR_THREADS) GR_LAUNCH(8);
+    else if (m <= 16 * GR_THREADS) GR_LAUNCH(16);
+    else GR_LAUNCH(32);
+#undef GR_LAUNCH
+    OGC_CHECK_LAUNCH("ogc_three_interpolate_grad_rev");
     return OGC_OK;
 }

@@ -173,14 +173,16 @@ class ThreeInterpolate(Function):
     """Reference: pointnet2.py:143-187 -> three_interpolate_wrapper / ..._grad_wrapper."""
 
     @staticmethod
-    def forward(ctx, features: torch.Tensor, idx: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+    def forward(ctx, features: torch.Tensor, idx: torch.Tensor, weight: torch.Tensor, rev=None) -> torch.Tensor:
         # features (B, C, M), idx (B, n, 3), weight (B, n, 3) -> (B, C, n)
+        # rev (optional, not in the reference): fused.group_reverse(idx, M) — the gradient becomes a gather
         assert features.is_contiguous()
         assert idx.is_contiguous()
         assert weight.is_contiguous()
         B, c, m = features.size()
         n = idx.size(1)
         ctx.three_interpolate_for_backward = (idx, weight, m)
+        ctx.rev = rev
         output = _new(features, (B, c, n), torch.float32)
         _native.three_interpolate_wrapper(B, c, m, n, features, idx, weight, output)
         return output
@@ -189,9 +191,15 @@ class ThreeInterpolate(Function):
     def backward(ctx, grad_out: torch.Tensor):
         idx, weight, m = ctx.three_interpolate_for_backward
         B, c, n = grad_out.size()
+        rev = getattr(ctx, "rev", None)
+        if rev is not None and getattr(_native, "three_interpolate_grad_rev_wrapper", None) is not None:
+            grad_features = _new(grad_out, (B, c, m), torch.float32)
+            _native.three_interpolate_grad_rev_wrapper(B, c, n, m, grad_out.contiguous(), weight, rev[0], rev[1], rev[2],
+                                                       grad_features)
+            return grad_features, None, None, None
         grad_features = _new(grad_out, (B, c, m), torch.float32, fill=0.0)
         _native.three_interpolate_grad_wrapper(B, c, n, m, grad_out.contiguous(), idx, weight, grad_features)
-        return grad_features, None, None
+        return grad_features, None, None, None
 
 
 three_interpolate = ThreeInterpolate.apply

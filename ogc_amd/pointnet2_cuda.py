@@ -123,6 +123,14 @@ def group_points_grad_rev_wrapper(b, c, n, npoints, nsample, grad_out, rev_start
     return 1
 
 
+def three_interpolate_grad_rev_wrapper(b, c, n, m, grad_out, weight, rev_start, rev_pos, heads, grad_points):
+    """grad_points (b, c, m) of three_interpolate as a gather over group_reverse(idx (b, n, 3), m); overwrites."""
+    _run("ogc_three_interpolate_grad_rev", grad_out, b, c, n, m, _f(grad_out, "grad_out"), _f(weight, "weight"),
+         _i(rev_start, "rev_start"), _check(rev_pos, torch.int16, "rev_pos"), _check(heads, torch.int16, "heads"),
+         _f(grad_points, "grad_points"))
+    return 1
+
+
 def gather_points_wrapper(b, c, n, npoints, points, idx, out):
     _run("ogc_gather_points", points, b, c, n, npoints, _f(points, "points"), _i(idx, "idx"), _f(out, "out"))
     return 1

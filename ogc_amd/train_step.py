@@ -130,9 +130,12 @@ def train_step(segnet, criterion, optimizer, batch, it, aug_transform, sync=True
                              **kw)
     try:
         loss.backward()
-    except RuntimeError:  # the reference returns without stepping (train_seg.py:75-78)
-        if _is_distributed(segnet):
-            raise  # a rank that leaves the step alone would hang the others in the gradient collective
+    except RuntimeError as err:  # the reference returns without stepping (train_seg.py:75-78)
+        from ._lib import OgcOpsError
+        if _is_distributed(segnet) or isinstance(err, OgcOpsError):
+            # a rank that leaves the step alone would hang the others in the gradient collective; and a failing operator of
+            # THIS library is a bug to be seen, not a numerical accident of the batch
+            raise
         pending = PendingStep(losses, HostScalars(torch.tensor([True])))
         pending.prefetched = upcoming
         return pending.result() if sync else pending
@@ -208,8 +211,9 @@ def flow_train_step(flownet, criterion, optimizer, batch, model_iters, sync=True
     loss, losses = criterion(pc1, pc2, flow_preds, sync=False, extra=extra)
     try:
         loss.backward()
-    except RuntimeError:  # train_flow.py:80-83: the step is skipped
-        if _is_distributed(flownet):
+    except RuntimeError as err:  # train_flow.py:80-83: the step is skipped
+        from ._lib import OgcOpsError
+        if _is_distributed(flownet) or isinstance(err, OgcOpsError):
             raise
         from .utils.streams import HostScalars
         pending = PendingStep(losses, HostScalars(torch.tensor([True])))

@@ -152,7 +152,12 @@ class PointnetFPModule(nn.Module):
         dist, idx = three_nn(unknown.contiguous(), known.contiguous())
         dist_recip = 1.0 / (dist + 1e-8)                                  # :99
         weight = dist_recip / dist_recip.sum(dim=2, keepdim=True)         # :100-101
-        return {"idx": idx.contiguous(), "weight": weight.contiguous()}
+        idx, weight = idx.contiguous(), weight.contiguous()
+        rev = None
+        if torch.is_grad_enabled() and idx.is_cuda and (3 * idx.shape[1]) % 16 == 0:
+            from ..fused import group_reverse
+            rev = group_reverse(idx.int() if idx.dtype != torch.int32 else idx, known.shape[1])
+        return {"idx": idx, "weight": weight, "rev": rev}
 
     def forward(self, unknown, known, unknow_feats, known_feats, geometry=None):
         # unknown (B, n, 3), known (B, m, 3), unknow_feats (B, C1, n), known_feats (B, C2, m) -> (B, mlp[-1], n)
@@ -161,7 +166,8 @@ class PointnetFPModule(nn.Module):
                 geometry = self.plan_geometry(unknown, known)
             elif hasattr(geometry, "get"):
                 geometry = geometry.get()
-            interpolated = three_interpolate(known_feats.contiguous(), geometry["idx"], geometry["weight"])
+            interpolated = three_interpolate(known_feats.contiguous(), geometry["idx"], geometry["weight"],
+                                             geometry.get("rev"))
         else:
             interpolated = known_feats.expand(*known_feats.size()[0:2], unknown.size(1))
         if unknow_feats is not None:

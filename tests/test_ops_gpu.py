@@ -332,6 +332,35 @@ def test_group_gradient_as_a_gather(nat, B, C, N, P, S):
         assert np.array_equal(bits.reshape(-1).astype(bool), head[b])
 
 
+@pytest.mark.parametrize("B,C,M,N", [(2, 256, 512, 1024), (3, 5, 100, 48), (2, 64, 2048, 8192), (1, 7, 3000, 4096)])
+def test_three_interpolate_gradient_as_a_gather(nat, B, C, M, N):
+    """ogc_three_interpolate_grad_rev against a float64 scatter-add and the atomic kernel; through the autograd Function too."""
+    from ogc_amd import fused
+    from ogc_amd.pointnet2.pointnet2 import three_interpolate
+    rng = np.random.default_rng(M + N)
+    idx = rng.integers(0, M, (B, N, 3)).astype(np.int32)
+    idx[:, ::5, 1] = idx[:, ::5, 0]                      # equal consecutive entries (runs) inside and across rows
+    idx[:, 1::7, 0] = idx[:, 0:-1:7, 2][:, :idx[:, 1::7, 0].shape[1]]
+    w = rng.random((B, N, 3)).astype(np.float32)
+    g = rng.standard_normal((B, C, N)).astype(np.float32)
+    want = np.zeros((B, C, M))
+    for b in range(B):
+        for k in range(3):
+            np.add.at(want[b].T, idx[b, :, k], (g[b].astype(np.float64) * w[b, :, k]).T)
+    rev = fused.group_reverse(T(idx), M)
+    assert rev is not None
+    got = torch.full((B, C, M), -3.0, device=DEV)
+    nat.three_interpolate_grad_rev_wrapper(B, C, N, M, T(g), T(w), rev[0], rev[1], rev[2], got)
+    scale = np.abs(want).max() + 1e-30
+    assert np.abs(got.cpu().numpy() - want).max() <= 2e-6 * scale
+    old = torch.zeros(B, C, M, device=DEV)
+    nat.three_interpolate_grad_wrapper(B, C, N, M, T(g), T(idx), T(w), old)
+    assert np.abs(old.cpu().numpy() - got.cpu().numpy()).max() <= 4e-6 * scale
+    feats = torch.randn(B, C, M, device=DEV, requires_grad=True)
+    three_interpolate(feats, T(idx), T(w), rev).backward(T(g))
+    assert np.abs(feats.grad.cpu().numpy() - want).max() <= 2e-6 * scale
+
+
 def test_gather_and_group_forward_exact(nat, oracle):
     rng = np.random.default_rng(3)
     for (B, C, N, P, S) in [(2, 5, 50, 11, 4), (2, 96, 2048, 1024, 64), (1, 3, 8192, 2048, 64), (3, 7, 100, 13, 3),

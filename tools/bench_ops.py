@@ -125,8 +125,11 @@ def main():
             byt = B * (4 * C * M + 24 * N + 4 * C * N)
             gp = torch.zeros(B, C, M, device=DEV)
             ms2 = timeit(lambda: nat.three_interpolate_grad_wrapper(B, C, N, M, out, i3, w, gp), a.iters)
-            print("interp B=%-3d C=%-4d M=%-5d N=%-5d fwd %8.3f ms %8.1f GB/s | bwd %8.3f ms %8.1f GB/s" %
-                  (B, C, M, N, ms, byt / ms / 1e6, ms2, byt / ms2 / 1e6))
+            from ogc_amd import fused
+            rev = fused.group_reverse(i3, M)
+            ms3 = timeit(lambda: nat.three_interpolate_grad_rev_wrapper(B, C, N, M, out, w, rev[0], rev[1], rev[2], gp), a.iters)
+            print("interp B=%-3d C=%-4d M=%-5d N=%-5d fwd %8.3f ms %8.1f GB/s | bwd (atomics) %8.3f ms %8.1f GB/s | "
+                  "bwd (gather) %8.3f ms %8.1f GB/s" % (B, C, M, N, ms, byt / ms / 1e6, ms2, byt / ms2 / 1e6, ms3, byt / ms3 / 1e6))
 
 
 def bench_conv_gn(ops, iters):
