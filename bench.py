@@ -48,8 +48,8 @@ OFFLINE = {
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=4, help="samples per GPU (config batch_size: 4)")
     ap.add_argument("--npoint", type=int, default=8192)
     ap.add_argument("--no-cpu-baseline", action="store_true")
