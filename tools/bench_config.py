@@ -20,21 +20,29 @@ if os.environ.get("OVERLAP_HEAD") is not None:
     net.overlap_head = os.environ["OVERLAP_HEAD"] == "1"
 single = cfg["dataset"] == "waymo"
 crit = build_criterion(cfg["loss"], single_frame=single)
-opt = make_optimizer(net.parameters(), lr=cfg["lr"])
+graph = os.environ.get("GRAPH") == "1"   # the step replayed as one HIP graph (ogc_amd/graph_step.py)
+opt = make_optimizer(net.parameters(), lr=cfg["lr"], capturable=graph)
 outdoor = cfg["dataset"] in ("kittisf", "waymo")
 batch = make_scene_batch(cfg["batch_size"], cfg["segnet"]["n_point"], cfg["segnet"]["n_slot"], seed=1, outdoor=outdoor, aug=True, device="cuda")
 if single:
     batch = tuple(x[:, ::2].contiguous() for x in batch)
 views = batch[1].shape[1]
 pre, pend = None, None
+gs = None
+if graph:
+    from ogc_amd.graph_step import GraphedTrainStep
+    gs = GraphedTrainStep(net, crit, opt, batch, 10 ** 6, True)
 for i in range(5 + steps):
     if i == 5:
         torch.cuda.synchronize(); t0 = time.perf_counter()
+    if gs is not None:
+        pend = gs.step(batch)
+        continue
     pend = train_step(net, crit, opt, batch, 10 ** 6, True, sync=False, prefetched=pre, next_batch=batch)
     pre = pend.prefetched
 torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) / steps * 1e3
 clouds = cfg["batch_size"] * views
-print("%s [%s]: batch %d x %d views x %d points: %.2f ms/step = %.0f clouds/s, peak HBM %.2f GiB, loss %s" %
-      (cfg["dataset"], prec, cfg["batch_size"], views, cfg["segnet"]["n_point"], ms, clouds / ms * 1e3,
+print("%s [%s%s]: batch %d x %d views x %d points: %.2f ms/step = %.0f clouds/s, peak HBM %.2f GiB, loss %s" %
+      (cfg["dataset"], prec, ", HIP graph" if graph else "", cfg["batch_size"], views, cfg["segnet"]["n_point"], ms, clouds / ms * 1e3,
        torch.cuda.max_memory_allocated() / 2 ** 30, {k: round(v, 4) for k, v in pend.result()[0].items()}))
