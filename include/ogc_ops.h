@@ -461,6 +461,10 @@ int ogc_conv1x1_gemm(int b, int M, int K, int hw, int transpose_a, const float *
  * Requires, beyond ogc_conv1x1_gemm: groups <= 32, (M / groups) % 4 == 0 and K <= 100 (OGC_ERR_UNSUPPORTED otherwise:
  * wider layers run the plain GEMM and the GroupNorm entry points compute their own statistics). */
 int ogc_conv1x1_gn_slots(void);
+/* 1 if the forward convolution can produce the next GroupNorm's statistics on the way for this shape (ogc_conv1x1_gemm_gnstats,
+ * affine = 0; ogc_conv1x1_gemm_affine with groups > 0, affine = 1): K <= 100, or a shape of the streaming kernel (fp32
+ * operands, 100 < K <= 160, hw a multiple of 64, b * hw / 64 >= 2048). */
+int ogc_conv1x1_gemm_stats_supported(int b, int M, int K, int hw, int affine);
 
 /* Operand precision of ogc_conv1x1_gemm* / ogc_conv1x1_wgrad* (process-wide; returns the previous setting).
  * 0 (default): fp32 operands on v_mfma_f32_16x16x4_f32 — exact fp32 FMA chains, the parity mode.

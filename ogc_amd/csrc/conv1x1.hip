@@ -476,13 +476,18 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_gemm_kernel(int M,
 // them; the whole weight matrix is staged in LDS once per workgroup (one workgroup of four waves per CU).
 // EXACT: K fills the KQ register quads (Kq == KQ) and M is a multiple of 64 — no wave-uniform branch is left between the
 // MFMAs of a tile (a scalar compare-and-branch between two MFMAs costs issue slots the matrix pipe cannot fill).
-template <int KQ, bool PRO, bool EXACT>
+// STATS: the sums and sums of squares of the outputs per (sample, GroupNorm group) as well (see conv1x1_gemm_kernel): a lane's
+// four rows x four positions, summed over the sixteen lanes of its DPP row, go straight to the fp64 accumulators in global
+// memory (copy blockIdx.x % GN_SLOTS): 32 atomics per wavefront and 64-row tile.
+template <int KQ, bool PRO, bool EXACT, bool STATS = false>
 __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_gemm_stream_kernel(int M, int K, int hw, int ntiles,
                                                                                  const float *__restrict__ w,
                                                                                  const float *__restrict__ in,
                                                                                  float *__restrict__ out,
                                                                                  const float *__restrict__ pa,
-                                                                                 const float *__restrict__ pb, int pro_relu) {
+                                                                                 const float *__restrict__ pb, int pro_relu,
+                                                                                 int groups = 1, int nbatch = 1,
+                                                                                 double *__restrict__ stats = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float a_lds[]; // [M / 64 tiles][64][ogc_a_ld(Kq)], then PRO: [wave][2][KQ * 4]
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 15, kk = lane >> 4;
@@ -515,8 +520,34 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_gemm_stream_kernel
     // waiting for the prefetched tile as well.
     float *cw = a_lds + (size_t)Mt * 64 * a_ld + wave * (2 * KQ * 4);
     int coef_b = -1;
+    // STATS: fp64 partial sums per (64-row tile, 16-row block, row quad) in a wave-private strip of LDS (each slot has one
+    // writer: lane 16 kk of the wave), flushed to the global accumulators when the wave moves on to another sample — a
+    // wave walks a CONTIGUOUS range of position tiles, so that happens once or twice per launch.
+    double *sacc = reinterpret_cast<double *>(a_lds + (size_t)Mt * 64 * a_ld + (PRO ? WG_WAVES * 2 * FW_KQ_MAX * 4 : 0)) +
+                   wave * (4 * 16 * 2);
+    int stat_b = -1;
+    auto flush_stats = [&]() {
+        if constexpr (STATS) {
+            if (stat_b >= 0) {
+                const int cpg = M / groups; // channels per group, a multiple of 4 on this path
+                double *dst = stats + ((size_t)(blockIdx.x % GN_SLOTS) * nbatch + stat_b) * 2 * groups;
+                if (lane < Mt * 16) { // slot = (mt * 4 + a) * 4 + kk  ->  rows mt * 64 + a * 16 + kk * 4 ..
+                    const int m = (lane >> 4) * 64 + ((lane >> 2) & 3) * 16 + (lane & 3) * 4;
+                    if (m < M) {
+                        unsafeAtomicAdd(dst + 2 * (m / cpg), sacc[2 * lane]);
+                        unsafeAtomicAdd(dst + 2 * (m / cpg) + 1, sacc[2 * lane + 1]);
+                    }
+                }
+            }
+            if (lane < 64) { sacc[2 * lane] = 0.0; sacc[2 * lane + 1] = 0.0; }
+            __builtin_amdgcn_wave_barrier();
+        }
+    };
     auto compute_store = [&](int t, float4(&x)[KQ]) {
         const int b = t / tiles_per_img, p0 = (t - b * tiles_per_img) * 64;
+        if constexpr (STATS) {
+            if (b != stat_b) { flush_stats(); stat_b = b; }
+        }
         if (PRO) { // the previous layer's GroupNorm (+ ReLU) applied to the tile in place
             if (b != coef_b) {
                 coef_b = b;
@@ -574,40 +605,83 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_gemm_stream_kernel
                         *reinterpret_cast<float4 *>(outb + (size_t)m0 * hw + off_out) =
                             make_float4(acc[a][0][r], acc[a][1][r], acc[a][2][r], acc[a][3][r]);
                 }
+            if constexpr (STATS) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    if (EXACT || a < nblk) {
+                        float sm = 0.f, sq = 0.f; // the lane's 4 rows x 4 positions; rows >= M are exact zeros
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                const float v = acc[a][c][r];
+                                sm += v;
+                                sq += v * v;
+                            }
+                        sm += ogc_dpp_f32<0xB1>(sm); sq += ogc_dpp_f32<0xB1>(sq);
+                        sm += ogc_dpp_f32<0x4E>(sm); sq += ogc_dpp_f32<0x4E>(sq);
+                        sm += ogc_dpp_f32<0x141>(sm); sq += ogc_dpp_f32<0x141>(sq);
+                        sm += ogc_dpp_f32<0x140>(sm); sq += ogc_dpp_f32<0x140>(sq);
+                        if (j == 0) {
+                            const int slot = (mt * 4 + a) * 4 + kk;
+                            sacc[2 * slot] += (double)sm;
+                            sacc[2 * slot + 1] += (double)sq;
+                        }
+                    }
+                }
+            }
         }
     };
     float4 xa[KQ], xb[KQ];
-    int t = blockIdx.x * WG_WAVES + wave;
-    load_tile(t, xa);
-    for (; t + nw < ntiles; t += 2 * nw) { // two tiles per round, no branch in the body
-        load_tile(t + nw, xb);
-        compute_store(t, xa);
-        load_tile(t + 2 * nw, xa);
-        compute_store(t + nw, xb);
+    // a wave walks a contiguous range of position tiles (it stays inside one sample most of the time)
+    const int per = (ntiles + nw - 1) / nw;
+    int t = (blockIdx.x * WG_WAVES + wave) * per;
+    const int t_end = min(ntiles, t + per);
+    if (STATS) flush_stats(); // (clears the strip)
+    if (t < t_end) {
+        load_tile(t, xa);
+        for (; t + 1 < t_end; t += 2) { // two tiles per round, no branch in the body
+            load_tile(t + 1, xb);
+            compute_store(t, xa);
+            load_tile(t + 2, xa);
+            compute_store(t + 1, xb);
+        }
+        if (t < t_end) compute_store(t, xa);
     }
-    if (t < ntiles) compute_store(t, xa);
+    if (STATS) flush_stats();
 }
 
 // the streaming kernel for this shape, or false when the tile kernel should run
-template <bool PRO>
-bool gemm_stream_launch(int b, int M, int K, int hw, const float *w, const float *in, float *out, const float *pa,
-                        const float *pb, int pro_relu, hipStream_t s) {
+// shapes the streaming kernel takes (fp32 operands only)
+bool gemm_stream_eligible(int b, int M, int K, int hw, bool pro) {
     const int Kq = (K + 3) / 4, Mt = (M + 63) / 64;
     const long long ntiles = (long long)b * (hw / 64);
-    const size_t lds = ((size_t)Mt * 64 * ogc_a_ld(Kq) + (PRO ? WG_WAVES * 2 * FW_KQ_MAX * 4 : 0)) * sizeof(float);
+    const size_t lds = ((size_t)Mt * 64 * ogc_a_ld(Kq) + (pro ? WG_WAVES * 2 * FW_KQ_MAX * 4 : 0)) * sizeof(float) +
+                       WG_WAVES * 4 * 16 * 2 * sizeof(double);
     static const bool off = getenv("OGC_GEMM_STREAM") && getenv("OGC_GEMM_STREAM")[0] == '0';
-    if (off || Kq <= 25 || Kq > FW_KQ_MAX || lds > 156 * 1024 || ntiles < 2048 || ntiles >= (1ll << 31)) return false;
+    return !(off || g_matmul_bf16 || (hw & 63) != 0 || Kq <= 25 || Kq > FW_KQ_MAX || lds > 156 * 1024 || ntiles < 2048 ||
+             ntiles >= (1ll << 31));
+}
+
+template <bool PRO, bool STATS = false>
+bool gemm_stream_launch(int b, int M, int K, int hw, const float *w, const float *in, float *out, const float *pa,
+                        const float *pb, int pro_relu, hipStream_t s, int groups = 1, double *stats = nullptr) {
+    const int Kq = (K + 3) / 4, Mt = (M + 63) / 64;
+    const long long ntiles = (long long)b * (hw / 64);
+    const size_t lds = ((size_t)Mt * 64 * ogc_a_ld(Kq) + (PRO ? WG_WAVES * 2 * FW_KQ_MAX * 4 : 0)) * sizeof(float) +
+                       WG_WAVES * 4 * 16 * 2 * sizeof(double);
+    if (!gemm_stream_eligible(b, M, K, hw, PRO)) return false;
     const int wgs = (int)(ntiles / WG_WAVES < 256 ? ntiles / WG_WAVES : 256);
 #define OGC_STREAM(KQV, EX)                                                                                                  \
     do {                                                                                                                     \
         static bool raised = false;                                                                                          \
-        const void *fn = reinterpret_cast<const void *>(&conv1x1_gemm_stream_kernel<KQV, PRO, EX>);                          \
+        const void *fn = reinterpret_cast<const void *>(&conv1x1_gemm_stream_kernel<KQV, PRO, EX, STATS>);                   \
         if (!raised) {                                                                                                       \
             if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess) return false;  \
             raised = true;                                                                                                   \
         }                                                                                                                    \
-        hipLaunchKernelGGL((conv1x1_gemm_stream_kernel<KQV, PRO, EX>), dim3(wgs), dim3(WG_WAVES * OGC_WAVE), lds, s, M, K, hw, \
-                           (int)ntiles, w, in, out, pa, pb, pro_relu);                                                       \
+        hipLaunchKernelGGL((conv1x1_gemm_stream_kernel<KQV, PRO, EX, STATS>), dim3(wgs), dim3(WG_WAVES * OGC_WAVE), lds, s,  \
+                           M, K, hw, (int)ntiles, w, in, out, pa, pb, pro_relu, groups, b, stats);                           \
     } while (0)
     const bool full_rows = M % 64 == 0;
     if (Kq == 32 && full_rows) OGC_STREAM(32, true);         // K = 125 .. 128 (the 128-channel layers)
@@ -622,8 +696,9 @@ template <bool T, bool STATS, bool PRO, bool POOL = false>
 int gemm_launch(int b, int M, int K, int hw, int groups, const float *w, const float *in, float *out, double *stats,
                 const float *pa, const float *pb, int pro_relu, hipStream_t s, PoolOut pool = PoolOut()) {
     const int Kq = (K + 3) / 4;
-    if constexpr (!T && !STATS && !POOL) {
-        if (!g_matmul_bf16 && gemm_stream_launch<PRO>(b, M, K, hw, w, in, out, pa, pb, pro_relu, s)) return OGC_OK;
+    if constexpr (!T && !POOL) {
+        if (!g_matmul_bf16 && gemm_stream_launch<PRO, STATS>(b, M, K, hw, w, in, out, pa, pb, pro_relu, s, groups, stats))
+            return OGC_OK;
     }
     const size_t lds = (size_t)64 * ogc_a_ld(Kq) * sizeof(float); // (the bf16 staging needs half of it)
     dim3 grid(ogc_divup(hw, 64 * WG_WAVES), b);
@@ -679,6 +754,12 @@ extern "C" int ogc_conv1x1_gemm(int b, int M, int K, int hw, int transpose_a, co
 
 extern "C" int ogc_conv1x1_gn_slots(void) { return GN_SLOTS; }
 
+extern "C" int ogc_conv1x1_gemm_stats_supported(int b, int M, int K, int hw, int affine) {
+    // can ogc_conv1x1_gemm_gnstats (affine = 0) / ogc_conv1x1_gemm_affine with groups > 0 (affine = 1) take this shape?
+    if (b < 1 || M < 1 || K < 1 || hw < 1) return 0;
+    return (K <= 100 || gemm_stream_eligible(b, M, K, hw, affine != 0)) ? 1 : 0;
+}
+
 extern "C" int ogc_set_matmul_precision(int bf16) {
     const int previous = g_matmul_bf16;
     g_matmul_bf16 = bf16 ? 1 : 0;
@@ -696,10 +777,11 @@ extern "C" int ogc_conv1x1_gemm_gnstats(int b, int M, int K, int hw, int groups,
                       groups);
         return OGC_ERR_UNSUPPORTED;
     }
-    if (K > 100) {
-        // with the 33- and 40-float4 input tiles the kernel has no registers to spare: the statistics epilogue costs
-        // 0.08-0.15 ms there against 0.05-0.10 ms for the separate statistics pass (tools/bench_ops.py --ops conv)
-        ogc_set_error("ogc_conv1x1_gemm_gnstats: not profitable for K > 100 (K=%d); use ogc_conv1x1_gemm", K);
+    if (K > 100 && !gemm_stream_eligible(b, M, K, hw, false)) {
+        // with the 33- and 40-float4 input tiles the TILE kernel has no registers to spare: the statistics epilogue costs
+        // 0.08-0.15 ms there against 0.05-0.10 ms for the separate statistics pass (tools/bench_ops.py --ops conv); the
+        // streaming kernel (ogc_conv1x1_gemm_stats_supported) adds them for ~nothing
+        ogc_set_error("ogc_conv1x1_gemm_gnstats: not profitable for K > 100 (K=%d) on this shape; use ogc_conv1x1_gemm", K);
         return OGC_ERR_UNSUPPORTED;
     }
     if (b == 0) return OGC_OK;
@@ -760,8 +842,9 @@ extern "C" int ogc_conv1x1_gemm_affine(int b, int M, int K, int hw, int relu, in
     hipStream_t s = (hipStream_t)stream;
     if (groups > 0) {
         OGC_REQUIRE(stats, "ogc_conv1x1_gemm_affine: null pointer");
-        if (groups > 32 || M % groups != 0 || (M / groups) % 4 != 0 || K > 100) {
-            ogc_set_error("ogc_conv1x1_gemm_affine: output statistics need groups <= 32, (M / groups) %% 4 == 0, K <= 100");
+        if (groups > 32 || M % groups != 0 || (M / groups) % 4 != 0 || (K > 100 && !gemm_stream_eligible(b, M, K, hw, true))) {
+            ogc_set_error("ogc_conv1x1_gemm_affine: output statistics need groups <= 32, (M / groups) %% 4 == 0, K <= 100 "
+                          "(or a shape of the streaming kernel: ogc_conv1x1_gemm_stats_supported)");
             return OGC_ERR_UNSUPPORTED;
         }
         if (hipMemsetAsync(stats, 0, sizeof(double) * 2 * GN_SLOTS * (size_t)b * groups, s) != hipSuccess) {

@@ -117,6 +117,11 @@ def group_norm_act_maxpool(x, gn: torch.nn.GroupNorm, relu: bool, stats=None, ex
     return group_norm_act(x, gn, relu, stats).max(dim=3)[0]
 
 
+def _stats_ok(nat, B, cout, cin, hw, affine):
+    fn = getattr(nat, "conv1x1_gemm_stats_supported", None)
+    return fn is not None and nat.get_matmul_precision() == "fp32" and fn(B, cout, cin, hw, affine)
+
+
 def _gemm_ok(K, hw):
     return hw % 64 == 0 and K <= 160
 
@@ -156,8 +161,9 @@ class _PointwiseConv(Function):
         if _gemm_ok(cin, hw) and not ctx.small:
             y = torch.empty((B, cout) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
             if (gn_groups > 0 and gn_groups <= 32 and cout % gn_groups == 0 and (cout // gn_groups) % 4 == 0
-                    and cin <= 100  # wider input tiles leave the kernel no registers for the statistics epilogue
-                    and getattr(nat, "conv1x1_gemm_gnstats_wrapper", None) is not None):
+                    # (K > 100: only the streaming kernel has registers to spare for the statistics epilogue)
+                    and getattr(nat, "conv1x1_gemm_gnstats_wrapper", None) is not None
+                    and (cin <= 100 or _stats_ok(nat, B, cout, cin, hw, False))):
                 stats = torch.empty(nat.conv1x1_gn_slots() * B * gn_groups * 2, dtype=torch.float64, device=x.device)
                 nat.conv1x1_gemm_gnstats_wrapper(B, cout, cin, hw, gn_groups, weight.detach().contiguous(), x, y, stats)
             elif _plain_gemm_mine(cin):
@@ -646,9 +652,10 @@ class _NormActConv(Function):
         w = conv_weight.detach().contiguous()
         stats = extremes = None
         if (next_groups > 0 and next_groups <= 32 and cout % next_groups == 0 and (cout // next_groups) % 4 == 0
-                and cin <= 100):
+                and (cin <= 100 or _stats_ok(nat, B, cout, cin, hw, True))):
             stats = torch.empty(nat.conv1x1_gn_slots() * B * next_groups * 2, dtype=torch.float64, device=dev)
-            if pool and next_gamma is not None and getattr(nat, "conv1x1_gemm_affine_pool_wrapper", None) is not None:
+            if (pool and cin <= 100 and next_gamma is not None
+                    and getattr(nat, "conv1x1_gemm_affine_pool_wrapper", None) is not None):
                 # last layer of a set-abstraction MLP: also the extreme of every neighbourhood, for the max-pool
                 centres = hw // pool
                 yext = torch.empty(B, cout, centres, dtype=torch.float32, device=dev)

@@ -524,6 +524,11 @@ def get_matmul_precision():
     return _precision
 
 
+def conv1x1_gemm_stats_supported(b, m, k, hw, affine):
+    """Can the forward convolution of this shape also produce the next GroupNorm's statistics?"""
+    return bool(_lib.load().ogc_conv1x1_gemm_stats_supported(int(b), int(m), int(k), int(hw), 1 if affine else 0))
+
+
 def conv1x1_gn_slots():
     """Number of accumulator copies conv1x1_gemm_gnstats_wrapper fills (ogc_conv1x1_gn_slots)."""
     return _lib.load().ogc_conv1x1_gn_slots()

@@ -790,6 +790,39 @@ def test_conv_gemm_gnstats(shape):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(4, 128, 128, 32768, 8, 1), (4, 131, 128, 32768, 4, 0), (8, 128, 256, 16384, 32, 1),
+                                   (4, 160, 96, 32768, 8, 1), (4, 128, 128, 32768, 8, 0)])
+def test_conv_statistics_from_the_streaming_kernel(shape):
+    """Wide layers (K > 100, >= 2048 position tiles): the streaming forward kernel also produces the next GroupNorm's
+    statistics — plain (ogc_conv1x1_gemm_gnstats) and with the previous norm folded into the operand load
+    (ogc_conv1x1_gemm_affine, groups > 0): same output bits as without statistics, sums equal to fp64 sums."""
+    from ogc_amd import pointnet2_cuda as nat
+    B, cin, cout, hw, groups, affine = shape
+    assert nat.conv1x1_gemm_stats_supported(B, cout, cin, hw, affine)
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(B, cin, hw, generator=g).cuda()
+    w = (torch.randn(cout, cin, generator=g) * 0.2).cuda()
+    pa, pb = (torch.rand(B, cin, generator=g) + 0.5).cuda(), (torch.randn(B, cin, generator=g) * 0.3).cuda()
+    y0 = torch.empty(B, cout, hw, device="cuda")
+    y1 = torch.full_like(y0, float("nan"))
+    slots = nat.conv1x1_gn_slots()
+    stats = torch.full((slots * B * groups * 2,), float("nan"), dtype=torch.float64, device="cuda")
+    if affine:
+        nat.conv1x1_gemm_affine_wrapper(B, cout, cin, hw, 1, 0, w, x, pa, pb, y0, None)
+        nat.conv1x1_gemm_affine_wrapper(B, cout, cin, hw, 1, groups, w, x, pa, pb, y1, stats)
+    else:
+        nat.conv1x1_gemm_wrapper(B, cout, cin, hw, 0, w, x, y0)
+        nat.conv1x1_gemm_gnstats_wrapper(B, cout, cin, hw, groups, w, x, y1, stats)
+    assert torch.equal(y0, y1)
+    got = stats.view(slots, B, groups, 2).sum(0)
+    yg = y1.double().view(B, groups, -1)
+    ref = torch.stack([yg.sum(-1), (yg * yg).sum(-1)], -1)
+    scale = torch.stack([yg.abs().sum(-1), (yg * yg).sum(-1)], -1)
+    assert ((got - ref).abs() <= 1e-6 * scale + 1e-9).all()
+    assert not nat.conv1x1_gemm_stats_supported(1, cout, cin, 1024, affine)   # too few tiles: the separate pass
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("training", [True, False])
 @pytest.mark.parametrize("pool", [False, True])
 @pytest.mark.parametrize("shape", [(3, 16, 40, 8), (2, 35, 128, 16), (4, 64, 33, 4)])
