@@ -479,7 +479,8 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_gemm_kernel(int M,
 // STATS: the sums and sums of squares of the outputs per (sample, GroupNorm group) as well (see conv1x1_gemm_kernel): a lane's
 // four rows x four positions, summed over the sixteen lanes of its DPP row, go straight to the fp64 accumulators in global
 // memory (copy blockIdx.x % GN_SLOTS): 32 atomics per wavefront and 64-row tile.
-template <int KQ, bool PRO, bool EXACT, bool STATS = false>
+// POOL: the extreme of every neighbourhood as well (PoolOut; see conv1x1_gemm_kernel), for the max-pool that ends the MLP.
+template <int KQ, bool PRO, bool EXACT, bool STATS = false, bool POOL = false>
 __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_gemm_stream_kernel(int M, int K, int hw, int ntiles,
                                                                                  const float *__restrict__ w,
                                                                                  const float *__restrict__ in,
@@ -487,7 +488,8 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_gemm_stream_kernel
                                                                                  const float *__restrict__ pa,
                                                                                  const float *__restrict__ pb, int pro_relu,
                                                                                  int groups = 1, int nbatch = 1,
-                                                                                 double *__restrict__ stats = nullptr) {
+                                                                                 double *__restrict__ stats = nullptr,
+                                                                                 PoolOut pool = PoolOut()) {
     extern __shared__ __attribute__((aligned(16))) float a_lds[]; // [M / 64 tiles][64][ogc_a_ld(Kq)], then PRO: [wave][2][KQ * 4]
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 15, kk = lane >> 4;
@@ -605,6 +607,43 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_gemm_stream_kernel
                         *reinterpret_cast<float4 *>(outb + (size_t)m0 * hw + off_out) =
                             make_float4(acc[a][0][r], acc[a][1][r], acc[a][2][r], acc[a][3][r]);
                 }
+            if constexpr (POOL) {
+                const int m0p = mt * 64;
+                const int seg = pool.s >> 2;                 // lanes per neighbourhood: 4, 8 or 16
+                const int centres = hw / pool.s;
+                const int centre = (p0 + 4 * j) / pool.s;    // of this lane's four positions
+                const size_t o0 = ((size_t)b * M + m0p + kk * 4) * centres + centre;
+                float *const ye = pool.yext + o0;
+                int *const ae = pool.aext + o0;
+                const bool writer = (j & (seg - 1)) == 0;
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    if (EXACT || a < nblk) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int m = m0p + a * 16 + kk * 4 + r;
+                            const float sg = (m < M && pool.sign[m] < 0.f) ? -1.f : 1.f;   // exact: +-1 * v
+                            const float v0 = sg * acc[a][0][r], v1 = sg * acc[a][1][r];
+                            const float v2 = sg * acc[a][2][r], v3 = sg * acc[a][3][r];
+                            float hi = fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
+                            hi = fmaxf(hi, ogc_dpp_f32<0xB1>(hi));
+                            hi = fmaxf(hi, ogc_dpp_f32<0x4E>(hi));
+                            if (seg >= 8) hi = fmaxf(hi, ogc_dpp_f32<0x141>(hi));
+                            if (seg >= 16) hi = fmaxf(hi, ogc_dpp_f32<0x140>(hi));
+                            unsigned idx = v0 == hi ? 4 * j : (v1 == hi ? 4 * j + 1 : (v2 == hi ? 4 * j + 2 : (v3 == hi ? 4 * j + 3 : 64)));
+                            idx = min(idx, ogc_dpp_u32<0xB1>(idx));
+                            idx = min(idx, ogc_dpp_u32<0x4E>(idx));
+                            if (seg >= 8) idx = min(idx, ogc_dpp_u32<0x141>(idx));
+                            if (seg >= 16) idx = min(idx, ogc_dpp_u32<0x140>(idx));
+                            if (writer && m < M) {
+                                const int o = (a * 16 + r) * centres;
+                                ye[o] = sg * hi;
+                                ae[o] = (int)(idx & (unsigned)(pool.s - 1));   // index inside the neighbourhood
+                            }
+                        }
+                    }
+                }
+            }
             if constexpr (STATS) {
 #pragma unroll
                 for (int a = 0; a < 4; ++a) {
@@ -663,9 +702,10 @@ bool gemm_stream_eligible(int b, int M, int K, int hw, bool pro) {
              ntiles >= (1ll << 31));
 }
 
-template <bool PRO, bool STATS = false>
+template <bool PRO, bool STATS = false, bool POOL = false>
 bool gemm_stream_launch(int b, int M, int K, int hw, const float *w, const float *in, float *out, const float *pa,
-                        const float *pb, int pro_relu, hipStream_t s, int groups = 1, double *stats = nullptr) {
+                        const float *pb, int pro_relu, hipStream_t s, int groups = 1, double *stats = nullptr,
+                        PoolOut pool = PoolOut()) {
     const int Kq = (K + 3) / 4, Mt = (M + 63) / 64;
     const long long ntiles = (long long)b * (hw / 64);
     const size_t lds = ((size_t)Mt * 64 * ogc_a_ld(Kq) + (PRO ? WG_WAVES * 2 * FW_KQ_MAX * 4 : 0)) * sizeof(float) +
@@ -675,13 +715,13 @@ bool gemm_stream_launch(int b, int M, int K, int hw, const float *w, const float
 #define OGC_STREAM(KQV, EX)                                                                                                  \
     do {                                                                                                                     \
         static bool raised = false;                                                                                          \
-        const void *fn = reinterpret_cast<const void *>(&conv1x1_gemm_stream_kernel<KQV, PRO, EX, STATS>);                   \
+        const void *fn = reinterpret_cast<const void *>(&conv1x1_gemm_stream_kernel<KQV, PRO, EX, STATS, POOL>);             \
         if (!raised) {                                                                                                       \
             if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess) return false;  \
             raised = true;                                                                                                   \
         }                                                                                                                    \
-        hipLaunchKernelGGL((conv1x1_gemm_stream_kernel<KQV, PRO, EX, STATS>), dim3(wgs), dim3(WG_WAVES * OGC_WAVE), lds, s,  \
-                           M, K, hw, (int)ntiles, w, in, out, pa, pb, pro_relu, groups, b, stats);                           \
+        hipLaunchKernelGGL((conv1x1_gemm_stream_kernel<KQV, PRO, EX, STATS, POOL>), dim3(wgs), dim3(WG_WAVES * OGC_WAVE),    \
+                           lds, s, M, K, hw, (int)ntiles, w, in, out, pa, pb, pro_relu, groups, b, stats, pool);             \
     } while (0)
     const bool full_rows = M % 64 == 0;
     if (Kq == 32 && full_rows) OGC_STREAM(32, true);         // K = 125 .. 128 (the 128-channel layers)
@@ -696,8 +736,9 @@ template <bool T, bool STATS, bool PRO, bool POOL = false>
 int gemm_launch(int b, int M, int K, int hw, int groups, const float *w, const float *in, float *out, double *stats,
                 const float *pa, const float *pb, int pro_relu, hipStream_t s, PoolOut pool = PoolOut()) {
     const int Kq = (K + 3) / 4;
-    if constexpr (!T && !POOL) {
-        if (!g_matmul_bf16 && gemm_stream_launch<PRO, STATS>(b, M, K, hw, w, in, out, pa, pb, pro_relu, s, groups, stats))
+    if constexpr (!T && (!POOL || (STATS && PRO))) {
+        if (!g_matmul_bf16 &&
+            gemm_stream_launch<PRO, STATS, POOL>(b, M, K, hw, w, in, out, pa, pb, pro_relu, s, groups, stats, pool))
             return OGC_OK;
     }
     const size_t lds = (size_t)64 * ogc_a_ld(Kq) * sizeof(float); // (the bf16 staging needs half of it)
@@ -869,8 +910,9 @@ extern "C" int ogc_conv1x1_gemm_affine_pool(int b, int M, int K, int hw, int rel
     const int rc = gemm_check("ogc_conv1x1_gemm_affine_pool", b, M, K, hw, w, in, out);
     if (rc != OGC_OK) return rc;
     OGC_REQUIRE(pa && pb && next_gamma && stats && yext && aext, "ogc_conv1x1_gemm_affine_pool: null pointer");
-    if (groups < 1 || groups > 32 || M % groups != 0 || (M / groups) % 4 != 0 || K > 100 ||
-        (nsample != 16 && nsample != 32 && nsample != 64) || hw % nsample != 0) {
+    if (groups < 1 || groups > 32 || M % groups != 0 || (M / groups) % 4 != 0 ||
+        (K > 100 && !gemm_stream_eligible(b, M, K, hw, true)) || (nsample != 16 && nsample != 32 && nsample != 64) ||
+        hw % nsample != 0) {
         ogc_set_error("ogc_conv1x1_gemm_affine_pool: needs 1 <= groups <= 32, (M / groups) %% 4 == 0, K <= 100 and "
                       "nsample in {16, 32, 64} dividing hw (M=%d, groups=%d, K=%d, nsample=%d)", M, groups, K, nsample);
         return OGC_ERR_UNSUPPORTED;

@@ -654,8 +654,7 @@ class _NormActConv(Function):
         if (next_groups > 0 and next_groups <= 32 and cout % next_groups == 0 and (cout // next_groups) % 4 == 0
                 and (cin <= 100 or _stats_ok(nat, B, cout, cin, hw, True))):
             stats = torch.empty(nat.conv1x1_gn_slots() * B * next_groups * 2, dtype=torch.float64, device=dev)
-            if (pool and cin <= 100 and next_gamma is not None
-                    and getattr(nat, "conv1x1_gemm_affine_pool_wrapper", None) is not None):
+            if pool and next_gamma is not None and getattr(nat, "conv1x1_gemm_affine_pool_wrapper", None) is not None:
                 # last layer of a set-abstraction MLP: also the extreme of every neighbourhood, for the max-pool
                 centres = hw // pool
                 yext = torch.empty(B, cout, centres, dtype=torch.float32, device=dev)

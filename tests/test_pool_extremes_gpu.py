@@ -41,7 +41,9 @@ def _run(mlp, x, w, pooled_conv):
 
 @pytest.mark.parametrize("B,cin,widths,P,S", [(4, 32, [32, 64], 256, 64), (2, 16, [32, 32, 64], 128, 32),
                                                (3, 8, [16, 32], 64, 16), (16, 32, [32, 32], 2048, 64),
-                                               (1, 64, [64, 128], 64, 64)])
+                                               (1, 64, [64, 128], 64, 64),
+                                               # wide layers: the streaming kernel's epilogue (K > 100, >= 2048 position tiles)
+                                               (4, 128, [128, 256], 512, 64), (8, 64, [128, 128], 256, 64)])
 def test_pool_from_extremes_is_bit_identical(B, cin, widths, P, S):
     import ogc_amd  # noqa: F401
     mlp = _mlp(cin, widths)
