@@ -117,6 +117,13 @@ def group_norm_act_maxpool(x, gn: torch.nn.GroupNorm, relu: bool, stats=None, ex
     return group_norm_act(x, gn, relu, stats).max(dim=3)[0]
 
 
+# Neighbourhood extremes also from the streaming kernel (K > 100)?  Supported and bit-identical (tests/test_pool_extremes_gpu.py)
+# but not a gain: at one wavefront per SIMD the ~1300 VALU / DPP instructions per tile of the extremes epilogue are not hidden
+# behind another wave's MFMAs (128 -> 256 at C4: 0.33 -> 0.56 ms, against 0.14 ms for the pooling pass it saves; step
+# 12.35 vs 12.27 ms in an A/B on one GPU).
+POOL_EXTREMES_WIDE = False
+
+
 def _stats_ok(nat, B, cout, cin, hw, affine):
     fn = getattr(nat, "conv1x1_gemm_stats_supported", None)
     return fn is not None and nat.get_matmul_precision() == "fp32" and fn(B, cout, cin, hw, affine)
@@ -654,7 +661,8 @@ class _NormActConv(Function):
         if (next_groups > 0 and next_groups <= 32 and cout % next_groups == 0 and (cout // next_groups) % 4 == 0
                 and (cin <= 100 or _stats_ok(nat, B, cout, cin, hw, True))):
             stats = torch.empty(nat.conv1x1_gn_slots() * B * next_groups * 2, dtype=torch.float64, device=dev)
-            if pool and next_gamma is not None and getattr(nat, "conv1x1_gemm_affine_pool_wrapper", None) is not None:
+            if (pool and next_gamma is not None and (cin <= 100 or POOL_EXTREMES_WIDE)
+                    and getattr(nat, "conv1x1_gemm_affine_pool_wrapper", None) is not None):
                 # last layer of a set-abstraction MLP: also the extreme of every neighbourhood, for the max-pool
                 centres = hw // pool
                 yext = torch.empty(B, cout, centres, dtype=torch.float32, device=dev)

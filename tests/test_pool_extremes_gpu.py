@@ -44,8 +44,10 @@ def _run(mlp, x, w, pooled_conv):
                                                (1, 64, [64, 128], 64, 64),
                                                # wide layers: the streaming kernel's epilogue (K > 100, >= 2048 position tiles)
                                                (4, 128, [128, 256], 512, 64), (8, 64, [128, 128], 256, 64)])
-def test_pool_from_extremes_is_bit_identical(B, cin, widths, P, S):
+def test_pool_from_extremes_is_bit_identical(B, cin, widths, P, S, monkeypatch):
     import ogc_amd  # noqa: F401
+    from ogc_amd import fused
+    monkeypatch.setattr(fused, "POOL_EXTREMES_WIDE", True)   # (off by default: correct but not faster at K > 100)
     mlp = _mlp(cin, widths)
     torch.manual_seed(B + P)
     x = torch.randn(B, cin, P, S, device="cuda")
