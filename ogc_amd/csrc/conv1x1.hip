@@ -50,7 +50,9 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_wgrad_kernel(int b
                                                                            float *__restrict__ dw,
                                                                            const float *__restrict__ aff_a,
                                                                            const float *__restrict__ aff_b, int pro_relu) {
-    __shared__ float red[COB * CIB * 256]; // the workgroup's partial tile: COB*CIB blocks of 16x16
+    // the four waves' partial tiles, one slab each (plain stores: ds_add_f32 sustains well under one lane per cycle), summed
+    // by the threads that send them on
+    __shared__ float red[WG_WAVES][COB * CIB * 256];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 15, k = lane >> 4;
     const int co0 = blockIdx.y * (16 * COB), ci0 = blockIdx.z * (16 * CIB);
@@ -157,20 +159,17 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_wgrad_kernel(int b
     if (s < mine) fma16(ya, xa, faa, fba);
 
     // C/D layout of 16x16x4: lane l holds rows (l >> 4) * 4 + r (r = 0..3) of column l & 15
-    for (int t = threadIdx.x; t < COB * CIB * 256; t += WG_WAVES * OGC_WAVE) red[t] = 0.0f;
-    __syncthreads();
 #pragma unroll
     for (int a = 0; a < COB; ++a)
 #pragma unroll
         for (int c = 0; c < CIB; ++c)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                atomicAdd(&red[(a * CIB + c) * 256 + (k * 4 + r) * 16 + i], acc[a][c][r]);
+            for (int r = 0; r < 4; ++r) red[wave][(a * CIB + c) * 256 + (k * 4 + r) * 16 + i] = acc[a][c][r];
     __syncthreads();
     for (int t = threadIdx.x; t < COB * CIB * 256; t += WG_WAVES * OGC_WAVE) {
         const int blk = t >> 8, a = blk / CIB, c = blk % CIB;
         const int row = co0 + a * 16 + ((t & 255) >> 4), col = ci0 + c * 16 + (t & 15);
-        const float v = red[t];
+        const float v = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
         if (row < cout && col < cin && v != 0.0f) unsafeAtomicAdd(dw + (size_t)row * cin + col, v);
     }
 }

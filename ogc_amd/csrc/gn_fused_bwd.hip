@@ -41,7 +41,7 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void wgrad_moments_kernel(int c
                                                                            const float *__restrict__ aff_a,
                                                                            const float *__restrict__ aff_b,
                                                                            float *__restrict__ hm) {      // (B, 2, cout, cin)
-    __shared__ float red[2 * COB * CIB * 256];
+    __shared__ float red[WG_WAVES][COB * CIB * 256]; // one slab per wave (see conv1x1_wgrad_kernel), H then H2
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 15, k = lane >> 4;
     const int img = blockIdx.x / chunks, chunk = blockIdx.x - img * chunks;
@@ -124,25 +124,24 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void wgrad_moments_kernel(int c
     }
     if (s < mine) fma16(ya, xa);
 
-    for (int t = threadIdx.x; t < 2 * COB * CIB * 256; t += WG_WAVES * OGC_WAVE) red[t] = 0.0f;
-    __syncthreads();
-#pragma unroll
-    for (int a = 0; a < COB; ++a)
-#pragma unroll
-        for (int c = 0; c < CIB; ++c)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { // C/D layout: lane l holds rows (l >> 4) * 4 + r of column l & 15
-                atomicAdd(&red[(a * CIB + c) * 256 + (k * 4 + r) * 16 + i], acc1[a][c][r]);
-                atomicAdd(&red[(COB * CIB + a * CIB + c) * 256 + (k * 4 + r) * 16 + i], acc2[a][c][r]);
-            }
-    __syncthreads();
     float *dst = hm + (size_t)img * 2 * cout * cin;
-    for (int t = threadIdx.x; t < 2 * COB * CIB * 256; t += WG_WAVES * OGC_WAVE) {
-        const int which = t / (COB * CIB * 256), u = t - which * (COB * CIB * 256);
-        const int blk = u >> 8, a = blk / CIB, c = blk % CIB;
-        const int row = co0 + a * 16 + ((u & 255) >> 4), col = ci0 + c * 16 + (u & 15);
-        const float v = red[t];
-        if (row < cout && col < cin && v != 0.0f) unsafeAtomicAdd(dst + ((size_t)which * cout + row) * cin + col, v);
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+        if (which) __syncthreads();
+#pragma unroll
+        for (int a = 0; a < COB; ++a)
+#pragma unroll
+            for (int c = 0; c < CIB; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) // C/D layout: lane l holds rows (l >> 4) * 4 + r of column l & 15
+                    red[wave][(a * CIB + c) * 256 + (k * 4 + r) * 16 + i] = which ? acc2[a][c][r] : acc1[a][c][r];
+        __syncthreads();
+        for (int t = threadIdx.x; t < COB * CIB * 256; t += WG_WAVES * OGC_WAVE) {
+            const int blk = t >> 8, a = blk / CIB, c = blk % CIB;
+            const int row = co0 + a * 16 + ((t & 255) >> 4), col = ci0 + c * 16 + (t & 15);
+            const float v = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+            if (row < cout && col < cin && v != 0.0f) unsafeAtomicAdd(dst + ((size_t)which * cout + row) * cin + col, v);
+        }
     }
 }
 
