@@ -141,12 +141,13 @@ def test_bench_under_one_process_rccl_launcher():
     """`python -m torch.distributed.run --nproc-per-node 1 bench.py --gpus 1`: backend nccl (= RCCL), FlatDataParallel with
     the collective forced on, barrier + MAX-over-ranks timing.  The JSON line must parse, carry the collective's
     payload, and the step must cost what the un-launched step costs (the all-reduce of 2.4 MB is tens of microseconds)."""
-    args = ["--gpus", "1", "--steps", "6", "--warmup", "3", "--no-cpu-baseline"]
+    args = ["--gpus", "1", "--steps", "12", "--warmup", "5", "--no-cpu-baseline"]
     plain = _bench(args, launcher=False)
     dist_ = _bench(args, launcher=True)
     for r in (plain, dist_):
-        assert r["n_gpus"] == 1 and r["steps"] == 6 and r["unit"] == "point-clouds/s" and r["scaling"] == "weak"
+        assert r["n_gpus"] == 1 and r["steps"] == 12 and r["unit"] == "point-clouds/s" and r["scaling"] == "weak"
         assert r["config"]["optimizer_stepped"] is True
     assert dist_["collective"]["backend"] == "nccl" and dist_["collective"]["payload_bytes"] == 4 * 597248
     assert dist_["collective"]["avg_ms"] > 0
-    assert dist_["ms_per_step"] <= 1.10 * plain["ms_per_step"] + 0.3, (dist_["ms_per_step"], plain["ms_per_step"])
+    # (two processes one after the other on a shared box: 10 % + 0.6 ms of slack for the run-to-run spread of short runs)
+    assert dist_["ms_per_step"] <= 1.10 * plain["ms_per_step"] + 0.6, (dist_["ms_per_step"], plain["ms_per_step"])
