@@ -257,8 +257,17 @@ int mc_launch(int b, int hw, McGather ga, const float *x, const float *wt1, cons
 
 } // namespace
 
+// The shapes with a kernel: the set-abstraction blocks of the FlowStep3D nets at their C3 sizes (38 blocks per forward pass,
+// 7-9 launches each when run layer by layer) — (channels in, three widths, neighbours)
+#define OGC_MC_SHAPES(X)                                                                                        \
+    X(131, 128, 128, 128, 16) X(131, 128, 128, 128, 32) X(67, 128, 128, 128, 32) X(35, 64, 64, 64, 32)         \
+    X(6, 32, 32, 32, 32) X(6, 32, 32, 32, 16) X(6, 32, 32, 64, 16) X(67, 64, 64, 128, 16)
+
 extern "C" int ogc_mlp_chain_pool_supported(int c0, int c1, int c2, int c3, int nsample) {
-    return (c0 == 131 && c1 == 128 && c2 == 128 && c3 == 128 && nsample == 16) ? 1 : 0;
+#define OGC_MC_TEST(A, B, C, D, S) if (c0 == A && c1 == B && c2 == C && c3 == D && nsample == S) return 1;
+    OGC_MC_SHAPES(OGC_MC_TEST)
+#undef OGC_MC_TEST
+    return 0;
 }
 
 extern "C" int ogc_mlp_chain_pool(int b, int c0, int c1, int c2, int c3, int p, int nsample, const float *x,
@@ -272,8 +281,11 @@ extern "C" int ogc_mlp_chain_pool(int b, int c0, int c1, int c2, int c3, int p, 
                 "ogc_mlp_chain_pool: weights must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     const int hw = p * nsample;
-    if (c0 == 131 && c1 == 128 && c2 == 128 && c3 == 128 && nsample == 16)
-        return mc_launch<131, 128, 128, 128, 16, false>(b, hw, McGather{}, x, wt1, b1, wt2, b2, wt3, b3, out, s);
+#define OGC_MC_RUN(A, B, C, D, S)                                                   \
+    if (c0 == A && c1 == B && c2 == C && c3 == D && nsample == S)                   \
+        return mc_launch<A, B, C, D, S, false>(b, hw, McGather{}, x, wt1, b1, wt2, b2, wt3, b3, out, s);
+    OGC_MC_SHAPES(OGC_MC_RUN)
+#undef OGC_MC_RUN
     ogc_set_error("ogc_mlp_chain_pool: no kernel for %d -> %d -> %d -> %d with nsample %d", c0, c1, c2, c3, nsample);
     return OGC_ERR_UNSUPPORTED;
 }

@@ -907,22 +907,25 @@ def test_shared_mlp_deferred_normalisation(spec, pool, monkeypatch):
         torch.testing.assert_close(p1.grad, p2.grad, rtol=2e-3, atol=2e-4 * max(s, 1.0), msg=lambda m, n=n1: n + ": " + m)
 
 
-def test_mlp_chain_pool_matches_layerwise_inference(nat):
-    """ogc_mlp_chain_pool (the C3 correlation layer's 131 -> 128 -> 128 -> 128 MLP + max over 16 neighbours in one launch,
-    BatchNorm(eval) folded) against the layer-by-layer evaluation in float64, and FlowEmbedding end to end against the
-    un-fused path; ragged sizes (points not a multiple of a workgroup's 4) included."""
+@pytest.mark.parametrize("chan,S", [((131, 128, 128, 128), 16), ((131, 128, 128, 128), 32), ((67, 128, 128, 128), 32),
+                                    ((35, 64, 64, 64), 32), ((6, 32, 32, 32), 32), ((6, 32, 32, 32), 16), ((6, 32, 32, 64), 16),
+                                    ((67, 64, 64, 128), 16)])
+def test_mlp_chain_pool_matches_layerwise_inference(nat, chan, S):
+    """ogc_mlp_chain_pool (a set-abstraction block of the FlowStep3D nets — three conv / BatchNorm(eval) / ReLU layers and the
+    max over the neighbours — in one launch, BatchNorm folded) against the layer-by-layer evaluation in float64, at every
+    shape with a kernel; ragged sizes (points not a multiple of a workgroup's share) included."""
     import torch.nn as nn
     from ogc_amd import fused
-    g = torch.Generator().manual_seed(5)
+    g = torch.Generator().manual_seed(5 + sum(chan) + S)
     for B, P in ((1, 2048), (2, 37), (3, 130)):
-        convs = nn.ModuleList([nn.Conv2d(131, 128, 1, bias=False), nn.Conv2d(128, 128, 1, bias=False),
-                               nn.Conv2d(128, 128, 1, bias=False)]).to(DEV)
-        norms = nn.ModuleList([nn.BatchNorm2d(128) for _ in range(3)]).to(DEV).eval()
+        convs = nn.ModuleList([nn.Conv2d(chan[i], chan[i + 1], 1, bias=False) for i in range(3)]).to(DEV)
+        norms = nn.ModuleList([nn.BatchNorm2d(chan[i + 1]) for i in range(3)]).to(DEV).eval()
         with torch.no_grad():
             for bn in norms:
-                bn.weight.copy_(torch.rand(128, generator=g) + 0.5); bn.bias.copy_(torch.rand(128, generator=g) - 0.5)
-                bn.running_mean.copy_(torch.rand(128, generator=g) - 0.5); bn.running_var.copy_(torch.rand(128, generator=g) + 0.5)
-        x = torch.randn(B, 131, P, 16, generator=g).to(DEV)
+                c = bn.num_features
+                bn.weight.copy_(torch.rand(c, generator=g) + 0.5); bn.bias.copy_(torch.rand(c, generator=g) - 0.5)
+                bn.running_mean.copy_(torch.rand(c, generator=g) - 0.5); bn.running_var.copy_(torch.rand(c, generator=g) + 0.5)
+        x = torch.randn(B, chan[0], P, S, generator=g).to(DEV)
         with torch.no_grad():
             assert fused.mlp_chain_pool_available(x, convs, norms)
             got = fused.mlp_chain_pool(x, convs, norms)
