@@ -45,6 +45,9 @@ __device__ __forceinline__ float mc_group_max(float v) {
     return v;
 }
 
+// width a neighbourhood of S positions takes in a wavefront's columns
+constexpr int mc_padded(int S) { return S <= 16 ? S : (S + 15) / 16 * 16; }
+
 // weights of one layer: global Wt (KP rows x COUT, row-major, KP = K rounded up to 4, zero rows beyond K) -> LDS with
 // row stride COUT + 4 (4 * stride = 16 mod 32 banks: the two 16-float runs a half-wave reads never share a bank),
 // followed by the COUT biases
@@ -123,19 +126,32 @@ __global__ __launch_bounds__(MC_THREADS) void mlp_chain_pool_kernel(int hw, McGa
                                                                    const float *__restrict__ wt3, const float *__restrict__ b3,
                                                                    float *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float mc_lds[];
-    constexpr int NCB = S > 16 ? S / 16 : 1;       // column blocks (of 16 positions) per wavefront
+    // A neighbourhood that is not 4, 8 or a multiple of 16 wide (S = 24) is padded to SP columns by repeating its last
+    // neighbour: a maximum does not change when one of its arguments is taken twice.
+    constexpr int SP = mc_padded(S);
+    constexpr int NCB = SP > 16 ? SP / 16 : 1;     // column blocks (of 16 positions) per wavefront
     constexpr int C0P = (C0 + 3) / 4 * 4;
     constexpr int CL = C3 > 0 ? C3 : C2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, kk = lane >> 4;
     const int b = blockIdx.y;
-    const long long col0 = ((long long)blockIdx.x * MC_WAVES + wave) * (16 * NCB); // first position of this wavefront
+    const long long col0 = ((long long)blockIdx.x * MC_WAVES + wave) * (16 * NCB); // first (padded) position of this wavefront
+    const int p_total = hw / S;
+    const long long hwp = (long long)p_total * SP;
     const float *xb = x + (size_t)b * C0 * hw;
+    // padded position -> position in the (P, S) input
+    auto source = [&](long long colp) -> long long {
+        if constexpr (SP == S) return colp;
+        const long long point = colp / SP;
+        const int sp = (int)(colp - point * SP);
+        return point * S + (sp < S ? sp : S - 1);
+    };
 
     // ---- layer 1: B operands straight from global memory (k-step s = input rows 4 s .. 4 s + 3, lane (j, kk) row 4 s + kk)
     float xin[C0P / 4][NCB];
     if constexpr (CORR) {
         constexpr int CF = (C0 - 3) / 2;
-        const int P = hw / S;
+        static_assert(SP == S, "the gathering variant has no padded neighbourhoods");
+        const int P = p_total;
 #pragma unroll
         for (int c = 0; c < NCB; ++c) {
             const long long col = col0 + c * 16 + j;
@@ -159,13 +175,16 @@ __global__ __launch_bounds__(MC_THREADS) void mlp_chain_pool_kernel(int hw, McGa
         }
     } else {
 #pragma unroll
-        for (int s = 0; s < C0P / 4; ++s)
+        for (int c = 0; c < NCB; ++c) {
+            const long long colp = col0 + c * 16 + j;
+            const bool in = colp < hwp;
+            const long long col = in ? source(colp) : 0;
 #pragma unroll
-            for (int c = 0; c < NCB; ++c) {
+            for (int s = 0; s < C0P / 4; ++s) {
                 const int row = 4 * s + kk;
-                const long long col = col0 + c * 16 + j;
-                xin[s][c] = (row < C0 && col < hw) ? xb[(size_t)row * hw + col] : 0.0f;
+                xin[s][c] = (row < C0 && in) ? xb[(size_t)row * hw + col] : 0.0f;
             }
+        }
     }
     mc_stage_weights<C0P, C1>(mc_lds, wt1, b1);
     __syncthreads();
@@ -203,9 +222,8 @@ __global__ __launch_bounds__(MC_THREADS) void mlp_chain_pool_kernel(int hw, McGa
     mc_layer_from_regs<C1, C2, NCB>(mc_lds, h1, h2);
 
     // ---- max over the neighbourhood; lane j == first lane of its group stores (row 16 ob + 4 ib + r, point)
-    constexpr int SG = S > 16 ? 16 : S;
-    float *ob_out = out + (size_t)b * CL * (hw / S);
-    const int p_total = hw / S;
+    constexpr int SG = SP > 16 ? 16 : SP;
+    float *ob_out = out + (size_t)b * CL * p_total;
     auto pool_and_store = [&](const auto &last) {
 #pragma unroll
         for (int ob = 0; ob < CL / 16; ++ob)
@@ -215,7 +233,7 @@ __global__ __launch_bounds__(MC_THREADS) void mlp_chain_pool_kernel(int hw, McGa
 #pragma unroll
                 for (int c = 1; c < NCB; ++c) v = fmaxf(v, last[ob][c][r]);   // S = 32: the point's second column block
                 v = mc_group_max<SG>(v);
-                const long long point = (col0 + (NCB > 1 ? 0 : j)) / S;
+                const long long point = (col0 + (NCB > 1 ? 0 : j)) / SP;
                 if ((j % SG) == 0 && point < p_total) ob_out[(size_t)(ob * 16 + kk * 4 + r) * p_total + point] = v;
             }
     };
@@ -234,7 +252,10 @@ __global__ __launch_bounds__(MC_THREADS) void mlp_chain_pool_kernel(int hw, McGa
 template <int C0, int C1, int C2, int C3, int S, bool CORR>
 int mc_launch(int b, int hw, McGather ga, const float *x, const float *wt1, const float *b1, const float *wt2, const float *b2,
               const float *wt3, const float *b3, float *out, hipStream_t s) {
-    constexpr int NCB = S > 16 ? S / 16 : 1;
+    constexpr int SP = mc_padded(S);
+    constexpr int NCB = SP > 16 ? SP / 16 : 1;
+    static_assert(S == 4 || S == 8 || S >= 16, "neighbourhoods of 4, 8 or at least 16 positions");
+    static_assert(NCB <= 2, "a point's neighbourhood must fit one wavefront's column blocks");
     constexpr int C0P = (C0 + 3) / 4 * 4;
     constexpr int w1 = C0P * (C1 + 4) + C1, w2 = C1 * (C2 + 4) + C2, w3 = C3 > 0 ? C2 * (C3 + 4) + C3 : 0;
     constexpr int lds_floats = w1 > w2 ? (w1 > w3 ? w1 : w3) : (w2 > w3 ? w2 : w3);
@@ -248,7 +269,7 @@ int mc_launch(int b, int hw, McGather ga, const float *x, const float *wt1, cons
         }
         raised = true;
     }
-    dim3 grid(ogc_divup(hw, 16 * NCB * MC_WAVES), b);
+    dim3 grid(ogc_divup((long long)(hw / S) * SP, 16 * NCB * MC_WAVES), b);
     hipLaunchKernelGGL((mlp_chain_pool_kernel<C0, C1, C2, C3, S, CORR>), grid, dim3(MC_THREADS), lds_floats * 4, s, hw, ga, x, wt1, b1,
                        wt2, b2, wt3, b3, out);
     OGC_CHECK_LAUNCH("ogc_mlp_chain_pool");
@@ -261,7 +282,8 @@ int mc_launch(int b, int hw, McGather ga, const float *x, const float *wt1, cons
 // 7-9 launches each when run layer by layer) — (channels in, three widths, neighbours)
 #define OGC_MC_SHAPES(X)                                                                                        \
     X(131, 128, 128, 128, 16) X(131, 128, 128, 128, 32) X(67, 128, 128, 128, 32) X(35, 64, 64, 64, 32)         \
-    X(6, 32, 32, 32, 32) X(6, 32, 32, 32, 16) X(6, 32, 32, 64, 16) X(67, 64, 64, 128, 16)
+    X(6, 32, 32, 32, 32) X(6, 32, 32, 32, 16) X(6, 32, 32, 64, 16) X(67, 64, 64, 128, 16)                      \
+    X(35, 16, 16, 16, 8) X(67, 128, 128, 128, 8) X(131, 128, 128, 128, 24)
 
 extern "C" int ogc_mlp_chain_pool_supported(int c0, int c1, int c2, int c3, int nsample) {
 #define OGC_MC_TEST(A, B, C, D, S) if (c0 == A && c1 == B && c2 == C && c3 == D && nsample == S) return 1;
@@ -276,7 +298,7 @@ extern "C" int ogc_mlp_chain_pool(int b, int c0, int c1, int c2, int c3, int p, 
     OGC_REQUIRE(b >= 0 && p >= 0 && nsample >= 1, "ogc_mlp_chain_pool: bad shape");
     if (b == 0 || p == 0) return OGC_OK;
     OGC_REQUIRE(x && wt1 && b1 && wt2 && b2 && out && (c3 == 0 || (wt3 && b3)), "ogc_mlp_chain_pool: null pointer");
-    OGC_REQUIRE((long long)p * nsample < (1ll << 31) && b <= 65535, "ogc_mlp_chain_pool: sample exceeds 32-bit indexing");
+    OGC_REQUIRE((long long)p * (nsample + 15) < (1ll << 31) && b <= 65535, "ogc_mlp_chain_pool: sample exceeds 32-bit indexing");
     OGC_REQUIRE(((uintptr_t)wt1 & 15) == 0 && ((uintptr_t)wt2 & 15) == 0 && ((uintptr_t)wt3 & 15) == 0,
                 "ogc_mlp_chain_pool: weights must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;

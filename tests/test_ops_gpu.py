@@ -909,7 +909,8 @@ def test_shared_mlp_deferred_normalisation(spec, pool, monkeypatch):
 
 @pytest.mark.parametrize("chan,S", [((131, 128, 128, 128), 16), ((131, 128, 128, 128), 32), ((67, 128, 128, 128), 32),
                                     ((35, 64, 64, 64), 32), ((6, 32, 32, 32), 32), ((6, 32, 32, 32), 16), ((6, 32, 32, 64), 16),
-                                    ((67, 64, 64, 128), 16)])
+                                    ((67, 64, 64, 128), 16), ((35, 16, 16, 16), 8), ((67, 128, 128, 128), 8),
+                                    ((131, 128, 128, 128), 24)])
 def test_mlp_chain_pool_matches_layerwise_inference(nat, chan, S):
     """ogc_mlp_chain_pool (a set-abstraction block of the FlowStep3D nets — three conv / BatchNorm(eval) / ReLU layers and the
     max over the neighbours — in one launch, BatchNorm folded) against the layer-by-layer evaluation in float64, at every
