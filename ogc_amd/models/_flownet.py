@@ -29,6 +29,10 @@ def joint_fps(xyz_a, xyz_b, npoints, parent_ties=None, return_ties=False):
     return (idx_a, idx_b, ties) if return_ties else (idx_a, idx_b)
 
 
+def _stacked(a, b):
+    return None if a is None else [torch.cat([x, y]) for x, y in zip(a, b)]
+
+
 def _sa(npoint, nsample, in_channel, mlp, inorm, **kw):
     return PointNetSetAbstraction(npoint=npoint, radius=None, nsample=nsample, in_channel=in_channel, mlp=mlp,
                                   group_all=False, use_instance_norm=inorm, **kw)
@@ -200,6 +204,7 @@ class FlowStep3DBase(nn.Module):
         super().__init__()
         w = cfg["width"]
         self.k_decay_fact = k_decay_fact
+        self.use_instance_norm = use_instance_norm
         self.encoder_loc = EncoderLoc(npoint, use_instance_norm, cfg)
         self.encoder_glob = EncoderGlob(npoint, use_instance_norm, cfg)
         self.global_corr_layer = GlobalCorrLayer(npoint, use_instance_norm, cfg)
@@ -219,9 +224,23 @@ class FlowStep3DBase(nn.Module):
         fps1 = fps2 = None
         if pc1_loc.is_cuda and pc1_loc.shape == pc2_loc.shape:
             fps1, fps2 = joint_fps(pc1_loc, pc2_loc, self.encoder_glob.npoints(), parent_ties)
-        pc1_l_glob, feats1_glob = self.encoder_glob(pc1_loc, feats1_loc, fps1)
-        pc2_l_glob, feats2_glob = self.encoder_glob(pc2_loc, feats2_loc, fps2)
+        if fps1 is not None and self._two_clouds_per_call():
+            B = pc1_loc.shape[0]
+            pc_l, feats = self.encoder_glob(torch.cat([pc1_loc, pc2_loc]), torch.cat([feats1_loc, feats2_loc]),
+                                            _stacked(fps1, fps2))
+            pc1_l_glob, pc2_l_glob = [p[:B] for p in pc_l], [p[B:] for p in pc_l]
+            feats1_glob, feats2_glob = feats[:B], feats[B:]
+        else:
+            pc1_l_glob, feats1_glob = self.encoder_glob(pc1_loc, feats1_loc, fps1)
+            pc2_l_glob, feats2_glob = self.encoder_glob(pc2_loc, feats2_loc, fps2)
         return self.global_corr_layer(pc1_l_glob, pc2_l_glob, feats1_glob, feats2_glob)
+
+    def _two_clouds_per_call(self):
+        """May an encoder see both clouds of a pair as one batch of 2B?  Every operator of a set-abstraction block works per
+        cloud and per position except BatchNorm in training mode, whose statistics are those of the call (the reference
+        makes one call per cloud, models/flownet_kitti.py:213-214): so in evaluation mode, or with instance norm.  The
+        launches of the second cloud disappear, and at B = 1 a launch over 8192 points fills half of the chip at best."""
+        return (not self.training) or self.use_instance_norm
 
     def calc_h0(self, feats1_loc, pc):
         return torch.tanh(self.h0_net(pc, feats1_loc))
@@ -250,8 +269,14 @@ class FlowStep3DBase(nn.Module):
         if pc1.is_cuda and pc1.shape == pc2.shape:  # both sampling chains in one launch per level
             fps_idx1, fps_idx2, loc_ties = joint_fps(pc1, pc2, [self.encoder_loc.sa1.npoint, self.encoder_loc.sa2.npoint],
                                                      return_ties=True)
-        pc1_l_loc, feats1_loc, fps_idx1 = self.encoder_loc(pc1, feature1, fps_idx1)
-        pc2_l_loc, feats2_loc, _ = self.encoder_loc(pc2, feature2, fps_idx2)
+        if fps_idx1 is not None and self._two_clouds_per_call():
+            B = pc1.shape[0]
+            pc_l, feats, _ = self.encoder_loc(torch.cat([pc1, pc2]), torch.cat([feature1, feature2]), _stacked(fps_idx1, fps_idx2))
+            pc1_l_loc, pc2_l_loc = [pc1] + [p[:B] for p in pc_l[1:]], [pc2] + [p[B:] for p in pc_l[1:]]
+            feats1_loc, feats2_loc = feats[:B], feats[B:]
+        else:
+            pc1_l_loc, feats1_loc, fps_idx1 = self.encoder_loc(pc1, feature1, fps_idx1)
+            pc2_l_loc, feats2_loc, _ = self.encoder_loc(pc2, feature2, fps_idx2)
 
         corr_feats = self.calc_glob_corr(pc1_l_loc[-1], feats1_loc, pc2_l_loc[-1], feats2_loc, loc_ties)
         flow0_lr = self.flow0_regressor(pc1_l_loc, corr_feats)

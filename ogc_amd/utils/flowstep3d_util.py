@@ -6,7 +6,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..pointnet2.pointnet2 import (GroupAll, QueryAndGroup, ball_query, furthest_point_sample, gather_operation,
-                                   grouping_operation, knn, knn_radius_clamp, three_nn)
+                                   grouping_operation, knn, knn_radius_clamp, three_interpolate, three_nn)
 
 
 class geometry_memo:
@@ -34,7 +34,7 @@ class geometry_memo:
         key = (xyz.data_ptr(), xyz._version, tuple(xyz.shape))
         hit = memo.get(key)
         if hit is None or hit["ref"] is not xyz:
-            hit = {"ref": xyz, "xyz_t": None, "fps": {}, "new_xyz": {}, "knn": {}}
+            hit = {"ref": xyz, "xyz_t": None, "fps": {}, "new_xyz": {}, "knn": {}, "three_nn": {}}
             memo[key] = hit
         return hit
 
@@ -203,13 +203,20 @@ class PointNetFeaturePropogation(nn.Module):
 
     def forward(self, pos1, pos2, feature1, feature2):
         # pos1 (B, 3, N) dense, pos2 (B, 3, S) sparse, feature1 (B, D1, N) or None, feature2 (B, D2, S)
-        pos1_t = pos1.permute(0, 2, 1).contiguous()
-        pos2_t = pos2.permute(0, 2, 1).contiguous()
-        B, _, N = pos1.shape
-        dists, idx = three_nn(pos1_t, pos2_t)
-        weight = 1.0 / dists.clamp(min=1e-10)                                         # :169-170
-        weight = weight / weight.sum(dim=-1, keepdim=True)
-        interpolated = (grouping_operation(feature2, idx) * weight.view(B, 1, N, 3)).sum(dim=-1)
+        # the three neighbours and their weights depend on the coordinates only: FlowStep3D upsamples the coarse flow from
+        # the same centres to the same points in every iteration (models/flownet_kitti.py:224, :249)
+        memo = geometry_memo.entry(pos1)
+        hit = memo["three_nn"].get(id(pos2)) if memo is not None else None
+        if hit is None or hit[0] is not pos2:
+            dists, idx = three_nn(pos1.permute(0, 2, 1).contiguous(), pos2.permute(0, 2, 1).contiguous())
+            weight = 1.0 / dists.clamp(min=1e-10)                                     # :169-170
+            weight = (weight / weight.sum(dim=-1, keepdim=True)).contiguous()
+            hit = (pos2, idx, weight)
+            if memo is not None:
+                memo["three_nn"][id(pos2)] = hit
+        _, idx, weight = hit
+        # sum_k w_k f[idx_k] (:171): one kernel, evaluated as (w0 f0 + w1 f1) + w2 f2 without contraction
+        interpolated = three_interpolate(feature2.contiguous(), idx, weight)
         feat_new = interpolated if feature1 is None else torch.cat([interpolated, feature1], dim=1)
         if self.apply_mlp:
             feat_new = _shared_mlp(feat_new, self.mlp_convs, self.mlp_bns, pool=False)

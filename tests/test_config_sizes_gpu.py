@@ -115,6 +115,26 @@ def test_flownet_kitti_at_config_size():
         gc.close(p[:, ::8], g["C3/flow%d" % i], 1e-4, 1e-5, "C3/flow%d" % i)
 
 
+def test_flownet_two_clouds_per_encoder_call_changes_nothing():
+    """In evaluation mode the encoders see both clouds of a pair as one batch (models/_flownet.py
+    `_two_clouds_per_call`); the reference makes one call per cloud (models/flownet_kitti.py:213-214, :199-200).  Every
+    operator works per cloud: the predictions must be the same numbers, and with BatchNorm in training mode the calls
+    must stay apart."""
+    mod = importlib.import_module("ogc_amd.models.flownet_kitti")
+    net = detgen.fill_module(mod.FlowStep3D(npoint=2048, loc_flow_nn=16, loc_flow_rad=1.5), 8).to(DEV)
+    pc1, pc2 = T(detgen.cloud(2, 2048, 5)), T(detgen.cloud(2, 2048, 6))
+    net.train()
+    assert not net._two_clouds_per_call()
+    net.eval()
+    assert net._two_clouds_per_call()
+    with torch.no_grad():
+        both = net(pc1, pc2, pc1, pc2, iters=3)
+        net._two_clouds_per_call = lambda: False
+        apart = net(pc1, pc2, pc1, pc2, iters=3)
+    for a, b in zip(both, apart):
+        assert torch.equal(a, b)
+
+
 def test_c2_bf16_train_step_tracks_fp32():
     """BASELINE config 2: OGC-DR segnet_ogcdr, 4096-point clouds, bf16 — config/ogcdr_unsup_synthetic.yaml through one
     `train_step`, with bf16 operands in the 1x1 convolutions against the same step with fp32 operands (same weights,
