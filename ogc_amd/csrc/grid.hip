@@ -19,6 +19,8 @@
 // the cell coordinates of a centre and any of its hits differ by at most one even with fp32 rounding of the
 // quotient (relative error 1e-7 * up to 16384 cells << 0.01); points with non-finite coordinates can never be
 // hits (their distance is inf/NaN) and are left out of the grid.
+#include <stdlib.h>
+
 #include "ogc_common.h"
 #include "grid.h"
 
@@ -26,6 +28,21 @@ namespace ogc_grid {
 
 constexpr int GRID_MAX_CELLS = 16384;
 constexpr int BUILD_THREADS = 1024;
+
+// Development probe (tools/bq_probe.hip compiles this file with OGC_GRID_PROBE): cycle stamps of the build's phases
+// (workgroup 0) and per-phase cycle sums over all wavefronts of the query.
+#ifdef OGC_GRID_PROBE
+__device__ unsigned long long ogc_grid_probe[64];
+#define OGC_PROBE_BUILD(i) \
+    if (blockIdx.x == 0 && threadIdx.x == 0) ogc_grid_probe[i] = __builtin_amdgcn_s_memtime()
+#define OGC_PROBE_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define OGC_PROBE_ADD(i, a, b) \
+    if (threadIdx.x == 0 && (blockIdx.x & 63) == 0) atomicAdd(&ogc_grid_probe[i], (b) - (a))
+#else
+#define OGC_PROBE_BUILD(i)
+#define OGC_PROBE_T(var)
+#define OGC_PROBE_ADD(i, a, b)
+#endif
 
 __device__ __forceinline__ int cell_coord(float x, float mn, float inv_h, int g) {
     // floor((x - mn) * inv_h) clamped to [-2, g + 1]; NaN -> -2 (outside every neighbourhood)
@@ -80,7 +97,8 @@ __device__ __forceinline__ GridHdr grid_header(const float (&lo)[3], const float
     h.gx = (int)g[0]; h.gy = (int)g[1]; h.gz = (int)g[2];
     h.npts = 0;
     h.dense = 0;
-    h.pad[0] = h.pad[1] = h.pad[2] = 0;
+    h.heavy = 0;
+    h.pad[0] = h.pad[1] = 0;
     return h;
 }
 
@@ -104,6 +122,7 @@ __global__ __launch_bounds__(BUILD_THREADS) void grid_build_kernel(float knn_div
     float px[R], py[R], pz[R];
     int cell[R];
 
+    OGC_PROBE_BUILD(0);
     // 1. load + bounding box of the finite points
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     auto widen = [&](float x, float y, float z) {
@@ -132,7 +151,9 @@ __global__ __launch_bounds__(BUILD_THREADS) void grid_build_kernel(float knn_div
         const float lo = -ogc_wave_max_f32(-mn[a]), hi = ogc_wave_max_f32(mx[a]);
         if (lane == 0) { s_red[a][wave] = lo; s_red[3 + a][wave] = hi; }
     }
+    OGC_PROBE_BUILD(1);
     __syncthreads();
+    OGC_PROBE_BUILD(2);
     // the grid parameters are derived ONCE (double-precision pow / cbrt / floor loops: hundreds of instructions that
     // used to run on all 1024 threads of the one CU a cloud gets) and handed to the others through LDS
     if (wave == 0) {
@@ -147,6 +168,7 @@ __global__ __launch_bounds__(BUILD_THREADS) void grid_build_kernel(float knn_div
         if (lane == 0) s_hdr = grid_header(lo, hi, n, radius, knn_k, knn_div);
     }
     __syncthreads();
+    OGC_PROBE_BUILD(3);
     GridHdr h = s_hdr;
     const int ncell = h.gx * h.gy * h.gz;
     auto cell_of = [&](float x, float y, float z) -> int {
@@ -171,6 +193,7 @@ __global__ __launch_bounds__(BUILD_THREADS) void grid_build_kernel(float knn_div
         }
     }
     __syncthreads();
+    OGC_PROBE_BUILD(4);
 
     // 3. exclusive scan of s_cnt[0..ncell): a contiguous chunk per thread, wave scan of the chunk sums, wave totals
     const int per = (ncell + BUILD_THREADS - 1) / BUILD_THREADS;
@@ -185,6 +208,7 @@ __global__ __launch_bounds__(BUILD_THREADS) void grid_build_kernel(float knn_div
     }
     if (lane == 63) s_wave[wave] = incl;
     __syncthreads();
+    OGC_PROBE_BUILD(5);
     int before = 0, npts = 0;
 #pragma unroll
     for (int w = 0; w < BUILD_THREADS / 64; ++w) {
@@ -209,9 +233,11 @@ __global__ __launch_bounds__(BUILD_THREADS) void grid_build_kernel(float knn_div
         // stops after nsample hits) while a cell-ordered scan cannot.
         const double per_query = 27.0 * (double)npts / (double)ncell;
         h.dense = per_query > 0.25 * (double)n ? 1 : 0;
+        h.heavy = per_query > 100.0 ? 1 : 0;
         hdrs[b] = h;
     }
     __syncthreads();
+    OGC_PROBE_BUILD(6);
 
     // 4. scatter (order inside a cell is arbitrary; the queries order their results themselves).  One 16-byte record
     //    per point: x, y, z and the point's index (bit pattern), so a query reads a candidate with a single load.
@@ -233,6 +259,7 @@ __global__ __launch_bounds__(BUILD_THREADS) void grid_build_kernel(float knn_div
             else sp[atomicAdd(&s_tail, 1)] = make_float4(NAN, NAN, NAN, __int_as_float(k));
         }
     }
+    OGC_PROBE_BUILD(7);
 }
 
 static void launch_grid_build(int b, int n, float radius, int knn_k, int stride_cells, const float *xyz, GridHdr *hdrs,
@@ -321,15 +348,13 @@ __device__ __forceinline__ ogc_v2f sqdist_pair(ogc_v2f qx, ogc_v2f qy, ogc_v2f q
 // Clouds flagged dense by the build (the 27 cells hold a large share of the cloud, so cell lists buy nothing and
 // rows saturate early) are scanned in INDEX order instead, by the same wavefronts: hits then arrive in the order
 // of the output and a wavefront stops as soon as its eight rows are full.
-__global__ __launch_bounds__(OGC_WAVE) void ball_query_grid_kernel(int n, int m, float radius2, int nsample,
-                                                                   int hit_cap, int stride_cells,
-                                                                   const float *__restrict__ xyz,
-                                                                   const GridHdr *__restrict__ hdrs,
-                                                                   const int *__restrict__ cell_start,
-                                                                   const float4 *__restrict__ sorted_pts,
-                                                                   int *__restrict__ idx_out) {
-    extern __shared__ __attribute__((aligned(16))) int gq_smem[];
+// (the body of the kernel: ball_query_cells_kernel below runs it too, for the wavefronts its short lists cannot hold)
+__device__ __forceinline__ void ball_query_grid_body(int first_centre, int *gq_smem, int n, int m, float radius2, int nsample,
+                                                     int hit_cap, int stride_cells, const float *__restrict__ xyz,
+                                                     const GridHdr *__restrict__ hdrs, const int *__restrict__ cell_start,
+                                                     const float4 *__restrict__ sorted_pts, int *__restrict__ idx_out) {
     const int lane = threadIdx.x, b = blockIdx.y;
+    OGC_PROBE_T(pt0);
     const GridHdr h = hdrs[b];
     int *hits = gq_smem;                                       // [QPW][hit_cap]
     int *outr = gq_smem + QPW * hit_cap;                       // [QPW][nsample] sorted rows
@@ -338,7 +363,7 @@ __global__ __launch_bounds__(OGC_WAVE) void ball_query_grid_kernel(int n, int m,
     const float4 *pts = sorted_pts + (size_t)b * n;
 
     // every group of eight lanes holds the eight centres (lane & 7), so 8-lane butterflies see the whole set
-    const int pc = blockIdx.x * QPW + (lane & (QPW - 1));
+    const int pc = first_centre + (lane & (QPW - 1));
     float4 me = make_float4(NAN, NAN, NAN, __int_as_float(-1));
     if (pc < n) me = pts[pc]; // positions >= h.npts hold the non-finite points: no hits, an all-zero row
     const bool live = pc < h.npts;
@@ -435,6 +460,7 @@ __global__ __launch_bounds__(OGC_WAVE) void ball_query_grid_kernel(int n, int m,
             }
         }
     }
+    OGC_PROBE_T(pt1);
     // hit counts: lane c < 8 holds the count of centre c
     int cnt = 0;
 #pragma unroll
@@ -493,6 +519,7 @@ __global__ __launch_bounds__(OGC_WAVE) void ball_query_grid_kernel(int n, int m,
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
 
+    OGC_PROBE_T(pt2);
     // finish: eight lanes per centre
     const int sub = lane & (SUB - 1), qi = lane >> 3;
     const int total_hits = __shfl(cnt, qi, 64);
@@ -510,6 +537,7 @@ __global__ __launch_bounds__(OGC_WAVE) void ball_query_grid_kernel(int n, int m,
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
+    OGC_PROBE_T(pt3);
     if (q >= 0) {
         const int kept = min(total_hits, nsample);
         const int first = kept > 0 ? row[0] : 0;
@@ -527,6 +555,232 @@ __global__ __launch_bounds__(OGC_WAVE) void ball_query_grid_kernel(int n, int m,
             for (int j = sub; j < nsample; j += SUB) o[j] = j < kept ? row[j] : first;
         }
     }
+    OGC_PROBE_T(pt4);
+    OGC_PROBE_ADD(16, pt0, pt1);
+    OGC_PROBE_ADD(17, pt1, pt2);
+    OGC_PROBE_ADD(18, pt2, pt3);
+    OGC_PROBE_ADD(19, pt3, pt4);
+}
+
+__global__ __launch_bounds__(OGC_WAVE) void ball_query_grid_kernel(int n, int m, float radius2, int nsample,
+                                                                   int hit_cap, int stride_cells,
+                                                                   const float *__restrict__ xyz,
+                                                                   const GridHdr *__restrict__ hdrs,
+                                                                   const int *__restrict__ cell_start,
+                                                                   const float4 *__restrict__ sorted_pts,
+                                                                   int *__restrict__ idx_out) {
+    extern __shared__ __attribute__((aligned(16))) int gq_smem[];
+    ball_query_grid_body(blockIdx.x * QPW, gq_smem, n, m, radius2, nsample, hit_cap, stride_cells, xyz, hdrs, cell_start,
+                         sorted_pts, idx_out);
+}
+
+// ---- the same query with FOUR lanes per centre, for sparse neighbourhoods -----------------------------------------------
+// ball_query_grid_kernel deals the candidates of eight centres' common box to the 64 lanes and tests every centre against
+// every lane: with the ~60 candidates and 12 hits per centre of the loss's shape (8192 points in 60 x 4 x 80, r = 2) most
+// of its ~780 vector instructions per wavefront are bookkeeping — nine-run position lookups, a ballot, a scalar branch and
+// a slot computation per (centre, round), scalar broadcasts of the centres, a quadratic rank sort through LDS.  Here a
+// wavefront takes SIXTEEN centres consecutive in cell order and each gets four lanes, which walk the centre's own nine
+// runs (the three cells around it in x of each of the 3 x 3 rows): lane s tests candidates s and s + 4 of a run with one
+// packed distance, a hit's list slot is a population count over the group's bits of the two ballots, and a miss is
+// stored to a spare slot instead of branching.  Lists of up to BQ_FAST hits are then sorted IN REGISTERS by a bitonic
+// network over 4 lanes x 8 keys (exchanges at distance < 8 inside a lane, the others by quad permutations) and the
+// rows leave straight from the registers — no loop, no LDS round trip after two reads.  The rows are those of the
+// reference's index-ordered scan, as with the other kernel.  A wavefront with a longer list, and every wavefront of a
+// cloud the build flagged dense or heavy, runs the general body above (twice: eight centres each).
+constexpr int CL = 4;                 // lanes per centre
+constexpr int CPW = OGC_WAVE / CL;    // centres per wavefront
+constexpr int BQ_FAST = 32;           // hits per centre the register sort holds
+constexpr int BQ_LIST = BQ_FAST + 4;  // list stride (slot BQ_FAST takes the misses)
+constexpr int BQ_PAD = 16;            // records readable past the end of the cell-sorted array
+constexpr int BQ_CAP = 64;            // hit list of the general body when run from here
+
+template <int R>
+__device__ __forceinline__ int quad_bcast(int v) { // lane R of every group of four lanes
+    return __builtin_amdgcn_update_dpp(0, v, R * 0x55, 0xF, 0xF, true);
+}
+
+template <int NS>
+__global__ __launch_bounds__(OGC_WAVE, 8) void ball_query_cells_kernel(int n, int m, float radius2, int stride_cells,
+                                                                       const float *__restrict__ xyz,
+                                                                       const GridHdr *__restrict__ hdrs,
+                                                                       const int *__restrict__ cell_start,
+                                                                       const float4 *__restrict__ sorted_pts,
+                                                                       int *__restrict__ idx_out) {
+    extern __shared__ __attribute__((aligned(16))) int gq_smem[];
+    const int lane = threadIdx.x, b = blockIdx.y, sub = lane & (CL - 1), g = lane >> 2;
+    OGC_PROBE_T(pt0);
+    const GridHdr h = hdrs[b];
+    bool general = h.dense != 0 || h.heavy != 0;
+    if (!general) {
+        const int *cs = cell_start + (size_t)b * stride_cells;
+        const float4 *pts = sorted_pts + (size_t)b * n;
+        const int pc = blockIdx.x * CPW + g;
+        float4 me = make_float4(NAN, NAN, NAN, __int_as_float(-1));
+        if (pc < n) me = pts[pc]; // positions >= h.npts hold the non-finite points: no hits, an all-zero row
+        const bool live = pc < h.npts;
+        int *mine = gq_smem + g * BQ_LIST;
+        {   // every list starts as BQ_FAST +inf keys: the sort reads all of them
+            const int4 inf4 = make_int4(0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff);
+            int4 *l4 = reinterpret_cast<int4 *>(mine + sub * (BQ_FAST / CL));
+#pragma unroll
+            for (int i = 0; i < BQ_FAST / CL / 4; ++i) l4[i] = inf4;
+        }
+        // the centre's cell, as the build computed it (a live centre is finite: the conversion saturates where cell_coord
+        // clamps, and the clamp to the grid follows either way)
+        const int cx = min(max((int)floorf((me.x - h.minx) * h.inv_h), 0), h.gx - 1);
+        const int cy = min(max((int)floorf((me.y - h.miny) * h.inv_h), 0), h.gy - 1);
+        const int cz = min(max((int)floorf((me.z - h.minz) * h.inv_h), 0), h.gz - 1);
+        const int x0 = max(cx - 1, 0), x1 = min(cx + 1, h.gx - 1);
+        // run r = the cells x0 .. x1 of row (cy + r % 3 - 1, cz + r / 3 - 1): lane s fetches runs s and s + 4, all fetch run 8
+        // (no branch around the loads and all six in flight together: rows outside the grid read a clamped row and get
+        // length 0 afterwards)
+        auto row_of = [&](int r, bool &inside) {
+            const int r3 = r / 3;
+            const int y = cy + (r - 3 * r3) - 1, z = cz + r3 - 1;
+            inside = live && y >= 0 && y < h.gy && z >= 0 && z < h.gz;
+            return h.gx * (min(max(y, 0), h.gy - 1) + h.gy * min(max(z, 0), h.gz - 1));
+        };
+        bool in_a, in_b, in_c;
+        const int row_a = row_of(sub, in_a), row_b = row_of(sub + 4, in_b), row_c = row_of(8, in_c);
+        int lo_a = cs[row_a + x0], end_a = cs[row_a + x1 + 1];
+        int lo_b = cs[row_b + x0], end_b = cs[row_b + x1 + 1];
+        int lo_c = cs[row_c + x0], end_c = cs[row_c + x1 + 1];
+        asm volatile("" : "+v"(lo_a), "+v"(end_a), "+v"(lo_b), "+v"(end_b), "+v"(lo_c), "+v"(end_c));
+        const int len_a = in_a ? end_a - lo_a : 0, len_b = in_b ? end_b - lo_b : 0, len_c = in_c ? end_c - lo_c : 0;
+
+        int cnt = 0; // hits of my centre (the same number in its four lanes)
+        const unsigned below_a = (1u << sub) - 1u, below_b = 0xFu | (below_a << 4);
+        const int shift = CL * g;
+        // in_* / near_*: a candidate exists at that position / lies inside the ball.  The masks come straight from the
+        // comparisons (a ballot of their conjunction is lowered through a 0/1 register and a third comparison).
+        auto slots = [&](bool has_a, bool near_a, bool has_b, bool near_b, int ia, int ib) {
+            const unsigned long long ma = __builtin_amdgcn_ballot_w64(has_a) & __builtin_amdgcn_ballot_w64(near_a);
+            const unsigned long long mb = __builtin_amdgcn_ballot_w64(has_b) & __builtin_amdgcn_ballot_w64(near_b);
+            const unsigned bits = ((unsigned)(ma >> shift) & 0xFu) | (((unsigned)(mb >> shift) & 0xFu) << 4);
+            const int sa = cnt + __popc(bits & below_a), sb = cnt + __popc(bits & below_b);
+            mine[(has_a && near_a) ? min(sa, BQ_FAST) : BQ_FAST] = ia;
+            mine[(has_b && near_b) ? min(sb, BQ_FAST) : BQ_FAST] = ib;
+            cnt += __popc(bits);
+        };
+        const char *pts_bytes = reinterpret_cast<const char *>(pts);
+        auto record = [&](int position) { // (positions past the end of a run are read — the array is padded — and discarded)
+            return *reinterpret_cast<const float4 *>(pts_bytes + ((unsigned)position << 4));
+        };
+        // three runs at a time: six candidate loads in flight per lane
+#pragma unroll
+        for (int r0 = 0; r0 < 9; r0 += 3) {
+            int lo[3], hi[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int r = r0 + i;
+                const int l = r == 0 ? quad_bcast<0>(lo_a) : r == 1 ? quad_bcast<1>(lo_a) : r == 2 ? quad_bcast<2>(lo_a)
+                            : r == 3 ? quad_bcast<3>(lo_a) : r == 4 ? quad_bcast<0>(lo_b) : r == 5 ? quad_bcast<1>(lo_b)
+                            : r == 6 ? quad_bcast<2>(lo_b) : r == 7 ? quad_bcast<3>(lo_b) : lo_c;
+                const int w = r == 0 ? quad_bcast<0>(len_a) : r == 1 ? quad_bcast<1>(len_a) : r == 2 ? quad_bcast<2>(len_a)
+                            : r == 3 ? quad_bcast<3>(len_a) : r == 4 ? quad_bcast<0>(len_b) : r == 5 ? quad_bcast<1>(len_b)
+                            : r == 6 ? quad_bcast<2>(len_b) : r == 7 ? quad_bcast<3>(len_b) : len_c;
+                lo[i] = l;
+                hi[i] = l + w;
+            }
+            float4 ca[3], cb[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                ca[i] = record(lo[i] + sub);
+                cb[i] = record(lo[i] + sub + CL);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const ogc_v2f d = sqdist_pair(ogc_v2f{ca[i].x, cb[i].x}, ogc_v2f{ca[i].y, cb[i].y}, ogc_v2f{ca[i].z, cb[i].z},
+                                              me.x, me.y, me.z);
+                const int p = lo[i] + sub;
+                slots(p < hi[i], d.x < radius2, p + CL < hi[i], d.y < radius2, __float_as_int(ca[i].w), __float_as_int(cb[i].w));
+                // a run longer than eight candidates (wave-uniform test)
+                int pp = p + 2 * CL;
+                while (__builtin_amdgcn_ballot_w64(pp < hi[i]) != 0ull) {
+                    const float4 a = record(min(pp, n - 1)), c2 = record(min(pp + CL, n - 1));
+                    const ogc_v2f d2 = sqdist_pair(ogc_v2f{a.x, c2.x}, ogc_v2f{a.y, c2.y}, ogc_v2f{a.z, c2.z}, me.x, me.y, me.z);
+                    slots(pp < hi[i], d2.x < radius2, pp + CL < hi[i], d2.y < radius2, __float_as_int(a.w), __float_as_int(c2.w));
+                    pp += 2 * CL;
+                }
+            }
+        }
+        OGC_PROBE_T(pt1);
+        general = __builtin_amdgcn_ballot_w64(cnt > BQ_FAST) != 0ull;
+        if (!general) {
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            const int4 k0 = *reinterpret_cast<const int4 *>(mine + sub * 8);
+            const int4 k1 = *reinterpret_cast<const int4 *>(mine + sub * 8 + 4);
+            int x[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w};
+            // bitonic network, element e = 8 * lane + register, every exchange ascending (each merge starts with the
+            // "flip" e <-> e ^ (k - 1), then half-cleaners e <-> e ^ j)
+#define OGC_BQ_INTRA(MASK)                                                  \
+            _Pragma("unroll") for (int r_ = 0; r_ < 8; ++r_)                \
+                if ((r_ ^ (MASK)) > r_) {                                   \
+                    const int lo_ = min(x[r_], x[r_ ^ (MASK)]);             \
+                    x[r_ ^ (MASK)] = max(x[r_], x[r_ ^ (MASK)]);            \
+                    x[r_] = lo_;                                            \
+                }
+            // partner = register (r ^ RMASK) of the lane given by the quad permutation QP; the lower lane keeps the minimum
+#define OGC_BQ_INTER(QP, RMASK, UPPER)                                                                  \
+            {                                                                                           \
+                int p_[8];                                                                              \
+                _Pragma("unroll") for (int r_ = 0; r_ < 8; ++r_)                                        \
+                    p_[r_] = __builtin_amdgcn_update_dpp(0, x[r_ ^ (RMASK)], QP, 0xF, 0xF, true);       \
+                _Pragma("unroll") for (int r_ = 0; r_ < 8; ++r_)                                        \
+                    x[r_] = (UPPER) ? max(x[r_], p_[r_]) : min(x[r_], p_[r_]);                          \
+            }
+            const bool odd = (sub & 1) != 0, high = (sub & 2) != 0;
+            OGC_BQ_INTRA(1)                                                     // runs of 2
+            OGC_BQ_INTRA(3) OGC_BQ_INTRA(1)                                     // 4
+            OGC_BQ_INTRA(7) OGC_BQ_INTRA(2) OGC_BQ_INTRA(1)                     // 8
+            OGC_BQ_INTER(0xB1, 7, odd) OGC_BQ_INTRA(4) OGC_BQ_INTRA(2) OGC_BQ_INTRA(1)                              // 16: lane ^ 1
+            OGC_BQ_INTER(0x1B, 7, high) OGC_BQ_INTER(0xB1, 0, odd) OGC_BQ_INTRA(4) OGC_BQ_INTRA(2) OGC_BQ_INTRA(1)  // 32: lane ^ 3, ^ 1
+#undef OGC_BQ_INTRA
+#undef OGC_BQ_INTER
+            const int q = __float_as_int(me.w);
+            const int kept = min(cnt, NS);
+            const int first = cnt > 0 ? quad_bcast<0>(x[0]) : 0;
+            OGC_PROBE_T(pf2);
+            if (q >= 0) {
+                int *o = idx_out + ((size_t)b * m + q) * NS;
+                // lane L holds the sorted entries 8 L .. 8 L + 7.  Stores in which the group's four lanes cover 64
+                // CONTIGUOUS bytes need lane L to write entries 4 L .. 4 L + 3 (then 16 + 4 L ..): an exchange inside the
+                // quad (a store instruction whose lanes write every other 16 bytes leaves half-written lines everywhere)
+                int v[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v[r] = sub * 8 + r < kept ? x[r] : first;
+                int s1[4], s2[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int a1 = __builtin_amdgcn_update_dpp(0, v[r], 0x50, 0xF, 0xF, true);     // quad_perm [0,0,1,1]
+                    const int b1 = __builtin_amdgcn_update_dpp(0, v[r + 4], 0x50, 0xF, 0xF, true);
+                    const int a2 = __builtin_amdgcn_update_dpp(0, v[r], 0xFA, 0xF, 0xF, true);     // quad_perm [2,2,3,3]
+                    const int b2 = __builtin_amdgcn_update_dpp(0, v[r + 4], 0xFA, 0xF, 0xF, true);
+                    s1[r] = odd ? b1 : a1;
+                    s2[r] = odd ? b2 : a2;
+                }
+                const int j0 = sub * 4;
+                if (j0 < NS) *reinterpret_cast<int4 *>(o + j0) = make_int4(s1[0], s1[1], s1[2], s1[3]);
+                if (16 + j0 < NS) *reinterpret_cast<int4 *>(o + 16 + j0) = make_int4(s2[0], s2[1], s2[2], s2[3]);
+                const int4 pad = make_int4(first, first, first, first);
+#pragma unroll
+                for (int j = BQ_FAST; j < NS; j += 16) *reinterpret_cast<int4 *>(o + j + j0) = pad;
+            }
+            OGC_PROBE_T(pf3);
+            OGC_PROBE_ADD(16, pt0, pt1);
+            OGC_PROBE_ADD(18, pt1, pf2);
+            OGC_PROBE_ADD(19, pf2, pf3);
+            return;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier(); // the general body reuses the LDS
+    }
+#pragma unroll 1
+    for (int half = 0; half < CPW / QPW; ++half)
+        ball_query_grid_body(blockIdx.x * CPW + half * QPW, gq_smem, n, m, radius2, NS, BQ_CAP, stride_cells, xyz, hdrs,
+                             cell_start, sorted_pts, idx_out);
 }
 
 typedef unsigned long long u64;
@@ -902,6 +1156,12 @@ __global__ __launch_bounds__(OGC_WAVE) void knn_grid_kernel(int n, int m, int k,
 
 using namespace ogc_grid;
 
+// OGC_BQ_CELLS=0 in the environment: the general kernel for every row length (A/B runs, tests of both kernels)
+static bool ogc_bq_cells_enabled() {
+    const char *e = getenv("OGC_BQ_CELLS");
+    return !(e && e[0] == '0');
+}
+
 int ogc_ball_query_grid(int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz,
                         int *idx, hipStream_t s) {
     // hit slots per centre: the smallest list that holds a full row keeps the LDS footprint at ~5 KiB per wavefront,
@@ -915,15 +1175,27 @@ int ogc_ball_query_grid(int b, int n, int m, float radius, int nsample, const fl
     const int stride_cells = GRID_MAX_CELLS + 1;
     const size_t bytes_hdr = (sizeof(GridHdr) * b + 255) / 256 * 256;
     const size_t bytes_cs = (sizeof(int) * (size_t)b * stride_cells + 255) / 256 * 256;
-    const size_t bytes_pts = sizeof(float4) * (size_t)b * n;
+    const size_t bytes_pts = sizeof(float4) * ((size_t)b * n + BQ_PAD);
     char *ws = static_cast<char *>(ogc_workspace(s, bytes_hdr + bytes_cs + bytes_pts));
     if (!ws) return OGC_ERR_UNSUPPORTED;
     GridHdr *hdrs = reinterpret_cast<GridHdr *>(ws);
     int *cell_start = reinterpret_cast<int *>(ws + bytes_hdr);
     float4 *sorted_pts = reinterpret_cast<float4 *>(ws + bytes_hdr + bytes_cs);
     launch_grid_build(b, n, radius, 0, stride_cells, xyz, hdrs, cell_start, sorted_pts, s);
-    hipLaunchKernelGGL(ball_query_grid_kernel, dim3(ogc_divup(n, QPW), b), dim3(OGC_WAVE), lds, s, n, m,
-                       radius * radius, nsample, hit_cap, stride_cells, xyz, hdrs, cell_start, sorted_pts, idx);
+    // four lanes per centre for the usual row lengths; the general kernel (eight centres per wavefront) otherwise
+    const size_t lds_body = ((size_t)QPW * (BQ_CAP + nsample) + (size_t)(n + 31) / 32) * sizeof(int);
+    const size_t lds4 = lds_body > sizeof(int) * CPW * BQ_LIST ? lds_body : sizeof(int) * CPW * BQ_LIST;
+    const dim3 grid4(ogc_divup(n, CPW), b);
+#define OGC_BQ_CELLS(NS)                                                                                              \
+    hipLaunchKernelGGL(ball_query_cells_kernel<NS>, grid4, dim3(OGC_WAVE), lds4, s, n, m, radius * radius, stride_cells, xyz, \
+                       hdrs, cell_start, sorted_pts, idx)
+    if (nsample == 64 && ogc_bq_cells_enabled()) OGC_BQ_CELLS(64);
+    else if (nsample == 32 && ogc_bq_cells_enabled()) OGC_BQ_CELLS(32);
+    else if (nsample == 16 && ogc_bq_cells_enabled()) OGC_BQ_CELLS(16);
+    else
+        hipLaunchKernelGGL(ball_query_grid_kernel, dim3(ogc_divup(n, QPW), b), dim3(OGC_WAVE), lds, s, n, m,
+                           radius * radius, nsample, hit_cap, stride_cells, xyz, hdrs, cell_start, sorted_pts, idx);
+#undef OGC_BQ_CELLS
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         ogc_set_error("ogc_ball_query (grid): launch failed: %s", hipGetErrorString(e));

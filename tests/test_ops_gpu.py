@@ -594,10 +594,21 @@ GRID_BQ_CASES = [  # (n, m_or_None(same set), nsample, radius, scale)
 ]
 
 
+GRID_BQ_CASES += [  # the four-lanes-per-centre kernel (nsample 16 / 32 / 64): lists around its register sort's 32 keys, so that
+    # some wavefronts finish there and others fall back to the general body; rows shorter than the lists; a cloud size
+    # that is no multiple of the sixteen centres of a wavefront
+    (8192, None, 64, 3.0, (60, 4, 80)), (8192, None, 32, 2.6, (60, 4, 80)), (8191, None, 16, 2.0, (60, 4, 80)),
+    (4099, None, 32, 0.09, (1, 1, 1)), (2048, None, 16, 4.0, (60, 4, 80)),
+]
+
+
+@pytest.mark.parametrize("cells", ["1", "0"])
 @pytest.mark.parametrize("n,m,ns,r,scale", GRID_BQ_CASES)
-def test_ball_query_grid_path_bit_exact(nat, oracle, n, m, ns, r, scale):
+def test_ball_query_grid_path_bit_exact(nat, oracle, monkeypatch, n, m, ns, r, scale, cells):
     """The cell-list path (n >= 1024) must reproduce the brute-force semantics exactly, including the
-    first-nsample-in-index-order rule, duplicates, points outside the query set's extent and non-finite points."""
+    first-nsample-in-index-order rule, duplicates, points outside the query set's extent and non-finite points — with
+    either query kernel (OGC_BQ_CELLS=0: the general one for every row length)."""
+    monkeypatch.setenv("OGC_BQ_CELLS", cells)
     rng = np.random.default_rng(n + ns)
     xyz = cloud(rng, 2, n, scale=scale, dup=n // 7)
     if m is None:
@@ -615,8 +626,10 @@ def test_ball_query_grid_path_bit_exact(nat, oracle, n, m, ns, r, scale):
     assert np.array_equal(idx.cpu().numpy(), oracle.ball_query(r, ns, xyz, new))
 
 
-def test_ball_query_grid_clustered(nat, oracle):
+@pytest.mark.parametrize("cells", ["1", "0"])
+def test_ball_query_grid_clustered(nat, oracle, monkeypatch, cells):
     """Strongly non-uniform density (a LiDAR-like cloud: dense near the origin) and a flat (2-D) cloud."""
+    monkeypatch.setenv("OGC_BQ_CELLS", cells)
     rng = np.random.default_rng(99)
     rad = rng.random((2, 8192, 1), dtype=np.float32) ** 3 * 60
     ang = rng.random((2, 8192, 1), dtype=np.float32) * 2 * np.pi
