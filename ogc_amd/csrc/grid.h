@@ -8,7 +8,7 @@ struct GridHdr { // one per cloud, written by grid_build_kernel
     float minx, miny, minz, inv_h;
     int gx, gy, gz, npts; // npts = points with finite coordinates (the ones inserted)
     int dense;            // 1: the 27-cell neighbourhood holds a large share of the cloud -> all-pairs scan instead
-    int heavy;            // 1: ~100 or more candidates per centre: lists too long for ball_query_cells_kernel's register sort
+    int heavy;            // 1: 120 or more candidates per centre: lists too long for ball_query_cells_kernel's register sort
     int pad[2];
 };
 

@@ -52,6 +52,12 @@ __device__ __forceinline__ int cell_coord(float x, float mn, float inv_h, int g)
     return (int)f;
 }
 
+// max(floor((x - mn) * inv_h), 0) as an int, for a FINITE x: the cell coordinate before the clamp to the grid's upper edge
+// (the median keeps the conversion in range; a NaN — a centre that is no point of the grid — gives 0)
+__device__ __forceinline__ int cell_floor(float x, float mn, float inv_h) {
+    return (int)__builtin_amdgcn_fmed3f(floorf((x - mn) * inv_h), 0.0f, 1.0e9f);
+}
+
 // Grid parameters from the bounding box (every thread computes them redundantly: no serial section, no broadcast).
 __device__ __forceinline__ GridHdr grid_header(const float (&lo)[3], const float (&hi)[3], int n, float radius,
                                                int knn_k, float knn_div) {
@@ -131,12 +137,27 @@ __global__ __launch_bounds__(BUILD_THREADS) void grid_build_kernel(float knn_div
             mx[0] = fmaxf(mx[0], x); mx[1] = fmaxf(mx[1], y); mx[2] = fmaxf(mx[2], z);
         }
     };
+    // (PPT > 0: thread t owns the points t * PPT .. t * PPT + PPT - 1 — 3 PPT consecutive floats, read as 16-byte
+    // loads when the cloud's size and base allow it: 6 loads instead of 24 strided ones for PPT = 8)
     if (PPT > 0) {
+        const bool wide = PPT % 4 == 0 && (n & 3) == 0 && (((size_t)(const void *)pts) & 15) == 0;
+        if (wide && (t + 1) * R <= n) {
+            float f[3 * R];
+            const float4 *p4 = reinterpret_cast<const float4 *>(pts + (size_t)t * R * 3);
 #pragma unroll
-        for (int i = 0; i < R; ++i) {
-            const int k = t + i * BUILD_THREADS;
-            px[i] = py[i] = pz[i] = NAN;
-            if (k < n) { px[i] = pts[k * 3]; py[i] = pts[k * 3 + 1]; pz[i] = pts[k * 3 + 2]; }
+            for (int i = 0; i < 3 * R / 4; ++i) {
+                const float4 v = p4[i];
+                f[4 * i] = v.x; f[4 * i + 1] = v.y; f[4 * i + 2] = v.z; f[4 * i + 3] = v.w;
+            }
+#pragma unroll
+            for (int i = 0; i < R; ++i) { px[i] = f[3 * i]; py[i] = f[3 * i + 1]; pz[i] = f[3 * i + 2]; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                const int k = t * R + i;
+                px[i] = py[i] = pz[i] = NAN;
+                if (k < n) { px[i] = pts[k * 3]; py[i] = pts[k * 3 + 1]; pz[i] = pts[k * 3 + 2]; }
+            }
         }
     }
     for (int c = t; c < GRID_MAX_CELLS; c += BUILD_THREADS) s_cnt[c] = 0; // overlaps the loads
@@ -171,19 +192,20 @@ __global__ __launch_bounds__(BUILD_THREADS) void grid_build_kernel(float knn_div
     OGC_PROBE_BUILD(3);
     GridHdr h = s_hdr;
     const int ncell = h.gx * h.gy * h.gz;
+    // (a finite coordinate: the float -> int conversion saturates where cell_coord clamps to [-2, g + 1], and the clamp to
+    // the grid follows either way — the same cell, without cell_coord's two branches per axis)
     auto cell_of = [&](float x, float y, float z) -> int {
-        if (!(isfinite(x) && isfinite(y) && isfinite(z))) return -1;
-        const int cx = min(max(cell_coord(x, h.minx, h.inv_h, h.gx), 0), h.gx - 1);
-        const int cy = min(max(cell_coord(y, h.miny, h.inv_h, h.gy), 0), h.gy - 1);
-        const int cz = min(max(cell_coord(z, h.minz, h.inv_h, h.gz), 0), h.gz - 1);
-        return cx + h.gx * (cy + h.gy * cz);
+        const int cx = min(cell_floor(x, h.minx, h.inv_h), h.gx - 1);
+        const int cy = min(cell_floor(y, h.miny, h.inv_h), h.gy - 1);
+        const int cz = min(cell_floor(z, h.minz, h.inv_h), h.gz - 1);
+        return (isfinite(x) && isfinite(y) && isfinite(z)) ? cx + h.gx * (cy + h.gy * cz) : -1;
     };
 
     // 2. histogram (LDS atomics)
     if (PPT > 0) {
 #pragma unroll
         for (int i = 0; i < R; ++i) {
-            cell[i] = (t + i * BUILD_THREADS < n) ? cell_of(px[i], py[i], pz[i]) : -2;
+            cell[i] = (t * R + i < n) ? cell_of(px[i], py[i], pz[i]) : -2;
             if (cell[i] >= 0) atomicAdd(&s_cnt[cell[i]], 1);
         }
     } else {
@@ -233,7 +255,9 @@ __global__ __launch_bounds__(BUILD_THREADS) void grid_build_kernel(float knn_div
         // stops after nsample hits) while a cell-ordered scan cannot.
         const double per_query = 27.0 * (double)npts / (double)ncell;
         h.dense = per_query > 0.25 * (double)n ? 1 : 0;
-        h.heavy = per_query > 100.0 ? 1 : 0;
+        // ball_query_cells_kernel sorts lists of up to 32 hits: with full cells around it a centre has ~0.15 * per_query hits
+        // (ball / 27 cells), so beyond a mean of ~18 too many wavefronts would have to repeat their work in the general body
+        h.heavy = per_query > 120.0 ? 1 : 0;
         hdrs[b] = h;
     }
     __syncthreads();
@@ -247,7 +271,7 @@ __global__ __launch_bounds__(BUILD_THREADS) void grid_build_kernel(float knn_div
     if (PPT > 0) {
 #pragma unroll
         for (int i = 0; i < R; ++i) {
-            const int k = t + i * BUILD_THREADS;
+            const int k = t * R + i;
             if (cell[i] >= 0) sp[atomicAdd(&s_cnt[cell[i]], 1)] = make_float4(px[i], py[i], pz[i], __int_as_float(k));
             else if (cell[i] == -1) sp[atomicAdd(&s_tail, 1)] = make_float4(NAN, NAN, NAN, __int_as_float(k));
         }
@@ -590,9 +614,9 @@ __global__ __launch_bounds__(OGC_WAVE) void ball_query_grid_kernel(int n, int m,
 constexpr int CL = 4;                 // lanes per centre
 constexpr int CPW = OGC_WAVE / CL;    // centres per wavefront
 constexpr int BQ_FAST = 32;           // hits per centre the register sort holds
-constexpr int BQ_LIST = BQ_FAST + 4;  // list stride (slot BQ_FAST takes the misses)
+constexpr int BQ_CAP = 64;            // hit slots per centre (slot BQ_CAP takes the misses; also the general body's lists)
+constexpr int BQ_LIST = BQ_CAP + 4;   // list stride
 constexpr int BQ_PAD = 16;            // records readable past the end of the cell-sorted array
-constexpr int BQ_CAP = 64;            // hit list of the general body when run from here
 
 template <int R>
 __device__ __forceinline__ int quad_bcast(int v) { // lane R of every group of four lanes
@@ -627,9 +651,9 @@ __global__ __launch_bounds__(OGC_WAVE, 8) void ball_query_cells_kernel(int n, in
         }
         // the centre's cell, as the build computed it (a live centre is finite: the conversion saturates where cell_coord
         // clamps, and the clamp to the grid follows either way)
-        const int cx = min(max((int)floorf((me.x - h.minx) * h.inv_h), 0), h.gx - 1);
-        const int cy = min(max((int)floorf((me.y - h.miny) * h.inv_h), 0), h.gy - 1);
-        const int cz = min(max((int)floorf((me.z - h.minz) * h.inv_h), 0), h.gz - 1);
+        const int cx = min(cell_floor(me.x, h.minx, h.inv_h), h.gx - 1);
+        const int cy = min(cell_floor(me.y, h.miny, h.inv_h), h.gy - 1);
+        const int cz = min(cell_floor(me.z, h.minz, h.inv_h), h.gz - 1);
         const int x0 = max(cx - 1, 0), x1 = min(cx + 1, h.gx - 1);
         // run r = the cells x0 .. x1 of row (cy + r % 3 - 1, cz + r / 3 - 1): lane s fetches runs s and s + 4, all fetch run 8
         // (no branch around the loads and all six in flight together: rows outside the grid read a clamped row and get
@@ -658,8 +682,8 @@ __global__ __launch_bounds__(OGC_WAVE, 8) void ball_query_cells_kernel(int n, in
             const unsigned long long mb = __builtin_amdgcn_ballot_w64(has_b) & __builtin_amdgcn_ballot_w64(near_b);
             const unsigned bits = ((unsigned)(ma >> shift) & 0xFu) | (((unsigned)(mb >> shift) & 0xFu) << 4);
             const int sa = cnt + __popc(bits & below_a), sb = cnt + __popc(bits & below_b);
-            mine[(has_a && near_a) ? min(sa, BQ_FAST) : BQ_FAST] = ia;
-            mine[(has_b && near_b) ? min(sb, BQ_FAST) : BQ_FAST] = ib;
+            mine[(has_a && near_a) ? min(sa, BQ_CAP) : BQ_CAP] = ia;
+            mine[(has_b && near_b) ? min(sb, BQ_CAP) : BQ_CAP] = ib;
             cnt += __popc(bits);
         };
         const char *pts_bytes = reinterpret_cast<const char *>(pts);
@@ -706,7 +730,7 @@ __global__ __launch_bounds__(OGC_WAVE, 8) void ball_query_cells_kernel(int n, in
             }
         }
         OGC_PROBE_T(pt1);
-        general = __builtin_amdgcn_ballot_w64(cnt > BQ_FAST) != 0ull;
+        general = __builtin_amdgcn_ballot_w64(cnt > BQ_CAP) != 0ull;
         if (!general) {
             __builtin_amdgcn_s_waitcnt(0xc07f);
             __builtin_amdgcn_wave_barrier();
@@ -742,9 +766,9 @@ __global__ __launch_bounds__(OGC_WAVE, 8) void ball_query_cells_kernel(int n, in
             const int q = __float_as_int(me.w);
             const int kept = min(cnt, NS);
             const int first = cnt > 0 ? quad_bcast<0>(x[0]) : 0;
+            int *o = idx_out + ((size_t)b * m + max(q, 0)) * NS;
             OGC_PROBE_T(pf2);
-            if (q >= 0) {
-                int *o = idx_out + ((size_t)b * m + q) * NS;
+            if (cnt <= BQ_FAST && q >= 0) {
                 // lane L holds the sorted entries 8 L .. 8 L + 7.  Stores in which the group's four lanes cover 64
                 // CONTIGUOUS bytes need lane L to write entries 4 L .. 4 L + 3 (then 16 + 4 L ..): an exchange inside the
                 // quad (a store instruction whose lanes write every other 16 bytes leaves half-written lines everywhere)
@@ -767,6 +791,33 @@ __global__ __launch_bounds__(OGC_WAVE, 8) void ball_query_cells_kernel(int n, in
                 const int4 pad = make_int4(first, first, first, first);
 #pragma unroll
                 for (int j = BQ_FAST; j < NS; j += 16) *reinterpret_cast<int4 *>(o + j + j0) = pad;
+            }
+            // lists of 33 .. BQ_CAP hits (rare where this kernel is used), one at a time by the WHOLE wavefront: lane e takes
+            // element e, its rank is #{f : hits[f] < hits[e]} (distinct indices) from broadcast 16-byte reads of the list,
+            // entries are stored one by one.  (Four lanes doing this for their own centre take ~10 us, and so does sending
+            // the wavefront through the general body: the kernel ends with its slowest wavefront.)
+            unsigned long long big = __builtin_amdgcn_ballot_w64(sub == 0 && cnt > BQ_FAST);
+            while (big != 0ull) {
+                const int src = __ffsll((long long)big) - 1;
+                big &= big - 1ull;
+                const int cc = lane_bcast(cnt, src), qq = lane_bcast(q, src);
+                int *list = gq_smem + (src >> 2) * BQ_LIST;
+                if (lane < 4) list[cc + lane] = 0x7fffffff; // sentinels: the 16-byte reads run past the end
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
+                const int ve = lane < cc ? list[lane] : 0x7fffffff;
+                int rank = 0;
+                for (int f = 0; f < cc; f += 4) {
+                    const int4 w = *reinterpret_cast<const int4 *>(list + f);
+                    rank += (w.x < ve ? 1 : 0) + (w.y < ve ? 1 : 0) + (w.z < ve ? 1 : 0) + (w.w < ve ? 1 : 0);
+                }
+                const unsigned long long zero = __builtin_amdgcn_ballot_w64(lane < cc && rank == 0);
+                const int lowest = lane_bcast(ve, __ffsll((long long)zero) - 1);
+                if (qq >= 0) {
+                    int *oc = idx_out + ((size_t)b * m + qq) * NS;
+                    if (lane < cc && rank < NS) oc[rank] = ve;
+                    if (cc + lane < NS) oc[cc + lane] = lowest;
+                }
             }
             OGC_PROBE_T(pf3);
             OGC_PROBE_ADD(16, pt0, pt1);

@@ -46,6 +46,11 @@ int main(int argc, char **argv) {
             tb += a;
         }
         hipEventRecord(e0, s);
+        for (int i = 0; i < IT; ++i) launch_grid_build(B, N, radius, 0, stride_cells, xyz, hdrs, cell_start, sorted_pts, s);
+        hipEventRecord(e1, s); hipStreamSynchronize(s);
+        float bb; hipEventElapsedTime(&bb, e0, e1);
+        printf("build back to back: %.2f us per launch\n", bb / IT * 1e3);
+        hipEventRecord(e0, s);
         for (int i = 0; i < IT; ++i) ogc_ball_query_grid(B, N, N, radius, NS, xyz, xyz, idx, s);
         hipEventRecord(e1, s); hipStreamSynchronize(s);
         float a; hipEventElapsedTime(&a, e0, e1);
