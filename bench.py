@@ -31,13 +31,14 @@ FP32_MFMA_PEAK_TF = 157.3  # v_mfma_f32_16x16x4_f32 / 32x32x2_f32: the fp32 matr
 # Numbers NOT measured by this run: PMC counter readings of earlier profiling passes, kept with the file they came from.
 # (rocprofv3 --pmc cannot run inside the timed region; `roofline.traffic` is the one field the contract asks for.)
 OFFLINE = {
-    "ball_query_traffic_bytes": {"shape": [16, 8192, 8192, 64], "bytes": int((8653.8 + 855.6 + 32768 + 2199.5) * 1024),
+    "ball_query_traffic_bytes": {"shape": [16, 8192, 8192, 64], "bytes": int((8915.8 + 859.7 + 32768 + 2199.5) * 1024),
                                  "source": "profiles/r02_ball_query_pmc.txt (FETCH_SIZE + WRITE_SIZE of grid_build_kernel + "
-                                           "ball_query_grid_kernel, separate rocprofv3 --pmc passes; FETCH_SIZE as reported — "
+                                           "ball_query_cells_kernel<64>, separate rocprofv3 --pmc passes; FETCH_SIZE as reported — "
                                            "these kernels issue 12-16 byte gathers, not the wide streams the x2 gfx950 "
                                            "correction applies to)"},
-    "ball_query_valu_issue": {"kernel": "ball_query_grid_kernel", "wave_insts_valu": 12.84e6, "wave_insts_salu": 6.30e6,
-                              "kernel_us": 29.6, "peak_ginst_s": 614.4, "frac_of_issue_peak": round(12.84e6 / 29.6e-6 / 614.4e9, 3),
+    "ball_query_valu_issue": {"kernel": "ball_query_cells_kernel<64>", "wave_insts_valu": 8.58e6, "wave_insts_salu": 1.44e6,
+                              "kernel_us": 21.55, "peak_ginst_s": 614.4, "frac_of_issue_peak": round(8.58e6 / 21.55e-6 / 614.4e9, 3),
+                              "general_kernel": {"kernel": "ball_query_grid_kernel", "wave_insts_valu": 12.84e6, "kernel_us": 29.6},
                               "source": "profiles/r02_ball_query_pmc.txt"},
     "knn_clamped_valu_issue": {"kernel": "knn_grid_kernel<1> (radius-limited)", "source": "profiles/r02_knn_clamped_pmc.txt"},
     "step_traffic_mib": {"fetch_reported": 14922.5, "write": 12373.3,
@@ -270,7 +271,7 @@ def main():
             b_, n_, m_, _r, ns_ = bq[0][1][:5]
             alg = b_ * (12 * m_ + 12 * n_ + 4 * m_ * ns_)            # 12M + 12N + 4M*nsample per cloud
             gbs = alg / (ms * 1e-3) / 1e9
-            roof = {"kernel": "ogc_ball_query (grid_build_kernel + ball_query_grid_kernel)",
+            roof = {"kernel": "ogc_ball_query (grid_build_kernel + ball_query_cells_kernel<64>)",
                     "bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(gbs / HBM_PEAK_GBS, 5),
                     "traffic": (OFFLINE["ball_query_traffic_bytes"]["bytes"]
