@@ -167,6 +167,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        from ogc_amd.utils.dist_util import pin_rank_to_cores
+        pin_rank_to_cores()  # before the GPU runtime starts its helper threads: they inherit the block
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)

@@ -104,3 +104,30 @@ def data_parallel(module, process_group=None):
     if dist.is_available() and dist.is_initialized():
         return FlatDataParallel(module, process_group)
     return module
+
+
+def core_block(allowed, local_rank, local_world):
+    """The CPUs rank `local_rank` of `local_world` ranks on this host keeps: a contiguous block of the sorted allowed set
+    (at least one CPU; every rank a different block while there are enough of them)."""
+    cpus = sorted(allowed)
+    per = max(1, len(cpus) // max(1, local_world))
+    start = (local_rank * per) % len(cpus)
+    return set(cpus[start:start + per])
+
+
+def pin_rank_to_cores():
+    """One process per GPU, each with ONE hot thread: the step's ~600 launches take the launch thread 10-12 ms, about what
+    the GPU needs for the kernels of a C4 step, so a launch thread that is migrated between sockets or shares a core with
+    another rank's becomes the bottleneck of that rank (and, through the all-reduce, of all of them).  With more than one
+    rank on the host every rank keeps to its own block of the allowed CPUs (blocks in rank order: on the usual two-socket
+    hosts that is also the socket its GPU hangs on).  OGC_PIN_CORES=0 leaves the affinity alone.  Returns the block or None."""
+    import os
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+    if local_world <= 1 or os.environ.get("OGC_PIN_CORES", "1") == "0" or not hasattr(os, "sched_setaffinity"):
+        return None
+    block = core_block(os.sched_getaffinity(0), int(os.environ.get("LOCAL_RANK", "0")), local_world)
+    try:
+        os.sched_setaffinity(0, block)
+    except OSError:
+        return None
+    return block

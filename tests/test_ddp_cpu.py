@@ -129,3 +129,15 @@ def test_flat_data_parallel_with_rank_dependent_unused_parameters(tmp_path):
         assert torch.equal(g["a"], torch.full((3,), 2.0))
         assert torch.equal(g["b"], torch.full((2, 2), 1.5))
         assert torch.equal(g["c"], torch.full((5,), 3.5))
+
+
+def test_core_blocks_of_the_ranks_of_a_host():
+    """utils/dist_util.core_block: the ranks of a host keep to disjoint contiguous blocks of the allowed CPUs (one hot launch
+    thread per rank); fewer CPUs than ranks still gives every rank one."""
+    from ogc_amd.utils.dist_util import core_block
+    allowed = set(range(4, 100))          # a cpuset that does not start at 0
+    blocks = [core_block(allowed, r, 8) for r in range(8)]
+    assert all(len(b) == 12 for b in blocks) and len(set().union(*blocks)) == 96
+    assert blocks[0] == set(range(4, 16)) and blocks[7] == set(range(88, 100))
+    assert [core_block({0, 1, 2}, r, 8) for r in range(8)] == [{0}, {1}, {2}, {0}, {1}, {2}, {0}, {1}]
+    assert core_block({5}, 0, 1) == {5}
