@@ -940,7 +940,7 @@ __device__ __forceinline__ int knn_first_block(const float4 *__restrict__ pts, c
 // MODE 0: squared distances (ogc_knn).  MODE 1: sqrt + radius clamp of the indices (ogc_knn_clamped).
 constexpr int KNN_FLAT_CAP = 192; // positions of the first shell kept as one flat list per query (else: run by run)
 template <int MODE>
-__global__ __launch_bounds__(OGC_WAVE) void knn_grid_kernel(int n, int m, int k, float radius, float lim2, int stride_cells,
+__global__ __launch_bounds__(OGC_WAVE, 4) void knn_grid_kernel(int n, int m, int k, float radius, float lim2, int stride_cells,
                                                             const float *__restrict__ unknown,
                                                             const GridHdr *__restrict__ hdrs,
                                                             const int *__restrict__ cell_start,
