@@ -40,7 +40,7 @@ OFFLINE = {
                               "kernel_us": 21.55, "peak_ginst_s": 614.4, "frac_of_issue_peak": round(8.58e6 / 21.55e-6 / 614.4e9, 3),
                               "general_kernel": {"kernel": "ball_query_grid_kernel", "wave_insts_valu": 12.84e6, "kernel_us": 29.6},
                               "source": "profiles/r02_ball_query_pmc.txt"},
-    "knn_clamped_valu_issue": {"kernel": "knn_grid_kernel<1> (radius-limited)", "source": "profiles/r02_knn_clamped_pmc.txt"},
+    "knn_clamped_valu_issue": {"kernel": "knn_cells_kernel<32> + knn_grid_kernel<1> (deferred)", "source": "profiles/r02_knn_clamped_pmc.txt"},
     "step_traffic_mib": {"fetch_reported": 14922.5, "write": 12373.3,
                          "source": "profiles/r01_step_hbm_traffic_v20.txt (round-1 kernels; per-kernel table of one C4 step)"},
 }
@@ -112,7 +112,8 @@ def measure_extras(pc, a):
     ms_c = _time(lambda: nat.knn_clamped_wrapper(B, N, N, k, r, pc, pc, d, i))
     ms_p = _time(lambda: nat.knn_wrapper(B, N, N, k, pc, pc, d, i))
     out["roofline_knn"] = {
-        "kernel": "ogc_knn_clamped (grid_build_kernel + knn_grid_kernel<1>): the smoothness term's k-NN, k=%d clamped at %g m" % (k, r),
+        "kernel": "ogc_knn_clamped (grid_build_kernel + knn_cells_kernel<%d> + knn_grid_kernel<1> for the rows it leaves): the smoothness "
+                  "term's k-NN, k=%d clamped at %g m" % (k, k, r),
         "bound": "hbm", "achieved": round(alg / ms_c / 1e6, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(alg / ms_c / 1e6 / HBM_PEAK_GBS, 5), "avg_ms": round(ms_c, 4), "algorithmic_bytes": alg,
         "shape": {"B": B, "n": N, "m": N, "k": k, "radius": r},

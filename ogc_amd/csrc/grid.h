@@ -9,7 +9,8 @@ struct GridHdr { // one per cloud, written by grid_build_kernel
     int gx, gy, gz, npts; // npts = points with finite coordinates (the ones inserted)
     int dense;            // 1: the 27-cell neighbourhood holds a large share of the cloud -> all-pairs scan instead
     int heavy;            // 1: 120 or more candidates per centre: lists too long for ball_query_cells_kernel's register sort
-    int pad[2];
+    int knn_general;      // k-NN builds: 1 = knn_cells_kernel leaves this cloud to knn_grid_kernel (cells shorter than the radius, or crowded)
+    int pending;          // set by knn_cells_kernel when it left rows of this cloud to knn_grid_kernel (marked idx[row][0] = -1)
 };
 
 } // namespace ogc_grid

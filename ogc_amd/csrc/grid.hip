@@ -60,8 +60,9 @@ __device__ __forceinline__ int cell_floor(float x, float mn, float inv_h) {
 
 // Grid parameters from the bounding box (every thread computes them redundantly: no serial section, no broadcast).
 __device__ __forceinline__ GridHdr grid_header(const float (&lo)[3], const float (&hi)[3], int n, float radius,
-                                               int knn_k, float knn_div) {
+                                               int knn_k, float knn_div, int prefer_cells) {
     GridHdr h;
+    bool cells_ok = false;
     const bool any = lo[0] <= hi[0];
     double ext[3];
     for (int a = 0; a < 3; ++a) ext[a] = any ? (double)hi[a] - (double)lo[a] : 0.0;
@@ -87,6 +88,17 @@ __device__ __forceinline__ GridHdr grid_header(const float (&lo)[3], const float
             const double one_per_cell = pow(vol / (double)max(n, 1), 1.0 / (double)dims);
             const double limited = fmax((double)radius * 1.01, one_per_cell);
             if (limited < edge) edge = limited;
+            // A radius-limited search of the cloud in itself (prefer_cells): when a ball holds few points (mean <= 18 at the
+            // mean density) knn_cells_kernel finds them all in the 27 cells of edge 1.01 r around a query and sorts them in
+            // registers — the ball query's grid, far fewer candidates than the shells of the density-based one.
+            if (prefer_cells && radius < 1.0e18f) {
+                const double r = (double)radius;
+                const double ball = dims == 3 ? 4.18879 * r * r * r : (dims == 2 ? 3.14159 * r * r : 2.0 * r);
+                if ((double)n * ball <= 18.0 * vol) {
+                    edge = fmax(edge, r * 1.01); // (no finer than the density asks for: the build's cost grows with the cell count)
+                    cells_ok = true;
+                }
+            }
         }
     }
     if (!(edge > 0.0) || !isfinite(edge)) edge = fmax(maxext, 1.0);      // degenerate: one cell per axis
@@ -104,7 +116,8 @@ __device__ __forceinline__ GridHdr grid_header(const float (&lo)[3], const float
     h.npts = 0;
     h.dense = 0;
     h.heavy = 0;
-    h.pad[0] = h.pad[1] = 0;
+    h.knn_general = cells_ok ? 0 : 1;
+    h.pending = 0;
     return h;
 }
 
@@ -112,7 +125,8 @@ __device__ __forceinline__ GridHdr grid_header(const float (&lo)[3], const float
 // is read from memory once; PPT == 0: any size, the three passes re-read the cloud.  Five barriers in all: the
 // bounding box and the cell-count scan are wave-level (DPP / shuffles) with one 16-entry exchange through LDS each.
 template <int PPT>
-__global__ __launch_bounds__(BUILD_THREADS) void grid_build_kernel(float knn_div, int n, float radius, int knn_k, int stride_cells,
+__global__ __launch_bounds__(BUILD_THREADS) void grid_build_kernel(float knn_div, int n, float radius, int knn_k, int prefer_cells,
+                                                                   int stride_cells,
                                                                    const float *__restrict__ xyz,
                                                                    GridHdr *__restrict__ hdrs,
                                                                    int *__restrict__ cell_start,
@@ -186,7 +200,7 @@ __global__ __launch_bounds__(BUILD_THREADS) void grid_build_kernel(float knn_div
             lo[a] = -ogc_wave_max_f32(-l);
             hi[a] = ogc_wave_max_f32(u);
         }
-        if (lane == 0) s_hdr = grid_header(lo, hi, n, radius, knn_k, knn_div);
+        if (lane == 0) s_hdr = grid_header(lo, hi, n, radius, knn_k, knn_div, prefer_cells);
     }
     __syncthreads();
     OGC_PROBE_BUILD(3);
@@ -258,6 +272,9 @@ __global__ __launch_bounds__(BUILD_THREADS) void grid_build_kernel(float knn_div
         // ball_query_cells_kernel sorts lists of up to 32 hits: with full cells around it a centre has ~0.15 * per_query hits
         // (ball / 27 cells), so beyond a mean of ~18 too many wavefronts would have to repeat their work in the general body
         h.heavy = per_query > 120.0 ? 1 : 0;
+        // knn_cells_kernel (radius-limited search over the 27 cells around a query) needs cells at least as long as the radius —
+        // the same bound knn_grid_kernel stops its shells with — and lists that fit its register sort
+        if (!(1.0f * (1.0f / h.inv_h) * 0.999f >= radius) || per_query > 120.0) h.knn_general = 1;
         hdrs[b] = h;
     }
     __syncthreads();
@@ -287,16 +304,16 @@ __global__ __launch_bounds__(BUILD_THREADS) void grid_build_kernel(float knn_div
 }
 
 static void launch_grid_build(int b, int n, float radius, int knn_k, int stride_cells, const float *xyz, GridHdr *hdrs,
-                              int *cell_start, float4 *sorted_pts, hipStream_t s) {
+                              int *cell_start, float4 *sorted_pts, hipStream_t s, int prefer_cells = 0) {
     const float knn_div = 33.5f; // points per cell = k / 33.5: cell edge = half the expected k-th neighbour distance
     if (n <= 8 * BUILD_THREADS)
-        hipLaunchKernelGGL(grid_build_kernel<8>, dim3(b), dim3(BUILD_THREADS), 0, s, knn_div, n, radius, knn_k, stride_cells, xyz,
+        hipLaunchKernelGGL(grid_build_kernel<8>, dim3(b), dim3(BUILD_THREADS), 0, s, knn_div, n, radius, knn_k, prefer_cells, stride_cells, xyz,
                            hdrs, cell_start, sorted_pts);
     else if (n <= 16 * BUILD_THREADS)
-        hipLaunchKernelGGL(grid_build_kernel<16>, dim3(b), dim3(BUILD_THREADS), 0, s, knn_div, n, radius, knn_k, stride_cells,
+        hipLaunchKernelGGL(grid_build_kernel<16>, dim3(b), dim3(BUILD_THREADS), 0, s, knn_div, n, radius, knn_k, prefer_cells, stride_cells,
                            xyz, hdrs, cell_start, sorted_pts);
     else
-        hipLaunchKernelGGL(grid_build_kernel<0>, dim3(b), dim3(BUILD_THREADS), 0, s, knn_div, n, radius, knn_k, stride_cells, xyz,
+        hipLaunchKernelGGL(grid_build_kernel<0>, dim3(b), dim3(BUILD_THREADS), 0, s, knn_div, n, radius, knn_k, prefer_cells, stride_cells, xyz,
                            hdrs, cell_start, sorted_pts);
 }
 
@@ -941,7 +958,7 @@ __device__ __forceinline__ int knn_first_block(const float4 *__restrict__ pts, c
 constexpr int KNN_FLAT_CAP = 192; // positions of the first shell kept as one flat list per query (else: run by run)
 template <int MODE>
 __global__ __launch_bounds__(OGC_WAVE, 4) void knn_grid_kernel(int n, int m, int k, float radius, float lim2, int stride_cells,
-                                                            const float *__restrict__ unknown,
+                                                            int deferred, const float *__restrict__ unknown,
                                                             const GridHdr *__restrict__ hdrs,
                                                             const int *__restrict__ cell_start,
                                                             const float4 *__restrict__ sorted_pts,
@@ -952,8 +969,12 @@ __global__ __launch_bounds__(OGC_WAVE, 4) void knn_grid_kernel(int n, int m, int
     u64 *kept = kq_smem + (size_t)qi * k;           // [QPW][k]
     u64 *outk = kq_smem + (size_t)(QPW + qi) * k;   // [QPW][k]
     int *flat = reinterpret_cast<int *>(kq_smem + (size_t)2 * QPW * k); // [QPW][KNN_FLAT_CAP] positions of the first shell
-    const int p = blockIdx.x * QPW + qi;
     const GridHdr h = hdrs[b];
+    // deferred: knn_cells_kernel ran first.  It did every row of a cloud it could take except the rows it marked with
+    // idx[row][0] = -1 (a list longer than its register sort), and nothing of a cloud flagged knn_general.
+    if (deferred && !h.knn_general && !h.pending) return;
+    int p = blockIdx.x * QPW + qi;
+    if (deferred && !h.knn_general && p < n && idx_out[((size_t)b * n + p) * k] != -1) p = n; // done already: no work, no output
     const int *cs = cell_start + (size_t)b * stride_cells;
     const float4 *pts = sorted_pts + (size_t)b * m;
     const unsigned below = (1u << sub) - 1u;
@@ -1203,9 +1224,211 @@ __global__ __launch_bounds__(OGC_WAVE, 4) void knn_grid_kernel(int n, int m, int
     }
 }
 
+// ---- radius-limited k-NN of a cloud in itself with FOUR lanes per query ---------------------------------------------------
+// ogc_knn_clamped(pc, pc) with a radius (the smoothness term's lists, losses/seg_loss_unsup.py:150: k = 32 within 1 m — about 3
+// of the ~10 candidates the 27 cells hold): a neighbour beyond the radius is replaced by the nearest one whatever it is, so the
+// row is "the points within the radius, ascending by (distance, index), first K of them, the rest = the first".  That is the
+// ball query's traversal with another sort key: the structure of ball_query_cells_kernel — sixteen queries (= points, in cell
+// order) per wavefront, four lanes each walking the query's nine runs, slots from the ballots' bits, lists of up to 32 keys
+// sorted in registers (64-bit keys here) and stored straight from the registers.  knn_grid_kernel, launched after it in
+// `deferred` mode, does what is left: rows marked idx[row][0] = -1 (more than 32 points within the radius) and whole clouds
+// the build flagged knn_general (cells shorter than the radius, crowded cells).  Same results as knn_grid_kernel alone.
+constexpr int KQ_LIST = BQ_FAST + 4; // keys per list (slot BQ_FAST takes the misses)
+
+template <int K>
+__global__ __launch_bounds__(OGC_WAVE, 8) void knn_cells_kernel(int n, float lim2, int stride_cells, GridHdr *__restrict__ hdrs,
+                                                                const int *__restrict__ cell_start,
+                                                                const float4 *__restrict__ sorted_pts,
+                                                                float *__restrict__ dist_out, int *__restrict__ idx_out) {
+    extern __shared__ __attribute__((aligned(16))) u64 kc_smem[];
+    const int lane = threadIdx.x, b = blockIdx.y, sub = lane & (CL - 1), g = lane >> 2;
+    const GridHdr h = hdrs[b];
+    if (h.knn_general) return;
+    const int *cs = cell_start + (size_t)b * stride_cells;
+    const float4 *pts = sorted_pts + (size_t)b * n;
+    const int pc = blockIdx.x * CPW + g;
+    float4 me = make_float4(NAN, NAN, NAN, __int_as_float(-1));
+    if (pc < n) me = pts[pc]; // positions >= h.npts hold the non-finite points: nobody within the radius
+    const bool live = pc < h.npts;
+    u64 *mine = kc_smem + g * KQ_LIST;
+    {   // every list starts as BQ_FAST +inf keys: the sort reads all of them
+        const int4 inf4 = make_int4(-1, -1, -1, -1);
+        int4 *l4 = reinterpret_cast<int4 *>(mine + sub * (BQ_FAST / CL));
+#pragma unroll
+        for (int i = 0; i < BQ_FAST / CL / 2; ++i) l4[i] = inf4;
+    }
+    const int cx = min(cell_floor(me.x, h.minx, h.inv_h), h.gx - 1);
+    const int cy = min(cell_floor(me.y, h.miny, h.inv_h), h.gy - 1);
+    const int cz = min(cell_floor(me.z, h.minz, h.inv_h), h.gz - 1);
+    const int x0 = max(cx - 1, 0), x1 = min(cx + 1, h.gx - 1);
+    auto row_of = [&](int r, bool &inside) {
+        const int r3 = r / 3;
+        const int y = cy + (r - 3 * r3) - 1, z = cz + r3 - 1;
+        inside = live && y >= 0 && y < h.gy && z >= 0 && z < h.gz;
+        return h.gx * (min(max(y, 0), h.gy - 1) + h.gy * min(max(z, 0), h.gz - 1));
+    };
+    bool in_a, in_b, in_c;
+    const int row_a = row_of(sub, in_a), row_b = row_of(sub + 4, in_b), row_c = row_of(8, in_c);
+    int lo_a = cs[row_a + x0], end_a = cs[row_a + x1 + 1];
+    int lo_b = cs[row_b + x0], end_b = cs[row_b + x1 + 1];
+    int lo_c = cs[row_c + x0], end_c = cs[row_c + x1 + 1];
+    asm volatile("" : "+v"(lo_a), "+v"(end_a), "+v"(lo_b), "+v"(end_b), "+v"(lo_c), "+v"(end_c));
+    const int len_a = in_a ? end_a - lo_a : 0, len_b = in_b ? end_b - lo_b : 0, len_c = in_c ? end_c - lo_c : 0;
+
+    int cnt = 0; // points within the radius of my query (the same number in its four lanes)
+    const unsigned below_a = (1u << sub) - 1u, below_b = 0xFu | (below_a << 4);
+    const int shift = CL * g;
+    auto slots = [&](bool has_a, bool near_a, bool has_b, bool near_b, u64 ka, u64 kb) {
+        const unsigned long long ma = __builtin_amdgcn_ballot_w64(has_a) & __builtin_amdgcn_ballot_w64(near_a);
+        const unsigned long long mb = __builtin_amdgcn_ballot_w64(has_b) & __builtin_amdgcn_ballot_w64(near_b);
+        const unsigned bits = ((unsigned)(ma >> shift) & 0xFu) | (((unsigned)(mb >> shift) & 0xFu) << 4);
+        const int sa = cnt + __popc(bits & below_a), sb = cnt + __popc(bits & below_b);
+        mine[(has_a && near_a) ? min(sa, BQ_FAST) : BQ_FAST] = ka;
+        mine[(has_b && near_b) ? min(sb, BQ_FAST) : BQ_FAST] = kb;
+        cnt += __popc(bits);
+    };
+    const char *pts_bytes = reinterpret_cast<const char *>(pts);
+    auto record = [&](int position) { // (positions past the end of a run are read — the array is padded — and discarded)
+        return *reinterpret_cast<const float4 *>(pts_bytes + ((unsigned)position << 4));
+    };
+    auto key_of = [](float d, float w) { return ((u64)__float_as_uint(d) << 32) | (unsigned)__float_as_int(w); };
+#pragma unroll
+    for (int r0 = 0; r0 < 9; r0 += 3) {
+        int lo[3], hi[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int r = r0 + i;
+            const int l = r == 0 ? quad_bcast<0>(lo_a) : r == 1 ? quad_bcast<1>(lo_a) : r == 2 ? quad_bcast<2>(lo_a)
+                        : r == 3 ? quad_bcast<3>(lo_a) : r == 4 ? quad_bcast<0>(lo_b) : r == 5 ? quad_bcast<1>(lo_b)
+                        : r == 6 ? quad_bcast<2>(lo_b) : r == 7 ? quad_bcast<3>(lo_b) : lo_c;
+            const int w = r == 0 ? quad_bcast<0>(len_a) : r == 1 ? quad_bcast<1>(len_a) : r == 2 ? quad_bcast<2>(len_a)
+                        : r == 3 ? quad_bcast<3>(len_a) : r == 4 ? quad_bcast<0>(len_b) : r == 5 ? quad_bcast<1>(len_b)
+                        : r == 6 ? quad_bcast<2>(len_b) : r == 7 ? quad_bcast<3>(len_b) : len_c;
+            lo[i] = l;
+            hi[i] = l + w;
+        }
+        float4 ca[3], cb[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            ca[i] = record(lo[i] + sub);
+            cb[i] = record(lo[i] + sub + CL);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            // (query - candidate) squared, summed as (x + y) + z: the expression of knn_grid_kernel / the reference, per half
+            const ogc_v2f d = sqdist_pair(ogc_v2f{ca[i].x, cb[i].x}, ogc_v2f{ca[i].y, cb[i].y}, ogc_v2f{ca[i].z, cb[i].z},
+                                          me.x, me.y, me.z);
+            const int p = lo[i] + sub;
+            slots(p < hi[i], d.x <= lim2, p + CL < hi[i], d.y <= lim2, key_of(d.x, ca[i].w), key_of(d.y, cb[i].w));
+            int pp = p + 2 * CL;
+            while (__builtin_amdgcn_ballot_w64(pp < hi[i]) != 0ull) { // a run longer than eight candidates
+                const float4 a = record(min(pp, n - 1)), c2 = record(min(pp + CL, n - 1));
+                const ogc_v2f d2 = sqdist_pair(ogc_v2f{a.x, c2.x}, ogc_v2f{a.y, c2.y}, ogc_v2f{a.z, c2.z}, me.x, me.y, me.z);
+                slots(pp < hi[i], d2.x <= lim2, pp + CL < hi[i], d2.y <= lim2, key_of(d2.x, a.w), key_of(d2.y, c2.w));
+                pp += 2 * CL;
+            }
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    const int q = __float_as_int(me.w);
+    if (cnt > BQ_FAST) { // more keys than the register sort holds: the row goes to knn_grid_kernel
+        if (sub == 0 && q >= 0) {
+            idx_out[((size_t)b * n + q) * K] = -1;
+            hdrs[b].pending = 1;
+        }
+    }
+    u64 x[8];
+    {
+        const int4 *l4 = reinterpret_cast<const int4 *>(mine + sub * 8);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int4 v = l4[i];
+            x[2 * i] = ((u64)(unsigned)v.y << 32) | (unsigned)v.x;
+            x[2 * i + 1] = ((u64)(unsigned)v.w << 32) | (unsigned)v.z;
+        }
+    }
+    // bitonic network over 4 lanes x 8 keys, element e = 8 * lane + register, every exchange ascending (see ball_query_cells_kernel)
+#define OGC_KQ_INTRA(MASK)                                                  \
+    _Pragma("unroll") for (int r_ = 0; r_ < 8; ++r_)                        \
+        if ((r_ ^ (MASK)) > r_) {                                           \
+            const u64 a_ = x[r_], b_ = x[r_ ^ (MASK)];                      \
+            x[r_] = a_ < b_ ? a_ : b_;                                      \
+            x[r_ ^ (MASK)] = a_ < b_ ? b_ : a_;                             \
+        }
+#define OGC_KQ_INTER(QP, RMASK, UPPER)                                                                              \
+    {                                                                                                               \
+        u64 p_[8];                                                                                                  \
+        _Pragma("unroll") for (int r_ = 0; r_ < 8; ++r_) {                                                          \
+            const u64 v_ = x[r_ ^ (RMASK)];                                                                         \
+            const unsigned lo_ = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)v_, QP, 0xF, 0xF, true);   \
+            const unsigned hi_ = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(v_ >> 32), QP, 0xF, 0xF, true); \
+            p_[r_] = ((u64)hi_ << 32) | lo_;                                                                        \
+        }                                                                                                           \
+        _Pragma("unroll") for (int r_ = 0; r_ < 8; ++r_) {                                                          \
+            const bool mine_less_ = x[r_] < p_[r_];                                                                 \
+            x[r_] = (mine_less_ != (UPPER)) ? x[r_] : p_[r_];                                                       \
+        }                                                                                                           \
+    }
+    const bool odd = (sub & 1) != 0, high = (sub & 2) != 0;
+    OGC_KQ_INTRA(1)
+    OGC_KQ_INTRA(3) OGC_KQ_INTRA(1)
+    OGC_KQ_INTRA(7) OGC_KQ_INTRA(2) OGC_KQ_INTRA(1)
+    OGC_KQ_INTER(0xB1, 7, odd) OGC_KQ_INTRA(4) OGC_KQ_INTRA(2) OGC_KQ_INTRA(1)
+    OGC_KQ_INTER(0x1B, 7, high) OGC_KQ_INTER(0xB1, 0, odd) OGC_KQ_INTRA(4) OGC_KQ_INTRA(2) OGC_KQ_INTRA(1)
+#undef OGC_KQ_INTRA
+#undef OGC_KQ_INTER
+    const int kept = min(cnt, K);
+    const int first = cnt > 0 ? quad_bcast<0>((int)(unsigned)x[0]) : 0;
+    // entry j: (sqrt(d2), index) for j < kept, else (+inf, first).  Lane L holds entries 8 L .. 8 L + 7; it writes entries
+    // 4 L .. 4 L + 3 and 16 + 4 L .. (64 contiguous bytes per row and store): an exchange inside the quad.
+    int vi[8];
+    float vd[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const bool real = sub * 8 + r < kept;
+        vi[r] = real ? (int)(unsigned)x[r] : first;
+        vd[r] = real ? sqrtf(__uint_as_float((unsigned)(x[r] >> 32))) : INFINITY;
+    }
+    int i1[4], i2[4];
+    float d1[4], d2[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int ia1 = __builtin_amdgcn_update_dpp(0, vi[r], 0x50, 0xF, 0xF, true), ib1 = __builtin_amdgcn_update_dpp(0, vi[r + 4], 0x50, 0xF, 0xF, true);
+        const int ia2 = __builtin_amdgcn_update_dpp(0, vi[r], 0xFA, 0xF, 0xF, true), ib2 = __builtin_amdgcn_update_dpp(0, vi[r + 4], 0xFA, 0xF, 0xF, true);
+        const int da1 = __builtin_amdgcn_update_dpp(0, __float_as_int(vd[r]), 0x50, 0xF, 0xF, true);
+        const int db1 = __builtin_amdgcn_update_dpp(0, __float_as_int(vd[r + 4]), 0x50, 0xF, 0xF, true);
+        const int da2 = __builtin_amdgcn_update_dpp(0, __float_as_int(vd[r]), 0xFA, 0xF, 0xF, true);
+        const int db2 = __builtin_amdgcn_update_dpp(0, __float_as_int(vd[r + 4]), 0xFA, 0xF, 0xF, true);
+        i1[r] = odd ? ib1 : ia1;
+        i2[r] = odd ? ib2 : ia2;
+        d1[r] = __int_as_float(odd ? db1 : da1);
+        d2[r] = __int_as_float(odd ? db2 : da2);
+    }
+    if (q >= 0 && cnt <= BQ_FAST) {
+        const size_t base = ((size_t)b * n + q) * K;
+        const int j0 = sub * 4;
+        if (j0 < K) {
+            *reinterpret_cast<int4 *>(idx_out + base + j0) = make_int4(i1[0], i1[1], i1[2], i1[3]);
+            *reinterpret_cast<float4 *>(dist_out + base + j0) = make_float4(d1[0], d1[1], d1[2], d1[3]);
+        }
+        if (16 + j0 < K) {
+            *reinterpret_cast<int4 *>(idx_out + base + 16 + j0) = make_int4(i2[0], i2[1], i2[2], i2[3]);
+            *reinterpret_cast<float4 *>(dist_out + base + 16 + j0) = make_float4(d2[0], d2[1], d2[2], d2[3]);
+        }
+    }
+}
+
 } // namespace ogc_grid
 
 using namespace ogc_grid;
+
+// OGC_KNN_CELLS=0 in the environment: knn_grid_kernel alone (A/B runs, tests of both paths)
+static bool ogc_knn_cells_enabled() {
+    const char *e = getenv("OGC_KNN_CELLS");
+    return !(e && e[0] == '0');
+}
 
 // OGC_BQ_CELLS=0 in the environment: the general kernel for every row length (A/B runs, tests of both kernels)
 static bool ogc_bq_cells_enabled() {
@@ -1263,13 +1486,18 @@ int ogc_knn_grid(int mode, int b, int n, int m, int k, float radius, const float
     const int stride_cells = GRID_MAX_CELLS + 1;
     const size_t bytes_hdr = (sizeof(GridHdr) * b + 255) / 256 * 256;
     const size_t bytes_cs = (sizeof(int) * (size_t)b * stride_cells + 255) / 256 * 256;
-    const size_t bytes_pts = sizeof(float4) * (size_t)b * m;
+    const size_t bytes_pts = sizeof(float4) * ((size_t)b * m + BQ_PAD);
     char *ws = static_cast<char *>(ogc_workspace(s, bytes_hdr + bytes_cs + bytes_pts));
     if (!ws) return OGC_ERR_UNSUPPORTED;
     GridHdr *hdrs = reinterpret_cast<GridHdr *>(ws);
     int *cell_start = reinterpret_cast<int *>(ws + bytes_hdr);
     float4 *sorted_pts = reinterpret_cast<float4 *>(ws + bytes_hdr + bytes_cs);
-    launch_grid_build(b, m, mode == 1 ? radius : 0.0f, k, stride_cells, known, hdrs, cell_start, sorted_pts, s);
+    // radius-limited search of a cloud in itself (the smoothness term's neighbour lists): four lanes per query over the 27 cells
+    // around it first (the build then prefers cells of edge 1.01 r when balls are sparsely filled); knn_grid_kernel afterwards
+    // only does what that kernel left (marked rows, clouds flagged knn_general)
+    const bool cells = mode == 1 && radius > 0.0f && radius < 1.0e18f && unknown == known && n == m && (k == 16 || k == 32) &&
+                       ogc_knn_cells_enabled();
+    launch_grid_build(b, m, mode == 1 ? radius : 0.0f, k, stride_cells, known, hdrs, cell_start, sorted_pts, s, cells ? 1 : 0);
     dim3 grid(ogc_divup(n, QPW), b);
     // d2 <= lim2  <=>  sqrtf(d2) <= radius: the largest float whose correctly rounded root does not exceed the radius
     float lim2 = INFINITY;
@@ -1281,11 +1509,23 @@ int ogc_knn_grid(int mode, int b, int n, int m, int k, float radius, const float
             if (up < INFINITY && sqrtf(up) <= radius) lim2 = up;
         }
     }
+    int deferred = 0;
+    if (cells) {
+        const dim3 grid4(ogc_divup(n, CPW), b);
+        const size_t lds4 = sizeof(u64) * CPW * KQ_LIST;
+        if (k == 32)
+            hipLaunchKernelGGL(knn_cells_kernel<32>, grid4, dim3(OGC_WAVE), lds4, s, n, lim2, stride_cells, hdrs, cell_start,
+                               sorted_pts, dist, idx);
+        else
+            hipLaunchKernelGGL(knn_cells_kernel<16>, grid4, dim3(OGC_WAVE), lds4, s, n, lim2, stride_cells, hdrs, cell_start,
+                               sorted_pts, dist, idx);
+        deferred = 1;
+    }
     if (mode == 1)
-        hipLaunchKernelGGL(knn_grid_kernel<1>, grid, dim3(OGC_WAVE), lds, s, n, m, k, radius, lim2, stride_cells, unknown,
+        hipLaunchKernelGGL(knn_grid_kernel<1>, grid, dim3(OGC_WAVE), lds, s, n, m, k, radius, lim2, stride_cells, deferred, unknown,
                            hdrs, cell_start, sorted_pts, dist, idx);
     else
-        hipLaunchKernelGGL(knn_grid_kernel<0>, grid, dim3(OGC_WAVE), lds, s, n, m, k, radius, lim2, stride_cells, unknown,
+        hipLaunchKernelGGL(knn_grid_kernel<0>, grid, dim3(OGC_WAVE), lds, s, n, m, k, radius, lim2, stride_cells, 0, unknown,
                            hdrs, cell_start, sorted_pts, dist, idx);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

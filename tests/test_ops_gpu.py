@@ -168,6 +168,38 @@ def test_knn_clamped_radius_limited_edge_cases(nat, oracle, case):
     assert np.array_equal(dist.cpu().numpy()[ok], dr[ok])
 
 
+SELF_KNN_CASES = [  # (n, k, r, scale, dup): ogc_knn_clamped(pc, pc) — the four-lanes-per-query kernel + the deferred general pass
+    (8192, 32, 1.0, (60, 4, 80), 0),        # the C4 smoothness term: ~3 points within the radius
+    (8191, 32, 2.0, (60, 4, 80), 1000),     # lists around 12, duplicates (ties broken by index), size no multiple of 16
+    (4096, 16, 2.6, (60, 4, 80), 0),        # more points within the radius than k: the k nearest of up to 32
+    (8192, 32, 3.2, (60, 4, 80), 0),        # lists around the register sort's 32 keys: some rows left to knn_grid_kernel
+    (4099, 16, 0.09, (1, 1, 1), 50), (2048, 32, 6.0, (60, 4, 80), 0),   # crowded cells: the whole cloud goes to knn_grid_kernel
+    (3000, 32, 0.01, (60, 4, 80), 0),       # nobody but the query itself
+    (5000, 16, 1.5, (60, 0, 80), 0),        # a flat cloud
+]
+
+
+@pytest.mark.parametrize("cells", ["1", "0"])
+@pytest.mark.parametrize("n,k,r,scale,dup", SELF_KNN_CASES)
+def test_knn_clamped_of_a_cloud_in_itself(nat, oracle, monkeypatch, n, k, r, scale, dup, cells):
+    """Same tensor as queries and points (the loss's call): knn_cells_kernel takes the rows it can, knn_grid_kernel (deferred)
+    the rest; OGC_KNN_CELLS=0 is knn_grid_kernel alone.  Both must equal knn + clamp of the oracle, bit for bit."""
+    monkeypatch.setenv("OGC_KNN_CELLS", cells)
+    rng = np.random.default_rng(n + k)
+    pc = cloud(rng, 2, n, scale=scale, dup=dup)
+    pc[1, 5] = np.nan
+    pc[1, 77, 1] = np.inf
+    t = T(pc)
+    dist = torch.full((2, n, k), -5.0, device=DEV)
+    idx = torch.full((2, n, k), -7, dtype=torch.int32, device=DEV)
+    nat.knn_clamped_wrapper(2, n, n, k, r, t, t, dist, idx)
+    dr, ir = _clamped_reference(oracle, k, r, pc, pc)
+    ok = ~(np.isnan(pc).any(-1) | np.isinf(pc).any(-1))      # non-finite queries: the reference's rows are unspecified garbage
+    assert np.array_equal(idx.cpu().numpy()[ok], ir[ok])
+    assert np.array_equal(dist.cpu().numpy()[ok], dr[ok])
+    assert int(idx.min()) >= 0                                # no marker of the deferred pass is left behind
+
+
 @pytest.mark.parametrize("n,m", [(37, 50), (1000, 3), (8192, 2048), (1, 2), (513, 1)])
 def test_three_nn_bit_exact(nat, oracle, n, m):
     rng = np.random.default_rng(n + m)
