@@ -58,6 +58,13 @@ __device__ __forceinline__ int cell_floor(float x, float mn, float inv_h) {
     return (int)__builtin_amdgcn_fmed3f(floorf((x - mn) * inv_h), 0.0f, 1.0e9f);
 }
 
+// v^(1/dims) for the cell edge, in single precision (the edge only steers how many candidates a search meets — any positive
+// value gives the same results — and a double-precision pow on the one lane that derives the grid costs microseconds)
+__device__ __forceinline__ double dims_root(double v, int dims) {
+    const float f = (float)v;
+    return dims == 1 ? (double)f : (dims == 2 ? (double)sqrtf(f) : (double)cbrtf(f));
+}
+
 // Grid parameters from the bounding box (every thread computes them redundantly: no serial section, no broadcast).
 __device__ __forceinline__ GridHdr grid_header(const float (&lo)[3], const float (&hi)[3], int n, float radius,
                                                int knn_k, float knn_div, int prefer_cells) {
@@ -79,13 +86,13 @@ __device__ __forceinline__ GridHdr grid_header(const float (&lo)[3], const float
         // search then ends after the 5^d block (R = 2), ~3.7 k candidates in 3-D, where an edge of 0.73 r_k (the former
         // 2.5 k points per 3^d block) also needed R = 2 but scanned 11.6 k
         const double per_cell = fmax((double)knn_k / (dims == 3 ? (double)knn_div : (dims == 2 ? 12.6 : 4.0)), 0.5);
-        edge = dims > 0 ? pow(vol * per_cell / (double)max(n, 1), 1.0 / (double)dims) : 1.0;
+        edge = dims > 0 ? dims_root(vol * per_cell / (double)max(n, 1), dims) : 1.0;
         // radius-clamped search (ogc_knn_clamped): neighbours beyond `radius` are replaced by the nearest one anyway,
         // so the search may stop once the scanned block covers the radius.  When the radius is SHORTER than the
         // density-based edge, cells of edge 1.01 r make that one shell of far fewer candidates (but never less than
         // ~one point per cell: the nearest neighbour of a query in an empty region must still be found by shells).
         if (radius > 0.0f && radius < 3.0e38f && dims > 0) {
-            const double one_per_cell = pow(vol / (double)max(n, 1), 1.0 / (double)dims);
+            const double one_per_cell = dims_root(vol / (double)max(n, 1), dims);
             const double limited = fmax((double)radius * 1.01, one_per_cell);
             if (limited < edge) edge = limited;
             // A radius-limited search of the cloud in itself (prefer_cells): when a ball holds few points (mean <= 18 at the
