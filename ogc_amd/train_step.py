@@ -95,6 +95,23 @@ class PrefetchedGeometry:
                                        lambda: criterion.plan_geometry(self.pcs_l, aug_transform), after=ready)
 
 
+class _SplitViews(torch.autograd.Function):
+    """(b, t, n, k) -> t contiguous (b, n, k) tensors, one per view.  As `masks[:, tt]` or `masks.unbind(1)` the backward pass is
+    a zero-fill of the whole tensor, a copy and an add PER VIEW (twelve launches for four views in the step's trace); here it is
+    one stack, and the forward pass one transposing copy instead of one per view."""
+
+    @staticmethod
+    def forward(ctx, masks):
+        parts = masks.transpose(0, 1).contiguous()
+        ctx.shape = parts.shape[1:]
+        return tuple(parts.unbind(0))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        ref = next(g for g in grads if g is not None)
+        return torch.stack([g if g is not None else ref.new_zeros(ctx.shape) for g in grads], 1)
+
+
 def train_step(segnet, criterion, optimizer, batch, it, aug_transform, sync=True, prefetched=None, next_batch=None):
     """batch = (pcs (b,t,n,3), segms (b,t,n), flows (b,t,n,3), valids), already on the device.
     Returns (loss_dict, stepped); with sync=False a PendingStep whose result() gives the same pair later, so the
@@ -121,8 +138,7 @@ def train_step(segnet, criterion, optimizer, batch, it, aug_transform, sync=True
         kw = {}
     t, n = batch[1].size(1), batch[1].size(2)
     masks = masks.view(b, t, n, -1)
-    # unbind, not masks[:, tt]: its backward is one stack instead of a zero-fill, a copy and an add per view
-    masks_l = [m.contiguous() for m in masks.unbind(1)]
+    masks_l = list(_SplitViews.apply(masks))
     upcoming = None
     if next_batch is not None and on_gpu:
         upcoming = PrefetchedGeometry(segnet, criterion, next_batch, aug_transform)
