@@ -1,3 +1,5 @@
+"""ogc_ball_query on the bench's scenes with the four-lanes-per-centre kernel and with the general kernel alone (OGC_BQ_CELLS=0),
+in one Python process: per view set, then again after a few training steps in the same process (where bench.py measures)."""
 import os, sys, torch
 sys.path.insert(0, os.getcwd())
 import ogc_amd
