@@ -1502,8 +1502,8 @@ int ogc_knn_grid(int mode, int b, int n, int m, int k, float radius, const float
     // radius-limited search of a cloud in itself (the smoothness term's neighbour lists): four lanes per query over the 27 cells
     // around it first (the build then prefers cells of edge 1.01 r when balls are sparsely filled); knn_grid_kernel afterwards
     // only does what that kernel left (marked rows, clouds flagged knn_general)
-    const bool cells = mode == 1 && radius > 0.0f && radius < 1.0e18f && unknown == known && n == m && (k == 16 || k == 32) &&
-                       ogc_knn_cells_enabled();
+    const bool cells = mode == 1 && radius > 0.0f && radius < 1.0e18f && unknown == known && n == m &&
+                       (k == 4 || k == 8 || k == 16 || k == 32) && ogc_knn_cells_enabled();
     launch_grid_build(b, m, mode == 1 ? radius : 0.0f, k, stride_cells, known, hdrs, cell_start, sorted_pts, s, cells ? 1 : 0);
     dim3 grid(ogc_divup(n, QPW), b);
     // d2 <= lim2  <=>  sqrtf(d2) <= radius: the largest float whose correctly rounded root does not exceed the radius
@@ -1520,12 +1520,14 @@ int ogc_knn_grid(int mode, int b, int n, int m, int k, float radius, const float
     if (cells) {
         const dim3 grid4(ogc_divup(n, CPW), b);
         const size_t lds4 = sizeof(u64) * CPW * KQ_LIST;
-        if (k == 32)
-            hipLaunchKernelGGL(knn_cells_kernel<32>, grid4, dim3(OGC_WAVE), lds4, s, n, lim2, stride_cells, hdrs, cell_start,
-                               sorted_pts, dist, idx);
-        else
-            hipLaunchKernelGGL(knn_cells_kernel<16>, grid4, dim3(OGC_WAVE), lds4, s, n, lim2, stride_cells, hdrs, cell_start,
-                               sorted_pts, dist, idx);
+#define OGC_KNN_CELLS(K)                                                                                              \
+    hipLaunchKernelGGL(knn_cells_kernel<K>, grid4, dim3(OGC_WAVE), lds4, s, n, lim2, stride_cells, hdrs, cell_start, \
+                       sorted_pts, dist, idx)
+        if (k == 32) OGC_KNN_CELLS(32);          // the row lengths of the configs' smoothness terms (4 / 8: flow losses, OGC-DR)
+        else if (k == 16) OGC_KNN_CELLS(16);
+        else if (k == 8) OGC_KNN_CELLS(8);
+        else OGC_KNN_CELLS(4);
+#undef OGC_KNN_CELLS
         deferred = 1;
     }
     if (mode == 1)

@@ -176,6 +176,7 @@ SELF_KNN_CASES = [  # (n, k, r, scale, dup): ogc_knn_clamped(pc, pc) — the fou
     (4099, 16, 0.09, (1, 1, 1), 50), (2048, 32, 6.0, (60, 4, 80), 0),   # crowded cells: the whole cloud goes to knn_grid_kernel
     (3000, 32, 0.01, (60, 4, 80), 0),       # nobody but the query itself
     (5000, 16, 1.5, (60, 0, 80), 0),        # a flat cloud
+    (4096, 8, 0.04, (1, 1, 1), 0), (2048, 4, 0.5, (60, 4, 80), 7), (8192, 8, 1.0, (60, 4, 80), 0),   # the other configs' row lengths
 ]
 
 
