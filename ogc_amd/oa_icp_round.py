@@ -16,8 +16,12 @@ Kept from the reference so that rounds chain with `train_seg`:
   * with `--frames 4` the SAPIEN / OGC-DR variant: six ordered pairs of the four frames of a scene
     (`[[0,1],[1,0],[1,2],[2,1],[2,3],[3,2]]`, oa_icp.py:148), flows stored as `<dir>/<scene id>.npy` (6, N, 3) next to
     `<dir>.json` {"view_sel": ...} (oa_icp.py:187-191, datasets/dataset_ogcdr.py:147-157) — ogc_amd/utils/flow_store.py.
-Dataset readers are out of scope: scenes are the seeded synthetic ones of `train_seg`; when no predicted
-flow exists on disk for a scene, the ground-truth flow plus noise stands in for the flow network's prediction.
+With `--data-root DIR` the scenes and the input flows are read from, and the refined flows written to, a directory tree in the
+reference's layout (ogc_amd/datasets.py: `kittisf` -> <DIR>/data/<id>/..., split file `--mapping`; `ogcdr` -> <DIR>/data/<id>/...,
+<DIR>/data/<split>.lst) — the tree the reference's own oa_icp.py works on; tests/golden/flow_store.npz holds what that script
+wrote for a three-scene tree and tests/test_flow_store.py replays it here.  Without it the scenes are the seeded synthetic ones
+of `train_seg`, and when no predicted flow exists on disk for a scene the ground-truth flow plus noise stands in for the flow
+network's prediction.
 """
 import argparse
 import importlib
@@ -59,6 +63,9 @@ def main(argv=None):
     ap.add_argument("--synthetic", type=int, default=16, help="number of synthetic scenes")
     ap.add_argument("--device", default="cuda")
     ap.add_argument("--frames", type=int, default=2, help="2: frame pairs (KITTI layout); 4: SAPIEN / OGC-DR sequences")
+    ap.add_argument("--data-root", default=None, help="scenes and flows in the reference's directory layout (ogc_amd/datasets.py)")
+    ap.add_argument("--split", default="train")
+    ap.add_argument("--mapping", default=None, help="kittisf: the split file listing the scene ids (default <data-root>/<split>.txt)")
     args = ap.parse_args(argv)
     with open(args.config) as f:
         cfg = yaml.safe_load(f)
@@ -73,6 +80,9 @@ def main(argv=None):
     weight_path = os.path.join(cfg["save_path"] + "_R%d" % args.round, "best.pth.tar")
     segnet.load_state_dict(torch.load(weight_path, map_location=device)["model_state"])
     segnet.eval()
+
+    if args.data_root is not None:
+        return refine_data_root(args, cfg, segnet, device)
 
     predflow = cfg.get("predflow_path", "flowstep3d")
     in_dir = flow_dir(args.flow_root, predflow, args.round - 1 if args.round > 1 else None)
@@ -136,6 +146,61 @@ def main(argv=None):
                     flow_store.save_pair(out_dir, "%06d" % i, host[2 * j], host[2 * j + 1])
     report = {"round": args.round, "icp_iter": icp_iter, "pairs": count,
               "metrics": {k: dict(zip(("EPE", "AccS", "AccR", "Outlier"), [round(x, 5) for x in (v / max(count, 1)).tolist()]))
+                          for k, v in sums.items()},
+              "saved_to": out_dir if args.save else None}
+    print(json.dumps(report), flush=True)
+    return report
+
+
+def refine_data_root(args, cfg, segnet, device):
+    """The round on a directory tree in the reference's layout (oa_icp.py:141-229): two data sets over the same ordered frame
+    pairs — ground-truth flows for the report, predicted flows of the previous round as input — batches of whole scenes,
+    refined flow of the first frame of every pair saved through the data set's writer."""
+    from .datasets import KITTISceneFlowDataset, OGCDynamicRoomDataset
+    root = args.data_root
+    predflow = "flowstep3d" if args.round <= 1 else "flowstep3d_R%d" % (args.round - 1)       # oa_icp.py:143-146
+    decentralize = (cfg.get("data") or {}).get("decentralize", False)
+    if cfg["dataset"] == "kittisf":
+        view_sels, thresh = [[0, 1], [1, 0]], 0.05
+        mapping = args.mapping or os.path.join(root, args.split + ".txt")
+        kw = dict(data_root=root, mapping_path=mapping, downsampled=True, view_sels=view_sels, decentralize=decentralize)
+        test_set, test_set_predflow = KITTISceneFlowDataset(**kw), KITTISceneFlowDataset(predflow_path=predflow, **kw)
+    elif cfg["dataset"] == "ogcdr":
+        view_sels, thresh = [list(v) for v in flow_store.SEQUENCE_PAIRS], 0.01
+        kw = dict(data_root=root, split=args.split, view_sels=view_sels, decentralize=decentralize)
+        test_set, test_set_predflow = OGCDynamicRoomDataset(**kw), OGCDynamicRoomDataset(predflow_path=predflow, **kw)
+    else:
+        raise KeyError("no reader for dataset %r" % cfg["dataset"])
+    n_frame, batch_size = len(view_sels), args.test_batch_size
+    icp_iter = ICP_ITERS[args.round]
+    out_dir = flow_dir(root, args.saveflow_path, args.round)
+    if args.save:
+        assert batch_size % n_frame == 0, "Frame pairs of one scene should be in the same batch"   # oa_icp.py:179-180
+        os.makedirs(out_dir, exist_ok=True)
+        if cfg["dataset"] == "ogcdr":
+            flow_store.write_meta(out_dir, view_sels)
+    sums, count = {"input": 0.0, "kabsch": 0.0, "oa_icp": 0.0}, 0
+    n_batch = 0
+    for offset, start in enumerate(range(0, len(test_set), batch_size)):
+        sids = range(start, min(start + batch_size, len(test_set)))
+        samples, preds = [test_set[i] for i in sids], [test_set_predflow[i] for i in sids]
+        pc1 = torch.from_numpy(np.stack([s[0][0] for s in samples])).to(device)
+        pc2 = torch.from_numpy(np.stack([s[0][1] for s in samples])).to(device)
+        gt = torch.from_numpy(np.stack([s[2][0] for s in samples])).to(device)
+        pred = torch.from_numpy(np.stack([s[2][0] for s in preds])).to(device)
+        with torch.no_grad():
+            mask1, mask2 = segnet(pc1, pc1), segnet(pc2, pc2)
+            kabsch = weighted_kabsch(pc1, pred, mask1)
+            refined = object_aware_icp(pc1, pc2, pred, mask1, mask2, icp_iter=icp_iter)
+        # the reference averages per-BATCH metrics (AverageMeter over batches, oa_icp.py:214-221): kept
+        for key, flow in (("input", pred), ("kabsch", kabsch), ("oa_icp", refined)):
+            sums[key] = sums[key] + flow_metrics(gt, flow, epe_norm_thresh=thresh)
+        n_batch += 1
+        count += pc1.shape[0]
+        if args.save:
+            test_set._save_predflow(refined, save_root=out_dir, batch_size=batch_size, n_frame=n_frame, offset=offset)
+    report = {"round": args.round, "icp_iter": icp_iter, "pairs": count,
+              "metrics": {k: dict(zip(("EPE", "AccS", "AccR", "Outlier"), [round(x, 6) for x in (v / max(n_batch, 1)).tolist()]))
                           for k, v in sums.items()},
               "saved_to": out_dir if args.save else None}
     print(json.dumps(report), flush=True)

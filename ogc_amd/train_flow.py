@@ -18,7 +18,6 @@ Under DDP every rank normalises with its own BatchNorm statistics (no SyncBN), a
 import argparse
 import importlib
 import json
-import math
 import os
 import time
 
@@ -27,12 +26,12 @@ import torch.distributed as dist
 import yaml
 
 from .losses.flow_loss_unsup import ChamferLoss, SmoothLoss, UnsupervisedFlowStep3DLoss
-from .train_seg import SyntheticScenes, save_checkpoint, schedule_factor, norm_momentum
+from .train_seg import MAX_CONSECUTIVE_SKIPS, SyntheticScenes, schedule_factor, norm_momentum
 from .train_step import flow_train_step, make_optimizer
+from .utils.pytorch_util import AverageMeter, BNMomentumScheduler, LambdaLR, checkpoint_state, save_checkpoint
 
 FLOWNETS = {"sapien": "flownet_sapien", "ogcdr": "flownet_ogcdr", "ogcdrsv": "flownet_ogcdr", "kittisf": "flownet_kitti",
             "waymo": "flownet_kitti"}
-NORM_LAYERS = (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d, torch.nn.BatchNorm3d)
 
 
 def build_flow_criterion(cfg):
@@ -40,17 +39,114 @@ def build_flow_criterion(cfg):
                                       weights=cfg["weights"], iters_w=cfg["iters_w"])
 
 
-def evaluate(model, criterion, loader, device, model_iters):
-    model.eval()
-    total, count = 0.0, 0
-    with torch.no_grad():
-        for pcs, _, _, _ in loader:
-            pcs = pcs.to(device)
-            pc1, pc2 = pcs[:, 0].contiguous(), pcs[:, 1].contiguous()
-            loss, _ = criterion(pc1, pc2, model(pc1, pc2, pc1, pc2, iters=model_iters), sync=False)
-            total += float(loss)
-            count += 1
-    return total / max(count, 1)
+class Trainer(object):
+    """The reference's flow Trainer (train_flow.py:33-184) on this repo's step: same constructor arguments,
+    `_train_it(it, batch)`, `eval_epoch(loader)` and `train(n_epochs, train_loader, val_loader)`, same schedule calls, NaN rule,
+    best-checkpoint rule and checkpoint files.  Keyword-only extras: the data-parallel wrapper, device, rank / world, an
+    iteration cap, a log sink and a per-iteration callback for tests."""
+
+    def __init__(self, flownet, model_iters, criterion, optimizer, exp_base, lr_scheduler=None, bnm_scheduler=None, *,
+                 model=None, device=None, world=1, rank=0, max_iters=0, log=print, on_iteration=None):
+        self.flownet = flownet
+        self.model = model if model is not None else flownet
+        self.model_iters = model_iters
+        self.criterion = criterion
+        self.optimizer = optimizer
+        self.lr_scheduler = lr_scheduler
+        self.bnm_scheduler = bnm_scheduler
+        self.exp_base = exp_base
+        self.device = device if device is not None else next(flownet.parameters()).device
+        self.world, self.rank, self.max_iters, self.log, self.on_iteration = world, rank, max_iters, log, on_iteration
+        if rank == 0:
+            os.makedirs(exp_base, exist_ok=True)
+        self.checkpoint_name, self.best_name = "current", "best"
+        self.cur_epoch = 0
+        self._skipped_in_a_row = 0
+
+    def _train_it(self, it, batch, sync=True):
+        """train_flow.py:62-88: schedules stepped with the iteration number, forward over `model_iters` GRU iterations, loss
+        (+ the EPE of every iteration against the first frame's flow, monitored), backward, NaN rule, Adam."""
+        if self.lr_scheduler is not None:
+            self.lr_scheduler.step(it)
+        if self.bnm_scheduler is not None:
+            self.bnm_scheduler.step(it)
+        return flow_train_step(self.model, self.criterion, self.optimizer, batch, self.model_iters, sync=sync)
+
+    def eval_epoch(self, val_loader):
+        """(validation loss, mean loss_dict incl. the EPE terms).  The loss is the reference's number: the sum over the n
+        batches divided by n + 1 (train_flow.py:97-98,:115; see ogc_amd/train_seg.py::Trainer.eval_epoch)."""
+        from .metrics.flow_metric import epe_terms
+        self.model.eval()
+        eval_meter = AverageMeter()
+        total_loss, count = 0.0, 1.0
+        with torch.no_grad():
+            for pcs, _, flows, _ in val_loader:
+                pcs = pcs.to(self.device)
+                pc1, pc2 = pcs[:, 0].contiguous(), pcs[:, 1].contiguous()
+                flow_preds = self.model(pc1, pc2, pc1, pc2, iters=self.model_iters)
+                loss, loss_dict = self.criterion(pc1, pc2, flow_preds, extra=epe_terms(flows[:, 0].to(self.device), flow_preds))
+                total_loss += float(loss)
+                count += 1
+                eval_meter.append_loss(loss_dict)
+        return total_loss / count, eval_meter.get_mean_loss_dict()
+
+    def _save(self, is_best):
+        if self.rank == 0:
+            save_checkpoint(checkpoint_state(self.flownet), is_best, filename=os.path.join(self.exp_base, self.checkpoint_name),
+                            bestname=os.path.join(self.exp_base, self.best_name))
+
+    def train(self, n_epochs, train_loader, val_loader=None):
+        it, best_loss = 0, 1e10
+        self._save(True)  # initial weights as current and best (train_flow.py:126-130)
+        sampler = getattr(train_loader, "sampler", None)
+        for epoch in range(1, n_epochs + 1):
+            self.cur_epoch = epoch
+            if hasattr(sampler, "set_epoch"):
+                sampler.set_epoch(epoch)
+            train_meter, t0, in_flight, skipped = AverageMeter(), time.time(), None, 0
+
+            def account(pending, at):
+                nonlocal skipped
+                if pending is None:
+                    return
+                loss_dict, stepped = pending.result() if hasattr(pending, "result") else pending
+                skipped += 0 if stepped else 1
+                self._skipped_in_a_row = 0 if stepped else self._skipped_in_a_row + 1
+                if self._skipped_in_a_row >= MAX_CONSECUTIVE_SKIPS:
+                    raise RuntimeError("%d optimisation steps in a row were skipped (NaN gradients or a failing backward pass): "
+                                       "the weights are not being updated" % self._skipped_in_a_row)
+                train_meter.append_loss(loss_dict)
+                if self.on_iteration is not None:
+                    self.on_iteration(at, loss_dict, stepped)
+
+            for cpu_batch in train_loader:
+                batch = tuple(x.to(self.device, non_blocking=True) for x in cpu_batch)
+                # the scalars of step i are read while step i + 1 is already queued: the host never waits inside a step
+                pending = self._train_it(it, batch, sync=False)
+                account(in_flight, it - 1)
+                in_flight = pending
+                it += 1
+                if self.max_iters and it >= self.max_iters:
+                    break
+            account(in_flight, it - 1)
+            record = {"epoch": epoch, "it": it, "lr": self.optimizer.param_groups[0]["lr"],
+                      "train": {k: round(v, 5) for k, v in train_meter.get_mean_loss_dict().items()}, "skipped_steps": skipped}
+            if val_loader is not None:
+                val_loss, val_avg = self.eval_epoch(val_loader)
+                if self.world > 1:
+                    t = torch.tensor([val_loss], device=self.device)
+                    dist.all_reduce(t)
+                    val_loss = float(t) / self.world
+                is_best = val_loss < best_loss
+                best_loss = min(best_loss, val_loss)
+                self._save(is_best)
+                record.update(val_loss=round(val_loss, 5), val_terms={k: round(v, 5) for k, v in val_avg.items()}, is_best=is_best)
+            record["sec"] = round(time.time() - t0, 2)
+            if self.rank == 0:
+                self.log(json.dumps(record))
+            if self.max_iters and it >= self.max_iters:
+                break
+        return best_loss
 
 
 def main(argv=None):
@@ -103,56 +199,13 @@ def main(argv=None):
 
     optimizer = make_optimizer(net.parameters(), lr=cfg["lr"], weight_decay=cfg["weight_decay"])
     criterion = build_flow_criterion(cfg["loss"])
-    exp_base = cfg["save_path"]
-    if rank == 0:
-        os.makedirs(exp_base, exist_ok=True)
-        save_checkpoint(net, exp_base, True)  # initial weights as current and best (train_flow.py:126-130)
-
-    global_batch = cfg["batch_size"] * world
-    it, best = 0, 1e10
-    for epoch in range(1, cfg["epochs"] + 1):
-        if sampler is not None:
-            sampler.set_epoch(epoch)
-        sums, t0, in_flight = {}, time.time(), None
-
-        def account(pending):
-            if pending is not None:
-                for k, v in pending.result()[0].items():
-                    if math.isfinite(v):  # the reference's AverageMeter drops NaN values
-                        sums[k] = sums.get(k, 0.0) + v
-
-        for cpu_batch in train_loader:
-            seen = it * global_batch
-            for group in optimizer.param_groups:
-                group["lr"] = cfg["lr"] * schedule_factor(cfg, seen)
-            mom = norm_momentum(cfg, seen)
-            for m in net.modules():
-                if isinstance(m, NORM_LAYERS):
-                    m.momentum = mom
-            batch = tuple(x.to(device, non_blocking=True) for x in cpu_batch)
-            # the scalars of step i are read while step i+1 is already queued: the host never waits inside a step
-            pending = flow_train_step(model, criterion, optimizer, batch, model_iters, sync=False)
-            account(in_flight)
-            in_flight = pending
-            it += 1
-            if args.max_iters and it >= args.max_iters:
-                break
-        account(in_flight)
-        n_it = max(len(train_loader) if not args.max_iters else min(len(train_loader), it), 1)
-        val_loss = evaluate(model, criterion, val_loader, device, model_iters)
-        if distributed:
-            t = torch.tensor([val_loss], device=device)
-            dist.all_reduce(t)
-            val_loss = float(t) / world
-        if rank == 0:
-            is_best = val_loss < best
-            best = min(best, val_loss)
-            save_checkpoint(net, exp_base, is_best)
-            print(json.dumps({"epoch": epoch, "it": it, "lr": optimizer.param_groups[0]["lr"],
-                              "train": {k: round(v / n_it, 5) for k, v in sums.items()},
-                              "val_loss": round(val_loss, 5), "sec": round(time.time() - t0, 2)}), flush=True)
-        if args.max_iters and it >= args.max_iters:
-            break
+    global_batch = cfg["batch_size"] * world   # schedules by samples seen (train_flow.py:187-203), over all ranks
+    lr_scheduler = LambdaLR(optimizer, lr_lambda=lambda it: schedule_factor(cfg, it * global_batch))
+    bnm_scheduler = BNMomentumScheduler(net, bn_lambda=lambda it: norm_momentum(cfg, it * global_batch))
+    trainer = Trainer(net, model_iters, criterion, optimizer, exp_base=cfg["save_path"], lr_scheduler=lr_scheduler,
+                      bnm_scheduler=bnm_scheduler, model=model, device=device, world=world, rank=rank, max_iters=args.max_iters,
+                      log=lambda line: print(line, flush=True))
+    best = trainer.train(cfg["epochs"], train_loader, val_loader)
     if distributed:
         dist.destroy_process_group()
     return best

@@ -20,9 +20,7 @@ driver trains on seeded synthetic scenes with the loaders' sample contract (ogc_
 import argparse
 import importlib
 import json
-import math
 import os
-import shutil
 import time
 
 import torch
@@ -30,14 +28,16 @@ import torch.distributed as dist
 import yaml
 
 from .train_step import build_criterion, make_optimizer, train_step
+from .utils.pytorch_util import (NORM_LAYERS, AverageMeter, BNMomentumScheduler, LambdaLR, checkpoint_state,
+                                 save_checkpoint)
 from .utils.synthetic import make_scene_batch
 
 SEGNETS = {"sapien": "segnet_sapien", "ogcdr": "segnet_ogcdr", "kittisf": "segnet_kitti", "waymo": "segnet_kitti"}
 # ONE training set on every rank (DistributedSampler deals its scenes out): the flow store of oa_icp_round is keyed by
 # scene index, so all ranks — and the refinement round — must mean the same scene by the same index
 TRAIN_SEED = 1000
-NORM_LAYERS = (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d, torch.nn.BatchNorm3d, torch.nn.InstanceNorm1d,
-               torch.nn.InstanceNorm2d, torch.nn.InstanceNorm3d, torch.nn.GroupNorm)
+# a skipped step (NaN gradients, train_seg.py:81-83) is counted and logged per epoch; this many in a row end the run
+MAX_CONSECUTIVE_SKIPS = 50
 
 
 class SyntheticScenes(torch.utils.data.Dataset):
@@ -150,39 +150,190 @@ def norm_momentum(cfg, samples_seen):
     return max(cfg["bn_momentum"] * cfg["bn_decay"] ** int(samples_seen / cfg["decay_step"]), 1e-2)
 
 
-def save_checkpoint(net, exp_base, is_best):
-    state = {"model_state": net.state_dict()}
-    cur = os.path.join(exp_base, "current.pth.tar")
-    torch.save(state, cur)
-    if is_best:
-        shutil.copyfile(cur, os.path.join(exp_base, "best.pth.tar"))
+class Trainer(object):
+    """The reference's Trainer (train_seg.py:19-226) on this repo's step: same constructor arguments, `_train_it(it, batch,
+    aug_transform)`, `eval_epoch(loader)` and `train(n_epochs, train_set, train_loader, test_loader)` with the same schedule
+    calls, loss gating, NaN rule, augmentation switch, best-checkpoint rule and checkpoint files.  Keyword-only extras (not in
+    the reference): the wrapped model of a data-parallel run, the device the batches go to, the one-frame loss of the Waymo
+    trainer, HIP-graph replay, a cap on the number of iterations and a per-iteration callback for tests.
 
+    What the step does differently from the reference's is invisible here: the scalars of step i are read while step i + 1 is
+    already queued (`_train_it(..., sync=False)`), and the coordinate-only work of the next batch runs a step ahead."""
 
-def evaluate(model, criterion, loader, device, single_frame=False, ignore_npoint_thresh=0):
-    """Mean validation loss and the segmentation metrics of the first frame (train_seg.py:88-133: AP, PQ, F1, Pre, Rec)."""
-    import numpy as np
-    from .metrics.seg_metric import accumulate_eval_results, calculate_AP, calculate_PQ_F1
-    model.eval()
-    total, count = 0.0, 0
-    ious, matched, confs, n_gt = [], [], [], 0
-    with torch.no_grad():
-        for pcs, segms, flows, valids in loader:
-            if single_frame:
-                pcs, segms, flows = pcs[:, ::2].contiguous(), segms[:, ::2].contiguous(), flows[:, ::2].contiguous()
-            pcs, flows = pcs.to(device), flows.to(device)
-            b, t, n = segms.shape
-            flat = pcs.view(b * t, n, -1).contiguous()
-            masks = model(flat, flat).view(b, t, n, -1)
-            loss, _ = criterion([pcs[:, i].contiguous() for i in range(t)], [masks[:, i].contiguous() for i in range(t)],
-                                [flows[:, i].contiguous() for i in range(t)], step_w=False)
-            total += float(loss)
-            count += 1
-            a, m, c, g = accumulate_eval_results(segms[:, 0].to(device), masks[:, 0], ignore_npoint_thresh)
-            ious.append(a); matched.append(m); confs.append(c); n_gt += g
-    ious, matched, confs = np.concatenate(ious), np.concatenate(matched), np.concatenate(confs)
-    pq, f1, pre, rec = calculate_PQ_F1(ious, matched, n_gt)
-    metrics = {"AP": calculate_AP(matched, confs, n_gt), "PQ": float(pq), "F1": float(f1), "Pre": float(pre), "Rec": float(rec)}
-    return total / max(count, 1), metrics
+    def __init__(self, segnet, criterion, optimizer, aug_transform_epoch, ignore_npoint_thresh, exp_base, lr_scheduler=None,
+                 bnm_scheduler=None, *, model=None, device=None, world=1, rank=0, single_frame=False, hip_graph=False,
+                 max_iters=0, log=print, on_iteration=None, loss_start_steps=(0, 0, 0)):
+        self.segnet = segnet
+        self.model = model if model is not None else segnet   # what is called: the net, or its data-parallel wrapper
+        self.criterion = criterion
+        self.optimizer = optimizer
+        self.aug_transform_epoch = aug_transform_epoch
+        self.ignore_npoint_thresh = ignore_npoint_thresh
+        self.lr_scheduler = lr_scheduler
+        self.bnm_scheduler = bnm_scheduler
+        self.exp_base = exp_base
+        self.device = device if device is not None else next(segnet.parameters()).device
+        self.world, self.rank, self.single_frame = world, rank, single_frame
+        self.hip_graph, self.max_iters, self.log, self.on_iteration = hip_graph, max_iters, log, on_iteration
+        self.loss_start_steps = tuple(loss_start_steps)
+        if rank == 0:
+            os.makedirs(exp_base, exist_ok=True)
+        self.checkpoint_name, self.best_name = "current", "best"
+        self.cur_epoch = 0
+        self._skipped_in_a_row = 0
+        self._graphed, self._graphed_key, self._graph_holds = None, None, None
+
+    # ---- one optimisation step (train_seg.py:47-86)
+    def _train_it(self, it, batch, aug_transform=False, sync=True, prefetched=None, next_batch=None):
+        """lr / norm-momentum schedules stepped with the iteration number, then the step itself (ogc_amd/train_step.py: forward
+        over the views flattened into the batch, loss with step_w=True and it * b, backward, NaN rule, Adam).  Returns
+        (loss_dict, stepped) — or, with sync=False, the PendingStep whose result() gives that pair later."""
+        if self.lr_scheduler is not None:
+            self.lr_scheduler.step(it)
+        if self.bnm_scheduler is not None:
+            self.bnm_scheduler.step(it)
+        # `it * world`: train_step multiplies by the local batch size, so the loss gates see the samples of ALL ranks
+        return train_step(self.model, self.criterion, self.optimizer, batch, it * self.world, aug_transform, sync=sync,
+                          prefetched=prefetched, next_batch=next_batch)
+
+    def _graphed_it(self, it, batch, upcoming, aug_transform):
+        """The same step replayed as one HIP graph (graph_step.py); re-captured when anything the capture froze changes:
+        learning rate, norm momentum, which loss terms are active, augmentation, the batch shape."""
+        if self.lr_scheduler is not None:
+            self.lr_scheduler.step(it)
+        if self.bnm_scheduler is not None:
+            self.bnm_scheduler.step(it)
+        mom = next((m.momentum for m in self.segnet.modules() if isinstance(m, NORM_LAYERS)), None)
+        b = batch[1].size(0)
+        gates = tuple(it * self.world * b >= st for st in self.loss_start_steps)
+        key = (self.optimizer.param_groups[0]["lr"], mom, gates, aug_transform, tuple(batch[0].shape))
+        if self._graphed is None or key != self._graphed_key:
+            from .graph_step import GraphedTrainStep
+            if self._graphed is None or key[3:] != self._graphed_key[3:]:
+                self._graphed = GraphedTrainStep(self.model, self.criterion, self.optimizer, batch, it * self.world, aug_transform)
+            else:
+                self._graphed.load(batch)
+                self._graphed.recapture(it * self.world)
+            self._graphed_key, self._graph_holds = key, batch
+        elif self._graph_holds is not batch:
+            self._graphed.load(batch)
+        pending = self._graphed.step(upcoming if upcoming is not None else batch)
+        self._graph_holds = upcoming
+        return pending
+
+    # ---- validation (train_seg.py:88-133)
+    def eval_epoch(self, d_loader):
+        """(validation loss, mean loss_dict, {'Pred_IoU', 'Pred_Matched', 'Confidence', 'N_GT_Inst'} lists).  The loss is the
+        reference's number: the sum over the n batches divided by n + 1 (its counter starts at 1.0, train_seg.py:93-94,:114) —
+        kept, so that logged curves and the best-checkpoint choice of the two trainers agree number for number."""
+        from .metrics.seg_metric import accumulate_eval_results
+        self.model.eval()
+        eval_meter = AverageMeter()
+        total_loss, count = 0.0, 1.0
+        ap_eval_meter = {"Pred_IoU": [], "Pred_Matched": [], "Confidence": [], "N_GT_Inst": []}
+        with torch.no_grad():
+            for pcs, segms, flows, _ in d_loader:
+                if self.single_frame:
+                    pcs, segms, flows = pcs[:, ::2].contiguous(), segms[:, ::2].contiguous(), flows[:, ::2].contiguous()
+                pcs, flows = pcs.to(self.device), flows.to(self.device)
+                b, t, n = segms.shape
+                flat = pcs.view(b * t, n, -1).contiguous()
+                masks = self.model(flat, flat).view(b, t, n, -1)
+                loss, loss_dict = self.criterion([pcs[:, i].contiguous() for i in range(t)],
+                                                 [masks[:, i].contiguous() for i in range(t)],
+                                                 [flows[:, i].contiguous() for i in range(t)], step_w=False)
+                total_loss += float(loss)
+                count += 1
+                eval_meter.append_loss(loss_dict)
+                iou, matched, conf, n_gt = accumulate_eval_results(segms[:, 0].to(self.device), masks[:, 0],
+                                                                   self.ignore_npoint_thresh)
+                ap_eval_meter["Pred_IoU"].append(iou)
+                ap_eval_meter["Pred_Matched"].append(matched)
+                ap_eval_meter["Confidence"].append(conf)
+                ap_eval_meter["N_GT_Inst"].append(n_gt)
+        return total_loss / count, eval_meter.get_mean_loss_dict(), ap_eval_meter
+
+    def _save(self, is_best):
+        if self.rank == 0:
+            save_checkpoint(checkpoint_state(self.segnet), is_best, filename=os.path.join(self.exp_base, self.checkpoint_name),
+                            bestname=os.path.join(self.exp_base, self.best_name))
+
+    def _device_batches(self, loader):
+        for cpu_batch in loader:
+            if self.single_frame:  # Waymo: only backward flow exists, every other view is used (train_seg_waymo.py:59)
+                cpu_batch = tuple(x[:, ::2].contiguous() for x in cpu_batch)
+            yield tuple(x.to(self.device, non_blocking=True) for x in cpu_batch)
+
+    # ---- the epoch loop (train_seg.py:136-226)
+    def train(self, n_epochs, train_set, train_loader, test_loader=None):
+        import numpy as np
+        from .metrics.seg_metric import calculate_AP, calculate_PQ_F1
+        it, best_loss, aug_transform = 0, 1e10, False
+        self._save(True)  # the initial weights as current and best (train_seg.py:137-140)
+        sampler = getattr(train_loader, "sampler", None)
+        for epoch in range(1, n_epochs + 1):
+            self.cur_epoch = epoch
+            # augmented views (and with them the invariance loss) from the epoch after aug_transform_epoch (train_seg.py:151-154)
+            if epoch == self.aug_transform_epoch + 1:
+                aug_transform, train_set.aug_transform, best_loss = True, True, 1e10
+            if hasattr(sampler, "set_epoch"):
+                sampler.set_epoch(epoch)
+            train_meter, t0, in_flight, skipped = AverageMeter(), time.time(), None, 0
+
+            def account(pending, at):
+                nonlocal skipped
+                if pending is None:
+                    return
+                loss_dict, stepped = pending.result() if hasattr(pending, "result") else pending
+                skipped += 0 if stepped else 1
+                self._skipped_in_a_row = 0 if stepped else self._skipped_in_a_row + 1
+                if self._skipped_in_a_row >= MAX_CONSECUTIVE_SKIPS:
+                    raise RuntimeError("%d optimisation steps in a row were skipped (NaN gradients or a failing backward pass): "
+                                       "the weights are not being updated" % self._skipped_in_a_row)
+                train_meter.append_loss(loss_dict)
+                if self.on_iteration is not None:
+                    self.on_iteration(at, loss_dict, stepped)
+
+            self.model.train()
+            stream_of_batches = self._device_batches(train_loader)
+            batch, pre = next(stream_of_batches, None), None
+            while batch is not None:
+                upcoming = next(stream_of_batches, None)  # one batch ahead: its geometry is queued during this step
+                if self.hip_graph:
+                    pending = self._graphed_it(it, batch, upcoming, aug_transform)
+                else:
+                    pending = self._train_it(it, batch, aug_transform, sync=False, prefetched=pre, next_batch=upcoming)
+                    pre = pending.prefetched
+                # the scalars of step i are read while step i + 1 is already queued: the host never waits inside a step
+                account(in_flight, it - 1)
+                in_flight, batch = pending, upcoming
+                it += 1
+                if self.max_iters and it >= self.max_iters:
+                    break
+            account(in_flight, it - 1)
+            record = {"epoch": epoch, "it": it, "lr": self.optimizer.param_groups[0]["lr"], "aug": aug_transform,
+                      "train": {k: round(v, 5) for k, v in train_meter.get_mean_loss_dict().items()}, "skipped_steps": skipped}
+            if test_loader is not None:
+                val_loss, val_avg, ap = self.eval_epoch(test_loader)
+                if self.world > 1:
+                    t = torch.tensor([val_loss], device=self.device)
+                    dist.all_reduce(t)
+                    val_loss = float(t) / self.world
+                ious, matched, confs = (np.concatenate(ap[k]) for k in ("Pred_IoU", "Pred_Matched", "Confidence"))
+                n_gt = int(np.sum(ap["N_GT_Inst"]))
+                pq, f1, pre_, rec = calculate_PQ_F1(ious, matched, n_gt)
+                is_best = val_loss < best_loss
+                best_loss = min(best_loss, val_loss)
+                self._save(is_best)
+                record.update(val_loss=round(val_loss, 5), val_terms={k: round(v, 5) for k, v in val_avg.items()}, is_best=is_best,
+                              val={"AP": round(float(calculate_AP(matched, confs, n_gt)), 4), "PQ": round(float(pq), 4),
+                                   "F1": round(float(f1), 4), "Pre": round(float(pre_), 4), "Rec": round(float(rec), 4)})
+            record["sec"] = round(time.time() - t0, 2)
+            if self.rank == 0:
+                self.log(json.dumps(record))
+            if self.max_iters and it >= self.max_iters:
+                break
+        return best_loss
 
 
 def build_segnet(cfg):
@@ -267,98 +418,21 @@ def main(argv=None):
 
     use_graph = args.hip_graph and device.type == "cuda" and not distributed
     optimizer = make_optimizer(net.parameters(), lr=cfg["lr"], weight_decay=cfg["weight_decay"], capturable=use_graph)
-    graphed, graphed_key, graph_holds = None, None, None
     # Waymo: only backward flow exists, the trainer keeps every other view and uses the one-frame loss
     # (train_seg_waymo.py:59, :244-334)
     single_frame = cfg["dataset"] == "waymo"
     criterion = build_criterion(cfg["loss"], single_frame=single_frame)
-    exp_base = cfg["save_path"] + "_R%d" % args.round
-    if rank == 0:
-        os.makedirs(exp_base, exist_ok=True)
-        save_checkpoint(net, exp_base, True)  # initial weights as current and best
-
+    # schedules driven by samples seen (train_seg.py:230-245); under data parallelism the GLOBAL batch, so that they do not
+    # depend on the number of GPUs
     global_batch = cfg["batch_size"] * world
-    it, best = 0, 1e10
-    aug = False
-    for epoch in range(1, cfg["epochs"] + 1):
-        if epoch == cfg["aug_transform_epoch"] + 1:
-            aug, train_set.aug_transform, best = True, True, 1e10
-        if sampler is not None:
-            sampler.set_epoch(epoch)
-        sums, t0, in_flight = {}, time.time(), None
-
-        def account(pending):
-            if pending is not None:
-                for k, v in pending.result()[0].items():
-                    if math.isfinite(v):  # the reference's AverageMeter drops NaN values
-                        sums[k] = sums.get(k, 0.0) + v
-
-        def device_batches():
-            for cpu_batch in train_loader:
-                if single_frame:
-                    cpu_batch = tuple(x[:, ::2].contiguous() for x in cpu_batch)
-                yield tuple(x.to(device, non_blocking=True) for x in cpu_batch)
-
-        stream_of_batches = device_batches()
-        batch, pre = next(stream_of_batches, None), None
-        while batch is not None:
-            upcoming = next(stream_of_batches, None)  # one batch ahead: its geometry is queued during this step
-            seen = it * global_batch
-            for group in optimizer.param_groups:
-                group["lr"] = cfg["lr"] * schedule_factor(cfg, seen)
-            mom = norm_momentum(cfg, seen)
-            for m in net.modules():
-                if isinstance(m, NORM_LAYERS):
-                    m.momentum = mom
-            # the scalars of step i are read while step i+1 is already queued: the host never waits inside a step
-            if use_graph:
-                # everything the capture froze: learning rate, norm momentum, which loss terms are active, augmentation
-                gates = tuple(it * world * cfg["batch_size"] >= st for st in cfg["loss"].get("start_steps", [0, 0, 0]))
-                key = (optimizer.param_groups[0]["lr"], mom, gates, aug, tuple(batch[0].shape))
-                if graphed is None or key != graphed_key:
-                    from .graph_step import GraphedTrainStep
-                    if graphed is None or key[3:] != graphed_key[3:]:
-                        graphed = GraphedTrainStep(model, criterion, optimizer, batch, it * world, aug)
-                    else:
-                        graphed.load(batch)
-                        graphed.recapture(it * world)
-                    graphed_key, graph_holds = key, batch
-                elif graph_holds is not batch:
-                    graphed.load(batch)
-                pending = graphed.step(upcoming if upcoming is not None else batch)
-                account(in_flight)
-                in_flight = pending
-                graph_holds, batch = upcoming, upcoming
-                it += 1
-                if args.max_iters and it >= args.max_iters:
-                    break
-                continue
-            pending = train_step(model, criterion, optimizer, batch, it * world, aug, sync=False, prefetched=pre,
-                                 next_batch=upcoming)
-            pre, batch = pending.prefetched, upcoming
-            account(in_flight)
-            in_flight = pending
-            it += 1
-            if args.max_iters and it >= args.max_iters:
-                break
-        account(in_flight)
-        n_it = max(len(train_loader) if not args.max_iters else min(len(train_loader), it), 1)
-        val_loss, val_metrics = evaluate(model, criterion, val_loader, device, single_frame,
-                                         cfg.get("ignore_npoint_thresh", 0))
-        if distributed:
-            t = torch.tensor([val_loss], device=device)
-            dist.all_reduce(t)
-            val_loss = float(t) / world
-        if rank == 0:
-            is_best = val_loss < best
-            best = min(best, val_loss)
-            save_checkpoint(net, exp_base, is_best)
-            print(json.dumps({"epoch": epoch, "it": it, "lr": optimizer.param_groups[0]["lr"], "aug": aug,
-                              "train": {k: round(v / n_it, 5) for k, v in sums.items()},
-                              "val_loss": round(val_loss, 5), "val": {k: round(v, 4) for k, v in val_metrics.items()},
-                              "sec": round(time.time() - t0, 2)}), flush=True)
-        if args.max_iters and it >= args.max_iters:
-            break
+    lr_scheduler = LambdaLR(optimizer, lr_lambda=lambda it: schedule_factor(cfg, it * global_batch))
+    bnm_scheduler = BNMomentumScheduler(net, bn_lambda=lambda it: norm_momentum(cfg, it * global_batch))
+    trainer = Trainer(net, criterion, optimizer, aug_transform_epoch=cfg["aug_transform_epoch"],
+                      ignore_npoint_thresh=cfg.get("ignore_npoint_thresh", 0), exp_base=cfg["save_path"] + "_R%d" % args.round,
+                      lr_scheduler=lr_scheduler, bnm_scheduler=bnm_scheduler, model=model, device=device, world=world, rank=rank,
+                      single_frame=single_frame, hip_graph=use_graph, max_iters=args.max_iters,
+                      log=lambda line: print(line, flush=True), loss_start_steps=cfg["loss"].get("start_steps", [0, 0, 0]))
+    best = trainer.train(cfg["epochs"], train_set, train_loader, val_loader)
     if distributed:
         dist.destroy_process_group()
     return best

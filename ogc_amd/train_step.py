@@ -147,10 +147,10 @@ def train_step(segnet, criterion, optimizer, batch, it, aug_transform, sync=True
     try:
         loss.backward()
     except RuntimeError as err:  # the reference returns without stepping (train_seg.py:75-78)
-        from ._lib import OgcOpsError
-        if _is_distributed(segnet) or isinstance(err, OgcOpsError):
+        if _is_distributed(segnet) or _must_surface(err):
             # a rank that leaves the step alone would hang the others in the gradient collective; and a failing operator of
-            # THIS library is a bug to be seen, not a numerical accident of the batch
+            # THIS library, an out-of-memory condition or a runtime error of the device is a fault to be seen, not a numerical
+            # accident of the batch
             raise
         pending = PendingStep(losses, HostScalars(torch.tensor([True])))
         pending.prefetched = upcoming
@@ -176,6 +176,17 @@ def train_step(segnet, criterion, optimizer, batch, it, aug_transform, sync=True
         pending = PendingStep(losses, HostScalars(torch.tensor([skip])))
     pending.prefetched = upcoming
     return pending.result() if sync else pending
+
+
+def _must_surface(err):
+    """Failures of backward() that are NOT the numerical accidents the reference's `except RuntimeError` is there for: errors of
+    this library's operators, out-of-memory, HIP runtime errors.  Skipping the step on those would leave a run that never
+    updates its weights and never says why (the step is asynchronous: nobody reads the flag in time)."""
+    from ._lib import OgcOpsError
+    if isinstance(err, (OgcOpsError, torch.cuda.OutOfMemoryError)):
+        return True
+    text = str(err)
+    return any(tag in text for tag in ("HIP error", "hipError", "CUDA error", "out of memory", "rocBLAS", "MIOpen"))
 
 
 def _is_distributed(model):
@@ -228,8 +239,7 @@ def flow_train_step(flownet, criterion, optimizer, batch, model_iters, sync=True
     try:
         loss.backward()
     except RuntimeError as err:  # train_flow.py:80-83: the step is skipped
-        from ._lib import OgcOpsError
-        if _is_distributed(flownet) or isinstance(err, OgcOpsError):
+        if _is_distributed(flownet) or _must_surface(err):
             raise
         from .utils.streams import HostScalars
         pending = PendingStep(losses, HostScalars(torch.tensor([True])))

@@ -1,0 +1,210 @@
+"""The drivers against the REFERENCE'S OWN trainers: tests/golden/train_{seg,flow}_trace.npz hold what
+train_seg.Trainer.train / train_flow.Trainer.train of the reference did on a small in-memory data set (make_driver_golden.py
+ran them in the build container); here this repo's Trainer classes replay the same runs — same configuration, data and
+initial weights (tests/golden/driver_cases.py, detgen) — and must reproduce, iteration by iteration: the loss_dict, the
+learning rate, the norm momentum, whether augmented views were used, and the weights after the step (including the
+NaN-gradient step that must change nothing); epoch by epoch: validation loss and loss_dict, PQ / F1 / Pre / Rec and the
+best-checkpoint value.  CPU test on the oracle's operators, GPU test on the HIP operators."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import detgen  # noqa: E402
+import driver_cases as dc  # noqa: E402
+
+# Tolerances.  Learning rate, momentum, augmentation flag, the NaN rule and the checkpoint are exact.  For the floats the bar is
+# the north star's 1e-5 relative — where the run is that well conditioned.  It is not everywhere: the untrained nets' masks are
+# nearly uniform, so arg-max based terms (the invariance term's matching, the neighbour terms on clamped lists) jump on 1e-7
+# perturbations, and Adam turns the rounding noise of analytically zero gradients (biases in front of a norm layer) into steps
+# of size lr.  The fixtures therefore also hold the SAME run of the reference in float64 (train_*_trace_f64.npz; indices decided
+# in fp32, floats in fp64): the reference's own fp32 run deviates from it by up to 5e-2 in `invariance` and 6e-5 in the weights.
+# A value passes when it is within 1e-5 of the reference's fp32 value, or as close to the float64 truth as the reference's fp32
+# run is (3 x its worst deviation so far in the run: errors compound step by step) — i.e. a trainer that gated, weighted or
+# scheduled anything differently fails by orders of magnitude, a different summation order does not.
+LOSS_RTOL = 1e-5
+WEIGHT_REL = 1e-5
+BUDGET = 3.0
+
+
+def load(name):
+    return np.load(os.path.join(HERE, "golden", name + ".npz"))
+
+
+def weight_summary(net):
+    norms, heads = [], []
+    for _, p in net.named_parameters():
+        norms.append(float(p.detach().double().norm()))
+        h = p.detach().flatten()[:16].double().cpu().numpy()
+        heads.append(np.pad(h, (0, 16 - len(h))))
+    return np.array(norms), np.stack(heads)
+
+
+def rel_l2(a, b):
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+class Budget:
+    """Per loss term: the largest |reference fp32 - float64 truth| seen so far in the run."""
+
+    def __init__(self, names):
+        self.worst = {k: 0.0 for k in names}
+
+    def close(self, got, ref32, truth, names, what, rtol=LOSS_RTOL, atol=1e-7):
+        for k, g, w, t in zip(names, got, ref32, truth):
+            if np.isnan(w):
+                assert np.isnan(g), "%s %s: %r where the reference has NaN" % (what, k, g)
+                continue
+            self.worst[k] = max(self.worst[k], abs(w - t))
+            ok32 = abs(g - w) <= atol + rtol * abs(w)
+            ok64 = abs(g - t) <= atol + rtol * abs(t) + BUDGET * self.worst[k]
+            assert ok32 or ok64, "%s %s: %r, reference fp32 %r, float64 truth %r (budget %.2e)" % (what, k, g, w, t, BUDGET * self.worst[k])
+
+
+def run_seg(dev, tmp_path):
+    from ogc_amd.models.segnet_sapien import MaskFormer3D
+    from ogc_amd.train_seg import Trainer, norm_momentum, schedule_factor
+    from ogc_amd.train_step import build_criterion, make_optimizer
+    from ogc_amd.utils.pytorch_util import BNMomentumScheduler, LambdaLR
+    gold, truth, cfg = load("train_seg_trace"), load("train_seg_trace_f64"), dc.SEG_CFG
+    net = detgen.fill_module(MaskFormer3D(**cfg["segnet"]), 31).to(dev)
+    optimizer = make_optimizer(net.parameters(), lr=cfg["lr"], weight_decay=cfg["weight_decay"])
+    lr_scheduler = LambdaLR(optimizer, lr_lambda=lambda it: schedule_factor(cfg, it * cfg["batch_size"]))
+    bnm_scheduler = BNMomentumScheduler(net, bn_lambda=lambda it: norm_momentum(cfg, it * cfg["batch_size"]))
+    criterion = build_criterion(cfg["loss"])
+    names = list(gold["loss_names"])
+    seen, lines = [], []
+
+    def on_iteration(it, loss_dict, stepped):
+        seen.append((it, [loss_dict[k] for k in names], stepped))
+
+    trainer = Trainer(net, criterion, optimizer, aug_transform_epoch=cfg["aug_transform_epoch"],
+                      ignore_npoint_thresh=cfg["ignore_npoint_thresh"], exp_base=str(tmp_path / "seg_R1"), lr_scheduler=lr_scheduler,
+                      bnm_scheduler=bnm_scheduler, device=torch.device(dev), log=lines.append, on_iteration=on_iteration,
+                      loss_start_steps=cfg["loss"]["start_steps"])
+    # weights / schedule values right after every step: wrap the step (the trainer reads a step's scalars one step late)
+    after = []
+    inner = trainer._train_it
+
+    def recording(it, batch, aug_transform=False, **kw):
+        out = inner(it, batch, aug_transform, **kw)
+        mom = next(m.momentum for m in net.modules() if isinstance(m, torch.nn.GroupNorm))
+        after.append((optimizer.param_groups[0]["lr"], mom, bool(aug_transform)) + weight_summary(net))
+        return out
+
+    trainer._train_it = recording
+    train_set, val_set = dc.SegScenes(train=True), dc.SegScenes(train=False)
+    train_loader = torch.utils.data.DataLoader(train_set, batch_size=cfg["batch_size"], shuffle=False)
+    val_loader = torch.utils.data.DataLoader(val_set, batch_size=cfg["batch_size"], shuffle=False)
+    best = trainer.train(cfg["epochs"], train_set, train_loader, val_loader)
+
+    assert len(seen) == len(after) == len(gold["lr"]) == 9
+    worst_w, ref_w, budget = 0.0, 0.0, Budget(names)
+    for i, ((it, losses, stepped), (lr, mom, aug, norms, heads)) in enumerate(zip(seen, after)):
+        assert it == i
+        budget.close(losses, gold["loss"][i], truth["loss"][i], names, "iteration %d" % i)
+        assert abs(lr - gold["lr"][i]) <= 1e-12 and abs(mom - gold["momentum"][i]) <= 1e-12, (i, lr, mom)
+        assert aug == bool(gold["aug"][i])
+        assert stepped == (not np.isnan(gold["loss"][i]).any()), "iteration %d: NaN rule" % i
+        ref_w = max(ref_w, rel_l2(gold["heads"][i], truth["heads"][i]))
+        w32, w64 = rel_l2(heads, gold["heads"][i]), rel_l2(heads, truth["heads"][i])
+        assert w32 <= WEIGHT_REL or w64 <= WEIGHT_REL + BUDGET * ref_w, \
+            "iteration %d: weights %.2e from the reference's fp32 run, %.2e from the float64 truth (reference itself: %.2e)" % (i, w32, w64, ref_w)
+        worst_w = max(worst_w, w32)
+    # the NaN-gradient step changed nothing (weights of iteration 5 == iteration 4), the next one did
+    assert np.array_equal(after[5][4], after[4][4]) and not np.array_equal(after[6][4], after[5][4])
+    import json
+    recs = [json.loads(l) for l in lines]
+    assert [r["skipped_steps"] for r in recs] == [0, 1, 0]
+    vnames = list(gold["val_names"])
+    vbudget = Budget(vnames)
+    vbudget.worst = dict(budget.worst)
+    for e, r in enumerate(recs):
+        vbudget.close([r["val_loss"]], [gold["val_loss"][e]], [truth["val_loss"][e]], ["sum"], "epoch %d validation loss" % (e + 1), atol=1e-5)
+        vbudget.close([r["val_terms"][k] for k in vnames], gold["val_avg"][e], truth["val_avg"][e], vnames,
+                      "epoch %d validation" % (e + 1), atol=2e-5)
+        got_pq = [r["val"][k] for k in ("PQ", "F1", "Pre", "Rec")]
+        assert np.allclose(got_pq, gold["val_pq"][e], atol=1e-4), (got_pq, gold["val_pq"][e])
+    vbudget.close([best], [float(gold["best"][0])], [float(truth["best"][0])], ["sum"], "best validation loss", atol=1e-6)
+    ck = torch.load(str(tmp_path / "seg_R1" / "best.pth.tar"))
+    assert sorted(ck.keys()) == list(gold["ckpt_top"]) and sorted(ck["model_state"].keys()) == list(gold["ckpt_keys"])
+    return worst_w
+
+
+def test_train_seg_trainer_replays_the_reference_trainer_cpu(tmp_path, monkeypatch, oracle):
+    import ogc_amd.pointnet2.pointnet2 as api
+    monkeypatch.setattr(api, "_native", oracle.Pointnet2CudaCPU())
+    run_seg("cpu", tmp_path)
+
+
+@pytest.mark.gpu
+def test_train_seg_trainer_replays_the_reference_trainer_gpu(tmp_path):
+    print("weights rel L2 vs the reference trainer: %.2e" % run_seg("cuda", tmp_path))
+
+
+def run_flow(dev, tmp_path):
+    from ogc_amd.models.flownet_sapien import FlowStep3D
+    from ogc_amd.train_flow import Trainer, build_flow_criterion
+    from ogc_amd.train_seg import norm_momentum, schedule_factor
+    from ogc_amd.train_step import make_optimizer
+    from ogc_amd.utils.pytorch_util import BNMomentumScheduler, LambdaLR
+    gold, truth, cfg = load("train_flow_trace"), load("train_flow_trace_f64"), dc.FLOW_CFG
+    net = detgen.fill_module(FlowStep3D(**cfg["flownet"]), 32).to(dev)
+    optimizer = make_optimizer(net.parameters(), lr=cfg["lr"], weight_decay=cfg["weight_decay"])
+    lr_scheduler = LambdaLR(optimizer, lr_lambda=lambda it: schedule_factor(cfg, it * cfg["batch_size"]))
+    bnm_scheduler = BNMomentumScheduler(net, bn_lambda=lambda it: norm_momentum(cfg, it * cfg["batch_size"]))
+    names = list(gold["loss_names"])
+    seen, after, lines = [], [], []
+    trainer = Trainer(net, cfg["model_iters"], build_flow_criterion(cfg["loss"]), optimizer, exp_base=str(tmp_path / "flow"),
+                      lr_scheduler=lr_scheduler, bnm_scheduler=bnm_scheduler, device=torch.device(dev), log=lines.append,
+                      on_iteration=lambda it, ld, stepped: seen.append((it, [ld[k] for k in names], stepped)))
+    inner = trainer._train_it
+
+    def recording(it, batch, **kw):
+        out = inner(it, batch, **kw)
+        bn = next(m for m in net.modules() if isinstance(m, torch.nn.BatchNorm2d))
+        after.append((optimizer.param_groups[0]["lr"], bn.momentum, bn.running_mean.detach().cpu().numpy().copy()) + weight_summary(net))
+        return out
+
+    trainer._train_it = recording
+    train_loader = torch.utils.data.DataLoader(dc.FlowPairs(train=True), batch_size=cfg["batch_size"], shuffle=False)
+    val_loader = torch.utils.data.DataLoader(dc.FlowPairs(train=False), batch_size=cfg["batch_size"], shuffle=False)
+    best = trainer.train(cfg["epochs"], train_loader, val_loader)
+    assert len(seen) == len(after) == len(gold["lr"]) == 4
+    budget, ref_w = Budget(names), 0.0
+    for i, ((it, losses, stepped), (lr, mom, rmean, norms, heads)) in enumerate(zip(seen, after)):
+        assert it == i and stepped
+        budget.close(losses, gold["loss"][i], truth["loss"][i], names, "iteration %d" % i)
+        assert abs(lr - gold["lr"][i]) <= 1e-12 and abs(mom - gold["momentum"][i]) <= 1e-12, (i, lr, mom)
+        ref_w = max(ref_w, rel_l2(gold["heads"][i], truth["heads"][i]))
+        w32, w64 = rel_l2(heads, gold["heads"][i]), rel_l2(heads, truth["heads"][i])
+        assert w32 <= WEIGHT_REL or w64 <= WEIGHT_REL + BUDGET * ref_w, (i, w32, w64, ref_w)
+        # the norm momentum really reached the BatchNorm layers: running statistics follow the reference's
+        rm32, rm64 = rel_l2(rmean, gold["running_mean"][i]), rel_l2(rmean, truth["running_mean"][i])
+        assert rm32 <= 1e-5 or rm64 <= 1e-5 + BUDGET * rel_l2(gold["running_mean"][i], truth["running_mean"][i]), (i, rm32, rm64)
+    import json
+    recs = [json.loads(l) for l in lines]
+    vnames = list(gold["val_names"])
+    vb = Budget(vnames)
+    vb.worst = dict(budget.worst)
+    for e, r in enumerate(recs):
+        vb.close([r["val_loss"]], [gold["val_loss"][e]], [truth["val_loss"][e]], ["sum"], "epoch %d validation loss" % (e + 1), atol=1e-5)
+        vb.close([r["val_terms"][k] for k in vnames], gold["val_avg"][e], truth["val_avg"][e], vnames, "epoch %d validation" % (e + 1),
+                 atol=2e-5)
+    vb.close([best], [float(gold["best"][0])], [float(truth["best"][0])], ["sum"], "best validation loss", atol=1e-5)
+    assert os.path.exists(str(tmp_path / "flow" / "best.pth.tar")) and os.path.exists(str(tmp_path / "flow" / "current.pth.tar"))
+
+
+def test_train_flow_trainer_replays_the_reference_trainer_cpu(tmp_path, monkeypatch, oracle):
+    import ogc_amd.pointnet2.pointnet2 as api
+    monkeypatch.setattr(api, "_native", oracle.Pointnet2CudaCPU())
+    run_flow("cpu", tmp_path)
+
+
+@pytest.mark.gpu
+def test_train_flow_trainer_replays_the_reference_trainer_gpu(tmp_path):
+    run_flow("cuda", tmp_path)
