@@ -94,11 +94,14 @@ class SegScenes(torch.utils.data.Dataset):
 
 class FlowPairs(torch.utils.data.Dataset):
     """Four (train) or two (val) frame pairs for the FlowStep3D trainers (train_flow.py:62-76 reads pcs[:, 0], pcs[:, 1] and
-    flows[:, 0])."""
+    flows[:, 0]).  `seed`: the generator tries seeds until the reference's run is stable under one-ulp changes of the
+    coordinates (a neighbour of a warped point sitting exactly on a decision boundary moves the second prediction by 4e-3 on
+    every implementation, the reference's included) and stores the seed it took in the fixture; `ulp` applies such a change."""
 
-    def __init__(self, train=True):
+    def __init__(self, train=True, seed=1100, ulp=0):
         self.n = 4 if train else 2
-        self.seed = 1100 if train else 1300
+        self.seed = seed if train else seed + 200
+        self.ulp = ulp
 
     def __len__(self):
         return self.n
@@ -108,6 +111,9 @@ class FlowPairs(torch.utils.data.Dataset):
         perm = np.argsort(detgen.uniform((N_FLOW,), self.seed + 10 * i + 5))
         pc2 = (pc[0] + flow[0])[perm]
         segm = mask[0].argmax(-1).astype(np.int32)
+        if self.ulp:
+            step = np.sign(detgen.uniform(pc[0].shape, self.seed + 10 * i + 7 + self.ulp)).astype(np.float32)
+            pc[0] = np.nextafter(pc[0], pc[0] + step)
         return (np.stack([pc[0], pc2]).astype(np.float32), np.stack([segm, segm[perm]]),
                 np.stack([flow[0], -flow[0][perm]]).astype(np.float32), np.ones((2, N_FLOW), np.float32))
 

@@ -160,6 +160,24 @@ def gen_train_seg(f64=False):
 
 
 def gen_train_flow(f64=False):
+    """fp32: tries data seeds until the reference's run does not move (< 2e-4) under one-ulp changes of the coordinates, writes the
+    trace of that seed; float64: the truth for the seed the fp32 fixture holds."""
+    if f64:
+        seed = int(np.load(os.path.join(HERE, "train_flow_trace.npz"))["data_seed"][0])
+        return _trace_flow(True, seed, 0, write=True)
+    for seed in range(1100, 1140):
+        base = _trace_flow(False, seed, 0, write=False)
+        dev = 0.0
+        for ulp in (1, 2):
+            other = _trace_flow(False, seed, ulp, write=False)
+            dev = max(dev, float(np.max(np.abs(other["loss"] - base["loss"]) / np.abs(base["loss"]).clip(1e-30))))
+        print("seed %d: largest change of a loss under one-ulp perturbations %.2e" % (seed, dev), flush=True)
+        if dev < 2e-4:
+            return _trace_flow(False, seed, 0, write=True)
+    raise RuntimeError("no stable seed")
+
+
+def _trace_flow(f64, seed, ulp, write):
     import train_flow as ref
     from losses.flow_loss_unsup import ChamferLoss, SmoothLoss, UnsupervisedFlowStep3DLoss
     from models.flownet_sapien import FlowStep3D
@@ -179,8 +197,8 @@ def gen_train_flow(f64=False):
     trainer = ref.Trainer(flownet=net, model_iters=cfg["model_iters"], criterion=criterion, optimizer=optimizer,
                           exp_base=os.path.join(tmp, "flow"), lr_scheduler=lr_scheduler, bnm_scheduler=bnm_scheduler)
     wrap = _AsDouble if f64 else (lambda ds: ds)
-    train_loader = torch.utils.data.DataLoader(wrap(dc.FlowPairs(train=True)), batch_size=cfg["batch_size"], shuffle=False)
-    val_loader = torch.utils.data.DataLoader(wrap(dc.FlowPairs(train=False)), batch_size=cfg["batch_size"], shuffle=False)
+    train_loader = torch.utils.data.DataLoader(wrap(dc.FlowPairs(True, seed, ulp)), batch_size=cfg["batch_size"], shuffle=False)
+    val_loader = torch.utils.data.DataLoader(wrap(dc.FlowPairs(False, seed, ulp)), batch_size=cfg["batch_size"], shuffle=False)
     its, epochs = [], []
     inner = trainer._train_it
 
@@ -209,8 +227,11 @@ def gen_train_flow(f64=False):
                running_mean=np.stack([r["running_mean"] for r in its]),
                val_loss=np.array([e["val_loss"] for e in epochs]), val_names=np.array(sorted(epochs[0]["val_avg"])),
                val_avg=np.array([[float(e["val_avg"][k]) for k in sorted(e["val_avg"])] for e in epochs]), best=np.array([best]))
-    save("train_flow_trace_f64" if f64 else "train_flow_trace", **out)
+    out["data_seed"] = np.array([seed])
     shutil.rmtree(tmp)
+    if write:
+        save("train_flow_trace_f64" if f64 else "train_flow_trace", **out)
+    return out
 
 
 def tree_bytes(root):

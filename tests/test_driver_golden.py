@@ -172,8 +172,9 @@ def run_flow(dev, tmp_path):
         return out
 
     trainer._train_it = recording
-    train_loader = torch.utils.data.DataLoader(dc.FlowPairs(train=True), batch_size=cfg["batch_size"], shuffle=False)
-    val_loader = torch.utils.data.DataLoader(dc.FlowPairs(train=False), batch_size=cfg["batch_size"], shuffle=False)
+    seed = int(gold["data_seed"][0])   # the seed whose run is stable under one-ulp changes of the inputs (driver_cases.FlowPairs)
+    train_loader = torch.utils.data.DataLoader(dc.FlowPairs(True, seed), batch_size=cfg["batch_size"], shuffle=False)
+    val_loader = torch.utils.data.DataLoader(dc.FlowPairs(False, seed), batch_size=cfg["batch_size"], shuffle=False)
     best = trainer.train(cfg["epochs"], train_loader, val_loader)
     assert len(seen) == len(after) == len(gold["lr"]) == 4
     budget, ref_w = Budget(names), 0.0
