@@ -1,5 +1,7 @@
 """Host-side wrappers of the fused HIP extensions that replace Python-level op sequences of the reference's
 layers (no counterpart in its native module; see include/ogc_ops.h "fused extensions")."""
+import weakref
+
 import torch
 import torch.nn.functional as F
 from torch.autograd import Function
@@ -442,16 +444,26 @@ def conv_norm_act(x, conv, norm, relu=True, maxpool=False):
 
 
 # ---- whole MLP + max-pool in one launch (inference) ------------------------------------------------------------------
-_FOLDED = {}   # id(first conv) -> (versions, transposed folded weights, folded biases)
+_FOLDED = weakref.WeakKeyDictionary()   # first conv module -> (key, transposed folded weights, folded biases)
+_FOLD_GENERATION = [0]
+
+
+def note_training_mode():
+    """Called by the FlowStep3D blocks when they enter training mode: everything folded so far is stale from now on.  The tensor
+    version counters the cache also checks do not see training — the fused optimizer and the BatchNorm kernels of this library
+    write parameters and running statistics through raw pointers (measured: versions unchanged across a step) — so a net that
+    was evaluated, trained further and evaluated again would reuse the folded weights of the first evaluation."""
+    _FOLD_GENERATION[0] += 1
 
 
 def _fold_batch_norm(convs, norms):
     """W'_l = diag(a) W_l (transposed, rows padded to a multiple of 4), b_l = beta - mean * a with a = gamma / sqrt(var + eps):
-    BatchNorm in evaluation mode folded into the convolution before it.  Cached until a parameter or buffer changes."""
+    BatchNorm in evaluation mode folded into the convolution before it.  Cached per block until a parameter or buffer changes
+    (torch-level writes: version counters) or any block has been in training mode since (note_training_mode)."""
     tensors = [t for conv, bn in zip(convs, norms) for t in (conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var)]
-    versions = tuple((t.data_ptr(), t._version) for t in tensors)
-    hit = _FOLDED.get(id(convs[0]))
-    if hit is not None and hit[0] == versions:
+    key = (_FOLD_GENERATION[0],) + tuple((t.data_ptr(), t._version) for t in tensors)
+    hit = _FOLDED.get(convs[0])
+    if hit is not None and hit[0] == key:
         return hit[1], hit[2]
     wts, biases = [], []
     with torch.no_grad():
@@ -462,7 +474,7 @@ def _fold_batch_norm(convs, norms):
             wt[:w.shape[1]] = w.t()
             wts.append(wt.contiguous())
             biases.append((bn.bias - bn.running_mean * a).contiguous())
-    _FOLDED[id(convs[0])] = (versions, wts, biases)
+    _FOLDED[convs[0]] = (key, wts, biases)
     return wts, biases
 
 

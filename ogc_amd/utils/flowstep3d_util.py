@@ -53,11 +53,22 @@ def _shared_mlp(x, convs, norms, pool):
     return x
 
 
+class _FoldAware(nn.Module):
+    """Blocks whose evaluation-mode path runs on weights folded ahead of time (fused.mlp_chain_pool / corr_layer_pool): entering
+    training mode invalidates what was folded (fused.note_training_mode)."""
+
+    def train(self, mode=True):
+        if mode:
+            from ..fused import note_training_mode
+            note_training_mode()
+        return super().train(mode)
+
+
 def _norm2d(channels, use_instance_norm):
     return nn.InstanceNorm2d(channels, affine=True) if use_instance_norm else nn.BatchNorm2d(channels)
 
 
-class FlowEmbedding(nn.Module):
+class FlowEmbedding(_FoldAware):
     """The correlation layer: for every point of cloud 1, its ``nsample`` nearest points of cloud 2 (clamped to
     ``radius``), features [pos2 - pos1, feat2, feat1] -> MLP -> max.  Reference: flowstep3d_util.py:7-66."""
 
@@ -103,7 +114,7 @@ class FlowEmbedding(nn.Module):
         return pos1, _shared_mlp(feat1_new, self.mlp_convs, self.mlp_bns, pool=True)
 
 
-class PointNetSetAbstraction(nn.Module):
+class PointNetSetAbstraction(_FoldAware):
     """Reference: flowstep3d_util.py:69-138.  ``npoint == N`` is legal: FPS then returns a permutation and the
     output features are in FPS order (callers rely on this quirk)."""
 
@@ -185,7 +196,7 @@ class PointNetSetAbstraction(nn.Module):
         return new_xyz, new_points
 
 
-class PointNetFeaturePropogation(nn.Module):
+class PointNetFeaturePropogation(_FoldAware):
     """3-NN inverse-distance upsampling (distances clamped below at 1e-10), optional skip + Conv1d/BN MLP.
     Reference: flowstep3d_util.py:141-184."""
 
@@ -207,14 +218,14 @@ class PointNetFeaturePropogation(nn.Module):
         # the same centres to the same points in every iteration (models/flownet_kitti.py:224, :249)
         memo = geometry_memo.entry(pos1)
         hit = memo["three_nn"].get(id(pos2)) if memo is not None else None
-        if hit is None or hit[0] is not pos2:
+        if hit is None or hit[0] is not pos2 or hit[3] != (pos2.data_ptr(), pos2._version):
             dists, idx = three_nn(pos1.permute(0, 2, 1).contiguous(), pos2.permute(0, 2, 1).contiguous())
             weight = 1.0 / dists.clamp(min=1e-10)                                     # :169-170
             weight = (weight / weight.sum(dim=-1, keepdim=True)).contiguous()
-            hit = (pos2, idx, weight)
+            hit = (pos2, idx, weight, (pos2.data_ptr(), pos2._version))
             if memo is not None:
                 memo["three_nn"][id(pos2)] = hit
-        _, idx, weight = hit
+        _, idx, weight, _ = hit
         # sum_k w_k f[idx_k] (:171): one kernel, evaluated as (w0 f0 + w1 f1) + w2 f2 without contraction
         interpolated = three_interpolate(feature2.contiguous(), idx, weight)
         feat_new = interpolated if feature1 is None else torch.cat([interpolated, feature1], dim=1)

@@ -1018,6 +1018,42 @@ def test_flow_embedding_inference_uses_the_fused_chain(nat):
     torch.testing.assert_close(y, y_ref, rtol=1e-4, atol=1e-5)
 
 
+def test_folded_inference_weights_follow_training(nat):
+    """evaluate -> train -> evaluate: the second evaluation must see the trained weights and running statistics.  The fused
+    optimizer and this library's BatchNorm kernels write through raw pointers, which tensor version counters do not see — a cache
+    of folded weights keyed on versions alone served the first evaluation's weights for ever (found by the flow trainer's replay
+    test: validation loss of the second epoch off by 10 %)."""
+    from ogc_amd import fused
+    from ogc_amd.train_step import make_optimizer
+    from ogc_amd.utils.flowstep3d_util import PointNetSetAbstraction
+    torch.manual_seed(4)
+    sa = PointNetSetAbstraction(npoint=256, radius=None, nsample=16, in_channel=3, mlp=[32, 32, 32], group_all=False).to(DEV)
+    xyz = (torch.rand(2, 3, 1024, device=DEV) - 0.5) * 10
+    opt = make_optimizer(sa.parameters(), lr=1e-2)
+
+    def evaluate(fused_path):
+        sa.eval()
+        avail = fused.mlp_chain_pool_available
+        try:
+            if not fused_path:
+                fused.mlp_chain_pool_available = lambda *a: False
+            with torch.no_grad():
+                return sa(xyz, xyz)[1].clone()
+        finally:
+            fused.mlp_chain_pool_available = avail
+
+    first = evaluate(True)
+    torch.testing.assert_close(first, evaluate(False), rtol=1e-4, atol=1e-5)
+    for _ in range(3):                                   # running statistics and weights move, versions do not
+        sa.train()
+        opt.zero_grad()
+        (sa(xyz, xyz)[1] ** 2).mean().backward()
+        opt.step()
+    second, second_ref = evaluate(True), evaluate(False)
+    assert float((second_ref - first).abs().max()) > 1e-2, "the training steps should have changed the block"
+    torch.testing.assert_close(second, second_ref, rtol=1e-4, atol=1e-5)
+
+
 @pytest.mark.parametrize("B,cin,cout,hw,relu", [(4, 128, 128, 32768, 1), (3, 131, 256, 45056, 1), (8, 128, 64, 16384, 0)])
 def test_conv1x1_gemm_affine_streaming_kernel(nat, B, cin, cout, hw, relu):
     """ogc_conv1x1_gemm_affine at shapes that take the streaming kernel (K > 100, >= 2048 position tiles): out = W act(pa x + pb)
