@@ -51,8 +51,19 @@ int oracle_get_threads(void) {
 
 /* fp32 squared distance, source order (interpolate_gpu.cu:40, ball_query_gpu.cu:33,
  * sampling_gpu.cu:133 — note FPS writes (x2-x1), the others (u-x); squares are equal). */
+static int g_fmad = 0;
+
+/* 0 (default, what the HIP kernels and every parity test pin): the source expression, one rounding per operation.
+ * 1: the expression as `nvcc --fmad=true` (its default) contracts it — dx*dx + dy*dy + dz*dz becomes
+ * fma(dz, dz, fma(dy, dy, dx*dx)): two roundings fewer.  The reference's binary was built that way; this mode exists to COUNT
+ * how many indices of FPS / kNN / three-NN / ball query the contraction changes (tests/test_fma_sensitivity.py), nothing ships
+ * with it. */
+void oracle_set_fmad(int on) { g_fmad = on; }
+int oracle_get_fmad(void) { return g_fmad; }
+
 static inline float sqdist(float ax, float ay, float az, float bx, float by, float bz) {
     float dx = ax - bx, dy = ay - by, dz = az - bz;
+    if (g_fmad) return fmaf(dz, dz, fmaf(dy, dy, dx * dx));
     float xx = dx * dx, yy = dy * dy, zz = dz * dz;
     float s = xx + yy;
     return s + zz;

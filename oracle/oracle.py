@@ -61,6 +61,8 @@ def lib():
             fn.argtypes = argtypes
             fn.restype = _int
         L.oracle_set_threads.argtypes = [_int]
+        L.oracle_set_fmad.argtypes = [_int]
+        L.oracle_get_fmad.restype = _int
         L.oracle_get_threads.restype = _int
         L.oracle_fps_block_size.argtypes = [_int]
         L.oracle_fps_block_size.restype = _int
@@ -74,6 +76,18 @@ def set_threads(n):
 
 def get_threads():
     return lib().oracle_get_threads()
+
+
+class fmad:
+    """`with oracle.fmad():` — the distance expression contracted the way `nvcc --fmad=true` contracts it (see ogc_oracle.c);
+    for counting what the contraction changes, never for parity."""
+
+    def __enter__(self):
+        self._prev = lib().oracle_get_fmad()
+        lib().oracle_set_fmad(1)
+
+    def __exit__(self, *exc):
+        lib().oracle_set_fmad(self._prev)
 
 
 def fps_block_size(n):

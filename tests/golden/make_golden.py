@@ -340,6 +340,23 @@ def gen_models():
         save("model_" + name, **out)
 
 
+def gen_group_all():
+    """GroupAll (pointnet2/pointnet2.py:304-327) in its three modes, and the FlowStep3D set-abstraction layer with
+    group_all=True (utils/flowstep3d_util.py:99-138: no sampling, one group holding every point)."""
+    from pointnet2.pointnet2 import GroupAll
+    from utils.flowstep3d_util import PointNetSetAbstraction
+    xyz, feats = T(detgen.cloud(2, 40, 95, scale=(1, 1, 1))), T(detgen.uniform((2, 5, 40), 96))
+    out = {}
+    for tag, use_xyz, f in (("xyz_feats", True, feats), ("feats", False, feats), ("xyz", True, None)):
+        nf, gx = GroupAll(use_xyz)(xyz, None, f)
+        out[tag], out[tag + "_grouped_xyz"] = nf, gx
+    sa = detgen.fill_module(PointNetSetAbstraction(npoint=None, radius=None, nsample=None, in_channel=5, mlp=[8, 8],
+                                                   group_all=True), 9)
+    new_xyz, new_points = sa(xyz.transpose(1, 2).contiguous(), feats)
+    out["sa_new_xyz"], out["sa_new_points"] = new_xyz, new_points.detach()
+    save("group_all", **out)
+
+
 def gen_data_ops():
     """utils/data_util.py:8-38 — fps_downsample (numpy cloud -> FPS indices) and upsample_feat (3-NN inverse-distance
     upsampling of per-point features), executed by the reference's functions on the oracle's operators."""
@@ -459,3 +476,5 @@ if __name__ == "__main__":
         gen_fullsize()
     if "data_ops" in which:
         gen_data_ops()
+    if "group_all" in which:
+        gen_group_all()

@@ -31,6 +31,10 @@ def test_data_ops(cpu_ops):
     gc.run_data_ops("cpu")
 
 
+def test_group_all(cpu_ops):
+    gc.run_group_all("cpu")
+
+
 @pytest.mark.parametrize("name,npoint,n_level,feat_c,scale", gc.GCORR_CASES, ids=[c[0] for c in gc.GCORR_CASES])
 def test_global_corr_layer(cpu_ops, name, npoint, n_level, feat_c, scale):
     gc.run_global_corr("cpu", name, npoint, n_level, feat_c, scale).check()

@@ -35,6 +35,10 @@ def test_data_ops():
     gc.run_data_ops("cuda")
 
 
+def test_group_all():
+    gc.run_group_all("cuda")
+
+
 def test_seg_and_flow_metrics_on_device():
     """accumulate_eval_results / AP / PQ / F1 and eval_flow with the tensors on the GPU, against the reference's numpy
     implementations (fixture data_util.npz; same assertions as tests/test_golden_cpu.py)."""
