@@ -152,6 +152,25 @@ int ogc_ball_query(int b, int n, int m, float radius, int nsample, const float *
 int ogc_knn_clamped(int b, int n, int m, int k, float radius, const float *unknown,
                     const float *known, float *dist, int *idx, ogc_stream_t stream);
 
+/* One cell grid for several radius searches of the same clouds in themselves.  The smoothness term of the OGC loss searches every
+ * cloud twice — k nearest within r_knn, then the first nsample within r_ball
+ *   losses/seg_loss_unsup.py:120-123 (KnnLoss), :151-152 (BallQLoss), both on (pc, pc)
+ * — and ogc_knn_clamped / ogc_ball_query each sort the cloud into cells first (a third to a half of either call).  Here the
+ * caller builds the grid ONCE, for the largest radius it will ask for, into memory it owns, and runs the searches on it:
+ *   ogc_cell_grid_bytes(b, n)            size of the grid buffer (bytes; 256-byte aligned device memory)
+ *   ogc_cell_grid_build(b, n, r, xyz, grid)        cells of edge 1.01 r over each cloud's bounding box; xyz (b,n,3), n >= 1024
+ *   ogc_ball_query_cells(b, n, radius, nsample, xyz, grid, grid_radius, idx)       == ogc_ball_query(b, n, n, radius, nsample, xyz, xyz, idx)
+ *   ogc_knn_clamped_cells(b, n, k, radius, xyz, grid, grid_radius, dist, idx)      == ogc_knn_clamped(b, n, n, k, radius, xyz, xyz, dist, idx)
+ * for any radius <= grid_radius (the radius the grid was built with; larger ones are refused: OGC_ERR_UNSUPPORTED), bit for bit —
+ * cells longer than a query needs only add candidates.  The grid stays valid until the caller frees or overwrites it; the k-NN
+ * search writes a per-cloud flag into it (rows it left to its second kernel), nothing else does. */
+long long ogc_cell_grid_bytes(int b, int n);
+int ogc_cell_grid_build(int b, int n, float radius, const float *xyz, void *grid, ogc_stream_t stream);
+int ogc_ball_query_cells(int b, int n, float radius, int nsample, const float *xyz, const void *grid, float grid_radius, int *idx,
+                         ogc_stream_t stream);
+int ogc_knn_clamped_cells(int b, int n, int k, float radius, const float *xyz, void *grid, float grid_radius, float *dist, int *idx,
+                          ogc_stream_t stream);
+
 /* Batched 3x3 Kabsch rotation.  Replaces torch.svd + the reflection fix of the weighted-Kabsch fit
  *   losses/seg_loss_unsup.py:44-53:  u,s,v = svd(S); R = v diag(1,1,det(v u^T)) u^T.
  * S (nb,3,3) f32 cross-covariances (P_c^T diag(w) Q_c), R (nb,3,3) f32 out; valid (nb) i32 out or NULL:

@@ -31,6 +31,10 @@ SIGNATURES = {
     "ogc_group_points_grad_rev": [_int, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp],
     "ogc_ball_query": [_int, _int, _int, _flt, _int, _vp, _vp, _vp, _vp],
     "ogc_knn_clamped": [_int, _int, _int, _int, _flt, _vp, _vp, _vp, _vp, _vp],
+    "ogc_cell_grid_bytes": [_int, _int],
+    "ogc_cell_grid_build": [_int, _int, _flt, _vp, _vp, _vp],
+    "ogc_ball_query_cells": [_int, _int, _flt, _int, _vp, _vp, _flt, _vp, _vp],
+    "ogc_knn_clamped_cells": [_int, _int, _int, _flt, _vp, _vp, _flt, _vp, _vp, _vp],
     "ogc_kabsch_rotation": [_int, _vp, _vp, _vp, _vp],
     "ogc_lsap_maximize": [_int, _int, _vp, _vp, _vp],
     "ogc_rigid_moments": [_int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
@@ -117,6 +121,7 @@ def load():
             fn.restype = _int
         L.ogc_version.restype = _int
         L.ogc_slot_masks_ws_floats.restype = ctypes.c_longlong
+        L.ogc_cell_grid_bytes.restype = ctypes.c_longlong
         L.ogc_last_error.restype = ctypes.c_char_p
         _lib = L
     return _lib

@@ -123,7 +123,7 @@ __device__ __forceinline__ GridHdr grid_header(const float (&lo)[3], const float
     h.npts = 0;
     h.dense = 0;
     h.heavy = 0;
-    h.knn_general = cells_ok ? 0 : 1;
+    h.knn_general = (cells_ok || prefer_cells == 2) ? 0 : 1;   // (2: a grid shared by several searches, built for their largest radius)
     h.pending = 0;
     return h;
 }
@@ -1443,27 +1443,32 @@ static bool ogc_bq_cells_enabled() {
     return !(e && e[0] == '0');
 }
 
-int ogc_ball_query_grid(int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz,
-                        int *idx, hipStream_t s) {
+namespace {
+struct GridLayout { // one buffer: headers | cell starts | cell-sorted records (+ BQ_PAD readable records behind them)
+    size_t bytes_hdr, bytes_cs, bytes_pts;
+    GridLayout(int b, int n)
+        : bytes_hdr((sizeof(GridHdr) * b + 255) / 256 * 256),
+          bytes_cs((sizeof(int) * (size_t)b * (GRID_MAX_CELLS + 1) + 255) / 256 * 256),
+          bytes_pts(sizeof(float4) * ((size_t)b * n + BQ_PAD)) {}
+    size_t total() const { return bytes_hdr + bytes_cs + bytes_pts; }
+    GridHdr *hdrs(void *p) const { return reinterpret_cast<GridHdr *>(p); }
+    int *cell_start(void *p) const { return reinterpret_cast<int *>(static_cast<char *>(p) + bytes_hdr); }
+    float4 *sorted_pts(void *p) const { return reinterpret_cast<float4 *>(static_cast<char *>(p) + bytes_hdr + bytes_cs); }
+};
+constexpr int STRIDE_CELLS = GRID_MAX_CELLS + 1;
+
+// the query kernels of ogc_ball_query on a built grid (four lanes per centre for the usual row lengths; the general kernel —
+// eight centres per wavefront — otherwise)
+int launch_ball_query(const GridLayout &L, void *grid, int b, int n, int m, float radius, int nsample, const float *xyz, int *idx,
+                      hipStream_t s) {
+    GridHdr *hdrs = L.hdrs(grid);
+    int *cell_start = L.cell_start(grid);
+    float4 *sorted_pts = L.sorted_pts(grid);
+    const int stride_cells = STRIDE_CELLS;
     // hit slots per centre: the smallest list that holds a full row keeps the LDS footprint at ~5 KiB per wavefront,
     // i.e. the full eight wavefronts per SIMD; a centre with more hits takes the bitmap path
     const int hit_cap = nsample > 64 ? nsample : 64;
     const size_t lds = ((size_t)QPW * (hit_cap + nsample) + (size_t)(n + 31) / 32) * sizeof(int);
-    // the cell-ordered traversal needs the centres to BE the points (ball_query(pc, pc), the reference's only live
-    // use: losses/seg_loss_unsup.py:151, losses/flow_loss_unsup.py:84); other centre sets use the all-pairs scan
-    const bool same = (new_xyz == xyz) && (m == n);
-    if (!same || n < 1024 || lds > 64 * 1024 || !(radius > 0.0f) || !(radius < 3.0e38f)) return OGC_ERR_UNSUPPORTED;
-    const int stride_cells = GRID_MAX_CELLS + 1;
-    const size_t bytes_hdr = (sizeof(GridHdr) * b + 255) / 256 * 256;
-    const size_t bytes_cs = (sizeof(int) * (size_t)b * stride_cells + 255) / 256 * 256;
-    const size_t bytes_pts = sizeof(float4) * ((size_t)b * n + BQ_PAD);
-    char *ws = static_cast<char *>(ogc_workspace(s, bytes_hdr + bytes_cs + bytes_pts));
-    if (!ws) return OGC_ERR_UNSUPPORTED;
-    GridHdr *hdrs = reinterpret_cast<GridHdr *>(ws);
-    int *cell_start = reinterpret_cast<int *>(ws + bytes_hdr);
-    float4 *sorted_pts = reinterpret_cast<float4 *>(ws + bytes_hdr + bytes_cs);
-    launch_grid_build(b, n, radius, 0, stride_cells, xyz, hdrs, cell_start, sorted_pts, s);
-    // four lanes per centre for the usual row lengths; the general kernel (eight centres per wavefront) otherwise
     const size_t lds_body = ((size_t)QPW * (BQ_CAP + nsample) + (size_t)(n + 31) / 32) * sizeof(int);
     const size_t lds4 = lds_body > sizeof(int) * CPW * BQ_LIST ? lds_body : sizeof(int) * CPW * BQ_LIST;
     const dim3 grid4(ogc_divup(n, CPW), b);
@@ -1485,28 +1490,14 @@ int ogc_ball_query_grid(int b, int n, int m, float radius, int nsample, const fl
     return OGC_OK;
 }
 
-// k-NN over cell lists.  Returns OGC_OK after queueing build + query, or OGC_ERR_UNSUPPORTED (caller: all-pairs scan).
-int ogc_knn_grid(int mode, int b, int n, int m, int k, float radius, const float *unknown, const float *known,
-                 float *dist, int *idx, hipStream_t s) {
-    const size_t lds = (size_t)2 * QPW * k * sizeof(u64) + (size_t)QPW * KNN_FLAT_CAP * sizeof(int);
-    if (m < 1024 || m <= 4 * k || lds > 64 * 1024) return OGC_ERR_UNSUPPORTED;
-    const int stride_cells = GRID_MAX_CELLS + 1;
-    const size_t bytes_hdr = (sizeof(GridHdr) * b + 255) / 256 * 256;
-    const size_t bytes_cs = (sizeof(int) * (size_t)b * stride_cells + 255) / 256 * 256;
-    const size_t bytes_pts = sizeof(float4) * ((size_t)b * m + BQ_PAD);
-    char *ws = static_cast<char *>(ogc_workspace(s, bytes_hdr + bytes_cs + bytes_pts));
-    if (!ws) return OGC_ERR_UNSUPPORTED;
-    GridHdr *hdrs = reinterpret_cast<GridHdr *>(ws);
-    int *cell_start = reinterpret_cast<int *>(ws + bytes_hdr);
-    float4 *sorted_pts = reinterpret_cast<float4 *>(ws + bytes_hdr + bytes_cs);
-    // radius-limited search of a cloud in itself (the smoothness term's neighbour lists): four lanes per query over the 27 cells
-    // around it first (the build then prefers cells of edge 1.01 r when balls are sparsely filled); knn_grid_kernel afterwards
-    // only does what that kernel left (marked rows, clouds flagged knn_general)
-    const bool cells = mode == 1 && radius > 0.0f && radius < 1.0e18f && unknown == known && n == m &&
-                       (k == 4 || k == 8 || k == 16 || k == 32) && ogc_knn_cells_enabled();
-    launch_grid_build(b, m, mode == 1 ? radius : 0.0f, k, stride_cells, known, hdrs, cell_start, sorted_pts, s, cells ? 1 : 0);
-    dim3 grid(ogc_divup(n, QPW), b);
-    // d2 <= lim2  <=>  sqrtf(d2) <= radius: the largest float whose correctly rounded root does not exceed the radius
+bool ball_query_grid_applies(int n, int nsample, float radius) {
+    const int hit_cap = nsample > 64 ? nsample : 64;
+    const size_t lds = ((size_t)QPW * (hit_cap + nsample) + (size_t)(n + 31) / 32) * sizeof(int);
+    return n >= 1024 && lds <= 64 * 1024 && radius > 0.0f && radius < 3.0e38f;
+}
+
+// d2 <= lim2  <=>  sqrtf(d2) <= radius: the largest float whose correctly rounded root does not exceed the radius
+float knn_radius_limit2(int mode, float radius) {
     float lim2 = INFINITY;
     if (mode == 1 && radius >= 0.0f) {
         lim2 = radius * radius;
@@ -1516,6 +1507,20 @@ int ogc_knn_grid(int mode, int b, int n, int m, int k, float radius, const float
             if (up < INFINITY && sqrtf(up) <= radius) lim2 = up;
         }
     }
+    return lim2;
+}
+
+// the query kernels of ogc_knn / ogc_knn_clamped on a built grid.  cells: four lanes per query over the 27 cells around it first;
+// knn_grid_kernel afterwards only does what that kernel left (marked rows, clouds flagged knn_general)
+int launch_knn(const GridLayout &L, void *grid, int mode, int b, int n, int m, int k, float radius, bool cells, const float *unknown,
+               float *dist, int *idx, hipStream_t s) {
+    GridHdr *hdrs = L.hdrs(grid);
+    int *cell_start = L.cell_start(grid);
+    float4 *sorted_pts = L.sorted_pts(grid);
+    const int stride_cells = STRIDE_CELLS;
+    const size_t lds = (size_t)2 * QPW * k * sizeof(u64) + (size_t)QPW * KNN_FLAT_CAP * sizeof(int);
+    dim3 grid8(ogc_divup(n, QPW), b);
+    const float lim2 = knn_radius_limit2(mode, radius);
     int deferred = 0;
     if (cells) {
         const dim3 grid4(ogc_divup(n, CPW), b);
@@ -1531,10 +1536,10 @@ int ogc_knn_grid(int mode, int b, int n, int m, int k, float radius, const float
         deferred = 1;
     }
     if (mode == 1)
-        hipLaunchKernelGGL(knn_grid_kernel<1>, grid, dim3(OGC_WAVE), lds, s, n, m, k, radius, lim2, stride_cells, deferred, unknown,
+        hipLaunchKernelGGL(knn_grid_kernel<1>, grid8, dim3(OGC_WAVE), lds, s, n, m, k, radius, lim2, stride_cells, deferred, unknown,
                            hdrs, cell_start, sorted_pts, dist, idx);
     else
-        hipLaunchKernelGGL(knn_grid_kernel<0>, grid, dim3(OGC_WAVE), lds, s, n, m, k, radius, lim2, stride_cells, 0, unknown,
+        hipLaunchKernelGGL(knn_grid_kernel<0>, grid8, dim3(OGC_WAVE), lds, s, n, m, k, radius, lim2, stride_cells, 0, unknown,
                            hdrs, cell_start, sorted_pts, dist, idx);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
@@ -1542,4 +1547,90 @@ int ogc_knn_grid(int mode, int b, int n, int m, int k, float radius, const float
         return OGC_ERR_LAUNCH;
     }
     return OGC_OK;
+}
+
+bool knn_cells_applies(int mode, int n, int m, int k, float radius, bool same) {
+    return mode == 1 && radius > 0.0f && radius < 1.0e18f && same && n == m && (k == 4 || k == 8 || k == 16 || k == 32) &&
+           ogc_knn_cells_enabled();
+}
+} // namespace
+
+int ogc_ball_query_grid(int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz,
+                        int *idx, hipStream_t s) {
+    // the cell-ordered traversal needs the centres to BE the points (ball_query(pc, pc), the reference's only live
+    // use: losses/seg_loss_unsup.py:151, losses/flow_loss_unsup.py:84); other centre sets use the all-pairs scan
+    const bool same = (new_xyz == xyz) && (m == n);
+    if (!same || !ball_query_grid_applies(n, nsample, radius)) return OGC_ERR_UNSUPPORTED;
+    const GridLayout L(b, n);
+    void *ws = ogc_workspace(s, L.total());
+    if (!ws) return OGC_ERR_UNSUPPORTED;
+    launch_grid_build(b, n, radius, 0, STRIDE_CELLS, xyz, L.hdrs(ws), L.cell_start(ws), L.sorted_pts(ws), s);
+    return launch_ball_query(L, ws, b, n, m, radius, nsample, xyz, idx, s);
+}
+
+// k-NN over cell lists.  Returns OGC_OK after queueing build + query, or OGC_ERR_UNSUPPORTED (caller: all-pairs scan).
+int ogc_knn_grid(int mode, int b, int n, int m, int k, float radius, const float *unknown, const float *known,
+                 float *dist, int *idx, hipStream_t s) {
+    const size_t lds = (size_t)2 * QPW * k * sizeof(u64) + (size_t)QPW * KNN_FLAT_CAP * sizeof(int);
+    if (m < 1024 || m <= 4 * k || lds > 64 * 1024) return OGC_ERR_UNSUPPORTED;
+    const GridLayout L(b, m);
+    void *ws = ogc_workspace(s, L.total());
+    if (!ws) return OGC_ERR_UNSUPPORTED;
+    // radius-limited search of a cloud in itself (the smoothness term's neighbour lists): the build then prefers cells of edge
+    // 1.01 r when balls are sparsely filled
+    const bool cells = knn_cells_applies(mode, n, m, k, radius, unknown == known);
+    launch_grid_build(b, m, mode == 1 ? radius : 0.0f, k, STRIDE_CELLS, known, L.hdrs(ws), L.cell_start(ws), L.sorted_pts(ws), s,
+                      cells ? 1 : 0);
+    return launch_knn(L, ws, mode, b, n, m, k, radius, cells, unknown, dist, idx, s);
+}
+
+// ---- one grid for several radius searches of a batch of clouds in themselves (fused extension, include/ogc_ops.h) ------------
+extern "C" long long ogc_cell_grid_bytes(int b, int n) {
+    if (b < 0 || n < 0) return -1;
+    return (long long)GridLayout(b, n).total();
+}
+
+extern "C" int ogc_cell_grid_build(int b, int n, float radius, const float *xyz, void *grid, ogc_stream_t stream) {
+    OGC_REQUIRE(b >= 0 && n >= 0, "ogc_cell_grid_build: negative dimension");
+    if (b == 0 || n == 0) return OGC_OK;
+    OGC_REQUIRE(xyz && grid, "ogc_cell_grid_build: null pointer");
+    if (!(radius > 0.0f) || !(radius < 3.0e38f) || n < 1024) {
+        ogc_set_error("ogc_cell_grid_build: needs a finite positive radius and clouds of at least 1024 points (n=%d, r=%g)", n,
+                      (double)radius);
+        return OGC_ERR_UNSUPPORTED;
+    }
+    const GridLayout L(b, n);
+    launch_grid_build(b, n, radius, 0, STRIDE_CELLS, xyz, L.hdrs(grid), L.cell_start(grid), L.sorted_pts(grid), (hipStream_t)stream, 2);
+    OGC_CHECK_LAUNCH("ogc_cell_grid_build");
+    return OGC_OK;
+}
+
+extern "C" int ogc_ball_query_cells(int b, int n, float radius, int nsample, const float *xyz, const void *grid, float grid_radius,
+                                    int *idx, ogc_stream_t stream) {
+    OGC_REQUIRE(b >= 0 && n >= 0 && nsample >= 0, "ogc_ball_query_cells: negative dimension");
+    if (b == 0 || n == 0 || nsample == 0) return OGC_OK;
+    OGC_REQUIRE(xyz && grid && idx, "ogc_ball_query_cells: null pointer");
+    OGC_REQUIRE((long long)b * n * nsample < (1ll << 31), "ogc_ball_query_cells: idx exceeds 32-bit indexing");
+    // cells are 1.01 x the radius the grid was built for: a query of up to that radius finds its hits in the 27 cells around it
+    if (!(radius <= grid_radius) || !ball_query_grid_applies(n, nsample, radius)) {
+        ogc_set_error("ogc_ball_query_cells: radius %g exceeds the grid's (%g), or a shape the cell lists do not take (n=%d, "
+                      "nsample=%d)", (double)radius, (double)grid_radius, n, nsample);
+        return OGC_ERR_UNSUPPORTED;
+    }
+    return launch_ball_query(GridLayout(b, n), const_cast<void *>(grid), b, n, n, radius, nsample, xyz, idx, (hipStream_t)stream);
+}
+
+extern "C" int ogc_knn_clamped_cells(int b, int n, int k, float radius, const float *xyz, void *grid, float grid_radius, float *dist,
+                                     int *idx, ogc_stream_t stream) {
+    OGC_REQUIRE(b >= 0 && n >= 0 && k >= 1, "ogc_knn_clamped_cells: bad dimension");
+    if (b == 0 || n == 0) return OGC_OK;
+    OGC_REQUIRE(xyz && grid && dist && idx, "ogc_knn_clamped_cells: null pointer");
+    const size_t lds = (size_t)2 * QPW * k * sizeof(u64) + (size_t)QPW * KNN_FLAT_CAP * sizeof(int);
+    if (!(radius > 0.0f) || !(radius <= grid_radius) || n < 1024 || n <= 4 * k || lds > 64 * 1024) {
+        ogc_set_error("ogc_knn_clamped_cells: needs 0 < radius <= the grid's radius (%g vs %g), n >= 1024, n > 4 k", (double)radius,
+                      (double)grid_radius);
+        return OGC_ERR_UNSUPPORTED;
+    }
+    return launch_knn(GridLayout(b, n), grid, 1, b, n, n, k, radius, knn_cells_applies(1, n, n, k, radius, true), xyz, dist, idx,
+                      (hipStream_t)stream);
 }

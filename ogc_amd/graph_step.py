@@ -113,17 +113,21 @@ class GraphedTrainStep:
         s = self.stream
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
-            self._warm_up(it)
             if self.plan is None:
                 self.plan = PrefetchedGeometry(self.segnet, self.criterion, self.cur, self.aug)
-            torch.cuda.synchronize()
-            _resolve(self.plan, wait=False)
-            self.optimizer.zero_grad(set_to_none=True)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=s):
-                pending = train_step(self.segnet, self.criterion, self.optimizer, self.cur, it, self.aug, sync=False,
-                                     prefetched=self.plan)
-                _join_side_streams(torch.cuda.current_stream())
+            # warm-up and capture on side streams of their OWN (streams.stream_namespace): the eager geometry plans of step()
+            # run on the ordinary side streams underneath a replay, and must not meet captured kernels on a stream (and so on
+            # a scratch buffer) of theirs
+            with _streams.stream_namespace("graph:"):
+                self._warm_up(it)
+                torch.cuda.synchronize()
+                _resolve(self.plan, wait=False)
+                self.optimizer.zero_grad(set_to_none=True)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=s):
+                    pending = train_step(self.segnet, self.criterion, self.optimizer, self.cur, it, self.aug, sync=False,
+                                         prefetched=self.plan)
+                    _join_side_streams(torch.cuda.current_stream())
         torch.cuda.current_stream().wait_stream(s)
         self.graph, self.pending = graph, pending
         self._plan_dst = list(_plan_tensors(self.plan))

@@ -76,8 +76,11 @@ class SmoothLoss(nn.Module):
         searches them again for every refinement iteration's prediction (:126-130) although pc1 never changes."""
         pc = pc.contiguous()
         kl, bl = self.knn_loss, self.ball_q_loss
-        _, idx_knn = knn_radius_clamp(kl.k, kl.radius, pc, pc)
-        idx_ball = ball_query(bl.radius, bl.k, pc, pc)
+        from .seg_loss_unsup import _shared_grid_searches
+        idx_knn, idx_ball = _shared_grid_searches(pc, kl.k, kl.radius, bl.k, bl.radius)   # one cell grid for both searches
+        if idx_knn is None:
+            _, idx_knn = knn_radius_clamp(kl.k, kl.radius, pc, pc)
+            idx_ball = ball_query(bl.radius, bl.k, pc, pc)
         plan = {"knn": idx_knn, "ball": idx_ball}
         if pc.is_cuda:
             from ..fused import reverse_neighbours

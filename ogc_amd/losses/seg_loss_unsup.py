@@ -145,6 +145,26 @@ class KnnLoss(nn.Module):
         return _neighbour_consistency(mask, idx, self.k, self.cross_entropy, self.loss_norm)
 
 
+def _shared_grid_searches(pc, k, r_knn, nsample, r_ball):
+    """Both neighbour searches of the smoothness term — k nearest within r_knn (clamped), first nsample within r_ball, each of the
+    clouds in themselves — on ONE cell grid built for the larger radius (ogc_cell_grid_build: each search alone sorts the clouds
+    into cells first, a third to a half of its time).  Same index tensors as knn_radius_clamp / ball_query, bit for bit
+    (tests/test_ops_gpu.py::test_shared_cell_grid_searches).  (None, None) where the grid does not apply."""
+    from ..pointnet2 import pointnet2 as _api
+    cg = getattr(_api._native, "CellGrid", None)
+    if (cg is None or r_knn is None or r_ball is None or not pc.is_cuda or pc.dtype != torch.float32
+            or not cg.applies(pc, max(r_knn, r_ball)) or not (r_knn > 0) or pc.shape[1] <= 4 * k or nsample > 512):
+        return None, None
+    grid = cg(pc, max(r_knn, r_ball))
+    B, N, _ = pc.shape
+    dist = torch.empty(B, N, k, dtype=torch.float32, device=pc.device)
+    idx_knn = torch.empty(B, N, k, dtype=torch.int32, device=pc.device)
+    grid.knn_clamped(k, r_knn, dist, idx_knn)
+    idx_ball = torch.empty(B, N, nsample, dtype=torch.int32, device=pc.device)
+    grid.ball_query(r_ball, nsample, idx_ball)
+    return idx_knn, idx_ball
+
+
 class BallQLoss(nn.Module):
     """Mask smoothness over ball-query neighbours. Reference: :132-158."""
 
@@ -180,8 +200,10 @@ class SmoothLoss(nn.Module):
         the transposed lists the fused gradient kernel gathers over."""
         pc = torch.cat(list(pcs)).contiguous()
         kl, bl = self.knn_loss, self.ball_q_loss
-        _, idx_knn = knn_radius_clamp(kl.k, kl.radius, pc, pc)
-        idx_ball = ball_query(bl.radius, bl.k, pc, pc)
+        idx_knn, idx_ball = _shared_grid_searches(pc, kl.k, kl.radius, bl.k, bl.radius)
+        if idx_knn is None:
+            _, idx_knn = knn_radius_clamp(kl.k, kl.radius, pc, pc)
+            idx_ball = ball_query(bl.radius, bl.k, pc, pc)
         plan = {"knn": idx_knn, "ball": idx_ball}
         if pc.is_cuda:
             from ..fused import reverse_neighbours

@@ -188,6 +188,31 @@ def knn_clamped_wrapper(b, n, m, k, radius, unknown, known, dist, idx):
          _f(dist, "dist"), _i(idx, "idx"))
 
 
+class CellGrid:
+    """One cell grid for several radius searches of a batch of clouds in themselves (ogc_cell_grid_build): `xyz` (b, n, 3), cells
+    of edge 1.01 x `radius`.  `ball_query(radius, nsample)` / `knn_clamped(k, radius)` give what ball_query_wrapper /
+    knn_clamped_wrapper give for (xyz, xyz) and any radius up to the grid's, without sorting the clouds into cells again."""
+
+    def __init__(self, xyz, radius):
+        b, n, _ = xyz.shape
+        self.xyz, self.radius, self.b, self.n = xyz, float(radius), b, n
+        nbytes = int(_lib.load().ogc_cell_grid_bytes(b, n))
+        self.buf = torch.empty(nbytes, dtype=torch.uint8, device=xyz.device)
+        _run("ogc_cell_grid_build", xyz, b, n, self.radius, _f(xyz, "xyz"), self.buf.data_ptr())
+
+    @staticmethod
+    def applies(xyz, radius):
+        return xyz.is_cuda and xyz.dim() == 3 and xyz.shape[1] >= 1024 and 0.0 < float(radius) < 3.0e38
+
+    def ball_query(self, radius, nsample, idx):
+        _run("ogc_ball_query_cells", self.xyz, self.b, self.n, float(radius), nsample, _f(self.xyz, "xyz"), self.buf.data_ptr(),
+             self.radius, _i(idx, "idx"))
+
+    def knn_clamped(self, k, radius, dist, idx):
+        _run("ogc_knn_clamped_cells", self.xyz, self.b, self.n, k, float(radius), _f(self.xyz, "xyz"), self.buf.data_ptr(),
+             self.radius, _f(dist, "dist"), _i(idx, "idx"))
+
+
 def kabsch_rotation_wrapper(nb, S, R, valid=None):
     """R = V diag(1,1,det) U^T per 3x3 cross-covariance (ogc_kabsch_rotation); NaN matrices give the identity."""
     _run("ogc_kabsch_rotation", S, nb, _f(S, "S"), _f(R, "R"), 0 if valid is None else _i(valid, "valid"))

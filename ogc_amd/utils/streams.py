@@ -5,11 +5,30 @@ stream changes; ordering is enforced with events and the caching allocator is to
 import torch
 
 _side = {}
+_namespace = [""]
+
+
+class stream_namespace:
+    """Inside this scope side_stream() hands out streams of their own (`<prefix><key>`).  A graph capture runs in one: the
+    native operators keep their scratch buffers per stream (ogc_workspace), and kernels replayed from a graph are not ordered
+    against eager kernels queued on the stream they were captured from — so captured work and the eager work that runs
+    underneath a replay (the next batch's geometry plan) must never share a stream."""
+
+    def __init__(self, prefix):
+        self.prefix = prefix
+
+    def __enter__(self):
+        self._prev = _namespace[0]
+        _namespace[0] = self.prefix
+        return self
+
+    def __exit__(self, *exc):
+        _namespace[0] = self._prev
 
 
 def side_stream(device, key="geometry", priority=0):
     """The process-wide side stream `key` of `device`; `priority` (-1 = high) applies when it is first created."""
-    k = (torch.device(device).index, key)
+    k = (torch.device(device).index, _namespace[0] + key)
     if k not in _side:
         _side[k] = torch.cuda.Stream(device=device, priority=priority)
     return _side[k]

@@ -679,6 +679,40 @@ def test_ball_query_grid_clustered(nat, oracle, monkeypatch, cells):
     assert np.array_equal(idx.cpu().numpy(), oracle.ball_query(1.0, 64, flat, flat))
 
 
+@pytest.mark.parametrize("n,k,r_knn,ns,r_ball,scale,dup", [
+    (8192, 32, 1.0, 64, 2.0, (60, 4, 80), 0), (8192, 32, 1.0, 64, 2.0, (60, 4, 80), 900),   # C4's smoothness term
+    (4096, 8, 0.02, 16, 0.04, (1, 1, 1), 0),                                                # C2's
+    (2048, 4, 0.05, 8, 0.1, (1, 1, 1), 100), (16384, 32, 1.0, 64, 2.0, (60, 4, 80), 0),     # flow losses, C5
+    (3000, 16, 2.5, 32, 1.0, (30, 4, 40), 0),                                               # the k-NN radius the larger one
+    (4099, 32, 0.3, 16, 3.0, (20, 20, 20), 0),                                              # dense balls: rows beyond the fast paths
+])
+def test_shared_cell_grid_searches(nat, oracle, n, k, r_knn, ns, r_ball, scale, dup):
+    """ogc_cell_grid_build once (for the larger radius), then ogc_knn_clamped_cells and ogc_ball_query_cells on it: the index
+    tensors of knn + clamp and of the ball query of the oracle, bit for bit, and the distances of the kept neighbours; a radius
+    beyond the grid's is refused."""
+    rng = np.random.default_rng(n + k)
+    pc = cloud(rng, 2, n, scale=scale, dup=dup)
+    pc[1, 7] = np.nan
+    t = T(pc)
+    grid = nat.CellGrid(t, max(r_knn, r_ball))
+    dist = torch.full((2, n, k), -1.0, device=DEV)
+    ik = torch.full((2, n, k), -7, dtype=torch.int32, device=DEV)
+    grid.knn_clamped(k, r_knn, dist, ik)
+    ib = torch.full((2, n, ns), -7, dtype=torch.int32, device=DEV)
+    grid.ball_query(r_ball, ns, ib)
+    grid.knn_clamped(k, r_knn, dist, ik)            # a second search on the same grid (its per-cloud flag is stale by now)
+    d2, ki = oracle.knn(k, pc, pc)
+    beyond = ~(np.sqrt(d2) <= np.float32(r_knn))
+    want_i = np.where(beyond, np.repeat(ki[:, :, :1], k, axis=2), ki)
+    want_d = np.where(beyond, np.float32(np.inf), np.sqrt(d2))
+    nanrow = np.isnan(pc).any(-1)
+    got_i, got_d = ik.cpu().numpy(), dist.cpu().numpy()
+    assert np.array_equal(got_i[~nanrow], want_i[~nanrow]) and np.array_equal(got_d[~nanrow], want_d[~nanrow])
+    assert np.array_equal(ib.cpu().numpy(), oracle.ball_query(r_ball, ns, pc, pc))
+    with pytest.raises(Exception):
+        grid.ball_query(2.0 * max(r_knn, r_ball), ns, ib)
+
+
 GRID_KNN_CASES = [  # (n, m, k, scale, query_scale)
     (2048, 8192, 64, (60, 4, 80), 1.0), (8192, 8192, 32, (60, 4, 80), 1.0), (700, 4096, 200, (1, 1, 1), 1.0),
     (1000, 1024, 16, (60, 4, 80), 2.0),   # queries far outside the cloud's box
