@@ -34,7 +34,7 @@ def _plan_tensors(obj):
     elif isinstance(obj, _streams.Pending):
         yield from _plan_tensors(obj._value)
     elif isinstance(obj, PrefetchedGeometry):
-        yield from _plan_tensors([obj.flat, obj.pcs_l, obj.flows_l, obj.model, obj.loss])
+        yield from _plan_tensors([obj.flat, obj.pcs_s, obj.flows_s, obj.model, obj.loss])
     elif isinstance(obj, dict):
         for k in sorted(obj):
             yield from _plan_tensors(obj[k])

@@ -372,6 +372,58 @@ class RankLoss(nn.Module):
         return sv.sum(dim=1).mean().to(mask.dtype)
 
 
+_COEFF_CACHE = {}
+
+
+def _term_coefficients(n_view, aug, w_knn, w_ball, weights, device):
+    """(4, L) matrix taking the vector [dynamic per view (V) | k-NN term per view (V) | ball term per view (V) | matched distances
+    1->2 per pair (2) | 2->1 per pair (2)] to [dynamic, smooth, invariance, weighted sum] as the reference combines them
+    (seg_loss_unsup.py:353-392: sums over the views, halved when augmented views double them).  Cached per configuration: the
+    weights only change at the start steps, and building a device tensor from host numbers is a (blocking) copy."""
+    key = (n_view, bool(aug), float(w_knn), float(w_ball), tuple(float(w) for w in weights), str(device))
+    hit = _COEFF_CACHE.get(key)
+    if hit is None:
+        L = 3 * n_view + (4 if aug else 0)
+        scale = 0.5 if aug else 1.0
+        rows = [[0.0] * L for _ in range(4)]
+        for v in range(n_view):
+            rows[0][v] = scale
+            rows[1][n_view + v] = scale * float(w_knn)
+            rows[1][2 * n_view + v] = scale * float(w_ball)
+        if aug:
+            for j in range(4):
+                rows[2][3 * n_view + j] = 1.0
+        wd, ws, wi = (float(w) for w in weights)
+        rows[3] = [wd * a + ws * b_ + wi * c for a, b_, c in zip(rows[0], rows[1], rows[2])]
+        hit = torch.tensor(rows, dtype=torch.float32, device=device)
+        if len(_COEFF_CACHE) > 64:
+            _COEFF_CACHE.clear()
+        _COEFF_CACHE[key] = hit
+    return hit
+
+
+class _CombineTerms(torch.autograd.Function):
+    """loss = <last row of coeff, v>; its gradient w.r.t. v is that row, scaled.  (The monitored terms are the other rows —
+    formed off the critical path by _monitored_terms, and NOT as a matrix product: a NaN in one term — a NaN flow makes the
+    dynamic term NaN, the step is then skipped — must not leak into the others through 0 x NaN.)"""
+
+    @staticmethod
+    def forward(ctx, v, coeff):
+        ctx.save_for_backward(coeff)
+        return torch.dot(coeff[3], v)
+
+    @staticmethod
+    def backward(ctx, g_loss):
+        coeff, = ctx.saved_tensors
+        return coeff[3] * g_loss, None
+
+
+def _monitored_terms(v, coeff):
+    """[dynamic, smooth, invariance] from the per-view vector: every row sums only the entries it has a coefficient for."""
+    rows = coeff[:3]
+    return torch.where(rows != 0, rows * v.detach()[None], torch.zeros((), device=v.device)).sum(dim=1)
+
+
 class PendingLossDict:
     """The monitored scalars of one loss evaluation, copied to the host asynchronously (one non-blocking copy of a
     stacked tensor).  ``resolve()`` returns the reference's ``loss_dict`` of Python floats (:407-412)."""
@@ -416,7 +468,41 @@ class UnsupervisedOGCLoss(nn.Module):
             return self.smooth_loss.plan_views(list(pcs)[:n_view])
         return None
 
-    def forward(self, pcs, masks, flows, step_w=False, it=0, aug_transform=False, geometry=None, sync=True):
+    takes_stacked_views = True   # forward(..., stacked=(pc, mask, flow)): the views stacked along the batch, as ONE tensor each
+
+    def _stacked_terms(self, stacked, n_view, geometry, aug_transform, weights):
+        """The three differentiable terms from the view-major tensors (V B, N, .) — no concatenation of views, and the scalar
+        algebra of the reference (per-view means -> sums over views -> weighted sum, :353-392) as ONE small matrix product
+        instead of ~20 scalar kernels forward and as many backward.  None where a term has no fused kernel."""
+        from ..fused import (matched_distance_available, matched_distances, neighbour_consistency,
+                             neighbour_consistency_available, rigid_residual, rigid_residual_available)
+        pc, mask, flow = stacked
+        dl, sl, il = self.dynamic_loss, self.smooth_loss, self.invariance_loss
+        kl, bl = getattr(sl, "knn_loss", None), getattr(sl, "ball_q_loss", None)
+        if geometry is not None and not isinstance(geometry, dict):
+            geometry = geometry.get()   # a Pending from a side stream
+        if (kl is None or bl is None or not mask.is_cuda or pc.requires_grad or flow.requires_grad
+                or not isinstance(dl, DynamicLoss) or not rigid_residual_available(mask, dl.loss_norm)
+                or not neighbour_consistency_available(mask, kl.loss_norm, kl.cross_entropy)
+                or not neighbour_consistency_available(mask, bl.loss_norm, bl.cross_entropy)
+                or (aug_transform and not matched_distance_available(mask, il.loss_norm, il.cross_entropy))):
+            return None
+        if geometry is None:
+            geometry = sl.plan_views(list(pc.view((n_view, -1) + tuple(pc.shape[1:])).unbind(0)))
+        if "knn_rev" not in geometry or "ball_rev" not in geometry:
+            return None
+        parts = [rigid_residual(pc, pc + flow, mask, dl.loss_norm).view(n_view, -1).mean(dim=1),
+                 neighbour_consistency(mask, geometry["knn"], geometry["knn_rev"], kl.loss_norm).view(n_view, -1).mean(dim=1),
+                 neighbour_consistency(mask, geometry["ball"], geometry["ball_rev"], bl.loss_norm).view(n_view, -1).mean(dim=1)]
+        if aug_transform:
+            half = mask.shape[0] // 2   # pairs (view 0, view 2), (view 1, view 3): the first two views against the last two
+            d12, d21 = matched_distances(mask[:half], mask[half:], il.loss_norm)
+            parts += [d12.view(2, -1).mean(dim=1), d21.view(2, -1).mean(dim=1)]
+        coeff = _term_coefficients(n_view, aug_transform, sl.w_knn, sl.w_ball_q, weights, mask.device)
+        v = torch.cat(parts)
+        return _CombineTerms.apply(v, coeff), v, coeff
+
+    def forward(self, pcs, masks, flows, step_w=False, it=0, aug_transform=False, geometry=None, sync=True, stacked=None):
         # pcs / masks / flows: lists of 2 (or 4 with aug_transform) tensors (B, N, 3) / (B, N, K) / (B, N, 3)
         assert len(pcs) == len(masks) == len(flows), "Inconsistent number of frames!"
         n_view = 4 if aug_transform else 2
@@ -425,6 +511,14 @@ class UnsupervisedOGCLoss(nn.Module):
 
         def weight(w, start):
             return self.step_lossw(it, weight=w, start_step=start) if step_w else w
+
+        if stacked is not None and stacked[1].shape[0] == n_view * masks[0].shape[0]:
+            fast = self._stacked_terms(stacked, n_view, geometry, aug_transform,
+                                       (weight(self.w_dynamic, self.start_step_dynamic), weight(self.w_smooth, self.start_step_smooth),
+                                        weight(self.w_invariance, self.start_step_invariance)))
+            if fast is not None:
+                loss, v, coeff = fast
+                return self._with_monitors(loss, {'sum': loss}, masks, aug_transform, sync, lazy=(v, coeff))
 
         def total(vals):
             # the reference's association: (v1 + v2), then += (v3 + v4), then * 0.5  (:358-361)
@@ -458,9 +552,22 @@ class UnsupervisedOGCLoss(nn.Module):
             loss = loss + weight(self.w_invariance, self.start_step_invariance) * l_invariance
 
         terms['sum'] = loss
+        return self._with_monitors(loss, terms, masks, aug_transform, sync)
+
+    def _with_monitors(self, loss, terms, masks, aug_transform, sync, lazy=None):
+        def total(vals):
+            out = vals[0] + vals[1]
+            if aug_transform:
+                out = 0.5 * (out + (vals[2] + vals[3]))
+            return out
 
         def monitors():
             with torch.no_grad():  # monitoring only (:394-405)
+                if lazy is not None:   # the differentiable terms' values, from the vector the loss was formed from
+                    values = _monitored_terms(*lazy)
+                    terms['dynamic'], terms['smooth'] = values[0], values[1]
+                    if aug_transform:
+                        terms['invariance'] = values[2]
                 terms['entropy'] = total([self.entropy_loss(m) for m in masks])
                 terms['rank'] = total([self.rank_loss(m) for m in masks])
             return PendingLossDict(terms)
@@ -471,7 +578,7 @@ class UnsupervisedOGCLoss(nn.Module):
             from ..utils.streams import side_stream
             side = side_stream(loss.device, "monitor")
             side.wait_stream(torch.cuda.current_stream())
-            for t in list(masks) + list(terms.values()):
+            for t in list(masks) + list(terms.values()) + ([lazy[0]] if lazy is not None else []):
                 t.record_stream(side)
             with torch.cuda.stream(side):
                 pending = monitors()
@@ -485,6 +592,8 @@ class UnsupervisedOGCLossSingleFrame(UnsupervisedOGCLoss):
     (`pcs[:, ::2]`, :59 — Waymo only has backward flow), so a sample is ONE frame, plus its augmented twin once
     augmentation is on.  Dynamic / smooth / entropy / rank are averaged over the one or two views; the invariance term
     pairs the frame with its twin.  Same ``loss_dict`` keys."""
+
+    takes_stacked_views = False   # (one or two views per sample: the view-major fast path of the two-frame loss does not apply)
 
     def plan_geometry(self, pcs, aug_transform=False):
         n_view = 2 if aug_transform else 1

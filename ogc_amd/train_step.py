@@ -64,10 +64,14 @@ def make_optimizer(params, lr, weight_decay=0.0, capturable=False):
 
 
 def _views(batch):
+    """(clouds of all views for the network (b t, n, 3); per-view clouds and flows [(b, n, 3)] x t; the same view-major as ONE
+    tensor each (t b, n, 3)).  One transposing copy per tensor: the per-view lists are slices of it (the loss works on the
+    views stacked along the batch, which is the view-major tensor itself — no re-concatenation)."""
     pcs, segms, flows, _ = batch
     b, t, n = segms.size()
     flat = pcs.view(b * t, n, -1).contiguous()
-    return flat, [pcs[:, tt].contiguous() for tt in range(t)], [flows[:, tt].contiguous() for tt in range(t)]
+    pcs_s, flows_s = pcs.transpose(0, 1).contiguous(), flows.transpose(0, 1).contiguous()       # (t, b, n, 3)
+    return flat, list(pcs_s.unbind(0)), list(flows_s.unbind(0)), pcs_s.view(t * b, n, -1), flows_s.view(t * b, n, -1)
 
 
 class PrefetchedGeometry:
@@ -83,7 +87,7 @@ class PrefetchedGeometry:
         from .utils.streams import launch_on_side, side_stream
         net = segnet.module if hasattr(segnet, "module") else segnet
         self.batch, self.aug = batch, aug_transform
-        self.flat, self.pcs_l, self.flows_l = _views(batch)
+        self.flat, self.pcs_l, self.flows_l, self.pcs_s, self.flows_s = _views(batch)
         ready = torch.cuda.Event()
         ready.record()
         self.model = net.plan_geometry_async(self.flat, after=ready) if hasattr(net, "plan_geometry_async") else None
@@ -104,12 +108,22 @@ class _SplitViews(torch.autograd.Function):
     def forward(ctx, masks):
         parts = masks.transpose(0, 1).contiguous()
         ctx.shape = parts.shape[1:]
-        return tuple(parts.unbind(0))
+        ctx.set_materialize_grads(False)
+        # the views, and the view-major tensor they are slices of (t b, n, k): a loss that works on the stacked views takes
+        # that one and needs neither a concatenation forward nor a stack of per-view gradients backward
+        return tuple(parts.unbind(0)) + (parts.view((-1,) + tuple(parts.shape[2:])),)
 
     @staticmethod
     def backward(ctx, *grads):
-        ref = next(g for g in grads if g is not None)
-        return torch.stack([g if g is not None else ref.new_zeros(ctx.shape) for g in grads], 1)
+        views, stacked = grads[:-1], grads[-1]
+        total = None
+        if any(g is not None for g in views):
+            ref = next(g for g in views if g is not None)
+            total = torch.stack([g if g is not None else ref.new_zeros(ctx.shape) for g in views], 1)
+        if stacked is not None:
+            g = stacked.view((len(views),) + tuple(ctx.shape)).transpose(0, 1)
+            total = g if total is None else total + g
+        return total
 
 
 def train_step(segnet, criterion, optimizer, batch, it, aug_transform, sync=True, prefetched=None, next_batch=None):
@@ -129,16 +143,18 @@ def train_step(segnet, criterion, optimizer, batch, it, aug_transform, sync=True
     if prefetched is None and on_gpu:
         prefetched = PrefetchedGeometry(segnet, criterion, batch, aug_transform)  # queued now, behind nothing
     if prefetched is not None:
-        flat, pcs_l, flows_l = prefetched.flat, prefetched.pcs_l, prefetched.flows_l
+        flat, pcs_l, flows_l, pcs_s, flows_s = prefetched.flat, prefetched.pcs_l, prefetched.flows_l, prefetched.pcs_s, prefetched.flows_s
         masks = segnet(flat, flat, geometry=prefetched.model) if prefetched.model is not None else segnet(flat, flat)
         kw = {"geometry": prefetched.loss} if prefetched.loss is not None else {}
     else:
-        flat, pcs_l, flows_l = _views(batch)
+        flat, pcs_l, flows_l, pcs_s, flows_s = _views(batch)
         masks = segnet(flat, flat)
         kw = {}
     t, n = batch[1].size(1), batch[1].size(2)
     masks = masks.view(b, t, n, -1)
-    masks_l = list(_SplitViews.apply(masks))
+    *masks_l, masks_s = _SplitViews.apply(masks)
+    if getattr(criterion, "takes_stacked_views", False):
+        kw["stacked"] = (pcs_s, masks_s, flows_s)
     upcoming = None
     if next_batch is not None and on_gpu:
         upcoming = PrefetchedGeometry(segnet, criterion, next_batch, aug_transform)
