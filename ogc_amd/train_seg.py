@@ -360,6 +360,11 @@ def main(argv=None):
                          "thread's 10-12 ms per step, which is the bound for clouds of fewer than ~8192 points")
     ap.add_argument("--flow-root", default=None,
                     help="read predicted flows from <flow-root>/flow_preds/<predflow_path>[_R<round-1>] (train_seg.py:277-280)")
+    ap.add_argument("--data-root", default=None,
+                    help="train on scenes in the reference's directory layout instead of synthetic ones (kittisf, ogcdr: "
+                         "ogc_amd/datasets.py); predicted flows are read from <data-root>/flow_preds/<predflow_path>[_R<round-1>]")
+    ap.add_argument("--train-mapping", default=None, help="kittisf: split file of the training scenes (default: data.train_mapping)")
+    ap.add_argument("--val-mapping", default=None, help="kittisf: split file of the validation scenes (default: data.val_mapping)")
     ap.add_argument("--frames", type=int, default=2,
                     help="frames per synthetic scene: 2 = frame pairs (KITTI-style), 4 = SAPIEN / OGC-DR style sequences "
                          "sampled as the pairs [[0,1],[1,2],[2,3]] (train_seg.py:295), flows in the sequence layout")
@@ -402,7 +407,28 @@ def main(argv=None):
         name = cfg.get("predflow_path", "flowstep3d")
         predflow_dir = os.path.join(args.flow_root, "flow_preds", name if args.round <= 1 else "%s_R%d" % (name, args.round - 1))
     aug_args = (cfg.get("data") or {}).get("aug_transform_args") or None
-    if args.frames > 2:
+    if args.data_root is not None:
+        # scenes (and, from round 2 on, the refined flows of the round before) from a directory tree in the reference's layout
+        # (ogc_amd/datasets.py; train_seg.py:270-315): KITTI-SF needs the two split files, OGC-DR has them in the tree
+        from .datasets import KITTISceneFlowDataset, OGCDynamicRoomDataset
+        data = cfg.get("data") or {}
+        name = cfg.get("predflow_path", "flowstep3d")
+        predflow = name if args.round <= 1 else "%s_R%d" % (name, args.round - 1)
+        if cfg["dataset"] == "kittisf":
+            common = dict(data_root=args.data_root, downsampled=True, view_sels=[[0, 1]], predflow_path=predflow,
+                          decentralize=data.get("decentralize", False))
+            train_set = KITTISceneFlowDataset(mapping_path=args.train_mapping or data["train_mapping"], aug_transform_args=aug_args,
+                                              **common)
+            val_set = KITTISceneFlowDataset(mapping_path=args.val_mapping or data["val_mapping"], **common)
+        elif cfg["dataset"] == "ogcdr":
+            from .utils.flow_store import TRAIN_PAIRS
+            common = dict(data_root=args.data_root, view_sels=TRAIN_PAIRS, predflow_path=predflow,
+                          decentralize=data.get("decentralize", False))
+            train_set = OGCDynamicRoomDataset(split="train", aug_transform_args=aug_args, **common)
+            val_set = OGCDynamicRoomDataset(split="val", **common)
+        else:
+            raise KeyError("no reader for dataset %r (ogc_amd/datasets.py covers kittisf and ogcdr)" % cfg["dataset"])
+    elif args.frames > 2:
         from .utils.flow_store import TRAIN_PAIRS
         assert not outdoor and args.frames == 4, "sequences are the SAPIEN / OGC-DR sample format (4 frames)"
         train_set = SyntheticSequenceScenes(args.synthetic, seg["n_point"], seg["n_slot"], TRAIN_PAIRS, args.frames,
@@ -410,7 +436,8 @@ def main(argv=None):
     else:
         train_set = SyntheticScenes(args.synthetic, seg["n_point"], seg["n_slot"], outdoor, seed=TRAIN_SEED,
                                     predflow_dir=predflow_dir, aug_transform_args=aug_args)
-    val_set = SyntheticScenes(max(args.synthetic // 8, cfg["batch_size"]), seg["n_point"], seg["n_slot"], outdoor, seed=7)
+    if args.data_root is None:
+        val_set = SyntheticScenes(max(args.synthetic // 8, cfg["batch_size"]), seg["n_point"], seg["n_slot"], outdoor, seed=7)
     sampler = torch.utils.data.distributed.DistributedSampler(train_set) if distributed else None
     train_loader = torch.utils.data.DataLoader(train_set, batch_size=cfg["batch_size"], shuffle=sampler is None,
                                                sampler=sampler, drop_last=True)

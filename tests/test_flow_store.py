@@ -144,6 +144,45 @@ def run_round(dev, tmp_path):
     return worst
 
 
+def test_train_refine_train_on_a_data_root(tmp_path, monkeypatch, oracle, capsys):
+    """The reference's loop on a directory tree in its layout: train_seg (flows of the flow network under flow_preds/flowstep3d)
+    -> oa_icp_round --save (flow_preds/flowstep3d_R1) -> train_seg --round 2 reading the refined flows."""
+    import ogc_amd.pointnet2.pointnet2 as api
+    monkeypatch.setattr(api, "_native", oracle.Pointnet2CudaCPU())
+    from ogc_amd import oa_icp_round, train_seg
+    root = str(tmp_path / "kittisf")
+    dc.write_kitti_root(root)
+    dc.write_kitti_input_flows(root)
+    cfg = {"dataset": "kittisf", "save_path": str(tmp_path / "ckpt" / "seg"), "random_seed": 10, "predflow_path": "flowstep3d",
+           "data": {"root": root, "decentralize": True, "train_mapping": os.path.join(root, "train.txt"),
+                    "val_mapping": os.path.join(root, "train.txt"),
+                    "aug_transform_args": {"scale_low": 0.95, "scale_high": 1.05, "degree_range": [0, 180, 0], "shift_range": [0, 0, 0]}},
+           "aug_transform_epoch": 1, "ignore_npoint_thresh": 0, "epochs": 2, "batch_size": 1, "lr": 1e-3, "lr_decay": 0.7,
+           "lr_clip": 1e-5, "bn_momentum": 0.9, "bn_decay": 1.0, "weight_decay": 0.0, "decay_step": 100,
+           "segnet": dc.ICP_CFG["segnet"],
+           "loss": {"weights": [10.0, 0.1, 0.1], "start_steps": [0, 0, 0], "dynamic_loss_params": {"loss_norm": 2},
+                    "smooth_loss_params": {"w_knn": 3.0, "w_ball_q": 1.0, "knn_loss_params": {"k": 8, "radius": 1.0, "loss_norm": 1},
+                                           "ball_q_loss_params": {"k": 16, "radius": 2.0, "loss_norm": 1}},
+                    "invariance_loss_params": {"loss_norm": 2}}}
+    os.makedirs(tmp_path / "ckpt")
+    path = str(tmp_path / "cfg.yaml")
+    with open(path, "w") as f:
+        yaml.safe_dump(cfg, f)
+    train_seg.main([path, "--round", "1", "--device", "cpu", "--data-root", root])
+    rep = oa_icp_round.main([path, "--round", "1", "--device", "cpu", "--save", "--data-root", root, "--test_batch_size", "2"])
+    assert rep["pairs"] == 6
+    refined = os.path.join(root, "flow_preds", "flowstep3d_R1")
+    assert sorted(os.listdir(refined)) == dc.KITTI_IDS
+    train_seg.main([path, "--round", "2", "--device", "cpu", "--data-root", root])
+    assert os.path.exists(cfg["save_path"] + "_R2/best.pth.tar")
+    lines = [json.loads(l) for l in capsys.readouterr().out.splitlines() if l.startswith("{") and "epoch" in l]
+    assert len(lines) == 4 and [l["aug"] for l in lines] == [False, True, False, True] and all(l["it"] in (3, 6) for l in lines)
+    # round 2 trained on the refined flows: its data set reads the files the refinement wrote
+    from ogc_amd.datasets import KITTISceneFlowDataset
+    ds = KITTISceneFlowDataset(root, os.path.join(root, "train.txt"), downsampled=True, predflow_path="flowstep3d_R1")
+    np.testing.assert_array_equal(ds[1][2][0], np.load(os.path.join(refined, dc.KITTI_IDS[1], "flow1.npy")))
+
+
 def test_refinement_round_replays_the_reference_script_cpu(tmp_path, monkeypatch, oracle):
     import ogc_amd.pointnet2.pointnet2 as api
     monkeypatch.setattr(api, "_native", oracle.Pointnet2CudaCPU())

@@ -5,7 +5,7 @@
 export TMPDIR=/tmp
 for PM in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$PM
-  OGC_BENCH_MARK=1 timeout 500 rocprofv3 --pmc $PM --kernel-trace --output-format csv -d /tmp/pmc_$PM -o p -- python bench.py --no-cpu-baseline --steps 2 --warmup 2 > /dev/null 2>&1
+  OGC_BENCH_MARK=1 timeout 500 rocprofv3 --pmc $PM --kernel-trace --output-format csv -d /tmp/pmc_$PM -o p -- python bench.py --no-cpu-baseline --steps 3 --warmup 2 > /dev/null 2>&1
 done
 python - <<'PY'
 import csv, glob, re
@@ -17,10 +17,10 @@ for pm in ("FETCH_SIZE", "WRITE_SIZE"):
     rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == pm]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
     marks = [i for i, r in enumerate(rows) if "spin" in r["Kernel_Name"].lower() or "sleep" in r["Kernel_Name"].lower()]
-    lo = marks[0]
-    steps = len(marks)
+    lo, hi = marks[0], marks[-1]          # whole steps only: from the first marker to the last (bench.py runs more steps, with
+    steps = len(marks) - 1                # other settings, after its timed region)
     agg = defaultdict(lambda: [0, 0.0])
-    for r in rows[lo:]:
+    for r in rows[lo:hi]:
         n = r["Kernel_Name"]
         if "spin" in n.lower() or "sleep" in n.lower():
             continue
@@ -30,8 +30,8 @@ for pm in ("FETCH_SIZE", "WRITE_SIZE"):
     tot[pm] = agg
 names = sorted(set(tot["FETCH_SIZE"]) | set(tot["WRITE_SIZE"]),
                key=lambda k: -(tot["FETCH_SIZE"].get(k, [0, 0])[1] + tot["WRITE_SIZE"].get(k, [0, 0])[1]))
-print("HBM-side traffic per C4 training step (16 clouds x 8192 points), %d timed steps from the first marker to the end of\n"
-      "the run (the last step is followed by the isolated ball-query launches of bench.py).  MiB per step as reported\n"
+print("HBM-side traffic per C4 training step (16 clouds x 8192 points), mean of %d whole timed steps (marker to marker).\n"
+      "MiB per step as reported\n"
       "(KiB counters / 1024); FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950 (MI355X_MICROARCH.md), so the\n"
       "true read volume of the streaming kernels is up to twice the column." % steps)
 print("%-80s %7s %12s %12s" % ("kernel", "calls", "fetch MiB", "write MiB"))
