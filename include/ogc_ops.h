@@ -357,6 +357,27 @@ int ogc_conv1x1_dgrad_adjoint(int b, int cin, int cout, int hw, int relu, const 
                               const float *y_prev, const float *pa, const float *pb, const float *coef, float *grad_prev,
                               ogc_stream_t stream);
 
+/* The tail of a set-abstraction MLP backwards, without the dense gradient in between:  last layer
+ *   y = conv(relu(GroupNorm(y_prev)))  followed by  out = max over the neighbourhood of relu(GroupNorm'(y))
+ * (utils/pointnet2_util.py:38-42).  The gradient of that pooled GroupNorm w.r.t. y is affine in y except at the arg-max
+ * position of every neighbourhood:   g_y[b, ch, pr, j] = fmaf(c2, y, c3) + (j == argmax[b, ch, pr] ? ag : 0).
+ *   ogc_group_norm_maxpool_bwd_sparse: ogc_group_norm_maxpool_bwd with  coef2 (b, c, 2) = (c2, c3)  and
+ *       inj (b, c, p, 2) = (ag, argmax as its bit pattern)  in place of grad_x (b, c, p, s); grad_gamma / grad_beta as there.
+ *   ogc_conv1x1_wgrad_moments_pooled / ogc_conv1x1_dgrad_adjoint_pooled: ogc_conv1x1_wgrad_moments / _dgrad_adjoint of the
+ *       convolution that wrote y, taking (y, coef2, inj) for grad_y and rebuilding it with the expression above while they
+ *       load y — results identical, bit for bit, to the dense sequence; the pass that reads y and writes grad_y (the size of
+ *       the layer's activation each way) is gone.  hw = centres * nsample, nsample in {16, 32, 64}. */
+int ogc_group_norm_maxpool_bwd_sparse(int b, int c, int p, int s, int groups, int relu, const float *x, const float *gamma,
+                                      const float *mean, const float *rstd, const float *out, const int *argmax,
+                                      const float *grad_out, float *coef2, float *inj, float *grad_gamma,
+                                      float *grad_beta, double *ws, ogc_stream_t stream);
+int ogc_conv1x1_wgrad_moments_pooled(int b, int cin, int cout, int hw, int relu, int nsample, const float *y_prev,
+                                     const float *pa, const float *pb, const float *y, const float *coef2,
+                                     const float *inj, float *moments, ogc_stream_t stream);
+int ogc_conv1x1_dgrad_adjoint_pooled(int b, int cin, int cout, int hw, int relu, int nsample, const float *w, const float *y,
+                                     const float *coef2, const float *inj, const float *y_prev, const float *pa,
+                                     const float *pb, const float *coef, float *grad_prev, ogc_stream_t stream);
+
 /* A whole per-neighbourhood MLP and its max-pool in one launch, for INFERENCE
  *   utils/flowstep3d_util.py:57-66 (FlowEmbedding, the correlation layer) and :126-138 (set abstraction):
  *     for conv, bn in zip(mlp_convs, mlp_bns): x = relu(bn(conv(x)));   x = max(x, -1)

@@ -33,13 +33,19 @@ constexpr int WG_WAVES = 4;
 // Same operand layout as conv1x1_wgrad_kernel: for a step of 16 positions lane (i = l & 15, k = l >> 4) loads ONE float4 =
 // row (c0 + i), positions pb + 4k .. 4k+3; MFMA k-slot k of sub-step s is position pb + 4k + s for both operands.
 // A workgroup stays inside one sample (blockIdx.x = sample * chunks + chunk): H / H2 are per sample.
-template <int COB, int CIB>
+// POOLED: g_y is the gradient of a max-pooled GroupNorm in sparse form (ogc_group_norm_maxpool_bwd_sparse): `dy` is the
+// convolution's OUTPUT y, and g_y[row, pos] = fmaf(c2, y, c3) + (pos % S == arg ? ag : 0) is rebuilt from coef2[b, row] =
+// (c2, c3) and inj[b, row, pos / S] = (ag, arg) — a step's 16 positions lie inside one neighbourhood (S = 16, 32, 64).
+template <int COB, int CIB, bool POOLED>
 __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void wgrad_moments_kernel(int cin, int cout, int hw, int chunks,
                                                                            int steps_per_wave, int relu,
                                                                            const float *__restrict__ x,   // y_prev (B, cin, hw)
                                                                            const float *__restrict__ dy,  // g_y (B, cout, hw)
                                                                            const float *__restrict__ aff_a,
                                                                            const float *__restrict__ aff_b,
+                                                                           const float2 *__restrict__ coef2, // (B, cout)
+                                                                           const float2 *__restrict__ inj,   // (B, cout, hw >> s_shift)
+                                                                           int s_shift,
                                                                            float *__restrict__ hm) {      // (B, 2, cout, cin)
     __shared__ float red[WG_WAVES][COB * CIB * 256]; // one slab per wave (see conv1x1_wgrad_kernel), H then H2
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -58,10 +64,21 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void wgrad_moments_kernel(int c
             acc1[a][c] = (v4f){0.f, 0.f, 0.f, 0.f};
             acc2[a][c] = (v4f){0.f, 0.f, 0.f, 0.f};
         }
-    int yrow[COB], xrow[CIB];
-    float ca[CIB], cb[CIB];
+    int yrow[COB], xrow[CIB], jrow[COB];
+    float ca[CIB], cb[CIB], pc2[COB], pc3[COB];
+    const int centres = hw >> s_shift, smask = (1 << s_shift) - 1;
 #pragma unroll
-    for (int a = 0; a < COB; ++a) yrow[a] = min(co0 + a * 16 + i, cout - 1) * hw;
+    for (int a = 0; a < COB; ++a) {
+        const int row = min(co0 + a * 16 + i, cout - 1);
+        yrow[a] = row * hw;
+        if (POOLED) {
+            const float2 cc = coef2[(size_t)img * cout + row];
+            pc2[a] = cc.x;
+            pc3[a] = cc.y;
+            jrow[a] = row * centres;
+        }
+    }
+    const float2 *jb_ = POOLED ? inj + (size_t)img * cout * centres : nullptr;
 #pragma unroll
     for (int c = 0; c < CIB; ++c) {
         const int ch = min(ci0 + c * 16 + i, cin - 1);
@@ -77,15 +94,31 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void wgrad_moments_kernel(int c
     // for ALL outstanding loads wherever it needs one, which serialises the ping-pong): rows beyond the tensors are clamped
     // onto the last row — they only reach rows / columns of H, H2 that are never stored — and steps beyond the wave's
     // share re-read its last step and are not computed with.
-    auto load = [&](float4(&yv)[COB], float4(&xv)[CIB]) { // step `cur`, then advance
+    auto load = [&](float4(&yv)[COB], float4(&xv)[CIB], float2(&jv)[COB], int &jpos) { // step `cur`, then advance
         const int pb = cur * 16;
 #pragma unroll
         for (int a = 0; a < COB; ++a) yv[a] = *reinterpret_cast<const float4 *>(yb_ + yrow[a] + pb);
 #pragma unroll
         for (int c = 0; c < CIB; ++c) xv[c] = *reinterpret_cast<const float4 *>(xb_ + xrow[c] + pb);
+        if (POOLED) {
+#pragma unroll
+            for (int a = 0; a < COB; ++a) jv[a] = jb_[jrow[a] + (pb >> s_shift)];
+            jpos = (pb & smask) + 4 * k; // this lane's first position inside the neighbourhood
+        }
         cur = min(cur + 1, max(stop, 0));
     };
-    auto fma16 = [&](const float4(&yv)[COB], const float4(&xraw)[CIB]) {
+    auto fma16 = [&](float4(&yv)[COB], const float4(&xraw)[CIB], const float2(&jv)[COB], int jpos) {
+        if (POOLED) {
+#pragma unroll
+            for (int a = 0; a < COB; ++a) { // the expression of gn_maxpool_bwd_dx_kernel, bit for bit
+                const int rel = __float_as_int(jv[a].y) - jpos;
+                const float ag = jv[a].x;
+                yv[a].x = fmaf(pc2[a], yv[a].x, pc3[a]) + (rel == 0 ? ag : 0.f);
+                yv[a].y = fmaf(pc2[a], yv[a].y, pc3[a]) + (rel == 1 ? ag : 0.f);
+                yv[a].z = fmaf(pc2[a], yv[a].z, pc3[a]) + (rel == 2 ? ag : 0.f);
+                yv[a].w = fmaf(pc2[a], yv[a].w, pc3[a]) + (rel == 3 ? ag : 0.f);
+            }
+        }
         float4 m1[CIB], m2[CIB];
 #pragma unroll
         for (int c = 0; c < CIB; ++c) {
@@ -114,15 +147,17 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void wgrad_moments_kernel(int c
     };
 
     float4 ya[COB], xa[CIB], yb[COB], xb[CIB];
-    load(ya, xa);
+    float2 ja[COB], jb[COB];
+    int pa_ = 0, pb_ = 0;
+    load(ya, xa, ja, pa_);
     int s = 0;
     for (; s + 1 < mine; s += 2) { // ping-pong registers: next step's loads fly during the MFMAs (no branch in the body)
-        load(yb, xb);
-        fma16(ya, xa);
-        load(ya, xa);
-        fma16(yb, xb);
+        load(yb, xb, jb, pb_);
+        fma16(ya, xa, ja, pa_);
+        load(ya, xa, ja, pa_);
+        fma16(yb, xb, jb, pb_);
     }
-    if (s < mine) fma16(ya, xa);
+    if (s < mine) fma16(ya, xa, ja, pa_);
 
     float *dst = hm + (size_t)img * 2 * cout * cin;
 #pragma unroll
@@ -147,7 +182,7 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void wgrad_moments_kernel(int c
 
 template <int COB, int CIB>
 void moments_launch(int b, int cin, int cout, int hw, int relu, const float *x, const float *dy, const float *pa,
-                    const float *pb, float *hm, hipStream_t s) {
+                    const float *pb, const float *coef2, const float *inj, int s_shift, float *hm, hipStream_t s) {
     const int steps_per_img = hw >> 4;
     const int tiles = ogc_divup(cout, 16 * COB) * ogc_divup(cin, 16 * CIB);
     long long waves = (2048 / tiles) / b;            // wavefronts per sample and tile pair: ~2048 over the chip
@@ -157,8 +192,13 @@ void moments_launch(int b, int cin, int cout, int hw, int relu, const float *x, 
     spw = (spw + 1) / 2 * 2;
     const int chunks = ogc_divup(steps_per_img, spw * WG_WAVES);
     dim3 grid(b * chunks, ogc_divup(cout, 16 * COB), ogc_divup(cin, 16 * CIB));
-    hipLaunchKernelGGL((wgrad_moments_kernel<COB, CIB>), grid, dim3(WG_WAVES * OGC_WAVE), 0, s, cin, cout, hw, chunks, spw,
-                       relu, x, dy, pa, pb, hm);
+    const float2 *c2 = reinterpret_cast<const float2 *>(coef2), *ij = reinterpret_cast<const float2 *>(inj);
+    if (inj)
+        hipLaunchKernelGGL((wgrad_moments_kernel<COB, CIB, true>), grid, dim3(WG_WAVES * OGC_WAVE), 0, s, cin, cout, hw, chunks,
+                           spw, relu, x, dy, pa, pb, c2, ij, s_shift, hm);
+    else
+        hipLaunchKernelGGL((wgrad_moments_kernel<COB, CIB, false>), grid, dim3(WG_WAVES * OGC_WAVE), 0, s, cin, cout, hw, chunks,
+                           spw, relu, x, dy, pa, pb, c2, ij, 0, hm);
 }
 
 // ---- dW, the GroupNorm parameter gradients and the coefficients of the adjoint ----------------------------------------------
@@ -238,7 +278,9 @@ __global__ __launch_bounds__(256) void moments_combine_kernel(int b, int cin, in
 // The GEMM of conv1x1_gemm_kernel<TRANSPOSE_A = true> (M = cin, K = cout): a wave owns 64 positions, the whole K x 64 tile
 // of g_y in registers, A = w^T staged through LDS 64 rows at a time; the epilogue holds four consecutive positions of
 // an output row per lane and reads the same four of y_prev.
-template <int KQ>
+// POOLED: g_y in the sparse form of ogc_group_norm_maxpool_bwd_sparse, rebuilt from the convolution's output (`gy` = y) as
+// in wgrad_moments_kernel; a lane's four positions lie inside one neighbourhood (S >= 4).
+template <int KQ, bool POOLED>
 __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void dgrad_adjoint_kernel(int M, int K, int hw, int relu,
                                                                            const float *__restrict__ w,     // (K, M)
                                                                            const float *__restrict__ gy,    // (B, K, hw)
@@ -246,6 +288,9 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void dgrad_adjoint_kernel(int M
                                                                            const float *__restrict__ pa,
                                                                            const float *__restrict__ pb,
                                                                            const float *__restrict__ coef,  // (B, M, 3)
+                                                                           const float2 *__restrict__ coef2, // (B, K)
+                                                                           const float2 *__restrict__ inj,   // (B, K, hw >> s_shift)
+                                                                           int s_shift,
                                                                            float *__restrict__ out) {       // (B, M, hw)
     extern __shared__ __attribute__((aligned(16))) float a_lds[]; // [64][ogc_a_ld(Kq)] weights (conv_stage.h), then [64][5] coefficients
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -266,6 +311,27 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void dgrad_adjoint_kernel(int M
         const int row = q * 4 + kk;
         xin[q] = (live && q < Kq && row < K) ? *reinterpret_cast<const float4 *>(inb + (size_t)row * hw + p0 + 4 * j)
                                              : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (POOLED) {
+        const int centres = hw >> s_shift, pos = p0 + 4 * j;
+        const int centre = pos >> s_shift, jpos = pos & ((1 << s_shift) - 1);
+        float2 cc[KQ], jv[KQ];
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+            const int row = q * 4 + kk;
+            const bool in = live && q < Kq && row < K;
+            cc[q] = in ? coef2[(size_t)b * K + row] : make_float2(0.f, 0.f);
+            jv[q] = in ? inj[((size_t)b * K + row) * centres + centre] : make_float2(0.f, __int_as_float(-1));
+        }
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) { // the expression of gn_maxpool_bwd_dx_kernel, bit for bit (rows beyond K: zero)
+            const int rel = __float_as_int(jv[q].y) - jpos;
+            const float ag = jv[q].x;
+            xin[q].x = fmaf(cc[q].x, xin[q].x, cc[q].y) + (rel == 0 ? ag : 0.f);
+            xin[q].y = fmaf(cc[q].x, xin[q].y, cc[q].y) + (rel == 1 ? ag : 0.f);
+            xin[q].z = fmaf(cc[q].x, xin[q].z, cc[q].y) + (rel == 2 ? ag : 0.f);
+            xin[q].w = fmaf(cc[q].x, xin[q].w, cc[q].y) + (rel == 3 ? ag : 0.f);
+        }
     }
     for (int m0 = 0; m0 < M; m0 += 64) {
         __syncthreads(); // previous tile fully consumed
@@ -334,31 +400,59 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void dgrad_adjoint_kernel(int M
 
 } // namespace
 
-extern "C" int ogc_conv1x1_wgrad_moments(int b, int cin, int cout, int hw, int relu, const float *y_prev, const float *pa,
-                                         const float *pb, const float *grad_y, float *moments, ogc_stream_t stream) {
-    OGC_REQUIRE(b >= 0 && cin >= 1 && cout >= 1 && hw >= 1, "ogc_conv1x1_wgrad_moments: bad shape");
-    OGC_REQUIRE(y_prev && pa && pb && grad_y && moments, "ogc_conv1x1_wgrad_moments: null pointer");
+namespace {
+int nsample_shift(int nsample) { return nsample == 16 ? 4 : nsample == 32 ? 5 : nsample == 64 ? 6 : -1; }
+
+int wgrad_moments_impl(const char *name, int b, int cin, int cout, int hw, int relu, const float *y_prev, const float *pa,
+                       const float *pb, const float *grad_y, const float *coef2, const float *inj, int s_shift,
+                       float *moments, ogc_stream_t stream) {
+    OGC_REQUIRE(b >= 0 && cin >= 1 && cout >= 1 && hw >= 1, "%s: bad shape", name);
+    OGC_REQUIRE(y_prev && pa && pb && grad_y && moments, "%s: null pointer", name);
     if ((hw & 15) != 0 || (((uintptr_t)y_prev | (uintptr_t)grad_y) & 15) != 0) {
-        ogc_set_error("ogc_conv1x1_wgrad_moments: hw=%d must be a multiple of 16 and the tensors 16-byte aligned", hw);
+        ogc_set_error("%s: hw=%d must be a multiple of 16 and the tensors 16-byte aligned", name, hw);
         return OGC_ERR_UNSUPPORTED;
     }
     OGC_REQUIRE((long long)cin * hw < (1ll << 31) && (long long)cout * hw < (1ll << 31) && b <= 32768,
-                "ogc_conv1x1_wgrad_moments: one sample exceeds 32-bit indexing");
+                "%s: one sample exceeds 32-bit indexing", name);
     hipStream_t s = (hipStream_t)stream;
     if (b == 0) return OGC_OK;
     if (hipMemsetAsync(moments, 0, sizeof(float) * 2 * (size_t)b * cin * cout, s) != hipSuccess) {
-        ogc_set_error("ogc_conv1x1_wgrad_moments: memset failed");
+        ogc_set_error("%s: memset failed", name);
         return OGC_ERR_LAUNCH;
     }
-    if (cout <= 16 && cin <= 16) moments_launch<1, 1>(b, cin, cout, hw, relu, y_prev, grad_y, pa, pb, moments, s);
-    else if (cout <= 32 && cin <= 16) moments_launch<2, 1>(b, cin, cout, hw, relu, y_prev, grad_y, pa, pb, moments, s);
-    else if (cout <= 32 && cin <= 32) moments_launch<2, 2>(b, cin, cout, hw, relu, y_prev, grad_y, pa, pb, moments, s);
-    else if (cin <= 16) moments_launch<4, 1>(b, cin, cout, hw, relu, y_prev, grad_y, pa, pb, moments, s);
-    else if (cin <= 32) moments_launch<4, 2>(b, cin, cout, hw, relu, y_prev, grad_y, pa, pb, moments, s);
-    else if (cout <= 32) moments_launch<2, 4>(b, cin, cout, hw, relu, y_prev, grad_y, pa, pb, moments, s);
-    else moments_launch<4, 4>(b, cin, cout, hw, relu, y_prev, grad_y, pa, pb, moments, s);
-    OGC_CHECK_LAUNCH("ogc_conv1x1_wgrad_moments");
+#define OGC_ML(A, C) moments_launch<A, C>(b, cin, cout, hw, relu, y_prev, grad_y, pa, pb, coef2, inj, s_shift, moments, s)
+    if (cout <= 16 && cin <= 16) OGC_ML(1, 1);
+    else if (cout <= 32 && cin <= 16) OGC_ML(2, 1);
+    else if (cout <= 32 && cin <= 32) OGC_ML(2, 2);
+    else if (cin <= 16) OGC_ML(4, 1);
+    else if (cin <= 32) OGC_ML(4, 2);
+    else if (cout <= 32) OGC_ML(2, 4);
+    else OGC_ML(4, 4);
+#undef OGC_ML
+    OGC_CHECK_LAUNCH(name);
     return OGC_OK;
+}
+} // namespace
+
+extern "C" int ogc_conv1x1_wgrad_moments(int b, int cin, int cout, int hw, int relu, const float *y_prev, const float *pa,
+                                         const float *pb, const float *grad_y, float *moments, ogc_stream_t stream) {
+    return wgrad_moments_impl("ogc_conv1x1_wgrad_moments", b, cin, cout, hw, relu, y_prev, pa, pb, grad_y, nullptr, nullptr, 0,
+                              moments, stream);
+}
+
+// The same with grad_y in the sparse form of ogc_group_norm_maxpool_bwd_sparse: y (B, cout, hw) is the convolution's output,
+// hw = centres * nsample (nsample 16, 32 or 64).
+extern "C" int ogc_conv1x1_wgrad_moments_pooled(int b, int cin, int cout, int hw, int relu, int nsample, const float *y_prev,
+                                                const float *pa, const float *pb, const float *y, const float *coef2,
+                                                const float *inj, float *moments, ogc_stream_t stream) {
+    const int sh = nsample_shift(nsample);
+    if (sh < 0 || hw % nsample != 0 || (((uintptr_t)coef2 | (uintptr_t)inj) & 7) != 0) {
+        ogc_set_error("ogc_conv1x1_wgrad_moments_pooled: nsample=%d must be 16, 32 or 64 and divide hw=%d", nsample, hw);
+        return OGC_ERR_UNSUPPORTED;
+    }
+    OGC_REQUIRE(b == 0 || (coef2 && inj), "ogc_conv1x1_wgrad_moments_pooled: null pointer");
+    return wgrad_moments_impl("ogc_conv1x1_wgrad_moments_pooled", b, cin, cout, hw, relu, y_prev, pa, pb, y, coef2, inj, sh,
+                              moments, stream);
 }
 
 extern "C" int ogc_gn_moments_combine(int b, int cin, int cout, int hw, int groups, const float *moments, const float *w,
@@ -381,32 +475,62 @@ extern "C" int ogc_gn_moments_combine(int b, int cin, int cout, int hw, int grou
     return OGC_OK;
 }
 
-extern "C" int ogc_conv1x1_dgrad_adjoint(int b, int cin, int cout, int hw, int relu, const float *w, const float *grad_y,
-                                         const float *y_prev, const float *pa, const float *pb, const float *coef,
-                                         float *grad_prev, ogc_stream_t stream) {
-    OGC_REQUIRE(b >= 0 && cin >= 1 && cout >= 1 && hw >= 1, "ogc_conv1x1_dgrad_adjoint: bad shape");
-    OGC_REQUIRE(w && grad_y && y_prev && pa && pb && coef && grad_prev, "ogc_conv1x1_dgrad_adjoint: null pointer");
+namespace {
+int dgrad_adjoint_impl(const char *name, int b, int cin, int cout, int hw, int relu, const float *w, const float *grad_y,
+                       const float *y_prev, const float *pa, const float *pb, const float *coef, const float *coef2,
+                       const float *inj, int s_shift, float *grad_prev, ogc_stream_t stream) {
+    OGC_REQUIRE(b >= 0 && cin >= 1 && cout >= 1 && hw >= 1, "%s: bad shape", name);
+    OGC_REQUIRE(w && grad_y && y_prev && pa && pb && coef && grad_prev, "%s: null pointer", name);
     if ((hw & 63) != 0 || cout > 160 || (((uintptr_t)grad_y | (uintptr_t)y_prev | (uintptr_t)grad_prev) & 15) != 0) {
-        ogc_set_error("ogc_conv1x1_dgrad_adjoint: needs hw %% 64 == 0, cout <= 160 and 16-byte aligned tensors (hw=%d, cout=%d)",
-                      hw, cout);
+        ogc_set_error("%s: needs hw %% 64 == 0, cout <= 160 and 16-byte aligned tensors (hw=%d, cout=%d)", name, hw, cout);
         return OGC_ERR_UNSUPPORTED;
     }
     OGC_REQUIRE((long long)cin * hw < (1ll << 31) && (long long)cout * hw < (1ll << 31) && b <= 65535,
-                "ogc_conv1x1_dgrad_adjoint: one sample exceeds 32-bit indexing");
+                "%s: one sample exceeds 32-bit indexing", name);
     if (b == 0) return OGC_OK;
     const int M = cin, K = cout, Kq = (K + 3) / 4;
     const size_t lds = ((size_t)64 * ogc_a_ld(Kq) + 64 * 5) * sizeof(float);
     dim3 grid(ogc_divup(hw, 64 * WG_WAVES), b);
     hipStream_t s = (hipStream_t)stream;
-#define OGC_DGA(KQV)                                                                                                       \
-    hipLaunchKernelGGL((dgrad_adjoint_kernel<KQV>), grid, dim3(WG_WAVES * OGC_WAVE), lds, s, M, K, hw, relu, w, grad_y, y_prev, \
-                       pa, pb, coef, grad_prev)
+    const float2 *c2 = reinterpret_cast<const float2 *>(coef2), *ij = reinterpret_cast<const float2 *>(inj);
+#define OGC_DGA(KQV)                                                                                                        \
+    do {                                                                                                                    \
+        if (inj)                                                                                                            \
+            hipLaunchKernelGGL((dgrad_adjoint_kernel<KQV, true>), grid, dim3(WG_WAVES * OGC_WAVE), lds, s, M, K, hw, relu, w,  \
+                               grad_y, y_prev, pa, pb, coef, c2, ij, s_shift, grad_prev);                                  \
+        else                                                                                                                \
+            hipLaunchKernelGGL((dgrad_adjoint_kernel<KQV, false>), grid, dim3(WG_WAVES * OGC_WAVE), lds, s, M, K, hw, relu, w, \
+                               grad_y, y_prev, pa, pb, coef, c2, ij, 0, grad_prev);                                        \
+    } while (0)
     if (Kq <= 8) OGC_DGA(8);
     else if (Kq <= 16) OGC_DGA(16);
     else if (Kq <= 25) OGC_DGA(25);
     else if (Kq <= 33) OGC_DGA(33);
     else OGC_DGA(40);
 #undef OGC_DGA
-    OGC_CHECK_LAUNCH("ogc_conv1x1_dgrad_adjoint");
+    OGC_CHECK_LAUNCH(name);
     return OGC_OK;
+}
+} // namespace
+
+extern "C" int ogc_conv1x1_dgrad_adjoint(int b, int cin, int cout, int hw, int relu, const float *w, const float *grad_y,
+                                         const float *y_prev, const float *pa, const float *pb, const float *coef,
+                                         float *grad_prev, ogc_stream_t stream) {
+    return dgrad_adjoint_impl("ogc_conv1x1_dgrad_adjoint", b, cin, cout, hw, relu, w, grad_y, y_prev, pa, pb, coef, nullptr,
+                              nullptr, 0, grad_prev, stream);
+}
+
+// The same with grad_y in the sparse form of ogc_group_norm_maxpool_bwd_sparse (y: the convolution's output).
+extern "C" int ogc_conv1x1_dgrad_adjoint_pooled(int b, int cin, int cout, int hw, int relu, int nsample, const float *w,
+                                                const float *y, const float *coef2, const float *inj, const float *y_prev,
+                                                const float *pa, const float *pb, const float *coef, float *grad_prev,
+                                                ogc_stream_t stream) {
+    const int sh = nsample_shift(nsample);
+    if (sh < 0 || hw % nsample != 0 || (((uintptr_t)coef2 | (uintptr_t)inj) & 7) != 0) {
+        ogc_set_error("ogc_conv1x1_dgrad_adjoint_pooled: nsample=%d must be 16, 32 or 64 and divide hw=%d", nsample, hw);
+        return OGC_ERR_UNSUPPORTED;
+    }
+    OGC_REQUIRE(b == 0 || (coef2 && inj), "ogc_conv1x1_dgrad_adjoint_pooled: null pointer");
+    return dgrad_adjoint_impl("ogc_conv1x1_dgrad_adjoint_pooled", b, cin, cout, hw, relu, w, y, y_prev, pa, pb, coef, coef2, inj,
+                              sh, grad_prev, stream);
 }

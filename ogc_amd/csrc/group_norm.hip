@@ -440,6 +440,37 @@ __global__ __launch_bounds__(GN_THREADS) void gn_maxpool_bwd_dx_kernel(int c, in
     }
 }
 
+// The same gradient in SPARSE form, for consumers that rebuild it while loading x (gn_fused_bwd.hip: the weight- and input-
+// gradient kernels of the convolution that wrote x): dx[b, ch, pr, j] = fmaf(c2, x, c3) + (j == arg ? ag : 0) with
+//   coef2[b, ch] = (c2, c3)   and   inj[b, ch, pr] = (ag, arg as bits)
+// — 1/32 of dx's bytes instead of a pass that reads x and writes dx.
+template <bool RELU>
+__global__ __launch_bounds__(GN_THREADS) void gn_maxpool_bwd_sparse_kernel(int c, int p, int s, int groups,
+                                                                           const float *__restrict__ gamma,
+                                                                           const float *__restrict__ mean,
+                                                                           const float *__restrict__ rstd,
+                                                                           const double *__restrict__ dsdb, int slots,
+                                                                           const float *__restrict__ out,
+                                                                           const int *__restrict__ arg,
+                                                                           const float *__restrict__ gout,
+                                                                           float2 *__restrict__ coef2,
+                                                                           float2 *__restrict__ inj,
+                                                                           float *__restrict__ dgamma,
+                                                                           float *__restrict__ dbeta) {
+    const int b = blockIdx.z, ch = blockIdx.y;
+    const int cg = c / groups, row = b * groups + ch / cg;
+    const float a = rstd[row] * gamma[ch];
+    float c2, c3;
+    gn_bwd_prologue(c, groups, (double)cg * p * s, slots, gamma, mean, rstd, dsdb, dgamma, dbeta, c2, c3);
+    const size_t base = ((size_t)b * c + ch) * p;
+    for (int pr = blockIdx.x * GN_THREADS + threadIdx.x; pr < p; pr += gridDim.x * GN_THREADS) {
+        float g = gout[base + pr];
+        if (RELU && !(out[base + pr] > 0.f)) g = 0.f;
+        inj[base + pr] = make_float2(a * g, __int_as_float(arg[base + pr]));
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) coef2[(size_t)b * c + ch] = make_float2(c2, c3);
+}
+
 constexpr int GN_STATS_SLOTS = 32; // most partial sums per (b, group) the first pass writes  (ogc_group_norm_stats_slots)
 constexpr int GN_BWD_SLOTS = 8;    // most partial sums per (b, channel) of the backward sums  (ogc_group_norm_bwd_slots)
 
@@ -699,5 +730,46 @@ extern "C" int ogc_group_norm_maxpool_bwd(int b, int c, int p, int s, int groups
                            mean, rstd, dsdb, slots, out, argmax, grad_out, grad_x, grad_gamma, grad_beta);
     }
     OGC_CHECK_LAUNCH("ogc_group_norm_maxpool_bwd");
+    return OGC_OK;
+}
+
+// ogc_group_norm_maxpool_bwd without the dense result: coef2 (B, C, 2) and inj (B, C, P, 2) from which
+// ogc_conv1x1_wgrad_moments_pooled / ogc_conv1x1_dgrad_adjoint_pooled rebuild grad_x element by element (same expression,
+// same bits) while they load x.
+extern "C" int ogc_group_norm_maxpool_bwd_sparse(int b, int c, int p, int s, int groups, int relu, const float *x,
+                                                 const float *gamma, const float *mean, const float *rstd,
+                                                 const float *out, const int *argmax, const float *grad_out, float *coef2,
+                                                 float *inj, float *grad_gamma, float *grad_beta, double *ws,
+                                                 ogc_stream_t stream) {
+    OGC_REQUIRE(b >= 0 && c >= 1 && p >= 1 && groups >= 1 && c % groups == 0, "ogc_group_norm_maxpool_bwd_sparse: bad shape");
+    if (!gn_pool_shape_ok(s) || (((uintptr_t)coef2 | (uintptr_t)inj) & 7) != 0) {
+        ogc_set_error("ogc_group_norm_maxpool_bwd_sparse: unsupported nsample=%d or misaligned tensors", s);
+        return OGC_ERR_UNSUPPORTED;
+    }
+    if (b == 0) return OGC_OK;
+    OGC_REQUIRE(x && gamma && mean && rstd && out && argmax && grad_out && coef2 && inj && grad_gamma && grad_beta && ws,
+                "ogc_group_norm_maxpool_bwd_sparse: null pointer");
+    OGC_REQUIRE(b <= 65535, "ogc_group_norm_maxpool_bwd_sparse: batch exceeds the grid limit");
+    hipStream_t st = (hipStream_t)stream;
+    double *dsdb = ws;
+    int slots = ogc_divup(p, GN_THREADS * 4) > 0 ? ogc_divup(p, GN_THREADS * 4) : 1;
+    if (slots > GN_BWD_SLOTS) slots = GN_BWD_SLOTS;
+    dim3 gsum(slots, c, b);
+    int bx = ogc_divup(p, GN_THREADS * 4);
+    while (bx > 1 && (long long)bx * c * b > 4096) bx = (bx + 1) / 2;
+    dim3 grid(bx, c, b);
+    float2 *c2 = reinterpret_cast<float2 *>(coef2), *ij = reinterpret_cast<float2 *>(inj);
+    if (relu) {
+        hipLaunchKernelGGL(gn_maxpool_bwd_sums_kernel<true>, gsum, dim3(GN_THREADS), 0, st, c, p, s, x, out, argmax,
+                           grad_out, dsdb);
+        hipLaunchKernelGGL(gn_maxpool_bwd_sparse_kernel<true>, grid, dim3(GN_THREADS), 0, st, c, p, s, groups, gamma, mean,
+                           rstd, dsdb, slots, out, argmax, grad_out, c2, ij, grad_gamma, grad_beta);
+    } else {
+        hipLaunchKernelGGL(gn_maxpool_bwd_sums_kernel<false>, gsum, dim3(GN_THREADS), 0, st, c, p, s, x, out, argmax,
+                           grad_out, dsdb);
+        hipLaunchKernelGGL(gn_maxpool_bwd_sparse_kernel<false>, grid, dim3(GN_THREADS), 0, st, c, p, s, groups, gamma, mean,
+                           rstd, dsdb, slots, out, argmax, grad_out, c2, ij, grad_gamma, grad_beta);
+    }
+    OGC_CHECK_LAUNCH("ogc_group_norm_maxpool_bwd_sparse");
     return OGC_OK;
 }

@@ -639,6 +639,48 @@ FUSED_GN_BACKWARD_MAX_WIDTH = 64
 FUSED_GN_BACKWARD = True   # _NormActConv.backward through the moment matrices (csrc/gn_fused_bwd.hip); False: the separate passes
 
 
+def _norm_act_conv_forward(y_prev, stats_prev, gn_weight, gn_bias, conv_weight, gn_groups, eps, relu, next_groups, pool,
+                           next_gamma):
+    """y = conv(act(GroupNorm(y_prev))) with the norm applied on the way in (shared by _NormActConv and _NormActConvPool).
+    -> (y, statistics of y or None, neighbourhood extremes or None, mean, rstd, a, bb of the norm of y_prev)."""
+    nat = _api._native
+    B, cin = y_prev.shape[0], y_prev.shape[1]
+    cout = conv_weight.shape[0]
+    hw = y_prev.numel() // (B * cin)
+    dev = y_prev.device
+    mean = torch.empty(B * gn_groups, dtype=torch.float32, device=dev)
+    rstd = torch.empty_like(mean)
+    a = torch.empty(B * cin, dtype=torch.float32, device=dev)
+    bb = torch.empty_like(a)
+    gamma, beta = gn_weight.detach().contiguous(), gn_bias.detach().contiguous()
+    if stats_prev is not None:
+        nat.group_norm_coeffs_wrapper(B, cin, hw, gn_groups, eps, None, gamma, beta, stats_prev,
+                                      stats_prev.numel() // (2 * B * gn_groups), None, mean, rstd, a, bb)
+    else:
+        ws = nat.group_norm_ws(B, cin, gn_groups, False, dev)
+        nat.group_norm_coeffs_wrapper(B, cin, hw, gn_groups, eps, y_prev, gamma, beta, None, 0, ws, mean, rstd, a, bb)
+    y = torch.empty((B, cout) + tuple(y_prev.shape[2:]), dtype=torch.float32, device=dev)
+    w = conv_weight.detach().contiguous()
+    stats = extremes = None
+    if (next_groups > 0 and next_groups <= 32 and cout % next_groups == 0 and (cout // next_groups) % 4 == 0
+            and (cin <= 100 or _stats_ok(nat, B, cout, cin, hw, True))):
+        stats = torch.empty(nat.conv1x1_gn_slots() * B * next_groups * 2, dtype=torch.float64, device=dev)
+        if (pool and next_gamma is not None and (cin <= 100 or POOL_EXTREMES_WIDE)
+                and getattr(nat, "conv1x1_gemm_affine_pool_wrapper", None) is not None):
+            # last layer of a set-abstraction MLP: also the extreme of every neighbourhood, for the max-pool
+            centres = hw // pool
+            yext = torch.empty(B, cout, centres, dtype=torch.float32, device=dev)
+            aext = torch.empty(B, cout, centres, dtype=torch.int32, device=dev)
+            nat.conv1x1_gemm_affine_pool_wrapper(B, cout, cin, hw, relu, next_groups, pool, w, y_prev, a, bb,
+                                                 next_gamma.detach().contiguous(), y, stats, yext, aext)
+            extremes = (yext, aext)
+        else:
+            nat.conv1x1_gemm_affine_wrapper(B, cout, cin, hw, relu, next_groups, w, y_prev, a, bb, y, stats)
+    else:
+        nat.conv1x1_gemm_affine_wrapper(B, cout, cin, hw, relu, 0, w, y_prev, a, bb, y, None)
+    return y, stats, extremes, mean, rstd, a, bb
+
+
 # ---- deferred normalisation inside a SharedMLP ----------------------------------------------------------------
 class _NormActConv(Function):
     """y = conv(act(GroupNorm(y_prev))) WITHOUT materialising the normalised activation: the norm of the previous layer
@@ -649,43 +691,11 @@ class _NormActConv(Function):
     @staticmethod
     def forward(ctx, y_prev, stats_prev, gn_weight, gn_bias, conv_weight, gn_groups, eps, relu, next_groups, pool=0,
                 next_gamma=None):
-        nat = _api._native
         ctx.set_materialize_grads(False)  # no zero tensor (one fill launch per layer) for the statistics output
         y_prev = y_prev.contiguous()
-        B, cin = y_prev.shape[0], y_prev.shape[1]
-        cout = conv_weight.shape[0]
-        hw = y_prev.numel() // (B * cin)
-        dev = y_prev.device
-        mean = torch.empty(B * gn_groups, dtype=torch.float32, device=dev)
-        rstd = torch.empty_like(mean)
-        a = torch.empty(B * cin, dtype=torch.float32, device=dev)
-        bb = torch.empty_like(a)
-        gamma, beta = gn_weight.detach().contiguous(), gn_bias.detach().contiguous()
-        if stats_prev is not None:
-            nat.group_norm_coeffs_wrapper(B, cin, hw, gn_groups, eps, None, gamma, beta, stats_prev,
-                                          stats_prev.numel() // (2 * B * gn_groups), None, mean, rstd, a, bb)
-        else:
-            ws = nat.group_norm_ws(B, cin, gn_groups, False, dev)
-            nat.group_norm_coeffs_wrapper(B, cin, hw, gn_groups, eps, y_prev, gamma, beta, None, 0, ws, mean, rstd, a, bb)
-        y = torch.empty((B, cout) + tuple(y_prev.shape[2:]), dtype=torch.float32, device=dev)
-        w = conv_weight.detach().contiguous()
-        stats = extremes = None
-        if (next_groups > 0 and next_groups <= 32 and cout % next_groups == 0 and (cout // next_groups) % 4 == 0
-                and (cin <= 100 or _stats_ok(nat, B, cout, cin, hw, True))):
-            stats = torch.empty(nat.conv1x1_gn_slots() * B * next_groups * 2, dtype=torch.float64, device=dev)
-            if (pool and next_gamma is not None and (cin <= 100 or POOL_EXTREMES_WIDE)
-                    and getattr(nat, "conv1x1_gemm_affine_pool_wrapper", None) is not None):
-                # last layer of a set-abstraction MLP: also the extreme of every neighbourhood, for the max-pool
-                centres = hw // pool
-                yext = torch.empty(B, cout, centres, dtype=torch.float32, device=dev)
-                aext = torch.empty(B, cout, centres, dtype=torch.int32, device=dev)
-                nat.conv1x1_gemm_affine_pool_wrapper(B, cout, cin, hw, relu, next_groups, pool, w, y_prev, a, bb,
-                                                     next_gamma.detach().contiguous(), y, stats, yext, aext)
-                extremes = (yext, aext)
-            else:
-                nat.conv1x1_gemm_affine_wrapper(B, cout, cin, hw, relu, next_groups, w, y_prev, a, bb, y, stats)
-        else:
-            nat.conv1x1_gemm_affine_wrapper(B, cout, cin, hw, relu, 0, w, y_prev, a, bb, y, None)
+        y, stats, extremes, mean, rstd, a, bb = _norm_act_conv_forward(y_prev, stats_prev, gn_weight, gn_bias, conv_weight,
+                                                                       gn_groups, eps, relu, next_groups, pool, next_gamma)
+        hw = y_prev.numel() // (y_prev.shape[0] * y_prev.shape[1])
         ctx.save_for_backward(y_prev, gn_weight, gn_bias, conv_weight, mean, rstd, a, bb)
         ctx.cfg = (gn_groups, relu, hw)
         if extremes is not None:
@@ -763,6 +773,89 @@ def norm_act_conv(y_prev, stats_prev, gn, relu, conv, next_gn=None, pool=0):
     if pool:
         return res[0], res[1], (tuple(res[2:]) if len(res) > 2 else None)
     return res[0], res[1]
+
+
+# The tail of a set-abstraction MLP — last convolution, its GroupNorm / ReLU, the max over the neighbourhood — as ONE autograd
+# node, so that the gradient w.r.t. the convolution's output (the size of the level's widest activation) is never written: it
+# is affine in that output except at one arg-max position per neighbourhood, and the weight- / input-gradient kernels rebuild
+# it from (c2, c3) per channel and (value, position) per neighbourhood while they load the output (gn_fused_bwd.hip,
+# *_pooled).  Bit-identical to the two-node sequence (tests/test_ops_gpu.py::test_pooled_tail_backward); C4: the pass it
+# removes is 0.28 ms of a step at SA1's two scales.  False: the two nodes.
+SPARSE_POOL_BACKWARD = True
+
+
+class _NormActConvPool(Function):
+    """out (B, cout, P) = max over the neighbourhood of act2(GroupNorm2(conv(act(GroupNorm(y_prev))))), y_prev (B, cin, P, S)
+    the raw output of the previous convolution (reference sequence: utils/pointnet2_util.py:38-42 on the last SharedMLP
+    layer, utils/nn_util.py:45-85)."""
+
+    @staticmethod
+    def forward(ctx, y_prev, stats_prev, gn_weight, gn_bias, conv_weight, gn_groups, eps, relu, gn2_weight, gn2_bias,
+                groups2, eps2, relu2):
+        nat = _api._native
+        y_prev = y_prev.contiguous()
+        B, cin, P, S = y_prev.shape
+        cout = conv_weight.shape[0]
+        y, stats, extremes, mean, rstd, a, bb = _norm_act_conv_forward(y_prev, stats_prev, gn_weight, gn_bias, conv_weight,
+                                                                       gn_groups, eps, relu, groups2, S, gn2_weight)
+        dev = y_prev.device
+        out = torch.empty(B, cout, P, dtype=torch.float32, device=dev)
+        arg = torch.empty(B, cout, P, dtype=torch.int32, device=dev)
+        mean2 = torch.empty(B * groups2, dtype=torch.float32, device=dev)
+        rstd2 = torch.empty_like(mean2)
+        g2, b2 = gn2_weight.detach().contiguous(), gn2_bias.detach().contiguous()
+        nat.group_norm_pool_extremes_wrapper(B, cout, P, S, groups2, eps2, relu2, extremes[0], extremes[1], g2, b2, out, arg,
+                                             mean2, rstd2, stats, stats.numel() // (2 * B * groups2))
+        ctx.save_for_backward(y_prev, gn_weight, gn_bias, conv_weight, mean, rstd, a, bb, y, gn2_weight, mean2, rstd2, out, arg)
+        ctx.cfg = (gn_groups, relu, groups2, relu2)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        nat = _api._native
+        y_prev, gn_weight, gn_bias, conv_weight, mean, rstd, a, bb, y, gn2_weight, mean2, rstd2, out, arg = ctx.saved_tensors
+        gn_groups, relu, groups2, relu2 = ctx.cfg
+        B, cin, P, S = y_prev.shape
+        cout, hw, dev = conv_weight.shape[0], P * S, y_prev.device
+        # pooled GroupNorm backward in sparse form
+        coef2 = torch.empty(B, cout, 2, dtype=torch.float32, device=dev)
+        inj = torch.empty(B, cout, P, 2, dtype=torch.float32, device=dev)
+        gw2, gb2 = torch.empty_like(gn2_weight), torch.empty_like(gn2_weight)
+        ws = nat.group_norm_ws(B, cout, groups2, True, dev)
+        nat.group_norm_maxpool_bwd_sparse_wrapper(B, cout, P, S, groups2, relu2, y, gn2_weight.detach().contiguous(), mean2,
+                                                  rstd2, out, arg, grad_out.contiguous(), coef2, inj, gw2, gb2, ws)
+        # the convolution's backward (as _NormActConv.backward's moment-matrix path) on that form
+        w = conv_weight.detach().contiguous().view(cout, cin)
+        moments = torch.empty(B, 2, cout, cin, dtype=torch.float32, device=dev)
+        nat.conv1x1_wgrad_moments_pooled_wrapper(B, cin, cout, hw, relu, S, y_prev, a, bb, y, coef2, inj, moments)
+        coef = torch.empty(B, cin, 3, dtype=torch.float32, device=dev)
+        ggb = torch.empty(2, cin, dtype=torch.float32, device=dev)
+        gw, gb = ggb[0], ggb[1]
+        grad_w = torch.empty(cout, cin, dtype=torch.float32, device=dev)
+        nat.gn_moments_combine_wrapper(B, cin, cout, hw, gn_groups, moments, w, a, bb, mean, rstd,
+                                       gn_weight.detach().contiguous(), grad_w, coef, gw, gb)
+        grad_prev = torch.empty_like(y_prev)
+        nat.conv1x1_dgrad_adjoint_pooled_wrapper(B, cin, cout, hw, relu, S, w, y, coef2, inj, y_prev, a, bb, coef, grad_prev)
+        return (grad_prev, None, gw, gb, grad_w.view_as(conv_weight), None, None, None, gw2, gb2, None, None, None)
+
+
+def norm_act_conv_pool_available(y_prev, gn, conv, next_gn):
+    """Can the last layer of a set-abstraction MLP and its pooled GroupNorm run as _NormActConvPool?  (The shapes for which
+    _NormActConv takes the extremes path forwards and the moment-matrix path backwards.)"""
+    nat = _api._native
+    if not (SPARSE_POOL_BACKWARD and FUSED_GN_BACKWARD and y_prev.dim() == 4 and y_prev.shape[-1] in (16, 32, 64)
+            and next_gn is not None and next_gn.affine and norm_act_conv_available(y_prev, gn, conv)
+            and getattr(nat, "conv1x1_dgrad_adjoint_pooled_wrapper", None) is not None
+            and getattr(nat, "conv1x1_gemm_affine_pool_wrapper", None) is not None):
+        return False
+    cin, cout, g, g2 = y_prev.shape[1], conv.weight.shape[0], gn.num_groups, next_gn.num_groups
+    return ((y_prev.shape[2] * y_prev.shape[3]) % 64 == 0 and cin <= FUSED_GN_BACKWARD_MAX_WIDTH and cout <= FUSED_GN_BACKWARD_MAX_WIDTH and g <= 32 and cin % g == 0
+            and g2 <= 32 and cout % g2 == 0 and (cout // g2) % 4 == 0)
+
+
+def norm_act_conv_pool(y_prev, stats_prev, gn, relu, conv, next_gn, next_relu):
+    return _NormActConvPool.apply(y_prev, stats_prev, gn.weight, gn.bias, conv.weight, gn.num_groups, gn.eps, bool(relu),
+                                  next_gn.weight, next_gn.bias, next_gn.num_groups, next_gn.eps, bool(next_relu))
 
 
 class _SelfAttentionCore(Function):

@@ -460,6 +460,27 @@ def conv1x1_dgrad_adjoint_wrapper(b, cin, cout, hw, relu, w, grad_y, y_prev, pa,
          _f(y_prev, "y_prev"), _f(pa, "pa"), _f(pb, "pb"), _f(coef, "coef"), _f(grad_prev, "grad_prev"))
 
 
+def group_norm_maxpool_bwd_sparse_wrapper(b, c, p, s, groups, relu, x, gamma, mean, rstd, out, argmax, grad_out, coef2, inj,
+                                          grad_gamma, grad_beta, ws):
+    """coef2 (b, c, 2), inj (b, c, p, 2): the gradient of the pooled GroupNorm w.r.t. x in sparse form
+    (ogc_group_norm_maxpool_bwd_sparse)."""
+    _run("ogc_group_norm_maxpool_bwd_sparse", x, b, c, p, s, groups, int(relu), _f(x, "x"), _f(gamma, "gamma"),
+         _f(mean, "mean"), _f(rstd, "rstd"), _f(out, "out"), _i(argmax, "argmax"), _f(grad_out, "grad_out"),
+         _f(coef2, "coef2"), _f(inj, "inj"), _f(grad_gamma, "grad_gamma"), _f(grad_beta, "grad_beta"),
+         _check(ws, torch.float64, "ws"))
+
+
+def conv1x1_wgrad_moments_pooled_wrapper(b, cin, cout, hw, relu, nsample, y_prev, pa, pb, y, coef2, inj, moments):
+    _run("ogc_conv1x1_wgrad_moments_pooled", y_prev, b, cin, cout, hw, int(relu), nsample, _f(y_prev, "y_prev"), _f(pa, "pa"),
+         _f(pb, "pb"), _f(y, "y"), _f(coef2, "coef2"), _f(inj, "inj"), _f(moments, "moments"))
+
+
+def conv1x1_dgrad_adjoint_pooled_wrapper(b, cin, cout, hw, relu, nsample, w, y, coef2, inj, y_prev, pa, pb, coef, grad_prev):
+    _run("ogc_conv1x1_dgrad_adjoint_pooled", y, b, cin, cout, hw, int(relu), nsample, _f(w, "w"), _f(y, "y"),
+         _f(coef2, "coef2"), _f(inj, "inj"), _f(y_prev, "y_prev"), _f(pa, "pa"), _f(pb, "pb"), _f(coef, "coef"),
+         _f(grad_prev, "grad_prev"))
+
+
 def mlp_chain_pool_supported(c0, c1, c2, c3, nsample):
     """Is there a fused inference kernel for the MLP c0 -> c1 -> c2 [-> c3] followed by the max over nsample?"""
     return bool(_lib.load().ogc_mlp_chain_pool_supported(c0, c1, c2, c3, nsample))

@@ -173,7 +173,8 @@ def _shared_mlp_run(self, x, pool, first=None):
     last layer's norm / activation (/ max over the neighbourhood, `pool`) is one fused op.
     first: optional callable (conv, gn) -> (raw output, statistics) that evaluates the FIRST layer's convolution (a set-
     abstraction level fuses it with the grouping, fused.grouped_first_layer); `x` is then unused."""
-    from ..fused import (group_norm_act, group_norm_act_maxpool, norm_act_conv, norm_act_conv_available, pointwise_conv)
+    from ..fused import (group_norm_act, group_norm_act_maxpool, norm_act_conv, norm_act_conv_available,
+                         norm_act_conv_pool, norm_act_conv_pool_available, pointwise_conv)
     layers = list(self.children())
     pending = None  # (raw conv output, its GroupNorm statistics or None, the GroupNorm, relu?, neighbourhood extremes)
 
@@ -197,6 +198,9 @@ def _shared_mlp_run(self, x, pool, first=None):
             if pool and li == len(layers) - 1 and pending[0].dim() == 4 and pending[0].shape[-1] in (16, 32, 64):
                 # last layer before the max over the neighbourhood: the convolution also leaves each neighbourhood's
                 # extremes, from which the pooled activation follows without reading its output again
+                if norm_act_conv_pool_available(pending[0], pending[2], conv, gn):
+                    # ... and one autograd node for the whole tail: no dense gradient between the pooling and the convolution
+                    return norm_act_conv_pool(pending[0], pending[1], pending[2], pending[3], conv, gn, relu)
                 y, stats, extremes = norm_act_conv(pending[0], pending[1], pending[2], pending[3], conv, gn,
                                                    pool=pending[0].shape[-1])
             else:

@@ -65,3 +65,47 @@ def test_fused_gn_backward(B, cin, cout, hw, groups, relu):
         # as close to the exact gradient as the separate passes (which accumulate their sums in fp64), within a small factor
         assert e_new <= max(4 * e_old, 2e-6), (name, e_new, e_old)
         assert e_new < 1e-5, (name, e_new)
+
+
+@pytest.mark.parametrize("B,cin,cout,P,S,groups,groups2,relu2", [
+    (2, 32, 32, 128, 64, 4, 4, True), (3, 32, 64, 96, 64, 4, 8, True), (2, 16, 32, 40, 16, 4, 4, True),
+    (2, 64, 64, 66, 32, 8, 4, True), (1, 24, 48, 8, 64, 4, 4, False), (16, 32, 64, 2048, 64, 4, 4, True)])
+def test_pooled_tail_backward(B, cin, cout, P, S, groups, groups2, relu2):
+    """Last SharedMLP layer + pooled GroupNorm as one autograd node (fused._NormActConvPool: the gradient w.r.t. the
+    convolution's output stays in sparse form, ogc_group_norm_maxpool_bwd_sparse / *_pooled) against the two-node sequence
+    that writes it out: the kernels rebuild the same fp32 expression element by element, so the results agree up to the
+    order in which workgroups add their partial moment matrices (float atomics; the pooled GroupNorm's own results are identical)."""
+    import ogc_amd  # noqa: F401
+    from ogc_amd import fused
+    g = torch.Generator().manual_seed(B * 1000 + cin + cout + P)
+    y_prev = (torch.randn(B, cin, P, S, generator=g) * 1.5 + 0.3).cuda()
+    gn = torch.nn.GroupNorm(groups, cin).cuda()
+    gn2 = torch.nn.GroupNorm(groups2, cout).cuda()
+    conv = torch.nn.Conv2d(cin, cout, 1, bias=False).cuda()
+    with torch.no_grad():
+        for m in (gn, gn2):
+            m.weight.copy_(torch.rand(m.num_channels, generator=g) + 0.5)
+            m.weight[::5] *= -1.0                                  # negative scales: the pooled value is the minimum's image
+            m.bias.copy_(torch.rand(m.num_channels, generator=g) - 0.5)
+    probe = torch.randn(B, cout, P, generator=g).cuda()
+    params = list(gn.parameters()) + list(conv.parameters()) + list(gn2.parameters())
+
+    def run(one_node):
+        yp = y_prev.clone().requires_grad_(True)
+        for p in params:
+            p.grad = None
+        if one_node:
+            assert fused.norm_act_conv_pool_available(yp, gn, conv, gn2)
+            out = fused.norm_act_conv_pool(yp, None, gn, True, conv, gn2, relu2)
+        else:
+            y, stats, extremes = fused.norm_act_conv(yp, None, gn, True, conv, gn2, pool=S)
+            out = fused.group_norm_act_maxpool(y, gn2, relu2, stats, extremes)
+        (out * probe).sum().backward()
+        return [out.detach(), yp.grad] + [p.grad.clone() for p in params]
+
+    new, old = run(True), run(False)
+    for name, n_, o_ in zip(("out", "grad_prev", "gn.weight", "gn.bias", "conv.weight", "gn2.weight", "gn2.bias"), new, old):
+        if name in ("out", "gn2.weight", "gn2.bias"):
+            assert torch.equal(n_, o_), (name, _rel(n_, o_))
+        else:
+            assert _rel(n_, o_) < 2e-6, (name, _rel(n_, o_))

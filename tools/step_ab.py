@@ -1,0 +1,32 @@
+"""A/B of one module-level switch of ogc_amd.fused on the bench step, alternating in ONE process on one GPU:
+    python tools/step_ab.py SPARSE_POOL_BACKWARD [rounds]
+prints ms per step with the switch on / off for every round (20 timed steps each)."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CODE = """
+import sys, runpy
+sys.argv = ['bench.py', '--steps', '20', '--warmup', '5']
+import ogc_amd.fused as f
+setattr(f, %r, %s)
+runpy.run_path('bench.py', run_name='__main__')
+"""
+
+
+def once(name, value):
+    out = subprocess.run([sys.executable, "-c", CODE % (name, value)], cwd=ROOT, capture_output=True, text=True)
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    if not line:
+        raise SystemExit(out.stderr[-2000:])
+    return json.loads(line[-1])["ms_per_step"]
+
+
+if __name__ == "__main__":
+    name = sys.argv[1]
+    rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+    for r in range(rounds):
+        on, off = once(name, "True"), once(name, "False")
+        print("%s  on %.3f ms   off %.3f ms" % (name, on, off), flush=True)
