@@ -782,6 +782,9 @@ def norm_act_conv(y_prev, stats_prev, gn, relu, conv, next_gn=None, pool=0):
 # *_pooled).  Bit-identical to the two-node sequence (tests/test_ops_gpu.py::test_pooled_tail_backward); C4: the pass it
 # removes is 0.28 ms of a step at SA1's two scales.  False: the two nodes.
 SPARSE_POOL_BACKWARD = True
+# (Measured for SA2's 64 -> 128 tail as well, i.e. its backward through the moment matrices at 128 output rows: step
+# 11.75 -> 12.1-12.7 ms — the pooled variants of those kernels at that width run out of registers; the tail stays limited to
+# FUSED_GN_BACKWARD_MAX_WIDTH on both sides.)
 
 
 class _NormActConvPool(Function):
@@ -849,7 +852,8 @@ def norm_act_conv_pool_available(y_prev, gn, conv, next_gn):
             and getattr(nat, "conv1x1_gemm_affine_pool_wrapper", None) is not None):
         return False
     cin, cout, g, g2 = y_prev.shape[1], conv.weight.shape[0], gn.num_groups, next_gn.num_groups
-    return ((y_prev.shape[2] * y_prev.shape[3]) % 64 == 0 and cin <= FUSED_GN_BACKWARD_MAX_WIDTH and cout <= FUSED_GN_BACKWARD_MAX_WIDTH and g <= 32 and cin % g == 0
+    return ((y_prev.shape[2] * y_prev.shape[3]) % 64 == 0 and cin <= FUSED_GN_BACKWARD_MAX_WIDTH
+            and cout <= FUSED_GN_BACKWARD_MAX_WIDTH and g <= 32 and cin % g == 0
             and g2 <= 32 and cout % g2 == 0 and (cout // g2) % 4 == 0)
 
 

@@ -69,7 +69,7 @@ def test_fused_gn_backward(B, cin, cout, hw, groups, relu):
 
 @pytest.mark.parametrize("B,cin,cout,P,S,groups,groups2,relu2", [
     (2, 32, 32, 128, 64, 4, 4, True), (3, 32, 64, 96, 64, 4, 8, True), (2, 16, 32, 40, 16, 4, 4, True),
-    (2, 64, 64, 66, 32, 8, 4, True), (1, 24, 48, 8, 64, 4, 4, False), (16, 32, 64, 2048, 64, 4, 4, True)])
+    (2, 64, 64, 66, 32, 8, 4, True), (1, 24, 48, 8, 64, 4, 4, False), (16, 32, 64, 2048, 64, 4, 4, True), (4, 64, 128, 256, 64, 4, 4, True)])
 def test_pooled_tail_backward(B, cin, cout, P, S, groups, groups2, relu2):
     """Last SharedMLP layer + pooled GroupNorm as one autograd node (fused._NormActConvPool: the gradient w.r.t. the
     convolution's output stays in sparse form, ogc_group_norm_maxpool_bwd_sparse / *_pooled) against the two-node sequence
@@ -89,6 +89,8 @@ def test_pooled_tail_backward(B, cin, cout, P, S, groups, groups2, relu2):
             m.bias.copy_(torch.rand(m.num_channels, generator=g) - 0.5)
     probe = torch.randn(B, cout, P, generator=g).cuda()
     params = list(gn.parameters()) + list(conv.parameters()) + list(gn2.parameters())
+    width = fused.FUSED_GN_BACKWARD_MAX_WIDTH
+    fused.FUSED_GN_BACKWARD_MAX_WIDTH = 160          # the kernels are tested beyond the widths the product uses them at
 
     def run(one_node):
         yp = y_prev.clone().requires_grad_(True)
@@ -103,7 +105,10 @@ def test_pooled_tail_backward(B, cin, cout, P, S, groups, groups2, relu2):
         (out * probe).sum().backward()
         return [out.detach(), yp.grad] + [p.grad.clone() for p in params]
 
-    new, old = run(True), run(False)
+    try:
+        new, old = run(True), run(False)
+    finally:
+        fused.FUSED_GN_BACKWARD_MAX_WIDTH = width
     for name, n_, o_ in zip(("out", "grad_prev", "gn.weight", "gn.bias", "conv.weight", "gn2.weight", "gn2.bias"), new, old):
         if name in ("out", "gn2.weight", "gn2.bias"):
             assert torch.equal(n_, o_), (name, _rel(n_, o_))

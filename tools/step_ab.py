@@ -1,6 +1,7 @@
 """A/B of one module-level switch of ogc_amd.fused on the bench step, alternating in ONE process on one GPU:
-    python tools/step_ab.py SPARSE_POOL_BACKWARD [rounds]
-prints ms per step with the switch on / off for every round (20 timed steps each)."""
+    python tools/step_ab.py SPARSE_POOL_BACKWARD [rounds [value_a value_b]]
+prints ms per step with the switch at value_a (True) / value_b (False) for every round (20 timed steps each, a fresh process
+per measurement)."""
 import json
 import os
 import subprocess
@@ -27,6 +28,7 @@ def once(name, value):
 if __name__ == "__main__":
     name = sys.argv[1]
     rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+    va, vb = (sys.argv[3], sys.argv[4]) if len(sys.argv) > 4 else ("True", "False")
     for r in range(rounds):
-        on, off = once(name, "True"), once(name, "False")
-        print("%s  on %.3f ms   off %.3f ms" % (name, on, off), flush=True)
+        on, off = once(name, va), once(name, vb)
+        print("%s  %s: %.3f ms   %s: %.3f ms" % (name, va, on, vb, off), flush=True)
