@@ -313,24 +313,30 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void dgrad_adjoint_kernel(int M
                                              : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (POOLED) {
-        const int centres = hw >> s_shift, pos = p0 + 4 * j;
-        const int centre = pos >> s_shift, jpos = pos & ((1 << s_shift) - 1);
-        float2 cc[KQ], jv[KQ];
-#pragma unroll
-        for (int q = 0; q < KQ; ++q) {
-            const int row = q * 4 + kk;
-            const bool in = live && q < Kq && row < K;
-            cc[q] = in ? coef2[(size_t)b * K + row] : make_float2(0.f, 0.f);
-            jv[q] = in ? inj[((size_t)b * K + row) * centres + centre] : make_float2(0.f, __int_as_float(-1));
+        // (c2, c3, ag, arg) of the wave's K rows x (64 >> s_shift) neighbourhoods through a wave-private LDS table: read back one
+        // 16-byte entry per row right where it is used (held in registers next to the K x 64 tile they cost a wavefront per SIMD)
+        const int centres = hw >> s_shift, cpw = 64 >> s_shift;
+        float4 *tab = reinterpret_cast<float4 *>(cf + 64 * 5) + (size_t)wave * K * cpw;
+        for (int e = lane; e < K * cpw; e += OGC_WAVE) {
+            const int row = e / cpw, centre = (p0 >> s_shift) + (e - row * cpw);
+            const float2 cc = coef2[(size_t)b * K + row];
+            const float2 jj = (live && centre < centres) ? inj[((size_t)b * K + row) * centres + centre]
+                                                         : make_float2(0.f, __int_as_float(-1));
+            tab[e] = make_float4(cc.x, cc.y, jj.x, jj.y);
         }
+        __syncthreads();
+        const int mine = (4 * j) >> s_shift, jpos = (p0 + 4 * j) & ((1 << s_shift) - 1);
 #pragma unroll
-        for (int q = 0; q < KQ; ++q) { // the expression of gn_maxpool_bwd_dx_kernel, bit for bit (rows beyond K: zero)
-            const int rel = __float_as_int(jv[q].y) - jpos;
-            const float ag = jv[q].x;
-            xin[q].x = fmaf(cc[q].x, xin[q].x, cc[q].y) + (rel == 0 ? ag : 0.f);
-            xin[q].y = fmaf(cc[q].x, xin[q].y, cc[q].y) + (rel == 1 ? ag : 0.f);
-            xin[q].z = fmaf(cc[q].x, xin[q].z, cc[q].y) + (rel == 2 ? ag : 0.f);
-            xin[q].w = fmaf(cc[q].x, xin[q].w, cc[q].y) + (rel == 3 ? ag : 0.f);
+        for (int q = 0; q < KQ; ++q) { // the expression of gn_maxpool_bwd_dx_kernel, bit for bit (rows beyond K stay zero)
+            const int row = q * 4 + kk;
+            if (q < Kq && row < K) {
+                const float4 t = tab[row * cpw + mine];
+                const int rel = __float_as_int(t.w) - jpos;
+                xin[q].x = fmaf(t.x, xin[q].x, t.y) + (rel == 0 ? t.z : 0.f);
+                xin[q].y = fmaf(t.x, xin[q].y, t.y) + (rel == 1 ? t.z : 0.f);
+                xin[q].z = fmaf(t.x, xin[q].z, t.y) + (rel == 2 ? t.z : 0.f);
+                xin[q].w = fmaf(t.x, xin[q].w, t.y) + (rel == 3 ? t.z : 0.f);
+            }
         }
     }
     for (int m0 = 0; m0 < M; m0 += 64) {
@@ -489,7 +495,8 @@ int dgrad_adjoint_impl(const char *name, int b, int cin, int cout, int hw, int r
                 "%s: one sample exceeds 32-bit indexing", name);
     if (b == 0) return OGC_OK;
     const int M = cin, K = cout, Kq = (K + 3) / 4;
-    const size_t lds = ((size_t)64 * ogc_a_ld(Kq) + 64 * 5) * sizeof(float);
+    const size_t lds = ((size_t)64 * ogc_a_ld(Kq) + 64 * 5) * sizeof(float) +
+                       (inj ? (size_t)WG_WAVES * K * (64 >> s_shift) * sizeof(float4) : 0);
     dim3 grid(ogc_divup(hw, 64 * WG_WAVES), b);
     hipStream_t s = (hipStream_t)stream;
     const float2 *c2 = reinterpret_cast<const float2 *>(coef2), *ij = reinterpret_cast<const float2 *>(inj);
