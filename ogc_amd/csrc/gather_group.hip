@@ -664,6 +664,14 @@ extern "C" int ogc_group_reverse(int b, int n, int npoints, int nsample, const i
     }
     const int tc = ogc_group_reverse_chunk(n, npoints, nsample);
     const int chunks = (T + tc - 1) / tc;
+    if ((size_t)n * sizeof(int) > 60 * 1024) { // n = 16384: 64 KiB of histogram + the kernel's static words
+        static bool once = false;
+        if (!once) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(group_reverse_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * (int)sizeof(int));
+            once = true;
+        }
+    }
     hipLaunchKernelGGL(group_reverse_kernel, dim3(chunks, b), dim3(GRB_THREADS), (size_t)n * sizeof(int),
                        (hipStream_t)stream, n, T, tc, idx, rev_start, rev_pos, heads);
     OGC_CHECK_LAUNCH("ogc_group_reverse");
