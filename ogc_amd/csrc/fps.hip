@@ -59,6 +59,49 @@ __device__ __forceinline__ float fps_wave_max(float v) {
     return __int_as_float(max(max(r0, r1), max(r2, r3)));
 }
 
+// max of a signed 64-bit key over lanes 0..7 (or 0..15) of a wave (every one of them receives it): quad xor 1, quad xor 2,
+// half-row mirror (, row mirror).
+// Both halves of the key travel by DPP; one v_cmp_gt_i64 and two v_cndmask per step.
+template <int CTRL>
+__device__ __forceinline__ long long fps_dpp_max_i64(long long v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)v, CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(v >> 32), CTRL, 0xF, 0xF, true);
+    const long long o = ((long long)hi << 32) | (long long)(unsigned)lo;
+    return o > v ? o : v;
+}
+// the same step with a row broadcast (row_bcast:15 = 0x142 into rows 1 and 3, row_bcast:31 = 0x143 into rows 2 and 3): lanes
+// of the rows that are not written keep their own value
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ long long fps_dpp_bcast_max_i64(long long v) {
+    const int vlo = (int)(unsigned)v, vhi = (int)(v >> 32);
+    const int lo = __builtin_amdgcn_update_dpp(vlo, vlo, CTRL, ROW_MASK, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(vhi, vhi, CTRL, ROW_MASK, 0xF, false);
+    const long long o = ((long long)hi << 32) | (long long)(unsigned)lo;
+    return o > v ? o : v;
+}
+// max over all 64 lanes; the lanes of the LAST 16-lane row (48 .. 63) receive it.  No scalar-unit round trip.
+__device__ __forceinline__ long long fps_max_to_last_row_i64(long long v) {
+    v = fps_dpp_max_i64<0xB1>(v);
+    v = fps_dpp_max_i64<0x4E>(v);
+    v = fps_dpp_max_i64<0x141>(v);
+    v = fps_dpp_max_i64<0x140>(v);
+    v = fps_dpp_bcast_max_i64<0x142, 0xA>(v);
+    return fps_dpp_bcast_max_i64<0x143, 0xC>(v);
+}
+// (value bits, ~rank) as one signed 64-bit key: larger value first (bit patterns of non-negative floats, and of the -1 padding,
+// order as signed integers), then the smaller rank
+__device__ __forceinline__ long long fps_key(float v, unsigned rank) {
+    return (long long)(((u64)__float_as_uint(v) << 32) | (u64)(0xFFFFFFFFu - rank));
+}
+template <int LANES> // 4, 8 or 16: max over the first LANES lanes of every 16-lane row (each of them receives its row's)
+__device__ __forceinline__ long long fps_max_low_lanes_i64(long long v) {
+    v = fps_dpp_max_i64<0xB1>(v);
+    v = fps_dpp_max_i64<0x4E>(v);
+    if (LANES > 4) v = fps_dpp_max_i64<0x141>(v);
+    if (LANES > 8) v = fps_dpp_max_i64<0x140>(v); // row mirror: the other half of the 16-lane row
+    return v;
+}
+
 // (p - q)^2 summed over the axes for two points at once; per half: ((dx*dx + dy*dy) + dz*dz), one rounding per operation
 // (sampling_gpu.cu:133), never contracted.
 __device__ __forceinline__ ogc_v2f fps_sqdist2(ogc_v2f px, ogc_v2f py, ogc_v2f pz, ogc_v2f qx, ogc_v2f qy, ogc_v2f qz) {
@@ -277,7 +320,7 @@ __global__ __launch_bounds__(WAVES *OGC_WAVE) void fps_bucket_kernel(int n, int 
     extern __shared__ __attribute__((aligned(16))) float fps_smem[];
     u64 *best_word = reinterpret_cast<u64 *>(fps_smem);           // [2]
     float *red = fps_smem + 4;                                    // [8 * WAVES] reduction scratch
-    float *lx = fps_smem + 4 + 8 * 8, *ly = lx + FPSB_SLOTS, *lz = ly + FPSB_SLOTS; // xyz by RANK slot (rounds)
+    float *lx = fps_smem + 4 + 8 * 16, *ly = lx + FPSB_SLOTS, *lz = ly + FPSB_SLOTS; // xyz by RANK slot (rounds)
     int *hist = reinterpret_cast<int *>(lx);                      // [NBIN]  (build only: aliases lx)
     unsigned short *perm = reinterpret_cast<unsigned short *>(hist + NBIN); // [FPSB_SLOTS] sorted position -> point
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, b = blockIdx.x;
@@ -443,19 +486,21 @@ __global__ __launch_bounds__(WAVES *OGC_WAVE) void fps_bucket_kernel(int n, int 
     float blo[3] = {0.f, 0.f, 0.f}, bhi[3] = {0.f, 0.f, 0.f}, bmv = -1.0f;
     unsigned bmr = 0xFFFFFFFFu;
     int btie = 0;
+    // (records in lanes 48 + s: the wave-wide key maximum below arrives in the last 16-lane row without leaving the vector unit)
+    constexpr int REC0 = 48;
+    const bool is_rec = lane >= REC0 && lane < REC0 + BPW;
     auto reduce_bucket = [&](int s, float t0, float t1, unsigned r0, unsigned r1) {
-        const float tm = fmaxf(t0, t1);
-        const float wm = fps_wave_max(tm);
-        const bool h0 = t0 == wm, h1 = t1 == wm;
-        const unsigned cand = min(h0 ? r0 : 0xFFFFFFFFu, h1 ? r1 : 0xFFFFFFFFu);
-        // the usual case — one lane holds the maximum — needs one readlane instead of a second wave reduction
-        const unsigned long long holders = __builtin_amdgcn_ballot_w64(h0 || h1);
-        unsigned wr;
-        if (__popcll(holders) == 1) wr = (unsigned)__builtin_amdgcn_readlane((int)cand, (int)__builtin_ctzll(holders));
-        else wr = ogc_wave_min_u32(cand);
+        // ONE reduction of the packed key (value bits, ~rank) over the bucket's 128 points instead of max-then-arg: six DPP
+        // steps, each two moves, a 64-bit compare and two selects
+        const long long k0 = fps_key(t0, r0), k1 = fps_key(t1, r1);
+        const long long k = fps_max_to_last_row_i64(k0 > k1 ? k0 : k1);
         int tie = 0;
-        if (track) tie = __popcll(holders) > 1 || __builtin_amdgcn_ballot_w64(h0 && h1) != 0;
-        if (lane == s) { bmv = wm; bmr = wr; btie = tie; }
+        if (track) { // a second point with the winning value?  (off the critical path: only read after the round's barrier)
+            const float wm = __int_as_float(__builtin_amdgcn_readlane((int)(k >> 32), 63));
+            const bool h0 = t0 == wm, h1 = t1 == wm;
+            tie = __popcll(__builtin_amdgcn_ballot_w64(h0 || h1)) > 1 || __builtin_amdgcn_ballot_w64(h0 && h1) != 0;
+        }
+        if (lane == REC0 + s) { bmv = __int_as_float((int)(k >> 32)); bmr = 0xFFFFFFFFu - (unsigned)k; btie = tie; }
     };
 #pragma unroll
     for (int s = 0; s < BPW; ++s) {
@@ -470,7 +515,7 @@ __global__ __launch_bounds__(WAVES *OGC_WAVE) void fps_bucket_kernel(int n, int 
                 mn = fminf(mn, __shfl_xor(mn, off, 64));
                 mx = fmaxf(mx, __shfl_xor(mx, off, 64));
             }
-            if (lane == s) { blo[a] = mn; bhi[a] = mx; }
+            if (lane == REC0 + s) { blo[a] = mn; bhi[a] = mx; }
         }
         reduce_bucket(s, td[2 * s], td[2 * s + 1], rk[2 * s], rk[2 * s + 1]);
     }
@@ -489,7 +534,7 @@ __global__ __launch_bounds__(WAVES *OGC_WAVE) void fps_bucket_kernel(int n, int 
             dy = dy * dy;
             dz = dz * dz;
             const float d2 = (dx + dy) + dz;
-            reach = (unsigned)__builtin_amdgcn_ballot_w64(lane < BPW && (always || d2 < bmv));
+            reach = (unsigned)(__builtin_amdgcn_ballot_w64(is_rec && (always || d2 < bmv)) >> REC0);
         }
         // (2) update and re-reduce those
         if (reach != 0u) {
@@ -505,15 +550,14 @@ __global__ __launch_bounds__(WAVES *OGC_WAVE) void fps_bucket_kernel(int n, int 
                 }
             }
         }
-        // (3) the wave's best bucket -> LDS maximum over the waves; key = (value bits, ~rank)
-        const float mine = lane < BPW ? bmv : -1.0f;
-        const float wmax = fps_wave_max(mine);
-        const bool holds = lane < BPW && bmv == wmax;
-        const unsigned long long holders = __builtin_amdgcn_ballot_w64(holds);
-        unsigned wrho;
-        if (__popcll(holders) == 1) wrho = (unsigned)__builtin_amdgcn_readlane((int)bmr, (int)__builtin_ctzll(holders));
-        else wrho = ogc_wave_min_u32(holds ? bmr : 0xFFFFFFFFu);
-        if (lane == 0) atomicMax(&best_word[par], ((u64)__float_as_uint(wmax) << 32) | (u64)(0xFFFFFFFFu - wrho));
+        // (3) the wave's best bucket -> LDS maximum over the waves; key = (value bits, ~rank): larger value, then smaller rank.
+        // ONE reduction over the packed key of the BPW records (lanes 48 .. 48+BPW-1; the value bits ordered as signed integers like
+        // fps_wave_max, empty buckets at -1 never win) instead of max-then-arg: lane 48 ends up holding the winner's key in
+        // registers and hands it to the LDS maximum — no readlane / ballot / readlane round trip through the scalar unit.
+        static_assert(BPW == 4 || BPW == 8 || BPW == 16, "fps_max_low_lanes_i64 covers 4, 8 or 16 lanes");
+        long long key = is_rec ? fps_key(bmv, bmr) : (long long)0x8000000000000000ull;
+        key = fps_max_low_lanes_i64<BPW>(key);
+        if (lane == REC0) atomicMax(&best_word[par], (u64)key);
         if (t == 0) best_word[par ^ 1] = 0ull;
         __syncthreads();
         const u64 best = best_word[par];
@@ -521,7 +565,7 @@ __global__ __launch_bounds__(WAVES *OGC_WAVE) void fps_bucket_kernel(int n, int 
         x1 = lx[brho]; y1 = ly[brho]; z1 = lz[brho];
         if (t == 0) out[r] = (int)brho;
         if (track) { // did a second point attain this round's maximum?  Another bucket with it, or the winner's bucket twice
-            const bool eq = lane < BPW && __float_as_uint(bmv) == (unsigned)(best >> 32);
+            const bool eq = is_rec && __float_as_uint(bmv) == (unsigned)(best >> 32);
             const bool tie = eq && (bmr != brho || btie != 0);
             if (__builtin_amdgcn_ballot_w64(tie) != 0 && first_tie > r) first_tie = r;
         }
@@ -749,9 +793,13 @@ static int fps_impl(const char *name, int b, int n, int m, const float *xyz, flo
         // bucketed rounds (fps_bucket_kernel) pay from a few hundred samples on; OGC_FPS_BUCKETS=0: the plain rounds
         static const char *bk = getenv("OGC_FPS_BUCKETS");
         const int mode = bk ? atoi(bk) : 8;
-        const size_t lds = (4 + 64 + 3 * FPSB_SLOTS) * sizeof(float);
+        const size_t lds = (4 + 128 + 3 * FPSB_SLOTS) * sizeof(float);
         if (mode > 0 && m >= 256) {
-            if (mode == 8) {
+            if (mode == 16) {
+                static bool once16 = false;
+                if (!once16) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fps_bucket_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once16 = true; }
+                hipLaunchKernelGGL(fps_bucket_kernel<16>, dim3(b), dim3(1024), lds, s, n, m, shift, xyz, temp, idx, ties_in, ties_out);
+            } else if (mode == 8) {
                 static bool once8 = false;
                 if (!once8) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fps_bucket_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once8 = true; }
                 hipLaunchKernelGGL(fps_bucket_kernel<8>, dim3(b), dim3(512), lds, s, n, m, shift, xyz, temp, idx, ties_in, ties_out);
