@@ -433,6 +433,7 @@ int wgrad_moments_impl(const char *name, int b, int cin, int cout, int hw, int r
     else if (cin <= 16) OGC_ML(4, 1);
     else if (cin <= 32) OGC_ML(4, 2);
     else if (cout <= 32) OGC_ML(2, 4);
+    else if (inj) OGC_ML(4, 2); // the pooled <4, 4> instantiation runs out of registers (256 + 34): two column tiles instead
     else OGC_ML(4, 4);
 #undef OGC_ML
     OGC_CHECK_LAUNCH(name);

@@ -782,10 +782,10 @@ def norm_act_conv(y_prev, stats_prev, gn, relu, conv, next_gn=None, pool=0):
 # *_pooled).  Bit-identical to the two-node sequence (tests/test_ops_gpu.py::test_pooled_tail_backward); C4: the pass it
 # removes is 0.28 ms of a step at SA1's two scales.  False: the two nodes.
 SPARSE_POOL_BACKWARD = True
-# (Measured for SA2's 64 -> 128 tail as well, i.e. its backward through the moment matrices at 128 output rows: step
-# 11.75 -> 12.1-12.7 ms — the pooled variants of those kernels at that width run out of registers; the tail stays limited to
-# FUSED_GN_BACKWARD_MAX_WIDTH on both sides.)
-
+# widest convolution output of such a tail (input width: FUSED_GN_BACKWARD_MAX_WIDTH).  128 (SA2's 64 -> 128 tail through the
+# moment matrices with 64 x 32 tiles) is 0.95 against 0.98-1.01 ms in isolation (tools/pool_tail_compare.py) but 11.62 against
+# 11.56 ms in the step (tools/step_ab.py SPARSE_POOL_MAX_COUT 3 128 64): left at 64.
+SPARSE_POOL_MAX_COUT = 64
 
 class _NormActConvPool(Function):
     """out (B, cout, P) = max over the neighbourhood of act2(GroupNorm2(conv(act(GroupNorm(y_prev))))), y_prev (B, cin, P, S)
@@ -853,7 +853,7 @@ def norm_act_conv_pool_available(y_prev, gn, conv, next_gn):
         return False
     cin, cout, g, g2 = y_prev.shape[1], conv.weight.shape[0], gn.num_groups, next_gn.num_groups
     return ((y_prev.shape[2] * y_prev.shape[3]) % 64 == 0 and cin <= FUSED_GN_BACKWARD_MAX_WIDTH
-            and cout <= FUSED_GN_BACKWARD_MAX_WIDTH and g <= 32 and cin % g == 0
+            and cout <= max(FUSED_GN_BACKWARD_MAX_WIDTH, SPARSE_POOL_MAX_COUT) and g <= 32 and cin % g == 0
             and g2 <= 32 and cout % g2 == 0 and (cout // g2) % 4 == 0)
 
 
