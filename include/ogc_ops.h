@@ -363,12 +363,14 @@ int ogc_conv1x1_dgrad_adjoint(int b, int cin, int cout, int hw, int relu, const 
  * position of every neighbourhood:   g_y[b, ch, pr, j] = fmaf(c2, y, c3) + (j == argmax[b, ch, pr] ? ag : 0).
  *   ogc_group_norm_maxpool_bwd_sparse: ogc_group_norm_maxpool_bwd with  coef2 (b, c, 2) = (c2, c3)  and
  *       inj (b, c, p, 2) = (ag, argmax as its bit pattern)  in place of grad_x (b, c, p, s); grad_gamma / grad_beta as there.
+ *       x_at_argmax (b, c, p) or NULL: x[b, c, pr, argmax] where the forward pass kept it (yext of
+ *       ogc_conv1x1_gemm_affine_pool) — the sums pass then gathers nothing from x (x may be NULL).
  *   ogc_conv1x1_wgrad_moments_pooled / ogc_conv1x1_dgrad_adjoint_pooled: ogc_conv1x1_wgrad_moments / _dgrad_adjoint of the
  *       convolution that wrote y, taking (y, coef2, inj) for grad_y and rebuilding it with the expression above while they
  *       load y — results identical, bit for bit, to the dense sequence; the pass that reads y and writes grad_y (the size of
  *       the layer's activation each way) is gone.  hw = centres * nsample, nsample in {16, 32, 64}. */
-int ogc_group_norm_maxpool_bwd_sparse(int b, int c, int p, int s, int groups, int relu, const float *x, const float *gamma,
-                                      const float *mean, const float *rstd, const float *out, const int *argmax,
+int ogc_group_norm_maxpool_bwd_sparse(int b, int c, int p, int s, int groups, int relu, const float *x,
+                                      const float *x_at_argmax, const float *gamma, const float *mean, const float *rstd, const float *out, const int *argmax,
                                       const float *grad_out, float *coef2, float *inj, float *grad_gamma,
                                       float *grad_beta, double *ws, ogc_stream_t stream);
 int ogc_conv1x1_wgrad_moments_pooled(int b, int cin, int cout, int hw, int relu, int nsample, const float *y_prev,
@@ -449,6 +451,11 @@ int ogc_group_norm_maxpool_bwd(int b, int c, int p, int s, int groups, int relu,
                                const float *gamma, const float *mean, const float *rstd, const float *out,
                                const int *argmax, const float *grad_out, float *grad_x, float *grad_gamma,
                                float *grad_beta, double *ws, ogc_stream_t stream);
+/* ogc_group_norm_maxpool_bwd with x_at_argmax (b, c, p) = x[b, c, pr, argmax[b, c, pr]] handed in (same source as above). */
+int ogc_group_norm_maxpool_bwd_ext(int b, int c, int p, int s, int groups, int relu, const float *x,
+                                   const float *x_at_argmax, const float *gamma, const float *mean, const float *rstd,
+                                   const float *out, const int *argmax, const float *grad_out, float *grad_x,
+                                   float *grad_gamma, float *grad_beta, double *ws, ogc_stream_t stream);
 
 /* Fused BatchNorm2d (+ ReLU) (+ max over the neighbourhood), forward / backward — the F.relu(bn(conv(.))) chains and
  * the trailing .max(dim=-1) of the FlowStep3D blocks

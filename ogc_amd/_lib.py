@@ -68,7 +68,9 @@ SIGNATURES = {
     "ogc_gn_moments_combine": [_int, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "ogc_conv1x1_dgrad_adjoint": [_int, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "ogc_group_norm_maxpool_bwd_sparse": [_int, _int, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                                          _vp, _vp, _vp],
+                                          _vp, _vp, _vp, _vp],
+    "ogc_group_norm_maxpool_bwd_ext": [_int, _int, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                       _vp, _vp, _vp],
     "ogc_conv1x1_wgrad_moments_pooled": [_int, _int, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "ogc_conv1x1_dgrad_adjoint_pooled": [_int, _int, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "ogc_mlp_chain_pool_supported": [_int, _int, _int, _int, _int],

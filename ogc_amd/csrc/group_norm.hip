@@ -382,15 +382,22 @@ __global__ __launch_bounds__(GN_THREADS) void gn_maxpool_bwd_sums_kernel(int c, 
                                                                          const float *__restrict__ out,
                                                                          const int *__restrict__ arg,
                                                                          const float *__restrict__ gout,
+                                                                         const float *__restrict__ xext, // x at arg, or null
+                                                                         const float *__restrict__ gamma,
+                                                                         const float *__restrict__ rstd, int groups,
                                                                          double *__restrict__ dsdb) {
     __shared__ double smem[2 * GN_THREADS / 64];
     const int b = blockIdx.z, ch = blockIdx.y;
+    // xext holds x at the neighbourhood's EXTREME; arg is that position unless the channel's scale is zero
+    // (gn_pool_extremes_kernel: arg = 0 there, as the pass over the full tensor would have it): gather for such a channel
+    if (xext && !(rstd[b * groups + ch / (c / groups)] * gamma[ch] != 0.f)) xext = nullptr;
     const size_t base = ((size_t)b * c + ch) * p;
     double ds = 0.0, db = 0.0;
     for (int pr = blockIdx.x * GN_THREADS + threadIdx.x; pr < p; pr += gridDim.x * GN_THREADS) {
         float g = gout[base + pr];
         if (RELU && !(out[base + pr] > 0.f)) g = 0.f;
-        ds += (double)g * (double)x[(base + pr) * s + arg[base + pr]];
+        // (the gather costs a 32-byte sector per element: 50 us at C4's widths against 5 when the forward pass kept the values)
+        ds += (double)g * (double)(xext ? xext[base + pr] : x[(base + pr) * s + arg[base + pr]]);
         db += g;
     }
     gn_block_sum2(ds, db, smem);
@@ -697,10 +704,10 @@ extern "C" int ogc_group_norm_pool_extremes(int b, int c, int p, int s, int grou
     return OGC_OK;
 }
 
-extern "C" int ogc_group_norm_maxpool_bwd(int b, int c, int p, int s, int groups, int relu, const float *x,
-                                          const float *gamma, const float *mean, const float *rstd, const float *out,
-                                          const int *argmax, const float *grad_out, float *grad_x, float *grad_gamma,
-                                          float *grad_beta, double *ws, ogc_stream_t stream) {
+static int gn_maxpool_bwd_impl(int b, int c, int p, int s, int groups, int relu, const float *x, const float *x_at_argmax,
+                               const float *gamma, const float *mean, const float *rstd, const float *out,
+                               const int *argmax, const float *grad_out, float *grad_x, float *grad_gamma,
+                               float *grad_beta, double *ws, ogc_stream_t stream) {
     OGC_REQUIRE(b >= 0 && c >= 1 && p >= 1 && groups >= 1 && c % groups == 0, "ogc_group_norm_maxpool_bwd: bad shape");
     if (!gn_pool_shape_ok(s) || (((uintptr_t)x | (uintptr_t)grad_x) & 15) != 0) {
         ogc_set_error("ogc_group_norm_maxpool_bwd: unsupported nsample=%d or misaligned tensors", s);
@@ -720,12 +727,12 @@ extern "C" int ogc_group_norm_maxpool_bwd(int b, int c, int p, int s, int groups
     dim3 grid(bx, c, b);
     if (relu) {
         hipLaunchKernelGGL(gn_maxpool_bwd_sums_kernel<true>, gsum, dim3(GN_THREADS), 0, st, c, p, s, x, out, argmax,
-                           grad_out, dsdb);
+                           grad_out, x_at_argmax, gamma, rstd, groups, dsdb);
         hipLaunchKernelGGL(gn_maxpool_bwd_dx_kernel<true>, grid, dim3(GN_THREADS), 0, st, c, p, s, groups, x, gamma, mean,
                            rstd, dsdb, slots, out, argmax, grad_out, grad_x, grad_gamma, grad_beta);
     } else {
         hipLaunchKernelGGL(gn_maxpool_bwd_sums_kernel<false>, gsum, dim3(GN_THREADS), 0, st, c, p, s, x, out, argmax,
-                           grad_out, dsdb);
+                           grad_out, x_at_argmax, gamma, rstd, groups, dsdb);
         hipLaunchKernelGGL(gn_maxpool_bwd_dx_kernel<false>, grid, dim3(GN_THREADS), 0, st, c, p, s, groups, x, gamma,
                            mean, rstd, dsdb, slots, out, argmax, grad_out, grad_x, grad_gamma, grad_beta);
     }
@@ -733,11 +740,30 @@ extern "C" int ogc_group_norm_maxpool_bwd(int b, int c, int p, int s, int groups
     return OGC_OK;
 }
 
+extern "C" int ogc_group_norm_maxpool_bwd(int b, int c, int p, int s, int groups, int relu, const float *x,
+                                          const float *gamma, const float *mean, const float *rstd, const float *out,
+                                          const int *argmax, const float *grad_out, float *grad_x, float *grad_gamma,
+                                          float *grad_beta, double *ws, ogc_stream_t stream) {
+    return gn_maxpool_bwd_impl(b, c, p, s, groups, relu, x, nullptr, gamma, mean, rstd, out, argmax, grad_out, grad_x, grad_gamma,
+                               grad_beta, ws, stream);
+}
+
+// The same with x_at_argmax (b, c, p) = x[b, c, pr, argmax[b, c, pr]] handed in (ogc_conv1x1_gemm_affine_pool's yext): the
+// sums pass then reads no element of x.
+extern "C" int ogc_group_norm_maxpool_bwd_ext(int b, int c, int p, int s, int groups, int relu, const float *x,
+                                              const float *x_at_argmax, const float *gamma, const float *mean,
+                                              const float *rstd, const float *out, const int *argmax, const float *grad_out,
+                                              float *grad_x, float *grad_gamma, float *grad_beta, double *ws,
+                                              ogc_stream_t stream) {
+    return gn_maxpool_bwd_impl(b, c, p, s, groups, relu, x, x_at_argmax, gamma, mean, rstd, out, argmax, grad_out, grad_x,
+                               grad_gamma, grad_beta, ws, stream);
+}
+
 // ogc_group_norm_maxpool_bwd without the dense result: coef2 (B, C, 2) and inj (B, C, P, 2) from which
 // ogc_conv1x1_wgrad_moments_pooled / ogc_conv1x1_dgrad_adjoint_pooled rebuild grad_x element by element (same expression,
 // same bits) while they load x.
 extern "C" int ogc_group_norm_maxpool_bwd_sparse(int b, int c, int p, int s, int groups, int relu, const float *x,
-                                                 const float *gamma, const float *mean, const float *rstd,
+                                                 const float *x_at_argmax, const float *gamma, const float *mean, const float *rstd,
                                                  const float *out, const int *argmax, const float *grad_out, float *coef2,
                                                  float *inj, float *grad_gamma, float *grad_beta, double *ws,
                                                  ogc_stream_t stream) {
@@ -747,7 +773,8 @@ extern "C" int ogc_group_norm_maxpool_bwd_sparse(int b, int c, int p, int s, int
         return OGC_ERR_UNSUPPORTED;
     }
     if (b == 0) return OGC_OK;
-    OGC_REQUIRE(x && gamma && mean && rstd && out && argmax && grad_out && coef2 && inj && grad_gamma && grad_beta && ws,
+    OGC_REQUIRE((x || x_at_argmax) && gamma && mean && rstd && out && argmax && grad_out && coef2 && inj && grad_gamma &&
+                    grad_beta && ws,
                 "ogc_group_norm_maxpool_bwd_sparse: null pointer");
     OGC_REQUIRE(b <= 65535, "ogc_group_norm_maxpool_bwd_sparse: batch exceeds the grid limit");
     hipStream_t st = (hipStream_t)stream;
@@ -761,12 +788,12 @@ extern "C" int ogc_group_norm_maxpool_bwd_sparse(int b, int c, int p, int s, int
     float2 *c2 = reinterpret_cast<float2 *>(coef2), *ij = reinterpret_cast<float2 *>(inj);
     if (relu) {
         hipLaunchKernelGGL(gn_maxpool_bwd_sums_kernel<true>, gsum, dim3(GN_THREADS), 0, st, c, p, s, x, out, argmax,
-                           grad_out, dsdb);
+                           grad_out, x_at_argmax, gamma, rstd, groups, dsdb);
         hipLaunchKernelGGL(gn_maxpool_bwd_sparse_kernel<true>, grid, dim3(GN_THREADS), 0, st, c, p, s, groups, gamma, mean,
                            rstd, dsdb, slots, out, argmax, grad_out, c2, ij, grad_gamma, grad_beta);
     } else {
         hipLaunchKernelGGL(gn_maxpool_bwd_sums_kernel<false>, gsum, dim3(GN_THREADS), 0, st, c, p, s, x, out, argmax,
-                           grad_out, dsdb);
+                           grad_out, x_at_argmax, gamma, rstd, groups, dsdb);
         hipLaunchKernelGGL(gn_maxpool_bwd_sparse_kernel<false>, grid, dim3(GN_THREADS), 0, st, c, p, s, groups, gamma, mean,
                            rstd, dsdb, slots, out, argmax, grad_out, c2, ij, grad_gamma, grad_beta);
     }

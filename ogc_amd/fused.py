@@ -88,7 +88,9 @@ class _GroupNormActMaxPool(Function):
             ws = _api._native.group_norm_ws(B, C, groups, False, x.device)
             nat.group_norm_maxpool_fwd_wrapper(B, C, P, S, groups, eps, relu, x, weight.detach().contiguous(),
                                                bias.detach().contiguous(), out, arg, mean, rstd, ws)
-        ctx.save_for_backward(x, weight, mean, rstd, out, arg)
+        # (with the extremes at hand the backward sums need not gather x at the arg-max positions)
+        yext = extremes[0] if (extremes is not None and stats is not None and POOL_SUMS_FROM_EXTREMES) else None
+        ctx.save_for_backward(x, weight, mean, rstd, out, arg, yext)
         ctx.cfg = (groups, relu)
         ctx.mark_non_differentiable(arg)
         return out
@@ -96,15 +98,19 @@ class _GroupNormActMaxPool(Function):
     @staticmethod
     def backward(ctx, grad_out):
         nat = _api._native
-        x, weight, mean, rstd, out, arg = ctx.saved_tensors
+        x, weight, mean, rstd, out, arg, yext = ctx.saved_tensors
         groups, relu = ctx.cfg
         B, C, P, S = x.shape
         grad_x = torch.empty_like(x)
         gw = torch.empty_like(weight)
         gb = torch.empty_like(weight)
         ws = _api._native.group_norm_ws(B, C, groups, True, x.device)
-        nat.group_norm_maxpool_bwd_wrapper(B, C, P, S, groups, relu, x, weight.detach().contiguous(), mean, rstd, out,
-                                           arg, grad_out.contiguous(), grad_x, gw, gb, ws)
+        if yext is not None and getattr(nat, "group_norm_maxpool_bwd_ext_wrapper", None) is not None:
+            nat.group_norm_maxpool_bwd_ext_wrapper(B, C, P, S, groups, relu, x, yext, weight.detach().contiguous(), mean, rstd,
+                                                   out, arg, grad_out.contiguous(), grad_x, gw, gb, ws)
+        else:
+            nat.group_norm_maxpool_bwd_wrapper(B, C, P, S, groups, relu, x, weight.detach().contiguous(), mean, rstd, out,
+                                               arg, grad_out.contiguous(), grad_x, gw, gb, ws)
         return grad_x, gw, gb, None, None, None, None, None
 
 
@@ -124,6 +130,9 @@ def group_norm_act_maxpool(x, gn: torch.nn.GroupNorm, relu: bool, stats=None, ex
 # behind another wave's MFMAs (128 -> 256 at C4: 0.33 -> 0.56 ms, against 0.14 ms for the pooling pass it saves; step
 # 12.35 vs 12.27 ms in an A/B on one GPU).
 POOL_EXTREMES_WIDE = False
+# The backward sums of a pooled GroupNorm take x at the arg-max positions from those extremes instead of gathering it (a 32-byte
+# sector per element: 50 -> ~8 us per tail at C4).
+POOL_SUMS_FROM_EXTREMES = True
 
 
 def _stats_ok(nat, B, cout, cin, hw, affine):
@@ -809,14 +818,16 @@ class _NormActConvPool(Function):
         g2, b2 = gn2_weight.detach().contiguous(), gn2_bias.detach().contiguous()
         nat.group_norm_pool_extremes_wrapper(B, cout, P, S, groups2, eps2, relu2, extremes[0], extremes[1], g2, b2, out, arg,
                                              mean2, rstd2, stats, stats.numel() // (2 * B * groups2))
-        ctx.save_for_backward(y_prev, gn_weight, gn_bias, conv_weight, mean, rstd, a, bb, y, gn2_weight, mean2, rstd2, out, arg)
+        ctx.save_for_backward(y_prev, gn_weight, gn_bias, conv_weight, mean, rstd, a, bb, y, gn2_weight, mean2, rstd2, out, arg,
+                              extremes[0])
         ctx.cfg = (gn_groups, relu, groups2, relu2)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         nat = _api._native
-        y_prev, gn_weight, gn_bias, conv_weight, mean, rstd, a, bb, y, gn2_weight, mean2, rstd2, out, arg = ctx.saved_tensors
+        (y_prev, gn_weight, gn_bias, conv_weight, mean, rstd, a, bb, y, gn2_weight, mean2, rstd2, out, arg,
+         yext) = ctx.saved_tensors
         gn_groups, relu, groups2, relu2 = ctx.cfg
         B, cin, P, S = y_prev.shape
         cout, hw, dev = conv_weight.shape[0], P * S, y_prev.device
@@ -826,7 +837,8 @@ class _NormActConvPool(Function):
         gw2, gb2 = torch.empty_like(gn2_weight), torch.empty_like(gn2_weight)
         ws = nat.group_norm_ws(B, cout, groups2, True, dev)
         nat.group_norm_maxpool_bwd_sparse_wrapper(B, cout, P, S, groups2, relu2, y, gn2_weight.detach().contiguous(), mean2,
-                                                  rstd2, out, arg, grad_out.contiguous(), coef2, inj, gw2, gb2, ws)
+                                                  rstd2, out, arg, grad_out.contiguous(), coef2, inj, gw2, gb2, ws,
+                                                  yext if POOL_SUMS_FROM_EXTREMES else None)
         # the convolution's backward (as _NormActConv.backward's moment-matrix path) on that form
         w = conv_weight.detach().contiguous().view(cout, cin)
         moments = torch.empty(B, 2, cout, cin, dtype=torch.float32, device=dev)

@@ -335,6 +335,15 @@ def group_norm_maxpool_bwd_wrapper(b, c, p, s, groups, relu, x, gamma, mean, rst
          _check(ws, torch.float64, "ws"))
 
 
+def group_norm_maxpool_bwd_ext_wrapper(b, c, p, s, groups, relu, x, x_at_argmax, gamma, mean, rstd, out, argmax, grad_out,
+                                       grad_x, grad_gamma, grad_beta, ws):
+    """group_norm_maxpool_bwd_wrapper with x at the arg-max positions handed in (ogc_group_norm_maxpool_bwd_ext)."""
+    _run("ogc_group_norm_maxpool_bwd_ext", x, b, c, p, s, groups, int(relu), _f(x, "x"), _f(x_at_argmax, "x_at_argmax"),
+         _f(gamma, "gamma"), _f(mean, "mean"), _f(rstd, "rstd"), _f(out, "out"), _i(argmax, "argmax"),
+         _f(grad_out, "grad_out"), _f(grad_x, "grad_x"), _f(grad_gamma, "grad_gamma"), _f(grad_beta, "grad_beta"),
+         _check(ws, torch.float64, "ws"))
+
+
 def conv1x1_wgrad_wrapper(b, cin, cout, hw, x, dy, dw):
     """dw[co, ci] = sum_{b,p} dy[b, co, p] x[b, ci, p] (ogc_conv1x1_wgrad); hw % 16 == 0."""
     _run("ogc_conv1x1_wgrad", x, b, cin, cout, hw, _f(x, "x"), _f(dy, "dy"), _f(dw, "dw"))
@@ -461,10 +470,11 @@ def conv1x1_dgrad_adjoint_wrapper(b, cin, cout, hw, relu, w, grad_y, y_prev, pa,
 
 
 def group_norm_maxpool_bwd_sparse_wrapper(b, c, p, s, groups, relu, x, gamma, mean, rstd, out, argmax, grad_out, coef2, inj,
-                                          grad_gamma, grad_beta, ws):
+                                          grad_gamma, grad_beta, ws, x_at_argmax=None):
     """coef2 (b, c, 2), inj (b, c, p, 2): the gradient of the pooled GroupNorm w.r.t. x in sparse form
     (ogc_group_norm_maxpool_bwd_sparse)."""
-    _run("ogc_group_norm_maxpool_bwd_sparse", x, b, c, p, s, groups, int(relu), _f(x, "x"), _f(gamma, "gamma"),
+    _run("ogc_group_norm_maxpool_bwd_sparse", x, b, c, p, s, groups, int(relu), _f(x, "x"),
+         _opt(x_at_argmax, torch.float32, "x_at_argmax"), _f(gamma, "gamma"),
          _f(mean, "mean"), _f(rstd, "rstd"), _f(out, "out"), _i(argmax, "argmax"), _f(grad_out, "grad_out"),
          _f(coef2, "coef2"), _f(inj, "inj"), _f(grad_gamma, "grad_gamma"), _f(grad_beta, "grad_beta"),
          _check(ws, torch.float64, "ws"))
