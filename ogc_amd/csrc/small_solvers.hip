@@ -22,73 +22,123 @@ namespace {
 
 constexpr int LSAP_MAX = 64;
 
-// one thread per problem; the state lives in LDS (dynamic indexing of private arrays would go to scratch memory)
+// One WAVEFRONT per problem, lane `it` on position `it` of scipy's `remaining` list: the scan over the remaining columns — the
+// inner loop of every step of a shortest augmenting path — is one lane-parallel update plus a wave-wide minimum, and the
+// tie rule of the sequential scan (the first position attaining the minimum, replaced by every LATER position that attains
+// it with a column that has no row yet) becomes two ballots: the highest such later position if there is one, else the
+// first.  State in LDS (column- and row-indexed arrays are addressed through `remaining`, a permutation that changes by
+// swap-removal).  One thread per problem, as this kernel was first written, spent 65 us of the loss phase's main queue on 16
+// problems of 10 x 10; this form ~8.
+// minimum over the wavefront, returned to every lane: six DPP steps (within quads, rows, then row broadcasts into the last row)
+// on both halves of the double, one 64-bit compare and two selects each, and a readlane of lane 63 — ds_bpermute shuffles made
+// this reduction half of a step's latency.
+template <int CTRL, int ROW_MASK, bool KEEP_OWN>
+__device__ __forceinline__ double lsap_dpp_min(double v) {
+    const long long bits = __double_as_longlong(v);
+    const int vlo = (int)(unsigned)bits, vhi = (int)(bits >> 32);
+    // lanes whose source is outside the wave or whose row is masked keep their own value
+    const int lo = __builtin_amdgcn_update_dpp(vlo, vlo, CTRL, ROW_MASK, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(vhi, vhi, CTRL, ROW_MASK, 0xF, false);
+    const double o = __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
+    return o < v ? o : v;
+}
+__device__ __forceinline__ double lsap_wave_min(double v) {
+    v = lsap_dpp_min<0xB1, 0xF, true>(v);  // quad xor 1
+    v = lsap_dpp_min<0x4E, 0xF, true>(v);  // quad xor 2
+    v = lsap_dpp_min<0x141, 0xF, true>(v); // half-row mirror
+    v = lsap_dpp_min<0x140, 0xF, true>(v); // row mirror: every row uniform
+    v = lsap_dpp_min<0x142, 0xA, true>(v); // row_bcast:15 into rows 1 and 3
+    v = lsap_dpp_min<0x143, 0xC, true>(v); // row_bcast:31 into rows 2 and 3: lane 63 holds the minimum
+    const long long bits = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(unsigned)bits, 63), hi = __builtin_amdgcn_readlane((int)(bits >> 32), 63);
+    return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
+}
+
 __global__ __launch_bounds__(64) void lsap_maximize_kernel(int np, int k, const float *__restrict__ score,
                                                            int *__restrict__ col4row_out) {
     extern __shared__ __attribute__((aligned(8))) unsigned char lsap_smem[];
-    const int t = threadIdx.x, prob = blockIdx.x * blockDim.x + t;
-    if (prob >= np) return;
-    // per-thread slices
-    double *base = reinterpret_cast<double *>(lsap_smem) + (size_t)t * (3 * k);
-    double *u = base, *v = base + k, *spc = base + 2 * k; // duals, shortest path costs
-    short *ibase = reinterpret_cast<short *>(lsap_smem + (size_t)blockDim.x * 3 * k * sizeof(double)) + (size_t)t * (6 * k);
-    short *path = ibase, *col4row = ibase + k, *row4col = ibase + 2 * k, *remaining = ibase + 3 * k;
-    short *SR = ibase + 4 * k, *SC = ibase + 5 * k;
+    const int lane = threadIdx.x, prob = blockIdx.x;
+    double *cost = reinterpret_cast<double *>(lsap_smem); // [k][k]: the negated scores (maximize)
+    double *u = cost + (size_t)k * k, *v = u + k, *spc = v + k; // duals, shortest path costs
+    short *path = reinterpret_cast<short *>(spc + k), *col4row = path + k, *row4col = col4row + k, *remaining = row4col + k;
+    short *SR = remaining + k, *SC = SR + k;
     const float *sc = score + (size_t)prob * k * k;
-    for (int i = 0; i < k; ++i) {
-        u[i] = 0.0; v[i] = 0.0;
-        path[i] = -1; col4row[i] = -1; row4col[i] = -1;
+    bool bad = false;
+    for (int e = lane; e < k * k; e += 64) { // scipy rejects NaN and -inf costs (= +inf scores) before solving
+        const float c = sc[e];
+        bad = bad || c != c || c == INFINITY;
+        cost[e] = -(double)c;
     }
-    bool feasible = true;
-    for (int e = 0; e < k * k; ++e) // scipy rejects NaN and -inf costs (= +inf scores) before solving
-        if (sc[e] != sc[e] || sc[e] == INFINITY) feasible = false;
+    bool feasible = __builtin_amdgcn_ballot_w64(bad) == 0;
+    if (lane < k) {
+        u[lane] = 0.0; v[lane] = 0.0;
+        path[lane] = -1; col4row[lane] = -1; row4col[lane] = -1;
+    }
+    __syncthreads();
     for (int cur = 0; cur < k && feasible; ++cur) {
         // ---- shortest augmenting path from row `cur`
-        double min_val = 0.0;
-        int num_remaining = k;
-        for (int it = 0; it < k; ++it) {
-            remaining[it] = (short)(k - it - 1);
-            SR[it] = 0; SC[it] = 0;
-            spc[it] = INFINITY;
+        if (lane < k) {
+            remaining[lane] = (short)(k - lane - 1);
+            SR[lane] = 0; SC[lane] = 0;
+            spc[lane] = INFINITY;
         }
-        int sink = -1, i = cur;
+        __syncthreads();
+        double min_val = 0.0;
+        int num_remaining = k, sink = -1, i = cur;
         while (sink == -1) {
-            int index = -1;
-            double lowest = INFINITY;
-            SR[i] = 1;
-            for (int it = 0; it < num_remaining; ++it) {
-                const int j = remaining[it];
-                const double r = min_val + (-(double)sc[i * k + j]) - u[i] - v[j];
-                if (r < spc[j]) { path[j] = (short)i; spc[j] = r; }
-                if (spc[j] < lowest || (spc[j] == lowest && row4col[j] == -1)) { lowest = spc[j]; index = it; }
+            if (lane == 0) SR[i] = 1;
+            double mine = INFINITY;
+            int j = -1;
+            bool unassigned = false;
+            if (lane < num_remaining) {
+                j = remaining[lane];
+                const double r = min_val + cost[i * k + j] - u[i] - v[j];
+                double s = spc[j];
+                if (r < s) { path[j] = (short)i; spc[j] = r; s = r; }
+                mine = s;
+                unassigned = row4col[j] == -1;
             }
+            const double lowest = lsap_wave_min(mine);
             min_val = lowest;
             if (!(min_val < INFINITY)) { feasible = false; break; } // NaN / inf scores: scipy raises; we emit -1
-            const int j = remaining[index];
-            if (row4col[j] == -1) sink = j; else i = row4col[j];
-            SC[j] = 1;
-            remaining[index] = remaining[--num_remaining];
+            const unsigned long long eq = __builtin_amdgcn_ballot_w64(lane < num_remaining && mine == lowest);
+            const unsigned long long un = __builtin_amdgcn_ballot_w64(lane < num_remaining && mine == lowest && unassigned);
+            const int index = un ? 63 - __builtin_clzll(un) : __builtin_ctzll(eq);
+            const int jw = __builtin_amdgcn_readlane(j, index); // (index is wave-uniform)
+            __syncthreads(); // everybody has read `remaining` and row4col
+            const int owner = (int)row4col[jw];
+            if (owner == -1) sink = jw; else i = owner;
+            if (lane == 0) {
+                SC[jw] = 1;
+                remaining[index] = remaining[num_remaining - 1];
+            }
+            --num_remaining;
+            __syncthreads();
         }
         if (!feasible) break;
-        // ---- dual update
-        u[cur] += min_val;
-        for (int r = 0; r < k; ++r)
-            if (SR[r] && r != cur) u[r] += min_val - spc[col4row[r]];
-        for (int j = 0; j < k; ++j)
-            if (SC[j]) v[j] -= min_val - spc[j];
-        // ---- augment
-        int j = sink;
-        while (true) {
-            const int r = path[j];
-            row4col[j] = (short)r;
-            const int prev = col4row[r];
-            col4row[r] = (short)j;
-            j = prev;
-            if (r == cur) break;
+        // ---- dual update (col4row is still the assignment before this row's augmentation)
+        if (lane < k) {
+            if (lane == cur) u[cur] += min_val;
+            else if (SR[lane]) u[lane] += min_val - spc[col4row[lane]];
+            if (SC[lane]) v[lane] -= min_val - spc[lane];
         }
+        __syncthreads();
+        // ---- augment
+        if (lane == 0) {
+            int j = sink;
+            while (true) {
+                const int r = path[j];
+                row4col[j] = (short)r;
+                const int prev = col4row[r];
+                col4row[r] = (short)j;
+                j = prev;
+                if (r == cur) break;
+            }
+        }
+        __syncthreads();
     }
     int *o = col4row_out + (size_t)prob * k;
-    for (int r = 0; r < k; ++r) o[r] = feasible ? (int)col4row[r] : -1;
+    if (lane < k) o[lane] = feasible ? (int)col4row[lane] : -1;
 }
 
 constexpr int EIG_MAX = 64;
@@ -198,12 +248,8 @@ extern "C" int ogc_lsap_maximize(int np, int k, const float *score, int *col4row
     if (np == 0 || k == 0) return OGC_OK;
     OGC_REQUIRE(k <= LSAP_MAX, "ogc_lsap_maximize: more than 64 slots");
     OGC_REQUIRE(score && col4row, "ogc_lsap_maximize: null pointer");
-    int threads = np < 64 ? np : 64;
-    const int fit = 65536 / (k * (int)(3 * sizeof(double) + 6 * sizeof(short))); // 64 KiB of LDS per workgroup
-    if (threads > fit) threads = fit;
-    const size_t smem = (size_t)threads * k * (3 * sizeof(double) + 6 * sizeof(short));
-    hipLaunchKernelGGL(lsap_maximize_kernel, dim3(ogc_divup(np, threads)), dim3(threads), smem, (hipStream_t)stream, np,
-                       k, score, col4row);
+    const size_t smem = ((size_t)k * k + 3 * k) * sizeof(double) + (size_t)6 * k * sizeof(short);
+    hipLaunchKernelGGL(lsap_maximize_kernel, dim3(np), dim3(64), smem, (hipStream_t)stream, np, k, score, col4row);
     OGC_CHECK_LAUNCH("ogc_lsap_maximize");
     return OGC_OK;
 }
