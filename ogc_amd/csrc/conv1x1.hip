@@ -237,12 +237,80 @@ constexpr int GN_SLOTS = 16;  // spread of the fused GroupNorm statistics over c
 // smallest for gamma < 0: the largest of the negated values) — and that pass never reads `out`
 // (ogc_group_norm_pool_extremes).  A wave's 64 positions hold whole neighbourhoods; values are reduced over the 4
 // accumulator columns of a lane and the pool_s / 4 lanes of a DPP row first, then the smallest index attaining them.
+// max(x, x of the DPP partner) as ONE instruction.  (fmaxf on a DPP-moved value costs three: the move, a canonicalising
+// v_max of the moved value — the compiler cannot know it is not a signalling NaN — and the maximum.)  The two wait states a
+// DPP read needs after a VALU write of its source are inside the asm: the hazard recogniser does not look into it.
+template <int CTRL>
+__device__ __forceinline__ float ogc_max_dpp_f32(float x) {
+    float r;
+    if constexpr (CTRL == 0xB1)
+        asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(x));
+    else if constexpr (CTRL == 0x4E)
+        asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(x));
+    else if constexpr (CTRL == 0x141)
+        asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(x));
+    else
+        asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 row_mirror row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(x));
+    return r;
+}
+__device__ __forceinline__ float ogc_max3_f32(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float ogc_max2_f32(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 struct PoolOut {
     float *yext;          // (b, M, centres) largest raw output where sign[m] >= 0, smallest where sign[m] < 0
     int *aext;            // its neighbour index
     const float *sign;    // (M) the scale of the GroupNorm that follows (only its sign is used)
     int s;
 };
+
+// The extremes of the neighbourhoods in a wave's 64-row x 64-position tile (see POOL above).  acc[a][c][r]: row a * 16 + kk * 4 + r,
+// position p0 + 4 j + c.  SEG = lanes per neighbourhood (4, 8, 16 for 16, 32, 64 neighbours).  sgn: +-1 per row of the tile (LDS).
+template <int SEG, typename ACC>
+__device__ __forceinline__ void ogc_pool_extremes_epilogue(const ACC (&acc)[4][4], int nblk, const float *sgn, int j, int kk,
+                                                           int m0, int M, int centres, int pool_s, float *ye, int *ae) {
+    const bool writer = (j & (SEG - 1)) == 0;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        if (a < nblk) {
+            const float4 sg4 = *reinterpret_cast<const float4 *>(sgn + a * 16 + kk * 4);
+            const float sga[4] = {sg4.x, sg4.y, sg4.z, sg4.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + a * 16 + kk * 4 + r;
+                const float sg = sga[r]; // exact: +-1 * v
+                const float v0 = sg * acc[a][0][r], v1 = sg * acc[a][1][r];
+                const float v2 = sg * acc[a][2][r], v3 = sg * acc[a][3][r];
+                float hi = ogc_max3_f32(v0, v1, ogc_max2_f32(v2, v3));
+                hi = ogc_max_dpp_f32<0xB1>(hi);
+                hi = ogc_max_dpp_f32<0x4E>(hi);
+                if (SEG >= 8) hi = ogc_max_dpp_f32<0x141>(hi);
+                if (SEG >= 16) hi = ogc_max_dpp_f32<0x140>(hi);
+                // first position of the neighbourhood that attains it (64: none in this lane) — selects, no branches
+                unsigned idx = v3 == hi ? 4u * j + 3u : 64u;
+                idx = v2 == hi ? 4u * j + 2u : idx;
+                idx = v1 == hi ? 4u * j + 1u : idx;
+                idx = v0 == hi ? 4u * j : idx;
+                idx = min(idx, ogc_dpp_u32<0xB1>(idx));
+                idx = min(idx, ogc_dpp_u32<0x4E>(idx));
+                if (SEG >= 8) idx = min(idx, ogc_dpp_u32<0x141>(idx));
+                if (SEG >= 16) idx = min(idx, ogc_dpp_u32<0x140>(idx));
+                if (writer && m < M) {
+                    const int o = (a * 16 + r) * centres;
+                    ye[o] = sg * hi;
+                    ae[o] = (int)(idx & (unsigned)(pool_s - 1)); // index inside the neighbourhood
+                }
+            }
+        }
+    }
+}
 
 template <bool TRANSPOSE_A, int KQ, bool STATS, bool PRO, bool BF, bool POOL = false>
 __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_gemm_kernel(int M, int K, int hw, int groups,
@@ -255,6 +323,7 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_gemm_kernel(int M,
                                                                           PoolOut pool = PoolOut()) {
     extern __shared__ __attribute__((aligned(16))) float a_lds[]; // [64][ogc_a_ld(Kq)]: the current 64-row tile of A (conv_stage.h)
     __shared__ double s_stats[STATS ? 64 : 1];                    // [groups][2]
+    __shared__ __attribute__((aligned(16))) float s_sign[POOL ? 64 : 4]; // POOL: -1 for the tile's rows whose next scale is negative
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 15, kk = lane >> 4;
     const int b = blockIdx.y;
@@ -333,6 +402,9 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_gemm_kernel(int M,
         } else {
         ogc_stage_weight_tile<TRANSPOSE_A, WG_WAVES>(a_lds, w, m0, M, K, Kq); // a_lds[mi * LD + k] = A[m0 + mi][k]
         }
+        if constexpr (POOL) {
+            if (threadIdx.x < 64) s_sign[threadIdx.x] = (m0 + (int)threadIdx.x < M && pool.sign[m0 + threadIdx.x] < 0.f) ? -1.f : 1.f;
+        }
         __syncthreads();
         const int nblk = min(4, (M - m0 + 15) >> 4); // 16-row blocks of this tile that hold real rows (uniform)
         v4f acc[4][4];
@@ -389,42 +461,13 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_gemm_kernel(int M,
                     }
                 }
             if constexpr (POOL) {
-                const int seg = pool.s >> 2;                 // lanes per neighbourhood: 4, 8 or 16
                 const int centres = hw / pool.s;
                 const int centre = (p0 + 4 * j) / pool.s;    // of this lane's four positions
                 // outputs of row m0 + kk * 4 of this lane's centre; row a * 16 + r is (a * 16 + r) * centres further on
                 const size_t o0 = ((size_t)b * M + m0 + kk * 4) * centres + centre;
-                float *const ye = pool.yext + o0;
-                int *const ae = pool.aext + o0;
-                const bool writer = (j & (seg - 1)) == 0;
-#pragma unroll
-                for (int a = 0; a < 4; ++a) {
-                    if (a < nblk) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int m = m0 + a * 16 + kk * 4 + r;
-                            const float sg = (m < M && pool.sign[m] < 0.f) ? -1.f : 1.f;   // exact: +-1 * v
-                            const float v0 = sg * acc[a][0][r], v1 = sg * acc[a][1][r];
-                            const float v2 = sg * acc[a][2][r], v3 = sg * acc[a][3][r];
-                            float hi = fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
-                            hi = fmaxf(hi, ogc_dpp_f32<0xB1>(hi));
-                            hi = fmaxf(hi, ogc_dpp_f32<0x4E>(hi));
-                            if (seg >= 8) hi = fmaxf(hi, ogc_dpp_f32<0x141>(hi));
-                            if (seg >= 16) hi = fmaxf(hi, ogc_dpp_f32<0x140>(hi));
-                            // first position of the neighbourhood that attains it (64: none in this lane)
-                            unsigned idx = v0 == hi ? 4 * j : (v1 == hi ? 4 * j + 1 : (v2 == hi ? 4 * j + 2 : (v3 == hi ? 4 * j + 3 : 64)));
-                            idx = min(idx, ogc_dpp_u32<0xB1>(idx));
-                            idx = min(idx, ogc_dpp_u32<0x4E>(idx));
-                            if (seg >= 8) idx = min(idx, ogc_dpp_u32<0x141>(idx));
-                            if (seg >= 16) idx = min(idx, ogc_dpp_u32<0x140>(idx));
-                            if (writer && m < M) {
-                                const int o = (a * 16 + r) * centres;
-                                ye[o] = sg * hi;
-                                ae[o] = (int)(idx & (unsigned)(pool.s - 1));   // index inside the neighbourhood
-                            }
-                        }
-                    }
-                }
+                if (pool.s == 64) ogc_pool_extremes_epilogue<16>(acc, nblk, s_sign, j, kk, m0, M, centres, 64, pool.yext + o0, pool.aext + o0);
+                else if (pool.s == 32) ogc_pool_extremes_epilogue<8>(acc, nblk, s_sign, j, kk, m0, M, centres, 32, pool.yext + o0, pool.aext + o0);
+                else ogc_pool_extremes_epilogue<4>(acc, nblk, s_sign, j, kk, m0, M, centres, 16, pool.yext + o0, pool.aext + o0);
             }
             if (STATS) {
 #pragma unroll
