@@ -106,6 +106,7 @@ SIGNATURES = {
 }
 
 _lib = None
+_fns = {}  # entry point name -> bound ctypes function
 
 
 class OgcOpsError(RuntimeError):
@@ -136,9 +137,11 @@ def load():
 def call(name, *args):
     """Invoke an entry point; non-zero status becomes a Python exception (the reference would
     have printed and exit(-1)'d, e.g. ball_query_gpu.cu:62-66)."""
-    L = load()
-    rc = getattr(L, name)(*args)
+    fn = _fns.get(name)
+    if fn is None:
+        fn = _fns[name] = getattr(load(), name)
+    rc = fn(*args)
     if rc != 0:
-        msg = L.ogc_last_error().decode("utf-8", "replace")
+        msg = load().ogc_last_error().decode("utf-8", "replace")
         raise OgcOpsError("%s failed (status %d): %s" % (name, rc, msg))
     return rc

@@ -63,6 +63,72 @@ def make_optimizer(params, lr, weight_decay=0.0, capturable=False):
     return torch.optim.Adam(params, lr=lr, weight_decay=weight_decay, fused=fused, capturable=bool(capturable and fused))
 
 
+def _fused_adam_step(optimizer, found_inf):
+    """optimizer.step() of a fused torch.optim.Adam without its per-parameter Python — state lookup, list building and device
+    grouping for ~190 parameters cost the launch thread 0.9 ms per step, and at C4 that thread is level with the GPU.  The same
+    three calls torch makes (step counts + 1, torch._fused_adam_ with found_inf, step counts - found_inf) on lists cached on the
+    optimizer; the state tensors are those of optimizer.state, so state_dict() / load_state_dict() are unaffected.  Returns
+    False when the optimizer is not in the plain configuration this covers (the caller then calls optimizer.step())."""
+    if type(optimizer) is not torch.optim.Adam or not hasattr(torch, "_fused_adam_"):
+        return False
+    cache = getattr(optimizer, "_ogc_fused_lists", None)
+    if cache is not None:  # load_state_dict() replaces the group dictionaries and the state tensors: start over then
+        groups = optimizer.param_groups
+        if len(groups) != len(cache) or any(g is not c[0] or optimizer.state[c[1][0]].get("step") is not c[4][0]
+                                            for g, c in zip(groups, cache)):
+            cache = None
+    if cache is None:
+        cache = []
+        for group in optimizer.param_groups:
+            if (not group.get("fused") or group.get("amsgrad") or group.get("maximize") or group.get("differentiable")
+                    or group.get("decoupled_weight_decay") or isinstance(group["lr"], torch.Tensor)):
+                return False
+            params = list(group["params"])
+            if not params:
+                return False
+            states = [optimizer.state.get(p) for p in params]
+            if any(not st or "exp_avg" not in st for st in states):
+                return False  # first step: torch builds the state
+            if any(p.device != params[0].device or p.dtype != params[0].dtype or p.is_complex() for p in params):
+                return False
+            cache.append((group, params, [st["exp_avg"] for st in states], [st["exp_avg_sq"] for st in states],
+                          [st["step"] for st in states]))
+        optimizer._ogc_fused_lists = cache
+    work = []
+    for group, params, exp_avgs, exp_avg_sqs, steps in cache:
+        if len(group["params"]) != len(params):
+            optimizer._ogc_fused_lists = None
+            return False
+        grads = [p.grad for p in params]
+        if any(g is None for g in grads):
+            return False  # parameters without a gradient this step: torch's own filtering
+        work.append((group, params, grads, exp_avgs, exp_avg_sqs, steps))
+    for group, params, grads, exp_avgs, exp_avg_sqs, steps in work:
+        beta1, beta2 = group["betas"]
+        torch._foreach_add_(steps, 1)
+        torch._fused_adam_(params, grads, exp_avgs, exp_avg_sqs, [], steps, amsgrad=False, lr=group["lr"], beta1=beta1,
+                           beta2=beta2, weight_decay=group["weight_decay"], eps=group["eps"], maximize=False,
+                           grad_scale=None, found_inf=found_inf)
+        if found_inf is not None:
+            torch._foreach_sub_(steps, [found_inf] * len(steps))
+    optimizer._opt_called = True  # (what torch's LR schedulers look at to warn about the call order)
+    return True
+
+
+def _step_with_flag(optimizer, bad):
+    """Fused optimizer: the kernel itself skips the update (and the step count) when found_inf == 1."""
+    found_inf = bad.float().reshape(())
+    if _fused_adam_step(optimizer, found_inf):
+        return
+    optimizer.grad_scale = None
+    optimizer.found_inf = found_inf
+    try:
+        optimizer.step()
+    finally:
+        del optimizer.grad_scale
+        del optimizer.found_inf
+
+
 def _views(batch):
     """(clouds of all views for the network (b t, n, 3); per-view clouds and flows [(b, n, 3)] x t; the same view-major as ONE
     tensor each (t b, n, 3)).  One transposing copy per tensor: the per-view lists are slices of it (the loss works on the
@@ -176,14 +242,7 @@ def train_step(segnet, criterion, optimizer, batch, it, aug_transform, sync=True
     bad = torch.isnan(torch.stack(torch._foreach_norm(grads)).sum())  # NaN anywhere -> NaN norm
     # under DDP the all-reduced gradients make this decision identical on all ranks
     if getattr(optimizer, "_step_supports_amp_scaling", False) and bad.is_cuda:
-        # fused optimizer: the kernel itself skips the update (and the step count) when found_inf == 1
-        optimizer.grad_scale = None
-        optimizer.found_inf = bad.float().reshape(())
-        try:
-            optimizer.step()
-        finally:
-            del optimizer.grad_scale
-            del optimizer.found_inf
+        _step_with_flag(optimizer, bad)
         pending = PendingStep(losses, HostScalars(bad.reshape(1)))
     else:
         skip = bool(bad)  # host sync
@@ -224,13 +283,7 @@ def _nan_safe_step(params, optimizer):
     grads = [p.grad for p in params if p.grad is not None]
     bad = torch.isnan(torch.stack(torch._foreach_norm(grads)).sum())  # NaN anywhere -> NaN norm
     if getattr(optimizer, "_step_supports_amp_scaling", False) and bad.is_cuda:
-        optimizer.grad_scale = None
-        optimizer.found_inf = bad.float().reshape(())
-        try:
-            optimizer.step()
-        finally:
-            del optimizer.grad_scale
-            del optimizer.found_inf
+        _step_with_flag(optimizer, bad)
         return HostScalars(bad.reshape(1))
     skip = bool(bad)  # host sync
     if not skip:
