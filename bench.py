@@ -268,6 +268,32 @@ def main():
             extras["ms_per_step_all_fps_rounds"] = round((time.perf_counter() - t1) / 5 * 1e3, 3)
         finally:
             sa_util.FPS_CHAIN_SHORTCUT = True
+        if world == 1 and not dist.is_initialized():
+            # the same step replayed as ONE HIP graph (ogc_amd/graph_step.py; `--hip-graph` of the training driver): what a step
+            # costs when the launch thread is out of the picture.  A second network / optimizer (the capture needs step counts
+            # on the device); reported next to the eager headline, never instead of it.
+            try:
+                from ogc_amd.graph_step import GraphedTrainStep
+                torch.manual_seed(10)
+                net_g = MaskFormer3D(n_slot=10, n_point=a.npoint, use_xyz=True, n_transformer_layer=2,
+                                     transformer_embed_dim=128, transformer_input_pos_enc=False).to(dev)
+                gs = GraphedTrainStep(net_g, build_criterion(KITTI_LOSS),
+                                      make_optimizer(net_g.parameters(), lr=1e-3, weight_decay=0.0, capturable=True), batch, it, True)
+                for _ in range(3):
+                    gs.step(batch)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(10):
+                    pg = gs.step(batch)
+                torch.cuda.synchronize()
+                extras["ms_per_step_hip_graph"] = round((time.perf_counter() - t1) / 10 * 1e3, 3)
+                ld, ok = pg.result()
+                extras["hip_graph_note"] = ("the step as one replayed HIP graph (train_seg --hip-graph), 10 replays after the timed "
+                                            "region; stepped=%s, loss sum %.4f" % (bool(ok), ld.get("sum", float("nan"))))
+                del gs, net_g
+            except Exception as err:  # an extra reading must not cost the headline its line
+                extras["ms_per_step_hip_graph"] = None
+                extras["hip_graph_note"] = "not measured: %s" % (str(err)[:200],)
     if rank == 0:
         durs = timer.durations_ms()
         # In the step the ball query runs on the cell grid it shares with the loss's k-NN (ogc_cell_grid_build once per step for
