@@ -88,6 +88,26 @@ __device__ __forceinline__ long long fps_max_to_last_row_i64(long long v) {
     v = fps_dpp_bcast_max_i64<0x142, 0xA>(v);
     return fps_dpp_bcast_max_i64<0x143, 0xC>(v);
 }
+// 32-bit versions for max-then-arg without readlanes between the steps: six DPP steps each (the last two row broadcasts), the
+// lanes of the last row receive the result
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int fps_dpp_keep(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xF, false); }
+__device__ __forceinline__ int fps_max_to_last_row_i32(int v) {
+    v = max(v, fps_dpp_keep<0xB1, 0xF>(v));
+    v = max(v, fps_dpp_keep<0x4E, 0xF>(v));
+    v = max(v, fps_dpp_keep<0x141, 0xF>(v));
+    v = max(v, fps_dpp_keep<0x140, 0xF>(v));
+    v = max(v, fps_dpp_keep<0x142, 0xA>(v));
+    return max(v, fps_dpp_keep<0x143, 0xC>(v));
+}
+__device__ __forceinline__ unsigned fps_min_to_last_row_u32(unsigned v) {
+    v = min(v, (unsigned)fps_dpp_keep<0xB1, 0xF>((int)v));
+    v = min(v, (unsigned)fps_dpp_keep<0x4E, 0xF>((int)v));
+    v = min(v, (unsigned)fps_dpp_keep<0x141, 0xF>((int)v));
+    v = min(v, (unsigned)fps_dpp_keep<0x140, 0xF>((int)v));
+    v = min(v, (unsigned)fps_dpp_keep<0x142, 0xA>((int)v));
+    return min(v, (unsigned)fps_dpp_keep<0x143, 0xC>((int)v));
+}
 // (value bits, ~rank) as one signed 64-bit key: larger value first (bit patterns of non-negative floats, and of the -1 padding,
 // order as signed integers), then the smaller rank
 __device__ __forceinline__ long long fps_key(float v, unsigned rank) {
@@ -248,6 +268,8 @@ __global__ __launch_bounds__(THREADS) void fps_reg_kernel(int n, int m, int bs_s
         const float wmax = fps_wave_max(tmax);
         const unsigned wrho = ogc_wave_min_u32(tmax == wmax ? rho : 0xFFFFFFFFu);
         // cross-wave: one 64-bit LDS max per wave; key = (value bits, ~rank) so that larger value, then smaller rank wins
+        // (the wave's own winner as ONE reduction of that packed key — what fps_bucket_kernel does — is slower here: 0.455 ->
+        // 0.512 us per round at 2048 points, 1.32 -> 1.43 at 16384; max-then-arg keeps each step at one DPP instruction)
         if (lane == 0)
             atomicMax(&best_word[par], ((u64)__float_as_uint(wmax) << 32) | (u64)(0xFFFFFFFFu - wrho));
         if (t == 0) best_word[par ^ 1] = 0ull;
@@ -306,6 +328,11 @@ __device__ __forceinline__ unsigned fps_rank(int k, int bs_mask, int bs_shift, i
 // bucket goes to the 64-bit LDS maximum exactly as in fps_reg_kernel.  Values, winners and tie order are those of the
 // plain rounds (a skipped update is an update that changes nothing); tests/test_ops_gpu.py runs both against the oracle.
 // Clouds with a non-finite coordinate have no box: every bucket is updated every round.
+// 1: one reduction of a packed 64-bit key per bucket; 0: max-then-arg with 32-bit DPP steps and one readlane in between (measured,
+// 8192 -> 4096 / 8192 -> 2048 x 16: 0.691 / 0.736 us per round against 0.714 / 0.761)
+#ifndef FPS_BUCKET_PACKED_KEY
+#define FPS_BUCKET_PACKED_KEY 1
+#endif
 constexpr int FPSB_NB = 64;        // buckets
 constexpr int FPSB_SLOTS = 8192;   // points incl. padding: 64 buckets x 128
 constexpr int FPSB_KEYBITS = 12;
@@ -490,17 +517,29 @@ __global__ __launch_bounds__(WAVES *OGC_WAVE) void fps_bucket_kernel(int n, int 
     constexpr int REC0 = 48;
     const bool is_rec = lane >= REC0 && lane < REC0 + BPW;
     auto reduce_bucket = [&](int s, float t0, float t1, unsigned r0, unsigned r1) {
+#if FPS_BUCKET_PACKED_KEY
         // ONE reduction of the packed key (value bits, ~rank) over the bucket's 128 points instead of max-then-arg: six DPP
         // steps, each two moves, a 64-bit compare and two selects
         const long long k0 = fps_key(t0, r0), k1 = fps_key(t1, r1);
         const long long k = fps_max_to_last_row_i64(k0 > k1 ? k0 : k1);
+        const float wm = __int_as_float(__builtin_amdgcn_readlane((int)(k >> 32), 63));
+        const float rec_v = __int_as_float((int)(k >> 32));
+        const unsigned rec_r = 0xFFFFFFFFu - (unsigned)k;
+#else
+        // max-then-arg with every step ONE DPP instruction and a single readlane in between (the maximum has to reach all
+        // lanes for the comparison); both results arrive in the last row, where the records live
+        const int wbits = fps_max_to_last_row_i32(max(__float_as_int(t0), __float_as_int(t1)));
+        const float wm = __int_as_float(__builtin_amdgcn_readlane(wbits, 63));
+        const unsigned cand = min(t0 == wm ? r0 : 0xFFFFFFFFu, t1 == wm ? r1 : 0xFFFFFFFFu);
+        const float rec_v = wm;
+        const unsigned rec_r = fps_min_to_last_row_u32(cand);
+#endif
         int tie = 0;
-        if (track) { // a second point with the winning value?  (off the critical path: only read after the round's barrier)
-            const float wm = __int_as_float(__builtin_amdgcn_readlane((int)(k >> 32), 63));
+        if (track) { // a second point with the winning value?  (only read after the round's barrier)
             const bool h0 = t0 == wm, h1 = t1 == wm;
             tie = __popcll(__builtin_amdgcn_ballot_w64(h0 || h1)) > 1 || __builtin_amdgcn_ballot_w64(h0 && h1) != 0;
         }
-        if (lane == REC0 + s) { bmv = __int_as_float((int)(k >> 32)); bmr = 0xFFFFFFFFu - (unsigned)k; btie = tie; }
+        if (lane == REC0 + s) { bmv = rec_v; bmr = rec_r; btie = tie; }
     };
 #pragma unroll
     for (int s = 0; s < BPW; ++s) {
@@ -773,15 +812,6 @@ static int fps_impl(const char *name, int b, int n, int m, const float *xyz, flo
     const int bs = 1 << shift;
     const int slots = ((n + bs - 1) / bs) * bs; // rank slots = bs * ceil(n / bs)
     hipStream_t s = (hipStream_t)stream;
-    static const int force_threads = getenv("OGC_FPS_THREADS") ? atoi(getenv("OGC_FPS_THREADS")) : 0; // dev knob
-    if (force_threads == 1024 && slots > 1024 && slots <= 8192) {
-        if (slots <= 2048) fps_launch<2, 1024>(b, n, m, shift, xyz, temp, idx, ties_in, ties_out, s);
-        else if (slots <= 4096) fps_launch<4, 1024>(b, n, m, shift, xyz, temp, idx, ties_in, ties_out, s);
-        else fps_launch<8, 1024>(b, n, m, shift, xyz, temp, idx, ties_in, ties_out, s);
-    } else if (force_threads == 256 && slots > 2048 && slots <= 8192) {
-        if (slots <= 4096) fps_launch<16, 256>(b, n, m, shift, xyz, temp, idx, ties_in, ties_out, s);
-        else fps_launch<32, 256>(b, n, m, shift, xyz, temp, idx, ties_in, ties_out, s);
-    } else
     if (slots <= 64) fps_launch<1, 64>(b, n, m, shift, xyz, temp, idx, ties_in, ties_out, s);
     else if (slots <= 128) fps_launch<2, 64>(b, n, m, shift, xyz, temp, idx, ties_in, ties_out, s);
     else if (slots <= 256) fps_launch<4, 64>(b, n, m, shift, xyz, temp, idx, ties_in, ties_out, s);
