@@ -539,6 +539,11 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_gemm_stream_kernel
     const int tiles_per_img = hw >> 6;
     for (int mt = 0; mt < Mt; ++mt)
         ogc_stage_weight_tile<false, WG_WAVES>(a_lds + (size_t)mt * 64 * a_ld, w, mt * 64, M, K, Kq);
+    // POOL: -1 for the rows whose next scale is negative, after the other strips (16-byte aligned: every strip is)
+    float *sgn_all = a_lds + (size_t)Mt * 64 * a_ld + (PRO ? WG_WAVES * 2 * FW_KQ_MAX * 4 : 0) + WG_WAVES * 4 * 16 * 2 * 2;
+    if constexpr (POOL) {
+        for (int t = threadIdx.x; t < Mt * 64; t += WG_WAVES * OGC_WAVE) sgn_all[t] = (t < M && pool.sign[t] < 0.f) ? -1.f : 1.f;
+    }
     __syncthreads();
     const int nw = gridDim.x * WG_WAVES;
     // The loads of a tile are unconditional and of one shape (a load under a per-lane condition becomes an exec-masked block
@@ -651,40 +656,13 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_gemm_stream_kernel
                 }
             if constexpr (POOL) {
                 const int m0p = mt * 64;
-                const int seg = pool.s >> 2;                 // lanes per neighbourhood: 4, 8 or 16
                 const int centres = hw / pool.s;
                 const int centre = (p0 + 4 * j) / pool.s;    // of this lane's four positions
                 const size_t o0 = ((size_t)b * M + m0p + kk * 4) * centres + centre;
-                float *const ye = pool.yext + o0;
-                int *const ae = pool.aext + o0;
-                const bool writer = (j & (seg - 1)) == 0;
-#pragma unroll
-                for (int a = 0; a < 4; ++a) {
-                    if (EXACT || a < nblk) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int m = m0p + a * 16 + kk * 4 + r;
-                            const float sg = (m < M && pool.sign[m] < 0.f) ? -1.f : 1.f;   // exact: +-1 * v
-                            const float v0 = sg * acc[a][0][r], v1 = sg * acc[a][1][r];
-                            const float v2 = sg * acc[a][2][r], v3 = sg * acc[a][3][r];
-                            float hi = fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
-                            hi = fmaxf(hi, ogc_dpp_f32<0xB1>(hi));
-                            hi = fmaxf(hi, ogc_dpp_f32<0x4E>(hi));
-                            if (seg >= 8) hi = fmaxf(hi, ogc_dpp_f32<0x141>(hi));
-                            if (seg >= 16) hi = fmaxf(hi, ogc_dpp_f32<0x140>(hi));
-                            unsigned idx = v0 == hi ? 4 * j : (v1 == hi ? 4 * j + 1 : (v2 == hi ? 4 * j + 2 : (v3 == hi ? 4 * j + 3 : 64)));
-                            idx = min(idx, ogc_dpp_u32<0xB1>(idx));
-                            idx = min(idx, ogc_dpp_u32<0x4E>(idx));
-                            if (seg >= 8) idx = min(idx, ogc_dpp_u32<0x141>(idx));
-                            if (seg >= 16) idx = min(idx, ogc_dpp_u32<0x140>(idx));
-                            if (writer && m < M) {
-                                const int o = (a * 16 + r) * centres;
-                                ye[o] = sg * hi;
-                                ae[o] = (int)(idx & (unsigned)(pool.s - 1));   // index inside the neighbourhood
-                            }
-                        }
-                    }
-                }
+                const float *sg = sgn_all + m0p;
+                if (pool.s == 64) ogc_pool_extremes_epilogue<16>(acc, nblk, sg, j, kk, m0p, M, centres, 64, pool.yext + o0, pool.aext + o0);
+                else if (pool.s == 32) ogc_pool_extremes_epilogue<8>(acc, nblk, sg, j, kk, m0p, M, centres, 32, pool.yext + o0, pool.aext + o0);
+                else ogc_pool_extremes_epilogue<4>(acc, nblk, sg, j, kk, m0p, M, centres, 16, pool.yext + o0, pool.aext + o0);
             }
             if constexpr (STATS) {
 #pragma unroll
@@ -751,7 +729,7 @@ bool gemm_stream_launch(int b, int M, int K, int hw, const float *w, const float
     const int Kq = (K + 3) / 4, Mt = (M + 63) / 64;
     const long long ntiles = (long long)b * (hw / 64);
     const size_t lds = ((size_t)Mt * 64 * ogc_a_ld(Kq) + (PRO ? WG_WAVES * 2 * FW_KQ_MAX * 4 : 0)) * sizeof(float) +
-                       WG_WAVES * 4 * 16 * 2 * sizeof(double);
+                       WG_WAVES * 4 * 16 * 2 * sizeof(double) + (POOL ? (size_t)Mt * 64 * sizeof(float) : 0);
     if (!gemm_stream_eligible(b, M, K, hw, PRO)) return false;
     const int wgs = (int)(ntiles / WG_WAVES < 256 ? ntiles / WG_WAVES : 256);
 #define OGC_STREAM(KQV, EX)                                                                                                  \

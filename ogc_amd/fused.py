@@ -125,11 +125,11 @@ def group_norm_act_maxpool(x, gn: torch.nn.GroupNorm, relu: bool, stats=None, ex
     return group_norm_act(x, gn, relu, stats).max(dim=3)[0]
 
 
-# Neighbourhood extremes also from the streaming kernel (K > 100)?  Supported and bit-identical (tests/test_pool_extremes_gpu.py)
-# but not a gain: at one wavefront per SIMD the ~1300 VALU / DPP instructions per tile of the extremes epilogue are not hidden
-# behind another wave's MFMAs (128 -> 256 at C4: 0.33 -> 0.56 ms, against 0.14 ms for the pooling pass it saves; step
-# 12.35 vs 12.27 ms in an A/B on one GPU).
-POOL_EXTREMES_WIDE = False
+# Neighbourhood extremes also from the streaming kernel (K > 100: SA3's tail at C4).  Bit-identical
+# (tests/test_pool_extremes_gpu.py).  With the first epilogue it was a loss (128 -> 256: 0.33 -> 0.56 ms, against 0.14 ms for the
+# pooling pass it saves); with the round-3 epilogue (signs through LDS, branch-free, one-instruction DPP maxima) and the backward
+# sums taking y at the arg-max from the extremes it is a small gain: step 11.31 -> 11.28 ms (A/B, five rounds on one box).
+POOL_EXTREMES_WIDE = True
 # The backward sums of a pooled GroupNorm take x at the arg-max positions from those extremes instead of gathering it (a 32-byte
 # sector per element: 50 -> ~8 us per tail at C4).
 POOL_SUMS_FROM_EXTREMES = True
