@@ -21,7 +21,7 @@ for _ in range(N):
 pr.disable()
 torch.cuda.synchronize()
 st = pstats.Stats(pr)
-st.sort_stats("cumulative")
+st.sort_stats(sys.argv[1] if len(sys.argv) > 1 else "cumulative")
 import io
 buf = io.StringIO(); st.stream = buf; st.print_stats(70)
 out = buf.getvalue()
