@@ -367,7 +367,9 @@ class RankLoss(nn.Module):
         # fp32 products over short chunks, fp64 accumulation across chunks (an fp64 batched GEMM of this shape is ~50x
         # slower on the GPU and an fp32 sum over all N would lose digits)
         mc = m.reshape(B, N // chunk, chunk, K)
-        gram = torch.einsum('bcnk,bcnl->bckl', mc, mc).double().sum(dim=1)
+        # (bmm, not einsum('bcnk,bcnl->bckl'): the same batched product for less than half the launch-thread time)
+        m3 = mc.reshape(B * (N // chunk), chunk, K)
+        gram = torch.bmm(m3.transpose(1, 2), m3).view(B, N // chunk, K, K).double().sum(dim=1)
         sv = _sym_eigvals(gram).clamp_min(0).sqrt()
         return sv.sum(dim=1).mean().to(mask.dtype)
 
