@@ -84,6 +84,24 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(long long row_len,
 
 // grid (chunks over HW, C, B): y = act(a_c * x + b_c).  The first chunk of the first channel of a group also
 // publishes mean / rstd for the backward pass.
+// Sum of the `slots` copies of a (sum, sum of squares) accumulator, in slot order (the order every consumer must share: the
+// results are compared bit for bit), with the loads of eight slots in flight at a time instead of a load -> add chain per slot.
+__device__ __forceinline__ void gn_sum_slots(const double *__restrict__ first, size_t stride, int slots, double &sum,
+                                             double &sumsq) {
+    for (int s0 = 0; s0 < slots; s0 += 8) {
+        double2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            v[u] = *reinterpret_cast<const double2 *>(first + (size_t)min(s0 + u, slots - 1) * stride);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (s0 + u < slots) {
+                sum += v[u].x;
+                sumsq += v[u].y;
+            }
+    }
+}
+
 template <bool RELU>
 __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(int c, int hw, int groups, float eps,
                                                               const float *__restrict__ x,
@@ -98,11 +116,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(int c, int hw, int
     const int row = b * groups + g;
     const double n = (double)cg * hw;
     double sum = 0.0, sumsq = 0.0; // `slots` copies of the accumulator (1 from gn_stats_kernel, more from the fused conv)
-    for (int sl = 0; sl < slots; ++sl) {
-        const double *wsl = ws + ((size_t)sl * gridDim.z * groups + row) * 2;
-        sum += wsl[0];
-        sumsq += wsl[1];
-    }
+    gn_sum_slots(ws + (size_t)row * 2, (size_t)gridDim.z * groups * 2, slots, sum, sumsq);
     const double m = sum / n;
     const double var = fmax(sumsq / n - m * m, 0.0);
     const float mean = (float)m;
@@ -290,11 +304,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_maxpool_kernel(int c, int
     const int cg = c / groups, g = ch / cg, row = b * groups + g;
     const double n = (double)cg * p * s;
     double sum = 0.0, sumsq = 0.0;
-    for (int sl = 0; sl < slots; ++sl) {
-        const double *wsl = ws + ((size_t)sl * gridDim.z * groups + row) * 2;
-        sum += wsl[0];
-        sumsq += wsl[1];
-    }
+    gn_sum_slots(ws + (size_t)row * 2, (size_t)gridDim.z * groups * 2, slots, sum, sumsq);
     const double m = sum / n;
     const double var = fmax(sumsq / n - m * m, 0.0);
     const float mean = (float)m;
@@ -351,11 +361,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_pool_extremes_kernel(int c, int
     const int cg = c / groups, g = ch / cg, row = b * groups + g;
     const double n = (double)cg * p * s;
     double sum = 0.0, sumsq = 0.0;
-    for (int sl = 0; sl < slots; ++sl) {
-        const double *wsl = ws + ((size_t)sl * gridDim.y * groups + row) * 2;
-        sum += wsl[0];
-        sumsq += wsl[1];
-    }
+    gn_sum_slots(ws + (size_t)row * 2, (size_t)gridDim.y * groups * 2, slots, sum, sumsq);
     const double m = sum / n;
     const double var = fmax(sumsq / n - m * m, 0.0);
     const float mean = (float)m;
@@ -543,11 +549,7 @@ __global__ void gn_coeffs_kernel(int b, int c, int hw, int groups, float eps, co
     const int cg = c / groups, g = ch / cg, row = bi * groups + g;
     const double n = (double)cg * hw;
     double sum = 0.0, sumsq = 0.0;
-    for (int sl = 0; sl < slots; ++sl) {
-        const double *wsl = stats + ((size_t)sl * b * groups + row) * 2;
-        sum += wsl[0];
-        sumsq += wsl[1];
-    }
+    gn_sum_slots(stats + (size_t)row * 2, (size_t)b * groups * 2, slots, sum, sumsq);
     const double m = sum / n;
     const double var = fmax(sumsq / n - m * m, 0.0);
     const float mean = (float)m;
