@@ -23,13 +23,13 @@ class _GroupNormAct(Function):
         mean = torch.empty(B * groups, dtype=torch.float32, device=x.device)
         rstd = torch.empty_like(mean)
         if stats is not None:  # first pass already done by the producing convolution
-            nat.group_norm_fwd_stats_wrapper(B, C, hw, groups, eps, relu, x, weight.detach().contiguous(),
-                                             bias.detach().contiguous(), y, mean, rstd, stats,
+            nat.group_norm_fwd_stats_wrapper(B, C, hw, groups, eps, relu, x, weight.contiguous(),
+                                             bias.contiguous(), y, mean, rstd, stats,
                                              stats.numel() // (2 * B * groups))
         else:
             ws = _api._native.group_norm_ws(B, C, groups, False, x.device)
-            nat.group_norm_fwd_wrapper(B, C, hw, groups, eps, relu, x, weight.detach().contiguous(),
-                                       bias.detach().contiguous(), y, mean, rstd, ws)
+            nat.group_norm_fwd_wrapper(B, C, hw, groups, eps, relu, x, weight.contiguous(),
+                                       bias.contiguous(), y, mean, rstd, ws)
         ctx.save_for_backward(x, weight, bias, mean, rstd)
         ctx.cfg = (groups, relu, hw)
         return y
@@ -45,7 +45,7 @@ class _GroupNormAct(Function):
         gw = torch.empty_like(weight)
         gb = torch.empty_like(bias)
         ws = _api._native.group_norm_ws(B, C, groups, True, x.device)
-        nat.group_norm_bwd_wrapper(B, C, hw, groups, relu, x, weight.detach().contiguous(), bias.detach().contiguous(),
+        nat.group_norm_bwd_wrapper(B, C, hw, groups, relu, x, weight.contiguous(), bias.contiguous(),
                                    mean, rstd, grad_y, grad_x, gw, gb, ws)
         return grad_x, gw, gb, None, None, None, None
 
@@ -78,16 +78,16 @@ class _GroupNormActMaxPool(Function):
             # the convolution that wrote x also left the extremes of every neighbourhood: x is not read again
             yext, aext = extremes
             nat.group_norm_pool_extremes_wrapper(B, C, P, S, groups, eps, relu, yext, aext,
-                                                 weight.detach().contiguous(), bias.detach().contiguous(), out, arg,
+                                                 weight.contiguous(), bias.contiguous(), out, arg,
                                                  mean, rstd, stats, stats.numel() // (2 * B * groups))
         elif stats is not None:
-            nat.group_norm_maxpool_fwd_stats_wrapper(B, C, P, S, groups, eps, relu, x, weight.detach().contiguous(),
-                                                     bias.detach().contiguous(), out, arg, mean, rstd, stats,
+            nat.group_norm_maxpool_fwd_stats_wrapper(B, C, P, S, groups, eps, relu, x, weight.contiguous(),
+                                                     bias.contiguous(), out, arg, mean, rstd, stats,
                                                      stats.numel() // (2 * B * groups))
         else:
             ws = _api._native.group_norm_ws(B, C, groups, False, x.device)
-            nat.group_norm_maxpool_fwd_wrapper(B, C, P, S, groups, eps, relu, x, weight.detach().contiguous(),
-                                               bias.detach().contiguous(), out, arg, mean, rstd, ws)
+            nat.group_norm_maxpool_fwd_wrapper(B, C, P, S, groups, eps, relu, x, weight.contiguous(),
+                                               bias.contiguous(), out, arg, mean, rstd, ws)
         # (with the extremes at hand the backward sums need not gather x at the arg-max positions)
         yext = extremes[0] if (extremes is not None and stats is not None and POOL_SUMS_FROM_EXTREMES) else None
         ctx.save_for_backward(x, weight, mean, rstd, out, arg, yext)
@@ -106,10 +106,10 @@ class _GroupNormActMaxPool(Function):
         gb = torch.empty_like(weight)
         ws = _api._native.group_norm_ws(B, C, groups, True, x.device)
         if yext is not None and getattr(nat, "group_norm_maxpool_bwd_ext_wrapper", None) is not None:
-            nat.group_norm_maxpool_bwd_ext_wrapper(B, C, P, S, groups, relu, x, yext, weight.detach().contiguous(), mean, rstd,
+            nat.group_norm_maxpool_bwd_ext_wrapper(B, C, P, S, groups, relu, x, yext, weight.contiguous(), mean, rstd,
                                                    out, arg, grad_out.contiguous(), grad_x, gw, gb, ws)
         else:
-            nat.group_norm_maxpool_bwd_wrapper(B, C, P, S, groups, relu, x, weight.detach().contiguous(), mean, rstd, out,
+            nat.group_norm_maxpool_bwd_wrapper(B, C, P, S, groups, relu, x, weight.contiguous(), mean, rstd, out,
                                                arg, grad_out.contiguous(), grad_x, gw, gb, ws)
         return grad_x, gw, gb, None, None, None, None, None
 
@@ -190,9 +190,9 @@ class _PointwiseConv(Function):
                     and getattr(nat, "conv1x1_gemm_gnstats_wrapper", None) is not None
                     and (cin <= 100 or _stats_ok(nat, B, cout, cin, hw, False))):
                 stats = torch.empty(nat.conv1x1_gn_slots() * B * gn_groups * 2, dtype=torch.float64, device=x.device)
-                nat.conv1x1_gemm_gnstats_wrapper(B, cout, cin, hw, gn_groups, weight.detach().contiguous(), x, y, stats)
+                nat.conv1x1_gemm_gnstats_wrapper(B, cout, cin, hw, gn_groups, weight.contiguous(), x, y, stats)
             elif _plain_gemm_mine(cin):
-                nat.conv1x1_gemm_wrapper(B, cout, cin, hw, 0, weight.detach().contiguous(), x, y)
+                nat.conv1x1_gemm_wrapper(B, cout, cin, hw, 0, weight.contiguous(), x, y)
             else:
                 _weight_times_batch(weight.detach().view(cout, cin), x.reshape(B, cin, hw), out=y.view(B, cout, hw))
         else:
@@ -227,7 +227,7 @@ class _PointwiseConv(Function):
         if ctx.needs_input_grad[0]:
             if _gemm_ok(cout, hw) and _plain_gemm_mine(cout):
                 grad_x = torch.empty_like(x)
-                _api._native.conv1x1_gemm_wrapper(B, cin, cout, hw, 1, weight.detach().contiguous(), grad_y, grad_x)
+                _api._native.conv1x1_gemm_wrapper(B, cin, cout, hw, 1, weight.contiguous(), grad_y, grad_x)
             elif _gemm_ok(cout, hw):
                 grad_x = _weight_times_batch(weight.detach().view(cout, cin).t(), grad_y.reshape(B, cout, hw)).view_as(x)
             else:
@@ -365,8 +365,8 @@ class _BatchNormAct(Function):
         mean = None if lean else torch.empty(C, dtype=torch.float32, device=x.device)
         rstd = None if lean else torch.empty_like(mean)
         ws = None if (stats is not None or not training) else torch.empty(2 * C, dtype=torch.float64, device=x.device)
-        nat.batch_norm_fwd_wrapper(B, C, hw, eps, relu, training, momentum, x, weight.detach().contiguous(),
-                                   bias.detach().contiguous(), running_mean, running_var, y, mean, rstd, ws, stats,
+        nat.batch_norm_fwd_wrapper(B, C, hw, eps, relu, training, momentum, x, weight.contiguous(),
+                                   bias.contiguous(), running_mean, running_var, y, mean, rstd, ws, stats,
                                    0 if stats is None else stats.numel() // (2 * C))
         if not lean:
             ctx.save_for_backward(x, weight, bias, mean, rstd)
@@ -383,8 +383,8 @@ class _BatchNormAct(Function):
         gw = torch.empty_like(weight)
         gb = torch.empty_like(bias)
         ws = torch.empty(3 * C, dtype=torch.float64, device=x.device)
-        nat.batch_norm_bwd_wrapper(B, C, hw, relu, training, x, weight.detach().contiguous(),
-                                   bias.detach().contiguous(), mean, rstd, grad_y.contiguous(), grad_x, gw, gb, ws)
+        nat.batch_norm_bwd_wrapper(B, C, hw, relu, training, x, weight.contiguous(),
+                                   bias.contiguous(), mean, rstd, grad_y.contiguous(), grad_x, gw, gb, ws)
         return grad_x, gw, gb, None, None, None, None, None, None, None
 
 
@@ -403,8 +403,8 @@ class _BatchNormActMaxPool(Function):
         mean = None if lean else torch.empty(C, dtype=torch.float32, device=x.device)
         rstd = None if lean else torch.empty_like(mean)
         ws = None if (stats is not None or not training) else torch.empty(2 * C, dtype=torch.float64, device=x.device)
-        nat.batch_norm_maxpool_fwd_wrapper(B, C, P, S, eps, relu, training, momentum, x, weight.detach().contiguous(),
-                                           bias.detach().contiguous(), running_mean, running_var, out, arg, mean, rstd,
+        nat.batch_norm_maxpool_fwd_wrapper(B, C, P, S, eps, relu, training, momentum, x, weight.contiguous(),
+                                           bias.contiguous(), running_mean, running_var, out, arg, mean, rstd,
                                            ws, stats, 0 if stats is None else stats.numel() // (2 * C))
         if not lean:
             ctx.save_for_backward(x, weight, mean, rstd, out, arg)
@@ -421,7 +421,7 @@ class _BatchNormActMaxPool(Function):
         gw = torch.empty_like(weight)
         gb = torch.empty_like(weight)
         ws = torch.empty(3 * C, dtype=torch.float64, device=x.device)
-        nat.batch_norm_maxpool_bwd_wrapper(B, C, P, S, relu, training, x, weight.detach().contiguous(), mean, rstd, out,
+        nat.batch_norm_maxpool_bwd_wrapper(B, C, P, S, relu, training, x, weight.contiguous(), mean, rstd, out,
                                            arg, grad_out.contiguous(), grad_x, gw, gb, ws)
         return grad_x, gw, gb, None, None, None, None, None, None, None
 
@@ -668,7 +668,7 @@ def _norm_act_conv_forward(y_prev, stats_prev, gn_weight, gn_bias, conv_weight, 
     rstd = torch.empty_like(mean)
     a = torch.empty(B * cin, dtype=torch.float32, device=dev)
     bb = torch.empty_like(a)
-    gamma, beta = gn_weight.detach().contiguous(), gn_bias.detach().contiguous()
+    gamma, beta = gn_weight.contiguous(), gn_bias.contiguous()
     if stats_prev is not None:
         nat.group_norm_coeffs_wrapper(B, cin, hw, gn_groups, eps, None, gamma, beta, stats_prev,
                                       stats_prev.numel() // (2 * B * gn_groups), None, mean, rstd, a, bb)
@@ -676,7 +676,7 @@ def _norm_act_conv_forward(y_prev, stats_prev, gn_weight, gn_bias, conv_weight, 
         ws = nat.group_norm_ws(B, cin, gn_groups, False, dev)
         nat.group_norm_coeffs_wrapper(B, cin, hw, gn_groups, eps, y_prev, gamma, beta, None, 0, ws, mean, rstd, a, bb)
     y = torch.empty((B, cout) + tuple(y_prev.shape[2:]), dtype=torch.float32, device=dev)
-    w = conv_weight.detach().contiguous()
+    w = conv_weight.contiguous()
     stats = extremes = None
     if (next_groups > 0 and next_groups <= 32 and cout % next_groups == 0 and (cout // next_groups) % 4 == 0
             and (cin <= 100 or _stats_ok(nat, B, cout, cin, hw, True))):
@@ -688,7 +688,7 @@ def _norm_act_conv_forward(y_prev, stats_prev, gn_weight, gn_bias, conv_weight, 
             yext = torch.empty(B, cout, centres, dtype=torch.float32, device=dev)
             aext = torch.empty(B, cout, centres, dtype=torch.int32, device=dev)
             nat.conv1x1_gemm_affine_pool_wrapper(B, cout, cin, hw, relu, next_groups, pool, w, y_prev, a, bb,
-                                                 next_gamma.detach().contiguous(), y, stats, yext, aext)
+                                                 next_gamma.contiguous(), y, stats, yext, aext)
             extremes = (yext, aext)
         else:
             nat.conv1x1_gemm_affine_wrapper(B, cout, cin, hw, relu, next_groups, w, y_prev, a, bb, y, stats)
@@ -731,7 +731,7 @@ class _NormActConv(Function):
         B, cin = y_prev.shape[0], y_prev.shape[1]
         cout = conv_weight.shape[0]
         grad_y = grad_y.contiguous()
-        w = conv_weight.detach().contiguous()
+        w = conv_weight.contiguous()
         grad_w = torch.empty(cout, cin, dtype=torch.float32, device=y_prev.device)
         # (up to 64 channels: from 128 on the second accumulator set makes the weight-gradient kernel MFMA-bound and the
         # whole path slower than the separate passes — tools/gn_bwd_compare.py)
@@ -748,7 +748,7 @@ class _NormActConv(Function):
             ggb = torch.empty(2, cin, dtype=torch.float32, device=dev)
             gw, gb = ggb[0], ggb[1]
             nat.gn_moments_combine_wrapper(B, cin, cout, hw, gn_groups, moments, w.view(cout, cin), a, bb, mean, rstd,
-                                           gn_weight.detach().contiguous(), grad_w, coef, gw, gb)
+                                           gn_weight.contiguous(), grad_w, coef, gw, gb)
             grad_prev = torch.empty_like(y_prev)
             nat.conv1x1_dgrad_adjoint_wrapper(B, cin, cout, hw, relu, w.view(cout, cin), grad_y, y_prev, a, bb, coef, grad_prev)
             return grad_prev, None, gw, gb, grad_w.view_as(conv_weight), None, None, None, None, None, None
@@ -762,8 +762,8 @@ class _NormActConv(Function):
         grad_prev = torch.empty_like(y_prev)
         gw, gb = torch.empty_like(gn_weight), torch.empty_like(gn_bias)
         ws = nat.group_norm_ws(B, cin, gn_groups, True, y_prev.device)
-        nat.group_norm_bwd_wrapper(B, cin, hw, gn_groups, relu, y_prev, gn_weight.detach().contiguous(),
-                                   gn_bias.detach().contiguous(), mean, rstd, grad_z, grad_prev, gw, gb, ws)
+        nat.group_norm_bwd_wrapper(B, cin, hw, gn_groups, relu, y_prev, gn_weight.contiguous(),
+                                   gn_bias.contiguous(), mean, rstd, grad_z, grad_prev, gw, gb, ws)
         return grad_prev, None, gw, gb, grad_w.view_as(conv_weight), None, None, None, None, None, None
 
 
@@ -822,7 +822,7 @@ class _NormActConvPool(Function):
         arg = torch.empty(B, cout, P, dtype=torch.int32, device=dev)
         mean2 = torch.empty(B * groups2, dtype=torch.float32, device=dev)
         rstd2 = torch.empty_like(mean2)
-        g2, b2 = gn2_weight.detach().contiguous(), gn2_bias.detach().contiguous()
+        g2, b2 = gn2_weight.contiguous(), gn2_bias.contiguous()
         nat.group_norm_pool_extremes_wrapper(B, cout, P, S, groups2, eps2, relu2, extremes[0], extremes[1], g2, b2, out, arg,
                                              mean2, rstd2, stats, stats.numel() // (2 * B * groups2))
         ctx.save_for_backward(y_prev, gn_weight, gn_bias, conv_weight, mean, rstd, a, bb, y, gn2_weight, mean2, rstd2, out, arg,
@@ -843,11 +843,11 @@ class _NormActConvPool(Function):
         inj = torch.empty(B, cout, P, 2, dtype=torch.float32, device=dev)
         gw2, gb2 = torch.empty_like(gn2_weight), torch.empty_like(gn2_weight)
         ws = nat.group_norm_ws(B, cout, groups2, True, dev)
-        nat.group_norm_maxpool_bwd_sparse_wrapper(B, cout, P, S, groups2, relu2, y, gn2_weight.detach().contiguous(), mean2,
+        nat.group_norm_maxpool_bwd_sparse_wrapper(B, cout, P, S, groups2, relu2, y, gn2_weight.contiguous(), mean2,
                                                   rstd2, out, arg, grad_out.contiguous(), coef2, inj, gw2, gb2, ws,
                                                   yext if POOL_SUMS_FROM_EXTREMES else None)
         # the convolution's backward (as _NormActConv.backward's moment-matrix path) on that form
-        w = conv_weight.detach().contiguous().view(cout, cin)
+        w = conv_weight.contiguous().view(cout, cin)
         moments = torch.empty(B, 2, cout, cin, dtype=torch.float32, device=dev)
         nat.conv1x1_wgrad_moments_pooled_wrapper(B, cin, cout, hw, relu, S, y_prev, a, bb, y, coef2, inj, moments)
         coef = torch.empty(B, cin, 3, dtype=torch.float32, device=dev)
@@ -855,7 +855,7 @@ class _NormActConvPool(Function):
         gw, gb = ggb[0], ggb[1]
         grad_w = torch.empty(cout, cin, dtype=torch.float32, device=dev)
         nat.gn_moments_combine_wrapper(B, cin, cout, hw, gn_groups, moments, w, a, bb, mean, rstd,
-                                       gn_weight.detach().contiguous(), grad_w, coef, gw, gb)
+                                       gn_weight.contiguous(), grad_w, coef, gw, gb)
         grad_prev = torch.empty_like(y_prev)
         nat.conv1x1_dgrad_adjoint_pooled_wrapper(B, cin, cout, hw, relu, S, w, y, coef2, inj, y_prev, a, bb, coef, grad_prev)
         return (grad_prev, None, gw, gb, grad_w.view_as(conv_weight), None, None, None, gw2, gb2, None, None, None)
