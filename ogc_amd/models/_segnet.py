@@ -134,13 +134,12 @@ class MaskFormer3DBase(nn.Module):
         branch.train()
         sample = (torch.randn_like(coarse_feats).requires_grad_(True), coarse_pc.detach().clone())
         try:
-            graphed = torch.cuda.make_graphed_callables(branch, sample)
-            # (the capture's warm-up ran on a stream of its own, which is where autograd now expects these parameters'
+            # (the capture's warm-up runs on a stream of its own, which is where autograd then expects these parameters'
             # gradients to be accumulated; it synchronises the streams itself and says so once per process — not news here)
             quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
             if quiet is not None:
                 quiet(False)
-            return graphed
+            return torch.cuda.make_graphed_callables(branch, sample)
         except Exception as err:  # a capture that does not work on this stack must not take training down with it
             import warnings
             warnings.warn("slot branch not captured as a HIP graph (%s): running it eagerly" % (str(err)[:200],))
