@@ -1,5 +1,7 @@
 """Shared implementation of the three ``MaskFormer3D`` variants (reference: models/segnet_kitti.py,
 models/segnet_sapien.py, models/segnet_ogcdr.py — they differ only in the encoder/decoder table)."""
+import weakref
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -122,10 +124,21 @@ class MaskFormer3DBase(nn.Module):
             if made is None or made[0] != key:
                 made = (key, self._graph_slots(coarse_feats, coarse_pc))
                 self.__dict__["_slot_graph"] = made
-            if made[1] is not None:
-                return made[1](coarse_feats, coarse_pc)
+            if made[1] is not None and not self._slot_graph_busy():
+                out = made[1](coarse_feats, coarse_pc)
+                # the graphs work on STATIC buffers: a second forward pass before this one's backward pass (two clouds
+                # through the net, then one loss) would overwrite what that backward pass needs — such a call runs eagerly
+                done = [False]
+                out.register_hook(lambda g, d=done: d.__setitem__(0, True))
+                self.__dict__["_slot_graph_last"] = (weakref.ref(out), done)
+                return out
         slot = self.MF_head(coarse_feats.transpose(1, 2), coarse_pc)      # (B, K, D)
         return self.object_mlp(slot.transpose(1, 2))                      # (B, 64, K)
+
+    def _slot_graph_busy(self):
+        """Is the output of the last graphed call still alive with its backward pass not yet run?"""
+        last = self.__dict__.get("_slot_graph_last")
+        return last is not None and last[0]() is not None and not last[1][0]
 
     def _graph_slots(self, coarse_feats, coarse_pc):
         branch = _SlotBranch(self.MF_head, self.object_mlp)

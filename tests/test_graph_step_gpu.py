@@ -52,3 +52,36 @@ def test_graphed_step_matches_eager():
     num = sum(float((a - b.detach()).abs().sum()) for a, b in zip(w_eager, net.parameters()))
     den = sum(float((a - b).abs().sum()) for a, b in zip(w_eager, w0))
     assert num <= 0.05 * den, (num, den)
+
+
+@pytest.mark.gpu
+def test_graphed_slot_branch_is_reentrant_safe():
+    """The slot branch runs as a pair of HIP graphs on static buffers (MaskFormer3DBase._slots): same gradients as the eager
+    branch, and a SECOND forward pass before the first one's backward pass (two clouds through the net, one loss) must not
+    disturb the first."""
+    import ogc_amd  # noqa: F401
+    from ogc_amd.models.segnet_kitti import MaskFormer3D
+    torch.manual_seed(5)
+    net = MaskFormer3D(n_slot=6, n_point=1024, use_xyz=True, n_transformer_layer=1, transformer_embed_dim=64,
+                       transformer_input_pos_enc=False).cuda().train()
+    pcs = [torch.rand(2, 1024, 3, device="cuda") * torch.tensor([30.0, 3.0, 40.0], device="cuda") for _ in range(2)]
+    probes = [torch.randn(2, 1024, 6, device="cuda") for _ in range(2)]
+
+    def grads(graphed, both):
+        net.graph_slot_branch = graphed
+        net.__dict__.pop("_slot_graph_last", None)
+        net.zero_grad(set_to_none=True)
+        outs = [net(p, p) for p in (pcs if both else pcs[:1])]
+        sum((o * q).sum() for o, q in zip(outs, probes)).backward()
+        return [o.detach().clone() for o in outs], [p.grad.clone() for p in net.parameters()]
+
+    try:
+        ref_o, ref_g = grads(False, True)
+        for _ in range(2):                       # twice: the second round replays the graphs made by the first
+            got_o, got_g = grads(True, True)
+            for a, b in zip(got_o + got_g, ref_o + ref_g):
+                # (not bit for bit: the weight-gradient kernels add their partial sums with float atomics)
+                assert float((a - b).norm() / b.norm().clamp_min(1e-30)) < 2e-5, float((a - b).abs().max())
+        assert net.__dict__.get("_slot_graph") is not None and net.__dict__["_slot_graph"][1] is not None
+    finally:
+        net.graph_slot_branch = True
