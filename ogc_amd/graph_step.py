@@ -87,9 +87,9 @@ class GraphedTrainStep:
         assert first_batch[0].is_cuda, "GraphedTrainStep needs the batch on the GPU"
         assert optimizer.defaults.get("capturable"), "build the optimizer with capturable=True (make_optimizer)"
         self.segnet, self.criterion, self.optimizer, self.aug = segnet, criterion, optimizer, aug_transform
-        for m in segnet.modules():  # the whole step becomes one graph: no graphs of its own for the slot branch (its eager
-            if hasattr(m, "graph_slot_branch"):  # warm-up would otherwise make them, and move the gradient accumulation
-                m.graph_slot_branch = False      # of those parameters onto another stream)
+        from .utils import subgraph
+        subgraph.forbid(segnet)  # the whole step becomes one graph: no graphs of their own for its parts (the eager warm-up
+        #                          would otherwise make them, and move those parameters' gradient accumulation to another stream)
         self.cur = tuple(t.clone() if torch.is_tensor(t) else t for t in first_batch)
         self.stream = torch.cuda.Stream()
         self.graph, self.pending, self.plan = None, None, None

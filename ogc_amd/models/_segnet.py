@@ -1,31 +1,16 @@
 """Shared implementation of the three ``MaskFormer3D`` variants (reference: models/segnet_kitti.py,
 models/segnet_sapien.py, models/segnet_ogcdr.py — they differ only in the encoder/decoder table)."""
-import weakref
-
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import fused
+from ..utils import subgraph
 from ..utils.nn_util import Seq
 from ..utils.pointnet2_util import PointnetFPModule, PointnetSAModule, PointnetSAModuleMSG
 from ..utils.transformer_util import MaskFormerHead
 
 BN_CONFIG = {"class": "GroupNorm", "num_groups": 4}
-
-
-class _SlotBranch(nn.Module):
-    """MaskFormer head + object MLP as a module of their own, for torch.cuda.make_graphed_callables (which takes a module's
-    parameters as graph inputs).  Holds the parent's sub-modules; never registered as the parent's child (no second copy of the
-    parameters in its state_dict)."""
-
-    def __init__(self, head, mlp):
-        super().__init__()
-        self.head, self.mlp = head, mlp
-
-    def forward(self, coarse_feats, coarse_pc):
-        slot = self.head(coarse_feats.transpose(1, 2), coarse_pc)         # (B, K, D)
-        return self.mlp(slot.transpose(1, 2))                             # (B, 64, K)
 
 
 class MaskFormer3DBase(nn.Module):
@@ -107,56 +92,18 @@ class MaskFormer3DBase(nn.Module):
 
     # The slot branch is ~45 launches forwards and ~115 backwards on (B, K, E) tensors, each a few microseconds of GPU time and
     # ~15 of launch-thread time — 2 ms of the ~11 ms of Python a C4 step costs, on a thread that is level with the GPU.  In
-    # training it therefore runs as a pair of HIP graphs (forward, backward) made by torch.cuda.make_graphed_callables the first
-    # time a shape is seen: one launch each way, the same kernels in the same order.  Eager when evaluating, when gradients are
-    # off, inside an enclosing capture (graph_step.py), with parameters that do not require a gradient, or under a process group
-    # whose wrapper is not utils/dist_util.FlatDataParallel (DistributedDataParallel's gradient hooks and a captured backward
-    # pass crashed a rank in tests/test_ddp_gpu.py).
+    # training it therefore runs as a pair of HIP graphs (utils/subgraph.py): one launch each way, the same kernels in the same
+    # order.
     graph_slot_branch = True
 
-    def _slots(self, coarse_feats, coarse_pc):
-        if (self.graph_slot_branch and self.training and torch.is_grad_enabled() and coarse_feats.is_cuda
-                and coarse_feats.requires_grad and not torch.cuda.is_current_stream_capturing()
-                and (not (torch.distributed.is_available() and torch.distributed.is_initialized())
-                     or self.__dict__.get("_graphs_allowed_under_dp", False))):
-            key = (tuple(coarse_feats.shape), tuple(coarse_pc.shape), coarse_feats.dtype)
-            made = self.__dict__.get("_slot_graph")
-            if made is None or made[0] != key:
-                made = (key, self._graph_slots(coarse_feats, coarse_pc))
-                self.__dict__["_slot_graph"] = made
-            if made[1] is not None and not self._slot_graph_busy():
-                out = made[1](coarse_feats, coarse_pc)
-                # the graphs work on STATIC buffers: a second forward pass before this one's backward pass (two clouds
-                # through the net, then one loss) would overwrite what that backward pass needs — such a call runs eagerly
-                done = [False]
-                out.register_hook(lambda g, d=done: d.__setitem__(0, True))
-                self.__dict__["_slot_graph_last"] = (weakref.ref(out), done)
-                return out
+    def _slots_eager(self, coarse_feats, coarse_pc):
         slot = self.MF_head(coarse_feats.transpose(1, 2), coarse_pc)      # (B, K, D)
         return self.object_mlp(slot.transpose(1, 2))                      # (B, 64, K)
 
-    def _slot_graph_busy(self):
-        """Is the output of the last graphed call still alive with its backward pass not yet run?"""
-        last = self.__dict__.get("_slot_graph_last")
-        return last is not None and last[0]() is not None and not last[1][0]
-
-    def _graph_slots(self, coarse_feats, coarse_pc):
-        branch = _SlotBranch(self.MF_head, self.object_mlp)
-        if not all(p.requires_grad for p in branch.parameters()):
-            return None
-        branch.train()
-        sample = (torch.randn_like(coarse_feats).requires_grad_(True), coarse_pc.detach().clone())
-        try:
-            # (the capture's warm-up runs on a stream of its own, which is where autograd then expects these parameters'
-            # gradients to be accumulated; it synchronises the streams itself and says so once per process — not news here)
-            quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
-            if quiet is not None:
-                quiet(False)
-            return torch.cuda.make_graphed_callables(branch, sample)
-        except Exception as err:  # a capture that does not work on this stack must not take training down with it
-            import warnings
-            warnings.warn("slot branch not captured as a HIP graph (%s): running it eagerly" % (str(err)[:200],))
-            return None
+    def _slots(self, coarse_feats, coarse_pc):
+        if self.graph_slot_branch and coarse_feats.requires_grad:
+            return subgraph.run(self, "slots", self._slots_eager, (coarse_feats, coarse_pc), parts=(self.MF_head, self.object_mlp))
+        return self._slots_eager(coarse_feats, coarse_pc)
 
     def forward(self, pc, point_feats, geometry=None):
         # pc (B, N, 3), point_feats (B, N, 3) -> mask (B, N, K);  geometry: plan_geometry_async(pc) made earlier

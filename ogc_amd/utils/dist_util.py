@@ -30,9 +30,8 @@ class FlatDataParallel(nn.Module):
         self.world_size = dist.get_world_size(process_group)
         self._params = [p for p in module.parameters() if p.requires_grad]
         self._events = None   # [(start, end)] around every collective when time_collectives() was called
-        for m in module.modules():  # this wrapper puts no hooks on the parameters: sub-graphs of the forward pass stay allowed
-            if hasattr(m, "graph_slot_branch"):
-                m.__dict__["_graphs_allowed_under_dp"] = True
+        from . import subgraph
+        subgraph.allow_under_data_parallel(module)  # this wrapper puts no hooks on the parameters
         if broadcast and self.world_size > 1:
             self._broadcast([p.data for p in module.parameters()])
             bufs = [b.data for b in module.buffers() if b.is_floating_point()]
