@@ -1,4 +1,4 @@
-"""A/B of one module-level switch of ogc_amd.fused on the bench step, alternating in ONE process on one GPU:
+"""A/B of one module-level switch (NAME of ogc_amd.fused, or package.module:NAME) on the bench step, alternating in ONE process on one GPU:
     python tools/step_ab.py SPARSE_POOL_BACKWARD [rounds [value_a value_b]]
 prints ms per step with the switch at value_a (True) / value_b (False) for every round (20 timed steps each, a fresh process
 per measurement)."""
@@ -11,8 +11,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CODE = """
 import sys, runpy
 sys.argv = ['bench.py', '--steps', '20', '--warmup', '5']
-import ogc_amd.fused as f
-setattr(f, %r, %s)
+import importlib
+_mod, _, _name = %r.rpartition(":")
+setattr(importlib.import_module(_mod or "ogc_amd.fused"), _name, %s)
 runpy.run_path('bench.py', run_name='__main__')
 """
 
