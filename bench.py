@@ -31,18 +31,18 @@ FP32_MFMA_PEAK_TF = 157.3  # v_mfma_f32_16x16x4_f32 / 32x32x2_f32: the fp32 matr
 # Numbers NOT measured by this run: PMC counter readings of earlier profiling passes, kept with the file they came from.
 # (rocprofv3 --pmc cannot run inside the timed region; `roofline.traffic` is the one field the contract asks for.)
 OFFLINE = {
-    "ball_query_traffic_bytes": {"shape": [16, 8192, 8192, 64], "bytes": int((8911.0 + 863.0 + 32768 + 2199.5) * 1024),
+    "ball_query_traffic_bytes": {"shape": [16, 8192, 8192, 64], "bytes": int((8910.0 + 863.0 + 32768 + 2199.5) * 1024),
                                  "source": "profiles/r03_ball_query_pmc.txt (FETCH_SIZE + WRITE_SIZE of grid_build_kernel + "
                                            "ball_query_cells_kernel<64>, separate rocprofv3 --pmc passes; FETCH_SIZE as reported — "
                                            "these kernels issue 12-16 byte gathers, not the wide streams the x2 gfx950 "
                                            "correction applies to)"},
     "ball_query_valu_issue": {"kernel": "ball_query_cells_kernel<64>", "wave_insts_valu": 8.58e6, "wave_insts_salu": 1.44e6,
-                              "kernel_us": 21.69, "peak_ginst_s": 614.4, "frac_of_issue_peak": round(8.58e6 / 21.69e-6 / 614.4e9, 3),
+                              "kernel_us": 21.60, "peak_ginst_s": 614.4, "frac_of_issue_peak": round(8.58e6 / 21.60e-6 / 614.4e9, 3),
                               "general_kernel": {"kernel": "ball_query_grid_kernel", "wave_insts_valu": 12.84e6, "kernel_us": 29.6,
                                                  "source": "profiles/r02_ball_query_pmc.txt"},
                               "source": "profiles/r03_ball_query_pmc.txt"},
     "knn_clamped_valu_issue": {"kernel": "knn_cells_kernel<32> + knn_grid_kernel<1> (deferred)", "source": "profiles/r03_knn_clamped_pmc.txt"},
-    "step_traffic_mib": {"fetch_reported": 12701.4, "write": 9535.8,
+    "step_traffic_mib": {"fetch_reported": 12712.6, "write": 9538.6,
                          "source": "profiles/r03_step_hbm_traffic.txt (per-kernel FETCH_SIZE / WRITE_SIZE table of one round-3 C4 step, "
                                    "mean of whole timed steps; the estimate doubles the reported fetch: MI355X_MICROARCH.md)"},
 }
