@@ -171,6 +171,19 @@ int ogc_ball_query_cells(int b, int n, float radius, int nsample, const float *x
 int ogc_knn_clamped_cells(int b, int n, int k, float radius, const float *xyz, void *grid, float grid_radius, float *dist, int *idx,
                           ogc_stream_t stream);
 
+/* The NaN rule and the Adam update of a training step (train_seg.py:81-83 + torch.optim.Adam.step(), train_seg.py:320) as two
+ * launches over a chunk table, on torch's own state tensors (ogc_amd/csrc/adam.hip; fp32 parameters).
+ *   table  (device, int64, 5 x n_tensors): pointers of the parameters, exp_avg, exp_avg_sq, step counts (0-dim fp32 tensors),
+ *          then the element counts;  chunks (device, int32, n_chunks x 2): (tensor, first element) of every
+ *          ogc_adam_chunk()-element piece;  grad_ptrs: HOST array of the n_tensors gradient pointers (<= ogc_adam_max_tensors());
+ *   flag   (device, int32, zero on entry): 1 afterwards when a gradient held a NaN — the update and the step counts are then
+ *          skipped on the device;  step_snapshot: n_tensors floats of scratch. */
+int ogc_adam_max_tensors(void);
+int ogc_adam_chunk(void);
+int ogc_adam_step(int n_tensors, int n_chunks, const long long *table, const int *chunks, const void *const *grad_ptrs,
+                  float *step_snapshot, int *flag, float lr, float beta1, float beta2, float eps, float weight_decay,
+                  ogc_stream_t stream);
+
 /* Batched 3x3 Kabsch rotation.  Replaces torch.svd + the reflection fix of the weighted-Kabsch fit
  *   losses/seg_loss_unsup.py:44-53:  u,s,v = svd(S); R = v diag(1,1,det(v u^T)) u^T.
  * S (nb,3,3) f32 cross-covariances (P_c^T diag(w) Q_c), R (nb,3,3) f32 out; valid (nb) i32 out or NULL:

@@ -63,6 +63,74 @@ def make_optimizer(params, lr, weight_decay=0.0, capturable=False):
     return torch.optim.Adam(params, lr=lr, weight_decay=weight_decay, fused=fused, capturable=bool(capturable and fused))
 
 
+ADAM_KERNEL = True   # the NaN rule + the Adam update as two launches of this library (csrc/adam.hip); False: torch's fused step
+
+
+def _adam_kernel_step(optimizer):
+    """The reference's NaN-gradient rule and optimizer.step() of a torch.optim.Adam (one parameter group, fp32 parameters on one
+    GPU, L2 weight decay, no amsgrad) as ogc_adam_step: two launches over a chunk table instead of the eleven of
+    _foreach_norm / stack / sum / isnan / _foreach_add_ / 3 x multi_tensor_apply / _foreach_sub_ (0.3 ms of a C4 step's main
+    queue, 0.5 ms of its launch thread).  Works on the tensors of optimizer.state (exp_avg, exp_avg_sq, step), so state_dict() /
+    load_state_dict() are unaffected.  Returns the flag (int32, 1 where a gradient held a NaN and the step was skipped on the
+    device), or None when the optimizer is not in the configuration this covers (the caller then takes the torch path)."""
+    import ctypes
+    from . import _lib
+    if not ADAM_KERNEL or type(optimizer) is not torch.optim.Adam or len(optimizer.param_groups) != 1:
+        return None
+    group = optimizer.param_groups[0]
+    cache = getattr(optimizer, "_ogc_adam_tables", None)
+    if cache is not None:  # load_state_dict() replaces the group dictionaries and the state tensors; .to() the parameters
+        params = cache["params"]
+        if (cache["group"] is not group or len(group["params"]) != len(params) or params[0].data_ptr() != cache["first_ptr"]
+                or optimizer.state[params[0]].get("step") is not cache["first_step"]):
+            cache = None
+    if cache is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None  # (the tables are uploaded with host-to-device copies: not inside a capture)
+        if (group.get("amsgrad") or group.get("maximize") or group.get("differentiable") or group.get("decoupled_weight_decay")
+                or isinstance(group["lr"], torch.Tensor)):
+            return None
+        params = list(group["params"])
+        L = _lib.load()
+        if not params or len(params) > L.ogc_adam_max_tensors():
+            return None
+        states = [optimizer.state.get(p) for p in params]
+        if any(not st or "exp_avg" not in st or not torch.is_tensor(st.get("step")) for st in states):
+            return None  # first step: torch builds the state
+        dev = params[0].device
+        tensors = [[p for p in params], [st["exp_avg"] for st in states], [st["exp_avg_sq"] for st in states],
+                   [st["step"] for st in states]]
+        ok = (dev.type == "cuda" and all(t.device == dev and t.dtype == torch.float32 and t.is_contiguous()
+                                          for row in tensors for t in row)
+              and all(st["step"].numel() == 1 for st in states))
+        if not ok:
+            return None
+        chunk = L.ogc_adam_chunk()
+        rows = [[t.data_ptr() for t in row] for row in tensors] + [[p.numel() for p in params]]
+        pieces = [(i, off) for i, p in enumerate(params) for off in range(0, p.numel(), chunk)]
+        cache = {"group": group, "params": params, "first_ptr": params[0].data_ptr(), "first_step": states[0]["step"],
+                 "table": torch.tensor(rows, dtype=torch.int64, device=dev),
+                 "chunks": torch.tensor(pieces, dtype=torch.int32, device=dev), "n_chunks": len(pieces),
+                 "snapshot": torch.empty(len(params), dtype=torch.float32, device=dev),
+                 "array": ctypes.c_void_p * len(params)}
+        optimizer._ogc_adam_tables = cache
+    params = cache["params"]
+    ptrs = []
+    for p in params:
+        g = p.grad
+        if g is None or g.dtype != torch.float32 or g.device != p.device or not g.is_contiguous() or g.shape != p.shape:
+            return None  # parameters without a (plain) gradient this step: torch's own filtering
+        ptrs.append(g.data_ptr())
+    flag = torch.zeros(1, dtype=torch.int32, device=params[0].device)
+    beta1, beta2 = group["betas"]
+    _lib.call("ogc_adam_step", len(params), cache["n_chunks"], cache["table"].data_ptr(), cache["chunks"].data_ptr(),
+              cache["array"](*ptrs), cache["snapshot"].data_ptr(), flag.data_ptr(), float(group["lr"]), float(beta1),
+              float(beta2), float(group["eps"]), float(group["weight_decay"]),
+              torch.cuda.current_stream(params[0].device).cuda_stream)
+    optimizer._opt_called = True  # (what torch's LR schedulers look at to warn about the call order)
+    return flag
+
+
 def _fused_adam_step(optimizer, found_inf):
     """optimizer.step() of a fused torch.optim.Adam without its per-parameter Python — state lookup, list building and device
     grouping for ~190 parameters cost the launch thread 0.9 ms per step, and at C4 that thread is level with the GPU.  The same
@@ -243,9 +311,14 @@ def train_step(segnet, criterion, optimizer, batch, it, aug_transform, sync=True
         pending.prefetched = upcoming
         return pending.result() if sync else pending
     _average_gradients(segnet)
+    # under DDP the all-reduced gradients make the NaN decision identical on all ranks
+    flag = _adam_kernel_step(optimizer) if on_gpu else None
+    if flag is not None:
+        pending = PendingStep(losses, HostScalars(flag))
+        pending.prefetched = upcoming
+        return pending.result() if sync else pending
     grads = [p.grad for p in segnet.parameters() if p.grad is not None]
     bad = torch.isnan(torch.stack(torch._foreach_norm(grads)).sum())  # NaN anywhere -> NaN norm
-    # under DDP the all-reduced gradients make this decision identical on all ranks
     if getattr(optimizer, "_step_supports_amp_scaling", False) and bad.is_cuda:
         _step_with_flag(optimizer, bad)
         pending = PendingStep(losses, HostScalars(bad.reshape(1)))
@@ -285,6 +358,9 @@ def _nan_safe_step(params, optimizer):
     """The reference's NaN-gradient rule (train_seg.py:81-83, train_flow.py:84-86) without a host round trip when the
     optimizer is fused; returns a HostScalars holding the 'skipped' flag."""
     from .utils.streams import HostScalars
+    flag = _adam_kernel_step(optimizer)
+    if flag is not None:
+        return HostScalars(flag)
     grads = [p.grad for p in params if p.grad is not None]
     bad = torch.isnan(torch.stack(torch._foreach_norm(grads)).sum())  # NaN anywhere -> NaN norm
     if getattr(optimizer, "_step_supports_amp_scaling", False) and bad.is_cuda:
