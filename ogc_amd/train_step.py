@@ -78,6 +78,8 @@ def _adam_kernel_step(optimizer):
     if not ADAM_KERNEL or type(optimizer) is not torch.optim.Adam or len(optimizer.param_groups) != 1:
         return None
     group = optimizer.param_groups[0]
+    if not group["params"] or not group["params"][0].is_cuda:
+        return None
     cache = getattr(optimizer, "_ogc_adam_tables", None)
     if cache is not None:  # load_state_dict() replaces the group dictionaries and the state tensors; .to() the parameters
         params = cache["params"]
