@@ -53,11 +53,13 @@ def step(record=None):
     loss.backward()
     mark()
     mark()
-    grads = [p.grad for p in net.parameters() if p.grad is not None]
-    bad = torch.isnan(torch.stack(torch._foreach_norm(grads)).sum())
-    opt.grad_scale = None; opt.found_inf = bad.float().reshape(())
-    opt.step()
-    del opt.grad_scale, opt.found_inf
+    from ogc_amd.train_step import _adam_kernel_step
+    if _adam_kernel_step(opt) is None:  # (the first step: torch builds the optimizer's state)
+        grads = [p.grad for p in net.parameters() if p.grad is not None]
+        bad = torch.isnan(torch.stack(torch._foreach_norm(grads)).sum())
+        opt.grad_scale = None; opt.found_inf = bad.float().reshape(())
+        opt.step()
+        del opt.grad_scale, opt.found_inf
     mark()
     if record is not None:
         record.append(marks)
