@@ -342,7 +342,7 @@ int bn_prepare(const char *name, int b, int c, int hw, float eps, int training, 
                int slots, hipStream_t s) {
     if (training && !stats) {
         OGC_REQUIRE(ws, "%s: null workspace", name);
-        if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * c, s) != hipSuccess) {
+        if (ogc_zero_async(ws, sizeof(double) * 2 * c, s) != hipSuccess) {
             ogc_set_error("%s: memset failed", name);
             return OGC_ERR_LAUNCH;
         }
@@ -402,7 +402,7 @@ extern "C" int ogc_batch_norm_bwd(int b, int c, int hw, int relu, int training, 
     hipStream_t s = (hipStream_t)stream;
     double *dsdb = ws; // [c][2] fp64, then c2c3 [c][2] fp32
     float *c2c3 = reinterpret_cast<float *>(ws + (size_t)2 * c);
-    if (hipMemsetAsync(dsdb, 0, sizeof(double) * 2 * c, s) != hipSuccess) {
+    if (ogc_zero_async(dsdb, sizeof(double) * 2 * c, s) != hipSuccess) {
         ogc_set_error("ogc_batch_norm_bwd: memset failed");
         return OGC_ERR_LAUNCH;
     }
@@ -481,7 +481,7 @@ extern "C" int ogc_batch_norm_maxpool_bwd(int b, int c, int p, int s, int relu, 
     hipStream_t st = (hipStream_t)stream;
     double *dsdb = ws;
     float *c2c3 = reinterpret_cast<float *>(ws + (size_t)2 * c);
-    if (hipMemsetAsync(dsdb, 0, sizeof(double) * 2 * c, st) != hipSuccess) {
+    if (ogc_zero_async(dsdb, sizeof(double) * 2 * c, st) != hipSuccess) {
         ogc_set_error("ogc_batch_norm_maxpool_bwd: memset failed");
         return OGC_ERR_LAUNCH;
     }

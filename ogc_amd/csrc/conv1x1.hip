@@ -846,7 +846,7 @@ extern "C" int ogc_conv1x1_gemm_gnstats(int b, int M, int K, int hw, int groups,
         return OGC_ERR_UNSUPPORTED;
     }
     if (b == 0) return OGC_OK;
-    if (hipMemsetAsync(stats, 0, sizeof(double) * 2 * GN_SLOTS * (size_t)b * groups, (hipStream_t)stream) != hipSuccess) {
+    if (ogc_zero_async(stats, sizeof(double) * 2 * GN_SLOTS * (size_t)b * groups, (hipStream_t)stream) != hipSuccess) {
         ogc_set_error("ogc_conv1x1_gemm_gnstats: memset failed");
         return OGC_ERR_LAUNCH;
     }
@@ -867,7 +867,7 @@ int wgrad_impl(const char *name, int b, int cin, int cout, int hw, const float *
     OGC_REQUIRE((long long)cin * hw < (1ll << 31) && (long long)cout * hw < (1ll << 31),
                 "%s: one sample exceeds 32-bit indexing", name);
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(dw, 0, sizeof(float) * (size_t)cin * cout, s) != hipSuccess) {
+    if (ogc_zero_async(dw, sizeof(float) * (size_t)cin * cout, s) != hipSuccess) {
         ogc_set_error("%s: memset failed", name);
         return OGC_ERR_LAUNCH;
     }
@@ -908,7 +908,7 @@ extern "C" int ogc_conv1x1_gemm_affine(int b, int M, int K, int hw, int relu, in
                           "(or a shape of the streaming kernel: ogc_conv1x1_gemm_stats_supported)");
             return OGC_ERR_UNSUPPORTED;
         }
-        if (hipMemsetAsync(stats, 0, sizeof(double) * 2 * GN_SLOTS * (size_t)b * groups, s) != hipSuccess) {
+        if (ogc_zero_async(stats, sizeof(double) * 2 * GN_SLOTS * (size_t)b * groups, s) != hipSuccess) {
             ogc_set_error("ogc_conv1x1_gemm_affine: memset failed");
             return OGC_ERR_LAUNCH;
         }
@@ -939,7 +939,7 @@ extern "C" int ogc_conv1x1_gemm_affine_pool(int b, int M, int K, int hw, int rel
     }
     if (b == 0) return OGC_OK;
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(stats, 0, sizeof(double) * 2 * GN_SLOTS * (size_t)b * groups, s) != hipSuccess) {
+    if (ogc_zero_async(stats, sizeof(double) * 2 * GN_SLOTS * (size_t)b * groups, s) != hipSuccess) {
         ogc_set_error("ogc_conv1x1_gemm_affine_pool: memset failed");
         return OGC_ERR_LAUNCH;
     }

@@ -844,7 +844,7 @@ static int fps_impl(const char *name, int b, int n, int m, const float *xyz, flo
     else if (slots <= 16384) fps_launch<32, 512>(b, n, m, shift, xyz, temp, idx, ties_in, ties_out, s);
     else {
         // (these kernels do not track ties: a chain through them never takes the shortcut afterwards)
-        if (ties_out && hipMemsetAsync(ties_out, 0, sizeof(int) * (size_t)b, s) != hipSuccess) {
+        if (ties_out && ogc_zero_async(ties_out, sizeof(int) * (size_t)b, s) != hipSuccess) {
             ogc_set_error("%s: memset failed", name);
             return OGC_ERR_LAUNCH;
         }
@@ -855,7 +855,7 @@ static int fps_impl(const char *name, int b, int n, int m, const float *xyz, flo
         if (!(mode && mode[0] == 's') && (long long)b * G <= 256 && G <= 64 * 16) {
             const size_t bytes_words = sizeof(u64) * (size_t)b * 2 * G;
             char *ws = static_cast<char *>(ogc_workspace(s, bytes_words + sizeof(unsigned) * b));
-            if (ws && hipMemsetAsync(ws, 0, bytes_words + sizeof(unsigned) * b, s) == hipSuccess) {
+            if (ws && ogc_zero_async(ws, bytes_words + sizeof(unsigned) * b, s) == hipSuccess) {
                 u64 *words = reinterpret_cast<u64 *>(ws);
                 unsigned *counters = reinterpret_cast<unsigned *>(ws + bytes_words);
                 int gg = G;

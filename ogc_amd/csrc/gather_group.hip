@@ -423,7 +423,7 @@ extern "C" int ogc_group_linear_fwd(int b, int m, int n, int npoints, int nsampl
     int cpb = 1; // channels per workgroup: the largest power of two <= 16 dividing the group width
     while (cpb < 16 && cg % (cpb * 2) == 0) cpb *= 2;
     if (groups > 0 &&
-        hipMemsetAsync(stats, 0, sizeof(double) * 2 * GL_SLOTS * (size_t)b * groups, s) != hipSuccess) {
+        ogc_zero_async(stats, sizeof(double) * 2 * GL_SLOTS * (size_t)b * groups, s) != hipSuccess) {
         ogc_set_error("ogc_group_linear_fwd: memset failed");
         return OGC_ERR_LAUNCH;
     }
@@ -692,7 +692,7 @@ extern "C" int ogc_group_points_grad_rev(int b, int c, int n, int npoints, int n
     }
     hipStream_t s = (hipStream_t)stream;
     if (T == 0) {
-        if (hipMemsetAsync(grad_points, 0, sizeof(float) * (size_t)b * c * n, s) != hipSuccess) return OGC_ERR_LAUNCH;
+        if (ogc_zero_async(grad_points, sizeof(float) * (size_t)b * c * n, s) != hipSuccess) return OGC_ERR_LAUNCH;
         return OGC_OK;
     }
     const int tc = ogc_group_reverse_chunk(n, npoints, nsample);
@@ -726,7 +726,7 @@ extern "C" int ogc_three_interpolate_grad_rev(int b, int c, int n, int m, const 
     }
     hipStream_t s = (hipStream_t)stream;
     if (T == 0) {
-        if (hipMemsetAsync(grad_points, 0, sizeof(float) * (size_t)b * c * m, s) != hipSuccess) return OGC_ERR_LAUNCH;
+        if (ogc_zero_async(grad_points, sizeof(float) * (size_t)b * c * m, s) != hipSuccess) return OGC_ERR_LAUNCH;
         return OGC_OK;
     }
     const int tc = ogc_group_reverse_chunk(m, n, 3);

@@ -422,7 +422,7 @@ int wgrad_moments_impl(const char *name, int b, int cin, int cout, int hw, int r
                 "%s: one sample exceeds 32-bit indexing", name);
     hipStream_t s = (hipStream_t)stream;
     if (b == 0) return OGC_OK;
-    if (hipMemsetAsync(moments, 0, sizeof(float) * 2 * (size_t)b * cin * cout, s) != hipSuccess) {
+    if (ogc_zero_async(moments, sizeof(float) * 2 * (size_t)b * cin * cout, s) != hipSuccess) {
         ogc_set_error("%s: memset failed", name);
         return OGC_ERR_LAUNCH;
     }
@@ -471,7 +471,7 @@ extern "C" int ogc_gn_moments_combine(int b, int cin, int cout, int hw, int grou
     OGC_REQUIRE(moments && w && pa && pb && mean && rstd && gamma && grad_w && coef && grad_gamma && grad_beta,
                 "ogc_gn_moments_combine: null pointer");
     OGC_REQUIRE(grad_beta == grad_gamma + cin, "ogc_gn_moments_combine: grad_beta must follow grad_gamma (one 2 x cin buffer)");
-    if (hipMemsetAsync(grad_gamma, 0, sizeof(float) * 2 * (size_t)cin, (hipStream_t)stream) != hipSuccess) {
+    if (ogc_zero_async(grad_gamma, sizeof(float) * 2 * (size_t)cin, (hipStream_t)stream) != hipSuccess) {
         ogc_set_error("ogc_gn_moments_combine: memset failed");
         return OGC_ERR_LAUNCH;
     }

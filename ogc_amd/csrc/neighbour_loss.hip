@@ -225,8 +225,8 @@ extern "C" int ogc_reverse_neighbours(int b, int n, int k, const int *idx, int *
     if (b == 0) return OGC_OK;
     OGC_REQUIRE(rev_start, "ogc_reverse_neighbours: null pointer");
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(rev_start, 0, (size_t)b * (n + 1) * sizeof(int), s) != hipSuccess) {
-        ogc_set_error("ogc_reverse_neighbours: hipMemsetAsync failed");
+    if (ogc_zero_async(rev_start, (size_t)b * (n + 1) * sizeof(int), s) != hipSuccess) {
+        ogc_set_error("ogc_reverse_neighbours: zero fill failed");
         return OGC_ERR_LAUNCH;
     }
     const long long total = (long long)b * n * k;

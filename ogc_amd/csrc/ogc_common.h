@@ -31,6 +31,27 @@ void *ogc_workspace(hipStream_t stream, size_t bytes);
 
 static inline int ogc_divup(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// ---- zero-fill as a KERNEL ------------------------------------------------------------------------------------------
+// Not hipMemsetAsync: captured into a HIP graph (graph_step.py, utils/subgraph.py) a memset node of this stack zeroes
+// correctly on the first replay and fills with a few stale low bits on the later ones (tools/memset_probe.py: a buffer set
+// to 1e30 comes back as ~3e-41 where it should be 0) — harmless-looking, until the stale bits are large.  Every accumulator of
+// this library that kernels add into with atomics is zeroed by this launch instead.  `bytes` and `ptr` multiples of 4.
+namespace {
+__global__ void ogc_zero_kernel(uint32_t *__restrict__ p, size_t words) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += stride) p[i] = 0u;
+}
+} // namespace
+static inline hipError_t ogc_zero_async(void *ptr, size_t bytes, hipStream_t stream) {
+    if (bytes == 0) return hipSuccess;
+    if ((bytes & 3) != 0 || ((uintptr_t)ptr & 3) != 0) return hipErrorInvalidValue;
+    const size_t words = bytes >> 2;
+    size_t blocks = (words + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(ogc_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, static_cast<uint32_t *>(ptr), words);
+    return hipGetLastError();
+}
+
 // ---- arithmetic pinned to the reference's source expression ---------------------------------
 // d = (ux-x)*(ux-x) + (uy-y)*(uy-y) + (uz-z)*(uz-z), fp32, left to right, one rounding per
 // operation, never contracted into FMA (interpolate_gpu.cu:40, ball_query_gpu.cu:33,

@@ -240,7 +240,7 @@ extern "C" int ogc_rigid_moments(int vb, int n, int k, const float *pc, const fl
     if (vb == 0) return OGC_OK;
     OGC_REQUIRE(pc && pc2 && mask && mom && S && means, "ogc_rigid_moments: null pointer");
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(mom, 0, sizeof(double) * 16 * (size_t)vb * k, s) != hipSuccess) {
+    if (ogc_zero_async(mom, sizeof(double) * 16 * (size_t)vb * k, s) != hipSuccess) {
         ogc_set_error("ogc_rigid_moments: memset failed");
         return OGC_ERR_LAUNCH;
     }
@@ -297,7 +297,7 @@ extern "C" int ogc_mask_iou(int pb, int n, int k, const float *mask1, const floa
     if (pb == 0) return OGC_OK;
     OGC_REQUIRE(mask1 && mask2 && counts && iou, "ogc_mask_iou: null pointer");
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(counts, 0, sizeof(int) * (size_t)pb * k * k, s) != hipSuccess) {
+    if (ogc_zero_async(counts, sizeof(int) * (size_t)pb * k * k, s) != hipSuccess) {
         ogc_set_error("ogc_mask_iou: memset failed");
         return OGC_ERR_LAUNCH;
     }

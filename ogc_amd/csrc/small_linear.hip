@@ -145,8 +145,8 @@ extern "C" int ogc_small_linear_bwd(int rows, int n_in, int n_out, const float *
     if (rows == 0) {
         // no rows: the parameter gradients are zero
         hipError_t e = hipSuccess;
-        if (grad_weight) e = hipMemsetAsync(grad_weight, 0, sizeof(float) * (size_t)n_in * n_out, (hipStream_t)stream);
-        if (grad_bias && e == hipSuccess) e = hipMemsetAsync(grad_bias, 0, sizeof(float) * (size_t)n_out, (hipStream_t)stream);
+        if (grad_weight) e = ogc_zero_async(grad_weight, sizeof(float) * (size_t)n_in * n_out, (hipStream_t)stream);
+        if (grad_bias && e == hipSuccess) e = ogc_zero_async(grad_bias, sizeof(float) * (size_t)n_out, (hipStream_t)stream);
         OGC_REQUIRE(e == hipSuccess, "ogc_small_linear_bwd: memset failed: %s", hipGetErrorString(e));
         return OGC_OK;
     }

@@ -87,3 +87,34 @@ def test_graphed_slot_branch_is_reentrant_safe():
         assert made and made[0][0] is not None, "the slot branch was not captured"
     finally:
         net.graph_slot_branch = True
+
+
+@pytest.mark.gpu
+def test_accumulators_are_zeroed_on_every_replay():
+    """An entry point that zeroes its output and then adds into it with atomics (ogc_conv1x1_wgrad), captured in a HIP graph and
+    replayed with the output poisoned in between: exact zeros wherever the operands are zero, on EVERY replay.  (With
+    hipMemsetAsync in the library a memset node of this stack zeroed correctly on the first replay only — tools/memset_probe.py;
+    the library now zero-fills with a kernel, csrc/ogc_common.h.)"""
+    import ogc_amd  # noqa: F401
+    from ogc_amd import pointnet2_cuda as nat
+    B, cin, cout, hw = 2, 128, 128, 64
+    x = torch.zeros(B, cin, hw, device="cuda")
+    x[:, ::2] = torch.randn(B, cin // 2, hw, device="cuda")          # every other input channel is zero
+    dy = torch.randn(B, cout, hw, device="cuda")
+    ref = torch.bmm(dy, x.transpose(1, 2)).sum(0)
+    warm = torch.empty(cout, cin, device="cuda")
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        nat.conv1x1_wgrad_wrapper(B, cin, cout, hw, x, dy, warm)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        dw = torch.empty(cout, cin, device="cuda")
+        nat.conv1x1_wgrad_wrapper(B, cin, cout, hw, x, dy, dw)
+    for replay in range(4):
+        dw.fill_(1e30)
+        torch.cuda.synchronize()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert bool((dw[:, 1::2] == 0).all()), (replay, float(dw[:, 1::2].abs().max()))
+        assert float((dw - ref).norm() / ref.norm()) < 1e-5
