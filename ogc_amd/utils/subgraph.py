@@ -5,8 +5,8 @@ the bound, and on a loaded host it is.  The parts of the network that are fixed 
 the slot branch, the feature-propagation modules, the set-abstraction MLPs — can be recorded once with
 torch.cuda.make_graphed_callables and replayed with one launch each way: the same kernels in the same order on the same
 stream, Python out of the loop.  (Used for the slot branch.  The feature-propagation modules were tried as well — interpolation,
-concatenation and MLP with the neighbour lists as arguments — and dropped: the C4 step went from 11.2 to 12.2 ms, and one weight
-gradient came back with uninitialised values in tests/test_graph_step_gpu.py.)  What varies from step to step (features, coordinates, neighbour lists) enters as tensor
+concatenation and MLP with the neighbour lists as arguments — and dropped: the C4 step went from 11.2 to 12.2 ms.  The attempt
+is what exposed the memset nodes of this stack: DESIGN.md §4b, csrc/ogc_common.h ogc_zero_async.)  What varies from step to step (features, coordinates, neighbour lists) enters as tensor
 arguments, copied into the graph's static inputs; everything the body touches besides its arguments and the owner's
 parameters must be constant.
 
