@@ -5,6 +5,9 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+LOSS_TOL, WEIGHT_TOL = 1e-4, 0.01   # (passes at 2e-5 / 0.002; the test asked for 2e-3 / 0.05 while hipMemsetAsync nodes fed stale
+#                                     bits into the replayed step's accumulators)
+
 
 def _build(npoint):
     from ogc_amd.models.segnet_kitti import MaskFormer3D
@@ -46,12 +49,12 @@ def test_graphed_step_matches_eager():
         losses, stepped = gs.step(batches[(i + 1) % 3]).result()
         assert stepped
         for k in ("sum", "dynamic", "smooth", "invariance"):
-            assert abs(losses[k] - eager[i][k]) <= 2e-3 * max(1.0, abs(eager[i][k])), (i, k, losses[k], eager[i][k])
+            assert abs(losses[k] - eager[i][k]) <= LOSS_TOL * max(1.0, abs(eager[i][k])), (i, k, losses[k], eager[i][k])
     assert all(float(st["step"]) == steps for st in opt.state.values())
     # six Adam steps of 1e-3 move a weight by at most 6e-3; the two runs must agree far better than that on average
     num = sum(float((a - b.detach()).abs().sum()) for a, b in zip(w_eager, net.parameters()))
     den = sum(float((a - b).abs().sum()) for a, b in zip(w_eager, w0))
-    assert num <= 0.05 * den, (num, den)
+    assert num <= WEIGHT_TOL * den, (num, den)
 
 
 @pytest.mark.gpu
