@@ -42,7 +42,7 @@ OFFLINE = {
                                                  "source": "profiles/r02_ball_query_pmc.txt"},
                               "source": "profiles/r03_ball_query_pmc.txt"},
     "knn_clamped_valu_issue": {"kernel": "knn_cells_kernel<32> + knn_grid_kernel<1> (deferred)", "source": "profiles/r03_knn_clamped_pmc.txt"},
-    "step_traffic_mib": {"fetch_reported": 12679.7, "write": 9535.0,
+    "step_traffic_mib": {"fetch_reported": 12719.2, "write": 9533.3,
                          "source": "profiles/r03_step_hbm_traffic.txt (per-kernel FETCH_SIZE / WRITE_SIZE table of one round-3 C4 step, "
                                    "mean of whole timed steps; the estimate doubles the reported fetch: MI355X_MICROARCH.md)"},
 }
