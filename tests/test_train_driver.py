@@ -230,3 +230,18 @@ def test_all_ranks_train_on_the_scenes_the_refinement_round_wrote(monkeypatch):
     src = inspect.getsource(train_seg.main) + inspect.getsource(train_flow.main)
     assert "rank + 1" not in src
     assert "seed=1000" in inspect.getsource(oa_icp_round.main)
+
+
+def test_device_only_shortcuts_stay_out_of_the_way_on_cpu():
+    """The two-launch Adam step (ogc_adam_step) and the sub-graphs of utils/subgraph.py are for HIP tensors in training: with
+    CPU parameters the optimizer's own step is taken and bodies run eagerly."""
+    import torch
+    from ogc_amd.train_step import _adam_kernel_step, make_optimizer
+    from ogc_amd.utils import subgraph
+    lin = torch.nn.Linear(3, 2)
+    opt = make_optimizer(lin.parameters(), 1e-3)
+    lin(torch.randn(4, 3)).sum().backward()
+    assert _adam_kernel_step(opt) is None
+    x = torch.randn(4, 3, requires_grad=True)
+    assert not subgraph.allowed(lin.train(), x)
+    assert torch.equal(subgraph.run(lin, "lin", lambda t: lin(t), (x,)), lin(x))
