@@ -358,8 +358,11 @@ def main():
                     "note": "algorithmic bytes = B*(12M + 12N + 4M*nsample) (SURVEY 8d) / mean duration (HIP events on the launch "
                             "stream, inside the timed steps) of the query launch + half of the grid build it shares with the k-NN "
                             "search; the exact cell-list search tests ~N/60 candidates per centre, so the all-pairs figure of "
-                            "8*B*N*M flop no longer describes the work done; in the step the next batch's network geometry plan "
-                            "(FPS / kNN on a side stream) shares the chip with it (tools/bench_ops.py has the idle-GPU table)",
+                            "8*B*N*M flop no longer describes the work done.  A pair of HIP events reads event_pair_floor_ms with "
+                            "NOTHING between them (measured live, idle GPU): achieved / frac / avg_ms are the raw readings, "
+                            "floor_removed the same launches with that floor taken off, which is what the rocprofv3 kernel "
+                            "statistics of this command show (profiles/r03_bench_kernel_stats.csv; tools/bench_ops.py has the "
+                            "idle-GPU table)",
                     "all_pairs_equivalent_tpairs_per_s": round(b_ * n_ * m_ / (ms * 1e-3) / 1e12, 2)}
         others = {}
         for name in ("ogc_knn_clamped", "ogc_knn_clamped_cells", "ogc_cell_grid_build", "ogc_furthest_point_sampling",
