@@ -11,6 +11,9 @@ struct GridHdr { // one per cloud, written by grid_build_kernel
     int heavy;            // 1: 120 or more candidates per centre: lists too long for ball_query_cells_kernel's register sort
     int knn_general;      // k-NN builds: 1 = knn_cells_kernel leaves this cloud to knn_grid_kernel (cells shorter than the radius, or crowded)
     int pending;          // set by knn_cells_kernel when it left rows of this cloud to knn_grid_kernel (marked idx[row][0] = -1)
+    int fast;             // which coordinate runs fastest in the cell order: the grid's axes (fast, mid, slow) are (x, y, z) for 0,
+                          // (y, x, z) for 1, (z, x, y) for 2; minx / gx belong to the fast axis, miny / gy to the middle one, ...
+    int slab;             // 1: gx <= 2 — the cells (any x, y - 1 .. y + 1) of one z are ONE contiguous run: three runs per centre
 };
 
 } // namespace ogc_grid

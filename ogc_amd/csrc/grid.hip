@@ -58,68 +58,94 @@ __device__ __forceinline__ int cell_floor(float x, float mn, float inv_h) {
     return (int)__builtin_amdgcn_fmed3f(floorf((x - mn) * inv_h), 0.0f, 1.0e9f);
 }
 
-// v^(1/dims) for the cell edge, in single precision (the edge only steers how many candidates a search meets — any positive
-// value gives the same results — and a double-precision pow on the one lane that derives the grid costs microseconds)
-__device__ __forceinline__ double dims_root(double v, int dims) {
-    const float f = (float)v;
-    return dims == 1 ? (double)f : (dims == 2 ? (double)sqrtf(f) : (double)cbrtf(f));
-}
+// a point's coordinates along the grid's (fast, mid, slow) axes (GridHdr::fast; wave-uniform selects)
+#define OGC_GRID_AXES(H, X, Y, Z, FX, FY, FZ)                                                    \
+    const float FX = (H).fast == 0 ? (X) : ((H).fast == 1 ? (Y) : (Z)), FY = (H).fast == 0 ? (Y) : (X), \
+                FZ = (H).fast == 2 ? (Y) : (Z)
 
-// Grid parameters from the bounding box (every thread computes them redundantly: no serial section, no broadcast).
+// v^(1/dims) for the cell edge
+__device__ __forceinline__ float dims_root(float v, int dims) { return dims == 1 ? v : (dims == 2 ? sqrtf(v) : cbrtf(v)); }
+
+// Grid parameters from the bounding box, by ONE lane per workgroup, in single precision: the edge only steers which candidates
+// a search meets.  What the searches rely on holds for ANY origin, edge and cell counts: cell = min(floor((x - min) / h), g - 1)
+// clamped at 0 is monotone in x, so two points closer than r <= h / 1.01 along an axis are at most one cell apart (a 1 % margin
+// against the 1e-7 relative error of the fp32 quotient and of r * 1.01f itself).  (This used to be double-precision pow / cbrt /
+// division chains: ~2200 cycles on the one lane everybody waits for; now ~a quarter.)
 __device__ __forceinline__ GridHdr grid_header(const float (&lo)[3], const float (&hi)[3], int n, float radius,
                                                int knn_k, float knn_div, int prefer_cells) {
     GridHdr h;
     bool cells_ok = false;
     const bool any = lo[0] <= hi[0];
-    double ext[3];
-    for (int a = 0; a < 3; ++a) ext[a] = any ? (double)hi[a] - (double)lo[a] : 0.0;
-    double edge = (double)radius * 1.01;
-    const double maxext = fmax(ext[0], fmax(ext[1], ext[2]));
+    float ext[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) ext[a] = any ? fminf(hi[a] - lo[a], 3.0e38f) : 0.0f; // (a difference of finite numbers may overflow)
+    float edge = radius * 1.01f;
+    const float maxext = fmaxf(ext[0], fmaxf(ext[1], ext[2]));
     if (knn_k > 0) {
         // k-NN mode: pick the edge from the mean density so that the 3^d block around a query holds ~2.5 k points
         // (d = number of axes with a non-negligible extent: flat or linear clouds get fewer cells per block)
         int dims = 0;
-        double vol = 1.0;
+        float vol = 1.0f;
+#pragma unroll
         for (int a = 0; a < 3; ++a)
-            if (ext[a] > 1e-3 * maxext && ext[a] > 0.0) { ++dims; vol *= ext[a]; }
+            if (ext[a] > 1e-3f * maxext && ext[a] > 0.0f) { ++dims; vol *= ext[a]; }
         // cell edge = HALF the expected distance of the k-th neighbour (rho h^d = k / (V_d 2^d), V_d the unit ball): the
         // search then ends after the 5^d block (R = 2), ~3.7 k candidates in 3-D, where an edge of 0.73 r_k (the former
         // 2.5 k points per 3^d block) also needed R = 2 but scanned 11.6 k
-        const double per_cell = fmax((double)knn_k / (dims == 3 ? (double)knn_div : (dims == 2 ? 12.6 : 4.0)), 0.5);
-        edge = dims > 0 ? dims_root(vol * per_cell / (double)max(n, 1), dims) : 1.0;
+        const float inv_n = 1.0f / (float)max(n, 1);
+        const float per_cell = fmaxf((float)knn_k / (dims == 3 ? knn_div : (dims == 2 ? 12.6f : 4.0f)), 0.5f);
+        edge = dims > 0 ? dims_root(vol * per_cell * inv_n, dims) : 1.0f;
         // radius-clamped search (ogc_knn_clamped): neighbours beyond `radius` are replaced by the nearest one anyway,
         // so the search may stop once the scanned block covers the radius.  When the radius is SHORTER than the
         // density-based edge, cells of edge 1.01 r make that one shell of far fewer candidates (but never less than
         // ~one point per cell: the nearest neighbour of a query in an empty region must still be found by shells).
         if (radius > 0.0f && radius < 3.0e38f && dims > 0) {
-            const double one_per_cell = dims_root(vol / (double)max(n, 1), dims);
-            const double limited = fmax((double)radius * 1.01, one_per_cell);
+            const float one_per_cell = dims_root(vol * inv_n, dims);
+            const float limited = fmaxf(radius * 1.01f, one_per_cell);
             if (limited < edge) edge = limited;
             // A radius-limited search of the cloud in itself (prefer_cells): when a ball holds few points (mean <= 18 at the
             // mean density) knn_cells_kernel finds them all in the 27 cells of edge 1.01 r around a query and sorts them in
             // registers — the ball query's grid, far fewer candidates than the shells of the density-based one.
-            if (prefer_cells && radius < 1.0e18f) {
-                const double r = (double)radius;
-                const double ball = dims == 3 ? 4.18879 * r * r * r : (dims == 2 ? 3.14159 * r * r : 2.0 * r);
-                if ((double)n * ball <= 18.0 * vol) {
-                    edge = fmax(edge, r * 1.01); // (no finer than the density asks for: the build's cost grows with the cell count)
+            if (prefer_cells && radius < 1.0e12f) {
+                const float r = radius;
+                const float ball = dims == 3 ? 4.18879f * r * r * r : (dims == 2 ? 3.14159f * r * r : 2.0f * r);
+                if ((float)n * ball <= 18.0f * vol) {
+                    edge = fmaxf(edge, r * 1.01f); // (no finer than the density asks for: the build's cost grows with the cell count)
                     cells_ok = true;
                 }
             }
         }
     }
-    if (!(edge > 0.0) || !isfinite(edge)) edge = fmax(maxext, 1.0);      // degenerate: one cell per axis
-    edge = fmax(edge, maxext * 1e-6);                                    // keep the quotient well inside int range
-    double g[3];
+    if (!(edge > 0.0f) || !isfinite(edge)) edge = fmaxf(maxext, 1.0f);    // degenerate: one cell per axis
+    edge = fmaxf(edge, maxext * 1e-6f);                                   // keep the quotient well inside int range
+    float g0 = 1.0f, g1 = 1.0f, g2 = 1.0f;
     for (int it = 0; it < 64; ++it) {
-        for (int a = 0; a < 3; ++a) g[a] = floor(ext[a] / edge) + 1.0;
-        const double total = g[0] * g[1] * g[2];
-        if (total <= (double)GRID_MAX_CELLS) break;
-        edge *= cbrt(total / (double)GRID_MAX_CELLS) * 1.02;
+        const float inv = 1.0f / edge;
+        g0 = floorf(ext[0] * inv) + 1.0f; g1 = floorf(ext[1] * inv) + 1.0f; g2 = floorf(ext[2] * inv) + 1.0f;
+        const float total = g0 * g1 * g2;
+        if (total <= (float)GRID_MAX_CELLS) break;
+        edge *= cbrtf(total * (1.0f / (float)GRID_MAX_CELLS)) * 1.02f;
     }
-    h.minx = any ? lo[0] : 0.f; h.miny = any ? lo[1] : 0.f; h.minz = any ? lo[2] : 0.f;
-    h.inv_h = (float)(1.0 / edge);
-    h.gx = (int)g[0]; h.gy = (int)g[1]; h.gz = (int)g[2];
+    // Cell order.  A radius search visits the cells (x - 1 .. x + 1, y - 1 .. y + 1, z - 1 .. z + 1): nine runs of the
+    // cell-sorted array when x runs fastest.  When one axis has at most two cells (a road scene a few metres high searched with
+    // r = 2 m) and THAT axis runs fastest, the cells (all of it, y - 1 .. y + 1) of one z are contiguous: three runs, three
+    // times as long — the query kernels' cost is per run, not per candidate.  Otherwise x stays the fastest axis.
+    int fast = 0;
+    if (knn_k == 0 || prefer_cells != 0) {
+        if (g0 > 2.0f && g1 <= 2.0f && g1 <= g2) fast = 1;
+        else if (g0 > 2.0f && g2 <= 2.0f) fast = 2;
+    }
+    // (fast, mid, slow) = (x, y, z) | (y, x, z) | (z, x, y)
+    const float l0 = any ? lo[0] : 0.f, l1 = any ? lo[1] : 0.f, l2 = any ? lo[2] : 0.f;
+    h.minx = fast == 0 ? l0 : (fast == 1 ? l1 : l2);
+    h.miny = fast == 0 ? l1 : l0;
+    h.minz = fast == 2 ? l1 : l2;
+    h.inv_h = 1.0f / edge;
+    h.gx = (int)(fast == 0 ? g0 : (fast == 1 ? g1 : g2));
+    h.gy = (int)(fast == 0 ? g1 : g0);
+    h.gz = (int)(fast == 2 ? g1 : g2);
+    h.fast = fast;
+    h.slab = h.gx <= 2 ? 1 : 0;
     h.npts = 0;
     h.dense = 0;
     h.heavy = 0;
@@ -216,9 +242,10 @@ __global__ __launch_bounds__(BUILD_THREADS) void grid_build_kernel(float knn_div
     // (a finite coordinate: the float -> int conversion saturates where cell_coord clamps to [-2, g + 1], and the clamp to
     // the grid follows either way — the same cell, without cell_coord's two branches per axis)
     auto cell_of = [&](float x, float y, float z) -> int {
-        const int cx = min(cell_floor(x, h.minx, h.inv_h), h.gx - 1);
-        const int cy = min(cell_floor(y, h.miny, h.inv_h), h.gy - 1);
-        const int cz = min(cell_floor(z, h.minz, h.inv_h), h.gz - 1);
+        OGC_GRID_AXES(h, x, y, z, fx, fy, fz);
+        const int cx = min(cell_floor(fx, h.minx, h.inv_h), h.gx - 1);
+        const int cy = min(cell_floor(fy, h.miny, h.inv_h), h.gy - 1);
+        const int cz = min(cell_floor(fz, h.minz, h.inv_h), h.gz - 1);
         return (isfinite(x) && isfinite(y) && isfinite(z)) ? cx + h.gx * (cy + h.gy * cz) : -1;
     };
 
@@ -274,14 +301,14 @@ __global__ __launch_bounds__(BUILD_THREADS) void grid_build_kernel(float knn_div
         // mean number of candidates a centre would test (27 cells at the mean occupancy).  When that is a large share
         // of the cloud the cell lists buy nothing, and rows saturate early, which an index-ordered scan exploits (it
         // stops after nsample hits) while a cell-ordered scan cannot.
-        const double per_query = 27.0 * (double)npts / (double)ncell;
-        h.dense = per_query > 0.25 * (double)n ? 1 : 0;
+        const float per_query = 27.0f * (float)npts / (float)ncell;
+        h.dense = per_query > 0.25f * (float)n ? 1 : 0;
         // ball_query_cells_kernel sorts lists of up to 32 hits: with full cells around it a centre has ~0.15 * per_query hits
         // (ball / 27 cells), so beyond a mean of ~18 too many wavefronts would have to repeat their work in the general body
-        h.heavy = per_query > 120.0 ? 1 : 0;
+        h.heavy = per_query > 120.0f ? 1 : 0;
         // knn_cells_kernel (radius-limited search over the 27 cells around a query) needs cells at least as long as the radius —
         // the same bound knn_grid_kernel stops its shells with — and lists that fit its register sort
-        if (!(1.0f * (1.0f / h.inv_h) * 0.999f >= radius) || per_query > 120.0) h.knn_general = 1;
+        if (!(1.0f * (1.0f / h.inv_h) * 0.999f >= radius) || per_query > 120.0f) h.knn_general = 1;
         hdrs[b] = h;
     }
     __syncthreads();
@@ -310,10 +337,212 @@ __global__ __launch_bounds__(BUILD_THREADS) void grid_build_kernel(float knn_div
     OGC_PROBE_BUILD(7);
 }
 
+// The same build by SEVERAL workgroups per cloud, with nothing exchanged between them.  One workgroup per cloud is one CU per
+// cloud: 16 of 256 CUs for a batch of 16, each pushing 8192 16-byte records and the cell starts through its own store path
+// (the launch ends when those drain), its histogram and scatter serialised on one LDS.  Here every workgroup of a cloud reads
+// the WHOLE cloud (L2-resident after the first reader), derives the same bounding box and header, and computes every point's
+// cell — but owns only a contiguous range of cells [c_lo, c_hi): it counts the points below its range (its base offset), builds
+// the histogram / scan / cursors of its own range in LDS and scatters only the points that fall into it.  No grid barrier, no
+// flag: redundant arithmetic instead of communication.  Results: the same cell starts; the order of the points inside a cell
+// is arbitrary in both kernels (LDS atomics), which no query depends on.
+constexpr int SPLIT_MIN = 8;                                // parts per cloud (at least): a part owns <= GRID_MAX_CELLS / 8 cells
+constexpr int SPLIT_CELLS = GRID_MAX_CELLS / SPLIT_MIN;
+
+template <int PPT>
+__global__ __launch_bounds__(BUILD_THREADS) void grid_build_split_kernel(float knn_div, int nb, int split, int n, float radius,
+                                                                         int knn_k, int prefer_cells, int stride_cells,
+                                                                         const float *__restrict__ xyz,
+                                                                         GridHdr *__restrict__ hdrs,
+                                                                         int *__restrict__ cell_start,
+                                                                         float4 *__restrict__ sorted_pts) {
+    __shared__ int s_cnt[SPLIT_CELLS]; // histogram -> scatter cursors of the cells [c_lo, c_hi)
+    __shared__ float4 s_stage[BUILD_THREADS / 64 * 64 * 6]; // 6 KiB per wavefront: the transposition of the coalesced loads
+    __shared__ float s_red[6][BUILD_THREADS / 64];
+    __shared__ int s_wave[BUILD_THREADS / 64], s_counts[BUILD_THREADS / 64];
+    __shared__ int s_tail;
+    __shared__ GridHdr s_hdr;
+    static_assert(PPT > 0 && PPT % 8 == 0, "the split build keeps the cloud in registers, eight points per thread and pass");
+    const int t = threadIdx.x, b = blockIdx.x % nb, part = blockIdx.x / nb, lane = t & 63, wave = t >> 6;
+    const float *pts = xyz + (size_t)b * n * 3;
+    float px[PPT], py[PPT], pz[PPT];
+    int cell[PPT];
+    // thread t owns the points 8192 * pass + 8 t + i (i < 8) of pass = 0 .. PPT / 8 - 1
+    auto point_index = [&](int i) { return (i >> 3) * (8 * BUILD_THREADS) + t * 8 + (i & 7); };
+
+    OGC_PROBE_BUILD(0);
+    // 1. load + bounding box of the finite points.  A wavefront's 512 points of a pass are 6 KiB of contiguous memory: it
+    //    reads them as six fully coalesced 16-byte loads per lane (lane L takes the 16-byte pieces L, L + 64, ...), parks
+    //    them in its own LDS strip and reads back the 96 contiguous bytes of ITS eight points.  (Reading those 96 bytes
+    //    straight from memory — lanes 96 bytes apart, 48 cache lines per load instruction, every line visited by six
+    //    instructions — took 8.7 k cycles for the cloud, i.e. most of the kernel.)
+    const bool wide = (n & 3) == 0 && (((size_t)(const void *)pts) & 15) == 0;
+    if (wide) {
+        float4 *strip = s_stage + wave * (64 * 6);
+        const int n4 = n * 3 / 4; // 16-byte pieces of the cloud
+#pragma unroll
+        for (int pass = 0; pass < PPT / 8; ++pass) {
+            const int base4 = (pass * (8 * BUILD_THREADS) + wave * 512) * 3 / 4; // first piece of the wavefront's 512 points
+            const float4 *p4 = reinterpret_cast<const float4 *>(pts) + base4;
+            float4 v[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                v[j] = make_float4(NAN, NAN, NAN, NAN);
+                if (base4 + lane + 64 * j < n4) v[j] = p4[lane + 64 * j];
+            }
+            if (pass > 0) __builtin_amdgcn_wave_barrier(); // (the strip is read by this wavefront only)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) strip[lane + 64 * j] = v[j];
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            float f[24];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const float4 w = strip[lane * 6 + j];
+                f[4 * j] = w.x; f[4 * j + 1] = w.y; f[4 * j + 2] = w.z; f[4 * j + 3] = w.w;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { px[pass * 8 + i] = f[3 * i]; py[pass * 8 + i] = f[3 * i + 1]; pz[pass * 8 + i] = f[3 * i + 2]; }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+            const int k = point_index(i);
+            px[i] = py[i] = pz[i] = NAN;
+            if (k < n) { px[i] = pts[k * 3]; py[i] = pts[k * 3 + 1]; pz[i] = pts[k * 3 + 2]; }
+        }
+    }
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int c = t; c < SPLIT_CELLS; c += BUILD_THREADS) s_cnt[c] = 0; // overlaps the loads
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+        const float x = px[i], y = py[i], z = pz[i];
+        if (isfinite(x) && isfinite(y) && isfinite(z)) {
+            mn[0] = fminf(mn[0], x); mn[1] = fminf(mn[1], y); mn[2] = fminf(mn[2], z);
+            mx[0] = fmaxf(mx[0], x); mx[1] = fmaxf(mx[1], y); mx[2] = fmaxf(mx[2], z);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float lo = -ogc_wave_max_f32(-mn[a]), hi = ogc_wave_max_f32(mx[a]);
+        if (lane == 0) { s_red[a][wave] = lo; s_red[3 + a][wave] = hi; }
+    }
+    OGC_PROBE_BUILD(1);
+    __syncthreads();
+    OGC_PROBE_BUILD(2);
+    if (wave == 0) {
+        float lo[3], hi[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float l = lane < BUILD_THREADS / 64 ? s_red[a][lane] : INFINITY;
+            const float u = lane < BUILD_THREADS / 64 ? s_red[3 + a][lane] : -INFINITY;
+            lo[a] = -ogc_wave_max_f32(-l);
+            hi[a] = ogc_wave_max_f32(u);
+        }
+        if (lane == 0) s_hdr = grid_header(lo, hi, n, radius, knn_k, knn_div, prefer_cells);
+    }
+    __syncthreads();
+    OGC_PROBE_BUILD(3);
+    GridHdr h = s_hdr;
+    const int ncell = h.gx * h.gy * h.gz;
+    const int per = (ncell + split - 1) / split;                 // <= SPLIT_CELLS: split >= SPLIT_MIN
+    const int c_lo = min(part * per, ncell), c_hi = min(c_lo + per, ncell);
+
+    // 2. cells of ALL points; histogram of my range; how many points lie below it / in the grid at all
+    int counts = 0; // valid | below << 16   (n <= 16384: 15 bits each)
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+        const float x = px[i], y = py[i], z = pz[i];
+        OGC_GRID_AXES(h, x, y, z, fx, fy, fz);
+        const int cx = min(cell_floor(fx, h.minx, h.inv_h), h.gx - 1);
+        const int cy = min(cell_floor(fy, h.miny, h.inv_h), h.gy - 1);
+        const int cz = min(cell_floor(fz, h.minz, h.inv_h), h.gz - 1);
+        const bool fin = isfinite(x) && isfinite(y) && isfinite(z);
+        const int c = (point_index(i) < n) ? (fin ? cx + h.gx * (cy + h.gy * cz) : -1) : -2;
+        cell[i] = c;
+        counts += (c >= 0 ? 1 : 0) + ((c >= 0 && c < c_lo) ? 0x10000 : 0);
+        if (c >= c_lo && c < c_hi) atomicAdd(&s_cnt[c - c_lo], 1);
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) counts += __shfl_xor(counts, off, 64);
+    if (lane == 0) s_counts[wave] = counts;
+    __syncthreads();
+    OGC_PROBE_BUILD(4);
+
+    // 3. exclusive scan of my range's counts, offset by the points below the range
+    const int nloc = c_hi - c_lo;
+    const int chunk = (nloc + BUILD_THREADS - 1) / BUILD_THREADS;
+    const int c0 = min(t * chunk, nloc), c1 = min(c0 + chunk, nloc);
+    int sum = 0;
+    for (int c = c0; c < c1; ++c) sum += s_cnt[c];
+    int incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int up = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += up;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    OGC_PROBE_BUILD(5);
+    int before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < BUILD_THREADS / 64; ++w) {
+        before += w < wave ? s_wave[w] : 0;
+        total += s_counts[w];
+    }
+    const int npts = total & 0xFFFF, below = total >> 16;
+    int run = below + before + incl - sum;
+    int *cs = cell_start + (size_t)b * stride_cells;
+    for (int c = c0; c < c1; ++c) {
+        const int cnt = s_cnt[c];
+        s_cnt[c] = run; // becomes the scatter cursor
+        cs[c_lo + c] = run;
+        run += cnt;
+    }
+    if (t == 0 && part == 0) {
+        cs[ncell] = npts;
+        h.npts = npts;
+        // (the flags of grid_build_kernel: see there)
+        const float per_query = 27.0f * (float)npts / (float)ncell;
+        h.dense = per_query > 0.25f * (float)n ? 1 : 0;
+        h.heavy = per_query > 120.0f ? 1 : 0;
+        if (!(1.0f * (1.0f / h.inv_h) * 0.999f >= radius) || per_query > 120.0f) h.knn_general = 1;
+        hdrs[b] = h;
+    }
+    if (t == 0) s_tail = npts;
+    __syncthreads();
+    OGC_PROBE_BUILD(6);
+
+    // 4. scatter the points of my range (part 0: also the points outside the grid, behind all cells)
+    float4 *sp = sorted_pts + (size_t)b * n;
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+        const int k = point_index(i), c = cell[i];
+        if (c >= c_lo && c < c_hi) sp[atomicAdd(&s_cnt[c - c_lo], 1)] = make_float4(px[i], py[i], pz[i], __int_as_float(k));
+        else if (c == -1 && part == 0) sp[atomicAdd(&s_tail, 1)] = make_float4(NAN, NAN, NAN, __int_as_float(k));
+    }
+    OGC_PROBE_BUILD(7);
+}
+
+// parts per cloud of the split build (0: one workgroup per cloud).  OGC_GRID_SPLIT in the environment overrides (A/B runs).
+static int grid_build_parts(int n) {
+    static const int forced = [] { const char *e = getenv("OGC_GRID_SPLIT"); return e ? atoi(e) : -1; }();
+    if (n > 16 * BUILD_THREADS) return 0;
+    if (forced >= 0) return forced == 0 ? 0 : (forced < SPLIT_MIN ? SPLIT_MIN : (forced > 32 ? 32 : forced));
+    return n <= 8 * BUILD_THREADS ? 8 : 16;
+}
+
 static void launch_grid_build(int b, int n, float radius, int knn_k, int stride_cells, const float *xyz, GridHdr *hdrs,
                               int *cell_start, float4 *sorted_pts, hipStream_t s, int prefer_cells = 0) {
     const float knn_div = 33.5f; // points per cell = k / 33.5: cell edge = half the expected k-th neighbour distance
-    if (n <= 8 * BUILD_THREADS)
+    const int parts = grid_build_parts(n);
+    if (parts > 0 && n <= 8 * BUILD_THREADS)
+        hipLaunchKernelGGL(grid_build_split_kernel<8>, dim3(b * parts), dim3(BUILD_THREADS), 0, s, knn_div, b, parts, n, radius, knn_k,
+                           prefer_cells, stride_cells, xyz, hdrs, cell_start, sorted_pts);
+    else if (parts > 0)
+        hipLaunchKernelGGL(grid_build_split_kernel<16>, dim3(b * parts), dim3(BUILD_THREADS), 0, s, knn_div, b, parts, n, radius, knn_k,
+                           prefer_cells, stride_cells, xyz, hdrs, cell_start, sorted_pts);
+    else if (n <= 8 * BUILD_THREADS)
         hipLaunchKernelGGL(grid_build_kernel<8>, dim3(b), dim3(BUILD_THREADS), 0, s, knn_div, n, radius, knn_k, prefer_cells, stride_cells, xyz,
                            hdrs, cell_start, sorted_pts);
     else if (n <= 16 * BUILD_THREADS)
@@ -337,10 +566,18 @@ __device__ __forceinline__ float lane_bcast(float v, int src) {
 // pairs are then broadcast to scalars so that every lane can map a flat candidate number to an array position.
 // (A macro, not a struct: the eighteen scalars must stay in SGPRs — as members of an object passed by reference the
 // compiler put them in scratch memory and indexed them per candidate.)
-#define OGC_BOX_SETUP(XLO, XHI, Y0, Z0)                                                              \
+// (SLAB — GridHdr::slab, the fast axis has at most two cells: THREE runs, the cells (any x, XLO .. XHI) of the rows z - 1 ..
+// z + 1, where XLO .. XHI is then a range of y; the other six runs are empty)
+#define OGC_BOX_SETUP(SLAB, XLO, XHI, Y0, Z0)                                                        \
     {                                                                                                \
         int lo_ = 0, len_ = 0;                                                                       \
-        if (lane < 9) {                                                                              \
+        if ((SLAB) && lane < 3) {                                                                    \
+            const int z_ = (Z0) + lane - 1;                                                          \
+            if (z_ >= 0 && z_ < h.gz && (XLO) <= (XHI)) {                                            \
+                lo_ = cs[h.gx * ((XLO) + h.gy * z_)];                                                \
+                len_ = cs[h.gx * ((XHI) + h.gy * z_) + h.gx] - lo_;                                  \
+            }                                                                                        \
+        } else if (!(SLAB) && lane < 9) {                                                            \
             const int y_ = (Y0) + (lane % 3) - 1, z_ = (Z0) + (lane / 3) - 1;                        \
             if (y_ >= 0 && y_ < h.gy && z_ >= 0 && z_ < h.gz && (XLO) <= (XHI)) {                    \
                 const int rowc_ = h.gx * (y_ + h.gy * z_);                                           \
@@ -397,11 +634,11 @@ __device__ __forceinline__ ogc_v2f sqdist_pair(ogc_v2f qx, ogc_v2f qy, ogc_v2f q
 // rows saturate early) are scanned in INDEX order instead, by the same wavefronts: hits then arrive in the order
 // of the output and a wavefront stops as soon as its eight rows are full.
 // (the body of the kernel: ball_query_cells_kernel below runs it too, for the wavefronts its short lists cannot hold)
-__device__ __forceinline__ void ball_query_grid_body(int first_centre, int *gq_smem, int n, int m, float radius2, int nsample,
+__device__ __forceinline__ void ball_query_grid_body(int lane, int first_centre, int *gq_smem, int n, int m, float radius2, int nsample,
                                                      int hit_cap, int stride_cells, const float *__restrict__ xyz,
                                                      const GridHdr *__restrict__ hdrs, const int *__restrict__ cell_start,
                                                      const float4 *__restrict__ sorted_pts, int *__restrict__ idx_out) {
-    const int lane = threadIdx.x, b = blockIdx.y;
+    const int b = blockIdx.y;
     OGC_PROBE_T(pt0);
     const GridHdr h = hdrs[b];
     int *hits = gq_smem;                                       // [QPW][hit_cap]
@@ -457,24 +694,27 @@ __device__ __forceinline__ void ball_query_grid_body(int first_centre, int *gq_s
             if (all_full) break;
         }
     } else {
-        const int cx = cell_coord(me.x, h.minx, h.inv_h, h.gx);
-        const int cy = cell_coord(me.y, h.miny, h.inv_h, h.gy);
-        const int cz = cell_coord(me.z, h.minz, h.inv_h, h.gz);
+        OGC_GRID_AXES(h, me.x, me.y, me.z, fx, fy, fz);
+        const int cx = cell_coord(fx, h.minx, h.inv_h, h.gx);
+        const int cy = cell_coord(fy, h.miny, h.inv_h, h.gy);
+        const int cz = cell_coord(fz, h.minz, h.inv_h, h.gz);
+        const bool slab = h.slab != 0;
+        const int cr = slab ? cy : cx, gr = slab ? h.gy : h.gx; // the coordinate a batch's box ranges over
         unsigned todo = live_mask;
         while (todo != 0) {
             const int c0 = __ffs(todo) - 1;
             const int y0 = lane_bcast(cy, c0), z0 = lane_bcast(cz, c0);
-            const bool mine = live && cy == y0 && cz == z0;
+            const bool mine = live && (slab || cy == y0) && cz == z0; // (slab: a batch is the centres of one z)
             const unsigned batch = (unsigned)__builtin_amdgcn_ballot_w64(mine) & todo;
             todo &= ~batch;
-            int xlo = mine ? cx : 0x7fffffff, xhi = mine ? cx : -1;
+            int xlo = mine ? cr : 0x7fffffff, xhi = mine ? cr : -1;
 #pragma unroll
             for (int off = 1; off < QPW; off <<= 1) {
                 xlo = min(xlo, __shfl_xor(xlo, off, 64));
                 xhi = max(xhi, __shfl_xor(xhi, off, 64));
             }
-            const int bx0 = max(lane_bcast(xlo, 0) - 1, 0), bx1 = min(lane_bcast(xhi, 0) + 1, h.gx - 1);
-            OGC_BOX_SETUP(bx0, bx1, y0, z0)
+            const int bx0 = max(lane_bcast(xlo, 0) - 1, 0), bx1 = min(lane_bcast(xhi, 0) + 1, gr - 1);
+            OGC_BOX_SETUP(slab, bx0, bx1, y0, z0)
             const float4 nothing = make_float4(NAN, NAN, NAN, 0.0f); // NaN: never a hit
             float4 ahead = nothing; // the next round's candidate is in flight while this round is tested
             if (lane < box_total) ahead = pts[OGC_BOX_POSITION(lane)];
@@ -526,11 +766,13 @@ __device__ __forceinline__ void ball_query_grid_body(int first_centre, int *gq_s
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
         const float qx = lane_bcast(me.x, c), qy = lane_bcast(me.y, c), qz = lane_bcast(me.z, c);
-        const int ccx = cell_coord(qx, h.minx, h.inv_h, h.gx);
-        const int ccy = cell_coord(qy, h.miny, h.inv_h, h.gy);
-        const int ccz = cell_coord(qz, h.minz, h.inv_h, h.gz);
-        const int bx0 = max(ccx - 1, 0), bx1 = min(ccx + 1, h.gx - 1);
-        OGC_BOX_SETUP(bx0, bx1, ccy, ccz)
+        OGC_GRID_AXES(h, qx, qy, qz, gfx_, gfy_, gfz_);
+        const int ccx = cell_coord(gfx_, h.minx, h.inv_h, h.gx);
+        const int ccy = cell_coord(gfy_, h.miny, h.inv_h, h.gy);
+        const int ccz = cell_coord(gfz_, h.minz, h.inv_h, h.gz);
+        const bool slab_o = h.slab != 0;
+        const int bx0 = max((slab_o ? ccy : ccx) - 1, 0), bx1 = min((slab_o ? ccy : ccx) + 1, (slab_o ? h.gy : h.gx) - 1);
+        OGC_BOX_SETUP(slab_o, bx0, bx1, ccy, ccz)
         for (int f0 = 0; f0 < box_total; f0 += OGC_WAVE) {
             const int f = f0 + lane;
             if (f < box_total) {
@@ -618,7 +860,7 @@ __global__ __launch_bounds__(OGC_WAVE) void ball_query_grid_kernel(int n, int m,
                                                                    const float4 *__restrict__ sorted_pts,
                                                                    int *__restrict__ idx_out) {
     extern __shared__ __attribute__((aligned(16))) int gq_smem[];
-    ball_query_grid_body(blockIdx.x * QPW, gq_smem, n, m, radius2, nsample, hit_cap, stride_cells, xyz, hdrs, cell_start,
+    ball_query_grid_body(threadIdx.x, blockIdx.x * QPW, gq_smem, n, m, radius2, nsample, hit_cap, stride_cells, xyz, hdrs, cell_start,
                          sorted_pts, idx_out);
 }
 
@@ -647,22 +889,26 @@ __device__ __forceinline__ int quad_bcast(int v) { // lane R of every group of f
     return __builtin_amdgcn_update_dpp(0, v, R * 0x55, 0xF, 0xF, true);
 }
 
-template <int NS>
-__global__ __launch_bounds__(OGC_WAVE, 8) void ball_query_cells_kernel(int n, int m, float radius2, int stride_cells,
+template <int NS, int WPB>
+__global__ __launch_bounds__(OGC_WAVE * WPB, 8) void ball_query_cells_kernel(int n, int m, float radius2, int stride_cells, int lds_ints,
                                                                        const float *__restrict__ xyz,
                                                                        const GridHdr *__restrict__ hdrs,
                                                                        const int *__restrict__ cell_start,
                                                                        const float4 *__restrict__ sorted_pts,
                                                                        int *__restrict__ idx_out) {
-    extern __shared__ __attribute__((aligned(16))) int gq_smem[];
-    const int lane = threadIdx.x, b = blockIdx.y, sub = lane & (CL - 1), g = lane >> 2;
+    extern __shared__ __attribute__((aligned(16))) int gq_smem_all[];
+    // WPB independent wavefronts per workgroup (nothing is shared between them: a workgroup is only the unit of dispatch)
+    const int lane = threadIdx.x & (OGC_WAVE - 1), wave_in_block = threadIdx.x >> 6;
+    const int grp = blockIdx.x * WPB + wave_in_block; // sixteen centres
+    int *gq_smem = gq_smem_all + wave_in_block * lds_ints;
+    const int b = blockIdx.y, sub = lane & (CL - 1), g = lane >> 2;
     OGC_PROBE_T(pt0);
     const GridHdr h = hdrs[b];
     bool general = h.dense != 0 || h.heavy != 0;
     if (!general) {
         const int *cs = cell_start + (size_t)b * stride_cells;
         const float4 *pts = sorted_pts + (size_t)b * n;
-        const int pc = blockIdx.x * CPW + g;
+        const int pc = grp * CPW + g;
         float4 me = make_float4(NAN, NAN, NAN, __int_as_float(-1));
         if (pc < n) me = pts[pc]; // positions >= h.npts hold the non-finite points: no hits, an all-zero row
         const bool live = pc < h.npts;
@@ -675,13 +921,15 @@ __global__ __launch_bounds__(OGC_WAVE, 8) void ball_query_cells_kernel(int n, in
         }
         // the centre's cell, as the build computed it (a live centre is finite: the conversion saturates where cell_coord
         // clamps, and the clamp to the grid follows either way)
-        const int cx = min(cell_floor(me.x, h.minx, h.inv_h), h.gx - 1);
-        const int cy = min(cell_floor(me.y, h.miny, h.inv_h), h.gy - 1);
-        const int cz = min(cell_floor(me.z, h.minz, h.inv_h), h.gz - 1);
+        OGC_GRID_AXES(h, me.x, me.y, me.z, gfx, gfy, gfz);
+        const int cx = min(cell_floor(gfx, h.minx, h.inv_h), h.gx - 1);
+        const int cy = min(cell_floor(gfy, h.miny, h.inv_h), h.gy - 1);
+        const int cz = min(cell_floor(gfz, h.minz, h.inv_h), h.gz - 1);
         const int x0 = max(cx - 1, 0), x1 = min(cx + 1, h.gx - 1);
+        const bool slab = h.slab != 0; // (wave-uniform)
         // run r = the cells x0 .. x1 of row (cy + r % 3 - 1, cz + r / 3 - 1): lane s fetches runs s and s + 4, all fetch run 8
         // (no branch around the loads and all six in flight together: rows outside the grid read a clamped row and get
-        // length 0 afterwards)
+        // length 0 afterwards).  Slab grids: run r < 3 = the cells (any x, cy - 1 .. cy + 1) of z = cz + r - 1, lane s fetches run s.
         auto row_of = [&](int r, bool &inside) {
             const int r3 = r / 3;
             const int y = cy + (r - 3 * r3) - 1, z = cz + r3 - 1;
@@ -689,8 +937,18 @@ __global__ __launch_bounds__(OGC_WAVE, 8) void ball_query_cells_kernel(int n, in
             return h.gx * (min(max(y, 0), h.gy - 1) + h.gy * min(max(z, 0), h.gz - 1));
         };
         bool in_a, in_b, in_c;
-        const int row_a = row_of(sub, in_a), row_b = row_of(sub + 4, in_b), row_c = row_of(8, in_c);
-        int lo_a = cs[row_a + x0], end_a = cs[row_a + x1 + 1];
+        int row_a = row_of(sub, in_a), row_b = row_of(sub + 4, in_b), row_c = row_of(8, in_c);
+        int first_a = row_a + x0, last_a = row_a + x1 + 1;
+        if (slab) {
+            const int z = cz + sub - 1;
+            in_a = live && sub < 3 && z >= 0 && z < h.gz;
+            const int zc = min(max(z, 0), h.gz - 1);
+            first_a = h.gx * (max(cy - 1, 0) + h.gy * zc);
+            last_a = h.gx * (min(cy + 1, h.gy - 1) + h.gy * zc) + h.gx;
+            row_b = row_c = first_a - x0; // (their loads repeat lane s's first one; the runs do not exist)
+            in_b = in_c = false;
+        }
+        int lo_a = cs[first_a], end_a = cs[last_a];
         int lo_b = cs[row_b + x0], end_b = cs[row_b + x1 + 1];
         int lo_c = cs[row_c + x0], end_c = cs[row_c + x1 + 1];
         asm volatile("" : "+v"(lo_a), "+v"(end_a), "+v"(lo_b), "+v"(end_b), "+v"(lo_c), "+v"(end_c));
@@ -712,8 +970,32 @@ __global__ __launch_bounds__(OGC_WAVE, 8) void ball_query_cells_kernel(int n, in
         };
         const char *pts_bytes = reinterpret_cast<const char *>(pts);
         auto record = [&](int position) { // (positions past the end of a run are read — the array is padded — and discarded)
+#if defined(OGC_EXP) && OGC_EXP == 1
+            position = (position & 3) + pc; // experiment: the same instruction stream over trivially cached addresses
+#endif
             return *reinterpret_cast<const float4 *>(pts_bytes + ((unsigned)position << 4));
         };
+        if (slab) {
+            // three long runs, walked side by side: step t tests the candidates 8 t .. 8 t + 7 of each (six loads in flight per lane)
+            int p0 = quad_bcast<0>(lo_a), p1 = quad_bcast<1>(lo_a), p2 = quad_bcast<2>(lo_a);
+            const int hi0 = p0 + quad_bcast<0>(len_a), hi1 = p1 + quad_bcast<1>(len_a), hi2 = p2 + quad_bcast<2>(len_a);
+            p0 += sub; p1 += sub; p2 += sub;
+            const int last = n - 1;
+            for (;;) {
+                const float4 a0 = record(min(p0, last)), b0 = record(min(p0 + CL, last));
+                const float4 a1 = record(min(p1, last)), b1 = record(min(p1 + CL, last));
+                const float4 a2 = record(min(p2, last)), b2 = record(min(p2 + CL, last));
+                __builtin_amdgcn_sched_barrier(0);
+                const ogc_v2f d0 = sqdist_pair(ogc_v2f{a0.x, b0.x}, ogc_v2f{a0.y, b0.y}, ogc_v2f{a0.z, b0.z}, me.x, me.y, me.z);
+                slots(p0 < hi0, d0.x < radius2, p0 + CL < hi0, d0.y < radius2, __float_as_int(a0.w), __float_as_int(b0.w));
+                const ogc_v2f d1 = sqdist_pair(ogc_v2f{a1.x, b1.x}, ogc_v2f{a1.y, b1.y}, ogc_v2f{a1.z, b1.z}, me.x, me.y, me.z);
+                slots(p1 < hi1, d1.x < radius2, p1 + CL < hi1, d1.y < radius2, __float_as_int(a1.w), __float_as_int(b1.w));
+                const ogc_v2f d2 = sqdist_pair(ogc_v2f{a2.x, b2.x}, ogc_v2f{a2.y, b2.y}, ogc_v2f{a2.z, b2.z}, me.x, me.y, me.z);
+                slots(p2 < hi2, d2.x < radius2, p2 + CL < hi2, d2.y < radius2, __float_as_int(a2.w), __float_as_int(b2.w));
+                p0 += 2 * CL; p1 += 2 * CL; p2 += 2 * CL;
+                if (__builtin_amdgcn_ballot_w64(p0 < hi0 || p1 < hi1 || p2 < hi2) == 0ull) break;
+            }
+        } else
         // three runs at a time: six candidate loads in flight per lane
 #pragma unroll
         for (int r0 = 0; r0 < 9; r0 += 3) {
@@ -792,7 +1074,11 @@ __global__ __launch_bounds__(OGC_WAVE, 8) void ball_query_cells_kernel(int n, in
             const int first = cnt > 0 ? quad_bcast<0>(x[0]) : 0;
             int *o = idx_out + ((size_t)b * m + max(q, 0)) * NS;
             OGC_PROBE_T(pf2);
+#if defined(OGC_EXP) && OGC_EXP == 2
+            if (cnt <= BQ_FAST && q >= 0 && first == -12345) { // experiment: no row stores
+#else
             if (cnt <= BQ_FAST && q >= 0) {
+#endif
                 // lane L holds the sorted entries 8 L .. 8 L + 7.  Stores in which the group's four lanes cover 64
                 // CONTIGUOUS bytes need lane L to write entries 4 L .. 4 L + 3 (then 16 + 4 L ..): an exchange inside the
                 // quad (a store instruction whose lanes write every other 16 bytes leaves half-written lines everywhere)
@@ -854,7 +1140,7 @@ __global__ __launch_bounds__(OGC_WAVE, 8) void ball_query_cells_kernel(int n, in
     }
 #pragma unroll 1
     for (int half = 0; half < CPW / QPW; ++half)
-        ball_query_grid_body(blockIdx.x * CPW + half * QPW, gq_smem, n, m, radius2, NS, BQ_CAP, stride_cells, xyz, hdrs,
+        ball_query_grid_body(lane, grp * CPW + half * QPW, gq_smem, n, m, radius2, NS, BQ_CAP, stride_cells, xyz, hdrs,
                              cell_start, sorted_pts, idx_out);
 }
 
@@ -1070,9 +1356,10 @@ __global__ __launch_bounds__(OGC_WAVE, 4) void knn_grid_kernel(int n, int m, int
     const bool active = p < n && h.npts > 0 && qx == qx && qy == qy && qz == qz; // NaN queries select nothing
     if (active) {
         const float edge = 1.0f / h.inv_h;
-        const int cx = min(max(cell_coord(qx, h.minx, h.inv_h, h.gx), 0), h.gx - 1);
-        const int cy = min(max(cell_coord(qy, h.miny, h.inv_h, h.gy), 0), h.gy - 1);
-        const int cz = min(max(cell_coord(qz, h.minz, h.inv_h, h.gz), 0), h.gz - 1);
+        OGC_GRID_AXES(h, qx, qy, qz, fx, fy, fz);
+        const int cx = min(max(cell_coord(fx, h.minx, h.inv_h, h.gx), 0), h.gx - 1);
+        const int cy = min(max(cell_coord(fy, h.miny, h.inv_h, h.gy), 0), h.gy - 1);
+        const int cz = min(max(cell_coord(fz, h.minz, h.inv_h, h.gz), 0), h.gz - 1);
         const int rmax = max(max(max(cx, h.gx - 1 - cx), max(cy, h.gy - 1 - cy)), max(cz, h.gz - 1 - cz));
         const int R0 = limited ? 1 : 2; // radius (in cells) of the block scanned first
         for (int R = R0;; ++R) {
@@ -1264,10 +1551,12 @@ __global__ __launch_bounds__(OGC_WAVE, 8) void knn_cells_kernel(int n, float lim
 #pragma unroll
         for (int i = 0; i < BQ_FAST / CL / 2; ++i) l4[i] = inf4;
     }
-    const int cx = min(cell_floor(me.x, h.minx, h.inv_h), h.gx - 1);
-    const int cy = min(cell_floor(me.y, h.miny, h.inv_h), h.gy - 1);
-    const int cz = min(cell_floor(me.z, h.minz, h.inv_h), h.gz - 1);
+    OGC_GRID_AXES(h, me.x, me.y, me.z, gfx, gfy, gfz);
+    const int cx = min(cell_floor(gfx, h.minx, h.inv_h), h.gx - 1);
+    const int cy = min(cell_floor(gfy, h.miny, h.inv_h), h.gy - 1);
+    const int cz = min(cell_floor(gfz, h.minz, h.inv_h), h.gz - 1);
     const int x0 = max(cx - 1, 0), x1 = min(cx + 1, h.gx - 1);
+    const bool slab = h.slab != 0; // (wave-uniform; see ball_query_cells_kernel)
     auto row_of = [&](int r, bool &inside) {
         const int r3 = r / 3;
         const int y = cy + (r - 3 * r3) - 1, z = cz + r3 - 1;
@@ -1275,8 +1564,18 @@ __global__ __launch_bounds__(OGC_WAVE, 8) void knn_cells_kernel(int n, float lim
         return h.gx * (min(max(y, 0), h.gy - 1) + h.gy * min(max(z, 0), h.gz - 1));
     };
     bool in_a, in_b, in_c;
-    const int row_a = row_of(sub, in_a), row_b = row_of(sub + 4, in_b), row_c = row_of(8, in_c);
-    int lo_a = cs[row_a + x0], end_a = cs[row_a + x1 + 1];
+    int row_a = row_of(sub, in_a), row_b = row_of(sub + 4, in_b), row_c = row_of(8, in_c);
+    int first_a = row_a + x0, last_a = row_a + x1 + 1;
+    if (slab) {
+        const int z = cz + sub - 1;
+        in_a = live && sub < 3 && z >= 0 && z < h.gz;
+        const int zc = min(max(z, 0), h.gz - 1);
+        first_a = h.gx * (max(cy - 1, 0) + h.gy * zc);
+        last_a = h.gx * (min(cy + 1, h.gy - 1) + h.gy * zc) + h.gx;
+        row_b = row_c = first_a - x0;
+        in_b = in_c = false;
+    }
+    int lo_a = cs[first_a], end_a = cs[last_a];
     int lo_b = cs[row_b + x0], end_b = cs[row_b + x1 + 1];
     int lo_c = cs[row_c + x0], end_c = cs[row_c + x1 + 1];
     asm volatile("" : "+v"(lo_a), "+v"(end_a), "+v"(lo_b), "+v"(end_b), "+v"(lo_c), "+v"(end_c));
@@ -1299,6 +1598,26 @@ __global__ __launch_bounds__(OGC_WAVE, 8) void knn_cells_kernel(int n, float lim
         return *reinterpret_cast<const float4 *>(pts_bytes + ((unsigned)position << 4));
     };
     auto key_of = [](float d, float w) { return ((u64)__float_as_uint(d) << 32) | (unsigned)__float_as_int(w); };
+    if (slab) {
+        int p0 = quad_bcast<0>(lo_a), p1 = quad_bcast<1>(lo_a), p2 = quad_bcast<2>(lo_a);
+        const int hi0 = p0 + quad_bcast<0>(len_a), hi1 = p1 + quad_bcast<1>(len_a), hi2 = p2 + quad_bcast<2>(len_a);
+        p0 += sub; p1 += sub; p2 += sub;
+        const int last = n - 1;
+        for (;;) {
+            const float4 a0 = record(min(p0, last)), b0 = record(min(p0 + CL, last));
+            const float4 a1 = record(min(p1, last)), b1 = record(min(p1 + CL, last));
+            const float4 a2 = record(min(p2, last)), b2 = record(min(p2 + CL, last));
+            __builtin_amdgcn_sched_barrier(0);
+            const ogc_v2f d0 = sqdist_pair(ogc_v2f{a0.x, b0.x}, ogc_v2f{a0.y, b0.y}, ogc_v2f{a0.z, b0.z}, me.x, me.y, me.z);
+            slots(p0 < hi0, d0.x <= lim2, p0 + CL < hi0, d0.y <= lim2, key_of(d0.x, a0.w), key_of(d0.y, b0.w));
+            const ogc_v2f d1 = sqdist_pair(ogc_v2f{a1.x, b1.x}, ogc_v2f{a1.y, b1.y}, ogc_v2f{a1.z, b1.z}, me.x, me.y, me.z);
+            slots(p1 < hi1, d1.x <= lim2, p1 + CL < hi1, d1.y <= lim2, key_of(d1.x, a1.w), key_of(d1.y, b1.w));
+            const ogc_v2f d2 = sqdist_pair(ogc_v2f{a2.x, b2.x}, ogc_v2f{a2.y, b2.y}, ogc_v2f{a2.z, b2.z}, me.x, me.y, me.z);
+            slots(p2 < hi2, d2.x <= lim2, p2 + CL < hi2, d2.y <= lim2, key_of(d2.x, a2.w), key_of(d2.y, b2.w));
+            p0 += 2 * CL; p1 += 2 * CL; p2 += 2 * CL;
+            if (__builtin_amdgcn_ballot_w64(p0 < hi0 || p1 < hi1 || p2 < hi2) == 0ull) break;
+        }
+    } else
 #pragma unroll
     for (int r0 = 0; r0 < 9; r0 += 3) {
         int lo[3], hi[3];
@@ -1471,16 +1790,26 @@ int launch_ball_query(const GridLayout &L, void *grid, int b, int n, int m, floa
     const size_t lds = ((size_t)QPW * (hit_cap + nsample) + (size_t)(n + 31) / 32) * sizeof(int);
     const size_t lds_body = ((size_t)QPW * (BQ_CAP + nsample) + (size_t)(n + 31) / 32) * sizeof(int);
     const size_t lds4 = lds_body > sizeof(int) * CPW * BQ_LIST ? lds_body : sizeof(int) * CPW * BQ_LIST;
-    const dim3 grid4(ogc_divup(n, CPW), b);
+    // waves per workgroup of the four-lane kernel (a workgroup is only its unit of dispatch): OGC_BQ_WPB = 1 | 2 | 4
+    static const int wpb = [] { const char *e = getenv("OGC_BQ_WPB"); const int v = e ? atoi(e) : 1; return v == 2 || v == 4 ? v : 1; }();
+    const int lds4_ints = (int)((lds4 + 15) / 16 * 4);
+    const dim3 grid4(ogc_divup(ogc_divup(n, CPW), wpb), b);
+#define OGC_BQ_CELLS_W(NS, W)                                                                                         \
+    hipLaunchKernelGGL((ball_query_cells_kernel<NS, W>), grid4, dim3(OGC_WAVE * W), (size_t)lds4_ints * 4 * W, s, n, m, \
+                       radius * radius, stride_cells, lds4_ints, xyz, hdrs, cell_start, sorted_pts, idx)
 #define OGC_BQ_CELLS(NS)                                                                                              \
-    hipLaunchKernelGGL(ball_query_cells_kernel<NS>, grid4, dim3(OGC_WAVE), lds4, s, n, m, radius * radius, stride_cells, xyz, \
-                       hdrs, cell_start, sorted_pts, idx)
-    if (nsample == 64 && ogc_bq_cells_enabled()) OGC_BQ_CELLS(64);
-    else if (nsample == 32 && ogc_bq_cells_enabled()) OGC_BQ_CELLS(32);
-    else if (nsample == 16 && ogc_bq_cells_enabled()) OGC_BQ_CELLS(16);
+    {                                                                                                                 \
+        if (wpb == 4) OGC_BQ_CELLS_W(NS, 4);                                                                          \
+        else if (wpb == 2) OGC_BQ_CELLS_W(NS, 2);                                                                     \
+        else OGC_BQ_CELLS_W(NS, 1);                                                                                   \
+    }
+    if (nsample == 64 && ogc_bq_cells_enabled()) OGC_BQ_CELLS(64)
+    else if (nsample == 32 && ogc_bq_cells_enabled()) OGC_BQ_CELLS(32)
+    else if (nsample == 16 && ogc_bq_cells_enabled()) OGC_BQ_CELLS(16)
     else
         hipLaunchKernelGGL(ball_query_grid_kernel, dim3(ogc_divup(n, QPW), b), dim3(OGC_WAVE), lds, s, n, m,
                            radius * radius, nsample, hit_cap, stride_cells, xyz, hdrs, cell_start, sorted_pts, idx);
+#undef OGC_BQ_CELLS_W
 #undef OGC_BQ_CELLS
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
