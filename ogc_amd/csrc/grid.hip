@@ -881,8 +881,18 @@ constexpr int CL = 4;                 // lanes per centre
 constexpr int CPW = OGC_WAVE / CL;    // centres per wavefront
 constexpr int BQ_FAST = 32;           // hits per centre the register sort holds
 constexpr int BQ_CAP = 64;            // hit slots per centre (slot BQ_CAP takes the misses; also the general body's lists)
-constexpr int BQ_LIST = BQ_CAP + 4;   // list stride
-constexpr int BQ_PAD = 16;            // records readable past the end of the cell-sorted array
+constexpr int BQ_SEG = 20;            // ints per lane of a centre's LDS strip: 16 private hit slots, slot 16 takes misses / overflow
+constexpr int BQ_LIST = CL * BQ_SEG;  // ints per centre (the compacted list of up to BQ_CAP hits + sentinels lives in the same strip)
+constexpr int BQ_RUN = 128;           // longest run the slab walk takes (a longer one sends the wavefront to the general body)
+constexpr int BQ_PAD = BQ_RUN + 32;   // records readable past the end of the cell-sorted array (lanes whose run has ended read on)
+
+// 16-byte store of an output row piece, non-temporal: the rows are 33 MB that nobody in this launch reads again; as ordinary
+// stores they sit dirty in the L2s until the end-of-kernel write-back (1.6 us of the operator at the C4 loss shape).
+__device__ __forceinline__ void store_row16(int *p, int4 v) {
+    typedef int v4i_ __attribute__((ext_vector_type(4)));
+    const v4i_ vv = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(vv, reinterpret_cast<v4i_ *>(p));
+}
 
 template <int R>
 __device__ __forceinline__ int quad_bcast(int v) { // lane R of every group of four lanes
@@ -912,12 +922,13 @@ __global__ __launch_bounds__(OGC_WAVE * WPB, 8) void ball_query_cells_kernel(int
         float4 me = make_float4(NAN, NAN, NAN, __int_as_float(-1));
         if (pc < n) me = pts[pc]; // positions >= h.npts hold the non-finite points: no hits, an all-zero row
         const bool live = pc < h.npts;
-        int *mine = gq_smem + g * BQ_LIST;
-        {   // every list starts as BQ_FAST +inf keys: the sort reads all of them
+        int *mine = gq_smem + g * BQ_LIST; // the centre's strip
+        int *seg = mine + sub * BQ_SEG;    // my own hit slots
+        {   // every slot starts as +inf: the sort reads the first eight of each lane whatever was found
             const int4 inf4 = make_int4(0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff);
-            int4 *l4 = reinterpret_cast<int4 *>(mine + sub * (BQ_FAST / CL));
+            int4 *l4 = reinterpret_cast<int4 *>(seg);
 #pragma unroll
-            for (int i = 0; i < BQ_FAST / CL / 4; ++i) l4[i] = inf4;
+            for (int i = 0; i < 4; ++i) l4[i] = inf4;
         }
         // the centre's cell, as the build computed it (a live centre is finite: the conversion saturates where cell_coord
         // clamps, and the clamp to the grid follows either way)
@@ -954,47 +965,48 @@ __global__ __launch_bounds__(OGC_WAVE * WPB, 8) void ball_query_cells_kernel(int
         asm volatile("" : "+v"(lo_a), "+v"(end_a), "+v"(lo_b), "+v"(end_b), "+v"(lo_c), "+v"(end_c));
         const int len_a = in_a ? end_a - lo_a : 0, len_b = in_b ? end_b - lo_b : 0, len_c = in_c ? end_c - lo_c : 0;
 
-        int cnt = 0; // hits of my centre (the same number in its four lanes)
-        const unsigned below_a = (1u << sub) - 1u, below_b = 0xFu | (below_a << 4);
-        const int shift = CL * g;
-        // in_* / near_*: a candidate exists at that position / lies inside the ball.  The masks come straight from the
-        // comparisons (a ballot of their conjunction is lowered through a 0/1 register and a third comparison).
+        // Every lane appends ITS hits to ITS sixteen slots — no ballot, no slot arithmetic across the group (that was ~13 of
+        // the ~26 vector instructions a tested candidate cost); a miss is stored to slot 16 instead of branching, and so is
+        // the seventeenth hit of a lane (the count goes on: such a wavefront is redone by the general body).
+        int cnt_l = 0; // my hits
+        bool crowded = false; // (wave-uniform) a single centre's candidates do not fit the LDS strip: the general body takes over
         auto slots = [&](bool has_a, bool near_a, bool has_b, bool near_b, int ia, int ib) {
-            const unsigned long long ma = __builtin_amdgcn_ballot_w64(has_a) & __builtin_amdgcn_ballot_w64(near_a);
-            const unsigned long long mb = __builtin_amdgcn_ballot_w64(has_b) & __builtin_amdgcn_ballot_w64(near_b);
-            const unsigned bits = ((unsigned)(ma >> shift) & 0xFu) | (((unsigned)(mb >> shift) & 0xFu) << 4);
-            const int sa = cnt + __popc(bits & below_a), sb = cnt + __popc(bits & below_b);
-            mine[(has_a && near_a) ? min(sa, BQ_CAP) : BQ_CAP] = ia;
-            mine[(has_b && near_b) ? min(sb, BQ_CAP) : BQ_CAP] = ib;
-            cnt += __popc(bits);
+            const bool hit_a = has_a && near_a, hit_b = has_b && near_b;
+            seg[hit_a ? min(cnt_l, 16) : 16] = ia;
+            cnt_l += hit_a ? 1 : 0;
+            seg[hit_b ? min(cnt_l, 16) : 16] = ib;
+            cnt_l += hit_b ? 1 : 0;
         };
         const char *pts_bytes = reinterpret_cast<const char *>(pts);
         auto record = [&](int position) { // (positions past the end of a run are read — the array is padded — and discarded)
-#if defined(OGC_EXP) && OGC_EXP == 1
-            position = (position & 3) + pc; // experiment: the same instruction stream over trivially cached addresses
-#endif
             return *reinterpret_cast<const float4 *>(pts_bytes + ((unsigned)position << 4));
         };
         if (slab) {
-            // three long runs, walked side by side: step t tests the candidates 8 t .. 8 t + 7 of each (six loads in flight per lane)
-            int p0 = quad_bcast<0>(lo_a), p1 = quad_bcast<1>(lo_a), p2 = quad_bcast<2>(lo_a);
-            const int hi0 = p0 + quad_bcast<0>(len_a), hi1 = p1 + quad_bcast<1>(len_a), hi2 = p2 + quad_bcast<2>(len_a);
-            p0 += sub; p1 += sub; p2 += sub;
-            const int last = n - 1;
-            for (;;) {
-                const float4 a0 = record(min(p0, last)), b0 = record(min(p0 + CL, last));
-                const float4 a1 = record(min(p1, last)), b1 = record(min(p1 + CL, last));
-                const float4 a2 = record(min(p2, last)), b2 = record(min(p2 + CL, last));
-                __builtin_amdgcn_sched_barrier(0);
-                const ogc_v2f d0 = sqdist_pair(ogc_v2f{a0.x, b0.x}, ogc_v2f{a0.y, b0.y}, ogc_v2f{a0.z, b0.z}, me.x, me.y, me.z);
-                slots(p0 < hi0, d0.x < radius2, p0 + CL < hi0, d0.y < radius2, __float_as_int(a0.w), __float_as_int(b0.w));
-                const ogc_v2f d1 = sqdist_pair(ogc_v2f{a1.x, b1.x}, ogc_v2f{a1.y, b1.y}, ogc_v2f{a1.z, b1.z}, me.x, me.y, me.z);
-                slots(p1 < hi1, d1.x < radius2, p1 + CL < hi1, d1.y < radius2, __float_as_int(a1.w), __float_as_int(b1.w));
-                const ogc_v2f d2 = sqdist_pair(ogc_v2f{a2.x, b2.x}, ogc_v2f{a2.y, b2.y}, ogc_v2f{a2.z, b2.z}, me.x, me.y, me.z);
-                slots(p2 < hi2, d2.x < radius2, p2 + CL < hi2, d2.y < radius2, __float_as_int(a2.w), __float_as_int(b2.w));
-                p0 += 2 * CL; p1 += 2 * CL; p2 += 2 * CL;
-                if (__builtin_amdgcn_ballot_w64(p0 < hi0 || p1 < hi1 || p2 < hi2) == 0ull) break;
-            }
+            // three long runs, walked side by side: step t tests the candidates 8 t .. 8 t + 7 of each (six loads in flight per
+            // lane).  Positions are kept as byte offsets; a lane whose runs have ended keeps reading while others in the wavefront
+            // go on — at most BQ_RUN records past a run's end: the next cloud's records or the padding behind the last cloud.
+            crowded = __builtin_amdgcn_ballot_w64(len_a > BQ_RUN) != 0ull;
+            const int b0 = quad_bcast<0>(in_a ? lo_a : 0), b1 = quad_bcast<1>(in_a ? lo_a : 0), b2 = quad_bcast<2>(in_a ? lo_a : 0);
+            const unsigned e0 = (unsigned)(b0 + quad_bcast<0>(len_a)) << 4, e1 = (unsigned)(b1 + quad_bcast<1>(len_a)) << 4,
+                           e2 = (unsigned)(b2 + quad_bcast<2>(len_a)) << 4;
+            unsigned q0 = (unsigned)(b0 + sub) << 4, q1 = (unsigned)(b1 + sub) << 4, q2 = (unsigned)(b2 + sub) << 4;
+            auto rec = [&](unsigned byte_offset) { return *reinterpret_cast<const float4 *>(pts_bytes + byte_offset); };
+            constexpr unsigned NEXT = CL * 16u; // my second candidate of a step
+            if (!crowded)
+                for (;;) {
+                    const float4 a0 = rec(q0), c0 = rec(q0 + NEXT);
+                    const float4 a1 = rec(q1), c1 = rec(q1 + NEXT);
+                    const float4 a2 = rec(q2), c2 = rec(q2 + NEXT);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const ogc_v2f d0 = sqdist_pair(ogc_v2f{a0.x, c0.x}, ogc_v2f{a0.y, c0.y}, ogc_v2f{a0.z, c0.z}, me.x, me.y, me.z);
+                    slots(q0 < e0, d0.x < radius2, q0 + NEXT < e0, d0.y < radius2, __float_as_int(a0.w), __float_as_int(c0.w));
+                    const ogc_v2f d1 = sqdist_pair(ogc_v2f{a1.x, c1.x}, ogc_v2f{a1.y, c1.y}, ogc_v2f{a1.z, c1.z}, me.x, me.y, me.z);
+                    slots(q1 < e1, d1.x < radius2, q1 + NEXT < e1, d1.y < radius2, __float_as_int(a1.w), __float_as_int(c1.w));
+                    const ogc_v2f d2 = sqdist_pair(ogc_v2f{a2.x, c2.x}, ogc_v2f{a2.y, c2.y}, ogc_v2f{a2.z, c2.z}, me.x, me.y, me.z);
+                    slots(q2 < e2, d2.x < radius2, q2 + NEXT < e2, d2.y < radius2, __float_as_int(a2.w), __float_as_int(c2.w));
+                    q0 += 2 * NEXT; q1 += 2 * NEXT; q2 += 2 * NEXT;
+                    if (__builtin_amdgcn_ballot_w64(q0 < e0 || q1 < e1 || q2 < e2) == 0ull) break;
+                }
         } else
         // three runs at a time: six candidate loads in flight per lane
 #pragma unroll
@@ -1036,12 +1048,36 @@ __global__ __launch_bounds__(OGC_WAVE * WPB, 8) void ball_query_cells_kernel(int
             }
         }
         OGC_PROBE_T(pt1);
-        general = __builtin_amdgcn_ballot_w64(cnt > BQ_CAP) != 0ull;
+        // hits of my centre (the same number in its four lanes)
+        int cnt = cnt_l + __builtin_amdgcn_update_dpp(0, cnt_l, 0xB1, 0xF, 0xF, true); // quad_perm [1,0,3,2]
+        cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x4E, 0xF, 0xF, true);               // quad_perm [2,3,0,1]
+        general = crowded || __builtin_amdgcn_ballot_w64(cnt > BQ_CAP || cnt_l > 16) != 0ull;
         if (!general) {
             __builtin_amdgcn_s_waitcnt(0xc07f);
             __builtin_amdgcn_wave_barrier();
-            const int4 k0 = *reinterpret_cast<const int4 *>(mine + sub * 8);
-            const int4 k1 = *reinterpret_cast<const int4 *>(mine + sub * 8 + 4);
+            int4 k0 = *reinterpret_cast<const int4 *>(seg);
+            int4 k1 = *reinterpret_cast<const int4 *>(seg + 4);
+            // The sort below takes eight keys per lane.  A lane with more than eight hits (one wavefront in ~8 on the C4 scenes),
+            // or a centre with more than BQ_FAST: the four lanes' hits are first moved to the front of the centre's strip, one
+            // after the other — the list the long-list code further down expects — and read back eight per lane.
+            if (__builtin_amdgcn_ballot_w64(cnt_l > 8 || cnt > BQ_FAST) != 0ull) {
+                const int4 k2 = *reinterpret_cast<const int4 *>(seg + 8);
+                const int4 k3 = *reinterpret_cast<const int4 *>(seg + 12);
+                const int own[16] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w, k2.x, k2.y, k2.z, k2.w, k3.x, k3.y, k3.z, k3.w};
+                const int c0 = quad_bcast<0>(cnt_l), c1 = quad_bcast<1>(cnt_l), c2 = quad_bcast<2>(cnt_l);
+                const int before = (sub > 0 ? c0 : 0) + (sub > 1 ? c1 : 0) + (sub > 2 ? c2 : 0);
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier(); // everybody has read its slots
+                int *spare = mine + BQ_CAP + sub;  // (a write nobody reads)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) *(r < cnt_l ? mine + before + r : spare) = own[r];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) *(sub * 8 + r >= cnt ? mine + sub * 8 + r : spare) = 0x7fffffff;
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
+                k0 = *reinterpret_cast<const int4 *>(mine + sub * 8);
+                k1 = *reinterpret_cast<const int4 *>(mine + sub * 8 + 4);
+            }
             int x[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w};
             // bitonic network, element e = 8 * lane + register, every exchange ascending (each merge starts with the
             // "flip" e <-> e ^ (k - 1), then half-cleaners e <-> e ^ j)
@@ -1074,11 +1110,7 @@ __global__ __launch_bounds__(OGC_WAVE * WPB, 8) void ball_query_cells_kernel(int
             const int first = cnt > 0 ? quad_bcast<0>(x[0]) : 0;
             int *o = idx_out + ((size_t)b * m + max(q, 0)) * NS;
             OGC_PROBE_T(pf2);
-#if defined(OGC_EXP) && OGC_EXP == 2
-            if (cnt <= BQ_FAST && q >= 0 && first == -12345) { // experiment: no row stores
-#else
             if (cnt <= BQ_FAST && q >= 0) {
-#endif
                 // lane L holds the sorted entries 8 L .. 8 L + 7.  Stores in which the group's four lanes cover 64
                 // CONTIGUOUS bytes need lane L to write entries 4 L .. 4 L + 3 (then 16 + 4 L ..): an exchange inside the
                 // quad (a store instruction whose lanes write every other 16 bytes leaves half-written lines everywhere)
@@ -1096,11 +1128,11 @@ __global__ __launch_bounds__(OGC_WAVE * WPB, 8) void ball_query_cells_kernel(int
                     s2[r] = odd ? b2 : a2;
                 }
                 const int j0 = sub * 4;
-                if (j0 < NS) *reinterpret_cast<int4 *>(o + j0) = make_int4(s1[0], s1[1], s1[2], s1[3]);
-                if (16 + j0 < NS) *reinterpret_cast<int4 *>(o + 16 + j0) = make_int4(s2[0], s2[1], s2[2], s2[3]);
+                if (j0 < NS) store_row16(o + j0, make_int4(s1[0], s1[1], s1[2], s1[3]));
+                if (16 + j0 < NS) store_row16(o + 16 + j0, make_int4(s2[0], s2[1], s2[2], s2[3]));
                 const int4 pad = make_int4(first, first, first, first);
 #pragma unroll
-                for (int j = BQ_FAST; j < NS; j += 16) *reinterpret_cast<int4 *>(o + j + j0) = pad;
+                for (int j = BQ_FAST; j < NS; j += 16) store_row16(o + j + j0, pad);
             }
             // lists of 33 .. BQ_CAP hits (rare where this kernel is used), one at a time by the WHOLE wavefront: lane e takes
             // element e, its rank is #{f : hits[f] < hits[e]} (distinct indices) from broadcast 16-byte reads of the list,
@@ -1789,7 +1821,8 @@ int launch_ball_query(const GridLayout &L, void *grid, int b, int n, int m, floa
     const int hit_cap = nsample > 64 ? nsample : 64;
     const size_t lds = ((size_t)QPW * (hit_cap + nsample) + (size_t)(n + 31) / 32) * sizeof(int);
     const size_t lds_body = ((size_t)QPW * (BQ_CAP + nsample) + (size_t)(n + 31) / 32) * sizeof(int);
-    const size_t lds4 = lds_body > sizeof(int) * CPW * BQ_LIST ? lds_body : sizeof(int) * CPW * BQ_LIST;
+    const size_t lds_cells = sizeof(int) * CPW * BQ_LIST;
+    const size_t lds4 = lds_body > lds_cells ? lds_body : lds_cells;
     // waves per workgroup of the four-lane kernel (a workgroup is only its unit of dispatch): OGC_BQ_WPB = 1 | 2 | 4
     static const int wpb = [] { const char *e = getenv("OGC_BQ_WPB"); const int v = e ? atoi(e) : 1; return v == 2 || v == 4 ? v : 1; }();
     const int lds4_ints = (int)((lds4 + 15) / 16 * 4);
@@ -1803,9 +1836,10 @@ int launch_ball_query(const GridLayout &L, void *grid, int b, int n, int m, floa
         else if (wpb == 2) OGC_BQ_CELLS_W(NS, 2);                                                                     \
         else OGC_BQ_CELLS_W(NS, 1);                                                                                   \
     }
-    if (nsample == 64 && ogc_bq_cells_enabled()) OGC_BQ_CELLS(64)
-    else if (nsample == 32 && ogc_bq_cells_enabled()) OGC_BQ_CELLS(32)
-    else if (nsample == 16 && ogc_bq_cells_enabled()) OGC_BQ_CELLS(16)
+    const bool cells = ogc_bq_cells_enabled();
+    if (nsample == 64 && cells) OGC_BQ_CELLS(64)
+    else if (nsample == 32 && cells) OGC_BQ_CELLS(32)
+    else if (nsample == 16 && cells) OGC_BQ_CELLS(16)
     else
         hipLaunchKernelGGL(ball_query_grid_kernel, dim3(ogc_divup(n, QPW), b), dim3(OGC_WAVE), lds, s, n, m,
                            radius * radius, nsample, hit_cap, stride_cells, xyz, hdrs, cell_start, sorted_pts, idx);
