@@ -58,6 +58,16 @@ __device__ __forceinline__ int cell_floor(float x, float mn, float inv_h) {
     return (int)__builtin_amdgcn_fmed3f(floorf((x - mn) * inv_h), 0.0f, 1.0e9f);
 }
 
+// min(max(floor((x - mn) * inv_h), 0), g - 1) in four instructions: subtract, multiply (the same two roundings as cell_floor),
+// convert with floor rounding (saturating; NaN -> 0) and an integer median.  Equal to min(cell_floor(x, mn, inv_h), g - 1).
+__device__ __forceinline__ int cell_clamped(float x, float mn, float inv_h, int g) {
+    const float q = (x - mn) * inv_h;
+    int c, r;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(c) : "v"(q));
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(c), "v"(g - 1));
+    return r;
+}
+
 // a point's coordinates along the grid's (fast, mid, slow) axes (GridHdr::fast; wave-uniform selects)
 #define OGC_GRID_AXES(H, X, Y, Z, FX, FY, FZ)                                                    \
     const float FX = (H).fast == 0 ? (X) : ((H).fast == 1 ? (Y) : (Z)), FY = (H).fast == 0 ? (Y) : (X), \
@@ -412,36 +422,61 @@ __global__ __launch_bounds__(BUILD_THREADS) void grid_build_split_kernel(float k
             if (k < n) { px[i] = pts[k * 3]; py[i] = pts[k * 3 + 1]; pz[i] = pts[k * 3 + 2]; }
         }
     }
-    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int c = t; c < SPLIT_CELLS; c += BUILD_THREADS) s_cnt[c] = 0; // overlaps the loads
+    for (int c = t; c < SPLIT_CELLS; c += BUILD_THREADS) s_cnt[c] = 0;
+    // bounding box: minima / maxima of ALL coordinates first (v_min3 / v_max3 ignore NaNs; a point with one NaN coordinate lends
+    // its other two, which only widens the box) — three instructions per point instead of twelve.  An infinite coordinate shows
+    // in the result; then (once, all workgroups of the cloud alike) the box is taken again over the finite points only.
+    bool filtered = false;
+    for (;;) {
+        float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+        if (!filtered) {
 #pragma unroll
-    for (int i = 0; i < PPT; ++i) {
-        const float x = px[i], y = py[i], z = pz[i];
-        if (isfinite(x) && isfinite(y) && isfinite(z)) {
-            mn[0] = fminf(mn[0], x); mn[1] = fminf(mn[1], y); mn[2] = fminf(mn[2], z);
-            mx[0] = fmaxf(mx[0], x); mx[1] = fmaxf(mx[1], y); mx[2] = fmaxf(mx[2], z);
+            for (int i = 0; i < PPT; i += 2) {
+                mn[0] = ogc_min3_f32(mn[0], px[i], px[i + 1]); mx[0] = ogc_max3_f32(mx[0], px[i], px[i + 1]);
+                mn[1] = ogc_min3_f32(mn[1], py[i], py[i + 1]); mx[1] = ogc_max3_f32(mx[1], py[i], py[i + 1]);
+                mn[2] = ogc_min3_f32(mn[2], pz[i], pz[i + 1]); mx[2] = ogc_max3_f32(mx[2], pz[i], pz[i + 1]);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < PPT; ++i) {
+                const float x = px[i], y = py[i], z = pz[i];
+                if (isfinite(x) && isfinite(y) && isfinite(z)) {
+                    mn[0] = fminf(mn[0], x); mn[1] = fminf(mn[1], y); mn[2] = fminf(mn[2], z);
+                    mx[0] = fmaxf(mx[0], x); mx[1] = fmaxf(mx[1], y); mx[2] = fmaxf(mx[2], z);
+                }
+            }
         }
-    }
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        const float lo = -ogc_wave_max_f32(-mn[a]), hi = ogc_wave_max_f32(mx[a]);
-        if (lane == 0) { s_red[a][wave] = lo; s_red[3 + a][wave] = hi; }
-    }
-    OGC_PROBE_BUILD(1);
-    __syncthreads();
-    OGC_PROBE_BUILD(2);
-    if (wave == 0) {
-        float lo[3], hi[3];
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            const float l = lane < BUILD_THREADS / 64 ? s_red[a][lane] : INFINITY;
-            const float u = lane < BUILD_THREADS / 64 ? s_red[3 + a][lane] : -INFINITY;
-            lo[a] = -ogc_wave_max_f32(-l);
-            hi[a] = ogc_wave_max_f32(u);
+            const float lo = -ogc_wave_max_f32(-mn[a]), hi = ogc_wave_max_f32(mx[a]);
+            if (lane == 0) { s_red[a][wave] = lo; s_red[3 + a][wave] = hi; }
         }
-        if (lane == 0) s_hdr = grid_header(lo, hi, n, radius, knn_k, knn_div, prefer_cells);
+        OGC_PROBE_BUILD(1);
+        __syncthreads();
+        OGC_PROBE_BUILD(2);
+        if (wave == 0) {
+            float lo[3], hi[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float l = lane < BUILD_THREADS / 64 ? s_red[a][lane] : INFINITY;
+                const float u = lane < BUILD_THREADS / 64 ? s_red[3 + a][lane] : -INFINITY;
+                lo[a] = -ogc_wave_max_f32(-l);
+                hi[a] = ogc_wave_max_f32(u);
+            }
+            if (lane == 0) {
+                // (an empty box — no finite coordinate at all — keeps its +inf / -inf and needs no second look)
+                const bool infinite = lo[0] <= hi[0] && !(fabsf(lo[0]) < INFINITY && fabsf(lo[1]) < INFINITY && fabsf(lo[2]) < INFINITY &&
+                                                          fabsf(hi[0]) < INFINITY && fabsf(hi[1]) < INFINITY && fabsf(hi[2]) < INFINITY);
+                s_hdr = grid_header(lo, hi, n, radius, knn_k, knn_div, prefer_cells);
+                s_hdr.pending = (infinite && !filtered) ? 1 : 0; // (borrowed as the "take the box again" flag; 0 when the loop ends)
+            }
+        }
+        __syncthreads();
+        if (s_hdr.pending == 0) break;
+        filtered = true;
+        __syncthreads(); // everybody has read the flag before lane 0 writes the header again
     }
-    __syncthreads();
+    // (the loop ends behind a barrier: the header is visible)
     OGC_PROBE_BUILD(3);
     GridHdr h = s_hdr;
     const int ncell = h.gx * h.gy * h.gz;
@@ -454,10 +489,10 @@ __global__ __launch_bounds__(BUILD_THREADS) void grid_build_split_kernel(float k
     for (int i = 0; i < PPT; ++i) {
         const float x = px[i], y = py[i], z = pz[i];
         OGC_GRID_AXES(h, x, y, z, fx, fy, fz);
-        const int cx = min(cell_floor(fx, h.minx, h.inv_h), h.gx - 1);
-        const int cy = min(cell_floor(fy, h.miny, h.inv_h), h.gy - 1);
-        const int cz = min(cell_floor(fz, h.minz, h.inv_h), h.gz - 1);
-        const bool fin = isfinite(x) && isfinite(y) && isfinite(z);
+        const int cx = cell_clamped(fx, h.minx, h.inv_h, h.gx);
+        const int cy = cell_clamped(fy, h.miny, h.inv_h, h.gy);
+        const int cz = cell_clamped(fz, h.minz, h.inv_h, h.gz);
+        const bool fin = fabsf(x) < INFINITY && fabsf(y) < INFINITY && fabsf(z) < INFINITY;
         const int c = (point_index(i) < n) ? (fin ? cx + h.gx * (cy + h.gy * cz) : -1) : -2;
         cell[i] = c;
         counts += (c >= 0 ? 1 : 0) + ((c >= 0 && c < c_lo) ? 0x10000 : 0);

@@ -71,6 +71,12 @@ __device__ __forceinline__ float ogc_min_f32(float a, float b) {
     return r;
 }
 
+__device__ __forceinline__ float ogc_max3_f32(float a, float b, float c) { // NaN operands are ignored, as by v_min3
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 __device__ __forceinline__ float ogc_min3_f32(float a, float b, float c) {
     float r;
     asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
