@@ -7,7 +7,8 @@
 One "step" = `Trainer._train_it` of the reference (train_seg.py:47-86) on config C4 (SURVEY.md §8,
 config/seg/kittisf/kittisf_unsup.yaml): per GPU 4 samples x 4 views (2 frames + 2 augmented) of 8192 points,
 MaskFormer3D(segnet_kitti) forward on 16 clouds, UnsupervisedOGCLoss with all three terms active, backward,
-NaN-gradient check, Adam step.  Inputs are synthetic, seeded and already resident in HBM.  Weak scaling: every
+NaN-gradient check, Adam step.  Inputs are synthetic and seeded: four distinct batches, resident in HBM, rotated through the
+timed steps (the same steps with the host-to-device copy of every batch inside: `ms_per_step_with_h2d`).  Weak scaling: every
 rank has its own batch; gradients are averaged over RCCL by one flat ~2.4 MB all-reduce per step (utils/dist_util.py).
 
 Rank 0 prints ONE JSON line: value = whole-job point-clouds/s.  `roofline` is measured live (HIP events on the
@@ -86,6 +87,94 @@ def cpu_baseline(npoint):
                       "(OpenMP), %.1f s" % (npoint, dt)}
 
 
+def cpu_ops(pc_dev):
+    """BASELINE.md 3 / SURVEY 8d: each operator of the path on the host (the oracle: single thread and OpenMP over all cores)
+    and on the GPU, on the SAME tensors — one 8192-point cloud of the timed batch — median of 5 runs each.  B = 1 keeps the
+    single-thread scans to seconds; at B = 1 the GPU operators are launch-latency-bound (tools/bench_ops.py has the batched
+    table), so the ratio understates the batched GPU rate."""
+    import statistics
+    import numpy as np
+    from oracle import oracle as orc
+    from ogc_amd import pointnet2_cuda as nat
+    pc1 = pc_dev[:1].contiguous()
+    N = pc1.shape[1]
+    host = pc1.cpu().numpy()
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    teams = sorted({t for t in (8, 32, cores) if t <= cores})  # OpenMP team sizes tried (the operators are milliseconds long:
+                                                               # waking 256 threads costs more than most of them take)
+
+    def med(fn, reps=5):
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        return statistics.median(ts)
+
+    def gpu_med(fn, reps=5):
+        ts = []
+        fn()
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        return statistics.median(ts)
+
+    fps_idx = orc.fps(host, 2048)
+    centres = np.take_along_axis(host, fps_idx[:, :, None].astype(np.int64), 1)
+    cen_dev = torch.from_numpy(centres).to(pc1.device)
+    feats = np.random.default_rng(0).standard_normal((1, 64, 2048), dtype=np.float32)
+    nn_d, nn_i = orc.three_nn(host, centres)
+    w = (1.0 / (nn_d + 1e-8)); w = (w / w.sum(-1, keepdims=True)).astype(np.float32)
+    kidx = orc.knn(32, host, host)[1]
+    f_dev, i3_dev, w_dev = torch.from_numpy(feats).to(pc1.device), torch.from_numpy(nn_i).to(pc1.device), torch.from_numpy(w).to(pc1.device)
+    k_dev = torch.from_numpy(kidx).to(pc1.device)
+    m10 = np.random.default_rng(1).standard_normal((1, 10, N), dtype=np.float32)
+    m_dev = torch.from_numpy(m10).to(pc1.device)
+    d32 = torch.empty(1, N, 32, device=pc1.device); i32 = torch.empty(1, N, 32, dtype=torch.int32, device=pc1.device)
+    i64 = torch.zeros(1, N, 64, dtype=torch.int32, device=pc1.device)
+    d3 = torch.empty(1, N, 3, device=pc1.device); i3 = torch.empty(1, N, 3, dtype=torch.int32, device=pc1.device)
+    tmp = torch.empty(1, N, device=pc1.device); fi = torch.empty(1, 2048, dtype=torch.int32, device=pc1.device)
+    out_i = torch.empty(1, 64, N, device=pc1.device); out_g = torch.empty(1, 10, N, 32, device=pc1.device)
+
+    def fps_gpu():
+        tmp.fill_(1e10)
+        nat.furthest_point_sampling_wrapper(1, N, 2048, pc1, tmp, fi)
+
+    table = {
+        "furthest_point_sampling (8192 -> 2048)": (lambda: orc.fps(host, 2048), fps_gpu),
+        "knn (8192 <- 8192, k=32)": (lambda: orc.knn(32, host, host), lambda: nat.knn_wrapper(1, N, N, 32, pc1, pc1, d32, i32)),
+        "ball_query (8192 x 8192, r=2, nsample=64)": (lambda: orc.ball_query(2.0, 64, host, host),
+                                                       lambda: nat.ball_query_wrapper(1, N, N, 2.0, 64, pc1, pc1, i64)),
+        "three_nn (8192 <- 2048)": (lambda: orc.three_nn(host, centres), lambda: nat.three_nn_wrapper(1, N, 2048, pc1, cen_dev, d3, i3)),
+        "three_interpolate (C=64, 2048 -> 8192)": (lambda: orc.three_interpolate(feats, nn_i, w),
+                                                   lambda: nat.three_interpolate_wrapper(1, 64, 2048, N, f_dev, i3_dev, w_dev, out_i)),
+        "group_points (C=10, 8192 x 32)": (lambda: orc.group(m10, kidx), lambda: nat.group_points_wrapper(1, 10, N, N, 32, m_dev, k_dev, out_g)),
+    }
+    rows = {}
+    prev = orc.get_threads()
+    try:
+        for name, (cpu_fn, gpu_fn) in table.items():
+            orc.set_threads(1)
+            one = med(cpu_fn)
+            best = None
+            for t in teams:
+                orc.set_threads(t)
+                cpu_fn()  # (the team is created on the first call)
+                ms = med(cpu_fn)
+                if best is None or ms < best[0]:
+                    best = (ms, t)
+            rows[name] = {"cpu_1_thread_ms": round(one, 3), "cpu_openmp_ms": round(best[0], 3), "openmp_threads": best[1],
+                          "gpu_ms": round(gpu_med(gpu_fn), 4)}
+    finally:
+        orc.set_threads(prev)
+    return {"ops": rows, "cores_available": cores, "openmp_teams_tried": teams, "reps": 5, "statistic": "median",
+            "tensors": "one cloud (B = 1) of the timed batch; GPU times are host-synchronised wall times of one call (launch latency included)",
+            "kind": "port (oracle/ogc_oracle.c, the CPU restatement of pointnet2/src/*.cu; the reference has no CPU path)"}
+
+
 def _event_pair_floor(n=64):
     """What a pair of HIP events reads with NOTHING between them on the current stream (ms): the floor of every per-launch
     event measurement of LaunchTimer (two marker packets).  Minimum over `n` pairs on an otherwise idle GPU."""
@@ -113,6 +202,45 @@ def _time(fn, iters=20, warm=3):
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters
+
+
+def steps_with_h2d(model, crit, opt, host_batches, it, train_step, dev, steps=12, warm=3):
+    """The timed loop again with the loader's half of the boundary inside: every batch is copied from pinned host memory into one
+    of three device slots on a copy stream, two steps before the step that trains on it (the step in between prefetches its
+    geometry).  A slot is overwritten only after the step that trained on it has finished (event on the launch stream)."""
+    copy = torch.cuda.Stream(device=dev)
+    slots = [tuple(torch.empty(t.shape, dtype=t.dtype, device=dev) for t in host_batches[0]) for _ in range(3)]
+    done, ready = [None] * 3, [None] * 3
+
+    def upload(j):
+        s = j % 3
+        if done[s] is not None:
+            copy.wait_event(done[s])
+        with torch.cuda.stream(copy):
+            for d, h in zip(slots[s], host_batches[j % len(host_batches)]):
+                d.copy_(h, non_blocking=True)
+            ready[s] = torch.cuda.Event()
+            ready[s].record(copy)
+
+    main = torch.cuda.current_stream(dev)
+    upload(0)
+    upload(1)
+    main.wait_event(ready[0])
+    pre, t1 = None, None
+    for j in range(warm + steps):
+        if j == warm:
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+        upload(j + 2)
+        main.wait_event(ready[(j + 1) % 3])
+        pre = train_step(model, crit, opt, slots[j % 3], it, True, sync=False, prefetched=pre, next_batch=slots[(j + 1) % 3]).prefetched
+        done[j % 3] = torch.cuda.Event()
+        done[j % 3].record(main)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t1) / steps * 1e3
+    nbytes = sum(t.numel() * t.element_size() for t in host_batches[0])
+    return round(ms, 3), ("%d steps after the timed region; each batch (%.2f MB: clouds, flows, labels, valid flags) is copied from "
+                          "pinned host memory on a copy stream two steps ahead of its use" % (steps, nbytes / 1e6))
 
 
 def measure_extras(pc, a):
@@ -218,7 +346,16 @@ def main():
         model = FlatDataParallel(net)
     crit = build_criterion(KITTI_LOSS)
     opt = make_optimizer(net.parameters(), lr=1e-3, weight_decay=0.0)
-    batch = make_scene_batch(a.batch, a.npoint, 10, seed=1234 + rank, outdoor=True, aug=True, device=dev)
+    # NB distinct synthetic batches, generated on the host (pinned) and uploaded BEFORE the timed region: the timed steps rotate
+    # through them, so the batch a step prefetches geometry for really is the next one (different clouds, different FPS tie
+    # records), and `value` is measured with the inputs resident in HBM.  ms_per_step_with_h2d (an extra, after the timed region)
+    # repeats the steps with every batch copied from pinned host memory on a copy stream two steps ahead.
+    NB = 4
+    host_batches = [tuple(t.pin_memory() for t in make_scene_batch(a.batch, a.npoint, 10, seed=1234 + rank + 101 * j, outdoor=True,
+                                                                     aug=True))
+                    for j in range(NB)]
+    batches = [tuple(t.to(dev) for t in hb) for hb in host_batches]
+    batch = batches[0]
     clouds_per_step = a.batch * 4
 
     def sync():
@@ -231,8 +368,11 @@ def main():
     # also queues the network's coordinate-only work (FPS / kNN / 3-NN) of the FOLLOWING step on a side stream and consumes
     # the plan made during the previous step: one plan is computed per step, inside the timed region, none is reused.
     pre = None
+    step_no = 0
     for _ in range(a.warmup):
-        pre = train_step(model, crit, opt, batch, it, True, sync=False, prefetched=pre, next_batch=batch).prefetched
+        pre = train_step(model, crit, opt, batches[step_no % NB], it, True, sync=False, prefetched=pre,
+                         next_batch=batches[(step_no + 1) % NB]).prefetched
+        step_no += 1
     sync()
     if hasattr(model, "time_collectives"):
         model.time_collectives(True)
@@ -247,8 +387,10 @@ def main():
                 torch.cuda._sleep(1000)
             # sync=False: the step's scalars (losses, NaN flag) travel to the host asynchronously and are read after
             # the timed region; every step still computes and copies them
-            pending = train_step(model, crit, opt, batch, it, True, sync=False, prefetched=pre, next_batch=batch)
+            pending = train_step(model, crit, opt, batches[step_no % NB], it, True, sync=False, prefetched=pre,
+                                 next_batch=batches[(step_no + 1) % NB])
             pre = pending.prefetched
+            step_no += 1
         sync()
         elapsed = time.perf_counter() - t0
     loss_dict, stepped = pending.result()
@@ -269,20 +411,21 @@ def main():
         isolated_ms = _time(lambda: ball_query(bl["radius"], bl["k"], pc, pc))
         pair_floor_ms = _event_pair_floor()
         extras = measure_extras(pc, a)
+        extras["ms_per_step_with_h2d"], extras["h2d_note"] = steps_with_h2d(model, crit, opt, host_batches, it, train_step, dev)
         # steps with the FPS chain shortcut off: every encoder level runs all its sampling rounds, as it must for clouds
         # with duplicated points (synthetic uniform clouds are tie-free, so levels 2-3 cost ~10 us in the headline)
         import ogc_amd.utils.pointnet2_util as sa_util
         sa_util.FPS_CHAIN_SHORTCUT = False
         try:
             pre2 = None
-            for _ in range(2):
-                pre2 = train_step(model, crit, opt, batch, it, True, sync=False, prefetched=pre2, next_batch=batch).prefetched
+            for j in range(2 + 8):
+                if j == 2:
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                pre2 = train_step(model, crit, opt, batches[j % NB], it, True, sync=False, prefetched=pre2,
+                                  next_batch=batches[(j + 1) % NB]).prefetched
             torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(5):
-                pre2 = train_step(model, crit, opt, batch, it, True, sync=False, prefetched=pre2, next_batch=batch).prefetched
-            torch.cuda.synchronize()
-            extras["ms_per_step_all_fps_rounds"] = round((time.perf_counter() - t1) / 5 * 1e3, 3)
+            extras["ms_per_step_all_fps_rounds"] = round((time.perf_counter() - t1) / 8 * 1e3, 3)
         finally:
             sa_util.FPS_CHAIN_SHORTCUT = True
         if world == 1 and not dist.is_initialized():
@@ -405,6 +548,10 @@ def main():
                                  "note": "events on the launch stream around the collective, rank 0, inside the timed steps"}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.npoint)
+            try:
+                out["cpu_ops"] = cpu_ops(torch.cat([batch[0][:, v] for v in range(4)]))
+            except Exception as err:  # an extra table must not cost the headline its line
+                out["cpu_ops"] = {"error": str(err)[:200]}
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()

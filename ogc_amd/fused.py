@@ -9,6 +9,27 @@ from torch.autograd import Function
 from .pointnet2 import pointnet2 as _api
 
 
+
+# ---- which shapes do NOT take a fused kernel --------------------------------------------------------------------------------
+# Every `*_available` gate below answers "does the fused kernel cover this call?"; a False sends the caller down the plain
+# operator sequence — correct, slower, and silent.  GATE_MISSES counts those answers per gate (tests/test_fallbacks_gpu.py runs
+# one step of each configuration and pins the set, so a shape that quietly leaves a fused path shows up as a test failure).
+import collections as _collections
+import functools as _functools
+
+GATE_MISSES = _collections.Counter()
+
+
+def _gate(fn):
+    @_functools.wraps(fn)
+    def counted(*args, **kwargs):
+        ok = fn(*args, **kwargs)
+        if not ok:
+            GATE_MISSES[fn.__name__] += 1
+        return ok
+    return counted
+
+
 class _GroupNormAct(Function):
     """y = act(GroupNorm(x)) with act = ReLU or identity — one autograd node, two launches forward, three backward.
     Reference sequence: nn.GroupNorm then nn.ReLU(inplace=True) (utils/nn_util.py:6-11, :45-85)."""
@@ -333,6 +354,7 @@ def group_reverse(idx, n):
     return rev_start, rev_pos, heads
 
 
+@_gate
 def neighbour_consistency_available(mask, loss_norm, cross_entropy):
     return (mask.is_cuda and mask.dtype == torch.float32 and not cross_entropy and loss_norm in (1, 2)
             and mask.shape[-1] <= 40 and getattr(_api._native, "neighbour_consistency_fwd_wrapper", None) is not None)
@@ -494,6 +516,7 @@ def _fold_batch_norm(convs, norms):
     return wts, biases
 
 
+@_gate
 def mlp_chain_pool_available(x, convs, norms):
     """Inference only: every norm a BatchNorm in evaluation mode, nothing to differentiate, and a kernel for the shape."""
     nat = _api._native
@@ -511,6 +534,7 @@ def mlp_chain_pool_available(x, convs, norms):
     return nat.mlp_chain_pool_supported(c[0], c[1], c[2], c[3] if len(convs) > 2 else 0, x.shape[-1])
 
 
+@_gate
 def corr_layer_pool_available(feature1, feature2, idx, convs, norms):
     """FlowEmbedding in inference with a kernel for its shape: grouping, concatenation, MLP and max in one launch."""
     nat = _api._native
@@ -576,6 +600,7 @@ class _RigidBlend(Function):
         return None, None, grad_mask, None, None, None
 
 
+@_gate
 def rigid_residual_available(mask, loss_norm):
     return (mask.is_cuda and mask.dtype == torch.float32 and loss_norm in (1, 2) and mask.shape[-1] <= 32
             and getattr(_api._native, "rigid_blend_wrapper", None) is not None)
@@ -628,6 +653,7 @@ class _MatchedDistance(Function):
         return gm1, gm2, None, None, None
 
 
+@_gate
 def matched_distance_available(mask, loss_norm, cross_entropy):
     return (mask.is_cuda and mask.dtype == torch.float32 and not cross_entropy and loss_norm in (1, 2)
             and mask.shape[-1] <= 32 and getattr(_api._native, "matched_distance_wrapper", None) is not None
@@ -767,6 +793,7 @@ class _NormActConv(Function):
         return grad_prev, None, gw, gb, grad_w.view_as(conv_weight), None, None, None, None, None, None
 
 
+@_gate
 def norm_act_conv_available(y_prev, gn, conv):
     """Can conv(act(gn(y_prev))) run with the norm folded into the convolution's operand load?"""
     if not (y_prev.is_cuda and y_prev.dtype == torch.float32 and gn.affine and conv.bias is None and conv.groups == 1
@@ -861,6 +888,7 @@ class _NormActConvPool(Function):
         return (grad_prev, None, gw, gb, grad_w.view_as(conv_weight), None, None, None, gw2, gb2, None, None, None)
 
 
+@_gate
 def norm_act_conv_pool_available(y_prev, gn, conv, next_gn):
     """Can the last layer of a set-abstraction MLP and its pooled GroupNorm run as _NormActConvPool?  (The shapes for which
     _NormActConv takes the extremes path forwards and the moment-matrix path backwards.)"""
@@ -964,6 +992,7 @@ class _SlotMasks(Function):
         return gf, gs, None
 
 
+@_gate
 def slot_masks_available(feats, slots):
     """The fused mask read-out takes fp32 device tensors with at most 32 slots and 256 feature channels."""
     return (getattr(_api._native, "slot_masks_fwd_wrapper", None) is not None and feats.dim() == 3 and slots.dim() == 3
@@ -976,6 +1005,7 @@ def slot_masks(feats, slots, temperature=0.05):
     return _SlotMasks.apply(feats, slots, float(temperature))
 
 
+@_gate
 def attention_core_available(embed_dim, n_head, lq, lk, *tensors):
     """The fused attention core handles heads of 16 or 32 columns and needs lq * lk floats of LDS in its backward."""
     nat = _api._native
@@ -1185,6 +1215,7 @@ class _GroupedFirstLayer(Function):
         return None, None, grad_feat, None, grad_w, None, None, None, None
 
 
+@_gate
 def grouped_first_layer_available(xyz, new_xyz, features, idx, conv, gn):
     nat = _api._native
     return (features is not None and features.is_cuda and features.dtype == torch.float32 and idx is not None

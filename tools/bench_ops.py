@@ -145,10 +145,13 @@ def bench_conv_gn(ops, iters):
             dw = torch.empty(cout, cin, device=DEV)
             byt = 4.0 * B * hw * (cin + cout)
             f = timeit(lambda: nat.conv1x1_gemm_wrapper(B, cout, cin, hw, 0, w, x, y), iters)
-            d = timeit(lambda: nat.conv1x1_gemm_wrapper(B, cin, cout, hw, 1, w, y, dx), iters) if cout <= 160 else float("nan")
+            # (ogc_conv1x1_gemm takes K <= 160; the one wider input gradient of the step, 256 -> 128 at SA3, is a library product)
+            lib_dgrad = cout > 160
+            d = (timeit(lambda: torch.matmul(w.t(), y, out=dx), iters) if lib_dgrad else
+                 timeit(lambda: nat.conv1x1_gemm_wrapper(B, cin, cout, hw, 1, w, y, dx), iters))
             g = timeit(lambda: nat.conv1x1_wgrad_wrapper(B, cin, cout, hw, x, y, dw), iters)
-            print("conv  B=%-3d %4d->%-4d hw=%-6d fwd %7.3f ms %6.0f GB/s | dgrad %7.3f ms %6.0f GB/s | wgrad %7.3f ms %6.0f GB/s" %
-                  (B, cin, cout, hw, f, byt / f / 1e6, d, byt / d / 1e6, g, byt / g / 1e6))
+            print("conv  B=%-3d %4d->%-4d hw=%-6d fwd %7.3f ms %6.0f GB/s | dgrad%s %7.3f ms %6.0f GB/s | wgrad %7.3f ms %6.0f GB/s" %
+                  (B, cin, cout, hw, f, byt / f / 1e6, " (rocBLAS)" if lib_dgrad else "", d, byt / d / 1e6, g, byt / g / 1e6))
             # variants of the same layer: GroupNorm statistics in the epilogue (offered up to K = 100) and the previous
             # layer's GroupNorm + ReLU folded into the operand load
             gamma, beta = torch.ones(cout, device=DEV), torch.zeros(cout, device=DEV)
