@@ -22,6 +22,25 @@ SEG_CFG = {
              "invariance_loss_params": {"loss_norm": 2}},
 }
 
+# The Waymo trainer (train_seg_waymo.py:20-242: its own Trainer, every other view kept — `[:, ::2]`, :59 — and the one-frame loss
+# of :244-334) with segnet_kitti, as its main() builds it (:357-366).  512 points: the third set-abstraction level groups 64
+# neighbours out of 64 points.  Two epochs: without, then with the augmented twin of the frame.
+N_WAYMO, K_WAYMO = 512, 4
+WAYMO_CFG = {
+    "dataset": "waymo", "random_seed": 10, "aug_transform_epoch": 1, "ignore_npoint_thresh": 0,
+    # (a small learning rate, as for the flow trainer: at 1e-3 the reference's own run moves by 1e-3 .. 1e-2 in its loss terms under
+    # one-ulp changes of the coordinates — Adam turns rounding noise into steps of size lr and the IoU matching of near-uniform
+    # masks jumps on them)
+    "epochs": 2, "batch_size": 2, "lr": 1.0e-5, "lr_decay": 0.5, "lr_clip": 2.0e-6, "bn_momentum": 0.9, "bn_decay": 0.5,
+    "weight_decay": 1.0e-4, "decay_step": 4,
+    "segnet": {"n_slot": K_WAYMO, "n_point": N_WAYMO, "use_xyz": True, "n_transformer_layer": 1, "transformer_embed_dim": 32,
+               "transformer_input_pos_enc": False},
+    "loss": {"weights": [10.0, 0.1, 0.1], "start_steps": [0, 2, 6], "dynamic_loss_params": {"loss_norm": 2},
+             "smooth_loss_params": {"w_knn": 3.0, "w_ball_q": 1.0, "knn_loss_params": {"k": 4, "radius": 0.1, "loss_norm": 1},
+                                    "ball_q_loss_params": {"k": 8, "radius": 0.2, "loss_norm": 1}},
+             "invariance_loss_params": {"loss_norm": 2}},
+}
+
 N_FLOW = 256
 # (a small learning rate: Adam turns the rounding noise of this net's analytically zero gradients into steps of size lr, and
 # its warped-cloud neighbour searches jump on such steps — at lr = 1e-3 two CPUs differ by 1 % in the losses after ONE step)
@@ -59,9 +78,10 @@ class SegScenes(torch.utils.data.Dataset):
     second epoch) one of its flow vectors is NaN: that step's gradients are NaN and both trainers must leave the weights and
     the optimiser state alone (train_seg.py:81-83)."""
 
-    def __init__(self, train=True):
+    def __init__(self, train=True, npoint=N_SEG, nslot=K_SEG, seed=0, ulp=0):
         self.n = 6 if train else 2
-        self.seed = 700 if train else 900
+        self.seed = (700 if train else 900) + seed
+        self.npoint, self.nslot, self.ulp = npoint, nslot, ulp   # ulp: coordinates moved by one unit in the last place (see FlowPairs)
         self.aug_transform = False
         self.calls = [0] * self.n
         self.poison = train
@@ -71,9 +91,12 @@ class SegScenes(torch.utils.data.Dataset):
 
     def __getitem__(self, i):
         self.calls[i] += 1
-        pc, flow, mask = detgen.rigid_scene(1, N_SEG, K_SEG, self.seed + 10 * i, scale=(1.0, 1.0, 1.0))
+        pc, flow, mask = detgen.rigid_scene(1, self.npoint, self.nslot, self.seed + 10 * i, scale=(1.0, 1.0, 1.0))
+        if self.ulp:
+            step = np.sign(detgen.uniform(pc[0].shape, self.seed + 10 * i + 7 + self.ulp)).astype(np.float32)
+            pc[0] = np.nextafter(pc[0], pc[0] + step)
         pc1, f1 = pc[0].astype(np.float64), flow[0].astype(np.float64)
-        perm = np.argsort(detgen.uniform((N_SEG,), self.seed + 10 * i + 5))
+        perm = np.argsort(detgen.uniform((self.npoint,), self.seed + 10 * i + 5))
         pc2 = (pc1 + f1)[perm]
         f2 = -f1[perm]
         segm = mask[0].argmax(-1)

@@ -1,8 +1,8 @@
 """Generates the DRIVER fixtures by running the reference's own trainers and refinement script (imported / executed from
 /root/reference, which exists only in the build container) on the CPU oracle's operators:
 
-    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_driver_golden.py [seg] [flow] [store]
-    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_driver_golden.py seg64 flow64     (float64 truths, separate process)
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_driver_golden.py [seg] [waymo] [flow] [store]
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_driver_golden.py seg64 waymo64 flow64     (float64 truths, separate process)
 
   train_seg_trace.npz   train_seg.Trainer.train (train_seg.py:19-226) over 3 epochs of a six-scene in-memory data set, with its
                         LambdaLR(lr_curve) and BNMomentumScheduler(bn_curve): per iteration the loss_dict, the learning rate,
@@ -10,6 +10,9 @@
                         scene whose flow holds a NaN from the second epoch on); per epoch the validation loss, its loss_dict,
                         PQ / F1 / Pre / Rec and the best-checkpoint decision.  Loss terms are gated by `it * b`
                         (start_steps), augmented views switch on after `aug_transform_epoch`.
+  train_seg_waymo_trace.npz  the same for train_seg_waymo.Trainer.train (train_seg_waymo.py:20-242: every other view kept, :59; its own
+                        one-frame UnsupervisedOGCLoss, :244-334) with segnet_kitti on 512-point scenes, 2 epochs (the second with
+                        the augmented twin and the NaN step).
   train_flow_trace.npz  the same for train_flow.Trainer.train (train_flow.py:33-184) with flownet_sapien.
   flow_store.npz        what the reference's data sets write and read as predicted flows, and what its refinement script
                         oa_icp.py does end to end: KITTISceneFlowDataset._save_predflow / __getitem__ with predflow_path
@@ -92,15 +95,44 @@ class _AsDouble(torch.utils.data.Dataset):
         return pcs.astype(np.float64), segms, flows.astype(np.float64), valids.astype(np.float64)
 
 
-def gen_train_seg(f64=False):
-    import train_seg as ref
-    from losses.seg_loss_unsup import (DynamicLoss, EntropyLoss, InvarianceLoss, RankLoss, SmoothLoss, UnsupervisedOGCLoss)
+def gen_train_seg_waymo(f64=False):
+    """As gen_train_flow: fp32 tries data seeds until the reference's own run does not move (< 1e-4 on every loss term) under
+    one-ulp changes of the coordinates — a near-uniform mask on an IoU-matching boundary moves the invariance term by a percent
+    on every implementation, the reference's included — and writes that seed's trace; float64: the truth for the stored seed."""
+    if f64:
+        seed = int(np.load(os.path.join(HERE, "train_seg_waymo_trace.npz"))["data_seed"][0])
+        return gen_train_seg(True, True, seed, 0, True)
+    for seed in range(3000, 3400, 20):
+        base = gen_train_seg(False, True, seed, 0, False)
+        dev = 0.0
+        for ulp in (1, 2):
+            other = gen_train_seg(False, True, seed, ulp, False)
+            for key in ("loss", "val_avg"):
+                a, b = np.nan_to_num(other[key]), np.nan_to_num(base[key])
+                dev = max(dev, float(np.max(np.abs(a - b) / np.abs(b).clip(1e-3))))
+        print("seed %d: largest change of a loss under one-ulp perturbations %.2e" % (seed, dev), flush=True)
+        if dev < 1e-4:
+            return gen_train_seg(False, True, seed, 0, True)
+    raise RuntimeError("no stable seed")
+
+
+def gen_train_seg(f64=False, waymo=False, data_seed=3000, ulp=0, write=True):
+    """waymo: train_seg_waymo.Trainer.train (train_seg_waymo.py:20-242) with ITS UnsupervisedOGCLoss (:244-334) and segnet_kitti."""
+    from losses.seg_loss_unsup import DynamicLoss, EntropyLoss, InvarianceLoss, RankLoss, SmoothLoss
     from metrics.seg_metric import calculate_PQ_F1
-    from models.segnet_sapien import MaskFormer3D
     from utils.pytorch_util import BNMomentumScheduler
-    cfg = dc.SEG_CFG
+    if waymo:
+        import train_seg_waymo as ref
+        from models.segnet_kitti import MaskFormer3D
+        UnsupervisedOGCLoss = ref.UnsupervisedOGCLoss
+        cfg = dc.WAYMO_CFG
+    else:
+        import train_seg as ref
+        from losses.seg_loss_unsup import UnsupervisedOGCLoss
+        from models.segnet_sapien import MaskFormer3D
+        cfg = dc.SEG_CFG
     ref.args = types.SimpleNamespace(**cfg)
-    net = detgen.fill_module(MaskFormer3D(**cfg["segnet"]), 31)
+    net = detgen.fill_module(MaskFormer3D(**cfg["segnet"]), 33 if waymo else 31)
     if f64:
         net = net.double()
     optimizer = torch.optim.Adam(net.parameters(), lr=cfg["lr"], weight_decay=cfg["weight_decay"])
@@ -114,7 +146,11 @@ def gen_train_seg(f64=False):
     trainer = ref.Trainer(segnet=net, criterion=criterion, optimizer=optimizer, aug_transform_epoch=cfg["aug_transform_epoch"],
                           ignore_npoint_thresh=cfg["ignore_npoint_thresh"], exp_base=os.path.join(tmp, "seg_R1"),
                           lr_scheduler=lr_scheduler, bnm_scheduler=bnm_scheduler)
-    train_set, val_set = dc.SegScenes(train=True), dc.SegScenes(train=False)
+    if waymo:
+        train_set = dc.SegScenes(True, dc.N_WAYMO, dc.K_WAYMO, seed=data_seed, ulp=ulp)
+        val_set = dc.SegScenes(False, dc.N_WAYMO, dc.K_WAYMO, seed=data_seed, ulp=ulp)
+    else:
+        train_set, val_set = dc.SegScenes(train=True), dc.SegScenes(train=False)
     if f64:
         train_set, val_set = _AsDouble(train_set), _AsDouble(val_set)
     train_loader = torch.utils.data.DataLoader(train_set, batch_size=cfg["batch_size"], shuffle=False)
@@ -155,8 +191,12 @@ def gen_train_seg(f64=False):
     ck = torch.load(os.path.join(tmp, "seg_R1", "best.pth.tar"))
     out["ckpt_keys"] = np.array(sorted(ck["model_state"].keys()))
     out["ckpt_top"] = np.array(sorted(ck.keys()))
-    save("train_seg_trace_f64" if f64 else "train_seg_trace", **out)
     shutil.rmtree(tmp)
+    if waymo:
+        out["data_seed"] = np.array([data_seed])
+    if write:
+        save(("train_seg_waymo_trace" if waymo else "train_seg_trace") + ("_f64" if f64 else ""), **out)
+    return out
 
 
 def gen_train_flow(f64=False):
@@ -349,7 +389,7 @@ if __name__ == "__main__":
     assert os.path.isdir(REF), "the reference tree is only present in the build container"
     which = sys.argv[1:] or ["seg", "flow", "store"]
     orc.build()
-    if "seg64" in which or "flow64" in which:
+    if "seg64" in which or "flow64" in which or "waymo64" in which:
         # the float64 truth of the same runs (make_truth_f64.py's shims: indices decided in fp32, floats in fp64) — in a
         # process of its own: the shims replace the native module and the allocation factories
         from make_truth_f64 import install_shims_f64
@@ -360,12 +400,16 @@ if __name__ == "__main__":
         sys.modules["tensorboardX"].SummaryWriter = _Writer
         if "seg64" in which:
             gen_train_seg(f64=True)
+        if "waymo64" in which:
+            gen_train_seg_waymo(f64=True)
         if "flow64" in which:
             gen_train_flow(f64=True)
         sys.exit(0)
     shims()
     if "seg" in which:
         gen_train_seg()
+    if "waymo" in which:
+        gen_train_seg_waymo()
     if "flow" in which:
         gen_train_flow()
     if "store" in which:
