@@ -13,6 +13,13 @@ from ..utils.transformer_util import MaskFormerHead
 BN_CONFIG = {"class": "GroupNorm", "num_groups": 4}
 
 
+# Priority of the side stream the next batch's geometry plan runs on (0 = as the launch stream, -1 = high).  Its kernels are
+# short and latency-bound (an FPS round chain on one workgroup per cloud, searches of a few thousand queries); with the same
+# priority as the dense kernels their workgroups wait for a free slot behind thousands of the main queue's.
+import os as _os
+GEOMETRY_STREAM_PRIORITY = int(_os.environ.get("OGC_GEOMETRY_PRIORITY", "0"))
+
+
 class MaskFormer3DBase(nn.Module):
     """PointNet++ encoder/decoder -> per-point embedding; MaskFormer head -> K slot embeddings;
     mask = softmax_K(cos(point, slot) / 0.05).  Reference forward: models/segnet_kitti.py:62-89.
@@ -65,7 +72,7 @@ class MaskFormer3DBase(nn.Module):
         from ..utils.streams import Pending, side_stream
         n_sa, n_fp = len(self.SA_modules), len(self.FP_modules)
         sa_geo, fp_geo = [None] * n_sa, [None] * n_fp
-        stream = side_stream(pc.device, "segnet-geometry")
+        stream = side_stream(pc.device, "segnet-geometry", priority=GEOMETRY_STREAM_PRIORITY)
         if after is None:
             stream.wait_stream(torch.cuda.current_stream())
         else:
