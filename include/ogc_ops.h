@@ -579,6 +579,14 @@ int ogc_group_norm_pool_extremes(int b, int c, int p, int s, int groups, float e
                                  const int *aext, const float *gamma, const float *beta, float *out, int *argmax,
                                  float *mean, float *rstd, const double *stats, int slots, ogc_stream_t stream);
 
+/* One zero fill per training step (fused extension; nothing in the reference to replace: its Python zero-fills every gradient
+ * buffer it hands to the native module, pointnet2/pointnet2.py:73,181,224).  ogc_zero_arena_begin fills [base, base + bytes)
+ * with zeros by ONE launch on `stream`; until ogc_zero_arena_end every operator of this library that would zero an
+ * accumulator lying inside that region, on that stream, skips its own fill.  The caller hands every byte of the region to at
+ * most one operator between the two calls.  bytes and base multiples of 4. */
+int ogc_zero_arena_begin(void *base, int bytes, ogc_stream_t stream);
+int ogc_zero_arena_end(void);
+
 #ifdef __cplusplus
 }
 #endif

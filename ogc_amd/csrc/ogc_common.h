@@ -42,8 +42,11 @@ __global__ void ogc_zero_kernel(uint32_t *__restrict__ p, size_t words) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += stride) p[i] = 0u;
 }
 } // namespace
+// (api.hip) true when [ptr, ptr + bytes) lies in the region ogc_zero_arena_begin() zeroed on `stream` and handed out once
+bool ogc_zero_arena_covers(const void *ptr, size_t bytes, hipStream_t stream);
 static inline hipError_t ogc_zero_async(void *ptr, size_t bytes, hipStream_t stream) {
     if (bytes == 0) return hipSuccess;
+    if (ogc_zero_arena_covers(ptr, bytes, stream)) return hipSuccess; // one fill per step instead of one launch per accumulator
     if ((bytes & 3) != 0 || ((uintptr_t)ptr & 3) != 0) return hipErrorInvalidValue;
     const size_t words = bytes >> 2;
     size_t blocks = (words + 255) / 256;

@@ -17,6 +17,8 @@ from .pointnet2 import pointnet2 as _api
 import collections as _collections
 import functools as _functools
 
+from .utils.zero_arena import zeroed_empty  # buffers an operator zeroes before accumulating: one fill per step
+
 GATE_MISSES = _collections.Counter()
 
 
@@ -210,7 +212,7 @@ class _PointwiseConv(Function):
                     # (K > 100: only the streaming kernel has registers to spare for the statistics epilogue)
                     and getattr(nat, "conv1x1_gemm_gnstats_wrapper", None) is not None
                     and (cin <= 100 or _stats_ok(nat, B, cout, cin, hw, False))):
-                stats = torch.empty(nat.conv1x1_gn_slots() * B * gn_groups * 2, dtype=torch.float64, device=x.device)
+                stats = zeroed_empty(nat.conv1x1_gn_slots() * B * gn_groups * 2, torch.float64, x.device)
                 nat.conv1x1_gemm_gnstats_wrapper(B, cout, cin, hw, gn_groups, weight.contiguous(), x, y, stats)
             elif _plain_gemm_mine(cin):
                 nat.conv1x1_gemm_wrapper(B, cout, cin, hw, 0, weight.contiguous(), x, y)
@@ -260,7 +262,7 @@ class _PointwiseConv(Function):
                 # hw <= 16384; beyond that the streaming kernel wins — FlowStep3D's hw = 32768 layers lose 7 % here)
                 grad_w = torch.bmm(grad_y.reshape(B, cout, hw), x.reshape(B, cin, hw).transpose(1, 2)).sum(0)
             else:
-                grad_w = torch.empty(cout, cin, dtype=torch.float32, device=x.device)
+                grad_w = zeroed_empty((cout, cin), torch.float32, x.device)
                 _api._native.conv1x1_wgrad_wrapper(B, cin, cout, hw, x, grad_y, grad_w)
             grad_w = grad_w.view_as(weight)
         return grad_x, grad_w, None
@@ -327,7 +329,7 @@ def reverse_neighbours(idx):
     nat = _api._native
     idx = idx.contiguous()
     B, N, k = idx.shape
-    rev_start = torch.empty(B, N + 1, dtype=torch.int32, device=idx.device)
+    rev_start = zeroed_empty((B, N + 1), torch.int32, idx.device)
     rev_src = torch.empty(B, N * k, dtype=torch.int32, device=idx.device)
     rev_mult = torch.empty(B, N, dtype=torch.int32, device=idx.device)
     ws = torch.empty(B, N, dtype=torch.int32, device=idx.device)
@@ -615,7 +617,7 @@ def rigid_residual(pc, pc2, mask, loss_norm):
     VB, N, K = mask.shape
     dev = mask.device
     with torch.no_grad():
-        mom = torch.empty(VB * K * 16, dtype=torch.float64, device=dev)
+        mom = zeroed_empty(VB * K * 16, torch.float64, dev)
         S = torch.empty(VB * K, 3, 3, dtype=torch.float32, device=dev)
         means = torch.empty(VB * K, 6, dtype=torch.float32, device=dev)
         nat.rigid_moments_wrapper(VB, N, K, pc, pc2, mask.detach(), mom, S, means)
@@ -668,7 +670,7 @@ def matched_distances(mask1, mask2, loss_norm):
     PB, N, K = mask1.shape
     dev = mask1.device
     with torch.no_grad():
-        counts = torch.empty(PB * K * K, dtype=torch.int32, device=dev)
+        counts = zeroed_empty(PB * K * K, torch.int32, dev)
         iou = torch.empty(PB, K, K, dtype=torch.float32, device=dev)
         nat.mask_iou_wrapper(PB, N, K, mask1.detach(), mask2.detach(), counts, iou)
         both = torch.stack([iou, iou.transpose(1, 2)]).contiguous()          # (2, PB, K, K)
@@ -706,7 +708,7 @@ def _norm_act_conv_forward(y_prev, stats_prev, gn_weight, gn_bias, conv_weight, 
     stats = extremes = None
     if (next_groups > 0 and next_groups <= 32 and cout % next_groups == 0 and (cout // next_groups) % 4 == 0
             and (cin <= 100 or _stats_ok(nat, B, cout, cin, hw, True))):
-        stats = torch.empty(nat.conv1x1_gn_slots() * B * next_groups * 2, dtype=torch.float64, device=dev)
+        stats = zeroed_empty(nat.conv1x1_gn_slots() * B * next_groups * 2, torch.float64, dev)
         if (pool and next_gamma is not None and (cin <= 100 or POOL_EXTREMES_WIDE)
                 and getattr(nat, "conv1x1_gemm_affine_pool_wrapper", None) is not None):
             # last layer of a set-abstraction MLP: also the extreme of every neighbourhood, for the max-pool
@@ -758,7 +760,7 @@ class _NormActConv(Function):
         cout = conv_weight.shape[0]
         grad_y = grad_y.contiguous()
         w = conv_weight.contiguous()
-        grad_w = torch.empty(cout, cin, dtype=torch.float32, device=y_prev.device)
+        grad_w = zeroed_empty((cout, cin), torch.float32, y_prev.device)
         # (up to 64 channels: from 128 on the second accumulator set makes the weight-gradient kernel MFMA-bound and the
         # whole path slower than the separate passes — tools/gn_bwd_compare.py)
         if (FUSED_GN_BACKWARD and getattr(nat, "conv1x1_dgrad_adjoint_wrapper", None) is not None and hw % 64 == 0
@@ -768,10 +770,10 @@ class _NormActConv(Function):
             # moment matrices next to the weight gradient -> GroupNorm sums -> adjoint in the input gradient's epilogue:
             # the gradient w.r.t. the normalised activation and both GroupNorm backward passes never touch memory
             dev = y_prev.device
-            moments = torch.empty(B, 2, cout, cin, dtype=torch.float32, device=dev)
+            moments = zeroed_empty((B, 2, cout, cin), torch.float32, dev)
             nat.conv1x1_wgrad_moments_wrapper(B, cin, cout, hw, relu, y_prev, a, bb, grad_y, moments)
             coef = torch.empty(B, cin, 3, dtype=torch.float32, device=dev)
-            ggb = torch.empty(2, cin, dtype=torch.float32, device=dev)
+            ggb = zeroed_empty((2, cin), torch.float32, dev)
             gw, gb = ggb[0], ggb[1]
             nat.gn_moments_combine_wrapper(B, cin, cout, hw, gn_groups, moments, w.view(cout, cin), a, bb, mean, rstd,
                                            gn_weight.contiguous(), grad_w, coef, gw, gb)
@@ -875,10 +877,10 @@ class _NormActConvPool(Function):
                                                   yext if POOL_SUMS_FROM_EXTREMES else None)
         # the convolution's backward (as _NormActConv.backward's moment-matrix path) on that form
         w = conv_weight.contiguous().view(cout, cin)
-        moments = torch.empty(B, 2, cout, cin, dtype=torch.float32, device=dev)
+        moments = zeroed_empty((B, 2, cout, cin), torch.float32, dev)
         nat.conv1x1_wgrad_moments_pooled_wrapper(B, cin, cout, hw, relu, S, y_prev, a, bb, y, coef2, inj, moments)
         coef = torch.empty(B, cin, 3, dtype=torch.float32, device=dev)
-        ggb = torch.empty(2, cin, dtype=torch.float32, device=dev)
+        ggb = zeroed_empty((2, cin), torch.float32, dev)
         gw, gb = ggb[0], ggb[1]
         grad_w = torch.empty(cout, cin, dtype=torch.float32, device=dev)
         nat.gn_moments_combine_wrapper(B, cin, cout, hw, gn_groups, moments, w, a, bb, mean, rstd,
@@ -1167,7 +1169,7 @@ class _GroupedFirstLayer(Function):
         y = torch.empty(B, M, npoint, nsample, dtype=torch.float32, device=xyz.device)
         stats = None
         if gn_groups > 0:
-            stats = torch.empty(nat.conv1x1_gn_slots() * B * gn_groups * 2, dtype=torch.float64, device=xyz.device)
+            stats = zeroed_empty(nat.conv1x1_gn_slots() * B * gn_groups * 2, torch.float64, xyz.device)
         nat.group_linear_fwd_wrapper(B, M, N, npoint, nsample, gn_groups, P, idx, rel, wx, y, stats)
         ctx.save_for_backward(features, idx, rel, weight)
         if stats is not None:
@@ -1208,7 +1210,7 @@ class _GroupedFirstLayer(Function):
         grad_w = None
         if ctx.needs_input_grad[4]:
             if not one_pass:
-                dwx = torch.empty(M, 3, dtype=torch.float32, device=grad_y.device)
+                dwx = zeroed_empty((M, 3), torch.float32, grad_y.device)
                 nat.conv1x1_wgrad_wrapper(B, 3, M, T, rel, grad_y, dwx)
             dwf = torch.bmm(dP, features.detach().transpose(1, 2)).sum(0)
             grad_w = torch.cat([dwx, dwf], 1).view_as(weight)

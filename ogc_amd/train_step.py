@@ -271,10 +271,21 @@ def train_step(segnet, criterion, optimizer, batch, it, aug_transform, sync=True
     next_batch: the batch of the following step, if the caller already has it: its geometry is queued on side
     streams during this step and handed back as PendingStep.prefetched, to be passed as `prefetched=` next time."""
     from .utils.streams import HostScalars
+    from .utils.zero_arena import zero_arena
     segnet.train()
-    optimizer.zero_grad(set_to_none=True)
+    optimizer.zero_grad(set_to_none=True)   # (also drops last step's gradients that live in the zero arena, before it is refilled)
     b = batch[1].size(0)
     on_gpu = batch[0].is_cuda
+    if on_gpu:
+        # forward, loss and backward take their atomically accumulated buffers (statistics, weight gradients, moments, counters)
+        # from ONE region zeroed by one launch here (utils/zero_arena.py) instead of ~40 fills of their own
+        with zero_arena(batch[0].device):
+            return _train_step(segnet, criterion, optimizer, batch, it, aug_transform, sync, prefetched, next_batch, b, on_gpu)
+    return _train_step(segnet, criterion, optimizer, batch, it, aug_transform, sync, prefetched, next_batch, b, on_gpu)
+
+
+def _train_step(segnet, criterion, optimizer, batch, it, aug_transform, sync, prefetched, next_batch, b, on_gpu):
+    from .utils.streams import HostScalars
     if prefetched is not None and (prefetched.batch is not batch or prefetched.aug != aug_transform):
         prefetched = None
     if prefetched is None and on_gpu:

@@ -1,0 +1,90 @@
+"""One zero fill per training step (csrc/api.hip: ogc_zero_arena_begin / _end).
+
+~40 operators of a step accumulate with atomics into small buffers this package allocates for them — GroupNorm statistics,
+weight gradients, moment matrices, counters — and each zeroes its buffer with a launch of its own.  Inside ``with
+zero_arena(device):`` those buffers come from ``zeroed_empty`` instead of ``torch.empty``: slices of one persistent tensor that
+was zeroed by a single launch when the block was entered; the library then skips the operators' own fills (it recognises the
+region).  Outside such a block, on another stream, or when the step needs more than the region zeroed so far (the first step:
+the extent is learnt from the step before), ``zeroed_empty`` is ``torch.empty`` and the operator zeroes it as before.
+
+A slice lives until the NEXT ``with`` block of the same device is entered (the region is then zeroed again), i.e. for the rest
+of the training step that allocated it — long enough for statistics saved for the backward pass and for gradients on their way
+into ``param.grad`` / the optimizer of that step; nothing that outlives a step may be allocated here.
+"""
+import torch
+
+from .. import _lib
+
+CAPACITY = 64 << 20      # bytes of the persistent region per device
+LARGEST = 4 << 20        # larger requests are not worth a place in it (their fill is bandwidth, not launch latency)
+import os as _os
+ENABLED = _os.environ.get("OGC_ZERO_ARENA", "1") != "0"   # (0: every operator fills its own buffers — A/B runs)
+
+_ITEMSIZE = {torch.float32: 4, torch.float64: 8, torch.int32: 4, torch.int64: 8, torch.int16: 2, torch.uint8: 1}
+
+_arenas = {}
+_active = None
+
+
+class _Arena:
+    def __init__(self, device):
+        self.device = device
+        self.buf = torch.empty(CAPACITY, dtype=torch.uint8, device=device)
+        self.filled = 0      # bytes zeroed by this step's fill
+        self.used = 0        # bump pointer
+        self.want = 0        # extent the last step asked for (what the next fill covers)
+        self.stream = None
+
+    def begin(self):
+        self.stream = torch.cuda.current_stream(self.device).cuda_stream
+        self.filled = min((self.want + 255) // 256 * 256, CAPACITY)
+        self.used = self.want = 0
+        _lib.call("ogc_zero_arena_begin", self.buf.data_ptr(), self.filled, self.stream)
+
+    def take(self, shape, dtype):
+        n = 1
+        for d in shape:
+            n *= int(d)
+        nbytes = n * _ITEMSIZE[dtype]
+        if nbytes > LARGEST or nbytes == 0 or torch.cuda.current_stream(self.device).cuda_stream != self.stream:
+            return None                     # never part of the region
+        start = (self.want + 255) // 256 * 256
+        self.want = start + nbytes          # (learnt even when this request does not fit yet: the next step's fill is larger)
+        if start + nbytes > self.filled:
+            return None
+        return self.buf[start:start + nbytes].view(dtype).view(shape)
+
+
+class zero_arena:
+    """``with zero_arena(device):`` around the forward, loss and backward pass of ONE training step on the current stream."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+
+    def __enter__(self):
+        global _active
+        self.on = ENABLED and self.device.type == "cuda" and _active is None and not torch.cuda.is_current_stream_capturing()
+        if self.on:
+            a = _arenas.get(self.device)
+            if a is None:
+                a = _arenas[self.device] = _Arena(self.device)
+            a.begin()
+            _active = a
+        return self
+
+    def __exit__(self, *exc):
+        global _active
+        if self.on:
+            _active = None
+            _lib.call("ogc_zero_arena_end")
+
+
+def zeroed_empty(shape, dtype, device):
+    """A buffer an operator of this library will zero before accumulating into it: a pre-zeroed slice when a step's region is
+    active (the operator then skips its fill), plain ``torch.empty`` otherwise."""
+    a = _active
+    if a is not None and a.device == torch.device(device):
+        t = a.take(tuple(shape) if not isinstance(shape, int) else (shape,), dtype)
+        if t is not None:
+            return t
+    return torch.empty(shape, dtype=dtype, device=device)
