@@ -27,3 +27,6 @@ int ogc_ball_query_grid(int b, int n, int m, float radius, int nsample, const fl
 // the caller should run the all-pairs scan (small clouds, k too large for the LDS budget).
 int ogc_knn_grid(int mode, int b, int n, int m, int k, float radius, const float *unknown, const float *known,
                  float *dist, int *idx, hipStream_t s);
+
+// three_nn over cell lists (known clouds of 1024 points or more).  OGC_OK, or OGC_ERR_UNSUPPORTED: the caller runs its scan.
+int ogc_three_nn_grid(int b, int n, int m, const float *unknown, const float *known, float *dist2, int *idx, hipStream_t s);

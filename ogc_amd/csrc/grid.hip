@@ -568,8 +568,8 @@ static int grid_build_parts(int n) {
 }
 
 static void launch_grid_build(int b, int n, float radius, int knn_k, int stride_cells, const float *xyz, GridHdr *hdrs,
-                              int *cell_start, float4 *sorted_pts, hipStream_t s, int prefer_cells = 0) {
-    const float knn_div = 33.5f; // points per cell = k / 33.5: cell edge = half the expected k-th neighbour distance
+                              int *cell_start, float4 *sorted_pts, hipStream_t s, int prefer_cells = 0,
+                              float knn_div = 33.5f /* points per cell = k / knn_div; 33.5: cell edge = half the expected k-th neighbour distance */) {
     const int parts = grid_build_parts(n);
     if (parts > 0 && n <= 8 * BUILD_THREADS)
         hipLaunchKernelGGL(grid_build_split_kernel<8>, dim3(b * parts), dim3(BUILD_THREADS), 0, s, knn_div, b, parts, n, radius, knn_k,
@@ -1585,6 +1585,75 @@ __global__ __launch_bounds__(OGC_WAVE, 4) void knn_grid_kernel(int n, int m, int
     }
 }
 
+// ---- three nearest neighbours over the cell lists: ONE LANE PER QUERY ------------------------------------------------------------
+// three_nn (interpolate_gpu.cu:81-124: the feature-propagation modules' inverse-distance weights, 8192 targets against the 2048
+// centres of the level above) as an all-pairs scan tests every target against every centre.  Here a lane takes one target and
+// walks the cells around it shell by shell — rows of the (2R + 1)^3 block, a row's x-extent being one run of the cell-sorted
+// array — keeping the three smallest (distance, index) keys in registers; it stops when the third distance lies inside the
+// ball the scanned block is known to cover (R h, as knn_grid_kernel), or the block covers the grid.  The reference keeps
+// the EARLIER index among equal distances (strict '<' while scanning in index order): the smallest keys, whatever the order
+// in which candidates are met.  The grid holds ~1.5 points per cell, so the first block (27 cells, ~40 candidates against
+// 2048) ends ~95 % of the searches.  Lanes of a wavefront are unrelated targets: every loop runs to its longest lane.
+__global__ __launch_bounds__(OGC_WAVE, 8) void three_nn_grid_kernel(int n, int m, int stride_cells, const float *__restrict__ unknown,
+                                                                    const GridHdr *__restrict__ hdrs,
+                                                                    const int *__restrict__ cell_start,
+                                                                    const float4 *__restrict__ sorted_pts,
+                                                                    float *__restrict__ dist2, int *__restrict__ idx) {
+    const int lane = threadIdx.x, b = blockIdx.y, q = blockIdx.x * OGC_WAVE + lane;
+    const GridHdr h = hdrs[b];
+    const int *cs = cell_start + (size_t)b * stride_cells;
+    const float4 *pts = sorted_pts + (size_t)b * m;
+    float qx = NAN, qy = NAN, qz = NAN;
+    if (q < n) {
+        const float *u = unknown + ((size_t)b * n + q) * 3;
+        qx = u[0]; qy = u[1]; qz = u[2];
+    }
+    const u64 none = (u64)0x7f800000u << 32; // (+inf, index 0): what the reference's rows hold where nothing was found
+    u64 k1 = none, k2 = none, k3 = none;
+    const float edge = 1.0f / h.inv_h;
+    OGC_GRID_AXES(h, qx, qy, qz, fx, fy, fz);
+    const int cx = min(max(cell_coord(fx, h.minx, h.inv_h, h.gx), 0), h.gx - 1);
+    const int cy = min(max(cell_coord(fy, h.miny, h.inv_h, h.gy), 0), h.gy - 1);
+    const int cz = min(max(cell_coord(fz, h.minz, h.inv_h, h.gz), 0), h.gz - 1);
+    const int rmax = max(max(max(cx, h.gx - 1 - cx), max(cy, h.gy - 1 - cy)), max(cz, h.gz - 1 - cz));
+    bool open = q < n && h.npts > 0 && qx == qx && qy == qy && qz == qz; // (a NaN target selects nothing)
+    auto scan_run = [&](int j0, int j1) {
+        for (int j = j0; j < j1; ++j) {
+            const float4 c = pts[j];
+            const float d = ogc_sqdist(qx, qy, qz, c.x, c.y, c.z);
+            const u64 key = ((u64)__float_as_uint(d) << 32) | (unsigned)__float_as_int(c.w);
+            const bool c1 = key < k1, c2 = key < k2, c3 = key < k3;
+            k3 = c2 ? k2 : (c3 ? key : k3);
+            k2 = c1 ? k1 : (c2 ? key : k2);
+            k1 = c1 ? key : k1;
+        }
+    };
+    for (int R = 1; __builtin_amdgcn_ballot_w64(open) != 0ull; ++R) {
+        if (open) {
+            const int xa = max(cx - R, 0), xb = min(cx + R, h.gx - 1);
+            for (int z = max(cz - R, 0); z <= min(cz + R, h.gz - 1); ++z)
+                for (int y = max(cy - R, 0); y <= min(cy + R, h.gy - 1); ++y) {
+                    const int rowc = h.gx * (y + h.gy * z);
+                    const bool face = R == 1 || z == cz - R || z == cz + R || y == cy - R || y == cy + R;
+                    if (face) { // the row's whole x-extent belongs to shell R (R = 1: the full first block)
+                        scan_run(cs[rowc + xa], cs[rowc + xb + 1]);
+                    } else {    // inner row: only the two end cells are new
+                        if (cx - R >= 0) scan_run(cs[rowc + cx - R], cs[rowc + cx - R + 1]);
+                        if (cx + R <= h.gx - 1) scan_run(cs[rowc + cx + R], cs[rowc + cx + R + 1]);
+                    }
+                }
+            const float cover = (float)R * edge * 0.999f;
+            if (R >= rmax || __uint_as_float((unsigned)(k3 >> 32)) < cover * cover) open = false;
+        }
+    }
+    if (q < n) {
+        float *o = dist2 + ((size_t)b * n + q) * 3;
+        int *oi = idx + ((size_t)b * n + q) * 3;
+        o[0] = __uint_as_float((unsigned)(k1 >> 32)); o[1] = __uint_as_float((unsigned)(k2 >> 32)); o[2] = __uint_as_float((unsigned)(k3 >> 32));
+        oi[0] = (int)(unsigned)k1; oi[1] = (int)(unsigned)k2; oi[2] = (int)(unsigned)k3;
+    }
+}
+
 // ---- radius-limited k-NN of a cloud in itself with FOUR lanes per query ---------------------------------------------------
 // ogc_knn_clamped(pc, pc) with a radius (the smoothness term's lists, losses/seg_loss_unsup.py:150: k = 32 within 1 m — about 3
 // of the ~10 candidates the 27 cells hold): a neighbour beyond the radius is replaced by the nearest one whatever it is, so the
@@ -2031,4 +2100,25 @@ extern "C" int ogc_knn_clamped_cells(int b, int n, int k, float radius, const fl
     }
     return launch_knn(GridLayout(b, n), grid, 1, b, n, n, k, radius, knn_cells_applies(1, n, n, k, radius, true), xyz, dist, idx,
                       (hipStream_t)stream);
+}
+
+// three_nn over cell lists.  OGC_OK after queueing build + query, OGC_ERR_UNSUPPORTED when the caller should run its scan
+// (few known points: the scan is as fast; OGC_THREE_NN_GRID=0 in the environment).
+int ogc_three_nn_grid(int b, int n, int m, const float *unknown, const float *known, float *dist2, int *idx, hipStream_t s) {
+    static const bool on = [] { const char *e = getenv("OGC_THREE_NN_GRID"); return !(e && e[0] == '0'); }();
+    if (!on || m < 1024) return OGC_ERR_UNSUPPORTED;
+    const GridLayout L(b, m);
+    void *ws = ogc_workspace(s, L.total());
+    if (!ws) return OGC_ERR_UNSUPPORTED;
+    // density: 3 / 2 = 1.5 points per cell — the ball of radius h around a target (what the first block covers) then holds
+    // ~6 of them, three or more for ~95 % of the targets
+    launch_grid_build(b, m, 0.0f, 3, STRIDE_CELLS, known, L.hdrs(ws), L.cell_start(ws), L.sorted_pts(ws), s, 0, 2.0f);
+    hipLaunchKernelGGL(three_nn_grid_kernel, dim3(ogc_divup(n, OGC_WAVE), b), dim3(OGC_WAVE), 0, s, n, m, STRIDE_CELLS, unknown,
+                       L.hdrs(ws), L.cell_start(ws), L.sorted_pts(ws), dist2, idx);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        ogc_set_error("ogc_three_nn (grid): launch failed: %s", hipGetErrorString(e));
+        return OGC_ERR_LAUNCH;
+    }
+    return OGC_OK;
 }

@@ -277,6 +277,10 @@ extern "C" int ogc_three_nn(int b, int n, int m, const float *unknown, const flo
     OGC_REQUIRE(b >= 0 && n >= 0 && m >= 0, "ogc_three_nn: negative dimension");
     if (b == 0 || n == 0) return OGC_OK;
     OGC_REQUIRE(unknown && known && dist2 && idx, "ogc_three_nn: null pointer");
+    {   // known clouds of 1024 points or more: a cell-list search (grid.hip) instead of the all-pairs scan
+        const int rc = ogc_three_nn_grid(b, n, m, unknown, known, dist2, idx, (hipStream_t)stream);
+        if (rc != OGC_ERR_UNSUPPORTED) return rc;
+    }
     dim3 grid(ogc_divup(n, OGC_WAVE), b);
     hipLaunchKernelGGL(three_nn_kernel, grid, dim3(OGC_WAVE), 0, (hipStream_t)stream, n, m, unknown, known,
                        dist2, idx);

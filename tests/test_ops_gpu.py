@@ -753,6 +753,55 @@ def test_knn_grid_clustered_and_flat(nat, oracle):
     assert np.array_equal(idx, idxr) and np.array_equal(d2, d2r)
 
 
+def run_three_nn(nat, u, kn):
+    B, n, _ = u.shape
+    m = kn.shape[1]
+    d2 = torch.full((B, n, 3), -1.0, device=DEV)
+    idx = torch.full((B, n, 3), -7, dtype=torch.int32, device=DEV)
+    nat.three_nn_wrapper(B, n, m, T(u), T(kn), d2, idx)
+    return d2.cpu().numpy(), idx.cpu().numpy()
+
+
+@pytest.mark.parametrize("n,m,scale,qs", [(4096, 1024, (1, 1, 1), 1.0), (8192, 2048, (60, 4, 80), 1.0), (2048, 1024, (60, 4, 80), 1.0),
+                                          (777, 3000, (10, 10, 10), 3.0), (5000, 1500, (20, 20, 1e-3), 1.2)])
+def test_three_nn_grid_path_bit_exact(nat, oracle, monkeypatch, n, m, scale, qs):
+    """Cell-list three_nn (known clouds of >= 1024 points; one lane per target walking shells of cells): the rows of the
+    reference's index-ordered scan (interpolate_gpu.cu:81-124) — duplicated points (equal distances: the earlier index first),
+    targets outside the box, non-finite points and targets, searches that need more than the first block."""
+    rng = np.random.default_rng(n * 5 + m)
+    kn = cloud(rng, 2, m, scale=scale, dup=m // 5)
+    u = cloud(rng, 2, n, scale=tuple(qs * v for v in scale))
+    u[:, :40] = kn[:, :40]                   # targets that coincide with points (FP modules: the centres are a subset)
+    kn[1, 11] = np.nan
+    kn[1, 200, 1] = np.inf
+    u[0, 5, 2] = np.nan
+    d2, idx = run_three_nn(nat, u, kn)
+    d2r, idxr = oracle.three_nn(u, kn)
+    assert np.array_equal(idx, idxr)
+    assert np.array_equal(d2, d2r)
+
+
+def test_three_nn_grid_sparse_regions_and_ties(nat, oracle):
+    rng = np.random.default_rng(8)
+    # a dense core and a far halo: targets in the halo need many shells; all-identical points: every distance ties
+    core = rng.standard_normal((1, 1900, 3)).astype(np.float32)
+    halo = (rng.standard_normal((1, 148, 3)) * 200).astype(np.float32)
+    kn = np.concatenate([core, halo], 1)
+    u = np.concatenate([(rng.standard_normal((1, 600, 3)) * 150).astype(np.float32), core[:, :200]], 1)
+    d2, idx = run_three_nn(nat, u, kn)
+    d2r, idxr = oracle.three_nn(u, kn)
+    assert np.array_equal(idx, idxr) and np.array_equal(d2, d2r)
+    same = np.ones((1, 1024, 3), np.float32)
+    d2, idx = run_three_nn(nat, same[:, :70], same)
+    d2r, idxr = oracle.three_nn(same[:, :70], same)
+    assert np.array_equal(idx, idxr) and np.array_equal(d2, d2r)
+    two = np.ones((1, 1024, 3), np.float32)          # only two finite points: the third entry stays (inf, 0)
+    two[:, 2:] = np.nan
+    d2, idx = run_three_nn(nat, same[:, :5] * 2, two)
+    d2r, idxr = oracle.three_nn(same[:, :5] * 2, two)
+    assert np.array_equal(idx, idxr) and np.array_equal(d2, d2r)
+
+
 @pytest.mark.parametrize("B,cin,cout,hw", [(2, 6, 32, 256), (3, 32, 32, 1024), (2, 99, 64, 512), (2, 131, 128, 256),
                                            (1, 64, 256, 64), (16, 32, 64, 131072), (2, 384, 128, 1024), (4, 67, 64, 16)])
 def test_conv1x1_wgrad(nat, B, cin, cout, hw):
