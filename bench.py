@@ -32,19 +32,24 @@ FP32_MFMA_PEAK_TF = 157.3  # v_mfma_f32_16x16x4_f32 / 32x32x2_f32: the fp32 matr
 # Numbers NOT measured by this run: PMC counter readings of earlier profiling passes, kept with the file they came from.
 # (rocprofv3 --pmc cannot run inside the timed region; `roofline.traffic` is the one field the contract asks for.)
 OFFLINE = {
-    "ball_query_traffic_bytes": {"shape": [16, 8192, 8192, 64], "bytes": int((8910.0 + 863.0 + 32768 + 2199.5) * 1024),
-                                 "source": "profiles/r03_ball_query_pmc.txt (FETCH_SIZE + WRITE_SIZE of grid_build_kernel + "
-                                           "ball_query_cells_kernel<64>, separate rocprofv3 --pmc passes; FETCH_SIZE as reported — "
+    "ball_query_traffic_bytes": {"shape": [16, 8192, 8192, 64], "bytes": int((9189.0 + 880.0 + 35136.0 + 2199.8) * 1024),
+                                 "source": "profiles/r04_ball_query_pmc.txt (FETCH_SIZE + WRITE_SIZE of grid_build_split_kernel<8> + "
+                                           "ball_query_cells_kernel<64, 1>, separate rocprofv3 --pmc passes; FETCH_SIZE as reported — "
                                            "these kernels issue 12-16 byte gathers, not the wide streams the x2 gfx950 "
                                            "correction applies to)"},
-    "ball_query_valu_issue": {"kernel": "ball_query_cells_kernel<64>", "wave_insts_valu": 8.58e6, "wave_insts_salu": 1.44e6,
-                              "kernel_us": 21.60, "peak_ginst_s": 614.4, "frac_of_issue_peak": round(8.58e6 / 21.60e-6 / 614.4e9, 3),
-                              "general_kernel": {"kernel": "ball_query_grid_kernel", "wave_insts_valu": 12.84e6, "kernel_us": 29.6,
-                                                 "source": "profiles/r02_ball_query_pmc.txt"},
-                              "source": "profiles/r03_ball_query_pmc.txt"},
-    "knn_clamped_valu_issue": {"kernel": "knn_cells_kernel<32> + knn_grid_kernel<1> (deferred)", "source": "profiles/r03_knn_clamped_pmc.txt"},
-    "step_traffic_mib": {"fetch_reported": 12719.2, "write": 9533.3,
-                         "source": "profiles/r03_step_hbm_traffic.txt (per-kernel FETCH_SIZE / WRITE_SIZE table of one round-3 C4 step, "
+    "ball_query_kernels_us": {"ball_query_cells_kernel<64, 1>": 16.74, "grid_build_split_kernel<8>": 12.55,
+                              "query_plus_half_build_frac_of_hbm_peak": round(36700160 / ((16.74 + 12.55 / 2) * 1e-6) / 8e12, 4),
+                              "round_3": {"ball_query_cells_kernel<64>": 21.54, "grid_build_kernel<8>": 15.50},
+                              "source": "profiles/r04_ball_query_pmc.txt (rocprofv3 --kernel-trace --stats, idle GPU)"},
+    "ball_query_valu_issue": {"kernel": "ball_query_cells_kernel<64, 1>", "wave_insts_valu": 6.27e6, "kernel_us": 16.74,
+                              "peak_ginst_s": 1228.8, "frac_of_issue_peak": round(6.27e6 / 16.74e-6 / 1228.8e9, 3),
+                              "note": "peak = 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU on a SIMD (one wavefront alone "
+                                      "issues every 4)",
+                              "round_3": {"wave_insts_valu": 8.58e6, "kernel_us": 21.54},
+                              "source": "profiles/r04_ball_query_pmc.txt"},
+    "knn_clamped_valu_issue": {"kernel": "knn_cells_kernel<32> + knn_grid_kernel<1> (deferred)", "source": "profiles/r04_knn_clamped_pmc.txt"},
+    "step_traffic_mib": {"fetch_reported": 12663.4, "write": 9538.0,
+                         "source": "profiles/r04_step_hbm_traffic.txt (per-kernel FETCH_SIZE / WRITE_SIZE table of one round-4 C4 step, "
                                    "mean of whole timed steps; the estimate doubles the reported fetch: MI355X_MICROARCH.md)"},
 }
 
@@ -474,9 +479,9 @@ def main():
             m_ = n_
             alg = b_ * (12 * m_ + 12 * n_ + 4 * m_ * ns_)            # 12M + 12N + 4M*nsample per cloud
             gbs = alg / (ms * 1e-3) / 1e9
-            roof = {"kernel": ("ogc_ball_query_cells (ball_query_cells_kernel<64>) on the cell grid shared with the loss's k-NN, plus "
-                               "half of ogc_cell_grid_build (grid_build_kernel)") if shared else
-                              "ogc_ball_query (grid_build_kernel + ball_query_cells_kernel<64>)",
+            roof = {"kernel": ("ogc_ball_query_cells (ball_query_cells_kernel<64, 1>) on the cell grid shared with the loss's k-NN, plus "
+                               "half of ogc_cell_grid_build (grid_build_split_kernel<8>)") if shared else
+                              "ogc_ball_query (grid_build_split_kernel<8> + ball_query_cells_kernel<64, 1>)",
                     "bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(gbs / HBM_PEAK_GBS, 5),
                     "traffic": (OFFLINE["ball_query_traffic_bytes"]["bytes"]
@@ -504,7 +509,7 @@ def main():
                             "8*B*N*M flop no longer describes the work done.  A pair of HIP events reads event_pair_floor_ms with "
                             "NOTHING between them (measured live, idle GPU): achieved / frac / avg_ms are the raw readings, "
                             "floor_removed the same launches with that floor taken off, which is what the rocprofv3 kernel "
-                            "statistics of this command show (profiles/r03_bench_kernel_stats.csv; tools/bench_ops.py has the "
+                            "statistics of this command show (profiles/r04_bench_kernel_stats.csv; tools/bench_ops.py has the "
                             "idle-GPU table)",
                     "all_pairs_equivalent_tpairs_per_s": round(b_ * n_ * m_ / (ms * 1e-3) / 1e12, 2)}
         others = {}
