@@ -522,8 +522,13 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_gemm_kernel(int M,
 // four rows x four positions, summed over the sixteen lanes of its DPP row, go straight to the fp64 accumulators in global
 // memory (copy blockIdx.x % GN_SLOTS): 32 atomics per wavefront and 64-row tile.
 // POOL: the extreme of every neighbourhood as well (PoolOut; see conv1x1_gemm_kernel), for the max-pool that ends the MLP.
-template <int KQ, bool PRO, bool EXACT, bool STATS = false, bool POOL = false>
-__global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_gemm_stream_kernel(int M, int K, int hw, int ntiles,
+// DUAL: two workgroups per CU (two wavefronts per SIMD), ONE register set per wavefront.  With one wavefront per SIMD the
+// compiler's wait-count pass drains every load in flight — the prefetched next tile included — in front of each tile's MFMAs
+// (the run-time loop over row tiles loses its bookkeeping; unrolled, the kernel spills), so load, MFMA and store phases add
+// up.  Two wavefronts that each load, compute and store in turn fall out of step by themselves: one computes while the other
+// waits for memory.  Needs the weights of both workgroups in LDS (2 x ~70 KB at 128 x 128) and <= 256 registers.
+template <int KQ, bool PRO, bool EXACT, bool STATS = false, bool POOL = false, bool DUAL = false>
+__global__ __launch_bounds__(WG_WAVES *OGC_WAVE, DUAL ? 2 : 1) void conv1x1_gemm_stream_kernel(int M, int K, int hw, int ntiles,
                                                                                  const float *__restrict__ w,
                                                                                  const float *__restrict__ in,
                                                                                  float *__restrict__ out,
@@ -691,12 +696,21 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_gemm_stream_kernel
             }
         }
     };
-    float4 xa[KQ], xb[KQ];
     // a wave walks a contiguous range of position tiles (it stays inside one sample most of the time)
     const int per = (ntiles + nw - 1) / nw;
     int t = (blockIdx.x * WG_WAVES + wave) * per;
     const int t_end = min(ntiles, t + per);
     if (STATS) flush_stats(); // (clears the strip)
+    if constexpr (DUAL) {
+        float4 x1[KQ];
+        for (; t < t_end; ++t) {
+            load_tile(t, x1);
+            compute_store(t, x1);
+        }
+        if (STATS) flush_stats();
+        return;
+    }
+    float4 xa[KQ], xb[KQ];
     if (t < t_end) {
         load_tile(t, xa);
         for (; t + 1 < t_end; t += 2) { // two tiles per round, no branch in the body
@@ -732,16 +746,25 @@ bool gemm_stream_launch(int b, int M, int K, int hw, const float *w, const float
                        WG_WAVES * 4 * 16 * 2 * sizeof(double) + (POOL ? (size_t)Mt * 64 * sizeof(float) : 0);
     if (!gemm_stream_eligible(b, M, K, hw, PRO)) return false;
     const int wgs = (int)(ntiles / WG_WAVES < 256 ? ntiles / WG_WAVES : 256);
-#define OGC_STREAM(KQV, EX)                                                                                                  \
+#define OGC_STREAM_D(KQV, EX, DU, WGS)                                                                                       \
     do {                                                                                                                     \
         static bool raised = false;                                                                                          \
-        const void *fn = reinterpret_cast<const void *>(&conv1x1_gemm_stream_kernel<KQV, PRO, EX, STATS, POOL>);             \
+        const void *fn = reinterpret_cast<const void *>(&conv1x1_gemm_stream_kernel<KQV, PRO, EX, STATS, POOL, DU>);         \
         if (!raised) {                                                                                                       \
             if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess) return false;  \
             raised = true;                                                                                                   \
         }                                                                                                                    \
-        hipLaunchKernelGGL((conv1x1_gemm_stream_kernel<KQV, PRO, EX, STATS, POOL>), dim3(wgs), dim3(WG_WAVES * OGC_WAVE),    \
+        hipLaunchKernelGGL((conv1x1_gemm_stream_kernel<KQV, PRO, EX, STATS, POOL, DU>), dim3(WGS), dim3(WG_WAVES * OGC_WAVE), \
                            lds, s, M, K, hw, (int)ntiles, w, in, out, pa, pb, pro_relu, groups, b, stats, pool);             \
+    } while (0)
+    // two workgroups per CU where the weights of both fit the LDS (the 128-channel layers; OGC_GEMM_STREAM_DUAL=0: one)
+    static const bool dual_on = !(getenv("OGC_GEMM_STREAM_DUAL") && getenv("OGC_GEMM_STREAM_DUAL")[0] == '0');
+    const bool dual = dual_on && !POOL && 2 * (lds + 1024) <= 156 * 1024 && ntiles >= 4096;
+    const int wgs2 = (int)(ntiles / WG_WAVES < 512 ? ntiles / WG_WAVES : 512);
+#define OGC_STREAM(KQV, EX)                                                                                                  \
+    do {                                                                                                                     \
+        if (dual) OGC_STREAM_D(KQV, EX, true, wgs2);                                                                         \
+        else OGC_STREAM_D(KQV, EX, false, wgs);                                                                              \
     } while (0)
     const bool full_rows = M % 64 == 0;
     if (Kq == 32 && full_rows) OGC_STREAM(32, true);         // K = 125 .. 128 (the 128-channel layers)
@@ -749,6 +772,7 @@ bool gemm_stream_launch(int b, int M, int K, int hw, const float *w, const float
     else if (Kq <= 33) OGC_STREAM(33, false);
     else OGC_STREAM(40, false);
 #undef OGC_STREAM
+#undef OGC_STREAM_D
     return true;
 }
 
