@@ -525,6 +525,9 @@ int ogc_conv1x1_gn_slots(void);
  * affine = 0; ogc_conv1x1_gemm_affine with groups > 0, affine = 1): K <= 100, or a shape of the streaming kernel (fp32
  * operands, 100 < K <= 160, hw a multiple of 64, b * hw / 64 >= 2048). */
 int ogc_conv1x1_gemm_stats_supported(int b, int M, int K, int hw, int affine);
+/* 1 when ogc_conv1x1_gemm takes this shape on its streaming kernel (K in 101 .. 160, >= 2048 position tiles, fp32 operands):
+ * the shapes for which the host layers prefer it to a vendor GEMM for a plain product */
+int ogc_conv1x1_gemm_stream_supported(int b, int M, int K, int hw);
 
 /* Operand precision of ogc_conv1x1_gemm* / ogc_conv1x1_wgrad* (process-wide; returns the previous setting).
  * 0 (default): fp32 operands on v_mfma_f32_16x16x4_f32 — exact fp32 FMA chains, the parity mode.

@@ -527,7 +527,8 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_gemm_kernel(int M,
 // (the run-time loop over row tiles loses its bookkeeping; unrolled, the kernel spills), so load, MFMA and store phases add
 // up.  Two wavefronts that each load, compute and store in turn fall out of step by themselves: one computes while the other
 // waits for memory.  Needs the weights of both workgroups in LDS (2 x ~70 KB at 128 x 128) and <= 256 registers.
-template <int KQ, bool PRO, bool EXACT, bool STATS = false, bool POOL = false, bool DUAL = false>
+// TRANS: the A operand is w^T (the input gradient of the layer: out = w^T . in), staged transposed; everything else is the same.
+template <int KQ, bool PRO, bool EXACT, bool STATS = false, bool POOL = false, bool DUAL = false, bool TRANS = false>
 __global__ __launch_bounds__(WG_WAVES *OGC_WAVE, DUAL ? 2 : 1) void conv1x1_gemm_stream_kernel(int M, int K, int hw, int ntiles,
                                                                                  const float *__restrict__ w,
                                                                                  const float *__restrict__ in,
@@ -543,7 +544,7 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE, DUAL ? 2 : 1) void conv1x1_gemm
     const int Kq = (K + 3) >> 2, Mt = (M + 63) >> 6, a_ld = ogc_a_ld(Kq);
     const int tiles_per_img = hw >> 6;
     for (int mt = 0; mt < Mt; ++mt)
-        ogc_stage_weight_tile<false, WG_WAVES>(a_lds + (size_t)mt * 64 * a_ld, w, mt * 64, M, K, Kq);
+        ogc_stage_weight_tile<TRANS, WG_WAVES>(a_lds + (size_t)mt * 64 * a_ld, w, mt * 64, M, K, Kq);
     // POOL: -1 for the rows whose next scale is negative, after the other strips (16-byte aligned: every strip is)
     float *sgn_all = a_lds + (size_t)Mt * 64 * a_ld + (PRO ? WG_WAVES * 2 * FW_KQ_MAX * 4 : 0) + WG_WAVES * 4 * 16 * 2 * 2;
     if constexpr (POOL) {
@@ -736,7 +737,7 @@ bool gemm_stream_eligible(int b, int M, int K, int hw, bool pro) {
              ntiles >= (1ll << 31));
 }
 
-template <bool PRO, bool STATS = false, bool POOL = false>
+template <bool PRO, bool STATS = false, bool POOL = false, bool TRANS = false>
 bool gemm_stream_launch(int b, int M, int K, int hw, const float *w, const float *in, float *out, const float *pa,
                         const float *pb, int pro_relu, hipStream_t s, int groups = 1, double *stats = nullptr,
                         PoolOut pool = PoolOut()) {
@@ -749,12 +750,12 @@ bool gemm_stream_launch(int b, int M, int K, int hw, const float *w, const float
 #define OGC_STREAM_D(KQV, EX, DU, WGS)                                                                                       \
     do {                                                                                                                     \
         static bool raised = false;                                                                                          \
-        const void *fn = reinterpret_cast<const void *>(&conv1x1_gemm_stream_kernel<KQV, PRO, EX, STATS, POOL, DU>);         \
+        const void *fn = reinterpret_cast<const void *>(&conv1x1_gemm_stream_kernel<KQV, PRO, EX, STATS, POOL, DU, TRANS>);         \
         if (!raised) {                                                                                                       \
             if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess) return false;  \
             raised = true;                                                                                                   \
         }                                                                                                                    \
-        hipLaunchKernelGGL((conv1x1_gemm_stream_kernel<KQV, PRO, EX, STATS, POOL, DU>), dim3(WGS), dim3(WG_WAVES * OGC_WAVE), \
+        hipLaunchKernelGGL((conv1x1_gemm_stream_kernel<KQV, PRO, EX, STATS, POOL, DU, TRANS>), dim3(WGS), dim3(WG_WAVES * OGC_WAVE), \
                            lds, s, M, K, hw, (int)ntiles, w, in, out, pa, pb, pro_relu, groups, b, stats, pool);             \
     } while (0)
     // two workgroups per CU where the weights of both fit the LDS (the 128-channel layers; OGC_GEMM_STREAM_DUAL=0: one)
@@ -783,6 +784,10 @@ int gemm_launch(int b, int M, int K, int hw, int groups, const float *w, const f
     if constexpr (!T && (!POOL || (STATS && PRO))) {
         if (!g_matmul_bf16 &&
             gemm_stream_launch<PRO, STATS, POOL>(b, M, K, hw, w, in, out, pa, pb, pro_relu, s, groups, stats, pool))
+            return OGC_OK;
+    }
+    if constexpr (T && !STATS && !PRO && !POOL) { // the plain input gradient of a 101 .. 160-channel layer
+        if (!g_matmul_bf16 && gemm_stream_launch<false, false, false, true>(b, M, K, hw, w, in, out, pa, pb, pro_relu, s))
             return OGC_OK;
     }
     const size_t lds = (size_t)64 * ogc_a_ld(Kq) * sizeof(float); // (the bf16 staging needs half of it)
@@ -843,6 +848,13 @@ extern "C" int ogc_conv1x1_gemm_stats_supported(int b, int M, int K, int hw, int
     // can ogc_conv1x1_gemm_gnstats (affine = 0) / ogc_conv1x1_gemm_affine with groups > 0 (affine = 1) take this shape?
     if (b < 1 || M < 1 || K < 1 || hw < 1) return 0;
     return (K <= 100 || gemm_stream_eligible(b, M, K, hw, affine != 0)) ? 1 : 0;
+}
+
+extern "C" int ogc_conv1x1_gemm_stream_supported(int b, int M, int K, int hw) {
+    // does ogc_conv1x1_gemm (either orientation) run this shape on the streaming kernel — 101 .. 160 reduction channels, enough
+    // position tiles — where it is level with or ahead of the vendor GEMM?  (fp32 operands only)
+    if (b < 1 || M < 1 || K < 1 || hw < 1) return 0;
+    return gemm_stream_eligible(b, M, K, hw, false) ? 1 : 0;
 }
 
 extern "C" int ogc_set_matmul_precision(int bf16) {

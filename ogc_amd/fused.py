@@ -167,12 +167,24 @@ def _gemm_ok(K, hw):
     return hw % 64 == 0 and K <= 160
 
 
-def _plain_gemm_mine(K):
+# Input gradients of 101 .. 160-channel layers on the streaming MFMA kernel (round 4: transposed weights, two workgroups per CU)
+# instead of the vendor GEMM
+import os as _os
+DGRAD_STREAM = _os.environ.get("OGC_DGRAD_STREAM", "1") != "0"   # (0: the vendor GEMM, for A/B runs)
+
+
+def _plain_gemm_mine(K, dgrad_shape=None):
     """A PLAIN product (no folded normalisation on the way in, no statistics on the way out) of reduction length K:
-    the MFMA kernel wins up to 32 channels; from 64 up rocBLAS is 15-35 % faster at every C4 layer shape
-    (tools/dgrad_compare.py: 128 -> 128 input gradient 0.246 vs 0.173 ms), so those go through torch.matmul, unless bf16
-    operands were asked for (which only this repo's kernels provide)."""
-    return K <= 32 or _api._native.get_matmul_precision() != "fp32"
+    the tile kernel wins up to 32 channels; from 64 up rocBLAS is 15-35 % faster than it at every C4 layer shape
+    (tools/dgrad_compare.py: 128 -> 128 input gradient 0.246 vs 0.173 ms), so those go through torch.matmul — unless bf16
+    operands were asked for (which only this repo's kernels provide), or the product is an input gradient
+    (dgrad_shape = (B, M, hw)) that the streaming kernel takes."""
+    if K <= 32 or _api._native.get_matmul_precision() != "fp32":
+        return True
+    if DGRAD_STREAM and dgrad_shape is not None:
+        fn = getattr(_api._native, "conv1x1_gemm_stream_supported", None)
+        return fn is not None and fn(dgrad_shape[0], dgrad_shape[1], K, dgrad_shape[2])
+    return False
 
 
 # Below this many positions (B * hw) a 1x1 convolution goes to the vendor library: the MFMA kernel gives a wavefront 64
@@ -248,7 +260,7 @@ class _PointwiseConv(Function):
                 grad_w = torch.bmm(g3, x3.transpose(1, 2)).sum(0).view_as(weight)
             return grad_x, grad_w, None
         if ctx.needs_input_grad[0]:
-            if _gemm_ok(cout, hw) and _plain_gemm_mine(cout):
+            if _gemm_ok(cout, hw) and _plain_gemm_mine(cout, (B, cin, hw)):
                 grad_x = torch.empty_like(x)
                 _api._native.conv1x1_gemm_wrapper(B, cin, cout, hw, 1, weight.contiguous(), grad_y, grad_x)
             elif _gemm_ok(cout, hw):
@@ -782,7 +794,7 @@ class _NormActConv(Function):
             return grad_prev, None, gw, gb, grad_w.view_as(conv_weight), None, None, None, None, None, None
         nat.conv1x1_wgrad_affine_wrapper(B, cin, cout, hw, relu, y_prev, a, bb, grad_y, grad_w)
         # gradient w.r.t. the (never stored) normalised activation, then through GroupNorm (+ ReLU)
-        if _gemm_ok(cout, hw) and _plain_gemm_mine(cout):
+        if _gemm_ok(cout, hw) and _plain_gemm_mine(cout, (B, cin, hw)):
             grad_z = torch.empty_like(y_prev)
             nat.conv1x1_gemm_wrapper(B, cin, cout, hw, 1, w, grad_y, grad_z)
         else:

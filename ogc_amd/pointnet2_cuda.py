@@ -592,6 +592,11 @@ def get_matmul_precision():
     return _precision
 
 
+def conv1x1_gemm_stream_supported(b, m, k, hw):
+    """ogc_conv1x1_gemm_stream_supported: the plain product of this shape runs on the streaming MFMA kernel."""
+    return bool(_lib.load().ogc_conv1x1_gemm_stream_supported(int(b), int(m), int(k), int(hw)))
+
+
 def conv1x1_gemm_stats_supported(b, m, k, hw, affine):
     """Can the forward convolution of this shape also produce the next GroupNorm's statistics?"""
     return bool(_lib.load().ogc_conv1x1_gemm_stats_supported(int(b), int(m), int(k), int(hw), 1 if affine else 0))
