@@ -679,6 +679,37 @@ def test_ball_query_grid_clustered(nat, oracle, monkeypatch, cells):
     assert np.array_equal(idx.cpu().numpy(), oracle.ball_query(1.0, 64, flat, flat))
 
 
+@pytest.mark.parametrize("thin", [0, 1, 2])
+@pytest.mark.parametrize("ns", [16, 32, 64])
+def test_ball_query_slab_grids_every_orientation(nat, oracle, thin, ns):
+    """Round 4: on a cloud with at most two cells along one axis that axis runs fastest in the cell order and a centre's candidates
+    are THREE long runs (GridHdr::fast / slab) — whichever axis is the thin one.  The cloud mixes uniform background with blobs so
+    that one launch meets every branch of the four-lane kernel: lanes with more than eight hits (the group's lists are compacted),
+    centres with 33 .. 64 hits (whole-wavefront rank sort), more than 64 or a run longer than 128 records (general body), empty
+    and NaN rows.  Rows must be the reference's, bit for bit."""
+    rng = np.random.default_rng(100 * thin + ns)
+    n, r = 8192, 2.0
+    scale = [60.0, 60.0, 60.0]
+    scale[thin] = 3.9                                    # < 2 cells of edge 2.02
+    pc = ((rng.random((2, n, 3), dtype=np.float32) - 0.5) * np.array(scale, np.float32)).astype(np.float32)
+    # blobs: ~40 points within 1 m (lists of 33 .. 64), ~150 within 1.5 m (overflow), a tight knot of 300 (a run > 128)
+    for b in range(2):
+        for count, spread, at in ((40, 0.8, 10.0), (150, 1.2, -15.0), (300, 0.3, 22.0)):
+            sel = rng.choice(n, count, replace=False)
+            centre = np.array([at, at, at], np.float32)
+            centre[thin] = 0.5
+            pc[b, sel] = centre + (rng.random((count, 3), dtype=np.float32) - 0.5) * 2 * spread * np.array([1, 1, 1], np.float32)
+    pc[0, 3] = np.nan
+    pc[1, 100:110] = pc[1, 99]                            # duplicates
+    t = T(pc)
+    idx = torch.full((2, n, ns), -7, dtype=torch.int32, device=DEV)
+    nat.ball_query_wrapper(2, n, n, r, ns, t, t, idx)
+    want = oracle.ball_query(r, ns, pc, pc)
+    assert np.array_equal(idx.cpu().numpy(), want)
+    hits = (want != want[:, :, :1]).sum(-1) + 1           # (lower bound of the hits per row: distinct entries)
+    assert hits.max() == ns and hits.min() == 1           # saturated rows and lonely centres both occur
+
+
 @pytest.mark.parametrize("n,k,r_knn,ns,r_ball,scale,dup", [
     (8192, 32, 1.0, 64, 2.0, (60, 4, 80), 0), (8192, 32, 1.0, 64, 2.0, (60, 4, 80), 900),   # C4's smoothness term
     (4096, 8, 0.02, 16, 0.04, (1, 1, 1), 0),                                                # C2's
