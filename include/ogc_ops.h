@@ -177,11 +177,12 @@ int ogc_knn_clamped_cells(int b, int n, int k, float radius, const float *xyz, v
  *          then the element counts;  chunks (device, int32, n_chunks x 2): (tensor, first element) of every
  *          ogc_adam_chunk()-element piece;  grad_ptrs: HOST array of the n_tensors gradient pointers (<= ogc_adam_max_tensors());
  *   flag   (device, int32, zero on entry): 1 afterwards when a gradient held a NaN — the update and the step counts are then
- *          skipped on the device;  step_snapshot: n_tensors floats of scratch. */
+ *          skipped on the device;  step_snapshot: n_tensors floats of scratch.  Hyper-parameters are doubles as in ATen's
+ *          fused kernel (they meet the fp32 state in double expressions rounded once). */
 int ogc_adam_max_tensors(void);
 int ogc_adam_chunk(void);
 int ogc_adam_step(int n_tensors, int n_chunks, const long long *table, const int *chunks, const void *const *grad_ptrs,
-                  float *step_snapshot, int *flag, float lr, float beta1, float beta2, float eps, float weight_decay,
+                  float *step_snapshot, int *flag, double lr, double beta1, double beta2, double eps, double weight_decay,
                   ogc_stream_t stream);
 
 /* Batched 3x3 Kabsch rotation.  Replaces torch.svd + the reflection fix of the weighted-Kabsch fit
@@ -377,7 +378,8 @@ int ogc_conv1x1_dgrad_adjoint(int b, int cin, int cout, int hw, int relu, const 
  *   ogc_group_norm_maxpool_bwd_sparse: ogc_group_norm_maxpool_bwd with  coef2 (b, c, 2) = (c2, c3)  and
  *       inj (b, c, p, 2) = (ag, argmax as its bit pattern)  in place of grad_x (b, c, p, s); grad_gamma / grad_beta as there.
  *       x_at_argmax (b, c, p) or NULL: x[b, c, pr, argmax] where the forward pass kept it (yext of
- *       ogc_conv1x1_gemm_affine_pool) — the sums pass then gathers nothing from x (x may be NULL).
+ *       ogc_conv1x1_gemm_affine_pool) — the sums pass then gathers from x only for channels whose scale rstd * gamma
+ *       is zero (x itself is always required).
  *   ogc_conv1x1_wgrad_moments_pooled / ogc_conv1x1_dgrad_adjoint_pooled: ogc_conv1x1_wgrad_moments / _dgrad_adjoint of the
  *       convolution that wrote y, taking (y, coef2, inj) for grad_y and rebuilding it with the expression above while they
  *       load y — results identical, bit for bit, to the dense sequence; the pass that reads y and writes grad_y (the size of

@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libogc_ops.so")
 _vp = ctypes.c_void_p
 _int = ctypes.c_int
 _flt = ctypes.c_float
+_dbl = ctypes.c_double
 
 # name -> argtypes (stream is always the trailing void*)
 SIGNATURES = {
@@ -39,7 +40,7 @@ SIGNATURES = {
     "ogc_zero_arena_end": [],
     "ogc_adam_max_tensors": [],
     "ogc_adam_chunk": [],
-    "ogc_adam_step": [_int, _int, _vp, _vp, _vp, _vp, _vp, _flt, _flt, _flt, _flt, _flt, _vp],
+    "ogc_adam_step": [_int, _int, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl, _dbl, _dbl, _vp],
     "ogc_kabsch_rotation": [_int, _vp, _vp, _vp, _vp],
     "ogc_lsap_maximize": [_int, _int, _vp, _vp, _vp],
     "ogc_rigid_moments": [_int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp],

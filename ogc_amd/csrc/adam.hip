@@ -10,7 +10,7 @@
 //
 // The tensors stay torch's: parameters, exp_avg, exp_avg_sq and the per-parameter step counts of optimizer.state are
 // updated in place, so state_dict() / load_state_dict() see what torch's own step would have left (same formulas as
-// ATen's fused kernel: bias corrections in double, everything else in fp32 without contraction).
+// ATen's fused kernel: hyper-parameters and bias corrections in double, see adam_update_kernel).
 #include <math.h>
 
 #include "ogc_common.h"
@@ -47,8 +47,8 @@ __global__ __launch_bounds__(ADAM_THREADS) void adam_nan_kernel(int n_tensors, c
 __global__ __launch_bounds__(ADAM_THREADS) void adam_update_kernel(int n_tensors, const long long *__restrict__ table,
                                                                    const int *__restrict__ chunks, AdamGrads grads,
                                                                    const float *__restrict__ step_snapshot,
-                                                                   const int *__restrict__ flag, float lr, float beta1,
-                                                                   float beta2, float eps, float weight_decay) {
+                                                                   const int *__restrict__ flag, double lr, double beta1,
+                                                                   double beta2, double eps, double weight_decay) {
     if (*flag != 0) return; // a NaN somewhere: no update, no step count (train_seg.py:81-83)
     const int ti = chunks[2 * blockIdx.x], off = chunks[2 * blockIdx.x + 1];
     const long long nt = n_tensors;
@@ -59,18 +59,19 @@ __global__ __launch_bounds__(ADAM_THREADS) void adam_update_kernel(int n_tensors
     const float *g = grads.g[ti];
     const float step = step_snapshot[ti] + 1.0f;
     if (off == 0 && threadIdx.x == 0) *reinterpret_cast<float *>(table[3 * nt + ti]) = step;
-    // (ATen: fused_adam_utils.cuh — the corrections in double, then fp32)
-    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
-    const float step_size = (float)((double)lr / bc1);
-    const float bc2_sqrt = (float)sqrt(bc2);
-    const float w1 = 1.0f - beta1, w2 = 1.0f - beta2;
+    // ATen's FusedAdamMathFunctor / adam_math (ATen/native/cuda/fused_adam_utils.cuh of torch 2.10): the hyper-parameters are
+    // doubles, the bias corrections are computed in double and handed on as fp32, every expression that mixes a double
+    // hyper-parameter with fp32 state is evaluated in double and rounded once on assignment
+    const float bc1 = (float)(1.0 - pow(beta1, (double)step));
+    const float bc2_sqrt = (float)sqrt(1.0 - pow(beta2, (double)step));
+    const float step_size = (float)(lr / (double)bc1);
     const long long end = min((long long)off + ADAM_CHUNK, numel);
     for (long long e = off + threadIdx.x; e < end; e += ADAM_THREADS) {
         float param = p[e], grad = g[e], ea = m[e], es = v[e];
-        if (weight_decay != 0.0f) grad += param * weight_decay;
-        ea = w1 < 0.5f ? ea + w1 * (grad - ea) : grad - (grad - ea) * (1.0f - w1); // at::native lerp
-        es = es * beta2 + w2 * grad * grad;
-        const float denom = sqrtf(es) / bc2_sqrt + eps;
+        if (weight_decay != 0.0) grad = (float)((double)grad + (double)param * weight_decay);
+        ea = (float)(beta1 * (double)ea + (1.0 - beta1) * (double)grad);
+        es = (float)(beta2 * (double)es + (1.0 - beta2) * (double)grad * (double)grad);
+        const float denom = (float)((double)(sqrtf(es) / bc2_sqrt) + eps);
         param -= step_size * ea / denom;
         p[e] = param;
         m[e] = ea;
@@ -87,8 +88,8 @@ extern "C" int ogc_adam_chunk(void) { return ADAM_CHUNK; }
 // `table`, built once).  flag (device, int32) must be zero on entry and is 1 afterwards when a gradient held a NaN (the step
 // is then skipped on the device: nothing else is written).  step_snapshot: n_tensors floats of scratch.
 extern "C" int ogc_adam_step(int n_tensors, int n_chunks, const long long *table, const int *chunks,
-                             const void *const *grad_ptrs, float *step_snapshot, int *flag, float lr, float beta1,
-                             float beta2, float eps, float weight_decay, ogc_stream_t stream) {
+                             const void *const *grad_ptrs, float *step_snapshot, int *flag, double lr, double beta1,
+                             double beta2, double eps, double weight_decay, ogc_stream_t stream) {
     OGC_REQUIRE(n_tensors >= 0 && n_chunks >= 0, "ogc_adam_step: negative size");
     if (n_tensors == 0 || n_chunks == 0) return OGC_OK;
     OGC_REQUIRE(n_tensors <= ADAM_MAX_TENSORS, "ogc_adam_step: more than %d tensors in one call", ADAM_MAX_TENSORS);

@@ -727,11 +727,12 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE, DUAL ? 2 : 1) void conv1x1_gemm
 
 // the streaming kernel for this shape, or false when the tile kernel should run
 // shapes the streaming kernel takes (fp32 operands only)
-bool gemm_stream_eligible(int b, int M, int K, int hw, bool pro) {
+// (pool: the launch also carries the sign strip of the pooled epilogue — one float per staged row)
+bool gemm_stream_eligible(int b, int M, int K, int hw, bool pro, bool pool = false) {
     const int Kq = (K + 3) / 4, Mt = (M + 63) / 64;
     const long long ntiles = (long long)b * (hw / 64);
     const size_t lds = ((size_t)Mt * 64 * ogc_a_ld(Kq) + (pro ? WG_WAVES * 2 * FW_KQ_MAX * 4 : 0)) * sizeof(float) +
-                       WG_WAVES * 4 * 16 * 2 * sizeof(double);
+                       WG_WAVES * 4 * 16 * 2 * sizeof(double) + (pool ? (size_t)Mt * 64 * sizeof(float) : 0);
     static const bool off = getenv("OGC_GEMM_STREAM") && getenv("OGC_GEMM_STREAM")[0] == '0';
     return !(off || g_matmul_bf16 || (hw & 63) != 0 || Kq <= 25 || Kq > FW_KQ_MAX || lds > 156 * 1024 || ntiles < 2048 ||
              ntiles >= (1ll << 31));
@@ -745,7 +746,7 @@ bool gemm_stream_launch(int b, int M, int K, int hw, const float *w, const float
     const long long ntiles = (long long)b * (hw / 64);
     const size_t lds = ((size_t)Mt * 64 * ogc_a_ld(Kq) + (PRO ? WG_WAVES * 2 * FW_KQ_MAX * 4 : 0)) * sizeof(float) +
                        WG_WAVES * 4 * 16 * 2 * sizeof(double) + (POOL ? (size_t)Mt * 64 * sizeof(float) : 0);
-    if (!gemm_stream_eligible(b, M, K, hw, PRO)) return false;
+    if (!gemm_stream_eligible(b, M, K, hw, PRO, POOL) || lds > 156 * 1024) return false;
     const int wgs = (int)(ntiles / WG_WAVES < 256 ? ntiles / WG_WAVES : 256);
 #define OGC_STREAM_D(KQV, EX, DU, WGS)                                                                                       \
     do {                                                                                                                     \
@@ -967,7 +968,7 @@ extern "C" int ogc_conv1x1_gemm_affine_pool(int b, int M, int K, int hw, int rel
     if (rc != OGC_OK) return rc;
     OGC_REQUIRE(pa && pb && next_gamma && stats && yext && aext, "ogc_conv1x1_gemm_affine_pool: null pointer");
     if (groups < 1 || groups > 32 || M % groups != 0 || (M / groups) % 4 != 0 ||
-        (K > 100 && !gemm_stream_eligible(b, M, K, hw, true)) || (nsample != 16 && nsample != 32 && nsample != 64) ||
+        (K > 100 && !gemm_stream_eligible(b, M, K, hw, true, true)) || (nsample != 16 && nsample != 32 && nsample != 64) ||
         hw % nsample != 0) {
         ogc_set_error("ogc_conv1x1_gemm_affine_pool: needs 1 <= groups <= 32, (M / groups) %% 4 == 0, K <= 100 and "
                       "nsample in {16, 32, 64} dividing hw (M=%d, groups=%d, K=%d, nsample=%d)", M, groups, K, nsample);

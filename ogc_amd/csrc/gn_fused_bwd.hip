@@ -498,6 +498,11 @@ int dgrad_adjoint_impl(const char *name, int b, int cin, int cout, int hw, int r
     const int M = cin, K = cout, Kq = (K + 3) / 4;
     const size_t lds = ((size_t)64 * ogc_a_ld(Kq) + 64 * 5) * sizeof(float) +
                        (inj ? (size_t)WG_WAVES * K * (64 >> s_shift) * sizeof(float4) : 0);
+    if (lds > 64 * 1024) { // (the kernels keep the default dynamic-LDS limit)
+        ogc_set_error("%s: the weight tile and the pooled table need %zu bytes of LDS (> 64 KiB) at cout=%d, nsample=%d", name,
+                      lds, cout, 64 >> (6 - s_shift));
+        return OGC_ERR_UNSUPPORTED;
+    }
     dim3 grid(ogc_divup(hw, 64 * WG_WAVES), b);
     hipStream_t s = (hipStream_t)stream;
     const float2 *c2 = reinterpret_cast<const float2 *>(coef2), *ij = reinterpret_cast<const float2 *>(inj);

@@ -775,7 +775,7 @@ extern "C" int ogc_group_norm_maxpool_bwd_sparse(int b, int c, int p, int s, int
         return OGC_ERR_UNSUPPORTED;
     }
     if (b == 0) return OGC_OK;
-    OGC_REQUIRE((x || x_at_argmax) && gamma && mean && rstd && out && argmax && grad_out && coef2 && inj && grad_gamma &&
+    OGC_REQUIRE(x && gamma && mean && rstd && out && argmax && grad_out && coef2 && inj && grad_gamma &&
                     grad_beta && ws,
                 "ogc_group_norm_maxpool_bwd_sparse: null pointer");
     OGC_REQUIRE(b <= 65535, "ogc_group_norm_maxpool_bwd_sparse: batch exceeds the grid limit");

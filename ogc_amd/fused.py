@@ -913,7 +913,11 @@ def norm_act_conv_pool_available(y_prev, gn, conv, next_gn):
             and getattr(nat, "conv1x1_gemm_affine_pool_wrapper", None) is not None):
         return False
     cin, cout, g, g2 = y_prev.shape[1], conv.weight.shape[0], gn.num_groups, next_gn.num_groups
-    return ((y_prev.shape[2] * y_prev.shape[3]) % 64 == 0 and cin <= FUSED_GN_BACKWARD_MAX_WIDTH
+    # LDS of ogc_conv1x1_dgrad_adjoint_pooled: the weight tile + one (scale, offset, injection, arg-max) entry per wave,
+    # output channel and neighbourhood of a 64-position tile; the kernel keeps the default 64 KiB
+    kq = (cout + 3) // 4
+    lds = (64 * 4 * (kq | 1) + 320) * 4 + 4 * cout * (64 // y_prev.shape[-1]) * 16
+    return (lds <= 65536 and (y_prev.shape[2] * y_prev.shape[3]) % 64 == 0 and cin <= FUSED_GN_BACKWARD_MAX_WIDTH
             and cout <= max(FUSED_GN_BACKWARD_MAX_WIDTH, SPARSE_POOL_MAX_COUT) and g <= 32 and cin % g == 0
             and g2 <= 32 and cout % g2 == 0 and (cout // g2) % 4 == 0)
 

@@ -48,10 +48,13 @@ class _Body(nn.Module):
         return self._body(*tensors)
 
 
-def _key(name, tensors):
+def _key(name, tensors, parts):
+    """(The graphs replay against the parameter STORAGES they were captured with: net.to(), .float() or a re-wrap that moves a
+    parameter must not find the old graph.)"""
     from ..pointnet2 import pointnet2 as _api
     prec = getattr(_api._native, "get_matmul_precision", lambda: "fp32")()
-    return (name, prec, tuple((tuple(t.shape), t.dtype, bool(t.requires_grad)) for t in tensors))
+    where = tuple(p.data_ptr() for m in parts for p in m.parameters())
+    return (name, prec, tuple((tuple(t.shape), t.dtype, bool(t.requires_grad)) for t in tensors), where)
 
 
 def _make(owner, name, body, tensors, parts):
@@ -60,16 +63,19 @@ def _make(owner, name, body, tensors, parts):
         return None
     module.train()
     sample = tuple(t.detach().clone().requires_grad_(t.requires_grad) for t in tensors)
+    # (the capture's warm-up runs on a stream of its own, which is where autograd then expects these parameters' gradients
+    # to be accumulated; it synchronises the streams itself and says so — silenced for the capture only)
+    quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
     try:
-        # (the capture's warm-up runs on a stream of its own, which is where autograd then expects these parameters' gradients
-        # to be accumulated; it synchronises the streams itself and says so once per process — not news here)
-        quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
         if quiet is not None:
             quiet(False)
         return torch.cuda.make_graphed_callables(module, sample)
     except Exception as err:  # a capture that does not work on this stack must not take training down with it
         warnings.warn("'%s' of %s not captured as a HIP graph (%s): running eagerly" % (name, type(owner).__name__, str(err)[:300]))
         return None
+    finally:
+        if quiet is not None:
+            quiet(True)
 
 
 def run(owner, name, body, tensors, parts=None):
@@ -79,9 +85,12 @@ def run(owner, name, body, tensors, parts=None):
     if not allowed(owner, tensors[0]):
         return body(*tensors)
     store = owner.__dict__.setdefault("_subgraphs", {})
-    key = _key(name, tensors)
+    parts = [owner] if parts is None else list(parts)
+    key = _key(name, tensors, parts)
     if key not in store:
-        store[key] = [_make(owner, name, body, tensors, [owner] if parts is None else list(parts)), None]
+        for stale in [k for k in store if k[:3] == key[:3]]:  # the same body on parameters that have moved since
+            del store[stale]
+        store[key] = [_make(owner, name, body, tensors, parts), None]
     entry = store[key]
     graphed, last = entry
     if graphed is None or (last is not None and last[0]() is not None and not last[1][0]):

@@ -48,7 +48,8 @@ def test_python_binding_matches_the_prototypes():
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     text = re.sub(r"\s+", " ", text)
     protos = dict(re.findall(r"\b(ogc_[a-z0-9_]+)\s*\(([^()]*)\)\s*;", text))
-    kinds = {ctypes.c_void_p: "ptr", ctypes.c_int: "int", ctypes.c_float: "float", ctypes.c_longlong: "ll"}
+    kinds = {ctypes.c_void_p: "ptr", ctypes.c_int: "int", ctypes.c_float: "float", ctypes.c_double: "double",
+             ctypes.c_longlong: "ll"}
     for name, argtypes in _lib.SIGNATURES.items():
         params = [p.strip() for p in protos[name].split(",") if p.strip() not in ("", "void")]
         want = []
@@ -57,6 +58,8 @@ def test_python_binding_matches_the_prototypes():
                 want.append("ptr")
             elif p.startswith("float"):
                 want.append("float")
+            elif p.startswith("double"):
+                want.append("double")
             elif p.startswith("long long"):
                 want.append("ll")
             else:

@@ -93,6 +93,12 @@ def test_adam_kernel_equals_optimizer_step():
         for pa, pb in zip(a.parameters(), b.parameters()):
             assert torch.allclose(pa, pb, rtol=2e-6, atol=1e-7), (step, float((pa - pb).abs().max()))
     assert used[0] is False and all(used[1:]), used
+    # the kernel evaluates ATen's expressions (double hyper-parameters against fp32 state, rounded once per assignment): after
+    # seven steps nearly every parameter is the same fp32 number (what is left is the contraction of ATen's own build)
+    same = sum(int((pa == pb).sum()) for pa, pb in zip(a.parameters(), b.parameters()))
+    total = sum(pa.numel() for pa in a.parameters())
+    print("adam kernel vs torch fused: %d of %d parameters bit-identical after 7 steps" % (same, total))
+    assert same >= 0.9 * total, (same, total)
     sa, sb = oa.state_dict()["state"], ob.state_dict()["state"]
     for k in sa:
         assert float(sa[k]["step"]) == float(sb[k]["step"]) == 6.0
