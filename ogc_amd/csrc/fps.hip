@@ -333,23 +333,42 @@ __device__ __forceinline__ unsigned fps_rank(int k, int bs_mask, int bs_shift, i
 #ifndef FPS_BUCKET_PACKED_KEY
 #define FPS_BUCKET_PACKED_KEY 1
 #endif
-constexpr int FPSB_NB = 64;        // buckets
-constexpr int FPSB_SLOTS = 8192;   // points incl. padding: 64 buckets x 128
-constexpr int FPSB_KEYBITS = 12;
+// NB = 128 buckets (8193 .. 16384 points, sixteen wavefronts): the rank-ordered copy of the cloud no longer fits the LDS next to
+// nothing (192 KiB), so the winner's coordinates travel with the reduction instead.  Whenever a bucket is re-reduced the lane
+// that owns its new maximum leaves that point's coordinates in the bucket's LDS slot (private to the wavefront); the record lane
+// whose bucket is the wavefront's best copies that slot into the wavefront's slot of the ROUND (double-buffered by round parity,
+// rewritten by every wavefront every round) next to its 64-bit maximum; the key's low word carries the wavefront's number below
+// the rank (ranks are unique, so the passenger bits never decide a comparison), and after the barrier everybody reads the
+// winner's slot.  One more LDS round trip in front of the barrier (~50 ns) against an L2 round trip behind it.
+template <int NB>
+struct FpsBuckets {
+    static constexpr int SLOTS = NB * 128;             // points incl. padding
+    static constexpr int KEYBITS = NB <= 64 ? 12 : 13; // bins of the counting sort
+    static constexpr bool XYZ_LDS = SLOTS <= 8192;     // rank-ordered copy of the cloud in LDS
+    static constexpr int WSHIFT = XYZ_LDS ? 0 : 4;     // passenger bits below the rank in a key's low word: the wavefront
+};
+constexpr int FPSB_SLOTS = FpsBuckets<64>::SLOTS;
 
-template <int WAVES>
+template <int WAVES, int NB = 64>
 __global__ __launch_bounds__(WAVES *OGC_WAVE) void fps_bucket_kernel(int n, int m, int bs_shift,
                                                                       const float *__restrict__ xyz,
                                                                       float *__restrict__ temp, int *__restrict__ idxs,
                                                                       const int *__restrict__ ties_in,
                                                                       int *__restrict__ ties_out) {
-    constexpr int THREADS = WAVES * OGC_WAVE, BPW = FPSB_NB / WAVES, PTS = 2 * BPW, NBIN = 1 << FPSB_KEYBITS;
+    typedef FpsBuckets<NB> Cfg;
+    constexpr int THREADS = WAVES * OGC_WAVE, BPW = NB / WAVES, PTS = 2 * BPW, NBIN = 1 << Cfg::KEYBITS, SLOTS = Cfg::SLOTS;
+    constexpr bool XYZ_LDS = Cfg::XYZ_LDS;
+    constexpr int WSHIFT = Cfg::WSHIFT;
+    static_assert(WAVES <= 16 && (XYZ_LDS || WAVES <= (1 << WSHIFT)), "wavefront number in the key's passenger bits");
     extern __shared__ __attribute__((aligned(16))) float fps_smem[];
     u64 *best_word = reinterpret_cast<u64 *>(fps_smem);           // [2]
     float *red = fps_smem + 4;                                    // [8 * WAVES] reduction scratch
-    float *lx = fps_smem + 4 + 8 * 16, *ly = lx + FPSB_SLOTS, *lz = ly + FPSB_SLOTS; // xyz by RANK slot (rounds)
+    // !XYZ_LDS: cand[NB] (x, y, z, -) of every bucket's current maximum, wcand[2][WAVES] the wavefronts' best of a round
+    float4 *cand = reinterpret_cast<float4 *>(fps_smem + 4 + 8 * 16);
+    float4 *wcand = cand + (XYZ_LDS ? 0 : NB);
+    float *lx = reinterpret_cast<float *>(wcand + (XYZ_LDS ? 0 : 2 * WAVES)), *ly = lx + SLOTS, *lz = ly + SLOTS; // xyz by RANK slot (XYZ_LDS)
     int *hist = reinterpret_cast<int *>(lx);                      // [NBIN]  (build only: aliases lx)
-    unsigned short *perm = reinterpret_cast<unsigned short *>(hist + NBIN); // [FPSB_SLOTS] sorted position -> point
+    unsigned short *perm = reinterpret_cast<unsigned short *>(hist + NBIN); // [SLOTS] sorted position -> point
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, b = blockIdx.x;
     const float *__restrict__ dataset = xyz + (size_t)b * n * 3;
     float *tmp = temp + (size_t)b * n;
@@ -406,7 +425,7 @@ __global__ __launch_bounds__(WAVES *OGC_WAVE) void fps_bucket_kernel(int n, int 
     unsigned seq = 0u; // 2 bits per key bit (most significant key bit in the low bits of seq)
     {
         float cell[3] = {hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]};
-        for (int i = 0; i < FPSB_KEYBITS; ++i) {
+        for (int i = 0; i < Cfg::KEYBITS; ++i) {
             int a = 0;
             if (cell[1] > cell[a]) a = 1;
             if (cell[2] > cell[a]) a = 2;
@@ -435,7 +454,7 @@ __global__ __launch_bounds__(WAVES *OGC_WAVE) void fps_bucket_kernel(int n, int 
                 q[a] = min(max(c, 0), (1 << nbits[a]) - 1);
             }
             int key = 0;
-            for (int j = 0; j < FPSB_KEYBITS; ++j) {
+            for (int j = 0; j < Cfg::KEYBITS; ++j) {
                 const int a = (seq >> (2 * j)) & 3;
                 int bit;
                 if (a == 0) { --rem[0]; bit = (q[0] >> rem[0]) & 1; }
@@ -472,7 +491,7 @@ __global__ __launch_bounds__(WAVES *OGC_WAVE) void fps_bucket_kernel(int n, int 
     for (int i = 0; i < PTS; ++i) {
         const int k = t + i * THREADS;
         if (k < n) perm[hist[mykey[i]] + myoff[i]] = (unsigned short)k;
-        else if (k < FPSB_SLOTS) perm[k] = 0xFFFFu; // sorted positions n .. 8191 are padding
+        else if (k < SLOTS) perm[k] = 0xFFFFu; // sorted positions n .. SLOTS-1 are padding
     }
     __syncthreads();
     // ---- this lane's points: bucket (s, wave) = s * WAVES + wave, sorted positions 128 * bucket + 2 * lane + {0, 1}
@@ -487,7 +506,7 @@ __global__ __launch_bounds__(WAVES *OGC_WAVE) void fps_bucket_kernel(int n, int 
             py[j] = dataset[k * 3 + 1];
             pz[j] = dataset[k * 3 + 2];
             td[j] = tmp[k];
-            rk[j] = fps_rank(k, bs_mask, bs_shift, S);
+            rk[j] = (fps_rank(k, bs_mask, bs_shift, S) << WSHIFT) | (unsigned)(XYZ_LDS ? 0 : wave);
         } else {
             px[j] = py[j] = pz[j] = 0.0f;
             td[j] = -1.0f; // padding never wins: real values are >= 0 and min(d, -1) = -1
@@ -495,9 +514,11 @@ __global__ __launch_bounds__(WAVES *OGC_WAVE) void fps_bucket_kernel(int n, int 
         }
     }
     __syncthreads(); // everybody has read perm: the region becomes the rank-ordered copy of the cloud
+    if constexpr (XYZ_LDS) {
 #pragma unroll
-    for (int j = 0; j < PTS; ++j) {
-        if (rk[j] != 0xFFFFFFFFu) { lx[rk[j]] = px[j]; ly[rk[j]] = py[j]; lz[rk[j]] = pz[j]; }
+        for (int j = 0; j < PTS; ++j) {
+            if (rk[j] != 0xFFFFFFFFu) { lx[rk[j]] = px[j]; ly[rk[j]] = py[j]; lz[rk[j]] = pz[j]; }
+        }
     }
     if (t == 0) out[0] = 0;
     // known prefix (see fps_reg_kernel): fold samples 0 .. L-2 into the minima of every point, enter at r = L
@@ -516,7 +537,8 @@ __global__ __launch_bounds__(WAVES *OGC_WAVE) void fps_bucket_kernel(int n, int 
     // (records in lanes 48 + s: the wave-wide key maximum below arrives in the last 16-lane row without leaving the vector unit)
     constexpr int REC0 = 48;
     const bool is_rec = lane >= REC0 && lane < REC0 + BPW;
-    auto reduce_bucket = [&](int s, float t0, float t1, unsigned r0, unsigned r1) {
+    auto reduce_bucket = [&](int s, float t0, float t1, unsigned r0, unsigned r1, float c0x, float c0y, float c0z, float c1x,
+                             float c1y, float c1z) {
 #if FPS_BUCKET_PACKED_KEY
         // ONE reduction of the packed key (value bits, ~rank) over the bucket's 128 points instead of max-then-arg: six DPP
         // steps, each two moves, a 64-bit compare and two selects
@@ -540,6 +562,15 @@ __global__ __launch_bounds__(WAVES *OGC_WAVE) void fps_bucket_kernel(int n, int 
             tie = __popcll(__builtin_amdgcn_ballot_w64(h0 || h1)) > 1 || __builtin_amdgcn_ballot_w64(h0 && h1) != 0;
         }
         if (lane == REC0 + s) { bmv = rec_v; bmr = rec_r; btie = tie; }
+        if constexpr (!XYZ_LDS) { // the owner of the bucket's maximum leaves its coordinates in the bucket's slot
+#if FPS_BUCKET_PACKED_KEY
+            const unsigned wr = 0xFFFFFFFFu - (unsigned)__builtin_amdgcn_readlane((int)(unsigned)k, 63);
+#else
+            const unsigned wr = (unsigned)__builtin_amdgcn_readlane((int)rec_r, 63);
+#endif
+            if (r0 == wr) cand[s * WAVES + wave] = make_float4(c0x, c0y, c0z, 0.f);
+            else if (r1 == wr) cand[s * WAVES + wave] = make_float4(c1x, c1y, c1z, 0.f);
+        }
     };
 #pragma unroll
     for (int s = 0; s < BPW; ++s) {
@@ -556,7 +587,8 @@ __global__ __launch_bounds__(WAVES *OGC_WAVE) void fps_bucket_kernel(int n, int 
             }
             if (lane == REC0 + s) { blo[a] = mn; bhi[a] = mx; }
         }
-        reduce_bucket(s, td[2 * s], td[2 * s + 1], rk[2 * s], rk[2 * s + 1]);
+        reduce_bucket(s, td[2 * s], td[2 * s + 1], rk[2 * s], rk[2 * s + 1], px[2 * s], py[2 * s], pz[2 * s], px[2 * s + 1],
+                      py[2 * s + 1], pz[2 * s + 1]);
     }
     __syncthreads();
 
@@ -585,7 +617,8 @@ __global__ __launch_bounds__(WAVES *OGC_WAVE) void fps_bucket_kernel(int n, int 
                                                   (ogc_v2f){pz[2 * s], pz[2 * s + 1]}, qx, qy, qz);
                     td[2 * s] = ogc_min_f32(d.x, td[2 * s]);
                     td[2 * s + 1] = ogc_min_f32(d.y, td[2 * s + 1]);
-                    reduce_bucket(s, td[2 * s], td[2 * s + 1], rk[2 * s], rk[2 * s + 1]);
+                    reduce_bucket(s, td[2 * s], td[2 * s + 1], rk[2 * s], rk[2 * s + 1], px[2 * s], py[2 * s], pz[2 * s],
+                                  px[2 * s + 1], py[2 * s + 1], pz[2 * s + 1]);
                 }
             }
         }
@@ -594,15 +627,25 @@ __global__ __launch_bounds__(WAVES *OGC_WAVE) void fps_bucket_kernel(int n, int 
         // fps_wave_max, empty buckets at -1 never win) instead of max-then-arg: lane 48 ends up holding the winner's key in
         // registers and hands it to the LDS maximum — no readlane / ballot / readlane round trip through the scalar unit.
         static_assert(BPW == 4 || BPW == 8 || BPW == 16, "fps_max_low_lanes_i64 covers 4, 8 or 16 lanes");
-        long long key = is_rec ? fps_key(bmv, bmr) : (long long)0x8000000000000000ull;
-        key = fps_max_low_lanes_i64<BPW>(key);
-        if (lane == REC0) atomicMax(&best_word[par], (u64)key);
+        const long long mykey = is_rec ? fps_key(bmv, bmr) : (long long)0x8000000000000000ull;
+        const long long key = fps_max_low_lanes_i64<BPW>(mykey);
+        if constexpr (XYZ_LDS) {
+            if (lane == REC0) atomicMax(&best_word[par], (u64)key);
+        } else if (is_rec && mykey == key) { // the record lane of the wavefront's best bucket (s = lane - REC0)
+            wcand[par * WAVES + wave] = cand[(lane - REC0) * WAVES + wave];
+            atomicMax(&best_word[par], (u64)key);
+        }
         if (t == 0) best_word[par ^ 1] = 0ull;
         __syncthreads();
         const u64 best = best_word[par];
         const unsigned brho = 0xFFFFFFFFu - (unsigned)best;
-        x1 = lx[brho]; y1 = ly[brho]; z1 = lz[brho];
-        if (t == 0) out[r] = (int)brho;
+        if constexpr (XYZ_LDS) {
+            x1 = lx[brho]; y1 = ly[brho]; z1 = lz[brho];
+        } else {
+            const float4 c = wcand[par * WAVES + (brho & ((1u << WSHIFT) - 1u))];
+            x1 = c.x; y1 = c.y; z1 = c.z;
+        }
+        if (t == 0) out[r] = (int)(brho >> WSHIFT);
         if (track) { // did a second point attain this round's maximum?  Another bucket with it, or the winner's bucket twice
             const bool eq = is_rec && __float_as_uint(bmv) == (unsigned)(best >> 32);
             const bool tie = eq && (bmr != brho || btie != 0);
@@ -611,7 +654,7 @@ __global__ __launch_bounds__(WAVES *OGC_WAVE) void fps_bucket_kernel(int n, int 
     }
 #pragma unroll
     for (int j = 0; j < PTS; ++j) {
-        if (rk[j] != 0xFFFFFFFFu) tmp[fps_rank_to_k(rk[j], S, bs_shift)] = td[j];
+        if (rk[j] != 0xFFFFFFFFu) tmp[fps_rank_to_k(rk[j] >> WSHIFT, S, bs_shift)] = td[j];
     }
     __syncthreads();
     for (int r = L + t; r < m; r += THREADS) out[r] = fps_rank_to_k((unsigned)out[r], S, bs_shift);
@@ -841,7 +884,26 @@ static int fps_impl(const char *name, int b, int n, int m, const float *xyz, flo
         } else
             fps_launch<16, 512>(b, n, m, shift, xyz, temp, idx, ties_in, ties_out, s);
     }
-    else if (slots <= 16384) fps_launch<32, 512>(b, n, m, shift, xyz, temp, idx, ties_in, ties_out, s);
+    else if (slots <= 16384) {
+        // bucketed rounds with 128 buckets on eight wavefronts (OGC_FPS_BUCKETS=16: sixteen; 0: the plain rounds)
+        static const char *bk = getenv("OGC_FPS_BUCKETS");
+        const int mode = bk ? atoi(bk) : 8;
+        typedef FpsBuckets<128> Cfg;
+        const size_t lds = (4 + 128) * sizeof(float) + (128 + 2 * 16) * sizeof(float4) +
+                           (1 << Cfg::KEYBITS) * sizeof(int) + Cfg::SLOTS * sizeof(unsigned short);
+        if (mode > 0 && m >= 256) {
+            static bool once = false;
+            if (mode == 16) {
+                static bool once16 = false;
+                if (!once16) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fps_bucket_kernel<16, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once16 = true; }
+                hipLaunchKernelGGL((fps_bucket_kernel<16, 128>), dim3(b), dim3(1024), lds, s, n, m, shift, xyz, temp, idx, ties_in, ties_out);
+            } else {
+                if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fps_bucket_kernel<8, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; }
+                hipLaunchKernelGGL((fps_bucket_kernel<8, 128>), dim3(b), dim3(512), lds, s, n, m, shift, xyz, temp, idx, ties_in, ties_out);
+            }
+        } else
+            fps_launch<32, 512>(b, n, m, shift, xyz, temp, idx, ties_in, ties_out, s);
+    }
     else {
         // (these kernels do not track ties: a chain through them never takes the shortcut afterwards)
         if (ties_out && ogc_zero_async(ties_out, sizeof(int) * (size_t)b, s) != hipSuccess) {

@@ -25,7 +25,7 @@ for name, argtypes in sorted(_lib.SIGNATURES.items()):
         for t in argtypes[:-1]:
             if t is ctypes.c_int:
                 out.append(first_int if not seen_int else int_value); seen_int = True
-            elif t is ctypes.c_float:
+            elif t in (ctypes.c_float, ctypes.c_double):
                 out.append(1.0)
             else:
                 out.append(None)

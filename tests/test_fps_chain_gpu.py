@@ -103,30 +103,31 @@ def test_segnet_plan_uses_the_chain():
     assert torch.equal(sa_plans[2]["new_inds"], ar(sa_plans[2]["new_inds"].shape[1]))
 
 
-def test_first_tie_round_of_the_bucketed_rounds(oracle):
-    """8192-point clouds go through fps_bucket_kernel, which finds ties from its bucket records instead of the lanes'
-    registers: the first tied round it reports must be the one the plain rounds report (run in a second process with
-    OGC_FPS_BUCKETS=0), and the chain built on it must match plain sampling level by level."""
+@pytest.mark.parametrize("N,first", [(8192, 2048), (16384, 4096), (12001, 3000)])
+def test_first_tie_round_of_the_bucketed_rounds(oracle, N, first):
+    """4097 .. 16384-point clouds go through fps_bucket_kernel (64 or 128 buckets), which finds ties from its bucket records
+    instead of the lanes' registers: the first tied round it reports must be the one the plain rounds report (run in a second
+    process with OGC_FPS_BUCKETS=0), and the chain built on it must match plain sampling level by level."""
     import os, subprocess, sys, tempfile
     api = _api()
     g = torch.Generator().manual_seed(11)
-    pc = ((torch.rand(3, 8192, 3, generator=g) - 0.5) * torch.tensor([60.0, 4.0, 80.0]))
+    pc = ((torch.rand(3, N, 3, generator=g) - 0.5) * torch.tensor([60.0, 4.0, 80.0]))
     pc[1, 5000] = pc[1, 17]                     # one duplicate: a tie when the second of the pair would be picked ... never
-    pc[2, :4096] = torch.round(pc[2, :4096])    # lattice half: early ties
+    pc[2, :N // 2] = torch.round(pc[2, :N // 2])    # lattice half: early ties
     pc = pc.cuda().contiguous()
-    levels = chain(api, pc, [2048, 512])
+    levels = chain(api, pc, [first, 512])
     for lvl, (idx, plain, ties) in enumerate(levels):
         assert torch.equal(idx, plain), "level %d" % lvl
-    want = oracle.fps(pc.cpu().numpy(), 2048)
+    want = oracle.fps(pc.cpu().numpy(), first)
     np.testing.assert_array_equal(levels[0][0].cpu().numpy(), want)
     with tempfile.TemporaryDirectory() as d:
         np.save(os.path.join(d, "pc.npy"), pc.cpu().numpy())
         code = ("import numpy as np, torch, ogc_amd\n"
                 "from ogc_amd.pointnet2 import pointnet2 as api\n"
                 "pc = torch.from_numpy(np.load(r'%s')).cuda()\n"
-                "idx, t = api.furthest_point_sample_chain(pc, 2048, None)\n"
+                "idx, t = api.furthest_point_sample_chain(pc, %d, None)\n"
                 "np.save(r'%s', t.cpu().numpy()); np.save(r'%s', idx.cpu().numpy())\n"
-                % (os.path.join(d, "pc.npy"), os.path.join(d, "t.npy"), os.path.join(d, "i.npy")))
+                % (os.path.join(d, "pc.npy"), first, os.path.join(d, "t.npy"), os.path.join(d, "i.npy")))
         env = dict(os.environ, OGC_FPS_BUCKETS="0",
                    PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         subprocess.run([sys.executable, "-c", code], check=True, env=env, timeout=300)

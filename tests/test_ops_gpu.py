@@ -298,10 +298,13 @@ def _bucket_range_cloud(kind, rng, N):
 
 
 @pytest.mark.parametrize("kind", ["blobs", "line", "plane", "lattice", "far", "identical", "nonfinite"])
-@pytest.mark.parametrize("N,m", [(4097, 256), (5000, 1200), (6151, 3000), (8192, 4096), (8192, 8192)])
+@pytest.mark.parametrize("N,m", [(4097, 256), (5000, 1200), (6151, 3000), (8192, 4096), (8192, 8192),
+                                 (8193, 256), (11111, 2500), (16384, 4096), (16384, 16384)])  # > 8192: 128 buckets
 def test_fps_bucketed_rounds_bit_exact(nat, oracle, kind, N, m):
     if kind in ("lattice", "identical") and m > 3000:
         m = 3000  # (tie-heavy rounds are slow in the scalar oracle)
+    if N > 8192 and m > 8192:
+        m = 6000
     rng = np.random.default_rng(N + m + len(kind))
     xyz = _bucket_range_cloud(kind, rng, N)
     got, temp = run_fps(nat, xyz, m)
