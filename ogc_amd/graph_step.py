@@ -127,10 +127,17 @@ class GraphedTrainStep:
                 _resolve(self.plan, wait=False)
                 self.optimizer.zero_grad(set_to_none=True)
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph, stream=s):
-                    pending = train_step(self.segnet, self.criterion, self.optimizer, self.cur, it, self.aug, sync=False,
-                                         prefetched=self.plan)
-                    _join_side_streams(torch.cuda.current_stream())
+                import gc
+                collecting = gc.isenabled()  # (no collector pass inside the capture: see utils/subgraph._make)
+                gc.disable()
+                try:
+                    with torch.cuda.graph(graph, stream=s):
+                        pending = train_step(self.segnet, self.criterion, self.optimizer, self.cur, it, self.aug, sync=False,
+                                             prefetched=self.plan)
+                        _join_side_streams(torch.cuda.current_stream())
+                finally:
+                    if collecting:
+                        gc.enable()
         torch.cuda.current_stream().wait_stream(s)
         self.graph, self.pending = graph, pending
         self._plan_dst = list(_plan_tensors(self.plan))

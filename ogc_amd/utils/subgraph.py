@@ -17,6 +17,7 @@ run(owner, name, body, tensors, parts) evaluates body(*tensors) that way when it
   * the previous graphed call of this body has had its backward pass (or its output is gone): the graphs work on STATIC
     buffers, so a second forward pass before the first one's backward pass would overwrite what that pass needs.
 """
+import gc
 import warnings
 import weakref
 
@@ -66,14 +67,22 @@ def _make(owner, name, body, tensors, parts):
     # (the capture's warm-up runs on a stream of its own, which is where autograd then expects these parameters' gradients
     # to be accumulated; it synchronises the streams itself and says so — silenced for the capture only)
     quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+    # No collector pass inside the capture: a cycle collected there may free a tensor or an older graph of another network,
+    # and a runtime call of that kind on a capturing stream aborts the process (seen in tests/test_fallbacks_gpu.py, which
+    # builds one network after another).
+    collecting = gc.isenabled()
     try:
         if quiet is not None:
             quiet(False)
+        gc.collect()
+        gc.disable()
         return torch.cuda.make_graphed_callables(module, sample)
     except Exception as err:  # a capture that does not work on this stack must not take training down with it
         warnings.warn("'%s' of %s not captured as a HIP graph (%s): running eagerly" % (name, type(owner).__name__, str(err)[:300]))
         return None
     finally:
+        if collecting:
+            gc.enable()
         if quiet is not None:
             quiet(True)
 
