@@ -530,6 +530,12 @@ int ogc_conv1x1_gemm_stats_supported(int b, int M, int K, int hw, int affine);
 /* 1 when ogc_conv1x1_gemm takes this shape on its streaming kernel (K in 101 .. 160, >= 2048 position tiles, fp32 operands):
  * the shapes for which the host layers prefer it to a vendor GEMM for a plain product */
 int ogc_conv1x1_gemm_stream_supported(int b, int M, int K, int hw);
+/* The same product for ANY reduction length and row count (ogc_amd/csrc/gemm_chunk.hip: K walked in chunks, the weights'
+ * chunk in LDS, the input chunk in registers; few positions: the wavefronts of a workgroup split the rows): the Conv1d of
+ * the feature-propagation modules (utils/pointnet2_util.py:96-120 — 384 -> 128 on 1024 points ...) and the input gradient
+ * of layers wider than 160 channels, which went to the vendor library before.  hw % 64 == 0; fp32 operands. */
+int ogc_conv1x1_gemm_any(int b, int M, int K, int hw, int transpose_a, const float *w, const float *in, float *out,
+                         ogc_stream_t stream);
 
 /* Operand precision of ogc_conv1x1_gemm* / ogc_conv1x1_wgrad* (process-wide; returns the previous setting).
  * 0 (default): fp32 operands on v_mfma_f32_16x16x4_f32 — exact fp32 FMA chains, the parity mode.

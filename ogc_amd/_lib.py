@@ -90,6 +90,7 @@ SIGNATURES = {
     "ogc_conv1x1_gn_slots": [],
     "ogc_conv1x1_gemm_stats_supported": [_int, _int, _int, _int, _int],
     "ogc_conv1x1_gemm_stream_supported": [_int, _int, _int, _int],
+    "ogc_conv1x1_gemm_any": [_int, _int, _int, _int, _int, _vp, _vp, _vp, _vp],
     "ogc_set_matmul_precision": [_int],
     "ogc_group_norm_stats_slots": [],
     "ogc_group_norm_bwd_slots": [],

@@ -333,6 +333,9 @@ __device__ __forceinline__ unsigned fps_rank(int k, int bs_mask, int bs_shift, i
 #ifndef FPS_BUCKET_PACKED_KEY
 #define FPS_BUCKET_PACKED_KEY 1
 #endif
+#ifndef FPS_BUCKET_SKIP
+#define FPS_BUCKET_SKIP 1 // skip a bucket's re-reduction when its maximum is untouched (0: always reduce)
+#endif
 // NB = 128 buckets (8193 .. 16384 points, sixteen wavefronts): the rank-ordered copy of the cloud no longer fits the LDS next to
 // nothing (192 KiB), so the winner's coordinates travel with the reduction instead.  Whenever a bucket is re-reduced the lane
 // that owns its new maximum leaves that point's coordinates in the bucket's LDS slot (private to the wavefront); the record lane
@@ -534,6 +537,7 @@ __global__ __launch_bounds__(WAVES *OGC_WAVE) void fps_bucket_kernel(int n, int 
     float blo[3] = {0.f, 0.f, 0.f}, bhi[3] = {0.f, 0.f, 0.f}, bmv = -1.0f;
     unsigned bmr = 0xFFFFFFFFu;
     int btie = 0;
+
     // (records in lanes 48 + s: the wave-wide key maximum below arrives in the last 16-lane row without leaving the vector unit)
     constexpr int REC0 = 48;
     const bool is_rec = lane >= REC0 && lane < REC0 + BPW;
@@ -617,6 +621,18 @@ __global__ __launch_bounds__(WAVES *OGC_WAVE) void fps_bucket_kernel(int n, int 
                                                   (ogc_v2f){pz[2 * s], pz[2 * s + 1]}, qx, qy, qz);
                     td[2 * s] = ogc_min_f32(d.x, td[2 * s]);
                     td[2 * s + 1] = ogc_min_f32(d.y, td[2 * s + 1]);
+                    // Does the point that holds the bucket's maximum still hold it?  Then the record stands — every other
+                    // point only decreases, and none of them had the value — and the re-reduction (six 64-bit DPP steps, most
+                    // of a round's dependent chain) is skipped.  (With tie tracking on, only when no second point had the
+                    // value: its fate is not looked at here.)  The record comes out of its lane by v_readlane.
+                    if (FPS_BUCKET_SKIP) {
+                        const unsigned cur_r = (unsigned)__builtin_amdgcn_readlane((int)bmr, REC0 + s);
+                        const unsigned cur_v = (unsigned)__builtin_amdgcn_readlane(__float_as_int(bmv), REC0 + s);
+                        const int cur_t = track ? __builtin_amdgcn_readlane(btie, REC0 + s) : 0;
+                        const bool holds = (rk[2 * s] == cur_r && __float_as_uint(td[2 * s]) == cur_v) ||
+                                           (rk[2 * s + 1] == cur_r && __float_as_uint(td[2 * s + 1]) == cur_v);
+                        if (cur_t == 0 && __builtin_amdgcn_ballot_w64(holds) != 0) continue;
+                    }
                     reduce_bucket(s, td[2 * s], td[2 * s + 1], rk[2 * s], rk[2 * s + 1], px[2 * s], py[2 * s], pz[2 * s],
                                   px[2 * s + 1], py[2 * s + 1], pz[2 * s + 1]);
                 }

@@ -1,0 +1,202 @@
+// gemm_chunk.hip — the 1x1 convolution product for the shapes the register-tile kernels of conv1x1.hip do not take.
+//
+//     OUT[b, m, p] = sum_k A[m, k] IN[b, k, p],     A = w (M x K)  or  A = w^T (w stored K x M: the input gradient)
+//
+// Reference: the Conv1d / Conv2d of SharedMLP (utils/nn_util.py:45-85) in the feature-propagation modules
+// (utils/pointnet2_util.py:96-120: 384 -> 128 on 1024 points, 224 -> 64 on 2048, 67 -> 64 on 8192) and the input gradient of
+// the widest set-abstraction layer (128 <- 256 channels on 16 x 32768 positions).  conv1x1_gemm_kernel keeps the whole K x 64
+// input tile of a wavefront in registers (K <= 160) and gives a wavefront all output rows, so that (a) a reduction over 224,
+// 256 or 384 channels does not fit and (b) a layer of 16384 positions is 64 workgroups on 256 compute units; those products
+// went to the vendor library.  Here K is walked in CHUNKS of 4 KQ rows:
+//   * the IN chunk (4 KQ rows x 64 positions) of a wavefront goes from memory straight into registers — lane (kk = l >> 4,
+//     j = l & 15) holds IN[k0 + 4 q + kk][p0 + 4 j .. 4 j + 3], component c being column j of MFMA column block c, exactly as in
+//     conv1x1_gemm_kernel — double-buffered: the loads of chunk i + 1 are issued before the MFMAs of chunk i;
+//   * the A chunk (rows of the workgroup x 4 KQ) is staged through LDS (row stride 4 * odd: conflict-free ds_read_b32 of the
+//     operand), also double-buffered: ONE barrier per chunk;
+//   * SPLIT_M = false: the four wavefronts of a workgroup own four position tiles and the same 16 RB rows (IN is read once per
+//     row tile; large position counts);  SPLIT_M = true: the four wavefronts own the same position tile and 16 RB rows each
+//     (the IN chunk is loaded by all four — L1 / L2 hits — so that a layer of a few thousand positions still fills the chip).
+// v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 accumulation in k order within a lane's chain.
+#include <stdlib.h>
+
+#include "ogc_common.h"
+
+namespace {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+constexpr int GC_WAVES = 4;
+
+template <int RB, int KQ, bool SPLIT_M, bool TRANS>
+__global__ __launch_bounds__(GC_WAVES *OGC_WAVE, 2) void gemm_chunk_kernel(int M, int K, int hw, const float *__restrict__ w,
+                                                                         const float *__restrict__ in,
+                                                                         float *__restrict__ out) {
+    constexpr int KC = 4 * KQ, LD = 4 * (KQ | 1);
+    constexpr int MT = SPLIT_M ? 64 * RB : 16 * RB;        // rows of A staged per workgroup
+    constexpr int PER = (MT * KC) / (GC_WAVES * OGC_WAVE); // staged elements per thread and chunk
+    static_assert((MT * KC) % (GC_WAVES * OGC_WAVE) == 0 && PER >= 1, "staging split");
+    extern __shared__ __attribute__((aligned(16))) float gc_lds[]; // [2][MT][LD]
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int j = lane & 15, kk = lane >> 4;
+    const int b = blockIdx.z;
+    const int m0 = blockIdx.y * MT;
+    const int wrow = SPLIT_M ? wave * 16 * RB : 0;                    // this wavefront's first row inside the staged tile
+    const int p0 = SPLIT_M ? blockIdx.x * 64 : (blockIdx.x * GC_WAVES + wave) * 64;
+    const bool active = p0 < hw;                                      // (wave-uniform; !SPLIT_M: the last workgroup may be ragged)
+    const int pl = active ? p0 : 0;
+    const int nblk = min(RB, (M - m0 - wrow + 15) >> 4);              // row blocks with at least one real row (may be <= 0)
+    const float *inb = in + (size_t)b * K * hw + pl + 4 * j;
+    const int nchunks = (K + KC - 1) / KC;
+
+    v4f acc[RB][4];
+#pragma unroll
+    for (int a = 0; a < RB; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[a][c] = (v4f){0.f, 0.f, 0.f, 0.f};
+
+    // ---- loads of a chunk: A elements (zeros beyond the matrix), IN rows (clamped onto the last row: its weights are zeros)
+    auto load_a = [&](int k0, float(&av)[PER]) {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int e = t + i * (GC_WAVES * OGC_WAVE);
+            int mi, ki;
+            if (TRANS) { mi = e % MT; ki = e / MT; } else { mi = e / KC; ki = e % KC; } // consecutive lanes: consecutive addresses
+            const int m = m0 + mi, k = k0 + ki;
+            const bool ok = m < M && k < K;
+            const int mc = min(m, M - 1), kc = min(k, K - 1);
+            const float v = TRANS ? w[(size_t)kc * M + mc] : w[(size_t)mc * K + kc];
+            av[i] = ok ? v : 0.f;
+        }
+    };
+    auto store_a = [&](float *dst, const float(&av)[PER]) {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int e = t + i * (GC_WAVES * OGC_WAVE);
+            int mi, ki;
+            if (TRANS) { mi = e % MT; ki = e / MT; } else { mi = e / KC; ki = e % KC; }
+            dst[mi * LD + ki] = av[i];
+        }
+    };
+    auto load_in = [&](int k0, float4(&xv)[KQ]) {
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+            const int k = min(k0 + 4 * q + kk, K - 1);
+            xv[q] = *reinterpret_cast<const float4 *>(inb + (size_t)k * hw);
+        }
+    };
+    // Every row block is computed: rows beyond M are zeros in LDS, and the entry point picks RB so that few are (16 RB >= the
+    // rows of a tile, 67 rows -> RB = 5) — a wave-uniform `a < nblk` branch per row block between the MFMAs costs the matrix pipe
+    // issue slots, and the loop written twice (with and without it) spills.
+    auto compute = [&](const float *a_lds, const float4(&xv)[KQ]) {
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+            const float bx = xv[q].x, by = xv[q].y, bz = xv[q].z, bw = xv[q].w;
+#pragma unroll
+            for (int a = 0; a < RB; ++a) {
+                const float av = a_lds[(wrow + a * 16 + j) * LD + q * 4 + kk];
+                acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bx, acc[a][0], 0, 0, 0);
+                acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, by, acc[a][1], 0, 0, 0);
+                acc[a][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bz, acc[a][2], 0, 0, 0);
+                acc[a][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw, acc[a][3], 0, 0, 0);
+            }
+        }
+    };
+
+    float *buf0 = gc_lds, *buf1 = gc_lds + MT * LD;
+    float4 x0[KQ], x1[KQ];
+    float a_next[PER];
+    load_a(0, a_next);
+    load_in(0, x0);
+    store_a(buf0, a_next);
+    __syncthreads();
+    const bool work = nblk > 0; // (SPLIT_M: a wavefront whose rows all lie beyond M only helps staging)
+    // chunks in pairs so that the two register sets and the two LDS buffers are named, not indexed
+    for (int i = 0; i < nchunks; i += 2) {
+        const bool more1 = i + 1 < nchunks, more2 = i + 2 < nchunks;
+        if (more1) {
+            load_a((i + 1) * KC, a_next);
+            load_in((i + 1) * KC, x1);
+        }
+        if (work) compute(buf0, x0);
+        if (more1) store_a(buf1, a_next);
+        __syncthreads();
+        if (!more1) break;
+        if (more2) {
+            load_a((i + 2) * KC, a_next);
+            load_in((i + 2) * KC, x0);
+        }
+        if (work) compute(buf1, x1);
+        if (more2) store_a(buf0, a_next);
+        __syncthreads();
+    }
+    if (!active) return;
+    // acc[a][c][r]: row a * 16 + kk * 4 + r, position p0 + 4 j + c  ->  one float4 per row
+    float *ob = out + (size_t)b * M * hw + p0 + 4 * j;
+#pragma unroll
+    for (int a = 0; a < RB; ++a) {
+        if (a < nblk) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wrow + a * 16 + kk * 4 + r;
+                if (m < M)
+                    *reinterpret_cast<float4 *>(ob + (size_t)m * hw) =
+                        make_float4(acc[a][0][r], acc[a][1][r], acc[a][2][r], acc[a][3][r]);
+            }
+        }
+    }
+}
+
+template <int RB, int KQ, bool SPLIT_M>
+void gemm_chunk_launch(int b, int M, int K, int hw, int transpose_a, const float *w, const float *in, float *out,
+                       hipStream_t s) {
+    constexpr int MT = SPLIT_M ? 64 * RB : 16 * RB;
+    const size_t lds = (size_t)2 * MT * 4 * (KQ | 1) * sizeof(float);
+    dim3 grid(SPLIT_M ? hw / 64 : ogc_divup(hw, 64 * GC_WAVES), ogc_divup(M, MT), b);
+    if (transpose_a)
+        hipLaunchKernelGGL((gemm_chunk_kernel<RB, KQ, SPLIT_M, true>), grid, dim3(GC_WAVES * OGC_WAVE), lds, s, M, K, hw, w, in, out);
+    else
+        hipLaunchKernelGGL((gemm_chunk_kernel<RB, KQ, SPLIT_M, false>), grid, dim3(GC_WAVES * OGC_WAVE), lds, s, M, K, hw, w, in, out);
+}
+
+} // namespace
+
+// OUT[b, m, p] = sum_k A[m, k] IN[b, k, p] for ANY reduction length and row count (hw % 64 == 0): transpose_a == 0: A = w
+// (M x K), != 0: A = w^T with w stored (K x M).  fp32 operands whatever ogc_set_matmul_precision says.
+extern "C" int ogc_conv1x1_gemm_any(int b, int M, int K, int hw, int transpose_a, const float *w, const float *in, float *out,
+                                    ogc_stream_t stream) {
+    OGC_REQUIRE(b >= 0 && M >= 1 && K >= 1 && hw >= 1, "ogc_conv1x1_gemm_any: bad shape");
+    OGC_REQUIRE(w && in && out, "ogc_conv1x1_gemm_any: null pointer");
+    if ((hw & 63) != 0 || (((uintptr_t)in | (uintptr_t)out) & 15) != 0) {
+        ogc_set_error("ogc_conv1x1_gemm_any: needs hw %% 64 == 0 and 16-byte aligned tensors (hw=%d)", hw);
+        return OGC_ERR_UNSUPPORTED;
+    }
+    OGC_REQUIRE((long long)M * hw < (1ll << 31) && (long long)K * hw < (1ll << 31) && b <= 65535,
+                "ogc_conv1x1_gemm_any: one sample exceeds 32-bit indexing");
+    if (b == 0) return OGC_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const long long tiles = (long long)b * (hw / 64); // 64-position tiles
+#define GC_CASE(RBV, KQV, SPLIT)                                                              \
+    case RBV: gemm_chunk_launch<RBV, KQV, SPLIT>(b, M, K, hw, transpose_a, w, in, out, s); break
+    if (tiles >= 4096) {
+        // enough position tiles for one wavefront each with all rows of a (<= 128-row) tile: IN is read once per row tile.
+        // Row blocks per wavefront: the smallest that covers M in ceil(M / 128) tiles (224 rows: two tiles of 7 blocks)
+        const int ntile = ogc_divup(M, 128), rb = ogc_divup(M, 16 * ntile);
+        switch (rb) {
+            GC_CASE(1, 8, false); GC_CASE(2, 8, false); GC_CASE(3, 8, false); GC_CASE(4, 8, false);
+            GC_CASE(5, 8, false); GC_CASE(6, 8, false); GC_CASE(7, 4, false);
+            default: gemm_chunk_launch<8, 4, false>(b, M, K, hw, transpose_a, w, in, out, s);
+        }
+    } else {
+        // few positions: the wavefronts of a workgroup split the rows, 32 rows per wavefront where that still gives ~2 workgroups
+        // per compute unit and M fills them, 16 otherwise
+        const bool same_rows = 128 * ogc_divup(M, 128) == 64 * ogc_divup(M, 64); // (96 rows: 2 x 64 either way; 192: 256 vs 192)
+        const int rb = (M > 64 && same_rows && tiles * ogc_divup(M, 128) >= 512) ? 2 : 1;
+        switch (rb) {
+            GC_CASE(2, 8, true);
+            default: gemm_chunk_launch<1, 8, true>(b, M, K, hw, transpose_a, w, in, out, s);
+        }
+    }
+#undef GC_CASE
+    OGC_CHECK_LAUNCH("ogc_conv1x1_gemm_any");
+    return OGC_OK;
+}

@@ -201,6 +201,45 @@ def _weight_times_batch(w2d, x3, out=None):
     return torch.bmm(w2d.unsqueeze(0).expand(x3.shape[0], -1, -1), x3, out=out)
 
 
+# The products the register-tile kernels do not take — more than 160 reduction channels, fewer than _SMALL_CONV_POSITIONS
+# positions, plain 64-channel input gradients — on ogc_conv1x1_gemm_any (csrc/gemm_chunk.hip) and ogc_conv1x1_wgrad instead of the
+# vendor library (round 4; tools/gemm_any_compare.py: level with or ahead of rocBLAS on every such product of the C4 / C2 steps
+# except the 256-channel input gradient, 0.31 against 0.28 ms).  OGC_LIBRARY_GEMMS=1: the library routes, for A/B runs.
+LIBRARY_GEMMS = _os.environ.get("OGC_LIBRARY_GEMMS", "0") == "1"
+LIBRARY_WGRAD = LIBRARY_GEMMS or _os.environ.get("OGC_LIBRARY_WGRAD", "0") == "1"   # (the weight gradients alone)
+
+
+@_gate
+def gemm_any_available(x3):
+    return (not LIBRARY_GEMMS and x3.is_cuda and x3.dtype == torch.float32 and x3.shape[2] % 64 == 0 and x3.shape[0] <= 65535
+            and getattr(_api._native, "conv1x1_gemm_any_wrapper", None) is not None)
+
+
+def _product(w2d, x3, transpose, out=None):
+    """A . x3[b] for every sample: A = w2d (M, K), or w2d^T with w2d stored (K, M) when `transpose`; x3 (B, K, P) -> (B, M, P)."""
+    B, K, P = x3.shape
+    M = w2d.shape[1] if transpose else w2d.shape[0]
+    if gemm_any_available(x3):
+        x3 = x3.contiguous()
+        if out is None:
+            out = torch.empty(B, M, P, dtype=torch.float32, device=x3.device)
+        _api._native.conv1x1_gemm_any_wrapper(B, M, K, P, 1 if transpose else 0, w2d.contiguous(), x3, out)
+        return out
+    return _weight_times_batch(w2d.t() if transpose else w2d, x3, out=out)
+
+
+def _weight_grad(g3, x3):
+    """sum_b g3[b] . x3[b]^T: g3 (B, cout, P), x3 (B, cin, P) -> (cout, cin)."""
+    B, cout, P = g3.shape
+    cin = x3.shape[1]
+    if (not (LIBRARY_GEMMS or LIBRARY_WGRAD) and g3.is_cuda and P % 16 == 0 and g3.dtype == torch.float32
+            and getattr(_api._native, "conv1x1_wgrad_wrapper", None) is not None):
+        grad_w = zeroed_empty((cout, cin), torch.float32, g3.device)
+        _api._native.conv1x1_wgrad_wrapper(B, cin, cout, P, x3.contiguous(), g3.contiguous(), grad_w)
+        return grad_w
+    return torch.bmm(g3, x3.transpose(1, 2)).sum(0)
+
+
 class _PointwiseConv(Function):
     """y = conv(x, w) for a bias-free 1x1 convolution on NCHW fp32 tensors, on the hand-written fp32-MFMA kernels:
     ogc_conv1x1_gemm for the forward and the input gradient (when the shape fits its register tile; the vendor library
@@ -229,12 +268,13 @@ class _PointwiseConv(Function):
             elif _plain_gemm_mine(cin):
                 nat.conv1x1_gemm_wrapper(B, cout, cin, hw, 0, weight.contiguous(), x, y)
             else:
-                _weight_times_batch(weight.detach().view(cout, cin), x.reshape(B, cin, hw), out=y.view(B, cout, hw))
+                _product(weight.detach().view(cout, cin), x.reshape(B, cin, hw), False, out=y.view(B, cout, hw))
         else:
-            # shapes the MFMA kernels do not take (K > 160, ragged or tiny position counts): one batched rocBLAS product.
-            # NOT F.conv1d / F.conv2d: for these shapes MIOpen picks a naive direct-convolution kernel (0.46 ms for the
-            # 16 x 128 x 10 object features of the C4 step) or a Winograd kernel with transposes around it
-            y = _weight_times_batch(weight.detach().reshape(cout, cin), x.reshape(B, cin, hw)).view((B, cout) + tuple(x.shape[2:]))
+            # shapes the register-tile kernels do not take (K > 160, few positions): the chunked MFMA kernel; ragged position
+            # counts: one batched rocBLAS product.  NOT F.conv1d / F.conv2d: for these shapes MIOpen picks a naive direct-
+            # convolution kernel (0.46 ms for the 16 x 128 x 10 object features of the C4 step) or a Winograd kernel with
+            # transposes around it
+            y = _product(weight.detach().reshape(cout, cin), x.reshape(B, cin, hw), False).view((B, cout) + tuple(x.shape[2:]))
         if gn_groups > 0:
             if stats is not None:
                 ctx.mark_non_differentiable(stats)
@@ -255,23 +295,20 @@ class _PointwiseConv(Function):
         if ctx.small:
             g3, x3 = grad_y.reshape(B, cout, hw), x.reshape(B, cin, hw)
             if ctx.needs_input_grad[0]:
-                grad_x = _weight_times_batch(weight.detach().reshape(cout, cin).t(), g3).view_as(x)
+                grad_x = _product(weight.detach().reshape(cout, cin), g3, True).view_as(x)
             if ctx.needs_input_grad[1]:
-                grad_w = torch.bmm(g3, x3.transpose(1, 2)).sum(0).view_as(weight)
+                grad_w = _weight_grad(g3, x3).view_as(weight)
             return grad_x, grad_w, None
         if ctx.needs_input_grad[0]:
             if _gemm_ok(cout, hw) and _plain_gemm_mine(cout, (B, cin, hw)):
                 grad_x = torch.empty_like(x)
                 _api._native.conv1x1_gemm_wrapper(B, cin, cout, hw, 1, weight.contiguous(), grad_y, grad_x)
-            elif _gemm_ok(cout, hw):
-                grad_x = _weight_times_batch(weight.detach().view(cout, cin).t(), grad_y.reshape(B, cout, hw)).view_as(x)
             else:
-                grad_x = _weight_times_batch(weight.detach().reshape(cout, cin).t(), grad_y.reshape(B, cout, hw)).view_as(x)
+                grad_x = _product(weight.detach().reshape(cout, cin), grad_y.reshape(B, cout, hw), True).view_as(x)
         if ctx.needs_input_grad[1]:
-            if hw <= 16384 and _api._native.get_matmul_precision() == "fp32":
-                # few positions per sample (feature-propagation layers): one batched rocBLAS product per sample and a
-                # sum beat the streaming kernel, whose waves need long position ranges (tools/wgrad_compare.py: 2-3x at
-                # hw <= 16384; beyond that the streaming kernel wins — FlowStep3D's hw = 32768 layers lose 7 % here)
+            if (LIBRARY_GEMMS or LIBRARY_WGRAD) and hw <= 16384 and _api._native.get_matmul_precision() == "fp32":
+                # (until round 4: one batched rocBLAS product per sample and a sum for the feature-propagation layers; the
+                # weight-gradient kernel has since caught up at these sizes: tools/gemm_any_compare.py)
                 grad_w = torch.bmm(grad_y.reshape(B, cout, hw), x.reshape(B, cin, hw).transpose(1, 2)).sum(0)
             else:
                 grad_w = zeroed_empty((cout, cin), torch.float32, x.device)
@@ -798,7 +835,7 @@ class _NormActConv(Function):
             grad_z = torch.empty_like(y_prev)
             nat.conv1x1_gemm_wrapper(B, cin, cout, hw, 1, w, grad_y, grad_z)
         else:
-            grad_z = _weight_times_batch(w.view(cout, cin).t(), grad_y.reshape(B, cout, hw)).view_as(y_prev)
+            grad_z = _product(w.view(cout, cin), grad_y.reshape(B, cout, hw), True).view_as(y_prev)
         grad_prev = torch.empty_like(y_prev)
         gw, gb = torch.empty_like(gn_weight), torch.empty_like(gn_bias)
         ws = nat.group_norm_ws(B, cin, gn_groups, True, y_prev.device)
@@ -1181,7 +1218,7 @@ class _GroupedFirstLayer(Function):
         wx, wf = w[:, :3].contiguous(), w[:, 3:].contiguous()
         rel = torch.empty(B, 3, npoint, nsample, dtype=torch.float32, device=xyz.device)
         nat.group_concat_wrapper(B, 0, N, npoint, nsample, xyz, new_xyz, None, idx, rel)
-        P = _weight_times_batch(wf, features.detach())                              # (B, M, N)
+        P = _product(wf, features.detach(), False)                                  # (B, M, N)
         y = torch.empty(B, M, npoint, nsample, dtype=torch.float32, device=xyz.device)
         stats = None
         if gn_groups > 0:
@@ -1222,13 +1259,13 @@ class _GroupedFirstLayer(Function):
                 nat.group_linear_bwd_wrapper(B, M, N, npoint, nsample, grad_y, idx, rel, dP, dwx)
             else:
                 nat.group_points_grad_wrapper(B, M, N, npoint, nsample, grad_y, idx, dP)
-        grad_feat = _weight_times_batch(wf.t(), dP) if ctx.needs_input_grad[2] else None
+        grad_feat = _product(wf.contiguous(), dP, True) if ctx.needs_input_grad[2] else None
         grad_w = None
         if ctx.needs_input_grad[4]:
             if not one_pass:
                 dwx = zeroed_empty((M, 3), torch.float32, grad_y.device)
                 nat.conv1x1_wgrad_wrapper(B, 3, M, T, rel, grad_y, dwx)
-            dwf = torch.bmm(dP, features.detach().transpose(1, 2)).sum(0)
+            dwf = _weight_grad(dP, features.detach())
             grad_w = torch.cat([dwx, dwf], 1).view_as(weight)
         return None, None, grad_feat, None, grad_w, None, None, None, None
 

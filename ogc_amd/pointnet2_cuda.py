@@ -630,3 +630,8 @@ def group_norm_maxpool_fwd_stats_wrapper(b, c, p, s, groups, eps, relu, x, gamma
 def conv1x1_gemm_wrapper(b, M, K, hw, transpose_a, w, inp, out):
     """out[b, m, p] = sum_k A[m, k] in[b, k, p], A = w or w^T (ogc_conv1x1_gemm); hw % 64 == 0, K <= 160."""
     _run("ogc_conv1x1_gemm", inp, b, M, K, hw, int(transpose_a), _f(w, "w"), _f(inp, "in"), _f(out, "out"))
+
+
+def conv1x1_gemm_any_wrapper(b, M, K, hw, transpose_a, w, inp, out):
+    """out[b, m, p] = sum_k A[m, k] in[b, k, p], A = w or w^T, any K and M (ogc_conv1x1_gemm_any); hw % 64 == 0."""
+    _run("ogc_conv1x1_gemm_any", inp, b, M, K, hw, int(transpose_a), _f(w, "w"), _f(inp, "in"), _f(out, "out"))

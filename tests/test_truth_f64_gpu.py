@@ -19,6 +19,8 @@ def _hip():
 def _report(budget, capsys):
     with capsys.disabled():
         print("\n" + budget.table())
+        if getattr(budget, "own_cond_max", None) is not None:
+            print("largest gradient change under 1-ulp noise on the plain products (own conditioning): %.2e" % budget.own_cond_max)
     budget.check()
 
 
