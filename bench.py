@@ -271,6 +271,16 @@ def measure_extras(pc, a):
         "note": "idle GPU, 20 back-to-back launches; the radius-limited search stops once the scanned cells cover the clamp "
                 "radius (neighbours beyond it are replaced by the nearest one in the output).  Both searches are bound by "
                 "instruction issue, not by HBM (SURVEY 8d): the HBM fraction is reported because the north star asks for it"}
+    # the set-abstraction groupers' searches (queries = the sampled centres, k = 64, clamped at the level's radius) by themselves:
+    # in the step they ride the geometry side stream underneath the dense kernels, and kernel_ms reads their latency THERE
+    iso = {}
+    for (nq, nm, rad) in ((N // 4, N, 2.0), (N // 8, N // 4, 4.0), (N // 16, N // 8, 8.0)):
+        q, m_ = pc[:, :nq].contiguous(), pc[:, :nm].contiguous()
+        dq = torch.empty(B, nq, 64, device=pc.device)
+        iq = torch.empty(B, nq, 64, dtype=torch.int32, device=pc.device)
+        iso[str((B, nq, nm, 64))] = round(_time(lambda: nat.knn_clamped_wrapper(B, nq, nm, 64, rad, q, m_, dq, iq)), 4)
+    out["kernel_ms_isolated"] = {"ogc_knn_clamped": iso,
+                                 "note": "the same operator calls as kernel_ms.ogc_knn_clamped, 20 back to back on the idle GPU"}
     # dense per-group MLP GEMM on the fp32 matrix pipe: SA3's 128 -> 128 layer on 16 x 32768 positions
     Bc, cin, cout, hw = B, 128, 128, 32768
     x = torch.randn(Bc, cin, hw, device=pc.device)
@@ -284,7 +294,14 @@ def measure_extras(pc, a):
                    "hbm_gbs": round(4.0 * Bc * hw * (cin + cout) / ms_g / 1e6, 1),
                    "note": "MFMA utilisation of the widest hand-written GEMM of the step = useful fp32 flops / fp32 MFMA peak "
                            "(this layer sits where the fp32 MFMA roof and the HBM roof meet; narrower layers are HBM-bound)"}
-    del x, y
+    # the chunked kernel (csrc/gemm_chunk.hip) on the widest product of the step: SA3's 256-channel input gradient
+    wt = torch.randn(256, 128, device=pc.device)
+    gy = torch.randn(Bc, 256, hw, device=pc.device)
+    ms_c = _time(lambda: nat.conv1x1_gemm_any_wrapper(Bc, 128, 256, hw, 1, wt, gy, y))
+    tfc = 2.0 * Bc * hw * 128 * 256 / ms_c / 1e9
+    out["mfma"]["gemm_chunk_kernel"] = {"shape": "128 <- 256 channels (input gradient of SA3's last layer) on %d x %d positions" % (Bc, hw),
+                                        "achieved": round(tfc, 2), "frac": round(tfc / FP32_MFMA_PEAK_TF, 4), "avg_ms": round(ms_c, 4)}
+    del x, y, gy
     # FlowStep3D correlation layer at config C3's level-2 shape (BASELINE config 3): B = 1, 2048 points, k = 16
     from ogc_amd.utils.flowstep3d_util import FlowEmbedding
     torch.manual_seed(0)

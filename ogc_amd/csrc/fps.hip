@@ -334,7 +334,10 @@ __device__ __forceinline__ unsigned fps_rank(int k, int bs_mask, int bs_shift, i
 #define FPS_BUCKET_PACKED_KEY 1
 #endif
 #ifndef FPS_BUCKET_SKIP
-#define FPS_BUCKET_SKIP 1 // skip a bucket's re-reduction when its maximum is untouched (0: always reduce)
+// skip a bucket's re-reduction when its maximum is untouched (0: always reduce).  Only with 128 buckets (sixteen per wavefront:
+// 16384 -> 4096: 0.975 -> 0.931 us per round); with 64 the wavefront that owns the new sample always re-reduces that sample's
+// bucket and sets the round's time, the test only adds to it (8192 -> 2048: 0.757 -> 0.785 us)
+#define FPS_BUCKET_SKIP 1
 #endif
 // NB = 128 buckets (8193 .. 16384 points, sixteen wavefronts): the rank-ordered copy of the cloud no longer fits the LDS next to
 // nothing (192 KiB), so the winner's coordinates travel with the reduction instead.  Whenever a bucket is re-reduced the lane
@@ -625,7 +628,7 @@ __global__ __launch_bounds__(WAVES *OGC_WAVE) void fps_bucket_kernel(int n, int 
                     // point only decreases, and none of them had the value — and the re-reduction (six 64-bit DPP steps, most
                     // of a round's dependent chain) is skipped.  (With tie tracking on, only when no second point had the
                     // value: its fate is not looked at here.)  The record comes out of its lane by v_readlane.
-                    if (FPS_BUCKET_SKIP) {
+                    if constexpr (FPS_BUCKET_SKIP && NB > 64) {
                         const unsigned cur_r = (unsigned)__builtin_amdgcn_readlane((int)bmr, REC0 + s);
                         const unsigned cur_v = (unsigned)__builtin_amdgcn_readlane(__float_as_int(bmv), REC0 + s);
                         const int cur_t = track ? __builtin_amdgcn_readlane(btie, REC0 + s) : 0;
