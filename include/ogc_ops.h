@@ -561,6 +561,18 @@ int ogc_conv1x1_gemm_affine(int b, int M, int K, int hw, int relu, int groups, c
                             const float *pa, const float *pb, float *out, double *stats, ogc_stream_t stream);
 int ogc_conv1x1_wgrad_affine(int b, int cin, int cout, int hw, int relu, const float *x, const float *pa,
                              const float *pb, const float *dy, float *dw, ogc_stream_t stream);
+/* The LAST layer of a set-abstraction MLP backwards for layers wider than the fused GroupNorm path takes (64 channels), with the
+ * gradient of its pooled GroupNorm in the sparse form of ogc_group_norm_maxpool_bwd_sparse below: g_y (the size of the layer's
+ * activation) is rebuilt from (y, coef2, inj) while y is loaded instead of being written by one kernel and read by two.
+ *   ogc_conv1x1_wgrad_affine_pooled: ogc_conv1x1_wgrad_affine with (y, coef2, inj) for dy;
+ *   ogc_conv1x1_dgrad_pooled:        grad_z[b] = w^T . g_y[b]  (ogc_amd/csrc/gemm_chunk.hip), w (cout, cin); needs >= 1024 tiles of
+ *                                    64 positions (OGC_ERR_UNSUPPORTED otherwise), hw % 64 == 0.
+ * nsample in {16, 32, 64} dividing hw; fp32 operands.  Reference: utils/pointnet2_util.py:38-42, utils/nn_util.py:45-85. */
+int ogc_conv1x1_wgrad_affine_pooled(int b, int cin, int cout, int hw, int relu, int nsample, const float *x, const float *pa,
+                                    const float *pb, const float *y, const float *coef2, const float *inj, float *dw,
+                                    ogc_stream_t stream);
+int ogc_conv1x1_dgrad_pooled(int b, int cin, int cout, int hw, int nsample, const float *w, const float *y, const float *coef2,
+                             const float *inj, float *grad_z, ogc_stream_t stream);
 
 /* ogc_group_norm_fwd / ogc_group_norm_maxpool_fwd with the statistics supplied (`slots` copies, see above). */
 int ogc_group_norm_fwd_stats(int b, int c, int hw, int groups, float eps, int relu, const float *x,

@@ -97,6 +97,8 @@ SIGNATURES = {
     "ogc_group_norm_coeffs": [_int, _int, _int, _int, _flt, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _vp, _vp, _vp],
     "ogc_conv1x1_gemm_affine": [_int, _int, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "ogc_conv1x1_wgrad_affine": [_int, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp],
+    "ogc_conv1x1_wgrad_affine_pooled": [_int, _int, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "ogc_conv1x1_dgrad_pooled": [_int, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp],
     "ogc_batch_norm_fwd": [_int, _int, _int, _flt, _int, _int, _flt, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                            _int, _vp],
     "ogc_batch_norm_bwd": [_int, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],

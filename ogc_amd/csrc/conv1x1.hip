@@ -42,14 +42,21 @@ __device__ __forceinline__ v4s ogc_pack_bf16(float a, float b, float c, float d)
 
 // PRO: the layer's input was never materialised — x holds the previous layer's raw convolution output and the operand
 // is act(pa[b, ci] * x + pb[b, ci]), recomputed while loading (see conv1x1_gemm_kernel).
-template <int COB, int CIB, bool PRO, bool BF>
+// POOLED: dy is not stored — `dy` holds y, the convolution's raw output, and the gradient of the pooled GroupNorm behind it is
+// rebuilt while y is loaded:  g_y[row, pos] = fmaf(c2, y, c3) + (pos % S == arg ? ag : 0)  with (c2, c3) = coef2[b, row] and
+// (ag, arg) = inj[b, row, pos / S] (ogc_group_norm_maxpool_bwd_sparse; a step's 16 positions lie inside one neighbourhood,
+// S = 16, 32, 64) — the expression of gn_maxpool_bwd_dx_kernel, bit for bit.
+template <int COB, int CIB, bool PRO, bool BF, bool POOLED = false>
 __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_wgrad_kernel(int batch, int cin, int cout, int hw,
                                                                            int steps_per_wave,
                                                                            const float *__restrict__ x,
                                                                            const float *__restrict__ dy,
                                                                            float *__restrict__ dw,
                                                                            const float *__restrict__ aff_a,
-                                                                           const float *__restrict__ aff_b, int pro_relu) {
+                                                                           const float *__restrict__ aff_b, int pro_relu,
+                                                                           const float2 *__restrict__ coef2 = nullptr,
+                                                                           const float2 *__restrict__ inj = nullptr,
+                                                                           int s_shift = 0) {
     // the four waves' partial tiles, one slab each (plain stores: ds_add_f32 sustains well under one lane per cycle), summed
     // by the threads that send them on
     __shared__ float red[WG_WAVES][COB * CIB * 256];
@@ -75,8 +82,14 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_wgrad_kernel(int b
     int cur_off = (int)(start - (long long)cur_b * steps_per_img);
     int left = mine - 1; // steps after the current one; the walk stays on the last step once they are used up
     int yrow[COB], xrow[CIB], coef[CIB]; // one sample's activation fits 32-bit offsets (checked by the entry point)
+    constexpr int NP = POOLED ? COB : 1;
+    int orow[NP];
+    const int centres = hw >> s_shift, smask = (1 << s_shift) - 1;
 #pragma unroll
-    for (int a = 0; a < COB; ++a) yrow[a] = min(co0 + a * 16 + i, cout - 1) * hw;
+    for (int a = 0; a < COB; ++a) {
+        yrow[a] = min(co0 + a * 16 + i, cout - 1) * hw;
+        if (POOLED) orow[a] = min(co0 + a * 16 + i, cout - 1);
+    }
 #pragma unroll
     for (int c = 0; c < CIB; ++c) {
         coef[c] = min(ci0 + c * 16 + i, cin - 1);
@@ -89,12 +102,22 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_wgrad_kernel(int b
     // the ping-pong below: the next step's loads were waited for before the current step's MFMAs (50 % of the time of
     // this kernel at one wavefront per SIMD).  PRO: the affine map of this lane's input channels travels WITH the step
     // (eight cached dword loads more) for the same reason: loaded only at image changes, its wait was a vmcnt(0).
-    auto load = [&](float4(&yv)[COB], float4(&xv)[CIB], float(&fa)[CIB], float(&fb)[CIB]) { // current step, then advance
+    auto load = [&](float4(&yv)[COB], float4(&xv)[CIB], float(&fa)[CIB], float(&fb)[CIB], float2(&cc)[NP], float2(&jv)[NP],
+                    int &jpos) { // current step, then advance
         const int pb = cur_off * 16 + 4 * k;
         const float *yb_ = dy + (size_t)cur_b * cout * hw + pb;
         const float *xb_ = x + (size_t)cur_b * cin * hw + pb;
 #pragma unroll
         for (int a = 0; a < COB; ++a) yv[a] = *reinterpret_cast<const float4 *>(yb_ + yrow[a]);
+        if constexpr (POOLED) { // (travels with the step like the affine map below: the sample may change from step to step)
+#pragma unroll
+            for (int a = 0; a < COB; ++a) {
+                const size_t r = (size_t)cur_b * cout + orow[a];
+                cc[a] = coef2[r];
+                jv[a] = inj[r * centres + (pb >> s_shift)];
+            }
+            jpos = pb & smask; // this lane's first position inside the neighbourhood
+        }
 #pragma unroll
         for (int c = 0; c < CIB; ++c) {
             xv[c] = *reinterpret_cast<const float4 *>(xb_ + xrow[c]);
@@ -108,7 +131,21 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_wgrad_kernel(int b
             if (++cur_off == steps_per_img) { cur_off = 0; ++cur_b; }
         }
     };
-    auto fma16 = [&](const float4(&yv)[COB], const float4(&xraw)[CIB], const float(&fa)[CIB], const float(&fb)[CIB]) {
+    auto fma16 = [&](const float4(&yraw)[COB], const float4(&xraw)[CIB], const float(&fa)[CIB], const float(&fb)[CIB],
+                     const float2(&cc)[NP], const float2(&jv)[NP], int jpos) {
+        float4 yv[COB];
+#pragma unroll
+        for (int a = 0; a < COB; ++a) {
+            yv[a] = yraw[a];
+            if constexpr (POOLED) {
+                const int rel = __float_as_int(jv[a].y) - jpos;
+                const float ag = jv[a].x;
+                yv[a].x = fmaf(cc[a].x, yraw[a].x, cc[a].y) + (rel == 0 ? ag : 0.f);
+                yv[a].y = fmaf(cc[a].x, yraw[a].y, cc[a].y) + (rel == 1 ? ag : 0.f);
+                yv[a].z = fmaf(cc[a].x, yraw[a].z, cc[a].y) + (rel == 2 ? ag : 0.f);
+                yv[a].w = fmaf(cc[a].x, yraw[a].w, cc[a].y) + (rel == 3 ? ag : 0.f);
+            }
+        }
         float4 xv[CIB];
 #pragma unroll
         for (int c = 0; c < CIB; ++c) {
@@ -148,15 +185,17 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_wgrad_kernel(int b
 
     float4 ya[COB], xa[CIB], yb[COB], xb[CIB];
     float faa[CIB], fba[CIB], fab[CIB], fbb[CIB];
-    load(ya, xa, faa, fba);
+    float2 cca[NP], ccb[NP], jva[NP], jvb[NP];
+    int jpa = 0, jpb = 0;
+    load(ya, xa, faa, fba, cca, jva, jpa);
     int s = 0;
-    for (; s + 1 < mine; s += 2) { // ping-pong registers: next step's loads fly during the MFMAs.  No branch inside the
-        load(yb, xb, fab, fbb);    // loop body: with one, the accumulators travelled AGPR -> VGPR -> AGPR every round
-        fma16(ya, xa, faa, fba);
-        load(ya, xa, faa, fba);
-        fma16(yb, xb, fab, fbb);
+    for (; s + 1 < mine; s += 2) {               // ping-pong registers: next step's loads fly during the MFMAs.  No branch inside
+        load(yb, xb, fab, fbb, ccb, jvb, jpb);   // the loop body: with one, the accumulators travelled AGPR -> VGPR -> AGPR every round
+        fma16(ya, xa, faa, fba, cca, jva, jpa);
+        load(ya, xa, faa, fba, cca, jva, jpa);
+        fma16(yb, xb, fab, fbb, ccb, jvb, jpb);
     }
-    if (s < mine) fma16(ya, xa, faa, fba);
+    if (s < mine) fma16(ya, xa, faa, fba, cca, jva, jpa);
 
     // C/D layout of 16x16x4: lane l holds rows (l >> 4) * 4 + r (r = 0..3) of column l & 15
 #pragma unroll
@@ -176,7 +215,8 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_wgrad_kernel(int b
 
 template <int COB, int CIB>
 void wgrad_launch(int b, int cin, int cout, int hw, const float *x, const float *dy, float *dw, const float *pa,
-                  const float *pb, int pro_relu, hipStream_t s) {
+                  const float *pb, int pro_relu, hipStream_t s, const float2 *coef2 = nullptr, const float2 *inj = nullptr,
+                  int s_shift = 0) {
     const long long nsteps = (long long)b * (hw >> 4);
     const int tiles = ogc_divup(cout, 16 * COB) * ogc_divup(cin, 16 * CIB);
     // ~2048 waves over the chip per tile pair, but at least 8 steps (128 positions) per wave
@@ -194,7 +234,10 @@ void wgrad_launch(int b, int cin, int cout, int hw, const float *x, const float 
 #define OGC_WGRAD(PROV, BFV)                                                                                          \
     hipLaunchKernelGGL((conv1x1_wgrad_kernel<COB, CIB, PROV, BFV>), grid, dim3(WG_WAVES * OGC_WAVE), 0, s, b, cin, cout, \
                        hw, (int)spw, x, dy, dw, pa, pb, pro_relu)
-    if (g_matmul_bf16) {
+    if (inj) { // pooled form of dy (fp32 operands, previous layer's norm folded in): see POOLED
+        hipLaunchKernelGGL((conv1x1_wgrad_kernel<COB, CIB, true, false, true>), grid, dim3(WG_WAVES * OGC_WAVE), 0, s, b, cin, cout,
+                           hw, (int)spw, x, dy, dw, pa, pb, pro_relu, coef2, inj, s_shift);
+    } else if (g_matmul_bf16) {
         if (pa) OGC_WGRAD(true, true);
         else OGC_WGRAD(false, true);
     } else {
@@ -894,7 +937,8 @@ extern "C" int ogc_conv1x1_gemm_gnstats(int b, int M, int K, int hw, int groups,
 
 namespace {
 int wgrad_impl(const char *name, int b, int cin, int cout, int hw, const float *x, const float *dy, float *dw,
-               const float *pa, const float *pb, int pro_relu, ogc_stream_t stream) {
+               const float *pa, const float *pb, int pro_relu, ogc_stream_t stream, const float2 *coef2 = nullptr,
+               const float2 *inj = nullptr, int s_shift = 0) {
     OGC_REQUIRE(b >= 0 && cin >= 1 && cout >= 1 && hw >= 1, "%s: bad shape", name);
     OGC_REQUIRE(x && dy && dw, "%s: null pointer", name);
     if ((hw & 15) != 0 || (((uintptr_t)x | (uintptr_t)dy) & 15) != 0) {
@@ -911,6 +955,12 @@ int wgrad_impl(const char *name, int b, int cin, int cout, int hw, const float *
     if (b == 0) return OGC_OK;
     // register tile per wave: (16*COB) x (16*CIB) outputs.  Small channel counts use small tiles so that no MFMA
     // work is spent on padding; wide layers use 64x64 tiles (16 accumulators) and split the rest over the grid.
+    if (inj) { // (the pooled form is offered for the wide tails only: 64-row tiles)
+        if (cin <= 32) wgrad_launch<4, 2>(b, cin, cout, hw, x, dy, dw, pa, pb, pro_relu, s, coef2, inj, s_shift);
+        else wgrad_launch<4, 4>(b, cin, cout, hw, x, dy, dw, pa, pb, pro_relu, s, coef2, inj, s_shift);
+        OGC_CHECK_LAUNCH(name);
+        return OGC_OK;
+    }
     if (cout <= 16 && cin <= 16) wgrad_launch<1, 1>(b, cin, cout, hw, x, dy, dw, pa, pb, pro_relu, s);
     else if (cout <= 32 && cin <= 16) wgrad_launch<2, 1>(b, cin, cout, hw, x, dy, dw, pa, pb, pro_relu, s);
     else if (cout <= 32 && cin <= 32) wgrad_launch<2, 2>(b, cin, cout, hw, x, dy, dw, pa, pb, pro_relu, s);
@@ -992,4 +1042,20 @@ extern "C" int ogc_conv1x1_wgrad_affine(int b, int cin, int cout, int hw, int re
                                         const float *pb, const float *dy, float *dw, ogc_stream_t stream) {
     OGC_REQUIRE(pa && pb, "ogc_conv1x1_wgrad_affine: null pointer");
     return wgrad_impl("ogc_conv1x1_wgrad_affine", b, cin, cout, hw, x, dy, dw, pa, pb, relu, stream);
+}
+
+// ogc_conv1x1_wgrad_affine with dy in the sparse form of ogc_group_norm_maxpool_bwd_sparse: y is the convolution's raw output
+// (b, cout, hw) and g_y is rebuilt from (y, coef2, inj) while y is loaded (see POOLED at conv1x1_wgrad_kernel) — the weight
+// gradient of the LAST layer of a set-abstraction MLP without the dense gradient of its pooled GroupNorm.  fp32 operands.
+extern "C" int ogc_conv1x1_wgrad_affine_pooled(int b, int cin, int cout, int hw, int relu, int nsample, const float *x,
+                                               const float *pa, const float *pb, const float *y, const float *coef2,
+                                               const float *inj, float *dw, ogc_stream_t stream) {
+    OGC_REQUIRE(pa && pb && coef2 && inj, "ogc_conv1x1_wgrad_affine_pooled: null pointer");
+    const int sh = nsample == 16 ? 4 : nsample == 32 ? 5 : nsample == 64 ? 6 : -1;
+    if (sh < 0 || hw % nsample != 0 || (((uintptr_t)coef2 | (uintptr_t)inj) & 7) != 0) {
+        ogc_set_error("ogc_conv1x1_wgrad_affine_pooled: nsample=%d must be 16, 32 or 64 and divide hw=%d", nsample, hw);
+        return OGC_ERR_UNSUPPORTED;
+    }
+    return wgrad_impl("ogc_conv1x1_wgrad_affine_pooled", b, cin, cout, hw, x, y, dw, pa, pb, relu, stream,
+                      reinterpret_cast<const float2 *>(coef2), reinterpret_cast<const float2 *>(inj), sh);
 }

@@ -27,10 +27,17 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 
 constexpr int GC_WAVES = 4;
 
-template <int RB, int KQ, bool SPLIT_M, bool TRANS>
+// POOLED: IN is not stored — `in` holds y, the raw output of the LAST convolution of a set-abstraction MLP, and the operand is the
+// gradient of the pooled GroupNorm that follows it, rebuilt while y is loaded (include/ogc_ops.h, ogc_group_norm_maxpool_bwd_sparse):
+//     IN[b, k, p] = fmaf(c2, y, c3) + (p % S == arg ? ag : 0),   (c2, c3) = coef2[b, k],   (ag, arg) = inj[b, k, p / S]
+// — the expression of gn_maxpool_bwd_dx_kernel, bit for bit; a lane's four positions lie inside one neighbourhood (S >= 16).
+template <int RB, int KQ, bool SPLIT_M, bool TRANS, bool POOLED = false>
 __global__ __launch_bounds__(GC_WAVES *OGC_WAVE, 2) void gemm_chunk_kernel(int M, int K, int hw, const float *__restrict__ w,
                                                                          const float *__restrict__ in,
-                                                                         float *__restrict__ out) {
+                                                                         float *__restrict__ out,
+                                                                         const float2 *__restrict__ coef2 = nullptr,
+                                                                         const float2 *__restrict__ inj = nullptr,
+                                                                         int s_shift = 0) {
     constexpr int KC = 4 * KQ, LD = 4 * (KQ | 1);
     constexpr int MT = SPLIT_M ? 64 * RB : 16 * RB;        // rows of A staged per workgroup
     constexpr int PER = (MT * KC) / (GC_WAVES * OGC_WAVE); // staged elements per thread and chunk
@@ -77,11 +84,31 @@ __global__ __launch_bounds__(GC_WAVES *OGC_WAVE, 2) void gemm_chunk_kernel(int M
             dst[mi * LD + ki] = av[i];
         }
     };
-    auto load_in = [&](int k0, float4(&xv)[KQ]) {
+    constexpr int NP = POOLED ? KQ : 1;
+    const int centres = hw >> s_shift;
+    const int my_centre = (pl + 4 * j) >> s_shift, jpos = (pl + 4 * j) & ((1 << s_shift) - 1);
+    auto load_in = [&](int k0, float4(&xv)[KQ], float2(&cc)[NP], float2(&jv)[NP]) {
 #pragma unroll
         for (int q = 0; q < KQ; ++q) {
             const int k = min(k0 + 4 * q + kk, K - 1);
             xv[q] = *reinterpret_cast<const float4 *>(inb + (size_t)k * hw);
+            if constexpr (POOLED) {
+                cc[q] = coef2[(size_t)b * K + k];
+                jv[q] = inj[((size_t)b * K + k) * centres + my_centre];
+            }
+        }
+    };
+    auto rebuild = [&](float4(&xv)[KQ], const float2(&cc)[NP], const float2(&jv)[NP]) {
+        if constexpr (POOLED) {
+#pragma unroll
+            for (int q = 0; q < KQ; ++q) {
+                const int rel = __float_as_int(jv[q].y) - jpos;
+                const float ag = jv[q].x;
+                xv[q].x = fmaf(cc[q].x, xv[q].x, cc[q].y) + (rel == 0 ? ag : 0.f);
+                xv[q].y = fmaf(cc[q].x, xv[q].y, cc[q].y) + (rel == 1 ? ag : 0.f);
+                xv[q].z = fmaf(cc[q].x, xv[q].z, cc[q].y) + (rel == 2 ? ag : 0.f);
+                xv[q].w = fmaf(cc[q].x, xv[q].w, cc[q].y) + (rel == 3 ? ag : 0.f);
+            }
         }
     };
     // Every row block is computed: rows beyond M are zeros in LDS, and the entry point picks RB so that few are (16 RB >= the
@@ -104,9 +131,10 @@ __global__ __launch_bounds__(GC_WAVES *OGC_WAVE, 2) void gemm_chunk_kernel(int M
 
     float *buf0 = gc_lds, *buf1 = gc_lds + MT * LD;
     float4 x0[KQ], x1[KQ];
+    float2 c0[NP], c1[NP], j0[NP], j1[NP];
     float a_next[PER];
     load_a(0, a_next);
-    load_in(0, x0);
+    load_in(0, x0, c0, j0);
     store_a(buf0, a_next);
     __syncthreads();
     const bool work = nblk > 0; // (SPLIT_M: a wavefront whose rows all lie beyond M only helps staging)
@@ -115,16 +143,18 @@ __global__ __launch_bounds__(GC_WAVES *OGC_WAVE, 2) void gemm_chunk_kernel(int M
         const bool more1 = i + 1 < nchunks, more2 = i + 2 < nchunks;
         if (more1) {
             load_a((i + 1) * KC, a_next);
-            load_in((i + 1) * KC, x1);
+            load_in((i + 1) * KC, x1, c1, j1);
         }
+        rebuild(x0, c0, j0);
         if (work) compute(buf0, x0);
         if (more1) store_a(buf1, a_next);
         __syncthreads();
         if (!more1) break;
         if (more2) {
             load_a((i + 2) * KC, a_next);
-            load_in((i + 2) * KC, x0);
+            load_in((i + 2) * KC, x0, c0, j0);
         }
+        rebuild(x1, c1, j1);
         if (work) compute(buf1, x1);
         if (more2) store_a(buf0, a_next);
         __syncthreads();
@@ -200,3 +230,41 @@ extern "C" int ogc_conv1x1_gemm_any(int b, int M, int K, int hw, int transpose_a
     OGC_CHECK_LAUNCH("ogc_conv1x1_gemm_any");
     return OGC_OK;
 }
+
+// The input gradient of the LAST convolution of a set-abstraction MLP with the gradient of its pooled GroupNorm in the sparse form
+// of ogc_group_norm_maxpool_bwd_sparse:  grad_z[b] = w^T . g_y[b],  g_y rebuilt from (y, coef2, inj) while y is loaded (see
+// POOLED above) — the dense g_y (the size of the layer's activation) is neither written nor read.  w (cout, cin), y (b, cout, hw),
+// grad_z (b, cin, hw); any cin (row tiles of 64 up to 64 channels, of 128 beyond).  hw % 64 == 0,
+// nsample in {16, 32, 64} dividing hw, at least 1024 tiles of 64 positions (fewer: OGC_ERR_UNSUPPORTED, the caller keeps the dense path).
+extern "C" int ogc_conv1x1_dgrad_pooled(int b, int cin, int cout, int hw, int nsample, const float *w, const float *y,
+                                        const float *coef2, const float *inj, float *grad_z, ogc_stream_t stream) {
+    OGC_REQUIRE(b >= 0 && cin >= 1 && cout >= 1 && hw >= 1, "ogc_conv1x1_dgrad_pooled: bad shape");
+    OGC_REQUIRE(w && y && coef2 && inj && grad_z, "ogc_conv1x1_dgrad_pooled: null pointer");
+    const int sh = nsample == 16 ? 4 : nsample == 32 ? 5 : nsample == 64 ? 6 : -1;
+    if (sh < 0 || hw % nsample != 0 || (hw & 63) != 0 || (long long)b * (hw / 64) < 1024 ||
+        (((uintptr_t)y | (uintptr_t)grad_z) & 15) != 0 || (((uintptr_t)coef2 | (uintptr_t)inj) & 7) != 0) {
+        ogc_set_error("ogc_conv1x1_dgrad_pooled: needs nsample in {16, 32, 64} dividing hw, hw %% 64 == 0, >= 1024 tiles of 64 "
+                      "positions and aligned tensors (hw=%d, nsample=%d, b=%d)", hw, nsample, b);
+        return OGC_ERR_UNSUPPORTED;
+    }
+    OGC_REQUIRE((long long)cin * hw < (1ll << 31) && (long long)cout * hw < (1ll << 31) && b <= 65535,
+                "ogc_conv1x1_dgrad_pooled: one sample exceeds 32-bit indexing");
+    if (b == 0) return OGC_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const float2 *c2 = reinterpret_cast<const float2 *>(coef2), *ij = reinterpret_cast<const float2 *>(inj);
+    const int M = cin, K = cout;
+    if (M <= 64) {
+        constexpr int RB = 4, KQ = 4;
+        dim3 grid(ogc_divup(hw, 64 * GC_WAVES), ogc_divup(M, 16 * RB), b);
+        hipLaunchKernelGGL((gemm_chunk_kernel<RB, KQ, false, true, true>), grid, dim3(GC_WAVES * OGC_WAVE),
+                           (size_t)2 * 16 * RB * 4 * (KQ | 1) * sizeof(float), s, M, K, hw, w, y, grad_z, c2, ij, sh);
+    } else {
+        constexpr int RB = 8, KQ = 4;
+        dim3 grid(ogc_divup(hw, 64 * GC_WAVES), ogc_divup(M, 16 * RB), b);
+        hipLaunchKernelGGL((gemm_chunk_kernel<RB, KQ, false, true, true>), grid, dim3(GC_WAVES * OGC_WAVE),
+                           (size_t)2 * 16 * RB * 4 * (KQ | 1) * sizeof(float), s, M, K, hw, w, y, grad_z, c2, ij, sh);
+    }
+    OGC_CHECK_LAUNCH("ogc_conv1x1_dgrad_pooled");
+    return OGC_OK;
+}
+

@@ -880,6 +880,9 @@ SPARSE_POOL_BACKWARD = True
 # moment matrices with 64 x 32 tiles) is 0.95 against 0.98-1.01 ms in isolation (tools/pool_tail_compare.py) but 11.62 against
 # 11.56 ms in the step (tools/step_ab.py SPARSE_POOL_MAX_COUT 3 128 64): left at 64.
 SPARSE_POOL_MAX_COUT = 64
+# Tails wider than that keep the pooled gradient sparse as well (round 4), through the pooled forms of the PLAIN weight- and input-
+# gradient kernels instead of the moment-matrix pair (OGC_WIDE_POOL=0: the dense gradient, for A/B runs).
+WIDE_POOL_BACKWARD = _os.environ.get("OGC_WIDE_POOL", "1") != "0"
 
 class _NormActConvPool(Function):
     """out (B, cout, P) = max over the neighbourhood of act2(GroupNorm2(conv(act(GroupNorm(y_prev))))), y_prev (B, cin, P, S)
@@ -924,8 +927,22 @@ class _NormActConvPool(Function):
         nat.group_norm_maxpool_bwd_sparse_wrapper(B, cout, P, S, groups2, relu2, y, gn2_weight.contiguous(), mean2,
                                                   rstd2, out, arg, grad_out.contiguous(), coef2, inj, gw2, gb2, ws,
                                                   yext if POOL_SUMS_FROM_EXTREMES else None)
-        # the convolution's backward (as _NormActConv.backward's moment-matrix path) on that form
         w = conv_weight.contiguous().view(cout, cin)
+        if cin > FUSED_GN_BACKWARD_MAX_WIDTH or cout > max(FUSED_GN_BACKWARD_MAX_WIDTH, SPARSE_POOL_MAX_COUT):
+            # wide tails (SA2 64 -> 128, SA3 128 -> 256 at C4): weight and input gradient rebuild g_y from (y, coef2, inj) while
+            # they load y (round 4: ogc_conv1x1_wgrad_affine_pooled, ogc_conv1x1_dgrad_pooled) — the pass that wrote the dense g_y
+            # and the two that read it become two that read y; the GroupNorm of y_prev keeps its own backward kernels
+            grad_w = zeroed_empty((cout, cin), torch.float32, dev)
+            nat.conv1x1_wgrad_affine_pooled_wrapper(B, cin, cout, hw, relu, S, y_prev, a, bb, y, coef2, inj, grad_w)
+            grad_z = torch.empty_like(y_prev)
+            nat.conv1x1_dgrad_pooled_wrapper(B, cin, cout, hw, S, w, y, coef2, inj, grad_z)
+            grad_prev = torch.empty_like(y_prev)
+            gw, gb = torch.empty_like(gn_weight), torch.empty_like(gn_bias)
+            ws = nat.group_norm_ws(B, cin, gn_groups, True, dev)
+            nat.group_norm_bwd_wrapper(B, cin, hw, gn_groups, relu, y_prev, gn_weight.contiguous(), gn_bias.contiguous(), mean,
+                                       rstd, grad_z, grad_prev, gw, gb, ws)
+            return (grad_prev, None, gw, gb, grad_w.view_as(conv_weight), None, None, None, gw2, gb2, None, None, None)
+        # the convolution's backward (as _NormActConv.backward's moment-matrix path) on that form
         moments = zeroed_empty((B, 2, cout, cin), torch.float32, dev)
         nat.conv1x1_wgrad_moments_pooled_wrapper(B, cin, cout, hw, relu, S, y_prev, a, bb, y, coef2, inj, moments)
         coef = torch.empty(B, cin, 3, dtype=torch.float32, device=dev)
@@ -950,6 +967,14 @@ def norm_act_conv_pool_available(y_prev, gn, conv, next_gn):
             and getattr(nat, "conv1x1_gemm_affine_pool_wrapper", None) is not None):
         return False
     cin, cout, g, g2 = y_prev.shape[1], conv.weight.shape[0], gn.num_groups, next_gn.num_groups
+    if cin > FUSED_GN_BACKWARD_MAX_WIDTH or cout > max(FUSED_GN_BACKWARD_MAX_WIDTH, SPARSE_POOL_MAX_COUT):
+        # wide tails: the pooled forms of the plain weight / input gradient kernels (fp32 operands, enough position tiles for
+        # the chunked kernel, neighbourhood extremes from the forward convolution)
+        B, hw = y_prev.shape[0], y_prev.shape[2] * y_prev.shape[3]
+        return (WIDE_POOL_BACKWARD and getattr(nat, "conv1x1_dgrad_pooled_wrapper", None) is not None
+                and nat.get_matmul_precision() == "fp32" and hw % 64 == 0 and B * (hw // 64) >= 1024 and B <= 65535
+                and g <= 32 and cin % g == 0 and g2 <= 32 and cout % g2 == 0 and (cout // g2) % 4 == 0
+                and (cin <= 100 or (POOL_EXTREMES_WIDE and _stats_ok(nat, B, cout, cin, hw, True))))
     # LDS of ogc_conv1x1_dgrad_adjoint_pooled: the weight tile + one (scale, offset, injection, arg-max) entry per wave,
     # output channel and neighbourhood of a 64-position tile; the kernel keeps the default 64 KiB
     kq = (cout + 3) // 4

@@ -635,3 +635,16 @@ def conv1x1_gemm_wrapper(b, M, K, hw, transpose_a, w, inp, out):
 def conv1x1_gemm_any_wrapper(b, M, K, hw, transpose_a, w, inp, out):
     """out[b, m, p] = sum_k A[m, k] in[b, k, p], A = w or w^T, any K and M (ogc_conv1x1_gemm_any); hw % 64 == 0."""
     _run("ogc_conv1x1_gemm_any", inp, b, M, K, hw, int(transpose_a), _f(w, "w"), _f(inp, "in"), _f(out, "out"))
+
+
+def conv1x1_wgrad_affine_pooled_wrapper(b, cin, cout, hw, relu, nsample, x, pa, pb, y, coef2, inj, dw):
+    """ogc_conv1x1_wgrad_affine with dy in the sparse form (y, coef2, inj) of group_norm_maxpool_bwd_sparse_wrapper."""
+    _run("ogc_conv1x1_wgrad_affine_pooled", x, b, cin, cout, hw, int(relu), nsample, _f(x, "x"), _f(pa, "pa"), _f(pb, "pb"),
+         _f(y, "y"), _f(coef2, "coef2"), _f(inj, "inj"), _f(dw, "dw"))
+
+
+def conv1x1_dgrad_pooled_wrapper(b, cin, cout, hw, nsample, w, y, coef2, inj, grad_z):
+    """grad_z[b] = w^T . g_y[b] with g_y rebuilt from (y, coef2, inj) on load (ogc_conv1x1_dgrad_pooled)."""
+    _run("ogc_conv1x1_dgrad_pooled", y, b, cin, cout, hw, nsample, _f(w, "w"), _f(y, "y"), _f(coef2, "coef2"), _f(inj, "inj"),
+         _f(grad_z, "grad_z"))
+

@@ -18,16 +18,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # configuration -> {gate: times it answered False during one step} (observed on MI355X, and why)
 EXPECTED = {
-    # C4, segnet_kitti fp32.  norm_act_conv_pool: the pooled tails of SA2 (128 channels out) and SA3 (256 out) are wider than the
-    # fused normalise -> conv -> pool kernel's accumulator budget (fused.SPARSE_POOL_MAX_COUT); they run conv + pooled GroupNorm.
-    "kittisf": {"norm_act_conv_pool_available": 2},
+    # C4, segnet_kitti fp32: every gate answers yes since round 4 (the pooled tails of SA2, 128 channels out, and SA3, 256 out,
+    # run as one node through the pooled forms of the plain weight- / input-gradient kernels: fused.WIDE_POOL_BACKWARD)
+    "kittisf": {},
     # C5, the same network at 16384 points, one-frame loss
-    "waymo": {"norm_act_conv_pool_available": 2},
-    # C2 (bf16 operands) and C1: the two-level encoders of segnet_ogcdr / segnet_sapien end in 128- and 256-channel tails as well;
-    # norm_act_conv: the 256 -> 128 layer of their first feature-propagation module has more input channels than the GEMM with
-    # the folded normalisation takes (K <= 160)
+    "waymo": {},
+    # C2 (bf16 operands): the two-level encoder of segnet_ogcdr ends in 128- and 256-channel tails as well, and their pooled
+    # forms are fp32 kernels; norm_act_conv: the 256 -> 128 layer of the first feature-propagation module has more input channels
+    # than the GEMM with the folded normalisation takes (K <= 160)
     "ogcdr": {"norm_act_conv_pool_available": 2, "norm_act_conv_available": 1},
-    "sapien": {"norm_act_conv_pool_available": 2, "norm_act_conv_available": 1},
+    # C1 (512 points, 2 samples): the deeper of the two wide tails has fewer than 1024 tiles of 64 positions
+    "sapien": {"norm_act_conv_pool_available": 1, "norm_act_conv_available": 1},
 }
 # C3 forward: one set-abstraction block of FlowStep3D has an MLP the three-layer chain kernel does not cover
 EXPECTED_FLOW = {"mlp_chain_pool_available": 1}

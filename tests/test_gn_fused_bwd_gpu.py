@@ -114,3 +114,47 @@ def test_pooled_tail_backward(B, cin, cout, P, S, groups, groups2, relu2):
             assert torch.equal(n_, o_), (name, _rel(n_, o_))
         else:
             assert _rel(n_, o_) < 2e-6, (name, _rel(n_, o_))
+
+
+@pytest.mark.parametrize("B,cin,cout,P,S,groups,groups2,relu2", [
+    (16, 64, 128, 256, 64, 4, 4, True), (16, 128, 256, 128, 64, 4, 4, True), (8, 64, 128, 512, 32, 4, 8, True),
+    (4, 96, 160, 1024, 16, 4, 4, False), (16, 131, 128, 128, 64, 1, 4, True), (4, 32, 96, 512, 64, 4, 4, True)])
+def test_wide_pooled_tail_backward(B, cin, cout, P, S, groups, groups2, relu2):
+    """The same one-node tail for layers WIDER than the moment-matrix path takes (round 4: SA2 64 -> 128, SA3 128 -> 256 at C4):
+    the plain weight- and input-gradient kernels in their pooled forms (ogc_conv1x1_wgrad_affine_pooled, ogc_conv1x1_dgrad_pooled:
+    g_y rebuilt from (y, coef2, inj) on load) against the two-node sequence that writes the dense g_y.  Same fp32 expression
+    element by element: the pooled GroupNorm's results are identical, the rest agrees up to summation order."""
+    import ogc_amd  # noqa: F401
+    from ogc_amd import fused
+    g = torch.Generator().manual_seed(B * 1000 + cin + cout + P)
+    y_prev = (torch.randn(B, cin, P, S, generator=g) * 1.5 + 0.3).cuda()
+    gn = torch.nn.GroupNorm(groups, cin).cuda()
+    gn2 = torch.nn.GroupNorm(groups2, cout).cuda()
+    conv = torch.nn.Conv2d(cin, cout, 1, bias=False).cuda()
+    with torch.no_grad():
+        for m in (gn, gn2):
+            m.weight.copy_(torch.rand(m.num_channels, generator=g) + 0.5)
+            m.weight[::5] *= -1.0
+            m.bias.copy_(torch.rand(m.num_channels, generator=g) - 0.5)
+    probe = torch.randn(B, cout, P, generator=g).cuda()
+    params = list(gn.parameters()) + list(conv.parameters()) + list(gn2.parameters())
+
+    def run(one_node):
+        yp = y_prev.clone().requires_grad_(True)
+        for p in params:
+            p.grad = None
+        if one_node:
+            assert fused.WIDE_POOL_BACKWARD and fused.norm_act_conv_pool_available(yp, gn, conv, gn2)
+            out = fused.norm_act_conv_pool(yp, None, gn, True, conv, gn2, relu2)
+        else:
+            y, stats, extremes = fused.norm_act_conv(yp, None, gn, True, conv, gn2, pool=S)
+            out = fused.group_norm_act_maxpool(y, gn2, relu2, stats, extremes)
+        (out * probe).sum().backward()
+        return [out.detach(), yp.grad] + [p.grad.clone() for p in params]
+
+    new, old = run(True), run(False)
+    for name, n_, o_ in zip(("out", "grad_prev", "gn.weight", "gn.bias", "conv.weight", "gn2.weight", "gn2.bias"), new, old):
+        if name in ("out", "gn2.weight", "gn2.bias"):
+            assert torch.equal(n_, o_), (name, _rel(n_, o_))
+        else:
+            assert _rel(n_, o_) < 3e-6, (name, _rel(n_, o_))
