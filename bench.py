@@ -413,6 +413,7 @@ def main():
                                  next_batch=batches[(step_no + 1) % NB])
             pre = pending.prefetched
             step_no += 1
+        issued = time.perf_counter() - t0   # the launch thread is done queueing the K steps here; the GPU is still running them
         sync()
         elapsed = time.perf_counter() - t0
     loss_dict, stepped = pending.result()
@@ -553,6 +554,7 @@ def main():
                        "loss": {k: round(v, 5) for k, v in loss_dict.items()}},
             "roofline": roof,
             "kernel_ms": others,
+            "launch_thread_ms_per_step": round(issued / a.steps * 1e3, 3),
         }
         out.update(extras)
         out["fps_note"] = ("levels 2-3 of the encoder cost ~10 us in ms_per_step because the synthetic uniform clouds are free "

@@ -883,8 +883,11 @@ static int fps_impl(const char *name, int b, int n, int m, const float *xyz, flo
     else if (slots <= 4096) fps_launch<8, 512>(b, n, m, shift, xyz, temp, idx, ties_in, ties_out, s);
     else if (slots <= 8192) {
         // bucketed rounds (fps_bucket_kernel) pay from a few hundred samples on; OGC_FPS_BUCKETS=0: the plain rounds
+        // sixteen wavefronts (four buckets each) where the rounds are the caller's critical path and the chip is otherwise idle
+        // (a pair of clouds: FlowStep3D at B = 1: 0.711 -> 0.678 us per round); eight for batches, whose launches ride a side
+        // stream underneath dense kernels and must find room next to them
         static const char *bk = getenv("OGC_FPS_BUCKETS");
-        const int mode = bk ? atoi(bk) : 8;
+        const int mode = bk ? atoi(bk) : (b <= 4 ? 16 : 8);
         const size_t lds = (4 + 128 + 3 * FPSB_SLOTS) * sizeof(float);
         if (mode > 0 && m >= 256) {
             if (mode == 16) {
