@@ -31,17 +31,19 @@ constexpr int GC_WAVES = 4;
 // gradient of the pooled GroupNorm that follows it, rebuilt while y is loaded (include/ogc_ops.h, ogc_group_norm_maxpool_bwd_sparse):
 //     IN[b, k, p] = fmaf(c2, y, c3) + (p % S == arg ? ag : 0),   (c2, c3) = coef2[b, k],   (ag, arg) = inj[b, k, p / S]
 // — the expression of gn_maxpool_bwd_dx_kernel, bit for bit; a lane's four positions lie inside one neighbourhood (S >= 16).
-template <int RB, int KQ, bool SPLIT_M, bool TRANS, bool POOLED = false>
+// KA = 2: the weights are staged 2 x 4 KQ rows at a time — ONE barrier per two input chunks.  (The 128-row tile with 16-row chunks
+// reaches 111 TFLOP/s on 128 <- 256 channels, with 8-row chunks 86: the barrier is what it waits for; 32-row input chunks spill.)
+template <int RB, int KQ, bool SPLIT_M, bool TRANS, bool POOLED = false, int KA = 1>
 __global__ __launch_bounds__(GC_WAVES *OGC_WAVE, 2) void gemm_chunk_kernel(int M, int K, int hw, const float *__restrict__ w,
                                                                          const float *__restrict__ in,
                                                                          float *__restrict__ out,
                                                                          const float2 *__restrict__ coef2 = nullptr,
                                                                          const float2 *__restrict__ inj = nullptr,
                                                                          int s_shift = 0) {
-    constexpr int KC = 4 * KQ, LD = 4 * (KQ | 1);
-    constexpr int MT = SPLIT_M ? 64 * RB : 16 * RB;        // rows of A staged per workgroup
-    constexpr int PER = (MT * KC) / (GC_WAVES * OGC_WAVE); // staged elements per thread and chunk
-    static_assert((MT * KC) % (GC_WAVES * OGC_WAVE) == 0 && PER >= 1, "staging split");
+    constexpr int KC = 4 * KQ, KCA = KC * KA, LD = 4 * ((KQ * KA) | 1);
+    constexpr int MT = SPLIT_M ? 64 * RB : 16 * RB;         // rows of A staged per workgroup
+    constexpr int PER = (MT * KCA) / (GC_WAVES * OGC_WAVE); // staged elements per thread and A chunk
+    static_assert((MT * KCA) % (GC_WAVES * OGC_WAVE) == 0 && PER >= 1 && (KA == 1 || KA == 2), "staging split");
     extern __shared__ __attribute__((aligned(16))) float gc_lds[]; // [2][MT][LD]
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int j = lane & 15, kk = lane >> 4;
@@ -67,7 +69,7 @@ __global__ __launch_bounds__(GC_WAVES *OGC_WAVE, 2) void gemm_chunk_kernel(int M
         for (int i = 0; i < PER; ++i) {
             const int e = t + i * (GC_WAVES * OGC_WAVE);
             int mi, ki;
-            if (TRANS) { mi = e % MT; ki = e / MT; } else { mi = e / KC; ki = e % KC; } // consecutive lanes: consecutive addresses
+            if (TRANS) { mi = e % MT; ki = e / MT; } else { mi = e / KCA; ki = e % KCA; } // consecutive lanes: consecutive addresses
             const int m = m0 + mi, k = k0 + ki;
             const bool ok = m < M && k < K;
             const int mc = min(m, M - 1), kc = min(k, K - 1);
@@ -80,7 +82,7 @@ __global__ __launch_bounds__(GC_WAVES *OGC_WAVE, 2) void gemm_chunk_kernel(int M
         for (int i = 0; i < PER; ++i) {
             const int e = t + i * (GC_WAVES * OGC_WAVE);
             int mi, ki;
-            if (TRANS) { mi = e % MT; ki = e / MT; } else { mi = e / KC; ki = e % KC; }
+            if (TRANS) { mi = e % MT; ki = e / MT; } else { mi = e / KCA; ki = e % KCA; }
             dst[mi * LD + ki] = av[i];
         }
     };
@@ -114,13 +116,13 @@ __global__ __launch_bounds__(GC_WAVES *OGC_WAVE, 2) void gemm_chunk_kernel(int M
     // Every row block is computed: rows beyond M are zeros in LDS, and the entry point picks RB so that few are (16 RB >= the
     // rows of a tile, 67 rows -> RB = 5) — a wave-uniform `a < nblk` branch per row block between the MFMAs costs the matrix pipe
     // issue slots, and the loop written twice (with and without it) spills.
-    auto compute = [&](const float *a_lds, const float4(&xv)[KQ]) {
+    auto compute = [&](const float *a_lds, const float4(&xv)[KQ], int koff = 0) {
 #pragma unroll
         for (int q = 0; q < KQ; ++q) {
             const float bx = xv[q].x, by = xv[q].y, bz = xv[q].z, bw = xv[q].w;
 #pragma unroll
             for (int a = 0; a < RB; ++a) {
-                const float av = a_lds[(wrow + a * 16 + j) * LD + q * 4 + kk];
+                const float av = a_lds[(wrow + a * 16 + j) * LD + koff + q * 4 + kk];
                 acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bx, acc[a][0], 0, 0, 0);
                 acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, by, acc[a][1], 0, 0, 0);
                 acc[a][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bz, acc[a][2], 0, 0, 0);
@@ -138,6 +140,24 @@ __global__ __launch_bounds__(GC_WAVES *OGC_WAVE, 2) void gemm_chunk_kernel(int M
     store_a(buf0, a_next);
     __syncthreads();
     const bool work = nblk > 0; // (SPLIT_M: a wavefront whose rows all lie beyond M only helps staging)
+    if constexpr (KA == 2) {
+        // one A chunk (2 KC rows) per iteration: both input register sets are consumed against it, one barrier; input chunks
+        // beyond K are clamped rows against zero weights (no branch around them)
+        const int npairs = (nchunks + 1) / 2;
+        for (int p = 0; p < npairs; ++p) {
+            const bool more = p + 1 < npairs;
+            if (more) load_a((p + 1) * KCA, a_next);
+            load_in((2 * p + 1) * KC, x1, c1, j1);
+            rebuild(x0, c0, j0);
+            if (work) compute(buf0, x0, 0);
+            if (more) load_in((2 * p + 2) * KC, x0, c0, j0);
+            rebuild(x1, c1, j1);
+            if (work) compute(buf0, x1, KC);
+            if (more) store_a(buf1, a_next);
+            __syncthreads();
+            float *tmp = buf0; buf0 = buf1; buf1 = tmp;
+        }
+    } else
     // chunks in pairs so that the two register sets and the two LDS buffers are named, not indexed
     for (int i = 0; i < nchunks; i += 2) {
         const bool more1 = i + 1 < nchunks, more2 = i + 2 < nchunks;
@@ -176,16 +196,18 @@ __global__ __launch_bounds__(GC_WAVES *OGC_WAVE, 2) void gemm_chunk_kernel(int M
     }
 }
 
-template <int RB, int KQ, bool SPLIT_M>
+template <int RB, int KQ, bool SPLIT_M, int KA = 1>
 void gemm_chunk_launch(int b, int M, int K, int hw, int transpose_a, const float *w, const float *in, float *out,
                        hipStream_t s) {
     constexpr int MT = SPLIT_M ? 64 * RB : 16 * RB;
-    const size_t lds = (size_t)2 * MT * 4 * (KQ | 1) * sizeof(float);
+    const size_t lds = (size_t)2 * MT * 4 * ((KQ * KA) | 1) * sizeof(float);
     dim3 grid(SPLIT_M ? hw / 64 : ogc_divup(hw, 64 * GC_WAVES), ogc_divup(M, MT), b);
     if (transpose_a)
-        hipLaunchKernelGGL((gemm_chunk_kernel<RB, KQ, SPLIT_M, true>), grid, dim3(GC_WAVES * OGC_WAVE), lds, s, M, K, hw, w, in, out);
+        hipLaunchKernelGGL((gemm_chunk_kernel<RB, KQ, SPLIT_M, true, false, KA>), grid, dim3(GC_WAVES * OGC_WAVE), lds, s, M, K, hw,
+                           w, in, out, nullptr, nullptr, 0);
     else
-        hipLaunchKernelGGL((gemm_chunk_kernel<RB, KQ, SPLIT_M, false>), grid, dim3(GC_WAVES * OGC_WAVE), lds, s, M, K, hw, w, in, out);
+        hipLaunchKernelGGL((gemm_chunk_kernel<RB, KQ, SPLIT_M, false, false, KA>), grid, dim3(GC_WAVES * OGC_WAVE), lds, s, M, K, hw,
+                           w, in, out, nullptr, nullptr, 0);
 }
 
 } // namespace
@@ -214,7 +236,11 @@ extern "C" int ogc_conv1x1_gemm_any(int b, int M, int K, int hw, int transpose_a
         switch (rb) {
             GC_CASE(1, 8, false); GC_CASE(2, 8, false); GC_CASE(3, 8, false); GC_CASE(4, 8, false);
             GC_CASE(5, 8, false); GC_CASE(6, 8, false); GC_CASE(7, 4, false);
-            default: gemm_chunk_launch<8, 4, false>(b, M, K, hw, transpose_a, w, in, out, s);
+            default: {
+                static const char *kq = getenv("OGC_GEMM_CHUNK_KQ"); // development: 4 = one barrier per 16-row chunk
+                if (kq && kq[0] == '4') gemm_chunk_launch<8, 4, false>(b, M, K, hw, transpose_a, w, in, out, s);
+                else gemm_chunk_launch<8, 4, false, 2>(b, M, K, hw, transpose_a, w, in, out, s);
+            }
         }
     } else {
         // few positions: the wavefronts of a workgroup split the rows, 32 rows per wavefront where that still gives ~2 workgroups
