@@ -5,8 +5,11 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-LOSS_TOL, WEIGHT_TOL = 1e-4, 0.01   # (passes at 2e-5 / 0.002; the test asked for 2e-3 / 0.05 while hipMemsetAsync nodes fed stale
-#                                     bits into the replayed step's accumulators)
+LOSS_TOL, WEIGHT_TOL = 3e-4, 0.01   # (typically 2e-5 / 0.002; the test asked for 2e-3 / 0.05 while hipMemsetAsync nodes fed stale
+#                                     bits into the replayed step's accumulators.  3e-4 since round 4: both runs accumulate their
+#                                     weight gradients with float atomics — the feature-propagation layers' too now — in an order
+#                                     that differs from run to run, five optimizer steps amplify that, and once in ten runs of the
+#                                     suite the invariance term of step 4 differed by 1.1e-4)
 
 
 def _build(npoint):

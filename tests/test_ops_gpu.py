@@ -1003,25 +1003,29 @@ def test_batch_norm_act_fused(shape, pool, training):
         bn.bias.copy_(torch.randn(C, generator=g))
         bn.running_mean.copy_(torch.randn(C, generator=g) * 0.1)
         bn.running_var.copy_(torch.rand(C, generator=g) + 0.5)
-    conv2, bn2 = copy.deepcopy(conv), copy.deepcopy(bn)
+    # the torch op sequence on the HOST in float64: on the device it is MIOpen's convolution / batch-norm backward, which aborted
+    # the process once in ~10 runs of the suite on this stack (uncaught exception in the autograd thread, round 4) — and a float64
+    # reference is the better one anyway
+    conv2, bn2 = copy.deepcopy(conv).cpu().double(), copy.deepcopy(bn).cpu().double()
     for m in (bn, bn2):
         m.train(training)
-    x = torch.randn(B, 7, P, S, generator=g).cuda()
-    x1, x2 = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    x = torch.randn(B, 7, P, S, generator=g)
+    x1, x2 = x.cuda().requires_grad_(True), x.double().requires_grad_(True)
     y1 = conv_norm_act(x1, conv, bn, relu=True, maxpool=pool)
     y2 = torch.relu(bn2(conv2(x2)))
     if pool:
         y2 = y2.max(dim=-1)[0]
-    w = torch.randn(y2.shape, generator=g).cuda()
-    (y1 * w).sum().backward()
-    (y2 * w).sum().backward()
-    torch.testing.assert_close(y1, y2, rtol=1e-5, atol=2e-5)
-    torch.testing.assert_close(x1.grad, x2.grad, rtol=1e-4, atol=2e-5)
-    torch.testing.assert_close(conv.weight.grad, conv2.weight.grad, rtol=1e-4, atol=1e-3)
-    torch.testing.assert_close(bn.weight.grad, bn2.weight.grad, rtol=1e-4, atol=1e-3)
-    torch.testing.assert_close(bn.bias.grad, bn2.bias.grad, rtol=1e-4, atol=1e-3)
-    torch.testing.assert_close(bn.running_mean, bn2.running_mean, rtol=1e-5, atol=1e-6)
-    torch.testing.assert_close(bn.running_var, bn2.running_var, rtol=1e-5, atol=1e-6)
+    w = torch.randn(y2.shape, generator=g)
+    (y1 * w.cuda()).sum().backward()
+    (y2 * w.double()).sum().backward()
+    dev = lambda t: t.detach().float().cuda()  # noqa: E731
+    torch.testing.assert_close(y1, dev(y2), rtol=1e-5, atol=2e-5)
+    torch.testing.assert_close(x1.grad, dev(x2.grad), rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(conv.weight.grad, dev(conv2.weight.grad), rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(bn.weight.grad, dev(bn2.weight.grad), rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(bn.bias.grad, dev(bn2.bias.grad), rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(bn.running_mean, dev(bn2.running_mean), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(bn.running_var, dev(bn2.running_var), rtol=1e-5, atol=1e-6)
     assert int(bn.num_batches_tracked) == int(bn2.num_batches_tracked)
 
 
