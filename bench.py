@@ -462,16 +462,16 @@ def main():
                                      transformer_embed_dim=128, transformer_input_pos_enc=False).to(dev)
                 gs = GraphedTrainStep(net_g, build_criterion(KITTI_LOSS),
                                       make_optimizer(net_g.parameters(), lr=1e-3, weight_decay=0.0, capturable=True), batch, it, True)
-                for _ in range(3):
+                for _ in range(6):
                     gs.step(batch)
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
-                for _ in range(10):
+                for _ in range(20):
                     pg = gs.step(batch)
                 torch.cuda.synchronize()
-                extras["ms_per_step_hip_graph"] = round((time.perf_counter() - t1) / 10 * 1e3, 3)
+                extras["ms_per_step_hip_graph"] = round((time.perf_counter() - t1) / 20 * 1e3, 3)
                 ld, ok = pg.result()
-                extras["hip_graph_note"] = ("the step as one replayed HIP graph (train_seg --hip-graph), 10 replays after the timed "
+                extras["hip_graph_note"] = ("the step as one replayed HIP graph (train_seg --hip-graph), 20 replays after the timed "
                                             "region; stepped=%s, loss sum %.4f" % (bool(ok), ld.get("sum", float("nan"))))
                 del gs, net_g
             except Exception as err:  # an extra reading must not cost the headline its line
