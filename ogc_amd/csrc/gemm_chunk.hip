@@ -280,10 +280,10 @@ extern "C" int ogc_conv1x1_dgrad_pooled(int b, int cin, int cout, int hw, int ns
     const float2 *c2 = reinterpret_cast<const float2 *>(coef2), *ij = reinterpret_cast<const float2 *>(inj);
     const int M = cin, K = cout;
     if (M <= 64) {
-        constexpr int RB = 4, KQ = 4;
+        constexpr int RB = 4, KQ = 4, KA = 2; // (weights staged 32 rows at a time: registers to spare at 64 rows)
         dim3 grid(ogc_divup(hw, 64 * GC_WAVES), ogc_divup(M, 16 * RB), b);
-        hipLaunchKernelGGL((gemm_chunk_kernel<RB, KQ, false, true, true>), grid, dim3(GC_WAVES * OGC_WAVE),
-                           (size_t)2 * 16 * RB * 4 * (KQ | 1) * sizeof(float), s, M, K, hw, w, y, grad_z, c2, ij, sh);
+        hipLaunchKernelGGL((gemm_chunk_kernel<RB, KQ, false, true, true, KA>), grid, dim3(GC_WAVES * OGC_WAVE),
+                           (size_t)2 * 16 * RB * 4 * ((KQ * KA) | 1) * sizeof(float), s, M, K, hw, w, y, grad_z, c2, ij, sh);
     } else {
         constexpr int RB = 8, KQ = 4;
         dim3 grid(ogc_divup(hw, 64 * GC_WAVES), ogc_divup(M, 16 * RB), b);
