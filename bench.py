@@ -462,7 +462,7 @@ def main():
                                      transformer_embed_dim=128, transformer_input_pos_enc=False).to(dev)
                 gs = GraphedTrainStep(net_g, build_criterion(KITTI_LOSS),
                                       make_optimizer(net_g.parameters(), lr=1e-3, weight_decay=0.0, capturable=True), batch, it, True)
-                for _ in range(6):
+                for _ in range(25):
                     gs.step(batch)
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
