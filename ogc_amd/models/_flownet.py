@@ -11,7 +11,7 @@ from ..utils.flowstep3d_util import (FlowEmbedding, PointNetFeaturePropogation, 
                                      geometry_memo)
 
 
-def joint_fps(xyz_a, xyz_b, npoints, parent_ties=None, return_ties=False):
+def joint_fps(xyz_a, xyz_b, npoints, parent_ties=None, return_ties=False, all_ties=None):
     """FPS chains of TWO clouds in one launch per level.  Sampling is per cloud, so stacking both clouds along the
     batch gives each its own indices unchanged, but the sequential rounds (one workgroup per cloud) are paid once
     instead of twice.  Every level samples from the previous level's centres, which are stored in sampling order: a
@@ -23,10 +23,24 @@ def joint_fps(xyz_a, xyz_b, npoints, parent_ties=None, return_ties=False):
     idx_a, idx_b, ties = [], [], parent_ties
     for npoint in npoints:
         idx, ties = furthest_point_sample_chain(level.permute(0, 2, 1).contiguous(), npoint, ties)
+        if all_ties is not None:
+            all_ties.append(ties)   # (2B,) of this level, for geometry_memo.note_chain
         idx_a.append(idx[:B].contiguous())
         idx_b.append(idx[B:].contiguous())
         level = gather_operation(level.contiguous(), idx)
     return (idx_a, idx_b, ties) if return_ties else (idx_a, idx_b)
+
+
+def _note_levels(pc_a, pc_b, level_ties):
+    """Tell the geometry memo that level i >= 1 of both clouds' pyramids came out of a joint_fps chain (level_ties[i - 1]:
+    the (2B,) ties of that level, cloud a first): a set-abstraction layer sampling such a level AGAIN (npoint == n on the
+    coarse levels) continues the chain instead of running all its rounds (geometry_memo.note_chain)."""
+    for i, ties in enumerate(level_ties, start=1):
+        if ties is None or i >= len(pc_a):
+            continue
+        B = pc_a[i].shape[0]
+        geometry_memo.note_chain(pc_a[i], ties[:B])
+        geometry_memo.note_chain(pc_b[i], ties[B:])
 
 
 def _stacked(a, b):
@@ -222,8 +236,9 @@ class FlowStep3DBase(nn.Module):
     def calc_glob_corr(self, pc1_loc, feats1_loc, pc2_loc, feats2_loc, parent_ties=None):
         # parent_ties: the local encoder's sampling chain, which these centres end (they are in sampling order)
         fps1 = fps2 = None
+        level_ties = []
         if pc1_loc.is_cuda and pc1_loc.shape == pc2_loc.shape:
-            fps1, fps2 = joint_fps(pc1_loc, pc2_loc, self.encoder_glob.npoints(), parent_ties)
+            fps1, fps2 = joint_fps(pc1_loc, pc2_loc, self.encoder_glob.npoints(), parent_ties, all_ties=level_ties)
         if fps1 is not None and self._two_clouds_per_call():
             B = pc1_loc.shape[0]
             pc_l, feats = self.encoder_glob(torch.cat([pc1_loc, pc2_loc]), torch.cat([feats1_loc, feats2_loc]),
@@ -233,6 +248,7 @@ class FlowStep3DBase(nn.Module):
         else:
             pc1_l_glob, feats1_glob = self.encoder_glob(pc1_loc, feats1_loc, fps1)
             pc2_l_glob, feats2_glob = self.encoder_glob(pc2_loc, feats2_loc, fps2)
+        _note_levels(pc1_l_glob, pc2_l_glob, level_ties)
         return self.global_corr_layer(pc1_l_glob, pc2_l_glob, feats1_glob, feats2_glob)
 
     def _two_clouds_per_call(self):
@@ -266,9 +282,10 @@ class FlowStep3DBase(nn.Module):
         feature2 = feature2.permute(0, 2, 1).contiguous()
 
         fps_idx1 = fps_idx2 = loc_ties = None
+        level_ties = []
         if pc1.is_cuda and pc1.shape == pc2.shape:  # both sampling chains in one launch per level
             fps_idx1, fps_idx2, loc_ties = joint_fps(pc1, pc2, [self.encoder_loc.sa1.npoint, self.encoder_loc.sa2.npoint],
-                                                     return_ties=True)
+                                                     return_ties=True, all_ties=level_ties)
         if fps_idx1 is not None and self._two_clouds_per_call():
             B = pc1.shape[0]
             pc_l, feats, _ = self.encoder_loc(torch.cat([pc1, pc2]), torch.cat([feature1, feature2]), _stacked(fps_idx1, fps_idx2))
@@ -277,6 +294,7 @@ class FlowStep3DBase(nn.Module):
         else:
             pc1_l_loc, feats1_loc, fps_idx1 = self.encoder_loc(pc1, feature1, fps_idx1)
             pc2_l_loc, feats2_loc, _ = self.encoder_loc(pc2, feature2, fps_idx2)
+        _note_levels(pc1_l_loc, pc2_l_loc, level_ties)
 
         corr_feats = self.calc_glob_corr(pc1_l_loc[-1], feats1_loc, pc2_l_loc[-1], feats2_loc, loc_ties)
         flow0_lr = self.flow0_regressor(pc1_l_loc, corr_feats)

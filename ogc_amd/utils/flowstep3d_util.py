@@ -5,8 +5,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..pointnet2.pointnet2 import (GroupAll, QueryAndGroup, ball_query, furthest_point_sample, gather_operation,
-                                   grouping_operation, knn, knn_radius_clamp, three_interpolate, three_nn)
+from ..pointnet2.pointnet2 import (GroupAll, QueryAndGroup, ball_query, furthest_point_sample, furthest_point_sample_chain,
+                                   gather_operation, grouping_operation, knn, knn_radius_clamp, three_interpolate, three_nn)
 
 
 class geometry_memo:
@@ -34,9 +34,22 @@ class geometry_memo:
         key = (xyz.data_ptr(), xyz._version, tuple(xyz.shape))
         hit = memo.get(key)
         if hit is None or hit["ref"] is not xyz:
-            hit = {"ref": xyz, "xyz_t": None, "fps": {}, "new_xyz": {}, "knn": {}, "three_nn": {}}
+            hit = {"ref": xyz, "xyz_t": None, "fps": {}, "new_xyz": {}, "knn": {}, "three_nn": {}, "ties": None}
             memo[key] = hit
         return hit
+
+    @staticmethod
+    def note_chain(xyz, ties):
+        """`xyz` (B, 3, n) holds the centres of a level of an FPS chain IN SAMPLING ORDER and `ties` (B,) int32 is what
+        furthest_point_sample_chain returned for that level.  A set-abstraction layer that samples this cloud again — the
+        reference does so with npoint == n on the coarse levels (models/flownet_kitti.py:16, :30, :127, :144: a full run
+        of n sequential rounds whose answer is a permutation) — then continues the chain: the rounds the parent run decided
+        without a tie are not run again (the answer is 0, 1, ... for them, ogc_furthest_point_sampling_chain)."""
+        if ties is None:
+            return
+        hit = geometry_memo.entry(xyz)
+        if hit is not None:
+            hit["ties"] = ties.contiguous()
 
 
 def _shared_mlp(x, convs, norms, pool):
@@ -156,7 +169,10 @@ class PointNetSetAbstraction(_FoldAware):
                 if memo is not None and self.npoint in memo["fps"]:
                     fps_idx = memo["fps"][self.npoint]
                 else:
-                    fps_idx = furthest_point_sample(xyz_t, self.npoint)
+                    if memo is not None and memo["ties"] is not None and xyz_t.is_cuda:
+                        fps_idx, _ = furthest_point_sample_chain(xyz_t, self.npoint, memo["ties"])
+                    else:
+                        fps_idx = furthest_point_sample(xyz_t, self.npoint)
                     if memo is not None:
                         memo["fps"][self.npoint] = fps_idx
             if memo is not None and not given_idx and self.npoint in memo["new_xyz"]:

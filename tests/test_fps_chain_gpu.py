@@ -133,3 +133,51 @@ def test_first_tie_round_of_the_bucketed_rounds(oracle, N, first):
         subprocess.run([sys.executable, "-c", code], check=True, env=env, timeout=300)
         np.testing.assert_array_equal(levels[0][2].cpu().numpy(), np.load(os.path.join(d, "t.npy")))
         np.testing.assert_array_equal(levels[0][0].cpu().numpy(), np.load(os.path.join(d, "i.npy")))
+
+
+@pytest.mark.parametrize("kind", ["tie_free", "duplicates", "lattice"])
+def test_sampling_a_level_again_in_full_continues_the_chain(kind):
+    """FlowStep3D's coarse set-abstraction layers sample a level of the pyramid AGAIN with npoint == n (a permutation).  With the
+    level's ties the chain entry point skips the rounds the parent run decided without a tie; the indices are those of a full run."""
+    api = _api()
+    if kind == "tie_free":
+        g = torch.Generator().manual_seed(11)
+        pc = ((torch.rand(2, 4096, 3, generator=g) - 0.5) * torch.tensor([60.0, 4.0, 80.0]))
+    elif kind == "duplicates":
+        g = torch.Generator().manual_seed(12)
+        base = torch.rand(2, 1500, 3, generator=g)
+        pc = torch.cat([base, base[:, :548]], 1)                        # 2048 points, 548 of them twice: ties late in the run
+    else:
+        pc = lattice(16).unsqueeze(0).repeat(2, 1, 1)
+    pc = pc.cuda().contiguous()
+    m1 = pc.shape[1] // 2
+    idx1, ties1 = api.furthest_point_sample_chain(pc, m1, None)
+    level = api.gather_nd(pc, idx1.long()).contiguous()
+    for m in (m1, m1 // 2):
+        again, _ = api.furthest_point_sample_chain(level, m, ties1)
+        assert torch.equal(again, api.furthest_point_sample(level, m)), (kind, m)
+    if kind == "tie_free":
+        assert torch.equal(again, torch.arange(m1 // 2, device="cuda", dtype=torch.int32).expand_as(again))
+
+
+def test_flowstep3d_set_abstraction_takes_the_noted_chain():
+    """PointNetSetAbstraction inside a geometry_memo scope: a cloud noted as a chain level is sampled through the chain entry
+    point (same indices and features as without the note)."""
+    _api()
+    from ogc_amd.utils.flowstep3d_util import PointNetSetAbstraction, geometry_memo
+    api = _api()
+    torch.manual_seed(0)
+    g = torch.Generator().manual_seed(21)
+    base = torch.rand(2, 1800, 3, generator=g)
+    pc = torch.cat([base, base[:, :248]], 1).cuda().contiguous()        # (2, 2048, 3) with duplicates
+    idx1, ties1 = api.furthest_point_sample_chain(pc, 1024, None)
+    level = api.gather_nd(pc, idx1.long()).permute(0, 2, 1).contiguous()   # (2, 3, 1024)
+    sa = PointNetSetAbstraction(npoint=1024, radius=None, nsample=8, in_channel=3, mlp=[16, 16], group_all=False,
+                                return_fps=True).cuda().eval()
+    with torch.no_grad():
+        with geometry_memo():
+            xyz_a, feat_a, idx_a = sa(level, level)
+        with geometry_memo():
+            geometry_memo.note_chain(level, ties1)
+            xyz_b, feat_b, idx_b = sa(level, level)
+    assert torch.equal(idx_a, idx_b) and torch.equal(xyz_a, xyz_b) and torch.equal(feat_a, feat_b)
