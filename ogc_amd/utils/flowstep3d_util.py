@@ -183,6 +183,15 @@ class PointNetSetAbstraction(_FoldAware):
                     memo["new_xyz"][self.npoint] = new_xyz
         else:
             new_xyz = xyz
+        # the centres as (B, S, 3), once per call (and once per forward for coordinates the memo knows)
+        if not sampled:
+            new_xyz_t = xyz_t
+        elif memo is not None and not given_idx and self.npoint in memo.setdefault("new_xyz_t", {}):
+            new_xyz_t = memo["new_xyz_t"][self.npoint]
+        else:
+            new_xyz_t = new_xyz.transpose(2, 1).contiguous()
+            if memo is not None and not given_idx:
+                memo["new_xyz_t"][self.npoint] = new_xyz_t
         neighbours = None
         if memo is not None and sampled and not given_idx and isinstance(self.queryandgroup, QueryAndGroup):
             # un-clamped kNN shared between layers: the k nearest are a prefix of any larger search on the same inputs
@@ -190,13 +199,19 @@ class PointNetSetAbstraction(_FoldAware):
             cached = memo["knn"].get(self.npoint)
             if cached is None or cached[1].shape[2] < k:
                 kk = min(max(k, 32), xyz_t.shape[1])
-                cached = knn_radius_clamp(max(kk, k), None, new_xyz.transpose(2, 1).contiguous(), xyz_t)
+                cached = knn_radius_clamp(max(kk, k), None, new_xyz_t, xyz_t)
                 memo["knn"][self.npoint] = cached
-            neighbours = (cached[0][:, :, :k].contiguous(), cached[1][:, :, :k].contiguous())
+            # (the prefix as its own contiguous pair, once per row length: the recurrent blocks ask for the same few lengths on
+            # the same coordinates in every iteration — two copy launches per layer call otherwise)
+            prefix = memo["knn"].get((self.npoint, k))
+            if prefix is None or prefix[2] is not cached[1]:
+                prefix = (cached[0][:, :, :k].contiguous(), cached[1][:, :, :k].contiguous(), cached[1])
+                memo["knn"][(self.npoint, k)] = prefix
+            neighbours = prefix[:2]
         if neighbours is not None:
-            new_points, _ = self.queryandgroup(xyz_t, new_xyz.transpose(2, 1).contiguous(), points, neighbours=neighbours)
+            new_points, _ = self.queryandgroup(xyz_t, new_xyz_t, points, neighbours=neighbours)
         else:
-            new_points, _ = self.queryandgroup(xyz_t, new_xyz.transpose(2, 1).contiguous(), points)
+            new_points, _ = self.queryandgroup(xyz_t, new_xyz_t, points)
         if self.use_act and self.act is F.relu:
             new_points = _shared_mlp(new_points, self.mlp_convs, self.mlp_bns, pool=not self.mean_aggr)
             if self.mean_aggr:

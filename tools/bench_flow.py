@@ -30,6 +30,16 @@ def timed(fn, reps=5, warm=2):
 net.eval()
 with torch.no_grad():
     print("forward eval iters=5: %.2f ms" % timed(lambda: net(pc1, pc2, pc1, pc2, iters=5)))
+    # the launch thread's share: time until the call returns (nothing waits for the GPU inside the forward)
+    import time as _t
+    torch.cuda.synchronize(); t0 = _t.perf_counter()
+    for _ in range(5):
+        net(pc1, pc2, pc1, pc2, iters=5)
+    t_issue = (_t.perf_counter() - t0) / 5 * 1e3
+    torch.cuda.synchronize()
+    print("forward eval iters=5: launch thread %.2f ms per forward" % t_issue)
+    # (the forward as one replayed HIP graph — round 4, dropped: 8.24 ms against 7.74 ms eager, bit-identical; the launch thread is
+    # not what bounds this forward)
 net.train()
 crit = UnsupervisedFlowStep3DLoss(ChamferLoss(2), SmoothLoss(3., 1., {'k': 4, 'radius': 0.5, 'loss_norm': 1},
                                                               {'k': 8, 'radius': 1.0, 'loss_norm': 1}),
