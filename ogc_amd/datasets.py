@@ -8,6 +8,11 @@ one directory tree:
   OGCDynamicRoomDataset      <root>/data/<id>/{pc,segm,pose}_%02d.npy, <root>/data/<split>.lst
                              (datasets/dataset_ogcdr.py:30-157); predicted flows <root>/flow_preds/<name>/<id>.npy (P, N, 3) with
                              <root>/flow_preds/<name>.json {"view_sel": [...]} naming the P ordered frame pairs
+  SapienDataset              <root>/data/%06d.npz {pc (V, N, 3), segm (V, N), trans: {"cam": (V, 4, 4), part id: (V, 4, 4)}},
+                             <root>/meta.json {split: [ids]} (datasets/dataset_sapien.py:22-170); predicted flows in the
+                             OGC-DR layout under %06d.npy.  NOT pinned against the reference's class: it imports pyquaternion
+                             (utils/sapien_util.py), which this image lacks — tests/test_sapien_reader.py checks the flows against
+                             the rigid motions applied directly
 
 A sample is (pcs (t, N, 3) f32, segms (t, N) i32, flows (t, N, 3) f32, valids (t, N) f32), t = 2 frames, or 4 with
 `aug_transform` (two random similarity transforms of the pair, utils/data_util.py:140-195).  The one-hot label variant of the
@@ -140,3 +145,83 @@ class OGCDynamicRoomDataset(Dataset):
         for i in range(flow_pred.shape[0] // n_frame):
             idx = offset * batch_size // n_frame + i
             np.save(os.path.join(save_root, self.data_ids[idx] + ".npy"), flow_pred[i * n_frame:(i + 1) * n_frame])
+
+
+def _rigid_inverse(m):
+    """Inverse of a 4x4 rigid transform as (R^T, -R^T t) — what the reference's Isometry.inv() computes on (quaternion, t)
+    (utils/sapien_util.py:49-51), not a general matrix inverse."""
+    out = np.eye(4, dtype=np.float64)
+    out[:3, :3] = m[:3, :3].T
+    out[:3, 3] = -(m[:3, :3].T @ m[:3, 3])
+    return out
+
+
+def compute_part_flow(base_pc, base_segms, base_cam, base_motions, dest_cam, dest_motions):
+    """Flow of a SAPIEN frame from its parts' motions: part k (label k + 1) moves by
+    dest_cam^-1 . dest_motion_k . base_motion_k^-1 . base_cam (all 4x4, camera-to-world and part-to-world);
+    points of no part keep whatever np.empty_like holds in the reference — here 0 (datasets/dataset_sapien.py:12-20)."""
+    final_pc = base_pc.astype(np.float64).copy()
+    for k in range(len(base_motions)):
+        sel = np.where(base_segms == (k + 1))[0]
+        rel = _rigid_inverse(dest_cam) @ dest_motions[k] @ _rigid_inverse(base_motions[k]) @ base_cam
+        final_pc[sel] = base_pc[sel] @ rel[:3, :3].T + rel[:3, 3]
+    return (final_pc - base_pc).astype(base_pc.dtype)
+
+
+class SapienDataset(Dataset):
+    """Reference: datasets/dataset_sapien.py:22-170 (the one-hot label variant of the supervised baselines is out of scope)."""
+
+    def __init__(self, data_root, split="train", view_sels=[[0, 1]], predflow_path=None, decentralize=False, aug_transform=False,
+                 aug_transform_args=None):
+        import json
+        self.data_root = os.path.join(data_root, "data")
+        with open(os.path.join(data_root, "meta.json")) as f:
+            self.meta = json.load(f)
+        self.split, self.data_ids = split, self.meta[split]
+        self.view_sels = [list(v) for v in view_sels]
+        self.predflow_path, self.pf_view_sels = None, None
+        if predflow_path is not None:
+            self.predflow_path = os.path.join(data_root, "flow_preds", predflow_path)
+            self.pf_view_sels = flow_store.read_meta(self.predflow_path)
+            if self.pf_view_sels is None:
+                raise FileNotFoundError(self.predflow_path + ".json")
+            if any(sel not in self.pf_view_sels for sel in self.view_sels):
+                raise ValueError("Flow predictions cannot cover specified view selections!")
+        self.decentralize = decentralize
+        self.aug_transform, self.aug_transform_args = aug_transform, aug_transform_args
+
+    def __len__(self):
+        return len(self.data_ids) * len(self.view_sels)
+
+    def _name(self, idx):
+        return "%06d" % self.data_ids[idx]
+
+    def _load_data(self, idx):
+        data = np.load(os.path.join(self.data_root, self._name(idx) + ".npz"), allow_pickle=True)
+        return data["pc"].astype(np.float32), data["segm"], data["trans"].item()
+
+    def __getitem__(self, sid):
+        idx, view_sel = sid // len(self.view_sels), self.view_sels[sid % len(self.view_sels)]
+        pcs, segms, trans = self._load_data(idx)
+        n_parts = len(trans) - 1
+        a, b = view_sel
+        pcs, segms = pcs[view_sel], segms[view_sel]
+        if self.predflow_path is not None:
+            flows = flow_store.load_pair(self.predflow_path, self._name(idx), view_sel, self.pf_view_sels)
+            if flows is None:
+                raise FileNotFoundError(os.path.join(self.predflow_path, self._name(idx) + ".npy"))
+        else:
+            def motions(v):
+                return [np.asarray(trans[t][v], dtype=np.float64) for t in range(1, n_parts + 1)]
+            cam = lambda v: np.asarray(trans["cam"][v], dtype=np.float64)
+            flows = [compute_part_flow(pcs[0], segms[0], cam(a), motions(a), cam(b), motions(b)),
+                     compute_part_flow(pcs[1], segms[1], cam(b), motions(b), cam(a), motions(a))]
+        return _finish(list(pcs), list(segms), flows, self.decentralize, self.aug_transform, self.aug_transform_args)
+
+    def _save_predflow(self, flow_pred, save_root, batch_size, n_frame=1, offset=0):
+        """flow_pred (B, N, 3), the n_frame ordered pairs of a scene adjacent -> <save_root>/%06d.npy (n_frame, N, 3)
+        (dataset_sapien.py:140-151)."""
+        flow_pred = flow_pred.detach().cpu().numpy() if hasattr(flow_pred, "detach") else np.asarray(flow_pred)
+        for i in range(flow_pred.shape[0] // n_frame):
+            idx = offset * batch_size // n_frame + i
+            np.save(os.path.join(save_root, self._name(idx) + ".npy"), flow_pred[i * n_frame:(i + 1) * n_frame])

@@ -156,7 +156,7 @@ def refine_data_root(args, cfg, segnet, device):
     """The round on a directory tree in the reference's layout (oa_icp.py:141-229): two data sets over the same ordered frame
     pairs — ground-truth flows for the report, predicted flows of the previous round as input — batches of whole scenes,
     refined flow of the first frame of every pair saved through the data set's writer."""
-    from .datasets import KITTISceneFlowDataset, OGCDynamicRoomDataset
+    from .datasets import KITTISceneFlowDataset, OGCDynamicRoomDataset, SapienDataset
     root = args.data_root
     predflow = "flowstep3d" if args.round <= 1 else "flowstep3d_R%d" % (args.round - 1)       # oa_icp.py:143-146
     decentralize = (cfg.get("data") or {}).get("decentralize", False)
@@ -169,6 +169,14 @@ def refine_data_root(args, cfg, segnet, device):
         view_sels, thresh = [list(v) for v in flow_store.SEQUENCE_PAIRS], 0.01
         kw = dict(data_root=root, split=args.split, view_sels=view_sels, decentralize=decentralize)
         test_set, test_set_predflow = OGCDynamicRoomDataset(**kw), OGCDynamicRoomDataset(predflow_path=predflow, **kw)
+    elif cfg["dataset"] == "sapien":
+        # oa_icp.py:105-113: the test split lives in mbs-sapien, the others in mbs-shapepart (a root that already IS one of the
+        # two is taken as it is)
+        sub = os.path.join(root, "mbs-sapien" if args.split == "test" else "mbs-shapepart")
+        root = sub if os.path.isdir(sub) else root
+        view_sels, thresh = [list(v) for v in flow_store.SEQUENCE_PAIRS], 0.01
+        kw = dict(data_root=root, split=args.split, view_sels=view_sels, decentralize=decentralize)
+        test_set, test_set_predflow = SapienDataset(**kw), SapienDataset(predflow_path=predflow, **kw)
     else:
         raise KeyError("no reader for dataset %r" % cfg["dataset"])
     n_frame, batch_size = len(view_sels), args.test_batch_size
@@ -177,7 +185,7 @@ def refine_data_root(args, cfg, segnet, device):
     if args.save:
         assert batch_size % n_frame == 0, "Frame pairs of one scene should be in the same batch"   # oa_icp.py:179-180
         os.makedirs(out_dir, exist_ok=True)
-        if cfg["dataset"] == "ogcdr":
+        if cfg["dataset"] in ("ogcdr", "sapien"):
             flow_store.write_meta(out_dir, view_sels)
     sums, count = {"input": 0.0, "kabsch": 0.0, "oa_icp": 0.0}, 0
     n_batch = 0

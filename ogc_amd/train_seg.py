@@ -410,7 +410,7 @@ def main(argv=None):
     if args.data_root is not None:
         # scenes (and, from round 2 on, the refined flows of the round before) from a directory tree in the reference's layout
         # (ogc_amd/datasets.py; train_seg.py:270-315): KITTI-SF needs the two split files, OGC-DR has them in the tree
-        from .datasets import KITTISceneFlowDataset, OGCDynamicRoomDataset
+        from .datasets import KITTISceneFlowDataset, OGCDynamicRoomDataset, SapienDataset
         data = cfg.get("data") or {}
         name = cfg.get("predflow_path", "flowstep3d")
         predflow = name if args.round <= 1 else "%s_R%d" % (name, args.round - 1)
@@ -426,8 +426,15 @@ def main(argv=None):
                           decentralize=data.get("decentralize", False))
             train_set = OGCDynamicRoomDataset(split="train", aug_transform_args=aug_args, **common)
             val_set = OGCDynamicRoomDataset(split="val", **common)
+        elif cfg["dataset"] == "sapien":
+            from .utils.flow_store import TRAIN_PAIRS
+            sub = os.path.join(args.data_root, "mbs-shapepart")                                   # train_seg.py:296-297
+            common = dict(data_root=sub if os.path.isdir(sub) else args.data_root, view_sels=TRAIN_PAIRS, predflow_path=predflow,
+                          decentralize=data.get("decentralize", False))
+            train_set = SapienDataset(split="train", aug_transform_args=aug_args, **common)
+            val_set = SapienDataset(split="val", **common)
         else:
-            raise KeyError("no reader for dataset %r (ogc_amd/datasets.py covers kittisf and ogcdr)" % cfg["dataset"])
+            raise KeyError("no reader for dataset %r (ogc_amd/datasets.py covers kittisf, ogcdr and sapien)" % cfg["dataset"])
     elif args.frames > 2:
         from .utils.flow_store import TRAIN_PAIRS
         assert not outdoor and args.frames == 4, "sequences are the SAPIEN / OGC-DR sample format (4 frames)"
