@@ -2039,7 +2039,11 @@ int ogc_ball_query_grid(int b, int n, int m, float radius, int nsample, const fl
 int ogc_knn_grid(int mode, int b, int n, int m, int k, float radius, const float *unknown, const float *known,
                  float *dist, int *idx, hipStream_t s) {
     const size_t lds = (size_t)2 * QPW * k * sizeof(u64) + (size_t)QPW * KNN_FLAT_CAP * sizeof(int);
-    if (m < 1024 || m <= 4 * k || lds > 64 * 1024) return OGC_ERR_UNSUPPORTED;
+    // smallest cloud searched through cells (OGC_KNN_GRID_MIN in the environment, A/B runs; 1024 until round 4): below it the
+    // all-pairs scan, one lane per query — at B = 1 a 512-point level of FlowStep3D is 16 wavefronts scanning for 160 us, against
+    // ~60 us of build + search here (forward 7.70 -> 7.55 ms)
+    static const int min_m = [] { const char *e = getenv("OGC_KNN_GRID_MIN"); const int v = e ? atoi(e) : 256; return v < 64 ? 64 : v; }();
+    if (m < min_m || m <= 4 * k || lds > 64 * 1024) return OGC_ERR_UNSUPPORTED;
     const GridLayout L(b, m);
     void *ws = ogc_workspace(s, L.total());
     if (!ws) return OGC_ERR_UNSUPPORTED;

@@ -221,7 +221,12 @@ class PointNetSetAbstraction(_FoldAware):
             for conv, bn in zip(self.mlp_convs, self.mlp_bns):
                 new_points = self.act(bn(pointwise_conv(new_points, conv))) if self.use_act else \
                     pointwise_conv(new_points, conv)
-            new_points = new_points.mean(dim=-1) if self.mean_aggr else new_points.max(dim=-1)[0]
+            if self.mean_aggr:
+                new_points = new_points.mean(dim=-1)
+            elif new_points.requires_grad:
+                new_points = new_points.max(dim=-1)[0]      # (its backward sends the gradient to ONE arg-max, as the reference's)
+            else:
+                new_points = torch.amax(new_points, dim=-1)  # inference: the same values without the index half of the reduction
         if self.return_fps:
             return new_xyz, new_points, fps_idx
         return new_xyz, new_points

@@ -1,8 +1,9 @@
 export PYTHONPATH=$PWD
-mkdir -p gpurun_out/k5
-for i in 1 2; do
-OGC_BF16_WIDE_POOL=0 timeout 300 python tools/bench_config.py config/ogcdr_unsup_synthetic.yaml 20 2>&1 | grep "ms/step" | sed 's/^/off: /' >> gpurun_out/k5/ab.txt
-OGC_BF16_WIDE_POOL=1 timeout 300 python tools/bench_config.py config/ogcdr_unsup_synthetic.yaml 20 2>&1 | grep "ms/step" | sed 's/^/on:  /' >> gpurun_out/k5/ab.txt
+mkdir -p gpurun_out/k6
+for v in 1024 256 1024 256; do
+echo "OGC_KNN_GRID_MIN=$v" >> gpurun_out/k6/ab.txt
+OGC_KNN_GRID_MIN=$v timeout 300 python tools/bench_flow.py 8192 1 2>&1 | grep "forward eval iters=5:" | head -1 >> gpurun_out/k6/ab.txt
+OGC_KNN_GRID_MIN=$v timeout 300 python tools/bench_config.py config/sapien_unsup_synthetic.yaml 20 2>&1 | grep "ms/step" | cut -c1-80 >> gpurun_out/k6/ab.txt
 done
-python -m pytest tests/test_bf16_gpu.py tests/test_fallbacks_gpu.py -x -q 2>&1 | tail -15 >> gpurun_out/k5/ab.txt
-cat gpurun_out/k5/ab.txt
+OGC_KNN_GRID_MIN=128 python -m pytest tests/test_ops_gpu.py tests/test_golden_gpu.py -x -q -k "knn or golden or three" 2>&1 | tail -3 >> gpurun_out/k6/ab.txt
+cat gpurun_out/k6/ab.txt
