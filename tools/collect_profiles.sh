@@ -7,6 +7,6 @@ for f in steady phase_busy native_forward native_loss native_backward step_hbm_t
          graph_step flowstep3d corr_layer ball_ab; do
   [ -f "$src/$f.txt" ] && grep -v "amdgpu.ids" "$src/$f.txt" > "profiles/${r}_$f.txt"
 done
-cat "$src"/config_sapien.txt "$src"/config_ogcdr.txt "$src"/config_ogcdr_fp32.txt "$src"/config_waymo.txt "$src"/config_kittisf.txt 2>/dev/null \
+cat "$src"/config_sapien.txt "$src"/config_sapien_graph.txt "$src"/config_ogcdr.txt "$src"/config_ogcdr_fp32.txt "$src"/config_waymo.txt "$src"/config_kittisf.txt 2>/dev/null \
   | grep "ms/step" > "profiles/${r}_configs.txt"
 ls -la profiles/${r}_* | wc -l

@@ -16,6 +16,7 @@ for c in sapien ogcdr waymo kittisf; do
   timeout 300 python tools/bench_config.py config/${c}_unsup_synthetic.yaml 20 > "$out/config_$c.txt" 2>&1
 done
 PRECISION=fp32 timeout 300 python tools/bench_config.py config/ogcdr_unsup_synthetic.yaml 20 > "$out/config_ogcdr_fp32.txt" 2>&1
+GRAPH=1 timeout 300 python tools/bench_config.py config/sapien_unsup_synthetic.yaml 30 > "$out/config_sapien_graph.txt" 2>&1
 timeout 300 python tools/bench_flow.py 8192 1 > "$out/flowstep3d.txt" 2>&1
 timeout 300 python tools/corr_layer_time.py all > "$out/corr_layer.txt" 2>&1
 timeout 300 python tools/bq_ab.py > "$out/ball_ab.txt" 2>&1
