@@ -427,31 +427,7 @@ def main():
 
     isolated_ms, extras, pair_floor_ms = None, {}, 0.0
     if rank == 0:
-        # the same ball-query call on an otherwise idle GPU (in the step it shares the chip with the dense kernels)
-        from ogc_amd.pointnet2.pointnet2 import ball_query
-        pc = torch.cat([batch[0][:, v] for v in range(4)]).contiguous()
-        bl = KITTI_LOSS["smooth_loss_params"]["ball_q_loss_params"]
-        isolated_ms = _time(lambda: ball_query(bl["radius"], bl["k"], pc, pc))
-        pair_floor_ms = _event_pair_floor()
-        extras = measure_extras(pc, a)
-        extras["ms_per_step_with_h2d"], extras["h2d_note"] = steps_with_h2d(model, crit, opt, host_batches, it, train_step, dev)
-        # steps with the FPS chain shortcut off: every encoder level runs all its sampling rounds, as it must for clouds
-        # with duplicated points (synthetic uniform clouds are tie-free, so levels 2-3 cost ~10 us in the headline)
-        import ogc_amd.utils.pointnet2_util as sa_util
-        sa_util.FPS_CHAIN_SHORTCUT = False
-        try:
-            pre2 = None
-            for j in range(2 + 8):
-                if j == 2:
-                    torch.cuda.synchronize()
-                    t1 = time.perf_counter()
-                pre2 = train_step(model, crit, opt, batches[j % NB], it, True, sync=False, prefetched=pre2,
-                                  next_batch=batches[(j + 1) % NB]).prefetched
-            torch.cuda.synchronize()
-            extras["ms_per_step_all_fps_rounds"] = round((time.perf_counter() - t1) / 8 * 1e3, 3)
-        finally:
-            sa_util.FPS_CHAIN_SHORTCUT = True
-        if world == 1 and not dist.is_initialized():
+        def graph_reading():
             # the same step replayed as ONE HIP graph (ogc_amd/graph_step.py; `--hip-graph` of the training driver): what a step
             # costs when the launch thread is out of the picture.  A second network / optimizer (the capture needs step counts
             # on the device); reported next to the eager headline, never instead of it.
@@ -471,12 +447,52 @@ def main():
                 torch.cuda.synchronize()
                 extras["ms_per_step_hip_graph"] = round((time.perf_counter() - t1) / 20 * 1e3, 3)
                 ld, ok = pg.result()
-                extras["hip_graph_note"] = ("the step as one replayed HIP graph (train_seg --hip-graph), 20 replays after the timed "
+                extras["hip_graph_note"] = ("the step as one replayed HIP graph (train_seg --hip-graph), 20 replays right after the timed "
                                             "region; stepped=%s, loss sum %.4f" % (bool(ok), ld.get("sum", float("nan"))))
                 del gs, net_g
             except Exception as err:  # an extra reading must not cost the headline its line
                 extras["ms_per_step_hip_graph"] = None
                 extras["hip_graph_note"] = "not measured: %s" % (str(err)[:200],)
+        # The graph reading comes BEFORE the other extras (OGC_BENCH_GRAPH_FIRST=0: after them, as until round 4).  The host-to-device
+        # reading below creates a copy stream, the fifth stream of the process; ROCm maps streams onto four hardware queues by
+        # default, the copy stream's queue is then shared with one of the replay's streams and the replay measured 13.2-13.3 ms
+        # instead of 11.2-11.4 (bisected with OGC_BENCH_SKIP; GPU_MAX_HW_QUEUES=8 / 16 make both readings WORSE: 16.6 / 18.6 ms, 3
+        # costs the eager step 0.3 ms, 2 dead-locks the step's side streams).  tools/graph_step.py measures the same pair alone.
+        graph_first = os.environ.get("OGC_BENCH_GRAPH_FIRST", "1") != "0"
+        graph_extras = {}
+        if graph_first and world == 1 and not dist.is_initialized():
+            graph_reading()
+            graph_extras, extras = extras, {}
+        # the same ball-query call on an otherwise idle GPU (in the step it shares the chip with the dense kernels)
+        from ogc_amd.pointnet2.pointnet2 import ball_query
+        pc = torch.cat([batch[0][:, v] for v in range(4)]).contiguous()
+        bl = KITTI_LOSS["smooth_loss_params"]["ball_q_loss_params"]
+        isolated_ms = _time(lambda: ball_query(bl["radius"], bl["k"], pc, pc))
+        pair_floor_ms = _event_pair_floor()
+        skip = set(filter(None, os.environ.get("OGC_BENCH_SKIP", "").split(",")))  # (development: leave extras out)
+        extras = measure_extras(pc, a) if "ops" not in skip else {}
+        if "h2d" not in skip:
+            extras["ms_per_step_with_h2d"], extras["h2d_note"] = steps_with_h2d(model, crit, opt, host_batches, it, train_step, dev)
+        # steps with the FPS chain shortcut off: every encoder level runs all its sampling rounds, as it must for clouds
+        # with duplicated points (synthetic uniform clouds are tie-free, so levels 2-3 cost ~10 us in the headline)
+        import ogc_amd.utils.pointnet2_util as sa_util
+        sa_util.FPS_CHAIN_SHORTCUT = False
+        try:
+            pre2 = None
+            for j in range((2 + 8) if "fps" not in skip else 0):
+                if j == 2:
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                pre2 = train_step(model, crit, opt, batches[j % NB], it, True, sync=False, prefetched=pre2,
+                                  next_batch=batches[(j + 1) % NB]).prefetched
+            torch.cuda.synchronize()
+            if "fps" not in skip:
+                extras["ms_per_step_all_fps_rounds"] = round((time.perf_counter() - t1) / 8 * 1e3, 3)
+        finally:
+            sa_util.FPS_CHAIN_SHORTCUT = True
+        if not graph_first and world == 1 and not dist.is_initialized():
+            graph_reading()
+        extras.update(graph_extras)
     if rank == 0:
         durs = timer.durations_ms()
         # In the step the ball query runs on the cell grid it shares with the loss's k-NN (ogc_cell_grid_build once per step for
