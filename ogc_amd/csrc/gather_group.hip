@@ -198,6 +198,67 @@ __global__ __launch_bounds__(GG_THREADS) void group_xyz_rel_kernel(int n, int np
     o[2 * (size_t)T] = __fsub_rn(p[2], q[2]);
 }
 
+// ogc_group_concat in ONE launch: the workgroups of the last y-row write the three relative-coordinate rows (the expression of
+// group_xyz_rel_kernel), the others the gathered feature rows behind them (group_fwd_kernel).  At B = 1 (FlowStep3D inference: ~46
+// groupers per forward) the two launches of the pair are ~4 us each on a serial timeline.
+template <bool VEC4>
+__global__ __launch_bounds__(GG_THREADS) void group_concat_kernel(int c, int n, int T, int nsample, int ch_per_block,
+                                                                  long long out_bstride, const float *__restrict__ points,
+                                                                  const int *__restrict__ idx, const float *__restrict__ xyz,
+                                                                  const float *__restrict__ new_xyz, float *__restrict__ out) {
+    const int b = blockIdx.z;
+    const int *id = idx + (size_t)b * T;
+    float *ob = out + (size_t)b * out_bstride;
+    if (blockIdx.y == gridDim.y - 1) { // rows 0..2: xyz[idx] - centre
+        const int npoints = T / nsample;
+        const float *xb = xyz + (size_t)b * n * 3, *qb = new_xyz + (size_t)b * npoints * 3;
+        if (VEC4) {
+            const int t4 = (blockIdx.x * GG_THREADS + threadIdx.x) * 4;
+            if (t4 >= T) return;
+            const int4 i4 = *reinterpret_cast<const int4 *>(id + t4);
+            const int ii[4] = {i4.x, i4.y, i4.z, i4.w};
+            float r[3][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float *p = xb + (size_t)ii[j] * 3, *q = qb + (size_t)((t4 + j) / nsample) * 3;
+                r[0][j] = __fsub_rn(p[0], q[0]);
+                r[1][j] = __fsub_rn(p[1], q[1]);
+                r[2][j] = __fsub_rn(p[2], q[2]);
+            }
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+                *reinterpret_cast<float4 *>(ob + (size_t)a * T + t4) = make_float4(r[a][0], r[a][1], r[a][2], r[a][3]);
+        } else {
+            const int t = blockIdx.x * GG_THREADS + threadIdx.x;
+            if (t >= T) return;
+            const float *p = xb + (size_t)id[t] * 3, *q = qb + (size_t)(t / nsample) * 3;
+            ob[t] = __fsub_rn(p[0], q[0]);
+            ob[T + t] = __fsub_rn(p[1], q[1]);
+            ob[2 * (size_t)T + t] = __fsub_rn(p[2], q[2]);
+        }
+        return;
+    }
+    const int c0 = blockIdx.y * ch_per_block;
+    const int c1 = min(c, c0 + ch_per_block);
+    const float *p = points + ((size_t)b * c + c0) * n;
+    float *o = ob + (size_t)(3 + c0) * T;
+    if (VEC4) {
+        const int t4 = (blockIdx.x * GG_THREADS + threadIdx.x) * 4;
+        if (t4 >= T) return;
+        const int4 i4 = *reinterpret_cast<const int4 *>(id + t4);
+        for (int ch = c0; ch < c1; ++ch, p += n, o += T) {
+            float4 v;
+            v.x = p[i4.x]; v.y = p[i4.y]; v.z = p[i4.z]; v.w = p[i4.w];
+            *reinterpret_cast<float4 *>(o + t4) = v;
+        }
+    } else {
+        const int t = blockIdx.x * GG_THREADS + threadIdx.x;
+        if (t >= T) return;
+        const int i = id[t];
+        for (int ch = c0; ch < c1; ++ch, p += n, o += T) o[t] = p[i];
+    }
+}
+
 int pick_ch_per_block(int b, int c, int blocks_x) {
     // aim for >= ~2048 workgroups (8 per CU) before giving each workgroup more channels
     int cpb = 1;
@@ -329,6 +390,20 @@ extern "C" int ogc_group_concat(int b, int c, int n, int npoints, int nsample, c
     OGC_REQUIRE(xyz && new_xyz && idx && out && (points || c == 0), "ogc_group_concat: null pointer");
     const long long bstride = (long long)(3 + c) * T;
     OGC_REQUIRE(bstride < (1ll << 31) && b <= 65535, "ogc_group_concat: one sample exceeds 32-bit indexing");
+    if (c > 0 && nsample > 0 && (long long)c * n < (1ll << 31)) { // both halves in one launch (group_concat_kernel)
+        const bool vec = (T % 4 == 0) && aligned16(idx) && aligned16(out) && bstride % 4 == 0;
+        const int bx = ogc_divup(T, vec ? GG_THREADS * 4 : GG_THREADS);
+        const int cpb = pick_ch_per_block(b, c, bx);
+        dim3 grid(bx, ogc_divup(c, cpb) + 1, b);
+        if (vec)
+            hipLaunchKernelGGL(group_concat_kernel<true>, grid, dim3(GG_THREADS), 0, (hipStream_t)stream, c, n, T, nsample, cpb,
+                               bstride, points, idx, xyz, new_xyz, out);
+        else
+            hipLaunchKernelGGL(group_concat_kernel<false>, grid, dim3(GG_THREADS), 0, (hipStream_t)stream, c, n, T, nsample, cpb,
+                               bstride, points, idx, xyz, new_xyz, out);
+        OGC_CHECK_LAUNCH("ogc_group_concat");
+        return OGC_OK;
+    }
     hipLaunchKernelGGL(group_xyz_rel_kernel, dim3(ogc_divup(T, GG_THREADS), b), dim3(GG_THREADS), 0,
                        (hipStream_t)stream, n, npoints, nsample, bstride, xyz, new_xyz, idx, out);
     OGC_CHECK_LAUNCH("ogc_group_concat");
