@@ -75,6 +75,26 @@ def test_knn_nonfinite_candidates(nat, oracle):
     assert np.array_equal(d2, d2r)
 
 
+@pytest.mark.parametrize("m", [256, 600, 1023])
+def test_knn_small_clouds_through_the_cell_lists(nat, oracle, m):
+    """Clouds of 256 .. 1023 points take the cell-list search since round 4 (the all-pairs scan before): non-finite candidates,
+    exact twins, a far outlier that stretches the grid, queries outside the cloud's box."""
+    rng = np.random.default_rng(1000 + m)
+    u, kn = cloud(rng, 2, 300), cloud(rng, 2, m, dup=m // 8)
+    kn[0, 3, 0] = np.inf
+    kn[0, 17, 1] = np.nan
+    kn[1, 5] = 3e19            # squared distance overflows to +inf
+    kn[1, 9] = (500.0, -300.0, 40.0)
+    u[0, :10] *= 50.0
+    for k in (1, 16, 40):
+        if m <= 4 * k:
+            continue
+        d2, idx = run_knn(nat, k, u, kn)
+        d2r, idxr = oracle.knn(k, u, kn)
+        assert np.array_equal(idx, idxr), (m, k)
+        assert np.array_equal(d2, d2r), (m, k)
+
+
 def test_knn_config_scale_kitti_loss(nat, oracle):
     # C4 loss shape: n = m = 8192, k = 32 (config/seg/kittisf/kittisf_unsup.yaml via SURVEY §8)
     rng = np.random.default_rng(1234)
