@@ -1243,9 +1243,9 @@ __device__ __forceinline__ u64 knn_xor_lane(u64 v) {
     return ((u64)hi << 32) | lo;
 }
 
-template <int NK>
+template <int NK, int SUBT>
 __device__ __forceinline__ void knn_sort_keys(u64 (&key)[NK], int sub) {
-    constexpr int N = SUB * NK;
+    constexpr int N = SUBT * NK;
 #pragma unroll
     for (int size = 2; size <= N; size <<= 1) {
 #pragma unroll
@@ -1255,7 +1255,7 @@ __device__ __forceinline__ void knn_sort_keys(u64 (&key)[NK], int sub) {
                 const bool lower = (sub & lx) == 0;
 #pragma unroll
                 for (int t = 0; t < NK; ++t) {
-                    const u64 other = lx == 1 ? knn_xor_lane<1>(key[t]) : (lx == 2 ? knn_xor_lane<2>(key[t]) : knn_xor_lane<4>(key[t]));
+                    const u64 other = lx == 1 ? knn_xor_lane<1>(key[t]) : (lx == 2 ? knn_xor_lane<2>(key[t]) : (lx == 4 ? knn_xor_lane<4>(key[t]) : knn_xor_lane<8>(key[t])));
                     const bool up = ((sub * NK + t) & size) == 0;
                     const bool take = (up == lower) ? other < key[t] : other > key[t];
                     key[t] = take ? other : key[t];
@@ -1278,10 +1278,11 @@ __device__ __forceinline__ void knn_sort_keys(u64 (&key)[NK], int sub) {
 
 // keys of the flat candidate list `mine[0 .. total)` (total <= 8 NK), sorted; the k smallest go to kept[] in ascending order.
 // Returns the number kept.
-template <int NK>
+template <int NK, int SUBT>
 __device__ __forceinline__ int knn_first_block(const float4 *__restrict__ pts, const int *mine, int total, float qx, float qy,
                                                float qz, int sub, int k, u64 *kept, int have) {
     // slots 0 .. have - 1: the keys kept so far (a later shell merges into them); then the `total` new candidates
+    constexpr int SUB = SUBT; // lanes per query (shadows the file's constant)
     u64 key[NK];
     float4 cand[NK];
 #pragma unroll
@@ -1304,7 +1305,8 @@ __device__ __forceinline__ int knn_first_block(const float4 *__restrict__ pts, c
     valid += __builtin_amdgcn_ds_swizzle(valid, (1 << 10) | 0x1F);
     valid += __builtin_amdgcn_ds_swizzle(valid, (2 << 10) | 0x1F);
     valid += __builtin_amdgcn_ds_swizzle(valid, (4 << 10) | 0x1F);
-    knn_sort_keys<NK>(key, sub);
+    if constexpr (SUBT == 16) valid += __builtin_amdgcn_ds_swizzle(valid, (8 << 10) | 0x1F);
+    knn_sort_keys<NK, SUBT>(key, sub);
     const int keep = min(valid, k);
 #pragma unroll
     for (int t = 0; t < NK; ++t) {
@@ -1316,7 +1318,7 @@ __device__ __forceinline__ int knn_first_block(const float4 *__restrict__ pts, c
 
 // MODE 0: squared distances (ogc_knn).  MODE 1: sqrt + radius clamp of the indices (ogc_knn_clamped).
 constexpr int KNN_FLAT_CAP = 192; // positions of the first shell kept as one flat list per query (else: run by run)
-template <int MODE>
+template <int MODE, int SUBT = 8>
 __global__ __launch_bounds__(OGC_WAVE, 4) void knn_grid_kernel(int n, int m, int k, float radius, float lim2, int stride_cells,
                                                             int deferred, const float *__restrict__ unknown,
                                                             const GridHdr *__restrict__ hdrs,
@@ -1324,8 +1326,11 @@ __global__ __launch_bounds__(OGC_WAVE, 4) void knn_grid_kernel(int n, int m, int
                                                             const float4 *__restrict__ sorted_pts,
                                                             float *__restrict__ dist_out, int *__restrict__ idx_out) {
     extern __shared__ __attribute__((aligned(16))) u64 kq_smem[];
+    // SUBT lanes per query: 8 (eight queries per wavefront), or 16 (four) for launches that leave most of the chip idle — few
+    // queries of one or two clouds, FlowStep3D at B = 1 — where a wavefront's serial work per query, not the number of wavefronts, is the time
+    constexpr int SUB = SUBT, QPW = OGC_WAVE / SUBT;
     const int lane = threadIdx.x, b = blockIdx.y;
-    const int sub = lane & (SUB - 1), qi = lane >> 3;
+    const int sub = lane & (SUB - 1), qi = lane / SUB;
     u64 *kept = kq_smem + (size_t)qi * k;           // [QPW][k]
     u64 *outk = kq_smem + (size_t)(QPW + qi) * k;   // [QPW][k]
     int *flat = reinterpret_cast<int *>(kq_smem + (size_t)2 * QPW * k); // [QPW][KNN_FLAT_CAP] positions of the first shell
@@ -1389,7 +1394,7 @@ __global__ __launch_bounds__(OGC_WAVE, 4) void knn_grid_kernel(int n, int m, int
         }
         const u64 ball = __builtin_amdgcn_ballot_w64(adm);
         if (ball == 0) return;
-        const unsigned slice = (unsigned)(ball >> (qi * SUB)) & 0xFFu;
+        const unsigned slice = (unsigned)(ball >> (qi * SUB)) & ((1u << SUB) - 1u);
         if (slice == 0) return;
         const int nh = __popc(slice);
         kept_sorted = false;
@@ -1482,10 +1487,10 @@ __global__ __launch_bounds__(OGC_WAVE, 4) void knn_grid_kernel(int n, int m, int
                     }
                     __builtin_amdgcn_s_waitcnt(0xc07f);
                     __builtin_amdgcn_wave_barrier();
-                    if (!limited && R == R0 && total <= SUB * 16) {
+                    if (!limited && R == R0 && total <= 128) {
                         // plain k-NN, first block: select by sorting instead of insert-and-rescan (later shells admit few
                         // candidates — the kept maximum filters them — and a merge network per shell measured slower)
-                        cnt = knn_first_block<16>(pts, mine, total, qx, qy, qz, sub, k, kept, 0);
+                        cnt = knn_first_block<128 / SUB, SUB>(pts, mine, total, qx, qy, qz, sub, k, kept, 0);
                         __builtin_amdgcn_s_waitcnt(0xc07f);
                         __builtin_amdgcn_wave_barrier();
                         kept_sorted = true;
@@ -2002,11 +2007,28 @@ int launch_knn(const GridLayout &L, void *grid, int mode, int b, int n, int m, i
 #undef OGC_KNN_CELLS
         deferred = 1;
     }
-    if (mode == 1)
-        hipLaunchKernelGGL(knn_grid_kernel<1>, grid8, dim3(OGC_WAVE), lds, s, n, m, k, radius, lim2, stride_cells, deferred, unknown,
+    // sixteen lanes per query (four queries per wavefront) when eight would leave most SIMDs without a wavefront: the launch's time
+    // is then one wavefront's serial work (FlowStep3D at B = 1: 4096 queries = 512 wavefronts of ~48 us; forward 7.45 -> 7.07 ms).
+    // OGC_KNN_LANES=8|16 forces.
+    static const int forced_lanes = [] { const char *e = getenv("OGC_KNN_LANES"); return e ? atoi(e) : 0; }();
+    // (measured, tools/bench_ops.py --ops knn,knnc, 8 -> 16 lanes: 1 x 8192 x 8192, k = 32 0.079 -> 0.056 ms; 16 x 2048 <- 8192, k = 64
+    // 0.264 -> 0.238; 16 x 512 <- 1024, k = 64 0.190 -> 0.116; but 16 x 8192 x 8192 0.240 -> 0.249, and the radius-limited searches,
+    // which keep a handful of candidates, lose from 2048 wavefronts on: 16 x 1024 <- 2048 0.037 -> 0.042)
+    const bool limited = mode == 1 && radius >= 0.0f;
+    const long long waves8 = (long long)b * ogc_divup(n, QPW);
+    const bool wide = forced_lanes == 16 || (forced_lanes != 8 && waves8 <= (limited ? 1024 : 4096));
+    dim3 grid16(ogc_divup(n, OGC_WAVE / 16), b);
+    if (mode == 1 && wide)
+        hipLaunchKernelGGL((knn_grid_kernel<1, 16>), grid16, dim3(OGC_WAVE), lds, s, n, m, k, radius, lim2, stride_cells, deferred, unknown,
+                           hdrs, cell_start, sorted_pts, dist, idx);
+    else if (mode == 1)
+        hipLaunchKernelGGL((knn_grid_kernel<1, 8>), grid8, dim3(OGC_WAVE), lds, s, n, m, k, radius, lim2, stride_cells, deferred, unknown,
+                           hdrs, cell_start, sorted_pts, dist, idx);
+    else if (wide)
+        hipLaunchKernelGGL((knn_grid_kernel<0, 16>), grid16, dim3(OGC_WAVE), lds, s, n, m, k, radius, lim2, stride_cells, 0, unknown,
                            hdrs, cell_start, sorted_pts, dist, idx);
     else
-        hipLaunchKernelGGL(knn_grid_kernel<0>, grid8, dim3(OGC_WAVE), lds, s, n, m, k, radius, lim2, stride_cells, 0, unknown,
+        hipLaunchKernelGGL((knn_grid_kernel<0, 8>), grid8, dim3(OGC_WAVE), lds, s, n, m, k, radius, lim2, stride_cells, 0, unknown,
                            hdrs, cell_start, sorted_pts, dist, idx);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
