@@ -1255,7 +1255,7 @@ __device__ __forceinline__ void knn_sort_keys(u64 (&key)[NK], int sub) {
                 const bool lower = (sub & lx) == 0;
 #pragma unroll
                 for (int t = 0; t < NK; ++t) {
-                    const u64 other = lx == 1 ? knn_xor_lane<1>(key[t]) : (lx == 2 ? knn_xor_lane<2>(key[t]) : (lx == 4 ? knn_xor_lane<4>(key[t]) : knn_xor_lane<8>(key[t])));
+                    const u64 other = lx == 1 ? knn_xor_lane<1>(key[t]) : (lx == 2 ? knn_xor_lane<2>(key[t]) : (lx == 4 ? knn_xor_lane<4>(key[t]) : (lx == 8 ? knn_xor_lane<8>(key[t]) : knn_xor_lane<16>(key[t]))));
                     const bool up = ((sub * NK + t) & size) == 0;
                     const bool take = (up == lower) ? other < key[t] : other > key[t];
                     key[t] = take ? other : key[t];
@@ -1305,7 +1305,8 @@ __device__ __forceinline__ int knn_first_block(const float4 *__restrict__ pts, c
     valid += __builtin_amdgcn_ds_swizzle(valid, (1 << 10) | 0x1F);
     valid += __builtin_amdgcn_ds_swizzle(valid, (2 << 10) | 0x1F);
     valid += __builtin_amdgcn_ds_swizzle(valid, (4 << 10) | 0x1F);
-    if constexpr (SUBT == 16) valid += __builtin_amdgcn_ds_swizzle(valid, (8 << 10) | 0x1F);
+    if constexpr (SUBT >= 16) valid += __builtin_amdgcn_ds_swizzle(valid, (8 << 10) | 0x1F);
+    if constexpr (SUBT == 32) valid += __builtin_amdgcn_ds_swizzle(valid, (16 << 10) | 0x1F);
     knn_sort_keys<NK, SUBT>(key, sub);
     const int keep = min(valid, k);
 #pragma unroll
@@ -1394,7 +1395,7 @@ __global__ __launch_bounds__(OGC_WAVE, 4) void knn_grid_kernel(int n, int m, int
         }
         const u64 ball = __builtin_amdgcn_ballot_w64(adm);
         if (ball == 0) return;
-        const unsigned slice = (unsigned)(ball >> (qi * SUB)) & ((1u << SUB) - 1u);
+        const unsigned slice = (unsigned)(ball >> (qi * SUB)) & (SUB == 32 ? 0xFFFFFFFFu : ((1u << (SUB & 31)) - 1u));
         if (slice == 0) return;
         const int nh = __popc(slice);
         kept_sorted = false;
@@ -2017,8 +2018,16 @@ int launch_knn(const GridLayout &L, void *grid, int mode, int b, int n, int m, i
     const bool limited = mode == 1 && radius >= 0.0f;
     const long long waves8 = (long long)b * ogc_divup(n, QPW);
     const bool wide = forced_lanes == 16 || (forced_lanes != 8 && waves8 <= (limited ? 1024 : 4096));
-    dim3 grid16(ogc_divup(n, OGC_WAVE / 16), b);
-    if (mode == 1 && wide)
+    dim3 grid16(ogc_divup(n, OGC_WAVE / 16), b), grid32(ogc_divup(n, OGC_WAVE / 32), b);
+    // ... and thirty-two (two queries per wavefront) for the smallest launches (FlowStep3D's 2048-point levels at B = 1)
+    const bool wider = forced_lanes == 32 || (forced_lanes == 0 && waves8 <= (limited ? 256 : 1024)); // (1 x 8192 x 8192: 0.056 -> 0.050 ms)
+    if (mode == 1 && wider)
+        hipLaunchKernelGGL((knn_grid_kernel<1, 32>), grid32, dim3(OGC_WAVE), lds, s, n, m, k, radius, lim2, stride_cells, deferred, unknown,
+                           hdrs, cell_start, sorted_pts, dist, idx);
+    else if (wider)
+        hipLaunchKernelGGL((knn_grid_kernel<0, 32>), grid32, dim3(OGC_WAVE), lds, s, n, m, k, radius, lim2, stride_cells, 0, unknown,
+                           hdrs, cell_start, sorted_pts, dist, idx);
+    else if (mode == 1 && wide)
         hipLaunchKernelGGL((knn_grid_kernel<1, 16>), grid16, dim3(OGC_WAVE), lds, s, n, m, k, radius, lim2, stride_cells, deferred, unknown,
                            hdrs, cell_start, sorted_pts, dist, idx);
     else if (mode == 1)
