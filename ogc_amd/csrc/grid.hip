@@ -2082,11 +2082,20 @@ int ogc_knn_grid(int mode, int b, int n, int m, int k, float radius, const float
     // 1.01 r when balls are sparsely filled
     const bool cells = knn_cells_applies(mode, n, m, k, radius, unknown == known);
     // points per cell = k / knn_div (OGC_KNN_DIV in the environment: A/B runs)
-    // 33.5 = cell edge of half the expected k-th neighbour distance; measured (tools/bench_ops.py --ops knn, 16 x 8192 x 8192): k = 32
-    // 0.240 ms at 33.5, 0.221 at 28, 0.210 at 24 (but 8 x 16384 x 16384 0.257 / 0.260 / 0.315); k = 64 on 16 x 2048 <- 8192 0.239 at
-    // 33.5, 0.203 at 40, 0.327 at 28 — the first block's 128-key sort wants ~120 candidates in 125 cells whatever k is
+    // 33.5 = cell edge of half the expected k-th neighbour distance.  The first block's 128-key sort wants ~120 candidates in its 125
+    // cells; where the cloud is denser than its bounding box suggests (scenes: ground, objects) a block holds more and the query falls
+    // back to insertion, so full launches on scene-like clouds want SMALLER cells, while a launch that leaves the chip under-filled
+    // (one wavefront's latency) wants fewer, fuller cells.  Measured (ms; uniform slab / synthetic scene, 16 x 8192 x 8192):
+    //   k = 32: div 28 0.219 / 0.374, 33.5 0.240 / 0.305, 40 0.263 / 0.279;  k = 64: 33.5 - / 1.234, 40 - / 1.026, 48 - / 0.872
+    //   (16 x 2048 <- 8192, k = 64: 33.5 0.239 / 0.453, 48 0.205 / 0.346);  1 x 8192 x 8192, k = 32: 28 0.044 / 0.043, 33.5 0.050 / 0.050
     static const float forced_div = [] { const char *e = getenv("OGC_KNN_DIV"); const float v = e ? (float)atof(e) : 0.0f; return v > 1.0f ? v : 0.0f; }();
-    const float knn_div = forced_div > 0.0f ? forced_div : (k >= 56 && m >= 4096 ? 40.0f : (k >= 24 && k <= 40 ? 28.0f : 33.5f)); // (k = 64 in 2048 points: 0.152 ms at 33.5, 0.166 at 40)
+    const bool small_launch = (long long)b * ogc_divup(n, QPW) <= 1024;
+    float knn_div = 33.5f;
+    if (forced_div > 0.0f) knn_div = forced_div;
+    else if (small_launch) knn_div = (k >= 24 && k <= 40) ? 28.0f : 33.5f;
+    else if (k >= 56) knn_div = m >= 4096 ? 48.0f : 33.5f;
+    // (k = 24..40 on full launches stays at 33.5: 40 trades 0.305 -> 0.281 on scenes for 0.240 -> 0.264 on uniform clouds and 0.257 -> 0.309
+    // at 8 x 16384 x 16384)
     launch_grid_build(b, m, mode == 1 ? radius : 0.0f, k, STRIDE_CELLS, known, L.hdrs(ws), L.cell_start(ws), L.sorted_pts(ws), s,
                       cells ? 1 : 0, knn_div);
     return launch_knn(L, ws, mode, b, n, m, k, radius, cells, unknown, dist, idx, s);
