@@ -39,7 +39,11 @@ enum {
     OGC_ERR_UNSUPPORTED = -3  /* shape outside what the kernels handle */
 };
 
-/* Library version (major*10000 + minor*100 + patch) and last error text (thread-local). */
+/* Library version (major*10000 + minor*100 + patch) and last error text (thread-local).  OGC_VERSION is the version of THIS
+ * header; a caller checks ogc_version() == OGC_VERSION before anything else (ogc_amd/_lib.py does): the minor number moves with
+ * every change of an existing prototype.  0.2.0: ogc_adam_step takes its five hyper-parameters as double (float before), new
+ * entry points ogc_zero_arena_begin / _end, ogc_conv1x1_gemm_any, ogc_conv1x1_wgrad_affine_pooled, ogc_conv1x1_dgrad_pooled. */
+#define OGC_VERSION 200
 int ogc_version(void);
 const char *ogc_last_error(void);
 

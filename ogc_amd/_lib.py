@@ -115,6 +115,7 @@ SIGNATURES = {
                                    _vp, _vp],
 }
 
+HEADER_VERSION = 200   # OGC_VERSION of include/ogc_ops.h the SIGNATURES table above was written against
 _lib = None
 _fns = {}  # entry point name -> bound ctypes function
 
@@ -137,6 +138,9 @@ def load():
             fn.argtypes = argtypes
             fn.restype = _int
         L.ogc_version.restype = _int
+        if L.ogc_version() != HEADER_VERSION:
+            raise OgcOpsError("libogc_ops.so at %s is version %d, this package binds version %d of include/ogc_ops.h — rebuild it "
+                              "with `python ogc_amd/csrc/build.py --force`" % (LIB_PATH, L.ogc_version(), HEADER_VERSION))
         L.ogc_slot_masks_ws_floats.restype = ctypes.c_longlong
         L.ogc_cell_grid_bytes.restype = ctypes.c_longlong
         L.ogc_last_error.restype = ctypes.c_char_p

@@ -91,6 +91,6 @@ extern "C" int ogc_zero_arena_end(void) {
     return OGC_OK;
 }
 
-extern "C" int ogc_version(void) { return 100; /* 0.1.0 */ }
+extern "C" int ogc_version(void) { return OGC_VERSION; }
 
 extern "C" const char *ogc_last_error(void) { return g_err; }

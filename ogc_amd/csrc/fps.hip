@@ -19,6 +19,8 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "ogc_common.h"
 
 namespace {
@@ -843,6 +845,23 @@ int fps_ref_block_shift(int work_size) {
     return pow_2;
 }
 
+// Raises a kernel's dynamic-LDS cap (needed above 64 KiB), once per process and kernel; false when the runtime refuses — the
+// caller then launches a variant that needs less.
+static bool fps_allow_lds(const void *kernel, size_t lds) {
+    if (lds <= 64 * 1024) return true;
+    struct Entry { const void *kernel; size_t lds; bool ok; };
+    static Entry table[32];
+    static int used = 0;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    for (int i = 0; i < used; ++i)
+        if (table[i].kernel == kernel && table[i].lds >= lds) return table[i].ok;
+    const bool ok = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+    if (!ok) (void)hipGetLastError(); // (the refusal is handled: it must not be reported by the next launch check)
+    if (used < 32) table[used++] = Entry{kernel, lds, ok};
+    return ok;
+}
+
 template <int PTS, int THREADS>
 void fps_launch(int b, int n, int m, int shift, const float *xyz, float *temp, int *idx, const int *ties_in,
                 int *ties_out, hipStream_t stream) {
@@ -850,13 +869,11 @@ void fps_launch(int b, int n, int m, int shift, const float *xyz, float *temp, i
     constexpr bool lds_xyz = slots <= FPS_LDS_XYZ_MAX;
     constexpr size_t lds = 8 * sizeof(float) + (lds_xyz ? 3 * slots * sizeof(float) : 0);
     auto kern = fps_reg_kernel<PTS, THREADS, lds_xyz>;
-    if (lds > 64 * 1024) {
-        static bool once = false; // raise the dynamic-LDS cap once per process for this instantiation
-        if (!once) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            once = true;
-        }
+    if (!fps_allow_lds(reinterpret_cast<const void *>(kern), lds)) {
+        // no room for the rank-ordered copy of the cloud in LDS: the same rounds reading the winner's coordinates from memory
+        hipLaunchKernelGGL((fps_reg_kernel<PTS, THREADS, false>), dim3(b), dim3(THREADS), 8 * sizeof(float), stream, n, m, shift, xyz,
+                           temp, idx, ties_in, ties_out);
+        return;
     }
     hipLaunchKernelGGL(kern, dim3(b), dim3(THREADS), lds, stream, n, m, shift, xyz, temp, idx, ties_in, ties_out);
 }
@@ -889,18 +906,15 @@ static int fps_impl(const char *name, int b, int n, int m, const float *xyz, flo
         static const char *bk = getenv("OGC_FPS_BUCKETS");
         const int mode = bk ? atoi(bk) : (b <= 4 ? 16 : 8);
         const size_t lds = (4 + 128 + 3 * FPSB_SLOTS) * sizeof(float);
-        if (mode > 0 && m >= 256) {
+        const void *bucket_kernel = mode == 16 ? reinterpret_cast<const void *>(fps_bucket_kernel<16>)
+                                  : mode == 8  ? reinterpret_cast<const void *>(fps_bucket_kernel<8>)
+                                               : reinterpret_cast<const void *>(fps_bucket_kernel<4>);
+        if (mode > 0 && m >= 256 && fps_allow_lds(bucket_kernel, lds)) {
             if (mode == 16) {
-                static bool once16 = false;
-                if (!once16) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fps_bucket_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once16 = true; }
                 hipLaunchKernelGGL(fps_bucket_kernel<16>, dim3(b), dim3(1024), lds, s, n, m, shift, xyz, temp, idx, ties_in, ties_out);
             } else if (mode == 8) {
-                static bool once8 = false;
-                if (!once8) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fps_bucket_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once8 = true; }
                 hipLaunchKernelGGL(fps_bucket_kernel<8>, dim3(b), dim3(512), lds, s, n, m, shift, xyz, temp, idx, ties_in, ties_out);
             } else {
-                static bool once4 = false;
-                if (!once4) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fps_bucket_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once4 = true; }
                 hipLaunchKernelGGL(fps_bucket_kernel<4>, dim3(b), dim3(256), lds, s, n, m, shift, xyz, temp, idx, ties_in, ties_out);
             }
         } else
@@ -913,14 +927,13 @@ static int fps_impl(const char *name, int b, int n, int m, const float *xyz, flo
         typedef FpsBuckets<128> Cfg;
         const size_t lds = (4 + 128) * sizeof(float) + (128 + 2 * 16) * sizeof(float4) +
                            (1 << Cfg::KEYBITS) * sizeof(int) + Cfg::SLOTS * sizeof(unsigned short);
-        if (mode > 0 && m >= 256) {
-            static bool once = false;
+        const void *bucket_kernel = mode == 16 ? reinterpret_cast<const void *>(fps_bucket_kernel<16, 128>)
+                                               : reinterpret_cast<const void *>(fps_bucket_kernel<8, 128>);
+        // (the runtime refusing the > 64 KiB LDS these need: the plain rounds, fps_launch<32, 512>)
+        if (mode > 0 && m >= 256 && fps_allow_lds(bucket_kernel, lds)) {
             if (mode == 16) {
-                static bool once16 = false;
-                if (!once16) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fps_bucket_kernel<16, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once16 = true; }
                 hipLaunchKernelGGL((fps_bucket_kernel<16, 128>), dim3(b), dim3(1024), lds, s, n, m, shift, xyz, temp, idx, ties_in, ties_out);
             } else {
-                if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fps_bucket_kernel<8, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; }
                 hipLaunchKernelGGL((fps_bucket_kernel<8, 128>), dim3(b), dim3(512), lds, s, n, m, shift, xyz, temp, idx, ties_in, ties_out);
             }
         } else

@@ -63,7 +63,7 @@ __global__ __launch_bounds__(GC_WAVES *OGC_WAVE, 2) void gemm_chunk_kernel(int M
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[a][c] = (v4f){0.f, 0.f, 0.f, 0.f};
 
-    // ---- loads of a chunk: A elements (zeros beyond the matrix), IN rows (clamped onto the last row: its weights are zeros)
+    // ---- loads of a chunk: A elements (zeros beyond the matrix), IN rows (clamped onto the last row, zeroed in `rebuild`)
     auto load_a = [&](int k0, float(&av)[PER]) {
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(GC_WAVES *OGC_WAVE, 2) void gemm_chunk_kernel(int M
             }
         }
     };
-    auto rebuild = [&](float4(&xv)[KQ], const float2(&cc)[NP], const float2(&jv)[NP]) {
+    auto rebuild = [&](int k0, float4(&xv)[KQ], const float2(&cc)[NP], const float2(&jv)[NP]) {
         if constexpr (POOLED) {
 #pragma unroll
             for (int q = 0; q < KQ; ++q) {
@@ -111,6 +111,14 @@ __global__ __launch_bounds__(GC_WAVES *OGC_WAVE, 2) void gemm_chunk_kernel(int M
                 xv[q].z = fmaf(cc[q].x, xv[q].z, cc[q].y) + (rel == 2 ? ag : 0.f);
                 xv[q].w = fmaf(cc[q].x, xv[q].w, cc[q].y) + (rel == 3 ? ag : 0.f);
             }
+        }
+        // the ragged last chunk (K not a multiple of the chunk; wave-uniform test): rows beyond K were read from row K - 1 —
+        // they become zeros here, not "anything times a zero weight": an Inf / NaN in the last real channel must not turn every
+        // output row of its position into NaN (0 * Inf) where the library's product gives what the real terms give
+        if (k0 + KC > K) {
+#pragma unroll
+            for (int q = 0; q < KQ; ++q)
+                if (k0 + 4 * q + kk >= K) xv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     // Every row block is computed: rows beyond M are zeros in LDS, and the entry point picks RB so that few are (16 RB >= the
@@ -142,16 +150,16 @@ __global__ __launch_bounds__(GC_WAVES *OGC_WAVE, 2) void gemm_chunk_kernel(int M
     const bool work = nblk > 0; // (SPLIT_M: a wavefront whose rows all lie beyond M only helps staging)
     if constexpr (KA == 2) {
         // one A chunk (2 KC rows) per iteration: both input register sets are consumed against it, one barrier; input chunks
-        // beyond K are clamped rows against zero weights (no branch around them)
+        // beyond K are zero rows against zero weights (no branch around them)
         const int npairs = (nchunks + 1) / 2;
         for (int p = 0; p < npairs; ++p) {
             const bool more = p + 1 < npairs;
             if (more) load_a((p + 1) * KCA, a_next);
             load_in((2 * p + 1) * KC, x1, c1, j1);
-            rebuild(x0, c0, j0);
+            rebuild(2 * p * KC, x0, c0, j0);
             if (work) compute(buf0, x0, 0);
             if (more) load_in((2 * p + 2) * KC, x0, c0, j0);
-            rebuild(x1, c1, j1);
+            rebuild((2 * p + 1) * KC, x1, c1, j1);
             if (work) compute(buf0, x1, KC);
             if (more) store_a(buf1, a_next);
             __syncthreads();
@@ -165,7 +173,7 @@ __global__ __launch_bounds__(GC_WAVES *OGC_WAVE, 2) void gemm_chunk_kernel(int M
             load_a((i + 1) * KC, a_next);
             load_in((i + 1) * KC, x1, c1, j1);
         }
-        rebuild(x0, c0, j0);
+        rebuild(i * KC, x0, c0, j0);
         if (work) compute(buf0, x0);
         if (more1) store_a(buf1, a_next);
         __syncthreads();
@@ -174,7 +182,7 @@ __global__ __launch_bounds__(GC_WAVES *OGC_WAVE, 2) void gemm_chunk_kernel(int M
             load_a((i + 2) * KC, a_next);
             load_in((i + 2) * KC, x0, c0, j0);
         }
-        rebuild(x1, c1, j1);
+        rebuild((i + 1) * KC, x1, c1, j1);
         if (work) compute(buf1, x1);
         if (more2) store_a(buf0, a_next);
         __syncthreads();

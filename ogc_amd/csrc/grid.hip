@@ -423,19 +423,36 @@ __global__ __launch_bounds__(BUILD_THREADS) void grid_build_split_kernel(float k
         }
     }
     for (int c = t; c < SPLIT_CELLS; c += BUILD_THREADS) s_cnt[c] = 0;
-    // bounding box: minima / maxima of ALL coordinates first (v_min3 / v_max3 ignore NaNs; a point with one NaN coordinate lends
-    // its other two, which only widens the box) — three instructions per point instead of twelve.  An infinite coordinate shows
-    // in the result; then (once, all workgroups of the cloud alike) the box is taken again over the finite points only.
+    // bounding box: minima / maxima of ALL coordinates first (v_min3 / v_max3 ignore NaNs) — three instructions per point
+    // instead of twelve — next to a running sum of the coordinates' magnitudes, which is finite iff every coordinate is (or
+    // overflows: a false alarm).  A point with a non-finite coordinate is in no cell, and must not lend its other coordinates
+    // to the box either (grid_build_kernel takes the box over fully finite points; one stray (NaN, 1e30, 0) would stretch this
+    // one until the grid is a single cell): when the sum is not finite the box is taken again over the finite points only
+    // (once, all workgroups of the cloud alike).
     bool filtered = false;
     for (;;) {
         float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+        bool odd_one = false; // some coordinate of mine is NaN or infinite
         if (!filtered) {
+            float mag0 = 0.0f, mag1 = 0.0f;
 #pragma unroll
             for (int i = 0; i < PPT; i += 2) {
                 mn[0] = ogc_min3_f32(mn[0], px[i], px[i + 1]); mx[0] = ogc_max3_f32(mx[0], px[i], px[i + 1]);
                 mn[1] = ogc_min3_f32(mn[1], py[i], py[i + 1]); mx[1] = ogc_max3_f32(mx[1], py[i], py[i + 1]);
                 mn[2] = ogc_min3_f32(mn[2], pz[i], pz[i + 1]); mx[2] = ogc_max3_f32(mx[2], pz[i], pz[i + 1]);
             }
+            if (n >= PPT * BUILD_THREADS) { // (wave-uniform: every slot of mine is a point of the cloud)
+#pragma unroll
+                for (int i = 0; i < PPT; i += 2) {
+                    mag0 += (fabsf(px[i]) + fabsf(py[i])) + fabsf(pz[i]);
+                    mag1 += (fabsf(px[i + 1]) + fabsf(py[i + 1])) + fabsf(pz[i + 1]);
+                }
+            } else { // slots beyond n hold NaN fillers of the loads above: they must not raise the alarm
+#pragma unroll
+                for (int i = 0; i < PPT; ++i)
+                    if (point_index(i) < n) mag0 += (fabsf(px[i]) + fabsf(py[i])) + fabsf(pz[i]);
+            }
+            odd_one = !(mag0 + mag1 < INFINITY);
         } else {
 #pragma unroll
             for (int i = 0; i < PPT; ++i) {
@@ -446,11 +463,13 @@ __global__ __launch_bounds__(BUILD_THREADS) void grid_build_split_kernel(float k
                 }
             }
         }
+        const bool wave_odd = __builtin_amdgcn_ballot_w64(odd_one) != 0ull;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             const float lo = -ogc_wave_max_f32(-mn[a]), hi = ogc_wave_max_f32(mx[a]);
             if (lane == 0) { s_red[a][wave] = lo; s_red[3 + a][wave] = hi; }
         }
+        if (lane == 0) s_wave[wave] = wave_odd ? 1 : 0; // (s_wave is free until the scan)
         OGC_PROBE_BUILD(1);
         __syncthreads();
         OGC_PROBE_BUILD(2);
@@ -463,12 +482,10 @@ __global__ __launch_bounds__(BUILD_THREADS) void grid_build_split_kernel(float k
                 lo[a] = -ogc_wave_max_f32(-l);
                 hi[a] = ogc_wave_max_f32(u);
             }
+            const bool any_odd = __builtin_amdgcn_ballot_w64(lane < BUILD_THREADS / 64 && s_wave[lane] != 0) != 0ull;
             if (lane == 0) {
-                // (an empty box — no finite coordinate at all — keeps its +inf / -inf and needs no second look)
-                const bool infinite = lo[0] <= hi[0] && !(fabsf(lo[0]) < INFINITY && fabsf(lo[1]) < INFINITY && fabsf(lo[2]) < INFINITY &&
-                                                          fabsf(hi[0]) < INFINITY && fabsf(hi[1]) < INFINITY && fabsf(hi[2]) < INFINITY);
                 s_hdr = grid_header(lo, hi, n, radius, knn_k, knn_div, prefer_cells);
-                s_hdr.pending = (infinite && !filtered) ? 1 : 0; // (borrowed as the "take the box again" flag; 0 when the loop ends)
+                s_hdr.pending = (any_odd && !filtered) ? 1 : 0; // (borrowed as the "take the box again" flag; 0 when the loop ends)
             }
         }
         __syncthreads();

@@ -362,10 +362,11 @@ def _must_surface(err):
     if any(tag in text for tag in ("HIP error", "hipError", "CUDA error", "out of memory", "rocBLAS", "MIOpen")):
         return True
     # What the reference's handler was written for is a decomposition that fails on a degenerate batch (torch.svd / eigh in the
-    # backward pass of the rigid fit: "... failed to converge", "... singular", "... ill-conditioned").  Anything else — a
-    # shape or stride error inside one of this package's autograd Functions, a type error — is a bug, and a silently skipped
-    # step would hide it until MAX_CONSECUTIVE_SKIPS stops the run.
-    if not any(tag in text.lower() for tag in ("converge", "singular", "ill-conditioned", "svd", "eigh", "linalg", "nan", "inf")):
+    # backward pass of the rigid fit).  Those arrive as torch.linalg.LinAlgError (a RuntimeError subclass) or as a RuntimeError
+    # naming the solver routine ("... gesvd ... failed to converge", "hipsolver error ... syevd", "... is singular").  Anything
+    # else — a shape or stride error inside one of this package's autograd Functions, a type error — is a bug, and a silently
+    # skipped step would hide it until MAX_CONSECUTIVE_SKIPS stops the run.
+    if not (isinstance(err, _LINALG_ERRORS) or _SOLVER_WORDS.search(text)):
         return True
     global _first_skip_reported
     if not _first_skip_reported:
@@ -376,6 +377,12 @@ def _must_surface(err):
 
 
 _first_skip_reported = False
+_LINALG_ERRORS = tuple(t for t in (getattr(torch.linalg, "LinAlgError", None), getattr(torch._C, "_LinAlgError", None))
+                       if isinstance(t, type))
+# whole words only ("inf" / "nan" as bare substrings match "info", "inference", "nanoseconds": dropped)
+_SOLVER_WORDS = __import__("re").compile(
+    r"\b(gesvdj?|gesdd|syevd?j?|heevd?|geqrf|getrf|potrf|hipsolver|cusolver|rocsolver|lapack|magma|svd|eigh?|linalg|"
+    r"converge[ds]?|convergence|singular|ill-conditioned)\b", __import__("re").IGNORECASE)
 
 
 def _is_distributed(model):

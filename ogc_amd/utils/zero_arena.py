@@ -2,20 +2,23 @@
 
 ~40 operators of a step accumulate with atomics into small buffers this package allocates for them — GroupNorm statistics,
 weight gradients, moment matrices, counters — and each zeroes its buffer with a launch of its own.  Inside ``with
-zero_arena(device):`` those buffers come from ``zeroed_empty`` instead of ``torch.empty``: slices of one persistent tensor that
-was zeroed by a single launch when the block was entered; the library then skips the operators' own fills (it recognises the
-region).  Outside such a block, on another stream, or when the step needs more than the region zeroed so far (the first step:
-the extent is learnt from the step before), ``zeroed_empty`` is ``torch.empty`` and the operator zeroes it as before.
+zero_arena(device):`` those buffers come from ``zeroed_empty`` instead of ``torch.empty``: slices of ONE tensor that was
+allocated and zeroed by a single launch when the block was entered; the library then skips the operators' own fills (it
+recognises the region).  Outside such a block, on another stream, or when the step needs more than the region zeroed so far
+(the first step: the extent is learnt from the step before), ``zeroed_empty`` is ``torch.empty`` and the operator zeroes it as
+before.
 
-A slice lives until the NEXT ``with`` block of the same device is entered (the region is then zeroed again), i.e. for the rest
-of the training step that allocated it — long enough for statistics saved for the backward pass and for gradients on their way
-into ``param.grad`` / the optimizer of that step; nothing that outlives a step may be allocated here.
+The region is a FRESH allocation per step (normally the caching allocator hands the same block back: no cost).  A slice is an
+ordinary view of it, so a tensor that escapes the step — a weight gradient autograd keeps as ``param.grad``, a statistic saved
+by somebody — keeps its step's region alive and is never zeroed or handed out again: gradients may be held or accumulated
+across steps exactly as with ``torch.empty`` (tests/test_zero_arena_gpu.py).  The library's side of the contract is per step:
+every byte of the region goes to at most one operator between ``begin`` and ``end`` (the bump pointer below).
 """
 import torch
 
 from .. import _lib
 
-CAPACITY = 64 << 20      # bytes of the persistent region per device
+CAPACITY = 64 << 20      # largest region of a step, bytes
 LARGEST = 4 << 20        # larger requests are not worth a place in it (their fill is bandwidth, not launch latency)
 import os as _os
 ENABLED = _os.environ.get("OGC_ZERO_ARENA", "1") != "0"   # (0: every operator fills its own buffers — A/B runs)
@@ -29,7 +32,7 @@ _active = None
 class _Arena:
     def __init__(self, device):
         self.device = device
-        self.buf = torch.empty(CAPACITY, dtype=torch.uint8, device=device)
+        self.buf = None      # this step's region (a new tensor per step: escaped slices keep the old one alive)
         self.filled = 0      # bytes zeroed by this step's fill
         self.used = 0        # bump pointer
         self.want = 0        # extent the last step asked for (what the next fill covers)
@@ -39,7 +42,10 @@ class _Arena:
         self.stream = torch.cuda.current_stream(self.device).cuda_stream
         self.filled = min((self.want + 255) // 256 * 256, CAPACITY)
         self.used = self.want = 0
-        _lib.call("ogc_zero_arena_begin", self.buf.data_ptr(), self.filled, self.stream)
+        self.buf = None      # (first: the allocator may hand the same block back when nothing of the last step escaped)
+        if self.filled:
+            self.buf = torch.empty(self.filled, dtype=torch.uint8, device=self.device)
+        _lib.call("ogc_zero_arena_begin", self.buf.data_ptr() if self.filled else 0, self.filled, self.stream)
 
     def take(self, shape, dtype):
         n = 1

@@ -32,6 +32,10 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), "libogc_ops.so does not export %s" % name
     lib.ogc_version.restype = ctypes.c_int
     assert lib.ogc_version() >= 100
+    header = open(os.path.join(ROOT, "include", "ogc_ops.h")).read()
+    import re
+    from ogc_amd import _lib
+    assert lib.ogc_version() == int(re.search(r"#define OGC_VERSION (\d+)", header).group(1)) == _lib.HEADER_VERSION
 
 
 def test_python_binding_covers_every_entry_point():

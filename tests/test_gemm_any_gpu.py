@@ -58,3 +58,28 @@ def test_pointwise_conv_routes_match_the_library():
         for a, b in zip(*res):
             scale = float(b.abs().max())
             assert float((a - b).abs().max()) <= 2e-5 * scale, (cin, cout, n, float((a - b).abs().max()), scale)
+
+
+@pytest.mark.parametrize("B,M,K,hw", [(2, 40, 67, 256), (4, 100, 131, 65536), (2, 130, 259, 4096), (4, 16, 9, 65536)])
+def test_ragged_reduction_does_not_spread_non_finite_values(B, M, K, hw):
+    """K not a multiple of the chunk: the kernel reads the rows beyond K from row K - 1.  They must count as ZEROS, not as
+    "row K - 1 times a zero weight": an Inf in the last real channel gives Inf (not Inf + 0 * Inf = NaN) in the output rows
+    that use the channel, as in any IEEE product of the real terms."""
+    from ogc_amd import pointnet2_cuda as nat
+    g = torch.Generator(device="cuda").manual_seed(K)
+    w = torch.randn(M, K, device="cuda", generator=g)
+    w[::2, K - 1] = 0.0                                  # every other output row ignores the last channel
+    x = torch.randn(B, K, hw, device="cuda", generator=g)
+    x[:, K - 1, 5] = float("inf")
+    x[:, K - 1, 70] = float("nan")
+    for transpose in (0, 1):
+        a = w.t().contiguous() if transpose else w
+        out = torch.zeros(B, M, hw, device="cuda")
+        nat.conv1x1_gemm_any_wrapper(B, M, K, hw, transpose, a, x, out)
+        # (rows that ignore the channel hold 0 * Inf = NaN at that position in any product: not checked)
+        ref = torch.matmul(w, x)
+        clean = torch.ones(hw, dtype=torch.bool, device="cuda")
+        clean[5] = clean[70] = False
+        assert bool(torch.isfinite(out[:, :, clean]).all())
+        torch.testing.assert_close(out[:, :, clean], ref[:, :, clean], rtol=1e-4, atol=1e-4)
+        assert bool(torch.isinf(out[:, 1::2, 5]).all()) and bool(torch.isnan(out[:, 1::2, 70]).all())

@@ -1,6 +1,8 @@
 """GPU parity tests: the HIP kernels (called through the C ABI via ogc_amd.pointnet2_cuda) against the
 CPU oracle on the same seeded inputs.  Integer indices must be bit-exact; forward floats bit-exact
 (same fp32 rounding sequence); scatter-add gradients within 1e-5 relative (atomic order differs)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -1215,3 +1217,52 @@ def test_conv1x1_gemm_affine_streaming_kernel(nat, B, cin, cout, hw, relu):
     scale = torch.einsum("oi,bip->bop", w.double().abs(), z.abs())
     assert ((y.double() - ref).abs() / scale.clamp_min(1e-30)).max().item() < 2e-6
     assert torch.isfinite(y).all()
+
+
+_HDR_DUMP = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+import ogc_amd
+from ogc_amd import pointnet2_cuda as nat
+pc = torch.from_numpy(np.load(sys.argv[1])).cuda()
+grid = nat.CellGrid(pc, float(sys.argv[2]))
+torch.cuda.synchronize()
+hdr = grid.buf[:56 * pc.shape[0]].cpu().numpy().view(np.int32).reshape(pc.shape[0], 14)   # sizeof(GridHdr) = 56
+np.save(sys.argv[3], hdr)
+idx = torch.zeros(pc.shape[0], pc.shape[1], 32, dtype=torch.int32, device="cuda")
+grid.ball_query(float(sys.argv[2]), 32, idx)
+np.save(sys.argv[3] + ".idx.npy", idx.cpu().numpy())
+"""
+
+
+def test_split_and_single_workgroup_builds_agree_on_non_finite_points(tmp_path, oracle):
+    """grid_build_split_kernel (8 workgroups per cloud) against grid_build_kernel (one; OGC_GRID_SPLIT=0): the same header —
+    origin, edge, cell counts, flags — for clouds with NaN / infinite coordinates.  A point with ONE non-finite coordinate is in
+    no cell and lends nothing to the bounding box in either build: (NaN, 1e30, 0) used to stretch the split build's box until
+    the grid was a single cell (exact results, but every query a full scan)."""
+    import subprocess
+    import sys
+    rng = np.random.default_rng(5)
+    pc = cloud(rng, 3, 4096, scale=(30, 4, 40))
+    pc[0, 17] = (np.nan, 1e30, 0.0)
+    pc[0, 900] = (5.0, np.nan, -1e30)
+    pc[1, 3] = (np.inf, 0.0, 0.0)
+    pc[1, 4] = (0.0, -np.inf, np.nan)
+    # (cloud 2: all finite)
+    np.save(tmp_path / "pc.npy", pc)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "dump.py"
+    script.write_text(_HDR_DUMP % root)
+    hdrs, rows = {}, {}
+    for split in ("0", "8"):
+        env = dict(os.environ, OGC_GRID_SPLIT=split)
+        out = str(tmp_path / ("hdr%s.npy" % split))
+        subprocess.run([sys.executable, str(script), str(tmp_path / "pc.npy"), "1.5", out], check=True, env=env, timeout=300)
+        hdrs[split], rows[split] = np.load(out), np.load(out + ".idx.npy")
+    # GridHdr: 14 words (minx, miny, minz, inv_h, gx, gy, gz, npts, dense, heavy, knn_general, pending, fast, slab)
+    assert np.array_equal(hdrs["0"][:, :14], hdrs["8"][:, :14]), (hdrs["0"][:, :14], hdrs["8"][:, :14])
+    g = hdrs["8"][:, 4:7]
+    assert (g.prod(axis=1) > 100).all(), g             # a real grid, not one cell
+    assert list(hdrs["8"][:, 7]) == [4094, 4094, 4096]  # npts: the fully finite points
+    want = oracle.ball_query(1.5, 32, pc, pc)
+    assert np.array_equal(rows["0"], want) and np.array_equal(rows["8"], want)

@@ -245,3 +245,28 @@ def test_device_only_shortcuts_stay_out_of_the_way_on_cpu():
     x = torch.randn(4, 3, requires_grad=True)
     assert not subgraph.allowed(lin.train(), x)
     assert torch.equal(subgraph.run(lin, "lin", lambda t: lin(t), (x,)), lin(x))
+
+
+def test_backward_errors_are_classified_by_type_and_solver_name():
+    """The reference skips a step on ANY RuntimeError of backward() (train_seg.py:75-78); here only the numerical accidents
+    that handler exists for are skipped — a failed decomposition — and they are recognised by exception type or by the
+    solver's name as a whole word, not by substrings such as "inf" (which matches "info") or "nan"."""
+    import warnings
+
+    import torch
+
+    from ogc_amd import train_step as ts
+    from ogc_amd._lib import OgcOpsError
+    skipped = ["linalg.svd: The algorithm failed to converge because the input matrix is ill-conditioned",
+               "hipsolver error: HIPSOLVER_STATUS_INTERNAL_ERROR, when calling `hipsolverDnSsyevd(...)`",
+               "cusolver error: CUSOLVER_STATUS_EXECUTION_FAILED", "torch.linalg.eigh: the matrix is singular"]
+    surfaced = ["some info about an inference shape mismatch", "The size of tensor a (3) must match the size of tensor b (4)",
+                "nanoseconds elapsed", "HIP error: invalid device function", "HIP out of memory"]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for text in skipped:
+            assert ts._must_surface(RuntimeError(text)) is False, text
+        for text in surfaced:
+            assert ts._must_surface(RuntimeError(text)) is True, text
+        assert ts._must_surface(torch.linalg.LinAlgError("whatever it says")) is False
+        assert ts._must_surface(OgcOpsError("ogc_knn failed")) is True
