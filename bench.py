@@ -29,29 +29,87 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak (MI355X_MICROARCH.md)
 FP32_MFMA_PEAK_TF = 157.3  # v_mfma_f32_16x16x4_f32 / 32x32x2_f32: the fp32 matrix rate = the fp32 vector rate (same guide)
-# Numbers NOT measured by this run: PMC counter readings of earlier profiling passes, kept with the file they came from.
-# (rocprofv3 --pmc cannot run inside the timed region; `roofline.traffic` is the one field the contract asks for.)
-OFFLINE = {
-    "ball_query_traffic_bytes": {"shape": [16, 8192, 8192, 64], "bytes": int((9189.0 + 880.0 + 35136.0 + 2199.8) * 1024),
-                                 "source": "profiles/r04_ball_query_pmc.txt (FETCH_SIZE + WRITE_SIZE of grid_build_split_kernel<8> + "
-                                           "ball_query_cells_kernel<64, 1>, separate rocprofv3 --pmc passes; FETCH_SIZE as reported — "
-                                           "these kernels issue 12-16 byte gathers, not the wide streams the x2 gfx950 "
-                                           "correction applies to)"},
-    "ball_query_kernels_us": {"ball_query_cells_kernel<64, 1>": 16.74, "grid_build_split_kernel<8>": 12.55,
-                              "query_plus_half_build_frac_of_hbm_peak": round(36700160 / ((16.74 + 12.55 / 2) * 1e-6) / 8e12, 4),
-                              "round_3": {"ball_query_cells_kernel<64>": 21.54, "grid_build_kernel<8>": 15.50},
-                              "source": "profiles/r04_ball_query_pmc.txt (rocprofv3 --kernel-trace --stats, idle GPU)"},
-    "ball_query_valu_issue": {"kernel": "ball_query_cells_kernel<64, 1>", "wave_insts_valu": 6.27e6, "kernel_us": 16.74,
-                              "peak_ginst_s": 1228.8, "frac_of_issue_peak": round(6.27e6 / 16.74e-6 / 1228.8e9, 3),
-                              "note": "peak = 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU on a SIMD (one wavefront alone "
-                                      "issues every 4)",
-                              "round_3": {"wave_insts_valu": 8.58e6, "kernel_us": 21.54},
-                              "source": "profiles/r04_ball_query_pmc.txt"},
-    "knn_clamped_valu_issue": {"kernel": "knn_cells_kernel<32> + knn_grid_kernel<1> (deferred)", "source": "profiles/r04_knn_clamped_pmc.txt"},
-    "step_traffic_mib": {"fetch_reported": 12663.4, "write": 9538.0,
-                         "source": "profiles/r04_step_hbm_traffic.txt (per-kernel FETCH_SIZE / WRITE_SIZE table of one round-4 C4 step, "
-                                   "mean of whole timed steps; the estimate doubles the reported fetch: MI355X_MICROARCH.md)"},
-}
+# Numbers NOT measured by this run: PMC counter readings of earlier profiling passes (rocprofv3 --pmc cannot run inside the
+# timed region; `roofline.traffic` is the one such field the contract asks for).  They are READ from the tracked files under
+# profiles/ that hold them — the newest round's — when the line is printed: every number under `offline` is a line of the file
+# its `source` names, or absent (with the reason) when that file is missing or does not parse.
+def _newest_profile(stem):
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_%s.txt" % stem)))
+    return files[-1] if files else None
+
+
+def _parse_op_pmc(path):
+    """tools/pmc_op2.sh output: '<kernel[:40]> calls N avg X us min .. max ..' lines and '<kernel[:40]> COUNTER v1 v2 ..' lines
+    (one value per profiled launch).  -> {kernel: {"avg_us": x, COUNTER: median, ...}}"""
+    import re
+    out = {}
+    for line in open(path):
+        m = re.match(r"^(.{1,60}?)\s+calls\s+(\d+)\s+avg\s+([0-9.]+)\s+us", line)
+        if m:
+            out.setdefault(m.group(1).strip()[:40], {})["avg_us"] = float(m.group(3))   # (the counter lines carry 40 characters)
+            continue
+        m = re.match(r"^(.{1,42}?)\s+([A-Z][A-Z0-9_a-z]+)\s+((?:[-+0-9.e]+\s*)+)$", line)
+        if m:
+            vals = sorted(float(v) for v in m.group(3).split())
+            out.setdefault(m.group(1).strip()[:40], {})[m.group(2)] = vals[len(vals) // 2]
+    return out
+
+
+def _kernel(table, *parts):
+    for name, row in table.items():
+        if all(p in name for p in parts):
+            return name, row
+    raise KeyError("no kernel matching %r" % (parts,))
+
+
+def load_offline():
+    off = {}
+    rel = lambda p: os.path.relpath(p, ROOT)  # noqa: E731
+    path = _newest_profile("ball_query_pmc")
+    try:
+        if path is None:
+            raise FileNotFoundError("profiles/rNN_ball_query_pmc.txt")
+        t = _parse_op_pmc(path)
+        qn, q = _kernel(t, "ball_query_cells_kernel")
+        bn, b = _kernel(t, "grid_build")
+        kib = q["FETCH_SIZE"] + q["WRITE_SIZE"] + b["FETCH_SIZE"] + b["WRITE_SIZE"]
+        alg = 16 * (12 * 8192 + 12 * 8192 + 4 * 8192 * 64)
+        off["ball_query_traffic_bytes"] = {
+            "shape": [16, 8192, 8192, 64], "bytes": int(kib * 1024),
+            "source": "%s (median FETCH_SIZE + WRITE_SIZE of %s + %s over the profiled launches, separate rocprofv3 --pmc passes; "
+                      "FETCH_SIZE as reported — these kernels issue 12-16 byte gathers, not the wide streams the x2 gfx950 correction "
+                      "applies to)" % (rel(path), bn, qn)}
+        off["ball_query_kernels_us"] = {
+            qn: q["avg_us"], bn: b["avg_us"],
+            "query_plus_half_build_frac_of_hbm_peak": round(alg / ((q["avg_us"] + b["avg_us"] / 2) * 1e-6) / (HBM_PEAK_GBS * 1e9), 4),
+            "query_alone_frac_of_hbm_peak": round(alg / (q["avg_us"] * 1e-6) / (HBM_PEAK_GBS * 1e9), 4),
+            "source": "%s (rocprofv3 --kernel-trace, idle GPU, 16 x 8192 points, r = 2, 64 samples)" % rel(path)}
+        if "SQ_INSTS_VALU" in q:
+            peak = 256 * 4 * 2.4e9 / 2 / 1e9
+            off["ball_query_valu_issue"] = {
+                "kernel": qn, "wave_insts_valu": q["SQ_INSTS_VALU"], "kernel_us": q["avg_us"], "peak_ginst_s": peak,
+                "frac_of_issue_peak": round(q["SQ_INSTS_VALU"] / (q["avg_us"] * 1e-6) / (peak * 1e9), 3),
+                "lds_bank_conflict_share": (round(q["SQ_LDS_BANK_CONFLICT"] / q["SQ_LDS_IDX_ACTIVE"], 3)
+                                            if q.get("SQ_LDS_IDX_ACTIVE") else None),
+                "note": "peak = 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU on a SIMD (one wavefront alone issues every 4)",
+                "source": rel(path)}
+    except Exception as err:  # noqa: BLE001
+        off["ball_query_traffic_bytes"] = {"bytes": None, "shape": None, "source": rel(path) if path else None,
+                                           "error": "%s: %s" % (type(err).__name__, str(err)[:160])}
+    path = _newest_profile("step_hbm_traffic")
+    try:
+        if path is None:
+            raise FileNotFoundError("profiles/rNN_step_hbm_traffic.txt")
+        row = [ln for ln in open(path) if ln.startswith("ALL KERNELS")][-1].split()
+        off["step_traffic_mib"] = {
+            "fetch_reported": float(row[-2]), "write": float(row[-1]),
+            "source": "%s (per-kernel FETCH_SIZE / WRITE_SIZE table of one C4 step, mean of whole timed steps; the estimate doubles "
+                      "the reported fetch: MI355X_MICROARCH.md)" % rel(path)}
+    except Exception as err:  # noqa: BLE001
+        off["step_traffic_mib"] = {"fetch_reported": None, "write": None, "source": rel(path) if path else None,
+                                   "error": "%s: %s" % (type(err).__name__, str(err)[:160])}
+    return off
 
 
 def parse():
@@ -62,6 +120,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=4, help="samples per GPU (config batch_size: 4)")
     ap.add_argument("--npoint", type=int, default=8192)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--timed-only", action="store_true",
+                    help="print the line after the timed steps: no extras (graph replay, operator tables, copies), no CPU baseline — "
+                         "what the rocprofv3 --pmc passes of tools/pmc_step.sh run")
     return ap.parse_args()
 
 
@@ -426,7 +487,9 @@ def main():
     elapsed = float(t.item())
 
     isolated_ms, extras, pair_floor_ms = None, {}, 0.0
-    if rank == 0:
+    if a.timed_only:
+        a.no_cpu_baseline = True
+    if rank == 0 and not a.timed_only:
         def graph_reading():
             # the same step replayed as ONE HIP graph (ogc_amd/graph_step.py; `--hip-graph` of the training driver): what a step
             # costs when the launch thread is out of the picture.  A second network / optimizer (the capture needs step counts
@@ -494,6 +557,7 @@ def main():
             graph_reading()
         extras.update(graph_extras)
     if rank == 0:
+        offline = load_offline()
         durs = timer.durations_ms()
         # In the step the ball query runs on the cell grid it shares with the loss's k-NN (ogc_cell_grid_build once per step for
         # both searches, ogc_ball_query_cells / ogc_knn_clamped_cells on it): the operator's time is its query launch plus its
@@ -518,8 +582,9 @@ def main():
                               "ogc_ball_query (grid_build_split_kernel<8> + ball_query_cells_kernel<64, 1>)",
                     "bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(gbs / HBM_PEAK_GBS, 5),
-                    "traffic": (OFFLINE["ball_query_traffic_bytes"]["bytes"]
-                                if [b_, n_, m_, ns_] == OFFLINE["ball_query_traffic_bytes"]["shape"] else None),
+                    "traffic": (offline["ball_query_traffic_bytes"]["bytes"]
+                                if [b_, n_, m_, ns_] == offline["ball_query_traffic_bytes"]["shape"] else None),
+                    "traffic_source": offline["ball_query_traffic_bytes"].get("source"),
                     "launches": len(bq), "avg_ms": round(ms, 4), "algorithmic_bytes": alg,
                     "query_only": {"avg_ms": round(ms_q, 4), "achieved": round(alg / (ms_q * 1e-3) / 1e9, 2),
                                    "frac": round(alg / (ms_q * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
@@ -532,10 +597,11 @@ def main():
                                                       "achieved": round(alg / ((q + 0.5 * bld) * 1e-3) / 1e9, 2),
                                                       "frac": round(alg / ((q + 0.5 * bld) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)})(
                         max(ms_q - pair_floor_ms, 1e-6), max(ms_b - pair_floor_ms, 0.0) if shared else 0.0),
-                    "isolated": {"avg_ms": round(isolated_ms, 4), "achieved": round(alg / (isolated_ms * 1e-3) / 1e9, 2),
-                                 "frac": round(alg / (isolated_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                                 "note": "the stand-alone operator ogc_ball_query (its own grid build + query), 20 back-to-back "
-                                         "launches on an idle GPU after the timed region"},
+                    "isolated": None if isolated_ms is None else {
+                        "avg_ms": round(isolated_ms, 4), "achieved": round(alg / (isolated_ms * 1e-3) / 1e9, 2),
+                        "frac": round(alg / (isolated_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                        "note": "the stand-alone operator ogc_ball_query (its own grid build + query), 20 back-to-back "
+                                "launches on an idle GPU after the timed region"},
                     "shape": {"B": b_, "N": n_, "M": m_, "nsample": ns_},
                     "note": "algorithmic bytes = B*(12M + 12N + 4M*nsample) (SURVEY 8d) / mean duration (HIP events on the launch "
                             "stream, inside the timed steps) of the query launch + half of the grid build it shares with the k-NN "
@@ -576,10 +642,10 @@ def main():
         out["fps_note"] = ("levels 2-3 of the encoder cost ~10 us in ms_per_step because the synthetic uniform clouds are free "
                            "of exact fp32 distance ties (the chain shortcut, DESIGN.md); ms_per_step_all_fps_rounds is the same "
                            "step with the shortcut off, i.e. what clouds with duplicated points pay (FPS runs on a side stream)")
-        out["offline"] = OFFLINE
-        if (a.batch, a.npoint) == (4, 8192):
+        out["offline"] = offline
+        st = offline["step_traffic_mib"]
+        if (a.batch, a.npoint) == (4, 8192) and st["fetch_reported"] is not None:
             ms_step = elapsed / a.steps * 1e3
-            st = OFFLINE["step_traffic_mib"]
             out["offline"]["step_traffic_est_gbs"] = round((2 * st["fetch_reported"] + st["write"]) * 2 ** 20 / (ms_step * 1e-3) / 1e9, 1)
         if dist.is_initialized():
             out["collective"] = {"backend": dist.get_backend(), "op": "all_reduce(SUM) of one flat fp32 gradient buffer per step",

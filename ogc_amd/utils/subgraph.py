@@ -16,6 +16,12 @@ run(owner, name, body, tensors, parts) evaluates body(*tensors) that way when it
     gradient hooks and a captured backward pass crashed a rank in tests/test_ddp_gpu.py);
   * the previous graphed call of this body has had its backward pass (or its output is gone): the graphs work on STATIC
     buffers, so a second forward pass before the first one's backward pass would overwrite what that pass needs.
+
+Lifetime of gradients: as with torch.cuda.make_graphed_callables itself, the parameter gradients a graphed backward pass hands
+to autograd are its static buffers — ``param.grad`` of the modules in `parts` is valid until the NEXT replay of that body and
+is overwritten by it.  train_step consumes gradients inside the step that produced them (optimizer.zero_grad(set_to_none=True)
+comes first), so nothing there depends on more; code that holds or accumulates these gradients across steps sets
+``subgraph.ENABLED = False`` (or OGC_SUBGRAPHS=0 in the environment) and gets ordinary tensors (tests/test_zero_arena_gpu.py).
 """
 import gc
 import warnings
@@ -24,7 +30,9 @@ import weakref
 import torch
 import torch.nn as nn
 
-ENABLED = True
+import os as _os
+
+ENABLED = _os.environ.get("OGC_SUBGRAPHS", "1") != "0"
 
 
 def allowed(owner, ref):

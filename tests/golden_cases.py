@@ -357,12 +357,18 @@ class ErrorBudget:
     move by < 1e-6 — measured, and it is what the old 1e-2 gradient tolerances were silently absorbing.  `floor` keeps
     a tensor on which the reference's fp32 run happened to land unusually close to the truth from failing the test."""
 
-    def __init__(self, factor=2.0):
+    def __init__(self, factor=2.0, gate_flips=(), gate_flip_cap=2e-3):
         self.factor, self.rows, self.bad = factor, [], []
+        # tensors (by name) known to sit behind a ReLU / max-pool gate that flips inside the last bit of one fp32 product on
+        # this fixture: they may miss the bound above, up to `gate_flip_cap`.  The list is explicit and its length pinned.
+        self.gate_flips, self.gate_flip_cap, self.used_flips = frozenset(gate_flips), gate_flip_cap, set()
 
     def add(self, what, ours, ref32, truth, floor, cap=None, denom_floor=1e-300, cond=0.0):
         e_o, e_r = rel_l2(ours, truth, denom_floor), rel_l2(ref32, truth, denom_floor)
         ok = e_o <= max(self.factor * e_r, self.factor * cond, floor) and (cap is None or e_o <= cap)
+        if not ok and what in self.gate_flips and e_o <= self.gate_flip_cap:
+            self.used_flips.add(what)
+            ok = True
         self.rows.append((what, e_o, e_r, ok))
         if not ok:
             self.bad.append("%s: ours %.3e vs reference-fp32 %.3e, conditioning %.3e (floor %.1e, cap %s)" %
@@ -382,8 +388,26 @@ def _cond(truth, key):
     return 0.0 if v is None else float(v[0])
 
 
+# Gradient tensors allowed to miss the (reference-fp32 error, stored float64 conditioning, floor) bound, by fixture and NAME, up to
+# ErrorBudget.gate_flip_cap = 2e-3 relative (worst measured: 1.24e-3).  Why they exist: on the segnet_ogcdr fixture a ReLU /
+# max-pool gate of the first set-abstraction level sits between two fp32 roundings of one activation; the vendor GEMM's values moved
+# by ONE ulp flip it and change the gradients of everything upstream and beside it — 68 of the model's 181 gradient rows — by
+# ~1e-3 (own_grad_conditioning below measures that and the test prints it: a report, no part of the bound).  The forward output
+# of the same fixture is held to 1e-5 like every other.  The list is data (tests/golden/gate_flip_tensors.json) and its length is
+# pinned here: it may only shrink.
+def _gate_flip_tensors():
+    import json
+    with open(os.path.join(GOLD, "gate_flip_tensors.json")) as f:
+        return {k: tuple(v) for k, v in json.load(f).items()}
+
+
+GATE_FLIP_TENSORS = _gate_flip_tensors()   # tests/golden/gate_flip_tensors.json, written from tools/gate_flip_list.py's output
+MAX_GATE_FLIP_TENSORS = {"segnet_ogcdr": 68}   # one fixture; the other eight fixtures of these tests have no exception
+assert {k: len(v) for k, v in GATE_FLIP_TENSORS.items()} == MAX_GATE_FLIP_TENSORS, "the exception list may only shrink"
+
+
 def own_grad_conditioning(run, samples=6):
-    """Conditioning of the parameter gradients of THIS implementation at fp32 resolution, measured: run() (a fresh forward
+    """(A report, not a tolerance.)  Conditioning of the parameter gradients of THIS implementation at fp32 resolution, measured: run() (a fresh forward
     and backward pass, returning {name: gradient}) is repeated with every output of fused._product — the plain matrix
     products of the feature-propagation layers and of the point-wise part of a set-abstraction layer — moved by ONE ulp up
     or down at random, and the largest relative change of each gradient's norm / 32-entry head is returned.  Why: those
@@ -430,16 +454,15 @@ def own_grad_conditioning(run, samples=6):
     return cond
 
 
-def _grad_rows(budget, module, loss, gold32, truth, prefix32, prefix64, floor, own_cond=None):
+def _grad_rows(budget, module, loss, gold32, truth, prefix32, prefix64, floor):
     """Parameter gradients: the norm (relative) and the stored head of 32 entries (relative in L2 over the head).
     A flipped gate perturbs the gradient of EVERY parameter upstream of it, and which gates flip depends on the last
-    bits of the forward pass (eight noise samples do not visit all of them): a tensor is therefore also allowed a
-    quarter of the largest conditioning seen on any gradient tensor of the model."""
+    bits of the forward pass (eight noise samples do not visit all of them): a tensor is therefore also allowed an
+    eighth of the largest STORED conditioning (float64 re-evaluations of the reference, make_truth_f64.py) seen on any
+    gradient tensor of the model.  Nothing measured on this implementation enters the bound."""
     module.zero_grad()
     loss.backward()
-    own_cond = own_cond or {}
-    model_cond = {kind: max([float(v[0]) for k, v in truth.items() if k.startswith("cond/" + prefix64 + kind)]
-                            + [v for k, v in own_cond.items() if k.startswith(kind)] + [0.0])
+    model_cond = {kind: max([float(v[0]) for k, v in truth.items() if k.startswith("cond/" + prefix64 + kind)] + [0.0])
                   for kind in ("gnorm/", "ghead/")}
     for name, p in module.named_parameters():
         g = p.grad if p.grad is not None else torch.zeros_like(p)
@@ -448,15 +471,13 @@ def _grad_rows(budget, module, loss, gold32, truth, prefix32, prefix64, floor, o
             assert float(g.norm()) == 0.0, name
             continue
         budget.add("gnorm/" + name, g.norm().reshape(1), gold32[prefix32 + "gnorm/" + name], tn, floor,
-                   cond=max(_cond(truth, prefix64 + "gnorm/" + name), own_cond.get("gnorm/" + name, 0.0),
-                            0.125 * model_cond["gnorm/"]))
+                   cond=max(_cond(truth, prefix64 + "gnorm/" + name), 0.125 * model_cond["gnorm/"]))
         # the stored head (first 32 entries): error relative to the head's norm, or to the share of the whole
         # gradient's norm 32 typical entries carry when the head happens to be a vanishing part of it
         typical = float(tn[0]) * np.sqrt(min(32, p.numel()) / p.numel())
         # (a head is 32 numbers: its own floor is 6x the norm's — still 300x below the 1e-2 these tests used to allow)
         budget.add("ghead/" + name, g.flatten()[:32], gold32[prefix32 + "ghead/" + name], th, 6 * floor, denom_floor=typical,
-                   cond=max(_cond(truth, prefix64 + "ghead/" + name), own_cond.get("ghead/" + name, 0.0),
-                            0.125 * model_cond["ghead/"]))
+                   cond=max(_cond(truth, prefix64 + "ghead/" + name), 0.125 * model_cond["ghead/"]))
 
 
 def truth_segnet(dev, name, kw, N, B, out_cap=1e-5, floor=1e-6, grad_floor=5e-6):
@@ -467,7 +488,7 @@ def truth_segnet(dev, name, kw, N, B, out_cap=1e-5, floor=1e-6, grad_floor=5e-6)
     scale = (60, 4, 80) if name == "segnet_kitti" else (1, 1, 1)
     pc = T(detgen.cloud(B, N, 41, scale=scale))
     mask = net(pc, pc)
-    budget = ErrorBudget()
+    budget = ErrorBudget(gate_flips=GATE_FLIP_TENSORS.get(name, ()))
     budget.add(name + ".mask", mask, g["mask"], t["model_%s/mask" % name], floor, cap=out_cap)
     target = T(detgen.uniform(tuple(mask.shape), 42, 0.0, 1.0))
     own_cond = None
@@ -477,9 +498,9 @@ def truth_segnet(dev, name, kw, N, B, out_cap=1e-5, floor=1e-6, grad_floor=5e-6)
             m = net(pc, pc)
             ((m - target) ** 2).mean().backward()
             return {k: (p.grad if p.grad is not None else torch.zeros_like(p)).detach().clone() for k, p in net.named_parameters()}
-        own_cond = own_grad_conditioning(again)
+        own_cond = own_grad_conditioning(again)       # a REPORT (test_truth_f64_gpu prints it): no part of any bound
         budget.own_cond_max = max(own_cond.values()) if own_cond else 0.0
-    _grad_rows(budget, net, ((mask - target) ** 2).mean(), g, t, "", "model_%s/" % name, grad_floor, own_cond=own_cond)
+    _grad_rows(budget, net, ((mask - target) ** 2).mean(), g, t, "", "model_%s/" % name, grad_floor)
     return budget
 
 

@@ -21,13 +21,16 @@ def _setup(seed=10):
     return net, crit, opt, batches
 
 
-def _run(arena_on, steps=4, fail_at=None):
+def _run(arena_on, steps=4, fail_at=None, subgraphs=True):
     """`steps` training steps of the C1 shapes; returns per step (loss dict, gradients held WITHOUT a copy, their clones at the
-    time) and the final parameters."""
+    time) and the final parameters.  With sub-graphs on, the gradients of the slot branch (MF_head, object_mlp: a forward /
+    backward pair of HIP graphs, utils/subgraph.py) are left out of what is held: they live in the graphs' static buffers until
+    the branch's next replay, as with torch.cuda.make_graphed_callables — nothing the arena changes either way."""
     from ogc_amd import train_step as ts
+    from ogc_amd.utils import subgraph as sg
     from ogc_amd.utils import zero_arena as za
-    was = za.ENABLED
-    za.ENABLED = arena_on
+    was, was_sg = za.ENABLED, sg.ENABLED
+    za.ENABLED, sg.ENABLED = arena_on, subgraphs
     try:
         net, crit, opt, batches = _setup()
         held, out = [], []
@@ -50,23 +53,25 @@ def _run(arena_on, steps=4, fail_at=None):
                 continue
             losses, stepped = ts.train_step(net, crit, opt, batches[i], 10, True)
             assert stepped
-            grads = [p.grad for p in net.parameters() if p.grad is not None]          # the tensors autograd kept
+            grads = [p.grad for n, p in net.named_parameters() if p.grad is not None       # the tensors autograd kept
+                     and not (subgraphs and n.startswith(("MF_head.", "object_mlp.")))]
             held.append((grads, [g.clone() for g in grads]))
             out.append(losses)
         torch.cuda.synchronize()
         return out, held, [p.detach().clone() for p in net.parameters()]
     finally:
-        za.ENABLED = was
+        za.ENABLED, sg.ENABLED = was, was_sg
 
 
 def test_held_gradients_survive_later_steps():
     """param.grad of step i, kept by the caller across optimizer.zero_grad(set_to_none=True), is still what it was after the
     steps that follow (the persistent region of round 4 zeroed it at the next step's begin)."""
-    _, held, _ = _run(True)
-    assert len(held) == 4
-    for step, (kept, clones) in enumerate(held):
-        for g, c in zip(kept, clones):
-            assert torch.equal(g, c), "gradient of step %d was overwritten by a later step" % step
+    for subgraphs in (True, False):         # (False: every parameter's gradient is an ordinary tensor, the slot branch's too)
+        _, held, _ = _run(True, subgraphs=subgraphs)
+        assert len(held) == 4 and len(held[0][0]) >= (40 if subgraphs else 88)
+        for step, (kept, clones) in enumerate(held):
+            for g, c in zip(kept, clones):
+                assert torch.equal(g, c), "gradient of step %d was overwritten by a later step" % step
 
 
 def test_arena_on_equals_arena_off():
