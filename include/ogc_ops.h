@@ -45,6 +45,12 @@ enum {
  * entry points ogc_zero_arena_begin / _end, ogc_conv1x1_gemm_any, ogc_conv1x1_wgrad_affine_pooled, ogc_conv1x1_dgrad_pooled. */
 #define OGC_VERSION 200
 int ogc_version(void);
+/* 0: the squared distance of every search is the reference's SOURCE expression, ((dx*dx) + (dy*dy)) + (dz*dz), one rounding per
+ * operation (what all parity tests pin).  1: this is libogc_ops_fmad.so, the same library with the search kernels (FPS, kNN,
+ * three-NN, ball query) compiled to evaluate fma(dz, dz, fma(dy, dy, dx*dx)) — what `nvcc --fmad=true`, the reference's build,
+ * makes of that expression (pointnet2/setup.py has no -fmad=false); for comparisons against index tensors produced by the real
+ * CUDA binary on tie-heavy data.  Opt-in: OGC_FMAD=1 in the environment of ogc_amd. */
+int ogc_distance_contracted(void);
 const char *ogc_last_error(void);
 
 /* ---- furthest point sampling -------------------------------------------------------

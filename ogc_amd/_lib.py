@@ -7,7 +7,10 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libogc_ops.so")
+# OGC_FMAD=1: the variant whose search kernels contract the squared distance as the reference's nvcc build does (include/ogc_ops.h,
+# ogc_distance_contracted) — for comparing index tensors against outputs of the real CUDA binary; never the default
+FMAD = os.environ.get("OGC_FMAD", "0") == "1"
+LIB_PATH = os.path.join(_HERE, "csrc", "libogc_ops_fmad.so" if FMAD else "libogc_ops.so")
 
 _vp = ctypes.c_void_p
 _int = ctypes.c_int
@@ -141,6 +144,10 @@ def load():
         if L.ogc_version() != HEADER_VERSION:
             raise OgcOpsError("libogc_ops.so at %s is version %d, this package binds version %d of include/ogc_ops.h — rebuild it "
                               "with `python ogc_amd/csrc/build.py --force`" % (LIB_PATH, L.ogc_version(), HEADER_VERSION))
+        L.ogc_distance_contracted.restype = _int
+        if bool(L.ogc_distance_contracted()) != FMAD:
+            raise OgcOpsError("%s evaluates distances %s, OGC_FMAD asked for the other form" %
+                              (LIB_PATH, "contracted (fma)" if L.ogc_distance_contracted() else "un-contracted"))
         L.ogc_slot_masks_ws_floats.restype = ctypes.c_longlong
         L.ogc_cell_grid_bytes.restype = ctypes.c_longlong
         L.ogc_last_error.restype = ctypes.c_char_p

@@ -13,6 +13,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["api.hip", "knn.hip", "ball_query.hip", "fps.hip", "gather_group.hip", "interpolate.hip", "kabsch.hip", "small_solvers.hip", "neighbour_loss.hip", "soft_nn.hip", "seg_loss.hip", "group_norm.hip", "batch_norm.hip", "grid.hip", "conv1x1.hip", "attention.hip", "slot_masks.hip", "small_linear.hip", "mlp_chain.hip", "gn_fused_bwd.hip", "adam.hip", "gemm_chunk.hip"]
 HEADERS = ["ogc_common.h", "grid.h", "conv_stage.h", os.path.join("..", "..", "include", "ogc_ops.h")]
 LIB = os.path.join(HERE, "libogc_ops.so")
+# The search kernels once more with the distance expression contracted as `nvcc --fmad=true` contracts it (ogc_common.h, OGC_FMAD):
+# libogc_ops_fmad.so = those objects + all the others of libogc_ops.so.  Opt-in at load time (OGC_FMAD=1, ogc_amd/_lib.py).
+FMAD_SOURCES = ["knn.hip", "ball_query.hip", "fps.hip", "grid.hip"]
+LIB_FMAD = os.path.join(HERE, "libogc_ops_fmad.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
@@ -35,13 +39,20 @@ def _newer(target, deps):
 
 def build(force=False, verbose=False):
     hdrs = [os.path.join(HERE, h) for h in HEADERS] + [os.path.abspath(__file__)]
-    objs, jobs = [], []
+    objs, objs_fmad, jobs = [], [], []
     for s in SOURCES:
         src = os.path.join(HERE, s)
         obj = os.path.join(HERE, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or _newer(obj, [src] + hdrs):
             jobs.append([HIPCC] + FLAGS + ["-c", src, "-o", obj])
+        if s in FMAD_SOURCES:
+            obj_f = os.path.join(HERE, s.replace(".hip", ".fmad.o"))
+            objs_fmad.append(obj_f)
+            if force or _newer(obj_f, [src] + hdrs):
+                jobs.append([HIPCC] + FLAGS + ["-DOGC_FMAD=1", "-c", src, "-o", obj_f])
+        else:
+            objs_fmad.append(obj)
 
     def run(cmd):
         if verbose:
@@ -52,6 +63,8 @@ def build(force=False, verbose=False):
         list(ex.map(run, jobs))
     if force or jobs or _newer(LIB, objs):
         run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    if force or jobs or _newer(LIB_FMAD, objs_fmad):
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_FMAD] + objs_fmad)
     return LIB
 
 

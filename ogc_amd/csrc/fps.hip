@@ -128,11 +128,8 @@ __device__ __forceinline__ long long fps_max_low_lanes_i64(long long v) {
 // (sampling_gpu.cu:133), never contracted.
 __device__ __forceinline__ ogc_v2f fps_sqdist2(ogc_v2f px, ogc_v2f py, ogc_v2f pz, ogc_v2f qx, ogc_v2f qy, ogc_v2f qz) {
 #pragma clang fp contract(off)
-    ogc_v2f dx = px - qx, dy = py - qy, dz = pz - qz;
-    dx = dx * dx;
-    dy = dy * dy;
-    dz = dz * dz;
-    return (dx + dy) + dz;
+    const ogc_v2f dx = px - qx, dy = py - qy, dz = pz - qz;
+    return ogc_sqsum3(dx, dy, dz);
 }
 
 template <int PTS, int THREADS, bool LDS_XYZ>
@@ -610,10 +607,7 @@ __global__ __launch_bounds__(WAVES *OGC_WAVE) void fps_bucket_kernel(int n, int 
             float dx = fmaxf(fmaxf(blo[0] - x1, x1 - bhi[0]), 0.0f);
             float dy = fmaxf(fmaxf(blo[1] - y1, y1 - bhi[1]), 0.0f);
             float dz = fmaxf(fmaxf(blo[2] - z1, z1 - bhi[2]), 0.0f);
-            dx = dx * dx;
-            dy = dy * dy;
-            dz = dz * dz;
-            const float d2 = (dx + dy) + dz;
+            const float d2 = ogc_sqsum3(dx, dy, dz);
             reach = (unsigned)(__builtin_amdgcn_ballot_w64(is_rec && (always || d2 < bmv)) >> REC0);
         }
         // (2) update and re-reduce those

@@ -663,11 +663,8 @@ __device__ __forceinline__ float lane_bcast(float v, int src) {
 __device__ __forceinline__ ogc_v2f sqdist_pair(ogc_v2f qx, ogc_v2f qy, ogc_v2f qz, float x, float y, float z) {
 #pragma clang fp contract(off)
     const ogc_v2f cx2 = {x, x}, cy2 = {y, y}, cz2 = {z, z};
-    ogc_v2f dx = qx - cx2, dy = qy - cy2, dz = qz - cz2;
-    dx = dx * dx;
-    dy = dy * dy;
-    dz = dz * dz;
-    return (dx + dy) + dz;
+    const ogc_v2f dx = qx - cx2, dy = qy - cy2, dz = qz - cz2;
+    return ogc_sqsum3(dx, dy, dz);
 }
 
 // Ball query of a cloud against itself over the cell lists: ONE LANE PER CANDIDATE.

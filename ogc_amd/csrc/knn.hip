@@ -287,3 +287,12 @@ extern "C" int ogc_three_nn(int b, int n, int m, const float *unknown, const flo
     OGC_CHECK_LAUNCH("ogc_three_nn");
     return OGC_OK;
 }
+
+// 1 when this library's search kernels evaluate the squared distance as `nvcc --fmad=true` contracts it (libogc_ops_fmad.so), else 0
+extern "C" int ogc_distance_contracted(void) {
+#ifdef OGC_FMAD
+    return 1;
+#else
+    return 0;
+#endif
+}

@@ -59,10 +59,39 @@ static inline hipError_t ogc_zero_async(void *ptr, size_t bytes, hipStream_t str
 // d = (ux-x)*(ux-x) + (uy-y)*(uy-y) + (uz-z)*(uz-z), fp32, left to right, one rounding per
 // operation, never contracted into FMA (interpolate_gpu.cu:40, ball_query_gpu.cu:33,
 // sampling_gpu.cu:133).  The *_rn intrinsics are immune to -ffp-contract.
+//
+// OGC_FMAD (a compile-time variant, never the default): the same expression as `nvcc --fmad=true` — the reference's build —
+// contracts it, fma(dz, dz, fma(dy, dy, dx * dx)): two roundings fewer.  ogc_amd/csrc/build.py links the search kernels compiled
+// that way into libogc_ops_fmad.so, loaded instead of libogc_ops.so when OGC_FMAD=1 is in the environment, for a user who
+// holds index tensors of the reference's CUDA binary on tie-heavy data and wants to compare against them; its results equal
+// the oracle's under oracle_set_fmad(1) (tests/test_fmad_mode_gpu.py).  Every pruning argument of the kernels (cell lists,
+// bucket boxes) only uses that the expression is monotone in |dx|, |dy|, |dz| with IEEE rounding, which holds for both forms.
+typedef float ogc_v2f_ __attribute__((ext_vector_type(2)));
+#ifdef OGC_FMAD
+__device__ __forceinline__ float ogc_sqsum3(float dx, float dy, float dz) {
+    return __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, __fmul_rn(dx, dx)));
+}
+__device__ __forceinline__ ogc_v2f_ ogc_sqsum3(ogc_v2f_ dx, ogc_v2f_ dy, ogc_v2f_ dz) {
+#pragma clang fp contract(off)
+    const ogc_v2f_ xx = dx * dx;
+    return __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, xx));
+}
+#else
+__device__ __forceinline__ float ogc_sqsum3(float dx, float dy, float dz) {
+    return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+}
+__device__ __forceinline__ ogc_v2f_ ogc_sqsum3(ogc_v2f_ dx, ogc_v2f_ dy, ogc_v2f_ dz) {
+#pragma clang fp contract(off)
+    dx = dx * dx;
+    dy = dy * dy;
+    dz = dz * dz;
+    return (dx + dy) + dz;
+}
+#endif
 __device__ __forceinline__ float ogc_sqdist(float ax, float ay, float az, float bx, float by,
                                             float bz) {
     const float dx = __fsub_rn(ax, bx), dy = __fsub_rn(ay, by), dz = __fsub_rn(az, bz);
-    return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+    return ogc_sqsum3(dx, dy, dz);
 }
 
 // IEEE minNum in ONE instruction: hipcc expands fminf() to a canonicalising v_max + v_min pair because it cannot
@@ -145,6 +174,10 @@ __device__ __forceinline__ void ogc_dist8(const OgcGroup &c, float qx, float qy,
     for (int u = 0; u < 4; ++u) dy[u] = q2y - Y[u];
 #pragma unroll
     for (int u = 0; u < 4; ++u) dz[u] = q2z - Z[u];
+#ifdef OGC_FMAD
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s[u] = ogc_sqsum3(dx[u], dy[u], dz[u]);
+#else
 #pragma unroll
     for (int u = 0; u < 4; ++u) dx[u] = dx[u] * dx[u];
 #pragma unroll
@@ -155,6 +188,7 @@ __device__ __forceinline__ void ogc_dist8(const OgcGroup &c, float qx, float qy,
     for (int u = 0; u < 4; ++u) s[u] = dx[u] + dy[u];
 #pragma unroll
     for (int u = 0; u < 4; ++u) s[u] = s[u] + dz[u];
+#endif
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         d[2 * u] = s[u].x;

@@ -226,6 +226,34 @@ def test_fps_large_clouds_match_oracle(shape, oracle):
         np.testing.assert_array_equal(np.load(os.path.join(d, "out.npy")), want)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["n100000", "n180000_lattice"])
+def test_fps_raw_scan_sizes_match_the_oracle_hash(case):
+    """N = 100000 / 180000 -> 8192 (the data-preparation callers, data_prepare/kittisf/downsample_kittisf.py:25,49 through
+    utils/data_util.py:8-20): the cooperative kernel's indices against the SHA-256 of the oracle's, computed once on the host
+    by tests/golden/make_fps_large.py (20 s of CPU) and stored in tests/golden/fps_large_sha.json.  The second cloud has a
+    quarter of its points on a 1 m lattice: mass ties, resolved as the reference's block reduction resolves them."""
+    import hashlib
+    import json
+    import os
+    import sys
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    sys.path.insert(0, gold)
+    import make_fps_large as mk
+    from ogc_amd import pointnet2_cuda as nat
+    want = json.load(open(os.path.join(gold, "fps_large_sha.json")))[case]
+    pc = torch.from_numpy(mk.cloud(want["n"], want["seed"], want["lattice"])).cuda()
+    idx = torch.empty(1, want["m"], dtype=torch.int32, device="cuda")
+    temp = torch.full((1, want["n"]), 1e10, device="cuda")
+    nat.furthest_point_sampling_wrapper(1, want["n"], want["m"], pc, temp, idx)
+    got = idx.cpu().numpy()
+    assert [int(v) for v in got[0, :8]] == want["head"]
+    assert hashlib.sha256(np.ascontiguousarray(got, np.int32).tobytes()).hexdigest() == want["sha256"]
+    # the data-preparation entry point on the same cloud (ogc_amd/utils/data_util.fps_downsample -> the same indices)
+    from ogc_amd.utils.data_util import fps_downsample
+    assert np.array_equal(fps_downsample(pc[0].cpu().numpy(), want["m"]), got[0])
+
+
 def test_voting_at_ogcdr_size_agrees_with_dense_chains_and_helps():
     """Multi-frame voting at the OGC-DR scale-up size (4 frames x 4096 points, 8 slots): the chain-free propagation
     equals the reference's dense chained correspondences, the voted masks are distributions, and on a sequence whose
