@@ -612,6 +612,17 @@ int ogc_group_norm_pool_extremes(int b, int c, int p, int s, int groups, float e
                                  const int *aext, const float *gamma, const float *beta, float *out, int *argmax,
                                  float *mean, float *rstd, const double *stats, int slots, ogc_stream_t stream);
 
+/* The two nearest-neighbour distance terms of the Chamfer loss and their gradient (fused extension; replaces the gather /
+ * difference / norm sequence of losses/flow_loss_unsup.py:24-35 around the two knn(1, ., .) searches, which stay ogc_knn calls).
+ * p1 (b, n1, 3) = pc1 + flow, pc2 (b, n2, 3), idx12 (b, n1) = nearest point of pc2 for every point of p1, idx21 (b, n2) the other
+ * way round; p = 1 or 2 (the reference's loss_norm).  dist1 (b, n1), dist2 (b, n2) as the reference's dist1 / dist2.
+ * _grad: grad_p1 (b, n1, 3) = gradient of sum(g1 * dist1) + sum(g2 * dist2) w.r.t. p1 with the indices held constant
+ * (`idx.detach()` in the reference); zeroed by the entry point, accumulated with fp32 atomics. */
+int ogc_chamfer_terms(int b, int n1, int n2, int p, const float *p1, const float *pc2, const int *idx12, const int *idx21,
+                      float *dist1, float *dist2, ogc_stream_t stream);
+int ogc_chamfer_terms_grad(int b, int n1, int n2, int p, const float *p1, const float *pc2, const int *idx12, const int *idx21,
+                           const float *g1, const float *g2, float *grad_p1, ogc_stream_t stream);
+
 /* One zero fill per training step (fused extension; nothing in the reference to replace: its Python zero-fills every gradient
  * buffer it hands to the native module, pointnet2/pointnet2.py:73,181,224).  ogc_zero_arena_begin fills [base, base + bytes)
  * with zeros by ONE launch on `stream`; until ogc_zero_arena_end every operator of this library that would zero an

@@ -39,6 +39,8 @@ SIGNATURES = {
     "ogc_cell_grid_build": [_int, _int, _flt, _vp, _vp, _vp],
     "ogc_ball_query_cells": [_int, _int, _flt, _int, _vp, _vp, _flt, _vp, _vp],
     "ogc_knn_clamped_cells": [_int, _int, _int, _flt, _vp, _vp, _flt, _vp, _vp, _vp],
+    "ogc_chamfer_terms": [_int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "ogc_chamfer_terms_grad": [_int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "ogc_zero_arena_begin": [_vp, _int, _vp],
     "ogc_zero_arena_end": [],
     "ogc_adam_max_tensors": [],

@@ -225,6 +225,18 @@ class CellGrid:
              self.radius, _f(dist, "dist"), _i(idx, "idx"))
 
 
+def chamfer_terms_wrapper(b, n1, n2, p, p1, pc2, idx12, idx21, dist1, dist2):
+    """dist1[b, i] = |p1[b, i] - pc2[b, idx12[b, i]]|_p, dist2[b, j] = |pc2[b, j] - p1[b, idx21[b, j]]|_p (ogc_chamfer_terms)."""
+    _run("ogc_chamfer_terms", p1, b, n1, n2, int(p), _f(p1, "p1"), _f(pc2, "pc2"), _i(idx12, "idx12"), _i(idx21, "idx21"),
+         _f(dist1, "dist1"), _f(dist2, "dist2"))
+
+
+def chamfer_terms_grad_wrapper(b, n1, n2, p, p1, pc2, idx12, idx21, g1, g2, grad_p1):
+    """grad_p1 = d(sum g1 dist1 + sum g2 dist2) / d p1 with the indices held constant (ogc_chamfer_terms_grad)."""
+    _run("ogc_chamfer_terms_grad", p1, b, n1, n2, int(p), _f(p1, "p1"), _f(pc2, "pc2"), _i(idx12, "idx12"), _i(idx21, "idx21"),
+         _f(g1, "g1"), _f(g2, "g2"), _f(grad_p1, "grad_p1"))
+
+
 def kabsch_rotation_wrapper(nb, S, R, valid=None):
     """R = V diag(1,1,det) U^T per 3x3 cross-covariance (ogc_kabsch_rotation); NaN matrices give the identity."""
     _run("ogc_kabsch_rotation", S, nb, _f(S, "S"), _f(R, "R"), 0 if valid is None else _i(valid, "valid"))
