@@ -14,6 +14,8 @@
 //   * a wave owns a (16*COB) x (16*CIB) tile of dW in registers and strides over the positions; the next step's
 //     loads are issued before the current step's MFMAs; the four waves of a workgroup are reduced through LDS,
 //     workgroups through fp32 atomics into dW (zeroed by this entry point).
+#include <stdlib.h>
+
 #include "ogc_common.h"
 #include "conv_stage.h"
 
@@ -245,6 +247,198 @@ void wgrad_launch(int b, int cin, int cout, int hw, const float *x, const float 
         else OGC_WGRAD(false, false);
     }
 #undef OGC_WGRAD
+}
+
+
+// ---- the same weight gradient for WIDE layers (cin, cout >= 128): a 128 x 128 tile of dW per workgroup, operands shared through LDS
+// conv1x1_wgrad_kernel gives every wavefront a 64 x 64 tile and its own operand loads: at 128 -> 256 channels that is 8 tile
+// pairs, every dy element fetched by two of them and every x element by four — 2.1 GB through the L2s for 0.8 GB of tensors, at
+// 81 TFLOP/s.  Here the four wavefronts of a workgroup take the four 64 x 64 quarters of one 128 x 128 tile and walk the SAME
+// positions: a stage is 32 positions of 128 dy rows and 128 x rows (32 KiB), loaded ONCE by the workgroup (thread t: the 16-byte
+// piece t & 7 of rows (t >> 3) + 32 j — full 128-byte lines), transformed once (PRO: the previous layer's GroupNorm + ReLU on x;
+// POOLED: the pooled GroupNorm's gradient rebuilt from y, as in the kernel above, bit for bit) and parked in LDS, from where
+// every wavefront reads its 64 + 64 rows in the MFMA operand layout of the kernel above (lane (i, k): row i, positions 4k .. 4k + 3).
+// Stages are double-buffered: the loads of stage s + 1 are issued before the 128 MFMAs of stage s, their transform and LDS
+// write sit between the stage's two 16-position halves, one barrier per stage.  Two workgroups per CU (72 KiB of LDS each), so
+// one's barrier is the other's matrix time.  dy is read once per 128 input channels, x once per 128 output channels.
+constexpr int WS_POS = 32;              // positions per stage
+constexpr int WS_LD = WS_POS + 4;       // row stride in LDS (floats): 144 bytes, 16-byte aligned, rows spread over the banks
+
+// (Measured, 16 x 32768 positions: 128 -> 256 channels 0.480 -> 0.367 ms = 94 TFLOP/s, 256 -> 128 0.439 -> 0.354, 128 -> 128
+// 0.195 -> 0.198, with the previous layer's norm folded in 0.226 -> 0.202.  A 256 x 128 tile on eight wavefronts — both tensors
+// read from memory exactly once — gave the same 0.367 ms: the kernel is no longer bound by the operand traffic.)
+template <bool PRO, bool POOLED>
+__global__ __launch_bounds__(256, 2) void conv1x1_wgrad_shared_kernel(int batch, int cin, int cout, int hw, int stages_per_wg,
+                                                                      const float *__restrict__ x, const float *__restrict__ dy,
+                                                                      float *__restrict__ dw, const float *__restrict__ aff_a,
+                                                                      const float *__restrict__ aff_b, int pro_relu,
+                                                                      const float2 *__restrict__ coef2,
+                                                                      const float2 *__restrict__ inj, int s_shift) {
+    constexpr int YROWS = 128, WS_ROWS = YROWS + 128, YJ = 4, XJ = 4, NJ = YJ + XJ; // pieces per thread: dy, x
+    constexpr int RSTEP = 32;                                        // rows between a thread's pieces
+    extern __shared__ __attribute__((aligned(16))) float ws_lds[]; // [2][WS_ROWS][WS_LD]
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int i = lane & 15, k = lane >> 4;
+    const int co0 = blockIdx.y * YROWS, ci0 = blockIdx.z * 128;
+    const int half_r = wave >> 1, half_c = wave & 1;                 // this wavefront's 64 x 64 part of the tile
+    const int stages_per_img = hw / WS_POS;
+    const long long nstages = (long long)batch * stages_per_img;
+    const long long first = (long long)blockIdx.x * stages_per_wg;
+    const int mine = (int)max(0LL, min((long long)stages_per_wg, nstages - first));
+    if (mine == 0) return;                                           // (workgroup-uniform)
+
+    // my pieces of a stage: piece q of rows rr + RSTEP j (j < YJ: dy rows, then XJ x rows), clamped onto the tensors
+    const int q = t & 7, rr = t >> 3;
+    int grow[NJ], lrow[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int r = rr + RSTEP * (j < YJ ? j : j - YJ);
+        grow[j] = j < YJ ? min(co0 + r, cout - 1) : min(ci0 + r, cin - 1);
+        lrow[j] = (j < YJ ? r : YROWS + r) * WS_LD + 4 * q;
+    }
+    const int centres = POOLED ? hw >> s_shift : 0;
+    int cur_b = (int)(first / stages_per_img);
+    int cur_off = (int)(first - (long long)cur_b * stages_per_img);
+
+    float4 raw[NJ];
+    float fa[XJ], fb[XJ];
+    float2 cc[YJ], jv[YJ];
+    int jpos = 0;
+    auto fetch = [&]() { // the current stage into registers, then advance
+        const int pos = cur_off * WS_POS + 4 * q;
+        const float *yb_ = dy + (size_t)cur_b * cout * hw + pos;
+        const float *xb_ = x + (size_t)cur_b * cin * hw + pos;
+#pragma unroll
+        for (int j = 0; j < YJ; ++j) raw[j] = *reinterpret_cast<const float4 *>(yb_ + (size_t)grow[j] * hw);
+#pragma unroll
+        for (int j = YJ; j < NJ; ++j) raw[j] = *reinterpret_cast<const float4 *>(xb_ + (size_t)grow[j] * hw);
+        if constexpr (POOLED) {
+#pragma unroll
+            for (int j = 0; j < YJ; ++j) {
+                const size_t r = (size_t)cur_b * cout + grow[j];
+                cc[j] = coef2[r];
+                jv[j] = inj[r * centres + (pos >> s_shift)];
+            }
+            jpos = pos & ((1 << s_shift) - 1);
+        }
+        if constexpr (PRO) {
+#pragma unroll
+            for (int j = 0; j < XJ; ++j) {
+                fa[j] = aff_a[(size_t)cur_b * cin + grow[YJ + j]];
+                fb[j] = aff_b[(size_t)cur_b * cin + grow[YJ + j]];
+            }
+        }
+        if (++cur_off == stages_per_img) { cur_off = 0; ++cur_b; }
+    };
+    auto park = [&](float *buf) { // transform (the expressions of conv1x1_wgrad_kernel) and store to LDS
+#pragma unroll
+        for (int j = 0; j < YJ; ++j) {
+            float4 v = raw[j];
+            if constexpr (POOLED) {
+                const int rel = __float_as_int(jv[j].y) - jpos;
+                const float ag = jv[j].x;
+                v.x = fmaf(cc[j].x, v.x, cc[j].y) + (rel == 0 ? ag : 0.f);
+                v.y = fmaf(cc[j].x, v.y, cc[j].y) + (rel == 1 ? ag : 0.f);
+                v.z = fmaf(cc[j].x, v.z, cc[j].y) + (rel == 2 ? ag : 0.f);
+                v.w = fmaf(cc[j].x, v.w, cc[j].y) + (rel == 3 ? ag : 0.f);
+            }
+            *reinterpret_cast<float4 *>(buf + lrow[j]) = v;
+        }
+#pragma unroll
+        for (int j = 0; j < XJ; ++j) {
+            float4 v = raw[YJ + j];
+            if constexpr (PRO) {
+                v.x = fmaf(fa[j], v.x, fb[j]); v.y = fmaf(fa[j], v.y, fb[j]);
+                v.z = fmaf(fa[j], v.z, fb[j]); v.w = fmaf(fa[j], v.w, fb[j]);
+                if (pro_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            }
+            *reinterpret_cast<float4 *>(buf + lrow[YJ + j]) = v;
+        }
+    };
+
+    v4f acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[a][c] = (v4f){0.f, 0.f, 0.f, 0.f};
+    const int yoff = (half_r * 64 + i) * WS_LD + 4 * k, xoff = (YROWS + half_c * 64 + i) * WS_LD + 4 * k;
+    auto half_stage = [&](const float *buf, int h) { // 16 positions: 64 MFMAs
+        float4 yv[4], xv[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) yv[a] = *reinterpret_cast<const float4 *>(buf + yoff + a * 16 * WS_LD + h * 16);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) xv[c] = *reinterpret_cast<const float4 *>(buf + xoff + c * 16 * WS_LD + h * 16);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(yv[a].x, xv[c].x, acc[a][c], 0, 0, 0);
+                acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(yv[a].y, xv[c].y, acc[a][c], 0, 0, 0);
+                acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(yv[a].z, xv[c].z, acc[a][c], 0, 0, 0);
+                acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(yv[a].w, xv[c].w, acc[a][c], 0, 0, 0);
+            }
+    };
+
+    float *buf0 = ws_lds, *buf1 = ws_lds + WS_ROWS * WS_LD;
+    fetch();
+    park(buf0);
+    __syncthreads();
+    for (int st = 0; st < mine; ++st) {
+        const bool more = st + 1 < mine; // (workgroup-uniform)
+        if (more) fetch();
+        half_stage(buf0, 0);
+        if (more) park(buf1);            // (buf1 was last read before the barrier that ended the previous stage)
+        half_stage(buf0, 1);
+        __syncthreads();
+        float *tmp = buf0; buf0 = buf1; buf1 = tmp;
+    }
+    // C/D layout of 16x16x4: lane l holds rows (l >> 4) * 4 + r (r = 0..3) of column l & 15; workgroups add with fp32 atomics
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = co0 + half_r * 64 + a * 16 + k * 4 + r, col = ci0 + half_c * 64 + c * 16 + i;
+                const float v = acc[a][c][r];
+                if (row < cout && col < cin && v != 0.0f) unsafeAtomicAdd(dw + (size_t)row * cin + col, v);
+            }
+}
+
+// OGC_WGRAD_SHARED=0 in the environment: the 64 x 64 register tiles for every width (A/B runs, tests of both kernels)
+bool wgrad_shared_enabled() {
+    static const bool on = [] { const char *e = getenv("OGC_WGRAD_SHARED"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
+// true when the launch was made
+bool wgrad_shared_launch(int b, int cin, int cout, int hw, const float *x, const float *dy, float *dw, const float *pa,
+                         const float *pb, int pro_relu, hipStream_t s, const float2 *coef2, const float2 *inj, int s_shift) {
+    if (!wgrad_shared_enabled() || g_matmul_bf16 || cin < 128 || cout < 128 || (hw % WS_POS) != 0) return false;
+    if (inj && (1 << s_shift) < 4) return false;
+    const size_t lds = sizeof(float) * 2 * 256 * WS_LD;
+    const int tiles = ogc_divup(cout, 128) * ogc_divup(cin, 128);
+    const long long nstages = (long long)b * (hw / WS_POS);
+    // two workgroups per CU over all tiles, at least 8 stages each
+    long long wgs = 512 / tiles;
+    if (wgs < 1) wgs = 1;
+    long long spw = (nstages + wgs - 1) / wgs;
+    if (spw < 8) spw = 8;
+    const int gx = (int)((nstages + spw - 1) / spw);
+    dim3 grid(gx, ogc_divup(cout, 128), ogc_divup(cin, 128));
+#define OGC_WGS(PROV, POOLV)                                                                                                 \
+    {                                                                                                                        \
+        static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(conv1x1_wgrad_shared_kernel<PROV, POOLV>),  \
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;       \
+        if (!ok) { (void)hipGetLastError(); return false; }                                                                  \
+        hipLaunchKernelGGL((conv1x1_wgrad_shared_kernel<PROV, POOLV>), grid, dim3(256), lds, s, b, cin, cout, hw, (int)spw, x, \
+                           dy, dw, pa, pb, pro_relu, coef2, inj, s_shift);                                                    \
+    }
+    if (inj) { if (pa) OGC_WGS(true, true) else return false; }
+    else if (pa) OGC_WGS(true, false)
+    else OGC_WGS(false, false)
+#undef OGC_WGS
+    return true;
 }
 
 } // namespace
@@ -953,6 +1147,11 @@ int wgrad_impl(const char *name, int b, int cin, int cout, int hw, const float *
         return OGC_ERR_LAUNCH;
     }
     if (b == 0) return OGC_OK;
+    // layers of 128 channels and more on both sides: a 128 x 128 tile per workgroup, operands shared through LDS
+    if (wgrad_shared_launch(b, cin, cout, hw, x, dy, dw, pa, pb, pro_relu, s, coef2, inj, s_shift)) {
+        OGC_CHECK_LAUNCH(name);
+        return OGC_OK;
+    }
     // register tile per wave: (16*COB) x (16*CIB) outputs.  Small channel counts use small tiles so that no MFMA
     // work is spent on padding; wide layers use 64x64 tiles (16 accumulators) and split the rest over the grid.
     if (inj) { // (the pooled form is offered for the wide tails only: 64-row tiles)

@@ -874,6 +874,31 @@ def test_conv1x1_wgrad(nat, B, cin, cout, hw):
     assert err < 2e-6, err
 
 
+@pytest.mark.parametrize("B,cin,cout,hw", [(3, 200, 136, 4096), (16, 128, 256, 32768), (2, 128, 128, 96), (2, 160, 128, 48),
+                                           (5, 256, 128, 2080), (1, 130, 129, 32), (2, 384, 256, 1024)])
+def test_conv1x1_wgrad_wide_layers(nat, B, cin, cout, hw):
+    """cin, cout >= 128: the 128 x 128 workgroup tile with operands shared through LDS (conv1x1_wgrad_shared_kernel; hw % 32 != 0
+    stays on the register tiles) — plain and with the previous layer's GroupNorm + ReLU folded into the operand, against fp64:
+    ragged channel counts on both sides, a single stage, stage counts that do not divide among the workgroups."""
+    torch.manual_seed(cin * 7 + cout + hw)
+    x = torch.randn(B, cin, hw, device=DEV)
+    dy = torch.randn(B, cout, hw, device=DEV)
+    pa = torch.rand(B, cin, device=DEV) + 0.5
+    pb = torch.randn(B, cin, device=DEV) * 0.3
+    for affine in (False, True):
+        dw = torch.full((cout, cin), float("nan"), device=DEV)
+        if affine:
+            nat.conv1x1_wgrad_affine_wrapper(B, cin, cout, hw, 1, x, pa, pb, dy, dw)
+            xin = torch.relu(x * pa[:, :, None] + pb[:, :, None]).double()
+        else:
+            nat.conv1x1_wgrad_wrapper(B, cin, cout, hw, x, dy, dw)
+            xin = x.double()
+        ref = torch.einsum("bop,bip->oi", dy.double(), xin)
+        scale = torch.einsum("bop,bip->oi", dy.double().abs(), xin.abs())
+        err = ((dw.double() - ref).abs() / scale).max().item()
+        assert err < 2e-6, (affine, err)
+
+
 def test_pointwise_conv_autograd_matches_conv2d(nat):
     from ogc_amd.fused import pointwise_conv
     torch.manual_seed(3)
