@@ -105,6 +105,25 @@ __device__ __forceinline__ GridHdr grid_header(const float (&lo)[3], const float
         const float inv_n = 1.0f / (float)max(n, 1);
         const float per_cell = fmaxf((float)knn_k / (dims == 3 ? knn_div : (dims == 2 ? 12.6f : 4.0f)), 0.5f);
         edge = dims > 0 ? dims_root(vol * per_cell * inv_n, dims) : 1.0f;
+        if (knn_div < 0.0f && dims > 0) {
+            // knn_wave_kernel: the edge that puts ~(-knn_div) points into the query's block of five cells per axis CLIPPED to the
+            // bounding box — a road scene 4 m high is two or three cells thick whatever the edge, so the block is a slab and its
+            // cells may be much longer than the mean density of the box suggests (which counts a ball that the slab cuts off)
+            const float target = -knn_div;
+            const float rho = (float)max(n, 1) / vol;
+            edge = dims_root(target / (rho * (dims == 3 ? 125.0f : (dims == 2 ? 25.0f : 5.0f))), dims);
+            for (int it = 0; it < 3; ++it) {
+                float fixed = 1.0f;
+                int freed = 0;
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+                    if (ext[a] > 1e-3f * maxext && ext[a] > 0.0f) {
+                        if (5.0f * edge >= ext[a]) fixed *= ext[a]; else ++freed;
+                    }
+                if (freed == 0) break;
+                edge = dims_root(target / (rho * fixed * (freed == 3 ? 125.0f : (freed == 2 ? 25.0f : 5.0f))), freed);
+            }
+        }
         // radius-clamped search (ogc_knn_clamped): neighbours beyond `radius` are replaced by the nearest one anyway,
         // so the search may stop once the scanned block covers the radius.  When the radius is SHORTER than the
         // density-based edge, cells of edge 1.01 r make that one shell of far fewer candidates (but never less than
@@ -1352,9 +1371,10 @@ __global__ __launch_bounds__(OGC_WAVE, 4) void knn_grid_kernel(int n, int m, int
     const GridHdr h = hdrs[b];
     // deferred: knn_cells_kernel ran first.  It did every row of a cloud it could take except the rows it marked with
     // idx[row][0] = -1 (a list longer than its register sort), and nothing of a cloud flagged knn_general.
-    if (deferred && !h.knn_general && !h.pending) return;
+    // (deferred == 2: knn_wave_kernel ran first on EVERY cloud — whatever knn_general says — and marked the rows it left)
+    if (deferred && (deferred == 2 || !h.knn_general) && !h.pending) return;
     int p = blockIdx.x * QPW + qi;
-    if (deferred && !h.knn_general && p < n && idx_out[((size_t)b * n + p) * k] != -1) p = n; // done already: no work, no output
+    if (deferred && (deferred == 2 || !h.knn_general) && p < n && idx_out[((size_t)b * n + p) * k] != -1) p = n; // done already: no work, no output
     const int *cs = cell_start + (size_t)b * stride_cells;
     const float4 *pts = sorted_pts + (size_t)b * m;
     const unsigned below = (1u << sub) - 1u;
@@ -1604,6 +1624,229 @@ __global__ __launch_bounds__(OGC_WAVE, 4) void knn_grid_kernel(int n, int m, int
         }
     }
 }
+
+// ---- plain k-NN (k <= 32) with the WHOLE WAVEFRONT on one query at a time --------------------------------------------------
+// knn_grid_kernel gives a query eight lanes: the candidates of its first block (5^3 cells, ~120 points) are sorted by a 128-key
+// network of 64-bit compare-exchanges, five instructions each, and a query whose k-th neighbour lies outside that block — about
+// half of them: the cells are half the EXPECTED k-th distance — walks a second shell by insertion while the other seven queries of
+// the wavefront wait: ~5400 vector instructions per eight queries, 0.30 of the issue peak at 16 x 8192 x 8192, k = 32.
+// Selecting k of a few hundred candidates does not need them sorted.  Here a wavefront takes its queries one after the other:
+//   * cells of ~2 points (k / 16 per cell), block = 5 x 5 x 5 cells = 25 runs of the cell-sorted array, ~250 candidates covering
+//     1.28 x the expected k-th distance; lanes 0 .. 24 fetch the runs' bounds, a wave scan numbers the candidates, the lanes
+//     write their runs' positions into a flat LDS list and every lane then loads up to four candidates: one round trip each;
+//   * a THRESHOLD on the squared distance is moved until between k and 64 candidates lie at or below it: each trial is four
+//     compares whose masks are counted by the scalar unit; the first guess comes from the cell edge (the density), the next ones
+//     from count ~ T^(3/2) — two or three trials;
+//   * those <= 64 candidates are compacted into one (distance, index) key per lane and sorted by a 21-stage bitonic network
+//     ACROSS THE LANES (one 64-bit compare-exchange per lane and stage); lanes 0 .. k - 1 then hold the row, in order, and
+//     store it as two coalesced pieces.
+// Exact by the argument of knn_grid_kernel: everything outside the selection is farther than everything inside, keys are
+// distinct, and the row is accepted only when the k-th distance lies inside the ball the block is known to cover (or the block
+// covers the grid).  A query whose block does not (sparse regions, more than 256 candidates, more than 64 ties at the
+// threshold) is marked idx[row][0] = -1 for knn_grid_kernel, launched afterwards in `deferred == 2` mode.
+constexpr int KW_PER_LANE = 12;                      // candidates per lane, at most
+constexpr int KW_CAND = KW_PER_LANE * OGC_WAVE;      // per query and block
+// (cells: grid_header with knn_div = -(candidates wanted in the clipped block) = -min(7 k, 230))
+
+__device__ __forceinline__ u64 kw_xor_lane(u64 v, int d) {
+    const unsigned lo = __shfl_xor((unsigned)v, d, 64), hi = __shfl_xor((unsigned)(v >> 32), d, 64);
+    return ((u64)hi << 32) | lo;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(OGC_WAVE, 8) void knn_wave_kernel(int n, int m, int k, float radius, int stride_cells, int qpw,
+                                                               const float *__restrict__ unknown, GridHdr *__restrict__ hdrs,
+                                                               const int *__restrict__ cell_start,
+                                                               const float4 *__restrict__ sorted_pts,
+                                                               float *__restrict__ dist_out, int *__restrict__ idx_out) {
+    __shared__ int flat[KW_CAND];
+    __shared__ u64 slots[OGC_WAVE];
+    const int lane = threadIdx.x, b = blockIdx.y;
+    const GridHdr h = hdrs[b];
+    const int *cs = cell_start + (size_t)b * stride_cells;
+    const float4 *pts = sorted_pts + (size_t)b * m;
+    const float edge = 1.0f / h.inv_h;
+    // first threshold: the block (five cells per axis) was sized for ~7 k candidates; a ball holding `want` ~ 1.45 k of them at
+    // that density has the volume fraction want / (7 k) of the 125-cell cube (the count model of the trials below corrects it)
+    const float want = fminf(1.45f * (float)k, 48.0f);
+    const float rk = edge * cbrtf(125.0f * want / (4.18879f * fminf(7.0f * (float)k, 230.0f)));
+    const float t_first = rk * rk;
+    // row of the block a lane fetches the bounds of: (2R + 1)^2 rows, R = 2 (25 lanes) and R = 3 (49 lanes)
+    const int ry2 = lane % 5, rz2 = lane / 5, ry3 = lane % 7, rz3 = lane / 7;
+    bool any_left = false;
+    // the wavefront's queries (qpw <= 8), one per lane: coordinates and the cell of the projection into the grid, computed once
+    // side by side instead of once per query on every lane
+    float mqx = NAN, mqy = NAN, mqz = NAN;
+    {
+        const int pl = blockIdx.x * qpw + lane;
+        if (lane < qpw && pl < n) {
+            const float *u = unknown + ((size_t)b * n + pl) * 3;
+            mqx = u[0]; mqy = u[1]; mqz = u[2];
+        }
+    }
+    int mcx, mcy, mcz;
+    {
+        OGC_GRID_AXES(h, mqx, mqy, mqz, fx, fy, fz);
+        mcx = min(max(cell_coord(fx, h.minx, h.inv_h, h.gx), 0), h.gx - 1);
+        mcy = min(max(cell_coord(fy, h.miny, h.inv_h, h.gy), 0), h.gy - 1);
+        mcz = min(max(cell_coord(fz, h.minz, h.inv_h, h.gz), 0), h.gz - 1);
+    }
+    for (int qn = 0; qn < qpw; ++qn) {
+        const int p = (blockIdx.x * qpw + qn);
+        if (p >= n) break;
+        const float qx = lane_bcast(mqx, qn), qy = lane_bcast(mqy, qn), qz = lane_bcast(mqz, qn);
+        const size_t base = ((size_t)b * n + p) * k;
+        const bool active = h.npts > 0 && qx == qx && qy == qy && qz == qz; // NaN queries select nothing
+        int cnt = 0;
+        u64 key = ~0ull;
+        bool accept = true;
+        if (active) {
+            const int cx = lane_bcast(mcx, qn), cy = lane_bcast(mcy, qn), cz = lane_bcast(mcz, qn);
+            const int rmax = max(max(max(cx, h.gx - 1 - cx), max(cy, h.gy - 1 - cy)), max(cz, h.gz - 1 - cz));
+            float T = t_first;
+            // the block of (2R + 1)^3 cells, R = 2; a query whose k-th neighbour is not inside the ball that block covers tries
+            // R = 3 (the WHOLE block again: the wavefront re-reads ~250 records it had, instead of carrying them)
+            for (int R = 2; R <= 3; ++R) {
+                accept = true;
+                const int xa = max(cx - R, 0), xb = min(cx + R, h.gx - 1);
+                const int side = 2 * R + 1;
+                int s_r = 0, l_r = 0;
+                {
+                    const int y = cy + (R == 2 ? ry2 : ry3) - R, z = cz + (R == 2 ? rz2 : rz3) - R;
+                    if (lane < side * side && y >= 0 && y < h.gy && z >= 0 && z < h.gz) {
+                        const int rowc = h.gx * (y + h.gy * z);
+                        s_r = cs[rowc + xa];
+                        l_r = cs[rowc + xb + 1] - s_r;
+                    }
+                }
+                // inclusive scan over the wavefront in six DPP steps (row shifts, then the row broadcasts)
+                int incl = l_r;
+                incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, true);   // row_shr:1
+                incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, true);   // row_shr:2
+                incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, true);   // row_shr:4
+                incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, true);   // row_shr:8
+                incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xA, 0xF, true);   // row_bcast:15 into rows 1, 3
+                incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xC, 0xF, true);   // row_bcast:31 into rows 2, 3
+                const int total = __builtin_amdgcn_readlane(incl, 63);
+                if (total > KW_CAND) { accept = false; break; }     // a crowded block: left to knn_grid_kernel
+                const int w = incl - l_r;
+                for (int i = 0; __builtin_amdgcn_ballot_w64(i < l_r) != 0ull; ++i)
+                    if (i < l_r) flat[w + i] = s_r + i;
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
+                const int nch = (total + OGC_WAVE - 1) / OGC_WAVE;  // candidates per lane (wave-uniform)
+                float d[KW_PER_LANE];
+                int valid = 0;
+#pragma unroll
+                for (int j = 0; j < KW_PER_LANE; ++j) {
+                    d[j] = INFINITY;
+                    if (j < nch) {
+                        const int f = lane + OGC_WAVE * j;
+                        float4 rec = make_float4(NAN, NAN, NAN, 0.f);
+                        if (f < total) {
+                            rec = pts[flat[f]];
+                            flat[f] = __float_as_int(rec.w);     // (only this lane reads slot f: the list now holds the point's index)
+                        }
+                        const float dj = ogc_sqdist(qx, qy, qz, rec.x, rec.y, rec.z);
+                        const bool ok = dj < INFINITY;        // NaN / inf are never selected (empty slots hold NaN)
+                        d[j] = ok ? dj : INFINITY;
+                        valid += __popcll(__builtin_amdgcn_ballot_w64(ok));
+                    }
+                }
+                // the threshold: between min(k, valid) and 64 candidates at or below it
+                int below = 0;
+                if (valid <= k) {
+                    T = __int_as_float(0x7f7fffff);            // no more candidates than the row holds: all of them (every finite distance)
+                    below = valid;
+                } else {
+                    float lo_t = 0.0f, hi_t = 3.0e38f;         // count(lo_t) < k, count(hi_t) > 64 (once tried)
+                    bool found = false;
+                    if (!(T < 3.0e38f)) T = t_first;
+                    for (int it = 0; it < 24; ++it) {
+                        int c = 0;
+#pragma unroll
+                        for (int j = 0; j < KW_PER_LANE; ++j)
+                            if (j < nch) c += __popcll(__builtin_amdgcn_ballot_w64(d[j] <= T));
+                        if (c >= k && c <= OGC_WAVE) { below = c; found = true; break; }
+                        if (c < k) lo_t = T; else hi_t = T;
+                        // next trial: count ~ T^(3/2), kept strictly inside the bracket; bisection once the model stalls
+                        float next = T * __powf(want / fmaxf((float)c, 0.5f), 2.0f / 3.0f);
+                        if (it >= 6 || !(next > lo_t) || !(next < hi_t)) next = hi_t < 3.0e38f ? 0.5f * (lo_t + hi_t) : 2.0f * fmaxf(T, 1.0e-30f);
+                        if (!(next > lo_t) || !(next < hi_t)) break; // the bracket has no float left: ties
+                        T = next;
+                    }
+                    if (!found) { accept = false; break; }      // more than 64 - k ties at the k-th distance: knn_grid_kernel
+                }
+                int slot_base = 0;
+#pragma unroll
+                for (int j = 0; j < KW_PER_LANE; ++j) {
+                    if (j < nch) {
+                        const bool sel = d[j] <= T;
+                        const unsigned long long mask = __builtin_amdgcn_ballot_w64(sel);
+                        if (mask != 0ull) {
+                            const int slot = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, (unsigned)slot_base));
+                            if (sel) slots[slot] = ((u64)__float_as_uint(d[j]) << 32) | (unsigned)flat[lane + OGC_WAVE * j];
+                            slot_base += __popcll(mask);
+                        }
+                    }
+                }
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
+                key = lane < below ? slots[lane] : ~0ull;
+                // bitonic network over the 64 lanes, ascending: per stage ONE 64-bit compare; which lanes keep the smaller key is a
+                // constant of the stage (ascending block == lower lane of the pair), so "take the partner's key" is the compare's
+                // mask xor that constant — a scalar instruction — fed to the two selects (the keys are distinct, sentinels apart,
+                // which may go either way); partners by ds_swizzle (xor 1 .. 16) or a lane permutation (xor 32)
+#pragma unroll
+                for (int size = 2; size <= OGC_WAVE; size <<= 1) {
+#pragma unroll
+                    for (int dd = size >> 1; dd >= 1; dd >>= 1) {
+                        const u64 other = dd == 1 ? knn_xor_lane<1>(key) : dd == 2 ? knn_xor_lane<2>(key) : dd == 4 ? knn_xor_lane<4>(key)
+                                        : dd == 8 ? knn_xor_lane<8>(key) : dd == 16 ? knn_xor_lane<16>(key) : kw_xor_lane(key, 32);
+                        u64 keep_max = 0ull; // lanes that keep the LARGER key in this stage (compile-time constant)
+#pragma unroll
+                        for (int l = 0; l < OGC_WAVE; ++l)
+                            if ((((l & size) == 0) || size == OGC_WAVE) != ((l & dd) == 0)) keep_max |= 1ull << l;
+                        const u64 take = __builtin_amdgcn_ballot_w64(other < key) ^ keep_max;
+                        unsigned lo = (unsigned)key, hi = (unsigned)(key >> 32);
+                        asm("v_cndmask_b32 %0, %0, %2, %4\n\tv_cndmask_b32 %1, %1, %3, %4"
+                            : "+v"(lo), "+v"(hi) : "v"((unsigned)other), "v"((unsigned)(other >> 32)), "s"(take));
+                        key = ((u64)hi << 32) | lo;
+                    }
+                }
+                cnt = min(below, k);
+                __builtin_amdgcn_wave_barrier(); // (flat / slots are rewritten by the next block or query)
+                // the k-th neighbour must lie inside the ball the block covers — unless the block is the whole grid
+                const float cover = (float)R * edge * 0.999f;
+                const unsigned kth_hi = (unsigned)(__shfl(key, max(cnt - 1, 0), 64) >> 32);
+                if (rmax <= R || (cnt == k && __uint_as_float(kth_hi) < cover * cover)) break;
+                accept = false;                                 // (R = 3 did not cover it either: knn_grid_kernel's shells)
+            }
+        }
+        if (!accept) {
+            if (lane == 0) idx_out[base] = -1;
+            any_left = true;
+            continue;
+        }
+        const int first = cnt > 0 ? (int)(unsigned)__shfl(key, 0, 64) : 0;
+        if (lane < k) {
+            float dv = INFINITY;
+            int iv = 0;
+            if (lane < cnt) {
+                dv = __uint_as_float((unsigned)(key >> 32));
+                iv = (int)(unsigned)key;
+            }
+            if (MODE == 1) {
+                dv = sqrtf(dv);
+                if (dv > radius && radius >= 0.0f) { iv = first; dv = INFINITY; } // clamped entries carry dist = +inf
+            }
+            dist_out[base + lane] = dv;
+            idx_out[base + lane] = iv;
+        }
+    }
+    if (any_left && lane == 0) hdrs[b].pending = 1;
+}
+
 
 // ---- three nearest neighbours over the cell lists: ONE LANE PER QUERY ------------------------------------------------------------
 // three_nn (interpolate_gpu.cu:81-124: the feature-propagation modules' inverse-distance weights, 8192 targets against the 2048
@@ -2000,7 +2243,7 @@ float knn_radius_limit2(int mode, float radius) {
 // the query kernels of ogc_knn / ogc_knn_clamped on a built grid.  cells: four lanes per query over the 27 cells around it first;
 // knn_grid_kernel afterwards only does what that kernel left (marked rows, clouds flagged knn_general)
 int launch_knn(const GridLayout &L, void *grid, int mode, int b, int n, int m, int k, float radius, bool cells, const float *unknown,
-               float *dist, int *idx, hipStream_t s) {
+               float *dist, int *idx, hipStream_t s, bool wave = false) {
     GridHdr *hdrs = L.hdrs(grid);
     int *cell_start = L.cell_start(grid);
     float4 *sorted_pts = L.sorted_pts(grid);
@@ -2021,6 +2264,21 @@ int launch_knn(const GridLayout &L, void *grid, int mode, int b, int n, int m, i
         else OGC_KNN_CELLS(4);
 #undef OGC_KNN_CELLS
         deferred = 1;
+    } else if (wave) {
+        // the whole wavefront on one query at a time (k <= 32); knn_grid_kernel afterwards does the rows it marked
+        const long long queries = (long long)b * n;
+        int qpw = (int)(queries / 8192);
+        qpw = qpw < 1 ? 1 : (qpw > 8 ? 8 : qpw);
+        const dim3 gridw(ogc_divup(n, qpw), b);
+        if (mode == 1)
+            hipLaunchKernelGGL(knn_wave_kernel<1>, gridw, dim3(OGC_WAVE), 0, s, n, m, k, radius, stride_cells, qpw, unknown, hdrs,
+                               cell_start, sorted_pts, dist, idx);
+        else
+            hipLaunchKernelGGL(knn_wave_kernel<0>, gridw, dim3(OGC_WAVE), 0, s, n, m, k, radius, stride_cells, qpw, unknown, hdrs,
+                               cell_start, sorted_pts, dist, idx);
+        deferred = 2;
+        static const bool only = [] { const char *e = getenv("OGC_KNN_WAVE_ONLY"); return e && e[0] == '1'; }(); // (development:
+        if (only) return OGC_OK;                                  // rows left to knn_grid_kernel keep idx[row][0] = -1)
     }
     // sixteen lanes per query (four queries per wavefront) when eight would leave most SIMDs without a wavefront: the launch's time
     // is then one wavefront's serial work (FlowStep3D at B = 1: 4096 queries = 512 wavefronts of ~48 us; forward 7.45 -> 7.07 ms).
@@ -2039,7 +2297,7 @@ int launch_knn(const GridLayout &L, void *grid, int mode, int b, int n, int m, i
         hipLaunchKernelGGL((knn_grid_kernel<1, 32>), grid32, dim3(OGC_WAVE), lds, s, n, m, k, radius, lim2, stride_cells, deferred, unknown,
                            hdrs, cell_start, sorted_pts, dist, idx);
     else if (wider)
-        hipLaunchKernelGGL((knn_grid_kernel<0, 32>), grid32, dim3(OGC_WAVE), lds, s, n, m, k, radius, lim2, stride_cells, 0, unknown,
+        hipLaunchKernelGGL((knn_grid_kernel<0, 32>), grid32, dim3(OGC_WAVE), lds, s, n, m, k, radius, lim2, stride_cells, deferred, unknown,
                            hdrs, cell_start, sorted_pts, dist, idx);
     else if (mode == 1 && wide)
         hipLaunchKernelGGL((knn_grid_kernel<1, 16>), grid16, dim3(OGC_WAVE), lds, s, n, m, k, radius, lim2, stride_cells, deferred, unknown,
@@ -2048,10 +2306,10 @@ int launch_knn(const GridLayout &L, void *grid, int mode, int b, int n, int m, i
         hipLaunchKernelGGL((knn_grid_kernel<1, 8>), grid8, dim3(OGC_WAVE), lds, s, n, m, k, radius, lim2, stride_cells, deferred, unknown,
                            hdrs, cell_start, sorted_pts, dist, idx);
     else if (wide)
-        hipLaunchKernelGGL((knn_grid_kernel<0, 16>), grid16, dim3(OGC_WAVE), lds, s, n, m, k, radius, lim2, stride_cells, 0, unknown,
+        hipLaunchKernelGGL((knn_grid_kernel<0, 16>), grid16, dim3(OGC_WAVE), lds, s, n, m, k, radius, lim2, stride_cells, deferred, unknown,
                            hdrs, cell_start, sorted_pts, dist, idx);
     else
-        hipLaunchKernelGGL((knn_grid_kernel<0, 8>), grid8, dim3(OGC_WAVE), lds, s, n, m, k, radius, lim2, stride_cells, 0, unknown,
+        hipLaunchKernelGGL((knn_grid_kernel<0, 8>), grid8, dim3(OGC_WAVE), lds, s, n, m, k, radius, lim2, stride_cells, deferred, unknown,
                            hdrs, cell_start, sorted_pts, dist, idx);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
@@ -2110,9 +2368,14 @@ int ogc_knn_grid(int mode, int b, int n, int m, int k, float radius, const float
     else if (k >= 56) knn_div = m >= 4096 ? 48.0f : 33.5f;
     // (k = 24..40 on full launches stays at 33.5: 40 trades 0.305 -> 0.281 on scenes for 0.240 -> 0.264 on uniform clouds and 0.257 -> 0.309
     // at 8 x 16384 x 16384)
+    // k <= 32 outside the radius-limited self search: a wavefront per query over cells of k / 16 points (knn_wave_kernel);
+    // OGC_KNN_WAVE=0 in the environment: knn_grid_kernel alone (A/B runs, tests of both kernels)
+    static const bool wave_on = [] { const char *e = getenv("OGC_KNN_WAVE"); return !(e && e[0] == '0'); }();
+    const bool wave = wave_on && !cells && k <= 32 && forced_div == 0.0f;
+    if (wave) knn_div = -(7.0f * (float)k < 230.0f ? 7.0f * (float)k : 230.0f);
     launch_grid_build(b, m, mode == 1 ? radius : 0.0f, k, STRIDE_CELLS, known, L.hdrs(ws), L.cell_start(ws), L.sorted_pts(ws), s,
                       cells ? 1 : 0, knn_div);
-    return launch_knn(L, ws, mode, b, n, m, k, radius, cells, unknown, dist, idx, s);
+    return launch_knn(L, ws, mode, b, n, m, k, radius, cells, unknown, dist, idx, s, wave);
 }
 
 // ---- one grid for several radius searches of a batch of clouds in themselves (fused extension, include/ogc_ops.h) ------------
