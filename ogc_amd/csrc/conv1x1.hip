@@ -267,7 +267,8 @@ constexpr int WS_LD = WS_POS + 4;       // row stride in LDS (floats): 144 bytes
 // (Measured, 16 x 32768 positions: 128 -> 256 channels 0.480 -> 0.367 ms = 94 TFLOP/s, 256 -> 128 0.439 -> 0.354, 128 -> 128
 // 0.195 -> 0.198, with the previous layer's norm folded in 0.226 -> 0.202.  A 256 x 128 tile on eight wavefronts — both tensors
 // read from memory exactly once — gave the same 0.367 ms: the kernel is no longer bound by the operand traffic.)
-template <bool PRO, bool POOLED>
+// BF: operands rounded to bf16 on v_mfma_f32_16x16x16_bf16 (ogc_set_matmul_precision), as in conv1x1_wgrad_kernel.
+template <bool PRO, bool POOLED, bool BF = false>
 __global__ __launch_bounds__(256, 2) void conv1x1_wgrad_shared_kernel(int batch, int cin, int cout, int hw, int stages_per_wg,
                                                                       const float *__restrict__ x, const float *__restrict__ dy,
                                                                       float *__restrict__ dw, const float *__restrict__ aff_a,
@@ -368,15 +369,29 @@ __global__ __launch_bounds__(256, 2) void conv1x1_wgrad_shared_kernel(int batch,
         for (int a = 0; a < 4; ++a) yv[a] = *reinterpret_cast<const float4 *>(buf + yoff + a * 16 * WS_LD + h * 16);
 #pragma unroll
         for (int c = 0; c < 4; ++c) xv[c] = *reinterpret_cast<const float4 *>(buf + xoff + c * 16 * WS_LD + h * 16);
+        if constexpr (BF) {
+            // the lane's four consecutive positions are the four k-slots 4k .. 4k+3 of ONE 16x16x16 MFMA
+            v4s yb16[4], xb16[4];
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+            for (int a = 0; a < 4; ++a) yb16[a] = ogc_pack_bf16(yv[a].x, yv[a].y, yv[a].z, yv[a].w);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(yv[a].x, xv[c].x, acc[a][c], 0, 0, 0);
-                acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(yv[a].y, xv[c].y, acc[a][c], 0, 0, 0);
-                acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(yv[a].z, xv[c].z, acc[a][c], 0, 0, 0);
-                acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(yv[a].w, xv[c].w, acc[a][c], 0, 0, 0);
-            }
+            for (int c = 0; c < 4; ++c) xb16[c] = ogc_pack_bf16(xv[c].x, xv[c].y, xv[c].z, xv[c].w);
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(yb16[a], xb16[c], acc[a][c], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(yv[a].x, xv[c].x, acc[a][c], 0, 0, 0);
+                    acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(yv[a].y, xv[c].y, acc[a][c], 0, 0, 0);
+                    acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(yv[a].z, xv[c].z, acc[a][c], 0, 0, 0);
+                    acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(yv[a].w, xv[c].w, acc[a][c], 0, 0, 0);
+                }
+        }
     };
 
     float *buf0 = ws_lds, *buf1 = ws_lds + WS_ROWS * WS_LD;
@@ -414,7 +429,7 @@ bool wgrad_shared_enabled() {
 // true when the launch was made
 bool wgrad_shared_launch(int b, int cin, int cout, int hw, const float *x, const float *dy, float *dw, const float *pa,
                          const float *pb, int pro_relu, hipStream_t s, const float2 *coef2, const float2 *inj, int s_shift) {
-    if (!wgrad_shared_enabled() || g_matmul_bf16 || cin < 128 || cout < 128 || (hw % WS_POS) != 0) return false;
+    if (!wgrad_shared_enabled() || cin < 128 || cout < 128 || (hw % WS_POS) != 0) return false;
     if (inj && (1 << s_shift) < 4) return false;
     const size_t lds = sizeof(float) * 2 * 256 * WS_LD;
     const int tiles = ogc_divup(cout, 128) * ogc_divup(cin, 128);
@@ -426,17 +441,19 @@ bool wgrad_shared_launch(int b, int cin, int cout, int hw, const float *x, const
     if (spw < 8) spw = 8;
     const int gx = (int)((nstages + spw - 1) / spw);
     dim3 grid(gx, ogc_divup(cout, 128), ogc_divup(cin, 128));
-#define OGC_WGS(PROV, POOLV)                                                                                                 \
+#define OGC_WGS(PROV, POOLV, BFV)                                                                                            \
     {                                                                                                                        \
-        static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(conv1x1_wgrad_shared_kernel<PROV, POOLV>),  \
+        static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(conv1x1_wgrad_shared_kernel<PROV, POOLV, BFV>), \
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;       \
         if (!ok) { (void)hipGetLastError(); return false; }                                                                  \
-        hipLaunchKernelGGL((conv1x1_wgrad_shared_kernel<PROV, POOLV>), grid, dim3(256), lds, s, b, cin, cout, hw, (int)spw, x, \
-                           dy, dw, pa, pb, pro_relu, coef2, inj, s_shift);                                                    \
+        hipLaunchKernelGGL((conv1x1_wgrad_shared_kernel<PROV, POOLV, BFV>), grid, dim3(256), lds, s, b, cin, cout, hw, (int)spw, \
+                           x, dy, dw, pa, pb, pro_relu, coef2, inj, s_shift);                                                 \
     }
-    if (inj) { if (pa) OGC_WGS(true, true) else return false; }
-    else if (pa) OGC_WGS(true, false)
-    else OGC_WGS(false, false)
+    // (the pooled form keeps fp32 operands whatever the precision switch says, as with the register tiles)
+    if (inj) { if (pa) OGC_WGS(true, true, false) else return false; }
+    else if (g_matmul_bf16) { if (pa) OGC_WGS(true, false, true) else OGC_WGS(false, false, true) }
+    else if (pa) OGC_WGS(true, false, false)
+    else OGC_WGS(false, false, false)
 #undef OGC_WGS
     return true;
 }
