@@ -972,7 +972,7 @@ def norm_act_conv_pool_available(y_prev, gn, conv, next_gn):
         # the chunked kernel, neighbourhood extremes from the forward convolution)
         B, hw = y_prev.shape[0], y_prev.shape[2] * y_prev.shape[3]
         return (WIDE_POOL_BACKWARD and getattr(nat, "conv1x1_dgrad_pooled_wrapper", None) is not None
-                and nat.get_matmul_precision() == "fp32" and hw % 64 == 0 and B * (hw // 64) >= 1024 and B <= 65535
+                and hw % 64 == 0 and B * (hw // 64) >= 1024 and B <= 65535   # (any precision: the pooled forms keep fp32 operands)
                 and g <= 32 and cin % g == 0 and g2 <= 32 and cout % g2 == 0 and (cout // g2) % 4 == 0
                 and (cin <= 100 or (POOL_EXTREMES_WIDE and _stats_ok(nat, B, cout, cin, hw, True))))
     # LDS of ogc_conv1x1_dgrad_adjoint_pooled: the weight tile + one (scale, offset, injection, arg-max) entry per wave,
