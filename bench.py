@@ -531,9 +531,21 @@ def main():
         pc = torch.cat([batch[0][:, v] for v in range(4)]).contiguous()
         bl = KITTI_LOSS["smooth_loss_params"]["ball_q_loss_params"]
         isolated_ms = _time(lambda: ball_query(bl["radius"], bl["k"], pc, pc))
+        # ... and at four times the clouds per launch (the views of all four resident batches): what the operator reaches once its
+        # fixed costs — two dependent launches of ~5 us each before the first candidate is tested — are spread over more work
+        pc64 = torch.cat([torch.cat([bt[0][:, v] for v in range(4)]) for bt in batches]).contiguous()
+        ms64 = _time(lambda: ball_query(bl["radius"], bl["k"], pc64, pc64))
+        alg64 = pc64.shape[0] * (24 * pc64.shape[1] + 4 * pc64.shape[1] * bl["k"])
+        at64 = {
+            "kernel": "ogc_ball_query (own grid build + query), %d clouds of %d points per launch, idle GPU, 20 back to back" % (pc64.shape[0], pc64.shape[1]),
+            "avg_ms": round(ms64, 4), "algorithmic_bytes": alg64, "achieved": round(alg64 / (ms64 * 1e-3) / 1e9, 2),
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg64 / (ms64 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+            "note": "the same operator as roofline.isolated at 4 x the batch: per cloud the launch pair costs a quarter"}
+        del pc64
         pair_floor_ms = _event_pair_floor()
         skip = set(filter(None, os.environ.get("OGC_BENCH_SKIP", "").split(",")))  # (development: leave extras out)
         extras = measure_extras(pc, a) if "ops" not in skip else {}
+        extras["roofline_at_64_clouds"] = at64
         if "h2d" not in skip:
             extras["ms_per_step_with_h2d"], extras["h2d_note"] = steps_with_h2d(model, crit, opt, host_batches, it, train_step, dev)
         # steps with the FPS chain shortcut off: every encoder level runs all its sampling rounds, as it must for clouds
@@ -609,7 +621,7 @@ def main():
                             "8*B*N*M flop no longer describes the work done.  A pair of HIP events reads event_pair_floor_ms with "
                             "NOTHING between them (measured live, idle GPU): achieved / frac / avg_ms are the raw readings, "
                             "floor_removed the same launches with that floor taken off, which is what the rocprofv3 kernel "
-                            "statistics of this command show (profiles/r04_bench_kernel_stats.csv; tools/bench_ops.py has the "
+                            "statistics of this command show (profiles/rNN_bench_kernel_stats.csv of the newest round; tools/bench_ops.py has the "
                             "idle-GPU table)",
                     "all_pairs_equivalent_tpairs_per_s": round(b_ * n_ * m_ / (ms * 1e-3) / 1e12, 2)}
         others = {}
