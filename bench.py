@@ -40,12 +40,13 @@ def _newest_profile(stem):
 
 
 def _parse_op_pmc(path):
-    """tools/pmc_op2.sh output: '<kernel[:40]> calls N avg X us min .. max ..' lines and '<kernel[:40]> COUNTER v1 v2 ..' lines
-    (one value per profiled launch).  -> {kernel: {"avg_us": x, COUNTER: median, ...}}"""
+    """tools/pmc_op2.sh output: '<kernel[:60]> calls N median X us avg Y us min .. max ..' lines (files of round 4 and before:
+    no median, 'avg' is taken) and '<kernel[:40]> COUNTER v1 v2 ..' lines (one value per profiled launch).
+    -> {kernel: {"avg_us": the median launch duration, COUNTER: median, ...}}"""
     import re
     out = {}
     for line in open(path):
-        m = re.match(r"^(.{1,60}?)\s+calls\s+(\d+)\s+avg\s+([0-9.]+)\s+us", line)
+        m = re.match(r"^(.{1,60}?)\s+calls\s+(\d+)\s+(?:median|avg)\s+([0-9.]+)\s+us", line)
         if m:
             out.setdefault(m.group(1).strip()[:40], {})["avg_us"] = float(m.group(3))   # (the counter lines carry 40 characters)
             continue

@@ -4,12 +4,19 @@
 OP=${1:-ball}; B=${2:-16}; FILTER=${3:-grid}
 export TMPDIR=/tmp
 cd /tmp
-rm -rf /tmp/pm0; timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pm0 -o p -- python $GRAFT_REPO_ROOT/tools/one_op.py $OP $B 5 > /dev/null 2>&1
+rm -rf /tmp/pm0; timeout 200 rocprofv3 --kernel-trace --output-format csv -d /tmp/pm0 -o p -- python $GRAFT_REPO_ROOT/tools/one_op.py $OP $B 9 > /dev/null 2>&1
+# per kernel: calls, MEDIAN, mean, min, max of the launch durations (the first launch of a process can take several times the
+# others — code-object load —, which a mean over a handful of launches carries and the median does not)
 python - "$FILTER" <<'PY'
 import csv, glob, sys
-for r in csv.DictReader(open(glob.glob("/tmp/pm0/*kernel_stats.csv")[0])):
-    if sys.argv[1] in r["Name"]:
-        print("%-60s calls %s avg %.2f us min %.2f max %.2f" % (r["Name"][:60], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3))
+from collections import defaultdict
+d = defaultdict(list)
+for r in csv.DictReader(open(glob.glob("/tmp/pm0/*kernel_trace.csv")[0])):
+    if sys.argv[1] in r["Kernel_Name"]:
+        d[r["Kernel_Name"]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+for name, v in sorted(d.items()):
+    v.sort()
+    print("%-60s calls %d median %.2f us avg %.2f us min %.2f max %.2f" % (name[:60], len(v), v[len(v) // 2], sum(v) / len(v), v[0], v[-1]))
 PY
 for PM in "SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS SQ_INSTS_SMEM" "FETCH_SIZE" "WRITE_SIZE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE"; do
   rm -rf /tmp/pmc
