@@ -982,13 +982,16 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE, DUAL ? 2 : 1) void conv1x1_gemm
 // the streaming kernel for this shape, or false when the tile kernel should run
 // shapes the streaming kernel takes (fp32 operands only)
 // (pool: the launch also carries the sign strip of the pooled epilogue — one float per staged row)
-bool gemm_stream_eligible(int b, int M, int K, int hw, bool pro, bool pool = false) {
+// (any_precision: the variants with GroupNorm statistics / neighbourhood extremes in their epilogue keep fp32 operands under
+// `matmul_precision: bf16` too — the alternative there is the bf16 tile kernel followed by a statistics pass of its own, and for
+// a pooled tail the dense backward path)
+bool gemm_stream_eligible(int b, int M, int K, int hw, bool pro, bool pool = false, bool any_precision = false) {
     const int Kq = (K + 3) / 4, Mt = (M + 63) / 64;
     const long long ntiles = (long long)b * (hw / 64);
     const size_t lds = ((size_t)Mt * 64 * ogc_a_ld(Kq) + (pro ? WG_WAVES * 2 * FW_KQ_MAX * 4 : 0)) * sizeof(float) +
                        WG_WAVES * 4 * 16 * 2 * sizeof(double) + (pool ? (size_t)Mt * 64 * sizeof(float) : 0);
     static const bool off = getenv("OGC_GEMM_STREAM") && getenv("OGC_GEMM_STREAM")[0] == '0';
-    return !(off || g_matmul_bf16 || (hw & 63) != 0 || Kq <= 25 || Kq > FW_KQ_MAX || lds > 156 * 1024 || ntiles < 2048 ||
+    return !(off || (g_matmul_bf16 && !any_precision) || (hw & 63) != 0 || Kq <= 25 || Kq > FW_KQ_MAX || lds > 156 * 1024 || ntiles < 2048 ||
              ntiles >= (1ll << 31));
 }
 
@@ -1000,7 +1003,7 @@ bool gemm_stream_launch(int b, int M, int K, int hw, const float *w, const float
     const long long ntiles = (long long)b * (hw / 64);
     const size_t lds = ((size_t)Mt * 64 * ogc_a_ld(Kq) + (PRO ? WG_WAVES * 2 * FW_KQ_MAX * 4 : 0)) * sizeof(float) +
                        WG_WAVES * 4 * 16 * 2 * sizeof(double) + (POOL ? (size_t)Mt * 64 * sizeof(float) : 0);
-    if (!gemm_stream_eligible(b, M, K, hw, PRO, POOL) || lds > 156 * 1024) return false;
+    if (!gemm_stream_eligible(b, M, K, hw, PRO, POOL, STATS) || lds > 156 * 1024) return false;
     const int wgs = (int)(ntiles / WG_WAVES < 256 ? ntiles / WG_WAVES : 256);
 #define OGC_STREAM_D(KQV, EX, DU, WGS)                                                                                       \
     do {                                                                                                                     \
@@ -1037,7 +1040,7 @@ int gemm_launch(int b, int M, int K, int hw, int groups, const float *w, const f
                 const float *pa, const float *pb, int pro_relu, hipStream_t s, PoolOut pool = PoolOut()) {
     const int Kq = (K + 3) / 4;
     if constexpr (!T && (!POOL || (STATS && PRO))) {
-        if (!g_matmul_bf16 &&
+        if ((!g_matmul_bf16 || STATS) &&
             gemm_stream_launch<PRO, STATS, POOL>(b, M, K, hw, w, in, out, pa, pb, pro_relu, s, groups, stats, pool))
             return OGC_OK;
     }
@@ -1102,7 +1105,7 @@ extern "C" int ogc_conv1x1_gn_slots(void) { return GN_SLOTS; }
 extern "C" int ogc_conv1x1_gemm_stats_supported(int b, int M, int K, int hw, int affine) {
     // can ogc_conv1x1_gemm_gnstats (affine = 0) / ogc_conv1x1_gemm_affine with groups > 0 (affine = 1) take this shape?
     if (b < 1 || M < 1 || K < 1 || hw < 1) return 0;
-    return (K <= 100 || gemm_stream_eligible(b, M, K, hw, affine != 0)) ? 1 : 0;
+    return (K <= 100 || gemm_stream_eligible(b, M, K, hw, affine != 0, false, true)) ? 1 : 0;
 }
 
 extern "C" int ogc_conv1x1_gemm_stream_supported(int b, int M, int K, int hw) {
@@ -1129,7 +1132,7 @@ extern "C" int ogc_conv1x1_gemm_gnstats(int b, int M, int K, int hw, int groups,
                       groups);
         return OGC_ERR_UNSUPPORTED;
     }
-    if (K > 100 && !gemm_stream_eligible(b, M, K, hw, false)) {
+    if (K > 100 && !gemm_stream_eligible(b, M, K, hw, false, false, true)) {
         // with the 33- and 40-float4 input tiles the TILE kernel has no registers to spare: the statistics epilogue costs
         // 0.08-0.15 ms there against 0.05-0.10 ms for the separate statistics pass (tools/bench_ops.py --ops conv); the
         // streaming kernel (ogc_conv1x1_gemm_stats_supported) adds them for ~nothing
@@ -1206,7 +1209,7 @@ extern "C" int ogc_conv1x1_gemm_affine(int b, int M, int K, int hw, int relu, in
     hipStream_t s = (hipStream_t)stream;
     if (groups > 0) {
         OGC_REQUIRE(stats, "ogc_conv1x1_gemm_affine: null pointer");
-        if (groups > 32 || M % groups != 0 || (M / groups) % 4 != 0 || (K > 100 && !gemm_stream_eligible(b, M, K, hw, true))) {
+        if (groups > 32 || M % groups != 0 || (M / groups) % 4 != 0 || (K > 100 && !gemm_stream_eligible(b, M, K, hw, true, false, true))) {
             ogc_set_error("ogc_conv1x1_gemm_affine: output statistics need groups <= 32, (M / groups) %% 4 == 0, K <= 100 "
                           "(or a shape of the streaming kernel: ogc_conv1x1_gemm_stats_supported)");
             return OGC_ERR_UNSUPPORTED;
@@ -1234,7 +1237,7 @@ extern "C" int ogc_conv1x1_gemm_affine_pool(int b, int M, int K, int hw, int rel
     if (rc != OGC_OK) return rc;
     OGC_REQUIRE(pa && pb && next_gamma && stats && yext && aext, "ogc_conv1x1_gemm_affine_pool: null pointer");
     if (groups < 1 || groups > 32 || M % groups != 0 || (M / groups) % 4 != 0 ||
-        (K > 100 && !gemm_stream_eligible(b, M, K, hw, true, true)) || (nsample != 16 && nsample != 32 && nsample != 64) ||
+        (K > 100 && !gemm_stream_eligible(b, M, K, hw, true, true, true)) || (nsample != 16 && nsample != 32 && nsample != 64) ||
         hw % nsample != 0) {
         ogc_set_error("ogc_conv1x1_gemm_affine_pool: needs 1 <= groups <= 32, (M / groups) %% 4 == 0, K <= 100 and "
                       "nsample in {16, 32, 64} dividing hw (M=%d, groups=%d, K=%d, nsample=%d)", M, groups, K, nsample);

@@ -158,9 +158,16 @@ POOL_EXTREMES_WIDE = True
 POOL_SUMS_FROM_EXTREMES = True
 
 
+# Under `matmul_precision: bf16` the layers of more than 100 input channels whose convolution also produces the next GroupNorm's
+# statistics (and, for a tail, the neighbourhood extremes) CAN keep fp32 operands on the streaming kernel (OGC_BF16_WIDE_STATS=1);
+# default off: bf16 operands on the tile kernel with a statistics pass of its own behind it measured faster at C2 (25.7 against
+# 26.3 ms per step: the fp32 MFMA time of those layers outweighs the passes it saves).
+WIDE_STATS_UNDER_BF16 = __import__("os").environ.get("OGC_BF16_WIDE_STATS", "0") == "1"
+
+
 def _stats_ok(nat, B, cout, cin, hw, affine):
     fn = getattr(nat, "conv1x1_gemm_stats_supported", None)
-    return fn is not None and nat.get_matmul_precision() == "fp32" and fn(B, cout, cin, hw, affine)
+    return (fn is not None and (WIDE_STATS_UNDER_BF16 or nat.get_matmul_precision() == "fp32") and fn(B, cout, cin, hw, affine))
 
 
 def _gemm_ok(K, hw):
