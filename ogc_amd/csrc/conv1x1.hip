@@ -1040,7 +1040,8 @@ int gemm_launch(int b, int M, int K, int hw, int groups, const float *w, const f
                 const float *pa, const float *pb, int pro_relu, hipStream_t s, PoolOut pool = PoolOut()) {
     const int Kq = (K + 3) / 4;
     if constexpr (!T && (!POOL || (STATS && PRO))) {
-        if ((!g_matmul_bf16 || STATS) &&
+        static const bool wide_fp32 = [] { const char *e = getenv("OGC_BF16_WIDE_STATS"); return e && e[0] == '1'; }();
+        if ((!g_matmul_bf16 || (STATS && wide_fp32)) &&
             gemm_stream_launch<PRO, STATS, POOL>(b, M, K, hw, w, in, out, pa, pb, pro_relu, s, groups, stats, pool))
             return OGC_OK;
     }
@@ -1063,8 +1064,10 @@ int gemm_launch(int b, int M, int K, int hw, int groups, const float *w, const f
     else if (Kq <= 8) OGC_GEMM(8);
     else if (Kq <= 16) OGC_GEMM(16);
     else if (Kq <= 25) OGC_GEMM(25);
-    else if constexpr (POOL) return OGC_ERR_UNSUPPORTED; // the pooled variant is only offered with statistics, K <= 100
+    else if (POOL && !g_matmul_bf16) return OGC_ERR_UNSUPPORTED; // fp32 operands: the pooled variant is the streaming kernel's beyond K = 100
     else {
+        // (bf16 operands: the register tile has MFMA time to spare at these widths — the kernel is bound by its loads and stores —
+        // so the statistics / extremes epilogues ride along here too instead of a pass of their own)
         if (Kq <= 33) OGC_GEMM(33);
         else OGC_GEMM(40);
     }
@@ -1105,7 +1108,7 @@ extern "C" int ogc_conv1x1_gn_slots(void) { return GN_SLOTS; }
 extern "C" int ogc_conv1x1_gemm_stats_supported(int b, int M, int K, int hw, int affine) {
     // can ogc_conv1x1_gemm_gnstats (affine = 0) / ogc_conv1x1_gemm_affine with groups > 0 (affine = 1) take this shape?
     if (b < 1 || M < 1 || K < 1 || hw < 1) return 0;
-    return (K <= 100 || gemm_stream_eligible(b, M, K, hw, affine != 0, false, true)) ? 1 : 0;
+    return (K <= 100 || g_matmul_bf16 || gemm_stream_eligible(b, M, K, hw, affine != 0, false, true)) ? 1 : 0;
 }
 
 extern "C" int ogc_conv1x1_gemm_stream_supported(int b, int M, int K, int hw) {
@@ -1132,7 +1135,7 @@ extern "C" int ogc_conv1x1_gemm_gnstats(int b, int M, int K, int hw, int groups,
                       groups);
         return OGC_ERR_UNSUPPORTED;
     }
-    if (K > 100 && !gemm_stream_eligible(b, M, K, hw, false, false, true)) {
+    if (K > 100 && !g_matmul_bf16 && !gemm_stream_eligible(b, M, K, hw, false, false, true)) {
         // with the 33- and 40-float4 input tiles the TILE kernel has no registers to spare: the statistics epilogue costs
         // 0.08-0.15 ms there against 0.05-0.10 ms for the separate statistics pass (tools/bench_ops.py --ops conv); the
         // streaming kernel (ogc_conv1x1_gemm_stats_supported) adds them for ~nothing
@@ -1209,7 +1212,7 @@ extern "C" int ogc_conv1x1_gemm_affine(int b, int M, int K, int hw, int relu, in
     hipStream_t s = (hipStream_t)stream;
     if (groups > 0) {
         OGC_REQUIRE(stats, "ogc_conv1x1_gemm_affine: null pointer");
-        if (groups > 32 || M % groups != 0 || (M / groups) % 4 != 0 || (K > 100 && !gemm_stream_eligible(b, M, K, hw, true, false, true))) {
+        if (groups > 32 || M % groups != 0 || (M / groups) % 4 != 0 || (K > 100 && !g_matmul_bf16 && !gemm_stream_eligible(b, M, K, hw, true, false, true))) {
             ogc_set_error("ogc_conv1x1_gemm_affine: output statistics need groups <= 32, (M / groups) %% 4 == 0, K <= 100 "
                           "(or a shape of the streaming kernel: ogc_conv1x1_gemm_stats_supported)");
             return OGC_ERR_UNSUPPORTED;
@@ -1237,7 +1240,7 @@ extern "C" int ogc_conv1x1_gemm_affine_pool(int b, int M, int K, int hw, int rel
     if (rc != OGC_OK) return rc;
     OGC_REQUIRE(pa && pb && next_gamma && stats && yext && aext, "ogc_conv1x1_gemm_affine_pool: null pointer");
     if (groups < 1 || groups > 32 || M % groups != 0 || (M / groups) % 4 != 0 ||
-        (K > 100 && !gemm_stream_eligible(b, M, K, hw, true, true, true)) || (nsample != 16 && nsample != 32 && nsample != 64) ||
+        (K > 100 && !g_matmul_bf16 && !gemm_stream_eligible(b, M, K, hw, true, true, true)) || (nsample != 16 && nsample != 32 && nsample != 64) ||
         hw % nsample != 0) {
         ogc_set_error("ogc_conv1x1_gemm_affine_pool: needs 1 <= groups <= 32, (M / groups) %% 4 == 0, K <= 100 and "
                       "nsample in {16, 32, 64} dividing hw (M=%d, groups=%d, K=%d, nsample=%d)", M, groups, K, nsample);

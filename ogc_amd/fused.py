@@ -158,16 +158,17 @@ POOL_EXTREMES_WIDE = True
 POOL_SUMS_FROM_EXTREMES = True
 
 
-# Under `matmul_precision: bf16` the layers of more than 100 input channels whose convolution also produces the next GroupNorm's
-# statistics (and, for a tail, the neighbourhood extremes) CAN keep fp32 operands on the streaming kernel (OGC_BF16_WIDE_STATS=1);
-# default off: bf16 operands on the tile kernel with a statistics pass of its own behind it measured faster at C2 (25.7 against
-# 26.3 ms per step: the fp32 MFMA time of those layers outweighs the passes it saves).
-WIDE_STATS_UNDER_BF16 = __import__("os").environ.get("OGC_BF16_WIDE_STATS", "0") == "1"
+# Layers of more than 100 input channels whose convolution also produces the next GroupNorm's statistics (and, for a tail, the
+# neighbourhood extremes): fp32 operands -> the streaming kernel's epilogues; bf16 operands (round 5) -> the same epilogues on the
+# register-tile kernel, which has MFMA time to spare at that precision.  OGC_BF16_WIDE_STATS=1 keeps such layers on the fp32
+# streaming kernel under bf16 as well (measured slower at C2: 26.3 against 25.7 ms per step); OGC_BF16_WIDE_STATS=0 restores the
+# round-4 behaviour (a statistics pass of its own behind the bf16 product, the dense backward path behind a wide pooled tail).
+BF16_WIDE_STATS = __import__("os").environ.get("OGC_BF16_WIDE_STATS", "") != "0"
 
 
 def _stats_ok(nat, B, cout, cin, hw, affine):
     fn = getattr(nat, "conv1x1_gemm_stats_supported", None)
-    return (fn is not None and (WIDE_STATS_UNDER_BF16 or nat.get_matmul_precision() == "fp32") and fn(B, cout, cin, hw, affine))
+    return (fn is not None and (BF16_WIDE_STATS or nat.get_matmul_precision() == "fp32") and fn(B, cout, cin, hw, affine))
 
 
 def _gemm_ok(K, hw):

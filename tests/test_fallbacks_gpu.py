@@ -23,12 +23,11 @@ EXPECTED = {
     "kittisf": {},
     # C5, the same network at 16384 points, one-frame loss
     "waymo": {},
-    # C2 (bf16 operands): the two-level encoder of segnet_ogcdr ends in 128- and 256-channel tails as well.  Their pooled backward
-    # forms keep fp32 operands and run under either precision (round 5); the 128 -> 256 tail still misses: its forward needs the
-    # streaming kernel's GroupNorm statistics + neighbourhood extremes, which exist for fp32 operands only.  norm_act_conv: the
-    # 256 -> 128 layer of the first feature-propagation module has more input channels than the GEMM with the folded
-    # normalisation takes (K <= 160)
-    "ogcdr": {"norm_act_conv_pool_available": 1, "norm_act_conv_available": 1},
+    # C2 (bf16 operands): the two-level encoder of segnet_ogcdr ends in 128- and 256-channel tails as well; since round 5 both
+    # run as one node under bf16 too (statistics + neighbourhood extremes in the epilogue of the bf16 tile kernel, the pooled
+    # backward forms with fp32 operands).  norm_act_conv: the 256 -> 128 layer of the first feature-propagation module has more
+    # input channels than the GEMM with the folded normalisation takes (K <= 160)
+    "ogcdr": {"norm_act_conv_available": 1},
     # C1 (512 points, 2 samples): the deeper of the two wide tails has fewer than 1024 tiles of 64 positions
     "sapien": {"norm_act_conv_pool_available": 1, "norm_act_conv_available": 1},
 }
