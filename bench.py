@@ -323,13 +323,15 @@ def measure_extras(pc, a):
     ms_c = _time(lambda: nat.knn_clamped_wrapper(B, N, N, k, r, pc, pc, d, i))
     ms_p = _time(lambda: nat.knn_wrapper(B, N, N, k, pc, pc, d, i))
     out["roofline_knn"] = {
-        "kernel": "ogc_knn_clamped (grid_build_kernel + knn_cells_kernel<%d> + knn_grid_kernel<1> for the rows it leaves): the smoothness "
+        "kernel": "ogc_knn_clamped (grid_build_split_kernel + knn_cells_kernel<%d> + knn_grid_kernel<1> for the rows it leaves): the smoothness "
                   "term's k-NN, k=%d clamped at %g m" % (k, k, r),
         "bound": "hbm", "achieved": round(alg / ms_c / 1e6, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(alg / ms_c / 1e6 / HBM_PEAK_GBS, 5), "avg_ms": round(ms_c, 4), "algorithmic_bytes": alg,
         "shape": {"B": B, "n": N, "m": N, "k": k, "radius": r},
         "unclamped_ogc_knn": {"avg_ms": round(ms_p, 4), "achieved": round(alg / ms_p / 1e6, 2),
-                              "frac": round(alg / ms_p / 1e6 / HBM_PEAK_GBS, 5)},
+                              "frac": round(alg / ms_p / 1e6 / HBM_PEAK_GBS, 5),
+                              "kernel": "ogc_knn (grid_build_split_kernel + knn_wave_kernel<0>: a wavefront per query, threshold selection "
+                                        "+ 64-lane bitonic network; knn_grid_kernel for rows it marks)"},
         "note": "idle GPU, 20 back-to-back launches; the radius-limited search stops once the scanned cells cover the clamp "
                 "radius (neighbours beyond it are replaced by the nearest one in the output).  Both searches are bound by "
                 "instruction issue, not by HBM (SURVEY 8d): the HBM fraction is reported because the north star asks for it"}
