@@ -1,464 +1,9 @@
-// conv1x1.hip — weight gradient of the per-point (1x1) convolutions of the shared MLPs, on the fp32 MFMA pipe.
-//
-//     dW[co, ci] = sum_b sum_p dY[b, co, p] * X[b, ci, p]          X (B, Cin, HW), dY (B, Cout, HW), fp32, NCHW
-//
-// Replaces the weight-gradient half of the nn.Conv2d(kernel 1x1, bias=False) layers of SharedMLP
-// (reference: utils/nn_util.py:45-85, :155-172).  MIOpen serves this shape with an NHWC implicit-GEMM kernel wrapped
-// in two full-tensor NCHW->NHWC transposes (x and dy): on the C4 training step that is ~3 ms of transposes plus ~2 ms
-// of igemm per step.  Here the tensors are read once, in place:
-//   * GEMM view: M = Cout, N = Cin, K = B*HW (millions) — a tiny output and a huge reduction, i.e. a streaming,
-//     HBM-bound kernel; v_mfma_f32_16x16x4_f32 (exact fp32 FMA chains, 157 TF peak) keeps the math off the critical path;
-//   * operand layout without any shuffle: for a step of 16 positions, lane (i = l & 15, k = l >> 4) loads ONE float4
-//     = row (c0 + i), positions pb + 4k .. 4k+3.  MFMA k-slot k of sub-step s is position pb + 4k + s for BOTH
-//     operands, so component s of the two float4s are directly the A and B operands of sub-step s;
-//   * a wave owns a (16*COB) x (16*CIB) tile of dW in registers and strides over the positions; the next step's
-//     loads are issued before the current step's MFMAs; the four waves of a workgroup are reduced through LDS,
-//     workgroups through fp32 atomics into dW (zeroed by this entry point).
-#include <stdlib.h>
+// conv1x1.hip — forward and input-gradient GEMMs of the per-point (1x1) convolutions of the shared MLPs on the MFMA pipe
+// (reference: utils/nn_util.py:45-85); the weight gradients live in conv1x1_wgrad.hip, what both share in conv1x1_shared.h.
+#include "conv1x1_shared.h"
 
-#include "ogc_common.h"
-#include "conv_stage.h"
+int ogc_g_matmul_bf16 = 0;
 
-namespace {
-
-typedef float v4f __attribute__((ext_vector_type(4)));
-typedef short v4s __attribute__((ext_vector_type(4)));  // four bf16 MFMA operand values
-
-constexpr int WG_WAVES = 4;
-
-// Operand precision of the convolution kernels (ogc_set_matmul_precision): 0 = fp32 operands on
-// v_mfma_f32_16x16x4_f32 (default; results are exact fp32 FMA chains), 1 = operands rounded to bf16 (nearest even) on
-// v_mfma_f32_16x16x16_bf16, fp32 accumulation, tensors in memory stay fp32 — what autocast(bfloat16) gives the
-// reference's Conv2d layers (BASELINE config "OGC-DR ..., bf16").  Layers of 128 channels and more sit on the fp32
-// MFMA roof (157 TFLOP/s); with bf16 operands (2.5 PFLOP/s) they fall back onto the HBM roof.
-int g_matmul_bf16 = 0;
-
-__device__ __forceinline__ v4s ogc_pack_bf16(float a, float b, float c, float d) {
-    typedef float v2f __attribute__((ext_vector_type(2)));
-    typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
-    union { v2bf h[2]; v4s s; } u;
-    u.h[0] = __builtin_convertvector((v2f){a, b}, v2bf); // one v_cvt_pk_bf16_f32 per pair
-    u.h[1] = __builtin_convertvector((v2f){c, d}, v2bf);
-    return u.s;
-}
-
-// PRO: the layer's input was never materialised — x holds the previous layer's raw convolution output and the operand
-// is act(pa[b, ci] * x + pb[b, ci]), recomputed while loading (see conv1x1_gemm_kernel).
-// POOLED: dy is not stored — `dy` holds y, the convolution's raw output, and the gradient of the pooled GroupNorm behind it is
-// rebuilt while y is loaded:  g_y[row, pos] = fmaf(c2, y, c3) + (pos % S == arg ? ag : 0)  with (c2, c3) = coef2[b, row] and
-// (ag, arg) = inj[b, row, pos / S] (ogc_group_norm_maxpool_bwd_sparse; a step's 16 positions lie inside one neighbourhood,
-// S = 16, 32, 64) — the expression of gn_maxpool_bwd_dx_kernel, bit for bit.
-template <int COB, int CIB, bool PRO, bool BF, bool POOLED = false>
-__global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_wgrad_kernel(int batch, int cin, int cout, int hw,
-                                                                           int steps_per_wave,
-                                                                           const float *__restrict__ x,
-                                                                           const float *__restrict__ dy,
-                                                                           float *__restrict__ dw,
-                                                                           const float *__restrict__ aff_a,
-                                                                           const float *__restrict__ aff_b, int pro_relu,
-                                                                           const float2 *__restrict__ coef2 = nullptr,
-                                                                           const float2 *__restrict__ inj = nullptr,
-                                                                           int s_shift = 0) {
-    // the four waves' partial tiles, one slab each (plain stores: ds_add_f32 sustains well under one lane per cycle), summed
-    // by the threads that send them on
-    __shared__ float red[WG_WAVES][COB * CIB * 256];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int i = lane & 15, k = lane >> 4;
-    const int co0 = blockIdx.y * (16 * COB), ci0 = blockIdx.z * (16 * CIB);
-    const int steps_per_img = hw >> 4;
-    const long long nsteps = (long long)batch * steps_per_img;
-    const long long first = ((long long)blockIdx.x * WG_WAVES + wave) * steps_per_wave;
-    // this wavefront's steps: [first, first + mine) — everything about the walk is wave-uniform (SALU, scalar branches)
-    const int mine = (int)max(0LL, min((long long)steps_per_wave, nsteps - first));
-
-    v4f acc[COB][CIB];
-#pragma unroll
-    for (int a = 0; a < COB; ++a)
-#pragma unroll
-        for (int c = 0; c < CIB; ++c) acc[a][c] = (v4f){0.f, 0.f, 0.f, 0.f};
-
-    // The wave walks consecutive steps, so (image, position) advance incrementally: one division per wave instead of a
-    // 64-bit division per step (which cost more issue slots than the step's 64 MFMAs).
-    const long long start = min(first, nsteps - 1);
-    int cur_b = (int)(start / steps_per_img);
-    int cur_off = (int)(start - (long long)cur_b * steps_per_img);
-    int left = mine - 1; // steps after the current one; the walk stays on the last step once they are used up
-    int yrow[COB], xrow[CIB], coef[CIB]; // one sample's activation fits 32-bit offsets (checked by the entry point)
-    constexpr int NP = POOLED ? COB : 1;
-    int orow[NP];
-    const int centres = hw >> s_shift, smask = (1 << s_shift) - 1;
-#pragma unroll
-    for (int a = 0; a < COB; ++a) {
-        yrow[a] = min(co0 + a * 16 + i, cout - 1) * hw;
-        if (POOLED) orow[a] = min(co0 + a * 16 + i, cout - 1);
-    }
-#pragma unroll
-    for (int c = 0; c < CIB; ++c) {
-        coef[c] = min(ci0 + c * 16 + i, cin - 1);
-        xrow[c] = coef[c] * hw;
-    }
-    // EVERY load of a step is unconditional and of the same shape: rows beyond the tensors are clamped onto the last row
-    // (they only feed rows / columns of the tile that are never stored), steps beyond the wave's share re-read its last
-    // step and are not computed with.  A load under a per-lane condition (`row < cout ? *p : 0`) becomes its own
-    // exec-masked block and the compiler then waits for ALL outstanding loads wherever it needs one — which serialised
-    // the ping-pong below: the next step's loads were waited for before the current step's MFMAs (50 % of the time of
-    // this kernel at one wavefront per SIMD).  PRO: the affine map of this lane's input channels travels WITH the step
-    // (eight cached dword loads more) for the same reason: loaded only at image changes, its wait was a vmcnt(0).
-    auto load = [&](float4(&yv)[COB], float4(&xv)[CIB], float(&fa)[CIB], float(&fb)[CIB], float2(&cc)[NP], float2(&jv)[NP],
-                    int &jpos) { // current step, then advance
-        const int pb = cur_off * 16 + 4 * k;
-        const float *yb_ = dy + (size_t)cur_b * cout * hw + pb;
-        const float *xb_ = x + (size_t)cur_b * cin * hw + pb;
-#pragma unroll
-        for (int a = 0; a < COB; ++a) yv[a] = *reinterpret_cast<const float4 *>(yb_ + yrow[a]);
-        if constexpr (POOLED) { // (travels with the step like the affine map below: the sample may change from step to step)
-#pragma unroll
-            for (int a = 0; a < COB; ++a) {
-                const size_t r = (size_t)cur_b * cout + orow[a];
-                cc[a] = coef2[r];
-                jv[a] = inj[r * centres + (pb >> s_shift)];
-            }
-            jpos = pb & smask; // this lane's first position inside the neighbourhood
-        }
-#pragma unroll
-        for (int c = 0; c < CIB; ++c) {
-            xv[c] = *reinterpret_cast<const float4 *>(xb_ + xrow[c]);
-            if (PRO) {
-                fa[c] = aff_a[(size_t)cur_b * cin + coef[c]];
-                fb[c] = aff_b[(size_t)cur_b * cin + coef[c]];
-            }
-        }
-        if (left > 0) {
-            --left;
-            if (++cur_off == steps_per_img) { cur_off = 0; ++cur_b; }
-        }
-    };
-    auto fma16 = [&](const float4(&yraw)[COB], const float4(&xraw)[CIB], const float(&fa)[CIB], const float(&fb)[CIB],
-                     const float2(&cc)[NP], const float2(&jv)[NP], int jpos) {
-        float4 yv[COB];
-#pragma unroll
-        for (int a = 0; a < COB; ++a) {
-            yv[a] = yraw[a];
-            if constexpr (POOLED) {
-                const int rel = __float_as_int(jv[a].y) - jpos;
-                const float ag = jv[a].x;
-                yv[a].x = fmaf(cc[a].x, yraw[a].x, cc[a].y) + (rel == 0 ? ag : 0.f);
-                yv[a].y = fmaf(cc[a].x, yraw[a].y, cc[a].y) + (rel == 1 ? ag : 0.f);
-                yv[a].z = fmaf(cc[a].x, yraw[a].z, cc[a].y) + (rel == 2 ? ag : 0.f);
-                yv[a].w = fmaf(cc[a].x, yraw[a].w, cc[a].y) + (rel == 3 ? ag : 0.f);
-            }
-        }
-        float4 xv[CIB];
-#pragma unroll
-        for (int c = 0; c < CIB; ++c) {
-            xv[c] = xraw[c];
-            if (PRO) {
-                float4 v = xraw[c];
-                v.x = fmaf(fa[c], v.x, fb[c]); v.y = fmaf(fa[c], v.y, fb[c]);
-                v.z = fmaf(fa[c], v.z, fb[c]); v.w = fmaf(fa[c], v.w, fb[c]);
-                if (pro_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                xv[c] = v;
-            }
-        }
-        if constexpr (BF) {
-            // the lane's four consecutive positions are the four k-slots 4k .. 4k+3 of ONE 16x16x16 MFMA
-            v4s yb16[COB], xb16[CIB];
-#pragma unroll
-            for (int a = 0; a < COB; ++a) yb16[a] = ogc_pack_bf16(yv[a].x, yv[a].y, yv[a].z, yv[a].w);
-#pragma unroll
-            for (int c = 0; c < CIB; ++c) xb16[c] = ogc_pack_bf16(xv[c].x, xv[c].y, xv[c].z, xv[c].w);
-#pragma unroll
-            for (int a = 0; a < COB; ++a)
-#pragma unroll
-                for (int c = 0; c < CIB; ++c)
-                    acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(yb16[a], xb16[c], acc[a][c], 0, 0, 0);
-        } else {
-#pragma unroll
-            for (int a = 0; a < COB; ++a)
-#pragma unroll
-                for (int c = 0; c < CIB; ++c) {
-                    acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(yv[a].x, xv[c].x, acc[a][c], 0, 0, 0);
-                    acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(yv[a].y, xv[c].y, acc[a][c], 0, 0, 0);
-                    acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(yv[a].z, xv[c].z, acc[a][c], 0, 0, 0);
-                    acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(yv[a].w, xv[c].w, acc[a][c], 0, 0, 0);
-                }
-        }
-    };
-
-    float4 ya[COB], xa[CIB], yb[COB], xb[CIB];
-    float faa[CIB], fba[CIB], fab[CIB], fbb[CIB];
-    float2 cca[NP], ccb[NP], jva[NP], jvb[NP];
-    int jpa = 0, jpb = 0;
-    load(ya, xa, faa, fba, cca, jva, jpa);
-    int s = 0;
-    for (; s + 1 < mine; s += 2) {               // ping-pong registers: next step's loads fly during the MFMAs.  No branch inside
-        load(yb, xb, fab, fbb, ccb, jvb, jpb);   // the loop body: with one, the accumulators travelled AGPR -> VGPR -> AGPR every round
-        fma16(ya, xa, faa, fba, cca, jva, jpa);
-        load(ya, xa, faa, fba, cca, jva, jpa);
-        fma16(yb, xb, fab, fbb, ccb, jvb, jpb);
-    }
-    if (s < mine) fma16(ya, xa, faa, fba, cca, jva, jpa);
-
-    // C/D layout of 16x16x4: lane l holds rows (l >> 4) * 4 + r (r = 0..3) of column l & 15
-#pragma unroll
-    for (int a = 0; a < COB; ++a)
-#pragma unroll
-        for (int c = 0; c < CIB; ++c)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) red[wave][(a * CIB + c) * 256 + (k * 4 + r) * 16 + i] = acc[a][c][r];
-    __syncthreads();
-    for (int t = threadIdx.x; t < COB * CIB * 256; t += WG_WAVES * OGC_WAVE) {
-        const int blk = t >> 8, a = blk / CIB, c = blk % CIB;
-        const int row = co0 + a * 16 + ((t & 255) >> 4), col = ci0 + c * 16 + (t & 15);
-        const float v = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
-        if (row < cout && col < cin && v != 0.0f) unsafeAtomicAdd(dw + (size_t)row * cin + col, v);
-    }
-}
-
-template <int COB, int CIB>
-void wgrad_launch(int b, int cin, int cout, int hw, const float *x, const float *dy, float *dw, const float *pa,
-                  const float *pb, int pro_relu, hipStream_t s, const float2 *coef2 = nullptr, const float2 *inj = nullptr,
-                  int s_shift = 0) {
-    const long long nsteps = (long long)b * (hw >> 4);
-    const int tiles = ogc_divup(cout, 16 * COB) * ogc_divup(cin, 16 * CIB);
-    // ~2048 waves over the chip per tile pair, but at least 8 steps (128 positions) per wave
-    // Wavefronts over the chip per tile pair.  The 64x64 tiles (COB = CIB = 4) run best with ~1024 wavefronts in total —
-    // one workgroup per CU, twice the positions per wavefront, half as many LDS reductions and atomic epilogues
-    // (64 -> 64: 0.169 -> 0.150 ms, 128 -> 128: 0.258 -> 0.222 ms) — unless the tile grid is ragged (131 -> 128: six
-    // tiles, two of them nearly empty), where the finer split balances better; the small tiles keep ~2048.
-    long long waves = ((COB * CIB == 16 && tiles <= 4) ? 1024 : 2048) / tiles;
-    if (waves < 256) waves = 256;
-    long long spw = (nsteps + waves - 1) / waves;
-    if (spw < 8) spw = 8;
-    spw = (spw + 1) / 2 * 2;
-    const int wgs = (int)((nsteps + spw * WG_WAVES - 1) / (spw * WG_WAVES));
-    dim3 grid(wgs, ogc_divup(cout, 16 * COB), ogc_divup(cin, 16 * CIB));
-#define OGC_WGRAD(PROV, BFV)                                                                                          \
-    hipLaunchKernelGGL((conv1x1_wgrad_kernel<COB, CIB, PROV, BFV>), grid, dim3(WG_WAVES * OGC_WAVE), 0, s, b, cin, cout, \
-                       hw, (int)spw, x, dy, dw, pa, pb, pro_relu)
-    if (inj) { // pooled form of dy (fp32 operands, previous layer's norm folded in): see POOLED
-        hipLaunchKernelGGL((conv1x1_wgrad_kernel<COB, CIB, true, false, true>), grid, dim3(WG_WAVES * OGC_WAVE), 0, s, b, cin, cout,
-                           hw, (int)spw, x, dy, dw, pa, pb, pro_relu, coef2, inj, s_shift);
-    } else if (g_matmul_bf16) {
-        if (pa) OGC_WGRAD(true, true);
-        else OGC_WGRAD(false, true);
-    } else {
-        if (pa) OGC_WGRAD(true, false);
-        else OGC_WGRAD(false, false);
-    }
-#undef OGC_WGRAD
-}
-
-
-// ---- the same weight gradient for WIDE layers (cin, cout >= 128): a 128 x 128 tile of dW per workgroup, operands shared through LDS
-// conv1x1_wgrad_kernel gives every wavefront a 64 x 64 tile and its own operand loads: at 128 -> 256 channels that is 8 tile
-// pairs, every dy element fetched by two of them and every x element by four — 2.1 GB through the L2s for 0.8 GB of tensors, at
-// 81 TFLOP/s.  Here the four wavefronts of a workgroup take the four 64 x 64 quarters of one 128 x 128 tile and walk the SAME
-// positions: a stage is 32 positions of 128 dy rows and 128 x rows (32 KiB), loaded ONCE by the workgroup (thread t: the 16-byte
-// piece t & 7 of rows (t >> 3) + 32 j — full 128-byte lines), transformed once (PRO: the previous layer's GroupNorm + ReLU on x;
-// POOLED: the pooled GroupNorm's gradient rebuilt from y, as in the kernel above, bit for bit) and parked in LDS, from where
-// every wavefront reads its 64 + 64 rows in the MFMA operand layout of the kernel above (lane (i, k): row i, positions 4k .. 4k + 3).
-// Stages are double-buffered: the loads of stage s + 1 are issued before the 128 MFMAs of stage s, their transform and LDS
-// write sit between the stage's two 16-position halves, one barrier per stage.  Two workgroups per CU (72 KiB of LDS each), so
-// one's barrier is the other's matrix time.  dy is read once per 128 input channels, x once per 128 output channels.
-constexpr int WS_POS = 32;              // positions per stage
-constexpr int WS_LD = WS_POS + 4;       // row stride in LDS (floats): 144 bytes, 16-byte aligned, rows spread over the banks
-
-// (Measured, 16 x 32768 positions: 128 -> 256 channels 0.480 -> 0.367 ms = 94 TFLOP/s, 256 -> 128 0.439 -> 0.354, 128 -> 128
-// 0.195 -> 0.198, with the previous layer's norm folded in 0.226 -> 0.202.  A 256 x 128 tile on eight wavefronts — both tensors
-// read from memory exactly once — gave the same 0.367 ms: the kernel is no longer bound by the operand traffic.)
-// BF: operands rounded to bf16 on v_mfma_f32_16x16x16_bf16 (ogc_set_matmul_precision), as in conv1x1_wgrad_kernel.
-template <bool PRO, bool POOLED, bool BF = false>
-__global__ __launch_bounds__(256, 2) void conv1x1_wgrad_shared_kernel(int batch, int cin, int cout, int hw, int stages_per_wg,
-                                                                      const float *__restrict__ x, const float *__restrict__ dy,
-                                                                      float *__restrict__ dw, const float *__restrict__ aff_a,
-                                                                      const float *__restrict__ aff_b, int pro_relu,
-                                                                      const float2 *__restrict__ coef2,
-                                                                      const float2 *__restrict__ inj, int s_shift) {
-    constexpr int YROWS = 128, WS_ROWS = YROWS + 128, YJ = 4, XJ = 4, NJ = YJ + XJ; // pieces per thread: dy, x
-    constexpr int RSTEP = 32;                                        // rows between a thread's pieces
-    extern __shared__ __attribute__((aligned(16))) float ws_lds[]; // [2][WS_ROWS][WS_LD]
-    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int i = lane & 15, k = lane >> 4;
-    const int co0 = blockIdx.y * YROWS, ci0 = blockIdx.z * 128;
-    const int half_r = wave >> 1, half_c = wave & 1;                 // this wavefront's 64 x 64 part of the tile
-    const int stages_per_img = hw / WS_POS;
-    const long long nstages = (long long)batch * stages_per_img;
-    const long long first = (long long)blockIdx.x * stages_per_wg;
-    const int mine = (int)max(0LL, min((long long)stages_per_wg, nstages - first));
-    if (mine == 0) return;                                           // (workgroup-uniform)
-
-    // my pieces of a stage: piece q of rows rr + RSTEP j (j < YJ: dy rows, then XJ x rows), clamped onto the tensors
-    const int q = t & 7, rr = t >> 3;
-    int grow[NJ], lrow[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int r = rr + RSTEP * (j < YJ ? j : j - YJ);
-        grow[j] = j < YJ ? min(co0 + r, cout - 1) : min(ci0 + r, cin - 1);
-        lrow[j] = (j < YJ ? r : YROWS + r) * WS_LD + 4 * q;
-    }
-    const int centres = POOLED ? hw >> s_shift : 0;
-    int cur_b = (int)(first / stages_per_img);
-    int cur_off = (int)(first - (long long)cur_b * stages_per_img);
-
-    float4 raw[NJ];
-    float fa[XJ], fb[XJ];
-    float2 cc[YJ], jv[YJ];
-    int jpos = 0;
-    auto fetch = [&]() { // the current stage into registers, then advance
-        const int pos = cur_off * WS_POS + 4 * q;
-        const float *yb_ = dy + (size_t)cur_b * cout * hw + pos;
-        const float *xb_ = x + (size_t)cur_b * cin * hw + pos;
-#pragma unroll
-        for (int j = 0; j < YJ; ++j) raw[j] = *reinterpret_cast<const float4 *>(yb_ + (size_t)grow[j] * hw);
-#pragma unroll
-        for (int j = YJ; j < NJ; ++j) raw[j] = *reinterpret_cast<const float4 *>(xb_ + (size_t)grow[j] * hw);
-        if constexpr (POOLED) {
-#pragma unroll
-            for (int j = 0; j < YJ; ++j) {
-                const size_t r = (size_t)cur_b * cout + grow[j];
-                cc[j] = coef2[r];
-                jv[j] = inj[r * centres + (pos >> s_shift)];
-            }
-            jpos = pos & ((1 << s_shift) - 1);
-        }
-        if constexpr (PRO) {
-#pragma unroll
-            for (int j = 0; j < XJ; ++j) {
-                fa[j] = aff_a[(size_t)cur_b * cin + grow[YJ + j]];
-                fb[j] = aff_b[(size_t)cur_b * cin + grow[YJ + j]];
-            }
-        }
-        if (++cur_off == stages_per_img) { cur_off = 0; ++cur_b; }
-    };
-    auto park = [&](float *buf) { // transform (the expressions of conv1x1_wgrad_kernel) and store to LDS
-#pragma unroll
-        for (int j = 0; j < YJ; ++j) {
-            float4 v = raw[j];
-            if constexpr (POOLED) {
-                const int rel = __float_as_int(jv[j].y) - jpos;
-                const float ag = jv[j].x;
-                v.x = fmaf(cc[j].x, v.x, cc[j].y) + (rel == 0 ? ag : 0.f);
-                v.y = fmaf(cc[j].x, v.y, cc[j].y) + (rel == 1 ? ag : 0.f);
-                v.z = fmaf(cc[j].x, v.z, cc[j].y) + (rel == 2 ? ag : 0.f);
-                v.w = fmaf(cc[j].x, v.w, cc[j].y) + (rel == 3 ? ag : 0.f);
-            }
-            *reinterpret_cast<float4 *>(buf + lrow[j]) = v;
-        }
-#pragma unroll
-        for (int j = 0; j < XJ; ++j) {
-            float4 v = raw[YJ + j];
-            if constexpr (PRO) {
-                v.x = fmaf(fa[j], v.x, fb[j]); v.y = fmaf(fa[j], v.y, fb[j]);
-                v.z = fmaf(fa[j], v.z, fb[j]); v.w = fmaf(fa[j], v.w, fb[j]);
-                if (pro_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            }
-            *reinterpret_cast<float4 *>(buf + lrow[YJ + j]) = v;
-        }
-    };
-
-    v4f acc[4][4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[a][c] = (v4f){0.f, 0.f, 0.f, 0.f};
-    const int yoff = (half_r * 64 + i) * WS_LD + 4 * k, xoff = (YROWS + half_c * 64 + i) * WS_LD + 4 * k;
-    auto half_stage = [&](const float *buf, int h) { // 16 positions: 64 MFMAs
-        float4 yv[4], xv[4];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) yv[a] = *reinterpret_cast<const float4 *>(buf + yoff + a * 16 * WS_LD + h * 16);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) xv[c] = *reinterpret_cast<const float4 *>(buf + xoff + c * 16 * WS_LD + h * 16);
-        if constexpr (BF) {
-            // the lane's four consecutive positions are the four k-slots 4k .. 4k+3 of ONE 16x16x16 MFMA
-            v4s yb16[4], xb16[4];
-#pragma unroll
-            for (int a = 0; a < 4; ++a) yb16[a] = ogc_pack_bf16(yv[a].x, yv[a].y, yv[a].z, yv[a].w);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) xb16[c] = ogc_pack_bf16(xv[c].x, xv[c].y, xv[c].z, xv[c].w);
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(yb16[a], xb16[c], acc[a][c], 0, 0, 0);
-        } else {
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(yv[a].x, xv[c].x, acc[a][c], 0, 0, 0);
-                    acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(yv[a].y, xv[c].y, acc[a][c], 0, 0, 0);
-                    acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(yv[a].z, xv[c].z, acc[a][c], 0, 0, 0);
-                    acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(yv[a].w, xv[c].w, acc[a][c], 0, 0, 0);
-                }
-        }
-    };
-
-    float *buf0 = ws_lds, *buf1 = ws_lds + WS_ROWS * WS_LD;
-    fetch();
-    park(buf0);
-    __syncthreads();
-    for (int st = 0; st < mine; ++st) {
-        const bool more = st + 1 < mine; // (workgroup-uniform)
-        if (more) fetch();
-        half_stage(buf0, 0);
-        if (more) park(buf1);            // (buf1 was last read before the barrier that ended the previous stage)
-        half_stage(buf0, 1);
-        __syncthreads();
-        float *tmp = buf0; buf0 = buf1; buf1 = tmp;
-    }
-    // C/D layout of 16x16x4: lane l holds rows (l >> 4) * 4 + r (r = 0..3) of column l & 15; workgroups add with fp32 atomics
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = co0 + half_r * 64 + a * 16 + k * 4 + r, col = ci0 + half_c * 64 + c * 16 + i;
-                const float v = acc[a][c][r];
-                if (row < cout && col < cin && v != 0.0f) unsafeAtomicAdd(dw + (size_t)row * cin + col, v);
-            }
-}
-
-// OGC_WGRAD_SHARED=0 in the environment: the 64 x 64 register tiles for every width (A/B runs, tests of both kernels)
-bool wgrad_shared_enabled() {
-    static const bool on = [] { const char *e = getenv("OGC_WGRAD_SHARED"); return !(e && e[0] == '0'); }();
-    return on;
-}
-
-// true when the launch was made
-bool wgrad_shared_launch(int b, int cin, int cout, int hw, const float *x, const float *dy, float *dw, const float *pa,
-                         const float *pb, int pro_relu, hipStream_t s, const float2 *coef2, const float2 *inj, int s_shift) {
-    if (!wgrad_shared_enabled() || cin < 128 || cout < 128 || (hw % WS_POS) != 0) return false;
-    if (inj && (1 << s_shift) < 4) return false;
-    const size_t lds = sizeof(float) * 2 * 256 * WS_LD;
-    const int tiles = ogc_divup(cout, 128) * ogc_divup(cin, 128);
-    const long long nstages = (long long)b * (hw / WS_POS);
-    // two workgroups per CU over all tiles, at least 8 stages each
-    long long wgs = 512 / tiles;
-    if (wgs < 1) wgs = 1;
-    long long spw = (nstages + wgs - 1) / wgs;
-    if (spw < 8) spw = 8;
-    const int gx = (int)((nstages + spw - 1) / spw);
-    dim3 grid(gx, ogc_divup(cout, 128), ogc_divup(cin, 128));
-#define OGC_WGS(PROV, POOLV, BFV)                                                                                            \
-    {                                                                                                                        \
-        static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(conv1x1_wgrad_shared_kernel<PROV, POOLV, BFV>), \
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;       \
-        if (!ok) { (void)hipGetLastError(); return false; }                                                                  \
-        hipLaunchKernelGGL((conv1x1_wgrad_shared_kernel<PROV, POOLV, BFV>), grid, dim3(256), lds, s, b, cin, cout, hw, (int)spw, \
-                           x, dy, dw, pa, pb, pro_relu, coef2, inj, s_shift);                                                 \
-    }
-    // (the pooled form keeps fp32 operands whatever the precision switch says, as with the register tiles)
-    if (inj) { if (pa) OGC_WGS(true, true, false) else return false; }
-    else if (g_matmul_bf16) { if (pa) OGC_WGS(true, false, true) else OGC_WGS(false, false, true) }
-    else if (pa) OGC_WGS(true, false, false)
-    else OGC_WGS(false, false, false)
-#undef OGC_WGS
-    return true;
-}
-
-} // namespace
 
 namespace {
 
@@ -1152,53 +697,6 @@ extern "C" int ogc_conv1x1_gemm_gnstats(int b, int M, int K, int hw, int groups,
     return OGC_OK;
 }
 
-namespace {
-int wgrad_impl(const char *name, int b, int cin, int cout, int hw, const float *x, const float *dy, float *dw,
-               const float *pa, const float *pb, int pro_relu, ogc_stream_t stream, const float2 *coef2 = nullptr,
-               const float2 *inj = nullptr, int s_shift = 0) {
-    OGC_REQUIRE(b >= 0 && cin >= 1 && cout >= 1 && hw >= 1, "%s: bad shape", name);
-    OGC_REQUIRE(x && dy && dw, "%s: null pointer", name);
-    if ((hw & 15) != 0 || (((uintptr_t)x | (uintptr_t)dy) & 15) != 0) {
-        ogc_set_error("%s: hw=%d must be a multiple of 16 and x/dy 16-byte aligned", name, hw);
-        return OGC_ERR_UNSUPPORTED;
-    }
-    OGC_REQUIRE((long long)cin * hw < (1ll << 31) && (long long)cout * hw < (1ll << 31),
-                "%s: one sample exceeds 32-bit indexing", name);
-    hipStream_t s = (hipStream_t)stream;
-    if (ogc_zero_async(dw, sizeof(float) * (size_t)cin * cout, s) != hipSuccess) {
-        ogc_set_error("%s: memset failed", name);
-        return OGC_ERR_LAUNCH;
-    }
-    if (b == 0) return OGC_OK;
-    // layers of 128 channels and more on both sides: a 128 x 128 tile per workgroup, operands shared through LDS
-    if (wgrad_shared_launch(b, cin, cout, hw, x, dy, dw, pa, pb, pro_relu, s, coef2, inj, s_shift)) {
-        OGC_CHECK_LAUNCH(name);
-        return OGC_OK;
-    }
-    // register tile per wave: (16*COB) x (16*CIB) outputs.  Small channel counts use small tiles so that no MFMA
-    // work is spent on padding; wide layers use 64x64 tiles (16 accumulators) and split the rest over the grid.
-    if (inj) { // (the pooled form is offered for the wide tails only: 64-row tiles)
-        if (cin <= 32) wgrad_launch<4, 2>(b, cin, cout, hw, x, dy, dw, pa, pb, pro_relu, s, coef2, inj, s_shift);
-        else wgrad_launch<4, 4>(b, cin, cout, hw, x, dy, dw, pa, pb, pro_relu, s, coef2, inj, s_shift);
-        OGC_CHECK_LAUNCH(name);
-        return OGC_OK;
-    }
-    if (cout <= 16 && cin <= 16) wgrad_launch<1, 1>(b, cin, cout, hw, x, dy, dw, pa, pb, pro_relu, s);
-    else if (cout <= 32 && cin <= 16) wgrad_launch<2, 1>(b, cin, cout, hw, x, dy, dw, pa, pb, pro_relu, s);
-    else if (cout <= 32 && cin <= 32) wgrad_launch<2, 2>(b, cin, cout, hw, x, dy, dw, pa, pb, pro_relu, s);
-    else if (cin <= 16) wgrad_launch<4, 1>(b, cin, cout, hw, x, dy, dw, pa, pb, pro_relu, s);
-    else if (cin <= 32) wgrad_launch<4, 2>(b, cin, cout, hw, x, dy, dw, pa, pb, pro_relu, s);
-    else if (cout <= 32) wgrad_launch<2, 4>(b, cin, cout, hw, x, dy, dw, pa, pb, pro_relu, s);
-    else wgrad_launch<4, 4>(b, cin, cout, hw, x, dy, dw, pa, pb, pro_relu, s);
-    OGC_CHECK_LAUNCH(name);
-    return OGC_OK;
-}
-} // namespace
-
-extern "C" int ogc_conv1x1_wgrad(int b, int cin, int cout, int hw, const float *x, const float *dy, float *dw,
-                                 ogc_stream_t stream) {
-    return wgrad_impl("ogc_conv1x1_wgrad", b, cin, cout, hw, x, dy, dw, nullptr, nullptr, 0, stream);
-}
 
 // The two kernels above with the previous layer's GroupNorm (+ ReLU) folded into the operand load:
 // in' = act(pa[b, k] * in + pb[b, k]).  groups == 0: no statistics of the output.
@@ -1258,26 +756,4 @@ extern "C" int ogc_conv1x1_gemm_affine_pool(int b, int M, int K, int hw, int rel
     if (lrc != OGC_OK) return lrc;
     OGC_CHECK_LAUNCH("ogc_conv1x1_gemm_affine_pool");
     return OGC_OK;
-}
-
-extern "C" int ogc_conv1x1_wgrad_affine(int b, int cin, int cout, int hw, int relu, const float *x, const float *pa,
-                                        const float *pb, const float *dy, float *dw, ogc_stream_t stream) {
-    OGC_REQUIRE(pa && pb, "ogc_conv1x1_wgrad_affine: null pointer");
-    return wgrad_impl("ogc_conv1x1_wgrad_affine", b, cin, cout, hw, x, dy, dw, pa, pb, relu, stream);
-}
-
-// ogc_conv1x1_wgrad_affine with dy in the sparse form of ogc_group_norm_maxpool_bwd_sparse: y is the convolution's raw output
-// (b, cout, hw) and g_y is rebuilt from (y, coef2, inj) while y is loaded (see POOLED at conv1x1_wgrad_kernel) — the weight
-// gradient of the LAST layer of a set-abstraction MLP without the dense gradient of its pooled GroupNorm.  fp32 operands.
-extern "C" int ogc_conv1x1_wgrad_affine_pooled(int b, int cin, int cout, int hw, int relu, int nsample, const float *x,
-                                               const float *pa, const float *pb, const float *y, const float *coef2,
-                                               const float *inj, float *dw, ogc_stream_t stream) {
-    OGC_REQUIRE(pa && pb && coef2 && inj, "ogc_conv1x1_wgrad_affine_pooled: null pointer");
-    const int sh = nsample == 16 ? 4 : nsample == 32 ? 5 : nsample == 64 ? 6 : -1;
-    if (sh < 0 || hw % nsample != 0 || (((uintptr_t)coef2 | (uintptr_t)inj) & 7) != 0) {
-        ogc_set_error("ogc_conv1x1_wgrad_affine_pooled: nsample=%d must be 16, 32 or 64 and divide hw=%d", nsample, hw);
-        return OGC_ERR_UNSUPPORTED;
-    }
-    return wgrad_impl("ogc_conv1x1_wgrad_affine_pooled", b, cin, cout, hw, x, y, dw, pa, pb, relu, stream,
-                      reinterpret_cast<const float2 *>(coef2), reinterpret_cast<const float2 *>(inj), sh);
 }
