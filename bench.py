@@ -402,13 +402,18 @@ def main():
         from ogc_amd.utils.dist_util import pin_rank_to_cores
         pin_rank_to_cores()  # before the GPU runtime starts its helper threads: they inherit the block
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    # OGC_BENCH_SHARE_GPU=1 (tests only): every rank on cuda:0 — the multi-rank control flow of this file (sharding, barrier + MAX
+    # timing, one line from rank 0, nobody left alone in a collective) exercised on a one-GPU box, over OGC_BENCH_BACKEND=gloo
+    # (RCCL refuses two ranks on one device)
+    if os.environ.get("OGC_BENCH_SHARE_GPU") == "1":
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     under_launcher = "RANK" in os.environ and "MASTER_ADDR" in os.environ
     if world > 1 or under_launcher:  # a 1-process torchrun launch still exercises RCCL init + the DDP wrapper
         # no device_id: binding the group to the device at init (eager communicator) slows EVERY later launch of this
         # process on this stack — the same un-wrapped step takes 17.5 ms instead of 14.9 (tools/ddp_cost.py)
-        dist.init_process_group("nccl")
+        dist.init_process_group(os.environ.get("OGC_BENCH_BACKEND", "nccl"))
     assert world == a.gpus, "--gpus %d but WORLD_SIZE=%d" % (a.gpus, world)
 
     import ogc_amd  # noqa: F401  (fails loudly if libogc_ops.so is missing)
@@ -492,7 +497,9 @@ def main():
     isolated_ms, extras, pair_floor_ms = None, {}, 0.0
     if a.timed_only:
         a.no_cpu_baseline = True
-    if rank == 0 and not a.timed_only:
+    # The extras are single-GPU readings taken by rank 0 alone after the timed region; some of them run further training steps,
+    # i.e. gradient collectives the other ranks would not join: with more than one rank the line carries the timed region only.
+    if rank == 0 and not a.timed_only and world == 1:
         def graph_reading():
             # the same step replayed as ONE HIP graph (ogc_amd/graph_step.py; `--hip-graph` of the training driver): what a step
             # costs when the launch thread is out of the picture.  A second network / optimizer (the capture needs step counts
@@ -675,6 +682,7 @@ def main():
                 out["cpu_ops"] = {"error": str(err)[:200]}
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
+        sync()  # (nobody tears the group down while another rank may still be inside a collective)
         dist.destroy_process_group()
 
 

@@ -151,3 +151,25 @@ def test_bench_under_one_process_rccl_launcher():
     assert dist_["collective"]["avg_ms"] > 0
     # (two processes one after the other on a shared box: 10 % + 0.6 ms of slack for the run-to-run spread of short runs)
     assert dist_["ms_per_step"] <= 1.10 * plain["ms_per_step"] + 0.6, (dist_["ms_per_step"], plain["ms_per_step"])
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_share_the_gpu_over_gloo():
+    """bench.py's multi-rank control flow on the one-GPU box: two ranks (both on cuda:0, gloo instead of RCCL, which refuses two
+    ranks on one device) under the driver's launcher line.  The timed steps average gradients across the ranks; after them
+    NO rank may run further training steps alone (round 5: rank 0's single-GPU extras used to — a gradient collective the
+    other ranks never joined, i.e. a hang on the first real multi-GPU run); exactly one JSON line, whole-job throughput."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29700 + os.getpid() % 200), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4",
+           "--warmup", "2"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OGC_BENCH_SHARE_GPU="1", OGC_BENCH_BACKEND="gloo")
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=800)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 4 and r["scaling"] == "weak" and r["config"]["optimizer_stepped"] is True
+    assert r["config"]["parallelism"] == "dp2" and r["collective"]["world"] == 2 and r["collective"]["backend"] == "gloo"
+    # whole-job value: both ranks' clouds over the slower rank's time
+    assert abs(r["value"] - 2 * r["config"]["clouds_per_step_per_gpu"] / (r["ms_per_step"] * 1e-3)) <= 0.01 * r["value"]
+    assert "cpu_baseline" not in r and "ms_per_step_with_h2d" not in r      # single-GPU readings: N = 1 only
