@@ -127,7 +127,11 @@ def pin_rank_to_cores():
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
     if local_world <= 1 or os.environ.get("OGC_PIN_CORES", "1") == "0" or not hasattr(os, "sched_setaffinity"):
         return None
-    block = core_block(os.sched_getaffinity(0), int(os.environ.get("LOCAL_RANK", "0")), local_world)
+    allowed = os.sched_getaffinity(0)
+    if len(allowed) < 4 * local_world:
+        return None   # a rank keeps three threads busy (launch thread, autograd's backward thread, a runtime helper): blocks of
+                      # fewer than four CPUs would make them take turns — better left to the scheduler
+    block = core_block(allowed, int(os.environ.get("LOCAL_RANK", "0")), local_world)
     try:
         os.sched_setaffinity(0, block)
     except OSError:

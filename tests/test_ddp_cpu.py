@@ -141,3 +141,21 @@ def test_core_blocks_of_the_ranks_of_a_host():
     assert blocks[0] == set(range(4, 16)) and blocks[7] == set(range(88, 100))
     assert [core_block({0, 1, 2}, r, 8) for r in range(8)] == [{0}, {1}, {2}, {0}, {1}, {2}, {0}, {1}]
     assert core_block({5}, 0, 1) == {5}
+
+
+def test_ranks_are_not_pinned_to_blocks_of_fewer_than_four_cpus(monkeypatch):
+    """pin_rank_to_cores leaves the affinity alone when the host cannot give every rank four CPUs (a rank keeps a launch thread,
+    autograd's backward thread and a runtime helper busy)."""
+    import os
+    from ogc_amd.utils import dist_util
+    if not hasattr(os, "sched_setaffinity"):
+        pytest.skip("no sched_setaffinity")
+    calls = []
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(16)))
+    monkeypatch.setattr(os, "sched_setaffinity", lambda pid, cpus: calls.append(set(cpus)))
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+    monkeypatch.setenv("LOCAL_RANK", "3")
+    monkeypatch.delenv("OGC_PIN_CORES", raising=False)
+    assert dist_util.pin_rank_to_cores() is None and calls == []          # 16 CPUs, 8 ranks: two each
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(64)))
+    assert dist_util.pin_rank_to_cores() == set(range(24, 32)) and calls == [set(range(24, 32))]
