@@ -143,15 +143,18 @@ def cpu_baseline(npoint):
         crit = build_criterion(KITTI_LOSS)
         opt = torch.optim.Adam(net.parameters(), lr=1e-3)
         batch = make_scene_batch(1, npoint, 10, seed=1234, aug=True)
-        t0 = time.time()
-        train_step(net, crit, opt, batch, 1000, True)
-        dt = time.time() - t0
+        times = []
+        for _ in range(2):   # (two steps, the faster one reported: the first also pays the process's first touch of the CPU paths)
+            t0 = time.time()
+            train_step(net, crit, opt, batch, 1000, True)
+            times.append(time.time() - t0)
+        dt = min(times)
     finally:
         api._native = saved
     cores = min(torch.get_num_threads(), os.cpu_count() or 1)
     return {"value": round(4 / dt, 4), "unit": "point-clouds/s", "cores": cores, "kind": "port",
-            "sample": "1 train step, 1 sample x 4 views (4 clouds) of %d pts: torch-CPU layers + oracle operators "
-                      "(OpenMP), %.1f s" % (npoint, dt)}
+            "sample": "2 train steps of 1 sample x 4 views (4 clouds) of %d pts, the faster one: torch-CPU layers + oracle operators "
+                      "(OpenMP), %s s" % (npoint, " / ".join("%.1f" % t for t in times))}
 
 
 def cpu_ops(pc_dev):
