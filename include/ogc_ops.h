@@ -42,8 +42,9 @@ enum {
 /* Library version (major*10000 + minor*100 + patch) and last error text (thread-local).  OGC_VERSION is the version of THIS
  * header; a caller checks ogc_version() == OGC_VERSION before anything else (ogc_amd/_lib.py does): the minor number moves with
  * every change of an existing prototype.  0.2.0: ogc_adam_step takes its five hyper-parameters as double (float before), new
- * entry points ogc_zero_arena_begin / _end, ogc_conv1x1_gemm_any, ogc_conv1x1_wgrad_affine_pooled, ogc_conv1x1_dgrad_pooled. */
-#define OGC_VERSION 200
+ * entry points ogc_zero_arena_begin / _end, ogc_conv1x1_gemm_any, ogc_conv1x1_wgrad_affine_pooled, ogc_conv1x1_dgrad_pooled.  0.2.1 (the patch number moves with new entry
+ * points): ogc_gather_xyz_pair, ogc_flow_advance, ogc_linear_cn, ogc_gru_reset, ogc_gru_blend. */
+#define OGC_VERSION 201
 int ogc_version(void);
 /* 0: the squared distance of every search is the reference's SOURCE expression, ((dx*dx) + (dy*dy)) + (dz*dz), one rounding per
  * operation (what all parity tests pin).  1: this is libogc_ops_fmad.so, the same library with the search kernels (FPS, kNN,
@@ -622,6 +623,31 @@ int ogc_chamfer_terms(int b, int n1, int n2, int p, const float *p1, const float
                       float *dist1, float *dist2, ogc_stream_t stream);
 int ogc_chamfer_terms_grad(int b, int n1, int n2, int p, const float *p1, const float *pc2, const int *idx12, const int *idx21,
                            const float *g1, const float *g2, float *grad_p1, ogc_stream_t stream);
+
+/* The element-wise glue of FlowStep3D's refinement loop in inference (fused extensions; csrc/flow_step.hip).  Each replaces a
+ * run of framework operators of models/flownet_kitti.py on tensors of a few thousand elements, with the same fp32 operations in
+ * the same order (one rounding each, nothing contracted):
+ *   ogc_gather_xyz_pair  out (b, 3, m) = xyz (b, 3, n)[:, :, idx (b, m)] and out_t (b, m, 3) = its transpose
+ *                        (gather_operation + transpose(1, 2).contiguous(), utils/flowstep3d_util.py:110-118);
+ *   ogc_flow_advance     d = delta * scale (no multiplication when scale == 1), new = cur + d, flow = new - ref, all (b, 3, n);
+ *                        out_delta, out_new_t (b, n, 3) and out_flow may be null (flownet_kitti.py:229-231, :245-250: scale is
+ *                        the fp32 rounding of 1 / (k_decay_fact * it + 1), as torch divides by a Python scalar);
+ *   ogc_linear_cn        y (b, cout, n) = weight (cout, cin) x (b, cin, n) + bias, cout <= 4 — nn.Linear between two
+ *                        transposes (flownet_kitti.py:19, :38), sequential fp32 FMA over cin; bias may be null;
+ *   ogc_gru_reset        hx (b, c + cx, n) = cat([h, x]); rc (b, c, n, s) the reset gate's un-pooled convolution output, batch
+ *                        stride rc_batch_stride floats: out (b, c + cx, n) = cat([sigmoid(max_s rc) * h, x]) (:147-149);
+ *   ogc_gru_blend        z = sigmoid(max_s zc), q = tanh(max_s qc), out (b, c, n) = (1 - z) * h + z * q (:147, :149-150); zc, qc
+ *                        (b, c, n, s) and h (b, c, n) with their batch strides in floats.
+ * Gate pointers 16-byte aligned and gate batch strides multiples of 4 floats. */
+int ogc_gather_xyz_pair(int b, int n, int m, const float *xyz, const int *idx, float *out, float *out_t, ogc_stream_t stream);
+int ogc_flow_advance(int b, int n, float scale, const float *cur, const float *delta, const float *ref, float *out_delta,
+                     float *out_new, float *out_new_t, float *out_flow, ogc_stream_t stream);
+int ogc_linear_cn(int b, int cin, int cout, int n, const float *x, const float *weight, const float *bias, float *y,
+                  ogc_stream_t stream);
+int ogc_gru_reset(int b, int c, int cx, int n, int s, const float *rc, long long rc_batch_stride, const float *hx, float *out,
+                  ogc_stream_t stream);
+int ogc_gru_blend(int b, int c, int n, int s, const float *zc, long long zc_batch_stride, const float *qc,
+                  long long qc_batch_stride, const float *h, long long h_batch_stride, float *out, ogc_stream_t stream);
 
 /* One zero fill per training step (fused extension; nothing in the reference to replace: its Python zero-fills every gradient
  * buffer it hands to the native module, pointnet2/pointnet2.py:73,181,224).  ogc_zero_arena_begin fills [base, base + bytes)

@@ -16,6 +16,7 @@ _vp = ctypes.c_void_p
 _int = ctypes.c_int
 _flt = ctypes.c_float
 _dbl = ctypes.c_double
+_ll = ctypes.c_longlong
 
 # name -> argtypes (stream is always the trailing void*)
 SIGNATURES = {
@@ -41,6 +42,11 @@ SIGNATURES = {
     "ogc_knn_clamped_cells": [_int, _int, _int, _flt, _vp, _vp, _flt, _vp, _vp, _vp],
     "ogc_chamfer_terms": [_int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "ogc_chamfer_terms_grad": [_int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "ogc_gather_xyz_pair": [_int, _int, _int, _vp, _vp, _vp, _vp, _vp],
+    "ogc_flow_advance": [_int, _int, _flt, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "ogc_linear_cn": [_int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp],
+    "ogc_gru_reset": [_int, _int, _int, _int, _int, _vp, _ll, _vp, _vp, _vp],
+    "ogc_gru_blend": [_int, _int, _int, _int, _vp, _ll, _vp, _ll, _vp, _ll, _vp, _vp],
     "ogc_zero_arena_begin": [_vp, _int, _vp],
     "ogc_zero_arena_end": [],
     "ogc_adam_max_tensors": [],
@@ -120,7 +126,7 @@ SIGNATURES = {
                                    _vp, _vp],
 }
 
-HEADER_VERSION = 200   # OGC_VERSION of include/ogc_ops.h the SIGNATURES table above was written against
+HEADER_VERSION = 201   # OGC_VERSION of include/ogc_ops.h the SIGNATURES table above was written against
 _lib = None
 _fns = {}  # entry point name -> bound ctypes function
 

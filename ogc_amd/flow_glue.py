@@ -1,0 +1,84 @@
+"""The element-wise glue of FlowStep3D's refinement loop in inference, one launch per group of framework operators
+(``csrc/flow_step.hip``).  At C3 (one pair of 8192-point clouds, iters = 5) the forward is ~450 launches of a few microseconds each and
+its time is their number; each function here stands for three to six ``aten`` launches of models/flownet_kitti.py:135-151, :229-250
+with the same fp32 arithmetic.  Nothing here is differentiable: `available()` is False whenever autograd would record the
+operators (training keeps the reference's operator sequence), on CPU tensors, and when the native module is not the HIP one."""
+import numpy as np
+import torch
+
+from .pointnet2 import pointnet2 as _api
+
+ENABLED = True   # tests / A-B measurements switch the module off as a whole
+
+
+def available(*tensors):
+    """Inference on the HIP operators: no tensor of the call is being differentiated."""
+    nat = _api._native
+    if not ENABLED or getattr(nat, "gru_blend_wrapper", None) is None:
+        return False
+    for t in tensors:
+        if t is None:
+            continue
+        if not (t.is_cuda and t.dtype == torch.float32) or (torch.is_grad_enabled() and t.requires_grad):
+            return False
+    return True
+
+
+def gather_xyz_pair(xyz, idx):
+    """xyz (B, 3, N), idx (B, M) int32 -> (xyz[:, :, idx] (B, 3, M), the same as (B, M, 3)): gather_operation and the transposed
+    copy every set-abstraction layer makes of its centres (utils/flowstep3d_util.py:110-118)."""
+    B, _, N = xyz.shape
+    M = idx.shape[1]
+    out = torch.empty(B, 3, M, dtype=torch.float32, device=xyz.device)
+    out_t = torch.empty(B, M, 3, dtype=torch.float32, device=xyz.device)
+    _api._native.gather_xyz_pair_wrapper(B, N, M, xyz, idx, out, out_t)
+    return out, out_t
+
+
+def reciprocal_scale(divisor):
+    """What torch multiplies by when a float tensor is divided by a Python scalar on the GPU: 1 / divisor evaluated in double,
+    then rounded to fp32 (BinaryDivTrueKernel.cu: `a * inv_b` for a CPU-scalar divisor)."""
+    return float(np.float32(1.0 / float(divisor)))
+
+
+def flow_advance(cur, delta, ref, divisor=1.0, want_delta=False, want_t=False, want_flow=True):
+    """cur, delta, ref (B, 3, N): d = delta / divisor; new = cur + d; flow = new - ref.  Returns (d or None, new, new as (B, N, 3) or
+    None, flow or None) — flownet_kitti.py:229-231 and :245-250 as one launch."""
+    B, _, N = cur.shape
+    scale = 1.0 if divisor == 1 else reciprocal_scale(divisor)
+    new = torch.empty_like(cur)
+    d = torch.empty_like(cur) if want_delta and scale != 1.0 else None
+    new_t = torch.empty(B, N, 3, dtype=torch.float32, device=cur.device) if want_t else None
+    flow = torch.empty_like(cur) if want_flow else None
+    _api._native.flow_advance_wrapper(B, N, scale, cur, delta, ref if want_flow else None, d, new, new_t, flow)
+    if want_delta and d is None:
+        d = delta
+    return d, new, new_t, flow
+
+
+def linear_cn(x, weight, bias):
+    """nn.Linear applied along the channel axis of x (B, Cin, N) -> (B, Cout, N), Cout <= 4: the `fc` between two transposes of
+    FlowRegressor / Flow0Regressor (flownet_kitti.py:19, :38)."""
+    B, cin, N = x.shape
+    cout = weight.shape[0]
+    y = torch.empty(B, cout, N, dtype=torch.float32, device=x.device)
+    _api._native.linear_cn_wrapper(B, cin, cout, N, x, weight, bias, y)
+    return y
+
+
+def gru_reset(rc, hx, c):
+    """rc (B, C, N, S): the reset gate's convolution output before its max over the neighbours; hx (B, C + Cx, N) = cat([h, x]).
+    -> cat([sigmoid(max_s rc) * h, x]) (flownet_kitti.py:148-149)."""
+    B, ctot, N = hx.shape
+    out = torch.empty_like(hx)
+    _api._native.gru_reset_wrapper(B, c, ctot - c, N, rc.shape[3], rc, hx, out)
+    return out
+
+
+def gru_blend(zc, qc, hx, c):
+    """zc, qc (B, C, N, S) un-pooled gate / candidate outputs, h = hx[:, :C]: (1 - z) * h + z * q with z = sigmoid(max_s zc),
+    q = tanh(max_s qc) (flownet_kitti.py:147, :149-150)."""
+    B, ctot, N = hx.shape
+    out = torch.empty(B, c, N, dtype=torch.float32, device=hx.device)
+    _api._native.gru_blend_wrapper(B, c, N, zc.shape[3], zc, qc, hx, ctot * N, out)
+    return out

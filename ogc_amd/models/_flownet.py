@@ -6,6 +6,7 @@ checkpoints (``encoder_loc.sa1.mlp_convs.0.weight``, ``global_corr_layer.epsilon
 import torch
 import torch.nn as nn
 
+from .. import flow_glue
 from ..pointnet2.pointnet2 import furthest_point_sample_chain, gather_operation
 from ..utils.flowstep3d_util import (FlowEmbedding, PointNetFeaturePropogation, PointNetSetAbstraction,
                                      geometry_memo)
@@ -52,6 +53,14 @@ def _sa(npoint, nsample, in_channel, mlp, inorm, **kw):
                                   group_all=False, use_instance_norm=inorm, **kw)
 
 
+def _fc_channel_major(fc, x):
+    """nn.Linear along the channel axis of x (B, C, N) -> (B, 3, N): between two transposed copies in the reference
+    (flownet_kitti.py:19, :38), one launch on the channel-major tensor in inference."""
+    if flow_glue.available(x, fc.weight, fc.bias) and fc.weight.shape[0] <= 4 and x.is_contiguous():
+        return flow_glue.linear_cn(x, fc.weight, fc.bias)
+    return fc(x.permute(0, 2, 1).contiguous()).permute(0, 2, 1).contiguous()
+
+
 class Flow0Regressor(nn.Module):
     """Reference: flownet_kitti.py:6-19."""
 
@@ -63,7 +72,7 @@ class Flow0Regressor(nn.Module):
 
     def forward(self, pc1_l_loc, corr_feats):
         _, x = self.sa1(pc1_l_loc[2], corr_feats)
-        return self.fc(x.permute(0, 2, 1).contiguous()).permute(0, 2, 1).contiguous()
+        return _fc_channel_major(self.fc, x)
 
 
 class FlowRegressor(nn.Module):
@@ -79,7 +88,7 @@ class FlowRegressor(nn.Module):
     def forward(self, pc1_l_loc, corr_feats):
         _, x = self.sa1(pc1_l_loc[2], corr_feats)
         _, x = self.sa2(pc1_l_loc[2], x)
-        return self.fc(x.permute(0, 2, 1).contiguous()).permute(0, 2, 1).contiguous()
+        return _fc_channel_major(self.fc, x)
 
 
 class GlobalCorrLayer(nn.Module):
@@ -193,7 +202,18 @@ class GRU(nn.Module):
             setattr(self, name, _sa(int(npoint / 4), 4, in_ch, [hidden_dim], use_instance_norm, use_act=False))
 
     def forward(self, h, x, pc):
-        hx = torch.cat([h, x], dim=1)
+        # x: a tensor (B, input_dim, N), or the list of tensors whose concatenation along the channels it is
+        parts = list(x) if isinstance(x, (list, tuple)) else [x]
+        hx = torch.cat([h] + parts, dim=1)
+        if flow_glue.available(hx, *[p for m in (self.convz, self.convr, self.convq) for p in m.parameters()]):
+            # inference: the gates' max over the neighbours, their activations and the products around them in two launches
+            # (sigmoid, mul, cat | sigmoid, tanh, 1 - z, two products, sum — and the three maxima — otherwise)
+            c = h.shape[1]
+            zc = self.convz(pc, hx, pool=False)[1]
+            rc = self.convr(pc, hx, pool=False)[1]
+            qc = self.convq(pc, flow_glue.gru_reset(rc, hx, c), pool=False)[1]
+            return flow_glue.gru_blend(zc, qc, hx, c)
+        x = parts[0] if len(parts) == 1 else hx[:, h.shape[1]:]
         z = torch.sigmoid(self.convz(pc, hx)[1])
         r = torch.sigmoid(self.convr(pc, hx)[1])
         q = torch.tanh(self.convq(pc, torch.cat([r * h, x], dim=1))[1])
@@ -261,9 +281,12 @@ class FlowStep3DBase(nn.Module):
     def calc_h0(self, feats1_loc, pc):
         return torch.tanh(self.h0_net(pc, feats1_loc))
 
-    def get_x(self, feats1_loc_new, corr_feats, flow, pc):
+    def get_x(self, feats1_loc_new, corr_feats, flow, pc, parts=False):
+        # parts=True: the four tensors instead of their concatenation (the GRU concatenates them with its state in one go)
         _, flow_feats = self.flow_conv1(pc, flow)
         _, flow_feats = self.flow_conv2(pc, flow_feats)
+        if parts:
+            return [feats1_loc_new, corr_feats, flow_feats, flow]
         return torch.cat([feats1_loc_new, corr_feats, flow_feats, flow], dim=1)
 
     def get_x_slim(self, feats1_loc_new, corr_feats):
@@ -303,6 +326,8 @@ class FlowStep3DBase(nn.Module):
 
         h = self.calc_h0(feats1_loc, pc1_l_loc[-1])
 
+        if iters > 1 and flow_glue.available(pc1, flow0, flow0_lr):
+            return self._refine_inference(flow_predictions, pc1, pc1_l_loc, pc2_l_loc, feats2_loc, fps_idx1, flow0, flow0_lr, h, iters)
         pc1_new = pc1 + flow0.detach()
         pc1_new_lr = pc1_l_loc[2] + flow0_lr.detach()
         for it in range(iters - 1):
@@ -313,7 +338,7 @@ class FlowStep3DBase(nn.Module):
             pc1_new_l_loc, feats1_loc_new, _ = self.encoder_loc(pc1_new, pc1_new, fps_idx1)
             _, corr_feats = self.local_corr_layer(pc1_new_l_loc[-1], pc2_l_loc[-1], feats1_loc_new, feats2_loc)
 
-            x = self.get_x(feats1_loc_new, corr_feats, flow_lr, pc=pc1_l_loc[2])
+            x = self.get_x(feats1_loc_new, corr_feats, flow_lr, pc=pc1_l_loc[2], parts=True)
             h = self.gru(h=h, x=x, pc=pc1_l_loc[-1])
             delta_flow_lr = self.flow_regressor(pc1_l_loc, h) / (self.k_decay_fact * it + 1)
             pc1_new_lr = pc1_new_lr + delta_flow_lr
@@ -321,4 +346,27 @@ class FlowStep3DBase(nn.Module):
             delta_flow = self.flow_up_sample(pc1_l_loc[0], pc1_l_loc[2], None, delta_flow_lr)
             pc1_new = pc1_new + delta_flow
             flow_predictions.append((pc1_new - pc1).permute(0, 2, 1))
+        return flow_predictions
+
+    def _refine_inference(self, flow_predictions, pc1, pc1_l_loc, pc2_l_loc, feats2_loc, fps_idx1, flow0, flow0_lr, h, iters):
+        """The refinement loop above (flownet_kitti.py:229-250) when nothing is differentiated: the same operators on the same values,
+        with the sums / differences / scaling of the two running clouds as one launch each (flow_glue.flow_advance), which also
+        leaves the (B, N, 3) copy of the moved cloud for the encoder of the next iteration."""
+        # pc1 + flow0 (and its transpose), pc1_l_loc[2] + flow0_lr and the first low-resolution flow, (that sum) - pc1_l_loc[2]
+        _, pc1_new, pc1_new_t, _ = flow_glue.flow_advance(pc1, flow0, None, want_t=True, want_flow=False)
+        _, pc1_new_lr, _, flow_lr = flow_glue.flow_advance(pc1_l_loc[2], flow0_lr, pc1_l_loc[2])
+        for it in range(iters - 1):
+            geometry_memo.note_transposed(pc1_new, pc1_new_t)
+            pc1_new_l_loc, feats1_loc_new, _ = self.encoder_loc(pc1_new, pc1_new, fps_idx1)
+            _, corr_feats = self.local_corr_layer(pc1_new_l_loc[-1], pc2_l_loc[-1], feats1_loc_new, feats2_loc)
+
+            x = self.get_x(feats1_loc_new, corr_feats, flow_lr, pc=pc1_l_loc[2], parts=True)
+            h = self.gru(h=h, x=x, pc=pc1_l_loc[-1])
+            delta_flow_lr, pc1_new_lr, _, flow_lr = flow_glue.flow_advance(
+                pc1_new_lr, self.flow_regressor(pc1_l_loc, h), pc1_l_loc[2], divisor=self.k_decay_fact * it + 1, want_delta=True)
+
+            delta_flow = self.flow_up_sample(pc1_l_loc[0], pc1_l_loc[2], None, delta_flow_lr)
+            last = it == iters - 2
+            _, pc1_new, pc1_new_t, flow = flow_glue.flow_advance(pc1_new, delta_flow, pc1, want_t=not last)
+            flow_predictions.append(flow.permute(0, 2, 1))
         return flow_predictions

@@ -237,6 +237,37 @@ def chamfer_terms_grad_wrapper(b, n1, n2, p, p1, pc2, idx12, idx21, g1, g2, grad
          _f(g1, "g1"), _f(g2, "g2"), _f(grad_p1, "grad_p1"))
 
 
+def gather_xyz_pair_wrapper(b, n, m, xyz, idx, out, out_t):
+    """out (b, 3, m) = xyz (b, 3, n)[:, :, idx] and out_t (b, m, 3), its transpose, in one launch (ogc_gather_xyz_pair)."""
+    _run("ogc_gather_xyz_pair", xyz, b, n, m, _f(xyz, "xyz"), _i(idx, "idx"), _f(out, "out"), _f(out_t, "out_t"))
+
+
+def flow_advance_wrapper(b, n, scale, cur, delta, ref, out_delta, out_new, out_new_t, out_flow):
+    """d = delta * scale, new = cur + d, flow = new - ref on (b, 3, n) tensors (ogc_flow_advance); out_delta, out_new_t
+    (b, n, 3) and out_flow may be None."""
+    _run("ogc_flow_advance", cur, b, n, float(scale), _f(cur, "cur"), _f(delta, "delta"), 0 if ref is None else _f(ref, "ref"),
+         0 if out_delta is None else _f(out_delta, "out_delta"), _f(out_new, "out_new"),
+         0 if out_new_t is None else _f(out_new_t, "out_new_t"), 0 if out_flow is None else _f(out_flow, "out_flow"))
+
+
+def linear_cn_wrapper(b, cin, cout, n, x, weight, bias, y):
+    """y (b, cout, n) = weight (cout, cin) x (b, cin, n) + bias, cout <= 4 (ogc_linear_cn); bias may be None."""
+    _run("ogc_linear_cn", x, b, cin, cout, n, _f(x, "x"), _f(weight, "weight"), 0 if bias is None else _f(bias, "bias"), _f(y, "y"))
+
+
+def gru_reset_wrapper(b, c, cx, n, s, rc, hx, out):
+    """out (b, c + cx, n) = cat([sigmoid(max_s rc) * h, x]) for hx = cat([h, x]) and the un-pooled gate rc (b, c, n, s)
+    (ogc_gru_reset)."""
+    _run("ogc_gru_reset", hx, b, c, cx, n, s, _f(rc, "rc"), c * n * s, _f(hx, "hx"), _f(out, "out"))
+
+
+def gru_blend_wrapper(b, c, n, s, zc, qc, h, h_batch_stride, out):
+    """out (b, c, n) = (1 - z) * h + z * q, z = sigmoid(max_s zc), q = tanh(max_s qc) (ogc_gru_blend); h may be the first c
+    channels of a wider contiguous tensor whose batch stride (in floats) is h_batch_stride."""
+    _run("ogc_gru_blend", h, b, c, n, s, _f(zc, "zc"), c * n * s, _f(qc, "qc"), c * n * s, _f(h, "h"), int(h_batch_stride),
+         _f(out, "out"))
+
+
 def kabsch_rotation_wrapper(nb, S, R, valid=None):
     """R = V diag(1,1,det) U^T per 3x3 cross-covariance (ogc_kabsch_rotation); NaN matrices give the identity."""
     _run("ogc_kabsch_rotation", S, nb, _f(S, "S"), _f(R, "R"), 0 if valid is None else _i(valid, "valid"))

@@ -39,6 +39,24 @@ class geometry_memo:
         return hit
 
     @staticmethod
+    def transposed(xyz):
+        """xyz (B, 3, N) -> (B, N, 3) contiguous, once per coordinate tensor inside a scope."""
+        hit = geometry_memo.entry(xyz)
+        if hit is None:
+            return xyz.permute(0, 2, 1).contiguous()
+        if hit["xyz_t"] is None:
+            hit["xyz_t"] = xyz.permute(0, 2, 1).contiguous()
+        return hit["xyz_t"]
+
+    @staticmethod
+    def note_transposed(xyz, xyz_t):
+        """The producer of `xyz` (B, 3, N) already holds its (B, N, 3) copy: the consumers (the next set-abstraction layer, the
+        correlation layer) find it instead of making their own."""
+        hit = geometry_memo.entry(xyz)
+        if hit is not None and hit["xyz_t"] is None:
+            hit["xyz_t"] = xyz_t
+
+    @staticmethod
     def note_chain(xyz, ties):
         """`xyz` (B, 3, n) holds the centres of a level of an FPS chain IN SAMPLING ORDER and `ties` (B,) int32 is what
         furthest_point_sample_chain returned for that level.  A set-abstraction layer that samples this cloud again — the
@@ -104,8 +122,8 @@ class FlowEmbedding(_FoldAware):
 
     def forward(self, pos1, pos2, feature1, feature2):
         # pos1, pos2 (B, 3, N); feature1, feature2 (B, C, N) -> pos1, (B, mlp[-1], N)
-        pos1_t = pos1.permute(0, 2, 1).contiguous()
-        pos2_t = pos2.permute(0, 2, 1).contiguous()
+        pos1_t = geometry_memo.transposed(pos1)   # (the layer that made pos1 left its transpose in the memo; pos2 never moves)
+        pos2_t = geometry_memo.transposed(pos2)
         B, N, _ = pos1_t.shape
         if self.knn:
             _, idx = knn_radius_clamp(self.nsample, self.radius, pos1_t, pos2_t)     # :42-44
@@ -152,8 +170,12 @@ class PointNetSetAbstraction(_FoldAware):
         self.queryandgroup = GroupAll(self.use_xyz) if group_all else QueryAndGroup(radius, nsample, self.use_xyz)
         self.return_fps = return_fps
 
-    def forward(self, xyz, points, fps_idx=None):
+    def forward(self, xyz, points, fps_idx=None, pool=True):
         # xyz (B, 3, N), points (B, D, N) -> new_xyz (B, 3, S), new_points (B, D', S) [, fps_idx (B, S)]
+        # pool=False (blocks without activation only): new_points stay (B, D', S, nsample), the max over the neighbours is the
+        # caller's (the GRU folds it into its gate kernels, flow_glue.gru_reset / gru_blend)
+        from .. import flow_glue
+        assert pool or not (self.use_act or self.mean_aggr), "pool=False is for the blocks without activation"
         xyz = xyz.contiguous()
         memo = geometry_memo.entry(xyz)
         if memo is not None and memo["xyz_t"] is not None:
@@ -175,12 +197,18 @@ class PointNetSetAbstraction(_FoldAware):
                         fps_idx = furthest_point_sample(xyz_t, self.npoint)
                     if memo is not None:
                         memo["fps"][self.npoint] = fps_idx
+            new_xyz_t = None
             if memo is not None and not given_idx and self.npoint in memo["new_xyz"]:
                 new_xyz = memo["new_xyz"][self.npoint]
             else:
-                new_xyz = gather_operation(xyz, fps_idx)
+                if flow_glue.available(xyz):
+                    new_xyz, new_xyz_t = flow_glue.gather_xyz_pair(xyz, fps_idx)   # both layouts of the centres in one launch
+                else:
+                    new_xyz = gather_operation(xyz, fps_idx)
                 if memo is not None and not given_idx:
                     memo["new_xyz"][self.npoint] = new_xyz
+                    if new_xyz_t is not None:
+                        memo.setdefault("new_xyz_t", {})[self.npoint] = new_xyz_t
         else:
             new_xyz = xyz
         # the centres as (B, S, 3), once per call (and once per forward for coordinates the memo knows)
@@ -189,9 +217,12 @@ class PointNetSetAbstraction(_FoldAware):
         elif memo is not None and not given_idx and self.npoint in memo.setdefault("new_xyz_t", {}):
             new_xyz_t = memo["new_xyz_t"][self.npoint]
         else:
-            new_xyz_t = new_xyz.transpose(2, 1).contiguous()
+            if new_xyz_t is None:
+                new_xyz_t = new_xyz.transpose(2, 1).contiguous()
             if memo is not None and not given_idx:
                 memo["new_xyz_t"][self.npoint] = new_xyz_t
+        if sampled:
+            geometry_memo.note_transposed(new_xyz, new_xyz_t)   # whoever takes new_xyz as ITS coordinates finds the transpose
         neighbours = None
         if memo is not None and sampled and not given_idx and isinstance(self.queryandgroup, QueryAndGroup):
             # un-clamped kNN shared between layers: the k nearest are a prefix of any larger search on the same inputs
@@ -221,7 +252,9 @@ class PointNetSetAbstraction(_FoldAware):
             for conv, bn in zip(self.mlp_convs, self.mlp_bns):
                 new_points = self.act(bn(pointwise_conv(new_points, conv))) if self.use_act else \
                     pointwise_conv(new_points, conv)
-            if self.mean_aggr:
+            if not pool:
+                pass
+            elif self.mean_aggr:
                 new_points = new_points.mean(dim=-1)
             elif new_points.requires_grad:
                 new_points = new_points.max(dim=-1)[0]      # (its backward sends the gradient to ONE arg-max, as the reference's)

@@ -1,0 +1,104 @@
+"""flow_glue.py / csrc/flow_step.hip: the fused element-wise kernels of FlowStep3D's inference loop against the framework operator
+sequences they replace (models/flownet_kitti.py:135-151, :229-250), and the model with them on against the model with them off."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).cuda()
+
+
+@pytest.mark.parametrize("B,N,M", [(1, 8192, 4096), (2, 100, 37), (3, 1, 5)])
+def test_gather_xyz_pair(B, N, M):
+    from ogc_amd import flow_glue
+    from ogc_amd.pointnet2.pointnet2 import gather_operation
+    xyz = _rand(B, 3, N, seed=1, scale=30.0)
+    idx = torch.randint(0, N, (B, M), generator=torch.Generator().manual_seed(2), dtype=torch.int32).cuda()
+    out, out_t = flow_glue.gather_xyz_pair(xyz, idx)
+    ref = gather_operation(xyz, idx)
+    assert torch.equal(out, ref) and torch.equal(out_t, ref.transpose(1, 2).contiguous())
+
+
+@pytest.mark.parametrize("B,N,divisor", [(1, 8192, 1.0), (2, 2048, 1.8), (1, 77, 3.4), (2, 5, 1), (1, 999, 2.6), (1, 1000, 4.2), (1, 1001, 7.0)])
+def test_flow_advance_is_the_operator_sequence(B, N, divisor):
+    from ogc_amd import flow_glue
+    cur, delta, ref = _rand(B, 3, N, seed=3, scale=20.0), _rand(B, 3, N, seed=4), _rand(B, 3, N, seed=5, scale=20.0)
+    d, new, new_t, flow = flow_glue.flow_advance(cur, delta, ref, divisor=divisor, want_delta=True, want_t=True)
+    d_ref = delta / divisor                      # (torch: delta * fp32(1 / divisor), the reciprocal taken in double)
+    new_ref = cur + d_ref
+    assert torch.equal(d, d_ref) and torch.equal(new, new_ref) and torch.equal(flow, new_ref - ref)
+    assert torch.equal(new_t, new_ref.permute(0, 2, 1).contiguous())
+    d2, new2, t2, f2 = flow_glue.flow_advance(cur, delta, None, want_flow=False)
+    assert d2 is None and t2 is None and f2 is None and torch.equal(new2, cur + delta)
+
+
+@pytest.mark.parametrize("B,cin,cout,N", [(1, 128, 3, 2048), (2, 64, 3, 300), (1, 7, 4, 33), (2, 128, 1, 64)])
+def test_linear_cn(B, cin, cout, N):
+    from ogc_amd import flow_glue
+    x, w, bias = _rand(B, cin, N, seed=6), _rand(cout, cin, seed=7, scale=0.1), _rand(cout, seed=8)
+    y = flow_glue.linear_cn(x, w, bias)
+    ref = torch.nn.functional.linear(x.double().permute(0, 2, 1), w.double(), bias.double()).permute(0, 2, 1)
+    torch.testing.assert_close(y.double(), ref, rtol=1e-5, atol=1e-5)
+    y0 = flow_glue.linear_cn(x, w, None)
+    torch.testing.assert_close(y0.double(), ref - bias.double().view(1, -1, 1), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("B,C,Cx,N,S", [(1, 128, 211, 2048, 4), (2, 16, 5, 100, 4), (1, 8, 3, 33, 3), (2, 4, 0, 17, 8)])
+def test_gru_gates(B, C, Cx, N, S):
+    from ogc_amd import flow_glue
+    hx = _rand(B, C + Cx, N, seed=9)
+    rc, zc, qc = _rand(B, C, N, S, seed=10, scale=3.0), _rand(B, C, N, S, seed=11, scale=3.0), _rand(B, C, N, S, seed=12, scale=2.0)
+    h, x = hx[:, :C], hx[:, C:]
+    out = flow_glue.gru_reset(rc, hx, C)
+    ref = torch.cat([torch.sigmoid(torch.amax(rc, dim=-1)) * h, x], dim=1)
+    torch.testing.assert_close(out, ref, rtol=1e-6, atol=1e-7)
+    assert torch.equal(out[:, C:], x)
+    blend = flow_glue.gru_blend(zc, qc, hx, C)
+    z, q = torch.sigmoid(torch.amax(zc, dim=-1)), torch.tanh(torch.amax(qc, dim=-1))
+    torch.testing.assert_close(blend, (1 - z) * h + z * q, rtol=1e-6, atol=1e-7)
+    # a NaN among the neighbours stays a NaN, as torch.amax's
+    zc2 = zc.clone()
+    zc2[0, 0, 0, S - 1] = float("nan")
+    assert torch.isnan(flow_glue.gru_blend(zc2, qc, hx, C)[0, 0, 0])
+
+
+def test_not_available_when_differentiating_or_on_cpu():
+    from ogc_amd import flow_glue
+    a = torch.zeros(1, 3, 8, device="cuda")
+    assert flow_glue.available(a)
+    assert not flow_glue.available(a.clone().requires_grad_())
+    with torch.no_grad():
+        assert flow_glue.available(a.clone().requires_grad_())
+    assert not flow_glue.available(torch.zeros(1, 3, 8))
+    assert not flow_glue.available(a.double())
+
+
+@pytest.mark.parametrize("variant", ["kitti", "sapien"])
+def test_flowstep3d_inference_with_and_without_the_glue(variant):
+    """Same predictions (to fp32 rounding of the few operations whose summation order differs: the 3-channel linear layer) with the
+    fused loop as with the reference's operator sequence."""
+    import importlib
+    from ogc_amd import flow_glue
+    from ogc_amd.utils.synthetic import make_scene_batch
+    mod = importlib.import_module("ogc_amd.models.flownet_" + variant)
+    torch.manual_seed(0)
+    N = 2048 if variant == "kitti" else 512
+    net = mod.FlowStep3D(npoint=N, loc_flow_nn=16, loc_flow_rad=1.5).cuda().eval()
+    pcs = make_scene_batch(2, N, 6, seed=3, aug=False, device="cuda", outdoor=variant == "kitti")[0]
+    pc1, pc2 = pcs[:, 0].contiguous(), pcs[:, 1].contiguous()
+    was = flow_glue.ENABLED
+    try:
+        with torch.no_grad():
+            flow_glue.ENABLED = True
+            on = net(pc1, pc2, pc1, pc2, iters=4)
+            flow_glue.ENABLED = False
+            off = net(pc1, pc2, pc1, pc2, iters=4)
+    finally:
+        flow_glue.ENABLED = was
+    assert len(on) == len(off) == 4
+    for a, b in zip(on, off):
+        assert a.shape == b.shape
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-5)
