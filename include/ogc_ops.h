@@ -43,7 +43,8 @@ enum {
  * header; a caller checks ogc_version() == OGC_VERSION before anything else (ogc_amd/_lib.py does): the minor number moves with
  * every change of an existing prototype.  0.2.0: ogc_adam_step takes its five hyper-parameters as double (float before), new
  * entry points ogc_zero_arena_begin / _end, ogc_conv1x1_gemm_any, ogc_conv1x1_wgrad_affine_pooled, ogc_conv1x1_dgrad_pooled.  0.2.1 (the patch number moves with new entry
- * points): ogc_gather_xyz_pair, ogc_flow_advance, ogc_linear_cn, ogc_gru_reset, ogc_gru_blend. */
+ * points): ogc_gather_xyz_pair, ogc_flow_advance, ogc_linear_cn, ogc_gru_reset, ogc_gru_blend,
+ * ogc_soft_corr_flow. */
 #define OGC_VERSION 201
 int ogc_version(void);
 /* 0: the squared distance of every search is the reference's SOURCE expression, ((dx*dx) + (dy*dy)) + (dz*dz), one rounding per
@@ -633,17 +634,23 @@ int ogc_chamfer_terms_grad(int b, int n1, int n2, int p, const float *p1, const 
  *                        out_delta, out_new_t (b, n, 3) and out_flow may be null (flownet_kitti.py:229-231, :245-250: scale is
  *                        the fp32 rounding of 1 / (k_decay_fact * it + 1), as torch divides by a Python scalar);
  *   ogc_linear_cn        y (b, cout, n) = weight (cout, cin) x (b, cin, n) + bias, cout <= 4 — nn.Linear between two
- *                        transposes (flownet_kitti.py:19, :38), sequential fp32 FMA over cin; bias may be null;
+ *                        transposes (flownet_kitti.py:19, :38), fp32 FMA chains over the four quarters of cin, added in order; bias may be null;
  *   ogc_gru_reset        hx (b, c + cx, n) = cat([h, x]); rc (b, c, n, s) the reset gate's un-pooled convolution output, batch
  *                        stride rc_batch_stride floats: out (b, c + cx, n) = cat([sigmoid(max_s rc) * h, x]) (:147-149);
  *   ogc_gru_blend        z = sigmoid(max_s zc), q = tanh(max_s qc), out (b, c, n) = (1 - z) * h + z * q (:147, :149-150); zc, qc
  *                        (b, c, n, s) and h (b, c, n) with their batch strides in floats.
+ *   ogc_soft_corr_flow   GlobalCorrLayer's dense soft correspondence and coarse flow (:53-70): w_ij = exp(-(1 - cos(f1_i, f2_j)) /
+ *                        (exp(*epsilon) + 0.03)) where (|p_i|^2 + |q_j|^2) - 2 p_i.q_j < support, else 0; flow (b, 3, n1) =
+ *                        sum_j w_ij q_j / (sum_j w_ij + 1e-8) - p_i.  pc1 (b, 3, n1), pc2 (b, 3, n2), f1 (b, c, n1), f2 (b, c, n2),
+ *                        c a multiple of 4 up to 256; epsilon: the layer's parameter on the device (no host read).
  * Gate pointers 16-byte aligned and gate batch strides multiples of 4 floats. */
 int ogc_gather_xyz_pair(int b, int n, int m, const float *xyz, const int *idx, float *out, float *out_t, ogc_stream_t stream);
 int ogc_flow_advance(int b, int n, float scale, const float *cur, const float *delta, const float *ref, float *out_delta,
                      float *out_new, float *out_new_t, float *out_flow, ogc_stream_t stream);
 int ogc_linear_cn(int b, int cin, int cout, int n, const float *x, const float *weight, const float *bias, float *y,
                   ogc_stream_t stream);
+int ogc_soft_corr_flow(int b, int n1, int n2, int c, float support, const float *epsilon, const float *pc1, const float *pc2,
+                       const float *f1, const float *f2, float *flow, ogc_stream_t stream);
 int ogc_gru_reset(int b, int c, int cx, int n, int s, const float *rc, long long rc_batch_stride, const float *hx, float *out,
                   ogc_stream_t stream);
 int ogc_gru_blend(int b, int c, int n, int s, const float *zc, long long zc_batch_stride, const float *qc,

@@ -11,6 +11,9 @@
 //     linear_cn         y (b, cout, n) = W x + bias on channel-major x (b, cin, n), cout <= 4
 //     gru_reset         out = cat([sigmoid(max_s rc) * h, x])          with hx = cat([h, x]) as the input
 //     gru_blend         z = sigmoid(max_s zc), q = tanh(max_s qc):  out = (1 - z) * h + z * q
+//     soft_corr_flow    the dense soft correlation of the coarsest levels and the flow it implies (see the kernel)
+#include <type_traits>
+
 #include "ogc_common.h"
 
 namespace {
@@ -69,22 +72,46 @@ __global__ __launch_bounds__(256) void flow_advance_kernel(int n, float scale, c
     }
 }
 
+// 64 points per workgroup, one wavefront per quarter of the input channels (a thread's loads are independent of its sums, eight in
+// flight at a time; consecutive lanes read consecutive points): a lane per point walking all cin channels alone is one dependent
+// chain of cin loads — 32 us for 128 channels on 2048 points, against 4 us here.  The four partial sums are added in slice order.
 template <int COUT>
 __global__ __launch_bounds__(256) void linear_cn_kernel(int cin, int n, const float *__restrict__ x, const float *__restrict__ w,
                                                         const float *__restrict__ bias, float *__restrict__ y) {
-    const int b = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float *src = x + (size_t)b * cin * n + i;
+    __shared__ float part[3][COUT][64];
+    const int b = blockIdx.y, lane = threadIdx.x & 63, slice = threadIdx.x >> 6, i = blockIdx.x * 64 + lane;
+    const int per = (cin + 3) >> 2, c0 = slice * per, c1 = min(cin, c0 + per);
+    const float *src = x + (size_t)b * cin * n + min(i, n - 1);
     float acc[COUT];
 #pragma unroll
     for (int o = 0; o < COUT; ++o) acc[o] = 0.0f;
-    for (int c = 0; c < cin; ++c) {
+    int c = c0;
+    for (; c + 8 <= c1; c += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(c + u) * n];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int o = 0; o < COUT; ++o) acc[o] = fmaf(w[o * cin + c + u], v[u], acc[o]); // (w: wave-uniform, scalar loads)
+    }
+    for (; c < c1; ++c) {
         const float v = src[(size_t)c * n];
 #pragma unroll
-        for (int o = 0; o < COUT; ++o) acc[o] = fmaf(w[o * cin + c], v, acc[o]); // (w: wave-uniform addresses, scalar loads)
+        for (int o = 0; o < COUT; ++o) acc[o] = fmaf(w[o * cin + c], v, acc[o]);
     }
+    if (slice > 0) {
 #pragma unroll
-    for (int o = 0; o < COUT; ++o) y[((size_t)b * COUT + o) * n + i] = bias ? acc[o] + bias[o] : acc[o];
+        for (int o = 0; o < COUT; ++o) part[slice - 1][o][lane] = acc[o];
+    }
+    __syncthreads();
+    if (slice == 0 && i < n) {
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) {
+            const float sum = ((acc[o] + part[0][o][lane]) + part[1][o][lane]) + part[2][o][lane];
+            y[((size_t)b * COUT + o) * n + i] = bias ? sum + bias[o] : sum;
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void gru_reset_kernel(int c, int cx, int n, int s, const float *__restrict__ rc, long long rc_bs,
@@ -110,6 +137,92 @@ __global__ __launch_bounds__(256) void gru_blend_kernel(int c, int n, int s, con
     const float q = tanhf(pooled(qc + (size_t)b * qc_bs + p * s, s));
     const float hv = h[(size_t)b * h_bs + p];
     out[((size_t)b * c + ch) * n + i] = __fadd_rn(__fmul_rn(__fsub_rn(1.0f, z), hv), __fmul_rn(z, q));
+}
+
+// The dense soft correlation of the coarsest levels and the flow it implies (GlobalCorrLayer.calc_corr_mat + the three lines
+// after it, flownet_kitti.py:53-70): w_ij = exp(-(1 - cos(f1_i, f2_j)) / (e^epsilon + 0.03)) for pairs with
+// (|p_i|^2 + |q_j|^2) - 2 p_i.q_j < support, else 0;  flow_i = sum_j w_ij q_j / (sum_j w_ij + 1e-8) - p_i.  ~25 framework launches
+// on 256 x 256 matrices there.  A workgroup owns SC_ROWS points of cloud 1 (their features in LDS), a thread one point j of cloud 2
+// at a time: the dot products of its feature column with the SC_ROWS rows, the weights, and their sums over j reduced over the
+// workgroup at the end.  The cosine is (f1.f2) / (|f1| |f2|) with the reference's 1e-8 under both roots.
+constexpr int SC_ROWS = 4, SC_MAXC = 256;
+__global__ __launch_bounds__(256) void soft_corr_flow_kernel(int n1, int n2, int c, float support, const float *__restrict__ epsilon,
+                                                             const float *__restrict__ pc1, const float *__restrict__ pc2,
+                                                             const float *__restrict__ f1, const float *__restrict__ f2,
+                                                             float *__restrict__ flow) {
+    __shared__ float f1s[SC_MAXC][SC_ROWS];
+    __shared__ float rows[SC_ROWS][8];    // x, y, z, |p|^2, 1 / |f1| of the workgroup's rows
+    __shared__ float part[4][SC_ROWS][4]; // per wavefront: sum w, sum w q
+    const int b = blockIdx.y, i0 = blockIdx.x * SC_ROWS, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const float *p1 = pc1 + (size_t)b * 3 * n1, *p2 = pc2 + (size_t)b * 3 * n2;
+    const float *g1 = f1 + (size_t)b * c * n1, *g2 = f2 + (size_t)b * c * n2;
+    for (int e = t; e < c * SC_ROWS; e += 256) {
+        const int ch = e / SC_ROWS, ii = e % SC_ROWS;
+        f1s[ch][ii] = i0 + ii < n1 ? g1[(size_t)ch * n1 + i0 + ii] : 0.0f;
+    }
+    __syncthreads();
+    if (t < SC_ROWS) {
+        const int i = min(i0 + t, n1 - 1);
+        const float x = p1[i], y = p1[n1 + i], z = p1[2 * (size_t)n1 + i];
+        float nn = 0.0f;
+        for (int ch = 0; ch < c; ++ch) nn = fmaf(f1s[ch][t], f1s[ch][t], nn);
+        rows[t][0] = x; rows[t][1] = y; rows[t][2] = z;
+        rows[t][3] = __fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z));
+        rows[t][4] = __fdiv_rn(1.0f, sqrtf(nn + 1e-8f));
+    }
+    __syncthreads();
+    const float temperature = expf(epsilon[0]) + 0.03f;
+    float sw[SC_ROWS], sx[SC_ROWS], sy[SC_ROWS], sz[SC_ROWS];
+#pragma unroll
+    for (int ii = 0; ii < SC_ROWS; ++ii) sw[ii] = sx[ii] = sy[ii] = sz[ii] = 0.0f;
+    for (int j = t; j < n2; j += 256) {
+        float dot[SC_ROWS], nn = 0.0f;
+#pragma unroll
+        for (int ii = 0; ii < SC_ROWS; ++ii) dot[ii] = 0.0f;
+        auto channels = [&](int ch, auto width) { // `width` independent loads in flight (the loop is their latency otherwise)
+            constexpr int U = decltype(width)::value;
+            float v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = g2[(size_t)(ch + u) * n2 + j];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                nn = fmaf(v[u], v[u], nn);
+#pragma unroll
+                for (int ii = 0; ii < SC_ROWS; ++ii) dot[ii] = fmaf(f1s[ch + u][ii], v[u], dot[ii]);
+            }
+        };
+        int ch = 0;
+        for (; ch + 16 <= c; ch += 16) channels(ch, std::integral_constant<int, 16>());
+        for (; ch < c; ch += 4) channels(ch, std::integral_constant<int, 4>()); // (c is a multiple of 4)
+        const float inv2 = __fdiv_rn(1.0f, sqrtf(nn + 1e-8f));
+        const float qx = p2[j], qy = p2[n2 + j], qz = p2[2 * (size_t)n2 + j];
+        const float qq = __fadd_rn(__fadd_rn(__fmul_rn(qx, qx), __fmul_rn(qy, qy)), __fmul_rn(qz, qz));
+#pragma unroll
+        for (int ii = 0; ii < SC_ROWS; ++ii) {
+            const float gram = fmaf(rows[ii][2], qz, fmaf(rows[ii][1], qy, __fmul_rn(rows[ii][0], qx)));
+            const bool near = __fsub_rn(__fadd_rn(rows[ii][3], qq), __fmul_rn(2.0f, gram)) < support;
+            const float cosine = __fmul_rn(__fmul_rn(dot[ii], rows[ii][4]), inv2);
+            const float w = near ? expf(__fdiv_rn(-__fsub_rn(1.0f, cosine), temperature)) : 0.0f;
+            sw[ii] += w;
+            sx[ii] = fmaf(w, qx, sx[ii]); sy[ii] = fmaf(w, qy, sy[ii]); sz[ii] = fmaf(w, qz, sz[ii]);
+        }
+    }
+#pragma unroll
+    for (int ii = 0; ii < SC_ROWS; ++ii) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            sw[ii] += __shfl_xor(sw[ii], off, 64); sx[ii] += __shfl_xor(sx[ii], off, 64);
+            sy[ii] += __shfl_xor(sy[ii], off, 64); sz[ii] += __shfl_xor(sz[ii], off, 64);
+        }
+        if (lane == 0) { part[wave][ii][0] = sw[ii]; part[wave][ii][1] = sx[ii]; part[wave][ii][2] = sy[ii]; part[wave][ii][3] = sz[ii]; }
+    }
+    __syncthreads();
+    if (t < SC_ROWS * 3 && i0 + t / 3 < n1) {
+        const int ii = t / 3, a = t % 3;
+        const float w = (part[0][ii][0] + part[1][ii][0]) + (part[2][ii][0] + part[3][ii][0]);
+        const float v = (part[0][ii][1 + a] + part[1][ii][1 + a]) + (part[2][ii][1 + a] + part[3][ii][1 + a]);
+        flow[((size_t)b * 3 + a) * n1 + i0 + ii] = __fsub_rn(__fdiv_rn(v, __fadd_rn(w, 1e-8f)), rows[ii][a]);
+    }
 }
 
 } // namespace
@@ -146,7 +259,7 @@ extern "C" int ogc_linear_cn(int b, int cin, int cout, int n, const float *x, co
     if (b == 0 || n == 0) return OGC_OK;
     OGC_REQUIRE((x || cin == 0) && (weight || cin == 0) && y, "ogc_linear_cn: null pointer");
     OGC_REQUIRE(b <= 65535 && (long long)b * (cin > cout ? cin : cout) * n < (1ll << 31), "ogc_linear_cn: exceeds 32-bit indexing");
-    const dim3 grid(ogc_divup(n, 256), b), block(256);
+    const dim3 grid(ogc_divup(n, 64), b), block(256);
     hipStream_t s = (hipStream_t)stream;
     switch (cout) {
     case 1: hipLaunchKernelGGL(linear_cn_kernel<1>, grid, block, 0, s, cin, n, x, weight, bias, y); break;
@@ -187,5 +300,18 @@ extern "C" int ogc_gru_blend(int b, int c, int n, int s, const float *zc, long l
     hipLaunchKernelGGL(gru_blend_kernel, dim3(ogc_divup(n, 256), c, b), dim3(256), 0, (hipStream_t)stream, c, n, s, zc,
                        zc_batch_stride, qc, qc_batch_stride, h, h_batch_stride, out);
     OGC_CHECK_LAUNCH("ogc_gru_blend");
+    return OGC_OK;
+}
+
+extern "C" int ogc_soft_corr_flow(int b, int n1, int n2, int c, float support, const float *epsilon, const float *pc1,
+                                  const float *pc2, const float *f1, const float *f2, float *flow, ogc_stream_t stream) {
+    OGC_REQUIRE(b >= 0 && n1 >= 0 && n2 >= 0 && c >= 0, "ogc_soft_corr_flow: negative dimension");
+    OGC_REQUIRE(c <= SC_MAXC && (c & 3) == 0, "ogc_soft_corr_flow: feature width must be a multiple of 4 up to %d (got %d)", SC_MAXC, c);
+    if (b == 0 || n1 == 0) return OGC_OK;
+    OGC_REQUIRE(epsilon && pc1 && flow && (n2 == 0 || pc2) && (c == 0 || (f1 && (n2 == 0 || f2))), "ogc_soft_corr_flow: null pointer");
+    OGC_REQUIRE(b <= 65535 && (long long)b * (c > 3 ? c : 3) * (n1 > n2 ? n1 : n2) < (1ll << 31), "ogc_soft_corr_flow: exceeds 32-bit indexing");
+    hipLaunchKernelGGL(soft_corr_flow_kernel, dim3(ogc_divup(n1, SC_ROWS), b), dim3(256), 0, (hipStream_t)stream, n1, n2, c, support,
+                       epsilon, pc1, pc2, f1, f2, flow);
+    OGC_CHECK_LAUNCH("ogc_soft_corr_flow");
     return OGC_OK;
 }

@@ -66,19 +66,47 @@ def linear_cn(x, weight, bias):
     return y
 
 
-def gru_reset(rc, hx, c):
-    """rc (B, C, N, S): the reset gate's convolution output before its max over the neighbours; hx (B, C + Cx, N) = cat([h, x]).
-    -> cat([sigmoid(max_s rc) * h, x]) (flownet_kitti.py:148-149)."""
+def gru_reset(rc, hx, c, rc_channel0=0):
+    """rc (B, >= C, N, S): the reset gate's convolution output before its max over the neighbours, in channels [rc_channel0,
+    rc_channel0 + C); hx (B, C + Cx, N) = cat([h, x]).  -> cat([sigmoid(max_s rc) * h, x]) (flownet_kitti.py:148-149)."""
     B, ctot, N = hx.shape
     out = torch.empty_like(hx)
-    _api._native.gru_reset_wrapper(B, c, ctot - c, N, rc.shape[3], rc, hx, out)
+    _api._native.gru_reset_wrapper(B, c, ctot - c, N, rc.shape[3], rc, hx, out, rc_channel0)
     return out
 
 
-def gru_blend(zc, qc, hx, c):
-    """zc, qc (B, C, N, S) un-pooled gate / candidate outputs, h = hx[:, :C]: (1 - z) * h + z * q with z = sigmoid(max_s zc),
-    q = tanh(max_s qc) (flownet_kitti.py:147, :149-150)."""
+def gru_blend(zc, qc, hx, c, zc_channel0=0):
+    """zc (B, >= C, N, S) (the gate in channels [zc_channel0, zc_channel0 + C)), qc (B, C, N, S): un-pooled gate / candidate outputs,
+    h = hx[:, :C]: (1 - z) * h + z * q with z = sigmoid(max_s zc), q = tanh(max_s qc) (flownet_kitti.py:147, :149-150)."""
     B, ctot, N = hx.shape
     out = torch.empty(B, c, N, dtype=torch.float32, device=hx.device)
-    _api._native.gru_blend_wrapper(B, c, N, zc.shape[3], zc, qc, hx, ctot * N, out)
+    _api._native.gru_blend_wrapper(B, c, N, zc.shape[3], zc, qc, hx, ctot * N, out, zc_channel0)
     return out
+
+
+_STACKED = {}   # id(first weight) -> (key, stacked weight)
+
+
+def stacked_weight(*weights):
+    """The 1x1-convolution weights of blocks that read the same input, stacked along the output channels (one product instead of
+    one per block); rebuilt when any of them was written (version counters) or moved."""
+    key = tuple((w.data_ptr(), w._version, tuple(w.shape)) for w in weights)
+    hit = _STACKED.get(id(weights[0]))
+    if hit is None or hit[0] != key:
+        with torch.no_grad():
+            hit = (key, torch.cat([w.reshape(w.shape[0], -1) for w in weights]).contiguous())
+        _STACKED[id(weights[0])] = hit
+    return hit[1]
+
+
+def soft_corr_flow(pc1, pc2, f1, f2, epsilon, support):
+    """pc* (B, 3, n), f* (B, C, n) channel-major, epsilon the layer's (1,) parameter: the coarse flow (B, 3, n1) of
+    GlobalCorrLayer.forward's first three lines (flownet_kitti.py:53-70) without the (B, n1, n2) matrices."""
+    B, C, n1 = f1.shape
+    flow = torch.empty(B, 3, n1, dtype=torch.float32, device=pc1.device)
+    _api._native.soft_corr_flow_wrapper(B, n1, f2.shape[2], C, support, epsilon, pc1, pc2, f1, f2, flow)
+    return flow
+
+
+def soft_corr_flow_supported(f1):
+    return f1.shape[1] % 4 == 0 and f1.shape[1] <= 256

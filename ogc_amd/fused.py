@@ -352,6 +352,13 @@ def pointwise_conv(x, conv, gn=None):
     return (conv(x), None) if gn is not None else conv(x)
 
 
+def conv1x1_inference(x, weight2d):
+    """weight2d (cout, cin) applied along the channels of x (B, cin, ...) with nothing to differentiate: _PointwiseConv's forward
+    (the same kernels) on a weight that is not a module's — e.g. two blocks' weights stacked (flow_glue.stacked_weight)."""
+    with torch.no_grad():
+        return _PointwiseConv.apply(x.contiguous(), weight2d.view(weight2d.shape[0], weight2d.shape[1], *([1] * (x.dim() - 2))))
+
+
 class _NeighbourConsistency(Function):
     """per-point mean_j ||m_i - m_idx[i,j]||_p for point-major masks — one launch forward, one backward (a gather over
     the neighbour lists and their transposes).  Reference sequence: grouping_operation, broadcast difference, norm

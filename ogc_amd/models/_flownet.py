@@ -124,13 +124,22 @@ class GlobalCorrLayer(nn.Module):
 
     def forward(self, pc1_l_glob, pc2_l_glob, feats1_glob, feats2_glob):
         top = self.n_stage + 1  # index of the coarsest level in pc*_l_glob
+        if (flow_glue.available(pc1_l_glob[top], pc2_l_glob[top], feats1_glob, feats2_glob, self.epsilon)
+                and flow_glue.soft_corr_flow_supported(feats1_glob)):
+            # inference: weights, row sums and the weighted mean of cloud 2 in one launch, on the channel-major tensors
+            flow0_cm = flow_glue.soft_corr_flow(pc1_l_glob[top].contiguous(), pc2_l_glob[top].contiguous(), feats1_glob.contiguous(),
+                                                feats2_glob.contiguous(), self.epsilon, float(self.support_th))
+            return self._upsample(pc1_l_glob, top, flow0_cm)
         pcloud1 = pc1_l_glob[top].permute(0, 2, 1)
         pcloud2 = pc2_l_glob[top].permute(0, 2, 1)
         corr_mat = self.calc_corr_mat(pcloud1, pcloud2, feats1_glob.permute(0, 2, 1), feats2_glob.permute(0, 2, 1))
         row_sum = corr_mat.sum(-1, keepdim=True)
         flow0 = (corr_mat @ pcloud2.contiguous()) / (row_sum + 1e-8) - pcloud1.contiguous()
 
-        feats = self.fp0(pc1_l_glob[top - 1], pc1_l_glob[top], None, flow0.permute(0, 2, 1).contiguous())
+        return self._upsample(pc1_l_glob, top, flow0.permute(0, 2, 1).contiguous())
+
+    def _upsample(self, pc1_l_glob, top, flow0):
+        feats = self.fp0(pc1_l_glob[top - 1], pc1_l_glob[top], None, flow0)
         for i in range(1, self.n_stage + 1):
             level = top - i
             _, feats = getattr(self, "sa%d" % i)(pc1_l_glob[level], feats)
@@ -208,11 +217,13 @@ class GRU(nn.Module):
         if flow_glue.available(hx, *[p for m in (self.convz, self.convr, self.convq) for p in m.parameters()]):
             # inference: the gates' max over the neighbours, their activations and the products around them in two launches
             # (sigmoid, mul, cat | sigmoid, tanh, 1 - z, two products, sum — and the three maxima — otherwise)
+            # the update and reset gates read the same grouped input: one grouping and one product with both weights stacked
+            from ..fused import conv1x1_inference
             c = h.shape[1]
-            zc = self.convz(pc, hx, pool=False)[1]
-            rc = self.convr(pc, hx, pool=False)[1]
-            qc = self.convq(pc, flow_glue.gru_reset(rc, hx, c), pool=False)[1]
-            return flow_glue.gru_blend(zc, qc, hx, c)
+            zr = conv1x1_inference(self.convz(pc, hx, grouped_only=True)[1],
+                                   flow_glue.stacked_weight(self.convz.mlp_convs[0].weight, self.convr.mlp_convs[0].weight))
+            qc = self.convq(pc, flow_glue.gru_reset(zr, hx, c, rc_channel0=c), pool=False)[1]
+            return flow_glue.gru_blend(zr, qc, hx, c, zc_channel0=0)
         x = parts[0] if len(parts) == 1 else hx[:, h.shape[1]:]
         z = torch.sigmoid(self.convz(pc, hx)[1])
         r = torch.sigmoid(self.convr(pc, hx)[1])

@@ -255,17 +255,35 @@ def linear_cn_wrapper(b, cin, cout, n, x, weight, bias, y):
     _run("ogc_linear_cn", x, b, cin, cout, n, _f(x, "x"), _f(weight, "weight"), 0 if bias is None else _f(bias, "bias"), _f(y, "y"))
 
 
-def gru_reset_wrapper(b, c, cx, n, s, rc, hx, out):
-    """out (b, c + cx, n) = cat([sigmoid(max_s rc) * h, x]) for hx = cat([h, x]) and the un-pooled gate rc (b, c, n, s)
-    (ogc_gru_reset)."""
-    _run("ogc_gru_reset", hx, b, c, cx, n, s, _f(rc, "rc"), c * n * s, _f(hx, "hx"), _f(out, "out"))
+def soft_corr_flow_wrapper(b, n1, n2, c, support, epsilon, pc1, pc2, f1, f2, flow):
+    """GlobalCorrLayer's soft correspondence weights and the coarse flow they imply, in one launch (ogc_soft_corr_flow)."""
+    _run("ogc_soft_corr_flow", pc1, b, n1, n2, c, float(support), _f(epsilon, "epsilon"), _f(pc1, "pc1"), _f(pc2, "pc2"),
+         _f(f1, "f1"), _f(f2, "f2"), _f(flow, "flow"))
 
 
-def gru_blend_wrapper(b, c, n, s, zc, qc, h, h_batch_stride, out):
-    """out (b, c, n) = (1 - z) * h + z * q, z = sigmoid(max_s zc), q = tanh(max_s qc) (ogc_gru_blend); h may be the first c
-    channels of a wider contiguous tensor whose batch stride (in floats) is h_batch_stride."""
-    _run("ogc_gru_blend", h, b, c, n, s, _f(zc, "zc"), c * n * s, _f(qc, "qc"), c * n * s, _f(h, "h"), int(h_batch_stride),
-         _f(out, "out"))
+def _gate_ptr(t, channel0, c, name):
+    """Channels [channel0, channel0 + c) of a contiguous (b, ctot, n, s) fp32 tensor: (address, batch stride in floats)."""
+    base = _f(t, name)
+    ctot, n, s = t.shape[1], t.shape[2], t.shape[3]
+    if channel0 < 0 or channel0 + c > ctot:
+        raise ValueError("%s: channels [%d, %d) of %d" % (name, channel0, channel0 + c, ctot))
+    return base + 4 * channel0 * n * s, ctot * n * s
+
+
+def gru_reset_wrapper(b, c, cx, n, s, rc, hx, out, rc_channel0=0):
+    """out (b, c + cx, n) = cat([sigmoid(max_s rc) * h, x]) for hx = cat([h, x]) and the un-pooled gate: channels [rc_channel0,
+    rc_channel0 + c) of rc (b, >= c, n, s) (ogc_gru_reset)."""
+    ptr, bs = _gate_ptr(rc, rc_channel0, c, "rc")
+    _run("ogc_gru_reset", hx, b, c, cx, n, s, ptr, bs, _f(hx, "hx"), _f(out, "out"))
+
+
+def gru_blend_wrapper(b, c, n, s, zc, qc, h, h_batch_stride, out, zc_channel0=0):
+    """out (b, c, n) = (1 - z) * h + z * q, z = sigmoid(max_s zc), q = tanh(max_s qc) (ogc_gru_blend); zc: channels [zc_channel0,
+    zc_channel0 + c) of a (b, >= c, n, s) tensor; h may be the first c channels of a wider contiguous tensor whose batch stride
+    (in floats) is h_batch_stride."""
+    zp, zbs = _gate_ptr(zc, zc_channel0, c, "zc")
+    qp, qbs = _gate_ptr(qc, 0, c, "qc")
+    _run("ogc_gru_blend", h, b, c, n, s, zp, zbs, qp, qbs, _f(h, "h"), int(h_batch_stride), _f(out, "out"))
 
 
 def kabsch_rotation_wrapper(nb, S, R, valid=None):

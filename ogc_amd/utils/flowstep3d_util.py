@@ -170,10 +170,11 @@ class PointNetSetAbstraction(_FoldAware):
         self.queryandgroup = GroupAll(self.use_xyz) if group_all else QueryAndGroup(radius, nsample, self.use_xyz)
         self.return_fps = return_fps
 
-    def forward(self, xyz, points, fps_idx=None, pool=True):
+    def forward(self, xyz, points, fps_idx=None, pool=True, grouped_only=False):
         # xyz (B, 3, N), points (B, D, N) -> new_xyz (B, 3, S), new_points (B, D', S) [, fps_idx (B, S)]
         # pool=False (blocks without activation only): new_points stay (B, D', S, nsample), the max over the neighbours is the
-        # caller's (the GRU folds it into its gate kernels, flow_glue.gru_reset / gru_blend)
+        # caller's (the GRU folds it into its gate kernels, flow_glue.gru_reset / gru_blend).  grouped_only=True: stop in front of
+        # the MLP and return (new_xyz, the grouped input (B, 3 + D, S, nsample)) — two blocks on the same input share it
         from .. import flow_glue
         assert pool or not (self.use_act or self.mean_aggr), "pool=False is for the blocks without activation"
         xyz = xyz.contiguous()
@@ -243,6 +244,8 @@ class PointNetSetAbstraction(_FoldAware):
             new_points, _ = self.queryandgroup(xyz_t, new_xyz_t, points, neighbours=neighbours)
         else:
             new_points, _ = self.queryandgroup(xyz_t, new_xyz_t, points)
+        if grouped_only:
+            return new_xyz, new_points
         if self.use_act and self.act is F.relu:
             new_points = _shared_mlp(new_points, self.mlp_convs, self.mlp_bns, pool=not self.mean_aggr)
             if self.mean_aggr:

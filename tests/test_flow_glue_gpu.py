@@ -59,6 +59,10 @@ def test_gru_gates(B, C, Cx, N, S):
     blend = flow_glue.gru_blend(zc, qc, hx, C)
     z, q = torch.sigmoid(torch.amax(zc, dim=-1)), torch.tanh(torch.amax(qc, dim=-1))
     torch.testing.assert_close(blend, (1 - z) * h + z * q, rtol=1e-6, atol=1e-7)
+    # the gates as channel ranges of one wider tensor (update and reset gate from one stacked product)
+    zr = torch.cat([zc, rc], dim=1).contiguous()
+    assert torch.equal(flow_glue.gru_reset(zr, hx, C, rc_channel0=C), out)
+    assert torch.equal(flow_glue.gru_blend(zr, qc, hx, C, zc_channel0=0), blend)
     # a NaN among the neighbours stays a NaN, as torch.amax's
     zc2 = zc.clone()
     zc2[0, 0, 0, S - 1] = float("nan")
@@ -102,3 +106,25 @@ def test_flowstep3d_inference_with_and_without_the_glue(variant):
     for a, b in zip(on, off):
         assert a.shape == b.shape
         torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("B,n1,n2,C", [(1, 256, 256, 128), (2, 100, 77, 64), (1, 9, 300, 4)])
+def test_soft_corr_flow_is_the_global_correlation(B, n1, n2, C):
+    """GlobalCorrLayer's own operator sequence (calc_corr_mat, row sums, weighted mean; flownet_kitti.py:53-70) in fp64 against the
+    kernel; clouds wide enough that many pairs lie beyond the 10 m support."""
+    from ogc_amd import flow_glue
+    from ogc_amd.models.flownet_kitti import FlowStep3D
+    layer = FlowStep3D(npoint=512, loc_flow_nn=16, loc_flow_rad=1.5).global_corr_layer.cuda()
+    with torch.no_grad():
+        layer.epsilon.fill_(0.3)
+    p1, p2 = _rand(B, 3, n1, seed=20, scale=8.0), _rand(B, 3, n2, seed=21, scale=8.0)
+    f1, f2 = _rand(B, C, n1, seed=22), _rand(B, C, n2, seed=23)
+    with torch.no_grad():
+        flow = flow_glue.soft_corr_flow(p1, p2, f1, f2, layer.epsilon, float(layer.support_th))
+        dl = layer.double()
+        q1, q2 = p1.double().permute(0, 2, 1), p2.double().permute(0, 2, 1)
+        w = dl.calc_corr_mat(q1, q2, f1.double().permute(0, 2, 1), f2.double().permute(0, 2, 1))
+        ref = ((w @ q2) / (w.sum(-1, keepdim=True) + 1e-8) - q1).permute(0, 2, 1)
+        frac_out = (w == 0).double().mean().item()
+    assert 0.05 < frac_out < 0.95          # the support mask matters in this test
+    torch.testing.assert_close(flow.double(), ref, rtol=1e-4, atol=1e-4)
