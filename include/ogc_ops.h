@@ -44,7 +44,7 @@ enum {
  * every change of an existing prototype.  0.2.0: ogc_adam_step takes its five hyper-parameters as double (float before), new
  * entry points ogc_zero_arena_begin / _end, ogc_conv1x1_gemm_any, ogc_conv1x1_wgrad_affine_pooled, ogc_conv1x1_dgrad_pooled.  0.2.1 (the patch number moves with new entry
  * points): ogc_gather_xyz_pair, ogc_flow_advance, ogc_linear_cn, ogc_gru_reset, ogc_gru_blend,
- * ogc_soft_corr_flow. */
+ * ogc_soft_corr_flow, ogc_three_nn_weights; ogc_furthest_point_sampling_chain accepts temp == NULL. */
 #define OGC_VERSION 201
 int ogc_version(void);
 /* 0: the squared distance of every search is the reference's SOURCE expression, ((dx*dx) + (dy*dy)) + (dz*dz), one rounding per
@@ -76,7 +76,10 @@ int ogc_furthest_point_sampling(int b, int n, int m, const float *xyz, float *te
  * unique farthest point from samples 0..r-1 — the answer is 0, 1, ..., m-1 (written directly; temp is left untouched
  * and ties_out[i] = ties_in[i], so the chain can go on).  Otherwise the rounds are run as usual, so the result is in
  * every case the one ogc_furthest_point_sampling returns.  Clouds of more than 16384 points are always sampled and
- * report ties_out = 0 (nothing known). */
+ * report ties_out = 0 (nothing known).
+ * temp may be NULL for clouds of up to 16384 points (0.2.1): the running minima start at 1e10, stay in registers and are not
+ * handed back — what every caller of the reference does with them (pointnet2.py:33-35 allocates, fills and drops temp), without the
+ * fill launch and the (b, n) buffer. */
 int ogc_furthest_point_sampling_chain(int b, int n, int m, const float *xyz, float *temp, int *idx,
                                       const int *ties_in, int *ties_out, ogc_stream_t stream);
 
@@ -643,12 +646,16 @@ int ogc_chamfer_terms_grad(int b, int n1, int n2, int p, const float *p1, const 
  *                        (exp(*epsilon) + 0.03)) where (|p_i|^2 + |q_j|^2) - 2 p_i.q_j < support, else 0; flow (b, 3, n1) =
  *                        sum_j w_ij q_j / (sum_j w_ij + 1e-8) - p_i.  pc1 (b, 3, n1), pc2 (b, 3, n2), f1 (b, c, n1), f2 (b, c, n2),
  *                        c a multiple of 4 up to 256; epsilon: the layer's parameter on the device (no host read).
+ *   ogc_three_nn_weights weight (b, n, 3) from ogc_three_nn's squared distances dist2 (b, n, 3): r_k = 1 / max(sqrt(d2_k), 1e-10)
+ *                        (mode 0, utils/flowstep3d_util.py:169-170) or 1 / (sqrt(d2_k) + 1e-8) (mode 1, utils/pointnet2_util.py:99-101),
+ *                        weight_k = r_k / ((r_0 + r_1) + r_2).
  * Gate pointers 16-byte aligned and gate batch strides multiples of 4 floats. */
 int ogc_gather_xyz_pair(int b, int n, int m, const float *xyz, const int *idx, float *out, float *out_t, ogc_stream_t stream);
 int ogc_flow_advance(int b, int n, float scale, const float *cur, const float *delta, const float *ref, float *out_delta,
                      float *out_new, float *out_new_t, float *out_flow, ogc_stream_t stream);
 int ogc_linear_cn(int b, int cin, int cout, int n, const float *x, const float *weight, const float *bias, float *y,
                   ogc_stream_t stream);
+int ogc_three_nn_weights(int b, int n, int mode, const float *dist2, float *weight, ogc_stream_t stream);
 int ogc_soft_corr_flow(int b, int n1, int n2, int c, float support, const float *epsilon, const float *pc1, const float *pc2,
                        const float *f1, const float *f2, float *flow, ogc_stream_t stream);
 int ogc_gru_reset(int b, int c, int cx, int n, int s, const float *rc, long long rc_batch_stride, const float *hx, float *out,

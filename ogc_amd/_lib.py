@@ -45,6 +45,7 @@ SIGNATURES = {
     "ogc_gather_xyz_pair": [_int, _int, _int, _vp, _vp, _vp, _vp, _vp],
     "ogc_flow_advance": [_int, _int, _flt, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "ogc_linear_cn": [_int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp],
+    "ogc_three_nn_weights": [_int, _int, _int, _vp, _vp, _vp],
     "ogc_soft_corr_flow": [_int, _int, _int, _int, _flt, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "ogc_gru_reset": [_int, _int, _int, _int, _int, _vp, _ll, _vp, _vp, _vp],
     "ogc_gru_blend": [_int, _int, _int, _int, _vp, _ll, _vp, _ll, _vp, _ll, _vp, _vp],

@@ -11,6 +11,7 @@
 //     linear_cn         y (b, cout, n) = W x + bias on channel-major x (b, cin, n), cout <= 4
 //     gru_reset         out = cat([sigmoid(max_s rc) * h, x])          with hx = cat([h, x]) as the input
 //     gru_blend         z = sigmoid(max_s zc), q = tanh(max_s qc):  out = (1 - z) * h + z * q
+//     three_nn_weights  normalised inverse distances of the three neighbours from ogc_three_nn's squared distances
 //     soft_corr_flow    the dense soft correlation of the coarsest levels and the flow it implies (see the kernel)
 #include <type_traits>
 
@@ -137,6 +138,24 @@ __global__ __launch_bounds__(256) void gru_blend_kernel(int c, int n, int s, con
     const float q = tanhf(pooled(qc + (size_t)b * qc_bs + p * s, s));
     const float hv = h[(size_t)b * h_bs + p];
     out[((size_t)b * c + ch) * n + i] = __fadd_rn(__fmul_rn(__fsub_rn(1.0f, z), hv), __fmul_rn(z, q));
+}
+
+// inverse-distance weights of the three nearest neighbours from their SQUARED distances (what ogc_three_nn returns):
+// mode 0 (utils/flowstep3d_util.py:169-170)  r_k = 1 / max(sqrt(d2_k), 1e-10);  mode 1 (utils/pointnet2_util.py:99-101)  r_k = 1 /
+// (sqrt(d2_k) + 1e-8);  weight_k = r_k / ((r_0 + r_1) + r_2).  sqrt, clamp, reciprocal, sum and division as one launch.
+__global__ __launch_bounds__(256) void three_nn_weights_kernel(long long rows, int mode, const float *__restrict__ dist2,
+                                                               float *__restrict__ weight) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows) return;
+    float r[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float d = sqrtf(dist2[i * 3 + k]);
+        r[k] = __fdiv_rn(1.0f, mode == 0 ? fmaxf(d, 1e-10f) : __fadd_rn(d, 1e-8f));
+    }
+    const float sum = __fadd_rn(__fadd_rn(r[0], r[1]), r[2]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) weight[i * 3 + k] = __fdiv_rn(r[k], sum);
 }
 
 // The dense soft correlation of the coarsest levels and the flow it implies (GlobalCorrLayer.calc_corr_mat + the three lines
@@ -313,5 +332,17 @@ extern "C" int ogc_soft_corr_flow(int b, int n1, int n2, int c, float support, c
     hipLaunchKernelGGL(soft_corr_flow_kernel, dim3(ogc_divup(n1, SC_ROWS), b), dim3(256), 0, (hipStream_t)stream, n1, n2, c, support,
                        epsilon, pc1, pc2, f1, f2, flow);
     OGC_CHECK_LAUNCH("ogc_soft_corr_flow");
+    return OGC_OK;
+}
+
+extern "C" int ogc_three_nn_weights(int b, int n, int mode, const float *dist2, float *weight, ogc_stream_t stream) {
+    OGC_REQUIRE(b >= 0 && n >= 0, "ogc_three_nn_weights: negative dimension");
+    OGC_REQUIRE(mode == 0 || mode == 1, "ogc_three_nn_weights: mode 0 (clamp at 1e-10) or 1 (+ 1e-8), got %d", mode);
+    if (b == 0 || n == 0) return OGC_OK;
+    OGC_REQUIRE(dist2 && weight, "ogc_three_nn_weights: null pointer");
+    const long long rows = (long long)b * n;
+    OGC_REQUIRE(rows * 3 < (1ll << 31), "ogc_three_nn_weights: exceeds 32-bit indexing");
+    hipLaunchKernelGGL(three_nn_weights_kernel, dim3(ogc_divup(rows, 256)), dim3(256), 0, (hipStream_t)stream, rows, mode, dist2, weight);
+    OGC_CHECK_LAUNCH("ogc_three_nn_weights");
     return OGC_OK;
 }

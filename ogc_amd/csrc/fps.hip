@@ -148,7 +148,7 @@ __global__ __launch_bounds__(THREADS) void fps_reg_kernel(int n, int m, int bs_s
     const int lane = t & (OGC_WAVE - 1);
     const int b = blockIdx.x;
     const float *__restrict__ dataset = xyz + (size_t)b * n * 3;
-    float *tmp = temp + (size_t)b * n;
+    float *tmp = temp ? temp + (size_t)b * n : nullptr; // null: the minima start at 1e10 and are not handed back
     int *out = idxs + (size_t)b * m;
     const int S = (n + (1 << bs_shift) - 1) >> bs_shift;
     const int nslot = S << bs_shift; // rank slots in use (>= n)
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(THREADS) void fps_reg_kernel(int n, int m, int bs_s
             px[j] = dataset[k * 3 + 0];
             py[j] = dataset[k * 3 + 1];
             pz[j] = dataset[k * 3 + 2];
-            td[j] = tmp[k];
+            td[j] = tmp ? tmp[k] : 1e10f;
         } else {
             px[j] = py[j] = pz[j] = 0.0f;
             td[j] = -1.0f; // padding never wins: real values are >= 0 and fminf(d, -1) = -1
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(THREADS) void fps_reg_kernel(int n, int m, int bs_s
     for (int j = 0; j < PTS; ++j) {
         const unsigned rho = (unsigned)(t + j * THREADS);
         const int k = rho < (unsigned)nslot ? fps_rank_to_k(rho, S, bs_shift) : n;
-        if (k < n) tmp[k] = td[j];
+        if (k < n && tmp) tmp[k] = td[j];
     }
     // ranks -> point indices (kept off the per-round critical path: the division is ~20 dependent instructions)
     __syncthreads();
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(WAVES *OGC_WAVE) void fps_bucket_kernel(int n, int 
     unsigned short *perm = reinterpret_cast<unsigned short *>(hist + NBIN); // [SLOTS] sorted position -> point
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, b = blockIdx.x;
     const float *__restrict__ dataset = xyz + (size_t)b * n * 3;
-    float *tmp = temp + (size_t)b * n;
+    float *tmp = temp ? temp + (size_t)b * n : nullptr; // null: see fps_reg_kernel
     int *out = idxs + (size_t)b * m;
     const int S = (n + (1 << bs_shift) - 1) >> bs_shift, bs_mask = (1 << bs_shift) - 1;
 
@@ -510,7 +510,7 @@ __global__ __launch_bounds__(WAVES *OGC_WAVE) void fps_bucket_kernel(int n, int 
             px[j] = dataset[k * 3 + 0];
             py[j] = dataset[k * 3 + 1];
             pz[j] = dataset[k * 3 + 2];
-            td[j] = tmp[k];
+            td[j] = tmp ? tmp[k] : 1e10f;
             rk[j] = (fps_rank(k, bs_mask, bs_shift, S) << WSHIFT) | (unsigned)(XYZ_LDS ? 0 : wave);
         } else {
             px[j] = py[j] = pz[j] = 0.0f;
@@ -669,7 +669,7 @@ __global__ __launch_bounds__(WAVES *OGC_WAVE) void fps_bucket_kernel(int n, int 
     }
 #pragma unroll
     for (int j = 0; j < PTS; ++j) {
-        if (rk[j] != 0xFFFFFFFFu) tmp[fps_rank_to_k(rk[j] >> WSHIFT, S, bs_shift)] = td[j];
+        if (rk[j] != 0xFFFFFFFFu && tmp) tmp[fps_rank_to_k(rk[j] >> WSHIFT, S, bs_shift)] = td[j];
     }
     __syncthreads();
     for (int r = L + t; r < m; r += THREADS) out[r] = fps_rank_to_k((unsigned)out[r], S, bs_shift);
@@ -875,15 +875,19 @@ void fps_launch(int b, int n, int m, int shift, const float *xyz, float *temp, i
 } // namespace
 
 static int fps_impl(const char *name, int b, int n, int m, const float *xyz, float *temp, int *idx, const int *ties_in,
-                    int *ties_out, ogc_stream_t stream) {
+                    int *ties_out, ogc_stream_t stream, bool allow_null_temp) {
     OGC_REQUIRE(b >= 0 && n >= 0 && m >= 0, "%s: negative dimension", name);
     if (b == 0 || m <= 0) return OGC_OK; // sampling_gpu.cu:98
     OGC_REQUIRE(n >= 1, "%s: n must be >= 1 when m > 0", name);
-    OGC_REQUIRE(xyz && temp && idx, "%s: null pointer", name);
+    OGC_REQUIRE(xyz && idx, "%s: null pointer", name);
     OGC_REQUIRE((long long)b * n * 3 < (1ll << 31), "%s: xyz exceeds 32-bit indexing", name);
     const int shift = fps_ref_block_shift(n);
     const int bs = 1 << shift;
     const int slots = ((n + bs - 1) / bs) * bs; // rank slots = bs * ceil(n / bs)
+    // temp == null (the chain entry point only): the running minima live in registers for the whole run, start at the reference's
+    // 1e10 (pointnet2.py:33) and are not written back — no fill launch in front of the sampling, no (b, n) buffer
+    OGC_REQUIRE(temp || (allow_null_temp && slots <= 16384), "%s: temp is required%s", name,
+                allow_null_temp ? " above 16384 points (the minima are kept in memory there)" : "");
     hipStream_t s = (hipStream_t)stream;
     if (slots <= 64) fps_launch<1, 64>(b, n, m, shift, xyz, temp, idx, ties_in, ties_out, s);
     else if (slots <= 128) fps_launch<2, 64>(b, n, m, shift, xyz, temp, idx, ties_in, ties_out, s);
@@ -965,10 +969,10 @@ static int fps_impl(const char *name, int b, int n, int m, const float *xyz, flo
 
 extern "C" int ogc_furthest_point_sampling(int b, int n, int m, const float *xyz, float *temp, int *idx,
                                            ogc_stream_t stream) {
-    return fps_impl("ogc_furthest_point_sampling", b, n, m, xyz, temp, idx, nullptr, nullptr, stream);
+    return fps_impl("ogc_furthest_point_sampling", b, n, m, xyz, temp, idx, nullptr, nullptr, stream, false);
 }
 
 extern "C" int ogc_furthest_point_sampling_chain(int b, int n, int m, const float *xyz, float *temp, int *idx,
                                                  const int *ties_in, int *ties_out, ogc_stream_t stream) {
-    return fps_impl("ogc_furthest_point_sampling_chain", b, n, m, xyz, temp, idx, ties_in, ties_out, stream);
+    return fps_impl("ogc_furthest_point_sampling_chain", b, n, m, xyz, temp, idx, ties_in, ties_out, stream, true);
 }

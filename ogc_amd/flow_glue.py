@@ -110,3 +110,16 @@ def soft_corr_flow(pc1, pc2, f1, f2, epsilon, support):
 
 def soft_corr_flow_supported(f1):
     return f1.shape[1] % 4 == 0 and f1.shape[1] <= 256
+
+
+def three_nn_with_weights(unknown_t, known_t, mode=0):
+    """unknown_t (B, n, 3), known_t (B, m, 3) -> (idx (B, n, 3) int32, weight (B, n, 3)): three_nn and the normalised inverse
+    distances of utils/flowstep3d_util.py:168-170 (mode 0) in two launches instead of six."""
+    B, n, _ = unknown_t.shape
+    dist2 = torch.empty(B, n, 3, dtype=torch.float32, device=unknown_t.device)
+    idx = torch.empty(B, n, 3, dtype=torch.int32, device=unknown_t.device)
+    nat = _api._native
+    nat.three_nn_wrapper(B, n, known_t.shape[1], unknown_t, known_t, dist2, idx)
+    weight = torch.empty_like(dist2)
+    nat.three_nn_weights_wrapper(B, n, mode, dist2, weight)
+    return idx, weight

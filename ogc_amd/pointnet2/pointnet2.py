@@ -83,7 +83,9 @@ def furthest_point_sample_chain(xyz: torch.Tensor, npoint: int, parent_ties=None
     assert xyz.is_contiguous()
     B, N, _ = xyz.size()
     output = _new(xyz, (B, npoint), torch.int32)
-    temp = _new(xyz, (B, N), torch.float32, fill=1e10)
+    # (the running minima: the kernels keep them in registers and nobody reads them afterwards — no buffer, no fill launch;
+    # above 16384 points they live in memory)
+    temp = _new(xyz, (B, N), torch.float32, fill=1e10) if N > 16384 else None
     ties = torch.empty(B, dtype=torch.int32, device=xyz.device)
     chain(B, N, npoint, xyz, temp, output, parent_ties, ties)
     return output, ties

@@ -163,8 +163,9 @@ def furthest_point_sampling_wrapper(b, n, m, points, temp, idx):
 def furthest_point_sampling_chain_wrapper(b, n, m, points, temp, idx, ties_in, ties_out):
     """FPS along a chain of levels (ogc_furthest_point_sampling_chain): `ties_in` (b,) int32 from the run that produced
     `points` (its first n samples in order) lets tie-free samples skip the rounds; `ties_out` (b,) int32 records this
-    run's tie count.  Either may be None."""
-    _run("ogc_furthest_point_sampling_chain", points, b, n, m, _f(points, "points"), _f(temp, "temp"), _i(idx, "idx"),
+    run's tie count.  Either may be None; so may `temp` for n <= 16384 (the minima start at 1e10 and are not returned)."""
+    _run("ogc_furthest_point_sampling_chain", points, b, n, m, _f(points, "points"), 0 if temp is None else _f(temp, "temp"),
+         _i(idx, "idx"),
          _opt(ties_in, torch.int32, "ties_in"), _opt(ties_out, torch.int32, "ties_out"))
     return 1
 
@@ -253,6 +254,12 @@ def flow_advance_wrapper(b, n, scale, cur, delta, ref, out_delta, out_new, out_n
 def linear_cn_wrapper(b, cin, cout, n, x, weight, bias, y):
     """y (b, cout, n) = weight (cout, cin) x (b, cin, n) + bias, cout <= 4 (ogc_linear_cn); bias may be None."""
     _run("ogc_linear_cn", x, b, cin, cout, n, _f(x, "x"), _f(weight, "weight"), 0 if bias is None else _f(bias, "bias"), _f(y, "y"))
+
+
+def three_nn_weights_wrapper(b, n, mode, dist2, weight):
+    """Normalised inverse-distance weights (b, n, 3) from three_nn_wrapper's squared distances (ogc_three_nn_weights): mode 0 clamps
+    the distance at 1e-10 (FlowStep3D), mode 1 adds 1e-8 (the segmentation nets)."""
+    _run("ogc_three_nn_weights", dist2, b, n, int(mode), _f(dist2, "dist2"), _f(weight, "weight"))
 
 
 def soft_corr_flow_wrapper(b, n1, n2, c, support, epsilon, pc1, pc2, f1, f2, flow):

@@ -291,9 +291,14 @@ class PointNetFeaturePropogation(_FoldAware):
         memo = geometry_memo.entry(pos1)
         hit = memo["three_nn"].get(id(pos2)) if memo is not None else None
         if hit is None or hit[0] is not pos2 or hit[3] != (pos2.data_ptr(), pos2._version):
-            dists, idx = three_nn(pos1.permute(0, 2, 1).contiguous(), pos2.permute(0, 2, 1).contiguous())
-            weight = 1.0 / dists.clamp(min=1e-10)                                     # :169-170
-            weight = (weight / weight.sum(dim=-1, keepdim=True)).contiguous()
+            from .. import flow_glue
+            if flow_glue.available(pos1, pos2):
+                # inference: the transposed copies from the memo, sqrt / clamp / reciprocal / sum / division as one launch
+                idx, weight = flow_glue.three_nn_with_weights(geometry_memo.transposed(pos1), geometry_memo.transposed(pos2))
+            else:
+                dists, idx = three_nn(pos1.permute(0, 2, 1).contiguous(), pos2.permute(0, 2, 1).contiguous())
+                weight = 1.0 / dists.clamp(min=1e-10)                                     # :169-170
+                weight = (weight / weight.sum(dim=-1, keepdim=True)).contiguous()
             hit = (pos2, idx, weight, (pos2.data_ptr(), pos2._version))
             if memo is not None:
                 memo["three_nn"][id(pos2)] = hit

@@ -128,3 +128,35 @@ def test_soft_corr_flow_is_the_global_correlation(B, n1, n2, C):
         frac_out = (w == 0).double().mean().item()
     assert 0.05 < frac_out < 0.95          # the support mask matters in this test
     torch.testing.assert_close(flow.double(), ref, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("B,n,m", [(1, 8192, 2048), (2, 300, 50), (1, 5, 3)])
+def test_three_nn_with_weights(B, n, m):
+    from ogc_amd import flow_glue
+    from ogc_amd.pointnet2.pointnet2 import three_nn
+    unknown, known = _rand(B, n, 3, seed=30, scale=10.0), _rand(B, m, 3, seed=31, scale=10.0)
+    unknown[:, 0] = known[:, 0]          # a coincident pair: distance 0, clamped at 1e-10
+    idx, weight = flow_glue.three_nn_with_weights(unknown, known)
+    dists, idx_ref = three_nn(unknown, known)
+    w = 1.0 / dists.clamp(min=1e-10)
+    w = w / w.sum(dim=-1, keepdim=True)
+    assert torch.equal(idx, idx_ref)
+    torch.testing.assert_close(weight, w, rtol=1e-6, atol=1e-9)
+    # mode 1: the segmentation nets' form (utils/pointnet2_util.py:99-101)
+    w1 = torch.empty_like(weight)
+    from ogc_amd import pointnet2_cuda as nat
+    nat.three_nn_weights_wrapper(B, n, 1, dists * dists, w1)
+    r = 1.0 / ((dists * dists).sqrt() + 1e-8)
+    torch.testing.assert_close(w1, r / r.sum(dim=2, keepdim=True), rtol=1e-6, atol=1e-9)
+
+
+def test_fps_chain_without_temp_equals_fps():
+    """ogc_furthest_point_sampling_chain with temp == NULL (minima kept in registers, starting at 1e10): the indices of the plain
+    entry point, for the register kernel, the bucket kernels and a tie lattice."""
+    from ogc_amd.pointnet2.pointnet2 import furthest_point_sample, furthest_point_sample_chain
+    for B, N, m, seed in [(2, 300, 100, 1), (1, 2048, 512, 2), (2, 8192, 4096, 3), (1, 16384, 1024, 4), (3, 5000, 700, 5)]:
+        xyz = _rand(B, N, 3, seed=seed, scale=20.0)
+        if seed == 5:
+            xyz = torch.round(xyz)       # a lattice: exact distance ties
+        idx, ties = furthest_point_sample_chain(xyz, m)
+        assert torch.equal(idx, furthest_point_sample(xyz, m)), (B, N, m)
