@@ -31,6 +31,7 @@ extern "C" {
 #endif
 
 typedef void *ogc_stream_t; /* hipStream_t */
+typedef unsigned short ogc_bf16_t; /* one bfloat16 (the upper half of an fp32), storage only: the `_h` entry points */
 
 enum {
     OGC_OK = 0,
@@ -44,8 +45,9 @@ enum {
  * every change of an existing prototype.  0.2.0: ogc_adam_step takes its five hyper-parameters as double (float before), new
  * entry points ogc_zero_arena_begin / _end, ogc_conv1x1_gemm_any, ogc_conv1x1_wgrad_affine_pooled, ogc_conv1x1_dgrad_pooled.  0.2.1 (the patch number moves with new entry
  * points): ogc_gather_xyz_pair, ogc_flow_advance, ogc_linear_cn, ogc_gru_reset, ogc_gru_blend,
- * ogc_soft_corr_flow, ogc_three_nn_weights; ogc_furthest_point_sampling_chain accepts temp == NULL. */
-#define OGC_VERSION 201
+ * ogc_soft_corr_flow, ogc_three_nn_weights; ogc_furthest_point_sampling_chain accepts temp == NULL.  0.2.2: the `_h` entry points
+ * (activations of the shared MLPs stored as bf16; see "16-bit activations" at the end of this header). */
+#define OGC_VERSION 202
 int ogc_version(void);
 /* 0: the squared distance of every search is the reference's SOURCE expression, ((dx*dx) + (dy*dy)) + (dz*dz), one rounding per
  * operation (what all parity tests pin).  1: this is libogc_ops_fmad.so, the same library with the search kernels (FPS, kNN,
@@ -670,6 +672,57 @@ int ogc_gru_blend(int b, int c, int n, int s, const float *zc, long long zc_batc
  * most one operator between the two calls.  bytes and base multiples of 4. */
 int ogc_zero_arena_begin(void *base, int bytes, ogc_stream_t stream);
 int ogc_zero_arena_end(void);
+
+/* ---- 16-bit activations (`matmul_precision: bf16` of BASELINE config 2, verdict row g2) ------------------------------------------
+ * Inside a set-abstraction MLP (reference: utils/nn_util.py:45-85 on models/segnet_ogcdr.py:26-41) the only tensors of the size
+ * of an activation are the convolutions' raw outputs y and the gradients with respect to them; under bf16 operands every kernel
+ * that streams one is bound by its bytes.  The `_h` entry points below are the entry points of the same name with those tensors
+ * (and only those) stored as bf16 — ogc_bf16_t, round to nearest even on the way out; every argument is otherwise unchanged, and
+ * so is the arithmetic: fp32 accumulation, fp64 statistics, fp32 coefficients, fp32 pooled outputs.  Statistics and
+ * neighbourhood extremes a kernel produces next to a 16-bit output are those of the ROUNDED values, so that the norm that
+ * follows describes exactly the tensor it reads.  They need ogc_set_matmul_precision(1) (operands are bf16 as well —
+ * including the pooled forms, which keep fp32 operands for fp32 tensors) and 8-byte aligned tensors; OGC_ERR_UNSUPPORTED
+ * otherwise.  ogc_conv1x1_wgrad_xf_h: x fp32 (the relative coordinates of a grouped first layer), dy bf16. */
+int ogc_group_linear_fwd_h(int b, int m, int n, int npoints, int nsample, int groups, const float *P, const int *idx,
+                           const float *rel, const float *wx, ogc_bf16_t *y, double *stats, ogc_stream_t stream);
+int ogc_group_points_grad_rev_h(int b, int c, int n, int npoints, int nsample, const ogc_bf16_t *grad_out, const int *rev_start,
+                                const unsigned short *rev_pos, const unsigned short *heads, float *grad_points,
+                                ogc_stream_t stream);
+int ogc_conv1x1_gemm_h(int b, int M, int K, int hw, int transpose_a, const float *w, const ogc_bf16_t *in, ogc_bf16_t *out,
+                       ogc_stream_t stream);
+int ogc_conv1x1_gemm_affine_h(int b, int M, int K, int hw, int relu, int groups, const float *w, const ogc_bf16_t *in,
+                              const float *pa, const float *pb, ogc_bf16_t *out, double *stats, ogc_stream_t stream);
+int ogc_conv1x1_gemm_affine_pool_h(int b, int M, int K, int hw, int relu, int groups, int nsample, const float *w,
+                                   const ogc_bf16_t *in, const float *pa, const float *pb, const float *next_gamma,
+                                   ogc_bf16_t *out, double *stats, float *yext, int *aext, ogc_stream_t stream);
+int ogc_conv1x1_wgrad_xf_h(int b, int cin, int cout, int hw, const float *x, const ogc_bf16_t *dy, float *dw,
+                           ogc_stream_t stream);
+int ogc_conv1x1_wgrad_affine_h(int b, int cin, int cout, int hw, int relu, const ogc_bf16_t *x, const float *pa,
+                               const float *pb, const ogc_bf16_t *dy, float *dw, ogc_stream_t stream);
+int ogc_conv1x1_wgrad_affine_pooled_h(int b, int cin, int cout, int hw, int relu, int nsample, const ogc_bf16_t *x,
+                                      const float *pa, const float *pb, const ogc_bf16_t *y, const float *coef2,
+                                      const float *inj, float *dw, ogc_stream_t stream);
+int ogc_conv1x1_dgrad_pooled_h(int b, int cin, int cout, int hw, int nsample, const float *w, const ogc_bf16_t *y,
+                               const float *coef2, const float *inj, ogc_bf16_t *grad_z, ogc_stream_t stream);
+int ogc_conv1x1_wgrad_moments_h(int b, int cin, int cout, int hw, int relu, const ogc_bf16_t *y_prev, const float *pa,
+                                const float *pb, const ogc_bf16_t *grad_y, float *moments, ogc_stream_t stream);
+int ogc_conv1x1_wgrad_moments_pooled_h(int b, int cin, int cout, int hw, int relu, int nsample, const ogc_bf16_t *y_prev,
+                                       const float *pa, const float *pb, const ogc_bf16_t *y, const float *coef2,
+                                       const float *inj, float *moments, ogc_stream_t stream);
+int ogc_conv1x1_dgrad_adjoint_h(int b, int cin, int cout, int hw, int relu, const float *w, const ogc_bf16_t *grad_y,
+                                const ogc_bf16_t *y_prev, const float *pa, const float *pb, const float *coef,
+                                ogc_bf16_t *grad_prev, ogc_stream_t stream);
+int ogc_conv1x1_dgrad_adjoint_pooled_h(int b, int cin, int cout, int hw, int relu, int nsample, const float *w,
+                                       const ogc_bf16_t *y, const float *coef2, const float *inj, const ogc_bf16_t *y_prev,
+                                       const float *pa, const float *pb, const float *coef, ogc_bf16_t *grad_prev,
+                                       ogc_stream_t stream);
+int ogc_group_norm_bwd_h(int b, int c, int hw, int groups, int relu, const ogc_bf16_t *x, const float *gamma,
+                         const float *beta, const float *mean, const float *rstd, const ogc_bf16_t *grad_y,
+                         ogc_bf16_t *grad_x, float *grad_gamma, float *grad_beta, double *ws, ogc_stream_t stream);
+int ogc_group_norm_maxpool_bwd_sparse_h(int b, int c, int p, int s, int groups, int relu, const ogc_bf16_t *x,
+                                        const float *x_at_argmax, const float *gamma, const float *mean, const float *rstd,
+                                        const float *out, const int *argmax, const float *grad_out, float *coef2, float *inj,
+                                        float *grad_gamma, float *grad_beta, double *ws, ogc_stream_t stream);
 
 #ifdef __cplusplus
 }

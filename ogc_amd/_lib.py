@@ -128,7 +128,16 @@ SIGNATURES = {
                                    _vp, _vp],
 }
 
-HEADER_VERSION = 201   # OGC_VERSION of include/ogc_ops.h the SIGNATURES table above was written against
+# the 16-bit-activation forms (include/ogc_ops.h "16-bit activations"): the prototypes of the entry points they shadow
+for _n in ("ogc_group_linear_fwd", "ogc_group_points_grad_rev", "ogc_conv1x1_gemm", "ogc_conv1x1_gemm_affine",
+           "ogc_conv1x1_gemm_affine_pool", "ogc_conv1x1_wgrad_affine", "ogc_conv1x1_wgrad_affine_pooled",
+           "ogc_conv1x1_dgrad_pooled", "ogc_conv1x1_wgrad_moments", "ogc_conv1x1_wgrad_moments_pooled",
+           "ogc_conv1x1_dgrad_adjoint", "ogc_conv1x1_dgrad_adjoint_pooled", "ogc_group_norm_bwd",
+           "ogc_group_norm_maxpool_bwd_sparse"):
+    SIGNATURES[_n + "_h"] = SIGNATURES[_n]
+SIGNATURES["ogc_conv1x1_wgrad_xf_h"] = SIGNATURES["ogc_conv1x1_wgrad"]
+
+HEADER_VERSION = 202   # OGC_VERSION of include/ogc_ops.h the SIGNATURES table above was written against
 _lib = None
 _fns = {}  # entry point name -> bound ctypes function
 

@@ -1,6 +1,7 @@
 // conv1x1.hip — forward and input-gradient GEMMs of the per-point (1x1) convolutions of the shared MLPs on the MFMA pipe
 // (reference: utils/nn_util.py:45-85); the weight gradients live in conv1x1_wgrad.hip, what both share in conv1x1_shared.h.
 #include "conv1x1_shared.h"
+#include "act_io.h"
 
 int ogc_g_matmul_bf16 = 0;
 
@@ -111,11 +112,13 @@ __device__ __forceinline__ void ogc_pool_extremes_epilogue(const ACC (&acc)[4][4
     }
 }
 
-template <bool TRANSPOSE_A, int KQ, bool STATS, bool PRO, bool BF, bool POOL = false>
+// IT / OT: element types of `in` and `out` (float, or ogc_bf16 for activations kept in 16 bits: act_io.h); the statistics and
+// the extremes are then those of the ROUNDED outputs.
+template <bool TRANSPOSE_A, int KQ, bool STATS, bool PRO, bool BF, bool POOL = false, typename IT = float, typename OT = float>
 __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_gemm_kernel(int M, int K, int hw, int groups,
                                                                           const float *__restrict__ w, // (Cout, Cin)
-                                                                          const float *__restrict__ in,
-                                                                          float *__restrict__ out,
+                                                                          const IT *__restrict__ in,
+                                                                          OT *__restrict__ out,
                                                                           double *__restrict__ stats,
                                                                           const float *__restrict__ pa,
                                                                           const float *__restrict__ pb, int pro_relu,
@@ -129,16 +132,15 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_gemm_kernel(int M,
     const int p0 = (blockIdx.x * WG_WAVES + wave) * 64;
     const int Kq = (K + 3) >> 2, a_ld = ogc_a_ld(Kq);
     const bool live = p0 < hw; // hw is a multiple of 64 for every wave that is live
-    const float *inb = in + (size_t)b * K * hw;
-    float *outb = out + (size_t)b * M * hw;
+    const IT *inb = in + (size_t)b * K * hw;
+    OT *outb = out + (size_t)b * M * hw;
     if (STATS && threadIdx.x < 2 * groups) s_stats[threadIdx.x] = 0.0;
 
     float4 xin[KQ];
 #pragma unroll
     for (int q = 0; q < KQ; ++q) {
         const int row = q * 4 + kk;
-        xin[q] = (live && q < Kq && row < K) ? *reinterpret_cast<const float4 *>(inb + (size_t)row * hw + p0 + 4 * j)
-                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+        xin[q] = (live && q < Kq && row < K) ? ogc_ld4(inb + (size_t)row * hw + p0 + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (PRO) { // a second pass, so that all loads above are in flight before the first one is waited for; in chunks
                // of eight rows so that the coefficients stay transient in wide layers (no spare registers there)
@@ -249,6 +251,14 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_gemm_kernel(int M,
         }
         }
         if (live) {
+            if constexpr (sizeof(OT) == 2 && (STATS || POOL)) { // what follows sees the values as they are stored
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[a][c][r] = ogc_as_stored<OT>(acc[a][c][r]);
+            }
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -256,7 +266,7 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_gemm_kernel(int M,
                     const int m = m0 + a * 16 + kk * 4 + r; // C/D layout: row (l >> 4) * 4 + r, column l & 15
                     if (m < M) {
                         const float4 o = make_float4(acc[a][0][r], acc[a][1][r], acc[a][2][r], acc[a][3][r]);
-                        *reinterpret_cast<float4 *>(outb + (size_t)m * hw + p0 + 4 * j) = o;
+                        ogc_st4(outb + (size_t)m * hw + p0 + 4 * j, o);
                     }
                 }
             if constexpr (POOL) {
@@ -580,25 +590,30 @@ bool gemm_stream_launch(int b, int M, int K, int hw, const float *w, const float
     return true;
 }
 
-template <bool T, bool STATS, bool PRO, bool POOL = false>
-int gemm_launch(int b, int M, int K, int hw, int groups, const float *w, const float *in, float *out, double *stats,
+template <bool T, bool STATS, bool PRO, bool POOL = false, typename AT = float>
+int gemm_launch(int b, int M, int K, int hw, int groups, const float *w, const AT *in, AT *out, double *stats,
                 const float *pa, const float *pb, int pro_relu, hipStream_t s, PoolOut pool = PoolOut()) {
     const int Kq = (K + 3) / 4;
-    if constexpr (!T && (!POOL || (STATS && PRO))) {
+    constexpr bool F32 = sizeof(AT) == 4;
+    if constexpr (F32 && !T && (!POOL || (STATS && PRO))) {
         static const bool wide_fp32 = [] { const char *e = getenv("OGC_BF16_WIDE_STATS"); return e && e[0] == '1'; }();
         if ((!g_matmul_bf16 || (STATS && wide_fp32)) &&
             gemm_stream_launch<PRO, STATS, POOL>(b, M, K, hw, w, in, out, pa, pb, pro_relu, s, groups, stats, pool))
             return OGC_OK;
     }
-    if constexpr (T && !STATS && !PRO && !POOL) { // the plain input gradient of a 101 .. 160-channel layer
+    if constexpr (F32 && T && !STATS && !PRO && !POOL) { // the plain input gradient of a 101 .. 160-channel layer
         if (!g_matmul_bf16 && gemm_stream_launch<false, false, false, true>(b, M, K, hw, w, in, out, pa, pb, pro_relu, s))
             return OGC_OK;
     }
     const size_t lds = (size_t)64 * ogc_a_ld(Kq) * sizeof(float); // (the bf16 staging needs half of it)
     dim3 grid(ogc_divup(hw, 64 * WG_WAVES), b);
+    // 16-bit activations come with bf16 operands only (the entry points check the precision switch)
 #define OGC_GEMM(KQV)                                                                                                  \
     do {                                                                                                               \
-        if (g_matmul_bf16)                                                                                             \
+        if constexpr (!F32)                                                                                            \
+            hipLaunchKernelGGL((conv1x1_gemm_kernel<T, KQV, STATS, PRO, true, POOL, AT, AT>), grid,                     \
+                               dim3(WG_WAVES * OGC_WAVE), lds, s, M, K, hw, groups, w, in, out, stats, pa, pb, pro_relu, pool); \
+        else if (g_matmul_bf16)                                                                                        \
             hipLaunchKernelGGL((conv1x1_gemm_kernel<T, KQV, STATS, PRO, true, POOL>), grid, dim3(WG_WAVES * OGC_WAVE), \
                                lds, s, M, K, hw, groups, w, in, out, stats, pa, pb, pro_relu, pool);                   \
         else                                                                                                           \
@@ -620,12 +635,17 @@ int gemm_launch(int b, int M, int K, int hw, int groups, const float *w, const f
     return OGC_OK;
 }
 
-int gemm_check(const char *name, int b, int M, int K, int hw, const float *w, const float *in, const float *out) {
+template <typename AT>
+int gemm_check(const char *name, int b, int M, int K, int hw, const float *w, const AT *in, const AT *out) {
     OGC_REQUIRE(b >= 0 && M >= 1 && K >= 1 && hw >= 1, "%s: bad shape", name);
     OGC_REQUIRE(w && in && out, "%s: null pointer", name);
-    if ((hw & 63) != 0 || K > 4 * FW_KQ_MAX || (((uintptr_t)in | (uintptr_t)out) & 15) != 0) {
+    if ((hw & 63) != 0 || K > 4 * FW_KQ_MAX || (((uintptr_t)in | (uintptr_t)out) & ogc_act_mask<AT>()) != 0) {
         ogc_set_error("%s: needs hw %% 64 == 0, K <= %d and 16-byte aligned tensors (hw=%d, K=%d)", name,
                       4 * FW_KQ_MAX, hw, K);
+        return OGC_ERR_UNSUPPORTED;
+    }
+    if (sizeof(AT) == 2 && !g_matmul_bf16) {
+        ogc_set_error("%s: 16-bit activations need ogc_set_matmul_precision(1)", name);
         return OGC_ERR_UNSUPPORTED;
     }
     // batch offsets are 64-bit in the kernels; only one sample's activation must fit 32-bit offsets
@@ -637,15 +657,31 @@ int gemm_check(const char *name, int b, int M, int K, int hw, const float *w, co
 } // namespace
 
 // OUT[b, m, p] = sum_k A[m, k] IN[b, k, p];  transpose_a == 0: A = w (M x K);  != 0: A = w^T with w stored (K x M).
-extern "C" int ogc_conv1x1_gemm(int b, int M, int K, int hw, int transpose_a, const float *w, const float *in,
-                                float *out, ogc_stream_t stream) {
-    const int rc = gemm_check("ogc_conv1x1_gemm", b, M, K, hw, w, in, out);
+namespace {
+template <typename AT>
+int gemm_plain_impl(const char *name, int b, int M, int K, int hw, int transpose_a, const float *w, const AT *in, AT *out,
+                    ogc_stream_t stream) {
+    const int rc = gemm_check(name, b, M, K, hw, w, in, out);
     if (rc != OGC_OK) return rc;
     if (b == 0) return OGC_OK;
-    if (transpose_a) gemm_launch<true, false, false>(b, M, K, hw, 1, w, in, out, nullptr, nullptr, nullptr, 0, (hipStream_t)stream);
-    else gemm_launch<false, false, false>(b, M, K, hw, 1, w, in, out, nullptr, nullptr, nullptr, 0, (hipStream_t)stream);
-    OGC_CHECK_LAUNCH("ogc_conv1x1_gemm");
+    if (transpose_a)
+        gemm_launch<true, false, false, false, AT>(b, M, K, hw, 1, w, in, out, nullptr, nullptr, nullptr, 0, (hipStream_t)stream);
+    else
+        gemm_launch<false, false, false, false, AT>(b, M, K, hw, 1, w, in, out, nullptr, nullptr, nullptr, 0, (hipStream_t)stream);
+    OGC_CHECK_LAUNCH(name);
     return OGC_OK;
+}
+} // namespace
+
+extern "C" int ogc_conv1x1_gemm(int b, int M, int K, int hw, int transpose_a, const float *w, const float *in,
+                                float *out, ogc_stream_t stream) {
+    return gemm_plain_impl<float>("ogc_conv1x1_gemm", b, M, K, hw, transpose_a, w, in, out, stream);
+}
+
+// 16-bit activations (`in`, `out` bf16; bf16 operands: needs ogc_set_matmul_precision(1)) — see act_io.h
+extern "C" int ogc_conv1x1_gemm_h(int b, int M, int K, int hw, int transpose_a, const float *w, const ogc_bf16_t *in,
+                                  ogc_bf16_t *out, ogc_stream_t stream) {
+    return gemm_plain_impl<ogc_bf16>("ogc_conv1x1_gemm_h", b, M, K, hw, transpose_a, w, in, out, stream);
 }
 
 extern "C" int ogc_conv1x1_gn_slots(void) { return GN_SLOTS; }
@@ -672,7 +708,7 @@ extern "C" int ogc_set_matmul_precision(int bf16) {
 // Forward convolution that also produces the statistics of the GroupNorm that follows it.
 extern "C" int ogc_conv1x1_gemm_gnstats(int b, int M, int K, int hw, int groups, const float *w, const float *in,
                                         float *out, double *stats, ogc_stream_t stream) {
-    const int rc = gemm_check("ogc_conv1x1_gemm_gnstats", b, M, K, hw, w, in, out);
+    const int rc = gemm_check<float>("ogc_conv1x1_gemm_gnstats", b, M, K, hw, w, in, out);
     if (rc != OGC_OK) return rc;
     OGC_REQUIRE(stats, "ogc_conv1x1_gemm_gnstats: null pointer");
     if (groups < 1 || groups > 32 || M % groups != 0 || (M / groups) % 4 != 0) {
@@ -700,10 +736,11 @@ extern "C" int ogc_conv1x1_gemm_gnstats(int b, int M, int K, int hw, int groups,
 
 // The two kernels above with the previous layer's GroupNorm (+ ReLU) folded into the operand load:
 // in' = act(pa[b, k] * in + pb[b, k]).  groups == 0: no statistics of the output.
-extern "C" int ogc_conv1x1_gemm_affine(int b, int M, int K, int hw, int relu, int groups, const float *w, const float *in,
-                                       const float *pa, const float *pb, float *out, double *stats,
-                                       ogc_stream_t stream) {
-    const int rc = gemm_check("ogc_conv1x1_gemm_affine", b, M, K, hw, w, in, out);
+namespace {
+template <typename AT>
+int gemm_affine_impl(const char *name, int b, int M, int K, int hw, int relu, int groups, const float *w, const AT *in,
+                     const float *pa, const float *pb, AT *out, double *stats, ogc_stream_t stream) {
+    const int rc = gemm_check(name, b, M, K, hw, w, in, out);
     if (rc != OGC_OK) return rc;
     OGC_REQUIRE(pa && pb, "ogc_conv1x1_gemm_affine: null pointer");
     if (b == 0) return OGC_OK;
@@ -719,22 +756,36 @@ extern "C" int ogc_conv1x1_gemm_affine(int b, int M, int K, int hw, int relu, in
             ogc_set_error("ogc_conv1x1_gemm_affine: memset failed");
             return OGC_ERR_LAUNCH;
         }
-        gemm_launch<false, true, true>(b, M, K, hw, groups, w, in, out, stats, pa, pb, relu, s);
+        gemm_launch<false, true, true, false, AT>(b, M, K, hw, groups, w, in, out, stats, pa, pb, relu, s);
     } else {
-        gemm_launch<false, false, true>(b, M, K, hw, 1, w, in, out, nullptr, pa, pb, relu, s);
+        gemm_launch<false, false, true, false, AT>(b, M, K, hw, 1, w, in, out, nullptr, pa, pb, relu, s);
     }
-    OGC_CHECK_LAUNCH("ogc_conv1x1_gemm_affine");
+    OGC_CHECK_LAUNCH(name);
     return OGC_OK;
+}
+} // namespace
+
+extern "C" int ogc_conv1x1_gemm_affine(int b, int M, int K, int hw, int relu, int groups, const float *w, const float *in,
+                                       const float *pa, const float *pb, float *out, double *stats,
+                                       ogc_stream_t stream) {
+    return gemm_affine_impl<float>("ogc_conv1x1_gemm_affine", b, M, K, hw, relu, groups, w, in, pa, pb, out, stats, stream);
+}
+
+extern "C" int ogc_conv1x1_gemm_affine_h(int b, int M, int K, int hw, int relu, int groups, const float *w, const ogc_bf16_t *in,
+                                         const float *pa, const float *pb, ogc_bf16_t *out, double *stats,
+                                         ogc_stream_t stream) {
+    return gemm_affine_impl<ogc_bf16>("ogc_conv1x1_gemm_affine_h", b, M, K, hw, relu, groups, w, in, pa, pb, out, stats, stream);
 }
 
 // ogc_conv1x1_gemm_affine with output statistics, for the LAST layer of a set-abstraction MLP: positions are
 // (centre, neighbour) pairs, hw = centres * nsample, and the extreme of the raw output over each neighbourhood comes out
 // as well (see PoolOut) — the max-pool over the normalised activation is then ogc_group_norm_pool_extremes.
-extern "C" int ogc_conv1x1_gemm_affine_pool(int b, int M, int K, int hw, int relu, int groups, int nsample,
-                                            const float *w, const float *in, const float *pa, const float *pb,
-                                            const float *next_gamma, float *out, double *stats, float *yext, int *aext,
-                                            ogc_stream_t stream) {
-    const int rc = gemm_check("ogc_conv1x1_gemm_affine_pool", b, M, K, hw, w, in, out);
+namespace {
+template <typename AT>
+int gemm_affine_pool_impl(const char *name, int b, int M, int K, int hw, int relu, int groups, int nsample, const float *w,
+                          const AT *in, const float *pa, const float *pb, const float *next_gamma, AT *out, double *stats,
+                          float *yext, int *aext, ogc_stream_t stream) {
+    const int rc = gemm_check(name, b, M, K, hw, w, in, out);
     if (rc != OGC_OK) return rc;
     OGC_REQUIRE(pa && pb && next_gamma && stats && yext && aext, "ogc_conv1x1_gemm_affine_pool: null pointer");
     if (groups < 1 || groups > 32 || M % groups != 0 || (M / groups) % 4 != 0 ||
@@ -752,8 +803,26 @@ extern "C" int ogc_conv1x1_gemm_affine_pool(int b, int M, int K, int hw, int rel
     }
     PoolOut pool;
     pool.yext = yext; pool.aext = aext; pool.sign = next_gamma; pool.s = nsample;
-    const int lrc = gemm_launch<false, true, true, true>(b, M, K, hw, groups, w, in, out, stats, pa, pb, relu, s, pool);
+    const int lrc = gemm_launch<false, true, true, true, AT>(b, M, K, hw, groups, w, in, out, stats, pa, pb, relu, s, pool);
     if (lrc != OGC_OK) return lrc;
-    OGC_CHECK_LAUNCH("ogc_conv1x1_gemm_affine_pool");
+    OGC_CHECK_LAUNCH(name);
     return OGC_OK;
+}
+} // namespace
+
+extern "C" int ogc_conv1x1_gemm_affine_pool(int b, int M, int K, int hw, int relu, int groups, int nsample,
+                                            const float *w, const float *in, const float *pa, const float *pb,
+                                            const float *next_gamma, float *out, double *stats, float *yext, int *aext,
+                                            ogc_stream_t stream) {
+    return gemm_affine_pool_impl<float>("ogc_conv1x1_gemm_affine_pool", b, M, K, hw, relu, groups, nsample, w, in, pa, pb,
+                                        next_gamma, out, stats, yext, aext, stream);
+}
+
+// (yext holds the ROUNDED extremes: the values `out` holds at aext)
+extern "C" int ogc_conv1x1_gemm_affine_pool_h(int b, int M, int K, int hw, int relu, int groups, int nsample,
+                                              const float *w, const ogc_bf16_t *in, const float *pa, const float *pb,
+                                              const float *next_gamma, ogc_bf16_t *out, double *stats, float *yext, int *aext,
+                                              ogc_stream_t stream) {
+    return gemm_affine_pool_impl<ogc_bf16>("ogc_conv1x1_gemm_affine_pool_h", b, M, K, hw, relu, groups, nsample, w, in, pa, pb,
+                                           next_gamma, out, stats, yext, aext, stream);
 }

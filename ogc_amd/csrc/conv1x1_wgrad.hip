@@ -15,6 +15,7 @@
 //     loads are issued before the current step's MFMAs; the four waves of a workgroup are reduced through LDS,
 //     workgroups through fp32 atomics into dW (zeroed by this entry point).
 #include "conv1x1_shared.h"
+#include "act_io.h"
 
 namespace {
 
@@ -24,11 +25,12 @@ namespace {
 // rebuilt while y is loaded:  g_y[row, pos] = fmaf(c2, y, c3) + (pos % S == arg ? ag : 0)  with (c2, c3) = coef2[b, row] and
 // (ag, arg) = inj[b, row, pos / S] (ogc_group_norm_maxpool_bwd_sparse; a step's 16 positions lie inside one neighbourhood,
 // S = 16, 32, 64) — the expression of gn_maxpool_bwd_dx_kernel, bit for bit.
-template <int COB, int CIB, bool PRO, bool BF, bool POOLED = false>
+// XT / YT: element types of x and dy (float / ogc_bf16: act_io.h).
+template <int COB, int CIB, bool PRO, bool BF, bool POOLED = false, typename XT = float, typename YT = float>
 __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_wgrad_kernel(int batch, int cin, int cout, int hw,
                                                                            int steps_per_wave,
-                                                                           const float *__restrict__ x,
-                                                                           const float *__restrict__ dy,
+                                                                           const XT *__restrict__ x,
+                                                                           const YT *__restrict__ dy,
                                                                            float *__restrict__ dw,
                                                                            const float *__restrict__ aff_a,
                                                                            const float *__restrict__ aff_b, int pro_relu,
@@ -83,10 +85,10 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_wgrad_kernel(int b
     auto load = [&](float4(&yv)[COB], float4(&xv)[CIB], float(&fa)[CIB], float(&fb)[CIB], float2(&cc)[NP], float2(&jv)[NP],
                     int &jpos) { // current step, then advance
         const int pb = cur_off * 16 + 4 * k;
-        const float *yb_ = dy + (size_t)cur_b * cout * hw + pb;
-        const float *xb_ = x + (size_t)cur_b * cin * hw + pb;
+        const YT *yb_ = dy + (size_t)cur_b * cout * hw + pb;
+        const XT *xb_ = x + (size_t)cur_b * cin * hw + pb;
 #pragma unroll
-        for (int a = 0; a < COB; ++a) yv[a] = *reinterpret_cast<const float4 *>(yb_ + yrow[a]);
+        for (int a = 0; a < COB; ++a) yv[a] = ogc_ld4(yb_ + yrow[a]);
         if constexpr (POOLED) { // (travels with the step like the affine map below: the sample may change from step to step)
 #pragma unroll
             for (int a = 0; a < COB; ++a) {
@@ -98,7 +100,7 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_wgrad_kernel(int b
         }
 #pragma unroll
         for (int c = 0; c < CIB; ++c) {
-            xv[c] = *reinterpret_cast<const float4 *>(xb_ + xrow[c]);
+            xv[c] = ogc_ld4(xb_ + xrow[c]);
             if (PRO) {
                 fa[c] = aff_a[(size_t)cur_b * cin + coef[c]];
                 fb[c] = aff_b[(size_t)cur_b * cin + coef[c]];
@@ -191,8 +193,8 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_wgrad_kernel(int b
     }
 }
 
-template <int COB, int CIB>
-void wgrad_launch(int b, int cin, int cout, int hw, const float *x, const float *dy, float *dw, const float *pa,
+template <int COB, int CIB, typename XT = float, typename YT = float>
+void wgrad_launch(int b, int cin, int cout, int hw, const XT *x, const YT *dy, float *dw, const float *pa,
                   const float *pb, int pro_relu, hipStream_t s, const float2 *coef2 = nullptr, const float2 *inj = nullptr,
                   int s_shift = 0) {
     const long long nsteps = (long long)b * (hw >> 4);
@@ -210,17 +212,20 @@ void wgrad_launch(int b, int cin, int cout, int hw, const float *x, const float 
     const int wgs = (int)((nsteps + spw * WG_WAVES - 1) / (spw * WG_WAVES));
     dim3 grid(wgs, ogc_divup(cout, 16 * COB), ogc_divup(cin, 16 * CIB));
 #define OGC_WGRAD(PROV, BFV)                                                                                          \
-    hipLaunchKernelGGL((conv1x1_wgrad_kernel<COB, CIB, PROV, BFV>), grid, dim3(WG_WAVES * OGC_WAVE), 0, s, b, cin, cout, \
+    hipLaunchKernelGGL((conv1x1_wgrad_kernel<COB, CIB, PROV, BFV, false, XT, YT>), grid, dim3(WG_WAVES * OGC_WAVE), 0, s, b, cin, cout, \
                        hw, (int)spw, x, dy, dw, pa, pb, pro_relu)
     if (inj) { // pooled form of dy (fp32 operands, previous layer's norm folded in): see POOLED
-        hipLaunchKernelGGL((conv1x1_wgrad_kernel<COB, CIB, true, false, true>), grid, dim3(WG_WAVES * OGC_WAVE), 0, s, b, cin, cout,
+        // (fp32 operands for fp32 tensors whatever the precision switch says; 16-bit tensors: bf16 operands)
+        hipLaunchKernelGGL((conv1x1_wgrad_kernel<COB, CIB, true, sizeof(YT) == 2, true, XT, YT>), grid, dim3(WG_WAVES * OGC_WAVE), 0, s, b, cin, cout,
                            hw, (int)spw, x, dy, dw, pa, pb, pro_relu, coef2, inj, s_shift);
-    } else if (g_matmul_bf16) {
+    } else if (g_matmul_bf16 || sizeof(XT) == 2 || sizeof(YT) == 2) { // (16-bit tensors: checked to come with bf16 operands)
         if (pa) OGC_WGRAD(true, true);
         else OGC_WGRAD(false, true);
     } else {
-        if (pa) OGC_WGRAD(true, false);
-        else OGC_WGRAD(false, false);
+        if constexpr (sizeof(XT) == 4 && sizeof(YT) == 4) {
+            if (pa) OGC_WGRAD(true, false);
+            else OGC_WGRAD(false, false);
+        }
     }
 #undef OGC_WGRAD
 }
@@ -244,9 +249,9 @@ constexpr int WS_LD = WS_POS + 4;       // row stride in LDS (floats): 144 bytes
 // 0.195 -> 0.198, with the previous layer's norm folded in 0.226 -> 0.202.  A 256 x 128 tile on eight wavefronts — both tensors
 // read from memory exactly once — gave the same 0.367 ms: the kernel is no longer bound by the operand traffic.)
 // BF: operands rounded to bf16 on v_mfma_f32_16x16x16_bf16 (ogc_set_matmul_precision), as in conv1x1_wgrad_kernel.
-template <bool PRO, bool POOLED, bool BF = false>
+template <bool PRO, bool POOLED, bool BF = false, typename XT = float, typename YT = float>
 __global__ __launch_bounds__(256, 2) void conv1x1_wgrad_shared_kernel(int batch, int cin, int cout, int hw, int stages_per_wg,
-                                                                      const float *__restrict__ x, const float *__restrict__ dy,
+                                                                      const XT *__restrict__ x, const YT *__restrict__ dy,
                                                                       float *__restrict__ dw, const float *__restrict__ aff_a,
                                                                       const float *__restrict__ aff_b, int pro_relu,
                                                                       const float2 *__restrict__ coef2,
@@ -283,12 +288,12 @@ __global__ __launch_bounds__(256, 2) void conv1x1_wgrad_shared_kernel(int batch,
     int jpos = 0;
     auto fetch = [&]() { // the current stage into registers, then advance
         const int pos = cur_off * WS_POS + 4 * q;
-        const float *yb_ = dy + (size_t)cur_b * cout * hw + pos;
-        const float *xb_ = x + (size_t)cur_b * cin * hw + pos;
+        const YT *yb_ = dy + (size_t)cur_b * cout * hw + pos;
+        const XT *xb_ = x + (size_t)cur_b * cin * hw + pos;
 #pragma unroll
-        for (int j = 0; j < YJ; ++j) raw[j] = *reinterpret_cast<const float4 *>(yb_ + (size_t)grow[j] * hw);
+        for (int j = 0; j < YJ; ++j) raw[j] = ogc_ld4(yb_ + (size_t)grow[j] * hw);
 #pragma unroll
-        for (int j = YJ; j < NJ; ++j) raw[j] = *reinterpret_cast<const float4 *>(xb_ + (size_t)grow[j] * hw);
+        for (int j = YJ; j < NJ; ++j) raw[j] = ogc_ld4(xb_ + (size_t)grow[j] * hw);
         if constexpr (POOLED) {
 #pragma unroll
             for (int j = 0; j < YJ; ++j) {
@@ -403,7 +408,8 @@ bool wgrad_shared_enabled() {
 }
 
 // true when the launch was made
-bool wgrad_shared_launch(int b, int cin, int cout, int hw, const float *x, const float *dy, float *dw, const float *pa,
+template <typename XT, typename YT>
+bool wgrad_shared_launch(int b, int cin, int cout, int hw, const XT *x, const YT *dy, float *dw, const float *pa,
                          const float *pb, int pro_relu, hipStream_t s, const float2 *coef2, const float2 *inj, int s_shift) {
     if (!wgrad_shared_enabled() || cin < 128 || cout < 128 || (hw % WS_POS) != 0) return false;
     if (inj && (1 << s_shift) < 4) return false;
@@ -419,17 +425,17 @@ bool wgrad_shared_launch(int b, int cin, int cout, int hw, const float *x, const
     dim3 grid(gx, ogc_divup(cout, 128), ogc_divup(cin, 128));
 #define OGC_WGS(PROV, POOLV, BFV)                                                                                            \
     {                                                                                                                        \
-        static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(conv1x1_wgrad_shared_kernel<PROV, POOLV, BFV>), \
+        static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(conv1x1_wgrad_shared_kernel<PROV, POOLV, BFV, XT, YT>), \
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;       \
         if (!ok) { (void)hipGetLastError(); return false; }                                                                  \
-        hipLaunchKernelGGL((conv1x1_wgrad_shared_kernel<PROV, POOLV, BFV>), grid, dim3(256), lds, s, b, cin, cout, hw, (int)spw, \
+        hipLaunchKernelGGL((conv1x1_wgrad_shared_kernel<PROV, POOLV, BFV, XT, YT>), grid, dim3(256), lds, s, b, cin, cout, hw, (int)spw, \
                            x, dy, dw, pa, pb, pro_relu, coef2, inj, s_shift);                                                 \
     }
     // (the pooled form keeps fp32 operands whatever the precision switch says, as with the register tiles)
-    if (inj) { if (pa) OGC_WGS(true, true, false) else return false; }
-    else if (g_matmul_bf16) { if (pa) OGC_WGS(true, false, true) else OGC_WGS(false, false, true) }
-    else if (pa) OGC_WGS(true, false, false)
-    else OGC_WGS(false, false, false)
+    constexpr bool F32 = sizeof(XT) == 4 && sizeof(YT) == 4;
+    if (inj) { if (pa) OGC_WGS(true, true, !F32) else return false; }
+    else if (g_matmul_bf16 || !F32) { if (pa) OGC_WGS(true, false, true) else OGC_WGS(false, false, true) }
+    else if constexpr (F32) { if (pa) OGC_WGS(true, false, false) else OGC_WGS(false, false, false) }
 #undef OGC_WGS
     return true;
 }
@@ -437,13 +443,18 @@ bool wgrad_shared_launch(int b, int cin, int cout, int hw, const float *x, const
 } // namespace
 
 namespace {
-int wgrad_impl(const char *name, int b, int cin, int cout, int hw, const float *x, const float *dy, float *dw,
+template <typename XT, typename YT>
+int wgrad_impl(const char *name, int b, int cin, int cout, int hw, const XT *x, const YT *dy, float *dw,
                const float *pa, const float *pb, int pro_relu, ogc_stream_t stream, const float2 *coef2 = nullptr,
                const float2 *inj = nullptr, int s_shift = 0) {
     OGC_REQUIRE(b >= 0 && cin >= 1 && cout >= 1 && hw >= 1, "%s: bad shape", name);
     OGC_REQUIRE(x && dy && dw, "%s: null pointer", name);
-    if ((hw & 15) != 0 || (((uintptr_t)x | (uintptr_t)dy) & 15) != 0) {
+    if ((hw & 15) != 0 || ((uintptr_t)x & ogc_act_mask<XT>()) != 0 || ((uintptr_t)dy & ogc_act_mask<YT>()) != 0) {
         ogc_set_error("%s: hw=%d must be a multiple of 16 and x/dy 16-byte aligned", name, hw);
+        return OGC_ERR_UNSUPPORTED;
+    }
+    if ((sizeof(XT) == 2 || sizeof(YT) == 2) && !g_matmul_bf16) {
+        ogc_set_error("%s: 16-bit activations need ogc_set_matmul_precision(1)", name);
         return OGC_ERR_UNSUPPORTED;
     }
     OGC_REQUIRE((long long)cin * hw < (1ll << 31) && (long long)cout * hw < (1ll << 31),
@@ -462,18 +473,18 @@ int wgrad_impl(const char *name, int b, int cin, int cout, int hw, const float *
     // register tile per wave: (16*COB) x (16*CIB) outputs.  Small channel counts use small tiles so that no MFMA
     // work is spent on padding; wide layers use 64x64 tiles (16 accumulators) and split the rest over the grid.
     if (inj) { // (the pooled form is offered for the wide tails only: 64-row tiles)
-        if (cin <= 32) wgrad_launch<4, 2>(b, cin, cout, hw, x, dy, dw, pa, pb, pro_relu, s, coef2, inj, s_shift);
-        else wgrad_launch<4, 4>(b, cin, cout, hw, x, dy, dw, pa, pb, pro_relu, s, coef2, inj, s_shift);
+        if (cin <= 32) wgrad_launch<4, 2, XT, YT>(b, cin, cout, hw, x, dy, dw, pa, pb, pro_relu, s, coef2, inj, s_shift);
+        else wgrad_launch<4, 4, XT, YT>(b, cin, cout, hw, x, dy, dw, pa, pb, pro_relu, s, coef2, inj, s_shift);
         OGC_CHECK_LAUNCH(name);
         return OGC_OK;
     }
-    if (cout <= 16 && cin <= 16) wgrad_launch<1, 1>(b, cin, cout, hw, x, dy, dw, pa, pb, pro_relu, s);
-    else if (cout <= 32 && cin <= 16) wgrad_launch<2, 1>(b, cin, cout, hw, x, dy, dw, pa, pb, pro_relu, s);
-    else if (cout <= 32 && cin <= 32) wgrad_launch<2, 2>(b, cin, cout, hw, x, dy, dw, pa, pb, pro_relu, s);
-    else if (cin <= 16) wgrad_launch<4, 1>(b, cin, cout, hw, x, dy, dw, pa, pb, pro_relu, s);
-    else if (cin <= 32) wgrad_launch<4, 2>(b, cin, cout, hw, x, dy, dw, pa, pb, pro_relu, s);
-    else if (cout <= 32) wgrad_launch<2, 4>(b, cin, cout, hw, x, dy, dw, pa, pb, pro_relu, s);
-    else wgrad_launch<4, 4>(b, cin, cout, hw, x, dy, dw, pa, pb, pro_relu, s);
+    if (cout <= 16 && cin <= 16) wgrad_launch<1, 1, XT, YT>(b, cin, cout, hw, x, dy, dw, pa, pb, pro_relu, s);
+    else if (cout <= 32 && cin <= 16) wgrad_launch<2, 1, XT, YT>(b, cin, cout, hw, x, dy, dw, pa, pb, pro_relu, s);
+    else if (cout <= 32 && cin <= 32) wgrad_launch<2, 2, XT, YT>(b, cin, cout, hw, x, dy, dw, pa, pb, pro_relu, s);
+    else if (cin <= 16) wgrad_launch<4, 1, XT, YT>(b, cin, cout, hw, x, dy, dw, pa, pb, pro_relu, s);
+    else if (cin <= 32) wgrad_launch<4, 2, XT, YT>(b, cin, cout, hw, x, dy, dw, pa, pb, pro_relu, s);
+    else if (cout <= 32) wgrad_launch<2, 4, XT, YT>(b, cin, cout, hw, x, dy, dw, pa, pb, pro_relu, s);
+    else wgrad_launch<4, 4, XT, YT>(b, cin, cout, hw, x, dy, dw, pa, pb, pro_relu, s);
     OGC_CHECK_LAUNCH(name);
     return OGC_OK;
 }
@@ -484,24 +495,54 @@ extern "C" int ogc_conv1x1_wgrad(int b, int cin, int cout, int hw, const float *
     return wgrad_impl("ogc_conv1x1_wgrad", b, cin, cout, hw, x, dy, dw, nullptr, nullptr, 0, stream);
 }
 
+// 16-bit forms (act_io.h; bf16 operands: need ogc_set_matmul_precision(1)).  _xf: x fp32, dy bf16 (the three coordinate columns of
+// a grouped first layer: x = the relative coordinates); _h: both bf16.
+extern "C" int ogc_conv1x1_wgrad_xf_h(int b, int cin, int cout, int hw, const float *x, const ogc_bf16_t *dy, float *dw,
+                                      ogc_stream_t stream) {
+    return wgrad_impl<float, ogc_bf16>("ogc_conv1x1_wgrad_xf_h", b, cin, cout, hw, x, dy, dw, nullptr, nullptr, 0, stream);
+}
+
 extern "C" int ogc_conv1x1_wgrad_affine(int b, int cin, int cout, int hw, int relu, const float *x, const float *pa,
                                         const float *pb, const float *dy, float *dw, ogc_stream_t stream) {
     OGC_REQUIRE(pa && pb, "ogc_conv1x1_wgrad_affine: null pointer");
     return wgrad_impl("ogc_conv1x1_wgrad_affine", b, cin, cout, hw, x, dy, dw, pa, pb, relu, stream);
 }
 
+extern "C" int ogc_conv1x1_wgrad_affine_h(int b, int cin, int cout, int hw, int relu, const ogc_bf16_t *x, const float *pa,
+                                          const float *pb, const ogc_bf16_t *dy, float *dw, ogc_stream_t stream) {
+    OGC_REQUIRE(pa && pb, "ogc_conv1x1_wgrad_affine_h: null pointer");
+    return wgrad_impl<ogc_bf16, ogc_bf16>("ogc_conv1x1_wgrad_affine_h", b, cin, cout, hw, x, dy, dw, pa, pb, relu, stream);
+}
+
 // ogc_conv1x1_wgrad_affine with dy in the sparse form of ogc_group_norm_maxpool_bwd_sparse: y is the convolution's raw output
 // (b, cout, hw) and g_y is rebuilt from (y, coef2, inj) while y is loaded (see POOLED at conv1x1_wgrad_kernel) — the weight
 // gradient of the LAST layer of a set-abstraction MLP without the dense gradient of its pooled GroupNorm.  fp32 operands.
+namespace {
+template <typename AT>
+int wgrad_affine_pooled_impl(const char *name, int b, int cin, int cout, int hw, int relu, int nsample, const AT *x,
+                             const float *pa, const float *pb, const AT *y, const float *coef2, const float *inj, float *dw,
+                             ogc_stream_t stream) {
+    OGC_REQUIRE(pa && pb && coef2 && inj, "%s: null pointer", name);
+    const int sh = nsample == 16 ? 4 : nsample == 32 ? 5 : nsample == 64 ? 6 : -1;
+    if (sh < 0 || hw % nsample != 0 || (((uintptr_t)coef2 | (uintptr_t)inj) & 7) != 0) {
+        ogc_set_error("%s: nsample=%d must be 16, 32 or 64 and divide hw=%d", name, nsample, hw);
+        return OGC_ERR_UNSUPPORTED;
+    }
+    return wgrad_impl<AT, AT>(name, b, cin, cout, hw, x, y, dw, pa, pb, relu, stream, reinterpret_cast<const float2 *>(coef2),
+                              reinterpret_cast<const float2 *>(inj), sh);
+}
+} // namespace
+
 extern "C" int ogc_conv1x1_wgrad_affine_pooled(int b, int cin, int cout, int hw, int relu, int nsample, const float *x,
                                                const float *pa, const float *pb, const float *y, const float *coef2,
                                                const float *inj, float *dw, ogc_stream_t stream) {
-    OGC_REQUIRE(pa && pb && coef2 && inj, "ogc_conv1x1_wgrad_affine_pooled: null pointer");
-    const int sh = nsample == 16 ? 4 : nsample == 32 ? 5 : nsample == 64 ? 6 : -1;
-    if (sh < 0 || hw % nsample != 0 || (((uintptr_t)coef2 | (uintptr_t)inj) & 7) != 0) {
-        ogc_set_error("ogc_conv1x1_wgrad_affine_pooled: nsample=%d must be 16, 32 or 64 and divide hw=%d", nsample, hw);
-        return OGC_ERR_UNSUPPORTED;
-    }
-    return wgrad_impl("ogc_conv1x1_wgrad_affine_pooled", b, cin, cout, hw, x, y, dw, pa, pb, relu, stream,
-                      reinterpret_cast<const float2 *>(coef2), reinterpret_cast<const float2 *>(inj), sh);
+    return wgrad_affine_pooled_impl<float>("ogc_conv1x1_wgrad_affine_pooled", b, cin, cout, hw, relu, nsample, x, pa, pb, y, coef2,
+                                           inj, dw, stream);
+}
+
+extern "C" int ogc_conv1x1_wgrad_affine_pooled_h(int b, int cin, int cout, int hw, int relu, int nsample, const ogc_bf16_t *x,
+                                                 const float *pa, const float *pb, const ogc_bf16_t *y, const float *coef2,
+                                                 const float *inj, float *dw, ogc_stream_t stream) {
+    return wgrad_affine_pooled_impl<ogc_bf16>("ogc_conv1x1_wgrad_affine_pooled_h", b, cin, cout, hw, relu, nsample, x, pa, pb, y,
+                                              coef2, inj, dw, stream);
 }

@@ -12,6 +12,7 @@
 //
 // group_points is ONE kernel for both ops: gather_points is group_points with nsample = 1.
 #include "ogc_common.h"
+#include "act_io.h"
 
 namespace {
 
@@ -421,12 +422,14 @@ namespace {
 // GL_SLOTS copies of the (b, groups, 2) fp64 accumulator — the layout ogc_conv1x1_gemm_gnstats fills.
 constexpr int GL_SLOTS = 16;
 
+// OT: element type of y (float / ogc_bf16: act_io.h); the statistics are those of the stored values.
+template <typename OT>
 __global__ __launch_bounds__(GG_THREADS) void group_linear_fwd_kernel(int m, int n, int T, int cpb, int cg, int groups,
                                                                       const float *__restrict__ P,
                                                                       const int *__restrict__ idx,
                                                                       const float *__restrict__ rel,
                                                                       const float *__restrict__ wx,
-                                                                      float *__restrict__ y,
+                                                                      OT *__restrict__ y,
                                                                       double *__restrict__ stats) {
     __shared__ double red[2 * GG_THREADS / 64];
     const int b = blockIdx.z, c0 = blockIdx.y * cpb;
@@ -438,7 +441,7 @@ __global__ __launch_bounds__(GG_THREADS) void group_linear_fwd_kernel(int m, int
         const float4 rx = *reinterpret_cast<const float4 *>(rb), ry = *reinterpret_cast<const float4 *>(rb + T),
                      rz = *reinterpret_cast<const float4 *>(rb + 2 * (size_t)T);
         const float *p = P + ((size_t)b * m + c0) * n;
-        float *o = y + ((size_t)b * m + c0) * T + t4;
+        OT *o = y + ((size_t)b * m + c0) * T + t4;
         for (int ch = c0; ch < c0 + cpb; ++ch, p += n, o += T) {
             const float w0 = wx[ch * 3], w1 = wx[ch * 3 + 1], w2 = wx[ch * 3 + 2];
             float4 v;
@@ -446,7 +449,10 @@ __global__ __launch_bounds__(GG_THREADS) void group_linear_fwd_kernel(int m, int
             v.y = fmaf(w2, rz.y, fmaf(w1, ry.y, fmaf(w0, rx.y, p[i4.y])));
             v.z = fmaf(w2, rz.z, fmaf(w1, ry.z, fmaf(w0, rx.z, p[i4.z])));
             v.w = fmaf(w2, rz.w, fmaf(w1, ry.w, fmaf(w0, rx.w, p[i4.w])));
-            *reinterpret_cast<float4 *>(o) = v;
+            if constexpr (sizeof(OT) == 2) {
+                v.x = ogc_as_stored<OT>(v.x); v.y = ogc_as_stored<OT>(v.y); v.z = ogc_as_stored<OT>(v.z); v.w = ogc_as_stored<OT>(v.w);
+            }
+            ogc_st4(o, v);
             s += (v.x + v.y) + (v.z + v.w);
             ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
         }
@@ -478,9 +484,10 @@ __global__ __launch_bounds__(GG_THREADS) void group_linear_fwd_kernel(int m, int
 }
 } // namespace
 
-extern "C" int ogc_group_linear_fwd(int b, int m, int n, int npoints, int nsample, int groups, const float *P,
-                                    const int *idx, const float *rel, const float *wx, float *y, double *stats,
-                                    ogc_stream_t stream) {
+namespace {
+template <typename OT>
+int group_linear_fwd_impl(int b, int m, int n, int npoints, int nsample, int groups, const float *P, const int *idx,
+                          const float *rel, const float *wx, OT *y, double *stats, ogc_stream_t stream) {
     OGC_REQUIRE(b >= 0 && m >= 1 && n >= 1 && npoints >= 0 && nsample >= 0 && groups >= 0 &&
                     (long long)npoints * nsample < (1ll << 31),
                 "ogc_group_linear_fwd: bad dimensions");
@@ -489,7 +496,7 @@ extern "C" int ogc_group_linear_fwd(int b, int m, int n, int npoints, int nsampl
     OGC_REQUIRE(P && idx && rel && wx && y && (stats || groups == 0), "ogc_group_linear_fwd: null pointer");
     OGC_REQUIRE((long long)m * T < (1ll << 31) && (long long)m * n < (1ll << 31) && b <= 65535,
                 "ogc_group_linear_fwd: one sample exceeds 32-bit indexing");
-    if ((T & 3) != 0 || !aligned16(idx) || !aligned16(rel) || !aligned16(y) || (groups > 0 && m % groups != 0)) {
+    if ((T & 3) != 0 || !aligned16(idx) || !aligned16(rel) || ((uintptr_t)y & ogc_act_mask<OT>()) != 0 || (groups > 0 && m % groups != 0)) {
         ogc_set_error("ogc_group_linear_fwd: needs npoints * nsample %% 4 == 0, 16-byte aligned tensors, m %% groups == 0");
         return OGC_ERR_UNSUPPORTED;
     }
@@ -503,10 +510,23 @@ extern "C" int ogc_group_linear_fwd(int b, int m, int n, int npoints, int nsampl
         return OGC_ERR_LAUNCH;
     }
     dim3 grid(ogc_divup(T, GG_THREADS * 4), m / cpb, b);
-    hipLaunchKernelGGL(group_linear_fwd_kernel, grid, dim3(GG_THREADS), 0, s, m, n, T, cpb, cg, groups, P, idx, rel, wx,
+    hipLaunchKernelGGL(group_linear_fwd_kernel<OT>, grid, dim3(GG_THREADS), 0, s, m, n, T, cpb, cg, groups, P, idx, rel, wx,
                        y, groups > 0 ? stats : nullptr);
     OGC_CHECK_LAUNCH("ogc_group_linear_fwd");
     return OGC_OK;
+}
+} // namespace
+
+extern "C" int ogc_group_linear_fwd(int b, int m, int n, int npoints, int nsample, int groups, const float *P,
+                                    const int *idx, const float *rel, const float *wx, float *y, double *stats,
+                                    ogc_stream_t stream) {
+    return group_linear_fwd_impl<float>(b, m, n, npoints, nsample, groups, P, idx, rel, wx, y, stats, stream);
+}
+
+extern "C" int ogc_group_linear_fwd_h(int b, int m, int n, int npoints, int nsample, int groups, const float *P,
+                                      const int *idx, const float *rel, const float *wx, ogc_bf16_t *y, double *stats,
+                                      ogc_stream_t stream) {
+    return group_linear_fwd_impl<ogc_bf16>(b, m, n, npoints, nsample, groups, P, idx, rel, wx, y, stats, stream);
 }
 
 extern "C" int ogc_group_linear_bwd(int b, int m, int n, int npoints, int nsample, const float *grad_y, const int *idx,
@@ -627,9 +647,10 @@ __global__ __launch_bounds__(GRB_THREADS) void group_reverse_kernel(int n, int T
 // the lists out of global memory costs an L2 round trip per list step.  tc = 16 * GR_THREADS.
 // INTERP: the gradient of three_interpolate — position t = 3 i + k stands for grad_out[b, c, i] * weight[b, i, k] (the plane
 // has T / 3 values, the products are formed while staging).
-template <int NA, bool INTERP>
+// GT: element type of grad_out (float / ogc_bf16: act_io.h; the INTERP form is fp32 only).
+template <int NA, bool INTERP, typename GT = float>
 __global__ __launch_bounds__(GR_THREADS) void group_bwd_rev_kernel(int c, int n, int T, int tc, long long go_bstride,
-                                                                   const float *__restrict__ grad_out,
+                                                                   const GT *__restrict__ grad_out,
                                                                    const int *__restrict__ rev_start,
                                                                    const unsigned short *__restrict__ rev_pos,
                                                                    const unsigned short *__restrict__ heads,
@@ -639,7 +660,7 @@ __global__ __launch_bounds__(GR_THREADS) void group_bwd_rev_kernel(int c, int n,
     unsigned short *gr_pos = reinterpret_cast<unsigned short *>(gr_plane + tc);
     const int t = threadIdx.x, ch = blockIdx.x, b = blockIdx.y;
     const int chunks = (T + tc - 1) / tc;
-    const float *g = grad_out + (size_t)b * go_bstride + (size_t)ch * (INTERP ? T / 3 : T);
+    const GT *g = grad_out + (size_t)b * go_bstride + (size_t)ch * (INTERP ? T / 3 : T);
     const float *wt = INTERP ? weight + (size_t)b * T : nullptr;
     const int *rs = rev_start + (size_t)b * chunks * (n + 1);
     const unsigned short *rp = rev_pos + (size_t)b * T;
@@ -657,9 +678,10 @@ __global__ __launch_bounds__(GR_THREADS) void group_bwd_rev_kernel(int c, int n,
                 if constexpr (INTERP) {
                     const float4 w4 = *reinterpret_cast<const float4 *>(wt + tt + 4 * u);
                     const int q = tt + 4 * u;
-                    pre[u] = make_float4(w4.x * g[q / 3], w4.y * g[(q + 1) / 3], w4.z * g[(q + 2) / 3], w4.w * g[(q + 3) / 3]);
+                    pre[u] = make_float4(w4.x * ogc_ld1(g + q / 3), w4.y * ogc_ld1(g + (q + 1) / 3), w4.z * ogc_ld1(g + (q + 2) / 3),
+                                         w4.w * ogc_ld1(g + (q + 3) / 3));
                 } else {
-                    pre[u] = *reinterpret_cast<const float4 *>(g + tt + 4 * u);
+                    pre[u] = ogc_ld4(g + tt + 4 * u);
                 }
             }
         }
@@ -753,15 +775,17 @@ extern "C" int ogc_group_reverse(int b, int n, int npoints, int nsample, const i
     return OGC_OK;
 }
 
-extern "C" int ogc_group_points_grad_rev(int b, int c, int n, int npoints, int nsample, const float *grad_out,
-                                         const int *rev_start, const unsigned short *rev_pos,
-                                         const unsigned short *heads, float *grad_points, ogc_stream_t stream) {
+namespace {
+template <typename GT>
+int group_points_grad_rev_impl(int b, int c, int n, int npoints, int nsample, const GT *grad_out, const int *rev_start,
+                               const unsigned short *rev_pos, const unsigned short *heads, float *grad_points,
+                               ogc_stream_t stream) {
     OGC_REQUIRE(b >= 0 && c >= 0 && n >= 1 && npoints >= 0 && nsample >= 0 && (long long)npoints * nsample < (1ll << 31),
                 "ogc_group_points_grad_rev: bad dimensions");
     const int T = npoints * nsample;
     if (b == 0 || c == 0) return OGC_OK;
     OGC_REQUIRE(grad_out && rev_start && rev_pos && heads && grad_points, "ogc_group_points_grad_rev: null pointer");
-    if (T % 16 != 0 || !aligned16(grad_out) || !aligned16(rev_pos) || n > 32 * GR_THREADS || b > 65535) {
+    if (T % 16 != 0 || ((uintptr_t)grad_out & ogc_act_mask<GT>()) != 0 || !aligned16(rev_pos) || n > 32 * GR_THREADS || b > 65535) {
         ogc_set_error("ogc_group_points_grad_rev: needs npoints * nsample %% 16 == 0, 16-byte aligned tensors and n <= 16384");
         return OGC_ERR_UNSUPPORTED;
     }
@@ -775,7 +799,7 @@ extern "C" int ogc_group_points_grad_rev(int b, int c, int n, int npoints, int n
     const long long go_bstride = (long long)c * T;
     dim3 grid(c, b);
 #define GR_LAUNCH(NAV)                                                                                                         \
-    hipLaunchKernelGGL((group_bwd_rev_kernel<NAV, false>), grid, dim3(GR_THREADS), lds, s, c, n, T, tc, go_bstride, grad_out, \
+    hipLaunchKernelGGL((group_bwd_rev_kernel<NAV, false, GT>), grid, dim3(GR_THREADS), lds, s, c, n, T, tc, go_bstride, grad_out, \
                        rev_start, rev_pos, heads, nullptr, grad_points)
     if (n <= GR_THREADS) GR_LAUNCH(1);
     else if (n <= 2 * GR_THREADS) GR_LAUNCH(2);
@@ -786,6 +810,19 @@ extern "C" int ogc_group_points_grad_rev(int b, int c, int n, int npoints, int n
 #undef GR_LAUNCH
     OGC_CHECK_LAUNCH("ogc_group_points_grad_rev");
     return OGC_OK;
+}
+} // namespace
+
+extern "C" int ogc_group_points_grad_rev(int b, int c, int n, int npoints, int nsample, const float *grad_out,
+                                         const int *rev_start, const unsigned short *rev_pos,
+                                         const unsigned short *heads, float *grad_points, ogc_stream_t stream) {
+    return group_points_grad_rev_impl<float>(b, c, n, npoints, nsample, grad_out, rev_start, rev_pos, heads, grad_points, stream);
+}
+
+extern "C" int ogc_group_points_grad_rev_h(int b, int c, int n, int npoints, int nsample, const ogc_bf16_t *grad_out,
+                                           const int *rev_start, const unsigned short *rev_pos,
+                                           const unsigned short *heads, float *grad_points, ogc_stream_t stream) {
+    return group_points_grad_rev_impl<ogc_bf16>(b, c, n, npoints, nsample, grad_out, rev_start, rev_pos, heads, grad_points, stream);
 }
 
 extern "C" int ogc_three_interpolate_grad_rev(int b, int c, int n, int m, const float *grad_out, const float *weight,

@@ -20,10 +20,10 @@
 #include <stdlib.h>
 
 #include "ogc_common.h"
+#include "act_io.h"
+#include "conv1x1_shared.h"
 
 namespace {
-
-typedef float v4f __attribute__((ext_vector_type(4)));
 
 constexpr int GC_WAVES = 4;
 
@@ -33,10 +33,13 @@ constexpr int GC_WAVES = 4;
 // — the expression of gn_maxpool_bwd_dx_kernel, bit for bit; a lane's four positions lie inside one neighbourhood (S >= 16).
 // KA = 2: the weights are staged 2 x 4 KQ rows at a time — ONE barrier per two input chunks.  (The 128-row tile with 16-row chunks
 // reaches 111 TFLOP/s on 128 <- 256 channels, with 8-row chunks 86: the barrier is what it waits for; 32-row input chunks spill.)
-template <int RB, int KQ, bool SPLIT_M, bool TRANS, bool POOLED = false, int KA = 1>
+// AT: element type of in / out (float / ogc_bf16: act_io.h).  BF: operands rounded to bf16 on v_mfma_f32_16x16x16_bf16 — four
+// row quads (q .. q + 3) of the input chunk feed one MFMA: k-slot i of lane group kk is chunk row 4 (q + i) + kk for BOTH operands
+// (a permutation of the sixteen rows, which the sum over k does not see; cf. conv1x1_gemm_kernel).
+template <int RB, int KQ, bool SPLIT_M, bool TRANS, bool POOLED = false, int KA = 1, typename AT = float, bool BF = false>
 __global__ __launch_bounds__(GC_WAVES *OGC_WAVE, 2) void gemm_chunk_kernel(int M, int K, int hw, const float *__restrict__ w,
-                                                                         const float *__restrict__ in,
-                                                                         float *__restrict__ out,
+                                                                         const AT *__restrict__ in,
+                                                                         AT *__restrict__ out,
                                                                          const float2 *__restrict__ coef2 = nullptr,
                                                                          const float2 *__restrict__ inj = nullptr,
                                                                          int s_shift = 0) {
@@ -54,7 +57,7 @@ __global__ __launch_bounds__(GC_WAVES *OGC_WAVE, 2) void gemm_chunk_kernel(int M
     const bool active = p0 < hw;                                      // (wave-uniform; !SPLIT_M: the last workgroup may be ragged)
     const int pl = active ? p0 : 0;
     const int nblk = min(RB, (M - m0 - wrow + 15) >> 4);              // row blocks with at least one real row (may be <= 0)
-    const float *inb = in + (size_t)b * K * hw + pl + 4 * j;
+    const AT *inb = in + (size_t)b * K * hw + pl + 4 * j;
     const int nchunks = (K + KC - 1) / KC;
 
     v4f acc[RB][4];
@@ -93,7 +96,7 @@ __global__ __launch_bounds__(GC_WAVES *OGC_WAVE, 2) void gemm_chunk_kernel(int M
 #pragma unroll
         for (int q = 0; q < KQ; ++q) {
             const int k = min(k0 + 4 * q + kk, K - 1);
-            xv[q] = *reinterpret_cast<const float4 *>(inb + (size_t)k * hw);
+            xv[q] = ogc_ld4(inb + (size_t)k * hw);
             if constexpr (POOLED) {
                 cc[q] = coef2[(size_t)b * K + k];
                 jv[q] = inj[((size_t)b * K + k) * centres + my_centre];
@@ -125,6 +128,26 @@ __global__ __launch_bounds__(GC_WAVES *OGC_WAVE, 2) void gemm_chunk_kernel(int M
     // rows of a tile, 67 rows -> RB = 5) — a wave-uniform `a < nblk` branch per row block between the MFMAs costs the matrix pipe
     // issue slots, and the loop written twice (with and without it) spills.
     auto compute = [&](const float *a_lds, const float4(&xv)[KQ], int koff = 0) {
+        if constexpr (BF) {
+            static_assert(!BF || KQ % 4 == 0, "bf16 operands: whole groups of four row quads");
+#pragma unroll
+            for (int g = 0; g < KQ / 4; ++g) {
+                const v4s bx = ogc_pack_bf16(xv[4 * g].x, xv[4 * g + 1].x, xv[4 * g + 2].x, xv[4 * g + 3].x);
+                const v4s by = ogc_pack_bf16(xv[4 * g].y, xv[4 * g + 1].y, xv[4 * g + 2].y, xv[4 * g + 3].y);
+                const v4s bz = ogc_pack_bf16(xv[4 * g].z, xv[4 * g + 1].z, xv[4 * g + 2].z, xv[4 * g + 3].z);
+                const v4s bw = ogc_pack_bf16(xv[4 * g].w, xv[4 * g + 1].w, xv[4 * g + 2].w, xv[4 * g + 3].w);
+#pragma unroll
+                for (int a = 0; a < RB; ++a) {
+                    const float *ar = a_lds + (wrow + a * 16 + j) * LD + koff + 16 * g + kk;
+                    const v4s av = ogc_pack_bf16(ar[0], ar[4], ar[8], ar[12]);
+                    acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, bx, acc[a][0], 0, 0, 0);
+                    acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, by, acc[a][1], 0, 0, 0);
+                    acc[a][2] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, bz, acc[a][2], 0, 0, 0);
+                    acc[a][3] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, bw, acc[a][3], 0, 0, 0);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int q = 0; q < KQ; ++q) {
             const float bx = xv[q].x, by = xv[q].y, bz = xv[q].z, bw = xv[q].w;
@@ -189,16 +212,14 @@ __global__ __launch_bounds__(GC_WAVES *OGC_WAVE, 2) void gemm_chunk_kernel(int M
     }
     if (!active) return;
     // acc[a][c][r]: row a * 16 + kk * 4 + r, position p0 + 4 j + c  ->  one float4 per row
-    float *ob = out + (size_t)b * M * hw + p0 + 4 * j;
+    AT *ob = out + (size_t)b * M * hw + p0 + 4 * j;
 #pragma unroll
     for (int a = 0; a < RB; ++a) {
         if (a < nblk) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = m0 + wrow + a * 16 + kk * 4 + r;
-                if (m < M)
-                    *reinterpret_cast<float4 *>(ob + (size_t)m * hw) =
-                        make_float4(acc[a][0][r], acc[a][1][r], acc[a][2][r], acc[a][3][r]);
+                if (m < M) ogc_st4(ob + (size_t)m * hw, make_float4(acc[a][0][r], acc[a][1][r], acc[a][2][r], acc[a][3][r]));
             }
         }
     }
@@ -270,13 +291,17 @@ extern "C" int ogc_conv1x1_gemm_any(int b, int M, int K, int hw, int transpose_a
 // POOLED above) — the dense g_y (the size of the layer's activation) is neither written nor read.  w (cout, cin), y (b, cout, hw),
 // grad_z (b, cin, hw); any cin (row tiles of 64 up to 64 channels, of 128 beyond).  hw % 64 == 0,
 // nsample in {16, 32, 64} dividing hw, at least 1024 tiles of 64 positions (fewer: OGC_ERR_UNSUPPORTED, the caller keeps the dense path).
-extern "C" int ogc_conv1x1_dgrad_pooled(int b, int cin, int cout, int hw, int nsample, const float *w, const float *y,
-                                        const float *coef2, const float *inj, float *grad_z, ogc_stream_t stream) {
+namespace {
+template <typename AT>
+int dgrad_pooled_impl(int b, int cin, int cout, int hw, int nsample, const float *w, const AT *y, const float *coef2,
+                      const float *inj, AT *grad_z, ogc_stream_t stream) {
+    constexpr bool BF = sizeof(AT) == 2; // 16-bit tensors come with bf16 operands
     OGC_REQUIRE(b >= 0 && cin >= 1 && cout >= 1 && hw >= 1, "ogc_conv1x1_dgrad_pooled: bad shape");
     OGC_REQUIRE(w && y && coef2 && inj && grad_z, "ogc_conv1x1_dgrad_pooled: null pointer");
     const int sh = nsample == 16 ? 4 : nsample == 32 ? 5 : nsample == 64 ? 6 : -1;
     if (sh < 0 || hw % nsample != 0 || (hw & 63) != 0 || (long long)b * (hw / 64) < 1024 ||
-        (((uintptr_t)y | (uintptr_t)grad_z) & 15) != 0 || (((uintptr_t)coef2 | (uintptr_t)inj) & 7) != 0) {
+        (((uintptr_t)y | (uintptr_t)grad_z) & ogc_act_mask<AT>()) != 0 || (((uintptr_t)coef2 | (uintptr_t)inj) & 7) != 0 ||
+        (BF && !ogc_g_matmul_bf16)) {
         ogc_set_error("ogc_conv1x1_dgrad_pooled: needs nsample in {16, 32, 64} dividing hw, hw %% 64 == 0, >= 1024 tiles of 64 "
                       "positions and aligned tensors (hw=%d, nsample=%d, b=%d)", hw, nsample, b);
         return OGC_ERR_UNSUPPORTED;
@@ -290,15 +315,27 @@ extern "C" int ogc_conv1x1_dgrad_pooled(int b, int cin, int cout, int hw, int ns
     if (M <= 64) {
         constexpr int RB = 4, KQ = 4, KA = 2; // (weights staged 32 rows at a time: registers to spare at 64 rows)
         dim3 grid(ogc_divup(hw, 64 * GC_WAVES), ogc_divup(M, 16 * RB), b);
-        hipLaunchKernelGGL((gemm_chunk_kernel<RB, KQ, false, true, true, KA>), grid, dim3(GC_WAVES * OGC_WAVE),
+        hipLaunchKernelGGL((gemm_chunk_kernel<RB, KQ, false, true, true, KA, AT, BF>), grid, dim3(GC_WAVES * OGC_WAVE),
                            (size_t)2 * 16 * RB * 4 * ((KQ * KA) | 1) * sizeof(float), s, M, K, hw, w, y, grad_z, c2, ij, sh);
     } else {
         constexpr int RB = 8, KQ = 4;
         dim3 grid(ogc_divup(hw, 64 * GC_WAVES), ogc_divup(M, 16 * RB), b);
-        hipLaunchKernelGGL((gemm_chunk_kernel<RB, KQ, false, true, true>), grid, dim3(GC_WAVES * OGC_WAVE),
+        hipLaunchKernelGGL((gemm_chunk_kernel<RB, KQ, false, true, true, 1, AT, BF>), grid, dim3(GC_WAVES * OGC_WAVE),
                            (size_t)2 * 16 * RB * 4 * (KQ | 1) * sizeof(float), s, M, K, hw, w, y, grad_z, c2, ij, sh);
     }
     OGC_CHECK_LAUNCH("ogc_conv1x1_dgrad_pooled");
     return OGC_OK;
+}
+} // namespace
+
+extern "C" int ogc_conv1x1_dgrad_pooled(int b, int cin, int cout, int hw, int nsample, const float *w, const float *y,
+                                        const float *coef2, const float *inj, float *grad_z, ogc_stream_t stream) {
+    return dgrad_pooled_impl<float>(b, cin, cout, hw, nsample, w, y, coef2, inj, grad_z, stream);
+}
+
+// 16-bit y / grad_z, bf16 operands (needs ogc_set_matmul_precision(1))
+extern "C" int ogc_conv1x1_dgrad_pooled_h(int b, int cin, int cout, int hw, int nsample, const float *w, const ogc_bf16_t *y,
+                                          const float *coef2, const float *inj, ogc_bf16_t *grad_z, ogc_stream_t stream) {
+    return dgrad_pooled_impl<ogc_bf16>(b, cin, cout, hw, nsample, w, y, coef2, inj, grad_z, stream);
 }
 

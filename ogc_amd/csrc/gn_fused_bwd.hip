@@ -23,6 +23,7 @@
 //   ogc_conv1x1_dgrad_adjoint   g_prev
 #include "ogc_common.h"
 #include "conv_stage.h"
+#include "act_io.h"
 
 namespace {
 
@@ -36,11 +37,12 @@ constexpr int WG_WAVES = 4;
 // POOLED: g_y is the gradient of a max-pooled GroupNorm in sparse form (ogc_group_norm_maxpool_bwd_sparse): `dy` is the
 // convolution's OUTPUT y, and g_y[row, pos] = fmaf(c2, y, c3) + (pos % S == arg ? ag : 0) is rebuilt from coef2[b, row] =
 // (c2, c3) and inj[b, row, pos / S] = (ag, arg) — a step's 16 positions lie inside one neighbourhood (S = 16, 32, 64).
-template <int COB, int CIB, bool POOLED>
+// AT: element type of x and dy (float / ogc_bf16: act_io.h).
+template <int COB, int CIB, bool POOLED, typename AT = float>
 __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void wgrad_moments_kernel(int cin, int cout, int hw, int chunks,
                                                                            int steps_per_wave, int relu,
-                                                                           const float *__restrict__ x,   // y_prev (B, cin, hw)
-                                                                           const float *__restrict__ dy,  // g_y (B, cout, hw)
+                                                                           const AT *__restrict__ x,   // y_prev (B, cin, hw)
+                                                                           const AT *__restrict__ dy,  // g_y (B, cout, hw)
                                                                            const float *__restrict__ aff_a,
                                                                            const float *__restrict__ aff_b,
                                                                            const float2 *__restrict__ coef2, // (B, cout)
@@ -86,8 +88,8 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void wgrad_moments_kernel(int c
         ca[c] = aff_a[(size_t)img * cin + ch];
         cb[c] = aff_b[(size_t)img * cin + ch];
     }
-    const float *yb_ = dy + (size_t)img * cout * hw + 4 * k;
-    const float *xb_ = x + (size_t)img * cin * hw + 4 * k;
+    const AT *yb_ = dy + (size_t)img * cout * hw + 4 * k;
+    const AT *xb_ = x + (size_t)img * cin * hw + 4 * k;
     int cur = min(first, steps_per_img - 1);
     const int stop = min(first + mine, steps_per_img) - 1; // the walk stays on the wave's last step once it is reached
     // Unconditional loads of one shape (see conv1x1_wgrad_kernel: a load under a per-lane condition makes the compiler wait
@@ -97,9 +99,9 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void wgrad_moments_kernel(int c
     auto load = [&](float4(&yv)[COB], float4(&xv)[CIB], float2(&jv)[COB], int &jpos) { // step `cur`, then advance
         const int pb = cur * 16;
 #pragma unroll
-        for (int a = 0; a < COB; ++a) yv[a] = *reinterpret_cast<const float4 *>(yb_ + yrow[a] + pb);
+        for (int a = 0; a < COB; ++a) yv[a] = ogc_ld4(yb_ + yrow[a] + pb);
 #pragma unroll
-        for (int c = 0; c < CIB; ++c) xv[c] = *reinterpret_cast<const float4 *>(xb_ + xrow[c] + pb);
+        for (int c = 0; c < CIB; ++c) xv[c] = ogc_ld4(xb_ + xrow[c] + pb);
         if (POOLED) {
 #pragma unroll
             for (int a = 0; a < COB; ++a) jv[a] = jb_[jrow[a] + (pb >> s_shift)];
@@ -180,8 +182,8 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void wgrad_moments_kernel(int c
     }
 }
 
-template <int COB, int CIB>
-void moments_launch(int b, int cin, int cout, int hw, int relu, const float *x, const float *dy, const float *pa,
+template <int COB, int CIB, typename AT>
+void moments_launch(int b, int cin, int cout, int hw, int relu, const AT *x, const AT *dy, const float *pa,
                     const float *pb, const float *coef2, const float *inj, int s_shift, float *hm, hipStream_t s) {
     const int steps_per_img = hw >> 4;
     const int tiles = ogc_divup(cout, 16 * COB) * ogc_divup(cin, 16 * CIB);
@@ -194,10 +196,10 @@ void moments_launch(int b, int cin, int cout, int hw, int relu, const float *x, 
     dim3 grid(b * chunks, ogc_divup(cout, 16 * COB), ogc_divup(cin, 16 * CIB));
     const float2 *c2 = reinterpret_cast<const float2 *>(coef2), *ij = reinterpret_cast<const float2 *>(inj);
     if (inj)
-        hipLaunchKernelGGL((wgrad_moments_kernel<COB, CIB, true>), grid, dim3(WG_WAVES * OGC_WAVE), 0, s, cin, cout, hw, chunks,
+        hipLaunchKernelGGL((wgrad_moments_kernel<COB, CIB, true, AT>), grid, dim3(WG_WAVES * OGC_WAVE), 0, s, cin, cout, hw, chunks,
                            spw, relu, x, dy, pa, pb, c2, ij, s_shift, hm);
     else
-        hipLaunchKernelGGL((wgrad_moments_kernel<COB, CIB, false>), grid, dim3(WG_WAVES * OGC_WAVE), 0, s, cin, cout, hw, chunks,
+        hipLaunchKernelGGL((wgrad_moments_kernel<COB, CIB, false, AT>), grid, dim3(WG_WAVES * OGC_WAVE), 0, s, cin, cout, hw, chunks,
                            spw, relu, x, dy, pa, pb, c2, ij, 0, hm);
 }
 
@@ -280,18 +282,19 @@ __global__ __launch_bounds__(256) void moments_combine_kernel(int b, int cin, in
 // an output row per lane and reads the same four of y_prev.
 // POOLED: g_y in the sparse form of ogc_group_norm_maxpool_bwd_sparse, rebuilt from the convolution's output (`gy` = y) as
 // in wgrad_moments_kernel; a lane's four positions lie inside one neighbourhood (S >= 4).
-template <int KQ, bool POOLED>
+// AT: element type of gy, yprev and out (float / ogc_bf16: act_io.h).
+template <int KQ, bool POOLED, typename AT = float>
 __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void dgrad_adjoint_kernel(int M, int K, int hw, int relu,
                                                                            const float *__restrict__ w,     // (K, M)
-                                                                           const float *__restrict__ gy,    // (B, K, hw)
-                                                                           const float *__restrict__ yprev, // (B, M, hw)
+                                                                           const AT *__restrict__ gy,    // (B, K, hw)
+                                                                           const AT *__restrict__ yprev, // (B, M, hw)
                                                                            const float *__restrict__ pa,
                                                                            const float *__restrict__ pb,
                                                                            const float *__restrict__ coef,  // (B, M, 3)
                                                                            const float2 *__restrict__ coef2, // (B, K)
                                                                            const float2 *__restrict__ inj,   // (B, K, hw >> s_shift)
                                                                            int s_shift,
-                                                                           float *__restrict__ out) {       // (B, M, hw)
+                                                                           AT *__restrict__ out) {       // (B, M, hw)
     extern __shared__ __attribute__((aligned(16))) float a_lds[]; // [64][ogc_a_ld(Kq)] weights (conv_stage.h), then [64][5] coefficients
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 15, kk = lane >> 4;
@@ -299,9 +302,9 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void dgrad_adjoint_kernel(int M
     const int p0 = (blockIdx.x * WG_WAVES + wave) * 64;
     const int Kq = (K + 3) >> 2;
     const bool live = p0 < hw;
-    const float *inb = gy + (size_t)b * K * hw;
-    float *outb = out + (size_t)b * M * hw;
-    const float *yb = yprev + (size_t)b * M * hw;
+    const AT *inb = gy + (size_t)b * K * hw;
+    AT *outb = out + (size_t)b * M * hw;
+    const AT *yb = yprev + (size_t)b * M * hw;
     const int a_ld = ogc_a_ld(Kq);
     float *cf = a_lds + (size_t)64 * a_ld;
 
@@ -309,8 +312,7 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void dgrad_adjoint_kernel(int M
 #pragma unroll
     for (int q = 0; q < KQ; ++q) {
         const int row = q * 4 + kk;
-        xin[q] = (live && q < Kq && row < K) ? *reinterpret_cast<const float4 *>(inb + (size_t)row * hw + p0 + 4 * j)
-                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+        xin[q] = (live && q < Kq && row < K) ? ogc_ld4(inb + (size_t)row * hw + p0 + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (POOLED) {
         // (c2, c3, ag, arg) of the wave's K rows x (64 >> s_shift) neighbourhoods through a wave-private LDS table: read back one
@@ -364,8 +366,7 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void dgrad_adjoint_kernel(int M
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int m = m0 + a * 16 + kk * 4 + r;
-                    yv[r] = (live && m < M) ? *reinterpret_cast<const float4 *>(yb + (size_t)m * hw + p0 + 4 * j)
-                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+                    yv[r] = (live && m < M) ? ogc_ld4(yb + (size_t)m * hw + p0 + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
                 v4f acc[4];
 #pragma unroll
@@ -395,7 +396,7 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void dgrad_adjoint_kernel(int M
                             float4 o;
                             o.x = fmaf(al, g.x, fmaf(c2, y.x, c3)); o.y = fmaf(al, g.y, fmaf(c2, y.y, c3));
                             o.z = fmaf(al, g.z, fmaf(c2, y.z, c3)); o.w = fmaf(al, g.w, fmaf(c2, y.w, c3));
-                            *reinterpret_cast<float4 *>(outb + (size_t)m * hw + p0 + 4 * j) = o;
+                            ogc_st4(outb + (size_t)m * hw + p0 + 4 * j, o);
                         }
                     }
                 }
@@ -409,12 +410,13 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void dgrad_adjoint_kernel(int M
 namespace {
 int nsample_shift(int nsample) { return nsample == 16 ? 4 : nsample == 32 ? 5 : nsample == 64 ? 6 : -1; }
 
-int wgrad_moments_impl(const char *name, int b, int cin, int cout, int hw, int relu, const float *y_prev, const float *pa,
-                       const float *pb, const float *grad_y, const float *coef2, const float *inj, int s_shift,
+template <typename AT>
+int wgrad_moments_impl(const char *name, int b, int cin, int cout, int hw, int relu, const AT *y_prev, const float *pa,
+                       const float *pb, const AT *grad_y, const float *coef2, const float *inj, int s_shift,
                        float *moments, ogc_stream_t stream) {
     OGC_REQUIRE(b >= 0 && cin >= 1 && cout >= 1 && hw >= 1, "%s: bad shape", name);
     OGC_REQUIRE(y_prev && pa && pb && grad_y && moments, "%s: null pointer", name);
-    if ((hw & 15) != 0 || (((uintptr_t)y_prev | (uintptr_t)grad_y) & 15) != 0) {
+    if ((hw & 15) != 0 || (((uintptr_t)y_prev | (uintptr_t)grad_y) & ogc_act_mask<AT>()) != 0) {
         ogc_set_error("%s: hw=%d must be a multiple of 16 and the tensors 16-byte aligned", name, hw);
         return OGC_ERR_UNSUPPORTED;
     }
@@ -426,7 +428,7 @@ int wgrad_moments_impl(const char *name, int b, int cin, int cout, int hw, int r
         ogc_set_error("%s: memset failed", name);
         return OGC_ERR_LAUNCH;
     }
-#define OGC_ML(A, C) moments_launch<A, C>(b, cin, cout, hw, relu, y_prev, grad_y, pa, pb, coef2, inj, s_shift, moments, s)
+#define OGC_ML(A, C) moments_launch<A, C, AT>(b, cin, cout, hw, relu, y_prev, grad_y, pa, pb, coef2, inj, s_shift, moments, s)
     if (cout <= 16 && cin <= 16) OGC_ML(1, 1);
     else if (cout <= 32 && cin <= 16) OGC_ML(2, 1);
     else if (cout <= 32 && cin <= 32) OGC_ML(2, 2);
@@ -443,23 +445,45 @@ int wgrad_moments_impl(const char *name, int b, int cin, int cout, int hw, int r
 
 extern "C" int ogc_conv1x1_wgrad_moments(int b, int cin, int cout, int hw, int relu, const float *y_prev, const float *pa,
                                          const float *pb, const float *grad_y, float *moments, ogc_stream_t stream) {
-    return wgrad_moments_impl("ogc_conv1x1_wgrad_moments", b, cin, cout, hw, relu, y_prev, pa, pb, grad_y, nullptr, nullptr, 0,
-                              moments, stream);
+    return wgrad_moments_impl<float>("ogc_conv1x1_wgrad_moments", b, cin, cout, hw, relu, y_prev, pa, pb, grad_y, nullptr, nullptr, 0,
+                                     moments, stream);
+}
+
+extern "C" int ogc_conv1x1_wgrad_moments_h(int b, int cin, int cout, int hw, int relu, const ogc_bf16_t *y_prev, const float *pa,
+                                           const float *pb, const ogc_bf16_t *grad_y, float *moments, ogc_stream_t stream) {
+    return wgrad_moments_impl<ogc_bf16>("ogc_conv1x1_wgrad_moments_h", b, cin, cout, hw, relu, y_prev, pa, pb, grad_y, nullptr,
+                                        nullptr, 0, moments, stream);
 }
 
 // The same with grad_y in the sparse form of ogc_group_norm_maxpool_bwd_sparse: y (B, cout, hw) is the convolution's output,
 // hw = centres * nsample (nsample 16, 32 or 64).
+namespace {
+template <typename AT>
+int wgrad_moments_pooled_impl(const char *name, int b, int cin, int cout, int hw, int relu, int nsample, const AT *y_prev,
+                              const float *pa, const float *pb, const AT *y, const float *coef2, const float *inj,
+                              float *moments, ogc_stream_t stream) {
+    const int sh = nsample_shift(nsample);
+    if (sh < 0 || hw % nsample != 0 || (((uintptr_t)coef2 | (uintptr_t)inj) & 7) != 0) {
+        ogc_set_error("%s: nsample=%d must be 16, 32 or 64 and divide hw=%d", name, nsample, hw);
+        return OGC_ERR_UNSUPPORTED;
+    }
+    OGC_REQUIRE(b == 0 || (coef2 && inj), "%s: null pointer", name);
+    return wgrad_moments_impl<AT>(name, b, cin, cout, hw, relu, y_prev, pa, pb, y, coef2, inj, sh, moments, stream);
+}
+} // namespace
+
 extern "C" int ogc_conv1x1_wgrad_moments_pooled(int b, int cin, int cout, int hw, int relu, int nsample, const float *y_prev,
                                                 const float *pa, const float *pb, const float *y, const float *coef2,
                                                 const float *inj, float *moments, ogc_stream_t stream) {
-    const int sh = nsample_shift(nsample);
-    if (sh < 0 || hw % nsample != 0 || (((uintptr_t)coef2 | (uintptr_t)inj) & 7) != 0) {
-        ogc_set_error("ogc_conv1x1_wgrad_moments_pooled: nsample=%d must be 16, 32 or 64 and divide hw=%d", nsample, hw);
-        return OGC_ERR_UNSUPPORTED;
-    }
-    OGC_REQUIRE(b == 0 || (coef2 && inj), "ogc_conv1x1_wgrad_moments_pooled: null pointer");
-    return wgrad_moments_impl("ogc_conv1x1_wgrad_moments_pooled", b, cin, cout, hw, relu, y_prev, pa, pb, y, coef2, inj, sh,
-                              moments, stream);
+    return wgrad_moments_pooled_impl<float>("ogc_conv1x1_wgrad_moments_pooled", b, cin, cout, hw, relu, nsample, y_prev, pa, pb, y,
+                                            coef2, inj, moments, stream);
+}
+
+extern "C" int ogc_conv1x1_wgrad_moments_pooled_h(int b, int cin, int cout, int hw, int relu, int nsample,
+                                                  const ogc_bf16_t *y_prev, const float *pa, const float *pb, const ogc_bf16_t *y,
+                                                  const float *coef2, const float *inj, float *moments, ogc_stream_t stream) {
+    return wgrad_moments_pooled_impl<ogc_bf16>("ogc_conv1x1_wgrad_moments_pooled_h", b, cin, cout, hw, relu, nsample, y_prev, pa,
+                                               pb, y, coef2, inj, moments, stream);
 }
 
 extern "C" int ogc_gn_moments_combine(int b, int cin, int cout, int hw, int groups, const float *moments, const float *w,
@@ -483,12 +507,13 @@ extern "C" int ogc_gn_moments_combine(int b, int cin, int cout, int hw, int grou
 }
 
 namespace {
-int dgrad_adjoint_impl(const char *name, int b, int cin, int cout, int hw, int relu, const float *w, const float *grad_y,
-                       const float *y_prev, const float *pa, const float *pb, const float *coef, const float *coef2,
-                       const float *inj, int s_shift, float *grad_prev, ogc_stream_t stream) {
+template <typename AT>
+int dgrad_adjoint_impl(const char *name, int b, int cin, int cout, int hw, int relu, const float *w, const AT *grad_y,
+                       const AT *y_prev, const float *pa, const float *pb, const float *coef, const float *coef2,
+                       const float *inj, int s_shift, AT *grad_prev, ogc_stream_t stream) {
     OGC_REQUIRE(b >= 0 && cin >= 1 && cout >= 1 && hw >= 1, "%s: bad shape", name);
     OGC_REQUIRE(w && grad_y && y_prev && pa && pb && coef && grad_prev, "%s: null pointer", name);
-    if ((hw & 63) != 0 || cout > 160 || (((uintptr_t)grad_y | (uintptr_t)y_prev | (uintptr_t)grad_prev) & 15) != 0) {
+    if ((hw & 63) != 0 || cout > 160 || (((uintptr_t)grad_y | (uintptr_t)y_prev | (uintptr_t)grad_prev) & ogc_act_mask<AT>()) != 0) {
         ogc_set_error("%s: needs hw %% 64 == 0, cout <= 160 and 16-byte aligned tensors (hw=%d, cout=%d)", name, hw, cout);
         return OGC_ERR_UNSUPPORTED;
     }
@@ -509,10 +534,10 @@ int dgrad_adjoint_impl(const char *name, int b, int cin, int cout, int hw, int r
 #define OGC_DGA(KQV)                                                                                                        \
     do {                                                                                                                    \
         if (inj)                                                                                                            \
-            hipLaunchKernelGGL((dgrad_adjoint_kernel<KQV, true>), grid, dim3(WG_WAVES * OGC_WAVE), lds, s, M, K, hw, relu, w,  \
+            hipLaunchKernelGGL((dgrad_adjoint_kernel<KQV, true, AT>), grid, dim3(WG_WAVES * OGC_WAVE), lds, s, M, K, hw, relu, w,  \
                                grad_y, y_prev, pa, pb, coef, c2, ij, s_shift, grad_prev);                                  \
         else                                                                                                                \
-            hipLaunchKernelGGL((dgrad_adjoint_kernel<KQV, false>), grid, dim3(WG_WAVES * OGC_WAVE), lds, s, M, K, hw, relu, w, \
+            hipLaunchKernelGGL((dgrad_adjoint_kernel<KQV, false, AT>), grid, dim3(WG_WAVES * OGC_WAVE), lds, s, M, K, hw, relu, w, \
                                grad_y, y_prev, pa, pb, coef, c2, ij, 0, grad_prev);                                        \
     } while (0)
     if (Kq <= 8) OGC_DGA(8);
@@ -529,21 +554,45 @@ int dgrad_adjoint_impl(const char *name, int b, int cin, int cout, int hw, int r
 extern "C" int ogc_conv1x1_dgrad_adjoint(int b, int cin, int cout, int hw, int relu, const float *w, const float *grad_y,
                                          const float *y_prev, const float *pa, const float *pb, const float *coef,
                                          float *grad_prev, ogc_stream_t stream) {
-    return dgrad_adjoint_impl("ogc_conv1x1_dgrad_adjoint", b, cin, cout, hw, relu, w, grad_y, y_prev, pa, pb, coef, nullptr,
-                              nullptr, 0, grad_prev, stream);
+    return dgrad_adjoint_impl<float>("ogc_conv1x1_dgrad_adjoint", b, cin, cout, hw, relu, w, grad_y, y_prev, pa, pb, coef, nullptr,
+                                     nullptr, 0, grad_prev, stream);
+}
+
+extern "C" int ogc_conv1x1_dgrad_adjoint_h(int b, int cin, int cout, int hw, int relu, const float *w, const ogc_bf16_t *grad_y,
+                                           const ogc_bf16_t *y_prev, const float *pa, const float *pb, const float *coef,
+                                           ogc_bf16_t *grad_prev, ogc_stream_t stream) {
+    return dgrad_adjoint_impl<ogc_bf16>("ogc_conv1x1_dgrad_adjoint_h", b, cin, cout, hw, relu, w, grad_y, y_prev, pa, pb, coef,
+                                        nullptr, nullptr, 0, grad_prev, stream);
 }
 
 // The same with grad_y in the sparse form of ogc_group_norm_maxpool_bwd_sparse (y: the convolution's output).
+namespace {
+template <typename AT>
+int dgrad_adjoint_pooled_impl(const char *name, int b, int cin, int cout, int hw, int relu, int nsample, const float *w,
+                              const AT *y, const float *coef2, const float *inj, const AT *y_prev, const float *pa,
+                              const float *pb, const float *coef, AT *grad_prev, ogc_stream_t stream) {
+    const int sh = nsample_shift(nsample);
+    if (sh < 0 || hw % nsample != 0 || (((uintptr_t)coef2 | (uintptr_t)inj) & 7) != 0) {
+        ogc_set_error("%s: nsample=%d must be 16, 32 or 64 and divide hw=%d", name, nsample, hw);
+        return OGC_ERR_UNSUPPORTED;
+    }
+    OGC_REQUIRE(b == 0 || (coef2 && inj), "%s: null pointer", name);
+    return dgrad_adjoint_impl<AT>(name, b, cin, cout, hw, relu, w, y, y_prev, pa, pb, coef, coef2, inj, sh, grad_prev, stream);
+}
+} // namespace
+
 extern "C" int ogc_conv1x1_dgrad_adjoint_pooled(int b, int cin, int cout, int hw, int relu, int nsample, const float *w,
                                                 const float *y, const float *coef2, const float *inj, const float *y_prev,
                                                 const float *pa, const float *pb, const float *coef, float *grad_prev,
                                                 ogc_stream_t stream) {
-    const int sh = nsample_shift(nsample);
-    if (sh < 0 || hw % nsample != 0 || (((uintptr_t)coef2 | (uintptr_t)inj) & 7) != 0) {
-        ogc_set_error("ogc_conv1x1_dgrad_adjoint_pooled: nsample=%d must be 16, 32 or 64 and divide hw=%d", nsample, hw);
-        return OGC_ERR_UNSUPPORTED;
-    }
-    OGC_REQUIRE(b == 0 || (coef2 && inj), "ogc_conv1x1_dgrad_adjoint_pooled: null pointer");
-    return dgrad_adjoint_impl("ogc_conv1x1_dgrad_adjoint_pooled", b, cin, cout, hw, relu, w, y, y_prev, pa, pb, coef, coef2, inj,
-                              sh, grad_prev, stream);
+    return dgrad_adjoint_pooled_impl<float>("ogc_conv1x1_dgrad_adjoint_pooled", b, cin, cout, hw, relu, nsample, w, y, coef2, inj,
+                                            y_prev, pa, pb, coef, grad_prev, stream);
+}
+
+extern "C" int ogc_conv1x1_dgrad_adjoint_pooled_h(int b, int cin, int cout, int hw, int relu, int nsample, const float *w,
+                                                  const ogc_bf16_t *y, const float *coef2, const float *inj,
+                                                  const ogc_bf16_t *y_prev, const float *pa, const float *pb, const float *coef,
+                                                  ogc_bf16_t *grad_prev, ogc_stream_t stream) {
+    return dgrad_adjoint_pooled_impl<ogc_bf16>("ogc_conv1x1_dgrad_adjoint_pooled_h", b, cin, cout, hw, relu, nsample, w, y, coef2,
+                                               inj, y_prev, pa, pb, coef, grad_prev, stream);
 }

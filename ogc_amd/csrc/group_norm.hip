@@ -13,6 +13,7 @@
 // x is (B, C, HW) fp32 contiguous; the channels of a group are contiguous, so a (sample, group) row is one
 // contiguous run of (C/G)*HW floats.  Statistics: biased variance, rstd = 1/sqrt(var + eps), as nn.GroupNorm.
 #include "ogc_common.h"
+#include "act_io.h"
 
 namespace {
 
@@ -148,14 +149,15 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(int c, int hw, int
 // ---- backward -----------------------------------------------------------------------------------------------
 // grid (chunks, C, B): ds = sum dy'*x, db = sum dy' of one slice of a channel -> dsdb[chunk][b*c][2] (fp64, every slot
 // written once: no clearing, no atomics)
-template <bool RELU>
+// AT: element type of x, dy (and dx below): float / ogc_bf16 (act_io.h)
+template <bool RELU, typename AT = float>
 __global__ __launch_bounds__(GN_THREADS) void gn_bwd_sums_kernel(int c, int hw, int groups,
-                                                                 const float *__restrict__ x,
+                                                                 const AT *__restrict__ x,
                                                                  const float *__restrict__ gamma,
                                                                  const float *__restrict__ beta,
                                                                  const float *__restrict__ mean,
                                                                  const float *__restrict__ rstd,
-                                                                 const float *__restrict__ dy,
+                                                                 const AT *__restrict__ dy,
                                                                  double *__restrict__ dsdb) {
     __shared__ double smem[2 * GN_THREADS / 64];
     const int b = blockIdx.z, ch = blockIdx.y;
@@ -163,12 +165,12 @@ __global__ __launch_bounds__(GN_THREADS) void gn_bwd_sums_kernel(int c, int hw, 
     const float a = rstd[row] * gamma[ch];
     const float bb = beta[ch] - mean[row] * a;
     const size_t base = ((size_t)b * c + ch) * hw;
-    const float *px = x + base, *pd = dy + base;
+    const AT *px = x + base, *pd = dy + base;
     double s = 0.0, sb = 0.0;
-    if ((hw & 3) == 0 && (((uintptr_t)px | (uintptr_t)pd) & 15) == 0) {
+    if ((hw & 3) == 0 && (((uintptr_t)px | (uintptr_t)pd) & ogc_act_mask<AT>()) == 0) {
         for (int i = (blockIdx.x * GN_THREADS + threadIdx.x) * 4; i < hw; i += gridDim.x * GN_THREADS * 4) {
-            const float4 v = *reinterpret_cast<const float4 *>(px + i);
-            float4 d = *reinterpret_cast<const float4 *>(pd + i);
+            const float4 v = ogc_ld4(px + i);
+            float4 d = ogc_ld4(pd + i);
             if (RELU) {
                 d.x = fmaf(a, v.x, bb) > 0.f ? d.x : 0.f; d.y = fmaf(a, v.y, bb) > 0.f ? d.y : 0.f;
                 d.z = fmaf(a, v.z, bb) > 0.f ? d.z : 0.f; d.w = fmaf(a, v.w, bb) > 0.f ? d.w : 0.f;
@@ -178,8 +180,8 @@ __global__ __launch_bounds__(GN_THREADS) void gn_bwd_sums_kernel(int c, int hw, 
         }
     } else {
         for (int i = blockIdx.x * GN_THREADS + threadIdx.x; i < hw; i += gridDim.x * GN_THREADS) {
-            const float v = px[i];
-            float d = pd[i];
+            const float v = ogc_ld1(px + i);
+            float d = ogc_ld1(pd + i);
             if (RELU) d = fmaf(a, v, bb) > 0.f ? d : 0.f;
             s += (double)d * v;
             sb += d;
@@ -243,15 +245,15 @@ __device__ __forceinline__ void gn_bwd_prologue(int c, int groups, double n_grou
     }
 }
 
-template <bool RELU>
+template <bool RELU, typename AT = float>
 __global__ __launch_bounds__(GN_THREADS) void gn_bwd_dx_kernel(int c, int hw, int groups,
-                                                               const float *__restrict__ x,
+                                                               const AT *__restrict__ x,
                                                                const float *__restrict__ gamma,
                                                                const float *__restrict__ beta,
                                                                const float *__restrict__ mean,
                                                                const float *__restrict__ rstd,
                                                                const double *__restrict__ dsdb, int slots,
-                                                               const float *__restrict__ dy, float *__restrict__ dx,
+                                                               const AT *__restrict__ dy, AT *__restrict__ dx,
                                                                float *__restrict__ dgamma, float *__restrict__ dbeta) {
     const int b = blockIdx.z, ch = blockIdx.y;
     const int cg = c / groups, row = b * groups + ch / cg;
@@ -261,12 +263,12 @@ __global__ __launch_bounds__(GN_THREADS) void gn_bwd_dx_kernel(int c, int hw, in
     float c2, c3;
     gn_bwd_prologue(c, groups, (double)cg * hw, slots, gamma, mean, rstd, dsdb, dgamma, dbeta, c2, c3);
     const size_t base = ((size_t)b * c + ch) * hw;
-    const float *px = x + base, *pd = dy + base;
-    float *po = dx + base;
-    if ((hw & 3) == 0 && (((uintptr_t)px | (uintptr_t)pd | (uintptr_t)po) & 15) == 0) {
+    const AT *px = x + base, *pd = dy + base;
+    AT *po = dx + base;
+    if ((hw & 3) == 0 && (((uintptr_t)px | (uintptr_t)pd | (uintptr_t)po) & ogc_act_mask<AT>()) == 0) {
         for (int i = (blockIdx.x * GN_THREADS + threadIdx.x) * 4; i < hw; i += gridDim.x * GN_THREADS * 4) {
-            const float4 v = *reinterpret_cast<const float4 *>(px + i);
-            float4 d = *reinterpret_cast<const float4 *>(pd + i);
+            const float4 v = ogc_ld4(px + i);
+            float4 d = ogc_ld4(pd + i);
             if (RELU) {
                 d.x = fmaf(a, v.x, bb) > 0.f ? d.x : 0.f; d.y = fmaf(a, v.y, bb) > 0.f ? d.y : 0.f;
                 d.z = fmaf(a, v.z, bb) > 0.f ? d.z : 0.f; d.w = fmaf(a, v.w, bb) > 0.f ? d.w : 0.f;
@@ -274,14 +276,16 @@ __global__ __launch_bounds__(GN_THREADS) void gn_bwd_dx_kernel(int c, int hw, in
             float4 o;
             o.x = fmaf(a, d.x, fmaf(c2, v.x, c3)); o.y = fmaf(a, d.y, fmaf(c2, v.y, c3));
             o.z = fmaf(a, d.z, fmaf(c2, v.z, c3)); o.w = fmaf(a, d.w, fmaf(c2, v.w, c3));
-            *reinterpret_cast<float4 *>(po + i) = o;
+            ogc_st4(po + i, o);
         }
     } else {
-        for (int i = blockIdx.x * GN_THREADS + threadIdx.x; i < hw; i += gridDim.x * GN_THREADS) {
-            const float v = px[i];
-            float d = pd[i];
-            if (RELU) d = fmaf(a, v, bb) > 0.f ? d : 0.f;
-            po[i] = fmaf(a, d, fmaf(c2, v, c3));
+        if constexpr (sizeof(AT) == 4) { // (16-bit tensors: the entry point insists on the vector path)
+            for (int i = blockIdx.x * GN_THREADS + threadIdx.x; i < hw; i += gridDim.x * GN_THREADS) {
+                const float v = px[i];
+                float d = pd[i];
+                if (RELU) d = fmaf(a, v, bb) > 0.f ? d : 0.f;
+                po[i] = fmaf(a, d, fmaf(c2, v, c3));
+            }
         }
     }
 }
@@ -382,9 +386,9 @@ __global__ __launch_bounds__(GN_THREADS) void gn_pool_extremes_kernel(int c, int
 }
 
 // grid (chunks over P, C, B): ds, db from the sparse gradient (non-zero only at the arg-max element)
-template <bool RELU>
+template <bool RELU, typename XT = float>
 __global__ __launch_bounds__(GN_THREADS) void gn_maxpool_bwd_sums_kernel(int c, int p, int s,
-                                                                         const float *__restrict__ x,
+                                                                         const XT *__restrict__ x,
                                                                          const float *__restrict__ out,
                                                                          const int *__restrict__ arg,
                                                                          const float *__restrict__ gout,
@@ -403,7 +407,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_maxpool_bwd_sums_kernel(int c, 
         float g = gout[base + pr];
         if (RELU && !(out[base + pr] > 0.f)) g = 0.f;
         // (the gather costs a 32-byte sector per element: 50 us at C4's widths against 5 when the forward pass kept the values)
-        ds += (double)g * (double)(xext ? xext[base + pr] : x[(base + pr) * s + arg[base + pr]]);
+        ds += (double)g * (double)(xext ? xext[base + pr] : ogc_ld1(x + (base + pr) * s + arg[base + pr]));
         db += g;
     }
     gn_block_sum2(ds, db, smem);
@@ -603,12 +607,17 @@ extern "C" int ogc_group_norm_fwd_stats(int b, int c, int hw, int groups, float 
                        stats, slots, stream);
 }
 
-extern "C" int ogc_group_norm_bwd(int b, int c, int hw, int groups, int relu, const float *x, const float *gamma,
-                                  const float *beta, const float *mean, const float *rstd, const float *grad_y,
-                                  float *grad_x, float *grad_gamma, float *grad_beta, double *ws,
-                                  ogc_stream_t stream) {
+namespace {
+template <typename AT>
+int gn_bwd_impl(int b, int c, int hw, int groups, int relu, const AT *x, const float *gamma, const float *beta, const float *mean,
+                const float *rstd, const AT *grad_y, AT *grad_x, float *grad_gamma, float *grad_beta, double *ws,
+                ogc_stream_t stream) {
     OGC_REQUIRE(b >= 0 && c >= 1 && hw >= 1 && groups >= 1 && c % groups == 0, "ogc_group_norm_bwd: bad shape");
     if (b == 0) return OGC_OK;
+    if (sizeof(AT) == 2 && ((hw & 3) != 0 || (((uintptr_t)x | (uintptr_t)grad_y | (uintptr_t)grad_x) & 7) != 0)) {
+        ogc_set_error("ogc_group_norm_bwd_h: needs hw %% 4 == 0 and 8-byte aligned tensors");
+        return OGC_ERR_UNSUPPORTED;
+    }
     OGC_REQUIRE(x && gamma && beta && mean && rstd && grad_y && grad_x && grad_gamma && grad_beta && ws,
                 "ogc_group_norm_bwd: null pointer");
     hipStream_t s = (hipStream_t)stream;
@@ -618,18 +627,33 @@ extern "C" int ogc_group_norm_bwd(int b, int c, int hw, int groups, int relu, co
     dim3 grid(hw_chunks(b, c, hw), c, b);
     const int slots = (int)grid.x;
     if (relu) {
-        hipLaunchKernelGGL(gn_bwd_sums_kernel<true>, grid, dim3(GN_THREADS), 0, s, c, hw, groups, x, gamma, beta, mean,
+        hipLaunchKernelGGL((gn_bwd_sums_kernel<true, AT>), grid, dim3(GN_THREADS), 0, s, c, hw, groups, x, gamma, beta, mean,
                            rstd, grad_y, dsdb);
-        hipLaunchKernelGGL(gn_bwd_dx_kernel<true>, grid, dim3(GN_THREADS), 0, s, c, hw, groups, x, gamma, beta, mean,
+        hipLaunchKernelGGL((gn_bwd_dx_kernel<true, AT>), grid, dim3(GN_THREADS), 0, s, c, hw, groups, x, gamma, beta, mean,
                            rstd, dsdb, slots, grad_y, grad_x, grad_gamma, grad_beta);
     } else {
-        hipLaunchKernelGGL(gn_bwd_sums_kernel<false>, grid, dim3(GN_THREADS), 0, s, c, hw, groups, x, gamma, beta, mean,
+        hipLaunchKernelGGL((gn_bwd_sums_kernel<false, AT>), grid, dim3(GN_THREADS), 0, s, c, hw, groups, x, gamma, beta, mean,
                            rstd, grad_y, dsdb);
-        hipLaunchKernelGGL(gn_bwd_dx_kernel<false>, grid, dim3(GN_THREADS), 0, s, c, hw, groups, x, gamma, beta, mean,
+        hipLaunchKernelGGL((gn_bwd_dx_kernel<false, AT>), grid, dim3(GN_THREADS), 0, s, c, hw, groups, x, gamma, beta, mean,
                            rstd, dsdb, slots, grad_y, grad_x, grad_gamma, grad_beta);
     }
     OGC_CHECK_LAUNCH("ogc_group_norm_bwd");
     return OGC_OK;
+}
+} // namespace
+
+extern "C" int ogc_group_norm_bwd(int b, int c, int hw, int groups, int relu, const float *x, const float *gamma,
+                                  const float *beta, const float *mean, const float *rstd, const float *grad_y,
+                                  float *grad_x, float *grad_gamma, float *grad_beta, double *ws,
+                                  ogc_stream_t stream) {
+    return gn_bwd_impl<float>(b, c, hw, groups, relu, x, gamma, beta, mean, rstd, grad_y, grad_x, grad_gamma, grad_beta, ws, stream);
+}
+
+extern "C" int ogc_group_norm_bwd_h(int b, int c, int hw, int groups, int relu, const ogc_bf16_t *x, const float *gamma,
+                                    const float *beta, const float *mean, const float *rstd, const ogc_bf16_t *grad_y,
+                                    ogc_bf16_t *grad_x, float *grad_gamma, float *grad_beta, double *ws,
+                                    ogc_stream_t stream) {
+    return gn_bwd_impl<ogc_bf16>(b, c, hw, groups, relu, x, gamma, beta, mean, rstd, grad_y, grad_x, grad_gamma, grad_beta, ws, stream);
 }
 
 static bool gn_pool_shape_ok(int s) { return s >= 4 && s <= 256 && (s & (s - 1)) == 0; }
@@ -764,11 +788,12 @@ extern "C" int ogc_group_norm_maxpool_bwd_ext(int b, int c, int p, int s, int gr
 // ogc_group_norm_maxpool_bwd without the dense result: coef2 (B, C, 2) and inj (B, C, P, 2) from which
 // ogc_conv1x1_wgrad_moments_pooled / ogc_conv1x1_dgrad_adjoint_pooled rebuild grad_x element by element (same expression,
 // same bits) while they load x.
-extern "C" int ogc_group_norm_maxpool_bwd_sparse(int b, int c, int p, int s, int groups, int relu, const float *x,
-                                                 const float *x_at_argmax, const float *gamma, const float *mean, const float *rstd,
-                                                 const float *out, const int *argmax, const float *grad_out, float *coef2,
-                                                 float *inj, float *grad_gamma, float *grad_beta, double *ws,
-                                                 ogc_stream_t stream) {
+namespace {
+template <typename XT>
+int gn_maxpool_bwd_sparse_impl(int b, int c, int p, int s, int groups, int relu, const XT *x, const float *x_at_argmax,
+                               const float *gamma, const float *mean, const float *rstd, const float *out, const int *argmax,
+                               const float *grad_out, float *coef2, float *inj, float *grad_gamma, float *grad_beta, double *ws,
+                               ogc_stream_t stream) {
     OGC_REQUIRE(b >= 0 && c >= 1 && p >= 1 && groups >= 1 && c % groups == 0, "ogc_group_norm_maxpool_bwd_sparse: bad shape");
     if (!gn_pool_shape_ok(s) || (((uintptr_t)coef2 | (uintptr_t)inj) & 7) != 0) {
         ogc_set_error("ogc_group_norm_maxpool_bwd_sparse: unsupported nsample=%d or misaligned tensors", s);
@@ -789,16 +814,36 @@ extern "C" int ogc_group_norm_maxpool_bwd_sparse(int b, int c, int p, int s, int
     dim3 grid(bx, c, b);
     float2 *c2 = reinterpret_cast<float2 *>(coef2), *ij = reinterpret_cast<float2 *>(inj);
     if (relu) {
-        hipLaunchKernelGGL(gn_maxpool_bwd_sums_kernel<true>, gsum, dim3(GN_THREADS), 0, st, c, p, s, x, out, argmax,
+        hipLaunchKernelGGL((gn_maxpool_bwd_sums_kernel<true, XT>), gsum, dim3(GN_THREADS), 0, st, c, p, s, x, out, argmax,
                            grad_out, x_at_argmax, gamma, rstd, groups, dsdb);
         hipLaunchKernelGGL(gn_maxpool_bwd_sparse_kernel<true>, grid, dim3(GN_THREADS), 0, st, c, p, s, groups, gamma, mean,
                            rstd, dsdb, slots, out, argmax, grad_out, c2, ij, grad_gamma, grad_beta);
     } else {
-        hipLaunchKernelGGL(gn_maxpool_bwd_sums_kernel<false>, gsum, dim3(GN_THREADS), 0, st, c, p, s, x, out, argmax,
+        hipLaunchKernelGGL((gn_maxpool_bwd_sums_kernel<false, XT>), gsum, dim3(GN_THREADS), 0, st, c, p, s, x, out, argmax,
                            grad_out, x_at_argmax, gamma, rstd, groups, dsdb);
         hipLaunchKernelGGL(gn_maxpool_bwd_sparse_kernel<false>, grid, dim3(GN_THREADS), 0, st, c, p, s, groups, gamma, mean,
                            rstd, dsdb, slots, out, argmax, grad_out, c2, ij, grad_gamma, grad_beta);
     }
     OGC_CHECK_LAUNCH("ogc_group_norm_maxpool_bwd_sparse");
     return OGC_OK;
+}
+} // namespace
+
+extern "C" int ogc_group_norm_maxpool_bwd_sparse(int b, int c, int p, int s, int groups, int relu, const float *x,
+                                                 const float *x_at_argmax, const float *gamma, const float *mean, const float *rstd,
+                                                 const float *out, const int *argmax, const float *grad_out, float *coef2,
+                                                 float *inj, float *grad_gamma, float *grad_beta, double *ws,
+                                                 ogc_stream_t stream) {
+    return gn_maxpool_bwd_sparse_impl<float>(b, c, p, s, groups, relu, x, x_at_argmax, gamma, mean, rstd, out, argmax, grad_out,
+                                             coef2, inj, grad_gamma, grad_beta, ws, stream);
+}
+
+// (x in 16 bits; x_at_argmax stays fp32: the rounded extremes ogc_conv1x1_gemm_affine_pool_h wrote)
+extern "C" int ogc_group_norm_maxpool_bwd_sparse_h(int b, int c, int p, int s, int groups, int relu, const ogc_bf16_t *x,
+                                                   const float *x_at_argmax, const float *gamma, const float *mean,
+                                                   const float *rstd, const float *out, const int *argmax, const float *grad_out,
+                                                   float *coef2, float *inj, float *grad_gamma, float *grad_beta, double *ws,
+                                                   ogc_stream_t stream) {
+    return gn_maxpool_bwd_sparse_impl<ogc_bf16>(b, c, p, s, groups, relu, x, x_at_argmax, gamma, mean, rstd, out, argmax, grad_out,
+                                                coef2, inj, grad_gamma, grad_beta, ws, stream);
 }

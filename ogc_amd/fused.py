@@ -21,6 +21,31 @@ from .utils.zero_arena import zeroed_empty  # buffers an operator zeroes before 
 
 GATE_MISSES = _collections.Counter()
 
+# ---- 16-bit activations ------------------------------------------------------------------------------------------------------
+# Under `matmul_precision: bf16` the raw convolution outputs inside a set-abstraction MLP, and the gradients with respect to
+# them, are STORED as bf16 (csrc/act_io.h; the `_h` entry points of include/ogc_ops.h): those tensors are the only ones of the
+# size of an activation, every kernel that touches one is bound by its bytes, and nothing else changes type — statistics fp64,
+# coefficients / pooled outputs / parameters / their gradients fp32, coordinates and searches fp32.  The tensor's dtype carries
+# the decision from the first layer (grouped_first_layer(act16=True)) through the stack: every later node allocates what it
+# was given.  OGC_ACT16=0: fp32 activations with bf16 operands only (rounds 2-4), for A/B runs.
+ACT16 = __import__("os").environ.get("OGC_ACT16", "1") != "0"
+
+
+def act16_wanted(t):
+    """Should a set-abstraction MLP fed from tensor `t` keep its activations in 16 bits?"""
+    return (ACT16 and t is not None and t.is_cuda and getattr(_api._native, "get_matmul_precision", None) is not None
+            and _api._native.get_matmul_precision() == "bf16")
+
+
+def act16_leave(y):
+    """A 16-bit activation handed to a path that has no 16-bit form: widen it (counted: tests pin the set of such exits)."""
+    GATE_MISSES["act16_leave"] += 1
+    return y.float()
+
+
+def _is_act(t):
+    return t.dtype in (torch.float32, torch.bfloat16)
+
 
 def _gate(fn):
     @_functools.wraps(fn)
@@ -767,7 +792,7 @@ def _norm_act_conv_forward(y_prev, stats_prev, gn_weight, gn_bias, conv_weight, 
     else:
         ws = nat.group_norm_ws(B, cin, gn_groups, False, dev)
         nat.group_norm_coeffs_wrapper(B, cin, hw, gn_groups, eps, y_prev, gamma, beta, None, 0, ws, mean, rstd, a, bb)
-    y = torch.empty((B, cout) + tuple(y_prev.shape[2:]), dtype=torch.float32, device=dev)
+    y = torch.empty((B, cout) + tuple(y_prev.shape[2:]), dtype=y_prev.dtype, device=dev)
     w = conv_weight.contiguous()
     stats = extremes = None
     if (next_groups > 0 and next_groups <= 32 and cout % next_groups == 0 and (cout // next_groups) % 4 == 0
@@ -846,7 +871,7 @@ class _NormActConv(Function):
             return grad_prev, None, gw, gb, grad_w.view_as(conv_weight), None, None, None, None, None, None
         nat.conv1x1_wgrad_affine_wrapper(B, cin, cout, hw, relu, y_prev, a, bb, grad_y, grad_w)
         # gradient w.r.t. the (never stored) normalised activation, then through GroupNorm (+ ReLU)
-        if _gemm_ok(cout, hw) and _plain_gemm_mine(cout, (B, cin, hw)):
+        if y_prev.dtype is torch.bfloat16 or (_gemm_ok(cout, hw) and _plain_gemm_mine(cout, (B, cin, hw))):
             grad_z = torch.empty_like(y_prev)
             nat.conv1x1_gemm_wrapper(B, cin, cout, hw, 1, w, grad_y, grad_z)
         else:
@@ -862,13 +887,21 @@ class _NormActConv(Function):
 @_gate
 def norm_act_conv_available(y_prev, gn, conv):
     """Can conv(act(gn(y_prev))) run with the norm folded into the convolution's operand load?"""
-    if not (y_prev.is_cuda and y_prev.dtype == torch.float32 and gn.affine and conv.bias is None and conv.groups == 1
+    if not (y_prev.is_cuda and _is_act(y_prev) and gn.affine and conv.bias is None and conv.groups == 1
             and all(k == 1 for k in conv.kernel_size) and all(v == 1 for v in conv.stride)
             and all(v == 0 for v in conv.padding)
             and getattr(_api._native, "conv1x1_gemm_affine_wrapper", None) is not None):
         return False
     hw = y_prev.numel() // max(y_prev.shape[0] * y_prev.shape[1], 1)
+    if y_prev.dtype is torch.bfloat16 and _api._native.get_matmul_precision() != "bf16":
+        return False   # (the 16-bit forms come with bf16 operands)
     return _gemm_ok(y_prev.shape[1], hw)
+
+
+def act16_middle_ok(y_prev, gn, conv):
+    """May a MIDDLE layer of a shared MLP take a 16-bit y_prev?  (_NormActConv: beyond the moment-matrix widths its input
+    gradient is the tile kernel's, which holds <= 160 reduction channels.)"""
+    return norm_act_conv_available(y_prev, gn, conv) and conv.weight.shape[0] <= 160
 
 
 def norm_act_conv(y_prev, stats_prev, gn, relu, conv, next_gn=None, pool=0):
@@ -1247,7 +1280,7 @@ class _GroupedFirstLayer(Function):
     d features and d W_f; d W_xyz is a weight gradient with three input channels."""
 
     @staticmethod
-    def forward(ctx, xyz, new_xyz, features, idx, weight, gn_groups, rev_start=None, rev_pos=None, rev_heads=None):
+    def forward(ctx, xyz, new_xyz, features, idx, weight, gn_groups, rev_start=None, rev_pos=None, rev_heads=None, act16=False):
         nat = _api._native
         ctx.set_materialize_grads(False)
         ctx.rev = (rev_start, rev_pos, rev_heads) if rev_start is not None else None
@@ -1259,7 +1292,7 @@ class _GroupedFirstLayer(Function):
         rel = torch.empty(B, 3, npoint, nsample, dtype=torch.float32, device=xyz.device)
         nat.group_concat_wrapper(B, 0, N, npoint, nsample, xyz, new_xyz, None, idx, rel)
         P = _product(wf, features.detach(), False)                                  # (B, M, N)
-        y = torch.empty(B, M, npoint, nsample, dtype=torch.float32, device=xyz.device)
+        y = torch.empty(B, M, npoint, nsample, dtype=torch.bfloat16 if act16 else torch.float32, device=xyz.device)
         stats = None
         if gn_groups > 0:
             stats = zeroed_empty(nat.conv1x1_gn_slots() * B * gn_groups * 2, torch.float64, xyz.device)
@@ -1272,7 +1305,7 @@ class _GroupedFirstLayer(Function):
     @staticmethod
     def backward(ctx, grad_y, _grad_stats=None):
         if grad_y is None:
-            return (None,) * 9
+            return (None,) * 10
         nat = _api._native
         features, idx, rel, weight = ctx.saved_tensors
         B, C, N = features.shape
@@ -1284,6 +1317,8 @@ class _GroupedFirstLayer(Function):
         # the gather wins where lists are long and planes many (C4: SA2, SA3: 0.50 -> 0.13 ms, 0.33 -> 0.07); with ~16 entries
         # per point (SA1: 8192 points) the per-chunk list headers cost as much as the data and the atomic kernel stays
         gather = ctx.rev is not None and GROUP_GRAD_GATHER and T >= GROUP_GRAD_GATHER_MIN_FANIN * N and B * M >= 256
+        if grad_y.dtype is torch.bfloat16 and not gather:
+            grad_y = act16_leave(grad_y)   # (the scatter forms read fp32)
         one_pass = not gather and ctx.needs_input_grad[4] and N <= 16384 and T >= 4096 and T % 16 == 0
         if gather:
             # dP as a gather over the transposed neighbour lists of the geometry plan: no atomics, no zero fill; the three
@@ -1307,7 +1342,7 @@ class _GroupedFirstLayer(Function):
                 nat.conv1x1_wgrad_wrapper(B, 3, M, T, rel, grad_y, dwx)
             dwf = _weight_grad(dP, features.detach())
             grad_w = torch.cat([dwx, dwf], 1).view_as(weight)
-        return None, None, grad_feat, None, grad_w, None, None, None, None
+        return None, None, grad_feat, None, grad_w, None, None, None, None, None
 
 
 @_gate
@@ -1324,8 +1359,11 @@ GROUP_GRAD_GATHER = True   # grouping gradient as a gather over transposed lists
 GROUP_GRAD_GATHER_MIN_FANIN = 24
 
 
-def grouped_first_layer(xyz, new_xyz, features, idx, conv, gn, rev=None):
-    """(conv(QueryAndGroup(...)), statistics for `gn`) — see _GroupedFirstLayer.  rev: group_reverse(idx, N) or None."""
+def grouped_first_layer(xyz, new_xyz, features, idx, conv, gn, rev=None, act16=False):
+    """(conv(QueryAndGroup(...)), statistics for `gn`) — see _GroupedFirstLayer.  rev: group_reverse(idx, N) or None.
+    act16: store the output as bf16 (see ACT16; only with statistics, i.e. a GroupNorm behind the layer)."""
     rev = rev if rev is not None else (None, None, None)
+    T = idx.shape[1] * idx.shape[2]
+    act16 = bool(act16 and gn is not None and gn.affine and T % 64 == 0 and act16_wanted(features))
     return _GroupedFirstLayer.apply(xyz.contiguous(), new_xyz.contiguous(), features.contiguous(), idx.int().contiguous(),
-                                    conv.weight, 0 if gn is None else gn.num_groups, rev[0], rev[1], rev[2])
+                                    conv.weight, 0 if gn is None else gn.num_groups, rev[0], rev[1], rev[2], act16)

@@ -39,6 +39,14 @@ def _f(t, name):
     return _check(t, torch.float32, name)
 
 
+def _acts(tensors, names):
+    """The activation tensors of one call — raw convolution outputs / their gradients, all fp32 or all bf16 — as
+    (entry-point suffix, pointers): "_h" selects the 16-bit form (include/ogc_ops.h "16-bit activations")."""
+    if tensors[0].dtype is torch.bfloat16:
+        return "_h", [_check(t, torch.bfloat16, n) for t, n in zip(tensors, names)]
+    return "", [_f(t, n) for t, n in zip(tensors, names)]
+
+
 def _i(t, name):
     return _check(t, torch.int32, name)
 
@@ -129,7 +137,8 @@ def group_reverse_wrapper(b, n, npoints, nsample, idx, rev_start, rev_pos, heads
 
 def group_points_grad_rev_wrapper(b, c, n, npoints, nsample, grad_out, rev_start, rev_pos, heads, grad_points):
     """grad_points (b, c, n) = gather-sum of grad_out (b, c, npoints, nsample) over the transposed lists; overwrites."""
-    _run("ogc_group_points_grad_rev", grad_out, b, c, n, npoints, nsample, _f(grad_out, "grad_out"),
+    h, (go,) = _acts((grad_out,), ("grad_out",))
+    _run("ogc_group_points_grad_rev" + h, grad_out, b, c, n, npoints, nsample, go,
          _i(rev_start, "rev_start"), _check(rev_pos, torch.int16, "rev_pos"), _check(heads, torch.int16, "heads"),
          _f(grad_points, "grad_points"))
     return 1
@@ -313,8 +322,9 @@ def group_concat_grad_wrapper(b, c, n, npoints, nsample, grad_out, idx, grad_poi
 def group_linear_fwd_wrapper(b, m, n, npoints, nsample, groups, P, idx, rel, wx, y, stats):
     """y = P[idx] + wx . rel — the first layer of a set-abstraction MLP without the grouped tensor (ogc_group_linear_fwd);
     stats: float64, conv1x1_gn_slots() * b * groups * 2 elements, or None with groups == 0."""
-    _run("ogc_group_linear_fwd", P, b, m, n, npoints, nsample, int(groups), _f(P, "P"), _i(idx, "idx"), _f(rel, "rel"),
-         _f(wx, "wx"), _f(y, "y"), _opt(stats, torch.float64, "stats"))
+    h, (yp,) = _acts((y,), ("y",))
+    _run("ogc_group_linear_fwd" + h, P, b, m, n, npoints, nsample, int(groups), _f(P, "P"), _i(idx, "idx"), _f(rel, "rel"),
+         _f(wx, "wx"), yp, _opt(stats, torch.float64, "stats"))
 
 
 def group_linear_bwd_wrapper(b, m, n, npoints, nsample, grad_y, idx, rel, grad_p, dwx):
@@ -396,8 +406,9 @@ def group_norm_fwd_wrapper(b, c, hw, groups, eps, relu, x, gamma, beta, y, mean,
 def group_norm_bwd_wrapper(b, c, hw, groups, relu, x, gamma, beta, mean, rstd, grad_y, grad_x, grad_gamma, grad_beta,
                            ws):
     """Fused GroupNorm(+ReLU) backward (ogc_group_norm_bwd); ws: float64 scratch of 2*b*c + b*groups elements."""
-    _run("ogc_group_norm_bwd", x, b, c, hw, groups, int(relu), _f(x, "x"), _f(gamma, "gamma"), _f(beta, "beta"),
-         _f(mean, "mean"), _f(rstd, "rstd"), _f(grad_y, "grad_y"), _f(grad_x, "grad_x"),
+    h, (xp, gyp, gxp) = _acts((x, grad_y, grad_x), ("x", "grad_y", "grad_x"))
+    _run("ogc_group_norm_bwd" + h, x, b, c, hw, groups, int(relu), xp, _f(gamma, "gamma"), _f(beta, "beta"),
+         _f(mean, "mean"), _f(rstd, "rstd"), gyp, gxp,
          _f(grad_gamma, "grad_gamma"), _f(grad_beta, "grad_beta"), _check(ws, torch.float64, "ws"))
 
 
@@ -426,6 +437,9 @@ def group_norm_maxpool_bwd_ext_wrapper(b, c, p, s, groups, relu, x, x_at_argmax,
 
 def conv1x1_wgrad_wrapper(b, cin, cout, hw, x, dy, dw):
     """dw[co, ci] = sum_{b,p} dy[b, co, p] x[b, ci, p] (ogc_conv1x1_wgrad); hw % 16 == 0."""
+    if dy.dtype is torch.bfloat16:   # x fp32 (relative coordinates), dy in 16 bits
+        _run("ogc_conv1x1_wgrad_xf_h", x, b, cin, cout, hw, _f(x, "x"), _check(dy, torch.bfloat16, "dy"), _f(dw, "dw"))
+        return
     _run("ogc_conv1x1_wgrad", x, b, cin, cout, hw, _f(x, "x"), _f(dy, "dy"), _f(dw, "dw"))
 
 
@@ -474,8 +488,9 @@ def group_norm_coeffs_wrapper(b, c, hw, groups, eps, x, gamma, beta, stats, slot
 
 def conv1x1_gemm_affine_wrapper(b, M, K, hw, relu, groups, w, inp, pa, pb, out, stats):
     """Forward conv on act(pa * in + pb), optionally with the output's GroupNorm statistics (ogc_conv1x1_gemm_affine)."""
-    _run("ogc_conv1x1_gemm_affine", inp, b, M, K, hw, int(relu), int(groups), _f(w, "w"), _f(inp, "in"), _f(pa, "pa"),
-         _f(pb, "pb"), _f(out, "out"), _opt(stats, torch.float64, "stats"))
+    h, (ip, op) = _acts((inp, out), ("in", "out"))
+    _run("ogc_conv1x1_gemm_affine" + h, inp, b, M, K, hw, int(relu), int(groups), _f(w, "w"), ip, _f(pa, "pa"),
+         _f(pb, "pb"), op, _opt(stats, torch.float64, "stats"))
 
 
 def conv1x1_gemm_affine_pool_wrapper(b, M, K, hw, relu, groups, nsample, w, inp, pa, pb, next_gamma, out, stats, yext,
@@ -483,8 +498,9 @@ def conv1x1_gemm_affine_pool_wrapper(b, M, K, hw, relu, groups, nsample, w, inp,
     """conv1x1_gemm_affine_wrapper with statistics, plus per neighbourhood the extreme of the raw output (largest where
     next_gamma >= 0, smallest where it is negative) and its neighbour index (ogc_conv1x1_gemm_affine_pool);
     hw = centres * nsample, nsample in {16, 32, 64}."""
-    _run("ogc_conv1x1_gemm_affine_pool", inp, b, M, K, hw, int(relu), int(groups), int(nsample), _f(w, "w"),
-         _f(inp, "in"), _f(pa, "pa"), _f(pb, "pb"), _f(next_gamma, "next_gamma"), _f(out, "out"),
+    h, (ip, op) = _acts((inp, out), ("in", "out"))
+    _run("ogc_conv1x1_gemm_affine_pool" + h, inp, b, M, K, hw, int(relu), int(groups), int(nsample), _f(w, "w"),
+         ip, _f(pa, "pa"), _f(pb, "pb"), _f(next_gamma, "next_gamma"), op,
          _check(stats, torch.float64, "stats"), _f(yext, "yext"), _i(aext, "aext"))
 
 
@@ -498,8 +514,8 @@ def group_norm_pool_extremes_wrapper(b, c, p, s, groups, eps, relu, yext, aext, 
 
 def conv1x1_wgrad_affine_wrapper(b, cin, cout, hw, relu, x, pa, pb, dy, dw):
     """Weight gradient with the operand act(pa * x + pb) recomputed on load (ogc_conv1x1_wgrad_affine)."""
-    _run("ogc_conv1x1_wgrad_affine", x, b, cin, cout, hw, int(relu), _f(x, "x"), _f(pa, "pa"), _f(pb, "pb"),
-         _f(dy, "dy"), _f(dw, "dw"))
+    h, (xp, dyp) = _acts((x, dy), ("x", "dy"))
+    _run("ogc_conv1x1_wgrad_affine" + h, x, b, cin, cout, hw, int(relu), xp, _f(pa, "pa"), _f(pb, "pb"), dyp, _f(dw, "dw"))
 
 
 def _rows(t, name):
@@ -534,8 +550,9 @@ def attention_bwd_wrapper(h, scale, q, k, v, out, prob, dout, dq, dk, dv):
 
 
 def conv1x1_wgrad_moments_wrapper(b, cin, cout, hw, relu, y_prev, pa, pb, grad_y, moments):
-    _run("ogc_conv1x1_wgrad_moments", y_prev, b, cin, cout, hw, int(relu), _f(y_prev, "y_prev"), _f(pa, "pa"), _f(pb, "pb"),
-         _f(grad_y, "grad_y"), _f(moments, "moments"))
+    h, (yp, gp) = _acts((y_prev, grad_y), ("y_prev", "grad_y"))
+    _run("ogc_conv1x1_wgrad_moments" + h, y_prev, b, cin, cout, hw, int(relu), yp, _f(pa, "pa"), _f(pb, "pb"), gp,
+         _f(moments, "moments"))
 
 
 def gn_moments_combine_wrapper(b, cin, cout, hw, groups, moments, w, pa, pb, mean, rstd, gamma, grad_w, coef, gw, gb):
@@ -545,15 +562,17 @@ def gn_moments_combine_wrapper(b, cin, cout, hw, groups, moments, w, pa, pb, mea
 
 
 def conv1x1_dgrad_adjoint_wrapper(b, cin, cout, hw, relu, w, grad_y, y_prev, pa, pb, coef, grad_prev):
-    _run("ogc_conv1x1_dgrad_adjoint", grad_y, b, cin, cout, hw, int(relu), _f(w, "w"), _f(grad_y, "grad_y"),
-         _f(y_prev, "y_prev"), _f(pa, "pa"), _f(pb, "pb"), _f(coef, "coef"), _f(grad_prev, "grad_prev"))
+    h, (gp, yp, op) = _acts((grad_y, y_prev, grad_prev), ("grad_y", "y_prev", "grad_prev"))
+    _run("ogc_conv1x1_dgrad_adjoint" + h, grad_y, b, cin, cout, hw, int(relu), _f(w, "w"), gp, yp, _f(pa, "pa"), _f(pb, "pb"),
+         _f(coef, "coef"), op)
 
 
 def group_norm_maxpool_bwd_sparse_wrapper(b, c, p, s, groups, relu, x, gamma, mean, rstd, out, argmax, grad_out, coef2, inj,
                                           grad_gamma, grad_beta, ws, x_at_argmax=None):
     """coef2 (b, c, 2), inj (b, c, p, 2): the gradient of the pooled GroupNorm w.r.t. x in sparse form
     (ogc_group_norm_maxpool_bwd_sparse)."""
-    _run("ogc_group_norm_maxpool_bwd_sparse", x, b, c, p, s, groups, int(relu), _f(x, "x"),
+    h, (xp,) = _acts((x,), ("x",))
+    _run("ogc_group_norm_maxpool_bwd_sparse" + h, x, b, c, p, s, groups, int(relu), xp,
          _opt(x_at_argmax, torch.float32, "x_at_argmax"), _f(gamma, "gamma"),
          _f(mean, "mean"), _f(rstd, "rstd"), _f(out, "out"), _i(argmax, "argmax"), _f(grad_out, "grad_out"),
          _f(coef2, "coef2"), _f(inj, "inj"), _f(grad_gamma, "grad_gamma"), _f(grad_beta, "grad_beta"),
@@ -561,14 +580,15 @@ def group_norm_maxpool_bwd_sparse_wrapper(b, c, p, s, groups, relu, x, gamma, me
 
 
 def conv1x1_wgrad_moments_pooled_wrapper(b, cin, cout, hw, relu, nsample, y_prev, pa, pb, y, coef2, inj, moments):
-    _run("ogc_conv1x1_wgrad_moments_pooled", y_prev, b, cin, cout, hw, int(relu), nsample, _f(y_prev, "y_prev"), _f(pa, "pa"),
-         _f(pb, "pb"), _f(y, "y"), _f(coef2, "coef2"), _f(inj, "inj"), _f(moments, "moments"))
+    h, (ypp, yp) = _acts((y_prev, y), ("y_prev", "y"))
+    _run("ogc_conv1x1_wgrad_moments_pooled" + h, y_prev, b, cin, cout, hw, int(relu), nsample, ypp, _f(pa, "pa"),
+         _f(pb, "pb"), yp, _f(coef2, "coef2"), _f(inj, "inj"), _f(moments, "moments"))
 
 
 def conv1x1_dgrad_adjoint_pooled_wrapper(b, cin, cout, hw, relu, nsample, w, y, coef2, inj, y_prev, pa, pb, coef, grad_prev):
-    _run("ogc_conv1x1_dgrad_adjoint_pooled", y, b, cin, cout, hw, int(relu), nsample, _f(w, "w"), _f(y, "y"),
-         _f(coef2, "coef2"), _f(inj, "inj"), _f(y_prev, "y_prev"), _f(pa, "pa"), _f(pb, "pb"), _f(coef, "coef"),
-         _f(grad_prev, "grad_prev"))
+    h, (yp, ypp, op) = _acts((y, y_prev, grad_prev), ("y", "y_prev", "grad_prev"))
+    _run("ogc_conv1x1_dgrad_adjoint_pooled" + h, y, b, cin, cout, hw, int(relu), nsample, _f(w, "w"), yp,
+         _f(coef2, "coef2"), _f(inj, "inj"), ypp, _f(pa, "pa"), _f(pb, "pb"), _f(coef, "coef"), op)
 
 
 def mlp_chain_pool_supported(c0, c1, c2, c3, nsample):
@@ -697,7 +717,8 @@ def group_norm_maxpool_fwd_stats_wrapper(b, c, p, s, groups, eps, relu, x, gamma
 
 def conv1x1_gemm_wrapper(b, M, K, hw, transpose_a, w, inp, out):
     """out[b, m, p] = sum_k A[m, k] in[b, k, p], A = w or w^T (ogc_conv1x1_gemm); hw % 64 == 0, K <= 160."""
-    _run("ogc_conv1x1_gemm", inp, b, M, K, hw, int(transpose_a), _f(w, "w"), _f(inp, "in"), _f(out, "out"))
+    h, (ip, op) = _acts((inp, out), ("in", "out"))
+    _run("ogc_conv1x1_gemm" + h, inp, b, M, K, hw, int(transpose_a), _f(w, "w"), ip, op)
 
 
 def conv1x1_gemm_any_wrapper(b, M, K, hw, transpose_a, w, inp, out):
@@ -707,12 +728,13 @@ def conv1x1_gemm_any_wrapper(b, M, K, hw, transpose_a, w, inp, out):
 
 def conv1x1_wgrad_affine_pooled_wrapper(b, cin, cout, hw, relu, nsample, x, pa, pb, y, coef2, inj, dw):
     """ogc_conv1x1_wgrad_affine with dy in the sparse form (y, coef2, inj) of group_norm_maxpool_bwd_sparse_wrapper."""
-    _run("ogc_conv1x1_wgrad_affine_pooled", x, b, cin, cout, hw, int(relu), nsample, _f(x, "x"), _f(pa, "pa"), _f(pb, "pb"),
-         _f(y, "y"), _f(coef2, "coef2"), _f(inj, "inj"), _f(dw, "dw"))
+    h, (xp, yp) = _acts((x, y), ("x", "y"))
+    _run("ogc_conv1x1_wgrad_affine_pooled" + h, x, b, cin, cout, hw, int(relu), nsample, xp, _f(pa, "pa"), _f(pb, "pb"),
+         yp, _f(coef2, "coef2"), _f(inj, "inj"), _f(dw, "dw"))
 
 
 def conv1x1_dgrad_pooled_wrapper(b, cin, cout, hw, nsample, w, y, coef2, inj, grad_z):
     """grad_z[b] = w^T . g_y[b] with g_y rebuilt from (y, coef2, inj) on load (ogc_conv1x1_dgrad_pooled)."""
-    _run("ogc_conv1x1_dgrad_pooled", y, b, cin, cout, hw, nsample, _f(w, "w"), _f(y, "y"), _f(coef2, "coef2"), _f(inj, "inj"),
-         _f(grad_z, "grad_z"))
+    h, (yp, gp) = _acts((y, grad_z), ("y", "grad_z"))
+    _run("ogc_conv1x1_dgrad_pooled" + h, y, b, cin, cout, hw, nsample, _f(w, "w"), yp, _f(coef2, "coef2"), _f(inj, "inj"), gp)
 

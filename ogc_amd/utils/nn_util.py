@@ -173,13 +173,16 @@ def _shared_mlp_run(self, x, pool, first=None):
     last layer's norm / activation (/ max over the neighbourhood, `pool`) is one fused op.
     first: optional callable (conv, gn) -> (raw output, statistics) that evaluates the FIRST layer's convolution (a set-
     abstraction level fuses it with the grouping, fused.grouped_first_layer); `x` is then unused."""
-    from ..fused import (group_norm_act, group_norm_act_maxpool, norm_act_conv, norm_act_conv_available,
+    from ..fused import (act16_middle_ok, group_norm_act, group_norm_act_maxpool, norm_act_conv, norm_act_conv_available,
                          norm_act_conv_pool, norm_act_conv_pool_available, pointwise_conv)
     layers = list(self.children())
     pending = None  # (raw conv output, its GroupNorm statistics or None, the GroupNorm, relu?, neighbourhood extremes)
 
     def flush(p, last):
         y, stats, gn, relu, extremes = p
+        if y.dtype is torch.bfloat16:   # (no materialising GroupNorm of a 16-bit tensor: widen; counted in GATE_MISSES)
+            from ..fused import act16_leave
+            y, extremes = act16_leave(y), None
         if last and pool:
             return group_norm_act_maxpool(y, gn, relu, stats, extremes)
         return group_norm_act(y, gn, relu, stats)
@@ -194,6 +197,15 @@ def _shared_mlp_run(self, x, pool, first=None):
         conv_name, norm_name, relu = layer._names
         conv, gn = getattr(layer, conv_name), getattr(layer, norm_name)[0]
         extremes = None
+        if pending is not None and pending[0].dtype is torch.bfloat16:
+            # 16-bit activations continue only through the fused forms that have a 16-bit kernel: a middle layer through
+            # norm_act_conv, the pooled tail through the one-node norm_act_conv_pool; anything else widens first
+            tail = pool and li == len(layers) - 1
+            ok = (norm_act_conv_pool_available(pending[0], pending[2], conv, gn) if tail else
+                  (act16_middle_ok(pending[0], pending[2], conv) and li < len(layers) - 1))
+            if not ok:
+                from ..fused import act16_leave
+                pending = (act16_leave(pending[0]),) + tuple(pending[1:4]) + (None,)
         if pending is not None and norm_act_conv_available(pending[0], pending[2], conv):
             if pool and li == len(layers) - 1 and pending[0].dim() == 4 and pending[0].shape[-1] in (16, 32, 64):
                 # last layer before the max over the neighbourhood: the convolution also leaves each neighbourhood's

@@ -102,7 +102,8 @@ class _PointnetSAModuleBase(nn.Module):
                 if head is not None and grouped_first_layer_available(xyz, new_xyz, features, nn_idx, head[0], head[1]):
                     # grouping + first convolution without the (B, 3 + C, npoint, nsample) tensor in between
                     pooled.append(mlp.forward_maxpool(None, first=lambda conv, gn, j=nn_idx, rv=geometry["rev"][i]:
-                                                      grouped_first_layer(xyz, new_xyz, features, j, conv, gn, rv)))
+                                                      grouped_first_layer(xyz, new_xyz, features, j, conv, gn, rv,
+                                                                          act16=len(mlp) >= 2)))
                     continue
                 grouped = grouper(xyz, new_xyz, features, idx=nn_idx)[0]
             else:
