@@ -31,6 +31,20 @@ __device__ __forceinline__ uint2 ogc_pack4_bf16(const float4 &v) {
 __device__ __forceinline__ void ogc_st4(float *p, const float4 &v) { *reinterpret_cast<float4 *>(p) = v; }
 __device__ __forceinline__ void ogc_st4(ogc_bf16 *p, const float4 &v) { *reinterpret_cast<uint2 *>(p) = ogc_pack4_bf16(v); }
 
+// four fp32 -> four bf16 MFMA operand values as two explicit v_cvt_pk_bf16_f32 (the vector conversion of ogc_pack_bf16 can leave
+// the arrays it reads from in scratch memory when it is used inside a lambda: gemm_chunk.hip, round 5).  The wait states an MFMA
+// needs before it reads a VGPR a VALU instruction has just written are INSIDE the asm: the compiler's hazard recogniser does not
+// look into an asm block, and without them the matrix pipe reads the operand before the conversion has landed (NaN rows).
+typedef short ogc_v4s_ __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ ogc_v4s_ ogc_pack_bf16_rr(float a, float b, float c, float d) {
+    typedef unsigned v2u_ __attribute__((ext_vector_type(2)));
+    unsigned lo, hi;
+    asm("v_cvt_pk_bf16_f32 %0, %2, %3\n\tv_cvt_pk_bf16_f32 %1, %4, %5\n\ts_nop 1"
+        : "=&v"(lo), "=&v"(hi)
+        : "v"(a), "v"(b), "v"(c), "v"(d));
+    return __builtin_bit_cast(ogc_v4s_, (v2u_){lo, hi});
+}
+
 // the value as it will read back from a tensor of element type T (statistics and extremes of an output are taken over what is
 // STORED, so that the norm that follows sees exactly the distribution its mean / rstd describe)
 template <typename T>

@@ -193,11 +193,188 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_wgrad_kernel(int b
     }
 }
 
+// ---- the register-tile weight gradient from 16-bit gradients ------------------------------------------------------------------
+// conv1x1_wgrad_kernel with dy stored as bf16 moves half the bytes and is no faster: per 16 positions it issues one load per row
+// block — sixteen rows x 32 bytes: the vector memory pipe works per row, not per byte — plus the per-row coefficient loads.  Here
+// a step is 32 positions: lane (i, k) loads row i, positions pb + 8 k .. 8 k + 7 (sixteen bytes of a bf16 tensor, two float4 of
+// an fp32 x), and a lane's eight positions are the k-slots of TWO v_mfma_f32_16x16x16_bf16 (bf16 operands only: the 16-bit entry
+// points require ogc_set_matmul_precision(1)).  PRO / POOLED as in conv1x1_wgrad_kernel, the same expressions.
+__device__ __forceinline__ void ogc_unpack8(const uint4 &u, float (&f)[8]) {
+    f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xFFFF0000u);
+    f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xFFFF0000u);
+    f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xFFFF0000u);
+    f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xFFFF0000u);
+}
+struct Raw8 { uint4 a, b; }; // eight positions as loaded: bf16 -> a; fp32 -> a, b
+__device__ __forceinline__ void ogc_ld8(const ogc_bf16 *p, Raw8 &r) { r.a = *reinterpret_cast<const uint4 *>(p); }
+__device__ __forceinline__ void ogc_ld8(const float *p, Raw8 &r) {
+    r.a = *reinterpret_cast<const uint4 *>(p);
+    r.b = *reinterpret_cast<const uint4 *>(p + 4);
+}
+template <typename T>
+__device__ __forceinline__ void ogc_widen8(const Raw8 &r, float (&f)[8]) {
+    if constexpr (sizeof(T) == 2) {
+        ogc_unpack8(r.a, f);
+    } else {
+        f[0] = __uint_as_float(r.a.x); f[1] = __uint_as_float(r.a.y); f[2] = __uint_as_float(r.a.z); f[3] = __uint_as_float(r.a.w);
+        f[4] = __uint_as_float(r.b.x); f[5] = __uint_as_float(r.b.y); f[6] = __uint_as_float(r.b.z); f[7] = __uint_as_float(r.b.w);
+    }
+}
+
+template <int COB, int CIB, bool PRO, bool POOLED, typename XT>
+__global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_wgrad16_kernel(int batch, int cin, int cout, int hw,
+                                                                             int steps_per_wave, const XT *__restrict__ x,
+                                                                             const ogc_bf16 *__restrict__ dy,
+                                                                             float *__restrict__ dw,
+                                                                             const float *__restrict__ aff_a,
+                                                                             const float *__restrict__ aff_b, int pro_relu,
+                                                                             const float2 *__restrict__ coef2,
+                                                                             const float2 *__restrict__ inj, int s_shift) {
+    __shared__ float red[WG_WAVES][COB * CIB * 256];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = lane & 15, k = lane >> 4;
+    const int co0 = blockIdx.y * (16 * COB), ci0 = blockIdx.z * (16 * CIB);
+    const int steps_per_img = hw >> 5;
+    const long long nsteps = (long long)batch * steps_per_img;
+    const long long first = ((long long)blockIdx.x * WG_WAVES + wave) * steps_per_wave;
+    const int mine = (int)max(0LL, min((long long)steps_per_wave, nsteps - first));
+
+    v4f acc[COB][CIB];
+#pragma unroll
+    for (int a = 0; a < COB; ++a)
+#pragma unroll
+        for (int c = 0; c < CIB; ++c) acc[a][c] = (v4f){0.f, 0.f, 0.f, 0.f};
+    const long long start = min(first, nsteps - 1);
+    int cur_b = (int)(start / steps_per_img);
+    int cur_off = (int)(start - (long long)cur_b * steps_per_img);
+    int left = mine - 1;
+    int yrow[COB], xrow[CIB], coef[CIB];
+    constexpr int NP = POOLED ? COB : 1;
+    int orow[NP];
+    const int centres = hw >> s_shift, smask = (1 << s_shift) - 1;
+#pragma unroll
+    for (int a = 0; a < COB; ++a) {
+        yrow[a] = min(co0 + a * 16 + i, cout - 1) * hw;
+        if (POOLED) orow[a] = min(co0 + a * 16 + i, cout - 1);
+    }
+#pragma unroll
+    for (int c = 0; c < CIB; ++c) {
+        coef[c] = min(ci0 + c * 16 + i, cin - 1);
+        xrow[c] = coef[c] * hw;
+    }
+    // (unconditional loads of one shape; the affine map and the sparse gradient's entries travel with the step: see
+    // conv1x1_wgrad_kernel)
+    auto load = [&](Raw8(&yv)[COB], Raw8(&xv)[CIB], float(&fa)[CIB], float(&fb)[CIB], float2(&cc)[NP], float2(&jv)[NP], int &jpos) {
+        const int pb = cur_off * 32 + 8 * k;
+        const ogc_bf16 *yb_ = dy + (size_t)cur_b * cout * hw + pb;
+        const XT *xb_ = x + (size_t)cur_b * cin * hw + pb;
+#pragma unroll
+        for (int a = 0; a < COB; ++a) ogc_ld8(yb_ + yrow[a], yv[a]);
+        if constexpr (POOLED) { // a lane's eight positions lie inside one neighbourhood (S >= 16)
+#pragma unroll
+            for (int a = 0; a < COB; ++a) {
+                const size_t r = (size_t)cur_b * cout + orow[a];
+                cc[a] = coef2[r];
+                jv[a] = inj[r * centres + (pb >> s_shift)];
+            }
+            jpos = pb & smask;
+        }
+#pragma unroll
+        for (int c = 0; c < CIB; ++c) {
+            ogc_ld8(xb_ + xrow[c], xv[c]);
+            if (PRO) {
+                fa[c] = aff_a[(size_t)cur_b * cin + coef[c]];
+                fb[c] = aff_b[(size_t)cur_b * cin + coef[c]];
+            }
+        }
+        if (left > 0) {
+            --left;
+            if (++cur_off == steps_per_img) { cur_off = 0; ++cur_b; }
+        }
+    };
+    auto fma32 = [&](const Raw8(&yraw)[COB], const Raw8(&xraw)[CIB], const float(&fa)[CIB], const float(&fb)[CIB],
+                     const float2(&cc)[NP], const float2(&jv)[NP], int jpos) {
+        v4s y0[COB], y1[COB], x0[CIB], x1[CIB];
+#pragma unroll
+        for (int a = 0; a < COB; ++a) {
+            if constexpr (POOLED) {
+                float f[8];
+                ogc_unpack8(yraw[a].a, f);
+                const int rel = __float_as_int(jv[a].y) - jpos;
+                const float ag = jv[a].x;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = fmaf(cc[a].x, f[e], cc[a].y) + (rel == e ? ag : 0.f);
+                y0[a] = ogc_pack_bf16_rr(f[0], f[1], f[2], f[3]);
+                y1[a] = ogc_pack_bf16_rr(f[4], f[5], f[6], f[7]);
+            } else { // dense gradient: the stored bits are the operand
+                y0[a] = __builtin_bit_cast(v4s, make_uint2(yraw[a].a.x, yraw[a].a.y));
+                y1[a] = __builtin_bit_cast(v4s, make_uint2(yraw[a].a.z, yraw[a].a.w));
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CIB; ++c) {
+            if constexpr (!PRO && sizeof(XT) == 2) {
+                x0[c] = __builtin_bit_cast(v4s, make_uint2(xraw[c].a.x, xraw[c].a.y));
+                x1[c] = __builtin_bit_cast(v4s, make_uint2(xraw[c].a.z, xraw[c].a.w));
+            } else {
+                float f[8];
+                ogc_widen8<XT>(xraw[c], f);
+                if (PRO) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        f[e] = fmaf(fa[c], f[e], fb[c]);
+                        if (pro_relu) f[e] = fmaxf(f[e], 0.f);
+                    }
+                }
+                x0[c] = ogc_pack_bf16_rr(f[0], f[1], f[2], f[3]);
+                x1[c] = ogc_pack_bf16_rr(f[4], f[5], f[6], f[7]);
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < COB; ++a)
+#pragma unroll
+            for (int c = 0; c < CIB; ++c) {
+                acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(y0[a], x0[c], acc[a][c], 0, 0, 0);
+                acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(y1[a], x1[c], acc[a][c], 0, 0, 0);
+            }
+    };
+
+    Raw8 ya[COB], xa[CIB], yb[COB], xb[CIB];
+    float faa[CIB], fba[CIB], fab[CIB], fbb[CIB];
+    float2 cca[NP], ccb[NP], jva[NP], jvb[NP];
+    int jpa = 0, jpb = 0;
+    load(ya, xa, faa, fba, cca, jva, jpa);
+    int s = 0;
+    for (; s + 1 < mine; s += 2) {
+        load(yb, xb, fab, fbb, ccb, jvb, jpb);
+        fma32(ya, xa, faa, fba, cca, jva, jpa);
+        load(ya, xa, faa, fba, cca, jva, jpa);
+        fma32(yb, xb, fab, fbb, ccb, jvb, jpb);
+    }
+    if (s < mine) fma32(ya, xa, faa, fba, cca, jva, jpa);
+
+#pragma unroll
+    for (int a = 0; a < COB; ++a)
+#pragma unroll
+        for (int c = 0; c < CIB; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave][(a * CIB + c) * 256 + (k * 4 + r) * 16 + i] = acc[a][c][r];
+    __syncthreads();
+    for (int t = threadIdx.x; t < COB * CIB * 256; t += WG_WAVES * OGC_WAVE) {
+        const int blk = t >> 8, a = blk / CIB, c = blk % CIB;
+        const int row = co0 + a * 16 + ((t & 255) >> 4), col = ci0 + c * 16 + (t & 15);
+        const float v = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+        if (row < cout && col < cin && v != 0.0f) unsafeAtomicAdd(dw + (size_t)row * cin + col, v);
+    }
+}
+
 template <int COB, int CIB, typename XT = float, typename YT = float>
 void wgrad_launch(int b, int cin, int cout, int hw, const XT *x, const YT *dy, float *dw, const float *pa,
                   const float *pb, int pro_relu, hipStream_t s, const float2 *coef2 = nullptr, const float2 *inj = nullptr,
                   int s_shift = 0) {
-    const long long nsteps = (long long)b * (hw >> 4);
+    constexpr bool Y16 = sizeof(YT) == 2;
+    const bool wide = Y16 && (hw & 31) == 0 && (((uintptr_t)x | (uintptr_t)dy) & 15) == 0; // 32-position steps
+    const long long nsteps = (long long)b * (wide ? hw >> 5 : hw >> 4);
     const int tiles = ogc_divup(cout, 16 * COB) * ogc_divup(cin, 16 * CIB);
     // ~2048 waves over the chip per tile pair, but at least 8 steps (128 positions) per wave
     // Wavefronts over the chip per tile pair.  The 64x64 tiles (COB = CIB = 4) run best with ~1024 wavefronts in total —
@@ -211,6 +388,18 @@ void wgrad_launch(int b, int cin, int cout, int hw, const XT *x, const YT *dy, f
     spw = (spw + 1) / 2 * 2;
     const int wgs = (int)((nsteps + spw * WG_WAVES - 1) / (spw * WG_WAVES));
     dim3 grid(wgs, ogc_divup(cout, 16 * COB), ogc_divup(cin, 16 * CIB));
+    if constexpr (Y16) {
+        if (wide) {
+#define OGC_WGRAD16(PROV, POOLV)                                                                                               \
+    hipLaunchKernelGGL((conv1x1_wgrad16_kernel<COB, CIB, PROV, POOLV, XT>), grid, dim3(WG_WAVES * OGC_WAVE), 0, s, b, cin, cout, hw, \
+                       (int)spw, x, dy, dw, pa, pb, pro_relu, coef2, inj, s_shift)
+            if (inj) OGC_WGRAD16(true, true);
+            else if (pa) OGC_WGRAD16(true, false);
+            else OGC_WGRAD16(false, false);
+#undef OGC_WGRAD16
+            return;
+        }
+    }
 #define OGC_WGRAD(PROV, BFV)                                                                                          \
     hipLaunchKernelGGL((conv1x1_wgrad_kernel<COB, CIB, PROV, BFV, false, XT, YT>), grid, dim3(WG_WAVES * OGC_WAVE), 0, s, b, cin, cout, \
                        hw, (int)spw, x, dy, dw, pa, pb, pro_relu)

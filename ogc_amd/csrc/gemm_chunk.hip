@@ -27,6 +27,9 @@ namespace {
 
 constexpr int GC_WAVES = 4;
 
+// (ogc_pack_bf16_rr of act_io.h: the union / vector-conversion form leaves this kernel's input chunks in scratch memory)
+__device__ __forceinline__ v4s gc_pack_bf16(float a, float b, float c, float d) { return ogc_pack_bf16_rr(a, b, c, d); }
+
 // POOLED: IN is not stored — `in` holds y, the raw output of the LAST convolution of a set-abstraction MLP, and the operand is the
 // gradient of the pooled GroupNorm that follows it, rebuilt while y is loaded (include/ogc_ops.h, ogc_group_norm_maxpool_bwd_sparse):
 //     IN[b, k, p] = fmaf(c2, y, c3) + (p % S == arg ? ag : 0),   (c2, c3) = coef2[b, k],   (ag, arg) = inj[b, k, p / S]
@@ -129,35 +132,33 @@ __global__ __launch_bounds__(GC_WAVES *OGC_WAVE, 2) void gemm_chunk_kernel(int M
     // issue slots, and the loop written twice (with and without it) spills.
     auto compute = [&](const float *a_lds, const float4(&xv)[KQ], int koff = 0) {
         if constexpr (BF) {
-            static_assert(!BF || KQ % 4 == 0, "bf16 operands: whole groups of four row quads");
-#pragma unroll
-            for (int g = 0; g < KQ / 4; ++g) {
-                const v4s bx = ogc_pack_bf16(xv[4 * g].x, xv[4 * g + 1].x, xv[4 * g + 2].x, xv[4 * g + 3].x);
-                const v4s by = ogc_pack_bf16(xv[4 * g].y, xv[4 * g + 1].y, xv[4 * g + 2].y, xv[4 * g + 3].y);
-                const v4s bz = ogc_pack_bf16(xv[4 * g].z, xv[4 * g + 1].z, xv[4 * g + 2].z, xv[4 * g + 3].z);
-                const v4s bw = ogc_pack_bf16(xv[4 * g].w, xv[4 * g + 1].w, xv[4 * g + 2].w, xv[4 * g + 3].w);
-#pragma unroll
-                for (int a = 0; a < RB; ++a) {
-                    const float *ar = a_lds + (wrow + a * 16 + j) * LD + koff + 16 * g + kk;
-                    const v4s av = ogc_pack_bf16(ar[0], ar[4], ar[8], ar[12]);
-                    acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, bx, acc[a][0], 0, 0, 0);
-                    acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, by, acc[a][1], 0, 0, 0);
-                    acc[a][2] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, bz, acc[a][2], 0, 0, 0);
-                    acc[a][3] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, bw, acc[a][3], 0, 0, 0);
-                }
-            }
-            return;
-        }
-#pragma unroll
-        for (int q = 0; q < KQ; ++q) {
-            const float bx = xv[q].x, by = xv[q].y, bz = xv[q].z, bw = xv[q].w;
+            static_assert(!BF || KQ == 4, "bf16 operands: one group of four row quads per input chunk");
+            const float4 v0 = xv[0], v1 = xv[1], v2 = xv[2], v3 = xv[3];
+            const v4s bx = gc_pack_bf16(v0.x, v1.x, v2.x, v3.x);
+            const v4s by = gc_pack_bf16(v0.y, v1.y, v2.y, v3.y);
+            const v4s bz = gc_pack_bf16(v0.z, v1.z, v2.z, v3.z);
+            const v4s bw = gc_pack_bf16(v0.w, v1.w, v2.w, v3.w);
+            const float *ar = a_lds + (wrow + j) * LD + koff + kk;
 #pragma unroll
             for (int a = 0; a < RB; ++a) {
-                const float av = a_lds[(wrow + a * 16 + j) * LD + koff + q * 4 + kk];
-                acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bx, acc[a][0], 0, 0, 0);
-                acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, by, acc[a][1], 0, 0, 0);
-                acc[a][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bz, acc[a][2], 0, 0, 0);
-                acc[a][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw, acc[a][3], 0, 0, 0);
+                const v4s av = gc_pack_bf16(ar[a * 16 * LD], ar[a * 16 * LD + 4], ar[a * 16 * LD + 8], ar[a * 16 * LD + 12]);
+                acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, bx, acc[a][0], 0, 0, 0);
+                acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, by, acc[a][1], 0, 0, 0);
+                acc[a][2] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, bz, acc[a][2], 0, 0, 0);
+                acc[a][3] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, bw, acc[a][3], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < KQ; ++q) {
+                const float bx = xv[q].x, by = xv[q].y, bz = xv[q].z, bw = xv[q].w;
+#pragma unroll
+                for (int a = 0; a < RB; ++a) {
+                    const float av = a_lds[(wrow + a * 16 + j) * LD + koff + q * 4 + kk];
+                    acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bx, acc[a][0], 0, 0, 0);
+                    acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, by, acc[a][1], 0, 0, 0);
+                    acc[a][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bz, acc[a][2], 0, 0, 0);
+                    acc[a][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw, acc[a][3], 0, 0, 0);
+                }
             }
         }
     };

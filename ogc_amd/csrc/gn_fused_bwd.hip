@@ -25,6 +25,8 @@
 #include "conv_stage.h"
 #include "act_io.h"
 
+extern int ogc_g_matmul_bf16; // (conv1x1.hip) operand precision switch
+
 namespace {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -182,10 +184,177 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void wgrad_moments_kernel(int c
     }
 }
 
+// ---- the moment matrices from 16-bit tensors --------------------------------------------------------------------------------
+// With x and dy stored as bf16 the kernel above moves half the bytes and is no faster: per 16 positions it still issues one load
+// per row block (16 rows x 32 bytes each: the vector memory pipe works per row, not per byte) and 128 fp32 MFMAs (0.44 ms of
+// matrix time for the 64 x 64 layers of C2's first level, twice what the halved bytes cost).  Here a step is 32 positions — lane
+// (i, k) loads SIXTEEN bytes: row i, positions pb + 8 k .. 8 k + 7 — and the products run on v_mfma_f32_16x16x16_bf16 (a lane's
+// four consecutive positions are the four k-slots of one MFMA, as in conv1x1_wgrad_kernel's bf16 form; two MFMAs per lane load).
+// Nothing is rounded that was not already: dy (dense form) is used as loaded, the mask is 0 / 1, mask . x is x or 0; only the
+// POOLED form rebuilds g_y in fp32 and rounds it (bf16 operands, as everywhere under ogc_set_matmul_precision(1)).
+typedef short v4s16 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void ogc_unpack8(const uint4 &u, float (&f)[8]) {
+    f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xFFFF0000u);
+    f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xFFFF0000u);
+    f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xFFFF0000u);
+    f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xFFFF0000u);
+}
+
+template <int COB, int CIB, bool POOLED>
+__global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void wgrad_moments16_kernel(int cin, int cout, int hw, int chunks,
+                                                                             int steps_per_wave, int relu,
+                                                                             const ogc_bf16 *__restrict__ x,   // y_prev (B, cin, hw)
+                                                                             const ogc_bf16 *__restrict__ dy,  // g_y or y (B, cout, hw)
+                                                                             const float *__restrict__ aff_a,
+                                                                             const float *__restrict__ aff_b,
+                                                                             const float2 *__restrict__ coef2, // (B, cout)
+                                                                             const float2 *__restrict__ inj,   // (B, cout, hw >> s_shift)
+                                                                             int s_shift,
+                                                                             float *__restrict__ hm) {         // (B, 2, cout, cin)
+    __shared__ float red[WG_WAVES][COB * CIB * 256];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = lane & 15, k = lane >> 4;
+    const int img = blockIdx.x / chunks, chunk = blockIdx.x - img * chunks;
+    const int co0 = blockIdx.y * (16 * COB), ci0 = blockIdx.z * (16 * CIB);
+    const int steps_per_img = hw >> 5;
+    const int first = (chunk * WG_WAVES + wave) * steps_per_wave;
+    const int mine = max(0, min(steps_per_wave, steps_per_img - first));
+
+    v4f acc1[COB][CIB], acc2[COB][CIB];
+#pragma unroll
+    for (int a = 0; a < COB; ++a)
+#pragma unroll
+        for (int c = 0; c < CIB; ++c) {
+            acc1[a][c] = (v4f){0.f, 0.f, 0.f, 0.f};
+            acc2[a][c] = (v4f){0.f, 0.f, 0.f, 0.f};
+        }
+    int yrow[COB], xrow[CIB], jrow[COB];
+    float ca[CIB], cb[CIB], pc2[COB], pc3[COB];
+    const int centres = hw >> s_shift, smask = (1 << s_shift) - 1;
+#pragma unroll
+    for (int a = 0; a < COB; ++a) {
+        const int row = min(co0 + a * 16 + i, cout - 1);
+        yrow[a] = row * hw;
+        if (POOLED) {
+            const float2 cc = coef2[(size_t)img * cout + row];
+            pc2[a] = cc.x;
+            pc3[a] = cc.y;
+            jrow[a] = row * centres;
+        }
+    }
+    const float2 *jb_ = POOLED ? inj + (size_t)img * cout * centres : nullptr;
+#pragma unroll
+    for (int c = 0; c < CIB; ++c) {
+        const int ch = min(ci0 + c * 16 + i, cin - 1);
+        xrow[c] = ch * hw;
+        ca[c] = aff_a[(size_t)img * cin + ch];
+        cb[c] = aff_b[(size_t)img * cin + ch];
+    }
+    const ogc_bf16 *yb_ = dy + (size_t)img * cout * hw + 8 * k;
+    const ogc_bf16 *xb_ = x + (size_t)img * cin * hw + 8 * k;
+    int cur = min(first, steps_per_img - 1);
+    const int stop = min(first + mine, steps_per_img) - 1;
+    // (unconditional loads of one shape, clamped rows and steps: see wgrad_moments_kernel)
+    auto load = [&](uint4(&yv)[COB], uint4(&xv)[CIB], float2(&jv)[COB], int &jpos) { // step `cur`, then advance
+        const int pb = cur * 32;
+#pragma unroll
+        for (int a = 0; a < COB; ++a) yv[a] = *reinterpret_cast<const uint4 *>(yb_ + yrow[a] + pb);
+#pragma unroll
+        for (int c = 0; c < CIB; ++c) xv[c] = *reinterpret_cast<const uint4 *>(xb_ + xrow[c] + pb);
+        if (POOLED) { // a lane's eight positions lie inside one neighbourhood (S >= 16)
+#pragma unroll
+            for (int a = 0; a < COB; ++a) jv[a] = jb_[jrow[a] + ((pb + 8 * k) >> s_shift)];
+            jpos = (pb + 8 * k) & smask;
+        }
+        cur = min(cur + 1, max(stop, 0));
+    };
+    auto fma32 = [&](const uint4(&yraw)[COB], const uint4(&xraw)[CIB], const float2(&jv)[COB], int jpos) {
+        v4s16 y0[COB], y1[COB];
+#pragma unroll
+        for (int a = 0; a < COB; ++a) {
+            if (POOLED) { // the expression of gn_maxpool_bwd_dx_kernel on the stored y, rounded to the operand precision
+                float f[8];
+                ogc_unpack8(yraw[a], f);
+                const int rel = __float_as_int(jv[a].y) - jpos;
+                const float ag = jv[a].x;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = fmaf(pc2[a], f[e], pc3[a]) + (rel == e ? ag : 0.f);
+                y0[a] = ogc_pack_bf16_rr(f[0], f[1], f[2], f[3]);
+                y1[a] = ogc_pack_bf16_rr(f[4], f[5], f[6], f[7]);
+            } else {
+                y0[a] = __builtin_bit_cast(v4s16, make_uint2(yraw[a].x, yraw[a].y));
+                y1[a] = __builtin_bit_cast(v4s16, make_uint2(yraw[a].z, yraw[a].w));
+            }
+        }
+        v4s16 m1a[CIB], m1b[CIB], m2a[CIB], m2b[CIB];
+#pragma unroll
+        for (int c = 0; c < CIB; ++c) {
+            float f[8];
+            ogc_unpack8(xraw[c], f);
+            unsigned keep[4]; // 0xFFFF per 16-bit half whose position passes the ReLU
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool lo = relu ? fmaf(ca[c], f[2 * e], cb[c]) > 0.f : true;
+                const bool hi = relu ? fmaf(ca[c], f[2 * e + 1], cb[c]) > 0.f : true;
+                keep[e] = (lo ? 0x0000FFFFu : 0u) | (hi ? 0xFFFF0000u : 0u);
+            }
+            const unsigned xs[4] = {xraw[c].x, xraw[c].y, xraw[c].z, xraw[c].w};
+            m1a[c] = __builtin_bit_cast(v4s16, make_uint2(keep[0] & 0x3F803F80u, keep[1] & 0x3F803F80u)); // bf16 1.0 = 0x3F80
+            m1b[c] = __builtin_bit_cast(v4s16, make_uint2(keep[2] & 0x3F803F80u, keep[3] & 0x3F803F80u));
+            m2a[c] = __builtin_bit_cast(v4s16, make_uint2(keep[0] & xs[0], keep[1] & xs[1]));
+            m2b[c] = __builtin_bit_cast(v4s16, make_uint2(keep[2] & xs[2], keep[3] & xs[3]));
+        }
+#pragma unroll
+        for (int a = 0; a < COB; ++a)
+#pragma unroll
+            for (int c = 0; c < CIB; ++c) {
+                acc1[a][c] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(y0[a], m1a[c], acc1[a][c], 0, 0, 0);
+                acc2[a][c] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(y0[a], m2a[c], acc2[a][c], 0, 0, 0);
+                acc1[a][c] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(y1[a], m1b[c], acc1[a][c], 0, 0, 0);
+                acc2[a][c] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(y1[a], m2b[c], acc2[a][c], 0, 0, 0);
+            }
+    };
+
+    uint4 ya[COB], xa[CIB], yb[COB], xb[CIB];
+    float2 ja[COB], jb[COB];
+    int pa_ = 0, pb_ = 0;
+    load(ya, xa, ja, pa_);
+    int s = 0;
+    for (; s + 1 < mine; s += 2) { // ping-pong registers: next step's loads fly during the MFMAs (no branch in the body)
+        load(yb, xb, jb, pb_);
+        fma32(ya, xa, ja, pa_);
+        load(ya, xa, ja, pa_);
+        fma32(yb, xb, jb, pb_);
+    }
+    if (s < mine) fma32(ya, xa, ja, pa_);
+
+    float *dst = hm + (size_t)img * 2 * cout * cin;
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+        if (which) __syncthreads();
+#pragma unroll
+        for (int a = 0; a < COB; ++a)
+#pragma unroll
+            for (int c = 0; c < CIB; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    red[wave][(a * CIB + c) * 256 + (k * 4 + r) * 16 + i] = which ? acc2[a][c][r] : acc1[a][c][r];
+        __syncthreads();
+        for (int t = threadIdx.x; t < COB * CIB * 256; t += WG_WAVES * OGC_WAVE) {
+            const int blk = t >> 8, a = blk / CIB, c = blk % CIB;
+            const int row = co0 + a * 16 + ((t & 255) >> 4), col = ci0 + c * 16 + (t & 15);
+            const float v = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+            if (row < cout && col < cin && v != 0.0f) unsafeAtomicAdd(dst + ((size_t)which * cout + row) * cin + col, v);
+        }
+    }
+}
+
+
 template <int COB, int CIB, typename AT>
 void moments_launch(int b, int cin, int cout, int hw, int relu, const AT *x, const AT *dy, const float *pa,
                     const float *pb, const float *coef2, const float *inj, int s_shift, float *hm, hipStream_t s) {
-    const int steps_per_img = hw >> 4;
+    const int steps_per_img = sizeof(AT) == 2 ? hw >> 5 : hw >> 4; // (16-bit tensors: 32 positions per step)
     const int tiles = ogc_divup(cout, 16 * COB) * ogc_divup(cin, 16 * CIB);
     long long waves = (2048 / tiles) / b;            // wavefronts per sample and tile pair: ~2048 over the chip
     if (waves < 4) waves = 4;
@@ -195,12 +364,21 @@ void moments_launch(int b, int cin, int cout, int hw, int relu, const AT *x, con
     const int chunks = ogc_divup(steps_per_img, spw * WG_WAVES);
     dim3 grid(b * chunks, ogc_divup(cout, 16 * COB), ogc_divup(cin, 16 * CIB));
     const float2 *c2 = reinterpret_cast<const float2 *>(coef2), *ij = reinterpret_cast<const float2 *>(inj);
-    if (inj)
-        hipLaunchKernelGGL((wgrad_moments_kernel<COB, CIB, true, AT>), grid, dim3(WG_WAVES * OGC_WAVE), 0, s, cin, cout, hw, chunks,
-                           spw, relu, x, dy, pa, pb, c2, ij, s_shift, hm);
-    else
-        hipLaunchKernelGGL((wgrad_moments_kernel<COB, CIB, false, AT>), grid, dim3(WG_WAVES * OGC_WAVE), 0, s, cin, cout, hw, chunks,
-                           spw, relu, x, dy, pa, pb, c2, ij, 0, hm);
+    if constexpr (sizeof(AT) == 2) {
+        if (inj)
+            hipLaunchKernelGGL((wgrad_moments16_kernel<COB, CIB, true>), grid, dim3(WG_WAVES * OGC_WAVE), 0, s, cin, cout, hw,
+                               chunks, spw, relu, x, dy, pa, pb, c2, ij, s_shift, hm);
+        else
+            hipLaunchKernelGGL((wgrad_moments16_kernel<COB, CIB, false>), grid, dim3(WG_WAVES * OGC_WAVE), 0, s, cin, cout, hw,
+                               chunks, spw, relu, x, dy, pa, pb, c2, ij, 0, hm);
+    } else {
+        if (inj)
+            hipLaunchKernelGGL((wgrad_moments_kernel<COB, CIB, true, AT>), grid, dim3(WG_WAVES * OGC_WAVE), 0, s, cin, cout, hw, chunks,
+                               spw, relu, x, dy, pa, pb, c2, ij, s_shift, hm);
+        else
+            hipLaunchKernelGGL((wgrad_moments_kernel<COB, CIB, false, AT>), grid, dim3(WG_WAVES * OGC_WAVE), 0, s, cin, cout, hw, chunks,
+                               spw, relu, x, dy, pa, pb, c2, ij, 0, hm);
+    }
 }
 
 // ---- dW, the GroupNorm parameter gradients and the coefficients of the adjoint ----------------------------------------------
@@ -283,7 +461,9 @@ __global__ __launch_bounds__(256) void moments_combine_kernel(int b, int cin, in
 // POOLED: g_y in the sparse form of ogc_group_norm_maxpool_bwd_sparse, rebuilt from the convolution's output (`gy` = y) as
 // in wgrad_moments_kernel; a lane's four positions lie inside one neighbourhood (S >= 4).
 // AT: element type of gy, yprev and out (float / ogc_bf16: act_io.h).
-template <int KQ, bool POOLED, typename AT = float>
+// BF: operands rounded to bf16 on v_mfma_f32_16x16x16_bf16, staged as in conv1x1_gemm_kernel (the 16-bit instantiation: at 64 x 64
+// channels the fp32 MFMAs of a tile take 3.4 us per wavefront, twice what its halved bytes cost).
+template <int KQ, bool POOLED, typename AT = float, bool BF = false>
 __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void dgrad_adjoint_kernel(int M, int K, int hw, int relu,
                                                                            const float *__restrict__ w,     // (K, M)
                                                                            const AT *__restrict__ gy,    // (B, K, hw)
@@ -341,9 +521,41 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void dgrad_adjoint_kernel(int M
             }
         }
     }
+    typedef short v4s __attribute__((ext_vector_type(4)));
+    constexpr int GQ = (KQ + 3) / 4;
+    v4s xb[BF ? GQ : 1][4]; // BF: the tile as packed bf16 operands (k-slot i of lane group kk = row 4 (4 g + i) + kk)
+    if constexpr (BF) {
+#pragma unroll
+        for (int g = 0; g < GQ; ++g) {
+            float4 r[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) r[i] = 4 * g + i < KQ ? xin[4 * g + i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            xb[g][0] = ogc_pack_bf16_rr(r[0].x, r[1].x, r[2].x, r[3].x);
+            xb[g][1] = ogc_pack_bf16_rr(r[0].y, r[1].y, r[2].y, r[3].y);
+            xb[g][2] = ogc_pack_bf16_rr(r[0].z, r[1].z, r[2].z, r[3].z);
+            xb[g][3] = ogc_pack_bf16_rr(r[0].w, r[1].w, r[2].w, r[3].w);
+        }
+    }
     for (int m0 = 0; m0 < M; m0 += 64) {
         __syncthreads(); // previous tile fully consumed
-        ogc_stage_weight_tile<true, WG_WAVES>(a_lds, w, m0, M, K, Kq);
+        if constexpr (BF) {
+            // a_bf[(g * 64 + mi) * 4 + kr] = bf16 x 4 of A[m0 + mi][4 (4 g + i) + kr], i = 0..3;  A[m][k] = w[k * M + m]
+            v4s *a_bf = reinterpret_cast<v4s *>(a_lds);
+            const int Gq = (Kq + 3) >> 2;
+            for (int t = threadIdx.x; t < Gq * 256; t += WG_WAVES * OGC_WAVE) {
+                const int mi = t & 63, kr = (t >> 6) & 3, g = t >> 8; // consecutive lanes: consecutive m (coalesced rows of w)
+                const int m = m0 + mi;
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int k = 4 * (4 * g + i) + kr;
+                    v[i] = (m < M && k < K) ? w[(size_t)k * M + m] : 0.f;
+                }
+                a_bf[(g * 64 + mi) * 4 + kr] = ogc_pack_bf16_rr(v[0], v[1], v[2], v[3]);
+            }
+        } else {
+            ogc_stage_weight_tile<true, WG_WAVES>(a_lds, w, m0, M, K, Kq);
+        }
         for (int t = threadIdx.x; t < 64; t += WG_WAVES * OGC_WAVE) {
             const int m = m0 + t;
             const bool in = m < M;
@@ -371,6 +583,19 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void dgrad_adjoint_kernel(int M
                 v4f acc[4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) acc[c] = (v4f){0.f, 0.f, 0.f, 0.f};
+                if constexpr (BF) {
+                    const v4s *a_bf = reinterpret_cast<const v4s *>(a_lds);
+#pragma unroll
+                    for (int g = 0; g < GQ; ++g) {
+                        if (4 * g < Kq) {
+                            const v4s av = a_bf[(g * 64 + a * 16 + j) * 4 + kk];
+                            acc[0] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, xb[g][0], acc[0], 0, 0, 0);
+                            acc[1] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, xb[g][1], acc[1], 0, 0, 0);
+                            acc[2] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, xb[g][2], acc[2], 0, 0, 0);
+                            acc[3] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, xb[g][3], acc[3], 0, 0, 0);
+                        }
+                    }
+                } else {
 #pragma unroll
                 for (int q = 0; q < KQ; ++q) {
                     if (q < Kq) {
@@ -380,6 +605,7 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void dgrad_adjoint_kernel(int M
                         acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xin[q].z, acc[2], 0, 0, 0);
                         acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xin[q].w, acc[3], 0, 0, 0);
                     }
+                }
                 }
                 if (live) {
 #pragma unroll
@@ -416,8 +642,12 @@ int wgrad_moments_impl(const char *name, int b, int cin, int cout, int hw, int r
                        float *moments, ogc_stream_t stream) {
     OGC_REQUIRE(b >= 0 && cin >= 1 && cout >= 1 && hw >= 1, "%s: bad shape", name);
     OGC_REQUIRE(y_prev && pa && pb && grad_y && moments, "%s: null pointer", name);
-    if ((hw & 15) != 0 || (((uintptr_t)y_prev | (uintptr_t)grad_y) & ogc_act_mask<AT>()) != 0) {
-        ogc_set_error("%s: hw=%d must be a multiple of 16 and the tensors 16-byte aligned", name, hw);
+    if ((hw & (sizeof(AT) == 2 ? 31 : 15)) != 0 || (((uintptr_t)y_prev | (uintptr_t)grad_y) & 15) != 0) {
+        ogc_set_error("%s: hw=%d must be a multiple of 16 (32 for 16-bit tensors) and the tensors 16-byte aligned", name, hw);
+        return OGC_ERR_UNSUPPORTED;
+    }
+    if (sizeof(AT) == 2 && !ogc_g_matmul_bf16) {
+        ogc_set_error("%s: 16-bit activations need ogc_set_matmul_precision(1)", name);
         return OGC_ERR_UNSUPPORTED;
     }
     OGC_REQUIRE((long long)cin * hw < (1ll << 31) && (long long)cout * hw < (1ll << 31) && b <= 32768,
@@ -435,7 +665,7 @@ int wgrad_moments_impl(const char *name, int b, int cin, int cout, int hw, int r
     else if (cin <= 16) OGC_ML(4, 1);
     else if (cin <= 32) OGC_ML(4, 2);
     else if (cout <= 32) OGC_ML(2, 4);
-    else if (inj) OGC_ML(4, 2); // the pooled <4, 4> instantiation runs out of registers (256 + 34): two column tiles instead
+    else if (inj && sizeof(AT) == 4) OGC_ML(4, 2); // the pooled fp32 <4, 4> instantiation runs out of registers (256 + 34): two column tiles instead
     else OGC_ML(4, 4);
 #undef OGC_ML
     OGC_CHECK_LAUNCH(name);
@@ -523,6 +753,10 @@ int dgrad_adjoint_impl(const char *name, int b, int cin, int cout, int hw, int r
     const int M = cin, K = cout, Kq = (K + 3) / 4;
     const size_t lds = ((size_t)64 * ogc_a_ld(Kq) + 64 * 5) * sizeof(float) +
                        (inj ? (size_t)WG_WAVES * K * (64 >> s_shift) * sizeof(float4) : 0);
+    if (sizeof(AT) == 2 && !ogc_g_matmul_bf16) {
+        ogc_set_error("%s: 16-bit activations need ogc_set_matmul_precision(1)", name);
+        return OGC_ERR_UNSUPPORTED;
+    }
     if (lds > 64 * 1024) { // (the kernels keep the default dynamic-LDS limit)
         ogc_set_error("%s: the weight tile and the pooled table need %zu bytes of LDS (> 64 KiB) at cout=%d, nsample=%d", name,
                       lds, cout, 64 >> (6 - s_shift));
@@ -534,10 +768,10 @@ int dgrad_adjoint_impl(const char *name, int b, int cin, int cout, int hw, int r
 #define OGC_DGA(KQV)                                                                                                        \
     do {                                                                                                                    \
         if (inj)                                                                                                            \
-            hipLaunchKernelGGL((dgrad_adjoint_kernel<KQV, true, AT>), grid, dim3(WG_WAVES * OGC_WAVE), lds, s, M, K, hw, relu, w,  \
+            hipLaunchKernelGGL((dgrad_adjoint_kernel<KQV, true, AT, sizeof(AT) == 2>), grid, dim3(WG_WAVES * OGC_WAVE), lds, s, M, K, hw, relu, w,  \
                                grad_y, y_prev, pa, pb, coef, c2, ij, s_shift, grad_prev);                                  \
         else                                                                                                                \
-            hipLaunchKernelGGL((dgrad_adjoint_kernel<KQV, false, AT>), grid, dim3(WG_WAVES * OGC_WAVE), lds, s, M, K, hw, relu, w, \
+            hipLaunchKernelGGL((dgrad_adjoint_kernel<KQV, false, AT, sizeof(AT) == 2>), grid, dim3(WG_WAVES * OGC_WAVE), lds, s, M, K, hw, relu, w, \
                                grad_y, y_prev, pa, pb, coef, c2, ij, 0, grad_prev);                                        \
     } while (0)
     if (Kq <= 8) OGC_DGA(8);
