@@ -45,6 +45,19 @@ __device__ __forceinline__ ogc_v4s_ ogc_pack_bf16_rr(float a, float b, float c, 
     return __builtin_bit_cast(ogc_v4s_, (v2u_){lo, hi});
 }
 
+// gfx950's double-depth bf16 MFMA: D = A (16 x 32) . B (32 x 16) + C — lane (i = l & 15, k = l >> 4) supplies row / column i and
+// the k-slots 8 k .. 8 k + 7.  Here as "two 16x16x16 operand quads side by side" (slots 8 k .. 8 k + 3 from *0, the rest from *1):
+// every product of this library pairs the SAME k-slot of both operands, so how slots map to positions / channels is free as long
+// as both operands agree — which they do when both halves are built the same way.
+typedef float ogc_v4f_ __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ ogc_v4f_ ogc_mfma_bf16_k32(ogc_v4s_ a0, ogc_v4s_ a1, ogc_v4s_ b0, ogc_v4s_ b1, ogc_v4f_ c) {
+    typedef short v8s_ __attribute__((ext_vector_type(8)));
+    typedef __bf16 v8bf_ __attribute__((ext_vector_type(8)));
+    const v8s_ a = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+    const v8s_ b = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf_, a), __builtin_bit_cast(v8bf_, b), c, 0, 0, 0);
+}
+
 // the value as it will read back from a tensor of element type T (statistics and extremes of an output are taken over what is
 // STORED, so that the norm that follows sees exactly the distribution its mean / rstd describe)
 template <typename T>

@@ -2,6 +2,7 @@
 // (reference: utils/nn_util.py:45-85); the weight gradients live in conv1x1_wgrad.hip, what both share in conv1x1_shared.h.
 #include "conv1x1_shared.h"
 #include "act_io.h"
+#include "conv1x1_epilogue.h"
 
 int ogc_g_matmul_bf16 = 0;
 
@@ -16,8 +17,7 @@ namespace {
 // float4 stores — no shuffles on either side.  The whole IN tile (K x 64) stays in registers (read from HBM exactly
 // once); A is staged through LDS in [k/4][m][4] order (conflict-free ds_read_b32 of the A operand) one 64-row tile at
 // a time and shared by the four waves of the workgroup.
-constexpr int FW_KQ_MAX = 40; // K <= 160 channels held in registers (40 float4 per lane)
-constexpr int GN_SLOTS = 16;  // spread of the fused GroupNorm statistics over cache lines (see ogc_conv1x1_gemm_gnstats)
+// (FW_KQ_MAX, GN_SLOTS, PoolOut and the pooled epilogue: conv1x1_epilogue.h, shared with conv1x1_h.hip)
 
 // KQ: compile-time bound on ceil(K / 4) — the IN tile costs KQ float4 registers per lane, so narrow layers get a small
 // register footprint and more wavefronts per SIMD.  STATS: also accumulate, per (batch, GroupNorm group), the sum and
@@ -37,81 +37,6 @@ constexpr int GN_SLOTS = 16;  // spread of the fused GroupNorm statistics over c
 // smallest for gamma < 0: the largest of the negated values) — and that pass never reads `out`
 // (ogc_group_norm_pool_extremes).  A wave's 64 positions hold whole neighbourhoods; values are reduced over the 4
 // accumulator columns of a lane and the pool_s / 4 lanes of a DPP row first, then the smallest index attaining them.
-// max(x, x of the DPP partner) as ONE instruction.  (fmaxf on a DPP-moved value costs three: the move, a canonicalising
-// v_max of the moved value — the compiler cannot know it is not a signalling NaN — and the maximum.)  The two wait states a
-// DPP read needs after a VALU write of its source are inside the asm: the hazard recogniser does not look into it.
-template <int CTRL>
-__device__ __forceinline__ float ogc_max_dpp_f32(float x) {
-    float r;
-    if constexpr (CTRL == 0xB1)
-        asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(x));
-    else if constexpr (CTRL == 0x4E)
-        asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(x));
-    else if constexpr (CTRL == 0x141)
-        asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(x));
-    else
-        asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 row_mirror row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(x));
-    return r;
-}
-__device__ __forceinline__ float ogc_max3_f32(float a, float b, float c) {
-    float r;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-__device__ __forceinline__ float ogc_max2_f32(float a, float b) {
-    float r;
-    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-
-struct PoolOut {
-    float *yext;          // (b, M, centres) largest raw output where sign[m] >= 0, smallest where sign[m] < 0
-    int *aext;            // its neighbour index
-    const float *sign;    // (M) the scale of the GroupNorm that follows (only its sign is used)
-    int s;
-};
-
-// The extremes of the neighbourhoods in a wave's 64-row x 64-position tile (see POOL above).  acc[a][c][r]: row a * 16 + kk * 4 + r,
-// position p0 + 4 j + c.  SEG = lanes per neighbourhood (4, 8, 16 for 16, 32, 64 neighbours).  sgn: +-1 per row of the tile (LDS).
-template <int SEG, typename ACC>
-__device__ __forceinline__ void ogc_pool_extremes_epilogue(const ACC (&acc)[4][4], int nblk, const float *sgn, int j, int kk,
-                                                           int m0, int M, int centres, int pool_s, float *ye, int *ae) {
-    const bool writer = (j & (SEG - 1)) == 0;
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        if (a < nblk) {
-            const float4 sg4 = *reinterpret_cast<const float4 *>(sgn + a * 16 + kk * 4);
-            const float sga[4] = {sg4.x, sg4.y, sg4.z, sg4.w};
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + a * 16 + kk * 4 + r;
-                const float sg = sga[r]; // exact: +-1 * v
-                const float v0 = sg * acc[a][0][r], v1 = sg * acc[a][1][r];
-                const float v2 = sg * acc[a][2][r], v3 = sg * acc[a][3][r];
-                float hi = ogc_max3_f32(v0, v1, ogc_max2_f32(v2, v3));
-                hi = ogc_max_dpp_f32<0xB1>(hi);
-                hi = ogc_max_dpp_f32<0x4E>(hi);
-                if (SEG >= 8) hi = ogc_max_dpp_f32<0x141>(hi);
-                if (SEG >= 16) hi = ogc_max_dpp_f32<0x140>(hi);
-                // first position of the neighbourhood that attains it (64: none in this lane) — selects, no branches
-                unsigned idx = v3 == hi ? 4u * j + 3u : 64u;
-                idx = v2 == hi ? 4u * j + 2u : idx;
-                idx = v1 == hi ? 4u * j + 1u : idx;
-                idx = v0 == hi ? 4u * j : idx;
-                idx = min(idx, ogc_dpp_u32<0xB1>(idx));
-                idx = min(idx, ogc_dpp_u32<0x4E>(idx));
-                if (SEG >= 8) idx = min(idx, ogc_dpp_u32<0x141>(idx));
-                if (SEG >= 16) idx = min(idx, ogc_dpp_u32<0x140>(idx));
-                if (writer && m < M) {
-                    const int o = (a * 16 + r) * centres;
-                    ye[o] = sg * hi;
-                    ae[o] = (int)(idx & (unsigned)(pool_s - 1)); // index inside the neighbourhood
-                }
-            }
-        }
-    }
-}
-
 // IT / OT: element types of `in` and `out` (float, or ogc_bf16 for activations kept in 16 bits: act_io.h); the statistics and
 // the extremes are then those of the ROUNDED outputs.
 template <bool TRANSPOSE_A, int KQ, bool STATS, bool PRO, bool BF, bool POOL = false, typename IT = float, typename OT = float>
@@ -187,6 +112,8 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_gemm_kernel(int M,
         __syncthreads(); // previous tile fully consumed
         if constexpr (BF) {
             // a_bf[(g * 64 + mi) * 4 + kr] = bf16 x 4 of A[m0 + mi][4 * (4g + i) + kr], i = 0..3
+            // (one group per round.  All groups' loads in flight at once — ogc_stage_weight_tile_bf16 of conv_stage.h, which the
+            // adjoint kernel of gn_fused_bwd.hip uses — measured SLOWER here: 128 -> 256 pooled 0.93 -> 1.66 ms, 64 -> 64 0.33 -> 0.41)
             v4s *a_bf = reinterpret_cast<v4s *>(a_lds);
             const int Gq = (Kq + 3) >> 2;
             for (int t = threadIdx.x; t < Gq * 256; t += WG_WAVES * OGC_WAVE) {
@@ -215,8 +142,40 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_gemm_kernel(int M,
             for (int c = 0; c < 4; ++c) acc[a][c] = (v4f){0.f, 0.f, 0.f, 0.f};
         if constexpr (BF) {
             const v4s *a_bf = reinterpret_cast<const v4s *>(a_lds);
+            // pairs of groups (32 input rows) on gfx950's v_mfma_f32_16x16x32_bf16, a single last group on the 16x16x16 form
 #pragma unroll
-            for (int g = 0; g < GQ; ++g) {
+            for (int g = 0; g + 1 < GQ; g += 2) {
+                if (4 * (g + 1) < Kq) { // both groups hold rows (a group that was not staged is stale LDS, not zeros)
+                    v4s av0[4], av1[4];
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        av0[a] = a_bf[(g * 64 + a * 16 + j) * 4 + kk];
+                        av1[a] = a_bf[((g + 1) * 64 + a * 16 + j) * 4 + kk];
+                    }
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        if (a < nblk) {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c)
+                                acc[a][c] = ogc_mfma_bf16_k32(av0[a], av1[a], xb[g][c], xb[g + 1][c], acc[a][c]);
+                        }
+                    }
+                } else if (4 * g < Kq) {
+                    v4s av[4];
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) av[a] = a_bf[(g * 64 + a * 16 + j) * 4 + kk];
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        if (a < nblk) {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c)
+                                acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av[a], xb[g][c], acc[a][c], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            if constexpr (GQ % 2 == 1) {
+                constexpr int g = GQ - 1;
                 if (4 * g < Kq) {
                     v4s av[4];
 #pragma unroll
@@ -603,6 +562,11 @@ int gemm_launch(int b, int M, int K, int hw, int groups, const float *w, const A
     }
     if constexpr (F32 && T && !STATS && !PRO && !POOL) { // the plain input gradient of a 101 .. 160-channel layer
         if (!g_matmul_bf16 && gemm_stream_launch<false, false, false, true>(b, M, K, hw, w, in, out, pa, pb, pro_relu, s))
+            return OGC_OK;
+    }
+    if constexpr (!F32) { // 16-bit tensors: the persistent kernel of conv1x1_h.hip where there are enough position tiles
+        if (ogc_gemm16_launch(T, STATS, PRO, POOL, b, M, K, hw, groups, w, in, out, stats, pa, pb, pro_relu, s, pool.sign, pool.yext,
+                              pool.aext, pool.s))
             return OGC_OK;
     }
     const size_t lds = (size_t)64 * ogc_a_ld(Kq) * sizeof(float); // (the bf16 staging needs half of it)

@@ -197,8 +197,8 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_wgrad_kernel(int b
 // conv1x1_wgrad_kernel with dy stored as bf16 moves half the bytes and is no faster: per 16 positions it issues one load per row
 // block — sixteen rows x 32 bytes: the vector memory pipe works per row, not per byte — plus the per-row coefficient loads.  Here
 // a step is 32 positions: lane (i, k) loads row i, positions pb + 8 k .. 8 k + 7 (sixteen bytes of a bf16 tensor, two float4 of
-// an fp32 x), and a lane's eight positions are the k-slots of TWO v_mfma_f32_16x16x16_bf16 (bf16 operands only: the 16-bit entry
-// points require ogc_set_matmul_precision(1)).  PRO / POOLED as in conv1x1_wgrad_kernel, the same expressions.
+// an fp32 x), and a lane's eight positions are the eight k-slots of ONE v_mfma_f32_16x16x32_bf16 (gfx950; bf16 operands only: the
+// 16-bit entry points require ogc_set_matmul_precision(1)).  PRO / POOLED as in conv1x1_wgrad_kernel, the same expressions.
 __device__ __forceinline__ void ogc_unpack8(const uint4 &u, float (&f)[8]) {
     f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xFFFF0000u);
     f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xFFFF0000u);
@@ -334,8 +334,7 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_wgrad16_kernel(int
         for (int a = 0; a < COB; ++a)
 #pragma unroll
             for (int c = 0; c < CIB; ++c) {
-                acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(y0[a], x0[c], acc[a][c], 0, 0, 0);
-                acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(y1[a], x1[c], acc[a][c], 0, 0, 0);
+                acc[a][c] = ogc_mfma_bf16_k32(y0[a], y1[a], x0[c], x1[c], acc[a][c]); // v_mfma_f32_16x16x32_bf16 (gfx950)
             }
     };
 

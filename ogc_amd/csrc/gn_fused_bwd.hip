@@ -188,8 +188,8 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void wgrad_moments_kernel(int c
 // With x and dy stored as bf16 the kernel above moves half the bytes and is no faster: per 16 positions it still issues one load
 // per row block (16 rows x 32 bytes each: the vector memory pipe works per row, not per byte) and 128 fp32 MFMAs (0.44 ms of
 // matrix time for the 64 x 64 layers of C2's first level, twice what the halved bytes cost).  Here a step is 32 positions — lane
-// (i, k) loads SIXTEEN bytes: row i, positions pb + 8 k .. 8 k + 7 — and the products run on v_mfma_f32_16x16x16_bf16 (a lane's
-// four consecutive positions are the four k-slots of one MFMA, as in conv1x1_wgrad_kernel's bf16 form; two MFMAs per lane load).
+// (i, k) loads SIXTEEN bytes: row i, positions pb + 8 k .. 8 k + 7 — and the products run on gfx950's v_mfma_f32_16x16x32_bf16: a
+// lane's eight consecutive positions are its eight k-slots (one MFMA per lane load and accumulator; ogc_mfma_bf16_k32, act_io.h).
 // Nothing is rounded that was not already: dy (dense form) is used as loaded, the mask is 0 / 1, mask . x is x or 0; only the
 // POOLED form rebuilds g_y in fp32 and rounds it (bf16 operands, as everywhere under ogc_set_matmul_precision(1)).
 typedef short v4s16 __attribute__((ext_vector_type(4)));
@@ -309,10 +309,9 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void wgrad_moments16_kernel(int
         for (int a = 0; a < COB; ++a)
 #pragma unroll
             for (int c = 0; c < CIB; ++c) {
-                acc1[a][c] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(y0[a], m1a[c], acc1[a][c], 0, 0, 0);
-                acc2[a][c] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(y0[a], m2a[c], acc2[a][c], 0, 0, 0);
-                acc1[a][c] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(y1[a], m1b[c], acc1[a][c], 0, 0, 0);
-                acc2[a][c] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(y1[a], m2b[c], acc2[a][c], 0, 0, 0);
+                // one v_mfma_f32_16x16x32_bf16 per accumulator: the lane's eight positions are its eight k-slots
+                acc1[a][c] = ogc_mfma_bf16_k32(y0[a], y1[a], m1a[c], m1b[c], acc1[a][c]);
+                acc2[a][c] = ogc_mfma_bf16_k32(y0[a], y1[a], m2a[c], m2b[c], acc2[a][c]);
             }
     };
 
@@ -539,20 +538,7 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void dgrad_adjoint_kernel(int M
     for (int m0 = 0; m0 < M; m0 += 64) {
         __syncthreads(); // previous tile fully consumed
         if constexpr (BF) {
-            // a_bf[(g * 64 + mi) * 4 + kr] = bf16 x 4 of A[m0 + mi][4 (4 g + i) + kr], i = 0..3;  A[m][k] = w[k * M + m]
-            v4s *a_bf = reinterpret_cast<v4s *>(a_lds);
-            const int Gq = (Kq + 3) >> 2;
-            for (int t = threadIdx.x; t < Gq * 256; t += WG_WAVES * OGC_WAVE) {
-                const int mi = t & 63, kr = (t >> 6) & 3, g = t >> 8; // consecutive lanes: consecutive m (coalesced rows of w)
-                const int m = m0 + mi;
-                float v[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int k = 4 * (4 * g + i) + kr;
-                    v[i] = (m < M && k < K) ? w[(size_t)k * M + m] : 0.f;
-                }
-                a_bf[(g * 64 + mi) * 4 + kr] = ogc_pack_bf16_rr(v[0], v[1], v[2], v[3]);
-            }
+            ogc_stage_weight_tile_bf16<true, WG_WAVES, GQ>(a_lds, w, m0, M, K, Kq); // packed operands of w^T (conv_stage.h)
         } else {
             ogc_stage_weight_tile<true, WG_WAVES>(a_lds, w, m0, M, K, Kq);
         }

@@ -56,7 +56,7 @@ def _sa(npoint, nsample, in_channel, mlp, inorm, **kw):
 def _fc_channel_major(fc, x):
     """nn.Linear along the channel axis of x (B, C, N) -> (B, 3, N): between two transposed copies in the reference
     (flownet_kitti.py:19, :38), one launch on the channel-major tensor in inference."""
-    if flow_glue.available(x, fc.weight, fc.bias) and fc.weight.shape[0] <= 4 and x.is_contiguous():
+    if flow_glue.available(x, fc.weight, fc.bias, what="linear_cn") and fc.weight.shape[0] <= 4 and x.is_contiguous():
         return flow_glue.linear_cn(x, fc.weight, fc.bias)
     return fc(x.permute(0, 2, 1).contiguous()).permute(0, 2, 1).contiguous()
 
@@ -124,7 +124,7 @@ class GlobalCorrLayer(nn.Module):
 
     def forward(self, pc1_l_glob, pc2_l_glob, feats1_glob, feats2_glob):
         top = self.n_stage + 1  # index of the coarsest level in pc*_l_glob
-        if (flow_glue.available(pc1_l_glob[top], pc2_l_glob[top], feats1_glob, feats2_glob, self.epsilon)
+        if (flow_glue.available(pc1_l_glob[top], pc2_l_glob[top], feats1_glob, feats2_glob, self.epsilon, what="soft_corr")
                 and flow_glue.soft_corr_flow_supported(feats1_glob)):
             # inference: weights, row sums and the weighted mean of cloud 2 in one launch, on the channel-major tensors
             flow0_cm = flow_glue.soft_corr_flow(pc1_l_glob[top].contiguous(), pc2_l_glob[top].contiguous(), feats1_glob.contiguous(),
@@ -214,7 +214,7 @@ class GRU(nn.Module):
         # x: a tensor (B, input_dim, N), or the list of tensors whose concatenation along the channels it is
         parts = list(x) if isinstance(x, (list, tuple)) else [x]
         hx = torch.cat([h] + parts, dim=1)
-        if flow_glue.available(hx, *[p for m in (self.convz, self.convr, self.convq) for p in m.parameters()]):
+        if flow_glue.available(hx, *[p for m in (self.convz, self.convr, self.convq) for p in m.parameters()], what="gru"):
             # inference: the gates' max over the neighbours, their activations and the products around them in two launches
             # (sigmoid, mul, cat | sigmoid, tanh, 1 - z, two products, sum — and the three maxima — otherwise)
             # the update and reset gates read the same grouped input: one grouping and one product with both weights stacked
@@ -337,7 +337,7 @@ class FlowStep3DBase(nn.Module):
 
         h = self.calc_h0(feats1_loc, pc1_l_loc[-1])
 
-        if iters > 1 and flow_glue.available(pc1, flow0, flow0_lr):
+        if iters > 1 and flow_glue.available(pc1, flow0, flow0_lr, what="advance"):
             return self._refine_inference(flow_predictions, pc1, pc1_l_loc, pc2_l_loc, feats2_loc, fps_idx1, flow0, flow0_lr, h, iters)
         pc1_new = pc1 + flow0.detach()
         pc1_new_lr = pc1_l_loc[2] + flow0_lr.detach()

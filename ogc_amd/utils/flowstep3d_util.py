@@ -202,7 +202,7 @@ class PointNetSetAbstraction(_FoldAware):
             if memo is not None and not given_idx and self.npoint in memo["new_xyz"]:
                 new_xyz = memo["new_xyz"][self.npoint]
             else:
-                if flow_glue.available(xyz):
+                if flow_glue.available(xyz, what="gather_pair"):
                     new_xyz, new_xyz_t = flow_glue.gather_xyz_pair(xyz, fps_idx)   # both layouts of the centres in one launch
                 else:
                     new_xyz = gather_operation(xyz, fps_idx)
@@ -292,7 +292,7 @@ class PointNetFeaturePropogation(_FoldAware):
         hit = memo["three_nn"].get(id(pos2)) if memo is not None else None
         if hit is None or hit[0] is not pos2 or hit[3] != (pos2.data_ptr(), pos2._version):
             from .. import flow_glue
-            if flow_glue.available(pos1, pos2):
+            if flow_glue.available(pos1, pos2, what="three_nn_w"):
                 # inference: the transposed copies from the memo, sqrt / clamp / reciprocal / sum / division as one launch
                 idx, weight = flow_glue.three_nn_with_weights(geometry_memo.transposed(pos1), geometry_memo.transposed(pos2))
             else:

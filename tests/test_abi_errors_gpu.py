@@ -27,6 +27,8 @@ for name, argtypes in sorted(_lib.SIGNATURES.items()):
                 out.append(first_int if not seen_int else int_value); seen_int = True
             elif t in (ctypes.c_float, ctypes.c_double):
                 out.append(1.0)
+            elif t is ctypes.c_longlong:
+                out.append(int_value)   # (batch strides of the FlowStep3D gate kernels)
             else:
                 out.append(None)
         return out + [stream]

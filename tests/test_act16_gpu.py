@@ -283,3 +283,49 @@ def test_activations_are_stored_in_16_bits(nat):
         finally:
             fused.ACT16 = saved
     assert peak[True] < 0.62 * peak[False], peak
+
+
+@pytest.mark.parametrize("B,cin,cout,P,S", [(32, 64, 64, 256, 64), (32, 64, 128, 256, 64), (32, 128, 256, 512, 32), (64, 128, 128, 128, 64),
+                                            (32, 30, 64, 256, 64)])
+def test_persistent_kernel_equals_tile_kernel(nat, B, cin, cout, P, S):
+    """conv1x1_h.hip (persistent workgroups, weights staged once) against the tile kernel of conv1x1.hip (OGC_GEMM16=0) on launches
+    large enough for the former (>= 8192 tiles of 64 positions): identical outputs and extremes, statistics equal up to the order
+    of their fp64 additions."""
+    hw, groups = P * S, 4
+    assert B * (hw // 64) >= 8192
+    xh = rnd(B, cin, hw, seed=cin).to(BF)
+    w = rnd(cout, cin, seed=1, scale=cin ** -0.5)
+    pa, pb = torch.rand(B * cin, device=DEV) + 0.5, rnd(B * cin, seed=2)
+    gamma = rnd(cout, seed=5)
+    slots = nat.conv1x1_gn_slots()
+    g = rnd(B, cout, hw, seed=7).to(BF) if cout <= 160 else None
+    res = {}
+    for mode in ("0", "1"):
+        os.environ["OGC_GEMM16"] = mode
+        try:
+            y0 = torch.empty(B, cout, hw, device=DEV, dtype=BF)
+            nat.conv1x1_gemm_affine_wrapper(B, cout, cin, hw, 1, 0, w, xh, pa, pb, y0, None)
+            st = torch.zeros(slots * B * groups * 2, dtype=torch.float64, device=DEV)
+            y1 = torch.empty_like(y0)
+            nat.conv1x1_gemm_affine_wrapper(B, cout, cin, hw, 1, groups, w, xh, pa, pb, y1, st)
+            st2 = torch.zeros_like(st)
+            y2 = torch.empty_like(y0)
+            yext = torch.empty(B, cout, P, device=DEV)
+            aext = torch.empty(B, cout, P, dtype=torch.int32, device=DEV)
+            nat.conv1x1_gemm_affine_pool_wrapper(B, cout, cin, hw, 1, groups, S, w, xh, pa, pb, gamma, y2, st2, yext, aext)
+            dz = None
+            if g is not None:
+                dz = torch.empty(B, cin, hw, device=DEV, dtype=BF)
+                nat.conv1x1_gemm_wrapper(B, cin, cout, hw, 1, w, g, dz)
+            torch.cuda.synchronize()
+            res[mode] = (y0, y1, st.view(slots, B, groups, 2).sum(0), y2, st2.view(slots, B, groups, 2).sum(0), yext, aext, dz)
+        finally:
+            os.environ.pop("OGC_GEMM16", None)
+    for k, (a, b) in enumerate(zip(res["0"], res["1"])):
+        if a is None:
+            continue
+        if a.dtype == torch.float64:
+            assert torch.allclose(a, b, rtol=1e-11, atol=1e-6), k
+        else:
+            assert torch.equal(a, b), k
+    assert torch.equal(res["1"][0], res["1"][1]) and torch.equal(res["1"][0], res["1"][3])
