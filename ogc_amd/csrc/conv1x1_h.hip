@@ -26,7 +26,9 @@ constexpr int H_WAVES = 4;
 // PF: request the raw tile of step t + 1 as soon as step t's has been turned into operands (its loads then fly during step t's
 // MFMAs, epilogue and stores; costs its registers through that phase).  !PF: load at the top of the step and let the other
 // wavefronts of the SIMD cover the latency.  OCC: wavefronts per SIMD the kernel is built for (its register budget).
-template <bool TRANS, int KQ, bool STATS, bool PRO, bool POOL, bool PF, int OCC>
+// RAG: K does not fill the KQ quads (K % 4 != 0 or K < 4 KQ): rows beyond K — read from inside the tensor — are zeroed by selects.
+// (As a run-time test per quad it was sixteen branches per step.)
+template <bool TRANS, int KQ, bool STATS, bool PRO, bool POOL, bool PF, int OCC, bool RAG>
 __global__ __launch_bounds__(H_WAVES *OGC_WAVE, OCC) void conv1x1_gemm16_kernel(
     int M, int K, int hw, int ntiles, int nbatch, int groups, const float *__restrict__ w, const ogc_bf16 *__restrict__ in,
     ogc_bf16 *__restrict__ out, double *__restrict__ stats, const float *__restrict__ pa, const float *__restrict__ pb, int pro_relu,
@@ -133,7 +135,7 @@ __global__ __launch_bounds__(H_WAVES *OGC_WAVE, OCC) void conv1x1_gemm16_kernel(
                         v.x = fmaf(ca, v.x, cb); v.y = fmaf(ca, v.y, cb); v.z = fmaf(ca, v.z, cb); v.w = fmaf(ca, v.w, cb);
                         if (pro_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                     }
-                    if (q * 4 + 3 >= K) { // (wave-uniform: a quad that is not wholly inside — its rows beyond K were read from inside the tensor)
+                    if constexpr (RAG) {
                         if (q * 4 + kk >= K) v = make_float4(0.f, 0.f, 0.f, 0.f);
                     }
                     r[i] = v;
@@ -256,7 +258,7 @@ size_t gemm16_lds(int M, int K, int KQ, bool stats_on, bool pro, bool pool_on) {
            sizeof(float);
 }
 
-template <bool TRANS, int KQ, bool STATS, bool PRO, bool POOL, bool PF, int OCC>
+template <bool TRANS, int KQ, bool STATS, bool PRO, bool POOL, bool PF, int OCC, bool RAG>
 bool gemm16_go(int b, int M, int K, int hw, int groups, const float *w, const ogc_bf16 *in, ogc_bf16 *out, double *stats,
                const float *pa, const float *pb, int pro_relu, hipStream_t s, PoolOut pool) {
     const size_t lds = gemm16_lds(M, K, KQ, STATS, PRO, POOL);
@@ -265,7 +267,7 @@ bool gemm16_go(int b, int M, int K, int hw, int groups, const float *w, const og
     while (per_cu > 1 && (lds + 512) * per_cu > 156 * 1024) --per_cu;
     if (lds > 78 * 1024 || ntiles >= (1ll << 31)) return false;
     static bool raised = false;
-    const void *fn = reinterpret_cast<const void *>(&conv1x1_gemm16_kernel<TRANS, KQ, STATS, PRO, POOL, PF, OCC>);
+    const void *fn = reinterpret_cast<const void *>(&conv1x1_gemm16_kernel<TRANS, KQ, STATS, PRO, POOL, PF, OCC, RAG>);
     if (!raised) {
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 78 * 1024) != hipSuccess) {
             (void)hipGetLastError();
@@ -275,7 +277,7 @@ bool gemm16_go(int b, int M, int K, int hw, int groups, const float *w, const og
     }
     long long wgs = 256ll * per_cu;
     if (wgs > ntiles / H_WAVES) wgs = ntiles / H_WAVES;
-    hipLaunchKernelGGL((conv1x1_gemm16_kernel<TRANS, KQ, STATS, PRO, POOL, PF, OCC>), dim3((unsigned)wgs), dim3(H_WAVES * OGC_WAVE), lds,
+    hipLaunchKernelGGL((conv1x1_gemm16_kernel<TRANS, KQ, STATS, PRO, POOL, PF, OCC, RAG>), dim3((unsigned)wgs), dim3(H_WAVES * OGC_WAVE), lds,
                        s, M, K, hw, (int)ntiles, b, groups, w, in, out, stats, pa, pb, pro_relu, pool);
     return true;
 }
@@ -287,8 +289,13 @@ bool gemm16_kq(int b, int M, int K, int hw, int groups, const float *w, const og
 #define H_ARGS b, M, K, hw, groups, w, in, out, stats, pa, pb, pro_relu, s, pool
     // two wavefronts per SIMD either way (three, built without the prefetch, spill at K <= 64); the prefetched tile does not fit the
     // registers next to 33 quads of operands
-    if (Kq <= 16) return gemm16_go<TRANS, 16, STATS, PRO, POOL, true, 2>(H_ARGS);
-    if (Kq <= 33) return gemm16_go<TRANS, 33, STATS, PRO, POOL, false, 2>(H_ARGS);
+    const bool exact = (K & 3) == 0;
+    if (Kq <= 16) {
+        if (exact && Kq == 16) return gemm16_go<TRANS, 16, STATS, PRO, POOL, true, 2, false>(H_ARGS);
+        return gemm16_go<TRANS, 16, STATS, PRO, POOL, true, 2, true>(H_ARGS);
+    }
+    if (exact && Kq == 32) return gemm16_go<TRANS, 32, STATS, PRO, POOL, false, 2, false>(H_ARGS);
+    if (Kq <= 33) return gemm16_go<TRANS, 33, STATS, PRO, POOL, false, 2, true>(H_ARGS);
 #undef H_ARGS
     return false;
 }
