@@ -770,6 +770,20 @@ def matched_distances(mask1, mask2, loss_norm):
 
 FUSED_GN_BACKWARD_MAX_WIDTH = 64
 FUSED_GN_BACKWARD = True   # _NormActConv.backward through the moment matrices (csrc/gn_fused_bwd.hip); False: the separate passes
+# 16-bit activations: the moment matrices run on bf16 MFMAs (wgrad_moments16_kernel), so the second accumulator set that made the
+# fp32 kernel MFMA-bound at 128 channels costs nothing there, and the moment path COULD reach 128-channel layers (C2: SA2's inner
+# layer, the 64 -> 128 tail of SA1's second scale; OGC_ACT16_MOMENT_WIDTH=128).  Measured at C2: 17.0-17.1 ms per step against 16.4
+# with the fp32 limits (two tile pairs re-read both tensors, the adjoint kernel holds 128 reduction channels at two wavefronts per
+# SIMD) — the limit stays at 64.
+ACT16_MOMENT_WIDTH = int(__import__("os").environ.get("OGC_ACT16_MOMENT_WIDTH", "64"))
+
+
+def _moment_width(t):
+    return ACT16_MOMENT_WIDTH if t.dtype is torch.bfloat16 else FUSED_GN_BACKWARD_MAX_WIDTH
+
+
+def _pool_moment_cout(t):
+    return ACT16_MOMENT_WIDTH if t.dtype is torch.bfloat16 else max(FUSED_GN_BACKWARD_MAX_WIDTH, SPARSE_POOL_MAX_COUT)
 
 
 def _norm_act_conv_forward(y_prev, stats_prev, gn_weight, gn_bias, conv_weight, gn_groups, eps, relu, next_groups, pool,
@@ -853,7 +867,7 @@ class _NormActConv(Function):
         # (up to 64 channels: from 128 on the second accumulator set makes the weight-gradient kernel MFMA-bound and the
         # whole path slower than the separate passes — tools/gn_bwd_compare.py)
         if (FUSED_GN_BACKWARD and getattr(nat, "conv1x1_dgrad_adjoint_wrapper", None) is not None and hw % 64 == 0
-                and cout <= FUSED_GN_BACKWARD_MAX_WIDTH and cin <= FUSED_GN_BACKWARD_MAX_WIDTH and gn_groups <= 32
+                and cout <= _moment_width(y_prev) and cin <= _moment_width(y_prev) and gn_groups <= 32
                 and cin % gn_groups == 0):
             # (fp32 operands also under `matmul_precision: bf16`: these layers are HBM-bound, bf16 operands buy nothing here)
             # moment matrices next to the weight gradient -> GroupNorm sums -> adjoint in the input gradient's epilogue:
@@ -976,7 +990,7 @@ class _NormActConvPool(Function):
                                                   rstd2, out, arg, grad_out.contiguous(), coef2, inj, gw2, gb2, ws,
                                                   yext if POOL_SUMS_FROM_EXTREMES else None)
         w = conv_weight.contiguous().view(cout, cin)
-        if cin > FUSED_GN_BACKWARD_MAX_WIDTH or cout > max(FUSED_GN_BACKWARD_MAX_WIDTH, SPARSE_POOL_MAX_COUT):
+        if cin > _moment_width(y_prev) or cout > _pool_moment_cout(y_prev):
             # wide tails (SA2 64 -> 128, SA3 128 -> 256 at C4): weight and input gradient rebuild g_y from (y, coef2, inj) while
             # they load y (round 4: ogc_conv1x1_wgrad_affine_pooled, ogc_conv1x1_dgrad_pooled) — the pass that wrote the dense g_y
             # and the two that read it become two that read y; the GroupNorm of y_prev keeps its own backward kernels
@@ -1015,7 +1029,7 @@ def norm_act_conv_pool_available(y_prev, gn, conv, next_gn):
             and getattr(nat, "conv1x1_gemm_affine_pool_wrapper", None) is not None):
         return False
     cin, cout, g, g2 = y_prev.shape[1], conv.weight.shape[0], gn.num_groups, next_gn.num_groups
-    if cin > FUSED_GN_BACKWARD_MAX_WIDTH or cout > max(FUSED_GN_BACKWARD_MAX_WIDTH, SPARSE_POOL_MAX_COUT):
+    if cin > _moment_width(y_prev) or cout > _pool_moment_cout(y_prev):
         # wide tails: the pooled forms of the plain weight / input gradient kernels (fp32 operands, enough position tiles for
         # the chunked kernel, neighbourhood extremes from the forward convolution)
         B, hw = y_prev.shape[0], y_prev.shape[2] * y_prev.shape[3]
@@ -1027,8 +1041,8 @@ def norm_act_conv_pool_available(y_prev, gn, conv, next_gn):
     # output channel and neighbourhood of a 64-position tile; the kernel keeps the default 64 KiB
     kq = (cout + 3) // 4
     lds = (64 * 4 * (kq | 1) + 320) * 4 + 4 * cout * (64 // y_prev.shape[-1]) * 16
-    return (lds <= 65536 and (y_prev.shape[2] * y_prev.shape[3]) % 64 == 0 and cin <= FUSED_GN_BACKWARD_MAX_WIDTH
-            and cout <= max(FUSED_GN_BACKWARD_MAX_WIDTH, SPARSE_POOL_MAX_COUT) and g <= 32 and cin % g == 0
+    return (lds <= 65536 and (y_prev.shape[2] * y_prev.shape[3]) % 64 == 0 and cin <= _moment_width(y_prev)
+            and cout <= _pool_moment_cout(y_prev) and g <= 32 and cin % g == 0
             and g2 <= 32 and cout % g2 == 0 and (cout // g2) % 4 == 0)
 
 
