@@ -28,11 +28,21 @@ constexpr int H_WAVES = 4;
 // wavefronts of the SIMD cover the latency.  OCC: wavefronts per SIMD the kernel is built for (its register budget).
 // RAG: K does not fill the KQ quads (K % 4 != 0 or K < 4 KQ): rows beyond K — read from inside the tensor — are zeroed by selects.
 // (As a run-time test per quad it was sixteen branches per step.)
-template <bool TRANS, int KQ, bool STATS, bool PRO, bool POOL, bool PF, int OCC, bool RAG>
+// ADJ (with TRANS, nothing else): the input gradient of  y = conv(relu(GroupNorm(y_prev)))  with the GroupNorm adjoint in the epilogue
+// (dgrad_adjoint_kernel of gn_fused_bwd.hip, the same expressions):  out[b, m, p] = alpha[b, m] mask (sum_k w[k, m] in[b, k, p]) +
+// c2[b, m] y_prev[b, m, p] + c3[b, m],  mask = [pa[b, m] y_prev + pb[b, m] > 0] — pa, pb are indexed by OUTPUT row here, coef holds
+// (alpha, c2, c3) per (b, m); the five coefficients of a sample's rows sit in a wave-private LDS strip.
+struct AdjIn {
+    const ogc_bf16 *yprev; // (B, M, hw)
+    const float *coef;     // (B, M, 3)
+};
+
+template <bool TRANS, int KQ, bool STATS, bool PRO, bool POOL, bool PF, int OCC, bool RAG, bool ADJ = false>
 __global__ __launch_bounds__(H_WAVES *OGC_WAVE, OCC) void conv1x1_gemm16_kernel(
     int M, int K, int hw, int ntiles, int nbatch, int groups, const float *__restrict__ w, const ogc_bf16 *__restrict__ in,
     ogc_bf16 *__restrict__ out, double *__restrict__ stats, const float *__restrict__ pa, const float *__restrict__ pb, int pro_relu,
-    PoolOut pool) {
+    PoolOut pool, AdjIn adj = AdjIn()) {
+    static_assert(!ADJ || (TRANS && !STATS && !PRO && !POOL), "the adjoint epilogue belongs to the plain input gradient");
     constexpr int GQ = (KQ + 3) / 4;
     extern __shared__ __attribute__((aligned(16))) float h_lds[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -45,6 +55,7 @@ __global__ __launch_bounds__(H_WAVES *OGC_WAVE, OCC) void conv1x1_gemm16_kernel(
     float *cw = after_a + wave * (2 * KQ * 4);
     double *sacc = reinterpret_cast<double *>(after_a + (PRO ? H_WAVES * 2 * KQ * 4 : 0)) + wave * (Mt * 32);
     float *sgn_all = after_a + (PRO ? H_WAVES * 2 * KQ * 4 : 0) + (STATS ? H_WAVES * Mt * 64 : 0);
+    float *cf = after_a + wave * (Mt * 64 * 5); // ADJ: [Mt * 64][5] = pa, pb, alpha, c2, c3 of the current sample's rows
     for (int mt = 0; mt < Mt; ++mt) // (nothing else is live yet: all of a tile's loads in flight at once)
         ogc_stage_weight_tile_bf16<TRANS, H_WAVES, GQ>(a_all + (size_t)mt * Gq * 256, w, mt * 64, M, K, Kq);
     if constexpr (POOL) {
@@ -118,6 +129,21 @@ __global__ __launch_bounds__(H_WAVES *OGC_WAVE, OCC) void conv1x1_gemm16_kernel(
                 __builtin_amdgcn_wave_barrier();
             }
         }
+        if constexpr (ADJ) {
+            if (b != coef_b) {
+                coef_b = b;
+                for (int r = lane; r < Mt * 64; r += OGC_WAVE) {
+                    const bool in_m = r < M;
+                    const size_t e = (size_t)b * M + r;
+                    cf[r * 5 + 0] = in_m ? pa[e] : 0.f;
+                    cf[r * 5 + 1] = in_m ? pb[e] : 0.f;
+                    cf[r * 5 + 2] = in_m ? adj.coef[e * 3] : 0.f;
+                    cf[r * 5 + 3] = in_m ? adj.coef[e * 3 + 1] : 0.f;
+                    cf[r * 5 + 4] = in_m ? adj.coef[e * 3 + 2] : 0.f;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
         // ---- the raw tile -> packed operands (k-slot i of lane group kk of group g = input row 4 (4 g + i) + kk)
         v4s xb[GQ][4];
 #pragma unroll
@@ -159,6 +185,17 @@ __global__ __launch_bounds__(H_WAVES *OGC_WAVE, OCC) void conv1x1_gemm16_kernel(
             for (int a = 0; a < 4; ++a)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) acc[a][c] = (v4f){0.f, 0.f, 0.f, 0.f};
+            uint2 yv[ADJ ? 16 : 1]; // ADJ: y_prev at this lane's output positions, requested in front of the tile's MFMAs
+            if constexpr (ADJ) {
+                const ogc_bf16 *yb = adj.yprev + (size_t)b * M * hw + p0;
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int mu = min(mt * 64 + a * 16 + r, M - 1 - min(kk * 4, M - 1)); // (rows beyond M: a harmless re-read)
+                        yv[a * 4 + r] = *reinterpret_cast<const uint2 *>(yb + (size_t)mu * hw + soff);
+                    }
+            }
 #pragma unroll
             for (int g = 0; g + 1 < GQ; g += 2) {
                 if (4 * (g + 1) < Kq) { // both groups were staged
@@ -209,8 +246,22 @@ __global__ __launch_bounds__(H_WAVES *OGC_WAVE, OCC) void conv1x1_gemm16_kernel(
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int mu = mt * 64 + a * 16 + r; // the row is mu + 4 kk (C/D layout: row (l >> 4) * 4 + r, column l & 15):
+                    float4 o = make_float4(acc[a][0][r], acc[a][1][r], acc[a][2][r], acc[a][3][r]);
+                    if constexpr (ADJ) {
+                        const float *c5 = cf + (mu + coff * 4) * 5;
+                        const float fa = c5[0], fb = c5[1], al = c5[2], c2 = c5[3], c3 = c5[4];
+                        const uint2 u = yv[a * 4 + r];
+                        const float4 y = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u),
+                                                     __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xFFFF0000u));
+                        if (pro_relu) {
+                            o.x = fmaf(fa, y.x, fb) > 0.f ? o.x : 0.f; o.y = fmaf(fa, y.y, fb) > 0.f ? o.y : 0.f;
+                            o.z = fmaf(fa, y.z, fb) > 0.f ? o.z : 0.f; o.w = fmaf(fa, y.w, fb) > 0.f ? o.w : 0.f;
+                        }
+                        o.x = fmaf(al, o.x, fmaf(c2, y.x, c3)); o.y = fmaf(al, o.y, fmaf(c2, y.y, c3));
+                        o.z = fmaf(al, o.z, fmaf(c2, y.z, c3)); o.w = fmaf(al, o.w, fmaf(c2, y.w, c3));
+                    }
                     if (mu + kk * 4 < M)                 // a wave-uniform base + ONE 32-bit lane offset (see load_tile)
-                        ogc_st4(outb + (size_t)mu * hw + soff, make_float4(acc[a][0][r], acc[a][1][r], acc[a][2][r], acc[a][3][r]));
+                        ogc_st4(outb + (size_t)mu * hw + soff, o);
                 }
             if constexpr (POOL) {
                 const int m0p = mt * 64;
@@ -252,22 +303,22 @@ __global__ __launch_bounds__(H_WAVES *OGC_WAVE, OCC) void conv1x1_gemm16_kernel(
     if (STATS) flush_stats();
 }
 
-size_t gemm16_lds(int M, int K, int KQ, bool stats_on, bool pro, bool pool_on) {
+size_t gemm16_lds(int M, int K, int KQ, bool stats_on, bool pro, bool pool_on, bool adj = false) {
     const int Kq = (K + 3) / 4, Gq = (Kq + 3) / 4, Mt = (M + 63) / 64;
-    return ((size_t)Mt * Gq * 512 + (pro ? H_WAVES * 2 * KQ * 4 : 0) + (stats_on ? H_WAVES * Mt * 64 : 0) + (pool_on ? Mt * 64 : 0)) *
-           sizeof(float);
+    return ((size_t)Mt * Gq * 512 + (pro ? H_WAVES * 2 * KQ * 4 : 0) + (stats_on ? H_WAVES * Mt * 64 : 0) + (pool_on ? Mt * 64 : 0) +
+            (adj ? H_WAVES * Mt * 64 * 5 : 0)) * sizeof(float);
 }
 
-template <bool TRANS, int KQ, bool STATS, bool PRO, bool POOL, bool PF, int OCC, bool RAG>
+template <bool TRANS, int KQ, bool STATS, bool PRO, bool POOL, bool PF, int OCC, bool RAG, bool ADJ = false>
 bool gemm16_go(int b, int M, int K, int hw, int groups, const float *w, const ogc_bf16 *in, ogc_bf16 *out, double *stats,
-               const float *pa, const float *pb, int pro_relu, hipStream_t s, PoolOut pool) {
-    const size_t lds = gemm16_lds(M, K, KQ, STATS, PRO, POOL);
+               const float *pa, const float *pb, int pro_relu, hipStream_t s, PoolOut pool, AdjIn adj = AdjIn()) {
+    const size_t lds = gemm16_lds(M, K, KQ, STATS, PRO, POOL, ADJ);
     const long long ntiles = (long long)b * (hw / 64);
     int per_cu = OCC; // workgroups per CU: what the registers allow, and the LDS (160 KiB per CU)
     while (per_cu > 1 && (lds + 512) * per_cu > 156 * 1024) --per_cu;
     if (lds > 78 * 1024 || ntiles >= (1ll << 31)) return false;
     static bool raised = false;
-    const void *fn = reinterpret_cast<const void *>(&conv1x1_gemm16_kernel<TRANS, KQ, STATS, PRO, POOL, PF, OCC, RAG>);
+    const void *fn = reinterpret_cast<const void *>(&conv1x1_gemm16_kernel<TRANS, KQ, STATS, PRO, POOL, PF, OCC, RAG, ADJ>);
     if (!raised) {
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 78 * 1024) != hipSuccess) {
             (void)hipGetLastError();
@@ -277,8 +328,8 @@ bool gemm16_go(int b, int M, int K, int hw, int groups, const float *w, const og
     }
     long long wgs = 256ll * per_cu;
     if (wgs > ntiles / H_WAVES) wgs = ntiles / H_WAVES;
-    hipLaunchKernelGGL((conv1x1_gemm16_kernel<TRANS, KQ, STATS, PRO, POOL, PF, OCC, RAG>), dim3((unsigned)wgs), dim3(H_WAVES * OGC_WAVE), lds,
-                       s, M, K, hw, (int)ntiles, b, groups, w, in, out, stats, pa, pb, pro_relu, pool);
+    hipLaunchKernelGGL((conv1x1_gemm16_kernel<TRANS, KQ, STATS, PRO, POOL, PF, OCC, RAG, ADJ>), dim3((unsigned)wgs), dim3(H_WAVES * OGC_WAVE), lds,
+                       s, M, K, hw, (int)ntiles, b, groups, w, in, out, stats, pa, pb, pro_relu, pool, adj);
     return true;
 }
 
@@ -327,4 +378,22 @@ bool ogc_gemm16_launch(bool transpose_a, bool stats_on, bool pro, bool pool_on, 
     if (!stats_on && !pro) H_GO(false, false, false, false);
 #undef H_GO
     return false;
+}
+
+// The adjoint input gradient (ogc_conv1x1_dgrad_adjoint_h, dense form) on the persistent kernel, or false (fewer than 8192 position
+// tiles, more than 64 reduction channels — the 33-quad form has no registers for the y_prev rows —, OGC_GEMM16=0).
+bool ogc_gemm16_adjoint_launch(int b, int M, int K, int hw, int relu, const float *w, const unsigned short *gy,
+                               const unsigned short *yprev, const float *pa, const float *pb, const float *coef,
+                               unsigned short *out, hipStream_t s) {
+    const char *e = getenv("OGC_GEMM16");
+    if (e && e[0] == '0') return false;
+    const int Kq = (K + 3) / 4;
+    if ((hw & 63) != 0 || (long long)b * (hw / 64) < 8192 || Kq > 16 || M > 128) return false;
+    AdjIn adj;
+    adj.yprev = yprev; adj.coef = coef;
+    if ((K & 3) == 0 && Kq == 16)
+        return gemm16_go<true, 16, false, false, false, true, 2, false, true>(b, M, K, hw, 1, w, gy, out, nullptr, pa, pb, relu, s,
+                                                                              PoolOut(), adj);
+    return gemm16_go<true, 16, false, false, false, true, 2, true, true>(b, M, K, hw, 1, w, gy, out, nullptr, pa, pb, relu, s, PoolOut(),
+                                                                         adj);
 }

@@ -26,6 +26,10 @@
 #include "act_io.h"
 
 extern int ogc_g_matmul_bf16; // (conv1x1.hip) operand precision switch
+// (conv1x1_h.hip) the dense adjoint input gradient for 16-bit tensors on the persistent kernel; false: not its shape
+bool ogc_gemm16_adjoint_launch(int b, int M, int K, int hw, int relu, const float *w, const unsigned short *gy,
+                               const unsigned short *yprev, const float *pa, const float *pb, const float *coef,
+                               unsigned short *out, hipStream_t s);
 
 namespace {
 
@@ -750,6 +754,12 @@ int dgrad_adjoint_impl(const char *name, int b, int cin, int cout, int hw, int r
     }
     dim3 grid(ogc_divup(hw, 64 * WG_WAVES), b);
     hipStream_t s = (hipStream_t)stream;
+    if constexpr (sizeof(AT) == 2) { // dense form, enough tiles: the persistent kernel (the same expressions)
+        if (!inj && ogc_gemm16_adjoint_launch(b, M, K, hw, relu, w, grad_y, y_prev, pa, pb, coef, grad_prev, s)) {
+            OGC_CHECK_LAUNCH(name);
+            return OGC_OK;
+        }
+    }
     const float2 *c2 = reinterpret_cast<const float2 *>(coef2), *ij = reinterpret_cast<const float2 *>(inj);
 #define OGC_DGA(KQV)                                                                                                        \
     do {                                                                                                                    \

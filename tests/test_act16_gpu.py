@@ -313,12 +313,16 @@ def test_persistent_kernel_equals_tile_kernel(nat, B, cin, cout, P, S):
             yext = torch.empty(B, cout, P, device=DEV)
             aext = torch.empty(B, cout, P, dtype=torch.int32, device=DEV)
             nat.conv1x1_gemm_affine_pool_wrapper(B, cout, cin, hw, 1, groups, S, w, xh, pa, pb, gamma, y2, st2, yext, aext)
-            dz = None
+            dz = da = None
             if g is not None:
                 dz = torch.empty(B, cin, hw, device=DEV, dtype=BF)
                 nat.conv1x1_gemm_wrapper(B, cin, cout, hw, 1, w, g, dz)
+                # the adjoint input gradient (persistent for <= 64 reduction channels): y_prev = xh, its own coefficients
+                coef = rnd(B, cin, 3, seed=9, scale=0.2)
+                da = torch.empty(B, cin, hw, device=DEV, dtype=BF)
+                nat.conv1x1_dgrad_adjoint_wrapper(B, cin, cout, hw, 1, w, g, xh, pa, pb, coef, da)
             torch.cuda.synchronize()
-            res[mode] = (y0, y1, st.view(slots, B, groups, 2).sum(0), y2, st2.view(slots, B, groups, 2).sum(0), yext, aext, dz)
+            res[mode] = (y0, y1, st.view(slots, B, groups, 2).sum(0), y2, st2.view(slots, B, groups, 2).sum(0), yext, aext, dz, da)
         finally:
             os.environ.pop("OGC_GEMM16", None)
     for k, (a, b) in enumerate(zip(res["0"], res["1"])):
