@@ -574,15 +574,27 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void dgrad_adjoint_kernel(int M
 #pragma unroll
                 for (int c = 0; c < 4; ++c) acc[c] = (v4f){0.f, 0.f, 0.f, 0.f};
                 if constexpr (BF) {
+                    // pairs of groups on v_mfma_f32_16x16x32_bf16, a single last group on the 16x16x16 form — the order of
+                    // conv1x1_gemm16_kernel's adjoint form (conv1x1_h.hip), so that the two kernels agree bit for bit
                     const v4s *a_bf = reinterpret_cast<const v4s *>(a_lds);
 #pragma unroll
-                    for (int g = 0; g < GQ; ++g) {
+                    for (int g = 0; g + 1 < GQ; g += 2) {
+                        if (4 * (g + 1) < Kq) {
+                            const v4s av0 = a_bf[(g * 64 + a * 16 + j) * 4 + kk], av1 = a_bf[((g + 1) * 64 + a * 16 + j) * 4 + kk];
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) acc[c] = ogc_mfma_bf16_k32(av0, av1, xb[g][c], xb[g + 1][c], acc[c]);
+                        } else if (4 * g < Kq) {
+                            const v4s av = a_bf[(g * 64 + a * 16 + j) * 4 + kk];
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, xb[g][c], acc[c], 0, 0, 0);
+                        }
+                    }
+                    if constexpr (GQ % 2 == 1) {
+                        constexpr int g = GQ - 1;
                         if (4 * g < Kq) {
                             const v4s av = a_bf[(g * 64 + a * 16 + j) * 4 + kk];
-                            acc[0] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, xb[g][0], acc[0], 0, 0, 0);
-                            acc[1] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, xb[g][1], acc[1], 0, 0, 0);
-                            acc[2] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, xb[g][2], acc[2], 0, 0, 0);
-                            acc[3] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, xb[g][3], acc[3], 0, 0, 0);
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, xb[g][c], acc[c], 0, 0, 0);
                         }
                     }
                 } else {
