@@ -11,13 +11,8 @@ from .pointnet2 import pointnet2 as _api
 ENABLED = __import__("os").environ.get("OGC_FLOW_GLUE", "1") != "0"   # tests / A-B measurements switch the module off as a whole
 
 
-# Groups switched off (OGC_FLOW_GLUE_OFF=a,b; "none" for all on).  Default: the fused global correlation.  It evaluates the cosine as
-# dot(f1, f2) / (|f1| |f2|) where the reference normalises the features first (flownet_kitti.py:61-63) — the same number up to
-# fp32 rounding, but through exp(-(1 - cos) / eps) and five refinement iterations that moves the validation EPE of the trainer
-# replay (tests/test_driver_golden.py, flow trainer) by ~4e-4, which together with the GRU group's ~3e-4 exceeded that test's
-# budget (8.4e-4) at the end of round 5; either group alone stays inside.  The correlation is one launch at the coarsest level
-# (512 x 512 points), the GRU group is ~20 launches per iteration: the former is the cheaper one to give up.
-OFF = set(filter(None, __import__("os").environ.get("OGC_FLOW_GLUE_OFF", "soft_corr").split(","))) - {"none"}
+# Groups switched off (OGC_FLOW_GLUE_OFF=a,b), for bisecting: linear_cn, soft_corr, gru, advance, gather_pair, three_nn_w.
+OFF = set(filter(None, __import__("os").environ.get("OGC_FLOW_GLUE_OFF", "").split(","))) - {"none"}
 
 
 def available(*tensors, what=None):
@@ -98,8 +93,12 @@ _STACKED = {}   # id(first weight) -> (key, stacked weight)
 
 def stacked_weight(*weights):
     """The 1x1-convolution weights of blocks that read the same input, stacked along the output channels (one product instead of
-    one per block); rebuilt when any of them was written (version counters) or moved."""
-    key = tuple((w.data_ptr(), w._version, tuple(w.shape)) for w in weights)
+    one per block); rebuilt when any of them was written (version counters) or moved, or when any block has been in training mode
+    since (fused.note_training_mode: the fused optimizer writes parameters through raw pointers, which the version counters do not
+    see — a net evaluated, trained further and evaluated again would otherwise use the stacked weights of its first evaluation;
+    found by the flow trainer replay of tests/test_driver_golden.py at the end of round 5)."""
+    from . import fused as _fused
+    key = (_fused._FOLD_GENERATION[0],) + tuple((w.data_ptr(), w._version, tuple(w.shape)) for w in weights)
     hit = _STACKED.get(id(weights[0]))
     if hit is None or hit[0] != key:
         with torch.no_grad():

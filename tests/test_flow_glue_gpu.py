@@ -160,3 +160,39 @@ def test_fps_chain_without_temp_equals_fps():
             xyz = torch.round(xyz)       # a lattice: exact distance ties
         idx, ties = furthest_point_sample_chain(xyz, m)
         assert torch.equal(idx, furthest_point_sample(xyz, m)), (B, N, m)
+
+
+def test_glue_sees_weights_the_fused_optimizer_wrote():
+    """Evaluate, train one step (the fused Adam kernel writes parameters through raw pointers: no version counter moves), evaluate
+    again: the inference glue must use the NEW weights — its stacked gate weights are cached, and were keyed by version counters
+    alone until the flow trainer replay caught the second evaluation running on the first one's weights."""
+    from ogc_amd import flow_glue
+    from ogc_amd.models.flownet_kitti import FlowStep3D
+    from ogc_amd.train_step import make_optimizer
+    from ogc_amd.utils.synthetic import make_scene_batch
+    torch.manual_seed(0)
+    N = 1024
+    net = FlowStep3D(npoint=N, loc_flow_nn=16, loc_flow_rad=1.5).cuda()
+    opt = make_optimizer(net.parameters(), lr=1e-2)
+    pcs = make_scene_batch(1, N, 6, seed=3, aug=False, device="cuda", outdoor=True)[0]
+    pc1, pc2 = pcs[:, 0].contiguous(), pcs[:, 1].contiguous()
+
+    def evaluate(glue):
+        was = flow_glue.ENABLED
+        flow_glue.ENABLED = glue
+        try:
+            net.eval()
+            with torch.no_grad():
+                return net(pc1, pc2, pc1, pc2, iters=3)[-1].clone()
+        finally:
+            flow_glue.ENABLED = was
+
+    first = evaluate(True)
+    net.train()
+    out = net(pc1, pc2, pc1, pc2, iters=2)
+    sum(o.square().mean() for o in out).backward()
+    opt.step()
+    opt.zero_grad()
+    second_on, second_off = evaluate(True), evaluate(False)
+    assert float((second_off - first).abs().max()) > 1e-3          # the step really moved the predictions
+    torch.testing.assert_close(second_on, second_off, rtol=1e-4, atol=1e-5)
