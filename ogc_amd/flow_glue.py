@@ -88,7 +88,9 @@ def gru_blend(zc, qc, hx, c, zc_channel0=0):
     return out
 
 
-_STACKED = {}   # id(first weight) -> (key, stacked weight)
+import weakref as _weakref
+
+_STACKED = {}   # id(first weight) -> (key, stacked weight, weak references to ALL the weights: identity, not id, decides a hit)
 
 
 def stacked_weight(*weights):
@@ -96,13 +98,19 @@ def stacked_weight(*weights):
     one per block); rebuilt when any of them was written (version counters) or moved, or when any block has been in training mode
     since (fused.note_training_mode: the fused optimizer writes parameters through raw pointers, which the version counters do not
     see — a net evaluated, trained further and evaluated again would otherwise use the stacked weights of its first evaluation;
-    found by the flow trainer replay of tests/test_driver_golden.py at the end of round 5)."""
+    found by the flow trainer replay of tests/test_driver_golden.py at the end of round 5).  A hit also needs the cached weak
+    references to BE the weights (tensors cannot key a WeakKeyDictionary: their == is element-wise): an `id()` — or a device
+    address — is reused as soon as a net is freed, and a later net of the same shape must not inherit a dead one's entry."""
     from . import fused as _fused
     key = (_fused._FOLD_GENERATION[0],) + tuple((w.data_ptr(), w._version, tuple(w.shape)) for w in weights)
     hit = _STACKED.get(id(weights[0]))
-    if hit is None or hit[0] != key:
+    if hit is None or hit[0] != key or len(hit[2]) != len(weights) or any(r() is not w for r, w in zip(hit[2], weights)):
+        if len(_STACKED) > 256:   # entries of nets that are gone
+            for k in [k for k, v in _STACKED.items() if any(r() is None for r in v[2])]:
+                del _STACKED[k]
         with torch.no_grad():
-            hit = (key, torch.cat([w.reshape(w.shape[0], -1) for w in weights]).contiguous())
+            hit = (key, torch.cat([w.reshape(w.shape[0], -1) for w in weights]).contiguous(),
+                   tuple(_weakref.ref(w) for w in weights))
         _STACKED[id(weights[0])] = hit
     return hit[1]
 

@@ -63,6 +63,8 @@ class Budget:
             self.worst[k] = max(self.worst[k], abs(w - t))
             ok32 = abs(g - w) <= atol + rtol * abs(w)
             ok64 = abs(g - t) <= atol + rtol * abs(t) + BUDGET * self.worst[k]
+            if os.environ.get("OGC_TEST_VERBOSE"):   # (how far inside the budget a replay lands: tools/flow_glue_bisect.sh)
+                print("BUDGET %s %s: got %.6f ref32 %.6f truth %.6f allowed %.2e" % (what, k, g, w, t, atol + rtol * abs(t) + BUDGET * self.worst[k]))
             assert ok32 or ok64, "%s %s: %r, reference fp32 %r, float64 truth %r (budget %.2e)" % (what, k, g, w, t, BUDGET * self.worst[k])
 
 
