@@ -396,6 +396,50 @@ def measure_extras(pc, a):
     return out
 
 
+def config2_reading(dev, steps=12, warm=4):
+    """BASELINE config 2 next to the headline: config/ogcdr_unsup_synthetic.yaml (segnet_ogcdr, 8 samples x 4 views x 4096 points,
+    `matmul_precision: bf16` = bf16 operands + 16-bit activations inside the set-abstraction MLPs) through the same train_step loop,
+    `steps` steps after `warm`, fresh weights; the operand precision is restored afterwards."""
+    import yaml
+    from ogc_amd import fused
+    from ogc_amd.pointnet2 import pointnet2 as api
+    from ogc_amd.train_seg import build_segnet
+    from ogc_amd.train_step import build_criterion, make_optimizer, train_step
+    from ogc_amd.utils.synthetic import make_scene_batch
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "config", "ogcdr_unsup_synthetic.yaml")) as f:
+        cfg = yaml.safe_load(f)
+    prev = api._native.get_matmul_precision()
+    api._native.set_matmul_precision(cfg.get("matmul_precision", "fp32"))
+    try:
+        torch.manual_seed(cfg["random_seed"])
+        net = build_segnet(cfg).to(dev)
+        crit = build_criterion(cfg["loss"])
+        opt = make_optimizer(net.parameters(), lr=cfg["lr"])
+        batch = make_scene_batch(cfg["batch_size"], cfg["segnet"]["n_point"], cfg["segnet"]["n_slot"], seed=1, outdoor=False, aug=True,
+                                 device=dev)
+        torch.cuda.reset_peak_memory_stats()
+        pre, pend = None, None
+        for i in range(warm + steps):
+            if i == warm:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            pend = train_step(net, crit, opt, batch, 10 ** 6, True, sync=False, prefetched=pre, next_batch=batch)
+            pre = pend.prefetched
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        losses, stepped = pend.result()
+        clouds = cfg["batch_size"] * batch[1].shape[1]
+        return {"workload": "C2 OGC-DR train_seg unsup: segnet_ogcdr, %d samples x %d views x %d pts, matmul_precision %s" %
+                            (cfg["batch_size"], batch[1].shape[1], cfg["segnet"]["n_point"], cfg.get("matmul_precision", "fp32")),
+                "ms_per_step": round(ms, 3), "point_clouds_per_s": round(clouds / ms * 1e3, 1), "steps": steps, "warmup": warm,
+                "dtype": "bf16 operands and bf16-stored activations (ogc_amd.fused.ACT16=%s), fp32 accumulation / statistics / parameters" % fused.ACT16,
+                "optimizer_stepped": bool(stepped), "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
+                "act16_leave": int(fused.GATE_MISSES.get("act16_leave", 0)),
+                "loss_sum": round(float(losses["sum"]), 5)}
+    finally:
+        api._native.set_matmul_precision(prev)
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -581,6 +625,11 @@ def main():
         if not graph_first and world == 1 and not dist.is_initialized():
             graph_reading()
         extras.update(graph_extras)
+        if "c2" not in skip:
+            try:
+                extras["config2_ogcdr_bf16"] = config2_reading(dev)
+            except Exception as err:  # an extra reading must not cost the headline its line
+                extras["config2_ogcdr_bf16"] = {"error": str(err)[:200]}
     if rank == 0:
         offline = load_offline()
         durs = timer.durations_ms()
