@@ -564,6 +564,11 @@ int gemm_launch(int b, int M, int K, int hw, int groups, const float *w, const A
         if (!g_matmul_bf16 && gemm_stream_launch<false, false, false, true>(b, M, K, hw, w, in, out, pa, pb, pro_relu, s))
             return OGC_OK;
     }
+    if constexpr (F32) { // narrow fp32 layers with many position tiles: the persistent kernel of conv1x1_h.hip (same arithmetic)
+        if (!g_matmul_bf16 && ogc_gemm32_launch(T, STATS, PRO, POOL, b, M, K, hw, groups, w, in, out, stats, pa, pb, pro_relu, s,
+                                                pool.sign, pool.yext, pool.aext, pool.s))
+            return OGC_OK;
+    }
     if constexpr (!F32) { // 16-bit tensors: the persistent kernel of conv1x1_h.hip where there are enough position tiles
         if (ogc_gemm16_launch(T, STATS, PRO, POOL, b, M, K, hw, groups, w, in, out, stats, pa, pb, pro_relu, s, pool.sign, pool.yext,
                               pool.aext, pool.s))

@@ -92,3 +92,7 @@ bool ogc_gemm16_launch(bool transpose_a, bool stats_on, bool pro, bool pool_on, 
                        const float *w, const unsigned short *in, unsigned short *out, double *stats, const float *pa,
                        const float *pb, int pro_relu, hipStream_t s, const float *pool_sign, float *pool_yext, int *pool_aext,
                        int pool_s);
+// (conv1x1_h.hip) the persistent kernel for fp32 tensors with <= 64 reduction channels; false when the shape is not its
+bool ogc_gemm32_launch(bool transpose_a, bool stats_on, bool pro, bool pool_on, int b, int M, int K, int hw, int groups,
+                       const float *w, const float *in, float *out, double *stats, const float *pa, const float *pb, int pro_relu,
+                       hipStream_t s, const float *pool_sign, float *pool_yext, int *pool_aext, int pool_s);

@@ -303,6 +303,216 @@ __global__ __launch_bounds__(H_WAVES *OGC_WAVE, OCC) void conv1x1_gemm16_kernel(
     if (STATS) flush_stats();
 }
 
+// ---- the same persistent walk for fp32 tensors with at most 64 reduction channels (round 5, last session) ---------------------------
+// conv1x1_gemm_kernel's narrow fp32 layers — C4's first two levels: 32 -> 32 / 64 and 64 -> 64 / 128 channels on 2.1 M / 1.05 M
+// positions — run at 2.7-3.5 TB/s: the same chain of dependent round trips per four tiles that the 16-bit form exposed, half hidden by
+// twice the bytes.  (Wider layers have conv1x1_gemm_stream_kernel.)  Measured: a gain at 64 reduction channels (3.1 -> 4.0 TB/s),
+// a loss at 32 — the launcher takes K = 33 .. 64 only; the C4 step does not move either way (10.76-10.79 ms).  Operands stay fp32 on v_mfma_f32_16x16x4_f32 and every
+// accumulator sees its products in conv1x1_gemm_kernel's order (row quads ascending): the outputs are bit-identical
+// (tests/test_ops_gpu.py::test_persistent_fp32_kernel_equals_tile_kernel).  Two register sets: the operand tile (transformed in
+// place) and the raw tile of the next step, requested as soon as the operands exist.
+template <bool TRANS, int KQ, bool STATS, bool PRO, bool POOL, int OCC>
+__global__ __launch_bounds__(H_WAVES *OGC_WAVE, OCC) void conv1x1_gemm32_kernel(
+    int M, int K, int hw, int ntiles, int nbatch, int groups, const float *__restrict__ w, const float *__restrict__ in,
+    float *__restrict__ out, double *__restrict__ stats, const float *__restrict__ pa, const float *__restrict__ pb, int pro_relu,
+    PoolOut pool) {
+    extern __shared__ __attribute__((aligned(16))) float h_lds[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 15, kk = lane >> 4;
+    const int Kq = (K + 3) >> 2, Mt = (M + 63) >> 6, a_ld = ogc_a_ld(Kq);
+    const int tiles_per_img = hw >> 6;
+    // LDS: [Mt][64][a_ld] weights | PRO: [wave][2][KQ * 4] | STATS: [wave][Mt * 16][2] doubles | POOL: [Mt * 64] signs
+    float *after_a = h_lds + (size_t)Mt * 64 * a_ld;
+    float *cw = after_a + wave * (2 * KQ * 4);
+    double *sacc = reinterpret_cast<double *>(after_a + (PRO ? H_WAVES * 2 * KQ * 4 : 0)) + wave * (Mt * 32);
+    float *sgn_all = after_a + (PRO ? H_WAVES * 2 * KQ * 4 : 0) + (STATS ? H_WAVES * Mt * 64 : 0);
+    for (int mt = 0; mt < Mt; ++mt) ogc_stage_weight_tile<TRANS, H_WAVES>(h_lds + (size_t)mt * 64 * a_ld, w, mt * 64, M, K, Kq);
+    if constexpr (POOL) {
+        for (int t = threadIdx.x; t < Mt * 64; t += H_WAVES * OGC_WAVE) sgn_all[t] = (t < M && pool.sign[t] < 0.f) ? -1.f : 1.f;
+    }
+    __syncthreads();
+    const int nw = gridDim.x * H_WAVES;
+    const int per = (ntiles + nw - 1) / nw;
+    int t = (blockIdx.x * H_WAVES + wave) * per;
+    const int t_end = min(ntiles, t + per);
+    if (t >= t_end) return;
+    const unsigned off_main = (unsigned)(kk * hw + 4 * j);
+    const unsigned off_last = (unsigned)(min(kk, K - 1 - (Kq - 1) * 4) * hw + 4 * j);
+    auto load_tile = [&](int tt, float4(&x)[KQ]) {
+        tt = min(tt, t_end - 1);
+        const int b = tt / tiles_per_img, p0 = (tt - b * tiles_per_img) * 64;
+        const float *inb = in + (size_t)b * K * hw + p0;
+        unsigned om = off_main, ol = off_last; // (opaque per step: see conv1x1_gemm16_kernel)
+        asm volatile("" : "+v"(om), "+v"(ol));
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+            const float *rowq = inb + (size_t)(min(q, Kq - 1) * 4) * hw;
+            x[q] = *reinterpret_cast<const float4 *>(rowq + (q >= Kq - 1 ? ol : om));
+        }
+    };
+    int coef_b = -1, stat_b = -1;
+    auto flush_stats = [&]() {
+        if constexpr (STATS) {
+            if (stat_b >= 0) {
+                const int cpg = M / groups;
+                double *dst = stats + ((size_t)(blockIdx.x % GN_SLOTS) * nbatch + stat_b) * 2 * groups;
+                for (int sl = lane; sl < Mt * 16; sl += OGC_WAVE) {
+                    const int m = (sl >> 4) * 64 + ((sl >> 2) & 3) * 16 + (sl & 3) * 4;
+                    if (m < M) {
+                        unsafeAtomicAdd(dst + 2 * (m / cpg), sacc[2 * sl]);
+                        unsafeAtomicAdd(dst + 2 * (m / cpg) + 1, sacc[2 * sl + 1]);
+                    }
+                }
+            }
+            for (int sl = lane; sl < Mt * 16; sl += OGC_WAVE) { sacc[2 * sl] = 0.0; sacc[2 * sl + 1] = 0.0; }
+            __builtin_amdgcn_wave_barrier();
+        }
+    };
+    if (STATS) flush_stats();
+
+    float4 raw[KQ], x[KQ];
+    load_tile(t, raw);
+    for (; t < t_end; ++t) {
+        const int b = t / tiles_per_img, p0 = (t - b * tiles_per_img) * 64;
+        int aoff = j * a_ld + kk, coff = kk;
+        unsigned soff = (unsigned)(kk * 4 * hw + 4 * j);
+        asm volatile("" : "+v"(aoff), "+v"(coff), "+v"(soff));
+        if constexpr (STATS) {
+            if (b != stat_b) { flush_stats(); stat_b = b; }
+        }
+        if constexpr (PRO) {
+            if (b != coef_b) {
+                coef_b = b;
+                for (int r = lane; r < KQ * 4; r += OGC_WAVE) {
+                    cw[r] = r < K ? pa[(size_t)b * K + r] : 0.f;
+                    cw[KQ * 4 + r] = r < K ? pb[(size_t)b * K + r] : 0.f;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) { // the operand tile: the folded norm in place; rows beyond K are exact zeros
+            float4 v = raw[q];
+            if constexpr (PRO) {
+                const float ca = cw[q * 4 + coff], cb = cw[KQ * 4 + q * 4 + coff];
+                v.x = fmaf(ca, v.x, cb); v.y = fmaf(ca, v.y, cb); v.z = fmaf(ca, v.z, cb); v.w = fmaf(ca, v.w, cb);
+                if (pro_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            }
+            if (q * 4 + kk >= K) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            x[q] = v;
+        }
+        load_tile(t + 1, raw);
+
+        float *outb = out + (size_t)b * M * hw + p0;
+        for (int mt = 0; mt < Mt; ++mt) {
+            const float *at = h_lds + (size_t)mt * 64 * a_ld;
+            const int nblk = min(4, (M - mt * 64 + 15) >> 4);
+            v4f acc[4][4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[a][c] = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < KQ; ++q) {
+                if (q < Kq) {
+                    float av[4];
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) av[a] = at[a * 16 * a_ld + q * 4 + aoff]; // A[mt * 64 + 16 a + j][4 q + kk]
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        if (a < nblk) {
+                            acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], x[q].x, acc[a][0], 0, 0, 0);
+                            acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], x[q].y, acc[a][1], 0, 0, 0);
+                            acc[a][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], x[q].z, acc[a][2], 0, 0, 0);
+                            acc[a][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], x[q].w, acc[a][3], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int mu = mt * 64 + a * 16 + r;
+                    if (mu + kk * 4 < M)
+                        *reinterpret_cast<float4 *>(outb + (size_t)mu * hw + soff) =
+                            make_float4(acc[a][0][r], acc[a][1][r], acc[a][2][r], acc[a][3][r]);
+                }
+            if constexpr (POOL) {
+                const int m0p = mt * 64;
+                const int centres = hw / pool.s;
+                const int centre = (p0 + 4 * j) / pool.s;
+                const size_t o0 = ((size_t)b * M + m0p + kk * 4) * centres + centre;
+                const float *sg = sgn_all + m0p;
+                if (pool.s == 64) ogc_pool_extremes_epilogue<16>(acc, nblk, sg, j, kk, m0p, M, centres, 64, pool.yext + o0, pool.aext + o0);
+                else if (pool.s == 32) ogc_pool_extremes_epilogue<8>(acc, nblk, sg, j, kk, m0p, M, centres, 32, pool.yext + o0, pool.aext + o0);
+                else ogc_pool_extremes_epilogue<4>(acc, nblk, sg, j, kk, m0p, M, centres, 16, pool.yext + o0, pool.aext + o0);
+            }
+            if constexpr (STATS) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    if (a < nblk) {
+                        float sm = 0.f, sq = 0.f;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                const float v = acc[a][c][r];
+                                sm += v;
+                                sq += v * v;
+                            }
+                        sm += ogc_dpp_f32<0xB1>(sm); sq += ogc_dpp_f32<0xB1>(sq);
+                        sm += ogc_dpp_f32<0x4E>(sm); sq += ogc_dpp_f32<0x4E>(sq);
+                        sm += ogc_dpp_f32<0x141>(sm); sq += ogc_dpp_f32<0x141>(sq);
+                        sm += ogc_dpp_f32<0x140>(sm); sq += ogc_dpp_f32<0x140>(sq);
+                        if (j == 0) {
+                            const int slot = (mt * 4 + a) * 4 + kk;
+                            sacc[2 * slot] += (double)sm;
+                            sacc[2 * slot + 1] += (double)sq;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (STATS) flush_stats();
+}
+
+template <bool TRANS, int KQ, bool STATS, bool PRO, bool POOL, int OCC>
+bool gemm32_go(int b, int M, int K, int hw, int groups, const float *w, const float *in, float *out, double *stats, const float *pa,
+               const float *pb, int pro_relu, hipStream_t s, PoolOut pool) {
+    const int Kq = (K + 3) / 4, Mt = (M + 63) / 64;
+    const size_t lds = ((size_t)Mt * 64 * ogc_a_ld(Kq) + (PRO ? H_WAVES * 2 * KQ * 4 : 0) + (STATS ? H_WAVES * Mt * 64 : 0) +
+                        (POOL ? Mt * 64 : 0)) * sizeof(float);
+    const long long ntiles = (long long)b * (hw / 64);
+    int per_cu = OCC;
+    while (per_cu > 1 && (lds + 512) * per_cu > 156 * 1024) --per_cu;
+    if (lds > 78 * 1024 || ntiles >= (1ll << 31)) return false;
+    static bool raised = false;
+    const void *fn = reinterpret_cast<const void *>(&conv1x1_gemm32_kernel<TRANS, KQ, STATS, PRO, POOL, OCC>);
+    if (!raised) {
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 78 * 1024) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        raised = true;
+    }
+    long long wgs = 256ll * per_cu;
+    if (wgs > ntiles / H_WAVES) wgs = ntiles / H_WAVES;
+    hipLaunchKernelGGL((conv1x1_gemm32_kernel<TRANS, KQ, STATS, PRO, POOL, OCC>), dim3((unsigned)wgs), dim3(H_WAVES * OGC_WAVE), lds, s, M,
+                       K, hw, (int)ntiles, b, groups, w, in, out, stats, pa, pb, pro_relu, pool);
+    return true;
+}
+
+template <bool TRANS, bool STATS, bool PRO, bool POOL>
+bool gemm32_kq(int b, int M, int K, int hw, int groups, const float *w, const float *in, float *out, double *stats, const float *pa,
+               const float *pb, int pro_relu, hipStream_t s, PoolOut pool) {
+    const int Kq = (K + 3) / 4;
+    if (Kq <= 8) return gemm32_go<TRANS, 8, STATS, PRO, POOL, 2>(b, M, K, hw, groups, w, in, out, stats, pa, pb, pro_relu, s, pool);
+    if (Kq <= 16) return gemm32_go<TRANS, 16, STATS, PRO, POOL, 2>(b, M, K, hw, groups, w, in, out, stats, pa, pb, pro_relu, s, pool);
+    return false;
+}
+
 size_t gemm16_lds(int M, int K, int KQ, bool stats_on, bool pro, bool pool_on, bool adj = false) {
     const int Kq = (K + 3) / 4, Gq = (Kq + 3) / 4, Mt = (M + 63) / 64;
     return ((size_t)Mt * Gq * 512 + (pro ? H_WAVES * 2 * KQ * 4 : 0) + (stats_on ? H_WAVES * Mt * 64 : 0) + (pool_on ? Mt * 64 : 0) +
@@ -396,4 +606,35 @@ bool ogc_gemm16_adjoint_launch(int b, int M, int K, int hw, int relu, const floa
                                                                               PoolOut(), adj);
     return gemm16_go<true, 16, false, false, false, true, 2, true, true>(b, M, K, hw, 1, w, gy, out, nullptr, pa, pb, relu, s, PoolOut(),
                                                                          adj);
+}
+
+// The persistent fp32 kernel for this call (fp32 operands, <= 64 reduction channels, >= 8192 position tiles), or false.
+// OGC_GEMM32=0: the tile kernel (A/B runs, tests).
+bool ogc_gemm32_launch(bool transpose_a, bool stats_on, bool pro, bool pool_on, int b, int M, int K, int hw, int groups,
+                       const float *w, const float *in, float *out, double *stats, const float *pa, const float *pb, int pro_relu,
+                       hipStream_t s, const float *pool_sign, float *pool_yext, int *pool_aext, int pool_s) {
+    const char *e = getenv("OGC_GEMM32");
+    if (e && e[0] == '0') return false;
+    // 33 .. 64 reduction channels only: at 32 the tile kernel (32 registers of tile, five wavefronts per SIMD) is the faster one —
+    // 16 x 131072 positions, 32 -> 32: 0.168 against 0.179 ms, pooled 32 -> 64: 0.234 against 0.284; 64 -> 64 on 16 x 65536: 0.173
+    // against 0.134, pooled 64 -> 128: 0.292 against 0.270 (tools/gemm32_bench.py).  OGC_GEMM32=all: every K <= 64 (tests).
+    const bool all = e && e[0] == 'a';
+    if ((hw & 63) != 0 || (long long)b * (hw / 64) < 8192 || K > 64 || (K <= 32 && !all)) return false;
+    PoolOut pool;
+    pool.yext = pool_yext; pool.aext = pool_aext; pool.sign = pool_sign; pool.s = pool_s;
+#define H_GO(T, ST, PR, PO) return gemm32_kq<T, ST, PR, PO>(b, M, K, hw, groups, w, in, out, stats, pa, pb, pro_relu, s, pool)
+    if (transpose_a) {
+        if (!stats_on && !pro && !pool_on) H_GO(true, false, false, false);
+        return false;
+    }
+    if (pool_on) {
+        if (stats_on && pro) H_GO(false, true, true, true);
+        return false;
+    }
+    if (stats_on && pro) H_GO(false, true, true, false);
+    if (stats_on && !pro) H_GO(false, true, false, false);
+    if (!stats_on && pro) H_GO(false, false, true, false);
+    if (!stats_on && !pro) H_GO(false, false, false, false);
+#undef H_GO
+    return false;
 }

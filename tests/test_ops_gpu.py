@@ -1291,3 +1291,56 @@ def test_split_and_single_workgroup_builds_agree_on_non_finite_points(tmp_path, 
     assert list(hdrs["8"][:, 7]) == [4094, 4094, 4096]  # npts: the fully finite points
     want = oracle.ball_query(1.5, 32, pc, pc)
     assert np.array_equal(rows["0"], want) and np.array_equal(rows["8"], want)
+
+
+@pytest.mark.parametrize("B,cin,cout,P,S", [(32, 32, 32, 256, 64), (32, 32, 64, 256, 64), (32, 64, 128, 256, 64), (16, 6, 32, 512, 64),
+                                            (32, 30, 64, 256, 64), (64, 64, 64, 512, 16)])
+def test_persistent_fp32_kernel_equals_tile_kernel(nat, B, cin, cout, P, S):
+    """conv1x1_gemm32_kernel (csrc/conv1x1_h.hip: persistent workgroups for fp32 layers of <= 64 reduction channels and >= 8192
+    position tiles) against conv1x1_gemm_kernel (OGC_GEMM32=0): identical outputs and neighbourhood extremes — every accumulator
+    sees the same products in the same order —, statistics equal up to the order of their fp64 additions."""
+    import os
+    hw, groups = P * S, 4
+    assert B * (hw // 64) >= 8192
+    g = torch.Generator().manual_seed(cin * 100 + cout)
+    x = torch.randn(B, cin, hw, generator=g).to(DEV)
+    w = (torch.randn(cout, cin, generator=g) / cin ** 0.5).to(DEV)
+    pa, pb = (torch.rand(B * cin, generator=g) + 0.5).to(DEV), torch.randn(B * cin, generator=g).to(DEV)
+    gamma = torch.randn(cout, generator=g).to(DEV)
+    gy = torch.randn(B, cout, hw, generator=g).to(DEV)
+    slots = nat.conv1x1_gn_slots()
+    res = {}
+    for mode in ("0", "all"):   # ("all": every K <= 64; the default leaves K <= 32 to the tile kernel, which is faster there)
+        os.environ["OGC_GEMM32"] = mode
+        try:
+            y0 = torch.empty(B, cout, hw, device=DEV)
+            nat.conv1x1_gemm_affine_wrapper(B, cout, cin, hw, 1, 0, w, x, pa, pb, y0, None)
+            st = torch.zeros(slots * B * groups * 2, dtype=torch.float64, device=DEV)
+            y1 = torch.empty_like(y0)
+            nat.conv1x1_gemm_affine_wrapper(B, cout, cin, hw, 1, groups, w, x, pa, pb, y1, st)
+            st2 = torch.zeros_like(st)
+            y2 = torch.empty_like(y0)
+            yext = torch.empty(B, cout, P, device=DEV)
+            aext = torch.empty(B, cout, P, dtype=torch.int32, device=DEV)
+            nat.conv1x1_gemm_affine_pool_wrapper(B, cout, cin, hw, 1, groups, S, w, x, pa, pb, gamma, y2, st2, yext, aext)
+            st3 = torch.zeros_like(st)
+            y3 = torch.empty_like(y0)
+            nat.conv1x1_gemm_gnstats_wrapper(B, cout, cin, hw, groups, w, x, y3, st3)
+            y4 = torch.empty_like(y0)
+            nat.conv1x1_gemm_wrapper(B, cout, cin, hw, 0, w, x, y4)
+            dz = None
+            if cout <= 32:   # (plain input gradients of wider layers go to ogc_conv1x1_gemm_any in the product)
+                dz = torch.empty(B, cin, hw, device=DEV)
+                nat.conv1x1_gemm_wrapper(B, cin, cout, hw, 1, w, gy, dz)
+            torch.cuda.synchronize()
+            sums = lambda s_: s_.view(slots, B, groups, 2).sum(0)
+            res[mode] = (y0, y1, sums(st), y2, sums(st2), yext, aext, y3, sums(st3), y4, dz)
+        finally:
+            os.environ.pop("OGC_GEMM32", None)
+    for k, (a, b) in enumerate(zip(res["0"], res["all"])):
+        if a is None:
+            continue
+        if a.dtype == torch.float64:
+            assert torch.allclose(a, b, rtol=1e-11, atol=1e-6), k
+        else:
+            assert torch.equal(a, b), k
