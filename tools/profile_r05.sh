@@ -27,4 +27,5 @@ timeout 300 python tools/library_gemms.py > "$out/library_gemms.txt" 2>&1
 bash tools/c2_kernels.sh > /dev/null 2>&1; cp gpurun_out/c2/kernels.txt "$out/c2_kernels.txt" 2>/dev/null
 { echo "persistent kernel (conv1x1_h.hip)"; timeout 300 python tools/gemm16_bench.py 2>&1 | grep "TB/s"; echo "tile kernel (OGC_GEMM16=0)"; OGC_GEMM16=0 timeout 300 python tools/gemm16_bench.py 2>&1 | grep "TB/s"; } > "$out/c2_forward_kernels.txt"
 { for sw in "" "OGC_GEMM16=0" "OGC_ACT16=0" "OGC_ACT16_MOMENT_WIDTH=128"; do echo "== ${sw:-default}"; env $sw timeout 300 python tools/bench_config.py config/ogcdr_unsup_synthetic.yaml 20 2>&1 | grep "ms/step"; done; } > "$out/c2_switches.txt"
+bash tools/pmc_c2.sh > "$out/c2_hbm_traffic.txt" 2> "$out/c2_hbm_traffic.err"
 tail -1 "$out/bench_line.json" | cut -c1-200
