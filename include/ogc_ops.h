@@ -685,6 +685,11 @@ int ogc_zero_arena_end(void);
  * otherwise.  ogc_conv1x1_wgrad_xf_h: x fp32 (the relative coordinates of a grouped first layer), dy bf16. */
 int ogc_group_linear_fwd_h(int b, int m, int n, int npoints, int nsample, int groups, const float *P, const int *idx,
                            const float *rel, const float *wx, ogc_bf16_t *y, double *stats, ogc_stream_t stream);
+/* ... with P stored point-major, Pt (b, n, m): a position's channels are contiguous and one lane fetches them with 16-byte loads
+ * (a quarter of the cache-line lookups of the channel-major gather, which bound the 16-bit form).  m % 64 == 0, m / groups in
+ * {16, 32, 64} (or groups == 0), an even position count; y bit-identical to ogc_group_linear_fwd_h on the transposed P. */
+int ogc_group_linear_fwd_pt_h(int b, int m, int n, int npoints, int nsample, int groups, const float *Pt, const int *idx,
+                              const float *rel, const float *wx, ogc_bf16_t *y, double *stats, ogc_stream_t stream);
 int ogc_group_points_grad_rev_h(int b, int c, int n, int npoints, int nsample, const ogc_bf16_t *grad_out, const int *rev_start,
                                 const unsigned short *rev_pos, const unsigned short *heads, float *grad_points,
                                 ogc_stream_t stream);

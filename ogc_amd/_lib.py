@@ -136,6 +136,7 @@ for _n in ("ogc_group_linear_fwd", "ogc_group_points_grad_rev", "ogc_conv1x1_gem
            "ogc_group_norm_maxpool_bwd_sparse"):
     SIGNATURES[_n + "_h"] = SIGNATURES[_n]
 SIGNATURES["ogc_conv1x1_wgrad_xf_h"] = SIGNATURES["ogc_conv1x1_wgrad"]
+SIGNATURES["ogc_group_linear_fwd_pt_h"] = SIGNATURES["ogc_group_linear_fwd"]
 
 HEADER_VERSION = 202   # OGC_VERSION of include/ogc_ops.h the SIGNATURES table above was written against
 _lib = None

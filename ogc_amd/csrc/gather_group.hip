@@ -529,6 +529,138 @@ extern "C" int ogc_group_linear_fwd_h(int b, int m, int n, int npoints, int nsam
     return group_linear_fwd_impl<ogc_bf16>(b, m, n, npoints, nsample, groups, P, idx, rel, wx, y, stats, stream);
 }
 
+namespace {
+// ---- the same layer for 16-bit outputs with P stored POINT-MAJOR ------------------------------------------------------------------
+// group_linear_fwd_kernel reads P (b, m, n) with one four-byte gather per output element — 268 M of them for C2's first level, each
+// its own cache-line lookup, which is what its 0.32 ms are once the output is written as bf16 (0.54 GB: 1.7 TB/s).  Here P is
+// (b, n, m): a position's 64 channels are 256 contiguous bytes, fetched as sixteen 16-byte loads by the ONE lane that owns the
+// position (a quarter of the lookups, four channels each).  A lane owns two consecutive positions, so that every channel leaves as
+// a 4-byte store and a wavefront writes 256 contiguous bytes per channel; a workgroup handles 64 channels (blockIdx.y picks the
+// slice) of GLP_ITERS x 512 positions.  Same expression per element as group_linear_fwd_kernel (fmaf chain over x, y, z on top of
+// P), outputs rounded before the statistics: y is bit-identical, the statistics differ in the order of their additions.
+// CG: channels per GroupNorm group (16, 32 or 64: compile time, so that the per-group sums index registers).
+constexpr int GLP_ITERS = 4;
+
+template <int CG>
+__global__ __launch_bounds__(GG_THREADS) void group_linear_fwd_pt_kernel(int m, int n, int T, int groups, int with_stats,
+                                                                         const float *__restrict__ Pt,  // (b, n, m)
+                                                                         const int *__restrict__ idx,   // (b, T)
+                                                                         const float *__restrict__ rel, // (b, 3, T)
+                                                                         const float *__restrict__ wx,  // (m, 3)
+                                                                         ogc_bf16 *__restrict__ y,      // (b, m, T)
+                                                                         double *__restrict__ stats) {
+    constexpr int NG = 64 / CG; // groups inside the workgroup's 64 channels
+    __shared__ float s_wx[64 * 3];
+    __shared__ double red[GG_THREADS / 64][NG][2];
+    const int b = blockIdx.z, c0 = blockIdx.y * 64;
+    for (int e = threadIdx.x; e < 64 * 3; e += GG_THREADS) s_wx[e] = c0 + e / 3 < m ? wx[(c0 + e / 3) * 3 + e % 3] : 0.f;
+    __syncthreads();
+    double dgs[NG], dgss[NG]; // per iteration the fp32 partial sums of 2 x CG values move into fp64
+#pragma unroll
+    for (int g = 0; g < NG; ++g) dgs[g] = dgss[g] = 0.0;
+    const int *ib = idx + (size_t)b * T;
+    const float *rb = rel + (size_t)b * 3 * T;
+    const float *pb_ = Pt + (size_t)b * n * m + c0;
+    ogc_bf16 *yb = y + ((size_t)b * m + c0) * T;
+    for (int it = 0; it < GLP_ITERS; ++it) {
+        const int t2 = ((blockIdx.x * GLP_ITERS + it) * GG_THREADS + threadIdx.x) * 2;
+        if (t2 >= T) break;
+        const int2 i2 = *reinterpret_cast<const int2 *>(ib + t2);
+        const float2 rx = *reinterpret_cast<const float2 *>(rb + t2), ry = *reinterpret_cast<const float2 *>(rb + T + t2),
+                     rz = *reinterpret_cast<const float2 *>(rb + 2 * (size_t)T + t2);
+        const float4 *p0 = reinterpret_cast<const float4 *>(pb_ + (size_t)i2.x * m);
+        const float4 *p1 = reinterpret_cast<const float4 *>(pb_ + (size_t)i2.y * m);
+        float gs[NG], gss[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) gs[g] = gss[g] = 0.f;
+        float4 a[16], c[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) a[q] = p0[q];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) c[q] = p1[q];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float pa4[4] = {a[q].x, a[q].y, a[q].z, a[q].w}, pc4[4] = {c[q].x, c[q].y, c[q].z, c[q].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ch = q * 4 + e;
+                const float w0 = s_wx[ch * 3], w1 = s_wx[ch * 3 + 1], w2 = s_wx[ch * 3 + 2];
+                float v0 = fmaf(w2, rz.x, fmaf(w1, ry.x, fmaf(w0, rx.x, pa4[e])));
+                float v1 = fmaf(w2, rz.y, fmaf(w1, ry.y, fmaf(w0, rx.y, pc4[e])));
+                v0 = ogc_as_stored<ogc_bf16>(v0);
+                v1 = ogc_as_stored<ogc_bf16>(v1);
+                if (c0 + ch < m)
+                    *reinterpret_cast<unsigned *>(yb + (size_t)ch * T + t2) = (__float_as_uint(v0) >> 16) | (__float_as_uint(v1) & 0xFFFF0000u);
+                gs[ch / CG] += v0 + v1;
+                gss[ch / CG] += v0 * v0 + v1 * v1;
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < NG; ++g) { dgs[g] += (double)gs[g]; dgss[g] += (double)gss[g]; }
+    }
+    if (with_stats) { // uniform
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            double ds = dgs[g], dss = dgss[g];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                ds += __shfl_down(ds, off, 64);
+                dss += __shfl_down(dss, off, 64);
+            }
+            if (lane == 0) { red[wave][g][0] = ds; red[wave][g][1] = dss; }
+        }
+        __syncthreads();
+        if (threadIdx.x < NG * 2) {
+            const int g = threadIdx.x >> 1, which = threadIdx.x & 1;
+            double v = 0.0;
+            for (int w = 0; w < GG_THREADS / 64; ++w) v += red[w][g][which];
+            const int gg = c0 / CG + g;
+            if (gg < groups)
+                atomicAdd(stats + (((size_t)(blockIdx.x % GL_SLOTS) * gridDim.z + b) * groups + gg) * 2 + which, v);
+        }
+    }
+}
+} // namespace
+
+// ogc_group_linear_fwd_h with P stored point-major, Pt (b, n, m) — see group_linear_fwd_pt_kernel.  Needs m % 64 == 0, groups in
+// {0} or m / groups in {16, 32, 64}, npoints * nsample % 2 == 0, n * m and m * T below 2^31 (OGC_ERR_UNSUPPORTED otherwise: the
+// caller keeps the channel-major form).
+extern "C" int ogc_group_linear_fwd_pt_h(int b, int m, int n, int npoints, int nsample, int groups, const float *Pt,
+                                         const int *idx, const float *rel, const float *wx, ogc_bf16_t *y, double *stats,
+                                         ogc_stream_t stream) {
+    OGC_REQUIRE(b >= 0 && m >= 1 && n >= 1 && npoints >= 0 && nsample >= 0 && groups >= 0 &&
+                    (long long)npoints * nsample < (1ll << 31),
+                "ogc_group_linear_fwd_pt_h: bad dimensions");
+    const int T = npoints * nsample;
+    if (b == 0 || T == 0) return OGC_OK;
+    OGC_REQUIRE(Pt && idx && rel && wx && y && (stats || groups == 0), "ogc_group_linear_fwd_pt_h: null pointer");
+    const int cg = groups > 0 ? m / groups : 64;
+    if ((m & 63) != 0 || (T & 1) != 0 || (groups > 0 && (m % groups != 0 || (cg != 16 && cg != 32 && cg != 64))) ||
+        (long long)m * T >= (1ll << 31) || (long long)m * n >= (1ll << 31) || b > 65535 ||
+        (((uintptr_t)Pt) & 15) != 0 || (((uintptr_t)idx | (uintptr_t)rel) & 7) != 0 || (((uintptr_t)y) & 3) != 0) {
+        ogc_set_error("ogc_group_linear_fwd_pt_h: needs m %% 64 == 0, m / groups in {16, 32, 64}, an even position count and aligned tensors");
+        return OGC_ERR_UNSUPPORTED;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (groups > 0 && ogc_zero_async(stats, sizeof(double) * 2 * GL_SLOTS * (size_t)b * groups, s) != hipSuccess) {
+        ogc_set_error("ogc_group_linear_fwd_pt_h: memset failed");
+        return OGC_ERR_LAUNCH;
+    }
+    dim3 grid(ogc_divup(T, GG_THREADS * 2 * GLP_ITERS), m / 64, b);
+#define GLP(CGV) hipLaunchKernelGGL(group_linear_fwd_pt_kernel<CGV>, grid, dim3(GG_THREADS), 0, s, m, n, T, groups, groups > 0 ? 1 : 0, \
+                                    Pt, idx, rel, wx, y, stats)
+    if (cg == 16) GLP(16);
+    else if (cg == 32) GLP(32);
+    else GLP(64);
+#undef GLP
+    OGC_CHECK_LAUNCH("ogc_group_linear_fwd_pt_h");
+    return OGC_OK;
+}
+
+namespace {
+} // namespace
+
 extern "C" int ogc_group_linear_bwd(int b, int m, int n, int npoints, int nsample, const float *grad_y, const int *idx,
                                     const float *rel, float *grad_p, float *dwx, ogc_stream_t stream) {
     OGC_REQUIRE(b >= 0 && m >= 1 && n >= 1 && npoints >= 0 && nsample >= 0 &&

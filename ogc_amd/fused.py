@@ -1310,7 +1310,13 @@ class _GroupedFirstLayer(Function):
         stats = None
         if gn_groups > 0:
             stats = zeroed_empty(nat.conv1x1_gn_slots() * B * gn_groups * 2, torch.float64, xyz.device)
-        nat.group_linear_fwd_wrapper(B, M, N, npoint, nsample, gn_groups, P, idx, rel, wx, y, stats)
+        cg = M // gn_groups if gn_groups > 0 else 64
+        if (act16 and GROUP_LINEAR_POINT_MAJOR and M % 64 == 0 and cg in (16, 32, 64) and (npoint * nsample) % 2 == 0
+                and getattr(nat, "group_linear_fwd_pt_wrapper", None) is not None):
+            # 16-bit output: P point-major, so that a position's channels are one contiguous read (csrc/gather_group.hip)
+            nat.group_linear_fwd_pt_wrapper(B, M, N, npoint, nsample, gn_groups, P.transpose(1, 2).contiguous(), idx, rel, wx, y, stats)
+        else:
+            nat.group_linear_fwd_wrapper(B, M, N, npoint, nsample, gn_groups, P, idx, rel, wx, y, stats)
         ctx.save_for_backward(features, idx, rel, weight)
         if stats is not None:
             ctx.mark_non_differentiable(stats)
@@ -1369,6 +1375,7 @@ def grouped_first_layer_available(xyz, new_xyz, features, idx, conv, gn):
             and (gn is None or (gn.num_groups <= 32 and conv.weight.shape[0] % gn.num_groups == 0)))
 
 
+GROUP_LINEAR_POINT_MAJOR = _os.environ.get("OGC_GROUP_LINEAR_PT", "1") != "0"   # (16-bit first layers: P stored (B, N, M))
 GROUP_GRAD_GATHER = True   # grouping gradient as a gather over transposed lists when the geometry plan has them
 GROUP_GRAD_GATHER_MIN_FANIN = 24
 

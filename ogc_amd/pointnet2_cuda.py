@@ -327,6 +327,12 @@ def group_linear_fwd_wrapper(b, m, n, npoints, nsample, groups, P, idx, rel, wx,
          _f(wx, "wx"), yp, _opt(stats, torch.float64, "stats"))
 
 
+def group_linear_fwd_pt_wrapper(b, m, n, npoints, nsample, groups, Pt, idx, rel, wx, y, stats):
+    """group_linear_fwd_wrapper for a bf16 y with P stored point-major, Pt (b, n, m) (ogc_group_linear_fwd_pt_h)."""
+    _run("ogc_group_linear_fwd_pt_h", Pt, b, m, n, npoints, nsample, int(groups), _f(Pt, "Pt"), _i(idx, "idx"), _f(rel, "rel"),
+         _f(wx, "wx"), _check(y, torch.bfloat16, "y"), _opt(stats, torch.float64, "stats"))
+
+
 def group_linear_bwd_wrapper(b, m, n, npoints, nsample, grad_y, idx, rel, grad_p, dwx):
     """grad_p += scatter of grad_y, dwx += grad_y . rel in one pass over grad_y (ogc_group_linear_bwd); both zeroed by
     the caller.  Raises OgcOpsError (unsupported) outside n <= 16384, npoints * nsample >= 4096 and % 16 == 0."""

@@ -183,6 +183,17 @@ def test_grouped_first_layer_h(nat):
     sums = sth.view(slots, B, groups, 2).sum(0)
     assert torch.allclose(sums[..., 1], (v * v).sum(-1), rtol=1e-6)
     assert torch.allclose(sums[..., 0], v.sum(-1), rtol=1e-6, atol=1e-3 * v.abs().sum(-1).max().item())
+    # P point-major: the same y bit for bit, the same statistics up to the order of their additions
+    for Mv, gv in ((64, 4), (128, 4), (64, 1), (128, 8)):
+        Pv = rnd(B, Mv, N, seed=7)
+        wv = rnd(Mv, 3, seed=8)
+        ya, yb_ = (torch.empty(B, Mv, P, S, device=DEV, dtype=BF) for _ in range(2))
+        sa, sb = (torch.zeros(slots * B * gv * 2, dtype=torch.float64, device=DEV) for _ in range(2))
+        nat.group_linear_fwd_wrapper(B, Mv, N, P, S, gv, Pv, idx, relc, wv, ya, sa)
+        nat.group_linear_fwd_pt_wrapper(B, Mv, N, P, S, gv, Pv.transpose(1, 2).contiguous(), idx, relc, wv, yb_, sb)
+        assert torch.equal(ya, yb_)
+        ra, rb_ = sa.view(slots, B, gv, 2).sum(0), sb.view(slots, B, gv, 2).sum(0)
+        assert torch.allclose(ra[..., 1], rb_[..., 1], rtol=1e-6) and torch.allclose(ra[..., 0], rb_[..., 0], rtol=1e-6, atol=1e-5 * float(ya.float().abs().sum() / (B * gv)))
     # gradient: gather over the transposed lists, and the three coordinate columns of the weight gradient
     from ogc_amd import fused
     rev = fused.group_reverse(idx, N)
