@@ -945,12 +945,20 @@ __global__ __launch_bounds__(OGC_WAVE) void ball_query_grid_kernel(int n, int m,
 // rows leave straight from the registers — no loop, no LDS round trip after two reads.  The rows are those of the
 // reference's index-ordered scan, as with the other kernel.  A wavefront with a longer list, and every wavefront of a
 // cloud the build flagged dense or heavy, runs the general body above (twice: eight centres each).
+#ifndef OGC_BQ_STRIP_PAD
+#define OGC_BQ_STRIP_PAD 0
+#endif
 constexpr int CL = 4;                 // lanes per centre
 constexpr int CPW = OGC_WAVE / CL;    // centres per wavefront
 constexpr int BQ_FAST = 32;           // hits per centre the register sort holds
 constexpr int BQ_CAP = 64;            // hit slots per centre (slot BQ_CAP takes the misses; also the general body's lists)
 constexpr int BQ_SEG = 20;            // ints per lane of a centre's LDS strip: 16 private hit slots, slot 16 takes misses / overflow
-constexpr int BQ_LIST = CL * BQ_SEG;  // ints per centre (the compacted list of up to BQ_CAP hits + sentinels lives in the same strip)
+// ints per centre (the compacted list of up to BQ_CAP hits + sentinels lives in the same strip) + BQ_STRIP_PAD.  With 80 ints per
+// centre the sixteen strips of a wavefront start in two banks only (80 mod 32 = 16); padding the strips to 84 spreads them over
+// eight start banks but costs the eighth wavefront per SIMD (5376 bytes per wavefront: 18.1 against 16.9 us) — the pad stays 0 and
+// the MISSES, which are most of the stores, go to one of the four spare slots of a lane's segment by centre pair instead
+constexpr int BQ_STRIP_PAD = OGC_BQ_STRIP_PAD;
+constexpr int BQ_LIST = CL * BQ_SEG + BQ_STRIP_PAD;
 constexpr int BQ_RUN = 128;           // longest run the slab walk takes (a longer one sends the wavefront to the general body)
 constexpr int BQ_PAD = BQ_RUN + 32;   // records readable past the end of the cell-sorted array (lanes whose run has ended read on)
 
@@ -1038,11 +1046,14 @@ __global__ __launch_bounds__(OGC_WAVE * WPB, 8) void ball_query_cells_kernel(int
         // the seventeenth hit of a lane (the count goes on: such a wavefront is redone by the general body).
         int cnt_l = 0; // my hits
         bool crowded = false; // (wave-uniform) a single centre's candidates do not fit the LDS strip: the general body takes over
+        // (slots 16 .. 19 of a segment are spare: a miss goes to 16 + (centre pair mod 4), so that the eight centres whose strips
+        // start in the same bank spread their — frequent — miss stores over four banks instead of one)
+        const int miss = 16 + ((g >> 1) & 3);
         auto slots = [&](bool has_a, bool near_a, bool has_b, bool near_b, int ia, int ib) {
             const bool hit_a = has_a && near_a, hit_b = has_b && near_b;
-            seg[hit_a ? min(cnt_l, 16) : 16] = ia;
+            seg[hit_a ? min(cnt_l, 16) : miss] = ia;
             cnt_l += hit_a ? 1 : 0;
-            seg[hit_b ? min(cnt_l, 16) : 16] = ib;
+            seg[hit_b ? min(cnt_l, 16) : miss] = ib;
             cnt_l += hit_b ? 1 : 0;
         };
         const char *pts_bytes = reinterpret_cast<const char *>(pts);
