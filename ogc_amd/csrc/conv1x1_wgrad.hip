@@ -589,6 +589,191 @@ __global__ __launch_bounds__(256, 2) void conv1x1_wgrad_shared_kernel(int batch,
             }
 }
 
+// ---- the shared 128 x 128 tile for 16-bit tensors -----------------------------------------------------------------------------------
+// conv1x1_wgrad_shared_kernel with bf16 tensors still moves 8 bytes per lane and load, parks fp32 in LDS and lets every wavefront
+// convert what it reads (each value twice): 128 -> 256 pooled at C2 0.71 ms for 1.6 GB.  Here a stage is 64 positions: a thread
+// loads SIXTEEN bytes (8 positions of one row; 8 pieces x 32 rows per pass, four passes for the 128 + 128 rows), transforms once
+// (PRO / POOLED: the expressions of the kernel above) and parks the values as PACKED bf16 (row stride 72 elements = 144 bytes: the
+// 8-byte operand reads of a 16-lane row group fall into distinct bank pairs); a wavefront reads its operands ready-made — lane
+// (i, k): row i, positions 8 k .. 8 k + 7 of a 32-position half: one v_mfma_f32_16x16x32_bf16 per accumulator and half stage.
+constexpr int W16_POS = 64;            // positions per stage
+constexpr int W16_LD = W16_POS + 8;    // row stride in LDS (bf16 elements)
+
+template <bool PRO, bool POOLED>
+__global__ __launch_bounds__(256, 2) void conv1x1_wgrad_shared16_kernel(int batch, int cin, int cout, int hw, int stages_per_wg,
+                                                                        const ogc_bf16 *__restrict__ x, const ogc_bf16 *__restrict__ dy,
+                                                                        float *__restrict__ dw, const float *__restrict__ aff_a,
+                                                                        const float *__restrict__ aff_b, int pro_relu,
+                                                                        const float2 *__restrict__ coef2,
+                                                                        const float2 *__restrict__ inj, int s_shift) {
+    constexpr int YROWS = 128, W_ROWS = YROWS + 128, YJ = 4, XJ = 4, NJ = YJ + XJ; // pieces per thread: dy, x
+    constexpr int RSTEP = 32;                                                    // rows between a thread's pieces
+    extern __shared__ __attribute__((aligned(16))) ogc_bf16 w16_lds[]; // [2][W_ROWS][W16_LD]
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int i = lane & 15, k = lane >> 4;
+    const int co0 = blockIdx.y * YROWS, ci0 = blockIdx.z * 128;
+    const int half_r = wave >> 1, half_c = wave & 1;
+    const int stages_per_img = hw / W16_POS;
+    const long long nstages = (long long)batch * stages_per_img;
+    const long long first = (long long)blockIdx.x * stages_per_wg;
+    const int mine = (int)max(0LL, min((long long)stages_per_wg, nstages - first));
+    if (mine == 0) return;
+
+    const int q = t & 7, rr = t >> 3; // piece q (8 positions) of rows rr + RSTEP j
+    int grow[NJ], lrow[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int r = rr + RSTEP * (j < YJ ? j : j - YJ);
+        grow[j] = j < YJ ? min(co0 + r, cout - 1) : min(ci0 + r, cin - 1);
+        lrow[j] = (j < YJ ? r : YROWS + r) * W16_LD + 8 * q;
+    }
+    const int centres = POOLED ? hw >> s_shift : 0;
+    int cur_b = (int)(first / stages_per_img);
+    int cur_off = (int)(first - (long long)cur_b * stages_per_img);
+
+    uint4 raw[NJ];
+    float fa[XJ], fb[XJ];
+    float2 cc[YJ], jv[YJ];
+    int jpos = 0;
+    auto fetch = [&]() {
+        const int pos = cur_off * W16_POS + 8 * q;
+        const ogc_bf16 *yb_ = dy + (size_t)cur_b * cout * hw + pos;
+        const ogc_bf16 *xb_ = x + (size_t)cur_b * cin * hw + pos;
+#pragma unroll
+        for (int j = 0; j < YJ; ++j) raw[j] = *reinterpret_cast<const uint4 *>(yb_ + (size_t)grow[j] * hw);
+#pragma unroll
+        for (int j = YJ; j < NJ; ++j) raw[j] = *reinterpret_cast<const uint4 *>(xb_ + (size_t)grow[j] * hw);
+        if constexpr (POOLED) { // a piece's eight positions lie inside one neighbourhood (S >= 16)
+#pragma unroll
+            for (int j = 0; j < YJ; ++j) {
+                const size_t r = (size_t)cur_b * cout + grow[j];
+                cc[j] = coef2[r];
+                jv[j] = inj[r * centres + (pos >> s_shift)];
+            }
+            jpos = pos & ((1 << s_shift) - 1);
+        }
+        if constexpr (PRO) {
+#pragma unroll
+            for (int j = 0; j < XJ; ++j) {
+                fa[j] = aff_a[(size_t)cur_b * cin + grow[YJ + j]];
+                fb[j] = aff_b[(size_t)cur_b * cin + grow[YJ + j]];
+            }
+        }
+        if (++cur_off == stages_per_img) { cur_off = 0; ++cur_b; }
+    };
+    auto park = [&](ogc_bf16 *buf) {
+#pragma unroll
+        for (int j = 0; j < YJ; ++j) {
+            uint4 o = raw[j];
+            if constexpr (POOLED) {
+                float f[8];
+                ogc_unpack8(raw[j], f);
+                const int rel = __float_as_int(jv[j].y) - jpos;
+                const float ag = jv[j].x;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = fmaf(cc[j].x, f[e], cc[j].y) + (rel == e ? ag : 0.f);
+                const v4s lo = ogc_pack_bf16(f[0], f[1], f[2], f[3]), hi = ogc_pack_bf16(f[4], f[5], f[6], f[7]);
+                const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+                o = make_uint4(l2.x, l2.y, h2.x, h2.y);
+            }
+            *reinterpret_cast<uint4 *>(buf + lrow[j]) = o;
+        }
+#pragma unroll
+        for (int j = 0; j < XJ; ++j) {
+            uint4 o = raw[YJ + j];
+            if constexpr (PRO) {
+                float f[8];
+                ogc_unpack8(raw[YJ + j], f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    f[e] = fmaf(fa[j], f[e], fb[j]);
+                    if (pro_relu) f[e] = fmaxf(f[e], 0.f);
+                }
+                const v4s lo = ogc_pack_bf16(f[0], f[1], f[2], f[3]), hi = ogc_pack_bf16(f[4], f[5], f[6], f[7]);
+                const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+                o = make_uint4(l2.x, l2.y, h2.x, h2.y);
+            }
+            *reinterpret_cast<uint4 *>(buf + lrow[YJ + j]) = o;
+        }
+    };
+
+    v4f acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[a][c] = (v4f){0.f, 0.f, 0.f, 0.f};
+    const int yoff = (half_r * 64 + i) * W16_LD + 8 * k, xoff = (YROWS + half_c * 64 + i) * W16_LD + 8 * k;
+    auto half_stage = [&](const ogc_bf16 *buf, int h) { // 32 positions: one k32 MFMA per accumulator
+        uint4 yv[4], xv[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) yv[a] = *reinterpret_cast<const uint4 *>(buf + yoff + a * 16 * W16_LD + h * 32);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) xv[c] = *reinterpret_cast<const uint4 *>(buf + xoff + c * 16 * W16_LD + h * 32);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                acc[a][c] = ogc_mfma_bf16_k32(__builtin_bit_cast(v4s, make_uint2(yv[a].x, yv[a].y)),
+                                              __builtin_bit_cast(v4s, make_uint2(yv[a].z, yv[a].w)),
+                                              __builtin_bit_cast(v4s, make_uint2(xv[c].x, xv[c].y)),
+                                              __builtin_bit_cast(v4s, make_uint2(xv[c].z, xv[c].w)), acc[a][c]);
+    };
+
+    ogc_bf16 *buf0 = w16_lds, *buf1 = w16_lds + W_ROWS * W16_LD;
+    fetch();
+    park(buf0);
+    __syncthreads();
+    for (int st = 0; st < mine; ++st) {
+        const bool more = st + 1 < mine;
+        if (more) fetch();
+        half_stage(buf0, 0);
+        if (more) park(buf1);
+        half_stage(buf0, 1);
+        __syncthreads();
+        ogc_bf16 *tmp = buf0; buf0 = buf1; buf1 = tmp;
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = co0 + half_r * 64 + a * 16 + k * 4 + r, col = ci0 + half_c * 64 + c * 16 + i;
+                const float v = acc[a][c][r];
+                if (row < cout && col < cin && v != 0.0f) unsafeAtomicAdd(dw + (size_t)row * cin + col, v);
+            }
+}
+
+// true when the launch was made (both tensors bf16, hw a multiple of 64, 16-byte aligned)
+bool wgrad_shared16_launch(int b, int cin, int cout, int hw, const ogc_bf16 *x, const ogc_bf16 *dy, float *dw, const float *pa,
+                           const float *pb, int pro_relu, hipStream_t s, const float2 *coef2, const float2 *inj, int s_shift) {
+    static const bool off = [] { const char *e = getenv("OGC_WGRAD_SHARED16"); return e && e[0] == '0'; }();
+    if (off || cin < 128 || cout < 128 || (hw % W16_POS) != 0 || (((uintptr_t)x | (uintptr_t)dy) & 15) != 0) return false;
+    if (inj && ((1 << s_shift) < 8 || !pa)) return false;
+    const size_t lds = sizeof(ogc_bf16) * 2 * 256 * W16_LD;
+    const int tiles = ogc_divup(cout, 128) * ogc_divup(cin, 128);
+    const long long nstages = (long long)b * (hw / W16_POS);
+    long long wgs = 512 / tiles;
+    if (wgs < 1) wgs = 1;
+    long long spw = (nstages + wgs - 1) / wgs;
+    if (spw < 8) spw = 8;
+    const int gx = (int)((nstages + spw - 1) / spw);
+    dim3 grid(gx, ogc_divup(cout, 128), ogc_divup(cin, 128));
+#define OGC_WGS16(PROV, POOLV)                                                                                                 \
+    {                                                                                                                          \
+        static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(conv1x1_wgrad_shared16_kernel<PROV, POOLV>),   \
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;         \
+        if (!ok) { (void)hipGetLastError(); return false; }                                                                    \
+        hipLaunchKernelGGL((conv1x1_wgrad_shared16_kernel<PROV, POOLV>), grid, dim3(256), lds, s, b, cin, cout, hw, (int)spw, x, \
+                           dy, dw, pa, pb, pro_relu, coef2, inj, s_shift);                                                      \
+    }
+    if (inj) OGC_WGS16(true, true)
+    else if (pa) OGC_WGS16(true, false)
+    else OGC_WGS16(false, false)
+#undef OGC_WGS16
+    return true;
+}
+
 // OGC_WGRAD_SHARED=0 in the environment: the 64 x 64 register tiles for every width (A/B runs, tests of both kernels)
 bool wgrad_shared_enabled() {
     static const bool on = [] { const char *e = getenv("OGC_WGRAD_SHARED"); return !(e && e[0] == '0'); }();
@@ -654,6 +839,12 @@ int wgrad_impl(const char *name, int b, int cin, int cout, int hw, const XT *x, 
     }
     if (b == 0) return OGC_OK;
     // layers of 128 channels and more on both sides: a 128 x 128 tile per workgroup, operands shared through LDS
+    if constexpr (sizeof(XT) == 2 && sizeof(YT) == 2) { // both tensors in 16 bits: 64-position stages of packed operands
+        if (wgrad_shared16_launch(b, cin, cout, hw, x, dy, dw, pa, pb, pro_relu, s, coef2, inj, s_shift)) {
+            OGC_CHECK_LAUNCH(name);
+            return OGC_OK;
+        }
+    }
     if (wgrad_shared_launch(b, cin, cout, hw, x, dy, dw, pa, pb, pro_relu, s, coef2, inj, s_shift)) {
         OGC_CHECK_LAUNCH(name);
         return OGC_OK;
