@@ -344,3 +344,34 @@ def test_persistent_kernel_equals_tile_kernel(nat, B, cin, cout, P, S):
         else:
             assert torch.equal(a, b), k
     assert torch.equal(res["1"][0], res["1"][1]) and torch.equal(res["1"][0], res["1"][3])
+
+
+@pytest.mark.parametrize("npoint,nsample,mlp,B,N", [(256, 16, [6, 32, 32, 64], 16, 1024), (128, 32, [6, 64, 128], 8, 512),
+                                                    (64, 64, [6, 48, 48, 48], 4, 256), (256, 16, [6, 64], 4, 512),
+                                                    (100, 24, [6, 32, 32], 2, 300)])
+def test_other_level_shapes_run_and_agree(nat, npoint, nsample, mlp, B, N):
+    """Level shapes away from C2's — 16 / 32 neighbours, widths that are not multiples of 64, a two-layer and a one-layer MLP, a
+    neighbourhood size the pooled kernels do not take: whatever mix of 16-bit kernels and widened fall-backs a shape gets, the pooled
+    features agree with the fp32-activation run to bf16 accuracy and the gradients are finite and aligned with it."""
+    from ogc_amd import fused
+    from ogc_amd.utils.pointnet2_util import PointnetSAModule
+    res = {}
+    for on in (False, True):
+        torch.manual_seed(3)
+        sa = PointnetSAModule(mlp=list(mlp), npoint=npoint, radius=0.3, nsample=nsample, bn={"class": "GroupNorm", "num_groups": 4}).to(DEV)
+        g = torch.Generator().manual_seed(5)
+        xyz = torch.rand(B, N, 3, generator=g).to(DEV)
+        feats = torch.randn(B, mlp[0], N, generator=g).to(DEV).requires_grad_(True)
+        saved, fused.ACT16 = fused.ACT16, on
+        try:
+            _, out = sa(xyz, feats)
+            out.square().sum().backward()
+        finally:
+            fused.ACT16 = saved
+        res[on] = (out.detach(), feats.grad.detach(), torch.cat([p.grad.flatten() for p in sa.parameters()]))
+    (o0, f0, g0), (o1, f1, g1) = res[False], res[True]
+    assert torch.isfinite(o1).all() and torch.isfinite(f1).all() and torch.isfinite(g1).all()
+    assert rel(o1, o0) < 1e-2
+    for a, b in ((f1, f0), (g1, g0)):
+        cos = float((a.double() * b.double()).sum() / (a.double().norm() * b.double().norm() + 1e-30))
+        assert cos > 0.99, cos
