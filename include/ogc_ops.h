@@ -260,6 +260,12 @@ int ogc_group_points_grad_rev(int b, int c, int n, int npoints, int nsample, con
 
 /* The gradient of three_interpolate as the same gather: rev_* = ogc_group_reverse(b, m, n, 3, idx (b,n,3), ...) — position
  * t = 3 i + k stands for grad_out[b,c,i] * weight[b,i,k].  grad_points (b,c,m) is overwritten.  3 n a multiple of 16. */
+/* ogc_group_points_grad_rev that also returns, from the same pass over grad_out, the three coordinate columns of a grouped first
+ * layer's weight gradient (ogc_group_linear_fwd): dwx (c, 3) = sum_{b, pos} grad_out[b, ch, pos] * rel[b, k, pos] — the result of
+ * ogc_conv1x1_wgrad(rel, grad_out) without its second read of grad_out.  dwx is zeroed by the call.  (_h: grad_out in bf16.) */
+int ogc_group_points_grad_rev_dwx(int b, int c, int n, int npoints, int nsample, const float *grad_out, const int *rev_start,
+                                  const unsigned short *rev_pos, const unsigned short *heads, const float *rel,
+                                  float *grad_points, float *dwx, ogc_stream_t stream);
 int ogc_three_interpolate_grad_rev(int b, int c, int n, int m, const float *grad_out, const float *weight,
                                    const int *rev_start, const unsigned short *rev_pos, const unsigned short *heads,
                                    float *grad_points, ogc_stream_t stream);
@@ -693,6 +699,9 @@ int ogc_group_linear_fwd_pt_h(int b, int m, int n, int npoints, int nsample, int
 int ogc_group_points_grad_rev_h(int b, int c, int n, int npoints, int nsample, const ogc_bf16_t *grad_out, const int *rev_start,
                                 const unsigned short *rev_pos, const unsigned short *heads, float *grad_points,
                                 ogc_stream_t stream);
+int ogc_group_points_grad_rev_dwx_h(int b, int c, int n, int npoints, int nsample, const ogc_bf16_t *grad_out, const int *rev_start,
+                                    const unsigned short *rev_pos, const unsigned short *heads, const float *rel,
+                                    float *grad_points, float *dwx, ogc_stream_t stream);
 int ogc_conv1x1_gemm_h(int b, int M, int K, int hw, int transpose_a, const float *w, const ogc_bf16_t *in, ogc_bf16_t *out,
                        ogc_stream_t stream);
 int ogc_conv1x1_gemm_affine_h(int b, int M, int K, int hw, int relu, int groups, const float *w, const ogc_bf16_t *in,

@@ -34,6 +34,7 @@ SIGNATURES = {
     "ogc_group_reverse": [_int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp],
     "ogc_three_interpolate_grad_rev": [_int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "ogc_group_points_grad_rev": [_int, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp],
+    "ogc_group_points_grad_rev_dwx": [_int, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "ogc_ball_query": [_int, _int, _int, _flt, _int, _vp, _vp, _vp, _vp],
     "ogc_knn_clamped": [_int, _int, _int, _int, _flt, _vp, _vp, _vp, _vp, _vp],
     "ogc_cell_grid_bytes": [_int, _int],
@@ -133,7 +134,7 @@ for _n in ("ogc_group_linear_fwd", "ogc_group_points_grad_rev", "ogc_conv1x1_gem
            "ogc_conv1x1_gemm_affine_pool", "ogc_conv1x1_wgrad_affine", "ogc_conv1x1_wgrad_affine_pooled",
            "ogc_conv1x1_dgrad_pooled", "ogc_conv1x1_wgrad_moments", "ogc_conv1x1_wgrad_moments_pooled",
            "ogc_conv1x1_dgrad_adjoint", "ogc_conv1x1_dgrad_adjoint_pooled", "ogc_group_norm_bwd",
-           "ogc_group_norm_maxpool_bwd_sparse"):
+           "ogc_group_norm_maxpool_bwd_sparse", "ogc_group_points_grad_rev_dwx"):
     SIGNATURES[_n + "_h"] = SIGNATURES[_n]
 SIGNATURES["ogc_conv1x1_wgrad_xf_h"] = SIGNATURES["ogc_conv1x1_wgrad"]
 SIGNATURES["ogc_group_linear_fwd_pt_h"] = SIGNATURES["ogc_group_linear_fwd"]

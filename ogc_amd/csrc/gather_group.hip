@@ -780,20 +780,27 @@ __global__ __launch_bounds__(GRB_THREADS) void group_reverse_kernel(int n, int T
 // INTERP: the gradient of three_interpolate — position t = 3 i + k stands for grad_out[b, c, i] * weight[b, i, k] (the plane
 // has T / 3 values, the products are formed while staging).
 // GT: element type of grad_out (float / ogc_bf16: act_io.h; the INTERP form is fp32 only).
-template <int NA, bool INTERP, typename GT = float>
+// DWX (not with INTERP): the plane is the gradient of a grouped first layer's output (ogc_group_linear_fwd), and the three
+// coordinate columns of that layer's weight gradient — dwx[ch][k] = sum over samples and positions of grad_out * rel[b, k, pos] —
+// are accumulated from the values while they are staged (`weight` then holds rel (b, 3, T); 192 bytes of rel per thread and chunk,
+// shared by the sample's planes through the L2) instead of by a three-channel weight-gradient launch that reads grad_out again.
+template <int NA, bool INTERP, typename GT = float, bool DWX = false>
 __global__ __launch_bounds__(GR_THREADS) void group_bwd_rev_kernel(int c, int n, int T, int tc, long long go_bstride,
                                                                    const GT *__restrict__ grad_out,
                                                                    const int *__restrict__ rev_start,
                                                                    const unsigned short *__restrict__ rev_pos,
                                                                    const unsigned short *__restrict__ heads,
                                                                    const float *__restrict__ weight,
-                                                                   float *__restrict__ grad_points) {
+                                                                   float *__restrict__ grad_points,
+                                                                   float *__restrict__ dwx = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float gr_plane[]; // [tc] gradient values, then [tc] 16-bit positions
     unsigned short *gr_pos = reinterpret_cast<unsigned short *>(gr_plane + tc);
     const int t = threadIdx.x, ch = blockIdx.x, b = blockIdx.y;
     const int chunks = (T + tc - 1) / tc;
     const GT *g = grad_out + (size_t)b * go_bstride + (size_t)ch * (INTERP ? T / 3 : T);
     const float *wt = INTERP ? weight + (size_t)b * T : nullptr;
+    const float *relb = DWX ? weight + (size_t)b * 3 * T : nullptr;
+    float wx0 = 0.f, wx1 = 0.f, wx2 = 0.f;
     const int *rs = rev_start + (size_t)b * chunks * (n + 1);
     const unsigned short *rp = rev_pos + (size_t)b * T;
     const unsigned short *hd = heads + ((size_t)b * T >> 4);
@@ -814,6 +821,14 @@ __global__ __launch_bounds__(GR_THREADS) void group_bwd_rev_kernel(int c, int n,
                                          w4.w * ogc_ld1(g + (q + 3) / 3));
                 } else {
                     pre[u] = ogc_ld4(g + tt + 4 * u);
+                    if constexpr (DWX) {
+                        const float4 r0 = *reinterpret_cast<const float4 *>(relb + tt + 4 * u);
+                        const float4 r1 = *reinterpret_cast<const float4 *>(relb + T + tt + 4 * u);
+                        const float4 r2 = *reinterpret_cast<const float4 *>(relb + 2 * (size_t)T + tt + 4 * u);
+                        wx0 = fmaf(pre[u].w, r0.w, fmaf(pre[u].z, r0.z, fmaf(pre[u].y, r0.y, fmaf(pre[u].x, r0.x, wx0))));
+                        wx1 = fmaf(pre[u].w, r1.w, fmaf(pre[u].z, r1.z, fmaf(pre[u].y, r1.y, fmaf(pre[u].x, r1.x, wx1))));
+                        wx2 = fmaf(pre[u].w, r2.w, fmaf(pre[u].z, r2.z, fmaf(pre[u].y, r2.y, fmaf(pre[u].x, r2.x, wx2))));
+                    }
                 }
             }
         }
@@ -869,6 +884,19 @@ __global__ __launch_bounds__(GR_THREADS) void group_bwd_rev_kernel(int c, int n,
         const int j = t + k * GR_THREADS;
         if (j < n) gp[j] = acc[k];
     }
+    if constexpr (DWX) { // the plane's share of dwx[ch][0..2]: wave sums, then one atomic per wavefront and column
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            wx0 += __shfl_down(wx0, off, 64);
+            wx1 += __shfl_down(wx1, off, 64);
+            wx2 += __shfl_down(wx2, off, 64);
+        }
+        if ((t & 63) == 0) {
+            unsafeAtomicAdd(dwx + ch * 3, wx0);
+            unsafeAtomicAdd(dwx + ch * 3 + 1, wx1);
+            unsafeAtomicAdd(dwx + ch * 3 + 2, wx2);
+        }
+    }
 }
 
 } // namespace
@@ -911,7 +939,7 @@ namespace {
 template <typename GT>
 int group_points_grad_rev_impl(int b, int c, int n, int npoints, int nsample, const GT *grad_out, const int *rev_start,
                                const unsigned short *rev_pos, const unsigned short *heads, float *grad_points,
-                               ogc_stream_t stream) {
+                               ogc_stream_t stream, const float *rel = nullptr, float *dwx = nullptr) {
     OGC_REQUIRE(b >= 0 && c >= 0 && n >= 1 && npoints >= 0 && nsample >= 0 && (long long)npoints * nsample < (1ll << 31),
                 "ogc_group_points_grad_rev: bad dimensions");
     const int T = npoints * nsample;
@@ -930,9 +958,21 @@ int group_points_grad_rev_impl(int b, int c, int n, int npoints, int nsample, co
     const size_t lds = (size_t)tc * (sizeof(float) + sizeof(unsigned short));
     const long long go_bstride = (long long)c * T;
     dim3 grid(c, b);
+    if (dwx) {
+        if (!rel || !aligned16(rel) || ogc_zero_async(dwx, sizeof(float) * 3 * (size_t)c, s) != hipSuccess) {
+            ogc_set_error("ogc_group_points_grad_rev_dwx: rel missing / misaligned, or the fill of dwx failed");
+            return OGC_ERR_INVALID_ARG;
+        }
+    }
 #define GR_LAUNCH(NAV)                                                                                                         \
-    hipLaunchKernelGGL((group_bwd_rev_kernel<NAV, false, GT>), grid, dim3(GR_THREADS), lds, s, c, n, T, tc, go_bstride, grad_out, \
-                       rev_start, rev_pos, heads, nullptr, grad_points)
+    do {                                                                                                                       \
+        if (dwx)                                                                                                               \
+            hipLaunchKernelGGL((group_bwd_rev_kernel<NAV, false, GT, true>), grid, dim3(GR_THREADS), lds, s, c, n, T, tc,       \
+                               go_bstride, grad_out, rev_start, rev_pos, heads, rel, grad_points, dwx);                        \
+        else                                                                                                                   \
+            hipLaunchKernelGGL((group_bwd_rev_kernel<NAV, false, GT>), grid, dim3(GR_THREADS), lds, s, c, n, T, tc, go_bstride, \
+                               grad_out, rev_start, rev_pos, heads, nullptr, grad_points);                                     \
+    } while (0)
     if (n <= GR_THREADS) GR_LAUNCH(1);
     else if (n <= 2 * GR_THREADS) GR_LAUNCH(2);
     else if (n <= 4 * GR_THREADS) GR_LAUNCH(4);
@@ -949,6 +989,25 @@ extern "C" int ogc_group_points_grad_rev(int b, int c, int n, int npoints, int n
                                          const int *rev_start, const unsigned short *rev_pos,
                                          const unsigned short *heads, float *grad_points, ogc_stream_t stream) {
     return group_points_grad_rev_impl<float>(b, c, n, npoints, nsample, grad_out, rev_start, rev_pos, heads, grad_points, stream);
+}
+
+// ... and, from the same pass, the three coordinate columns of a grouped first layer's weight gradient: dwx (c, 3) = sum over samples
+// and positions of grad_out[b, ch, pos] * rel[b, k, pos] (rel (b, 3, npoints, nsample) as for ogc_group_linear_fwd; dwx is zeroed
+// here) — what ogc_conv1x1_wgrad(rel, grad_out) computes by reading grad_out a second time.
+extern "C" int ogc_group_points_grad_rev_dwx(int b, int c, int n, int npoints, int nsample, const float *grad_out,
+                                             const int *rev_start, const unsigned short *rev_pos, const unsigned short *heads,
+                                             const float *rel, float *grad_points, float *dwx, ogc_stream_t stream) {
+    OGC_REQUIRE(rel && dwx, "ogc_group_points_grad_rev_dwx: null pointer");
+    return group_points_grad_rev_impl<float>(b, c, n, npoints, nsample, grad_out, rev_start, rev_pos, heads, grad_points, stream, rel,
+                                             dwx);
+}
+
+extern "C" int ogc_group_points_grad_rev_dwx_h(int b, int c, int n, int npoints, int nsample, const ogc_bf16_t *grad_out,
+                                               const int *rev_start, const unsigned short *rev_pos, const unsigned short *heads,
+                                               const float *rel, float *grad_points, float *dwx, ogc_stream_t stream) {
+    OGC_REQUIRE(rel && dwx, "ogc_group_points_grad_rev_dwx_h: null pointer");
+    return group_points_grad_rev_impl<ogc_bf16>(b, c, n, npoints, nsample, grad_out, rev_start, rev_pos, heads, grad_points, stream,
+                                                rel, dwx);
 }
 
 extern "C" int ogc_group_points_grad_rev_h(int b, int c, int n, int npoints, int nsample, const ogc_bf16_t *grad_out,

@@ -1344,7 +1344,13 @@ class _GroupedFirstLayer(Function):
             # dP as a gather over the transposed neighbour lists of the geometry plan: no atomics, no zero fill; the three
             # xyz columns of the weight gradient are a three-channel weight gradient (second read of grad_y, one of rel)
             dP = torch.empty(B, M, N, dtype=torch.float32, device=grad_y.device)
-            nat.group_points_grad_rev_wrapper(B, M, N, npoint, nsample, grad_y, ctx.rev[0], ctx.rev[1], ctx.rev[2], dP)
+            if (ctx.needs_input_grad[4] and GROUP_REV_DWX and getattr(nat, "group_points_grad_rev_dwx_wrapper", None) is not None):
+                # ... and the three coordinate columns of the weight gradient from the same pass over grad_y
+                dwx = zeroed_empty((M, 3), torch.float32, grad_y.device)
+                nat.group_points_grad_rev_dwx_wrapper(B, M, N, npoint, nsample, grad_y, ctx.rev[0], ctx.rev[1], ctx.rev[2], rel, dP, dwx)
+                one_pass = True   # (dwx is made)
+            else:
+                nat.group_points_grad_rev_wrapper(B, M, N, npoint, nsample, grad_y, ctx.rev[0], ctx.rev[1], ctx.rev[2], dP)
         else:
             # dP and the three xyz columns of the weight gradient share one pass over grad_y where the scatter kernel's
             # LDS path applies; otherwise the scatter-add and a three-channel weight gradient
@@ -1376,6 +1382,10 @@ def grouped_first_layer_available(xyz, new_xyz, features, idx, conv, gn):
 
 
 GROUP_LINEAR_POINT_MAJOR = _os.environ.get("OGC_GROUP_LINEAR_PT", "1") != "0"   # (16-bit first layers: P stored (B, N, M))
+# dwx inside the gather-form grouping gradient (ogc_group_points_grad_rev_dwx: one read of grad_y less, but 192 bytes of rel per
+# thread and chunk through the L2s).  Measured at the end of round 5: C2 16.6-16.7 ms per step with it against 16.2 without (the
+# three-channel weight gradient it replaces is 0.42 ms of bf16 MFMAs), C4 10.73-10.75 either way — off; OGC_GROUP_REV_DWX=1 turns it on.
+GROUP_REV_DWX = _os.environ.get("OGC_GROUP_REV_DWX", "0") == "1"
 GROUP_GRAD_GATHER = True   # grouping gradient as a gather over transposed lists when the geometry plan has them
 GROUP_GRAD_GATHER_MIN_FANIN = 24
 

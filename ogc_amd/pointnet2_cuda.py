@@ -144,6 +144,15 @@ def group_points_grad_rev_wrapper(b, c, n, npoints, nsample, grad_out, rev_start
     return 1
 
 
+def group_points_grad_rev_dwx_wrapper(b, c, n, npoints, nsample, grad_out, rev_start, rev_pos, heads, rel, grad_points, dwx):
+    """group_points_grad_rev_wrapper + dwx (c, 3) = sum grad_out * rel from the same pass (ogc_group_points_grad_rev_dwx)."""
+    h, (go,) = _acts((grad_out,), ("grad_out",))
+    _run("ogc_group_points_grad_rev_dwx" + h, grad_out, b, c, n, npoints, nsample, go, _i(rev_start, "rev_start"),
+         _check(rev_pos, torch.int16, "rev_pos"), _check(heads, torch.int16, "heads"), _f(rel, "rel"),
+         _f(grad_points, "grad_points"), _f(dwx, "dwx"))
+    return 1
+
+
 def three_interpolate_grad_rev_wrapper(b, c, n, m, grad_out, weight, rev_start, rev_pos, heads, grad_points):
     """grad_points (b, c, m) of three_interpolate as a gather over group_reverse(idx (b, n, 3), m); overwrites."""
     _run("ogc_three_interpolate_grad_rev", grad_out, b, c, n, m, _f(grad_out, "grad_out"), _f(weight, "weight"),

@@ -206,6 +206,14 @@ def test_grouped_first_layer_h(nat):
     nat.conv1x1_wgrad_wrapper(B, 3, M, T, relc, gh.float(), w32)
     nat.conv1x1_wgrad_wrapper(B, 3, M, T, relc, gh, w16)
     assert rel(w16, w32) < 5e-6
+    # both from ONE pass over the gradient (ogc_group_points_grad_rev_dwx): the same dP bit for bit, dwx as the fp64 sum (fp32
+    # operands here; the separate weight-gradient kernel rounds rel to bf16 under this precision)
+    want = torch.einsum("bmt,bkt->mk", gh.double().view(B, M, T), relc.double().view(B, 3, T))
+    for gt in (gh, gh.float()):
+        dp, dwx = torch.empty(B, M, N, device=DEV), torch.empty(M, 3, device=DEV)
+        nat.group_points_grad_rev_dwx_wrapper(B, M, N, P, S, gt, rev[0], rev[1], rev[2], relc, dp, dwx)
+        assert torch.equal(dp, d32)
+        assert rel(dwx, want) < 1e-5
 
 
 def test_pooled_sums_h(nat):
