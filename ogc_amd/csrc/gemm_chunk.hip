@@ -39,7 +39,12 @@ __device__ __forceinline__ v4s gc_pack_bf16(float a, float b, float c, float d) 
 // AT: element type of in / out (float / ogc_bf16: act_io.h).  BF: operands rounded to bf16 on v_mfma_f32_16x16x16_bf16 — four
 // row quads (q .. q + 3) of the input chunk feed one MFMA: k-slot i of lane group kk is chunk row 4 (q + i) + kk for BOTH operands
 // (a permutation of the sixteen rows, which the sum over k does not see; cf. conv1x1_gemm_kernel).
-template <int RB, int KQ, bool SPLIT_M, bool TRANS, bool POOLED = false, int KA = 1, typename AT = float, bool BF = false>
+// TAB (POOLED): the (c2, c3, ag, arg) of the wavefront's tile — K rows x (64 >> s_shift) neighbourhoods — are fetched ONCE per tile
+// into a wave-private LDS table (as dgrad_adjoint_kernel does) and read back one 16-byte entry per row and chunk; without it every
+// chunk of sixteen rows issues eight 8-byte loads per lane for them next to its four data loads (K = 256: 128 against 64 + 8 load
+// instructions per lane and tile).
+template <int RB, int KQ, bool SPLIT_M, bool TRANS, bool POOLED = false, int KA = 1, typename AT = float, bool BF = false,
+          bool TAB = false>
 __global__ __launch_bounds__(GC_WAVES *OGC_WAVE, 2) void gemm_chunk_kernel(int M, int K, int hw, const float *__restrict__ w,
                                                                          const AT *__restrict__ in,
                                                                          AT *__restrict__ out,
@@ -92,22 +97,44 @@ __global__ __launch_bounds__(GC_WAVES *OGC_WAVE, 2) void gemm_chunk_kernel(int M
             dst[mi * LD + ki] = av[i];
         }
     };
-    constexpr int NP = POOLED ? KQ : 1;
+    constexpr int NP = (POOLED && !TAB) ? KQ : 1;
     const int centres = hw >> s_shift;
     const int my_centre = (pl + 4 * j) >> s_shift, jpos = (pl + 4 * j) & ((1 << s_shift) - 1);
+    const int cpw = 64 >> s_shift; // neighbourhoods of a 64-position tile
+    float4 *tab = reinterpret_cast<float4 *>(gc_lds + 2 * MT * LD) + (size_t)wave * K * cpw;
+    if constexpr (POOLED && TAB) {
+        for (int e = lane; e < K * cpw; e += OGC_WAVE) {
+            const int row = e / cpw, centre = (pl >> s_shift) + (e - row * cpw);
+            const float2 c2v = coef2[(size_t)b * K + row];
+            const float2 jj = centre < centres ? inj[((size_t)b * K + row) * centres + centre] : make_float2(0.f, __int_as_float(-1));
+            tab[e] = make_float4(c2v.x, c2v.y, jj.x, jj.y);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    const int mine_c = (4 * j) >> s_shift;
     auto load_in = [&](int k0, float4(&xv)[KQ], float2(&cc)[NP], float2(&jv)[NP]) {
 #pragma unroll
         for (int q = 0; q < KQ; ++q) {
             const int k = min(k0 + 4 * q + kk, K - 1);
             xv[q] = ogc_ld4(inb + (size_t)k * hw);
-            if constexpr (POOLED) {
+            if constexpr (POOLED && !TAB) {
                 cc[q] = coef2[(size_t)b * K + k];
                 jv[q] = inj[((size_t)b * K + k) * centres + my_centre];
             }
         }
     };
     auto rebuild = [&](int k0, float4(&xv)[KQ], const float2(&cc)[NP], const float2(&jv)[NP]) {
-        if constexpr (POOLED) {
+        if constexpr (POOLED && TAB) {
+#pragma unroll
+            for (int q = 0; q < KQ; ++q) {
+                const float4 te = tab[min(k0 + 4 * q + kk, K - 1) * cpw + mine_c];
+                const int rel = __float_as_int(te.w) - jpos;
+                xv[q].x = fmaf(te.x, xv[q].x, te.y) + (rel == 0 ? te.z : 0.f);
+                xv[q].y = fmaf(te.x, xv[q].y, te.y) + (rel == 1 ? te.z : 0.f);
+                xv[q].z = fmaf(te.x, xv[q].z, te.y) + (rel == 2 ? te.z : 0.f);
+                xv[q].w = fmaf(te.x, xv[q].w, te.y) + (rel == 3 ? te.z : 0.f);
+            }
+        } else if constexpr (POOLED) {
 #pragma unroll
             for (int q = 0; q < KQ; ++q) {
                 const int rel = __float_as_int(jv[q].y) - jpos;
@@ -313,16 +340,31 @@ int dgrad_pooled_impl(int b, int cin, int cout, int hw, int nsample, const float
     hipStream_t s = (hipStream_t)stream;
     const float2 *c2 = reinterpret_cast<const float2 *>(coef2), *ij = reinterpret_cast<const float2 *>(inj);
     const int M = cin, K = cout;
+    // the per-tile table of the sparse gradient's entries (TAB) where it fits next to the weights (K rows x 64 / nsample
+    // neighbourhoods x 16 bytes per wavefront; OGC_DGRAD_POOLED_TAB=0: per-chunk loads, for A/B runs)
+    static const bool tab_off = [] { const char *e = getenv("OGC_DGRAD_POOLED_TAB"); return e && e[0] == '0'; }();
+    const size_t tab_bytes = (size_t)GC_WAVES * K * (64 >> sh) * sizeof(float4);
+    const bool tab = !tab_off && tab_bytes <= 24 * 1024;
     if (M <= 64) {
         constexpr int RB = 4, KQ = 4, KA = 2; // (weights staged 32 rows at a time: registers to spare at 64 rows)
         dim3 grid(ogc_divup(hw, 64 * GC_WAVES), ogc_divup(M, 16 * RB), b);
-        hipLaunchKernelGGL((gemm_chunk_kernel<RB, KQ, false, true, true, KA, AT, BF>), grid, dim3(GC_WAVES * OGC_WAVE),
-                           (size_t)2 * 16 * RB * 4 * ((KQ * KA) | 1) * sizeof(float), s, M, K, hw, w, y, grad_z, c2, ij, sh);
+        const size_t lds = (size_t)2 * 16 * RB * 4 * ((KQ * KA) | 1) * sizeof(float);
+        if (tab)
+            hipLaunchKernelGGL((gemm_chunk_kernel<RB, KQ, false, true, true, KA, AT, BF, true>), grid, dim3(GC_WAVES * OGC_WAVE),
+                               lds + tab_bytes, s, M, K, hw, w, y, grad_z, c2, ij, sh);
+        else
+            hipLaunchKernelGGL((gemm_chunk_kernel<RB, KQ, false, true, true, KA, AT, BF>), grid, dim3(GC_WAVES * OGC_WAVE), lds, s, M,
+                               K, hw, w, y, grad_z, c2, ij, sh);
     } else {
         constexpr int RB = 8, KQ = 4;
         dim3 grid(ogc_divup(hw, 64 * GC_WAVES), ogc_divup(M, 16 * RB), b);
-        hipLaunchKernelGGL((gemm_chunk_kernel<RB, KQ, false, true, true, 1, AT, BF>), grid, dim3(GC_WAVES * OGC_WAVE),
-                           (size_t)2 * 16 * RB * 4 * (KQ | 1) * sizeof(float), s, M, K, hw, w, y, grad_z, c2, ij, sh);
+        const size_t lds = (size_t)2 * 16 * RB * 4 * (KQ | 1) * sizeof(float);
+        if (tab)
+            hipLaunchKernelGGL((gemm_chunk_kernel<RB, KQ, false, true, true, 1, AT, BF, true>), grid, dim3(GC_WAVES * OGC_WAVE),
+                               lds + tab_bytes, s, M, K, hw, w, y, grad_z, c2, ij, sh);
+        else
+            hipLaunchKernelGGL((gemm_chunk_kernel<RB, KQ, false, true, true, 1, AT, BF>), grid, dim3(GC_WAVES * OGC_WAVE), lds, s, M, K,
+                               hw, w, y, grad_z, c2, ij, sh);
     }
     OGC_CHECK_LAUNCH("ogc_conv1x1_dgrad_pooled");
     return OGC_OK;
