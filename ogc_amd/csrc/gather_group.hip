@@ -839,7 +839,24 @@ __global__ __launch_bounds__(GR_THREADS) void group_bwd_rev_kernel(int c, int n,
     float acc[NA];
 #pragma unroll
     for (int k = 0; k < NA; ++k) acc[k] = 0.0f;
+    // the bounds of my points' lists in a chunk travel one chunk ahead like the values (2 NA loads out of the L2: read after the
+    // barrier they were a dependent round trip in front of every chunk's walk)
+    // (up to sixteen points per thread: with thirty-two the 64 registers of bounds spill)
+    constexpr bool PFB = NA <= 16;
+    int nlo[NA], nhi[NA];
+    auto bounds = [&](int chunk) {
+#pragma unroll
+        for (int k = 0; k < NA; ++k) {
+            const int j = t + k * GR_THREADS;
+            nlo[k] = nhi[k] = chunk * tc;
+            if (j < n) {
+                nlo[k] = rs[(size_t)chunk * (n + 1) + j];
+                nhi[k] = rs[(size_t)chunk * (n + 1) + j + 1];
+            }
+        }
+    };
     fetch(0);
+    if (PFB) bounds(0);
     for (int chunk = 0; chunk < chunks; ++chunk) {
         {
             float v[16] = {pre[0].x, pre[0].y, pre[0].z, pre[0].w, pre[1].x, pre[1].y, pre[1].z, pre[1].w,
@@ -856,18 +873,18 @@ __global__ __launch_bounds__(GR_THREADS) void group_bwd_rev_kernel(int c, int n,
             }
         }
         __syncthreads();
-        if (chunk + 1 < chunks) fetch(chunk + 1); // in flight while the lists of this chunk are walked
         const int base = chunk * tc;
+        if (!PFB) bounds(chunk);
         int cur[NA], end[NA], longest = 0;
 #pragma unroll
         for (int k = 0; k < NA; ++k) {
-            const int j = t + k * GR_THREADS;
-            cur[k] = end[k] = 0;
-            if (j < n) {
-                cur[k] = rs[(size_t)chunk * (n + 1) + j] - base;
-                end[k] = rs[(size_t)chunk * (n + 1) + j + 1] - base;
-            }
+            cur[k] = nlo[k] - base;
+            end[k] = nhi[k] - base;
             longest = max(longest, end[k] - cur[k]);
+        }
+        if (chunk + 1 < chunks) { // in flight while the lists of this chunk are walked
+            fetch(chunk + 1);
+            if (PFB) bounds(chunk + 1);
         }
         for (int step = 0; step < longest; ++step) { // the NA lists of a thread advance together: NA independent reads
             float v[NA];
