@@ -261,14 +261,23 @@ __global__ __launch_bounds__(GN_THREADS) void gn_bwd_dx_kernel(int c, int hw, in
     const float a = r * gamma[ch];
     const float bb = beta[ch] - mean[row] * a;
     float c2, c3;
-    gn_bwd_prologue(c, groups, (double)cg * hw, slots, gamma, mean, rstd, dsdb, dgamma, dbeta, c2, c3);
     const size_t base = ((size_t)b * c + ch) * hw;
     const AT *px = x + base, *pd = dy + base;
     AT *po = dx + base;
-    if ((hw & 3) == 0 && (((uintptr_t)px | (uintptr_t)pd | (uintptr_t)po) & ogc_act_mask<AT>()) == 0) {
-        for (int i = (blockIdx.x * GN_THREADS + threadIdx.x) * 4; i < hw; i += gridDim.x * GN_THREADS * 4) {
-            const float4 v = ogc_ld4(px + i);
-            float4 d = ogc_ld4(pd + i);
+    const bool vec = (hw & 3) == 0 && (((uintptr_t)px | (uintptr_t)pd | (uintptr_t)po) & ogc_act_mask<AT>()) == 0;
+    // the first pieces of x and dy are requested BEFORE the prologue (a few hundred fp64 partial sums and two block reductions:
+    // several microseconds of a block that lives ~20): their latency runs underneath it
+    const int i0 = (blockIdx.x * GN_THREADS + threadIdx.x) * 4;
+    float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), d0 = v0;
+    if (vec && i0 < hw) {
+        v0 = ogc_ld4(px + i0);
+        d0 = ogc_ld4(pd + i0);
+    }
+    gn_bwd_prologue(c, groups, (double)cg * hw, slots, gamma, mean, rstd, dsdb, dgamma, dbeta, c2, c3);
+    if (vec) {
+        for (int i = i0; i < hw; i += gridDim.x * GN_THREADS * 4) {
+            const float4 v = i == i0 ? v0 : ogc_ld4(px + i);
+            float4 d = i == i0 ? d0 : ogc_ld4(pd + i);
             if (RELU) {
                 d.x = fmaf(a, v.x, bb) > 0.f ? d.x : 0.f; d.y = fmaf(a, v.y, bb) > 0.f ? d.y : 0.f;
                 d.z = fmaf(a, v.z, bb) > 0.f ? d.z : 0.f; d.w = fmaf(a, v.w, bb) > 0.f ? d.w : 0.f;
