@@ -556,7 +556,8 @@ int ogc_conv1x1_gemm_stream_supported(int b, int M, int K, int hw);
 /* The same product for ANY reduction length and row count (ogc_amd/csrc/gemm_chunk.hip: K walked in chunks, the weights'
  * chunk in LDS, the input chunk in registers; few positions: the wavefronts of a workgroup split the rows): the Conv1d of
  * the feature-propagation modules (utils/pointnet2_util.py:96-120 — 384 -> 128 on 1024 points ...) and the input gradient
- * of layers wider than 160 channels, which went to the vendor library before.  hw % 64 == 0; fp32 operands. */
+ * of layers wider than 160 channels, which went to the vendor library before.  hw % 64 == 0; operands as
+ * ogc_set_matmul_precision says (fp32 operands whatever the switch until 0.2.2). */
 int ogc_conv1x1_gemm_any(int b, int M, int K, int hw, int transpose_a, const float *w, const float *in, float *out,
                          ogc_stream_t stream);
 

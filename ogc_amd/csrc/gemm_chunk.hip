@@ -159,20 +159,23 @@ __global__ __launch_bounds__(GC_WAVES *OGC_WAVE, 2) void gemm_chunk_kernel(int M
     // issue slots, and the loop written twice (with and without it) spills.
     auto compute = [&](const float *a_lds, const float4(&xv)[KQ], int koff = 0) {
         if constexpr (BF) {
-            static_assert(!BF || KQ == 4, "bf16 operands: one group of four row quads per input chunk");
-            const float4 v0 = xv[0], v1 = xv[1], v2 = xv[2], v3 = xv[3];
-            const v4s bx = gc_pack_bf16(v0.x, v1.x, v2.x, v3.x);
-            const v4s by = gc_pack_bf16(v0.y, v1.y, v2.y, v3.y);
-            const v4s bz = gc_pack_bf16(v0.z, v1.z, v2.z, v3.z);
-            const v4s bw = gc_pack_bf16(v0.w, v1.w, v2.w, v3.w);
-            const float *ar = a_lds + (wrow + j) * LD + koff + kk;
+            static_assert(!BF || KQ % 4 == 0, "bf16 operands: whole groups of four row quads per input chunk");
 #pragma unroll
-            for (int a = 0; a < RB; ++a) {
-                const v4s av = gc_pack_bf16(ar[a * 16 * LD], ar[a * 16 * LD + 4], ar[a * 16 * LD + 8], ar[a * 16 * LD + 12]);
-                acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, bx, acc[a][0], 0, 0, 0);
-                acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, by, acc[a][1], 0, 0, 0);
-                acc[a][2] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, bz, acc[a][2], 0, 0, 0);
-                acc[a][3] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, bw, acc[a][3], 0, 0, 0);
+            for (int g = 0; g < KQ / 4; ++g) {
+                const float4 v0 = xv[4 * g], v1 = xv[4 * g + 1], v2 = xv[4 * g + 2], v3 = xv[4 * g + 3];
+                const v4s bx = gc_pack_bf16(v0.x, v1.x, v2.x, v3.x);
+                const v4s by = gc_pack_bf16(v0.y, v1.y, v2.y, v3.y);
+                const v4s bz = gc_pack_bf16(v0.z, v1.z, v2.z, v3.z);
+                const v4s bw = gc_pack_bf16(v0.w, v1.w, v2.w, v3.w);
+                const float *ar = a_lds + (wrow + j) * LD + koff + 16 * g + kk;
+#pragma unroll
+                for (int a = 0; a < RB; ++a) {
+                    const v4s av = gc_pack_bf16(ar[a * 16 * LD], ar[a * 16 * LD + 4], ar[a * 16 * LD + 8], ar[a * 16 * LD + 12]);
+                    acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, bx, acc[a][0], 0, 0, 0);
+                    acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, by, acc[a][1], 0, 0, 0);
+                    acc[a][2] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, bz, acc[a][2], 0, 0, 0);
+                    acc[a][3] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, bw, acc[a][3], 0, 0, 0);
+                }
             }
         } else {
 #pragma unroll
@@ -259,18 +262,25 @@ void gemm_chunk_launch(int b, int M, int K, int hw, int transpose_a, const float
     constexpr int MT = SPLIT_M ? 64 * RB : 16 * RB;
     const size_t lds = (size_t)2 * MT * 4 * ((KQ * KA) | 1) * sizeof(float);
     dim3 grid(SPLIT_M ? hw / 64 : ogc_divup(hw, 64 * GC_WAVES), ogc_divup(M, MT), b);
-    if (transpose_a)
-        hipLaunchKernelGGL((gemm_chunk_kernel<RB, KQ, SPLIT_M, true, false, KA>), grid, dim3(GC_WAVES * OGC_WAVE), lds, s, M, K, hw,
-                           w, in, out, nullptr, nullptr, 0);
-    else
-        hipLaunchKernelGGL((gemm_chunk_kernel<RB, KQ, SPLIT_M, false, false, KA>), grid, dim3(GC_WAVES * OGC_WAVE), lds, s, M, K, hw,
-                           w, in, out, nullptr, nullptr, 0);
+    // operands: fp32, or rounded to bf16 under ogc_set_matmul_precision(1) (since the end of round 5: until then this entry point
+    // kept fp32 operands whatever the switch said, and a bf16 configuration mixed the two)
+#define GC_GO(TR, BFV)                                                                                                           \
+    hipLaunchKernelGGL((gemm_chunk_kernel<RB, KQ, SPLIT_M, TR, false, KA, float, BFV>), grid, dim3(GC_WAVES * OGC_WAVE), lds, s, M, K, \
+                       hw, w, in, out, nullptr, nullptr, 0)
+    if (ogc_g_matmul_bf16) {
+        if (transpose_a) GC_GO(true, true);
+        else GC_GO(false, true);
+    } else {
+        if (transpose_a) GC_GO(true, false);
+        else GC_GO(false, false);
+    }
+#undef GC_GO
 }
 
 } // namespace
 
 // OUT[b, m, p] = sum_k A[m, k] IN[b, k, p] for ANY reduction length and row count (hw % 64 == 0): transpose_a == 0: A = w
-// (M x K), != 0: A = w^T with w stored (K x M).  fp32 operands whatever ogc_set_matmul_precision says.
+// (M x K), != 0: A = w^T with w stored (K x M).  Operands follow ogc_set_matmul_precision (fp32, or rounded to bf16).
 extern "C" int ogc_conv1x1_gemm_any(int b, int M, int K, int hw, int transpose_a, const float *w, const float *in, float *out,
                                     ogc_stream_t stream) {
     OGC_REQUIRE(b >= 0 && M >= 1 && K >= 1 && hw >= 1, "ogc_conv1x1_gemm_any: bad shape");

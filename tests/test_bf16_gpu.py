@@ -105,3 +105,20 @@ def test_shared_mlp_trains_in_bf16_mode(bf16_mode):
     for a, b in zip(outs["bf16"], outs["fp32"]):
         assert torch.isfinite(a).all()
         assert ((a - b).norm() / (b.norm() + 1e-12)).item() < 0.1
+
+
+@pytest.mark.parametrize("B,cin,cout,hw", [(4, 448, 256, 2048), (2, 131, 128, 4096), (16, 256, 128, 32768), (3, 67, 64, 1024), (2, 224, 64, 2048)])
+def test_bf16_gemm_any(bf16_mode, B, cin, cout, hw):
+    """ogc_conv1x1_gemm_any follows the operand switch since the end of round 5 (it kept fp32 operands before, so that a bf16
+    configuration mixed the two): both orientations against fp64 on operands rounded to bf16."""
+    nat = bf16_mode
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn(B, cin, hw, generator=g).cuda()
+    w = (torch.randn(cout, cin, generator=g) / cin ** 0.5).cuda()
+    y = torch.empty(B, cout, hw, device="cuda")
+    nat.conv1x1_gemm_any_wrapper(B, cout, cin, hw, 0, w, x, y)
+    close(y, torch.einsum("mk,bkp->bmp", r(w), r(x)), "forward")
+    dy = torch.randn(B, cout, hw, generator=g).cuda()
+    dx = torch.empty(B, cin, hw, device="cuda")
+    nat.conv1x1_gemm_any_wrapper(B, cin, cout, hw, 1, w, dy, dx)
+    close(dx, torch.einsum("mk,bmp->bkp", r(w), r(dy)), "input gradient")
