@@ -47,7 +47,7 @@ enum {
  * points): ogc_gather_xyz_pair, ogc_flow_advance, ogc_linear_cn, ogc_gru_reset, ogc_gru_blend,
  * ogc_soft_corr_flow, ogc_three_nn_weights; ogc_furthest_point_sampling_chain accepts temp == NULL.  0.2.2: the `_h` entry points
  * (activations of the shared MLPs stored as bf16; see "16-bit activations" at the end of this header). */
-#define OGC_VERSION 202
+#define OGC_VERSION 203
 int ogc_version(void);
 /* 0: the squared distance of every search is the reference's SOURCE expression, ((dx*dx) + (dy*dy)) + (dz*dz), one rounding per
  * operation (what all parity tests pin).  1: this is libogc_ops_fmad.so, the same library with the search kernels (FPS, kNN,
@@ -269,6 +269,12 @@ int ogc_group_points_grad_rev_dwx(int b, int c, int n, int npoints, int nsample,
 int ogc_three_interpolate_grad_rev(int b, int c, int n, int m, const float *grad_out, const float *weight,
                                    const int *rev_start, const unsigned short *rev_pos, const unsigned short *heads,
                                    float *grad_points, ogc_stream_t stream);
+/* ... with grad_out a channel slice of a wider gradient (what autograd hands the interpolation underneath the concatenation of
+ * PointnetFPModule.forward, utils/pointnet2_util.py:115-117): grad_out_bstride floats between consecutive samples' (c, n) planes,
+ * >= c n; rows stay n contiguous floats.  Saves the copy `.contiguous()` would make. */
+int ogc_three_interpolate_grad_rev_bs(int b, int c, int n, int m, const float *grad_out, long long grad_out_bstride,
+                                      const float *weight, const int *rev_start, const unsigned short *rev_pos,
+                                      const unsigned short *heads, float *grad_points, ogc_stream_t stream);
 
 /* Dynamic (rigid-motion) term of the OGC loss, fused.  Replaces DynamicLoss.forward + fit_motion_svd_batch
  *   losses/seg_loss_unsup.py:64-98, :10-61 (K-fold expanded clouds, einsums, ~65 launches per step).

@@ -33,6 +33,7 @@ SIGNATURES = {
     "ogc_group_reverse_chunk": [_int, _int, _int],
     "ogc_group_reverse": [_int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp],
     "ogc_three_interpolate_grad_rev": [_int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "ogc_three_interpolate_grad_rev_bs": [_int, _int, _int, _int, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp],
     "ogc_group_points_grad_rev": [_int, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp],
     "ogc_group_points_grad_rev_dwx": [_int, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "ogc_ball_query": [_int, _int, _int, _flt, _int, _vp, _vp, _vp, _vp],
@@ -139,7 +140,7 @@ for _n in ("ogc_group_linear_fwd", "ogc_group_points_grad_rev", "ogc_conv1x1_gem
 SIGNATURES["ogc_conv1x1_wgrad_xf_h"] = SIGNATURES["ogc_conv1x1_wgrad"]
 SIGNATURES["ogc_group_linear_fwd_pt_h"] = SIGNATURES["ogc_group_linear_fwd"]
 
-HEADER_VERSION = 202   # OGC_VERSION of include/ogc_ops.h the SIGNATURES table above was written against
+HEADER_VERSION = 203   # OGC_VERSION of include/ogc_ops.h the SIGNATURES table above was written against
 _lib = None
 _fns = {}  # entry point name -> bound ctypes function
 

@@ -1033,10 +1033,13 @@ extern "C" int ogc_group_points_grad_rev_h(int b, int c, int n, int npoints, int
     return group_points_grad_rev_impl<ogc_bf16>(b, c, n, npoints, nsample, grad_out, rev_start, rev_pos, heads, grad_points, stream);
 }
 
-extern "C" int ogc_three_interpolate_grad_rev(int b, int c, int n, int m, const float *grad_out, const float *weight,
-                                              const int *rev_start, const unsigned short *rev_pos,
-                                              const unsigned short *heads, float *grad_points, ogc_stream_t stream) {
+// grad_out_bstride: floats between the (c, n) planes of consecutive samples (c n for a dense tensor; larger when grad_out is a
+// channel slice of a wider gradient, as autograd hands it to the interpolation underneath a concatenation)
+extern "C" int ogc_three_interpolate_grad_rev_bs(int b, int c, int n, int m, const float *grad_out, long long grad_out_bstride,
+                                                 const float *weight, const int *rev_start, const unsigned short *rev_pos,
+                                                 const unsigned short *heads, float *grad_points, ogc_stream_t stream) {
     OGC_REQUIRE(b >= 0 && c >= 0 && n >= 0 && m >= 1 && (long long)n * 3 < (1ll << 31), "ogc_three_interpolate_grad_rev: bad dimensions");
+    OGC_REQUIRE(grad_out_bstride >= (long long)c * n, "ogc_three_interpolate_grad_rev: batch stride of grad_out below c n");
     if (b == 0 || c == 0) return OGC_OK;
     OGC_REQUIRE(grad_out && weight && rev_start && rev_pos && heads && grad_points, "ogc_three_interpolate_grad_rev: null pointer");
     const int T = 3 * n;
@@ -1051,7 +1054,7 @@ extern "C" int ogc_three_interpolate_grad_rev(int b, int c, int n, int m, const 
     }
     const int tc = ogc_group_reverse_chunk(m, n, 3);
     const size_t lds = (size_t)tc * (sizeof(float) + sizeof(unsigned short));
-    const long long go_bstride = (long long)c * n;
+    const long long go_bstride = grad_out_bstride;
     dim3 grid(c, b);
 #define GR_LAUNCH(NAV)                                                                                                        \
     hipLaunchKernelGGL((group_bwd_rev_kernel<NAV, true>), grid, dim3(GR_THREADS), lds, s, c, m, T, tc, go_bstride, grad_out, \
@@ -1065,4 +1068,11 @@ extern "C" int ogc_three_interpolate_grad_rev(int b, int c, int n, int m, const 
 #undef GR_LAUNCH
     OGC_CHECK_LAUNCH("ogc_three_interpolate_grad_rev");
     return OGC_OK;
+}
+
+extern "C" int ogc_three_interpolate_grad_rev(int b, int c, int n, int m, const float *grad_out, const float *weight,
+                                              const int *rev_start, const unsigned short *rev_pos,
+                                              const unsigned short *heads, float *grad_points, ogc_stream_t stream) {
+    return ogc_three_interpolate_grad_rev_bs(b, c, n, m, grad_out, (long long)(c > 0 ? c : 0) * (n > 0 ? n : 0), weight, rev_start,
+                                             rev_pos, heads, grad_points, stream);
 }

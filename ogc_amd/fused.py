@@ -1317,7 +1317,7 @@ class _GroupedFirstLayer(Function):
             nat.group_linear_fwd_pt_wrapper(B, M, N, npoint, nsample, gn_groups, P.transpose(1, 2).contiguous(), idx, rel, wx, y, stats)
         else:
             nat.group_linear_fwd_wrapper(B, M, N, npoint, nsample, gn_groups, P, idx, rel, wx, y, stats)
-        ctx.save_for_backward(features, idx, rel, weight)
+        ctx.save_for_backward(features, idx, rel, weight, wf)   # (wf: the backward pass would make the same copy again)
         if stats is not None:
             ctx.mark_non_differentiable(stats)
         return y, stats
@@ -1327,12 +1327,11 @@ class _GroupedFirstLayer(Function):
         if grad_y is None:
             return (None,) * 10
         nat = _api._native
-        features, idx, rel, weight = ctx.saved_tensors
+        features, idx, rel, weight, wf = ctx.saved_tensors
         B, C, N = features.shape
         npoint, nsample = idx.shape[1], idx.shape[2]
         M = weight.shape[0]
         grad_y = grad_y.contiguous()
-        wf = weight.detach().reshape(M, 3 + C)[:, 3:]
         T = npoint * nsample
         # the gather wins where lists are long and planes many (C4: SA2, SA3: 0.50 -> 0.13 ms, 0.33 -> 0.07); with ~16 entries
         # per point (SA1: 8192 points) the per-chunk list headers cost as much as the data and the atomic kernel stays

@@ -196,8 +196,14 @@ class ThreeInterpolate(Function):
         rev = getattr(ctx, "rev", None)
         if rev is not None and getattr(_native, "three_interpolate_grad_rev_wrapper", None) is not None:
             grad_features = _new(grad_out, (B, c, m), torch.float32)
-            _native.three_interpolate_grad_rev_wrapper(B, c, n, m, grad_out.contiguous(), weight, rev[0], rev[1], rev[2],
-                                                       grad_features)
+            sliced = getattr(_native, "three_interpolate_grad_rev_sliced_wrapper", None)
+            if (sliced is not None and B > 1 and not grad_out.is_contiguous() and grad_out.dtype is torch.float32
+                    and grad_out.stride(2) == 1 and grad_out.stride(1) == n and grad_out.stride(0) >= c * n):
+                # the gradient of cat([interpolated, skip features]) arrives as a channel slice: read where it lies
+                sliced(B, c, n, m, grad_out, weight, rev[0], rev[1], rev[2], grad_features)
+            else:
+                _native.three_interpolate_grad_rev_wrapper(B, c, n, m, grad_out.contiguous(), weight, rev[0], rev[1], rev[2],
+                                                           grad_features)
             return grad_features, None, None, None
         grad_features = _new(grad_out, (B, c, m), torch.float32, fill=0.0)
         _native.three_interpolate_grad_wrapper(B, c, n, m, grad_out.contiguous(), idx, weight, grad_features)

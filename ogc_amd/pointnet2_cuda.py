@@ -161,6 +161,19 @@ def three_interpolate_grad_rev_wrapper(b, c, n, m, grad_out, weight, rev_start, 
     return 1
 
 
+def three_interpolate_grad_rev_sliced_wrapper(b, c, n, m, grad_out, weight, rev_start, rev_pos, heads, grad_points):
+    """three_interpolate_grad_rev on a grad_out that is a CHANNEL SLICE of a wider (b, c', n) gradient (rows dense, samples
+    c' n apart: what autograd's concatenation node hands down) — read in place (ogc_three_interpolate_grad_rev_bs)."""
+    if not (isinstance(grad_out, torch.Tensor) and grad_out.is_cuda and grad_out.dtype is torch.float32 and grad_out.dim() == 3
+            and tuple(grad_out.shape) == (b, c, n) and grad_out.stride(2) == 1 and grad_out.stride(1) == n
+            and grad_out.stride(0) >= c * n):
+        raise RuntimeError("grad_out must be a float32 HIP tensor (b, c, n) with dense rows and planes")
+    _run("ogc_three_interpolate_grad_rev_bs", grad_out, b, c, n, m, grad_out.data_ptr(), grad_out.stride(0), _f(weight, "weight"),
+         _i(rev_start, "rev_start"), _check(rev_pos, torch.int16, "rev_pos"), _check(heads, torch.int16, "heads"),
+         _f(grad_points, "grad_points"))
+    return 1
+
+
 def gather_points_wrapper(b, c, n, npoints, points, idx, out):
     _run("ogc_gather_points", points, b, c, n, npoints, _f(points, "points"), _i(idx, "idx"), _f(out, "out"))
     return 1

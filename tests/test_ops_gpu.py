@@ -417,6 +417,23 @@ def test_three_interpolate_gradient_as_a_gather(nat, B, C, M, N):
     feats = torch.randn(B, C, M, device=DEV, requires_grad=True)
     three_interpolate(feats, T(idx), T(w), rev).backward(T(g))
     assert np.abs(feats.grad.cpu().numpy() - want).max() <= 2e-6 * scale
+    # grad_out as a channel slice of a wider gradient (underneath a concatenation): read in place, the same bits
+    wide = torch.randn(B, C + 5, N, device=DEV)
+    wide[:, :C] = T(g)
+    sliced = torch.full((B, C, M), 7.0, device=DEV)
+    nat.three_interpolate_grad_rev_sliced_wrapper(B, C, N, M, wide[:, :C], T(w), rev[0], rev[1], rev[2], sliced)
+    assert torch.equal(sliced, got)
+    off = torch.full((B, C, M), 7.0, device=DEV)
+    wide[:, 5:] = T(g)
+    nat.three_interpolate_grad_rev_sliced_wrapper(B, C, N, M, wide[:, 5:], T(w), rev[0], rev[1], rev[2], off)
+    assert torch.equal(off, got)
+    with pytest.raises(RuntimeError):
+        nat.three_interpolate_grad_rev_sliced_wrapper(B, C, N, M, wide[:, :C, ::2], T(w), rev[0], rev[1], rev[2], off)
+    if B > 1:
+        feats2 = torch.randn(B, C, M, device=DEV, requires_grad=True)
+        skip = torch.randn(B, 5, N, device=DEV, requires_grad=True)
+        torch.cat([three_interpolate(feats2, T(idx), T(w), rev), skip], 1).backward(torch.cat([T(g), skip.detach()], 1))
+        assert np.abs(feats2.grad.cpu().numpy() - want).max() <= 2e-6 * scale
 
 
 def test_gather_and_group_forward_exact(nat, oracle):
