@@ -276,6 +276,20 @@ int ogc_three_interpolate_grad_rev_bs(int b, int c, int n, int m, const float *g
                                       const float *weight, const int *rev_start, const unsigned short *rev_pos,
                                       const unsigned short *heads, float *grad_points, ogc_stream_t stream);
 
+/* The scalar algebra either side of the fused loss terms (losses/seg_loss_unsup.py:353-392: a mean per term and view, summed
+ * and weighted; the masks' gradient as the sum of its five consumers'), one launch per direction.  Pointer / size ARRAYS are host
+ * memory, read during the call; at most 8 tensors.
+ * ogc_view_means:      out[k] = mean of row k, rows of tensor 0 first: tensor i is dense fp32, viewed as (rows[i], len[i]).
+ * ogc_view_means_grad: grad[i][r, :] = (weight[k(i, r)] * g_loss[0]) * (1 / len[i]) — the adjoint of the means under
+ *                      loss = <weight, out>; weight (sum rows) and g_loss (1) are device memory.
+ * ogc_sum_ranges:      out[e] = sum over the parts i with first[i] <= e < first[i] + count[i] of src[i][e - first[i]], in part
+ *                      order; 0 where no part covers e.  total = elements of out. */
+int ogc_view_means(int parts, const float *const *src, const int *rows, const long long *len, float *out, ogc_stream_t stream);
+int ogc_view_means_grad(int parts, float *const *grad, const int *rows, const long long *len, const float *weight,
+                        const float *g_loss, ogc_stream_t stream);
+int ogc_sum_ranges(int parts, const float *const *src, const long long *first, const long long *count, long long total,
+                   float *out, ogc_stream_t stream);
+
 /* Dynamic (rigid-motion) term of the OGC loss, fused.  Replaces DynamicLoss.forward + fit_motion_svd_batch
  *   losses/seg_loss_unsup.py:64-98, :10-61 (K-fold expanded clouds, einsums, ~65 launches per step).
  * ogc_rigid_moments: per (cloud, slot) the weighted moments of p = pc and q = pc2 with weights mask[:, slot], accumulated

@@ -33,6 +33,9 @@ SIGNATURES = {
     "ogc_group_reverse_chunk": [_int, _int, _int],
     "ogc_group_reverse": [_int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp],
     "ogc_three_interpolate_grad_rev": [_int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "ogc_view_means": [_int, _vp, _vp, _vp, _vp, _vp],
+    "ogc_view_means_grad": [_int, _vp, _vp, _vp, _vp, _vp, _vp],
+    "ogc_sum_ranges": [_int, _vp, _vp, _vp, _ll, _vp, _vp],
     "ogc_three_interpolate_grad_rev_bs": [_int, _int, _int, _int, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp],
     "ogc_group_points_grad_rev": [_int, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp],
     "ogc_group_points_grad_rev_dwx": [_int, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],

@@ -420,6 +420,66 @@ class _CombineTerms(torch.autograd.Function):
         return coeff[3] * g_loss, None
 
 
+LOSS_GLUE = __import__("os").environ.get("OGC_LOSS_GLUE", "1") != "0"   # the two Functions below instead of framework operators
+_GLUE_PARTS = __import__("os").environ.get("OGC_LOSS_GLUE_PARTS", "means,fork").split(",")   # (bisecting)
+
+
+def _glue_available(*tensors):
+    from .. import pointnet2_cuda as nat
+    return (LOSS_GLUE and getattr(nat, "view_means_wrapper", None) is not None
+            and all(t.is_cuda and t.dtype is torch.float32 for t in tensors))
+
+
+class _ViewMeansCombine(torch.autograd.Function):
+    """(loss, v) with v = cat([part.view(rows, -1).mean(1) for part in parts]) and loss = <coeff[3], v> — the per-view means of
+    every term and their weighted sum (:353-392) as ONE kernel and a dot product, and backward ONE kernel that writes every
+    term's gradient ((coeff * g) * (1 / len), MeanBackward's own arithmetic) instead of a broadcast division per term
+    (csrc/loss_glue.hip).  v is returned for the monitors and carries no gradient."""
+
+    @staticmethod
+    def forward(ctx, coeff, rows, *parts):
+        from .. import pointnet2_cuda as nat
+        parts = [p.contiguous() for p in parts]
+        v = torch.empty(sum(rows), dtype=torch.float32, device=parts[0].device)
+        nat.view_means_wrapper(parts, list(rows), v)
+        ctx.save_for_backward(coeff)
+        ctx.rows, ctx.shapes = list(rows), [p.shape for p in parts]
+        ctx.mark_non_differentiable(v)
+        return torch.dot(coeff[3], v), v
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_v=None):
+        from .. import pointnet2_cuda as nat
+        coeff, = ctx.saved_tensors
+        grads = [torch.empty(s, dtype=torch.float32, device=coeff.device) for s in ctx.shapes]
+        nat.view_means_grad_wrapper(grads, ctx.rows, coeff[3], g_loss.contiguous())
+        return (None, None) + tuple(grads)
+
+
+class _MaskConsumers(torch.autograd.Function):
+    """The stacked masks handed to their five consumers — three take all views, the invariance term the first and the second
+    half — so that the five gradients are added by ONE kernel (ogc_sum_ranges) instead of four additions and two zero-filled
+    embeddings of the halves."""
+
+    @staticmethod
+    def forward(ctx, mask, half):
+        ctx.half_elems = half * mask[0].numel()
+        ctx.shape = mask.shape
+        ctx.set_materialize_grads(False)
+        return mask.view_as(mask), mask.view_as(mask), mask.view_as(mask), mask[:half], mask[half:]
+
+    @staticmethod
+    def backward(ctx, *grads):
+        from .. import pointnet2_cuda as nat
+        firsts = [0, 0, 0, 0, ctx.half_elems]
+        have = [(g.contiguous(), f) for g, f in zip(grads, firsts) if g is not None]
+        if not have:
+            return None, None
+        out = torch.empty(ctx.shape, dtype=torch.float32, device=have[0][0].device)
+        nat.sum_ranges_wrapper([g for g, _ in have], [f for _, f in have], out)
+        return out, None
+
+
 def _monitored_terms(v, coeff):
     """[dynamic, smooth, invariance] from the per-view vector: every row sums only the entries it has a coefficient for."""
     rows = coeff[:3]
@@ -493,15 +553,25 @@ class UnsupervisedOGCLoss(nn.Module):
             geometry = sl.plan_views(list(pc.view((n_view, -1) + tuple(pc.shape[1:])).unbind(0)))
         if "knn_rev" not in geometry or "ball_rev" not in geometry:
             return None
-        parts = [rigid_residual(pc, pc + flow, mask, dl.loss_norm).view(n_view, -1).mean(dim=1),
-                 neighbour_consistency(mask, geometry["knn"], geometry["knn_rev"], kl.loss_norm).view(n_view, -1).mean(dim=1),
-                 neighbour_consistency(mask, geometry["ball"], geometry["ball_rev"], bl.loss_norm).view(n_view, -1).mean(dim=1)]
+        half = mask.shape[0] // 2   # pairs (view 0, view 2), (view 1, view 3): the first two views against the last two
+        glue = _glue_available(mask)
+        if glue and aug_transform and mask.requires_grad and "fork" in _GLUE_PARTS:
+            m_dyn, m_knn, m_ball, m_lo, m_hi = _MaskConsumers.apply(mask, half)
+        else:
+            m_dyn = m_knn = m_ball = mask
+            m_lo, m_hi = mask[:half], mask[half:]
+        terms = [rigid_residual(pc, pc + flow, m_dyn, dl.loss_norm),
+                 neighbour_consistency(m_knn, geometry["knn"], geometry["knn_rev"], kl.loss_norm),
+                 neighbour_consistency(m_ball, geometry["ball"], geometry["ball_rev"], bl.loss_norm)]
+        rows = [n_view] * 3
         if aug_transform:
-            half = mask.shape[0] // 2   # pairs (view 0, view 2), (view 1, view 3): the first two views against the last two
-            d12, d21 = matched_distances(mask[:half], mask[half:], il.loss_norm)
-            parts += [d12.view(2, -1).mean(dim=1), d21.view(2, -1).mean(dim=1)]
+            terms += list(matched_distances(m_lo, m_hi, il.loss_norm))
+            rows += [2, 2]
         coeff = _term_coefficients(n_view, aug_transform, sl.w_knn, sl.w_ball_q, weights, mask.device)
-        v = torch.cat(parts)
+        if glue and "means" in _GLUE_PARTS and all(t.numel() % r == 0 and t.numel() > 0 for t, r in zip(terms, rows)):
+            loss, v = _ViewMeansCombine.apply(coeff, tuple(rows), *terms)
+            return loss, v, coeff
+        v = torch.cat([t.view(r, -1).mean(dim=1) for t, r in zip(terms, rows)])
         return _CombineTerms.apply(v, coeff), v, coeff
 
     def forward(self, pcs, masks, flows, step_w=False, it=0, aug_transform=False, geometry=None, sync=True, stacked=None):

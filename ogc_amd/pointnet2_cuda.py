@@ -174,6 +174,41 @@ def three_interpolate_grad_rev_sliced_wrapper(b, c, n, m, grad_out, weight, rev_
     return 1
 
 
+def _host_array(ctype, values):
+    return (ctype * len(values))(*values)
+
+
+def view_means_wrapper(tensors, rows, out):
+    """out[k] = mean of row k of the dense fp32 tensors viewed as (rows[i], numel / rows[i]) (ogc_view_means)."""
+    import ctypes
+    lens = [t.numel() // r for t, r in zip(tensors, rows)]
+    if any(l * r != t.numel() or r < 1 for t, r, l in zip(tensors, rows, lens)) or out.numel() != sum(rows):
+        raise RuntimeError("view_means: rows do not divide the tensors, or out has the wrong length")
+    _run("ogc_view_means", out, len(tensors), _host_array(ctypes.c_void_p, [_f(t, "tensor") for t in tensors]),
+         _host_array(ctypes.c_int, rows), _host_array(ctypes.c_longlong, lens), _f(out, "out"))
+    return 1
+
+
+def view_means_grad_wrapper(grads, rows, weight, g_loss):
+    """grads[i] viewed as (rows[i], len_i) = (weight[k] * g_loss) / len_i, row by row (ogc_view_means_grad)."""
+    import ctypes
+    lens = [t.numel() // r for t, r in zip(grads, rows)]
+    if any(l * r != t.numel() or r < 1 for t, r, l in zip(grads, rows, lens)) or weight.numel() != sum(rows) or g_loss.numel() != 1:
+        raise RuntimeError("view_means_grad: rows do not divide the tensors, or weight / g_loss have the wrong length")
+    _run("ogc_view_means_grad", weight, len(grads), _host_array(ctypes.c_void_p, [_f(t, "grad") for t in grads]),
+         _host_array(ctypes.c_int, rows), _host_array(ctypes.c_longlong, lens), _f(weight, "weight"), _f(g_loss, "g_loss"))
+    return 1
+
+
+def sum_ranges_wrapper(parts, firsts, out):
+    """out (flat) = sum of the dense fp32 parts, part i laid over the elements [firsts[i], firsts[i] + numel) (ogc_sum_ranges)."""
+    import ctypes
+    _run("ogc_sum_ranges", out, len(parts), _host_array(ctypes.c_void_p, [_f(t, "part") for t in parts]),
+         _host_array(ctypes.c_longlong, firsts), _host_array(ctypes.c_longlong, [t.numel() for t in parts]), out.numel(),
+         _f(out, "out"))
+    return 1
+
+
 def gather_points_wrapper(b, c, n, npoints, points, idx, out):
     _run("ogc_gather_points", points, b, c, n, npoints, _f(points, "points"), _i(idx, "idx"), _f(out, "out"))
     return 1

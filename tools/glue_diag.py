@@ -1,0 +1,25 @@
+import torch, sys, os
+sys.path.insert(0, os.getcwd())
+from ogc_amd.losses import seg_loss_unsup as L
+from ogc_amd.train_step import KITTI_LOSS, _SplitViews, _views, build_criterion
+from ogc_amd.utils.synthetic import make_scene_batch
+DEV="cuda"
+crit = build_criterion(KITTI_LOSS)
+batch = make_scene_batch(2, 2048, 10, seed=77, outdoor=True, aug=True, device=DEV)
+flat, pcs_l, flows_l, pcs_s, flows_s = _views(batch)
+b, t, n = batch[1].shape
+logits = torch.randn(b, t, n, 10, device=DEV, generator=torch.Generator(device=DEV).manual_seed(3))
+res=[]
+for glue in (False, False, True, True):
+    L.LOSS_GLUE = glue
+    x = logits.clone().requires_grad_(True)
+    m = torch.softmax(x, -1); m.retain_grad()
+    *masks_l, masks_s = _SplitViews.apply(m)
+    loss, losses = crit(pcs_l, masks_l, flows_l, step_w=True, it=4000, aug_transform=True, sync=False, stacked=(pcs_s, masks_s, flows_s))
+    loss.backward()
+    res.append((loss.item(), x.grad.clone(), m.grad.clone()))
+def cmp(a,b,name):
+    for k,nm in ((1,"dlogits"),(2,"dmask")):
+        d=(a[k]-b[k]).abs().max().item()/b[k].abs().max().item(); nr=(a[k]-b[k]).double().norm().item()/b[k].double().norm().item()
+        print(name, nm, "loss %.9g %.9g  max %.3g norm %.3g"%(a[0],b[0],d,nr))
+cmp(res[0],res[1],"off/off"); cmp(res[2],res[3],"on/on"); cmp(res[2],res[0],"on/off")
