@@ -1,3 +1,5 @@
+"""The stacked OGC loss with and without the loss-glue kernels (losses/seg_loss_unsup.py LOSS_GLUE): run-to-run spread of one
+form against the difference between the two, at the masks' gradient and behind the softmax.  (development tool)"""
 import torch, sys, os
 sys.path.insert(0, os.getcwd())
 from ogc_amd.losses import seg_loss_unsup as L
