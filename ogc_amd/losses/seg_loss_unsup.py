@@ -194,11 +194,12 @@ class SmoothLoss(nn.Module):
     def forward(self, pc, mask):
         return (self.w_knn * self.knn_loss(pc, mask)) + (self.w_ball_q * self.ball_q_loss(pc, mask))
 
-    def plan_views(self, pcs):
+    def plan_views(self, pcs, stacked=None):
         """Neighbour indices of all views (coordinates only; may run ahead on a side stream): ONE kNN and ONE
         ball-query launch over the concatenated views (B*V clouds fill the GPU far better than V launches of B), plus
-        the transposed lists the fused gradient kernel gathers over."""
-        pc = torch.cat(list(pcs)).contiguous()
+        the transposed lists the fused gradient kernel gathers over.  stacked: the views as one (V B, N, 3) tensor, when the
+        caller holds them that way (then nothing is concatenated)."""
+        pc = stacked.contiguous() if stacked is not None else torch.cat(list(pcs)).contiguous()
         kl, bl = self.knn_loss, self.ball_q_loss
         idx_knn, idx_ball = _shared_grid_searches(pc, kl.k, kl.radius, bl.k, bl.radius)
         if idx_knn is None:
@@ -550,7 +551,7 @@ class UnsupervisedOGCLoss(nn.Module):
                 or (aug_transform and not matched_distance_available(mask, il.loss_norm, il.cross_entropy))):
             return None
         if geometry is None:
-            geometry = sl.plan_views(list(pc.view((n_view, -1) + tuple(pc.shape[1:])).unbind(0)))
+            geometry = sl.plan_views(list(pc.view((n_view, -1) + tuple(pc.shape[1:])).unbind(0)), stacked=pc)
         if "knn_rev" not in geometry or "ball_rev" not in geometry:
             return None
         half = mask.shape[0] // 2   # pairs (view 0, view 2), (view 1, view 3): the first two views against the last two

@@ -109,7 +109,7 @@ class _PointnetSAModuleBase(nn.Module):
             else:
                 grouped = grouper(xyz, new_xyz, features)[0]  # (B, C', npoint, nsample)
             pooled.append(mlp.forward_maxpool(grouped))       # shared MLP, then max over nsample (:38-42)
-        new_features = torch.cat(pooled, dim=1)
+        new_features = torch.cat(pooled, dim=1) if len(pooled) != 1 else pooled[0]   # (one scale: nothing to join, no copy)
         if return_inds:
             return new_xyz, new_features, new_inds
         return new_xyz, new_features
