@@ -659,7 +659,9 @@ int ogc_chamfer_terms_grad(int b, int n1, int n2, int p, const float *p1, const 
 
 /* The element-wise glue of FlowStep3D's refinement loop in inference (fused extensions; csrc/flow_step.hip).  Each replaces a
  * run of framework operators of models/flownet_kitti.py on tensors of a few thousand elements, with the same fp32 operations in
- * the same order (one rounding each, nothing contracted):
+ * the same order (one rounding each, nothing contracted) — except ogc_linear_cn and ogc_soft_corr_flow, whose dot products are
+ * FMA chains in an order of their own (the reference calls addmm / normalises and calls bmm): those two agree with the reference
+ * within tolerance, not to the bit:
  *   ogc_gather_xyz_pair  out (b, 3, m) = xyz (b, 3, n)[:, :, idx (b, m)] and out_t (b, m, 3) = its transpose
  *                        (gather_operation + transpose(1, 2).contiguous(), utils/flowstep3d_util.py:110-118);
  *   ogc_flow_advance     d = delta * scale (no multiplication when scale == 1), new = cur + d, flow = new - ref, all (b, 3, n);
@@ -678,7 +680,7 @@ int ogc_chamfer_terms_grad(int b, int n1, int n2, int p, const float *p1, const 
  *   ogc_three_nn_weights weight (b, n, 3) from ogc_three_nn's squared distances dist2 (b, n, 3): r_k = 1 / max(sqrt(d2_k), 1e-10)
  *                        (mode 0, utils/flowstep3d_util.py:169-170) or 1 / (sqrt(d2_k) + 1e-8) (mode 1, utils/pointnet2_util.py:99-101),
  *                        weight_k = r_k / ((r_0 + r_1) + r_2).
- * Gate pointers 16-byte aligned and gate batch strides multiples of 4 floats. */
+ * When s is a multiple of 4: gate pointers 16-byte aligned and gate batch strides multiples of 4 floats (other s: no requirement). */
 int ogc_gather_xyz_pair(int b, int n, int m, const float *xyz, const int *idx, float *out, float *out_t, ogc_stream_t stream);
 int ogc_flow_advance(int b, int n, float scale, const float *cur, const float *delta, const float *ref, float *out_delta,
                      float *out_new, float *out_new_t, float *out_flow, ogc_stream_t stream);

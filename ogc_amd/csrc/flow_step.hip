@@ -5,7 +5,9 @@
 // utils/flowstep3d_util.py:110-118 (gather of the cached centres, then their transpose).  One forward at C3 (one pair of 8192
 // points, iters = 5) is ~450 launches of a few microseconds each and its time is their number: every kernel here stands for
 // three to six framework launches on tensors of a few thousand elements.  Arithmetic: the same fp32 operations in the same
-// order as the operator sequence it replaces, one rounding per operation (no contraction).
+// order as the operator sequence it replaces, one rounding per operation (no contraction) — except soft_corr_flow and
+// linear_cn, whose dot products are fused multiply-add chains (the reference normalises the features and calls bmm / addmm,
+// a different summation order): those two are held to a tolerance, not to the bit (tests/test_flow_glue_gpu.py).
 //     gather_xyz_pair   out = xyz[:, :, idx] as (b, 3, m) AND as (b, m, 3)
 //     flow_advance      d = delta * scale;  new = cur + d;  flow = new - ref   (+ new as (b, n, 3))
 //     linear_cn         y (b, cout, n) = W x + bias on channel-major x (b, cin, n), cout <= 4
@@ -295,7 +297,8 @@ extern "C" int ogc_gru_reset(int b, int c, int cx, int n, int s, const float *rc
     OGC_REQUIRE(b >= 0 && c >= 0 && cx >= 0 && n >= 0 && s >= 1, "ogc_gru_reset: bad dimension");
     if (b == 0 || n == 0 || c + cx == 0) return OGC_OK;
     OGC_REQUIRE((rc || c == 0) && hx && out, "ogc_gru_reset: null pointer");
-    OGC_REQUIRE(rc_batch_stride >= (long long)c * n * s && (rc_batch_stride & 3) == 0 && ((uintptr_t)rc & 15) == 0,
+    // (16-byte loads only when a neighbourhood is a whole number of float4: other widths take pooled()'s scalar walk)
+    OGC_REQUIRE(rc_batch_stride >= (long long)c * n * s && ((s & 3) != 0 || ((rc_batch_stride & 3) == 0 && ((uintptr_t)rc & 15) == 0)),
                 "ogc_gru_reset: batch stride / alignment of the gate");
     OGC_REQUIRE(b <= 65535 && c + cx <= 65535 && (long long)b * (c + cx) * n < (1ll << 31) &&
                     (long long)b * rc_batch_stride < (1ll << 31), "ogc_gru_reset: exceeds 32-bit indexing");
@@ -312,7 +315,7 @@ extern "C" int ogc_gru_blend(int b, int c, int n, int s, const float *zc, long l
     OGC_REQUIRE(zc && qc && h && out, "ogc_gru_blend: null pointer");
     const long long need = (long long)c * n * s;
     OGC_REQUIRE(zc_batch_stride >= need && qc_batch_stride >= need && h_batch_stride >= (long long)c * n &&
-                    ((zc_batch_stride | qc_batch_stride) & 3) == 0 && (((uintptr_t)zc | (uintptr_t)qc) & 15) == 0,
+                    ((s & 3) != 0 || (((zc_batch_stride | qc_batch_stride) & 3) == 0 && (((uintptr_t)zc | (uintptr_t)qc) & 15) == 0)),
                 "ogc_gru_blend: batch strides / alignment of the gates");
     OGC_REQUIRE(b <= 65535 && c <= 65535 && (long long)b * zc_batch_stride < (1ll << 31) && (long long)b * qc_batch_stride < (1ll << 31) &&
                     (long long)b * h_batch_stride < (1ll << 31), "ogc_gru_blend: exceeds 32-bit indexing");

@@ -839,20 +839,26 @@ int fps_ref_block_shift(int work_size) {
     return pow_2;
 }
 
-// Raises a kernel's dynamic-LDS cap (needed above 64 KiB), once per process and kernel; false when the runtime refuses — the
-// caller then launches a variant that needs less.
+// Raises a kernel's dynamic-LDS cap (needed above 64 KiB), once per process, DEVICE and kernel (the attribute belongs to the
+// kernel's code object on one device: a process that drives several GPUs must raise it on each); false when the runtime
+// refuses — the caller then launches a variant that needs less.
 static bool fps_allow_lds(const void *kernel, size_t lds) {
     if (lds <= 64 * 1024) return true;
-    struct Entry { const void *kernel; size_t lds; bool ok; };
-    static Entry table[32];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    struct Entry { const void *kernel; int dev; size_t lds; bool ok; };
+    static Entry table[128];
     static int used = 0;
     static std::mutex mu;
     std::lock_guard<std::mutex> lock(mu);
     for (int i = 0; i < used; ++i)
-        if (table[i].kernel == kernel && table[i].lds >= lds) return table[i].ok;
+        if (table[i].kernel == kernel && table[i].dev == dev && table[i].lds >= lds) return table[i].ok;
     const bool ok = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
     if (!ok) (void)hipGetLastError(); // (the refusal is handled: it must not be reported by the next launch check)
-    if (used < 32) table[used++] = Entry{kernel, lds, ok};
+    if (used < 128) table[used++] = Entry{kernel, dev, lds, ok};
     return ok;
 }
 

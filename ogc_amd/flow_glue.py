@@ -105,12 +105,12 @@ def stacked_weight(*weights):
     key = (_fused._FOLD_GENERATION[0],) + tuple((w.data_ptr(), w._version, tuple(w.shape)) for w in weights)
     hit = _STACKED.get(id(weights[0]))
     if hit is None or hit[0] != key or len(hit[2]) != len(weights) or any(r() is not w for r, w in zip(hit[2], weights)):
-        if len(_STACKED) > 256:   # entries of nets that are gone
-            for k in [k for k, v in _STACKED.items() if any(r() is None for r in v[2])]:
-                del _STACKED[k]
         with torch.no_grad():
             hit = (key, torch.cat([w.reshape(w.shape[0], -1) for w in weights]).contiguous(),
                    tuple(_weakref.ref(w) for w in weights))
+        if id(weights[0]) not in _STACKED:
+            # the entry (and the device memory of its stacked copy) goes when the first weight does: a freed network leaves nothing
+            _weakref.finalize(weights[0], _STACKED.pop, id(weights[0]), None)
         _STACKED[id(weights[0])] = hit
     return hit[1]
 

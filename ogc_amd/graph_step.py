@@ -23,8 +23,19 @@ rate unless the optimizer was built with a tensor `lr`.  Reference step: train_s
 """
 import torch
 
-from .train_step import PrefetchedGeometry, train_step
+import os
+
+from .train_step import PrefetchedGeometry, prepare_adam_kernel, train_step
 from .utils import streams as _streams
+
+
+# Side streams of the step that are NOT forked inside the capture (utils/streams.stream_namespace): "all", or a comma-separated
+# list of keys ("monitor", "segnet-slots"); OGC_GRAPH_INLINE sets it.  Default: none — measured at C4 (round 6,
+# profiles/r06_graph_step.txt): every branch forked 10.74-10.81 ms per replayed step, the monitor terms in line 11.03-11.08,
+# monitor + slot branch 11.56, everything on one stream 11.53: the serialised small kernels cost more than the joins they save.
+INLINE_BRANCHES = tuple(k for k in os.environ.get("OGC_GRAPH_INLINE", "").split(",") if k)
+if INLINE_BRANCHES == ("all",):
+    INLINE_BRANCHES = "all"
 
 
 def _plan_tensors(obj):
@@ -41,6 +52,23 @@ def _plan_tensors(obj):
     elif isinstance(obj, (list, tuple)):
         for v in obj:
             yield from _plan_tensors(v)
+
+
+def _copy_all(dst, src):
+    """dst[i] <- src[i] for lists of tensors of MIXED dtypes: one multi-tensor launch per dtype.  torch._foreach_copy_ on the
+    mixed list (int32 index tables next to fp32 coordinates) leaves its fast route and issues one device-to-device copy per
+    tensor — 40 blit launches of ~5 us behind every replay of the step, which the next replay waits for (0.2 ms per step in
+    the kernel trace, profiles/r06_graph_step.txt)."""
+    groups = {}
+    for d, v in zip(dst, src):
+        if d.dtype != v.dtype or d.shape != v.shape:
+            raise RuntimeError("graph step: a plan tensor changed its type or shape (%s %s <- %s %s)"
+                               % (d.dtype, tuple(d.shape), v.dtype, tuple(v.shape)))
+        g = groups.setdefault(d.dtype, ([], []))
+        g[0].append(d)
+        g[1].append(v)
+    for ds, vs in groups.values():
+        torch._foreach_copy_(ds, vs)
 
 
 def _resolve(obj, wait):
@@ -109,6 +137,9 @@ class GraphedTrainStep:
                 for v in st.values():
                     if torch.is_tensor(v):
                         v.zero_()
+        # the step's own optimizer kernel (NaN rule + Adam, csrc/adam.hip) uploads its pointer tables from the host: before the
+        # capture, now that the state tensors exist (inside it the step would fall back to torch's eleven launches)
+        prepare_adam_kernel(self.optimizer)
 
     def recapture(self, it):
         """(Re)build the graph for the loss weights of iteration `it` (and the optimizer's current hyper-parameters)."""
@@ -121,7 +152,7 @@ class GraphedTrainStep:
             # warm-up and capture on side streams of their OWN (streams.stream_namespace): the eager geometry plans of step()
             # run on the ordinary side streams underneath a replay, and must not meet captured kernels on a stream (and so on
             # a scratch buffer) of theirs
-            with _streams.stream_namespace("graph:"):
+            with _streams.stream_namespace("graph:", inline=INLINE_BRANCHES):
                 self._warm_up(it)
                 torch.cuda.synchronize()
                 _resolve(self.plan, wait=False)
@@ -151,9 +182,8 @@ class GraphedTrainStep:
         with torch.cuda.stream(s):
             fresh = PrefetchedGeometry(self.segnet, self.criterion, batch, self.aug)
             _resolve(fresh, wait=True)
-            torch._foreach_copy_(self._plan_dst, list(_plan_tensors(fresh)))
-            torch._foreach_copy_([d for d in self.cur if torch.is_tensor(d)],
-                                 [v for d, v in zip(self.cur, batch) if torch.is_tensor(d)])
+            _copy_all(self._plan_dst + [d for d in self.cur if torch.is_tensor(d)],
+                      list(_plan_tensors(fresh)) + [v for d, v in zip(self.cur, batch) if torch.is_tensor(d)])
 
     def step(self, next_batch):
         s = self.stream
@@ -169,9 +199,8 @@ class GraphedTrainStep:
             _resolve(upcoming, wait=True)  # behind the replay: join the side streams, then shift
             src = list(_plan_tensors(upcoming))
             assert len(src) == len(self._plan_dst)
-            torch._foreach_copy_(self._plan_dst, src)
-            torch._foreach_copy_([d for d in self.cur if torch.is_tensor(d)],
-                                 [v for d, v in zip(self.cur, next_batch) if torch.is_tensor(d)])
+            _copy_all(self._plan_dst + [d for d in self.cur if torch.is_tensor(d)],
+                      src + [v for d, v in zip(self.cur, next_batch) if torch.is_tensor(d)])
             return self._pending_of_this_replay()
 
     def _pending_of_this_replay(self):

@@ -66,7 +66,13 @@ def make_optimizer(params, lr, weight_decay=0.0, capturable=False):
 ADAM_KERNEL = True   # the NaN rule + the Adam update as two launches of this library (csrc/adam.hip); False: torch's fused step
 
 
-def _adam_kernel_step(optimizer):
+def prepare_adam_kernel(optimizer):
+    """Build (or re-validate) the pointer tables of _adam_kernel_step without launching anything: what a HIP-graph capture of the
+    step needs done beforehand.  True when the optimizer is in the configuration the kernel covers and its state exists."""
+    return _adam_kernel_step(optimizer, tables_only=True) is True
+
+
+def _adam_kernel_step(optimizer, tables_only=False):
     """The reference's NaN-gradient rule and optimizer.step() of a torch.optim.Adam (one parameter group, fp32 parameters on one
     GPU, L2 weight decay, no amsgrad) as ogc_adam_step: two launches over a chunk table instead of the eleven of
     _foreach_norm / stack / sum / isnan / _foreach_add_ / 3 x multi_tensor_apply / _foreach_sub_ (0.3 ms of a C4 step's main
@@ -94,7 +100,9 @@ def _adam_kernel_step(optimizer):
                 cache = None
     if cache is None:
         if torch.cuda.is_current_stream_capturing():
-            return None  # (the tables are uploaded with host-to-device copies: not inside a capture)
+            # the tables are uploaded with host-to-device copies: not inside a capture (graph_step.py builds them right before it
+            # begins — prepare_adam_kernel — so a captured step does take this path)
+            return None
         if (group.get("amsgrad") or group.get("maximize") or group.get("differentiable") or group.get("decoupled_weight_decay")
                 or isinstance(group["lr"], torch.Tensor)):
             return None
@@ -122,6 +130,8 @@ def _adam_kernel_step(optimizer):
                  "snapshot": torch.empty(len(params), dtype=torch.float32, device=dev),
                  "array": ctypes.c_void_p * len(params)}
         optimizer._ogc_adam_tables = cache
+    if tables_only:
+        return True
     params = cache["params"]
     ptrs = []
     for p in params:
@@ -380,9 +390,13 @@ _first_skip_reported = False
 _LINALG_ERRORS = tuple(t for t in (getattr(torch.linalg, "LinAlgError", None), getattr(torch._C, "_LinAlgError", None))
                        if isinstance(t, type))
 # whole words only ("inf" / "nan" as bare substrings match "info", "inference", "nanoseconds": dropped)
+# autograd node names of anomaly mode ("Function 'SvdBackward0' returned nan values", 'LinalgEighBackward0', 'LinalgSvdBackward0')
+# carry the solver's name glued to "Backward<n>": matched by the second alternative
 _SOLVER_WORDS = __import__("re").compile(
     r"\b(gesvdj?|gesdd|syevd?j?|heevd?|geqrf|getrf|potrf|hipsolver|cusolver|rocsolver|lapack|magma|svd|eigh?|linalg|"
-    r"converge[ds]?|convergence|singular|ill-conditioned)\b", __import__("re").IGNORECASE)
+    r"converge[ds]?|convergence|singular|ill-conditioned)\b"
+    r"|\b(linalg)?_?(svd|eigh?|eigvalsh?|qr|cholesky|inv(erse)?(_ex)?|solve(_ex)?|det|slogdet|lstsq|pinv)\w*backward\d*\b"
+    r"|returned nan values", __import__("re").IGNORECASE)
 
 
 def _is_distributed(model):

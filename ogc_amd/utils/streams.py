@@ -6,6 +6,7 @@ import torch
 
 _side = {}
 _namespace = [""]
+_inline = [()]
 
 
 class stream_namespace:
@@ -14,20 +15,25 @@ class stream_namespace:
     against eager kernels queued on the stream they were captured from — so captured work and the eager work that runs
     underneath a replay (the next batch's geometry plan) must never share a stream."""
 
-    def __init__(self, prefix):
-        self.prefix = prefix
+    def __init__(self, prefix, inline=()):
+        """inline: keys of side streams that are NOT forked inside this scope — side_stream() answers with the current stream
+        for them ("all": for every key).  A graph capture uses it for branches whose kernels cost less than the joins they need:
+        the graph executor leaves ~20 us at a dependency between two branches where back-to-back kernels of one branch leave ~2."""
+        self.prefix, self.inline = prefix, inline
 
     def __enter__(self):
-        self._prev = _namespace[0]
-        _namespace[0] = self.prefix
+        self._prev = (_namespace[0], _inline[0])
+        _namespace[0], _inline[0] = self.prefix, self.inline
         return self
 
     def __exit__(self, *exc):
-        _namespace[0] = self._prev
+        _namespace[0], _inline[0] = self._prev
 
 
 def side_stream(device, key="geometry", priority=0):
     """The process-wide side stream `key` of `device`; `priority` (-1 = high) applies when it is first created."""
+    if _inline[0] == "all" or key in _inline[0]:
+        return torch.cuda.current_stream(device)
     k = (torch.device(device).index, _namespace[0] + key)
     if k not in _side:
         _side[k] = torch.cuda.Stream(device=device, priority=priority)

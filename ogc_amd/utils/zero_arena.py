@@ -22,6 +22,8 @@ CAPACITY = 64 << 20      # largest region of a step, bytes
 LARGEST = 4 << 20        # larger requests are not worth a place in it (their fill is bandwidth, not launch latency)
 import os as _os
 ENABLED = _os.environ.get("OGC_ZERO_ARENA", "1") != "0"   # (0: every operator fills its own buffers — A/B runs)
+CAPTURE = _os.environ.get("OGC_ZERO_ARENA_CAPTURE", "1") != "0"   # (0: off inside a HIP-graph capture, as until round 5)
+PINNED_LIMIT = 1 << 30   # bytes of regions kept alive by escaped slices, in a row, before the arena switches itself off
 
 _ITEMSIZE = {torch.float32: 4, torch.float64: 8, torch.int32: 4, torch.int64: 8, torch.int16: 2, torch.uint8: 1}
 
@@ -37,13 +39,43 @@ class _Arena:
         self.used = 0        # bump pointer
         self.want = 0        # extent the last step asked for (what the next fill covers)
         self.stream = None
+        self.pinned_regions = 0   # retired regions, in a row, that escaped slices kept alive
+        self.pinned_bytes = 0
+        self.disabled = False
+
+    def _retire(self):
+        """The last step's region is dropped here.  Slices of it that somebody still holds (a gradient kept across steps, a saved
+        statistic) pin the WHOLE region, not their own bytes: count what may be pinned that way, and when a caller keeps
+        collecting such tensors step after step (they pile up, up to CAPACITY each) say so once and stop handing out slices —
+        the operators then zero ordinary tensors, as they do without the arena."""
+        if self.buf is None:
+            return
+        try:  # references to the storage: `buf`, the wrapper made on this line, + one per live slice
+            held = torch._C._storage_Use_Count(self.buf.untyped_storage()._cdata) - 2
+        except Exception:  # (a private call of torch: without it nothing is counted)
+            held = 0
+        if held > 0:
+            self.pinned_regions += 1
+            self.pinned_bytes += self.filled
+            if self.pinned_bytes > PINNED_LIMIT and not self.disabled:
+                self.disabled = True
+                import warnings
+                warnings.warn("zero arena: %d step regions in a row (%.0f MiB) are still referenced by tensors that escaped their "
+                              "step; the arena is switched off for this process (operators zero their own buffers again)"
+                              % (self.pinned_regions, self.pinned_bytes / 2 ** 20))
+        else:
+            self.pinned_regions = self.pinned_bytes = 0   # only an unbroken run of pinned regions is a pile
+        self.buf = None
 
     def begin(self):
         self.stream = torch.cuda.current_stream(self.device).cuda_stream
-        self.filled = min((self.want + 255) // 256 * 256, CAPACITY)
+        self._retire()       # (first: the allocator may hand the same block back when nothing of the last step escaped)
+        self.filled = 0 if self.disabled else min((self.want + 255) // 256 * 256, CAPACITY)
         self.used = self.want = 0
-        self.buf = None      # (first: the allocator may hand the same block back when nothing of the last step escaped)
         if self.filled:
+            # inside a HIP-graph capture this allocation comes from the graph's pool (a static address) and the fill below is a
+            # kernel node: every replay starts from a zeroed region, and what escapes (param.grad) lives in graph memory like
+            # every other tensor of the capture
             self.buf = torch.empty(self.filled, dtype=torch.uint8, device=self.device)
         _lib.call("ogc_zero_arena_begin", self.buf.data_ptr() if self.filled else 0, self.filled, self.stream)
 
@@ -69,7 +101,8 @@ class zero_arena:
 
     def __enter__(self):
         global _active
-        self.on = ENABLED and self.device.type == "cuda" and _active is None and not torch.cuda.is_current_stream_capturing()
+        self.on = ENABLED and self.device.type == "cuda" and _active is None and (
+            CAPTURE or not torch.cuda.is_current_stream_capturing())
         if self.on:
             a = _arenas.get(self.device)
             if a is None:

@@ -1,8 +1,12 @@
 """The C4 training step eagerly (with the one-batch-ahead geometry prefetch) and as ONE HIP graph (ogc_amd/graph_step.py):
 ms per step of both, and the losses of the first steps side by side."""
+import os
 import sys
 import time
 import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+PHASE = os.environ.get("PHASE", "both")   # eager | graph | both  (tools/graph_gaps.py traces one at a time)
 
 import ogc_amd  # noqa: F401
 from ogc_amd.graph_step import GraphedTrainStep
@@ -26,18 +30,20 @@ batches = [make_scene_batch(4, npoint, 10, seed=1234 + i, outdoor=True, aug=True
 net, crit, opt = build()
 pre = None
 eager_losses = []
-for i in range(25):
+for i in range(25 if PHASE != "graph" else 0):
     p = train_step(net, crit, opt, batches[i % 3], 1000, True, sync=False, prefetched=pre, next_batch=batches[(i + 1) % 3])
     pre = p.prefetched
     if i < 6:
         eager_losses.append(p.result()[0]["sum"])
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-for i in range(25, 45):
+for i in range(25, 45 if PHASE != "graph" else 25):
     pre = train_step(net, crit, opt, batches[i % 3], 1000, True, sync=False, prefetched=pre,
                      next_batch=batches[(i + 1) % 3]).prefetched
 torch.cuda.synchronize()
 print("eager : %.3f ms/step" % ((time.perf_counter() - t0) / 20 * 1e3))
+if PHASE == "eager":
+    sys.exit(0)
 
 net, crit, opt = build()
 gs = GraphedTrainStep(net, crit, opt, batches[0], 1000, True)
