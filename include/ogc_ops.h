@@ -46,8 +46,9 @@ enum {
  * entry points ogc_zero_arena_begin / _end, ogc_conv1x1_gemm_any, ogc_conv1x1_wgrad_affine_pooled, ogc_conv1x1_dgrad_pooled.  0.2.1 (the patch number moves with new entry
  * points): ogc_gather_xyz_pair, ogc_flow_advance, ogc_linear_cn, ogc_gru_reset, ogc_gru_blend,
  * ogc_soft_corr_flow, ogc_three_nn_weights; ogc_furthest_point_sampling_chain accepts temp == NULL.  0.2.2: the `_h` entry points
- * (activations of the shared MLPs stored as bf16; see "16-bit activations" at the end of this header). */
-#define OGC_VERSION 203
+ * (activations of the shared MLPs stored as bf16; see "16-bit activations" at the end of this header).  0.2.4: ogc_set_deterministic /
+ * ogc_get_deterministic. */
+#define OGC_VERSION 204
 int ogc_version(void);
 /* 0: the squared distance of every search is the reference's SOURCE expression, ((dx*dx) + (dy*dy)) + (dz*dz), one rounding per
  * operation (what all parity tests pin).  1: this is libogc_ops_fmad.so, the same library with the search kernels (FPS, kNN,
@@ -55,6 +56,22 @@ int ogc_version(void);
  * makes of that expression (pointnet2/setup.py has no -fmad=false); for comparisons against index tensors produced by the real
  * CUDA binary on tie-heavy data.  Opt-in: OGC_FMAD=1 in the environment of ogc_amd. */
 int ogc_distance_contracted(void);
+/* The deterministic-gradient mode (csrc/det.hip; OGC_DETERMINISTIC=1 in the environment of ogc_amd sets it at load time).  The
+ * reference accumulates gradients with float atomics (pointnet2/src/group_points_gpu.cu:24, interpolate_gpu.cu:211-213,
+ * sampling_gpu.cu:62): their order, and so the last bits of every sum, change from launch to launch — as do this library's fast
+ * kernels.  With the mode on, the entry points below form every sum in a FIXED order (bit-identical results from run to run and
+ * from process to process on one device and build), slower, same contracts otherwise:
+ *   scatter-adds as gathers over ascending position lists — ogc_group_points_grad, ogc_gather_points_grad, ogc_group_concat_grad,
+ *     ogc_group_linear_bwd, ogc_three_interpolate_grad, ogc_chamfer_terms_grad; the transposed lists of ogc_group_reverse and
+ *     ogc_reverse_neighbours come out sorted, which fixes the order inside ogc_group_points_grad_rev*, ogc_three_interpolate_grad_rev*
+ *     and ogc_neighbour_consistency_bwd;
+ *   per-workgroup partials + one ordered pass — the weight gradients ogc_conv1x1_wgrad* (all forms), the BatchNorm statistics and
+ *     gradient sums of ogc_batch_norm_fwd / _bwd / _maxpool_fwd / _maxpool_bwd.
+ * Not converted (the GroupNorm statistics taken in convolution epilogues, the moment matrices of ogc_conv1x1_wgrad_moments*): the
+ * host layers route around them while the mode is on (ogc_amd/fused.py, DETERMINISTIC).  Forward results do not depend on the mode
+ * except through BatchNorm's batch statistics (fp64 sums, now in slab order). */
+int ogc_set_deterministic(int on);
+int ogc_get_deterministic(void);
 const char *ogc_last_error(void);
 
 /* ---- furthest point sampling -------------------------------------------------------

@@ -10,6 +10,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # OGC_FMAD=1: the variant whose search kernels contract the squared distance as the reference's nvcc build does (include/ogc_ops.h,
 # ogc_distance_contracted) — for comparing index tensors against outputs of the real CUDA binary; never the default
 FMAD = os.environ.get("OGC_FMAD", "0") == "1"
+# OGC_DETERMINISTIC=1: gradients summed in a fixed order (include/ogc_ops.h: ogc_set_deterministic) — a test mode, slower
+DETERMINISTIC = os.environ.get("OGC_DETERMINISTIC", "0") == "1"
 LIB_PATH = os.path.join(_HERE, "csrc", "libogc_ops_fmad.so" if FMAD else "libogc_ops.so")
 
 _vp = ctypes.c_void_p
@@ -20,6 +22,8 @@ _ll = ctypes.c_longlong
 
 # name -> argtypes (stream is always the trailing void*)
 SIGNATURES = {
+    "ogc_set_deterministic": [_int],
+    "ogc_get_deterministic": [],
     "ogc_furthest_point_sampling": [_int, _int, _int, _vp, _vp, _vp, _vp],
     "ogc_furthest_point_sampling_chain": [_int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp],
     "ogc_gather_points": [_int, _int, _int, _int, _vp, _vp, _vp, _vp],
@@ -143,7 +147,7 @@ for _n in ("ogc_group_linear_fwd", "ogc_group_points_grad_rev", "ogc_conv1x1_gem
 SIGNATURES["ogc_conv1x1_wgrad_xf_h"] = SIGNATURES["ogc_conv1x1_wgrad"]
 SIGNATURES["ogc_group_linear_fwd_pt_h"] = SIGNATURES["ogc_group_linear_fwd"]
 
-HEADER_VERSION = 203   # OGC_VERSION of include/ogc_ops.h the SIGNATURES table above was written against
+HEADER_VERSION = 204   # OGC_VERSION of include/ogc_ops.h the SIGNATURES table above was written against
 _lib = None
 _fns = {}  # entry point name -> bound ctypes function
 
@@ -176,13 +180,26 @@ def load():
         L.ogc_slot_masks_ws_floats.restype = ctypes.c_longlong
         L.ogc_cell_grid_bytes.restype = ctypes.c_longlong
         L.ogc_last_error.restype = ctypes.c_char_p
+        L.ogc_set_deterministic(1 if DETERMINISTIC else 0)
         _lib = L
     return _lib
+
+
+def set_deterministic(on):
+    """Switch the deterministic-gradient mode of the library and of the host layers (fused.py reads this module's flag)."""
+    global DETERMINISTIC
+    DETERMINISTIC = bool(on)
+    load().ogc_set_deterministic(1 if on else 0)
+
+
+CALL_COUNTS = None   # a collections.Counter() here counts the entry points called (tools/det_probe.py)
 
 
 def call(name, *args):
     """Invoke an entry point; non-zero status becomes a Python exception (the reference would
     have printed and exit(-1)'d, e.g. ball_query_gpu.cu:62-66)."""
+    if CALL_COUNTS is not None:
+        CALL_COUNTS[name] += 1
     fn = _fns.get(name)
     if fn is None:
         fn = _fns[name] = getattr(load(), name)

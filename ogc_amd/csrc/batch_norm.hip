@@ -45,8 +45,10 @@ __device__ __forceinline__ void bn_block_sum2(double &a, double &b, double *smem
 }
 
 // grid (chunks, C, B): partial sum / sum of squares of one (sample, channel) segment -> ws[c][0..1] (fp64 atomics)
+// part (deterministic mode, else null): the workgroup's pair goes to slab (sample, chunk) of part instead — summed in slab order
+// by ogc_det_reduce_f64
 __global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(int c, int hw, const float *__restrict__ x,
-                                                              double *__restrict__ ws) {
+                                                              double *__restrict__ ws, double *__restrict__ part) {
     __shared__ double smem[2 * BN_THREADS / 64];
     const int b = blockIdx.z, ch = blockIdx.y;
     const float *p = x + ((size_t)b * c + ch) * hw;
@@ -66,8 +68,14 @@ __global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(int c, int hw, con
     }
     bn_block_sum2(s, ss, smem);
     if (threadIdx.x == 0) {
-        atomicAdd(ws + (size_t)ch * 2, s);
-        atomicAdd(ws + (size_t)ch * 2 + 1, ss);
+        if (part) {
+            double *slab = part + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 2 * c;
+            slab[(size_t)ch * 2] = s;
+            slab[(size_t)ch * 2 + 1] = ss;
+        } else {
+            atomicAdd(ws + (size_t)ch * 2, s);
+            atomicAdd(ws + (size_t)ch * 2 + 1, ss);
+        }
     }
 }
 
@@ -177,7 +185,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_sums_kernel(int c, int hw, 
                                                                  const float *__restrict__ mean,
                                                                  const float *__restrict__ rstd,
                                                                  const float *__restrict__ dy,
-                                                                 double *__restrict__ dsdb) {
+                                                                 double *__restrict__ dsdb, double *__restrict__ part) {
     __shared__ double smem[2 * BN_THREADS / 64];
     const int b = blockIdx.z, ch = blockIdx.y;
     const float a = rstd[ch] * gamma[ch];
@@ -207,8 +215,14 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_sums_kernel(int c, int hw, 
     }
     bn_block_sum2(s, sb, smem);
     if (threadIdx.x == 0) {
-        atomicAdd(dsdb + (size_t)ch * 2, s);
-        atomicAdd(dsdb + (size_t)ch * 2 + 1, sb);
+        if (part) {
+            double *slab = part + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 2 * c;
+            slab[(size_t)ch * 2] = s;
+            slab[(size_t)ch * 2 + 1] = sb;
+        } else {
+            atomicAdd(dsdb + (size_t)ch * 2, s);
+            atomicAdd(dsdb + (size_t)ch * 2 + 1, sb);
+        }
     }
 }
 
@@ -277,7 +291,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_maxpool_bwd_sums_kernel(int c, 
                                                                          const float *__restrict__ out,
                                                                          const int *__restrict__ arg,
                                                                          const float *__restrict__ gout,
-                                                                         double *__restrict__ dsdb) {
+                                                                         double *__restrict__ dsdb, double *__restrict__ part) {
     __shared__ double smem[2 * BN_THREADS / 64];
     const int b = blockIdx.z, ch = blockIdx.y;
     const size_t base = ((size_t)b * c + ch) * p;
@@ -290,8 +304,14 @@ __global__ __launch_bounds__(BN_THREADS) void bn_maxpool_bwd_sums_kernel(int c, 
     }
     bn_block_sum2(ds, db, smem);
     if (threadIdx.x == 0) {
-        atomicAdd(dsdb + (size_t)ch * 2, ds);
-        atomicAdd(dsdb + (size_t)ch * 2 + 1, db);
+        if (part) {
+            double *slab = part + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 2 * c;
+            slab[(size_t)ch * 2] = ds;
+            slab[(size_t)ch * 2 + 1] = db;
+        } else {
+            atomicAdd(dsdb + (size_t)ch * 2, ds);
+            atomicAdd(dsdb + (size_t)ch * 2 + 1, db);
+        }
     }
 }
 
@@ -336,6 +356,14 @@ int bn_chunks(int b, int c, int hw) {
 
 bool bn_pool_shape_ok(int s) { return s >= 4 && s <= 256 && (s & (s - 1)) == 0; }
 
+// deterministic mode: one slab of 2 c doubles per workgroup of the split (grid.x chunks x grid.z samples), every entry written
+double *bn_partials(const char *name, dim3 grid, int c, hipStream_t s) {
+    if (!ogc_deterministic()) return nullptr;
+    double *part = static_cast<double *>(ogc_det_scratch(s, sizeof(double) * 2 * (size_t)c * grid.x * grid.z));
+    if (!part) ogc_set_error("%s (deterministic): no scratch memory", name);
+    return part;
+}
+
 // statistics (unless supplied) + finalize; leaves mean / rstd per channel
 int bn_prepare(const char *name, int b, int c, int hw, float eps, int training, float momentum, const float *x,
                float *running_mean, float *running_var, float *mean, float *rstd, double *ws, const double *stats,
@@ -346,7 +374,11 @@ int bn_prepare(const char *name, int b, int c, int hw, float eps, int training, 
             ogc_set_error("%s: memset failed", name);
             return OGC_ERR_LAUNCH;
         }
-        hipLaunchKernelGGL(bn_stats_kernel, dim3(bn_chunks(b, c, hw), c, b), dim3(BN_THREADS), 0, s, c, hw, x, ws);
+        const dim3 grid(bn_chunks(b, c, hw), c, b);
+        double *part = bn_partials(name, grid, c, s);
+        if (ogc_deterministic() && !part) return OGC_ERR_LAUNCH;
+        hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(BN_THREADS), 0, s, c, hw, x, ws, part);
+        if (part && ogc_det_reduce_f64(ws, part, (int)(grid.x * grid.z), 2ll * c, 0, s) != hipSuccess) return OGC_ERR_LAUNCH;
         stats = ws;
         slots = 1;
     }
@@ -407,12 +439,15 @@ extern "C" int ogc_batch_norm_bwd(int b, int c, int hw, int relu, int training, 
         return OGC_ERR_LAUNCH;
     }
     dim3 grid(bn_chunks(b, c, hw), c, b);
+    double *part = bn_partials("ogc_batch_norm_bwd", grid, c, s);
+    if (ogc_deterministic() && !part) return OGC_ERR_LAUNCH;
     if (relu)
         hipLaunchKernelGGL(bn_bwd_sums_kernel<true>, grid, dim3(BN_THREADS), 0, s, c, hw, x, gamma, beta, mean, rstd,
-                           grad_y, dsdb);
+                           grad_y, dsdb, part);
     else
         hipLaunchKernelGGL(bn_bwd_sums_kernel<false>, grid, dim3(BN_THREADS), 0, s, c, hw, x, gamma, beta, mean, rstd,
-                           grad_y, dsdb);
+                           grad_y, dsdb, part);
+    if (part && ogc_det_reduce_f64(dsdb, part, (int)(grid.x * grid.z), 2ll * c, 0, s) != hipSuccess) return OGC_ERR_LAUNCH;
     hipLaunchKernelGGL(bn_bwd_params_kernel, dim3(ogc_divup(c, 256)), dim3(256), 0, s, c, (double)b * (double)hw,
                        training, gamma, mean, rstd, dsdb, grad_gamma, grad_beta, c2c3);
     if (relu)
@@ -488,12 +523,15 @@ extern "C" int ogc_batch_norm_maxpool_bwd(int b, int c, int p, int s, int relu, 
     int bs = ogc_divup(p, BN_THREADS);
     while (bs > 1 && (long long)bs * c * b > 4096) bs = (bs + 1) / 2;
     dim3 gsum(bs, c, b);
+    double *part = bn_partials("ogc_batch_norm_maxpool_bwd", gsum, c, st);
+    if (ogc_deterministic() && !part) return OGC_ERR_LAUNCH;
     if (relu)
         hipLaunchKernelGGL(bn_maxpool_bwd_sums_kernel<true>, gsum, dim3(BN_THREADS), 0, st, c, p, s, x, out, argmax,
-                           grad_out, dsdb);
+                           grad_out, dsdb, part);
     else
         hipLaunchKernelGGL(bn_maxpool_bwd_sums_kernel<false>, gsum, dim3(BN_THREADS), 0, st, c, p, s, x, out, argmax,
-                           grad_out, dsdb);
+                           grad_out, dsdb, part);
+    if (part && ogc_det_reduce_f64(dsdb, part, (int)(gsum.x * gsum.z), 2ll * c, 0, st) != hipSuccess) return OGC_ERR_LAUNCH;
     hipLaunchKernelGGL(bn_bwd_params_kernel, dim3(ogc_divup(c, 256)), dim3(256), 0, st, c,
                        (double)b * (double)p * (double)s, training, gamma, mean, rstd, dsdb, grad_gamma, grad_beta, c2c3);
     const int rows_per_block = BN_THREADS / (s / 4);

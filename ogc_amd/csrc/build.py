@@ -10,7 +10,7 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["api.hip", "knn.hip", "ball_query.hip", "fps.hip", "gather_group.hip", "interpolate.hip", "kabsch.hip", "small_solvers.hip", "neighbour_loss.hip", "soft_nn.hip", "seg_loss.hip", "group_norm.hip", "batch_norm.hip", "grid.hip", "conv1x1.hip", "conv1x1_h.hip", "conv1x1_wgrad.hip", "attention.hip", "slot_masks.hip", "small_linear.hip", "loss_glue.hip", "mlp_chain.hip", "gn_fused_bwd.hip", "adam.hip", "gemm_chunk.hip", "chamfer.hip", "flow_step.hip"]
+SOURCES = ["api.hip", "det.hip", "knn.hip", "ball_query.hip", "fps.hip", "gather_group.hip", "interpolate.hip", "kabsch.hip", "small_solvers.hip", "neighbour_loss.hip", "soft_nn.hip", "seg_loss.hip", "group_norm.hip", "batch_norm.hip", "grid.hip", "conv1x1.hip", "conv1x1_h.hip", "conv1x1_wgrad.hip", "attention.hip", "slot_masks.hip", "small_linear.hip", "loss_glue.hip", "mlp_chain.hip", "gn_fused_bwd.hip", "adam.hip", "gemm_chunk.hip", "chamfer.hip", "flow_step.hip"]
 HEADERS = ["ogc_common.h", "grid.h", "conv_stage.h", "conv1x1_shared.h", "act_io.h", "conv1x1_epilogue.h", os.path.join("..", "..", "include", "ogc_ops.h")]
 LIB = os.path.join(HERE, "libogc_ops.so")
 # The search kernels once more with the distance expression contracted as `nvcc --fmad=true` contracts it (ogc_common.h, OGC_FMAD):

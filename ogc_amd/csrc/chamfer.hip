@@ -64,6 +64,43 @@ __global__ __launch_bounds__(256) void chamfer_terms_grad_kernel(int n1, int n2,
     unsafeAtomicAdd(o + 2, gz);
 }
 
+// deterministic mode: one thread per point of p1 — its own term (direction 1) first, then the terms of the points of pc2 whose
+// nearest neighbour it is (direction 2) in ascending order of those points (lists from ogc_det_lists over idx21)
+__global__ __launch_bounds__(256) void chamfer_terms_grad_det_kernel(int n1, int n2, int p, const float *__restrict__ p1,
+                                                                     const float *__restrict__ pc2, const int *__restrict__ idx12,
+                                                                     const int *__restrict__ start, const int *__restrict__ pos,
+                                                                     const float *__restrict__ g1, const float *__restrict__ g2,
+                                                                     float *__restrict__ grad_p1) {
+    const int b = blockIdx.y, k1 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k1 >= n1) return;
+    const float *a = p1 + (size_t)b * n1 * 3, *c = pc2 + (size_t)b * n2 * 3;
+    const float *u = a + (size_t)k1 * 3;
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    auto term = [&](const float *v, float g) {
+        const float dx = u[0] - v[0], dy = u[1] - v[1], dz = u[2] - v[2];
+        float gx, gy, gz;
+        if (p == 1) {
+            gx = dx > 0.f ? g : (dx < 0.f ? -g : 0.f);
+            gy = dy > 0.f ? g : (dy < 0.f ? -g : 0.f);
+            gz = dz > 0.f ? g : (dz < 0.f ? -g : 0.f);
+        } else {
+            const float nrm = sqrtf((dx * dx + dy * dy) + dz * dz);
+            const float s = nrm > 0.f ? g / nrm : 0.f;
+            gx = dx * s; gy = dy * s; gz = dz * s;
+        }
+        ax += gx; ay += gy; az += gz;
+    };
+    term(c + (size_t)idx12[(size_t)b * n1 + k1] * 3, g1[(size_t)b * n1 + k1]);
+    const int *rs = start + (size_t)b * (n1 + 1);
+    const int *ps = pos + (size_t)b * n2;
+    for (int e = rs[k1]; e < rs[k1 + 1]; ++e) {
+        const int i = ps[e];
+        term(c + (size_t)i * 3, g2[(size_t)b * n2 + i]);
+    }
+    float *o = grad_p1 + ((size_t)b * n1 + k1) * 3;
+    o[0] = ax; o[1] = ay; o[2] = az;
+}
+
 } // namespace
 
 extern "C" int ogc_chamfer_terms(int b, int n1, int n2, int p, const float *p1, const float *pc2, const int *idx12,
@@ -89,6 +126,15 @@ extern "C" int ogc_chamfer_terms_grad(int b, int n1, int n2, int p, const float 
     OGC_REQUIRE(p1 && pc2 && idx12 && idx21 && g1 && g2 && grad_p1, "ogc_chamfer_terms_grad: null pointer");
     OGC_REQUIRE(b <= 65535 && (long long)b * (n1 > n2 ? n1 : n2) * 3 < (1ll << 31), "ogc_chamfer_terms_grad: exceeds 32-bit indexing");
     hipStream_t s = (hipStream_t)stream;
+    if (ogc_deterministic()) {
+        const int *start = nullptr, *pos = nullptr;
+        const int rc = ogc_det_lists("ogc_chamfer_terms_grad", b, n1, n2, idx21, &start, &pos, 0, nullptr, s);
+        if (rc != OGC_OK) return rc;
+        hipLaunchKernelGGL(chamfer_terms_grad_det_kernel, dim3(ogc_divup(n1, 256), b), dim3(256), 0, s, n1, n2, p, p1, pc2, idx12,
+                           start, pos, g1, g2, grad_p1);
+        OGC_CHECK_LAUNCH("ogc_chamfer_terms_grad");
+        return OGC_OK;
+    }
     if (ogc_zero_async(grad_p1, sizeof(float) * (size_t)b * n1 * 3, s) != hipSuccess) {
         ogc_set_error("ogc_chamfer_terms_grad: zero fill failed");
         return OGC_ERR_LAUNCH;

@@ -26,6 +26,16 @@ namespace {
 // (ag, arg) = inj[b, row, pos / S] (ogc_group_norm_maxpool_bwd_sparse; a step's 16 positions lie inside one neighbourhood,
 // S = 16, 32, 64) — the expression of gn_maxpool_bwd_dx_kernel, bit for bit.
 // XT / YT: element types of x and dy (float / ogc_bf16: act_io.h).
+// A workgroup's share of dW[row][col].  Ordinarily one fp32 atomic per element and workgroup (the workgroups of a tile split the
+// positions among them: blockIdx.x); with slab != 0 (the deterministic mode, det.hip) a plain store into slab blockIdx.x of a
+// scratch buffer instead — zeros included — and ogc_det_reduce_f32 adds the slabs to dW in blockIdx.x order afterwards.
+__device__ __forceinline__ void wgrad_emit(float *__restrict__ dw, long long slab, int row, int col, int cout, int cin, float v) {
+    if (row < cout && col < cin) {
+        if (slab) dw[(size_t)blockIdx.x * slab + (size_t)row * cin + col] = v;
+        else if (v != 0.0f) unsafeAtomicAdd(dw + (size_t)row * cin + col, v);
+    }
+}
+
 template <int COB, int CIB, bool PRO, bool BF, bool POOLED = false, typename XT = float, typename YT = float>
 __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_wgrad_kernel(int batch, int cin, int cout, int hw,
                                                                            int steps_per_wave,
@@ -36,7 +46,7 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_wgrad_kernel(int b
                                                                            const float *__restrict__ aff_b, int pro_relu,
                                                                            const float2 *__restrict__ coef2 = nullptr,
                                                                            const float2 *__restrict__ inj = nullptr,
-                                                                           int s_shift = 0) {
+                                                                           int s_shift = 0, long long slab = 0) {
     // the four waves' partial tiles, one slab each (plain stores: ds_add_f32 sustains well under one lane per cycle), summed
     // by the threads that send them on
     __shared__ float red[WG_WAVES][COB * CIB * 256];
@@ -189,7 +199,7 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_wgrad_kernel(int b
         const int blk = t >> 8, a = blk / CIB, c = blk % CIB;
         const int row = co0 + a * 16 + ((t & 255) >> 4), col = ci0 + c * 16 + (t & 15);
         const float v = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
-        if (row < cout && col < cin && v != 0.0f) unsafeAtomicAdd(dw + (size_t)row * cin + col, v);
+        wgrad_emit(dw, slab, row, col, cout, cin, v);
     }
 }
 
@@ -229,7 +239,8 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_wgrad16_kernel(int
                                                                              const float *__restrict__ aff_a,
                                                                              const float *__restrict__ aff_b, int pro_relu,
                                                                              const float2 *__restrict__ coef2,
-                                                                             const float2 *__restrict__ inj, int s_shift) {
+                                                                             const float2 *__restrict__ inj, int s_shift,
+                                                                             long long slab) {
     __shared__ float red[WG_WAVES][COB * CIB * 256];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 15, k = lane >> 4;
@@ -363,8 +374,30 @@ __global__ __launch_bounds__(WG_WAVES *OGC_WAVE) void conv1x1_wgrad16_kernel(int
         const int blk = t >> 8, a = blk / CIB, c = blk % CIB;
         const int row = co0 + a * 16 + ((t & 255) >> 4), col = ci0 + c * 16 + (t & 15);
         const float v = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
-        if (row < cout && col < cin && v != 0.0f) unsafeAtomicAdd(dw + (size_t)row * cin + col, v);
+        wgrad_emit(dw, slab, row, col, cout, cin, v);
     }
+}
+
+// Deterministic mode: `splits` zeroed slabs of cout x cin floats in the stream's scratch (a workgroup without positions leaves
+// its slab alone); nullptr + g_wgrad_det_failed when the scratch cannot be had.  Otherwise dw itself and slab 0.
+thread_local bool g_wgrad_det_failed = false;
+float *wgrad_det_slabs(float *dw, int splits, int cin, int cout, long long &slab, hipStream_t s) {
+    slab = 0;
+    if (!ogc_deterministic()) return dw;
+    const size_t words = (size_t)splits * cout * cin;
+    float *part = static_cast<float *>(ogc_det_scratch(s, words * sizeof(float)));
+    if (!part) {
+        g_wgrad_det_failed = true;
+        return nullptr;
+    }
+    const size_t blocks = (words + 255) / 256;
+    hipLaunchKernelGGL(ogc_zero_kernel, dim3((unsigned)(blocks > 2048 ? 2048 : blocks)), dim3(256), 0, s,
+                       reinterpret_cast<uint32_t *>(part), words);
+    slab = (long long)cout * cin;
+    return part;
+}
+void wgrad_det_finish(float *dw, const float *part, int splits, long long slab, hipStream_t s) {
+    if (slab && ogc_det_reduce_f32(dw, part, splits, slab, 1, s) != hipSuccess) g_wgrad_det_failed = true;
 }
 
 template <int COB, int CIB, typename XT = float, typename YT = float>
@@ -387,25 +420,29 @@ void wgrad_launch(int b, int cin, int cout, int hw, const XT *x, const YT *dy, f
     spw = (spw + 1) / 2 * 2;
     const int wgs = (int)((nsteps + spw * WG_WAVES - 1) / (spw * WG_WAVES));
     dim3 grid(wgs, ogc_divup(cout, 16 * COB), ogc_divup(cin, 16 * CIB));
+    long long slab = 0;
+    float *const dst = wgrad_det_slabs(dw, wgs, cin, cout, slab, s); // (dw itself unless the deterministic mode is on)
+    if (!dst) return;
     if constexpr (Y16) {
         if (wide) {
 #define OGC_WGRAD16(PROV, POOLV)                                                                                               \
     hipLaunchKernelGGL((conv1x1_wgrad16_kernel<COB, CIB, PROV, POOLV, XT>), grid, dim3(WG_WAVES * OGC_WAVE), 0, s, b, cin, cout, hw, \
-                       (int)spw, x, dy, dw, pa, pb, pro_relu, coef2, inj, s_shift)
+                       (int)spw, x, dy, dst, pa, pb, pro_relu, coef2, inj, s_shift, slab)
             if (inj) OGC_WGRAD16(true, true);
             else if (pa) OGC_WGRAD16(true, false);
             else OGC_WGRAD16(false, false);
 #undef OGC_WGRAD16
+            wgrad_det_finish(dw, dst, wgs, slab, s);
             return;
         }
     }
 #define OGC_WGRAD(PROV, BFV)                                                                                          \
     hipLaunchKernelGGL((conv1x1_wgrad_kernel<COB, CIB, PROV, BFV, false, XT, YT>), grid, dim3(WG_WAVES * OGC_WAVE), 0, s, b, cin, cout, \
-                       hw, (int)spw, x, dy, dw, pa, pb, pro_relu)
+                       hw, (int)spw, x, dy, dst, pa, pb, pro_relu, nullptr, nullptr, 0, slab)
     if (inj) { // pooled form of dy (fp32 operands, previous layer's norm folded in): see POOLED
         // (fp32 operands for fp32 tensors whatever the precision switch says; 16-bit tensors: bf16 operands)
         hipLaunchKernelGGL((conv1x1_wgrad_kernel<COB, CIB, true, sizeof(YT) == 2, true, XT, YT>), grid, dim3(WG_WAVES * OGC_WAVE), 0, s, b, cin, cout,
-                           hw, (int)spw, x, dy, dw, pa, pb, pro_relu, coef2, inj, s_shift);
+                           hw, (int)spw, x, dy, dst, pa, pb, pro_relu, coef2, inj, s_shift, slab);
     } else if (g_matmul_bf16 || sizeof(XT) == 2 || sizeof(YT) == 2) { // (16-bit tensors: checked to come with bf16 operands)
         if (pa) OGC_WGRAD(true, true);
         else OGC_WGRAD(false, true);
@@ -416,6 +453,7 @@ void wgrad_launch(int b, int cin, int cout, int hw, const XT *x, const YT *dy, f
         }
     }
 #undef OGC_WGRAD
+    wgrad_det_finish(dw, dst, wgs, slab, s);
 }
 
 
@@ -443,7 +481,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_wgrad_shared_kernel(int batch,
                                                                       float *__restrict__ dw, const float *__restrict__ aff_a,
                                                                       const float *__restrict__ aff_b, int pro_relu,
                                                                       const float2 *__restrict__ coef2,
-                                                                      const float2 *__restrict__ inj, int s_shift) {
+                                                                      const float2 *__restrict__ inj, int s_shift, long long slab) {
     constexpr int YROWS = 128, WS_ROWS = YROWS + 128, YJ = 4, XJ = 4, NJ = YJ + XJ; // pieces per thread: dy, x
     constexpr int RSTEP = 32;                                        // rows between a thread's pieces
     extern __shared__ __attribute__((aligned(16))) float ws_lds[]; // [2][WS_ROWS][WS_LD]
@@ -585,7 +623,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_wgrad_shared_kernel(int batch,
             for (int r = 0; r < 4; ++r) {
                 const int row = co0 + half_r * 64 + a * 16 + k * 4 + r, col = ci0 + half_c * 64 + c * 16 + i;
                 const float v = acc[a][c][r];
-                if (row < cout && col < cin && v != 0.0f) unsafeAtomicAdd(dw + (size_t)row * cin + col, v);
+                wgrad_emit(dw, slab, row, col, cout, cin, v);
             }
 }
 
@@ -605,7 +643,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_wgrad_shared16_kernel(int batc
                                                                         float *__restrict__ dw, const float *__restrict__ aff_a,
                                                                         const float *__restrict__ aff_b, int pro_relu,
                                                                         const float2 *__restrict__ coef2,
-                                                                        const float2 *__restrict__ inj, int s_shift) {
+                                                                        const float2 *__restrict__ inj, int s_shift, long long slab) {
     constexpr int YROWS = 128, W_ROWS = YROWS + 128, YJ = 4, XJ = 4, NJ = YJ + XJ; // pieces per thread: dy, x
     constexpr int RSTEP = 32;                                                    // rows between a thread's pieces
     extern __shared__ __attribute__((aligned(16))) ogc_bf16 w16_lds[]; // [2][W_ROWS][W16_LD]
@@ -740,7 +778,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_wgrad_shared16_kernel(int batc
             for (int r = 0; r < 4; ++r) {
                 const int row = co0 + half_r * 64 + a * 16 + k * 4 + r, col = ci0 + half_c * 64 + c * 16 + i;
                 const float v = acc[a][c][r];
-                if (row < cout && col < cin && v != 0.0f) unsafeAtomicAdd(dw + (size_t)row * cin + col, v);
+                wgrad_emit(dw, slab, row, col, cout, cin, v);
             }
 }
 
@@ -759,18 +797,22 @@ bool wgrad_shared16_launch(int b, int cin, int cout, int hw, const ogc_bf16 *x, 
     if (spw < 8) spw = 8;
     const int gx = (int)((nstages + spw - 1) / spw);
     dim3 grid(gx, ogc_divup(cout, 128), ogc_divup(cin, 128));
+    long long slab = 0;
+    float *const dst = wgrad_det_slabs(dw, gx, cin, cout, slab, s);
+    if (!dst) return true; // (the failure is reported by wgrad_impl)
 #define OGC_WGS16(PROV, POOLV)                                                                                                 \
     {                                                                                                                          \
         static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(conv1x1_wgrad_shared16_kernel<PROV, POOLV>),   \
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;         \
         if (!ok) { (void)hipGetLastError(); return false; }                                                                    \
         hipLaunchKernelGGL((conv1x1_wgrad_shared16_kernel<PROV, POOLV>), grid, dim3(256), lds, s, b, cin, cout, hw, (int)spw, x, \
-                           dy, dw, pa, pb, pro_relu, coef2, inj, s_shift);                                                      \
+                           dy, dst, pa, pb, pro_relu, coef2, inj, s_shift, slab);                                               \
     }
     if (inj) OGC_WGS16(true, true)
     else if (pa) OGC_WGS16(true, false)
     else OGC_WGS16(false, false)
 #undef OGC_WGS16
+    wgrad_det_finish(dw, dst, gx, slab, s);
     return true;
 }
 
@@ -796,20 +838,25 @@ bool wgrad_shared_launch(int b, int cin, int cout, int hw, const XT *x, const YT
     if (spw < 8) spw = 8;
     const int gx = (int)((nstages + spw - 1) / spw);
     dim3 grid(gx, ogc_divup(cout, 128), ogc_divup(cin, 128));
+    constexpr bool F32 = sizeof(XT) == 4 && sizeof(YT) == 4;
+    if (inj && !pa) return false;
+    long long slab = 0;
+    float *const dst = wgrad_det_slabs(dw, gx, cin, cout, slab, s);
+    if (!dst) return true; // (the failure is reported by wgrad_impl)
 #define OGC_WGS(PROV, POOLV, BFV)                                                                                            \
     {                                                                                                                        \
         static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(conv1x1_wgrad_shared_kernel<PROV, POOLV, BFV, XT, YT>), \
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;       \
         if (!ok) { (void)hipGetLastError(); return false; }                                                                  \
         hipLaunchKernelGGL((conv1x1_wgrad_shared_kernel<PROV, POOLV, BFV, XT, YT>), grid, dim3(256), lds, s, b, cin, cout, hw, (int)spw, \
-                           x, dy, dw, pa, pb, pro_relu, coef2, inj, s_shift);                                                 \
+                           x, dy, dst, pa, pb, pro_relu, coef2, inj, s_shift, slab);                                          \
     }
     // (the pooled form keeps fp32 operands whatever the precision switch says, as with the register tiles)
-    constexpr bool F32 = sizeof(XT) == 4 && sizeof(YT) == 4;
-    if (inj) { if (pa) OGC_WGS(true, true, !F32) else return false; }
+    if (inj) { OGC_WGS(true, true, !F32) }
     else if (g_matmul_bf16 || !F32) { if (pa) OGC_WGS(true, false, true) else OGC_WGS(false, false, true) }
     else if constexpr (F32) { if (pa) OGC_WGS(true, false, false) else OGC_WGS(false, false, false) }
 #undef OGC_WGS
+    wgrad_det_finish(dw, dst, gx, slab, s);
     return true;
 }
 
@@ -838,16 +885,25 @@ int wgrad_impl(const char *name, int b, int cin, int cout, int hw, const XT *x, 
         return OGC_ERR_LAUNCH;
     }
     if (b == 0) return OGC_OK;
+    g_wgrad_det_failed = false;
+    struct DetCheck { // (deterministic mode: a launcher that could not get its slabs or its ordered pass says so here)
+        const char *name;
+        int status() const {
+            if (!g_wgrad_det_failed) return OGC_OK;
+            ogc_set_error("%s (deterministic): no scratch memory for the partial tiles, or their ordered pass failed", name);
+            return OGC_ERR_LAUNCH;
+        }
+    } det{name};
     // layers of 128 channels and more on both sides: a 128 x 128 tile per workgroup, operands shared through LDS
     if constexpr (sizeof(XT) == 2 && sizeof(YT) == 2) { // both tensors in 16 bits: 64-position stages of packed operands
         if (wgrad_shared16_launch(b, cin, cout, hw, x, dy, dw, pa, pb, pro_relu, s, coef2, inj, s_shift)) {
             OGC_CHECK_LAUNCH(name);
-            return OGC_OK;
+            return det.status();
         }
     }
     if (wgrad_shared_launch(b, cin, cout, hw, x, dy, dw, pa, pb, pro_relu, s, coef2, inj, s_shift)) {
         OGC_CHECK_LAUNCH(name);
-        return OGC_OK;
+        return det.status();
     }
     // register tile per wave: (16*COB) x (16*CIB) outputs.  Small channel counts use small tiles so that no MFMA
     // work is spent on padding; wide layers use 64x64 tiles (16 accumulators) and split the rest over the grid.
@@ -855,7 +911,7 @@ int wgrad_impl(const char *name, int b, int cin, int cout, int hw, const XT *x, 
         if (cin <= 32) wgrad_launch<4, 2, XT, YT>(b, cin, cout, hw, x, dy, dw, pa, pb, pro_relu, s, coef2, inj, s_shift);
         else wgrad_launch<4, 4, XT, YT>(b, cin, cout, hw, x, dy, dw, pa, pb, pro_relu, s, coef2, inj, s_shift);
         OGC_CHECK_LAUNCH(name);
-        return OGC_OK;
+        return det.status();
     }
     if (cout <= 16 && cin <= 16) wgrad_launch<1, 1, XT, YT>(b, cin, cout, hw, x, dy, dw, pa, pb, pro_relu, s);
     else if (cout <= 32 && cin <= 16) wgrad_launch<2, 1, XT, YT>(b, cin, cout, hw, x, dy, dw, pa, pb, pro_relu, s);
@@ -865,7 +921,7 @@ int wgrad_impl(const char *name, int b, int cin, int cout, int hw, const XT *x, 
     else if (cout <= 32) wgrad_launch<2, 4, XT, YT>(b, cin, cout, hw, x, dy, dw, pa, pb, pro_relu, s);
     else wgrad_launch<4, 4, XT, YT>(b, cin, cout, hw, x, dy, dw, pa, pb, pro_relu, s);
     OGC_CHECK_LAUNCH(name);
-    return OGC_OK;
+    return det.status();
 }
 } // namespace
 

@@ -292,6 +292,34 @@ int group_fwd(const char *name, int b, int c, int n, int T, const float *points,
     return OGC_OK;
 }
 
+// deterministic mode: dwx[ch][k] += sum over samples and positions of grad_out[b, ch, t] * rel[b, k, t] — one workgroup per channel,
+// thread i takes positions i, i + 256, ... of sample 0, 1, ... in that order, then a fixed tree over the 256 partial sums
+__global__ __launch_bounds__(256) void det_dwx_kernel(int b, int c, int T, long long go_bstride, const float *__restrict__ grad_out,
+                                                      const float *__restrict__ rel, float *__restrict__ dwx) {
+    __shared__ float red[3][256];
+    const int ch = blockIdx.x, t0 = threadIdx.x;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int bb = 0; bb < b; ++bb) {
+        const float *g = grad_out + (size_t)bb * go_bstride + (size_t)ch * T;
+        const float *r = rel + (size_t)bb * 3 * T;
+        for (int t = t0; t < T; t += 256) {
+            const float v = g[t];
+            a0 = fmaf(v, r[t], a0);
+            a1 = fmaf(v, r[(size_t)T + t], a1);
+            a2 = fmaf(v, r[2 * (size_t)T + t], a2);
+        }
+    }
+    red[0][t0] = a0; red[1][t0] = a1; red[2][t0] = a2;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (t0 < off) {
+            red[0][t0] += red[0][t0 + off]; red[1][t0] += red[1][t0 + off]; red[2][t0] += red[2][t0 + off];
+        }
+        __syncthreads();
+    }
+    if (t0 < 3) dwx[ch * 3 + t0] += red[t0][0];
+}
+
 int group_bwd(const char *name, int b, int c, int n, int T, const float *grad_out, const int *idx,
               float *grad_points, ogc_stream_t stream, long long go_bstride = -1, const float *rel = nullptr,
               float *dwx = nullptr) {
@@ -302,6 +330,15 @@ int group_bwd(const char *name, int b, int c, int n, int T, const float *grad_ou
     OGC_REQUIRE(grad_out && idx && grad_points, "%s: null pointer", name);
     OGC_REQUIRE(go_bstride < (1ll << 31) && (long long)c * n < (1ll << 31) && b <= 65535,
                 "%s: one sample exceeds 32-bit indexing", name);
+    if (ogc_deterministic()) {
+        // every sum in ascending position order, one thread per output (det.hip); the coordinate columns of a grouped first
+        // layer's weight gradient by one workgroup per channel in a fixed order
+        const int rc = ogc_det_scatter_add(name, b, c, n, T, idx, grad_out, go_bstride, nullptr, 0, grad_points, 1, (hipStream_t)stream);
+        if (rc != OGC_OK || !dwx) return rc;
+        hipLaunchKernelGGL(det_dwx_kernel, dim3(c), dim3(256), 0, (hipStream_t)stream, b, c, T, go_bstride, grad_out, rel, dwx);
+        OGC_CHECK_LAUNCH(name);
+        return OGC_OK;
+    }
     const bool vec = (T % 4 == 0) && aligned16(idx) && aligned16(grad_out) && go_bstride % 4 == 0;
     // LDS-privatised path: the per-channel image (n floats) must fit a 64 KiB budget at least once
     if (vec && n <= 16384 && T >= 4096 && T % 16 == 0) {
@@ -715,7 +752,7 @@ constexpr int GRB_THREADS = 1024;
 __global__ __launch_bounds__(GRB_THREADS) void group_reverse_kernel(int n, int T, int tc, const int *__restrict__ idx,
                                                                     int *__restrict__ rev_start,
                                                                     unsigned short *__restrict__ rev_pos,
-                                                                    unsigned short *__restrict__ heads) {
+                                                                    unsigned short *__restrict__ heads, int sorted) {
     extern __shared__ int grb_hist[]; // [n] counts, then cursors
     __shared__ int wsum[GRB_THREADS / 64];
     __shared__ int carry;
@@ -770,6 +807,21 @@ __global__ __launch_bounds__(GRB_THREADS) void group_reverse_kernel(int n, int T
         const int j = id[p];
         const bool head = (p & 15) == 0 || id[p - 1] != j;
         if (head && j >= 0 && j < n) rp[atomicAdd(&grb_hist[j], 1)] = (unsigned short)(p - t0);
+    }
+    if (sorted) { // deterministic mode: the slot an entry got inside its list was a race — every list ascending (insertion, in place)
+        __syncthreads();
+        for (int j = t; j < n; j += GRB_THREADS) {
+            const int lo = rs[j], hi = rs[j + 1];
+            for (int i = lo + 1; i < hi; ++i) {
+                const unsigned short v = rp[i];
+                int k = i - 1;
+                while (k >= lo && rp[k] > v) {
+                    rp[k + 1] = rp[k];
+                    --k;
+                }
+                rp[k + 1] = v;
+            }
+        }
     }
 }
 
@@ -947,7 +999,7 @@ extern "C" int ogc_group_reverse(int b, int n, int npoints, int nsample, const i
         }
     }
     hipLaunchKernelGGL(group_reverse_kernel, dim3(chunks, b), dim3(GRB_THREADS), (size_t)n * sizeof(int),
-                       (hipStream_t)stream, n, T, tc, idx, rev_start, rev_pos, heads);
+                       (hipStream_t)stream, n, T, tc, idx, rev_start, rev_pos, heads, ogc_deterministic() ? 1 : 0);
     OGC_CHECK_LAUNCH("ogc_group_reverse");
     return OGC_OK;
 }

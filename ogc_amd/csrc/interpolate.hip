@@ -132,6 +132,9 @@ extern "C" int ogc_three_interpolate_grad(int b, int c, int n, int m, const floa
     OGC_REQUIRE(grad_out && idx && weight && grad_points, "ogc_three_interpolate_grad: null pointer");
     OGC_REQUIRE((long long)b * c * n < (1ll << 31) && (long long)b * c * m < (1ll << 31),
                 "ogc_three_interpolate_grad: tensor exceeds 32-bit indexing");
+    if (ogc_deterministic()) // the three products of a target in position order, every sum ascending (det.hip)
+        return ogc_det_scatter_add("ogc_three_interpolate_grad", b, c, m, 3ll * n, idx, grad_out, (long long)c * n, weight, 1,
+                                   grad_points, 1, (hipStream_t)stream);
     if (m <= 16384 && n >= 1024) { // LDS-privatised path: CC channel images of m floats within 64 KiB
         int cc = 4096 / m;   // 16 KiB images (one channel when m > 4096): more workgroups per CU, see group_bwd
         if (cc < 1) cc = 1;

@@ -134,6 +134,26 @@ __global__ __launch_bounds__(256) void rev_fill_kernel(long long total, int n, i
     rev_src[b * (long long)n * k + pos] = (int)((unsigned)src | (e % k == 0 ? REV_FIRST : 0u));
 }
 
+// deterministic mode: the slot an entry got inside its list was a race between the lanes of rev_fill_kernel — every list
+// ascending by source point (the flag bit rides along), one thread per destination, in place
+__global__ __launch_bounds__(256) void rev_sort_kernel(int n, int k, const int *__restrict__ rev_start, int *__restrict__ rev_src) {
+    const int j = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (j >= n) return;
+    const int *rs = rev_start + (size_t)b * (n + 1);
+    int *a = rev_src + (size_t)b * n * k;
+    const int lo = rs[j], hi = rs[j + 1];
+    for (int i = lo + 1; i < hi; ++i) {
+        const int v = a[i];
+        const unsigned key = (unsigned)v & ~REV_FIRST;
+        int q = i - 1;
+        while (q >= lo && ((unsigned)a[q] & ~REV_FIRST) > key) {
+            a[q + 1] = a[q];
+            --q;
+        }
+        a[q + 1] = v;
+    }
+}
+
 template <int P>
 __device__ __forceinline__ void nc_edge(const float *a, const float *b_, int c, float w, float *g /*[c] in LDS*/,
                                         int stride) {
@@ -242,6 +262,7 @@ extern "C" int ogc_reverse_neighbours(int b, int n, int k, const int *idx, int *
     }
     hipLaunchKernelGGL(rev_scan_kernel, dim3(b), dim3(1024), 0, s, n, rev_start, ws);
     hipLaunchKernelGGL(rev_fill_kernel, dim3(blocks), dim3(256), 0, s, total, n, k, idx, ws, rev_src);
+    if (ogc_deterministic()) hipLaunchKernelGGL(rev_sort_kernel, dim3(ogc_divup(n, 256), b), dim3(256), 0, s, n, k, rev_start, rev_src);
     OGC_CHECK_LAUNCH("ogc_reverse_neighbours");
     return OGC_OK;
 }

@@ -31,6 +31,19 @@ void *ogc_workspace(hipStream_t stream, size_t bytes);
 
 static inline int ogc_divup(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// ---- the deterministic-gradient mode (det.hip; ogc_set_deterministic) -------------------------------------------------------
+bool ogc_deterministic();
+void *ogc_det_scratch(hipStream_t stream, size_t bytes); // grow-only scratch per (device, stream), apart from ogc_workspace
+// dst[e] (+)= part[0 * n + e] + part[1 * n + e] + ... in slot order, one thread per element
+hipError_t ogc_det_reduce_f32(float *dst, const float *part, int slots, long long n, int accumulate, hipStream_t s);
+hipError_t ogc_det_reduce_f64(double *dst, const double *part, int slots, long long n, int accumulate, hipStream_t s);
+// per sample the positions t (ascending) with idx[b, t] == j: start (b, n + 1), pos (b, T), in the stream's deterministic scratch
+int ogc_det_lists(const char *name, int b, int n, long long T, const int *idx, const int **start_out, const int **pos_out,
+                  size_t extra, void **extra_ptr, hipStream_t s);
+// out (b, c, n) (+)= sum over t with idx[b, t] == j of grad_out[b, ch, t] (interp: grad_out[b, ch, t / 3] * weight[b, t]), ascending t
+int ogc_det_scatter_add(const char *name, int b, int c, int n, long long T, const int *idx, const float *grad_out,
+                        long long go_bstride, const float *weight, int interp, float *out, int accumulate, hipStream_t s);
+
 // ---- zero-fill as a KERNEL ------------------------------------------------------------------------------------------
 // Not hipMemsetAsync: captured into a HIP graph (graph_step.py, utils/subgraph.py) a memset node of this stack zeroes
 // correctly on the first replay and fills with a few stale low bits on the later ones (tools/memset_probe.py: a buffer set

@@ -18,8 +18,9 @@ namespace {
 constexpr int SL_THREADS = 256;
 constexpr int SL_KMAX = 32;
 
+// store: a plain store instead of the atomic (deterministic mode: global_out is then this workgroup's own slab)
 __device__ __forceinline__ void block_sum_doubles(double *vals, int nval, double *smem /* [nval][4] */,
-                                                  double *global_out) {
+                                                  double *global_out, bool store = false) {
     // wave reduce, then one LDS slot per wave, then thread 0..nval-1 adds the 4 waves and issues the global atomic
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int v = 0; v < nval; ++v) {
@@ -32,7 +33,8 @@ __device__ __forceinline__ void block_sum_doubles(double *vals, int nval, double
     if ((int)threadIdx.x < nval) {
         double s = 0.0;
         for (int w = 0; w < SL_THREADS / 64; ++w) s += smem[threadIdx.x * (SL_THREADS / 64) + w];
-        atomicAdd(global_out + threadIdx.x, s);
+        if (store) global_out[threadIdx.x] = s;
+        else atomicAdd(global_out + threadIdx.x, s);
     }
 }
 
@@ -40,7 +42,7 @@ __device__ __forceinline__ void block_sum_doubles(double *vals, int nval, double
 __global__ __launch_bounds__(SL_THREADS) void rigid_moments_kernel(int n, int k, const float *__restrict__ pc,
                                                                    const float *__restrict__ pc2,
                                                                    const float *__restrict__ mask,
-                                                                   double *__restrict__ mom) {
+                                                                   double *__restrict__ mom, double *__restrict__ part) {
     __shared__ double smem[16 * (SL_THREADS / 64)];
     const int slot = blockIdx.y, vb = blockIdx.z;
     const float *p = pc + (size_t)vb * n * 3, *q = pc2 + (size_t)vb * n * 3;
@@ -60,7 +62,9 @@ __global__ __launch_bounds__(SL_THREADS) void rigid_moments_kernel(int n, int k,
         a[10] += wpy * qx; a[11] += wpy * qy; a[12] += wpy * qz;
         a[13] += wpz * qx; a[14] += wpz * qy; a[15] += wpz * qz;
     }
-    block_sum_doubles(a, 16, smem, mom + ((size_t)vb * k + slot) * 16);
+    // part (deterministic mode): chunk blockIdx.x's sums go to slab blockIdx.x; ogc_det_reduce_f64 adds the slabs in order
+    if (part) block_sum_doubles(a, 16, smem, part + (((size_t)blockIdx.x * gridDim.z + vb) * k + slot) * 16, true);
+    else block_sum_doubles(a, 16, smem, mom + ((size_t)vb * k + slot) * 16);
 }
 
 // one thread per (vb, slot): centred cross-covariance (float, for ogc_kabsch_rotation) and the weighted means
@@ -244,9 +248,19 @@ extern "C" int ogc_rigid_moments(int vb, int n, int k, const float *pc, const fl
         ogc_set_error("ogc_rigid_moments: memset failed");
         return OGC_ERR_LAUNCH;
     }
-    if (n > 0)
-        hipLaunchKernelGGL(rigid_moments_kernel, dim3(sl_chunks(n, vb * k), k, vb), dim3(SL_THREADS), 0, s, n, k, pc, pc2,
-                           mask, mom);
+    if (n > 0) {
+        const int chunks = sl_chunks(n, vb * k);
+        double *part = nullptr;
+        if (ogc_deterministic()) {
+            part = static_cast<double *>(ogc_det_scratch(s, sizeof(double) * 16 * (size_t)vb * k * chunks));
+            if (!part) {
+                ogc_set_error("ogc_rigid_moments (deterministic): no scratch memory");
+                return OGC_ERR_LAUNCH;
+            }
+        }
+        hipLaunchKernelGGL(rigid_moments_kernel, dim3(chunks, k, vb), dim3(SL_THREADS), 0, s, n, k, pc, pc2, mask, mom, part);
+        if (part && ogc_det_reduce_f64(mom, part, chunks, 16ll * vb * k, 0, s) != hipSuccess) return OGC_ERR_LAUNCH;
+    }
     hipLaunchKernelGGL(rigid_finalize_kernel, dim3(ogc_divup(vb * k, 64)), dim3(64), 0, s, vb * k, mom, S, means);
     OGC_CHECK_LAUNCH("ogc_rigid_moments");
     return OGC_OK;

@@ -21,6 +21,16 @@ from .utils.zero_arena import zeroed_empty  # buffers an operator zeroes before 
 
 GATE_MISSES = _collections.Counter()
 
+
+def deterministic():
+    """The deterministic-gradient mode (OGC_DETERMINISTIC=1 / _lib.set_deterministic; include/ogc_ops.h: ogc_set_deterministic).
+    The library's converted entry points then sum in a fixed order; the host layers below leave the fused forms whose kernels are
+    not converted — GroupNorm statistics taken in a convolution's epilogue (fp64 atomics), the moment-matrix backward, the
+    grouped first layer — for the plain sequence conv -> GroupNorm (+ ReLU, + max), whose kernels write every partial once
+    (csrc/group_norm.hip) or go through the ordered passes of csrc/det.hip.  A test mode."""
+    from . import _lib
+    return _lib.DETERMINISTIC
+
 # ---- 16-bit activations ------------------------------------------------------------------------------------------------------
 # Under `matmul_precision: bf16` the raw convolution outputs inside a set-abstraction MLP, and the gradients with respect to
 # them, are STORED as bf16 (csrc/act_io.h; the `_h` entry points of include/ogc_ops.h): those tensors are the only ones of the
@@ -360,6 +370,8 @@ def pointwise_conv(x, conv, gn=None):
             and all(v == 0 for v in conv.padding) and getattr(_api._native, "conv1x1_wgrad_wrapper", None) is not None):
         if gn is None:
             return _PointwiseConv.apply(x, conv.weight)
+        if deterministic():   # (no statistics from the epilogue: the norm takes its own, slotted pass)
+            return _PointwiseConv.apply(x, conv.weight), None
         if gn.affine:
             return _PointwiseConv.apply(x, conv.weight, gn.num_groups)
         return _PointwiseConv.apply(x, conv.weight), None
@@ -901,6 +913,8 @@ class _NormActConv(Function):
 @_gate
 def norm_act_conv_available(y_prev, gn, conv):
     """Can conv(act(gn(y_prev))) run with the norm folded into the convolution's operand load?"""
+    if deterministic():   # (its epilogue statistics and moment matrices are atomic sums: see deterministic())
+        return False
     if not (y_prev.is_cuda and _is_act(y_prev) and gn.affine and conv.bias is None and conv.groups == 1
             and all(k == 1 for k in conv.kernel_size) and all(v == 1 for v in conv.stride)
             and all(v == 0 for v in conv.padding)
@@ -1373,6 +1387,8 @@ class _GroupedFirstLayer(Function):
 @_gate
 def grouped_first_layer_available(xyz, new_xyz, features, idx, conv, gn):
     nat = _api._native
+    if deterministic():   # (statistics by atomics in ogc_group_linear_fwd's epilogue)
+        return False
     return (features is not None and features.is_cuda and features.dtype == torch.float32 and idx is not None
             and getattr(nat, "group_linear_fwd_wrapper", None) is not None and conv.bias is None
             and conv.weight.shape[1] == 3 + features.shape[1] and (idx.shape[1] * idx.shape[2]) % 16 == 0
