@@ -316,6 +316,8 @@ int ogc_sum_ranges(int parts, const float *const *src, const long long *first, c
  * ogc_rigid_translation: t = qbar - R pbar; fits flagged invalid get R = I, t = 0 (:40-42, :58-59).  R is updated in place.
  * ogc_rigid_blend: backward == 0: out (vb,n) = || sum_k mask[n,k] (R_k p_n + t_k) - q_n ||_p;  backward != 0:
  *   out (vb,n,k) = d/d mask of that, times grad_out (vb,n) (the fit itself is detached, :91).  p = 1 or 2; k <= 32.
+ *   p == 0 (forward only): out (vb,n,3) = sum_k mask[n,k] (R_k p_n + t_k) - q_n, the vector itself — with pc2 = pc the
+ *   mask-blended rigid flow of object-aware ICP (oa_icp.py:31-38, :75-83).
  * pc, pc2 (vb,n,3), mask (vb,n,k) point-major, R (vb*k,3,3), t (vb*k,3). */
 int ogc_rigid_moments(int vb, int n, int k, const float *pc, const float *pc2, const float *mask, double *mom, float *S,
                       float *means, ogc_stream_t stream);

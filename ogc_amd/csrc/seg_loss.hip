@@ -127,6 +127,10 @@ __global__ __launch_bounds__(SL_THREADS) void rigid_blend_kernel(int n, int k, c
         bx = fmaf(w, tx, bx); by = fmaf(w, ty, by); bz = fmaf(w, tz, bz);
     }
     const float dx = bx - pc2[pi * 3], dy = by - pc2[pi * 3 + 1], dz = bz - pc2[pi * 3 + 2];
+    if (P == 0) { // the difference itself (object-aware ICP: the mask-blended rigid flow, oa_icp.py:31-38 with pc2 = pc)
+        out[pi * 3] = dx; out[pi * 3 + 1] = dy; out[pi * 3 + 2] = dz;
+        return;
+    }
     if (!BWD) {
         out[pi] = P == 1 ? (fabsf(dx) + fabsf(dy)) + fabsf(dz) : sqrtf((dx * dx + dy * dy) + dz * dz);
         return;
@@ -281,7 +285,7 @@ extern "C" int ogc_rigid_blend(int vb, int n, int k, int p, int backward, const 
                                const float *mask, const float *R, const float *t, const float *grad_out, float *out,
                                ogc_stream_t stream) {
     OGC_REQUIRE(vb >= 0 && n >= 0 && k >= 1, "ogc_rigid_blend: bad shape");
-    OGC_REQUIRE(p == 1 || p == 2, "ogc_rigid_blend: norm must be 1 or 2");
+    OGC_REQUIRE(p == 1 || p == 2 || (p == 0 && !backward), "ogc_rigid_blend: norm must be 1 or 2 (0: the difference vector, forward only)");
     if (k > SL_KMAX) {
         ogc_set_error("ogc_rigid_blend: more than %d slots", SL_KMAX);
         return OGC_ERR_UNSUPPORTED;
@@ -292,7 +296,8 @@ extern "C" int ogc_rigid_blend(int vb, int n, int k, int p, int backward, const 
     hipStream_t s = (hipStream_t)stream;
 #define OGC_BLEND(PV, BV) \
     hipLaunchKernelGGL((rigid_blend_kernel<PV, BV>), grid, block, 0, s, n, k, pc, pc2, mask, R, t, grad_out, out)
-    if (p == 1 && !backward) OGC_BLEND(1, false);
+    if (p == 0) OGC_BLEND(0, false);
+    else if (p == 1 && !backward) OGC_BLEND(1, false);
     else if (p == 1) OGC_BLEND(1, true);
     else if (!backward) OGC_BLEND(2, false);
     else OGC_BLEND(2, true);

@@ -103,6 +103,74 @@ def test_soft_nn_target(shape, scale):
     assert err_kernel <= max(4.0 * err_torch, 1e-5 * scale), (err_kernel, err_torch)
 
 
+def test_soft_nn_target_at_the_refinement_shape():
+    """Object-aware ICP's own shape (oa_icp.py:175: B = 4, N = 8192, K = 10 — the KITTI-SF refinement round): the fused step
+    against the reference's op sequence in fp64, evaluated in chunks of 1024 query rows (a (4, 8192, 8192) fp64 tensor is 2 GiB;
+    the sequence holds several), and against the same sequence in fp32 torch as the yardstick.  Scene-scale coordinates
+    (60 x 4 x 80 m), frame 2 a rigidly moved, permuted copy of frame 1 with centimetre noise: the regime in which cdist's
+    |a|^2 + |b|^2 - 2 a.b is ill-conditioned and the kernel must be no worse than torch's own fp32."""
+    from ogc_amd import pointnet2_cuda as nat
+    B, N, K, tau = 4, 8192, 10, 0.01
+    g = torch.Generator().manual_seed(4810)
+    p2 = ((torch.rand(B, N, 3, generator=g) - 0.5) * torch.tensor([60.0, 4.0, 80.0])).cuda()
+    src = torch.stack([torch.randperm(N, generator=g) for _ in range(B)]).cuda()
+    p1 = torch.gather(p2, 1, src.unsqueeze(-1).expand(-1, -1, 3)) + 0.02 * torch.randn(B, N, 3, generator=g).cuda()
+    lab2 = torch.randint(0, K, (B, N), generator=g).cuda()
+    lab1 = torch.gather(lab2, 1, src)
+    eye = torch.eye(K).cuda()
+    m1 = (4 * eye[lab1] + torch.randn(B, N, K, generator=g).cuda()).softmax(-1).contiguous()
+    m2 = (4 * eye[lab2] + torch.randn(B, N, K, generator=g).cuda()).softmax(-1).contiguous()
+    out = torch.empty(B, N, 3, device="cuda")
+    nat.soft_nn_target_wrapper(B, N, N, K, tau, p1.contiguous(), p2.contiguous(), m1, m2, out)
+
+    def ref(dtype, rows):
+        a, b_, ma, mb = p1[:, rows].to(dtype), p2.to(dtype), m1[:, rows].to(dtype), m2.to(dtype)
+        corr = (-torch.cdist(a, b_) / tau).softmax(-1)
+        corr = corr * torch.einsum('bmk,bnk->bmn', ma, mb)
+        corr = corr / corr.sum(-1, keepdim=True).clamp(1e-10)
+        return torch.einsum('bmn,bnj->bmj', corr, b_)
+
+    err_kernel = err_torch = 0.0
+    for r0 in range(0, N, 1024):
+        rows = slice(r0, r0 + 1024)
+        exact = ref(torch.float64, rows)
+        err_kernel = max(err_kernel, (out[:, rows].double() - exact).abs().max().item())
+        err_torch = max(err_torch, (ref(torch.float32, rows).double() - exact).abs().max().item())
+    print("soft-NN at 4 x 8192 x 8192 x 10: max |kernel - fp64| %.3e, max |torch fp32 - fp64| %.3e" % (err_kernel, err_torch))
+    assert err_kernel <= max(4.0 * err_torch, 1e-5 * 80.0), (err_kernel, err_torch)
+
+
+@pytest.mark.parametrize("k", [3, 10, 13, 20])
+def test_soft_nn_kernels_agree(k, monkeypatch):
+    """The matrix-core form and the lane-per-query form of ogc_soft_nn_target (csrc/soft_nn.hip) on the same inputs — ragged
+    sizes, every operand width (K <= 8 / 12 / 16 / 32) — through a child-free switch: both are reachable by size (n2 < 256
+    takes the lane-per-query kernel), so compare each against fp64 on a size where both run via the OGC_SOFT_NN_MFMA switch."""
+    import subprocess, sys, os
+    code = (
+        "import torch, ogc_amd\n"
+        "from ogc_amd import pointnet2_cuda as nat\n"
+        "g = torch.Generator().manual_seed(%d)\n"
+        "B, N1, N2, K = 2, 777, 1301, %d\n"
+        "p2 = ((torch.rand(B, N2, 3, generator=g) - 0.5) * 20).cuda()\n"
+        "p1 = (p2[:, torch.randint(0, N2, (N1,), generator=g)] + 0.02 * torch.randn(B, N1, 3, generator=g).cuda()).contiguous()\n"
+        "m1 = torch.randn(B, N1, K, generator=g).cuda().mul(3).softmax(-1).contiguous()\n"
+        "m2 = torch.randn(B, N2, K, generator=g).cuda().mul(3).softmax(-1).contiguous()\n"
+        "out = torch.empty(B, N1, 3, device='cuda')\n"
+        "nat.soft_nn_target_wrapper(B, N1, N2, K, 0.01, p1, p2, m1, m2, out)\n"
+        "torch.save(out.cpu(), '%s')\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for flag in ("1", "0"):
+        path = "/tmp/ogc_soft_nn_%s_%d.pt" % (flag, k)
+        env = dict(os.environ, OGC_SOFT_NN_MFMA=flag, PYTHONPATH=root)
+        r = subprocess.run([sys.executable, "-c", code % (k, k, path)], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-1500:]
+        outs.append(torch.load(path))
+    err = (outs[0] - outs[1]).abs().max().item()
+    print("K = %d: max |matrix-core - lane-per-query| = %.3e" % (k, err))
+    assert err <= 2e-4, err   # (both within fp32 of the ill-conditioned distance formula; scale 20)
+
+
 class _NoFused:
     """The native module without the loss-level fused entry points: forces the reference-shaped op sequence."""
     HIDE = ("rigid_blend_wrapper", "matched_distance_wrapper")

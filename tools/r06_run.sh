@@ -1,8 +1,6 @@
 export PYTHONPATH=$PWD TMPDIR=/tmp
 mkdir -p gpurun_out/r06
 O=$PWD/gpurun_out/r06
-timeout 1500 python -m pytest tests/test_deterministic_gpu.py -q -m gpu > $O/t_det.log 2>&1; tail -15 $O/t_det.log
-for i in 1 2 3; do timeout 900 python -m pytest tests/test_driver_golden.py -q -m gpu -k "flow_trainer_replays" 2>&1 | tail -1; done
-# cost of the switch at C4
-timeout 600 python bench.py --timed-only --steps 10 --warmup 5 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('C4 atomic kernels  ms/step', d['ms_per_step'])"
-OGC_DETERMINISTIC=1 timeout 900 python bench.py --timed-only --steps 10 --warmup 5 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('C4 deterministic    ms/step', d['ms_per_step'])"
+timeout 900 python -m pytest tests/test_golden_gpu.py tests/test_flow_store.py tests/test_fused_loss_gpu.py tests/test_truth_f64_gpu.py -q -m gpu > $O/t_g.log 2>&1; tail -5 $O/t_g.log
+timeout 300 python tools/bench_icp.py 4 20 > $O/icp.txt 2>&1; tail -3 $O/icp.txt
+bash tools/kprof.sh $O/icp_kernels.txt $PWD/tools/bench_icp.py 4 20 > $O/icp_kprof.log 2>&1; grep -v "Cijk\|at::native" $O/icp_kernels.txt | head -12
