@@ -440,6 +440,82 @@ def config2_reading(dev, steps=12, warm=4):
         api._native.set_matmul_precision(prev)
 
 
+def oa_icp_reading(dev, iters=20, reps=5):
+    """Object-aware ICP at its own shape (reference oa_icp.py:41-84, :175: the KITTI-SF refinement round — B = 4 scenes of 8192
+    points, K = 10 slots, 20 iterations): ms per call of ogc_amd.oa_icp.object_aware_icp, and the soft-NN step's pair rate
+    (B N^2 (query, candidate) pairs per iteration) against the fp32 MFMA peak its two dot products run on (5 + K padded to 8 + 12
+    reduction terms -> 2 * 20 flop per pair)."""
+    from ogc_amd.oa_icp import object_aware_icp
+    from ogc_amd.utils.synthetic import make_scene_batch
+    B, N, K = 4, 8192, 10
+    pcs, segms, flows, _ = make_scene_batch(B, N, K, seed=5, aug=False, device=dev)
+    pc1, pc2, flow = pcs[:, 0].contiguous(), pcs[:, 1].contiguous(), flows[:, 0].contiguous()
+    eye = torch.eye(K, device=dev)
+    g = torch.Generator(device=dev).manual_seed(7)
+    mask1 = (4 * eye[segms[:, 0].long().to(dev) % K] + torch.randn(B, N, K, device=dev, generator=g)).softmax(-1)
+    mask2 = (4 * eye[segms[:, 1].long().to(dev) % K] + torch.randn(B, N, K, device=dev, generator=g)).softmax(-1)
+    noisy = flow + 0.05 * torch.randn(B, N, 3, device=dev, generator=g)
+    with torch.no_grad():
+        object_aware_icp(pc1, pc2, noisy, mask1, mask2, icp_iter=iters, temperature=0.01)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            out = object_aware_icp(pc1, pc2, noisy, mask1, mask2, icp_iter=iters, temperature=0.01)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / reps * 1e3
+        # the soft-NN step alone (ogc_soft_nn_target, the pack of the candidates included)
+        from ogc_amd import pointnet2_cuda as nat
+        target = torch.empty(B, N, 3, device=dev)
+        q = (pc1 + noisy).contiguous()
+        m1c, m2c = mask1.contiguous(), mask2.contiguous()
+        step_ms = _time(lambda: nat.soft_nn_target_wrapper(B, N, N, K, 0.01, q, pc2, m1c, m2c, target))
+    pairs = B * N * N
+    tflops = pairs * 2 * 20 / (step_ms * 1e-3) / 1e12
+    return {"workload": "object_aware_icp, B = %d, N = %d, K = %d, %d iterations (oa_icp.py:175 round 1)" % (B, N, K, iters),
+            "ms_per_call": round(ms, 3), "ms_per_iteration": round(ms / iters, 4),
+            "soft_nn_step": {"kernel": "ogc_soft_nn_target (soft_nn_pack_kernel + soft_nn_mfma_kernel<3>)", "avg_ms": round(step_ms, 4),
+                             "gpairs_per_s": round(pairs / (step_ms * 1e-3) / 1e9, 1),
+                             "bound": "mfma", "achieved": round(tflops, 2), "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                             "frac": round(tflops / FP32_MFMA_PEAK_TF, 4),
+                             "note": "2 x 20 flop per pair on v_mfma_f32_16x16x4_f32 (8 of them carry zeros: 5 distance + 10 mask "
+                                     "terms padded to 8 + 12); the vector unit does max / sqrt / scale / 2 exp2 / 5 fma per pair"},
+            "epe_vs_truth": round(float((out - flow).norm(dim=-1).mean()), 4), "epe_of_input": round(float((noisy - flow).norm(dim=-1).mean()), 4)}
+
+
+def config3_flow_train_reading(dev, steps=8, warm=3):
+    """BASELINE config 3 as train_flow.py runs it (reference train_flow.py:33-86): FlowStep3D (flownet_kitti) on 8192-point pairs,
+    batch 4, 4 refinement iterations, UnsupervisedFlowStep3DLoss (Chamfer + smoothness on every iteration), backward, NaN rule,
+    Adam — ogc_amd.train_step.flow_train_step."""
+    from ogc_amd.losses.flow_loss_unsup import ChamferLoss, SmoothLoss, UnsupervisedFlowStep3DLoss
+    from ogc_amd.models.flownet_kitti import FlowStep3D
+    from ogc_amd.train_step import flow_train_step, make_optimizer
+    from ogc_amd.utils.synthetic import make_scene_batch
+    B, N, iters = 4, 8192, 4
+    torch.manual_seed(10)
+    net = FlowStep3D(npoint=N, loc_flow_nn=16, loc_flow_rad=1.5).to(dev)
+    crit = UnsupervisedFlowStep3DLoss(ChamferLoss(2), SmoothLoss(3., 1., {'k': 4, 'radius': 0.5, 'loss_norm': 1},
+                                                                  {'k': 8, 'radius': 1.0, 'loss_norm': 1}),
+                                      weights=[0.75, 0.25], iters_w=[0.8, 0.2, 0.4, 0.6])
+    opt = make_optimizer(net.parameters(), lr=1e-3)
+    pcs, _, flows, _ = make_scene_batch(B, N, 10, seed=1, aug=False, device=dev)
+    batch = (pcs, None, flows, None)
+    torch.cuda.reset_peak_memory_stats()
+    pend = None
+    for i in range(warm + steps):
+        if i == warm:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        pend = flow_train_step(net, crit, opt, batch, iters, sync=False)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    losses, stepped = pend.result()
+    return {"workload": "C3 KITTI-SF train_flow unsup: flownet_kitti (FlowStep3D), %d pairs x %d pts, iters = %d, fwd + loss + bwd + Adam"
+                        % (B, N, iters),
+            "ms_per_step": round(ms, 3), "point_cloud_pairs_per_s": round(B / ms * 1e3, 1), "steps": steps, "warmup": warm,
+            "dtype": "f32", "optimizer_stepped": bool(stepped), "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
+            "loss_sum": round(float(losses["sum"]), 5)}
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -630,6 +706,16 @@ def main():
                 extras["config2_ogcdr_bf16"] = config2_reading(dev)
             except Exception as err:  # an extra reading must not cost the headline its line
                 extras["config2_ogcdr_bf16"] = {"error": str(err)[:200]}
+        if "c3" not in skip:
+            try:
+                extras["config3_flow_train"] = config3_flow_train_reading(dev)
+            except Exception as err:
+                extras["config3_flow_train"] = {"error": str(err)[:200]}
+        if "icp" not in skip:
+            try:
+                extras["oa_icp"] = oa_icp_reading(dev)
+            except Exception as err:
+                extras["oa_icp"] = {"error": str(err)[:200]}
     if rank == 0:
         offline = load_offline()
         durs = timer.durations_ms()
