@@ -498,14 +498,18 @@ def config3_flow_train_reading(dev, steps=8, warm=3):
                                       weights=[0.75, 0.25], iters_w=[0.8, 0.2, 0.4, 0.6])
     opt = make_optimizer(net.parameters(), lr=1e-3)
     pcs, _, flows, _ = make_scene_batch(B, N, 10, seed=1, aug=False, device=dev)
-    batch = (pcs, None, flows, None)
+    # two distinct resident batches, alternating: the batch a step prefetches the sampling chains of really is the next one
+    batches = [(pcs, None, flows, None)]
+    pcs_b, _, flows_b, _ = make_scene_batch(B, N, 10, seed=2, aug=False, device=dev)
+    batches.append((pcs_b, None, flows_b, None))
     torch.cuda.reset_peak_memory_stats()
-    pend = None
+    pend, ahead = None, None
     for i in range(warm + steps):
         if i == warm:
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-        pend = flow_train_step(net, crit, opt, batch, iters, sync=False)
+        pend = flow_train_step(net, crit, opt, batches[i % 2], iters, sync=False, prefetched=ahead, next_batch=batches[(i + 1) % 2])
+        ahead = pend.prefetched
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
     losses, stepped = pend.result()

@@ -489,7 +489,7 @@ class _BatchNormAct(Function):
         lean = not training and not any(ctx.needs_input_grad[:3])
         mean = None if lean else torch.empty(C, dtype=torch.float32, device=x.device)
         rstd = None if lean else torch.empty_like(mean)
-        ws = None if (stats is not None or not training) else torch.empty(2 * C, dtype=torch.float64, device=x.device)
+        ws = None if (stats is not None or not training) else zeroed_empty(2 * C, torch.float64, x.device)
         nat.batch_norm_fwd_wrapper(B, C, hw, eps, relu, training, momentum, x, weight.contiguous(),
                                    bias.contiguous(), running_mean, running_var, y, mean, rstd, ws, stats,
                                    0 if stats is None else stats.numel() // (2 * C))
@@ -507,7 +507,7 @@ class _BatchNormAct(Function):
         grad_x = torch.empty_like(x)
         gw = torch.empty_like(weight)
         gb = torch.empty_like(bias)
-        ws = torch.empty(3 * C, dtype=torch.float64, device=x.device)
+        ws = zeroed_empty(3 * C, torch.float64, x.device)   # (the library zeroes its first 2 C doubles: skipped inside a step arena)
         nat.batch_norm_bwd_wrapper(B, C, hw, relu, training, x, weight.contiguous(),
                                    bias.contiguous(), mean, rstd, grad_y.contiguous(), grad_x, gw, gb, ws)
         return grad_x, gw, gb, None, None, None, None, None, None, None
@@ -527,7 +527,7 @@ class _BatchNormActMaxPool(Function):
         lean = not training and not any(ctx.needs_input_grad[:3])
         mean = None if lean else torch.empty(C, dtype=torch.float32, device=x.device)
         rstd = None if lean else torch.empty_like(mean)
-        ws = None if (stats is not None or not training) else torch.empty(2 * C, dtype=torch.float64, device=x.device)
+        ws = None if (stats is not None or not training) else zeroed_empty(2 * C, torch.float64, x.device)
         nat.batch_norm_maxpool_fwd_wrapper(B, C, P, S, eps, relu, training, momentum, x, weight.contiguous(),
                                            bias.contiguous(), running_mean, running_var, out, arg, mean, rstd,
                                            ws, stats, 0 if stats is None else stats.numel() // (2 * C))
@@ -545,7 +545,7 @@ class _BatchNormActMaxPool(Function):
         grad_x = torch.empty_like(x)
         gw = torch.empty_like(weight)
         gb = torch.empty_like(weight)
-        ws = torch.empty(3 * C, dtype=torch.float64, device=x.device)
+        ws = zeroed_empty(3 * C, torch.float64, x.device)   # (the library zeroes its first 2 C doubles: skipped inside a step arena)
         nat.batch_norm_maxpool_bwd_wrapper(B, C, P, S, relu, training, x, weight.contiguous(), mean, rstd, out,
                                            arg, grad_out.contiguous(), grad_x, gw, gb, ws)
         return grad_x, gw, gb, None, None, None, None, None, None, None

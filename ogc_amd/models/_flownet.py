@@ -303,13 +303,40 @@ class FlowStep3DBase(nn.Module):
     def get_x_slim(self, feats1_loc_new, corr_feats):
         return torch.cat([feats1_loc_new, corr_feats], dim=1)
 
-    def forward(self, pc1, pc2, feature1, feature2, iters=1):
-        # pc*, feature* (B, N, 3) -> list of `iters` flow predictions, each (B, N, 3)
-        with geometry_memo():  # FPS / kNN on unchanged coordinates are computed once per forward
-            return self._forward(pc1, pc2, feature1, feature2, iters)
+    def plan_geometry_async(self, pc1, pc2, after=None):
+        """The sampling chains of the local encoder for a FUTURE pair (pc*, (B, N, 3)), queued on a side stream: furthest point
+        sampling is the one part of a forward pass that depends on coordinates only AND is sequential — 4096 + 2048 rounds for
+        an 8192-point pair, 3.4 ms of one workgroup per cloud, at the head of the step's critical path — so a trainer that
+        already holds the next batch lets it run underneath the current step's dense kernels (train_step.flow_train_step,
+        `next_batch=`), as the segmentation step does (models/_segnet.py).  Returns the handle `forward(..., geometry=)` takes.
+        after: an event marking the pair ready (the side stream then waits for that only)."""
+        from ..utils.streams import launch_on_side, side_stream
+        if not (pc1.is_cuda and pc1.shape == pc2.shape):
+            return None
+        stream = side_stream(pc1.device, "flownet-geometry")
+        pc1.record_stream(stream)
+        pc2.record_stream(stream)
 
-    def _forward(self, pc1, pc2, feature1, feature2, iters):
+        def chains():
+            level_ties = []
+            a, b_ = pc1.permute(0, 2, 1).contiguous(), pc2.permute(0, 2, 1).contiguous()
+            idx1, idx2, ties = joint_fps(a, b_, [self.encoder_loc.sa1.npoint, self.encoder_loc.sa2.npoint], return_ties=True,
+                                         all_ties=level_ties)
+            return {"fps1": idx1, "fps2": idx2, "ties": ties, "level_ties": level_ties, "shape": tuple(pc1.shape)}
+
+        return launch_on_side(stream, chains, after=after)
+
+    def forward(self, pc1, pc2, feature1, feature2, iters=1, geometry=None):
+        # pc*, feature* (B, N, 3) -> list of `iters` flow predictions, each (B, N, 3)
+        # geometry: plan_geometry_async(pc1, pc2) made earlier (the same clouds: sampling depends on nothing else)
+        with geometry_memo():  # FPS / kNN on unchanged coordinates are computed once per forward
+            return self._forward(pc1, pc2, feature1, feature2, iters, geometry)
+
+    def _forward(self, pc1, pc2, feature1, feature2, iters, geometry=None):
         flow_predictions = []
+        planned = geometry.get() if geometry is not None else None
+        if planned is not None and planned["shape"] != tuple(pc1.shape):
+            planned = None
         pc1 = pc1.permute(0, 2, 1).contiguous()
         pc2 = pc2.permute(0, 2, 1).contiguous()
         feature1 = feature1.permute(0, 2, 1).contiguous()
@@ -317,7 +344,9 @@ class FlowStep3DBase(nn.Module):
 
         fps_idx1 = fps_idx2 = loc_ties = None
         level_ties = []
-        if pc1.is_cuda and pc1.shape == pc2.shape:  # both sampling chains in one launch per level
+        if planned is not None:
+            fps_idx1, fps_idx2, loc_ties, level_ties = planned["fps1"], planned["fps2"], planned["ties"], planned["level_ties"]
+        elif pc1.is_cuda and pc1.shape == pc2.shape:  # both sampling chains in one launch per level
             fps_idx1, fps_idx2, loc_ties = joint_fps(pc1, pc2, [self.encoder_loc.sa1.npoint, self.encoder_loc.sa2.npoint],
                                                      return_ties=True, all_ties=level_ties)
         if fps_idx1 is not None and self._two_clouds_per_call():

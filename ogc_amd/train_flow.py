@@ -63,14 +63,15 @@ class Trainer(object):
         self.cur_epoch = 0
         self._skipped_in_a_row = 0
 
-    def _train_it(self, it, batch, sync=True):
+    def _train_it(self, it, batch, sync=True, prefetched=None, next_batch=None):
         """train_flow.py:62-88: schedules stepped with the iteration number, forward over `model_iters` GRU iterations, loss
         (+ the EPE of every iteration against the first frame's flow, monitored), backward, NaN rule, Adam."""
         if self.lr_scheduler is not None:
             self.lr_scheduler.step(it)
         if self.bnm_scheduler is not None:
             self.bnm_scheduler.step(it)
-        return flow_train_step(self.model, self.criterion, self.optimizer, batch, self.model_iters, sync=sync)
+        return flow_train_step(self.model, self.criterion, self.optimizer, batch, self.model_iters, sync=sync, prefetched=prefetched,
+                               next_batch=next_batch)
 
     def eval_epoch(self, val_loader):
         """(validation loss, mean loss_dict incl. the EPE terms).  The loss is the reference's number: the sum over the n
@@ -119,13 +120,25 @@ class Trainer(object):
                 if self.on_iteration is not None:
                     self.on_iteration(at, loss_dict, stepped)
 
-            for cpu_batch in train_loader:
-                batch = tuple(x.to(self.device, non_blocking=True) for x in cpu_batch)
+            # one batch ahead (as the segmentation trainer): the sampling chains of batch i + 1 run on a side stream underneath
+            # step i's backward pass (train_step.flow_train_step, next_batch=)
+            loader = iter(train_loader)
+
+            def fetch():
+                cpu_batch = next(loader, None)
+                return None if cpu_batch is None else tuple(x.to(self.device, non_blocking=True) for x in cpu_batch)
+
+            batch, ahead = fetch(), None
+            while batch is not None:
+                upcoming = fetch()
+                on_gpu = batch[0].is_cuda
                 # the scalars of step i are read while step i + 1 is already queued: the host never waits inside a step
-                pending = self._train_it(it, batch, sync=False)
+                pending = self._train_it(it, batch, sync=False, **({"prefetched": ahead, "next_batch": upcoming} if on_gpu else {}))
+                ahead = getattr(pending, "prefetched", None)
                 account(in_flight, it - 1)
                 in_flight = pending
                 it += 1
+                batch = upcoming
                 if self.max_iters and it >= self.max_iters:
                     break
             account(in_flight, it - 1)
