@@ -194,6 +194,40 @@ def set_deterministic(on):
 
 CALL_COUNTS = None   # a collections.Counter() here counts the entry points called (tools/det_probe.py)
 
+# Tracing: OGC_ROCTX=1 brackets every entry point with a roctx range named after the REFERENCE kernel it stands
+# for (K1 .. K10 of SURVEY §8: pointnet2/src/*_gpu.cu) or, for the fused extensions, after the entry point itself — what
+# `rocprofv3 --marker-trace` shows next to the kernel rows.  Off by default: two library calls per launch.
+ROCTX_NAMES = {
+    "ogc_furthest_point_sampling": "K1 furthest_point_sampling", "ogc_furthest_point_sampling_chain": "K1 furthest_point_sampling (chain)",
+    "ogc_gather_points": "K2 gather_points", "ogc_gather_points_grad": "K3 gather_points_grad",
+    "ogc_knn": "K4 knn", "ogc_knn_clamped": "K4 knn (+ sqrt + radius clamp)", "ogc_knn_clamped_cells": "K4 knn (shared cell grid)",
+    "ogc_three_nn": "K5 three_nn", "ogc_three_interpolate": "K6 three_interpolate",
+    "ogc_three_interpolate_grad": "K7 three_interpolate_grad", "ogc_three_interpolate_grad_rev": "K7 three_interpolate_grad (gather form)",
+    "ogc_three_interpolate_grad_rev_bs": "K7 three_interpolate_grad (gather form)",
+    "ogc_group_points": "K8 group_points", "ogc_group_points_grad": "K9 group_points_grad",
+    "ogc_group_points_grad_rev": "K9 group_points_grad (gather form)",
+    "ogc_ball_query": "K10 ball_query", "ogc_ball_query_cells": "K10 ball_query (shared cell grid)",
+}
+_roctx = None
+
+
+def _roctx_lib():
+    global _roctx
+    if _roctx is None:
+        _roctx = False
+        if os.environ.get("OGC_ROCTX", "0") == "1":
+            for name in ("librocprofiler-sdk-roctx.so", "libroctx64.so"):
+                try:
+                    lib = ctypes.CDLL(os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib", name))
+                    lib.roctxRangePushA.argtypes = [ctypes.c_char_p]
+                    lib.roctxRangePushA.restype = ctypes.c_int
+                    lib.roctxRangePop.restype = ctypes.c_int
+                    _roctx = lib
+                    break
+                except (OSError, AttributeError):
+                    continue
+    return _roctx
+
 
 def call(name, *args):
     """Invoke an entry point; non-zero status becomes a Python exception (the reference would
@@ -203,7 +237,15 @@ def call(name, *args):
     fn = _fns.get(name)
     if fn is None:
         fn = _fns[name] = getattr(load(), name)
-    rc = fn(*args)
+    tx = _roctx_lib()
+    if tx:
+        tx.roctxRangePushA(ROCTX_NAMES.get(name, name).encode())
+        try:
+            rc = fn(*args)
+        finally:
+            tx.roctxRangePop()
+    else:
+        rc = fn(*args)
     if rc != 0:
         msg = load().ogc_last_error().decode("utf-8", "replace")
         raise OgcOpsError("%s failed (status %d): %s" % (name, rc, msg))

@@ -450,7 +450,11 @@ def main(argv=None):
                                                sampler=sampler, drop_last=True)
     val_loader = torch.utils.data.DataLoader(val_set, batch_size=cfg["batch_size"], shuffle=False)
 
-    use_graph = args.hip_graph and device.type == "cuda" and not distributed
+    # One replayed HIP graph per step also under data parallelism (round 6): the flat gradient all-reduce of FlatDataParallel is
+    # captured with the step (RCCL takes part in a capture: tools/graph_rccl.py, tests/test_graph_step_gpu.py), so every rank's
+    # launch thread costs ~1 ms per step — what makes eight ranks on one host launchable.  Not with torch's
+    # DistributedDataParallel (--ddp): its per-parameter hooks and bucket streams are not part of this capture.
+    use_graph = args.hip_graph and device.type == "cuda" and not (distributed and getattr(args, "ddp", False))
     optimizer = make_optimizer(net.parameters(), lr=cfg["lr"], weight_decay=cfg["weight_decay"], capturable=use_graph)
     # Waymo: only backward flow exists, the trainer keeps every other view and uses the one-frame loss
     # (train_seg_waymo.py:59, :244-334)

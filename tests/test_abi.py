@@ -115,3 +115,12 @@ def test_install_drop_in():
                 sys.modules.pop(k, None)
             else:
                 sys.modules[k] = v
+
+
+def test_roctx_names_cover_the_ten_reference_kernels():
+    """with OGC_ROCTX=1 every C-ABI call is bracketed by a roctx range; the ten reference kernels K1..K10
+     each have a named range, and every name maps to a declared entry point."""
+    from ogc_amd import _lib
+    ks = {v.split()[0] for v in _lib.ROCTX_NAMES.values()}
+    assert ks == {"K%d" % i for i in range(1, 11)}
+    assert set(_lib.ROCTX_NAMES) <= set(_lib.SIGNATURES)

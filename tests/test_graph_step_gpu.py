@@ -124,3 +124,19 @@ def test_accumulators_are_zeroed_on_every_replay():
         torch.cuda.synchronize()
         assert bool((dw[:, 1::2] == 0).all()), (replay, float(dw[:, 1::2].abs().max()))
         assert float((dw - ref).norm() / ref.norm()) < 1e-5
+
+
+@pytest.mark.timeout(900)
+def test_graphed_step_with_the_rccl_all_reduce_inside():
+    """One process, backend nccl (= RCCL), FlatDataParallel with the collective forced on: the whole step INCLUDING the flat
+    gradient all-reduce is captured into one HIP graph (tools/graph_rccl.py) and replayed; six steps give the eager step's
+    losses.  (More than one rank needs more than one GPU: the data-parallel graph is exercised at world size 1 here, the
+    arithmetic of the collective at world size 2 over gloo in tests/test_ddp_cpu.py.)"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=root)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port",
+           "29537", os.path.join(root, "tools", "graph_rccl.py"), "1024"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=800)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+    assert "GRAPH_RCCL_OK" in out.stdout, out.stdout[-1500:]
