@@ -47,8 +47,8 @@ enum {
  * points): ogc_gather_xyz_pair, ogc_flow_advance, ogc_linear_cn, ogc_gru_reset, ogc_gru_blend,
  * ogc_soft_corr_flow, ogc_three_nn_weights; ogc_furthest_point_sampling_chain accepts temp == NULL.  0.2.2: the `_h` entry points
  * (activations of the shared MLPs stored as bf16; see "16-bit activations" at the end of this header).  0.2.4: ogc_set_deterministic /
- * ogc_get_deterministic. */
-#define OGC_VERSION 204
+ * ogc_get_deterministic.  0.2.5: ogc_group_linear_fwd_direct. */
+#define OGC_VERSION 205
 int ogc_version(void);
 /* 0: the squared distance of every search is the reference's SOURCE expression, ((dx*dx) + (dy*dy)) + (dz*dz), one rounding per
  * operation (what all parity tests pin).  1: this is libogc_ops_fmad.so, the same library with the search kernels (FPS, kNN,
@@ -255,6 +255,13 @@ int ogc_group_concat_grad(int b, int c, int n, int npoints, int nsample, const f
  * gradients are small per-point GEMMs: d features = W_f^T grad_p, d W_f = sum_b grad_p f^T. */
 int ogc_group_linear_fwd(int b, int m, int n, int npoints, int nsample, int groups, const float *P, const int *idx,
                          const float *rel, const float *wx, float *y, double *stats, ogc_stream_t stream);
+/* ogc_group_linear_fwd for 1 .. 4 feature channels (an encoder's first level: the features are the coordinates) without the
+ * point-wise product P: feats (b, cf, n), w (m, 3 + cf) the layer's weight rows; every output is ONE fused-multiply-add chain over
+ * the input channels [rel x, y, z, f_0 ..] ascending — the order of the reference's convolution over cat([grouped_xyz,
+ * grouped_features]) (pointnet2/pointnet2.py:286-297, utils/nn_util.py:45-85) and of this library's matrix kernels.  Other
+ * arguments, statistics layout and preconditions as ogc_group_linear_fwd. */
+int ogc_group_linear_fwd_direct(int b, int m, int cf, int n, int npoints, int nsample, int groups, const float *feats,
+                                const int *idx, const float *rel, const float *w, float *y, double *stats, ogc_stream_t stream);
 int ogc_group_linear_bwd(int b, int m, int n, int npoints, int nsample, const float *grad_y, const int *idx,
                          const float *rel, float *grad_p, float *dwx, ogc_stream_t stream);
 

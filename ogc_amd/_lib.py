@@ -23,6 +23,7 @@ _ll = ctypes.c_longlong
 # name -> argtypes (stream is always the trailing void*)
 SIGNATURES = {
     "ogc_set_deterministic": [_int],
+    "ogc_group_linear_fwd_direct": [_int, _int, _int, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "ogc_get_deterministic": [],
     "ogc_furthest_point_sampling": [_int, _int, _int, _vp, _vp, _vp, _vp],
     "ogc_furthest_point_sampling_chain": [_int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp],
@@ -147,7 +148,7 @@ for _n in ("ogc_group_linear_fwd", "ogc_group_points_grad_rev", "ogc_conv1x1_gem
 SIGNATURES["ogc_conv1x1_wgrad_xf_h"] = SIGNATURES["ogc_conv1x1_wgrad"]
 SIGNATURES["ogc_group_linear_fwd_pt_h"] = SIGNATURES["ogc_group_linear_fwd"]
 
-HEADER_VERSION = 204   # OGC_VERSION of include/ogc_ops.h the SIGNATURES table above was written against
+HEADER_VERSION = 205   # OGC_VERSION of include/ogc_ops.h the SIGNATURES table above was written against
 _lib = None
 _fns = {}  # entry point name -> bound ctypes function
 

@@ -522,6 +522,123 @@ __global__ __launch_bounds__(GG_THREADS) void group_linear_fwd_kernel(int m, int
 } // namespace
 
 namespace {
+// The same layer for FEW feature channels (the first level of an encoder: the features are the coordinates, CF = 3): the reduction
+// has 3 + CF terms, so the feature part is applied per POSITION as well — CF gathered feature values instead of one gathered value of
+// P per OUTPUT channel (m >= 32 of them), and no point-wise product in front — and every output is ONE fused-multiply-add chain over
+// the layer's input channels in their order, [rel x, y, z, f_0 ..] — the order in which the reference's convolution and this library's
+// matrix kernels (v_mfma_f32_16x16x4_f32, k ascending) walk cat([grouped_xyz, grouped_features]).  P[idx] + W_xyz rel rounds the two
+// halves separately; on the segnet_ogcdr fixture that one bit put an activation of the first level on the other side of its
+// ReLU / max-pool gate and moved 68 gradient tensors by 1e-3 (tests/golden_cases.py, gate_flip_tensors.json until round 6).
+template <typename OT, int CF>
+__global__ __launch_bounds__(GG_THREADS) void group_linear_direct_kernel(int m, int n, int T, int cpb, int cg, int groups,
+                                                                         const float *__restrict__ feats, // (b, CF, n)
+                                                                         const int *__restrict__ idx,
+                                                                         const float *__restrict__ rel,
+                                                                         const float *__restrict__ w,     // (m, 3 + CF)
+                                                                         OT *__restrict__ y, double *__restrict__ stats) {
+    __shared__ double red[2 * GG_THREADS / 64];
+    const int b = blockIdx.z, c0 = blockIdx.y * cpb;
+    const int t4 = (blockIdx.x * GG_THREADS + threadIdx.x) * 4;
+    float s = 0.f, ss = 0.f;
+    if (t4 < T) {
+        const int4 i4 = *reinterpret_cast<const int4 *>(idx + (size_t)b * T + t4);
+        const float *rb = rel + (size_t)b * 3 * T + t4;
+        const float4 rx = *reinterpret_cast<const float4 *>(rb), ry = *reinterpret_cast<const float4 *>(rb + T),
+                     rz = *reinterpret_cast<const float4 *>(rb + 2 * (size_t)T);
+        float4 f[CF];
+#pragma unroll
+        for (int c = 0; c < CF; ++c) {
+            const float *fp = feats + ((size_t)b * CF + c) * n;
+            f[c] = make_float4(fp[i4.x], fp[i4.y], fp[i4.z], fp[i4.w]);
+        }
+        OT *o = y + ((size_t)b * m + c0) * T + t4;
+        for (int ch = c0; ch < c0 + cpb; ++ch, o += T) {
+            const float *wr = w + (size_t)ch * (3 + CF);
+            float4 v;
+            v.x = fmaf(wr[2], rz.x, fmaf(wr[1], ry.x, wr[0] * rx.x));
+            v.y = fmaf(wr[2], rz.y, fmaf(wr[1], ry.y, wr[0] * rx.y));
+            v.z = fmaf(wr[2], rz.z, fmaf(wr[1], ry.z, wr[0] * rx.z));
+            v.w = fmaf(wr[2], rz.w, fmaf(wr[1], ry.w, wr[0] * rx.w));
+#pragma unroll
+            for (int c = 0; c < CF; ++c) {
+                const float wc = wr[3 + c];
+                v.x = fmaf(wc, f[c].x, v.x); v.y = fmaf(wc, f[c].y, v.y); v.z = fmaf(wc, f[c].z, v.z); v.w = fmaf(wc, f[c].w, v.w);
+            }
+            if constexpr (sizeof(OT) == 2) {
+                v.x = ogc_as_stored<OT>(v.x); v.y = ogc_as_stored<OT>(v.y); v.z = ogc_as_stored<OT>(v.z); v.w = ogc_as_stored<OT>(v.w);
+            }
+            ogc_st4(o, v);
+            s += (v.x + v.y) + (v.z + v.w);
+            ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        }
+    }
+    if (stats) { // uniform — as group_linear_fwd_kernel
+        double ds = s, dss = ss;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            ds += __shfl_down(ds, off, 64);
+            dss += __shfl_down(dss, off, 64);
+        }
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        if (lane == 0) {
+            red[wave * 2] = ds;
+            red[wave * 2 + 1] = dss;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double a = 0.0, q = 0.0;
+            for (int wv = 0; wv < GG_THREADS / 64; ++wv) {
+                a += red[wv * 2];
+                q += red[wv * 2 + 1];
+            }
+            double *dst = stats + (((size_t)(blockIdx.x % GL_SLOTS) * gridDim.z + b) * groups + c0 / cg) * 2;
+            atomicAdd(dst, a);
+            atomicAdd(dst + 1, q);
+        }
+    }
+}
+} // namespace
+
+// ogc_group_linear_fwd for 1 .. 4 feature channels without P: y[b, ch, (i, j)] = the fused-multiply-add chain over
+// [rel (3), features[:, idx] (cf)] with the layer's weight rows w (m, 3 + cf), input channels ascending.  feats (b, cf, n); the other
+// arguments, the statistics layout and the preconditions are ogc_group_linear_fwd's.
+extern "C" int ogc_group_linear_fwd_direct(int b, int m, int cf, int n, int npoints, int nsample, int groups, const float *feats,
+                                           const int *idx, const float *rel, const float *w, float *y, double *stats,
+                                           ogc_stream_t stream) {
+    OGC_REQUIRE(b >= 0 && m >= 1 && n >= 1 && npoints >= 0 && nsample >= 0 && groups >= 0 && (long long)npoints * nsample < (1ll << 31),
+                "ogc_group_linear_fwd_direct: bad dimensions");
+    OGC_REQUIRE(cf >= 1 && cf <= 4, "ogc_group_linear_fwd_direct: 1 .. 4 feature channels (got %d)", cf);
+    const int T = npoints * nsample;
+    if (b == 0 || T == 0) return OGC_OK;
+    OGC_REQUIRE(feats && idx && rel && w && y && (stats || groups == 0), "ogc_group_linear_fwd_direct: null pointer");
+    OGC_REQUIRE((long long)m * T < (1ll << 31) && (long long)cf * n < (1ll << 31) && b <= 65535,
+                "ogc_group_linear_fwd_direct: one sample exceeds 32-bit indexing");
+    if ((T & 3) != 0 || !aligned16(idx) || !aligned16(rel) || !aligned16(y) || (groups > 0 && m % groups != 0)) {
+        ogc_set_error("ogc_group_linear_fwd_direct: needs npoints * nsample %% 4 == 0, 16-byte aligned tensors, m %% groups == 0");
+        return OGC_ERR_UNSUPPORTED;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int cg = groups > 0 ? m / groups : m;
+    int cpb = 1;
+    while (cpb < 16 && cg % (cpb * 2) == 0) cpb *= 2;
+    if (groups > 0 && ogc_zero_async(stats, sizeof(double) * 2 * GL_SLOTS * (size_t)b * groups, s) != hipSuccess) {
+        ogc_set_error("ogc_group_linear_fwd_direct: memset failed");
+        return OGC_ERR_LAUNCH;
+    }
+    dim3 grid(ogc_divup(T, GG_THREADS * 4), m / cpb, b);
+    double *st = groups > 0 ? stats : nullptr;
+#define OGC_GLD(CFV) \
+    hipLaunchKernelGGL((group_linear_direct_kernel<float, CFV>), grid, dim3(GG_THREADS), 0, s, m, n, T, cpb, cg, groups, feats, idx, rel, w, y, st)
+    if (cf == 1) OGC_GLD(1);
+    else if (cf == 2) OGC_GLD(2);
+    else if (cf == 3) OGC_GLD(3);
+    else OGC_GLD(4);
+#undef OGC_GLD
+    OGC_CHECK_LAUNCH("ogc_group_linear_fwd_direct");
+    return OGC_OK;
+}
+
+namespace {
 template <typename OT>
 int group_linear_fwd_impl(int b, int m, int n, int npoints, int nsample, int groups, const float *P, const int *idx,
                           const float *rel, const float *wx, OT *y, double *stats, ogc_stream_t stream) {

@@ -975,8 +975,11 @@ __device__ __forceinline__ int quad_bcast(int v) { // lane R of every group of f
     return __builtin_amdgcn_update_dpp(0, v, R * 0x55, 0xF, 0xF, true);
 }
 
+#ifndef OGC_BQ_MINWAVES
+#define OGC_BQ_MINWAVES 8   // wavefronts per SIMD the register budget leaves room for (tools/bq_probe.hip builds variants)
+#endif
 template <int NS, int WPB>
-__global__ __launch_bounds__(OGC_WAVE * WPB, 8) void ball_query_cells_kernel(int n, int m, float radius2, int stride_cells, int lds_ints,
+__global__ __launch_bounds__(OGC_WAVE * WPB, OGC_BQ_MINWAVES) void ball_query_cells_kernel(int n, int m, float radius2, int stride_cells, int lds_ints,
                                                                        const float *__restrict__ xyz,
                                                                        const GridHdr *__restrict__ hdrs,
                                                                        const int *__restrict__ cell_start,

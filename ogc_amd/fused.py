@@ -1319,13 +1319,19 @@ class _GroupedFirstLayer(Function):
         wx, wf = w[:, :3].contiguous(), w[:, 3:].contiguous()
         rel = torch.empty(B, 3, npoint, nsample, dtype=torch.float32, device=xyz.device)
         nat.group_concat_wrapper(B, 0, N, npoint, nsample, xyz, new_xyz, None, idx, rel)
-        P = _product(wf, features.detach(), False)                                  # (B, M, N)
         y = torch.empty(B, M, npoint, nsample, dtype=torch.bfloat16 if act16 else torch.float32, device=xyz.device)
         stats = None
         if gn_groups > 0:
             stats = zeroed_empty(nat.conv1x1_gn_slots() * B * gn_groups * 2, torch.float64, xyz.device)
         cg = M // gn_groups if gn_groups > 0 else 64
-        if (act16 and GROUP_LINEAR_POINT_MAJOR and M % 64 == 0 and cg in (16, 32, 64) and (npoint * nsample) % 2 == 0
+        direct = (GROUP_LINEAR_DIRECT and C <= 4 and not act16 and getattr(nat, "group_linear_fwd_direct_wrapper", None) is not None)
+        P = None if direct else _product(wf, features.detach(), False)              # (B, M, N)
+        if direct:
+            # few feature channels (an encoder's first level): no point-wise product, one k-ascending chain per output
+            # (ogc_group_linear_fwd_direct) — the rounding of the reference's convolution over the concatenated channels
+            nat.group_linear_fwd_direct_wrapper(B, M, C, N, npoint, nsample, gn_groups, features.detach().contiguous(), idx, rel,
+                                                w.contiguous(), y, stats)
+        elif (act16 and GROUP_LINEAR_POINT_MAJOR and M % 64 == 0 and cg in (16, 32, 64) and (npoint * nsample) % 2 == 0
                 and getattr(nat, "group_linear_fwd_pt_wrapper", None) is not None):
             # 16-bit output: P point-major, so that a position's channels are one contiguous read (csrc/gather_group.hip)
             nat.group_linear_fwd_pt_wrapper(B, M, N, npoint, nsample, gn_groups, P.transpose(1, 2).contiguous(), idx, rel, wx, y, stats)
@@ -1396,6 +1402,7 @@ def grouped_first_layer_available(xyz, new_xyz, features, idx, conv, gn):
             and (gn is None or (gn.num_groups <= 32 and conv.weight.shape[0] % gn.num_groups == 0)))
 
 
+GROUP_LINEAR_DIRECT = _os.environ.get("OGC_GROUP_LINEAR_DIRECT", "1") != "0"   # (0: P[idx] + W_xyz rel at every width, as until round 5)
 GROUP_LINEAR_POINT_MAJOR = _os.environ.get("OGC_GROUP_LINEAR_PT", "1") != "0"   # (16-bit first layers: P stored (B, N, M))
 # dwx inside the gather-form grouping gradient (ogc_group_points_grad_rev_dwx: one read of grad_y less, but 192 bytes of rel per
 # thread and chunk through the L2s).  Measured at the end of round 5: C2 16.6-16.7 ms per step with it against 16.2 without (the

@@ -390,6 +390,13 @@ def group_linear_fwd_pt_wrapper(b, m, n, npoints, nsample, groups, Pt, idx, rel,
          _f(wx, "wx"), _check(y, torch.bfloat16, "y"), _opt(stats, torch.float64, "stats"))
 
 
+def group_linear_fwd_direct_wrapper(b, m, cf, n, npoints, nsample, groups, feats, idx, rel, w, y, stats):
+    """ogc_group_linear_fwd for 1 .. 4 feature channels: one fused-multiply-add chain over [rel, features[idx]] per output
+    (ogc_group_linear_fwd_direct); w (m, 3 + cf) fp32, y fp32."""
+    _run("ogc_group_linear_fwd_direct", feats, b, m, cf, n, npoints, nsample, int(groups), _f(feats, "feats"), _i(idx, "idx"),
+         _f(rel, "rel"), _f(w, "w"), _f(y, "y"), _opt(stats, torch.float64, "stats"))
+
+
 def group_linear_bwd_wrapper(b, m, n, npoints, nsample, grad_y, idx, rel, grad_p, dwx):
     """grad_p += scatter of grad_y, dwx += grad_y . rel in one pass over grad_y (ogc_group_linear_bwd); both zeroed by
     the caller.  Raises OgcOpsError (unsupported) outside n <= 16384, npoints * nsample >= 4096 and % 16 == 0."""

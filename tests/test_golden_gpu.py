@@ -69,9 +69,9 @@ def test_vote_and_clustering_metrics():
 def test_segnet_forward_backward(name, kw, N, B):
     # closeness to ONE fp32 evaluation of the reference; how close both are to the exact result, and why single gradient
     # tensors can differ by 1e-3 (gate flips), is tests/test_truth_f64_gpu.py
-    gc.run_segnet("cuda", name, kw, N, B, rtol=2e-4, atol=2e-6, grad_rtol=1e-2)
+    gc.run_segnet("cuda", name, kw, N, B, rtol=2e-4, atol=2e-6, grad_rtol=2e-3)
 
 
 @pytest.mark.parametrize("name,kw,N,iters", gc.FLOW_CASES, ids=[c[0] for c in gc.FLOW_CASES])
 def test_flownet_forward_backward(name, kw, N, iters):
-    gc.run_flownet("cuda", name, kw, N, iters, rtol=1e-4, atol=1e-5, grad_rtol=2e-2)
+    gc.run_flownet("cuda", name, kw, N, iters, rtol=1e-4, atol=1e-5, grad_rtol=2e-3)

@@ -66,3 +66,39 @@ def test_sa_level_with_and_without_the_fusion(monkeypatch):
         outs.append([new_feats.detach(), f.grad] + [p.grad.clone() for p in sa.parameters()])
     for a, b in zip(*outs):
         assert (a - b).abs().max().item() <= 2e-4 * b.abs().max().item() + 1e-7
+
+
+@pytest.mark.parametrize("cf,m,groups", [(3, 32, 4), (3, 64, 4), (1, 16, 0), (4, 32, 2)])
+def test_direct_first_layer_is_one_chain_over_the_concatenated_channels(cf, m, groups):
+    """ogc_group_linear_fwd_direct (few feature channels: an encoder's first level) against the layer as the reference runs it —
+    QueryAndGroup's concatenation, then the 1x1 convolution over [rel (3), features (cf)] on this library's matrix kernel
+    (ogc_conv1x1_gemm: v_mfma_f32_16x16x4_f32, input channels ascending): the same fused-multiply-add chain, so the same BITS;
+    and its GroupNorm statistics against the values it stored."""
+    from ogc_amd import pointnet2_cuda as nat
+    g = torch.Generator().manual_seed(100 * cf + m)
+    B, N, npoint, nsample = 2, 1024, 256, 32
+    xyz = (torch.rand(B, N, 3, generator=g) * 2 - 1).cuda()
+    new_xyz = xyz[:, :npoint].contiguous()
+    feats = torch.randn(B, cf, N, generator=g).cuda()
+    idx = torch.randint(0, N, (B, npoint, nsample), generator=g, dtype=torch.int32).cuda()
+    w = torch.randn(m, 3 + cf, generator=g).cuda()
+    T = npoint * nsample
+    rel = torch.empty(B, 3, npoint, nsample, device="cuda")
+    nat.group_concat_wrapper(B, 0, N, npoint, nsample, xyz, new_xyz, None, idx, rel)
+    y = torch.empty(B, m, npoint, nsample, device="cuda")
+    stats = torch.zeros(nat.conv1x1_gn_slots() * B * groups * 2, dtype=torch.float64, device="cuda") if groups else None
+    nat.group_linear_fwd_direct_wrapper(B, m, cf, N, npoint, nsample, groups, feats, idx, rel, w, y, stats)
+    grouped = torch.empty(B, 3 + cf, npoint, nsample, device="cuda")
+    nat.group_concat_wrapper(B, cf, N, npoint, nsample, xyz, new_xyz, feats, idx, grouped)
+    ref = torch.empty(B, m, npoint, nsample, device="cuda")
+    nat.conv1x1_gemm_wrapper(B, m, 3 + cf, T, 0, w, grouped, ref)
+    exact = torch.einsum("oc,bcps->bops", w.double(), grouped.double())
+    print("cf=%d m=%d: %d of %d outputs differ in the last bits from the matrix kernel's" % (cf, m, int((y != ref).sum()), y.numel()))
+    assert torch.equal(y, ref)
+    assert ((y.double() - exact).norm() / exact.norm()).item() <= 1e-6
+    if groups:
+        s = stats.view(-1, B, groups, 2).sum(0)
+        yg = y.double().view(B, groups, -1)
+        # (a thread adds its outputs in fp32 before the fp64 tree: 1e-6 relative)
+        torch.testing.assert_close(s[..., 0], yg.sum(-1), rtol=1e-6, atol=1e-3)
+        torch.testing.assert_close(s[..., 1], (yg * yg).sum(-1), rtol=1e-6, atol=1e-3)

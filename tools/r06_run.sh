@@ -1,2 +1,3 @@
-export PYTHONPATH=$PWD TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
-timeout 600 python -m torch.distributed.run --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 tools/graph_rccl.py 1024 2>&1 | grep -v Warn | tail -12
+export PYTHONPATH=$PWD TMPDIR=/tmp
+timeout 900 python -m pytest tests/test_grouped_first_layer_gpu.py -q -m gpu -s 2>&1 | grep -v Warn | tail -12
+timeout 900 python -m pytest tests/test_fallbacks_gpu.py tests/test_config_sizes_gpu.py tests/test_bf16_gpu.py tests/test_act16_gpu.py -q -m gpu 2>&1 | tail -3
