@@ -262,6 +262,8 @@ int ogc_group_linear_fwd(int b, int m, int n, int npoints, int nsample, int grou
  * arguments, statistics layout and preconditions as ogc_group_linear_fwd. */
 int ogc_group_linear_fwd_direct(int b, int m, int cf, int n, int npoints, int nsample, int groups, const float *feats,
                                 const int *idx, const float *rel, const float *w, float *y, double *stats, ogc_stream_t stream);
+int ogc_group_linear_fwd_direct_h(int b, int m, int cf, int n, int npoints, int nsample, int groups, const float *feats,
+                                  const int *idx, const float *rel, const float *w, ogc_bf16_t *y, double *stats, ogc_stream_t stream);
 int ogc_group_linear_bwd(int b, int m, int n, int npoints, int nsample, const float *grad_y, const int *idx,
                          const float *rel, float *grad_p, float *dwx, ogc_stream_t stream);
 

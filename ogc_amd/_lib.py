@@ -145,6 +145,7 @@ for _n in ("ogc_group_linear_fwd", "ogc_group_points_grad_rev", "ogc_conv1x1_gem
            "ogc_conv1x1_dgrad_adjoint", "ogc_conv1x1_dgrad_adjoint_pooled", "ogc_group_norm_bwd",
            "ogc_group_norm_maxpool_bwd_sparse", "ogc_group_points_grad_rev_dwx"):
     SIGNATURES[_n + "_h"] = SIGNATURES[_n]
+SIGNATURES["ogc_group_linear_fwd_direct_h"] = SIGNATURES["ogc_group_linear_fwd_direct"]
 SIGNATURES["ogc_conv1x1_wgrad_xf_h"] = SIGNATURES["ogc_conv1x1_wgrad"]
 SIGNATURES["ogc_group_linear_fwd_pt_h"] = SIGNATURES["ogc_group_linear_fwd"]
 

@@ -602,9 +602,10 @@ __global__ __launch_bounds__(GG_THREADS) void group_linear_direct_kernel(int m, 
 // ogc_group_linear_fwd for 1 .. 4 feature channels without P: y[b, ch, (i, j)] = the fused-multiply-add chain over
 // [rel (3), features[:, idx] (cf)] with the layer's weight rows w (m, 3 + cf), input channels ascending.  feats (b, cf, n); the other
 // arguments, the statistics layout and the preconditions are ogc_group_linear_fwd's.
-extern "C" int ogc_group_linear_fwd_direct(int b, int m, int cf, int n, int npoints, int nsample, int groups, const float *feats,
-                                           const int *idx, const float *rel, const float *w, float *y, double *stats,
-                                           ogc_stream_t stream) {
+namespace {
+template <typename OT>
+int group_linear_fwd_direct_impl(int b, int m, int cf, int n, int npoints, int nsample, int groups, const float *feats,
+                                 const int *idx, const float *rel, const float *w, OT *y, double *stats, ogc_stream_t stream) {
     OGC_REQUIRE(b >= 0 && m >= 1 && n >= 1 && npoints >= 0 && nsample >= 0 && groups >= 0 && (long long)npoints * nsample < (1ll << 31),
                 "ogc_group_linear_fwd_direct: bad dimensions");
     OGC_REQUIRE(cf >= 1 && cf <= 4, "ogc_group_linear_fwd_direct: 1 .. 4 feature channels (got %d)", cf);
@@ -613,7 +614,7 @@ extern "C" int ogc_group_linear_fwd_direct(int b, int m, int cf, int n, int npoi
     OGC_REQUIRE(feats && idx && rel && w && y && (stats || groups == 0), "ogc_group_linear_fwd_direct: null pointer");
     OGC_REQUIRE((long long)m * T < (1ll << 31) && (long long)cf * n < (1ll << 31) && b <= 65535,
                 "ogc_group_linear_fwd_direct: one sample exceeds 32-bit indexing");
-    if ((T & 3) != 0 || !aligned16(idx) || !aligned16(rel) || !aligned16(y) || (groups > 0 && m % groups != 0)) {
+    if ((T & 3) != 0 || !aligned16(idx) || !aligned16(rel) || ((uintptr_t)y & ogc_act_mask<OT>()) != 0 || (groups > 0 && m % groups != 0)) {
         ogc_set_error("ogc_group_linear_fwd_direct: needs npoints * nsample %% 4 == 0, 16-byte aligned tensors, m %% groups == 0");
         return OGC_ERR_UNSUPPORTED;
     }
@@ -628,7 +629,7 @@ extern "C" int ogc_group_linear_fwd_direct(int b, int m, int cf, int n, int npoi
     dim3 grid(ogc_divup(T, GG_THREADS * 4), m / cpb, b);
     double *st = groups > 0 ? stats : nullptr;
 #define OGC_GLD(CFV) \
-    hipLaunchKernelGGL((group_linear_direct_kernel<float, CFV>), grid, dim3(GG_THREADS), 0, s, m, n, T, cpb, cg, groups, feats, idx, rel, w, y, st)
+    hipLaunchKernelGGL((group_linear_direct_kernel<OT, CFV>), grid, dim3(GG_THREADS), 0, s, m, n, T, cpb, cg, groups, feats, idx, rel, w, y, st)
     if (cf == 1) OGC_GLD(1);
     else if (cf == 2) OGC_GLD(2);
     else if (cf == 3) OGC_GLD(3);
@@ -636,6 +637,22 @@ extern "C" int ogc_group_linear_fwd_direct(int b, int m, int cf, int n, int npoi
 #undef OGC_GLD
     OGC_CHECK_LAUNCH("ogc_group_linear_fwd_direct");
     return OGC_OK;
+}
+} // namespace
+
+extern "C" int ogc_group_linear_fwd_direct(int b, int m, int cf, int n, int npoints, int nsample, int groups, const float *feats,
+                                           const int *idx, const float *rel, const float *w, float *y, double *stats,
+                                           ogc_stream_t stream) {
+    return group_linear_fwd_direct_impl<float>(b, m, cf, n, npoints, nsample, groups, feats, idx, rel, w, y, stats, stream);
+}
+
+// 16-bit activations (act_io.h): y stored as bf16, the statistics those of the stored values — 12 gathered bytes per position
+// instead of the 4 m bytes of a P row (ogc_group_linear_fwd_pt_h: 256 bytes at m = 64)
+extern "C" int ogc_group_linear_fwd_direct_h(int b, int m, int cf, int n, int npoints, int nsample, int groups, const float *feats,
+                                             const int *idx, const float *rel, const float *w, ogc_bf16_t *y, double *stats,
+                                             ogc_stream_t stream) {
+    return group_linear_fwd_direct_impl<ogc_bf16>(b, m, cf, n, npoints, nsample, groups, feats, idx, rel, w,
+                                                  reinterpret_cast<ogc_bf16 *>(y), stats, stream);
 }
 
 namespace {

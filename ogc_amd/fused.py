@@ -1324,7 +1324,7 @@ class _GroupedFirstLayer(Function):
         if gn_groups > 0:
             stats = zeroed_empty(nat.conv1x1_gn_slots() * B * gn_groups * 2, torch.float64, xyz.device)
         cg = M // gn_groups if gn_groups > 0 else 64
-        direct = (GROUP_LINEAR_DIRECT and C <= 4 and not act16 and getattr(nat, "group_linear_fwd_direct_wrapper", None) is not None)
+        direct = GROUP_LINEAR_DIRECT and C <= 4 and getattr(nat, "group_linear_fwd_direct_wrapper", None) is not None
         P = None if direct else _product(wf, features.detach(), False)              # (B, M, N)
         if direct:
             # few feature channels (an encoder's first level): no point-wise product, one k-ascending chain per output

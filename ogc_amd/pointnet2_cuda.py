@@ -393,8 +393,9 @@ def group_linear_fwd_pt_wrapper(b, m, n, npoints, nsample, groups, Pt, idx, rel,
 def group_linear_fwd_direct_wrapper(b, m, cf, n, npoints, nsample, groups, feats, idx, rel, w, y, stats):
     """ogc_group_linear_fwd for 1 .. 4 feature channels: one fused-multiply-add chain over [rel, features[idx]] per output
     (ogc_group_linear_fwd_direct); w (m, 3 + cf) fp32, y fp32."""
-    _run("ogc_group_linear_fwd_direct", feats, b, m, cf, n, npoints, nsample, int(groups), _f(feats, "feats"), _i(idx, "idx"),
-         _f(rel, "rel"), _f(w, "w"), _f(y, "y"), _opt(stats, torch.float64, "stats"))
+    h, (yp,) = _acts((y,), ("y",))
+    _run("ogc_group_linear_fwd_direct" + h, feats, b, m, cf, n, npoints, nsample, int(groups), _f(feats, "feats"), _i(idx, "idx"),
+         _f(rel, "rel"), _f(w, "w"), yp, _opt(stats, torch.float64, "stats"))
 
 
 def group_linear_bwd_wrapper(b, m, n, npoints, nsample, grad_y, idx, rel, grad_p, dwx):
