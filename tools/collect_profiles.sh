@@ -20,7 +20,7 @@ take() {  # take <source> <destination> [filter]
 }
 for f in bench_line.json bench_kernel_stats.csv; do take "$src/$f" "profiles/${r}_$f"; done
 for f in steady phase_busy native_forward native_loss native_backward step_hbm_traffic ball_query_pmc knn_clamped_pmc knn_plain_pmc ops \
-         graph_step flowstep3d corr_layer ball_ab bq_probe library_gemms sizing c2_kernels c2_forward_kernels c2_switches c2_hbm_traffic; do
+         graph_step flowstep3d corr_layer ball_ab bq_probe library_gemms sizing c2_kernels c2_forward_kernels c2_switches c2_hbm_traffic oa_icp flow_train deterministic gate_flip bq_occupancy; do
   [ -f "$src/$f.txt" ] && take "$src/$f.txt" "profiles/${r}_$f.txt" "amdgpu.ids"
 done
 cfg=$(cat "$src"/config_sapien.txt "$src"/config_sapien_graph.txt "$src"/config_ogcdr.txt "$src"/config_ogcdr_fp32.txt "$src"/config_waymo.txt "$src"/config_kittisf.txt 2>/dev/null \
