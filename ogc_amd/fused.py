@@ -1402,6 +1402,18 @@ def grouped_first_layer_available(xyz, new_xyz, features, idx, conv, gn):
             and (gn is None or (gn.num_groups <= 32 and conv.weight.shape[0] % gn.num_groups == 0)))
 
 
+# An encoder's FIRST level with fp32 activations (features = the coordinates, no gradient wanted for them): QueryAndGroup's
+# six-channel tensor + the matrix kernel with its statistics epilogue (ogc_conv1x1_gemm_gnstats) + a six-channel weight gradient,
+# instead of the grouped first layer — whose backward scatter-adds 32 / 64 channels of dy into a per-point tensor nobody needs
+# when the features take no gradient (group_bwd_lds_kernel: 0.28 ms per C4 step).  A/B on one box, round 6: 10.39-10.41 -> 10.29-10.31
+# ms per C4 step; same rounding (one chain over the concatenated channels), the gate-flip list stays empty.  OGC_FIRST_LEVEL_PLAIN=0:
+# the grouped first layer (its direct form) there as well.  16-bit activations (C2) keep the direct kernel: it stores bf16.
+FIRST_LEVEL_PLAIN = _os.environ.get("OGC_FIRST_LEVEL_PLAIN", "1") != "0"
+
+
+def first_level_plain(features):
+    return bool(FIRST_LEVEL_PLAIN and features is not None and features.is_cuda and features.shape[1] <= 4
+                and not features.requires_grad and not act16_wanted(features) and not deterministic())
 GROUP_LINEAR_DIRECT = _os.environ.get("OGC_GROUP_LINEAR_DIRECT", "1") != "0"   # (0: P[idx] + W_xyz rel at every width, as until round 5)
 GROUP_LINEAR_POINT_MAJOR = _os.environ.get("OGC_GROUP_LINEAR_PT", "1") != "0"   # (16-bit first layers: P stored (B, N, M))
 # dwx inside the gather-form grouping gradient (ogc_group_points_grad_rev_dwx: one read of grad_y less, but 192 bytes of rel per

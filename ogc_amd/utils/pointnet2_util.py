@@ -93,12 +93,12 @@ class _PointnetSAModuleBase(nn.Module):
         new_xyz = geometry["new_xyz"] if geometry is not None else None
         new_inds = geometry["new_inds"] if geometry is not None else None
 
-        from ..fused import grouped_first_layer, grouped_first_layer_available
+        from ..fused import first_level_plain, grouped_first_layer, grouped_first_layer_available
         pooled = []
         for i, (grouper, mlp) in enumerate(zip(self.groupers, self.mlps)):
             if isinstance(grouper, QueryAndGroup):
                 nn_idx = geometry["idx"][i]
-                head = mlp.first_layer() if (grouper.use_xyz and xyz.is_cuda) else None
+                head = mlp.first_layer() if (grouper.use_xyz and xyz.is_cuda and not first_level_plain(features)) else None
                 if head is not None and grouped_first_layer_available(xyz, new_xyz, features, nn_idx, head[0], head[1]):
                     # grouping + first convolution without the (B, 3 + C, npoint, nsample) tensor in between
                     pooled.append(mlp.forward_maxpool(None, first=lambda conv, gn, j=nn_idx, rv=geometry["rev"][i]:
