@@ -16,6 +16,8 @@
 // Semantics of nn.BatchNorm2d: training = batch statistics with biased variance for the normalisation, running
 // statistics updated with `momentum` and the UNBIASED variance; evaluation = running statistics, whose gradient is
 // the plain affine map (c2 = c3 = 0).
+#include <stdlib.h>
+
 #include "ogc_common.h"
 
 namespace {
@@ -41,6 +43,65 @@ __device__ __forceinline__ void bn_block_sum2(double &a, double &b, double *smem
             a += smem[w * 2];
             b += smem[w * 2 + 1];
         }
+    }
+}
+
+// ---- finalize folded into the consumers (round 6) ---------------------------------------------------------------------------------
+// A training-mode BatchNorm used to be stats -> finalize -> apply forwards and sums -> params -> dx backwards: the two middle
+// launches are one thread per channel, ~4.5 us each plus a dependent kernel boundary, 210 of them per FlowStep3D training step
+// whose launch thread is as busy as its GPU.  Every workgroup of the apply / dx kernel now derives ITS channel's coefficients from
+// the channel's sums itself (the same double-precision expressions, so the same values bit for bit), and the workgroup
+// (chunk 0, sample 0) of a channel also writes what the middle launch wrote: mean / rstd / running statistics, dgamma / dbeta.
+struct BnFin {   // stats == nullptr: not folded (the coefficients come from mean / rstd / var as before)
+    const double *stats;
+    int slots;
+    double count;
+    float momentum;
+    float *running_mean, *running_var, *mean_out, *rstd_out;
+};
+
+__device__ __forceinline__ void bn_fin(const BnFin &f, int c, int ch, float eps, bool writer, float &mean, float &rstd) {
+    double sum = 0.0, sumsq = 0.0;
+    for (int sl = 0; sl < f.slots; ++sl) {
+        sum += f.stats[((size_t)sl * c + ch) * 2];
+        sumsq += f.stats[((size_t)sl * c + ch) * 2 + 1];
+    }
+    const double m = sum / f.count;
+    const double var = fmax(sumsq / f.count - m * m, 0.0);
+    mean = (float)m;
+    rstd = (float)(1.0 / sqrt(var + (double)eps));
+    if (writer) {
+        f.mean_out[ch] = mean;
+        f.rstd_out[ch] = rstd;
+        if (f.running_mean && f.running_var) {
+            const double unbiased = f.count > 1.0 ? var * f.count / (f.count - 1.0) : var;
+            f.running_mean[ch] = (float)((1.0 - (double)f.momentum) * (double)f.running_mean[ch] + (double)f.momentum * m);
+            f.running_var[ch] = (float)((1.0 - (double)f.momentum) * (double)f.running_var[ch] + (double)f.momentum * unbiased);
+        }
+    }
+}
+
+struct BnBwdFin {   // dsdb == nullptr: not folded (c2, c3 come from the c2c3 buffer)
+    const double *dsdb;
+    double count;
+    int training;
+    float *dgamma, *dbeta;
+};
+
+__device__ __forceinline__ void bn_bwd_fin(const BnBwdFin &f, int ch, float gamma, float mean, float rstd, bool writer, float &c2f,
+                                           float &c3f) {
+    const double ds = f.dsdb[(size_t)ch * 2], db = f.dsdb[(size_t)ch * 2 + 1];
+    const double m = mean, r = rstd, g = gamma;
+    double c2 = 0.0, c3 = 0.0;
+    if (f.training) {
+        c2 = g * (db * m - ds) * r * r * r / f.count;
+        c3 = -c2 * m - g * db * r / f.count;
+    }
+    c2f = (float)c2;
+    c3f = (float)c3;
+    if (writer) {
+        f.dgamma[ch] = (float)((ds - m * db) * r);
+        f.dbeta[ch] = (float)db;
     }
 }
 
@@ -114,11 +175,14 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(int c, int hw, con
                                                               const float *__restrict__ mean,
                                                               const float *__restrict__ rstd,
                                                               const float *__restrict__ var, float eps,
-                                                              float *__restrict__ y) {
+                                                              float *__restrict__ y, BnFin fin) {
     const int b = blockIdx.z, ch = blockIdx.y;
     // var != nullptr: evaluation straight from the running statistics (mean = running_mean), no finalize launch
-    const float a = (var ? (float)(1.0 / sqrt((double)var[ch] + (double)eps)) : rstd[ch]) * gamma[ch];
-    const float bb = beta[ch] - mean[ch] * a;
+    float mu, rs;
+    if (fin.stats) bn_fin(fin, c, ch, eps, blockIdx.x == 0 && b == 0 && threadIdx.x == 0, mu, rs);
+    else { mu = mean[ch]; rs = var ? (float)(1.0 / sqrt((double)var[ch] + (double)eps)) : rstd[ch]; }
+    const float a = rs * gamma[ch];
+    const float bb = beta[ch] - mu * a;
     const size_t base = ((size_t)b * c + ch) * hw;
     const float *px = x + base;
     float *py = y + base;
@@ -146,10 +210,13 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_maxpool_kernel(int c, int
                                                                       const float *__restrict__ mean,
                                                                       const float *__restrict__ rstd,
                                                                       const float *__restrict__ var, float eps,
-                                                                      float *__restrict__ out, int *__restrict__ arg) {
+                                                                      float *__restrict__ out, int *__restrict__ arg, BnFin fin) {
     const int b = blockIdx.z, ch = blockIdx.y;
-    const float a = (var ? (float)(1.0 / sqrt((double)var[ch] + (double)eps)) : rstd[ch]) * gamma[ch];
-    const float bb = beta[ch] - mean[ch] * a;
+    float mu, rs;
+    if (fin.stats) bn_fin(fin, c, ch, eps, blockIdx.x == 0 && b == 0 && threadIdx.x == 0, mu, rs);
+    else { mu = mean[ch]; rs = var ? (float)(1.0 / sqrt((double)var[ch] + (double)eps)) : rstd[ch]; }
+    const float a = rs * gamma[ch];
+    const float bb = beta[ch] - mu * a;
     const int L = s >> 2;
     const int rows_per_block = BN_THREADS / L;
     const int sub = threadIdx.x % L;
@@ -253,11 +320,13 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_dx_kernel(int c, int hw, co
                                                                const float *__restrict__ mean,
                                                                const float *__restrict__ rstd,
                                                                const float *__restrict__ c2c3,
-                                                               const float *__restrict__ dy, float *__restrict__ dx) {
+                                                               const float *__restrict__ dy, float *__restrict__ dx, BnBwdFin fin) {
     const int b = blockIdx.z, ch = blockIdx.y;
     const float a = rstd[ch] * gamma[ch];
     const float bb = beta[ch] - mean[ch] * a;
-    const float c2 = c2c3[ch * 2], c3 = c2c3[ch * 2 + 1];
+    float c2, c3;
+    if (fin.dsdb) bn_bwd_fin(fin, ch, gamma[ch], mean[ch], rstd[ch], blockIdx.x == 0 && b == 0 && threadIdx.x == 0, c2, c3);
+    else { c2 = c2c3[ch * 2]; c3 = c2c3[ch * 2 + 1]; }
     const size_t base = ((size_t)b * c + ch) * hw;
     const float *px = x + base, *pd = dy + base;
     float *po = dx + base;
@@ -324,10 +393,13 @@ __global__ __launch_bounds__(BN_THREADS) void bn_maxpool_bwd_dx_kernel(int c, in
                                                                        const float *__restrict__ out,
                                                                        const int *__restrict__ arg,
                                                                        const float *__restrict__ gout,
-                                                                       float *__restrict__ dx) {
+                                                                       float *__restrict__ dx, const float *__restrict__ mean,
+                                                                       BnBwdFin fin) {
     const int b = blockIdx.z, ch = blockIdx.y;
     const float a = rstd[ch] * gamma[ch];
-    const float c2 = c2c3[ch * 2], c3 = c2c3[ch * 2 + 1];
+    float c2, c3;
+    if (fin.dsdb) bn_bwd_fin(fin, ch, gamma[ch], mean[ch], rstd[ch], blockIdx.x == 0 && b == 0 && threadIdx.x == 0, c2, c3);
+    else { c2 = c2c3[ch * 2]; c3 = c2c3[ch * 2 + 1]; }
     const int L = s >> 2;
     const int rows_per_block = BN_THREADS / L;
     const int sub = threadIdx.x % L;
@@ -356,6 +428,12 @@ int bn_chunks(int b, int c, int hw) {
 
 bool bn_pool_shape_ok(int s) { return s >= 4 && s <= 256 && (s & (s - 1)) == 0; }
 
+// OGC_BN_FOLD=0 in the environment: the finalize / params launches of their own, as until round 5 (A/B runs, tests of both)
+bool bn_fold_finalize() {
+    static const bool on = [] { const char *e = getenv("OGC_BN_FOLD"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 // deterministic mode: one slab of 2 c doubles per workgroup of the split (grid.x chunks x grid.z samples), every entry written
 double *bn_partials(const char *name, dim3 grid, int c, hipStream_t s) {
     if (!ogc_deterministic()) return nullptr;
@@ -365,9 +443,11 @@ double *bn_partials(const char *name, dim3 grid, int c, hipStream_t s) {
 }
 
 // statistics (unless supplied) + finalize; leaves mean / rstd per channel
+// fin: training mode — the finalize step is left to the apply kernel (see BnFin); evaluation mode keeps the finalize launch
 int bn_prepare(const char *name, int b, int c, int hw, float eps, int training, float momentum, const float *x,
                float *running_mean, float *running_var, float *mean, float *rstd, double *ws, const double *stats,
-               int slots, hipStream_t s) {
+               int slots, hipStream_t s, BnFin *fin) {
+    *fin = BnFin{nullptr, 0, 0.0, 0.f, nullptr, nullptr, nullptr, nullptr};
     if (training && !stats) {
         OGC_REQUIRE(ws, "%s: null workspace", name);
         if (ogc_zero_async(ws, sizeof(double) * 2 * c, s) != hipSuccess) {
@@ -383,6 +463,10 @@ int bn_prepare(const char *name, int b, int c, int hw, float eps, int training, 
         slots = 1;
     }
     if (!training) OGC_REQUIRE(running_mean && running_var, "%s: evaluation mode needs running statistics", name);
+    if (training && bn_fold_finalize()) {
+        *fin = BnFin{stats, slots, (double)b * (double)hw, momentum, running_mean, running_var, mean, rstd};
+        return OGC_OK;
+    }
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(ogc_divup(c, 256)), dim3(256), 0, s, c, (double)b * (double)hw, eps,
                        training, momentum, stats, slots, running_mean, running_var, mean, rstd);
     return OGC_OK;
@@ -403,22 +487,23 @@ extern "C" int ogc_batch_norm_fwd(int b, int c, int hw, float eps, int relu, int
     OGC_REQUIRE((long long)c * hw < (1ll << 31) && b <= 65535, "ogc_batch_norm_fwd: one sample exceeds 32-bit indexing");
     hipStream_t s = (hipStream_t)stream;
     const float *var = nullptr;
+    BnFin fin{nullptr, 0, 0.0, 0.f, nullptr, nullptr, nullptr, nullptr};
     if (inline_eval) {
         OGC_REQUIRE(running_mean && running_var, "ogc_batch_norm_fwd: evaluation mode needs running statistics");
         mean = running_mean;
         var = running_var;
     } else {
         const int rc = bn_prepare("ogc_batch_norm_fwd", b, c, hw, eps, training, momentum, x, running_mean, running_var,
-                                  mean, rstd, ws, stats, slots, s);
+                                  mean, rstd, ws, stats, slots, s, &fin);
         if (rc != OGC_OK) return rc;
     }
     dim3 grid(bn_chunks(b, c, hw), c, b);
     if (relu)
         hipLaunchKernelGGL(bn_apply_kernel<true>, grid, dim3(BN_THREADS), 0, s, c, hw, x, gamma, beta, mean, rstd, var, eps,
-                           y);
+                           y, fin);
     else
         hipLaunchKernelGGL(bn_apply_kernel<false>, grid, dim3(BN_THREADS), 0, s, c, hw, x, gamma, beta, mean, rstd, var,
-                           eps, y);
+                           eps, y, fin);
     OGC_CHECK_LAUNCH("ogc_batch_norm_fwd");
     return OGC_OK;
 }
@@ -448,14 +533,17 @@ extern "C" int ogc_batch_norm_bwd(int b, int c, int hw, int relu, int training, 
         hipLaunchKernelGGL(bn_bwd_sums_kernel<false>, grid, dim3(BN_THREADS), 0, s, c, hw, x, gamma, beta, mean, rstd,
                            grad_y, dsdb, part);
     if (part && ogc_det_reduce_f64(dsdb, part, (int)(grid.x * grid.z), 2ll * c, 0, s) != hipSuccess) return OGC_ERR_LAUNCH;
-    hipLaunchKernelGGL(bn_bwd_params_kernel, dim3(ogc_divup(c, 256)), dim3(256), 0, s, c, (double)b * (double)hw,
-                       training, gamma, mean, rstd, dsdb, grad_gamma, grad_beta, c2c3);
+    BnBwdFin bfin{nullptr, 0.0, 0, nullptr, nullptr};
+    if (bn_fold_finalize()) bfin = BnBwdFin{dsdb, (double)b * (double)hw, training, grad_gamma, grad_beta};
+    else
+        hipLaunchKernelGGL(bn_bwd_params_kernel, dim3(ogc_divup(c, 256)), dim3(256), 0, s, c, (double)b * (double)hw,
+                           training, gamma, mean, rstd, dsdb, grad_gamma, grad_beta, c2c3);
     if (relu)
         hipLaunchKernelGGL(bn_bwd_dx_kernel<true>, grid, dim3(BN_THREADS), 0, s, c, hw, x, gamma, beta, mean, rstd, c2c3,
-                           grad_y, grad_x);
+                           grad_y, grad_x, bfin);
     else
         hipLaunchKernelGGL(bn_bwd_dx_kernel<false>, grid, dim3(BN_THREADS), 0, s, c, hw, x, gamma, beta, mean, rstd,
-                           c2c3, grad_y, grad_x);
+                           c2c3, grad_y, grad_x, bfin);
     OGC_CHECK_LAUNCH("ogc_batch_norm_bwd");
     return OGC_OK;
 }
@@ -477,13 +565,14 @@ extern "C" int ogc_batch_norm_maxpool_fwd(int b, int c, int p, int s, float eps,
                 "ogc_batch_norm_maxpool_fwd: one sample exceeds 32-bit indexing");
     hipStream_t st = (hipStream_t)stream;
     const float *var = nullptr;
+    BnFin fin{nullptr, 0, 0.0, 0.f, nullptr, nullptr, nullptr, nullptr};
     if (inline_eval) {
         OGC_REQUIRE(running_mean && running_var, "ogc_batch_norm_maxpool_fwd: evaluation mode needs running statistics");
         mean = running_mean;
         var = running_var;
     } else {
         const int rc = bn_prepare("ogc_batch_norm_maxpool_fwd", b, c, p * s, eps, training, momentum, x, running_mean,
-                                  running_var, mean, rstd, ws, stats, slots, st);
+                                  running_var, mean, rstd, ws, stats, slots, st, &fin);
         if (rc != OGC_OK) return rc;
     }
     const int rows_per_block = BN_THREADS / (s / 4);
@@ -492,10 +581,10 @@ extern "C" int ogc_batch_norm_maxpool_fwd(int b, int c, int p, int s, float eps,
     dim3 grid(bx, c, b);
     if (relu)
         hipLaunchKernelGGL(bn_apply_maxpool_kernel<true>, grid, dim3(BN_THREADS), 0, st, c, p, s, x, gamma, beta, mean,
-                           rstd, var, eps, out, argmax);
+                           rstd, var, eps, out, argmax, fin);
     else
         hipLaunchKernelGGL(bn_apply_maxpool_kernel<false>, grid, dim3(BN_THREADS), 0, st, c, p, s, x, gamma, beta, mean,
-                           rstd, var, eps, out, argmax);
+                           rstd, var, eps, out, argmax, fin);
     OGC_CHECK_LAUNCH("ogc_batch_norm_maxpool_fwd");
     return OGC_OK;
 }
@@ -532,18 +621,21 @@ extern "C" int ogc_batch_norm_maxpool_bwd(int b, int c, int p, int s, int relu, 
         hipLaunchKernelGGL(bn_maxpool_bwd_sums_kernel<false>, gsum, dim3(BN_THREADS), 0, st, c, p, s, x, out, argmax,
                            grad_out, dsdb, part);
     if (part && ogc_det_reduce_f64(dsdb, part, (int)(gsum.x * gsum.z), 2ll * c, 0, st) != hipSuccess) return OGC_ERR_LAUNCH;
-    hipLaunchKernelGGL(bn_bwd_params_kernel, dim3(ogc_divup(c, 256)), dim3(256), 0, st, c,
-                       (double)b * (double)p * (double)s, training, gamma, mean, rstd, dsdb, grad_gamma, grad_beta, c2c3);
+    BnBwdFin bfin{nullptr, 0.0, 0, nullptr, nullptr};
+    if (bn_fold_finalize()) bfin = BnBwdFin{dsdb, (double)b * (double)p * (double)s, training, grad_gamma, grad_beta};
+    else
+        hipLaunchKernelGGL(bn_bwd_params_kernel, dim3(ogc_divup(c, 256)), dim3(256), 0, st, c,
+                           (double)b * (double)p * (double)s, training, gamma, mean, rstd, dsdb, grad_gamma, grad_beta, c2c3);
     const int rows_per_block = BN_THREADS / (s / 4);
     int bx = ogc_divup(p, rows_per_block);
     while (bx > 1 && (long long)bx * c * b > 8192) bx = (bx + 1) / 2;
     dim3 grid(bx, c, b);
     if (relu)
         hipLaunchKernelGGL(bn_maxpool_bwd_dx_kernel<true>, grid, dim3(BN_THREADS), 0, st, c, p, s, x, gamma, rstd, c2c3,
-                           out, argmax, grad_out, grad_x);
+                           out, argmax, grad_out, grad_x, mean, bfin);
     else
         hipLaunchKernelGGL(bn_maxpool_bwd_dx_kernel<false>, grid, dim3(BN_THREADS), 0, st, c, p, s, x, gamma, rstd, c2c3,
-                           out, argmax, grad_out, grad_x);
+                           out, argmax, grad_out, grad_x, mean, bfin);
     OGC_CHECK_LAUNCH("ogc_batch_norm_maxpool_bwd");
     return OGC_OK;
 }

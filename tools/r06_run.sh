@@ -1,2 +1,3 @@
 export PYTHONPATH=$PWD TMPDIR=/tmp
-timeout 900 python bench.py --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d['config2_ogcdr_bf16']['ms_per_step'], d['config3_flow_train']['ms_per_step'], d['oa_icp']['ms_per_call'], d['ms_per_step_with_h2d'], d.get('ms_per_step_hip_graph'))"
+timeout 900 python -m pytest tests/test_golden_gpu.py tests/test_driver_golden.py tests/test_deterministic_gpu.py tests/test_truth_f64_gpu.py tests/test_flow_glue_gpu.py tests/test_config_sizes_gpu.py -q -m gpu 2>&1 | tail -3
+for v in 1 0 1 0; do OGC_BN_FOLD=$v timeout 600 python tools/flow_train_prof.py 8 2>&1 | tail -1 | cut -c100-200 | sed "s/^/fold=$v /"; done
